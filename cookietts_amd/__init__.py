@@ -1,0 +1,9 @@
+"""cookietts_amd - MI355X-native mel-to-wave hot path of CookiePPP/cookietts.
+
+Python host mirrors of the reference's model API (``WaveGlow(**cfg).infer``) over a C-ABI
+HIP library (``include/cookietts_hip.h``, sources in ``cookietts_amd/csrc``).
+"""
+from . import synthetic  # noqa: F401
+from .waveglow import WaveGlow  # noqa: F401
+
+__all__ = ["WaveGlow", "synthetic"]

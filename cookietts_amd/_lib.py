@@ -1,0 +1,115 @@
+"""ctypes binding of the C-ABI HIP library (``include/cookietts_hip.h``).
+
+The product path has no CPU fallback: if ``libcookietts_hip.so`` is missing or fails to
+load, :func:`lib` raises, and every op built on it raises with it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+from . import build as _build
+
+_LOCK = threading.Lock()
+_LIB = None
+
+
+class WaveGlowConfig(C.Structure):
+    """``ctts_waveglow_config`` (include/cookietts_hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "n_mel_channels", "n_group", "n_flows", "n_early_every", "n_early_size",
+        "win_length", "hop_length", "n_layers", "n_channels", "kernel_size", "cond_hidden")]
+
+
+class WaveGlowGeometry(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("steps", "ld", "pad", "n_remaining")]
+
+
+_FP = C.c_void_p  # device pointers travel as integers
+
+
+class WaveGlowFlowWeights(C.Structure):
+    _fields_ = [
+        ("start_w", _FP), ("start_b", _FP),
+        ("cond_w", _FP * 3), ("cond_b", _FP * 3),
+        ("in_w", C.POINTER(_FP)), ("in_b", C.POINTER(_FP)),
+        ("rs_w", C.POINTER(_FP)), ("rs_b", C.POINTER(_FP)),
+        ("end_w", _FP), ("end_b", _FP), ("w_inverse", _FP),
+    ]
+
+
+# name -> (restype, argtypes); kept in one table so tests can check every symbol the
+# header declares is exported.
+_CFG = C.POINTER(WaveGlowConfig)
+SIGNATURES = {
+    "ctts_abi_version": (C.c_int, []),
+    "ctts_last_error": (C.c_char_p, []),
+    "ctts_waveglow_geometry_for": (C.c_int, [_CFG, C.c_int32, C.POINTER(WaveGlowGeometry)]),
+    "ctts_fold_weightnorm_f32": (C.c_int, [_FP, _FP, _FP, C.c_int32, C.c_int32, _FP]),
+    "ctts_waveglow_packed_bytes": (C.c_size_t, [_CFG]),
+    "ctts_waveglow_pack_upsample": (C.c_int, [_CFG, _FP, _FP, _FP, _FP]),
+    "ctts_waveglow_pack_flow": (C.c_int, [_CFG, C.c_int32, C.POINTER(WaveGlowFlowWeights), _FP, _FP]),
+    "ctts_waveglow_workspace_bytes": (C.c_size_t, [_CFG, C.c_int32, C.c_int32]),
+    "ctts_waveglow_infer_f32": (C.c_int, [_CFG, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP, C.c_size_t, _FP]),
+    "ctts_upsample_squeeze_f32": (C.c_int, [_CFG, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP]),
+    "ctts_wn_cond_f32": (C.c_int, [_CFG, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP]),
+    "ctts_wn_stack_f32": (C.c_int, [_CFG, _FP, C.c_int32, _FP, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP]),
+    "ctts_flow_tail_f32": (C.c_int, [_CFG, _FP, C.c_int32, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP]),
+    "ctts_profile_enable": (C.c_int, [C.c_int32]),
+    "ctts_profile_collect": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+}
+
+PROF_WN_IN = 0
+PROF_WN_RS = 1
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises HipLibraryError if unavailable."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    with _LOCK:
+        if _LIB is not None:
+            return _LIB
+        path = lib_path()
+        if not os.path.exists(path):
+            raise HipLibraryError(
+                f"{path} is missing: build it with `python -m cookietts_amd.build` "
+                "(or __graft_entry__.build()); there is no CPU fallback for the hot path")
+        try:
+            handle = C.CDLL(path)
+        except OSError as e:  # pragma: no cover - depends on the box
+            raise HipLibraryError(f"cannot load {path}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise HipLibraryError(f"{path} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        if handle.ctts_abi_version() != 1:
+            raise HipLibraryError(f"ABI version mismatch: library reports {handle.ctts_abi_version()}")
+        _LIB = handle
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().ctts_last_error()
+        raise HipLibraryError(f"{what} failed (rc={rc}): {msg.decode(errors='replace') if msg else ''}")
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor / None as a ctypes void pointer value."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())

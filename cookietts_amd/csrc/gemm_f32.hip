@@ -1,0 +1,193 @@
+// fp32 MFMA conv-GEMM for gfx950 (see gemm_f32.h for the contract).
+//
+// Tiling (CDNA4-first, 64-wide waves):
+//   workgroup = 256 threads = 4 waves as 2 (M) x 2 (N); block tile 256 x 128, K chunk 16.
+//   wave tile 128 x 64 = 4 x 2 tiles of v_mfma_f32_32x32x2_f32 -> 128 accumulator VGPRs,
+//   2 waves per SIMD (2 workgroups per CU) so one wave's LDS/global/barrier time is covered
+//   by the other wave's MFMAs; the f32 MFMA pipe (64 cycles per 32x32x2) is the bound.
+//   LDS: 2 stages x (A 16x256 + B 16x128) fp32 = 48 KiB; both operands k-major so a
+//   fragment is one conflict-free ds_read_b32 per lane (lane l: row/col l&31, k = l>>5).
+//   Global->LDS staging goes through registers and is issued one chunk ahead of the MFMAs
+//   (the f32 MFMA rate leaves >10x headroom on the load path).
+#include "gemm_f32.h"
+
+namespace ctts {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int A_STAGE = GEMM_KC * GEMM_BM;              // 4096 floats
+constexpr int B_STAGE = GEMM_KC * GEMM_BN;              // 2048 floats
+constexpr int STAGE = A_STAGE + B_STAGE;                // 6144 floats = 24 KiB
+
+__device__ __forceinline__ float4 load4(const float* p, int aligned) {
+    if (aligned) return *reinterpret_cast<const float4*>(p);
+    float4 v;
+    v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3];
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_precise(float u) { return 1.0f / (1.0f + expf(-u)); }
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    // block -> (m-block, n-tile, batch).  Dispatch places block id on XCD id % 8, so with
+    // mb = id % MB an XCD keeps re-using the same 1-2 weight slices in its private L2.
+    int id = blockIdx.x;
+    const int mb = id % a.MB;
+    id /= a.MB;
+    const int tile = id % a.ntiles;
+    const int b = id / a.ntiles;
+    const int n0 = tile * GEMM_BN;
+
+    const float* Ablk = a.A + (size_t)mb * a.nch_total * A_STAGE;
+
+    // staging assignments
+    const int brow = t >> 4;            // 0..15  (k row of the B chunk)
+    const int bcol = (t & 15) * 4;      // 0..60  (+64 for the second load)
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float4 ra[4], rb[2];
+    int seg = 0, local = 0;
+
+    auto issue_loads = [&](int ch) {
+        const float* ap = Ablk + (size_t)ch * A_STAGE + t * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const float4*>(ap + j * 1024);
+        const GemmSeg& s = a.seg[seg];
+        const float* bp = s.base + (size_t)b * s.bstride +
+                          (size_t)(mb * s.mb_rows + local * GEMM_KC + brow) * a.ld +
+                          (a.pad + n0 + s.shift + bcol);
+        rb[0] = load4(bp, s.aligned);
+        rb[1] = load4(bp + 64, s.aligned);
+        if (++local == s.nch) { local = 0; ++seg; }
+    };
+    auto store_lds = [&](int buf) {
+        float* As = lds + buf * STAGE;
+        float* Bs = As + A_STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(As + t * 4 + j * 1024) = ra[j];
+        *reinterpret_cast<float4*>(Bs + brow * GEMM_BN + bcol) = rb[0];
+        *reinterpret_cast<float4*>(Bs + brow * GEMM_BN + bcol + 64) = rb[1];
+    };
+
+    issue_loads(0);
+    store_lds(0);
+    __syncthreads();
+
+    const int nch = a.nch_total;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int cur = ch & 1;
+        if (ch + 1 < nch) issue_loads(ch + 1);
+        const float* As = lds + cur * STAGE + wm * 128 + l31;
+        const float* Bs = lds + cur * STAGE + A_STAGE + wn * 64 + l31;
+#pragma unroll
+        for (int ks = 0; ks < GEMM_KC / 2; ++ks) {
+            const int krow = 2 * ks + lhi;
+            float av[4], bv[2];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) av[mt] = As[krow * GEMM_BM + mt * 32];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) bv[nt] = Bs[krow * GEMM_BN + nt * 32];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+        }
+        if (ch + 1 < nch) store_lds(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const float* bias = a.bias + mb * GEMM_BM + wm * 128;
+    if constexpr (EPI == GEMM_EPI_GATE) {
+        float* dst = a.dst0 + (size_t)b * a.dst0_bstride;
+        const int cbase = mb * 128 + wm * 64;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int n = n0 + wn * 64 + nt * 32 + l31;
+                if (n < a.L) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                        const float ut = acc[mt][nt][r] + bias[mt * 32 + row];
+                        const float us = acc[mt + 2][nt][r] + bias[64 + mt * 32 + row];
+                        dst[(size_t)(cbase + mt * 32 + row) * a.ld + a.pad + n] = tanhf(ut) * sigmoidf_precise(us);
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int rbase = mb * GEMM_BM + wm * 128 + mt * 32;   // uniform per tile
+            if (rbase >= a.M) continue;                              // zero-padded rows of a ragged M
+            const bool second = rbase >= a.split;                    // split is a multiple of 32
+            float* dst = second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride;
+            const int accum = second ? a.acc1 : a.acc0;
+            const int rdst = second ? rbase - a.split : rbase;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int n = n0 + wn * 64 + nt * 32 + l31;
+                if (n < a.L) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                        float v = acc[mt][nt][r] + bias[mt * 32 + row];
+                        float* p = dst + (size_t)(rdst + row) * a.ld + a.pad + n;
+                        if (accum) v += *p;
+                        *p = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int launch_gemm_f32(int epi, const GemmArgs& a, hipStream_t stream) {
+    CTTS_CHECK_ARG(a.nseg >= 1 && a.nseg <= GEMM_MAX_SEG, "gemm: nseg=%d", a.nseg);
+    int nch = 0;
+    for (int s = 0; s < a.nseg; ++s) {
+        CTTS_CHECK_ARG(a.seg[s].nch > 0, "gemm: empty segment %d", s);
+        CTTS_CHECK_ARG(a.seg[s].shift >= -a.pad && a.seg[s].shift <= a.pad,
+                       "gemm: shift %d exceeds halo %d", a.seg[s].shift, a.pad);
+        nch += a.seg[s].nch;
+    }
+    CTTS_CHECK_ARG(nch == a.nch_total, "gemm: chunk count mismatch %d vs %d", nch, a.nch_total);
+    CTTS_CHECK_ARG(a.ld % 4 == 0 && a.ntiles * GEMM_BN + 2 * a.pad <= a.ld && a.L <= a.ntiles * GEMM_BN,
+                   "gemm: bad geometry ld=%d pad=%d L=%d ntiles=%d", a.ld, a.pad, a.L, a.ntiles);
+    CTTS_CHECK_ARG(epi == GEMM_EPI_GATE || a.split % 32 == 0, "gemm: split %d not a multiple of 32", a.split);
+    CTTS_CHECK_ARG(a.M % 32 == 0 && a.M > (a.MB - 1) * GEMM_BM && a.M <= a.MB * GEMM_BM, "gemm: M=%d MB=%d", a.M, a.MB);
+    const long long blocks = (long long)a.MB * a.ntiles * a.batch;
+    CTTS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "gemm: grid %lld", blocks);
+    dim3 grid((unsigned)blocks), block(256);
+    if (epi == GEMM_EPI_GATE)
+        hipLaunchKernelGGL(conv_gemm_f32_kernel<GEMM_EPI_GATE>, grid, block, 0, stream, a);
+    else
+        hipLaunchKernelGGL(conv_gemm_f32_kernel<GEMM_EPI_SPLIT>, grid, block, 0, stream, a);
+    CTTS_CHECK_LAUNCH("conv_gemm_f32");
+    return CTTS_OK;
+}
+
+}  // namespace ctts

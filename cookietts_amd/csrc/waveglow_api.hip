@@ -1,0 +1,436 @@
+// C ABI of the WaveGlow (glow.py topology) mel->wave path: packed-weight layout, workspace
+// layout and the launch sequence.  See include/cookietts_hip.h for the contract.
+#include <mutex>
+#include <vector>
+
+#include "gemm_f32.h"
+#include "waveglow_kernels.h"
+
+namespace ctts {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+
+constexpr size_t ALIGN_F = 64;  // section alignment in floats (256 B)
+inline size_t align_up(size_t v) { return (v + ALIGN_F - 1) / ALIGN_F * ALIGN_F; }
+constexpr int A_TILE = GEMM_KC * GEMM_BM;
+
+struct FlowDims { int n_rem, n_half, ch_off; };
+
+struct Plan {
+    ctts_waveglow_config c;
+    int C, H, K0, n_in;                 // WN channels, cond hidden, n_mel*G, flows
+    int nch0, nch1h, nch_in, nch_rs;    // K chunks: cond0, cond1, in-layer, res/skip
+    int mb_in;                          // M-blocks of the in-layer GEMM
+    std::vector<FlowDims> fd;
+    // packed blob offsets (floats)
+    size_t up_w, up_b, cond0_A, cond0_b, cond1_A, cond1_b;
+    struct Flow {
+        size_t start_w, start_b, end_w, end_b, winv;
+        std::vector<size_t> in_A, in_b, rs_A, rs_b;
+    };
+    std::vector<Flow> fl;
+    size_t total;
+
+    int rs_rows(int layer) const { return layer < c.n_layers - 1 ? 2 * C : C; }
+    int rs_mb(int layer) const { return (rs_rows(layer) + GEMM_BM - 1) / GEMM_BM; }
+};
+
+int make_plan(const ctts_waveglow_config* cfg, Plan& p) {
+    CTTS_CHECK_ARG(cfg != nullptr, "config is NULL");
+    p.c = *cfg;
+    const auto& c = p.c;
+    CTTS_CHECK_ARG(c.n_flows >= 1 && c.n_layers >= 1 && c.n_layers <= 12, "n_flows=%d n_layers=%d", c.n_flows, c.n_layers);
+    CTTS_CHECK_ARG(c.n_group >= 2 && c.n_group % 2 == 0 && c.n_group <= 8, "n_group=%d (even, <= 8)", c.n_group);
+    CTTS_CHECK_ARG(c.kernel_size == 3, "kernel_size=%d (only 3 built)", c.kernel_size);
+    CTTS_CHECK_ARG(c.n_channels >= 128 && c.n_channels % 128 == 0, "n_channels=%d (multiple of 128)", c.n_channels);
+    CTTS_CHECK_ARG(c.cond_hidden == GEMM_BM, "cond_hidden=%d (reference hard-codes 256)", c.cond_hidden);
+    CTTS_CHECK_ARG(c.hop_length > 0 && c.win_length % c.hop_length == 0 && c.hop_length % c.n_group == 0,
+                   "win=%d hop=%d n_group=%d", c.win_length, c.hop_length, c.n_group);
+    CTTS_CHECK_ARG((c.n_mel_channels * c.n_group) % GEMM_KC == 0, "n_mel*n_group=%d not a multiple of 16",
+                   c.n_mel_channels * c.n_group);
+    CTTS_CHECK_ARG(c.n_early_every >= 1 && c.n_early_size >= 0 && c.n_early_size % 2 == 0, "early outputs");
+    p.C = c.n_channels;
+    p.H = c.cond_hidden;
+    p.K0 = c.n_mel_channels * c.n_group;
+    p.nch0 = p.K0 / GEMM_KC;
+    p.nch1h = p.H / GEMM_KC;
+    p.nch_in = (c.kernel_size * p.C + p.H) / GEMM_KC;
+    p.nch_rs = p.C / GEMM_KC;
+    p.mb_in = 2 * p.C / GEMM_BM;
+    // per-flow channel counts exactly as glow.py:251-265
+    int n_half = c.n_group / 2, n_rem = c.n_group;
+    p.fd.resize(c.n_flows);
+    for (int k = 0; k < c.n_flows; ++k) {
+        if (k % c.n_early_every == 0 && k > 0) { n_half -= c.n_early_size / 2; n_rem -= c.n_early_size; }
+        CTTS_CHECK_ARG(n_half >= 1 && n_rem == 2 * n_half, "flow %d: n_half=%d n_remaining=%d", k, n_half, n_rem);
+        p.fd[k] = {n_rem, n_half, c.n_group - n_rem};
+    }
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o = align_up(o + n); return r; };
+    p.up_w = take((size_t)c.n_mel_channels * c.n_mel_channels * c.win_length);
+    p.up_b = take(c.n_mel_channels);
+    p.cond0_A = take((size_t)c.n_flows * p.nch0 * A_TILE);
+    p.cond0_b = take((size_t)c.n_flows * GEMM_BM);
+    p.cond1_A = take((size_t)c.n_flows * p.nch1h * A_TILE);
+    p.cond1_b = take((size_t)c.n_flows * GEMM_BM);
+    p.fl.resize(c.n_flows);
+    for (int k = 0; k < c.n_flows; ++k) {
+        auto& f = p.fl[k];
+        f.start_w = take((size_t)p.C * p.fd[k].n_half);
+        f.start_b = take(p.C);
+        f.end_w = take((size_t)2 * p.fd[k].n_half * p.C);
+        f.end_b = take(2 * p.fd[k].n_half);
+        f.winv = take((size_t)p.fd[k].n_rem * p.fd[k].n_rem);
+        for (int i = 0; i < c.n_layers; ++i) {
+            f.in_A.push_back(take((size_t)p.mb_in * p.nch_in * A_TILE));
+            f.in_b.push_back(take((size_t)p.mb_in * GEMM_BM));
+            f.rs_A.push_back(take((size_t)p.rs_mb(i) * p.nch_rs * A_TILE));
+            f.rs_b.push_back(take((size_t)p.rs_mb(i) * GEMM_BM));
+        }
+    }
+    p.total = o;
+    return CTTS_OK;
+}
+
+struct Geom { int L, ld, pad, ntiles; };
+
+int make_geom(const Plan& p, int frames, Geom& g) {
+    CTTS_CHECK_ARG(frames >= 1, "frames=%d", frames);
+    const long long T = (long long)frames * p.c.hop_length;
+    g.L = (int)(T / p.c.n_group);
+    int maxd = 1 << (p.c.n_layers - 1);
+    g.pad = round_up(maxd > 128 ? maxd : 128, 32);
+    g.ntiles = (g.L + GEMM_BN - 1) / GEMM_BN;
+    g.ld = g.ntiles * GEMM_BN + 2 * g.pad;
+    return CTTS_OK;
+}
+
+struct Workspace {
+    float *audio, *spect, *h_tmp, *h_all, *x, *act, *out;
+    size_t total;  // floats
+};
+
+void carve(const Plan& p, const Geom& g, int batch, float* base, Workspace& w) {
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o = align_up(o + n); return base ? base + r : nullptr; };
+    const size_t B = batch;
+    w.audio = take(B * p.c.n_group * g.L);
+    w.spect = take(B * p.K0 * g.ld);
+    w.h_tmp = take(B * p.c.n_flows * p.H * g.ld);
+    w.h_all = take(B * p.c.n_flows * p.H * g.ld);
+    w.x = take(B * p.C * g.ld);
+    w.act = take(B * p.C * g.ld);
+    w.out = take(B * p.C * g.ld);
+    w.total = o;
+}
+
+// ---- profiling hooks ---------------------------------------------------------------
+struct Prof {
+    std::mutex mu;
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[CTTS_PROF_N];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+} g_prof;
+
+struct ProfScope {
+    int which; hipStream_t s; hipEvent_t stop = nullptr; bool active = false;
+    ProfScope(int which_, hipStream_t s_) : which(which_), s(s_) {
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        if (!g_prof.on) return;
+        std::pair<hipEvent_t, hipEvent_t> e;
+        if (!g_prof.pool.empty()) { e = g_prof.pool.back(); g_prof.pool.pop_back(); }
+        else { if (hipEventCreate(&e.first) != hipSuccess || hipEventCreate(&e.second) != hipSuccess) return; }
+        (void)hipEventRecord(e.first, s);
+        stop = e.second;
+        g_prof.ev[which].push_back(e);
+        active = true;
+    }
+    ~ProfScope() { if (active) (void)hipEventRecord(stop, s); }
+};
+
+// ---- stage launchers ---------------------------------------------------------------
+GemmArgs base_args(const Geom& g, int batch) {
+    GemmArgs a{};
+    a.ld = g.ld; a.pad = g.pad; a.L = g.L; a.ntiles = g.ntiles; a.batch = batch;
+    return a;
+}
+
+int run_cond(const Plan& p, const Geom& g, const float* blob, const float* spect, float* h_tmp, float* h_all,
+             int batch, hipStream_t s) {
+    const long long hstride = (long long)p.c.n_flows * p.H * g.ld;
+    GemmArgs a = base_args(g, batch);
+    a.A = blob + p.cond0_A; a.bias = blob + p.cond0_b;
+    a.nseg = 1; a.nch_total = p.nch0; a.MB = p.c.n_flows;
+    a.seg[0] = {spect, (long long)p.K0 * g.ld, p.nch0, 0, 0, 1};
+    a.dst0 = h_tmp; a.dst0_bstride = hstride; a.acc0 = 0;
+    a.dst1 = h_tmp; a.dst1_bstride = hstride; a.acc1 = 0;
+    a.split = p.c.n_flows * GEMM_BM;
+    a.M = p.c.n_flows * GEMM_BM;
+    int rc = launch_gemm_f32(GEMM_EPI_SPLIT, a, s);
+    if (rc) return rc;
+    a.A = blob + p.cond1_A; a.bias = blob + p.cond1_b;
+    a.nch_total = p.nch1h;
+    a.seg[0] = {h_tmp, hstride, p.nch1h, 0, GEMM_BM, 1};
+    a.dst0 = h_all; a.dst1 = h_all;
+    return launch_gemm_f32(GEMM_EPI_SPLIT, a, s);
+}
+
+int run_wn_stack(const Plan& p, const Geom& g, const float* blob, int k, const float* audio, const float* h_all,
+                 float* x, float* act, float* out, int batch, hipStream_t s) {
+    const auto& f = p.fl[k];
+    const auto& d = p.fd[k];
+    const long long cstride = (long long)p.C * g.ld;
+    const long long hstride = (long long)p.c.n_flows * p.H * g.ld;
+    int rc = launch_wn_start(audio, blob + f.start_w, blob + f.start_b, x, batch, p.C, p.c.n_group, d.ch_off,
+                             d.n_half, g.L, g.ld, g.pad, s);
+    if (rc) return rc;
+    const int ncx = p.C / GEMM_KC;
+    for (int i = 0; i < p.c.n_layers; ++i) {
+        const int dil = 1 << i;
+        {
+            GemmArgs a = base_args(g, batch);
+            a.A = blob + f.in_A[i]; a.bias = blob + f.in_b[i];
+            a.nseg = 4; a.nch_total = p.nch_in; a.MB = p.mb_in;
+            a.seg[0] = {x, cstride, ncx, -dil, 0, (dil % 4 == 0) ? 1 : 0};
+            a.seg[1] = {x, cstride, ncx, 0, 0, 1};
+            a.seg[2] = {x, cstride, ncx, dil, 0, (dil % 4 == 0) ? 1 : 0};
+            a.seg[3] = {h_all + (size_t)k * p.H * g.ld, hstride, p.nch1h, 0, 0, 1};
+            a.dst0 = act; a.dst0_bstride = cstride;
+            a.M = 2 * p.C;
+            ProfScope ps(CTTS_PROF_WN_IN, s);
+            rc = launch_gemm_f32(GEMM_EPI_GATE, a, s);
+            if (rc) return rc;
+        }
+        {
+            const bool last = i == p.c.n_layers - 1;
+            GemmArgs a = base_args(g, batch);
+            a.A = blob + f.rs_A[i]; a.bias = blob + f.rs_b[i];
+            a.nseg = 1; a.nch_total = p.nch_rs; a.MB = p.rs_mb(i);
+            a.seg[0] = {act, cstride, p.nch_rs, 0, 0, 1};
+            a.M = p.rs_rows(i);
+            a.dst0 = x; a.dst0_bstride = cstride; a.acc0 = 1;
+            a.dst1 = out; a.dst1_bstride = cstride; a.acc1 = i > 0 ? 1 : 0;
+            a.split = last ? 0 : p.C;
+            ProfScope ps(CTTS_PROF_WN_RS, s);
+            rc = launch_gemm_f32(GEMM_EPI_SPLIT, a, s);
+            if (rc) return rc;
+        }
+    }
+    return CTTS_OK;
+}
+
+int run_flow_tail(const Plan& p, const Geom& g, const float* blob, int k, const float* out, float* audio,
+                  float* wave, int batch, hipStream_t s) {
+    const auto& f = p.fl[k];
+    const auto& d = p.fd[k];
+    return launch_flow_tail(out, audio, wave, blob + f.end_w, blob + f.end_b, blob + f.winv, batch, p.C,
+                            p.c.n_group, d.ch_off, d.n_half, g.L, g.ld, g.pad, s);
+}
+
+}  // namespace
+}  // namespace ctts
+
+using namespace ctts;
+
+extern "C" {
+
+int ctts_abi_version(void) { return CTTS_ABI_VERSION; }
+const char* ctts_last_error(void) { return g_err; }
+
+int ctts_waveglow_geometry_for(const ctts_waveglow_config* cfg, int32_t frames, ctts_waveglow_geometry* out) {
+    Plan p; Geom g;
+    int rc = make_plan(cfg, p); if (rc) return rc;
+    rc = make_geom(p, frames, g); if (rc) return rc;
+    CTTS_CHECK_ARG(out != nullptr, "geometry out is NULL");
+    out->steps = g.L; out->ld = g.ld; out->pad = g.pad; out->n_remaining = p.fd.back().n_rem;
+    return CTTS_OK;
+}
+
+int ctts_fold_weightnorm_f32(const float* v, const float* g, float* w, int32_t out_ch, int32_t fan, void* stream) {
+    CTTS_CHECK_ARG(v && g && w, "fold_weightnorm: NULL pointer");
+    return launch_fold_weightnorm(v, g, w, out_ch, fan, as_stream(stream));
+}
+
+size_t ctts_waveglow_packed_bytes(const ctts_waveglow_config* cfg) {
+    Plan p;
+    if (make_plan(cfg, p)) return 0;
+    return p.total * sizeof(float);
+}
+
+int ctts_waveglow_pack_upsample(const ctts_waveglow_config* cfg, const float* up_w, const float* up_b, void* packed,
+                                void* stream) {
+    Plan p;
+    int rc = make_plan(cfg, p); if (rc) return rc;
+    CTTS_CHECK_ARG(up_w && up_b && packed, "pack_upsample: NULL pointer");
+    float* blob = static_cast<float*>(packed);
+    const size_t nw = (size_t)p.c.n_mel_channels * p.c.n_mel_channels * p.c.win_length;
+    CTTS_CHECK_HIP(hipMemcpyAsync(blob + p.up_w, up_w, nw * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)));
+    CTTS_CHECK_HIP(hipMemcpyAsync(blob + p.up_b, up_b, p.c.n_mel_channels * sizeof(float), hipMemcpyDeviceToDevice,
+                                  as_stream(stream)));
+    return CTTS_OK;
+}
+
+int ctts_waveglow_pack_flow(const ctts_waveglow_config* cfg, int32_t k, const ctts_waveglow_flow_weights* w,
+                            void* packed, void* stream) {
+    Plan p;
+    int rc = make_plan(cfg, p); if (rc) return rc;
+    CTTS_CHECK_ARG(k >= 0 && k < p.c.n_flows, "pack_flow: flow %d", k);
+    CTTS_CHECK_ARG(w && packed, "pack_flow: NULL pointer");
+    hipStream_t s = as_stream(stream);
+    float* blob = static_cast<float*>(packed);
+    const auto& f = p.fl[k];
+    const auto& d = p.fd[k];
+    const int C = p.C, H = p.H, ks = p.c.kernel_size;
+    auto d2d = [&](size_t off, const float* src, size_t n) -> int {
+        CTTS_CHECK_ARG(src != nullptr, "pack_flow: NULL weight pointer");
+        CTTS_CHECK_HIP(hipMemcpyAsync(blob + off, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return CTTS_OK;
+    };
+    if ((rc = d2d(f.start_w, w->start_w, (size_t)C * d.n_half))) return rc;
+    if ((rc = d2d(f.start_b, w->start_b, C))) return rc;
+    if ((rc = d2d(f.end_w, w->end_w, (size_t)2 * d.n_half * C))) return rc;
+    if ((rc = d2d(f.end_b, w->end_b, 2 * d.n_half))) return rc;
+    if ((rc = d2d(f.winv, w->w_inverse, (size_t)d.n_rem * d.n_rem))) return rc;
+    // cond layers 0/1: this flow is M-block k of the flow-batched GEMMs
+    CTTS_CHECK_ARG(w->cond_w[0] && w->cond_w[1] && w->cond_w[2] && w->cond_b[0] && w->cond_b[1] && w->cond_b[2],
+                   "pack_flow: NULL cond weights");
+    if ((rc = launch_pack_a(blob + p.cond0_A + (size_t)k * p.nch0 * A_TILE, w->cond_w[0], 1, p.nch0, 0, p.K0,
+                            GEMM_EPI_SPLIT, C, H, 0, p.K0, 1, s))) return rc;
+    if ((rc = launch_pack_bias(blob + p.cond0_b + (size_t)k * GEMM_BM, 1, w->cond_b[0], 0, nullptr, 0,
+                               GEMM_EPI_SPLIT, C, H, s))) return rc;
+    if ((rc = launch_pack_a(blob + p.cond1_A + (size_t)k * p.nch1h * A_TILE, w->cond_w[1], 1, p.nch1h, 0, H,
+                            GEMM_EPI_SPLIT, C, H, 0, H, 1, s))) return rc;
+    if ((rc = launch_pack_bias(blob + p.cond1_b + (size_t)k * GEMM_BM, 1, w->cond_b[1], 0, nullptr, 0,
+                               GEMM_EPI_SPLIT, C, H, s))) return rc;
+    for (int i = 0; i < p.c.n_layers; ++i) {
+        CTTS_CHECK_ARG(w->in_w[i] && w->in_b[i] && w->rs_w[i] && w->rs_b[i], "pack_flow: NULL layer %d weights", i);
+        // in-layer: K = [tap0 | tap1 | tap2 | cond];  in_w[i] is [2C][C][ks]
+        for (int t = 0; t < ks; ++t)
+            if ((rc = launch_pack_a(blob + f.in_A[i], w->in_w[i] + t, p.mb_in, p.nch_in, t * C, C, GEMM_EPI_GATE, C,
+                                    2 * C, 0, (long long)C * ks, ks, s))) return rc;
+        // cond layer 2 rows [2C*i, 2C*(i+1)) of [2C*n_layers][H]
+        if ((rc = launch_pack_a(blob + f.in_A[i], w->cond_w[2], p.mb_in, p.nch_in, ks * C, H, GEMM_EPI_GATE, C,
+                                2 * C, (long long)2 * C * i, H, 1, s))) return rc;
+        if ((rc = launch_pack_bias(blob + f.in_b[i], p.mb_in, w->in_b[i], 0, w->cond_b[2], (long long)2 * C * i,
+                                   GEMM_EPI_GATE, C, 2 * C, s))) return rc;
+        const int rows = p.rs_rows(i);
+        if ((rc = launch_pack_a(blob + f.rs_A[i], w->rs_w[i], p.rs_mb(i), p.nch_rs, 0, C, GEMM_EPI_SPLIT, C, rows,
+                                0, C, 1, s))) return rc;
+        if ((rc = launch_pack_bias(blob + f.rs_b[i], p.rs_mb(i), w->rs_b[i], 0, nullptr, 0, GEMM_EPI_SPLIT, C, rows,
+                                   s))) return rc;
+    }
+    return CTTS_OK;
+}
+
+size_t ctts_waveglow_workspace_bytes(const ctts_waveglow_config* cfg, int32_t batch, int32_t frames) {
+    Plan p; Geom g; Workspace w;
+    if (make_plan(cfg, p) || make_geom(p, frames, g) || batch < 1) return 0;
+    carve(p, g, batch, nullptr, w);
+    return w.total * sizeof(float);
+}
+
+int ctts_upsample_squeeze_f32(const ctts_waveglow_config* cfg, const void* packed, const float* mel, float* spect,
+                              int32_t batch, int32_t frames, void* stream) {
+    Plan p; Geom g;
+    int rc = make_plan(cfg, p); if (rc) return rc;
+    rc = make_geom(p, frames, g); if (rc) return rc;
+    CTTS_CHECK_ARG(packed && mel && spect && batch >= 1, "upsample_squeeze: bad argument");
+    const float* blob = static_cast<const float*>(packed);
+    return launch_upsample_squeeze(mel, blob + p.up_w, blob + p.up_b, spect, batch, p.c.n_mel_channels, frames,
+                                   p.c.win_length, p.c.hop_length, p.c.n_group, g.ld, g.pad, as_stream(stream));
+}
+
+int ctts_wn_cond_f32(const ctts_waveglow_config* cfg, const void* packed, const float* spect, float* h_tmp,
+                     float* h_all, int32_t batch, int32_t frames, void* stream) {
+    Plan p; Geom g;
+    int rc = make_plan(cfg, p); if (rc) return rc;
+    rc = make_geom(p, frames, g); if (rc) return rc;
+    CTTS_CHECK_ARG(packed && spect && h_tmp && h_all && batch >= 1, "wn_cond: bad argument");
+    return run_cond(p, g, static_cast<const float*>(packed), spect, h_tmp, h_all, batch, as_stream(stream));
+}
+
+int ctts_wn_stack_f32(const ctts_waveglow_config* cfg, const void* packed, int32_t flow, const float* audio,
+                      const float* h_all, float* x, float* act, float* out, int32_t batch, int32_t frames,
+                      void* stream) {
+    Plan p; Geom g;
+    int rc = make_plan(cfg, p); if (rc) return rc;
+    rc = make_geom(p, frames, g); if (rc) return rc;
+    CTTS_CHECK_ARG(flow >= 0 && flow < p.c.n_flows, "wn_stack: flow %d", flow);
+    CTTS_CHECK_ARG(packed && audio && h_all && x && act && out && batch >= 1, "wn_stack: bad argument");
+    return run_wn_stack(p, g, static_cast<const float*>(packed), flow, audio, h_all, x, act, out, batch,
+                        as_stream(stream));
+}
+
+int ctts_flow_tail_f32(const ctts_waveglow_config* cfg, const void* packed, int32_t flow, const float* out,
+                       float* audio, float* wave, int32_t batch, int32_t frames, void* stream) {
+    Plan p; Geom g;
+    int rc = make_plan(cfg, p); if (rc) return rc;
+    rc = make_geom(p, frames, g); if (rc) return rc;
+    CTTS_CHECK_ARG(flow >= 0 && flow < p.c.n_flows, "flow_tail: flow %d", flow);
+    CTTS_CHECK_ARG(packed && out && audio && batch >= 1, "flow_tail: bad argument");
+    return run_flow_tail(p, g, static_cast<const float*>(packed), flow, out, audio, wave, batch, as_stream(stream));
+}
+
+int ctts_waveglow_infer_f32(const ctts_waveglow_config* cfg, const void* packed, const float* mel,
+                            const float* z_scaled, float* wave, int32_t batch, int32_t frames, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    Plan p; Geom g; Workspace w;
+    int rc = make_plan(cfg, p); if (rc) return rc;
+    rc = make_geom(p, frames, g); if (rc) return rc;
+    CTTS_CHECK_ARG(packed && mel && z_scaled && wave && workspace && batch >= 1, "infer: bad argument");
+    carve(p, g, batch, static_cast<float*>(workspace), w);
+    if (w.total * sizeof(float) > workspace_bytes) {
+        set_error("infer: workspace %zu bytes < required %zu", workspace_bytes, w.total * sizeof(float));
+        return CTTS_E_WORKSPACE;
+    }
+    hipStream_t s = as_stream(stream);
+    const float* blob = static_cast<const float*>(packed);
+    CTTS_CHECK_HIP(hipMemcpyAsync(w.audio, z_scaled, (size_t)batch * p.c.n_group * g.L * sizeof(float),
+                                  hipMemcpyDeviceToDevice, s));
+    rc = launch_upsample_squeeze(mel, blob + p.up_w, blob + p.up_b, w.spect, batch, p.c.n_mel_channels, frames,
+                                 p.c.win_length, p.c.hop_length, p.c.n_group, g.ld, g.pad, s);
+    if (rc) return rc;
+    rc = run_cond(p, g, blob, w.spect, w.h_tmp, w.h_all, batch, s);
+    if (rc) return rc;
+    for (int k = p.c.n_flows - 1; k >= 0; --k) {
+        rc = run_wn_stack(p, g, blob, k, w.audio, w.h_all, w.x, w.act, w.out, batch, s);
+        if (rc) return rc;
+        rc = run_flow_tail(p, g, blob, k, w.out, w.audio, k == 0 ? wave : nullptr, batch, s);
+        if (rc) return rc;
+    }
+    return CTTS_OK;
+}
+
+int ctts_profile_enable(int32_t on) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.on = on != 0;
+    return CTTS_OK;
+}
+
+int ctts_profile_collect(int32_t which, int64_t* launches, double* total_ms) {
+    CTTS_CHECK_ARG(which >= 0 && which < CTTS_PROF_N && launches && total_ms, "profile_collect: bad argument");
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    double tot = 0.0;
+    int64_t n = 0;
+    for (auto& e : g_prof.ev[which]) {
+        float ms = 0.f;
+        CTTS_CHECK_HIP(hipEventSynchronize(e.second));
+        CTTS_CHECK_HIP(hipEventElapsedTime(&ms, e.first, e.second));
+        tot += ms; ++n;
+        g_prof.pool.push_back(e);
+    }
+    g_prof.ev[which].clear();
+    *launches = n; *total_ms = tot;
+    return CTTS_OK;
+}
+
+}  // extern "C"

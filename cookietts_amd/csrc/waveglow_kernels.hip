@@ -1,0 +1,343 @@
+// Non-GEMM kernels of the WaveGlow path (all HBM-bound byte/float shuffles around the
+// MFMA conv-GEMM) and the weight-ingest kernels.  gfx950 only.
+#include "waveglow_kernels.h"
+
+namespace ctts {
+
+namespace {
+
+// ------------------------------------------------------------------ weight ingest ----
+// w[o][:] = v[o][:] * (g[o] / ||v[o][:]||): one workgroup per output channel.
+__global__ __launch_bounds__(256) void fold_weightnorm_kernel(const float* __restrict__ v,
+                                                              const float* __restrict__ g,
+                                                              float* __restrict__ w, int fan) {
+    __shared__ float red[4];
+    const int o = blockIdx.x;
+    const float* vr = v + (size_t)o * fan;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < fan; i += 256) { const float x = vr[i]; s = fmaf(x, x, s); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float tot = red[0] + red[1] + red[2] + red[3];
+    const float scale = g[o] / sqrtf(tot);
+    float* wr = w + (size_t)o * fan;
+    for (int i = threadIdx.x; i < fan; i += 256) wr[i] = vr[i] * scale;
+}
+
+// dst packed [MB][nch_total][16][256];  fills K range [k_off, k_off + ksrc):
+//   dst(mb, k, r) = src[(src_row_off + dense_row(mb, r)) * src_row_stride + (k - k_off) * src_k_stride]
+__global__ __launch_bounds__(256) void pack_a_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                     int nch_total, int k_off, int ksrc, int epi, int C, int M,
+                                                     long long src_row_off, long long src_row_stride,
+                                                     int src_k_stride) {
+    const int mb = blockIdx.y;
+    const int k = blockIdx.x;  // 0..ksrc-1
+    const int r = threadIdx.x;
+    const int drow = gemm_dense_row(epi, mb, r, C);
+    const int kk = k_off + k;
+    dst[((size_t)mb * nch_total + kk / GEMM_KC) * (GEMM_KC * GEMM_BM) + (kk % GEMM_KC) * GEMM_BM + r] =
+        drow < M ? src[(src_row_off + drow) * src_row_stride + (long long)k * src_k_stride] : 0.f;
+}
+
+// dst[mb*256 + r] = src0[off0 + dense_row] (+ src1[off1 + dense_row])
+__global__ __launch_bounds__(256) void pack_bias_kernel(float* __restrict__ dst, const float* __restrict__ src0,
+                                                        long long off0, const float* __restrict__ src1,
+                                                        long long off1, int epi, int C, int M) {
+    const int mb = blockIdx.x, r = threadIdx.x;
+    const int row = gemm_dense_row(epi, mb, r, C);
+    float v = 0.f;
+    if (row < M) {
+        v = src0[off0 + row];
+        if (src1) v += src1[off1 + row];
+    }
+    dst[mb * GEMM_BM + r] = v;
+}
+
+// ------------------------------------------------------------ upsample + squeeze ----
+// spect[b][o*G+g][pad + l] = bias[o] + sum_{j<taps} sum_i mel[b][i][q-j] * W[i][o][p + hop*j],
+//   t = G*l + g = hop*q + p.            (glow.py:318-324)
+// Workgroup: one batch item, UQ consecutive frames q, UO output channels; thread <-> phase p
+// (hop == 256 threads).  Each W element is loaded once per (i, j, o) and reused for UQ frames
+// from registers; mel values are wave-uniform LDS broadcasts.  The [UO][UQ][256] result is
+// transposed through LDS so that every spect row is written as contiguous runs of
+// UQ*hop/G time steps.
+constexpr int UP_UQ = 8;
+constexpr int UP_UO = 8;
+
+template <int HOP, int G>
+__global__ __launch_bounds__(HOP) void upsample_squeeze_kernel(const float* __restrict__ mel,
+                                                               const float* __restrict__ W,
+                                                               const float* __restrict__ bias,
+                                                               float* __restrict__ spect, int n_mel, int F,
+                                                               int win, int ld, int pad) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int taps = win / HOP;
+    const int nfr = UP_UQ + taps - 1;            // frames of mel this block touches
+    float* smel = smem;                          // [n_mel][nfr]
+    float* stile = smem + n_mel * nfr;           // [UO/2][G][UQ*HOP/G + 8] transposed result
+    const int p = threadIdx.x;
+    const int q0 = blockIdx.x * UP_UQ;
+    const int o0 = blockIdx.y * UP_UO;
+    const int b = blockIdx.z;
+    const float* melb = mel + (size_t)b * n_mel * F;
+    for (int idx = p; idx < n_mel * nfr; idx += HOP) {
+        const int i = idx / nfr, ff = idx % nfr;
+        const int f = q0 - (taps - 1) + ff;      // frame index, may be <0 or >=F
+        smel[idx] = (f >= 0 && f < F) ? melb[(size_t)i * F + f] : 0.f;
+    }
+    __syncthreads();
+
+    float acc[UP_UO][UP_UQ];
+#pragma unroll
+    for (int o = 0; o < UP_UO; ++o)
+#pragma unroll
+        for (int q = 0; q < UP_UQ; ++q) acc[o][q] = 0.f;
+
+    for (int i = 0; i < n_mel; ++i) {
+        const float* sm = smel + i * nfr;
+        for (int j = 0; j < taps; ++j) {
+            float w[UP_UO];
+#pragma unroll
+            for (int o = 0; o < UP_UO; ++o)
+                w[o] = (o0 + o < n_mel) ? W[((size_t)i * n_mel + o0 + o) * win + j * HOP + p] : 0.f;
+            // frame q0+q uses mel frame q0+q-j  -> smel index (taps-1) + q - j
+#pragma unroll
+            for (int q = 0; q < UP_UQ; ++q) {
+                const float m = sm[taps - 1 + q - j];
+#pragma unroll
+                for (int o = 0; o < UP_UO; ++o) acc[o][q] = fmaf(m, w[o], acc[o][q]);
+            }
+        }
+    }
+    // transpose through LDS (two passes of UO/2 channels): t = HOP*q + p -> (g = p % G, l_local = q*(HOP/G) + p/G)
+    constexpr int LPQ = HOP / G;                 // time steps per frame
+    constexpr int ROW = UP_UQ * LPQ;             // time steps per block
+    constexpr int ROWP = ROW + 8;                // +8 floats: 2-way (free) instead of 8-way write conflicts
+    constexpr int HO = UP_UO / 2;
+    const int g = p % G, lq = p / G;
+    const int L = F * LPQ;
+    const int l0 = q0 * LPQ;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();
+#pragma unroll
+        for (int o = 0; o < HO; ++o)
+#pragma unroll
+            for (int q = 0; q < UP_UQ; ++q) stile[(o * G + g) * ROWP + q * LPQ + lq] = acc[half * HO + o][q];
+        __syncthreads();
+        for (int idx = p; idx < HO * G * ROW; idx += HOP) {
+            const int row = idx / ROW, ll = idx % ROW;
+            const int o = o0 + half * HO + row / G;
+            if (o < n_mel && l0 + ll < L)
+                spect[((size_t)b * n_mel * G + (size_t)(o0 + half * HO) * G + row) * ld + pad + l0 + ll] =
+                    stile[row * ROWP + ll] + bias[o];
+        }
+    }
+}
+
+// --------------------------------------------------------------------- WN start ----
+// x[b][c][pad + n] = bs[c] + sum_{j<h} Ws[c][j] * audio[b][ch_off + j][n]     (glow.py:189)
+template <int H>
+__global__ __launch_bounds__(256) void wn_start_kernel(const float* __restrict__ audio, const float* __restrict__ Ws,
+                                                       const float* __restrict__ bs, float* __restrict__ x,
+                                                       int C, int G, int ch_off, int L, int ld, int pad) {
+    const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int b = blockIdx.z;
+    if (n >= L) return;
+    float4 a[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j)
+        a[j] = *reinterpret_cast<const float4*>(audio + ((size_t)b * G + ch_off + j) * L + n);
+    const int c0 = blockIdx.y * 32;
+    float* xb = x + (size_t)b * C * ld + pad + n;
+    for (int c = c0; c < c0 + 32 && c < C; ++c) {
+        float4 v;
+        const float bias = bs[c];
+        v.x = v.y = v.z = v.w = bias;
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            const float w = Ws[c * H + j];
+            v.x = fmaf(w, a[j].x, v.x); v.y = fmaf(w, a[j].y, v.y);
+            v.z = fmaf(w, a[j].z, v.z); v.w = fmaf(w, a[j].w, v.w);
+        }
+        *reinterpret_cast<float4*>(xb + (size_t)c * ld) = v;
+    }
+}
+
+// -------------------------------------------------------------------- flow tail ----
+// e = Wend * out + bend; (b, log_s) = (e[:h], e[h:]); a1 = (a1 - b) / exp(log_s);
+// audio[ch_off : ch_off+2h] = Winv * [a0; a1]; optional un-squeeze to wave.
+// (glow.py:222, 337-340, 349).  Workgroup = 4 waves x 256 time steps; each wave reduces a
+// quarter of the C skip channels with 16-byte loads, partial sums meet in LDS.
+template <int H>
+__global__ __launch_bounds__(256) void flow_tail_kernel(const float* __restrict__ out, float* __restrict__ audio,
+                                                        float* __restrict__ wave, const float* __restrict__ Wend,
+                                                        const float* __restrict__ bend, const float* __restrict__ Winv,
+                                                        int C, int G, int ch_off, int L, int ld, int pad) {
+    constexpr int E = 2 * H;
+    __shared__ __attribute__((aligned(16))) float part[3][E][256];
+    __shared__ float sWinv[E * E];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * 256 + lane * 4;
+    if (threadIdx.x < E * E) sWinv[threadIdx.x] = Winv[threadIdx.x];
+    float4 e[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) e[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int cq = C / 4;
+    const int cbeg = __builtin_amdgcn_readfirstlane(wv * cq);
+    // columns beyond L inside the padded row are readable (zero / never stored)
+    const float* ob = out + (size_t)b * C * ld + pad + n;
+    for (int c = cbeg; c < cbeg + cq; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(ob + (size_t)c * ld);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const float w = Wend[j * C + c];
+            e[j].x = fmaf(w, v.x, e[j].x); e[j].y = fmaf(w, v.y, e[j].y);
+            e[j].z = fmaf(w, v.z, e[j].z); e[j].w = fmaf(w, v.w, e[j].w);
+        }
+    }
+    if (wv > 0) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) *reinterpret_cast<float4*>(&part[wv - 1][j][lane * 4]) = e[j];
+    }
+    __syncthreads();
+    if (wv != 0 || n >= L) return;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const float bj = bend[j];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float4 pv = *reinterpret_cast<const float4*>(&part[q][j][lane * 4]);
+            e[j].x += pv.x; e[j].y += pv.y; e[j].z += pv.z; e[j].w += pv.w;
+        }
+        e[j].x += bj; e[j].y += bj; e[j].z += bj; e[j].w += bj;
+    }
+    float* ab = audio + ((size_t)b * G + ch_off) * L + n;
+    float4 a[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) a[j] = *reinterpret_cast<const float4*>(ab + (size_t)j * L);
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+        a[H + j].x = (a[H + j].x - e[j].x) / expf(e[H + j].x);
+        a[H + j].y = (a[H + j].y - e[j].y) / expf(e[H + j].y);
+        a[H + j].z = (a[H + j].z - e[j].z) / expf(e[H + j].z);
+        a[H + j].w = (a[H + j].w - e[j].w) / expf(e[H + j].w);
+    }
+    float4 m[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const float w = sWinv[i * E + j];
+            s.x = fmaf(w, a[j].x, s.x); s.y = fmaf(w, a[j].y, s.y);
+            s.z = fmaf(w, a[j].z, s.z); s.w = fmaf(w, a[j].w, s.w);
+        }
+        m[i] = s;
+    }
+    if (wave == nullptr) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) *reinterpret_cast<float4*>(ab + (size_t)i * L) = m[i];
+    } else if constexpr (E % 4 == 0) {
+        // un-squeeze: wave[b][G*l + g] = audio[b][g][l]; on the last flow ch_off == 0 and E == G
+        float* wb = wave + (size_t)b * G * L + (size_t)n * G;
+        const float* mf = reinterpret_cast<const float*>(m);   // m[i].{x,y,z,w} = channel i, step n+{0..3}
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < E; i += 4) {
+                float4 v = make_float4(mf[(i + 0) * 4 + s], mf[(i + 1) * 4 + s], mf[(i + 2) * 4 + s], mf[(i + 3) * 4 + s]);
+                *reinterpret_cast<float4*>(wb + s * G + i) = v;
+            }
+    }
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------- host launchers ----
+
+int launch_fold_weightnorm(const float* v, const float* g, float* w, int out_ch, int fan, hipStream_t s) {
+    CTTS_CHECK_ARG(out_ch > 0 && fan > 0, "fold_weightnorm: out_ch=%d fan=%d", out_ch, fan);
+    hipLaunchKernelGGL(fold_weightnorm_kernel, dim3(out_ch), dim3(256), 0, s, v, g, w, fan);
+    CTTS_CHECK_LAUNCH("fold_weightnorm");
+    return CTTS_OK;
+}
+
+int launch_pack_a(float* dst, const float* src, int MB, int nch_total, int k_off, int ksrc, int epi, int C, int M,
+                  long long src_row_off, long long src_row_stride, int src_k_stride, hipStream_t s) {
+    CTTS_CHECK_ARG(k_off >= 0 && ksrc > 0 && k_off + ksrc <= nch_total * GEMM_KC, "pack_a: k range");
+    hipLaunchKernelGGL(pack_a_kernel, dim3(ksrc, MB), dim3(256), 0, s, dst, src, nch_total, k_off, ksrc, epi, C, M,
+                       src_row_off, src_row_stride, src_k_stride);
+    CTTS_CHECK_LAUNCH("pack_a");
+    return CTTS_OK;
+}
+
+int launch_pack_bias(float* dst, int MB, const float* src0, long long off0, const float* src1, long long off1,
+                     int epi, int C, int M, hipStream_t s) {
+    hipLaunchKernelGGL(pack_bias_kernel, dim3(MB), dim3(256), 0, s, dst, src0, off0, src1, off1, epi, C, M);
+    CTTS_CHECK_LAUNCH("pack_bias");
+    return CTTS_OK;
+}
+
+int launch_upsample_squeeze(const float* mel, const float* W, const float* bias, float* spect, int batch,
+                            int n_mel, int F, int win, int hop, int G, int ld, int pad, hipStream_t s) {
+    CTTS_CHECK_ARG(hop == 256 && G == 8, "upsample_squeeze: only hop=256, n_group=8 built (got %d, %d)", hop, G);
+    CTTS_CHECK_ARG(win % hop == 0, "upsample_squeeze: win %d not a multiple of hop %d", win, hop);
+    const int taps = win / hop;
+    const size_t smem = ((size_t)n_mel * (UP_UQ + taps - 1) + (size_t)(UP_UO / 2) * G * (UP_UQ * (hop / G) + 8)) * sizeof(float);
+    CTTS_CHECK_ARG(smem <= 64 * 1024, "upsample_squeeze: LDS %zu", smem);
+    dim3 grid((F + UP_UQ - 1) / UP_UQ, (n_mel + UP_UO - 1) / UP_UO, batch);
+    hipLaunchKernelGGL((upsample_squeeze_kernel<256, 8>), grid, dim3(256), smem, s, mel, W, bias, spect, n_mel, F,
+                       win, ld, pad);
+    CTTS_CHECK_LAUNCH("upsample_squeeze");
+    return CTTS_OK;
+}
+
+int launch_wn_start(const float* audio, const float* Ws, const float* bs, float* x, int batch, int C, int G,
+                    int ch_off, int n_half, int L, int ld, int pad, hipStream_t s) {
+    CTTS_CHECK_ARG(L % 4 == 0, "wn_start: L=%d not a multiple of 4", L);
+    dim3 grid((L / 4 + 255) / 256, (C + 31) / 32, batch);
+#define CTTS_START_CASE(H)                                                                                     \
+    case H:                                                                                                    \
+        hipLaunchKernelGGL(wn_start_kernel<H>, grid, dim3(256), 0, s, audio, Ws, bs, x, C, G, ch_off, L, ld,   \
+                           pad);                                                                               \
+        break;
+    switch (n_half) {
+        CTTS_START_CASE(1) CTTS_START_CASE(2) CTTS_START_CASE(3) CTTS_START_CASE(4)
+        default:
+            set_error("wn_start: n_half=%d unsupported (1..4)", n_half);
+            return CTTS_E_ARG;
+    }
+#undef CTTS_START_CASE
+    CTTS_CHECK_LAUNCH("wn_start");
+    return CTTS_OK;
+}
+
+int launch_flow_tail(const float* out, float* audio, float* wave, const float* Wend, const float* bend,
+                     const float* Winv, int batch, int C, int G, int ch_off, int n_half, int L, int ld, int pad,
+                     hipStream_t s) {
+    CTTS_CHECK_ARG(L % 4 == 0 && C % 4 == 0, "flow_tail: L=%d C=%d", L, C);
+    CTTS_CHECK_ARG(wave == nullptr || (ch_off == 0 && 2 * n_half == G && G % 4 == 0),
+                   "flow_tail: un-squeeze needs the full group (ch_off=%d n_half=%d G=%d)", ch_off, n_half, G);
+    dim3 grid((L + 255) / 256, batch);
+#define CTTS_TAIL_CASE(H)                                                                                       \
+    case H:                                                                                                     \
+        hipLaunchKernelGGL(flow_tail_kernel<H>, grid, dim3(256), 0, s, out, audio, wave, Wend, bend, Winv, C, G, \
+                           ch_off, L, ld, pad);                                                                 \
+        break;
+    switch (n_half) {
+        CTTS_TAIL_CASE(1) CTTS_TAIL_CASE(2) CTTS_TAIL_CASE(3) CTTS_TAIL_CASE(4)
+        default:
+            set_error("flow_tail: n_half=%d unsupported (1..4)", n_half);
+            return CTTS_E_ARG;
+    }
+#undef CTTS_TAIL_CASE
+    CTTS_CHECK_LAUNCH("flow_tail");
+    return CTTS_OK;
+}
+
+}  // namespace ctts

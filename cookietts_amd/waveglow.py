@@ -1,0 +1,324 @@
+"""WaveGlow vocoder (NVIDIA-style topology) on the MI355X HIP path.
+
+Host-side mirror of the reference's ``WaveGlow`` ``nn.Module``
+(``/root/reference/CookieTTS/_4_mtw/waveglow/glow.py:225-350``): same constructor
+kwargs, same ``state_dict`` keys (``upsample.*``, ``WN.{k}.{start,end,cond_layers.j,
+in_layers.i,res_skip_layers.i}.*`` with ``weight_g``/``weight_v``, ``convinv.{k}.conv.weight``),
+same ``infer(spect, speaker_id=None, sigma=1.0)`` contract, so reference checkpoints
+and callers drop in.  All arithmetic of ``infer`` runs in the C-ABI HIP library
+(``include/cookietts_hip.h``); PyTorch only owns device memory, the stream and the RNG
+draw.  There is no CPU fallback: without the library, or with CPU tensors, it raises.
+
+Deliberate deviations from reference quirks (SURVEY.md §8a "Quirks"):
+  * early-output noise (glow.py:342-347) is drawn with the device generator for any
+    device instead of the CUDA-only ``torch.cuda.FloatTensor`` constructor, and all noise
+    is drawn up front (``infer_from_noise`` takes it explicitly for deterministic parity);
+  * ``spect_scaling=True`` references parameters the reference never creates
+    (glow.py:233-235 vs :315-316) -> ``NotImplementedError`` here;
+  * ``remove_weightnorm`` works (the reference's raises AttributeError, glow.py:358).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+__all__ = ["WaveGlow", "Invertible1x1Conv", "WN"]
+
+
+class _Conv1dParams(nn.Module):
+    """Parameter holder with nn.Conv1d's names/shapes/default init (no forward)."""
+
+    def __init__(self, in_ch, out_ch, k, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_ch, in_ch, k))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            bound = 1.0 / math.sqrt(in_ch * k)
+            self.bias = nn.Parameter(torch.empty(out_ch).uniform_(-bound, bound))
+        else:
+            self.register_parameter("bias", None)
+
+
+class _WeightNormConv1d(nn.Module):
+    """``nn.utils.weight_norm(nn.Conv1d(...))`` as stored in checkpoints: weight_g, weight_v, bias."""
+
+    def __init__(self, in_ch, out_ch, k):
+        super().__init__()
+        plain = _Conv1dParams(in_ch, out_ch, k)
+        v = plain.weight.data
+        self.bias = plain.bias
+        self.weight_g = nn.Parameter(v.flatten(1).norm(dim=1).view(out_ch, 1, 1).clone())
+        self.weight_v = nn.Parameter(v.clone())
+
+    def remove_weight_norm(self):
+        if hasattr(self, "weight_v") and self.weight_v is not None:
+            v, g = self.weight_v.data, self.weight_g.data
+            w = v * (g / v.flatten(1).norm(dim=1).view(-1, 1, 1))
+            del self._parameters["weight_g"], self._parameters["weight_v"]
+            self.weight = nn.Parameter(w)
+
+
+class Invertible1x1Conv(nn.Module):
+    """Parameter holder for glow.py:65-83 (random orthonormal init, det > 0)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.conv = _Conv1dParams(c, c, 1, bias=False)
+        W = torch.linalg.qr(torch.randn(c, c))[0]
+        if torch.det(W) < 0:
+            W[:, 0] = -1 * W[:, 0]
+        self.conv.weight.data = W.view(c, c, 1).contiguous()
+
+
+class WN(nn.Module):
+    """Parameter holder for glow.py:110-186."""
+
+    def __init__(self, n_in_channels, n_mel_channels, n_layers, n_channels, kernel_size,
+                 speaker_embed_dim, rezero):
+        super().__init__()
+        assert kernel_size % 2 == 1
+        assert n_channels % 2 == 0
+        if speaker_embed_dim:
+            raise NotImplementedError("speaker_embed_dim > 0 is not built on the HIP path yet")
+        if rezero:
+            raise NotImplementedError("rezero=True is not built on the HIP path yet")
+        self.n_layers = n_layers
+        self.n_channels = n_channels
+        self.speaker_embed_dim = speaker_embed_dim
+        hidden = 256  # glow.py:153
+        self.start = _WeightNormConv1d(n_in_channels, n_channels, 1)
+        self.end = _Conv1dParams(n_channels, 2 * n_in_channels, 1)
+        self.end.weight.data.zero_()
+        self.end.bias.data.zero_()
+        self.cond_layers = nn.ModuleList([
+            _WeightNormConv1d(n_mel_channels, hidden, 1),
+            _WeightNormConv1d(hidden, hidden, 1),
+            _WeightNormConv1d(hidden, 2 * n_channels * n_layers, 1)])
+        self.in_layers = nn.ModuleList()
+        self.res_skip_layers = nn.ModuleList()
+        for i in range(n_layers):
+            self.in_layers.append(_WeightNormConv1d(n_channels, 2 * n_channels, kernel_size))
+            rs = 2 * n_channels if i < n_layers - 1 else n_channels
+            self.res_skip_layers.append(_WeightNormConv1d(n_channels, rs, 1))
+
+
+class WaveGlow(nn.Module):
+    def __init__(self, yoyo, yoyo_WN, n_mel_channels, n_flows, n_group, n_early_every, n_early_size,
+                 memory_efficient, spect_scaling, upsample_mode, WN_config, win_length, hop_length):
+        super().__init__()
+        if upsample_mode != 'normal':
+            raise NotImplementedError("only upsample_mode='normal' (groups=1) is built")
+        if memory_efficient:
+            raise NotImplementedError("memory_efficient builds no layers in the reference (glow.py:263)")
+        assert n_group % 2 == 0
+        self.spect_scaling = spect_scaling
+        self.multispeaker = WN_config['speaker_embed_dim'] > 0
+        self.n_mel_channels = n_mel_channels
+        self.n_flows = n_flows
+        self.n_group = n_group
+        self.n_early_every = n_early_every
+        self.n_early_size = n_early_size
+        self.win_length = win_length
+        self.hop_length = hop_length
+        self.WN_config = dict(WN_config)
+
+        # nn.ConvTranspose1d(n_mel, n_mel, win, stride=hop): weight [in, out, win]
+        self.upsample = nn.Module()
+        w = torch.empty(n_mel_channels, n_mel_channels, win_length)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(n_mel_channels * win_length)
+        self.upsample.weight = nn.Parameter(w)
+        self.upsample.bias = nn.Parameter(torch.empty(n_mel_channels).uniform_(-bound, bound))
+
+        self.WN = nn.ModuleList()
+        self.convinv = nn.ModuleList()
+        n_half = n_group // 2
+        n_remaining_channels = n_group
+        for k in range(n_flows):
+            if k % n_early_every == 0 and k > 0:
+                n_half = n_half - n_early_size // 2
+                n_remaining_channels = n_remaining_channels - n_early_size
+            self.convinv.append(Invertible1x1Conv(n_remaining_channels))
+            self.WN.append(WN(n_half, n_mel_channels * n_group, **WN_config))
+        self.n_remaining_channels = n_remaining_channels
+
+        self._packed = None          # (device, blob tensor)
+        self._workspaces = {}        # (device, B, F) -> zero-initialised workspace tensor
+
+    # ------------------------------------------------------------------ plumbing ----
+    def c_config(self):
+        wn = self.WN_config
+        return _lib.WaveGlowConfig(
+            n_mel_channels=self.n_mel_channels, n_group=self.n_group, n_flows=self.n_flows,
+            n_early_every=self.n_early_every, n_early_size=self.n_early_size,
+            win_length=self.win_length, hop_length=self.hop_length, n_layers=wn['n_layers'],
+            n_channels=wn['n_channels'], kernel_size=wn['kernel_size'], cond_hidden=256)
+
+    def _invalidate(self):
+        self._packed = None
+        self._workspaces = {}
+        for m in self.convinv:
+            if hasattr(m, 'W_inverse'):
+                del m.W_inverse
+
+    def _apply(self, fn, *a, **kw):
+        self._invalidate()
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        self._invalidate()
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def repack(self):
+        """Call after modifying parameters in place; the next infer re-ingests the weights."""
+        self._invalidate()
+
+    @staticmethod
+    def remove_weightnorm(model):
+        for wn in model.WN:
+            wn.start.remove_weight_norm()
+            for layer in list(wn.in_layers) + list(wn.cond_layers) + list(wn.res_skip_layers):
+                layer.remove_weight_norm()
+        model._invalidate()
+        return model
+
+    def _dense_weight(self, layer, stream, keep):
+        """fp32 contiguous folded conv weight on the model's device (fold runs in the HIP library)."""
+        lib = _lib.lib()
+        if getattr(layer, 'weight_v', None) is not None:
+            v = layer.weight_v.detach().float().contiguous()
+            g = layer.weight_g.detach().float().contiguous()
+            w = torch.empty_like(v)
+            _lib.check(lib.ctts_fold_weightnorm_f32(_lib.ptr(v), _lib.ptr(g), _lib.ptr(w), v.shape[0],
+                                                   v[0].numel(), stream), "ctts_fold_weightnorm_f32")
+            keep += [v, g, w]
+            return w
+        w = layer.weight.detach().float().contiguous()
+        keep.append(w)
+        return w
+
+    def _ensure_packed(self, device):
+        if self._packed is not None and self._packed[0] == device:
+            return self._packed[1]
+        if device.type != 'cuda':
+            raise _lib.HipLibraryError("WaveGlow HIP path needs the model on a GPU (no CPU fallback)")
+        lib = _lib.lib()
+        for p in self.parameters():
+            if p.device != device:
+                raise RuntimeError(f"parameter on {p.device}, input on {device}: move the model first")
+        cfg = self.c_config()
+        nbytes = lib.ctts_waveglow_packed_bytes(C.byref(cfg))
+        if nbytes == 0:
+            raise _lib.HipLibraryError("unsupported WaveGlow config: " + lib.ctts_last_error().decode())
+        with torch.cuda.device(device):
+            stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            blob = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)
+            keep = []
+            up_w = self.upsample.weight.detach().float().contiguous()
+            up_b = self.upsample.bias.detach().float().contiguous()
+            keep += [up_w, up_b]
+            _lib.check(lib.ctts_waveglow_pack_upsample(C.byref(cfg), _lib.ptr(up_w), _lib.ptr(up_b),
+                                                      _lib.ptr(blob), stream), "ctts_waveglow_pack_upsample")
+            n_layers = self.WN_config['n_layers']
+            for k in range(self.n_flows):
+                wn = self.WN[k]
+                fw = _lib.WaveGlowFlowWeights()
+
+                def dev(t):
+                    t = t.detach().float().contiguous()
+                    keep.append(t)
+                    return t.data_ptr()
+
+                fw.start_w = self._dense_weight(wn.start, stream, keep).data_ptr()
+                fw.start_b = dev(wn.start.bias)
+                for j in range(3):
+                    fw.cond_w[j] = self._dense_weight(wn.cond_layers[j], stream, keep).data_ptr()
+                    fw.cond_b[j] = dev(wn.cond_layers[j].bias)
+                arrs = {}
+                for name, layers in (("in", wn.in_layers), ("rs", wn.res_skip_layers)):
+                    wa = (C.c_void_p * n_layers)()
+                    ba = (C.c_void_p * n_layers)()
+                    for i in range(n_layers):
+                        wa[i] = self._dense_weight(layers[i], stream, keep).data_ptr()
+                        ba[i] = dev(layers[i].bias)
+                    arrs[name] = (wa, ba)
+                fw.in_w, fw.in_b = arrs["in"]
+                fw.rs_w, fw.rs_b = arrs["rs"]
+                fw.end_w = dev(wn.end.weight)
+                fw.end_b = dev(wn.end.bias)
+                # glow.py:90-99: W.float().inverse(), cached on the module as W_inverse
+                W = self.convinv[k].conv.weight.detach().squeeze(-1)
+                W_inverse = W.float().cpu().inverse().to(device).contiguous()   # host fp32 inverse
+                self.convinv[k].W_inverse = W_inverse[..., None]
+                keep.append(W_inverse)
+                fw.w_inverse = W_inverse.data_ptr()
+                _lib.check(lib.ctts_waveglow_pack_flow(C.byref(cfg), k, C.byref(fw), _lib.ptr(blob), stream),
+                           f"ctts_waveglow_pack_flow({k})")
+            torch.cuda.current_stream(device).synchronize()   # dense temporaries may now be freed
+        self._packed = (device, blob)
+        return blob
+
+    def _workspace(self, device, B, F):
+        key = (device, B, F)
+        ws = self._workspaces.get(key)
+        if ws is None:
+            lib = _lib.lib()
+            cfg = self.c_config()
+            nbytes = lib.ctts_waveglow_workspace_bytes(C.byref(cfg), B, F)
+            if nbytes == 0:
+                raise _lib.HipLibraryError("workspace query failed: " + lib.ctts_last_error().decode())
+            self._workspaces.clear()     # one live geometry at a time
+            ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)
+            self._workspaces[key] = ws
+        return ws
+
+    def steps_for(self, frames):
+        return frames * self.hop_length // self.n_group
+
+    # --------------------------------------------------------------------- the path ----
+    def infer_from_noise(self, spect, z_scaled):
+        """Deterministic entry: ``z_scaled`` [B, n_group, L] already multiplied by sigma.
+
+        Rows: the last ``n_remaining_channels`` are the initial latent (glow.py:326), the
+        rows above are the early-output noise in prepend order (glow.py:342-347).
+        """
+        if self.spect_scaling:
+            raise NotImplementedError("spect_scaling=True is broken in the reference (glow.py:233-235)")
+        if spect.dim() == 2:
+            spect = spect.unsqueeze(0)
+        device = spect.device
+        blob = self._ensure_packed(device)
+        lib = _lib.lib()
+        B, M, F = spect.shape
+        assert M == self.n_mel_channels, (M, self.n_mel_channels)
+        L = self.steps_for(F)
+        assert tuple(z_scaled.shape) == (B, self.n_group, L), (tuple(z_scaled.shape), (B, self.n_group, L))
+        mel = spect.detach().float().contiguous()
+        z = z_scaled.detach().to(device=device, dtype=torch.float32).contiguous()
+        ws = self._workspace(device, B, F)
+        wave = torch.empty(B, L * self.n_group, dtype=torch.float32, device=device)
+        cfg = self.c_config()
+        with torch.cuda.device(device):
+            stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            _lib.check(lib.ctts_waveglow_infer_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(mel), _lib.ptr(z),
+                                                  _lib.ptr(wave), B, F, _lib.ptr(ws), ws.numel() * 4, stream),
+                       "ctts_waveglow_infer_f32")
+        return wave.to(spect.dtype)
+
+    def infer(self, spect, speaker_id=None, sigma=1.0):
+        """``glow.WaveGlow.infer``: spect [B, n_mel, F] -> audio [B, F*hop] on spect's device."""
+        if self.multispeaker and speaker_id is not None:
+            raise NotImplementedError("multispeaker WaveGlow is not built on the HIP path yet")
+        if spect.dim() == 2:
+            spect = spect.unsqueeze(0)
+        B, _, F = spect.shape
+        z = torch.randn(B, self.n_group, self.steps_for(F), device=spect.device, dtype=torch.float32)
+        return self.infer_from_noise(spect, z * sigma)
+
+    def forward(self, spect, audio=None, speaker_id=None):
+        raise NotImplementedError("training direction (glow.py:267-312) is outside the inference hot path")

@@ -1,0 +1,157 @@
+/*
+ * cookietts_hip.h - C ABI of the MI355X (gfx950) mel-to-wave hot path.
+ *
+ * The reference (CookiePPP/cookietts) has no FFI layer: its hot path sits behind Python
+ * nn.Module classes that dispatch stock PyTorch ops.  This header is the
+ * boundary those ops are replaced at.  Every entry point cites the reference code it
+ * replaces (paths relative to /root/reference/CookieTTS/).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - All data pointers are DEVICE pointers owned by the caller (PyTorch-ROCm in the
+ *     Python host).  The library never allocates or frees device memory; scratch is a
+ *     caller-provided workspace sized by ctts_*_workspace_bytes().
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All work is
+ *     enqueued asynchronously on it; no entry point synchronises.
+ *   - Return value: 0 = ok, negative = error (CTTS_E_*); ctts_last_error() returns a
+ *     thread-local human-readable message for the last failure on this thread.
+ *   - No hidden global state: the immutable pair (config, packed weight blob) is the
+ *     "plan"; calls are thread-safe per (workspace, stream).
+ *
+ * "Padded activation layout": internal activation tensors are [B][rows][ld] fp32 with
+ * the L valid time steps of a row at columns [pad, pad+L) and zeros in the halo, so
+ * dilated-conv taps read x[l +- d] without bounds checks (ld, pad from
+ * ctts_waveglow_geometry()).
+ */
+#ifndef COOKIETTS_HIP_H
+#define COOKIETTS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTTS_OK 0
+#define CTTS_E_ARG (-1)       /* bad argument / unsupported shape */
+#define CTTS_E_LAUNCH (-2)    /* HIP launch or runtime error */
+#define CTTS_E_WORKSPACE (-3) /* workspace too small */
+
+#define CTTS_ABI_VERSION 1
+
+int ctts_abi_version(void);
+const char* ctts_last_error(void);
+
+/* Constructor arguments of the reference model that shape the path:
+ * _4_mtw/waveglow/glow.py:226-265 (WaveGlow.__init__) and :114-186 (WN.__init__). */
+typedef struct ctts_waveglow_config {
+    int32_t n_mel_channels; /* 80 */
+    int32_t n_group;        /* 8 */
+    int32_t n_flows;        /* 12 */
+    int32_t n_early_every;  /* 4 */
+    int32_t n_early_size;   /* 2 */
+    int32_t win_length;     /* 1024: ConvTranspose1d kernel */
+    int32_t hop_length;     /* 256: ConvTranspose1d stride */
+    int32_t n_layers;       /* 8 WN layers, dilation 2^i */
+    int32_t n_channels;     /* 512 WN channels (multiple of 128) */
+    int32_t kernel_size;    /* 3 */
+    int32_t cond_hidden;    /* 256, hard-coded at glow.py:153 */
+} ctts_waveglow_config;
+
+typedef struct ctts_waveglow_geometry {
+    int32_t steps;          /* L = frames*hop/n_group */
+    int32_t ld;             /* row stride of padded activation tensors (floats) */
+    int32_t pad;            /* left halo (floats) */
+    int32_t n_remaining;    /* channels of the initial latent (glow.py:265) */
+} ctts_waveglow_geometry;
+
+int ctts_waveglow_geometry_for(const ctts_waveglow_config* cfg, int32_t frames,
+                               ctts_waveglow_geometry* out);
+
+/* ---- weight ingest (replaces torch weight_norm hooks + module construction) ---------- */
+
+/* w[o][:] = v[o][:] * (g[o] / ||v[o][:]||_2): torch.nn.utils.weight_norm as applied at
+ * glow.py:135-137,155-165,171-173,184 (checkpoint keys *.weight_g / *.weight_v). */
+int ctts_fold_weightnorm_f32(const float* v, const float* g, float* w, int32_t out_ch,
+                             int32_t fan, void* stream);
+
+/* Dense (already weight-norm-folded) fp32 weights of ONE flow, in the reference's own
+ * tensor layouts (state_dict shapes, glow.py:110-186 / :65-83). */
+typedef struct ctts_waveglow_flow_weights {
+    const float* start_w;      /* [C][n_half]              WN.k.start */
+    const float* start_b;      /* [C] */
+    const float* cond_w[3];    /* [H][n_mel*G], [H][H], [2*C*n_layers][H]   WN.k.cond_layers.j */
+    const float* cond_b[3];
+    const float* const* in_w;  /* n_layers x [2C][C][ks]   WN.k.in_layers.i */
+    const float* const* in_b;  /* n_layers x [2C] */
+    const float* const* rs_w;  /* n_layers x [2C or C][C]  WN.k.res_skip_layers.i */
+    const float* const* rs_b;
+    const float* end_w;        /* [2*n_half][C]            WN.k.end */
+    const float* end_b;        /* [2*n_half] */
+    const float* w_inverse;    /* [c][c] fp32 inverse of convinv.k.conv.weight (glow.py:90-99) */
+} ctts_waveglow_flow_weights;
+
+/* Bytes of the packed weight blob (device) for this config. */
+size_t ctts_waveglow_packed_bytes(const ctts_waveglow_config* cfg);
+/* Pack upsample.{weight [n_mel][n_mel][win], bias [n_mel]} (glow.py:238-241). */
+int ctts_waveglow_pack_upsample(const ctts_waveglow_config* cfg, const float* up_w,
+                                const float* up_b, void* packed, void* stream);
+/* Pack one flow's weights into the MFMA-tile order the kernels stream. */
+int ctts_waveglow_pack_flow(const ctts_waveglow_config* cfg, int32_t flow,
+                            const ctts_waveglow_flow_weights* w, void* packed, void* stream);
+
+/* ---- the hot path -------------------------------------------------------------------- */
+
+size_t ctts_waveglow_workspace_bytes(const ctts_waveglow_config* cfg, int32_t batch,
+                                     int32_t frames);
+
+/* WaveGlow.infer (glow.py:314-350) with the noise made an explicit input.
+ *   mel      [B][n_mel][F]      fp32 dense
+ *   z_scaled [B][n_group][L]    fp32 dense, sigma already applied: the last n_remaining
+ *                               rows are the initial latent (glow.py:326), the rows above
+ *                               are the early-output noise in prepend order (glow.py:342-347)
+ *   wave     [B][F*hop]         fp32 dense (glow.py:349)
+ * workspace must be zero-filled once before its FIRST use with a given (batch, frames)
+ * geometry (halo columns are never written afterwards). */
+int ctts_waveglow_infer_f32(const ctts_waveglow_config* cfg, const void* packed,
+                            const float* mel, const float* z_scaled, float* wave,
+                            int32_t batch, int32_t frames, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+/* Stage entry points (same kernels, exposed for parity tests and profiling). */
+
+/* upsample (ConvTranspose1d) + trim + squeeze: glow.py:318-324.  spect is padded layout
+ * [B][n_mel*G][ld]. */
+int ctts_upsample_squeeze_f32(const ctts_waveglow_config* cfg, const void* packed,
+                              const float* mel, float* spect, int32_t batch, int32_t frames,
+                              void* stream);
+/* One flow's WN stack: glow.py:188-222 up to (not including) `end`.  Reads audio rows
+ * [ch_off, ch_off+n_half) of audio [B][n_group][L] dense and h_all (cond hidden for all
+ * flows, from ctts_wn_cond_f32); leaves the skip sum in `out` (padded [B][C][ld]). */
+int ctts_wn_cond_f32(const ctts_waveglow_config* cfg, const void* packed, const float* spect,
+                     float* h_tmp, float* h_all, int32_t batch, int32_t frames, void* stream);
+int ctts_wn_stack_f32(const ctts_waveglow_config* cfg, const void* packed, int32_t flow,
+                      const float* audio, const float* h_all, float* x, float* act, float* out,
+                      int32_t batch, int32_t frames, void* stream);
+/* `end` 1x1 conv + affine coupling inverse + inverse 1x1 conv (+ un-squeeze on the last
+ * flow): glow.py:222,337-340,349.  Updates audio in place; if `wave` is non-NULL the
+ * mixed channels are written un-squeezed to wave [B][L*n_group] instead. */
+int ctts_flow_tail_f32(const ctts_waveglow_config* cfg, const void* packed, int32_t flow,
+                       const float* out, float* audio, float* wave, int32_t batch,
+                       int32_t frames, void* stream);
+
+/* ---- in-library kernel timing (bench.py roofline leg) --------------------------------- */
+/* When enabled, ctts_waveglow_infer_f32 brackets every launch of the dominant kernel
+ * (WN in-layer GEMM: dilated conv + cond + gate) with hipEvents on `stream`. */
+#define CTTS_PROF_WN_IN 0
+#define CTTS_PROF_WN_RS 1
+#define CTTS_PROF_N 2
+int ctts_profile_enable(int32_t on);
+/* Synchronises the recorded events and returns launches + summed milliseconds; resets. */
+int ctts_profile_collect(int32_t which, int64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COOKIETTS_HIP_H */

@@ -1,0 +1,162 @@
+"""CPU oracle for the WaveGlow mel->wave path (NVIDIA-style ``glow.py`` topology).
+
+TEST INFRASTRUCTURE ONLY.  This is a numpy fp32 restatement of the reference's
+algorithm, written from the equations in SURVEY.md §8(a) "Verified restatement of
+rows G2-G8", not from the reference's code.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it;
+the product path (``cookietts_amd``) never does and fails loudly without its HIP
+library.
+
+Parity pin: ``tests/golden/waveglow_*.npz`` hold outputs of the reference itself
+(``/root/reference/CookieTTS/_4_mtw/waveglow/glow.py`` ``WaveGlow.infer``, imported
+and run on CPU by ``tests/golden/make_golden.py``); ``tests/test_oracle_golden.py``
+checks this file against them.
+
+Reference lines each function follows (paths relative to /root/reference/CookieTTS):
+  fold_weightnorm   torch ``nn.utils.weight_norm`` as applied at _4_mtw/waveglow/glow.py:135-186
+  upsample_squeeze  glow.py:318-324 (ConvTranspose1d, trim ``win-hop``, unfold to groups)
+  wn_forward        glow.py:188-222 (+ fused gate glow.py:34-41)
+  waveglow_infer    glow.py:314-350 (coupling inverse :337-338, inverse 1x1 conv :85-99,
+                    early-output re-injection :342-347, un-squeeze :349)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+
+
+def fold_weightnorm(g, v):
+    """w = v * (g / ||v||), norm over every dim except 0 (per output channel)."""
+    v = np.asarray(v, dtype=F32)
+    g = np.asarray(g, dtype=F32)
+    norm = np.sqrt(np.sum(v * v, axis=tuple(range(1, v.ndim)), keepdims=True, dtype=F32))
+    return (v * (g.reshape(norm.shape) / norm)).astype(F32)
+
+
+def _conv_weight(sd, prefix):
+    """Effective conv weight [O, I, K] for a layer stored weight-normed or plain."""
+    if prefix + ".weight" in sd:
+        return np.asarray(sd[prefix + ".weight"], dtype=F32)
+    return fold_weightnorm(sd[prefix + ".weight_g"], sd[prefix + ".weight_v"])
+
+
+def fold_state_dict(sd):
+    """Fold every weight_g/weight_v pair once (what ``remove_weightnorm`` would leave behind)."""
+    out = {}
+    for k, v in sd.items():
+        if k.endswith(".weight_v"):
+            out[k[:-2]] = fold_weightnorm(sd[k[:-2] + "_g"], v)
+        elif not k.endswith(".weight_g"):
+            out[k] = np.asarray(v, dtype=F32)
+    return out
+
+
+def _conv1x1(w, b, x):
+    """w [O, I, 1], b [O], x [B, I, L] -> [B, O, L]."""
+    return np.matmul(np.ascontiguousarray(w[:, :, 0]), x) + b[None, :, None]
+
+
+def _shift(x, s):
+    """y[..., l] = x[..., l + s], zero outside [0, L)."""
+    if s == 0:
+        return x
+    y = np.zeros_like(x)
+    if s > 0:
+        y[..., :-s] = x[..., s:]
+    else:
+        y[..., -s:] = x[..., :s]
+    return y
+
+
+def upsample_squeeze(mel, w_up, b_up, hop, n_group):
+    """mel [B, M, F] -> spect [B, M*n_group, F*hop/n_group].
+
+    y[b,o,t] = bias[o] + sum_{i,f} mel[b,i,f] * w_up[i,o,t - f*hop]   for 0 <= t - f*hop < win
+    keep t < F*hop;  spect[b, o*G + g, l] = y[b, o, G*l + g].
+    """
+    mel = np.asarray(mel, dtype=F32)
+    B, M, F = mel.shape
+    win = w_up.shape[2]
+    taps = win // hop
+    assert taps * hop == win
+    y = np.zeros((B, w_up.shape[1], F + taps - 1, hop), dtype=F32)
+    xt = np.ascontiguousarray(mel.transpose(0, 2, 1))           # [B, F, I]
+    for j in range(taps):
+        wj = w_up[:, :, j * hop:(j + 1) * hop].reshape(M, -1)   # [I, O*hop]
+        contrib = np.matmul(xt, wj).reshape(B, F, w_up.shape[1], hop)
+        y[:, :, j:j + F, :] += contrib.transpose(0, 2, 1, 3)
+    y = y[:, :, :F, :].reshape(B, w_up.shape[1], F * hop) + b_up[None, :, None]
+    L = F * hop // n_group
+    y = y.reshape(B, y.shape[1], L, n_group)                    # [B, O, L, G]
+    return np.ascontiguousarray(y.transpose(0, 1, 3, 2)).reshape(B, -1, L)
+
+
+def wn_forward(sd, prefix, audio0, spect, n_layers, n_channels, trace=None):
+    """One WN stack: returns (b, log_s), each [B, n_half, L]."""
+    C = n_channels
+    x = _conv1x1(_conv_weight(sd, prefix + ".start"), sd[prefix + ".start.bias"], audio0)
+    c = spect
+    j = 0
+    while f"{prefix}.cond_layers.{j}.bias" in sd:               # no nonlinearity between layers
+        c = _conv1x1(_conv_weight(sd, f"{prefix}.cond_layers.{j}"),
+                     sd[f"{prefix}.cond_layers.{j}.bias"], c)
+        j += 1
+    out = np.zeros_like(x)
+    for i in range(n_layers):
+        d = 2 ** i
+        w = _conv_weight(sd, f"{prefix}.in_layers.{i}")          # [2C, C, 3]
+        u = sd[f"{prefix}.in_layers.{i}.bias"][None, :, None] + c[:, 2 * C * i:2 * C * (i + 1), :]
+        ks = w.shape[2]
+        for t in range(ks):
+            u = u + np.matmul(np.ascontiguousarray(w[:, :, t]), _shift(x, (t - ks // 2) * d))
+        u = u.astype(F32)
+        act = np.tanh(u[:, :C]) * (F32(1.0) / (F32(1.0) + np.exp(-u[:, C:])))
+        r = _conv1x1(_conv_weight(sd, f"{prefix}.res_skip_layers.{i}"),
+                     sd[f"{prefix}.res_skip_layers.{i}.bias"], act.astype(F32))
+        if i < n_layers - 1:
+            x = x + r[:, :C]
+            out = out + r[:, C:]
+        else:
+            out = out + r
+        if trace is not None:
+            trace.append((x.copy(), out.copy()))
+    e = _conv1x1(np.asarray(sd[prefix + ".end.weight"], dtype=F32), sd[prefix + ".end.bias"], out)
+    h = e.shape[1] // 2
+    return e[:, :h], e[:, h:]
+
+
+def waveglow_infer(sd, cfg, mel, z_scaled, flow_trace=None):
+    """mel [B, n_mel, F], z_scaled [B, n_group, L] (sigma already applied) -> wave [B, F*hop].
+
+    ``z_scaled`` rows: the last ``n_remaining_channels`` are the initial latent; the
+    ``n_early_size`` rows above are prepended after flow k = n_early_every*(m-1), etc.
+    (see cookietts_amd.synthetic.synthetic_noise).
+    """
+    sd = {k: np.asarray(v, dtype=F32) for k, v in sd.items()}
+    G = cfg["n_group"]
+    wn = cfg["WN_config"]
+    n_flows, every, esize = cfg["n_flows"], cfg["n_early_every"], cfg["n_early_size"]
+    spect = upsample_squeeze(mel, sd["upsample.weight"], sd["upsample.bias"], cfg["hop_length"], G)
+    B, _, L = spect.shape
+    z_scaled = np.asarray(z_scaled, dtype=F32)
+    assert z_scaled.shape == (B, G, L), (z_scaled.shape, (B, G, L))
+    n_early = sum(1 for k in range(1, n_flows) if k % every == 0)
+    lo = n_early * esize
+    audio = z_scaled[:, lo:, :]
+    for k in reversed(range(n_flows)):
+        h = audio.shape[1] // 2
+        a0, a1 = audio[:, :h], audio[:, h:]
+        b, s = wn_forward(sd, f"WN.{k}", a0, spect, wn["n_layers"], wn["n_channels"])
+        a1 = ((a1 - b) / np.exp(s)).astype(F32)
+        audio = np.concatenate([a0, a1], axis=1)
+        w = sd[f"convinv.{k}.conv.weight"][:, :, 0]
+        w_inv = np.linalg.inv(w.astype(F32)).astype(F32)
+        audio = np.matmul(w_inv, audio).astype(F32)
+        if k % every == 0 and k > 0:
+            lo -= esize
+            audio = np.concatenate([z_scaled[:, lo:lo + esize, :], audio], axis=1)
+        if flow_trace is not None:
+            flow_trace.append(audio.copy())
+    assert lo == 0
+    return np.ascontiguousarray(audio.transpose(0, 2, 1)).reshape(B, -1)

@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE ITSELF.
+
+Run in the build container only (``/root/reference`` does not exist on the GPU box):
+
+    python tests/golden/make_golden.py [waveglow]
+
+What is captured is data only - inputs and the reference's outputs.  Weights are not
+stored: they come from the deterministic numpy recipe ``cookietts_amd.synthetic``
+(seed recorded in each fixture), loaded into the reference model through its own
+``load_state_dict``.
+
+Oracle-only shims, living only here:
+  * ``torch.cuda.FloatTensor`` aliased to the CPU ``torch.FloatTensor`` so that the
+    reference's early-output noise draw (glow.py:343-346) runs without a GPU.  The noise
+    it draws is recorded by replaying the same torch RNG sequence from the same seed.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+
+from cookietts_amd import synthetic  # noqa: E402
+
+
+def _ref_waveglow(cfg, sd_np):
+    from CookieTTS._4_mtw.waveglow import glow
+    model = glow.WaveGlow(**cfg)
+    missing = model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()},
+                                    strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return model.eval()
+
+
+def _run_ref_infer(model, cfg, mel, sigma, torch_seed):
+    """Run the reference's own ``infer`` and return (wave, z_scaled[B,G,L]) with the noise it drew."""
+    B, _, F = mel.shape
+    G = cfg["n_group"]
+    L = F * cfg["hop_length"] // G
+    chans = synthetic.waveglow_flow_channels(cfg)
+    n_rem_final = chans[-1][0]
+    esize = cfg["n_early_size"]
+    early_flows = [k for k in reversed(range(cfg["n_flows"])) if k % cfg["n_early_every"] == 0 and k > 0]
+
+    # replay of the RNG sequence infer() will consume (glow.py:326 then :343-346 per early flow)
+    torch.manual_seed(torch_seed)
+    z = np.zeros((B, G, L), dtype=np.float32)
+    lo = len(early_flows) * esize
+    assert lo + n_rem_final == G
+    z[:, lo:] = torch.ones(B, n_rem_final, L).normal_(std=sigma).numpy()
+    for _ in early_flows:
+        lo -= esize
+        z[:, lo:lo + esize] = (sigma * torch.FloatTensor(B, esize, L).normal_()).numpy()
+
+    saved = getattr(torch.cuda, "FloatTensor", None)
+    torch.cuda.FloatTensor = torch.FloatTensor          # shim: CPU stand-in for the CUDA-only ctor
+    try:
+        torch.manual_seed(torch_seed)
+        with torch.no_grad():
+            wave = model.infer(torch.from_numpy(mel.copy()), sigma=sigma)
+    finally:
+        if saved is not None:
+            torch.cuda.FloatTensor = saved
+    return wave.numpy().astype(np.float32), z
+
+
+def make_waveglow():
+    torch.set_num_threads(8)
+    cases = [
+        # name, config key, batch, frames, sigma, seed
+        ("toy", "toy", 2, 12, 1.0, 11),
+        ("toy_early", "toy_early", 2, 9, 0.8, 12),          # exercises early-output re-injection
+        ("small", "small", 1, 200, 0.6, 1234),              # BASELINE config 1, end to end
+        ("full_short", "full", 1, 16, 0.6, 1234),           # BASELINE config 2 topology, short mel
+    ]
+    for name, key, B, F, sigma, seed in cases:
+        cfg = synthetic.WAVEGLOW_CONFIGS[key]
+        sd = synthetic.waveglow_state_dict(cfg, seed=seed)
+        model = _ref_waveglow(cfg, sd)
+        mel = synthetic.synthetic_mel(B, F, cfg["n_mel_channels"], seed=seed)
+        wave, z = _run_ref_infer(model, cfg, mel, sigma, torch_seed=seed)
+        assert wave.shape == (B, F * cfg["hop_length"]) and np.isfinite(wave).all()
+        extras = {}
+        if name in ("toy", "small"):
+            # per-stage intermediates from the reference's own sub-modules (flow n_flows-1)
+            with torch.no_grad():
+                up = model.upsample(torch.from_numpy(mel))
+                up = up[:, :, :-(cfg["win_length"] - cfg["hop_length"])]
+                sp = up.unfold(2, cfg["n_group"], cfg["n_group"]).permute(0, 2, 1, 3)
+                sp = sp.contiguous().view(sp.size(0), sp.size(1), -1).permute(0, 2, 1)
+                k = cfg["n_flows"] - 1
+                n_rem = synthetic.waveglow_flow_channels(cfg)[k][0]
+                a = torch.from_numpy(z[:, cfg["n_group"] - n_rem:, :].copy())
+                b_, s_ = model.WN[k](a[:, :n_rem // 2], sp)
+            extras = dict(spect_head=sp[:, :, :64].numpy().astype(np.float32),
+                          spect_checksum=np.float64(sp.double().sum().item()),
+                          wn_last_b=b_.numpy().astype(np.float32),
+                          wn_last_s=s_.numpy().astype(np.float32))
+        path = os.path.join(HERE, f"waveglow_{name}.npz")
+        np.savez_compressed(path, config_key=key, seed=seed, sigma=np.float32(sigma), mel=mel,
+                            z_scaled=z, wave=wave, **extras)
+        rms = float(np.sqrt(np.mean(wave.astype(np.float64) ** 2)))
+        print(f"[golden] {name}: wave {wave.shape} rms={rms:.4f} max={np.abs(wave).max():.3f} -> "
+              f"{os.path.getsize(path) / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["waveglow"]
+    if "waveglow" in which:
+        make_waveglow()

@@ -1,0 +1,90 @@
+"""CPU-side checks: the C-ABI library builds, loads and exports what the header declares;
+the Python host mirrors the reference's module surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+from cookietts_amd import WaveGlow, _lib, synthetic
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, "include", "cookietts_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ctts_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(hip_lib_path):
+    declared = _declared_symbols()
+    assert len(declared) >= 12
+    handle = ctypes.CDLL(hip_lib_path)
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in include/cookietts_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == declared, "ctypes signature table out of sync with the header"
+    assert handle.ctts_abi_version() == 1
+
+
+def test_host_side_queries_run_without_gpu(hip_lib_path):
+    """Geometry / size queries are pure host code: callable on the build box."""
+    lib = _lib.lib()
+    m = WaveGlow(**synthetic.WAVEGLOW_CONFIGS["toy"])
+    c = m.c_config()
+    geo = _lib.WaveGlowGeometry()
+    assert lib.ctts_waveglow_geometry_for(ctypes.byref(c), 900, ctypes.byref(geo)) == 0
+    assert geo.steps == 28800 and geo.pad == 128 and geo.ld == 28800 + 256 and geo.n_remaining == 8
+    assert lib.ctts_waveglow_packed_bytes(ctypes.byref(c)) > 0
+    assert lib.ctts_waveglow_workspace_bytes(ctypes.byref(c), 2, 10) > 0
+    bad = m.c_config()
+    bad.n_channels = 100
+    assert lib.ctts_waveglow_packed_bytes(ctypes.byref(bad)) == 0
+    assert b"n_channels" in lib.ctts_last_error()
+    bad = m.c_config()
+    bad.kernel_size = 5
+    assert lib.ctts_waveglow_geometry_for(ctypes.byref(bad), 10, ctypes.byref(geo)) == -1
+
+
+@pytest.mark.parametrize("key", ["toy", "toy_early", "small"])
+def test_state_dict_keys_and_shapes_match_reference_format(key):
+    cfg = synthetic.WAVEGLOW_CONFIGS[key]
+    sd = synthetic.waveglow_state_dict(cfg, seed=1)
+    m = WaveGlow(**cfg)
+    own = m.state_dict()
+    assert sorted(own) == sorted(sd)
+    for k, v in sd.items():
+        assert tuple(own[k].shape) == v.shape, k
+    m.load_state_dict(synthetic.to_torch(sd))
+    assert torch.equal(m.WN[0].start.weight_v, torch.from_numpy(sd["WN.0.start.weight_v"]))
+    assert m.n_remaining_channels == synthetic.waveglow_flow_channels(cfg)[-1][0]
+    assert m.multispeaker is False
+
+
+def test_default_init_matches_reference_conventions():
+    m = WaveGlow(**synthetic.WAVEGLOW_CONFIGS["toy"])
+    assert float(m.WN[0].end.weight.abs().max()) == 0.0           # glow.py:141-144
+    W = m.convinv[0].conv.weight.squeeze(-1)
+    assert torch.allclose(W @ W.t(), torch.eye(W.shape[0]), atol=1e-5) and torch.det(W) > 0   # glow.py:76-83
+    g = m.WN[0].start.weight_g.flatten()
+    assert torch.allclose(g, m.WN[0].start.weight_v.flatten(1).norm(dim=1))
+
+
+def test_unsupported_options_fail_loudly():
+    cfg = dict(synthetic.WAVEGLOW_CONFIGS["toy"])
+    with pytest.raises(NotImplementedError):
+        WaveGlow(**dict(cfg, upsample_mode="simple"))
+    wn = dict(cfg["WN_config"], speaker_embed_dim=16)
+    with pytest.raises(NotImplementedError):
+        WaveGlow(**dict(cfg, WN_config=wn))
+
+
+def test_synthetic_recipe_is_deterministic():
+    cfg = synthetic.WAVEGLOW_CONFIGS["toy"]
+    a = synthetic.waveglow_state_dict(cfg, seed=7)
+    b = synthetic.waveglow_state_dict(cfg, seed=7)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert np.abs(a["WN.0.end.weight"]).max() > 0
+    z = synthetic.synthetic_noise(2, 8, 64, seed=3)
+    assert z.shape == (2, 8, 64) and abs(float(z.std()) - 1.0) < 0.1

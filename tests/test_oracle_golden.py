@@ -1,0 +1,58 @@
+"""The CPU oracle against vectors produced by the reference itself (tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, rms_rel_err
+from cookietts_amd import synthetic
+from oracle import waveglow_oracle as wo
+
+# waveform RMS relative error bound of BASELINE.json is 1e-3; the oracle itself must sit far inside it.
+ORACLE_TOL = 5e-6
+
+
+def _load(name):
+    g = np.load(os.path.join(GOLDEN, f"waveglow_{name}.npz"))
+    cfg = synthetic.WAVEGLOW_CONFIGS[str(g["config_key"])]
+    sd = synthetic.waveglow_state_dict(cfg, seed=int(g["seed"]))
+    return g, cfg, sd
+
+
+@pytest.mark.parametrize("name", ["toy", "toy_early", "small", "full_short"])
+def test_waveglow_oracle_matches_reference(name):
+    g, cfg, sd = _load(name)
+    wave = wo.waveglow_infer(sd, cfg, g["mel"], g["z_scaled"])
+    assert wave.shape == g["wave"].shape
+    assert rms_rel_err(wave, g["wave"]) < ORACLE_TOL
+
+
+@pytest.mark.parametrize("name", ["toy", "small"])
+def test_stage_intermediates(name):
+    g, cfg, sd = _load(name)
+    spect = wo.upsample_squeeze(g["mel"], sd["upsample.weight"], sd["upsample.bias"], cfg["hop_length"],
+                                cfg["n_group"])
+    assert np.abs(spect[:, :, :64] - g["spect_head"]).max() < 1e-4        # mel L_inf bound of BASELINE.json
+    assert abs(float(spect.astype(np.float64).sum()) - float(g["spect_checksum"])) < 1e-3 * spect.size ** 0.5
+    k = cfg["n_flows"] - 1
+    n_rem = synthetic.waveglow_flow_channels(cfg)[k][0]
+    a = g["z_scaled"][:, cfg["n_group"] - n_rem:, :]
+    b, s = wo.wn_forward(sd, f"WN.{k}", a[:, :n_rem // 2], spect, cfg["WN_config"]["n_layers"],
+                         cfg["WN_config"]["n_channels"])
+    assert rms_rel_err(b, g["wn_last_b"]) < ORACLE_TOL
+    assert rms_rel_err(s, g["wn_last_s"]) < ORACLE_TOL
+
+
+def test_weightnorm_fold_is_not_identity():
+    cfg = synthetic.WAVEGLOW_CONFIGS["toy"]
+    sd = synthetic.waveglow_state_dict(cfg, seed=3)
+    w = wo.fold_weightnorm(sd["WN.0.start.weight_g"], sd["WN.0.start.weight_v"])
+    assert np.abs(w - sd["WN.0.start.weight_v"]).max() > 1e-3
+    n = np.sqrt((w.astype(np.float64) ** 2).sum(axis=(1, 2)))
+    assert np.allclose(n, sd["WN.0.start.weight_g"].reshape(-1), rtol=1e-5)
+
+
+def test_flow_channels_match_reference_schedule():
+    # glow.py:255-265 with n_early_every=4, n_early_size=2, 12 flows (SURVEY.md §8 notation)
+    cfg = synthetic.WAVEGLOW_CONFIGS["full"]
+    assert [c for c, _ in synthetic.waveglow_flow_channels(cfg)] == [8, 8, 8, 8, 6, 6, 6, 6, 4, 4, 4, 4]

@@ -1,0 +1,115 @@
+"""Parity of the HIP path (through the C ABI) with the reference goldens and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rms_rel_err
+from cookietts_amd import WaveGlow, synthetic
+
+pytestmark = pytest.mark.gpu
+
+# BASELINE.json: waveform RMS relative error <= 1e-3 (fp32, identical weights / mel / noise)
+WAVE_TOL = 1e-3
+
+
+def _model(key, seed):
+    cfg = synthetic.WAVEGLOW_CONFIGS[key]
+    sd = synthetic.waveglow_state_dict(cfg, seed=seed)
+    m = WaveGlow(**cfg)
+    m.load_state_dict(synthetic.to_torch(sd))
+    return m.cuda().eval(), cfg, sd
+
+
+@pytest.mark.parametrize("name", ["toy", "toy_early", "small", "full_short"])
+def test_waveglow_matches_reference_golden(hip_lib_path, name):
+    g = np.load(os.path.join(GOLDEN, f"waveglow_{name}.npz"))
+    m, cfg, _ = _model(str(g["config_key"]), int(g["seed"]))
+    wave = m.infer_from_noise(torch.from_numpy(g["mel"]).cuda(), torch.from_numpy(g["z_scaled"]).cuda())
+    torch.cuda.synchronize()
+    wave = wave.cpu().numpy()
+    assert wave.shape == g["wave"].shape and np.isfinite(wave).all()
+    err = rms_rel_err(wave, g["wave"])
+    print(f"{name}: rms rel err vs reference = {err:.3e}")
+    assert err < WAVE_TOL
+
+
+@pytest.mark.parametrize("B,F", [(1, 1), (3, 5), (2, 37), (1, 130)])
+def test_waveglow_matches_oracle_ragged_shapes(hip_lib_path, B, F):
+    """Ragged tile edges: L = 32*F is not a multiple of the 128-step GEMM tile for most F."""
+    from oracle import waveglow_oracle as wo
+    m, cfg, sd = _model("toy_early", 21)
+    mel = synthetic.synthetic_mel(B, F, seed=F)
+    z = synthetic.synthetic_noise(B, cfg["n_group"], F * 32, seed=F) * np.float32(0.7)
+    ref = wo.waveglow_infer(sd, cfg, mel, z)
+    wave = m.infer_from_noise(torch.from_numpy(mel).cuda(), torch.from_numpy(z).cuda()).cpu().numpy()
+    assert rms_rel_err(wave, ref) < WAVE_TOL
+    # second call on the same workspace (halo must still be zero) and after a different geometry
+    m.infer_from_noise(torch.from_numpy(synthetic.synthetic_mel(1, 3)).cuda(),
+                       torch.from_numpy(synthetic.synthetic_noise(1, 8, 96)).cuda())
+    wave2 = m.infer_from_noise(torch.from_numpy(mel).cuda(), torch.from_numpy(z).cuda()).cpu().numpy()
+    assert np.array_equal(wave, wave2)
+
+
+def test_batch_items_are_independent(hip_lib_path):
+    m, cfg, _ = _model("toy", 5)
+    mel = torch.from_numpy(synthetic.synthetic_mel(4, 20, seed=9)).cuda()
+    z = torch.from_numpy(synthetic.synthetic_noise(4, 8, 640, seed=9)).cuda()
+    full = m.infer_from_noise(mel, z)
+    for b in range(4):
+        one = m.infer_from_noise(mel[b:b + 1], z[b:b + 1])
+        assert torch.equal(one[0], full[b])
+
+
+def test_infer_api_contract(hip_lib_path):
+    """glow.WaveGlow.infer contract: [B, n_mel, F] -> [B, F*hop] on the input device, sigma scales noise."""
+    m, cfg, _ = _model("toy", 5)
+    mel = torch.from_numpy(synthetic.synthetic_mel(2, 10)).cuda()
+    torch.manual_seed(0)
+    a = m.infer(mel, sigma=0.6)
+    assert a.shape == (2, 10 * 256) and a.is_cuda and a.dtype == mel.dtype and torch.isfinite(a).all()
+    torch.manual_seed(0)
+    b = m.infer(mel, sigma=0.6)
+    assert torch.equal(a, b)
+    assert m.convinv[0].W_inverse.shape == (8, 8, 1)         # cached like glow.py:97
+    # weight-norm removal must not change the function
+    z = torch.from_numpy(synthetic.synthetic_noise(2, 8, 320)).cuda()
+    before = m.infer_from_noise(mel, z)
+    WaveGlow.remove_weightnorm(m)
+    assert "WN.0.start.weight" in m.state_dict() and "WN.0.start.weight_g" not in m.state_dict()
+    after = m.infer_from_noise(mel, z)
+    assert rms_rel_err(after.cpu().numpy(), before.cpu().numpy()) < 1e-5
+
+
+def test_stage_upsample_squeeze_against_oracle(hip_lib_path):
+    import ctypes as C
+    from cookietts_amd import _lib
+    from oracle import waveglow_oracle as wo
+    m, cfg, sd = _model("toy", 5)
+    B, F = 2, 19
+    mel = synthetic.synthetic_mel(B, F, seed=4)
+    ref = wo.upsample_squeeze(mel, sd["upsample.weight"], sd["upsample.bias"], 256, 8)
+    blob = m._ensure_packed(torch.device("cuda", 0))
+    lib = _lib.lib()
+    c = m.c_config()
+    geo = _lib.WaveGlowGeometry()
+    _lib.check(lib.ctts_waveglow_geometry_for(C.byref(c), F, C.byref(geo)), "geometry")
+    spect = torch.zeros(B, 640, geo.ld, device="cuda")
+    melt = torch.from_numpy(mel).cuda()
+    _lib.check(lib.ctts_upsample_squeeze_f32(C.byref(c), _lib.ptr(blob), _lib.ptr(melt), _lib.ptr(spect), B, F,
+                                            None), "upsample_squeeze")
+    torch.cuda.synchronize()
+    got = spect[:, :, geo.pad:geo.pad + geo.steps].cpu().numpy()
+    assert np.abs(got - ref).max() < 1e-4                     # mel-domain L_inf bound of BASELINE.json
+    halo = spect.clone()
+    halo[:, :, geo.pad:geo.pad + geo.steps] = 0
+    assert float(halo.abs().max()) == 0.0                     # halo columns stay zero
+
+
+def test_no_cpu_fallback(hip_lib_path):
+    from cookietts_amd import _lib
+    cfg = synthetic.WAVEGLOW_CONFIGS["toy"]
+    m = WaveGlow(**cfg)
+    with pytest.raises(_lib.HipLibraryError):
+        m.infer(torch.zeros(1, 80, 4))
