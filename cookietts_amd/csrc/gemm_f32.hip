@@ -28,7 +28,15 @@ __device__ __forceinline__ float4 load4(const float* p, int aligned) {
     return v;
 }
 
-__device__ __forceinline__ float sigmoidf_precise(float u) { return 1.0f / (1.0f + expf(-u)); }
+// Gate math on the hardware transcendental unit: exp via v_exp_f32 (2^x), reciprocal via
+// v_rcp_f32 (1 ulp).  Absolute error of tanh/sigmoid <= ~3e-7, far inside the parity budget.
+__device__ __forceinline__ float fast_sigmoid(float u) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f));
+}
+__device__ __forceinline__ float fast_tanh(float u) {
+    // tanh(u) = 1 - 2 / (1 + e^{2u}); saturates correctly at +-inf
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * 2.8853900817779268f));
+}
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a) {
@@ -63,60 +71,107 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    float4 ra[4], rb[2];
+    // Segment table -> scalar registers (static indices only: a dynamically indexed kernarg
+    // struct would be copied to scratch).
+    const float* sbase[GEMM_MAX_SEG];
+    int snch[GEMM_MAX_SEG], salign[GEMM_MAX_SEG];
+#pragma unroll
+    for (int s = 0; s < GEMM_MAX_SEG; ++s) {
+        const GemmSeg& g = a.seg[s];
+        // everything except the k-row of the chunk folded into one per-thread base pointer
+        sbase[s] = g.base + (size_t)b * g.bstride + (size_t)(mb * g.mb_rows + brow) * a.ld +
+                   (a.pad + n0 + g.shift + bcol);
+        snch[s] = s < a.nseg ? g.nch : 0x7fffffff;
+        salign[s] = g.aligned;
+    }
+    const size_t chunk_rows = (size_t)GEMM_KC * a.ld;
+
+    float4 ra0, ra1, ra2, ra3, rb0, rb1;
     int seg = 0, local = 0;
+    const float* ap = Ablk + t * 4;
 
-    auto issue_loads = [&](int ch) {
-        const float* ap = Ablk + (size_t)ch * A_STAGE + t * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const float4*>(ap + j * 1024);
-        const GemmSeg& s = a.seg[seg];
-        const float* bp = s.base + (size_t)b * s.bstride +
-                          (size_t)(mb * s.mb_rows + local * GEMM_KC + brow) * a.ld +
-                          (a.pad + n0 + s.shift + bcol);
-        rb[0] = load4(bp, s.aligned);
-        rb[1] = load4(bp + 64, s.aligned);
-        if (++local == s.nch) { local = 0; ++seg; }
-    };
-    auto store_lds = [&](int buf) {
-        float* As = lds + buf * STAGE;
-        float* Bs = As + A_STAGE;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(As + t * 4 + j * 1024) = ra[j];
-        *reinterpret_cast<float4*>(Bs + brow * GEMM_BN + bcol) = rb[0];
-        *reinterpret_cast<float4*>(Bs + brow * GEMM_BN + bcol + 64) = rb[1];
-    };
+#define CTTS_ISSUE_LOADS()                                                                      \
+    do {                                                                                        \
+        ra0 = *reinterpret_cast<const float4*>(ap);                                             \
+        ra1 = *reinterpret_cast<const float4*>(ap + 1024);                                      \
+        ra2 = *reinterpret_cast<const float4*>(ap + 2048);                                      \
+        ra3 = *reinterpret_cast<const float4*>(ap + 3072);                                      \
+        ap += A_STAGE;                                                                          \
+        const float* sb = seg == 0 ? sbase[0] : seg == 1 ? sbase[1] : seg == 2 ? sbase[2] : sbase[3]; \
+        const int sn = seg == 0 ? snch[0] : seg == 1 ? snch[1] : seg == 2 ? snch[2] : snch[3];  \
+        const int sa = seg == 0 ? salign[0] : seg == 1 ? salign[1] : seg == 2 ? salign[2] : salign[3]; \
+        const float* bp = sb + (size_t)local * chunk_rows;                                      \
+        rb0 = load4(bp, sa);                                                                    \
+        rb1 = load4(bp + 64, sa);                                                               \
+        if (++local == sn) { local = 0; ++seg; }                                                \
+    } while (0)
 
-    issue_loads(0);
-    store_lds(0);
+#define CTTS_STORE_LDS(buf)                                                                     \
+    do {                                                                                        \
+        float* As_ = lds + (buf) * STAGE + t * 4;                                               \
+        float* Bs_ = lds + (buf) * STAGE + A_STAGE + brow * GEMM_BN + bcol;                     \
+        *reinterpret_cast<float4*>(As_) = ra0;                                                  \
+        *reinterpret_cast<float4*>(As_ + 1024) = ra1;                                           \
+        *reinterpret_cast<float4*>(As_ + 2048) = ra2;                                           \
+        *reinterpret_cast<float4*>(As_ + 3072) = ra3;                                           \
+        *reinterpret_cast<float4*>(Bs_) = rb0;                                                  \
+        *reinterpret_cast<float4*>(Bs_ + 64) = rb1;                                             \
+    } while (0)
+
+#define CTTS_LOAD_FRAG(AV, BV, ks)                                                              \
+    do {                                                                                        \
+        const int krow_ = 2 * (ks) + lhi;                                                       \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) AV[mt] = As[krow_ * GEMM_BM + mt * 32]; \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) BV[nt] = Bs[krow_ * GEMM_BN + nt * 32]; \
+    } while (0)
+
+#define CTTS_MFMA(AV, BV)                                                                       \
+    do {                                                                                        \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                        \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                    \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[mt], BV[nt], acc[mt][nt], 0, 0, 0); \
+    } while (0)
+
+    CTTS_ISSUE_LOADS();
+    CTTS_STORE_LDS(0);
     __syncthreads();
 
     const int nch = a.nch_total;
     for (int ch = 0; ch < nch; ++ch) {
         const int cur = ch & 1;
-        if (ch + 1 < nch) issue_loads(ch + 1);
+        const bool more = ch + 1 < nch;
+        if (more) CTTS_ISSUE_LOADS();
         const float* As = lds + cur * STAGE + wm * 128 + l31;
         const float* Bs = lds + cur * STAGE + A_STAGE + wn * 64 + l31;
+        // k-step ks+1's fragments are read from LDS while ks runs on the MFMA pipe; the
+        // sched_group_barrier sequence pins that software pipeline (hipcc otherwise sinks every
+        // ds_read to just before its first use and exposes the LDS latency 16x per chunk).
+        float av[GEMM_KC / 2][4], bv[GEMM_KC / 2][2];
 #pragma unroll
-        for (int ks = 0; ks < GEMM_KC / 2; ++ks) {
-            const int krow = 2 * ks + lhi;
-            float av[4], bv[2];
+        for (int ks = 0; ks < GEMM_KC / 2; ++ks) CTTS_LOAD_FRAG(av[ks], bv[ks], ks);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) av[mt] = As[krow * GEMM_BM + mt * 32];
+        for (int ks = 0; ks < GEMM_KC / 2; ++ks) CTTS_MFMA(av[ks], bv[ks]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);      // 3 x ds_read2_b32: fragments of k-step 0
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) bv[nt] = Bs[krow * GEMM_BN + nt * 32];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+        for (int ks = 0; ks < GEMM_KC / 2 - 1; ++ks) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // fragments of k-step ks+1
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);  // 8 MFMAs of k-step ks
         }
-        if (ch + 1 < nch) store_lds(cur ^ 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        if (more) CTTS_STORE_LDS(cur ^ 1);
         __syncthreads();
     }
+#undef CTTS_ISSUE_LOADS
+#undef CTTS_STORE_LDS
+#undef CTTS_LOAD_FRAG
+#undef CTTS_MFMA
 
     // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const float* bias = a.bias + mb * GEMM_BM + wm * 128;
+    // bias via LDS: a global bias load between the stores would force vmcnt(0) (which on gfx9
+    // also drains the stores) once per element.
+    lds[t] = a.bias[mb * GEMM_BM + t];
+    __syncthreads();
+    const float* bias = lds + wm * 128;
     if constexpr (EPI == GEMM_EPI_GATE) {
         float* dst = a.dst0 + (size_t)b * a.dst0_bstride;
         const int cbase = mb * 128 + wm * 64;
@@ -131,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
                         const float ut = acc[mt][nt][r] + bias[mt * 32 + row];
                         const float us = acc[mt + 2][nt][r] + bias[64 + mt * 32 + row];
-                        dst[(size_t)(cbase + mt * 32 + row) * a.ld + a.pad + n] = tanhf(ut) * sigmoidf_precise(us);
+                        dst[(size_t)(cbase + mt * 32 + row) * a.ld + a.pad + n] = fast_tanh(ut) * fast_sigmoid(us);
                     }
                 }
             }
@@ -145,6 +200,24 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
             float* dst = second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride;
             const int accum = second ? a.acc1 : a.acc0;
             const int rdst = second ? rbase - a.split : rbase;
+            // read-modify-write: issue all 32 loads of this row-tile before the first store so
+            // the wave pays one memory latency per tile, not one per element (the compiler must
+            // otherwise order every load behind the previous, possibly aliasing, store).
+            float old[2][16];
+            if (accum) {   // uniform; columns >= L of a padded row are readable, so no per-lane guard
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                        old[nt][r] = dst[(size_t)(rdst + row) * a.ld + a.pad + n0 + wn * 64 + nt * 32 + l31];
+                    }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) old[nt][r] = 0.0f;
+            }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const int n = n0 + wn * 64 + nt * 32 + l31;
@@ -152,10 +225,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                        float v = acc[mt][nt][r] + bias[mt * 32 + row];
-                        float* p = dst + (size_t)(rdst + row) * a.ld + a.pad + n;
-                        if (accum) v += *p;
-                        *p = v;
+                        dst[(size_t)(rdst + row) * a.ld + a.pad + n] = acc[mt][nt][r] + bias[mt * 32 + row] + old[nt][r];
                     }
                 }
             }
