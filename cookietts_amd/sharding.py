@@ -1,0 +1,95 @@
+"""Utterance-batch sharding of vocoder inference across the GPUs of one node.
+
+The reference has no multi-GPU inference (its ``start_worker`` is a stub,
+``_5_infer/t2s_server/text2speech.py:779-787``).  Utterances are independent through the
+whole path, so the shard unit is the utterance: every rank holds a full
+weight replica and runs its slice of the batch; there is no collective inside the hot
+path.  The only exchange steps are the ones a serving process needs around it:
+
+  * ``broadcast_state_dict``  - once per model, rank 0 -> all (RCCL broadcast over xGMI);
+  * ``scatter_mels``          - per request batch, rank 0 -> each rank's slice;
+  * ``gather_waves``          - per request batch, every rank -> rank 0, direct
+                                point-to-point (a ring would be bound by one xGMI link).
+
+One process per GPU, ``torch.distributed`` (backend "nccl" = RCCL on ROCm; "gloo" on CPU for
+the tests).  Nothing here touches the HIP library: it moves tensors only.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+__all__ = ["shard_counts", "broadcast_state_dict", "scatter_mels", "gather_waves", "sharded_infer"]
+
+
+def shard_counts(n_items: int, world: int) -> List[int]:
+    """Contiguous split, first ``n_items % world`` ranks take one extra utterance."""
+    base, extra = divmod(n_items, world)
+    return [base + (1 if r < extra else 0) for r in range(world)]
+
+
+def broadcast_state_dict(module: torch.nn.Module, src: int = 0, group=None) -> None:
+    """Make every rank's parameters/buffers equal to rank ``src``'s (in place)."""
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
+    if hasattr(module, "repack"):
+        module.repack()
+
+
+def scatter_mels(mels: Optional[torch.Tensor], n_mel: int, device, src: int = 0, group=None):
+    """rank ``src`` holds ``mels`` [N, n_mel, F]; returns this rank's slice [n_r, n_mel, F].
+
+    Slices are padded to the largest shard so the collective is regular; the pad is cut
+    off again before returning.
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    meta = torch.zeros(2, dtype=torch.int64, device=device)
+    if rank == src:
+        assert mels is not None and mels.dim() == 3 and mels.shape[1] == n_mel
+        meta[0], meta[1] = mels.shape[0], mels.shape[2]
+    dist.broadcast(meta, src=src, group=group)
+    n_items, frames = int(meta[0]), int(meta[1])
+    counts = shard_counts(n_items, world)
+    cmax = max(max(counts), 1)
+    recv = torch.empty(cmax, n_mel, frames, dtype=torch.float32, device=device)
+    chunks = None
+    if rank == src:
+        chunks, start = [], 0
+        for c in counts:
+            buf = torch.zeros(cmax, n_mel, frames, dtype=torch.float32, device=device)
+            buf[:c] = mels[start:start + c].to(device=device, dtype=torch.float32)
+            chunks.append(buf)
+            start += c
+    dist.scatter(recv, chunks, src=src, group=group)
+    return recv[:counts[rank]], counts
+
+
+def gather_waves(wave: torch.Tensor, counts: Sequence[int], dst: int = 0, group=None):
+    """Every rank contributes ``wave`` [n_r, T]; rank ``dst`` gets [sum n_r, T], others None."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    cmax = max(max(counts), 1)
+    T = wave.shape[1]
+    send = torch.zeros(cmax, T, dtype=wave.dtype, device=wave.device)
+    send[:wave.shape[0]] = wave
+    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+def sharded_infer(infer_fn: Callable[[torch.Tensor], torch.Tensor], mels: Optional[torch.Tensor],
+                  n_mel: int, device, root: int = 0, group=None):
+    """scatter -> local ``infer_fn(mel_slice) -> [n_r, T]`` -> gather.  Returns waves on ``root``."""
+    local, counts = scatter_mels(mels, n_mel, device, src=root, group=group)
+    if local.shape[0] > 0:
+        wave = infer_fn(local)
+    else:   # this rank got no utterance: contribute an empty slab of the right width
+        frames = local.shape[2]
+        probe = infer_fn(torch.zeros(1, n_mel, frames, device=device))
+        wave = probe[:0]
+    return gather_waves(wave, counts, dst=root, group=group)

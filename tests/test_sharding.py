@@ -1,0 +1,64 @@
+"""world_size-2 gloo run of the utterance-batch sharding helpers (CPU, no HIP involved)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cookietts_amd import sharding
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _fake_vocoder(mel):                       # [n, 80, F] -> [n, F*4]; item-wise, like the real path
+    return (mel.mean(dim=1, keepdim=True) * torch.arange(1, 5).view(1, 4, 1)).transpose(1, 2).reshape(mel.shape[0], -1)
+
+
+def _worker(rank, world, port, n_items, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        mels = torch.randn(n_items, 80, 6) if rank == 0 else None
+        lin = torch.nn.Linear(3, 2)
+        torch.manual_seed(100 + rank)
+        with torch.no_grad():
+            lin.weight.normal_()
+        sharding.broadcast_state_dict(lin, src=0)
+        w = lin.weight.detach().clone()
+        ws = [torch.empty_like(w) for _ in range(world)]
+        dist.all_gather(ws, w)
+        same = all(torch.equal(ws[0], x) for x in ws)
+        out = sharding.sharded_infer(_fake_vocoder, mels, 80, torch.device("cpu"), root=0)
+        if rank == 0:
+            q.put((same, torch.equal(out, _fake_vocoder(mels)), tuple(out.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items", [5, 1, 4])
+def test_sharded_infer_matches_single_process(n_items):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_items, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    same, equal, shape = q.get(timeout=10)
+    assert same and equal and shape == (n_items, 24)
+
+
+def test_shard_counts():
+    assert sharding.shard_counts(256, 8) == [32] * 8
+    assert sharding.shard_counts(5, 2) == [3, 2]
+    assert sharding.shard_counts(1, 4) == [1, 0, 0, 0]
