@@ -4,6 +4,7 @@ Python host mirrors of the reference's model API (``WaveGlow(**cfg).infer``) ove
 HIP library (``include/cookietts_hip.h``, sources in ``cookietts_amd/csrc``).
 """
 from . import synthetic  # noqa: F401
+from .audio import STFT, TacotronSTFT  # noqa: F401
 from .waveglow import WaveGlow  # noqa: F401
 
-__all__ = ["WaveGlow", "synthetic"]
+__all__ = ["WaveGlow", "STFT", "TacotronSTFT", "synthetic"]

@@ -22,6 +22,12 @@ class WaveGlowConfig(C.Structure):
         "win_length", "hop_length", "n_layers", "n_channels", "kernel_size", "cond_hidden")]
 
 
+class StftConfig(C.Structure):
+    """``ctts_stft_config``."""
+    _fields_ = [("filter_length", C.c_int32), ("hop_length", C.c_int32), ("win_length", C.c_int32),
+                ("n_mel_channels", C.c_int32), ("clamp_val", C.c_float)]
+
+
 class WaveGlowGeometry(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("steps", "ld", "pad", "n_remaining")]
 
@@ -56,6 +62,11 @@ SIGNATURES = {
     "ctts_wn_cond_f32": (C.c_int, [_CFG, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP]),
     "ctts_wn_stack_f32": (C.c_int, [_CFG, _FP, C.c_int32, _FP, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP]),
     "ctts_flow_tail_f32": (C.c_int, [_CFG, _FP, C.c_int32, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP]),
+    "ctts_stft_packed_bytes": (C.c_size_t, [C.POINTER(StftConfig)]),
+    "ctts_stft_pack": (C.c_int, [C.POINTER(StftConfig), _FP, _FP, _FP, _FP]),
+    "ctts_stft_workspace_bytes": (C.c_size_t, [C.POINTER(StftConfig), C.c_int32, C.c_int32]),
+    "ctts_stft_mel_f32": (C.c_int, [C.POINTER(StftConfig), _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP,
+                                    C.c_size_t, _FP]),
     "ctts_profile_enable": (C.c_int, [C.c_int32]),
     "ctts_profile_collect": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }

@@ -22,7 +22,13 @@ enum GemmEpilogue : int {
     GEMM_EPI_SPLIT = 0,
     // block rows are (64 tanh, 64 sigmoid) per wave-row: dst0[c] = tanh(u_t) * sigmoid(u_s)
     GEMM_EPI_GATE = 1,
+    // same row pairing, (re, im) rows: dst0[c] = sqrt(re^2 + im^2)          (STFT magnitude)
+    GEMM_EPI_MAG = 2,
+    // dst0[row] = log(max(acc + bias, clip))                                 (mel projection + log)
+    GEMM_EPI_LOG = 3,
 };
+
+__host__ __device__ inline bool gemm_epi_is_pair(int epi) { return epi == GEMM_EPI_GATE || epi == GEMM_EPI_MAG; }
 
 struct GemmSeg {
     const float* base;    // [B][rows][ld] padded layout
@@ -44,19 +50,25 @@ struct GemmArgs {
     int M;                // valid rows (multiple of 32); rows >= M of the last M-block are padding
     float* dst0; long long dst0_bstride; int acc0;
     float* dst1; long long dst1_bstride; int acc1;
-    int split;            // GEMM_EPI_SPLIT row split; GEMM_EPI_GATE: unused
+    int split;            // GEMM_EPI_SPLIT row split; pair epilogues: unused
+    int pairC;            // pair epilogues: number of valid channels (rows c and pairC + c of the dense matrix)
+    int dst_ld, dst_pad;  // row stride / left pad of the destination tensors (usually == ld, pad)
+    float clip;           // GEMM_EPI_LOG clamp
 };
 
 // Row of the dense weight matrix held by block-local row r of M-block mb.
-// GEMM_EPI_GATE interleaves so that each wave-row (128 rows) owns 64 tanh channels and
+// Pair epilogues (GATE, MAG) interleave so that each wave-row (128 rows) owns 64 tanh channels and
 // the 64 matching sigmoid channels (dense rows c and C + c).
-__host__ __device__ inline int gemm_dense_row(int epi, int mb, int r, int C) {
-    if (epi == GEMM_EPI_GATE) {
+// Returns -1 for padding rows (their packed weights and bias are zero).
+__host__ __device__ inline int gemm_dense_row(int epi, int mb, int r, int C, int M) {
+    if (gemm_epi_is_pair(epi)) {
         const int wm = r >> 7, rr = r & 127;
         const int c = mb * 128 + wm * 64 + (rr & 63);
+        if (c >= C) return -1;
         return (rr < 64) ? c : C + c;
     }
-    return mb * GEMM_BM + r;
+    const int row = mb * GEMM_BM + r;
+    return row < M ? row : -1;
 }
 
 int launch_gemm_f32(int epi, const GemmArgs& a, hipStream_t stream);

@@ -172,11 +172,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
     lds[t] = a.bias[mb * GEMM_BM + t];
     __syncthreads();
     const float* bias = lds + wm * 128;
-    if constexpr (EPI == GEMM_EPI_GATE) {
+    if constexpr (EPI == GEMM_EPI_GATE || EPI == GEMM_EPI_MAG) {
         float* dst = a.dst0 + (size_t)b * a.dst0_bstride;
         const int cbase = mb * 128 + wm * 64;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
+            if (cbase + mt * 32 >= a.pairC) continue;             // uniform: whole tile is channel padding
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const int n = n0 + wn * 64 + nt * 32 + l31;
@@ -184,9 +185,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                        const float ut = acc[mt][nt][r] + bias[mt * 32 + row];
-                        const float us = acc[mt + 2][nt][r] + bias[64 + mt * 32 + row];
-                        dst[(size_t)(cbase + mt * 32 + row) * a.ld + a.pad + n] = fast_tanh(ut) * fast_sigmoid(us);
+                        const int c = cbase + mt * 32 + row;
+                        const float u0 = acc[mt][nt][r] + bias[mt * 32 + row];
+                        const float u1 = acc[mt + 2][nt][r] + bias[64 + mt * 32 + row];
+                        float v;
+                        if constexpr (EPI == GEMM_EPI_GATE) v = fast_tanh(u0) * fast_sigmoid(u1);
+                        else v = sqrtf(u0 * u0 + u1 * u1);
+                        if (c < a.pairC) dst[(size_t)c * a.dst_ld + a.dst_pad + n] = v;
                     }
                 }
             }
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                        old[nt][r] = dst[(size_t)(rdst + row) * a.ld + a.pad + n0 + wn * 64 + nt * 32 + l31];
+                        old[nt][r] = dst[(size_t)(rdst + row) * a.dst_ld + a.dst_pad + n0 + wn * 64 + nt * 32 + l31];
                     }
             } else {
 #pragma unroll
@@ -225,7 +230,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                        dst[(size_t)(rdst + row) * a.ld + a.pad + n] = acc[mt][nt][r] + bias[mt * 32 + row] + old[nt][r];
+                        float v = acc[mt][nt][r] + bias[mt * 32 + row] + old[nt][r];
+                        if constexpr (EPI == GEMM_EPI_LOG) v = logf(fmaxf(v, a.clip));
+                        if (rbase + row < a.M) dst[(size_t)(rdst + row) * a.dst_ld + a.dst_pad + n] = v;
                     }
                 }
             }
@@ -247,15 +254,21 @@ int launch_gemm_f32(int epi, const GemmArgs& a, hipStream_t stream) {
     CTTS_CHECK_ARG(nch == a.nch_total, "gemm: chunk count mismatch %d vs %d", nch, a.nch_total);
     CTTS_CHECK_ARG(a.ld % 4 == 0 && a.ntiles * GEMM_BN + 2 * a.pad <= a.ld && a.L <= a.ntiles * GEMM_BN,
                    "gemm: bad geometry ld=%d pad=%d L=%d ntiles=%d", a.ld, a.pad, a.L, a.ntiles);
-    CTTS_CHECK_ARG(epi == GEMM_EPI_GATE || a.split % 32 == 0, "gemm: split %d not a multiple of 32", a.split);
-    CTTS_CHECK_ARG(a.M % 32 == 0 && a.M > (a.MB - 1) * GEMM_BM && a.M <= a.MB * GEMM_BM, "gemm: M=%d MB=%d", a.M, a.MB);
+    CTTS_CHECK_ARG(gemm_epi_is_pair(epi) || a.split % 32 == 0, "gemm: split %d not a multiple of 32", a.split);
+    CTTS_CHECK_ARG(gemm_epi_is_pair(epi) ? (a.pairC > (a.MB - 1) * 128 && a.pairC <= a.MB * 128)
+                                         : (a.M > (a.MB - 1) * GEMM_BM && a.M <= a.MB * GEMM_BM),
+                   "gemm: M=%d pairC=%d MB=%d", a.M, a.pairC, a.MB);
+    CTTS_CHECK_ARG(a.dst_ld > 0, "gemm: dst_ld not set");
     const long long blocks = (long long)a.MB * a.ntiles * a.batch;
     CTTS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "gemm: grid %lld", blocks);
     dim3 grid((unsigned)blocks), block(256);
-    if (epi == GEMM_EPI_GATE)
-        hipLaunchKernelGGL(conv_gemm_f32_kernel<GEMM_EPI_GATE>, grid, block, 0, stream, a);
-    else
-        hipLaunchKernelGGL(conv_gemm_f32_kernel<GEMM_EPI_SPLIT>, grid, block, 0, stream, a);
+    switch (epi) {
+        case GEMM_EPI_GATE: hipLaunchKernelGGL(conv_gemm_f32_kernel<GEMM_EPI_GATE>, grid, block, 0, stream, a); break;
+        case GEMM_EPI_MAG: hipLaunchKernelGGL(conv_gemm_f32_kernel<GEMM_EPI_MAG>, grid, block, 0, stream, a); break;
+        case GEMM_EPI_LOG: hipLaunchKernelGGL(conv_gemm_f32_kernel<GEMM_EPI_LOG>, grid, block, 0, stream, a); break;
+        case GEMM_EPI_SPLIT: hipLaunchKernelGGL(conv_gemm_f32_kernel<GEMM_EPI_SPLIT>, grid, block, 0, stream, a); break;
+        default: set_error("gemm: unknown epilogue %d", epi); return CTTS_E_ARG;
+    }
     CTTS_CHECK_LAUNCH("conv_gemm_f32");
     return CTTS_OK;
 }

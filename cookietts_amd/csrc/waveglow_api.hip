@@ -161,6 +161,7 @@ struct ProfScope {
 GemmArgs base_args(const Geom& g, int batch) {
     GemmArgs a{};
     a.ld = g.ld; a.pad = g.pad; a.L = g.L; a.ntiles = g.ntiles; a.batch = batch;
+    a.dst_ld = g.ld; a.dst_pad = g.pad;
     return a;
 }
 
@@ -205,7 +206,7 @@ int run_wn_stack(const Plan& p, const Geom& g, const float* blob, int k, const f
             a.seg[2] = {x, cstride, ncx, dil, 0, (dil % 4 == 0) ? 1 : 0};
             a.seg[3] = {h_all + (size_t)k * p.H * g.ld, hstride, p.nch1h, 0, 0, 1};
             a.dst0 = act; a.dst0_bstride = cstride;
-            a.M = 2 * p.C;
+            a.M = 2 * p.C; a.pairC = p.C;
             ProfScope ps(CTTS_PROF_WN_IN, s);
             rc = launch_gemm_f32(GEMM_EPI_GATE, a, s);
             if (rc) return rc;

@@ -35,10 +35,10 @@ __global__ __launch_bounds__(256) void pack_a_kernel(float* __restrict__ dst, co
     const int mb = blockIdx.y;
     const int k = blockIdx.x;  // 0..ksrc-1
     const int r = threadIdx.x;
-    const int drow = gemm_dense_row(epi, mb, r, C);
+    const int drow = gemm_dense_row(epi, mb, r, C, M);
     const int kk = k_off + k;
     dst[((size_t)mb * nch_total + kk / GEMM_KC) * (GEMM_KC * GEMM_BM) + (kk % GEMM_KC) * GEMM_BM + r] =
-        drow < M ? src[(src_row_off + drow) * src_row_stride + (long long)k * src_k_stride] : 0.f;
+        drow >= 0 ? src[(src_row_off + drow) * src_row_stride + (long long)k * src_k_stride] : 0.f;
 }
 
 // dst[mb*256 + r] = src0[off0 + dense_row] (+ src1[off1 + dense_row])
@@ -46,9 +46,9 @@ __global__ __launch_bounds__(256) void pack_bias_kernel(float* __restrict__ dst,
                                                         long long off0, const float* __restrict__ src1,
                                                         long long off1, int epi, int C, int M) {
     const int mb = blockIdx.x, r = threadIdx.x;
-    const int row = gemm_dense_row(epi, mb, r, C);
+    const int row = gemm_dense_row(epi, mb, r, C, M);
     float v = 0.f;
-    if (row < M) {
+    if (row >= 0 && src0) {
         v = src0[off0 + row];
         if (src1) v += src1[off1 + row];
     }

@@ -141,6 +141,31 @@ int ctts_flow_tail_f32(const ctts_waveglow_config* cfg, const void* packed, int3
                        const float* out, float* audio, float* wave, int32_t batch,
                        int32_t frames, void* stream);
 
+/* ---- STFT / mel frontend (utils/audio/stft.py) ------------------------------------------- */
+
+/* STFT.__init__ (stft.py:46-77) / TacotronSTFT.__init__ (:155-166) arguments that shape the path. */
+typedef struct ctts_stft_config {
+    int32_t filter_length;   /* 1024 (multiple of 16) */
+    int32_t hop_length;      /* 256 */
+    int32_t win_length;      /* 1024 (informational: the window is already folded into the basis) */
+    int32_t n_mel_channels;  /* 80; 0 = magnitude only */
+    float clamp_val;         /* 1e-5: dynamic_range_compression clip (audio_processing.py:78-84) */
+} ctts_stft_config;
+
+size_t ctts_stft_packed_bytes(const ctts_stft_config* cfg);
+/* forward_basis [2*(N/2+1)][N] = the module buffer of stft.py:60-76 ([Re;Im] DFT rows x window),
+ * mel_basis [n_mel][N/2+1] = the buffer of stft.py:163-166 (may be NULL when n_mel_channels == 0). */
+int ctts_stft_pack(const ctts_stft_config* cfg, const float* forward_basis, const float* mel_basis,
+                   void* packed, void* stream);
+size_t ctts_stft_workspace_bytes(const ctts_stft_config* cfg, int32_t batch, int32_t samples);
+/* STFT.transform_jit magnitude (stft.py:79-111) and TacotronSTFT.mel_spectrogram (:180-207):
+ *   y   [B][T] fp32 in [-1, 1];   frames = T / hop + 1
+ *   mag [B][N/2+1][frames]  (may be NULL)      mel [B][n_mel][frames] = log(max(mel_basis @ mag, clamp))
+ * workspace zero-filled once before first use (as for WaveGlow). */
+int ctts_stft_mel_f32(const ctts_stft_config* cfg, const void* packed, const float* y, float* mag,
+                      float* mel, int32_t batch, int32_t samples, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 /* ---- in-library kernel timing (bench.py roofline leg) --------------------------------- */
 /* When enabled, ctts_waveglow_infer_f32 brackets every launch of the dominant kernel
  * (WN in-layer GEMM: dilated conv + cond + gate) with hipEvents on `stream`. */

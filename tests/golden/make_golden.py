@@ -112,7 +112,58 @@ def make_waveglow():
               f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def _stub_audio_deps():
+    """librosa / iso226 are not installed: minimal stand-ins so the reference's stft.py imports.
+    `mel` is the Slaney restatement from the oracle (PARITY UNPINNED there, see its header)."""
+    import types
+    from oracle import stft_oracle as so
+    librosa = types.ModuleType("librosa")
+    util = types.ModuleType("librosa.util")
+    filters = types.ModuleType("librosa.filters")
+
+    def pad_center(data, size, axis=-1, **kw):
+        return so.pad_center(np.asarray(data), size)
+
+    def tiny(x):
+        return np.finfo(np.asarray(x).dtype if np.issubdtype(np.asarray(x).dtype, np.floating) else np.float32).tiny
+
+    def normalize(x, norm=None, **kw):
+        assert norm is None
+        return x
+    util.pad_center, util.tiny, util.normalize = pad_center, tiny, normalize
+    filters.mel = lambda sr, n_fft, n_mels=128, fmin=0.0, fmax=None: so.slaney_mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+    librosa.util, librosa.filters = util, filters
+    sys.modules.update({"librosa": librosa, "librosa.util": util, "librosa.filters": filters})
+
+
+def make_stft():
+    _stub_audio_deps()
+    from CookieTTS.utils.audio.stft import STFT, TacotronSTFT
+    rng = np.random.default_rng(77)
+    B, T = 2, 22050
+    t = np.arange(T) / 22050.0
+    y = np.stack([0.4 * np.sin(2 * np.pi * 220 * t) + 0.2 * np.sin(2 * np.pi * 3300 * t + 1.0),
+                  0.5 * np.sin(2 * np.pi * (100 + 2000 * t) * t)]).astype(np.float32)
+    y += 0.05 * rng.standard_normal((B, T)).astype(np.float32)
+    y = np.clip(y, -1.0, 1.0)
+    taco = TacotronSTFT()                                    # defaults: 1024/256/1024, 80 mel, 22050 Hz, 0-8000 Hz
+    with torch.no_grad():
+        mel = taco.mel_spectrogram(torch.from_numpy(y)).numpy()
+        mag, _ = taco.stft_fn.transform(torch.from_numpy(y), return_phase=False)
+        small = STFT(filter_length=800, hop_length=200, win_length=800)     # the class defaults (stft.py:48)
+        y2 = y[:, :5000]
+        mag2, _ = small.transform(torch.from_numpy(y2), return_phase=False)
+    path = os.path.join(HERE, "stft_mel.npz")
+    np.savez_compressed(path, y=y, mel=mel.astype(np.float32), mag_rows=mag.numpy()[:, ::32, :].astype(np.float32),
+                        mag_sum=np.float64(mag.double().sum().item()),
+                        mel_basis_rowsum=taco.mel_basis.numpy().sum(axis=1).astype(np.float32),
+                        mag800=mag2.numpy().astype(np.float32))
+    print(f"[golden] stft_mel: mel {mel.shape} mag {tuple(mag.shape)} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["waveglow"]
+    which = sys.argv[1:] or ["waveglow", "stft"]
     if "waveglow" in which:
         make_waveglow()
+    if "stft" in which:
+        make_stft()
