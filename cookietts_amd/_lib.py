@@ -45,6 +45,18 @@ class WaveGlowFlowWeights(C.Structure):
     ]
 
 
+class WaveFlowConfig(C.Structure):
+    """``ctts_waveflow_config``."""
+    _fields_ = [(n, C.c_int32) for n in ("n_mel_channels", "n_flows", "n_group", "n_layers", "n_channels",
+                                         "kernel_size_w", "kernel_size_h", "dilation_h")]
+
+
+class WaveFlowFlowWeights(C.Structure):
+    _fields_ = [("start_w", _FP), ("start_b", _FP), ("cond_w", _FP), ("cond_b", _FP),
+                ("in_w", C.POINTER(_FP)), ("in_b", C.POINTER(_FP)), ("rs_w", C.POINTER(_FP)), ("rs_b", C.POINTER(_FP)),
+                ("end_w", _FP), ("end_b", _FP)]
+
+
 # name -> (restype, argtypes); kept in one table so tests can check every symbol the
 # header declares is exported.
 _CFG = C.POINTER(WaveGlowConfig)
@@ -62,6 +74,11 @@ SIGNATURES = {
     "ctts_wn_cond_f32": (C.c_int, [_CFG, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP]),
     "ctts_wn_stack_f32": (C.c_int, [_CFG, _FP, C.c_int32, _FP, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP]),
     "ctts_flow_tail_f32": (C.c_int, [_CFG, _FP, C.c_int32, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP]),
+    "ctts_waveflow_packed_bytes": (C.c_size_t, [C.POINTER(WaveFlowConfig)]),
+    "ctts_waveflow_pack_flow": (C.c_int, [C.POINTER(WaveFlowConfig), C.c_int32, C.POINTER(WaveFlowFlowWeights), _FP, _FP]),
+    "ctts_waveflow_workspace_bytes": (C.c_size_t, [C.POINTER(WaveFlowConfig), C.c_int32, C.c_int32]),
+    "ctts_waveflow_inverse_f32": (C.c_int, [C.POINTER(WaveFlowConfig), _FP, _FP, _FP, _FP, C.c_int32, C.c_int32,
+                                            C.c_int32, _FP, C.c_size_t, _FP]),
     "ctts_stft_packed_bytes": (C.c_size_t, [C.POINTER(StftConfig)]),
     "ctts_stft_pack": (C.c_int, [C.POINTER(StftConfig), _FP, _FP, _FP, _FP]),
     "ctts_stft_workspace_bytes": (C.c_size_t, [C.POINTER(StftConfig), C.c_int32, C.c_int32]),

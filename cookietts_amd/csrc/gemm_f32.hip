@@ -1,14 +1,16 @@
 // fp32 MFMA conv-GEMM for gfx950 (see gemm_f32.h for the contract).
 //
 // Tiling (CDNA4-first, 64-wide waves):
-//   workgroup = 256 threads = 4 waves as 2 (M) x 2 (N); block tile 256 x 128, K chunk 16.
-//   wave tile 128 x 64 = 4 x 2 tiles of v_mfma_f32_32x32x2_f32 -> 128 accumulator VGPRs,
-//   2 waves per SIMD (2 workgroups per CU) so one wave's LDS/global/barrier time is covered
-//   by the other wave's MFMAs; the f32 MFMA pipe (64 cycles per 32x32x2) is the bound.
-//   LDS: 2 stages x (A 16x256 + B 16x128) fp32 = 48 KiB; both operands k-major so a
-//   fragment is one conflict-free ds_read_b32 per lane (lane l: row/col l&31, k = l>>5).
+//   workgroup = 256 threads = 4 waves; wave tile 128 x 64 = 4 x 2 tiles of
+//   v_mfma_f32_32x32x2_f32 -> 128 accumulator VGPRs, ~200 VGPRs total, 2 waves per SIMD
+//   (2 workgroups per CU) so one wave's LDS/global/barrier time is covered by the other
+//   wave's MFMAs; the f32 MFMA pipe (64 cycles per 32x32x2) is the bound.
+//   Block tile 256 x 128 (waves 2x2) or 128 x 256 (waves 1x4); K chunk 16.
+//   LDS: 2 stages x 24 KiB, both operands k-major so a fragment is one conflict-free
+//   ds_read2_b32 per lane pair of tiles (lane l: row/col l&31, k = l>>5).
 //   Global->LDS staging goes through registers and is issued one chunk ahead of the MFMAs
-//   (the f32 MFMA rate leaves >10x headroom on the load path).
+//   (the f32 MFMA rate leaves >10x headroom on the load path); the LDS->MFMA software
+//   pipeline is pinned with sched_group_barrier.
 #include "gemm_f32.h"
 
 namespace ctts {
@@ -17,16 +19,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int A_STAGE = GEMM_KC * GEMM_BM;              // 4096 floats
-constexpr int B_STAGE = GEMM_KC * GEMM_BN;              // 2048 floats
-constexpr int STAGE = A_STAGE + B_STAGE;                // 6144 floats = 24 KiB
-
-__device__ __forceinline__ float4 load4(const float* p, int aligned) {
-    if (aligned) return *reinterpret_cast<const float4*>(p);
-    float4 v;
-    v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3];
-    return v;
-}
+constexpr int STAGE = GEMM_KC * (256 + 128);            // 6144 floats = 24 KiB for both shapes
+constexpr int SEGTAB = 2 * STAGE;                       // segment table: GEMM_MAX_SEG x 4 dwords
+constexpr int LDS_FLOATS = SEGTAB + GEMM_MAX_SEG * 4;
 
 // Gate math on the hardware transcendental unit: exp via v_exp_f32 (2^x), reciprocal via
 // v_rcp_f32 (1 ulp).  Absolute error of tanh/sigmoid <= ~3e-7, far inside the parity budget.
@@ -38,14 +33,28 @@ __device__ __forceinline__ float fast_tanh(float u) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * 2.8853900817779268f));
 }
 
-template <int EPI>
+// 16 bytes from a 4-byte-aligned address (dilation 1 and 2 taps): the backend emits one
+// global_load_dwordx4, which gfx950 serves unaligned.
+__device__ __forceinline__ float4 load4u(const float* p) {
+    float4 v;
+    v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3];
+    return v;
+}
+
+template <int EPI, int WM>
 __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    constexpr int BM = 128 * WM;
+    constexpr int WN = 4 / WM;
+    constexpr int BN = 64 * WN;
+    constexpr int A_STAGE = GEMM_KC * BM;
+    constexpr int NA = BM / 64;                          // float4 loads per thread per A stage
+    constexpr int NB = BN / 64;                          // float4 loads per thread per B stage
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lhi = lane >> 5;
 
     // block -> (m-block, n-tile, batch).  Dispatch places block id on XCD id % 8, so with
@@ -55,13 +64,35 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
     id /= a.MB;
     const int tile = id % a.ntiles;
     const int b = id / a.ntiles;
-    const int n0 = tile * GEMM_BN;
+    const int n0 = tile * BN;
 
-    const float* Ablk = a.A + (size_t)mb * a.nch_total * A_STAGE;
+    // segment table -> LDS (a dynamically indexed kernarg struct would be copied to scratch)
+#pragma unroll
+    for (int sidx = 0; sidx < GEMM_MAX_SEG; ++sidx) {      // static kernarg indices only
+        if (t == sidx) {
+            const GemmSeg& g = a.seg[sidx];
+            unsigned int* e = reinterpret_cast<unsigned int*>(lds + SEGTAB + sidx * 4);
+            if (sidx < a.nseg) {
+                const float* base = g.base + (size_t)b * g.bstride + (size_t)(mb * g.mb_rows) * a.ld +
+                                    (a.pad + n0 + g.shift);
+                const unsigned long long u = reinterpret_cast<unsigned long long>(base);
+                e[0] = (unsigned int)u;
+                e[1] = (unsigned int)(u >> 32);
+                e[2] = (unsigned int)g.nch;
+            } else {
+                e[0] = 0; e[1] = 0; e[2] = 0x7fffffffu;
+            }
+            e[3] = 0;
+        }
+    }
 
-    // staging assignments
+    const int nalloc = a.a_nch_alloc ? a.a_nch_alloc : a.nch_total;
+    const float* ap = a.A + ((size_t)mb * nalloc + a.a_ch_off) * A_STAGE + t * 4;
+
     const int brow = t >> 4;            // 0..15  (k row of the B chunk)
-    const int bcol = (t & 15) * 4;      // 0..60  (+64 for the second load)
+    const int bcol = (t & 15) * 4;      // 0..60  (+64 j)
+    const size_t thread_off = (size_t)brow * a.ld + bcol;
+    const size_t chunk_rows = (size_t)GEMM_KC * a.ld;
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -71,65 +102,48 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    // Segment table -> scalar registers (static indices only: a dynamically indexed kernarg
-    // struct would be copied to scratch).
-    const float* sbase[GEMM_MAX_SEG];
-    int snch[GEMM_MAX_SEG], salign[GEMM_MAX_SEG];
-#pragma unroll
-    for (int s = 0; s < GEMM_MAX_SEG; ++s) {
-        const GemmSeg& g = a.seg[s];
-        // everything except the k-row of the chunk folded into one per-thread base pointer
-        sbase[s] = g.base + (size_t)b * g.bstride + (size_t)(mb * g.mb_rows + brow) * a.ld +
-                   (a.pad + n0 + g.shift + bcol);
-        snch[s] = s < a.nseg ? g.nch : 0x7fffffff;
-        salign[s] = g.aligned;
-    }
-    const size_t chunk_rows = (size_t)GEMM_KC * a.ld;
-
-    float4 ra0, ra1, ra2, ra3, rb0, rb1;
+    // named registers (arrays indexed inside the pipelined loop end up in scratch)
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
     int seg = 0, local = 0;
-    const float* ap = Ablk + t * 4;
+    __syncthreads();                    // segment table visible
 
 #define CTTS_ISSUE_LOADS()                                                                      \
     do {                                                                                        \
         ra0 = *reinterpret_cast<const float4*>(ap);                                             \
         ra1 = *reinterpret_cast<const float4*>(ap + 1024);                                      \
-        ra2 = *reinterpret_cast<const float4*>(ap + 2048);                                      \
-        ra3 = *reinterpret_cast<const float4*>(ap + 3072);                                      \
+        if constexpr (NA > 2) {                                                                 \
+            ra2 = *reinterpret_cast<const float4*>(ap + 2048);                                  \
+            ra3 = *reinterpret_cast<const float4*>(ap + 3072);                                  \
+        }                                                                                       \
         ap += A_STAGE;                                                                          \
-        const float* sb = seg == 0 ? sbase[0] : seg == 1 ? sbase[1] : seg == 2 ? sbase[2] : sbase[3]; \
-        const int sn = seg == 0 ? snch[0] : seg == 1 ? snch[1] : seg == 2 ? snch[2] : snch[3];  \
-        const int sa = seg == 0 ? salign[0] : seg == 1 ? salign[1] : seg == 2 ? salign[2] : salign[3]; \
-        const float* bp = sb + (size_t)local * chunk_rows;                                      \
-        rb0 = load4(bp, sa);                                                                    \
-        rb1 = load4(bp + 64, sa);                                                               \
-        if (++local == sn) { local = 0; ++seg; }                                                \
+        const uint4 e = *reinterpret_cast<const uint4*>(lds + SEGTAB + seg * 4);                \
+        const float* bp = reinterpret_cast<const float*>(((unsigned long long)e.y << 32) | e.x) + \
+                          (size_t)local * chunk_rows + thread_off;                              \
+        rb0 = load4u(bp);                                                                       \
+        rb1 = load4u(bp + 64);                                                                  \
+        if constexpr (NB > 2) {                                                                 \
+            rb2 = load4u(bp + 128);                                                             \
+            rb3 = load4u(bp + 192);                                                             \
+        }                                                                                       \
+        if (++local == (int)e.z) { local = 0; ++seg; }                                          \
     } while (0)
 
 #define CTTS_STORE_LDS(buf)                                                                     \
     do {                                                                                        \
         float* As_ = lds + (buf) * STAGE + t * 4;                                               \
-        float* Bs_ = lds + (buf) * STAGE + A_STAGE + brow * GEMM_BN + bcol;                     \
+        float* Bs_ = lds + (buf) * STAGE + A_STAGE + brow * BN + bcol;                          \
         *reinterpret_cast<float4*>(As_) = ra0;                                                  \
         *reinterpret_cast<float4*>(As_ + 1024) = ra1;                                           \
-        *reinterpret_cast<float4*>(As_ + 2048) = ra2;                                           \
-        *reinterpret_cast<float4*>(As_ + 3072) = ra3;                                           \
+        if constexpr (NA > 2) {                                                                 \
+            *reinterpret_cast<float4*>(As_ + 2048) = ra2;                                       \
+            *reinterpret_cast<float4*>(As_ + 3072) = ra3;                                       \
+        }                                                                                       \
         *reinterpret_cast<float4*>(Bs_) = rb0;                                                  \
         *reinterpret_cast<float4*>(Bs_ + 64) = rb1;                                             \
-    } while (0)
-
-#define CTTS_LOAD_FRAG(AV, BV, ks)                                                              \
-    do {                                                                                        \
-        const int krow_ = 2 * (ks) + lhi;                                                       \
-        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) AV[mt] = As[krow_ * GEMM_BM + mt * 32]; \
-        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) BV[nt] = Bs[krow_ * GEMM_BN + nt * 32]; \
-    } while (0)
-
-#define CTTS_MFMA(AV, BV)                                                                       \
-    do {                                                                                        \
-        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                        \
-            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                    \
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[mt], BV[nt], acc[mt][nt], 0, 0, 0); \
+        if constexpr (NB > 2) {                                                                 \
+            *reinterpret_cast<float4*>(Bs_ + 128) = rb2;                                        \
+            *reinterpret_cast<float4*>(Bs_ + 192) = rb3;                                        \
+        }                                                                                       \
     } while (0)
 
     CTTS_ISSUE_LOADS();
@@ -148,9 +162,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
         // ds_read to just before its first use and exposes the LDS latency 16x per chunk).
         float av[GEMM_KC / 2][4], bv[GEMM_KC / 2][2];
 #pragma unroll
-        for (int ks = 0; ks < GEMM_KC / 2; ++ks) CTTS_LOAD_FRAG(av[ks], bv[ks], ks);
+        for (int ks = 0; ks < GEMM_KC / 2; ++ks) {
+            const int krow = 2 * ks + lhi;
 #pragma unroll
-        for (int ks = 0; ks < GEMM_KC / 2; ++ks) CTTS_MFMA(av[ks], bv[ks]);
+            for (int mt = 0; mt < 4; ++mt) av[ks][mt] = As[krow * BM + mt * 32];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) bv[ks][nt] = Bs[krow * BN + nt * 32];
+        }
+#pragma unroll
+        for (int ks = 0; ks < GEMM_KC / 2; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks][mt], bv[ks][nt], acc[mt][nt], 0, 0, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);      // 3 x ds_read2_b32: fragments of k-step 0
 #pragma unroll
         for (int ks = 0; ks < GEMM_KC / 2 - 1; ++ks) {
@@ -163,18 +188,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
     }
 #undef CTTS_ISSUE_LOADS
 #undef CTTS_STORE_LDS
-#undef CTTS_LOAD_FRAG
-#undef CTTS_MFMA
 
     // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     // bias via LDS: a global bias load between the stores would force vmcnt(0) (which on gfx9
     // also drains the stores) once per element.
-    lds[t] = a.bias[mb * GEMM_BM + t];
+    if (t < BM) lds[t] = a.bias[mb * BM + t];
     __syncthreads();
     const float* bias = lds + wm * 128;
     if constexpr (EPI == GEMM_EPI_GATE || EPI == GEMM_EPI_MAG) {
         float* dst = a.dst0 + (size_t)b * a.dst0_bstride;
-        const int cbase = mb * 128 + wm * 64;
+        const int cbase = (mb * WM + wm) * 64;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             if (cbase + mt * 32 >= a.pairC) continue;             // uniform: whole tile is channel padding
@@ -199,10 +222,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
     } else {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const int rbase = mb * GEMM_BM + wm * 128 + mt * 32;   // uniform per tile
+            const int rbase = mb * BM + wm * 128 + mt * 32;          // uniform per tile
             if (rbase >= a.M) continue;                              // zero-padded rows of a ragged M
             const bool second = rbase >= a.split;                    // split is a multiple of 32
             float* dst = second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride;
+            const float* src = second ? dst : (a.src0 ? a.src0 + (size_t)b * a.src0_bstride : dst);
             const int accum = second ? a.acc1 : a.acc0;
             const int rdst = second ? rbase - a.split : rbase;
             // read-modify-write: issue all 32 loads of this row-tile before the first store so
@@ -215,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                        old[nt][r] = dst[(size_t)(rdst + row) * a.dst_ld + a.dst_pad + n0 + wn * 64 + nt * 32 + l31];
+                        old[nt][r] = src[(size_t)(rdst + row) * a.dst_ld + a.dst_pad + n0 + wn * 64 + nt * 32 + l31];
                     }
             } else {
 #pragma unroll
@@ -240,33 +264,45 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
     }
 }
 
+template <int EPI>
+void launch_shape(int bm, dim3 grid, hipStream_t stream, const GemmArgs& a) {
+    if (bm == 128) hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 1>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 2>), grid, dim3(256), 0, stream, a);
+}
+
 }  // namespace
 
-int launch_gemm_f32(int epi, const GemmArgs& a, hipStream_t stream) {
+int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
+    GemmArgs a = a_in;
+    if (a.bm == 0) a.bm = 256;
+    CTTS_CHECK_ARG(a.bm == 256 || a.bm == 128, "gemm: bm=%d", a.bm);
+    const int bn = gemm_bn(a.bm);
     CTTS_CHECK_ARG(a.nseg >= 1 && a.nseg <= GEMM_MAX_SEG, "gemm: nseg=%d", a.nseg);
     int nch = 0;
     for (int s = 0; s < a.nseg; ++s) {
-        CTTS_CHECK_ARG(a.seg[s].nch > 0, "gemm: empty segment %d", s);
+        CTTS_CHECK_ARG(a.seg[s].nch > 0 && a.seg[s].base, "gemm: empty segment %d", s);
         CTTS_CHECK_ARG(a.seg[s].shift >= -a.pad && a.seg[s].shift <= a.pad,
                        "gemm: shift %d exceeds halo %d", a.seg[s].shift, a.pad);
         nch += a.seg[s].nch;
     }
     CTTS_CHECK_ARG(nch == a.nch_total, "gemm: chunk count mismatch %d vs %d", nch, a.nch_total);
-    CTTS_CHECK_ARG(a.ld % 4 == 0 && a.ntiles * GEMM_BN + 2 * a.pad <= a.ld && a.L <= a.ntiles * GEMM_BN,
-                   "gemm: bad geometry ld=%d pad=%d L=%d ntiles=%d", a.ld, a.pad, a.L, a.ntiles);
+    CTTS_CHECK_ARG(a.a_nch_alloc == 0 || a.a_ch_off + a.nch_total <= a.a_nch_alloc, "gemm: A chunk window");
+    CTTS_CHECK_ARG(a.ld % 4 == 0 && a.ntiles * bn + 2 * a.pad <= a.ld && a.L <= a.ntiles * bn,
+                   "gemm: bad geometry ld=%d pad=%d L=%d ntiles=%d bn=%d", a.ld, a.pad, a.L, a.ntiles, bn);
     CTTS_CHECK_ARG(gemm_epi_is_pair(epi) || a.split % 32 == 0, "gemm: split %d not a multiple of 32", a.split);
-    CTTS_CHECK_ARG(gemm_epi_is_pair(epi) ? (a.pairC > (a.MB - 1) * 128 && a.pairC <= a.MB * 128)
-                                         : (a.M > (a.MB - 1) * GEMM_BM && a.M <= a.MB * GEMM_BM),
-                   "gemm: M=%d pairC=%d MB=%d", a.M, a.pairC, a.MB);
-    CTTS_CHECK_ARG(a.dst_ld > 0, "gemm: dst_ld not set");
+    const int cpb = a.bm / 2;   // pair channels per M-block
+    CTTS_CHECK_ARG(gemm_epi_is_pair(epi) ? (a.pairC > (a.MB - 1) * cpb && a.pairC <= a.MB * cpb)
+                                         : (a.M > (a.MB - 1) * a.bm && a.M <= a.MB * a.bm),
+                   "gemm: M=%d pairC=%d MB=%d bm=%d", a.M, a.pairC, a.MB, a.bm);
+    CTTS_CHECK_ARG(a.dst_ld > 0 && a.dst0, "gemm: destination not set");
     const long long blocks = (long long)a.MB * a.ntiles * a.batch;
     CTTS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "gemm: grid %lld", blocks);
-    dim3 grid((unsigned)blocks), block(256);
+    dim3 grid((unsigned)blocks);
     switch (epi) {
-        case GEMM_EPI_GATE: hipLaunchKernelGGL(conv_gemm_f32_kernel<GEMM_EPI_GATE>, grid, block, 0, stream, a); break;
-        case GEMM_EPI_MAG: hipLaunchKernelGGL(conv_gemm_f32_kernel<GEMM_EPI_MAG>, grid, block, 0, stream, a); break;
-        case GEMM_EPI_LOG: hipLaunchKernelGGL(conv_gemm_f32_kernel<GEMM_EPI_LOG>, grid, block, 0, stream, a); break;
-        case GEMM_EPI_SPLIT: hipLaunchKernelGGL(conv_gemm_f32_kernel<GEMM_EPI_SPLIT>, grid, block, 0, stream, a); break;
+        case GEMM_EPI_GATE: launch_shape<GEMM_EPI_GATE>(a.bm, grid, stream, a); break;
+        case GEMM_EPI_MAG: launch_shape<GEMM_EPI_MAG>(a.bm, grid, stream, a); break;
+        case GEMM_EPI_LOG: launch_shape<GEMM_EPI_LOG>(a.bm, grid, stream, a); break;
+        case GEMM_EPI_SPLIT: launch_shape<GEMM_EPI_SPLIT>(a.bm, grid, stream, a); break;
         default: set_error("gemm: unknown epilogue %d", epi); return CTTS_E_ARG;
     }
     CTTS_CHECK_LAUNCH("conv_gemm_f32");

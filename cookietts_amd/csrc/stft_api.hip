@@ -97,11 +97,11 @@ int ctts_stft_pack(const ctts_stft_config* cfg, const float* forward_basis, cons
     hipStream_t s = as_stream(stream);
     float* blob = static_cast<float*>(packed);
     CTTS_CHECK_HIP(hipMemsetAsync(blob, 0, p.total * sizeof(float), s));
-    rc = launch_pack_a(blob + p.basis_A, forward_basis, p.mb_mag, p.N / GEMM_KC, 0, p.N, GEMM_EPI_MAG, p.cutoff,
+    rc = launch_pack_a(blob + p.basis_A, forward_basis, GEMM_BM, p.mb_mag, p.N / GEMM_KC, 0, p.N, GEMM_EPI_MAG, p.cutoff,
                        2 * p.cutoff, 0, p.N, 1, s);
     if (rc) return rc;
     if (p.c.n_mel_channels > 0)
-        rc = launch_pack_a(blob + p.mel_A, mel_basis, p.mb_mel, p.kmel / GEMM_KC, 0, p.cutoff, GEMM_EPI_LOG, 0,
+        rc = launch_pack_a(blob + p.mel_A, mel_basis, GEMM_BM, p.mb_mel, p.kmel / GEMM_KC, 0, p.cutoff, GEMM_EPI_LOG, 0,
                            p.c.n_mel_channels, 0, p.cutoff, 1, s);
     return rc;
 }
@@ -136,7 +136,7 @@ int ctts_stft_mel_f32(const ctts_stft_config* cfg, const void* packed, const flo
     a.ld = g.ld; a.pad = 0; a.L = g.frames; a.ntiles = g.ntiles; a.batch = batch;
     a.A = blob + p.basis_A; a.bias = blob + p.zero_bias;
     a.nseg = 1; a.nch_total = p.N / GEMM_KC; a.MB = p.mb_mag;
-    a.seg[0] = {xf, (long long)p.N * g.ld, p.N / GEMM_KC, 0, 0, 1};
+    a.seg[0] = {xf, (long long)p.N * g.ld, p.N / GEMM_KC, 0, 0, 0};
     a.M = 2 * p.cutoff; a.pairC = p.cutoff;
     a.dst0 = wmag; a.dst0_bstride = (long long)p.kmel * g.ld; a.dst_ld = g.ld; a.dst_pad = 0;
     rc = launch_gemm_f32(GEMM_EPI_MAG, a, s);
@@ -152,7 +152,7 @@ int ctts_stft_mel_f32(const ctts_stft_config* cfg, const void* packed, const flo
         m.ld = g.ld; m.pad = 0; m.L = g.frames; m.ntiles = g.ntiles; m.batch = batch;
         m.A = blob + p.mel_A; m.bias = blob + p.zero_bias;
         m.nseg = 1; m.nch_total = p.kmel / GEMM_KC; m.MB = p.mb_mel;
-        m.seg[0] = {wmag, (long long)p.kmel * g.ld, p.kmel / GEMM_KC, 0, 0, 1};
+        m.seg[0] = {wmag, (long long)p.kmel * g.ld, p.kmel / GEMM_KC, 0, 0, 0};
         m.M = p.c.n_mel_channels; m.split = p.mb_mel * GEMM_BM;
         m.dst0 = mel; m.dst0_bstride = (long long)p.c.n_mel_channels * g.frames; m.acc0 = 0;
         m.dst1 = mel; m.dst1_bstride = m.dst0_bstride; m.acc1 = 0;

@@ -1,0 +1,376 @@
+// WaveFlow (ax core, waveflow=True) on the fp32 MFMA conv-GEMM.
+//
+// The height axis (n_group rows) is autoregressive (efficient_modules.py:42-65): row r+1 of a flow
+// needs the WN_2d output for row r, so a flow is n_group-1 sequential row passes, each n_layers x
+// {in-layer GEMM + gate, res/skip GEMM}.  The (k_h, k_w) Conv2d with dilation (d_h, 2^i) and no
+// height padding (glow_ax.py:518-523) is a GEMM whose K axis is [height tap][width tap][channel]:
+// height taps read earlier rows' layer inputs from a ring of k_h slots per layer (the reference's
+// audio_queues, glow_ax.py:597-602), width taps are column shifts in the padded layout.  Rows
+// 0..k_h-2 simply skip the leading (all-zero) height taps via the A-chunk window - no queue
+// zero-fill.  Conditioning: interp(Wc*mel + bc) == Wc*interp(mel) + bc (linear interpolation
+// commutes with the 1x1 conv), so mel is interpolated ONCE to L steps and the cond layer becomes
+// extra K of every in-layer GEMM (the [B, 2*C*n_layers, L] tensor is never materialised).
+// PermuteHeight (efficient_modules.py:360-403) is folded into a logical->physical row map.
+#include <vector>
+
+#include "gemm_f32.h"
+#include "waveglow_kernels.h"
+
+namespace ctts {
+namespace {
+
+constexpr size_t ALIGN_F = 64;
+inline size_t align_up(size_t v) { return (v + ALIGN_F - 1) / ALIGN_F * ALIGN_F; }
+constexpr int WF_BM = 128;
+
+struct WfPlan {
+    ctts_waveflow_config c;
+    int C, kmel, nch_in, nch_c;      // nch_c = chunks per (tap) segment
+    struct Flow { size_t start_w, start_b, end_w, end_b; std::vector<size_t> in_A, in_b, rs_A, rs_b; };
+    std::vector<Flow> fl;
+    size_t total;
+    int rs_rows(int i) const { return i < c.n_layers - 1 ? 2 * C : C; }
+    int rs_mb(int i) const { return (rs_rows(i) + WF_BM - 1) / WF_BM; }
+    int in_mb() const { return (C + 63) / 64; }
+};
+
+int make_wf_plan(const ctts_waveflow_config* cfg, WfPlan& p) {
+    CTTS_CHECK_ARG(cfg != nullptr, "waveflow config is NULL");
+    p.c = *cfg;
+    const auto& c = p.c;
+    CTTS_CHECK_ARG(c.n_flows >= 1 && c.n_layers >= 1 && c.n_layers <= 12, "n_flows=%d n_layers=%d", c.n_flows, c.n_layers);
+    CTTS_CHECK_ARG(c.n_group >= 2 && c.n_group <= 64, "n_group=%d", c.n_group);
+    CTTS_CHECK_ARG(c.n_channels >= 64 && c.n_channels % 64 == 0, "n_channels=%d (multiple of 64)", c.n_channels);
+    CTTS_CHECK_ARG(c.kernel_size_w % 2 == 1 && c.kernel_size_w >= 1 && c.kernel_size_h >= 1, "kernel %dx%d",
+                   c.kernel_size_h, c.kernel_size_w);
+    CTTS_CHECK_ARG(c.dilation_h == 1, "dilation_h=%d (only 1 built)", c.dilation_h);
+    CTTS_CHECK_ARG(c.kernel_size_h * c.kernel_size_w + 1 <= GEMM_MAX_SEG, "kernel %dx%d needs more than %d segments",
+                   c.kernel_size_h, c.kernel_size_w, GEMM_MAX_SEG);
+    CTTS_CHECK_ARG(c.n_mel_channels >= 1, "n_mel_channels=%d", c.n_mel_channels);
+    p.C = c.n_channels;
+    p.kmel = round_up(c.n_mel_channels, GEMM_KC);
+    p.nch_c = p.C / GEMM_KC;
+    p.nch_in = c.kernel_size_h * c.kernel_size_w * p.nch_c + p.kmel / GEMM_KC;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o = align_up(o + n); return r; };
+    p.fl.resize(c.n_flows);
+    for (int k = 0; k < c.n_flows; ++k) {
+        auto& f = p.fl[k];
+        f.start_w = take(p.C); f.start_b = take(p.C);
+        f.end_w = take(2 * p.C); f.end_b = take(2);
+        for (int i = 0; i < c.n_layers; ++i) {
+            f.in_A.push_back(take((size_t)p.in_mb() * p.nch_in * GEMM_KC * WF_BM));
+            f.in_b.push_back(take((size_t)p.in_mb() * WF_BM));
+            f.rs_A.push_back(take((size_t)p.rs_mb(i) * p.nch_c * GEMM_KC * WF_BM));
+            f.rs_b.push_back(take((size_t)p.rs_mb(i) * WF_BM));
+        }
+    }
+    p.total = o;
+    return CTTS_OK;
+}
+
+struct WfGeom { int L, ld, pad, ntiles; };
+
+int make_wf_geom(const WfPlan& p, int samples, WfGeom& g) {
+    CTTS_CHECK_ARG(samples >= p.c.n_group && samples % p.c.n_group == 0, "samples=%d not a multiple of n_group=%d",
+                   samples, p.c.n_group);
+    g.L = samples / p.c.n_group;
+    CTTS_CHECK_ARG(g.L % 4 == 0, "samples/n_group=%d must be a multiple of 4", g.L);
+    const int maxshift = (p.c.kernel_size_w / 2) << (p.c.n_layers - 1);
+    g.pad = round_up(maxshift > 128 ? maxshift : 128, 32);
+    const int bn = gemm_bn(WF_BM);
+    g.ntiles = (g.L + bn - 1) / bn;
+    g.ld = g.ntiles * bn + 2 * g.pad;
+    return CTTS_OK;
+}
+
+struct WfWs { float *rows, *mel_up, *X, *act, *out; size_t total, xslot; };
+
+void wf_carve(const WfPlan& p, const WfGeom& g, int batch, float* base, WfWs& w) {
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o = align_up(o + n); return base ? base + r : nullptr; };
+    const size_t B = batch;
+    w.rows = take(B * p.c.n_group * g.L);
+    w.mel_up = take(B * p.kmel * g.ld);
+    w.xslot = align_up(B * p.C * g.ld);
+    w.X = take(w.xslot * p.c.n_layers * p.c.kernel_size_h);
+    w.act = take(B * p.C * g.ld);
+    w.out = take(B * p.C * g.ld);
+    w.total = o;
+}
+
+// rows[b][g][l] = z[b][G*l + g]   (efficient_model_ax.py:310)
+__global__ __launch_bounds__(256) void wf_squeeze_kernel(const float* __restrict__ z, float* __restrict__ rows,
+                                                         int G, int L) {
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (l >= L) return;
+    const float* zb = z + (size_t)b * G * L + (size_t)l * G;
+    float* rb = rows + (size_t)b * G * L + l;
+    for (int g = 0; g < G; ++g) rb[(size_t)g * L] = zb[g];
+}
+
+struct RowMap { int phys[64]; };
+
+// audio[b][G*l + g] = rows[b][phys[g]][l]   (ax:346, with the accumulated PermuteHeight map)
+__global__ __launch_bounds__(256) void wf_unsqueeze_kernel(const float* __restrict__ rows, float* __restrict__ audio,
+                                                           int G, int L, RowMap map) {
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (l >= L) return;
+    const float* rb = rows + (size_t)b * G * L + l;
+    float* ab = audio + (size_t)b * G * L + (size_t)l * G;
+    for (int g = 0; g < G; ++g) ab[g] = rb[(size_t)map.phys[g] * L];
+}
+
+// rows: NaN -> 0 in place   (ax:13-16, 333-334)
+__global__ __launch_bounds__(256) void wf_nan_to_zero_kernel(float* __restrict__ rows, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = reinterpret_cast<float4*>(rows)[i];
+    v.x = (v.x != v.x) ? 0.f : v.x; v.y = (v.y != v.y) ? 0.f : v.y;
+    v.z = (v.z != v.z) ? 0.f : v.z; v.w = (v.w != v.w) ? 0.f : v.w;
+    reinterpret_cast<float4*>(rows)[i] = v;
+}
+
+// mel_up[b][m][pad + l] = linear interpolation (align_corners=True) of mel[b][m][:] to L steps,
+// fp32 exactly like ATen's upsample_linear1d (glow_ax.py:545-554)
+__global__ __launch_bounds__(256) void wf_interp_kernel(const float* __restrict__ mel, float* __restrict__ up,
+                                                        int n_mel, int kmel, int F, int L, int ld, int pad) {
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    const int m = blockIdx.y, b = blockIdx.z;
+    if (l >= L) return;
+    float v;
+    const float* src = mel + ((size_t)b * n_mel + m) * F;
+    if (F == L) {
+        v = src[l];
+    } else {
+        const float scale = L > 1 ? (float)(F - 1) / (float)(L - 1) : 0.f;
+        const float real = scale * (float)l;
+        const int i0 = (int)real;
+        const int i1 = i0 + 1 < F ? i0 + 1 : F - 1;
+        const float l1 = real - (float)i0;
+        const float l0 = 1.0f - l1;
+        v = l0 * src[i0] + l1 * src[i1];
+    }
+    up[((size_t)b * kmel + m) * ld + pad + l] = v;
+}
+
+// X0[b][c][pad + l] = ws[c] * rows[b][row][l] + bs[c]   (Conv2d(1->C, 1x1), glow_ax.py:558)
+__global__ __launch_bounds__(256) void wf_start_kernel(const float* __restrict__ rows, const float* __restrict__ ws,
+                                                       const float* __restrict__ bs, float* __restrict__ x, int C,
+                                                       int G, int row, int L, int ld, int pad) {
+    const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int b = blockIdx.z;
+    if (n >= L) return;
+    const float4 a = *reinterpret_cast<const float4*>(rows + ((size_t)b * G + row) * L + n);
+    const int c0 = blockIdx.y * 16;
+    float* xb = x + (size_t)b * C * ld + pad + n;
+    for (int c = c0; c < c0 + 16 && c < C; ++c) {
+        const float w = ws[c], bias = bs[c];
+        float4 v;
+        v.x = w * a.x + bias; v.y = w * a.y + bias; v.z = w * a.z + bias; v.w = w * a.w + bias;
+        *reinterpret_cast<float4*>(xb + (size_t)c * ld) = v;
+    }
+}
+
+// e = Wend * out + bend; log_s = e[0], t = e[1]; rows[b][row][l] = (rows[b][row][l] - t) / exp(log_s)
+// (glow_ax.py:628, efficient_modules.py:61-62).  4 waves x 256 steps, each wave reduces C/4 channels.
+__global__ __launch_bounds__(256) void wf_tail_kernel(const float* __restrict__ out, float* __restrict__ rows,
+                                                      const float* __restrict__ Wend, const float* __restrict__ bend,
+                                                      int C, int G, int row, int L, int ld, int pad) {
+    __shared__ __attribute__((aligned(16))) float part[3][2][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * 256 + lane * 4;
+    float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;
+    const int cq = C / 4;
+    const int cbeg = __builtin_amdgcn_readfirstlane(wv * cq);
+    const float* ob = out + (size_t)b * C * ld + pad + n;
+    for (int c = cbeg; c < cbeg + cq; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(ob + (size_t)c * ld);
+        const float w0 = Wend[c], w1 = Wend[C + c];
+        e0.x = fmaf(w0, v.x, e0.x); e0.y = fmaf(w0, v.y, e0.y); e0.z = fmaf(w0, v.z, e0.z); e0.w = fmaf(w0, v.w, e0.w);
+        e1.x = fmaf(w1, v.x, e1.x); e1.y = fmaf(w1, v.y, e1.y); e1.z = fmaf(w1, v.z, e1.z); e1.w = fmaf(w1, v.w, e1.w);
+    }
+    if (wv > 0) {
+        *reinterpret_cast<float4*>(&part[wv - 1][0][lane * 4]) = e0;
+        *reinterpret_cast<float4*>(&part[wv - 1][1][lane * 4]) = e1;
+    }
+    __syncthreads();
+    if (wv != 0 || n >= L) return;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const float4 p0 = *reinterpret_cast<const float4*>(&part[q][0][lane * 4]);
+        const float4 p1 = *reinterpret_cast<const float4*>(&part[q][1][lane * 4]);
+        e0.x += p0.x; e0.y += p0.y; e0.z += p0.z; e0.w += p0.w;
+        e1.x += p1.x; e1.y += p1.y; e1.z += p1.z; e1.w += p1.w;
+    }
+    const float b0 = bend[0], b1 = bend[1];
+    float* rp = rows + ((size_t)b * G + row) * L + n;
+    float4 a = *reinterpret_cast<const float4*>(rp);
+    a.x = (a.x - (e1.x + b1)) / expf(e0.x + b0);
+    a.y = (a.y - (e1.y + b1)) / expf(e0.y + b0);
+    a.z = (a.z - (e1.z + b1)) / expf(e0.z + b0);
+    a.w = (a.w - (e1.w + b1)) / expf(e0.w + b0);
+    *reinterpret_cast<float4*>(rp) = a;
+}
+
+void wf_permutation(int k, int G, int* perm) {
+    for (int g = 0; g < G; ++g) perm[g] = G - 1 - g;                       // reverse (k % 4 in {0,1})
+    if (k % 4 == 2 || k % 4 == 3) {                                        // reverse each half separately
+        const int half = G / 2;
+        for (int g = 0; g < half; ++g) perm[g] = half - 1 - g;
+        for (int g = half; g < G; ++g) perm[g] = G - 1 - (g - half);
+    }
+}
+
+}  // namespace
+}  // namespace ctts
+
+using namespace ctts;
+
+extern "C" {
+
+size_t ctts_waveflow_packed_bytes(const ctts_waveflow_config* cfg) {
+    WfPlan p;
+    if (make_wf_plan(cfg, p)) return 0;
+    return p.total * sizeof(float);
+}
+
+int ctts_waveflow_pack_flow(const ctts_waveflow_config* cfg, int32_t k, const ctts_waveflow_flow_weights* w,
+                            void* packed, void* stream) {
+    WfPlan p;
+    int rc = make_wf_plan(cfg, p); if (rc) return rc;
+    CTTS_CHECK_ARG(k >= 0 && k < p.c.n_flows && w && packed, "waveflow pack_flow: bad argument");
+    CTTS_CHECK_ARG(w->start_w && w->start_b && w->cond_w && w->cond_b && w->in_w && w->in_b && w->rs_w && w->rs_b &&
+                   w->end_w && w->end_b, "waveflow pack_flow: NULL weight pointer");
+    hipStream_t s = as_stream(stream);
+    float* blob = static_cast<float*>(packed);
+    const auto& f = p.fl[k];
+    const int C = p.C, kh = p.c.kernel_size_h, kw = p.c.kernel_size_w, nm = p.c.n_mel_channels;
+    CTTS_CHECK_HIP(hipMemcpyAsync(blob + f.start_w, w->start_w, C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    CTTS_CHECK_HIP(hipMemcpyAsync(blob + f.start_b, w->start_b, C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    CTTS_CHECK_HIP(hipMemcpyAsync(blob + f.end_w, w->end_w, 2 * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    CTTS_CHECK_HIP(hipMemcpyAsync(blob + f.end_b, w->end_b, 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    for (int i = 0; i < p.c.n_layers; ++i) {
+        CTTS_CHECK_ARG(w->in_w[i] && w->in_b[i] && w->rs_w[i] && w->rs_b[i], "waveflow pack_flow: NULL layer %d", i);
+        CTTS_CHECK_HIP(hipMemsetAsync(blob + f.in_A[i], 0, (size_t)p.in_mb() * p.nch_in * GEMM_KC * WF_BM * sizeof(float), s));
+        // K = [height tap a][width tap j][channel] then the cond rows;  in_w[i] is [2C][C][kh][kw]
+        for (int a = 0; a < kh; ++a)
+            for (int j = 0; j < kw; ++j)
+                if ((rc = launch_pack_a(blob + f.in_A[i], w->in_w[i] + a * kw + j, WF_BM, p.in_mb(), p.nch_in,
+                                        (a * kw + j) * C, C, GEMM_EPI_GATE, C, 2 * C, 0, (long long)C * kh * kw,
+                                        kh * kw, s))) return rc;
+        if ((rc = launch_pack_a(blob + f.in_A[i], w->cond_w, WF_BM, p.in_mb(), p.nch_in, kh * kw * C, nm,
+                                GEMM_EPI_GATE, C, 2 * C, (long long)2 * C * i, nm, 1, s))) return rc;
+        if ((rc = launch_pack_bias(blob + f.in_b[i], WF_BM, p.in_mb(), w->in_b[i], 0, w->cond_b, (long long)2 * C * i,
+                                   GEMM_EPI_GATE, C, 2 * C, s))) return rc;
+        const int rows = p.rs_rows(i);
+        if ((rc = launch_pack_a(blob + f.rs_A[i], w->rs_w[i], WF_BM, p.rs_mb(i), p.nch_c, 0, C, GEMM_EPI_SPLIT, C, rows,
+                                0, C, 1, s))) return rc;
+        if ((rc = launch_pack_bias(blob + f.rs_b[i], WF_BM, p.rs_mb(i), w->rs_b[i], 0, nullptr, 0, GEMM_EPI_SPLIT, C,
+                                   rows, s))) return rc;
+    }
+    return CTTS_OK;
+}
+
+size_t ctts_waveflow_workspace_bytes(const ctts_waveflow_config* cfg, int32_t batch, int32_t samples) {
+    WfPlan p; WfGeom g; WfWs w;
+    if (make_wf_plan(cfg, p) || make_wf_geom(p, samples, g) || batch < 1) return 0;
+    wf_carve(p, g, batch, nullptr, w);
+    return w.total * sizeof(float);
+}
+
+int ctts_waveflow_inverse_f32(const ctts_waveflow_config* cfg, const void* packed, const float* z, const float* mel,
+                              float* audio, int32_t batch, int32_t samples, int32_t frames, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    WfPlan p; WfGeom g; WfWs w;
+    int rc = make_wf_plan(cfg, p); if (rc) return rc;
+    rc = make_wf_geom(p, samples, g); if (rc) return rc;
+    CTTS_CHECK_ARG(packed && z && mel && audio && workspace && batch >= 1 && frames >= 1, "waveflow inverse: bad argument");
+    wf_carve(p, g, batch, static_cast<float*>(workspace), w);
+    if (w.total * sizeof(float) > workspace_bytes) {
+        set_error("waveflow inverse: workspace %zu bytes < required %zu", workspace_bytes, w.total * sizeof(float));
+        return CTTS_E_WORKSPACE;
+    }
+    hipStream_t s = as_stream(stream);
+    const float* blob = static_cast<const float*>(packed);
+    const int G = p.c.n_group, C = p.C, L = g.L, kh = p.c.kernel_size_h, kw = p.c.kernel_size_w;
+    const long long cstride = (long long)C * g.ld;
+    const dim3 lgrid((L + 255) / 256, batch);
+
+    hipLaunchKernelGGL(wf_squeeze_kernel, lgrid, dim3(256), 0, s, z, w.rows, G, L);
+    CTTS_CHECK_LAUNCH("wf_squeeze");
+    hipLaunchKernelGGL(wf_interp_kernel, dim3((L + 255) / 256, p.c.n_mel_channels, batch), dim3(256), 0, s, mel,
+                       w.mel_up, p.c.n_mel_channels, p.kmel, frames, L, g.ld, g.pad);
+    CTTS_CHECK_LAUNCH("wf_interp");
+
+    // logical row g of the current flow lives in physical row phys[g] of w.rows
+    int phys[64], perm[64], tmp[64];
+    for (int i = 0; i < G; ++i) phys[i] = i;
+    auto X = [&](int layer, int slot) { return w.X + ((size_t)layer * kh + slot) * w.xslot; };
+
+    for (int k = p.c.n_flows - 1; k >= 0; --k) {
+        const auto& f = p.fl[k];
+        wf_permutation(k, G, perm);
+        for (int i = 0; i < G; ++i) tmp[i] = phys[perm[i]];
+        for (int i = 0; i < G; ++i) phys[i] = tmp[i];
+        for (int r = 0; r < G - 1; ++r) {
+            const int slot = r % kh;
+            hipLaunchKernelGGL(wf_start_kernel, dim3((L / 4 + 255) / 256, (C + 15) / 16, batch), dim3(256), 0, s,
+                               w.rows, blob + f.start_w, blob + f.start_b, X(0, slot), C, G, phys[r], L, g.ld, g.pad);
+            CTTS_CHECK_LAUNCH("wf_start");
+            const int a_min = (kh - 1 - r) > 0 ? (kh - 1 - r) : 0;   // earlier rows do not exist: skip those taps
+            for (int i = 0; i < p.c.n_layers; ++i) {
+                const int dw = 1 << i;
+                GemmArgs a{};
+                a.bm = WF_BM;
+                a.ld = g.ld; a.pad = g.pad; a.L = L; a.ntiles = g.ntiles; a.batch = batch;
+                a.dst_ld = g.ld; a.dst_pad = g.pad;
+                a.A = blob + f.in_A[i]; a.bias = blob + f.in_b[i];
+                a.a_nch_alloc = p.nch_in; a.a_ch_off = a_min * kw * p.nch_c;
+                a.MB = p.in_mb(); a.M = 2 * C; a.pairC = C;
+                int ns = 0;
+                for (int ah = a_min; ah < kh; ++ah) {
+                    const int src_row = r - (kh - 1 - ah);
+                    for (int j = 0; j < kw; ++j)
+                        a.seg[ns++] = {X(i, src_row % kh), cstride, p.nch_c, (j - kw / 2) * dw, 0, 0};
+                }
+                a.seg[ns++] = {w.mel_up, (long long)p.kmel * g.ld, p.kmel / GEMM_KC, 0, 0, 0};
+                a.nseg = ns;
+                a.nch_total = (kh - a_min) * kw * p.nch_c + p.kmel / GEMM_KC;
+                a.dst0 = w.act; a.dst0_bstride = cstride;
+                if ((rc = launch_gemm_f32(GEMM_EPI_GATE, a, s))) return rc;
+
+                const bool last = i == p.c.n_layers - 1;
+                GemmArgs q{};
+                q.bm = WF_BM;
+                q.ld = g.ld; q.pad = g.pad; q.L = L; q.ntiles = g.ntiles; q.batch = batch;
+                q.dst_ld = g.ld; q.dst_pad = g.pad;
+                q.A = blob + f.rs_A[i]; q.bias = blob + f.rs_b[i];
+                q.nseg = 1; q.nch_total = p.nch_c; q.MB = p.rs_mb(i); q.M = p.rs_rows(i);
+                q.seg[0] = {w.act, cstride, p.nch_c, 0, 0, 0};
+                // x_{i+1}[row r] = x_i[row r] + res : written into layer i+1's ring slot (its queue entry)
+                q.dst0 = last ? w.out : X(i + 1, slot); q.dst0_bstride = cstride; q.acc0 = 1;
+                q.src0 = X(i, slot); q.src0_bstride = cstride;
+                q.dst1 = w.out; q.dst1_bstride = cstride; q.acc1 = i > 0 ? 1 : 0;
+                q.split = last ? 0 : C;
+                if ((rc = launch_gemm_f32(GEMM_EPI_SPLIT, q, s))) return rc;
+            }
+            hipLaunchKernelGGL(wf_tail_kernel, lgrid, dim3(256), 0, s, w.out, w.rows, blob + f.end_w, blob + f.end_b, C,
+                               G, phys[r + 1], L, g.ld, g.pad);
+            CTTS_CHECK_LAUNCH("wf_tail");
+        }
+        const size_t n4 = (size_t)batch * G * L / 4;
+        hipLaunchKernelGGL(wf_nan_to_zero_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, w.rows, n4);
+        CTTS_CHECK_LAUNCH("wf_nan_to_zero");
+    }
+    RowMap map;
+    for (int i = 0; i < 64; ++i) map.phys[i] = i < G ? phys[i] : 0;
+    hipLaunchKernelGGL(wf_unsqueeze_kernel, lgrid, dim3(256), 0, s, w.rows, audio, G, L, map);
+    CTTS_CHECK_LAUNCH("wf_unsqueeze");
+    return CTTS_OK;
+}
+
+}  // extern "C"

@@ -171,7 +171,7 @@ int run_cond(const Plan& p, const Geom& g, const float* blob, const float* spect
     GemmArgs a = base_args(g, batch);
     a.A = blob + p.cond0_A; a.bias = blob + p.cond0_b;
     a.nseg = 1; a.nch_total = p.nch0; a.MB = p.c.n_flows;
-    a.seg[0] = {spect, (long long)p.K0 * g.ld, p.nch0, 0, 0, 1};
+    a.seg[0] = {spect, (long long)p.K0 * g.ld, p.nch0, 0, 0, 0};
     a.dst0 = h_tmp; a.dst0_bstride = hstride; a.acc0 = 0;
     a.dst1 = h_tmp; a.dst1_bstride = hstride; a.acc1 = 0;
     a.split = p.c.n_flows * GEMM_BM;
@@ -180,7 +180,7 @@ int run_cond(const Plan& p, const Geom& g, const float* blob, const float* spect
     if (rc) return rc;
     a.A = blob + p.cond1_A; a.bias = blob + p.cond1_b;
     a.nch_total = p.nch1h;
-    a.seg[0] = {h_tmp, hstride, p.nch1h, 0, GEMM_BM, 1};
+    a.seg[0] = {h_tmp, hstride, p.nch1h, 0, GEMM_BM, 0};
     a.dst0 = h_all; a.dst1 = h_all;
     return launch_gemm_f32(GEMM_EPI_SPLIT, a, s);
 }
@@ -201,10 +201,10 @@ int run_wn_stack(const Plan& p, const Geom& g, const float* blob, int k, const f
             GemmArgs a = base_args(g, batch);
             a.A = blob + f.in_A[i]; a.bias = blob + f.in_b[i];
             a.nseg = 4; a.nch_total = p.nch_in; a.MB = p.mb_in;
-            a.seg[0] = {x, cstride, ncx, -dil, 0, (dil % 4 == 0) ? 1 : 0};
-            a.seg[1] = {x, cstride, ncx, 0, 0, 1};
-            a.seg[2] = {x, cstride, ncx, dil, 0, (dil % 4 == 0) ? 1 : 0};
-            a.seg[3] = {h_all + (size_t)k * p.H * g.ld, hstride, p.nch1h, 0, 0, 1};
+            a.seg[0] = {x, cstride, ncx, -dil, 0, 0};
+            a.seg[1] = {x, cstride, ncx, 0, 0, 0};
+            a.seg[2] = {x, cstride, ncx, dil, 0, 0};
+            a.seg[3] = {h_all + (size_t)k * p.H * g.ld, hstride, p.nch1h, 0, 0, 0};
             a.dst0 = act; a.dst0_bstride = cstride;
             a.M = 2 * p.C; a.pairC = p.C;
             ProfScope ps(CTTS_PROF_WN_IN, s);
@@ -216,7 +216,7 @@ int run_wn_stack(const Plan& p, const Geom& g, const float* blob, int k, const f
             GemmArgs a = base_args(g, batch);
             a.A = blob + f.rs_A[i]; a.bias = blob + f.rs_b[i];
             a.nseg = 1; a.nch_total = p.nch_rs; a.MB = p.rs_mb(i);
-            a.seg[0] = {act, cstride, p.nch_rs, 0, 0, 1};
+            a.seg[0] = {act, cstride, p.nch_rs, 0, 0, 0};
             a.M = p.rs_rows(i);
             a.dst0 = x; a.dst0_bstride = cstride; a.acc0 = 1;
             a.dst1 = out; a.dst1_bstride = cstride; a.acc1 = i > 0 ? 1 : 0;
@@ -304,29 +304,29 @@ int ctts_waveglow_pack_flow(const ctts_waveglow_config* cfg, int32_t k, const ct
     // cond layers 0/1: this flow is M-block k of the flow-batched GEMMs
     CTTS_CHECK_ARG(w->cond_w[0] && w->cond_w[1] && w->cond_w[2] && w->cond_b[0] && w->cond_b[1] && w->cond_b[2],
                    "pack_flow: NULL cond weights");
-    if ((rc = launch_pack_a(blob + p.cond0_A + (size_t)k * p.nch0 * A_TILE, w->cond_w[0], 1, p.nch0, 0, p.K0,
+    if ((rc = launch_pack_a(blob + p.cond0_A + (size_t)k * p.nch0 * A_TILE, w->cond_w[0], GEMM_BM, 1, p.nch0, 0, p.K0,
                             GEMM_EPI_SPLIT, C, H, 0, p.K0, 1, s))) return rc;
-    if ((rc = launch_pack_bias(blob + p.cond0_b + (size_t)k * GEMM_BM, 1, w->cond_b[0], 0, nullptr, 0,
+    if ((rc = launch_pack_bias(blob + p.cond0_b + (size_t)k * GEMM_BM, GEMM_BM, 1, w->cond_b[0], 0, nullptr, 0,
                                GEMM_EPI_SPLIT, C, H, s))) return rc;
-    if ((rc = launch_pack_a(blob + p.cond1_A + (size_t)k * p.nch1h * A_TILE, w->cond_w[1], 1, p.nch1h, 0, H,
+    if ((rc = launch_pack_a(blob + p.cond1_A + (size_t)k * p.nch1h * A_TILE, w->cond_w[1], GEMM_BM, 1, p.nch1h, 0, H,
                             GEMM_EPI_SPLIT, C, H, 0, H, 1, s))) return rc;
-    if ((rc = launch_pack_bias(blob + p.cond1_b + (size_t)k * GEMM_BM, 1, w->cond_b[1], 0, nullptr, 0,
+    if ((rc = launch_pack_bias(blob + p.cond1_b + (size_t)k * GEMM_BM, GEMM_BM, 1, w->cond_b[1], 0, nullptr, 0,
                                GEMM_EPI_SPLIT, C, H, s))) return rc;
     for (int i = 0; i < p.c.n_layers; ++i) {
         CTTS_CHECK_ARG(w->in_w[i] && w->in_b[i] && w->rs_w[i] && w->rs_b[i], "pack_flow: NULL layer %d weights", i);
         // in-layer: K = [tap0 | tap1 | tap2 | cond];  in_w[i] is [2C][C][ks]
         for (int t = 0; t < ks; ++t)
-            if ((rc = launch_pack_a(blob + f.in_A[i], w->in_w[i] + t, p.mb_in, p.nch_in, t * C, C, GEMM_EPI_GATE, C,
+            if ((rc = launch_pack_a(blob + f.in_A[i], w->in_w[i] + t, GEMM_BM, p.mb_in, p.nch_in, t * C, C, GEMM_EPI_GATE, C,
                                     2 * C, 0, (long long)C * ks, ks, s))) return rc;
         // cond layer 2 rows [2C*i, 2C*(i+1)) of [2C*n_layers][H]
-        if ((rc = launch_pack_a(blob + f.in_A[i], w->cond_w[2], p.mb_in, p.nch_in, ks * C, H, GEMM_EPI_GATE, C,
+        if ((rc = launch_pack_a(blob + f.in_A[i], w->cond_w[2], GEMM_BM, p.mb_in, p.nch_in, ks * C, H, GEMM_EPI_GATE, C,
                                 2 * C, (long long)2 * C * i, H, 1, s))) return rc;
-        if ((rc = launch_pack_bias(blob + f.in_b[i], p.mb_in, w->in_b[i], 0, w->cond_b[2], (long long)2 * C * i,
+        if ((rc = launch_pack_bias(blob + f.in_b[i], GEMM_BM, p.mb_in, w->in_b[i], 0, w->cond_b[2], (long long)2 * C * i,
                                    GEMM_EPI_GATE, C, 2 * C, s))) return rc;
         const int rows = p.rs_rows(i);
-        if ((rc = launch_pack_a(blob + f.rs_A[i], w->rs_w[i], p.rs_mb(i), p.nch_rs, 0, C, GEMM_EPI_SPLIT, C, rows,
+        if ((rc = launch_pack_a(blob + f.rs_A[i], w->rs_w[i], GEMM_BM, p.rs_mb(i), p.nch_rs, 0, C, GEMM_EPI_SPLIT, C, rows,
                                 0, C, 1, s))) return rc;
-        if ((rc = launch_pack_bias(blob + f.rs_b[i], p.rs_mb(i), w->rs_b[i], 0, nullptr, 0, GEMM_EPI_SPLIT, C, rows,
+        if ((rc = launch_pack_bias(blob + f.rs_b[i], GEMM_BM, p.rs_mb(i), w->rs_b[i], 0, nullptr, 0, GEMM_EPI_SPLIT, C, rows,
                                    s))) return rc;
     }
     return CTTS_OK;

@@ -26,33 +26,35 @@ __global__ __launch_bounds__(256) void fold_weightnorm_kernel(const float* __res
     for (int i = threadIdx.x; i < fan; i += 256) wr[i] = vr[i] * scale;
 }
 
-// dst packed [MB][nch_total][16][256];  fills K range [k_off, k_off + ksrc):
+// dst packed [MB][nch_total][16][bm];  fills K range [k_off, k_off + ksrc):
 //   dst(mb, k, r) = src[(src_row_off + dense_row(mb, r)) * src_row_stride + (k - k_off) * src_k_stride]
-__global__ __launch_bounds__(256) void pack_a_kernel(float* __restrict__ dst, const float* __restrict__ src,
+__global__ __launch_bounds__(256) void pack_a_kernel(float* __restrict__ dst, const float* __restrict__ src, int bm,
                                                      int nch_total, int k_off, int ksrc, int epi, int C, int M,
                                                      long long src_row_off, long long src_row_stride,
                                                      int src_k_stride) {
     const int mb = blockIdx.y;
     const int k = blockIdx.x;  // 0..ksrc-1
     const int r = threadIdx.x;
-    const int drow = gemm_dense_row(epi, mb, r, C, M);
+    if (r >= bm) return;
+    const int drow = gemm_dense_row(epi, bm, mb, r, C, M);
     const int kk = k_off + k;
-    dst[((size_t)mb * nch_total + kk / GEMM_KC) * (GEMM_KC * GEMM_BM) + (kk % GEMM_KC) * GEMM_BM + r] =
+    dst[((size_t)mb * nch_total + kk / GEMM_KC) * (GEMM_KC * bm) + (kk % GEMM_KC) * bm + r] =
         drow >= 0 ? src[(src_row_off + drow) * src_row_stride + (long long)k * src_k_stride] : 0.f;
 }
 
-// dst[mb*256 + r] = src0[off0 + dense_row] (+ src1[off1 + dense_row])
-__global__ __launch_bounds__(256) void pack_bias_kernel(float* __restrict__ dst, const float* __restrict__ src0,
+// dst[mb*bm + r] = src0[off0 + dense_row] (+ src1[off1 + dense_row])
+__global__ __launch_bounds__(256) void pack_bias_kernel(float* __restrict__ dst, int bm, const float* __restrict__ src0,
                                                         long long off0, const float* __restrict__ src1,
                                                         long long off1, int epi, int C, int M) {
     const int mb = blockIdx.x, r = threadIdx.x;
-    const int row = gemm_dense_row(epi, mb, r, C, M);
+    if (r >= bm) return;
+    const int row = gemm_dense_row(epi, bm, mb, r, C, M);
     float v = 0.f;
     if (row >= 0 && src0) {
         v = src0[off0 + row];
         if (src1) v += src1[off1 + row];
     }
-    dst[mb * GEMM_BM + r] = v;
+    dst[mb * bm + r] = v;
 }
 
 // ------------------------------------------------------------ upsample + squeeze ----
@@ -267,18 +269,18 @@ int launch_fold_weightnorm(const float* v, const float* g, float* w, int out_ch,
     return CTTS_OK;
 }
 
-int launch_pack_a(float* dst, const float* src, int MB, int nch_total, int k_off, int ksrc, int epi, int C, int M,
+int launch_pack_a(float* dst, const float* src, int bm, int MB, int nch_total, int k_off, int ksrc, int epi, int C, int M,
                   long long src_row_off, long long src_row_stride, int src_k_stride, hipStream_t s) {
     CTTS_CHECK_ARG(k_off >= 0 && ksrc > 0 && k_off + ksrc <= nch_total * GEMM_KC, "pack_a: k range");
-    hipLaunchKernelGGL(pack_a_kernel, dim3(ksrc, MB), dim3(256), 0, s, dst, src, nch_total, k_off, ksrc, epi, C, M,
+    hipLaunchKernelGGL(pack_a_kernel, dim3(ksrc, MB), dim3(256), 0, s, dst, src, bm, nch_total, k_off, ksrc, epi, C, M,
                        src_row_off, src_row_stride, src_k_stride);
     CTTS_CHECK_LAUNCH("pack_a");
     return CTTS_OK;
 }
 
-int launch_pack_bias(float* dst, int MB, const float* src0, long long off0, const float* src1, long long off1,
+int launch_pack_bias(float* dst, int bm, int MB, const float* src0, long long off0, const float* src1, long long off1,
                      int epi, int C, int M, hipStream_t s) {
-    hipLaunchKernelGGL(pack_bias_kernel, dim3(MB), dim3(256), 0, s, dst, src0, off0, src1, off1, epi, C, M);
+    hipLaunchKernelGGL(pack_bias_kernel, dim3(MB), dim3(256), 0, s, dst, bm, src0, off0, src1, off1, epi, C, M);
     CTTS_CHECK_LAUNCH("pack_bias");
     return CTTS_OK;
 }

@@ -20,6 +20,9 @@ import numpy as np
 
 __all__ = [
     "WAVEGLOW_CONFIGS",
+    "WAVEFLOW_CONFIGS",
+    "waveflow_config",
+    "waveflow_state_dict",
     "waveglow_config",
     "waveglow_flow_channels",
     "waveglow_state_dict",
@@ -64,6 +67,65 @@ def waveglow_flow_channels(cfg):
             n_rem -= cfg["n_early_size"]
         out.append((n_rem, n_half))
     return out
+
+
+def waveflow_config(n_flows=8, n_group=16, n_channels=64, n_layers=8, kernel_size_w=3, kernel_size_h=3,
+                    n_mel_channels=80, hop_length=256):
+    """Constructor kwargs of the reference ``efficient_model_ax.WaveGlow`` for BASELINE config 4
+    (SURVEY.md 8d row 4)."""
+    return dict(n_mel_channels=n_mel_channels, n_flows=n_flows, n_group=n_group, n_early_every=100,
+                n_early_size=2, memory_efficient=0.0, spect_scaling=False, upsample_mode='normal',
+                upsample_first=False, speaker_embed=0, cond_layers=0, cond_hidden_channels=256,
+                cond_output_channels=256, cond_kernel_size=1, cond_residual=False, cond_padding_mode='zeros',
+                waveflow=True, channel_mixing='permuteheight', mix_first=False, win_length=1024,
+                hop_length=hop_length, sampling_rate=22050,
+                WN_config=dict(n_layers=n_layers, n_channels=n_channels, kernel_size_w=kernel_size_w,
+                               kernel_size_h=kernel_size_h, n_layers_dilations_w=None,
+                               n_layers_dilations_h=[1] * n_layers, speaker_embed_dim=0, rezero=False,
+                               cond_layers=1, cond_activation_func='none', negative_slope=None,
+                               cond_hidden_channels=256, cond_padding_mode='zeros', seperable_conv=False,
+                               res_skip=True, merge_res_skip=False, upsample_mode='linear', cond_kernel_size=1))
+
+
+WAVEFLOW_CONFIGS = {
+    "toy": waveflow_config(n_flows=4, n_group=8, n_channels=64, n_layers=3),
+    "full": waveflow_config(),                                   # config 4: 8 flows, 64 ch, h = 16
+}
+
+
+def waveflow_state_dict(cfg, seed=1234, end_std=None):
+    """Random-init state dict with the reference's keys (SURVEY.md 8a "Checkpoint keys"):
+    ``WN.k.WN.{start,in_layers.i,res_skip_layers.i,cond_layers.0}.{bias,weight_g,weight_v}``,
+    ``WN.k.WN.end.{weight,bias}`` (PermuteHeight has no parameters)."""
+    rng = np.random.default_rng(seed)
+    wn = cfg["WN_config"]
+    C, n_layers = wn["n_channels"], wn["n_layers"]
+    kh, kw = wn["kernel_size_h"], wn["kernel_size_w"]
+    n_mel = cfg["n_mel_channels"]
+    if end_std is None:
+        end_std = 0.25 / np.sqrt(C)
+    sd = {}
+
+    def wn_conv(prefix, shape, fan):
+        bound = 1.0 / np.sqrt(fan)
+        v = _uniform(rng, shape, bound)
+        norm = np.sqrt((v.astype(np.float64) ** 2).reshape(shape[0], -1).sum(axis=1))
+        jitter = 0.9 + 0.2 * rng.random((shape[0],), dtype=np.float32)
+        sd[prefix + ".weight_v"] = v
+        sd[prefix + ".weight_g"] = (norm * jitter).astype(np.float32).reshape((shape[0],) + (1,) * (len(shape) - 1))
+        sd[prefix + ".bias"] = _uniform(rng, (shape[0],), bound)
+
+    for k in range(cfg["n_flows"]):
+        p = f"WN.{k}.WN"
+        wn_conv(p + ".start", (C, 1, 1, 1), 1)
+        sd[p + ".end.weight"] = rng.standard_normal((2, C, 1, 1), dtype=np.float32) * np.float32(end_std)
+        sd[p + ".end.bias"] = rng.standard_normal((2,), dtype=np.float32) * np.float32(0.02)
+        wn_conv(p + ".cond_layers.0", (2 * C * n_layers, n_mel, 1), n_mel * 4)
+        for i in range(n_layers):
+            wn_conv(f"{p}.in_layers.{i}", (2 * C, C, kh, kw), C * kh * kw)
+            rs = 2 * C if i < n_layers - 1 else C
+            wn_conv(f"{p}.res_skip_layers.{i}", (rs, C, 1, 1), C)
+    return sd
 
 
 def _uniform(rng, shape, bound):

@@ -141,6 +141,52 @@ int ctts_flow_tail_f32(const ctts_waveglow_config* cfg, const void* packed, int3
                        const float* out, float* audio, float* wave, int32_t batch,
                        int32_t frames, void* stream);
 
+/* ---- WaveFlow ("ax" core, waveflow=True): _4_mtw/waveglow/efficient_model_ax.py --------- */
+
+/* Constructor arguments that shape the path (efficient_model_ax.py:19-169, glow_ax.py:427-543).
+ * Built option subset = BASELINE config 4: channel_mixing='permuteheight', mix_first=False, no
+ * model-level cond layers / speaker embedding, WN_2d with one k=1 cond layer + linear upsampling,
+ * GTU gate, res_skip=True, merge_res_skip=False, no separable conv, n_early_every > n_flows. */
+typedef struct ctts_waveflow_config {
+    int32_t n_mel_channels;  /* 80 */
+    int32_t n_flows;         /* 8 (even) */
+    int32_t n_group;         /* 16: height of the squeezed audio */
+    int32_t n_layers;        /* 8, width dilation 2^i */
+    int32_t n_channels;      /* 64 (multiple of 64) */
+    int32_t kernel_size_w;   /* 3 (odd) */
+    int32_t kernel_size_h;   /* 3 */
+    int32_t dilation_h;      /* 1 (all layers) */
+} ctts_waveflow_config;
+
+/* Dense, weight-norm-folded fp32 weights of one flow in checkpoint layouts
+ * (keys WN.k.WN.*): */
+typedef struct ctts_waveflow_flow_weights {
+    const float* start_w;      /* [C]                 WN.start (Conv2d 1->C, 1x1) */
+    const float* start_b;      /* [C] */
+    const float* cond_w;       /* [2*C*n_layers][n_mel]   WN.cond_layers.0 (k=1) */
+    const float* cond_b;       /* [2*C*n_layers] */
+    const float* const* in_w;  /* n_layers x [2C][C][kh][kw] */
+    const float* const* in_b;  /* n_layers x [2C] */
+    const float* const* rs_w;  /* n_layers x [2C or C][C] */
+    const float* const* rs_b;
+    const float* end_w;        /* [2][C] (row 0 = log_s, row 1 = t; efficient_modules.py:61) */
+    const float* end_b;        /* [2] */
+} ctts_waveflow_flow_weights;
+
+size_t ctts_waveflow_packed_bytes(const ctts_waveflow_config* cfg);
+int ctts_waveflow_pack_flow(const ctts_waveflow_config* cfg, int32_t flow,
+                            const ctts_waveflow_flow_weights* w, void* packed, void* stream);
+size_t ctts_waveflow_workspace_bytes(const ctts_waveflow_config* cfg, int32_t batch,
+                                     int32_t samples);
+/* WaveGlow.inverse(z, cond) of the ax core (efficient_model_ax.py:279-357) for waveflow=True:
+ *   z    [B][T] fp32, sigma applied (T multiple of n_group)      mel [B][n_mel][frames] (as passed
+ *   to inverse(), i.e. already padded by infer())                audio [B][T]
+ * Includes the per-flow NaN -> 0 (ax:333-334).  Workspace zero-filled once before first use. */
+int ctts_waveflow_inverse_f32(const ctts_waveflow_config* cfg, const void* packed, const float* z,
+                              const float* mel, float* audio, int32_t batch, int32_t samples,
+                              int32_t frames, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
 /* ---- STFT / mel frontend (utils/audio/stft.py) ------------------------------------------- */
 
 /* STFT.__init__ (stft.py:46-77) / TacotronSTFT.__init__ (:155-166) arguments that shape the path. */

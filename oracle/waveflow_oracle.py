@@ -1,0 +1,137 @@
+"""CPU oracle for the WaveFlow path of the "ax" WaveGlow core (BASELINE config 4).
+
+TEST INFRASTRUCTURE ONLY (see oracle/waveglow_oracle.py header for the import rule).
+numpy fp32 restatement written from SURVEY.md §8(a) "Verified restatement of rows W1-W4".
+Reference lines followed (relative to /root/reference/CookieTTS/_4_mtw/waveglow/):
+  waveflow_inverse   efficient_model_ax.py:279-357 (z.view(B,-1,G).transpose :310, flow loop :325-340,
+                     ignore_nan :333-334, un-squeeze :346)
+  permutation        efficient_modules.py:360-403 (PermuteHeight: reverse / bipartite reverse)
+  coupling           efficient_modules.py:42-65  (row 0 passes, (x - t) / exp(log_s))
+  wn2d_row           glow_ax.py:556-635 (start :558, cond layer + linear interp :564-592,545-554,
+                     row queue :597-602, Conv2d (k_h,k_w) dil (d_h,2^i) width pad only :518-523, GTU gate
+                     :36-43, res/skip :615-626, end :628)
+  waveflow_infer     efficient_model_ax.py:359-388 (pad one zero frame, samples, trim hop)
+
+Parity pin: tests/golden/waveflow_*.npz = outputs of the reference's own ``inverse(z, cond)`` /
+``infer`` (tests/golden/make_golden.py).  Restrictions (config 4's option subset): waveflow=True,
+channel_mixing='permuteheight', mix_first=False, model-level cond_layers=0, no speaker embedding,
+WN cond_layers=1 with kernel 1, no separable conv, res_skip=True, merge_res_skip=False, GTU gate,
+n_early_every > n_flows.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .waveglow_oracle import fold_weightnorm
+
+F32 = np.float32
+
+
+def _w(sd, prefix):
+    if prefix + ".weight" in sd:
+        return np.asarray(sd[prefix + ".weight"], dtype=F32)
+    return fold_weightnorm(sd[prefix + ".weight_g"], sd[prefix + ".weight_v"])
+
+
+def permutation(k, G):
+    """Row permutation P_k (its own inverse): new[g] = old[perm[g]]."""
+    idx = list(range(G))
+    if k % 4 in (2, 3):
+        half = G // 2
+        return idx[:half][::-1] + idx[half:][::-1]
+    return idx[::-1]
+
+
+def lerp_align_corners(x, out_len):
+    """F.interpolate(mode='linear', align_corners=True) on the last axis, fp32 like ATen's CPU kernel:
+    scale = (in-1)/(out-1) in fp32, real = scale*dst, i0 = int(real), l1 = real - i0."""
+    x = np.asarray(x, dtype=F32)
+    n_in = x.shape[-1]
+    if out_len == n_in:
+        return x.copy()
+    scale = F32(n_in - 1) / F32(out_len - 1) if out_len > 1 else F32(0)
+    real = (scale * np.arange(out_len, dtype=F32)).astype(F32)
+    i0 = real.astype(np.int64)
+    i1 = np.minimum(i0 + 1, n_in - 1)
+    l1 = (real - i0.astype(F32)).astype(F32)
+    l0 = (F32(1.0) - l1).astype(F32)
+    return (l0 * x[..., i0] + l1 * x[..., i1]).astype(F32)
+
+
+def _shift(x, s):
+    if s == 0:
+        return x
+    y = np.zeros_like(x)
+    if s > 0:
+        y[..., :-s] = x[..., s:]
+    else:
+        y[..., -s:] = x[..., :s]
+    return y
+
+
+def waveflow_inverse(sd, cfg, z, mel):
+    """z [B, T] (sigma applied), mel [B, n_mel, F'] (already padded by infer) -> audio [B, T]."""
+    sd = {k: np.asarray(v, dtype=F32) for k, v in sd.items()}
+    G, n_flows = cfg["n_group"], cfg["n_flows"]
+    wn = cfg["WN_config"]
+    C, n_layers = wn["n_channels"], wn["n_layers"]
+    kh, kw = wn["kernel_size_h"], wn["kernel_size_w"]
+    dhs = wn["n_layers_dilations_h"]
+    dhs = [dhs] * n_layers if isinstance(dhs, int) else list(dhs)
+    z = np.asarray(z, dtype=F32)
+    B, T = z.shape
+    L = T // G
+    a = np.ascontiguousarray(z.reshape(B, L, G).transpose(0, 2, 1))        # a[b, g, l] = z[b, G*l + g]
+    for k in reversed(range(n_flows)):
+        p = f"WN.{k}.WN"
+        a = a[:, permutation(k, G), :]
+        wc = _w(sd, p + ".cond_layers.0")[:, :, 0]
+        cond = lerp_align_corners(np.matmul(wc, mel) + sd[p + ".cond_layers.0.bias"][None, :, None], L)
+        ws = _w(sd, p + ".start").reshape(C)
+        bs = sd[p + ".start.bias"]
+        win = [_w(sd, f"{p}.in_layers.{i}") for i in range(n_layers)]          # [2C, C, kh, kw]
+        wrs = [_w(sd, f"{p}.res_skip_layers.{i}")[:, :, 0, 0] for i in range(n_layers)]
+        wend = sd[p + ".end.weight"][:, :, 0, 0]
+        bend = sd[p + ".end.bias"]
+        y = [a[:, 0, :]]
+        queues = [np.zeros((B, C, (kh - 1) * dhs[i], L), dtype=F32) for i in range(n_layers)]
+        for r in range(G - 1):
+            x = ws[None, :, None] * y[r][:, None, :] + bs[None, :, None]       # [B, C, L]
+            out = None
+            for i in range(n_layers):
+                dw, dh = 2 ** i, dhs[i]
+                pad = ((kw - 1) * dw) // 2
+                Q = np.concatenate([queues[i], x[:, :, None, :]], axis=2)      # [B, C, (kh-1)dh+1, L]
+                queues[i] = Q[:, :, 1:, :] if (kh - 1) * dh > 0 else queues[i]
+                u = (sd[f"{p}.in_layers.{i}.bias"][None, :, None] + cond[:, 2 * C * i:2 * C * (i + 1), :]).astype(F32)
+                for ah in range(kh):
+                    row = Q[:, :, ah * dh, :]
+                    for j in range(kw):
+                        u = u + np.matmul(np.ascontiguousarray(win[i][:, :, ah, j]), _shift(row, j * dw - pad))
+                u = u.astype(F32)
+                act = (np.tanh(u[:, :C]) * (F32(1.0) / (F32(1.0) + np.exp(-u[:, C:])))).astype(F32)
+                rs = np.matmul(wrs[i], act) + sd[f"{p}.res_skip_layers.{i}.bias"][None, :, None]
+                if i < n_layers - 1:
+                    x = x + rs[:, :C]
+                    out = rs[:, C:] if out is None else out + rs[:, C:]
+                else:
+                    out = rs if out is None else out + rs
+            e = np.matmul(wend, out) + bend[None, :, None]                     # [B, 2, L]
+            log_s, t = e[:, 0, :], e[:, 1, :]
+            with np.errstate(over="ignore", invalid="ignore"):
+                y.append(((a[:, r + 1, :] - t) / np.exp(log_s)).astype(F32))
+        a = np.stack(y, axis=1)
+        a = np.where(np.isnan(a), F32(0), a).astype(F32)
+    return np.ascontiguousarray(a.transpose(0, 2, 1)).reshape(B, T)
+
+
+def waveflow_infer(sd, cfg, mel, z, artifact_trimming=1):
+    """infer() wrapper: pad `artifact_trimming` zero frames, z [B, F*hop], drop the last hop samples."""
+    mel = np.asarray(mel, dtype=F32)
+    hop = cfg["hop_length"]
+    melp = np.pad(mel, ((0, 0), (0, 0), (0, artifact_trimming))) if artifact_trimming > 0 else mel
+    samples = (melp.shape[2] - 1) * hop
+    samples -= samples % cfg["n_group"]
+    assert z.shape == (mel.shape[0], samples), (z.shape, samples)
+    audio = waveflow_inverse(sd, cfg, z, melp)
+    return audio[:, :-artifact_trimming * hop] if artifact_trimming > 0 else audio

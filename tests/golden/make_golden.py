@@ -161,8 +161,53 @@ def make_stft():
     print(f"[golden] stft_mel: mel {mel.shape} mag {tuple(mag.shape)} -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def _ref_waveflow(cfg, sd_np):
+    """Import the reference's ax core (needs librosa / iso226 stand-ins and np.product)."""
+    import types
+    _stub_audio_deps()
+    if "iso226" not in sys.modules:
+        iso = types.ModuleType("iso226")
+        iso.iso226_spl_itpl = lambda *a, **k: None
+        sys.modules["iso226"] = iso
+    if not hasattr(np, "product"):
+        np.product = np.prod
+    from CookieTTS._4_mtw.waveglow import efficient_model_ax as ax
+    model = ax.WaveGlow(**cfg)
+    res = model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    return model.eval()
+
+
+def make_waveflow():
+    import copy
+    torch.set_num_threads(8)
+    cases = [("toy", "toy", 2, 6, 0.7, 5), ("toy_odd", "toy", 1, 11, 1.0, 6), ("full_short", "full", 1, 5, 0.6, 1234)]
+    for name, key, B, F, sigma, seed in cases:
+        cfg = synthetic.WAVEFLOW_CONFIGS[key]
+        sd = synthetic.waveflow_state_dict(cfg, seed=seed)
+        model = _ref_waveflow(copy.deepcopy(cfg), sd)
+        mel = synthetic.synthetic_mel(B, F, cfg["n_mel_channels"], seed=seed)
+        # the reference's own infer() (ax:359-388); the noise it draws is replayed from the same seed
+        torch.manual_seed(seed)
+        z = torch.empty(B, F * cfg["hop_length"]).normal_(std=sigma).numpy()
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            audio = model.infer(torch.from_numpy(mel.copy()), sigma=sigma).numpy()
+            melp = np.pad(mel, ((0, 0), (0, 0), (0, 1)))
+            inv, _ = model.inverse(torch.from_numpy(z.copy()), torch.from_numpy(melp.copy()))
+        inv = inv.numpy()
+        assert audio.shape == (B, (F - 1) * cfg["hop_length"]) and np.isfinite(audio).all()
+        assert np.array_equal(inv[:, :audio.shape[1]], audio), "noise replay out of sync with infer()"
+        path = os.path.join(HERE, f"waveflow_{name}.npz")
+        np.savez_compressed(path, config_key=key, seed=seed, sigma=np.float32(sigma), mel=mel, z=z, audio=audio,
+                            inverse_full=inv.astype(np.float32))
+        print(f"[golden] waveflow {name}: audio {audio.shape} rms={audio.std():.4f} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["waveglow", "stft"]
+    which = sys.argv[1:] or ["waveglow", "stft", "waveflow"]
+    if "waveflow" in which:
+        make_waveflow()
     if "waveglow" in which:
         make_waveglow()
     if "stft" in which:

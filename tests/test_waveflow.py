@@ -1,0 +1,103 @@
+"""WaveFlow (ax core, config 4): oracle vs reference goldens (CPU), HIP vs goldens / oracle (GPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rms_rel_err
+from cookietts_amd import synthetic
+from oracle import waveflow_oracle as wf
+
+WAVE_TOL = 1e-3           # BASELINE.json waveform RMS rel-err bound
+ORACLE_TOL = 5e-6
+
+
+def _load(name):
+    g = np.load(os.path.join(GOLDEN, f"waveflow_{name}.npz"))
+    cfg = synthetic.WAVEFLOW_CONFIGS[str(g["config_key"])]
+    return g, cfg, synthetic.waveflow_state_dict(cfg, seed=int(g["seed"]))
+
+
+@pytest.mark.parametrize("name", ["toy", "toy_odd", "full_short"])
+def test_oracle_matches_reference(name):
+    g, cfg, sd = _load(name)
+    out = wf.waveflow_infer(sd, cfg, g["mel"], g["z"])
+    assert out.shape == g["audio"].shape                       # (F-1)*hop samples
+    assert rms_rel_err(out, g["audio"]) < ORACLE_TOL
+    melp = np.pad(g["mel"], ((0, 0), (0, 0), (0, 1)))
+    assert rms_rel_err(wf.waveflow_inverse(sd, cfg, g["z"], melp), g["inverse_full"]) < ORACLE_TOL
+
+
+def test_permutation_is_involution_and_matches_reference_pattern():
+    assert wf.permutation(0, 8) == [7, 6, 5, 4, 3, 2, 1, 0]
+    assert wf.permutation(2, 8) == [3, 2, 1, 0, 7, 6, 5, 4]    # efficient_modules.py:366-367 example
+    for k in range(8):
+        p = wf.permutation(k, 16)
+        assert [p[i] for i in p] == list(range(16))
+
+
+def test_nan_is_zeroed_per_flow():
+    cfg = synthetic.WAVEFLOW_CONFIGS["toy"]
+    sd = synthetic.waveflow_state_dict(cfg, seed=2)
+    z = np.random.default_rng(0).standard_normal((1, 512)).astype(np.float32)
+    z[0, 17] = np.nan
+    out = wf.waveflow_inverse(sd, cfg, z, synthetic.synthetic_mel(1, 3))
+    assert np.isfinite(out).all()
+
+
+def test_host_state_dict_keys_match_reference_format():
+    from cookietts_amd.waveglow_ax import WaveGlow
+    for key in ("toy", "full"):
+        cfg = synthetic.WAVEFLOW_CONFIGS[key]
+        sd = synthetic.waveflow_state_dict(cfg, seed=1)
+        m = WaveGlow(**cfg)
+        own = m.state_dict()
+        assert sorted(own) == sorted(sd)
+        assert all(tuple(own[k].shape) == sd[k].shape for k in sd)
+    with pytest.raises(NotImplementedError):
+        WaveGlow(**dict(synthetic.WAVEFLOW_CONFIGS["toy"], channel_mixing='1x1conv'))
+    with pytest.raises(NotImplementedError):
+        WaveGlow(**dict(synthetic.WAVEFLOW_CONFIGS["toy"], waveflow=False))
+
+
+def _model(key, seed):
+    from cookietts_amd.waveglow_ax import WaveGlow
+    cfg = synthetic.WAVEFLOW_CONFIGS[key]
+    sd = synthetic.waveflow_state_dict(cfg, seed=seed)
+    m = WaveGlow(**cfg)
+    m.load_state_dict(synthetic.to_torch(sd))
+    return m.cuda().eval(), cfg, sd
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["toy", "toy_odd", "full_short"])
+def test_hip_matches_reference_golden(hip_lib_path, name):
+    g, cfg, _ = _load(name)
+    m, _, _ = _model(str(g["config_key"]), int(g["seed"]))
+    melp = torch.from_numpy(np.pad(g["mel"], ((0, 0), (0, 0), (0, 1)))).cuda()
+    audio, _ = m.inverse(torch.from_numpy(g["z"]).cuda(), melp)
+    assert not audio.is_cuda                                   # return_CPU=True default (ax:348-349)
+    err = rms_rel_err(audio.numpy(), g["inverse_full"])
+    print(f"waveflow {name}: rms rel err vs reference = {err:.3e}")
+    assert err < WAVE_TOL
+
+
+@pytest.mark.gpu
+def test_hip_infer_contract_and_ragged_vs_oracle(hip_lib_path):
+    m, cfg, sd = _model("toy", 9)
+    B, Fr = 2, 37                                              # L = 36*256/8 ... ragged vs the 256-step tile
+    mel = synthetic.synthetic_mel(B, Fr, seed=3)
+    torch.manual_seed(4)
+    out = m.infer(torch.from_numpy(mel).cuda(), sigma=0.8, return_CPU=False)
+    assert out.is_cuda and out.shape == (B, (Fr - 1) * 256) and torch.isfinite(out).all()
+    z = np.random.default_rng(5).standard_normal((B, Fr * 256)).astype(np.float32) * np.float32(0.8)
+    melp = np.pad(mel, ((0, 0), (0, 0), (0, 1)))
+    ref = wf.waveflow_inverse(sd, cfg, z, melp)
+    got, _ = m.inverse(torch.from_numpy(z).cuda(), torch.from_numpy(melp).cuda())
+    assert rms_rel_err(got.numpy(), ref) < WAVE_TOL
+    # NaN in the latent is zeroed per flow, like ax:333-334
+    z2 = z.copy()
+    z2[0, 100] = np.nan
+    got2, _ = m.inverse(torch.from_numpy(z2).cuda(), torch.from_numpy(melp).cuda())
+    assert torch.isfinite(got2).all()
