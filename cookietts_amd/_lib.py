@@ -57,6 +57,25 @@ class WaveFlowFlowWeights(C.Structure):
                 ("end_w", _FP), ("end_b", _FP)]
 
 
+class TacoDecoderConfig(C.Structure):
+    """``ctts_taco_decoder_config``."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "n_mel_channels", "memory_in_dim", "memory_dim", "attention_dim", "attention_rnn_dim", "decoder_rnn_dim",
+        "second_decoder_rnn_dim", "prenet_dim", "location_n_filters", "location_kernel_size", "window_range")]
+
+
+class LstmWeights(C.Structure):
+    _fields_ = [("w_ih", _FP), ("w_hh", _FP), ("b_ih", _FP), ("b_hh", _FP)]
+
+
+class TacoDecoderWeights(C.Structure):
+    _fields_ = [("bottleneck_w", _FP), ("memory_layer_w", _FP), ("query_w", _FP), ("v_w", _FP), ("loc_conv_w", _FP),
+                ("loc_dense_w", _FP), ("prenet_w1", _FP), ("prenet_w2", _FP),
+                ("att_rnn", LstmWeights), ("dec_rnn", LstmWeights), ("dec2_rnn", LstmWeights),
+                ("proj_w", _FP), ("proj_b", _FP), ("gate_w", _FP), ("gate_b", _FP),
+                ("windowed_att_pos_offset", C.c_float), ("exp_smoothing_factor", C.c_float)]
+
+
 # name -> (restype, argtypes); kept in one table so tests can check every symbol the
 # header declares is exported.
 _CFG = C.POINTER(WaveGlowConfig)
@@ -79,6 +98,13 @@ SIGNATURES = {
     "ctts_waveflow_workspace_bytes": (C.c_size_t, [C.POINTER(WaveFlowConfig), C.c_int32, C.c_int32]),
     "ctts_waveflow_inverse_f32": (C.c_int, [C.POINTER(WaveFlowConfig), _FP, _FP, _FP, _FP, C.c_int32, C.c_int32,
                                             C.c_int32, _FP, C.c_size_t, _FP]),
+    "ctts_taco_decoder_packed_bytes": (C.c_size_t, [C.POINTER(TacoDecoderConfig)]),
+    "ctts_taco_decoder_pack": (C.c_int, [C.POINTER(TacoDecoderConfig), C.POINTER(TacoDecoderWeights), _FP, _FP]),
+    "ctts_taco_decoder_workspace_bytes": (C.c_size_t, [C.POINTER(TacoDecoderConfig), C.c_int32, C.c_int32]),
+    "ctts_taco_decoder_init_f32": (C.c_int, [C.POINTER(TacoDecoderConfig), _FP, _FP, _FP, C.c_int32, C.c_int32, _FP,
+                                             C.c_size_t, _FP]),
+    "ctts_taco_decoder_steps_f32": (C.c_int, [C.POINTER(TacoDecoderConfig), _FP, _FP, _FP, _FP, _FP, C.c_int32,
+                                              C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP, _FP]),
     "ctts_stft_packed_bytes": (C.c_size_t, [C.POINTER(StftConfig)]),
     "ctts_stft_pack": (C.c_int, [C.POINTER(StftConfig), _FP, _FP, _FP, _FP]),
     "ctts_stft_workspace_bytes": (C.c_size_t, [C.POINTER(StftConfig), C.c_int32, C.c_int32]),

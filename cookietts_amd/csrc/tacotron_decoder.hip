@@ -1,0 +1,557 @@
+// Tacotron2-TM decoder loop (model.py:668-767, 851-916) for gfx950.
+//
+// One mel frame per step, strictly sequential, batch of a few utterances: every step re-reads the
+// 27 M LSTM/projection weights (108 MB fp32), so the step is bound by weight streaming (HBM /
+// Infinity Cache), not by arithmetic.  Round-1 structure: five dependent launches per step
+//   lstm_step (attention RNN) -> attention_step -> lstm_step (decoder RNN) -> lstm_step (2nd decoder RNN)
+//   -> project_prenet (mel + gate projection, next step's prenet)
+// each sized so its weight stream is spread over ~256 workgroups (one per CU):
+//   lstm_step: a workgroup owns R hidden units; wave g streams the R rows of gate g (i,f,g,o) of W_ih|W_hh
+//   with 16-byte loads against the batch's input vectors staged in LDS, 64-lane shuffle reductions, then
+//   the cell update for its units - the gate pre-activations never leave the CU.
+//   attention_step: one workgroup per utterance; windowed attention (+-16 tokens) means only 33
+//   energies are finite, so location conv, energies, softmax (wave-level reductions), context and the
+//   expected position are computed for the window only; weights outside it are exact zeros.
+#include "common.h"
+
+namespace ctts {
+namespace {
+
+constexpr size_t ALIGN_F = 64;
+inline size_t align_up(size_t v) { return (v + ALIGN_F - 1) / ALIGN_F * ALIGN_F; }
+constexpr int MAX_NB = 4;
+
+struct DecPlan {
+    ctts_taco_decoder_config c;
+    int I_att, I_dec, I_d2, Dproj;
+    size_t bottleneck_wT, memory_wT, query_w, v_w, loc_conv_w, loc_dense_w, prenet_w1T, prenet_w2T;
+    size_t att[4], dec[4], d2[4];
+    size_t proj_w, proj_b, scalars;   // proj rows: n_mel mel rows then the gate row; scalars: offset, smoothing
+    size_t total;
+};
+
+int make_dec_plan(const ctts_taco_decoder_config* cfg, DecPlan& p) {
+    CTTS_CHECK_ARG(cfg != nullptr, "decoder config is NULL");
+    p.c = *cfg;
+    const auto& c = p.c;
+    CTTS_CHECK_ARG(c.n_mel_channels >= 1 && c.n_mel_channels <= 256, "n_mel_channels=%d", c.n_mel_channels);
+    CTTS_CHECK_ARG(c.prenet_dim == 256, "prenet_dim=%d (kernel is built for 256)", c.prenet_dim);
+    CTTS_CHECK_ARG(c.memory_dim % 4 == 0 && c.attention_rnn_dim % 4 == 0 && c.decoder_rnn_dim % 4 == 0 &&
+                   c.second_decoder_rnn_dim == c.decoder_rnn_dim, "rnn dims must be multiples of 4 and Rd2 == Rd");
+    CTTS_CHECK_ARG(c.attention_dim >= 1 && c.attention_dim <= 256 && c.location_n_filters >= 1 &&
+                   c.location_n_filters <= 64 && c.location_kernel_size % 2 == 1 && c.location_kernel_size <= 63,
+                   "attention shape");
+    CTTS_CHECK_ARG(c.window_range >= 1 && c.window_range <= 31, "window_range=%d", c.window_range);
+    CTTS_CHECK_ARG(c.memory_in_dim >= 1, "memory_in_dim");
+    p.I_att = c.prenet_dim + c.memory_dim + c.decoder_rnn_dim;
+    p.I_dec = c.attention_rnn_dim + c.memory_dim;
+    p.I_d2 = c.decoder_rnn_dim;
+    p.Dproj = c.second_decoder_rnn_dim + c.memory_dim;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o = align_up(o + n); return r; };
+    p.bottleneck_wT = take((size_t)c.memory_in_dim * c.memory_dim);
+    p.memory_wT = take((size_t)c.memory_dim * c.attention_dim);
+    p.query_w = take((size_t)c.attention_dim * c.attention_rnn_dim);
+    p.v_w = take(c.attention_dim);
+    p.loc_conv_w = take((size_t)c.location_n_filters * 2 * c.location_kernel_size);
+    p.loc_dense_w = take((size_t)c.attention_dim * c.location_n_filters);
+    p.prenet_w1T = take((size_t)c.n_mel_channels * c.prenet_dim);
+    p.prenet_w2T = take((size_t)c.prenet_dim * c.prenet_dim);
+    auto lstm = [&](size_t* a, int I, int H) {
+        a[0] = take((size_t)4 * H * I); a[1] = take((size_t)4 * H * H); a[2] = take(4 * H); a[3] = take(4 * H);
+    };
+    lstm(p.att, p.I_att, c.attention_rnn_dim);
+    lstm(p.dec, p.I_dec, c.decoder_rnn_dim);
+    lstm(p.d2, p.I_d2, c.second_decoder_rnn_dim);
+    p.proj_w = take((size_t)(c.n_mel_channels + 1) * p.Dproj);
+    p.proj_b = take(c.n_mel_channels + 1);
+    p.scalars = take(4);
+    p.total = o;
+    return CTTS_OK;
+}
+
+struct DecWs {
+    float *memory, *pm, *att_h[2], *att_c, *dec_h[2], *dec_c, *d2_h[2], *d2_c, *w, *cum, *ctx, *pos, *prenet;
+    int* lengths;
+    size_t total;
+};
+
+int pad_batch(int b) { return b <= 1 ? 1 : b <= 2 ? 2 : 4; }
+
+void dec_carve(const DecPlan& p, int batch, int T, float* base, DecWs& w) {
+    const auto& c = p.c;
+    const size_t NB = pad_batch(batch);
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o = align_up(o + n); return base ? base + r : nullptr; };
+    w.memory = take(NB * T * c.memory_dim);
+    w.pm = take(NB * T * c.attention_dim);
+    for (int i = 0; i < 2; ++i) w.att_h[i] = take(NB * c.attention_rnn_dim);
+    w.att_c = take(NB * c.attention_rnn_dim);
+    for (int i = 0; i < 2; ++i) w.dec_h[i] = take(NB * c.decoder_rnn_dim);
+    w.dec_c = take(NB * c.decoder_rnn_dim);
+    for (int i = 0; i < 2; ++i) w.d2_h[i] = take(NB * c.second_decoder_rnn_dim);
+    w.d2_c = take(NB * c.second_decoder_rnn_dim);
+    w.w = take(NB * T); w.cum = take(NB * T);
+    w.ctx = take(NB * c.memory_dim);
+    w.pos = take(NB);
+    w.prenet = take(NB * c.prenet_dim);
+    w.lengths = reinterpret_cast<int*>(take(NB));
+    w.total = o;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+// dst[k][o] = src[o][k]
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int O, int K) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)O * K) return;
+    const int k = i / O, o = i % O;
+    dst[i] = src[(size_t)o * K + k];
+}
+
+// out[r][o] = sum_k in[r][k] * WT[k][o]  (4 rows per workgroup share every weight load)
+__global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ in, const float* __restrict__ WT,
+                                                          float* __restrict__ out, int rows, int K, int O) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [4][K]
+    const int r0 = blockIdx.x * 4;
+    for (int i = threadIdx.x; i < 4 * K; i += 256) {
+        const int r = i / K, k = i % K;
+        xs[i] = (r0 + r < rows) ? in[(size_t)(r0 + r) * K + k] : 0.f;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < O; o += 256) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float w = WT[(size_t)k * O + o];
+            a0 = fmaf(xs[k], w, a0); a1 = fmaf(xs[K + k], w, a1);
+            a2 = fmaf(xs[2 * K + k], w, a2); a3 = fmaf(xs[3 * K + k], w, a3);
+        }
+        if (r0 + 0 < rows) out[(size_t)(r0 + 0) * O + o] = a0;
+        if (r0 + 1 < rows) out[(size_t)(r0 + 1) * O + o] = a1;
+        if (r0 + 2 < rows) out[(size_t)(r0 + 2) * O + o] = a2;
+        if (r0 + 3 < rows) out[(size_t)(r0 + 3) * O + o] = a3;
+    }
+}
+
+// ---- LSTM cell step ------------------------------------------------------------------
+// inputs in0|in1|in2 are [NB][n_i] row-major pieces of the concatenated cell input.
+template <int NB, int R>
+__global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict__ Wih, const float* __restrict__ Whh,
+                                                        const float* __restrict__ bih, const float* __restrict__ bhh,
+                                                        const float* __restrict__ in0, int n0,
+                                                        const float* __restrict__ in1, int n1,
+                                                        const float* __restrict__ in2, int n2,
+                                                        const float* __restrict__ h_old, float* __restrict__ h_new,
+                                                        float* __restrict__ c, const float* __restrict__ h_add,
+                                                        int I, int H) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int K = I + H;
+    float* xs = smem;                       // [NB][K]   cell input | previous hidden
+    float* gates = smem + NB * K;           // [4][R][NB]
+    const int t = threadIdx.x, lane = t & 63, g = t >> 6;
+    const int u0 = blockIdx.x * R;
+    for (int i = t; i < NB * K; i += 256) {
+        const int b = i / K, k = i % K;
+        float v;
+        if (k < n0) v = in0[b * n0 + k];
+        else if (k < n0 + n1) v = in1[b * n1 + (k - n0)];
+        else if (k < I) v = in2[b * n2 + (k - n0 - n1)];
+        else v = h_old[b * H + (k - I)];
+        xs[i] = v;
+    }
+    __syncthreads();
+    float acc[R][NB];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
+    const float* wr = Wih + (size_t)(g * H + u0) * I;
+    for (int k = lane * 4; k < I; k += 256) {
+        float4 xv[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) xv[b] = *reinterpret_cast<const float4*>(xs + b * K + k);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float4 w = *reinterpret_cast<const float4*>(wr + (size_t)r * I + k);
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                acc[r][b] += w.x * xv[b].x + w.y * xv[b].y + w.z * xv[b].z + w.w * xv[b].w;
+        }
+    }
+    const float* wh = Whh + (size_t)(g * H + u0) * H;
+    for (int k = lane * 4; k < H; k += 256) {
+        float4 xv[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) xv[b] = *reinterpret_cast<const float4*>(xs + b * K + I + k);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float4 w = *reinterpret_cast<const float4*>(wh + (size_t)r * H + k);
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                acc[r][b] += w.x * xv[b].x + w.y * xv[b].y + w.z * xv[b].z + w.w * xv[b].w;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float s = wave_sum(acc[r][b]);
+            if (lane == 0) gates[(g * R + r) * NB + b] = s + bih[g * H + u0 + r] + bhh[g * H + u0 + r];
+        }
+    __syncthreads();
+    if (t < R * NB) {
+        const int r = t / NB, b = t % NB;
+        const float ig = sigmoidf_(gates[(0 * R + r) * NB + b]);
+        const float fg = sigmoidf_(gates[(1 * R + r) * NB + b]);
+        const float gg = tanhf(gates[(2 * R + r) * NB + b]);
+        const float og = sigmoidf_(gates[(3 * R + r) * NB + b]);
+        const int idx = b * H + u0 + r;
+        const float cy = fg * c[idx] + ig * gg;
+        c[idx] = cy;
+        h_new[idx] = og * tanhf(cy);
+    }
+}
+
+// ---- attention step --------------------------------------------------------------------
+struct AttnArgs {
+    const float *Wq, *v, *Wloc, *Wd, *scalars;
+    const float *att_h, *memory, *pm;
+    float *w, *cum, *ctx, *pos, *align_out;
+    const int* lengths;
+    int T, A, Ra, Dm, F, K, R, step, max_steps;
+};
+
+__global__ __launch_bounds__(256) void attention_step_kernel(const AttnArgs a) {
+    __shared__ float q[256];
+    __shared__ float wcat[2][128];
+    __shared__ float wloc[64 * 2 * 63];
+    __shared__ float loc[64][65];
+    __shared__ float en[64];
+    __shared__ float wts[64];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int W = 2 * a.R + 1, padk = (a.K - 1) / 2;
+    // window start (model.py:131-140); round = half-to-even
+    const int len = a.lengths[b];
+    float cur = a.pos[b];
+    const float off = a.scalars[0];
+    if (off != 0.f) cur += off;
+    cur = fminf(fmaxf(cur, (float)a.R), (float)(len - 1 - a.R));
+    const int s = (int)rintf(fmaxf(cur - (float)a.R, 0.f));
+    // query projection: wave per row
+    {
+        const float* h = a.att_h + (size_t)b * a.Ra;
+        for (int r = wv; r < a.A; r += 4) {
+            const float* wr = a.Wq + (size_t)r * a.Ra;
+            float acc = 0.f;
+            for (int k = lane * 4; k < a.Ra; k += 256) {
+                const float4 w = *reinterpret_cast<const float4*>(wr + k);
+                const float4 x = *reinterpret_cast<const float4*>(h + k);
+                acc += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w;
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) q[r] = acc;
+        }
+    }
+    // previous / cumulative weights around the window, location conv filters
+    for (int i = t; i < 2 * (W + a.K - 1); i += 256) {
+        const int c = i / (W + a.K - 1), j = i % (W + a.K - 1);
+        const int pos = s - padk + j;
+        const float* src = c == 0 ? a.w : a.cum;
+        wcat[c][j] = (pos >= 0 && pos < a.T) ? src[(size_t)b * a.T + pos] : 0.f;
+    }
+    for (int i = t; i < a.F * 2 * a.K; i += 256) wloc[i] = a.Wloc[i];
+    __syncthreads();
+    for (int i = t; i < W * a.F; i += 256) {
+        const int tt = i / a.F, f = i % a.F;
+        float acc = 0.f;
+        for (int c = 0; c < 2; ++c)
+            for (int j = 0; j < a.K; ++j) acc = fmaf(wloc[(f * 2 + c) * a.K + j], wcat[c][tt + j], acc);
+        loc[tt][f] = acc;
+    }
+    __syncthreads();
+    // energies: one wave per window position, lanes over attention dims
+    for (int tt = wv; tt < W; tt += 4) {
+        const int pos = s + tt;
+        float e = 0.f;
+        if (pos < len && pos < a.T) {
+            for (int ad = lane; ad < a.A; ad += 64) {
+                const float* wd = a.Wd + (size_t)ad * a.F;
+                float acc = 0.f;
+                for (int f = 0; f < a.F; ++f) acc = fmaf(wd[f], loc[tt][f], acc);
+                acc += q[ad];
+                acc += a.pm[((size_t)b * a.T + pos) * a.A + ad];
+                e = fmaf(a.v[ad], tanhf(acc), e);
+            }
+            e = wave_sum(e);
+        } else {
+            e = -INFINITY;
+        }
+        if (lane == 0) en[tt] = e;
+    }
+    __syncthreads();
+    if (wv == 0) {     // softmax over the window with wave-level reductions
+        const float e = lane < W ? en[lane] : -INFINITY;
+        const float m = wave_max(e);
+        const float pexp = lane < W ? expf(e - m) : 0.f;
+        const float sum = wave_sum(pexp);
+        const float wgt = pexp / sum;
+        if (lane < W) wts[lane] = wgt;
+        const float np = wave_sum(lane < W ? wgt * (float)(s + lane) : 0.f);
+        if (lane == 0) {
+            const float sf = sigmoidf_(a.scalars[1]);
+            a.pos[b] = a.pos[b] * sf + np * (1.0f - sf);
+        }
+    }
+    __syncthreads();
+    for (int d = t; d < a.Dm; d += 256) {
+        float acc = 0.f;
+        for (int tt = 0; tt < W; ++tt) {
+            const int pos = s + tt;
+            if (pos < a.T) acc = fmaf(wts[tt], a.memory[((size_t)b * a.T + pos) * a.Dm + d], acc);
+        }
+        a.ctx[(size_t)b * a.Dm + d] = acc;
+    }
+    for (int p = t; p < a.T; p += 256) {
+        const float wgt = (p >= s && p < s + W) ? wts[p - s] : 0.f;
+        a.w[(size_t)b * a.T + p] = wgt;
+        a.cum[(size_t)b * a.T + p] += wgt;
+        a.align_out[((size_t)b * a.max_steps + a.step) * a.T + p] = wgt;
+    }
+}
+
+// ---- projection + next prenet ------------------------------------------------------------
+struct ProjArgs {
+    const float *Wp, *bp, *W1T, *W2T;
+    const float *dec_h, *d2_h, *ctx;
+    const unsigned char* keep;       // masks of the NEXT step: [2][B][P], or NULL on the last step
+    float *mel_out, *gate_out, *prenet_out;
+    int n_mel, Rd, Dm, P, B, step, max_steps;
+};
+
+__global__ __launch_bounds__(256) void project_prenet_kernel(const ProjArgs a) {
+    __shared__ __attribute__((aligned(16))) float v[2048];
+    __shared__ float mel[256];
+    __shared__ float a1[256];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int D = a.Rd + a.Dm;
+    for (int i = t; i < D; i += 256)
+        v[i] = i < a.Rd ? a.dec_h[(size_t)b * a.Rd + i] + a.d2_h[(size_t)b * a.Rd + i] : a.ctx[(size_t)b * a.Dm + (i - a.Rd)];
+    __syncthreads();
+    for (int r = wv; r <= a.n_mel; r += 4) {        // rows 0..n_mel-1 = mel, row n_mel = gate
+        const float* wr = a.Wp + (size_t)r * D;
+        float acc = 0.f;
+        for (int k = lane * 4; k < D; k += 256) {
+            const float4 w = *reinterpret_cast<const float4*>(wr + k);
+            const float4 x = *reinterpret_cast<const float4*>(v + k);
+            acc += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w;
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            acc += a.bp[r];
+            if (r < a.n_mel) {
+                mel[r] = acc;
+                a.mel_out[((size_t)b * a.n_mel + r) * a.max_steps + a.step] = acc;
+            } else {
+                a.gate_out[(size_t)b * a.max_steps + a.step] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    if (a.keep == nullptr) return;
+    // prenet of the next step: relu(W . x) * keep * 2 twice (model.py:187-190), P == 256 == blockDim
+    float acc = 0.f;
+    for (int k = 0; k < a.n_mel; ++k) acc = fmaf(a.W1T[(size_t)k * a.P + t], mel[k], acc);
+    a1[t] = fmaxf(acc, 0.f) * (a.keep[(size_t)b * a.P + t] ? 2.0f : 0.0f);
+    __syncthreads();
+    acc = 0.f;
+    for (int k = 0; k < a.P; ++k) acc = fmaf(a.W2T[(size_t)k * a.P + t], a1[k], acc);
+    a.prenet_out[(size_t)b * a.P + t] = fmaxf(acc, 0.f) * (a.keep[((size_t)a.B + b) * a.P + t] ? 2.0f : 0.0f);
+}
+
+template <int NB>
+int launch_lstm(const float* blob, const size_t* off, const float* in0, int n0, const float* in1, int n1,
+                const float* in2, int n2, const float* h_old, float* h_new, float* c, int I, int H, hipStream_t s) {
+    const size_t smem_base = (size_t)NB * (I + H) * sizeof(float);
+#define CTTS_LSTM_CASE(RR)                                                                                         \
+    if (H % RR == 0 && H / RR <= 320) {                                                                           \
+        const size_t smem = smem_base + 4 * RR * NB * sizeof(float);                                              \
+        hipLaunchKernelGGL((lstm_step_kernel<NB, RR>), dim3(H / RR), dim3(256), smem, s, blob + off[0],           \
+                           blob + off[1], blob + off[2], blob + off[3], in0, n0, in1, n1, in2, n2, h_old, h_new, c, \
+                           nullptr, I, H);                                                                         \
+        CTTS_CHECK_LAUNCH("lstm_step");                                                                            \
+        return CTTS_OK;                                                                                            \
+    }
+    CTTS_LSTM_CASE(1) CTTS_LSTM_CASE(2) CTTS_LSTM_CASE(3) CTTS_LSTM_CASE(4) CTTS_LSTM_CASE(5) CTTS_LSTM_CASE(6)
+    CTTS_LSTM_CASE(8)
+#undef CTTS_LSTM_CASE
+    set_error("lstm_step: no tiling for hidden size %d", H);
+    return CTTS_E_ARG;
+}
+
+int launch_lstm_nb(int NB, const float* blob, const size_t* off, const float* in0, int n0, const float* in1, int n1,
+                   const float* in2, int n2, const float* h_old, float* h_new, float* c, int I, int H, hipStream_t s) {
+    switch (NB) {
+        case 1: return launch_lstm<1>(blob, off, in0, n0, in1, n1, in2, n2, h_old, h_new, c, I, H, s);
+        case 2: return launch_lstm<2>(blob, off, in0, n0, in1, n1, in2, n2, h_old, h_new, c, I, H, s);
+        default: return launch_lstm<4>(blob, off, in0, n0, in1, n1, in2, n2, h_old, h_new, c, I, H, s);
+    }
+}
+
+}  // namespace
+}  // namespace ctts
+
+using namespace ctts;
+
+extern "C" {
+
+size_t ctts_taco_decoder_packed_bytes(const ctts_taco_decoder_config* cfg) {
+    DecPlan p;
+    if (make_dec_plan(cfg, p)) return 0;
+    return p.total * sizeof(float);
+}
+
+int ctts_taco_decoder_pack(const ctts_taco_decoder_config* cfg, const ctts_taco_decoder_weights* w, void* packed,
+                           void* stream) {
+    DecPlan p;
+    int rc = make_dec_plan(cfg, p); if (rc) return rc;
+    CTTS_CHECK_ARG(w && packed, "decoder pack: NULL pointer");
+    const auto& c = p.c;
+    hipStream_t s = as_stream(stream);
+    float* blob = static_cast<float*>(packed);
+    auto copy = [&](size_t off, const float* src, size_t n) -> int {
+        CTTS_CHECK_ARG(src != nullptr, "decoder pack: NULL weight pointer");
+        CTTS_CHECK_HIP(hipMemcpyAsync(blob + off, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return CTTS_OK;
+    };
+    auto transpose = [&](size_t off, const float* src, int O, int K) -> int {
+        CTTS_CHECK_ARG(src != nullptr, "decoder pack: NULL weight pointer");
+        const size_t n = (size_t)O * K;
+        hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, blob + off, O, K);
+        CTTS_CHECK_LAUNCH("transpose");
+        return CTTS_OK;
+    };
+    if ((rc = transpose(p.bottleneck_wT, w->bottleneck_w, c.memory_dim, c.memory_in_dim))) return rc;
+    if ((rc = transpose(p.memory_wT, w->memory_layer_w, c.attention_dim, c.memory_dim))) return rc;
+    if ((rc = copy(p.query_w, w->query_w, (size_t)c.attention_dim * c.attention_rnn_dim))) return rc;
+    if ((rc = copy(p.v_w, w->v_w, c.attention_dim))) return rc;
+    if ((rc = copy(p.loc_conv_w, w->loc_conv_w, (size_t)c.location_n_filters * 2 * c.location_kernel_size))) return rc;
+    if ((rc = copy(p.loc_dense_w, w->loc_dense_w, (size_t)c.attention_dim * c.location_n_filters))) return rc;
+    if ((rc = transpose(p.prenet_w1T, w->prenet_w1, c.prenet_dim, c.n_mel_channels))) return rc;
+    if ((rc = transpose(p.prenet_w2T, w->prenet_w2, c.prenet_dim, c.prenet_dim))) return rc;
+    auto lstm = [&](const size_t* off, const ctts_lstm_weights& l, int I, int H) -> int {
+        int r;
+        if ((r = copy(off[0], l.w_ih, (size_t)4 * H * I))) return r;
+        if ((r = copy(off[1], l.w_hh, (size_t)4 * H * H))) return r;
+        if ((r = copy(off[2], l.b_ih, 4 * H))) return r;
+        return copy(off[3], l.b_hh, 4 * H);
+    };
+    if ((rc = lstm(p.att, w->att_rnn, p.I_att, c.attention_rnn_dim))) return rc;
+    if ((rc = lstm(p.dec, w->dec_rnn, p.I_dec, c.decoder_rnn_dim))) return rc;
+    if ((rc = lstm(p.d2, w->dec2_rnn, p.I_d2, c.second_decoder_rnn_dim))) return rc;
+    if ((rc = copy(p.proj_w, w->proj_w, (size_t)c.n_mel_channels * p.Dproj))) return rc;
+    if ((rc = copy(p.proj_w + (size_t)c.n_mel_channels * p.Dproj, w->gate_w, p.Dproj))) return rc;
+    if ((rc = copy(p.proj_b, w->proj_b, c.n_mel_channels))) return rc;
+    if ((rc = copy(p.proj_b + c.n_mel_channels, w->gate_b, 1))) return rc;
+    const float sc[4] = {w->windowed_att_pos_offset, w->exp_smoothing_factor, 0.f, 0.f};
+    CTTS_CHECK_HIP(hipMemcpyAsync(blob + p.scalars, sc, sizeof(sc), hipMemcpyHostToDevice, s));
+    CTTS_CHECK_HIP(hipStreamSynchronize(s));     // `sc` is a stack temporary
+    return CTTS_OK;
+}
+
+size_t ctts_taco_decoder_workspace_bytes(const ctts_taco_decoder_config* cfg, int32_t batch, int32_t text_len) {
+    DecPlan p; DecWs w;
+    if (make_dec_plan(cfg, p) || batch < 1 || batch > MAX_NB || text_len < 1) return 0;
+    dec_carve(p, batch, text_len, nullptr, w);
+    return w.total * sizeof(float);
+}
+
+int ctts_taco_decoder_init_f32(const ctts_taco_decoder_config* cfg, const void* packed, const float* memory_in,
+                               const int32_t* lengths, int32_t batch, int32_t text_len, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    DecPlan p; DecWs w;
+    int rc = make_dec_plan(cfg, p); if (rc) return rc;
+    CTTS_CHECK_ARG(packed && memory_in && lengths && workspace, "decoder init: NULL pointer");
+    CTTS_CHECK_ARG(batch >= 1 && batch <= MAX_NB, "decoder init: batch=%d (1..%d built)", batch, MAX_NB);
+    CTTS_CHECK_ARG(text_len >= 1, "decoder init: text_len=%d", text_len);
+    dec_carve(p, batch, text_len, static_cast<float*>(workspace), w);
+    if (w.total * sizeof(float) > workspace_bytes) {
+        set_error("decoder init: workspace %zu bytes < required %zu", workspace_bytes, w.total * sizeof(float));
+        return CTTS_E_WORKSPACE;
+    }
+    const auto& c = p.c;
+    hipStream_t s = as_stream(stream);
+    const float* blob = static_cast<const float*>(packed);
+    CTTS_CHECK_HIP(hipMemsetAsync(workspace, 0, w.total * sizeof(float), s));
+    CTTS_CHECK_HIP(hipMemcpyAsync(w.lengths, lengths, batch * sizeof(int), hipMemcpyDeviceToDevice, s));
+    const int rows = batch * text_len;
+    CTTS_CHECK_ARG((size_t)4 * c.memory_in_dim * sizeof(float) <= 64 * 1024, "decoder init: memory_in_dim too large");
+    hipLaunchKernelGGL(linear_rows_kernel, dim3((rows + 3) / 4), dim3(256), (size_t)4 * c.memory_in_dim * sizeof(float), s,
+                       memory_in, blob + p.bottleneck_wT, w.memory, rows, c.memory_in_dim, c.memory_dim);
+    CTTS_CHECK_LAUNCH("memory_bottleneck");
+    hipLaunchKernelGGL(linear_rows_kernel, dim3((rows + 3) / 4), dim3(256), (size_t)4 * c.memory_dim * sizeof(float), s,
+                       w.memory, blob + p.memory_wT, w.pm, rows, c.memory_dim, c.attention_dim);
+    CTTS_CHECK_LAUNCH("memory_layer");
+    return CTTS_OK;
+}
+
+int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void* packed, const uint8_t* keep_masks,
+                                float* mel_out, float* gate_out, float* align_out, int32_t batch, int32_t text_len,
+                                int32_t step0, int32_t n_steps, int32_t max_steps, void* workspace, void* stream) {
+    DecPlan p; DecWs w;
+    int rc = make_dec_plan(cfg, p); if (rc) return rc;
+    CTTS_CHECK_ARG(packed && keep_masks && mel_out && gate_out && align_out && workspace, "decoder steps: NULL pointer");
+    CTTS_CHECK_ARG(batch >= 1 && batch <= MAX_NB && step0 >= 0 && n_steps >= 0 && step0 + n_steps <= max_steps,
+                   "decoder steps: batch=%d step0=%d n_steps=%d max_steps=%d", batch, step0, n_steps, max_steps);
+    dec_carve(p, batch, text_len, static_cast<float*>(workspace), w);
+    const auto& c = p.c;
+    const int NB = pad_batch(batch);
+    hipStream_t s = as_stream(stream);
+    const float* blob = static_cast<const float*>(packed);
+    for (int step = step0; step < step0 + n_steps; ++step) {
+        const int cur = step & 1, nxt = cur ^ 1;    // h ping-pong: read [cur], write [nxt]
+        // attention RNN on [prenet | context | decoder hidden]   (model.py:707-717)
+        rc = launch_lstm_nb(NB, blob, p.att, w.prenet, c.prenet_dim, w.ctx, c.memory_dim, w.dec_h[cur], c.decoder_rnn_dim,
+                            w.att_h[cur], w.att_h[nxt], w.att_c, p.I_att, c.attention_rnn_dim, s);
+        if (rc) return rc;
+        AttnArgs a{};
+        a.Wq = blob + p.query_w; a.v = blob + p.v_w; a.Wloc = blob + p.loc_conv_w; a.Wd = blob + p.loc_dense_w;
+        a.scalars = blob + p.scalars;
+        a.att_h = w.att_h[nxt]; a.memory = w.memory; a.pm = w.pm;
+        a.w = w.w; a.cum = w.cum; a.ctx = w.ctx; a.pos = w.pos; a.align_out = align_out; a.lengths = w.lengths;
+        a.T = text_len; a.A = c.attention_dim; a.Ra = c.attention_rnn_dim; a.Dm = c.memory_dim;
+        a.F = c.location_n_filters; a.K = c.location_kernel_size; a.R = c.window_range;
+        a.step = step; a.max_steps = max_steps;
+        hipLaunchKernelGGL(attention_step_kernel, dim3(batch), dim3(256), 0, s, a);
+        CTTS_CHECK_LAUNCH("attention_step");
+        // decoder RNN on [attention hidden | context], second decoder RNN on the first's output
+        rc = launch_lstm_nb(NB, blob, p.dec, w.att_h[nxt], c.attention_rnn_dim, w.ctx, c.memory_dim, nullptr, 0,
+                            w.dec_h[cur], w.dec_h[nxt], w.dec_c, p.I_dec, c.decoder_rnn_dim, s);
+        if (rc) return rc;
+        rc = launch_lstm_nb(NB, blob, p.d2, w.dec_h[nxt], c.decoder_rnn_dim, nullptr, 0, nullptr, 0, w.d2_h[cur],
+                            w.d2_h[nxt], w.d2_c, p.I_d2, c.second_decoder_rnn_dim, s);
+        if (rc) return rc;
+        ProjArgs q{};
+        q.Wp = blob + p.proj_w; q.bp = blob + p.proj_b; q.W1T = blob + p.prenet_w1T; q.W2T = blob + p.prenet_w2T;
+        q.dec_h = w.dec_h[nxt]; q.d2_h = w.d2_h[nxt]; q.ctx = w.ctx;
+        q.keep = step + 1 < max_steps ? keep_masks + (size_t)(step + 1) * 2 * batch * c.prenet_dim : nullptr;
+        q.mel_out = mel_out; q.gate_out = gate_out; q.prenet_out = w.prenet;
+        q.n_mel = c.n_mel_channels; q.Rd = c.second_decoder_rnn_dim; q.Dm = c.memory_dim; q.P = c.prenet_dim;
+        q.B = batch; q.step = step; q.max_steps = max_steps;
+        hipLaunchKernelGGL(project_prenet_kernel, dim3(batch), dim3(256), 0, s, q);
+        CTTS_CHECK_LAUNCH("project_prenet");
+    }
+    return CTTS_OK;
+}
+
+}  // extern "C"

@@ -29,6 +29,10 @@ __all__ = [
     "synthetic_mel",
     "synthetic_noise",
     "to_torch",
+    "tacotron_hparams",
+    "tacotron_memory_in_dim",
+    "tacotron_state_dict",
+    "prenet_dropout_masks",
 ]
 
 
@@ -202,3 +206,88 @@ def to_torch(sd, device=None):
     import torch
     return {k: torch.from_numpy(np.ascontiguousarray(v)).to(device) if device else torch.from_numpy(np.ascontiguousarray(v))
             for k, v in sd.items()}
+
+
+# ----------------------------------------------------------------------------- Tacotron2-TM ----
+def tacotron_hparams(**overrides):
+    """The model-shaping defaults of the reference's ``create_hparams()``
+    (_2_ttm/tacotron2_tm/hparams.py:139-279) as a plain attribute object, with ``fp16_run=False``.
+    (Importing hparams.py itself drags in the text frontend; only these values shape the model.)"""
+    from types import SimpleNamespace
+    hp = dict(
+        fp16_run=False, mask_padding=True, n_mel_channels=80, n_frames_per_step=1, context_frames=1,
+        gate_threshold=0.5, gate_delay=10, max_decoder_steps=3000,
+        n_symbols=179, symbols_embedding_dim=512,
+        encoder_speaker_embed_dim=64, encoder_concat_speaker_embed='before_conv', encoder_kernel_size=5,
+        encoder_n_convolutions=3, encoder_conv_hidden_dim=512, encoder_LSTM_dim=1024,
+        sylpsnet_layer_dims=[32, 32], emotion_classes=['neutral'] * 16,
+        torchMoji_attDim=2304, torchMoji_crushedDim=32, torchMoji_BatchNorm=True,
+        n_speakers=512, speaker_embedding_dim=256,
+        use_memory_bottleneck=True, memory_bottleneck_dim=512, memory_bottleneck_bias=False,
+        hide_startstop_tokens=False,
+        prenet_dim=256, prenet_layers=2, prenet_batchnorm=False, prenet_bn_momentum=0.5, p_prenet_dropout=0.5,
+        prenet_speaker_embed_dim=0, prenet_noise=0.0, prenet_blur_min=0.0, prenet_blur_max=0.0,
+        attention_rnn_dim=1280, AttRNN_hidden_dropout_type='dropout', p_AttRNN_hidden_dropout=0.10,
+        AttRNN_extra_decoder_input=True,
+        decoder_rnn_dim=768, DecRNN_hidden_dropout_type='dropout', p_DecRNN_hidden_dropout=0.25,
+        decoder_residual_connection=False, second_decoder_rnn_dim=768, second_decoder_residual_connection=True,
+        attention_type=0, attention_dim=192, windowed_attention_range=16, windowed_att_pos_offset=1.25,
+        windowed_att_pos_learned=True, attention_learned_temperature=False,
+        attention_location_n_filters=32, attention_location_kernel_size=31, num_att_mixtures=1,
+        attention_layers=1, normalize_attention_input=True, normalize_AttRNN_output=False,
+        use_postnet=True, postnet_embedding_dim=512, postnet_kernel_size=5, postnet_n_convolutions=6,
+        postnet_residual_connections=3, p_teacher_forcing=1.0, teacher_force_till=20, drop_frame_rate=0.0)
+    hp.update(overrides)
+    return SimpleNamespace(**hp)
+
+
+def tacotron_memory_in_dim(hp):
+    return hp.encoder_LSTM_dim + hp.speaker_embedding_dim + hp.torchMoji_crushedDim + 1
+
+
+def tacotron_state_dict(hp, seed=1234, shapes=None):
+    """Random-init state dict for the reference's ``Tacotron2`` (keys/shapes of its own
+    ``state_dict()``; ``shapes`` = {key: shape} from a constructed module, or None to derive them
+    from ``cookietts_amd.tacotron2.Tacotron2(hp)``).  Deterministic numpy recipe:
+    weights ~ U(+-1/sqrt(fan_in)), BatchNorm running stats non-trivial, the two zero-initialised
+    learnable scalars (decoder.exp_smoothing_factor, attention windowed_att_pos_offset) non-zero,
+    and the sylps head forced positive so log(pred_sylps) is finite."""
+    if shapes is None:
+        from .tacotron2 import Tacotron2
+        shapes = {k: tuple(v.shape) for k, v in Tacotron2(hp).state_dict().items()}
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for key in sorted(shapes):
+        shape = tuple(shapes[key])
+        if key.endswith("num_batches_tracked"):
+            sd[key] = np.zeros(shape, dtype=np.int64)
+        elif key.endswith("running_var"):
+            sd[key] = (0.5 + rng.random(shape, dtype=np.float32)).astype(np.float32)
+        elif key.endswith("running_mean"):
+            sd[key] = _uniform(rng, shape, 0.1)
+        elif key == "decoder.exp_smoothing_factor":
+            sd[key] = np.full(shape, 0.3, dtype=np.float32)
+        elif key.endswith("windowed_att_pos_offset"):
+            sd[key] = np.full(shape, 1.25, dtype=np.float32)
+        elif key == "sylps_net.res_weight":
+            sd[key] = np.asarray(0.01, dtype=np.float32).reshape(shape)
+        elif key == "encoder.sylps_layer.linear_layer.weight":
+            sd[key] = np.zeros(shape, dtype=np.float32)
+        elif key == "encoder.sylps_layer.linear_layer.bias":
+            sd[key] = np.full(shape, 4.0, dtype=np.float32)
+        elif ".1.weight" in key and ("convolutions" in key) or key == "tm_bn.weight":      # BatchNorm gamma
+            sd[key] = (0.8 + 0.4 * rng.random(shape, dtype=np.float32)).astype(np.float32)
+        elif "embedding" in key and key.endswith("weight"):
+            sd[key] = _uniform(rng, shape, 0.5)
+        elif len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            sd[key] = _uniform(rng, shape, 1.0 / np.sqrt(fan_in))
+        else:
+            sd[key] = _uniform(rng, shape, 0.05)
+    return sd
+
+
+def prenet_dropout_masks(n_steps, batch, prenet_dim=256, seed=1234):
+    """Keep-masks (uint8 0/1) for the prenet's always-on dropout (model.py:189-190): [steps, 2, B, dim]."""
+    rng = np.random.default_rng(seed + 15485863)
+    return (rng.random((n_steps, 2, batch, prenet_dim)) < 0.5).astype(np.uint8)

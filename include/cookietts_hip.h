@@ -187,6 +187,72 @@ int ctts_waveflow_inverse_f32(const ctts_waveflow_config* cfg, const void* packe
                               int32_t frames, void* workspace, size_t workspace_bytes,
                               void* stream);
 
+/* ---- Tacotron2-TM decoder loop: _2_ttm/tacotron2_tm/model.py:668-767, 851-916 -------------- */
+
+/* Shapes from hparams.py (:201-258).  Built topology = the repo defaults: attention_type 0 with
+ * windowed attention, AttRNN_extra_decoder_input=True, two decoder LSTMs with residual, 2-layer prenet. */
+typedef struct ctts_taco_decoder_config {
+    int32_t n_mel_channels;        /* 80 */
+    int32_t memory_in_dim;         /* 1313 = encoder 1024 + speaker 256 + sylzu 1 + torchMoji 32 */
+    int32_t memory_dim;            /* 512  memory_bottleneck_dim */
+    int32_t attention_dim;         /* 192 */
+    int32_t attention_rnn_dim;     /* 1280 */
+    int32_t decoder_rnn_dim;       /* 768 */
+    int32_t second_decoder_rnn_dim;/* 768 (== decoder_rnn_dim: residual) */
+    int32_t prenet_dim;            /* 256 */
+    int32_t location_n_filters;    /* 32 */
+    int32_t location_kernel_size;  /* 31 */
+    int32_t window_range;          /* 16 */
+} ctts_taco_decoder_config;
+
+typedef struct ctts_lstm_weights {   /* torch LSTMCell layout, gate order i,f,g,o (layers.py:308-372) */
+    const float* w_ih;  /* [4H][I] */
+    const float* w_hh;  /* [4H][H] */
+    const float* b_ih;  /* [4H] */
+    const float* b_hh;  /* [4H] */
+} ctts_lstm_weights;
+
+/* Dense fp32 device pointers in checkpoint layouts (state_dict keys decoder.*). */
+typedef struct ctts_taco_decoder_weights {
+    const float* bottleneck_w;    /* [memory_dim][memory_in_dim]   memory_bottleneck.bottleneck (no bias) */
+    const float* memory_layer_w;  /* [A][memory_dim]               attention_layer.memory_layer */
+    const float* query_w;         /* [A][Ra]                       attention_layer.query_layer */
+    const float* v_w;             /* [A]                           attention_layer.v */
+    const float* loc_conv_w;      /* [F][2][K]                     location_layer.location_conv */
+    const float* loc_dense_w;     /* [A][F]                        location_layer.location_dense */
+    const float* prenet_w1;       /* [P][n_mel]                    prenet.layers.0 (no bias) */
+    const float* prenet_w2;       /* [P][P]                        prenet.layers.1 */
+    ctts_lstm_weights att_rnn;    /* I = P + memory_dim + Rd, H = Ra */
+    ctts_lstm_weights dec_rnn;    /* I = Ra + memory_dim,     H = Rd */
+    ctts_lstm_weights dec2_rnn;   /* I = Rd,                  H = Rd2 */
+    const float* proj_w;          /* [n_mel][Rd2 + memory_dim]     linear_projection */
+    const float* proj_b;          /* [n_mel] */
+    const float* gate_w;          /* [Rd2 + memory_dim]            gate_layer */
+    const float* gate_b;          /* [1] */
+    float windowed_att_pos_offset;/* attention_layer.windowed_att_pos_offset (learned scalar) */
+    float exp_smoothing_factor;   /* decoder.exp_smoothing_factor (raw; sigmoid applied inside) */
+} ctts_taco_decoder_weights;
+
+size_t ctts_taco_decoder_packed_bytes(const ctts_taco_decoder_config* cfg);
+int ctts_taco_decoder_pack(const ctts_taco_decoder_config* cfg, const ctts_taco_decoder_weights* w,
+                           void* packed, void* stream);
+size_t ctts_taco_decoder_workspace_bytes(const ctts_taco_decoder_config* cfg, int32_t batch,
+                                         int32_t text_len);
+/* Decoder.inference prologue (model.py:866-877): memory bottleneck, processed_memory, zero states.
+ *   memory_in [B][text_len][memory_in_dim],  lengths [B] int32 (device). */
+int ctts_taco_decoder_init_f32(const ctts_taco_decoder_config* cfg, const void* packed,
+                               const float* memory_in, const int32_t* lengths, int32_t batch,
+                               int32_t text_len, void* workspace, size_t workspace_bytes,
+                               void* stream);
+/* Run decoder steps [step0, step0 + n_steps) (model.py:879-883 body = prenet + decode()).
+ *   keep_masks [max_steps][2][B][P] uint8: the prenet's always-on dropout keep-masks (model.py:189-190)
+ *   mel_out [B][n_mel][max_steps], gate_out [B][max_steps] (logits), align_out [B][max_steps][text_len]
+ * The stop rule (model.py:898-904) is evaluated by the caller on gate_out between calls. */
+int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void* packed,
+                                const uint8_t* keep_masks, float* mel_out, float* gate_out,
+                                float* align_out, int32_t batch, int32_t text_len, int32_t step0,
+                                int32_t n_steps, int32_t max_steps, void* workspace, void* stream);
+
 /* ---- STFT / mel frontend (utils/audio/stft.py) ------------------------------------------- */
 
 /* STFT.__init__ (stft.py:46-77) / TacotronSTFT.__init__ (:155-166) arguments that shape the path. */

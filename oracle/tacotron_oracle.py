@@ -1,0 +1,145 @@
+"""CPU oracle for the Tacotron2-TM mel loop (BASELINE config 5).
+
+TEST INFRASTRUCTURE ONLY (see oracle/waveglow_oracle.py header for the import rule).
+numpy fp32 restatement written from SURVEY.md §8(a) "Verified restatement of rows T5-T9" plus
+rows T2-T4, T10.  Reference lines followed (relative to /root/reference/CookieTTS/):
+  lstm_cell            utils/model/layers.py:308-372 (eval branch: gates i,f,g,o; no dropout/zoneout)
+  prenet               _2_ttm/tacotron2_tm/model.py:180-193 (no biases; dropout ALWAYS applied)
+  attention_step       model.py:93-161 + LocationLayer :49-65 (window mask :131-146, softmax, bmm, new_pos)
+  decoder_init         model.py:870-871 (MemoryBottleneck :319-332), :507-608 (zero states, memory_layer)
+  decoder_step         model.py:668-767
+  stop_step            model.py:879-904
+  decoder_inference    model.py:851-916
+  encoder / postnet / tacotron_inference  model.py:283-316, 218-228, 1044-1080,
+                       tacotron2_ssvae/nets/SylpsNet.py:52-61, untts/model.py:310-337 (eval BatchNorm)
+
+Parity pin: tests/golden/tacotron_*.npz = outputs of the reference's own ``Decoder.inference`` /
+``Tacotron2.inference`` (tests/golden/make_golden.py) with the prenet dropout masks captured.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+
+
+def _sig(x):
+    return (F32(1.0) / (F32(1.0) + np.exp(-x))).astype(F32)
+
+
+def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
+    g = (x @ w_ih.T + b_ih + h @ w_hh.T + b_hh).astype(F32)
+    H = h.shape[1]
+    i, f, gg, o = g[:, :H], g[:, H:2 * H], g[:, 2 * H:3 * H], g[:, 3 * H:]
+    c2 = (_sig(f) * c + _sig(i) * np.tanh(gg)).astype(F32)
+    h2 = (_sig(o) * np.tanh(c2)).astype(F32)
+    return h2, c2
+
+
+def prenet(sd, x, keep1, keep2):
+    """keep masks are 0/1; kept activations are scaled by 1/(1-p) = 2 (F.dropout p=0.5)."""
+    w1 = sd["decoder.prenet.layers.0.linear_layer.weight"]
+    w2 = sd["decoder.prenet.layers.1.linear_layer.weight"]
+    a = np.maximum(x @ w1.T, 0).astype(F32) * (keep1.astype(F32) * F32(2.0))
+    return np.maximum(a @ w2.T, 0).astype(F32) * (keep2.astype(F32) * F32(2.0))
+
+
+def decoder_init(sd, memory_in):
+    wb = sd["decoder.memory_bottleneck.bottleneck.linear_layer.weight"]
+    memory = (memory_in @ wb.T).astype(F32)
+    if "decoder.memory_bottleneck.bottleneck.linear_layer.bias" in sd:
+        memory = memory + sd["decoder.memory_bottleneck.bottleneck.linear_layer.bias"]
+    wm = sd["decoder.attention_layer.memory_layer.linear_layer.weight"]
+    return memory, (memory @ wm.T).astype(F32)
+
+
+def attention_step(sd, hp, att_h, memory, processed_memory, w_prev, cum, pos, lengths):
+    """Returns (context [B, mem], weights [B, T], new_pos [B])."""
+    B, T, _ = memory.shape
+    wloc = sd["decoder.attention_layer.location_layer.location_conv.conv.weight"]       # [F, 2, K]
+    wd = sd["decoder.attention_layer.location_layer.location_dense.linear_layer.weight"]  # [A, F]
+    wq = sd["decoder.attention_layer.query_layer.linear_layer.weight"]                  # [A, R]
+    v = sd["decoder.attention_layer.v.linear_layer.weight"][0]                          # [A]
+    K = wloc.shape[2]
+    padk = (K - 1) // 2
+    cat = np.stack([w_prev, cum], axis=1)                                               # [B, 2, T]
+    catp = np.pad(cat, ((0, 0), (0, 0), (padk, padk)))
+    loc = np.zeros((B, wloc.shape[0], T), dtype=F32)
+    for j in range(K):
+        loc += np.einsum("fc,bct->bft", wloc[:, :, j], catp[:, :, j:j + T]).astype(F32)
+    proc = (np.einsum("bft,af->bta", loc, wd) + (att_h @ wq.T)[:, None, :] + processed_memory).astype(F32)
+    e = (np.tanh(proc) @ v).astype(F32)                                                 # [B, T]
+    R = hp.windowed_attention_range
+    off = sd["decoder.attention_layer.windowed_att_pos_offset"].reshape(-1)[0] if \
+        "decoder.attention_layer.windowed_att_pos_offset" in sd else F32(0)
+    cur = (pos + off).astype(F32) if off != 0 else pos
+    cur = np.minimum(np.maximum(cur, F32(R)), (lengths - 1 - R).astype(F32))
+    start = np.rint(np.maximum(cur - F32(R), F32(0)))                                   # round half to even
+    end = start + 2 * R
+    t = np.arange(T)[None, :]
+    allowed = (t >= start[:, None]) & (t <= end[:, None]) & (t < lengths[:, None])
+    e = np.where(allowed, e, -np.inf).astype(F32)
+    m = e.max(axis=1, keepdims=True)
+    p = np.exp(e - m).astype(F32)
+    w = (p / p.sum(axis=1, keepdims=True)).astype(F32)
+    ctx = np.einsum("bt,btd->bd", w, memory).astype(F32)
+    new_pos = (w * np.arange(T, dtype=F32)[None, :]).sum(axis=1).astype(F32)
+    return ctx, w, new_pos
+
+
+def _lstm_params(sd, prefix):
+    return (sd[prefix + ".weight_ih"], sd[prefix + ".weight_hh"], sd[prefix + ".bias_ih"], sd[prefix + ".bias_hh"])
+
+
+def decoder_inference_steps(sd, hp, memory_in, lengths, keep_masks, n_steps):
+    """Run exactly ``n_steps`` decoder steps.  Returns mel [B, n_mel, T], gate logits [B, T], alignments
+    [B, T, txt_T].  ``keep_masks`` [n_steps, 2, B, prenet_dim] uint8."""
+    sd = {k: np.asarray(v) for k, v in sd.items()}
+    memory_in = np.asarray(memory_in, dtype=F32)
+    lengths = np.asarray(lengths).astype(np.int64)
+    B, T, _ = memory_in.shape
+    memory, pm = decoder_init(sd, memory_in)
+    Ra, Rd, Rd2 = hp.attention_rnn_dim, hp.decoder_rnn_dim, hp.second_decoder_rnn_dim
+    att_h = np.zeros((B, Ra), F32); att_c = np.zeros((B, Ra), F32)
+    dec_h = np.zeros((B, Rd), F32); dec_c = np.zeros((B, Rd), F32)
+    d2_h = np.zeros((B, Rd2), F32); d2_c = np.zeros((B, Rd2), F32)
+    w = np.zeros((B, T), F32); cum = np.zeros((B, T), F32)
+    ctx = np.zeros((B, memory.shape[2]), F32); pos = np.zeros((B,), F32)
+    x = np.zeros((B, hp.n_mel_channels), F32)
+    sf = _sig(sd["decoder.exp_smoothing_factor"].reshape(-1)[0].astype(F32))
+    wp, bp = sd["decoder.linear_projection.linear_layer.weight"], sd["decoder.linear_projection.linear_layer.bias"]
+    wg, bg = sd["decoder.gate_layer.linear_layer.weight"], sd["decoder.gate_layer.linear_layer.bias"]
+    mels, gates, aligns = [], [], []
+    for i in range(n_steps):
+        p = prenet(sd, x, keep_masks[i, 0], keep_masks[i, 1])
+        att_h, att_c = lstm_cell(np.concatenate([p, ctx, dec_h], axis=1), att_h, att_c,
+                                 *_lstm_params(sd, "decoder.attention_rnn"))
+        ctx, w, new_pos = attention_step(sd, hp, att_h, memory, pm, w, cum, pos, lengths)
+        pos = (pos * sf + new_pos * (F32(1.0) - sf)).astype(F32)
+        cum = (cum + w).astype(F32)
+        dec_h, dec_c = lstm_cell(np.concatenate([att_h, ctx], axis=1), dec_h, dec_c,
+                                 *_lstm_params(sd, "decoder.decoder_rnn"))
+        d2_h, d2_c = lstm_cell(dec_h, d2_h, d2_c, *_lstm_params(sd, "decoder.second_decoder_rnn"))
+        d = (dec_h + d2_h).astype(F32)
+        dc = np.concatenate([d, ctx], axis=1)
+        gate = (dc @ wg.T + bg).astype(F32)[:, 0]
+        mel = (dc @ wp.T + bp).astype(F32)
+        mels.append(mel); gates.append(gate); aligns.append(w)
+        x = mel
+    return (np.stack(mels, axis=2), np.stack(gates, axis=1), np.stack(aligns, axis=1))
+
+
+def stop_step(gate_logits, gate_threshold, gate_delay, max_decoder_steps):
+    """Number of steps the reference's loop executes (model.py:879-904) given per-step gate logits
+    [B, >= that many steps].  Returns n_steps (<= max_decoder_steps)."""
+    B, n = gate_logits.shape
+    sig_max = np.zeros(B, dtype=F32)
+    break_point = max_decoder_steps
+    for i in range(min(n, max_decoder_steps)):
+        if i > 4:
+            sig_max = np.maximum(_sig(gate_logits[:, i].astype(F32)), sig_max)
+        if sig_max.min() > gate_threshold:
+            break_point = min(break_point, i + gate_delay)
+        if i >= break_point:
+            return i + 1
+    return min(n, max_decoder_steps)

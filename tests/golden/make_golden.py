@@ -204,8 +204,75 @@ def make_waveflow():
         print(f"[golden] waveflow {name}: audio {audio.shape} rms={audio.std():.4f} -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def _ref_tacotron(hp, seed):
+    """Reference Tacotron2 with the recipe weights.  Shims: no-op RNNCellBase input checks
+    (removed in torch 2.x, called at utils/model/layers.py:375-379)."""
+    import json
+    import torch.nn.modules.rnn as rnn
+    if not hasattr(rnn.RNNCellBase, "check_forward_input"):
+        rnn.RNNCellBase.check_forward_input = lambda self, x: None
+        rnn.RNNCellBase.check_forward_hidden = lambda self, x, h, s='': None
+    from CookieTTS._2_ttm.tacotron2_tm import model as ref_model
+    torch.manual_seed(0)
+    m = ref_model.Tacotron2(hp)
+    shapes = {k: list(v.shape) for k, v in m.state_dict().items()}
+    with open(os.path.join(HERE, "tacotron_state_shapes.json"), "w") as f:
+        json.dump(shapes, f, indent=0, sort_keys=True)
+    sd = synthetic.tacotron_state_dict(hp, seed=seed, shapes=shapes)
+    res = m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    return m.eval(), ref_model, sd
+
+
+class _MaskedDropout:
+    """Stand-in for F.dropout inside the reference's model.py that applies OUR keep-masks to the prenet's
+    always-on dropout (model.py:189-190) so the golden is reproducible without torch's RNG."""
+
+    def __init__(self, masks):
+        self.masks, self.calls = masks, 0
+
+    def __call__(self, x, p=0.5, training=True, inplace=False):
+        if not training or p == 0:
+            return x
+        assert p == 0.5 and x.shape[-1] == self.masks.shape[-1]
+        step, layer = divmod(self.calls, 2)
+        self.calls += 1
+        keep = torch.from_numpy(self.masks[step, layer].astype(np.float32))
+        return x * keep * 2.0
+
+
+def make_tacotron():
+    torch.set_num_threads(8)
+    hp = synthetic.tacotron_hparams()
+    seed = 1234
+    model, ref_model, sd = _ref_tacotron(hp, seed)
+    rng = np.random.default_rng(99)
+    # ---- decoder-only golden: Decoder.inference on a synthetic memory, fixed number of steps
+    B, T_txt, n_steps = 2, 60, 14
+    lengths = np.array([60, 41], dtype=np.int64)
+    memory_in = (rng.standard_normal((B, T_txt, synthetic.tacotron_memory_in_dim(hp))) * 0.5).astype(np.float32)
+    masks = synthetic.prenet_dropout_masks(n_steps, B, hp.prenet_dim, seed=seed)
+    saved = ref_model.F.dropout
+    ref_model.F.dropout = _MaskedDropout(masks)
+    try:
+        model.decoder.max_decoder_steps = n_steps
+        model.decoder.gate_threshold = 2.0            # sigmoid never exceeds it: run all n_steps
+        with torch.no_grad():
+            mel, gate, align, _ = model.decoder.inference(torch.from_numpy(memory_in), torch.from_numpy(lengths))
+    finally:
+        ref_model.F.dropout = saved
+    path = os.path.join(HERE, "tacotron_decoder.npz")
+    np.savez_compressed(path, seed=seed, memory_in=memory_in, lengths=lengths, masks=masks,
+                        mel=mel.numpy().astype(np.float32), gate_sigmoid=gate.numpy().astype(np.float32),
+                        alignments=align.numpy().astype(np.float32))
+    print(f"[golden] tacotron_decoder: mel {tuple(mel.shape)} align {tuple(align.shape)} "
+          f"-> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["waveglow", "stft", "waveflow"]
+    which = sys.argv[1:] or ["waveglow", "stft", "waveflow", "tacotron"]
+    if "tacotron" in which:
+        make_tacotron()
     if "waveflow" in which:
         make_waveflow()
     if "waveglow" in which:

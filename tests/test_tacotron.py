@@ -1,0 +1,147 @@
+"""Tacotron2-TM decoder loop (config 5): oracle vs reference golden (CPU), HIP vs golden / oracle (GPU)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from cookietts_amd import synthetic
+from oracle import tacotron_oracle as to
+
+MEL_TOL = 1e-4            # BASELINE.json: mel L_inf <= 1e-4
+
+
+def _golden():
+    g = np.load(os.path.join(GOLDEN, "tacotron_decoder.npz"))
+    hp = synthetic.tacotron_hparams()
+    shapes = json.load(open(os.path.join(GOLDEN, "tacotron_state_shapes.json")))
+    return g, hp, synthetic.tacotron_state_dict(hp, seed=int(g["seed"]), shapes=shapes), shapes
+
+
+def test_oracle_matches_reference_decoder_golden():
+    g, hp, sd, _ = _golden()
+    mel, gate, align = to.decoder_inference_steps(sd, hp, g["memory_in"], g["lengths"], g["masks"], g["masks"].shape[0])
+    assert mel.shape == g["mel"].shape == (2, 80, 14)
+    assert np.abs(mel - g["mel"]).max() < 1e-6
+    assert np.abs(1 / (1 + np.exp(-gate)) - g["gate_sigmoid"]).max() < 1e-6
+    assert np.abs(align - g["alignments"]).max() < 1e-6
+    assert ((g["alignments"] > 0).sum(axis=2) == 33).all()        # +-16 window (model.py:131-146)
+    assert np.allclose(g["alignments"].sum(axis=2), 1.0, atol=1e-5)
+
+
+def test_host_module_tree_matches_reference_state_dict():
+    from cookietts_amd.tacotron2 import Tacotron2
+    _, hp, sd, shapes = _golden()
+    m = Tacotron2(hp)
+    own = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert own == shapes                                           # same keys, same shapes as the reference's
+    m.load_state_dict(synthetic.to_torch(sd))
+    assert synthetic.tacotron_state_dict(hp, seed=1234).keys() == sd.keys()
+
+
+def test_stop_rule_matches_reference_semantics():
+    """model.py:879-904: max of sigmoid(gate) tracked only for i > 4; stop gate_delay steps after ALL items crossed."""
+    from cookietts_amd.tacotron2 import stop_step
+    gates = np.full((2, 40), -5.0, dtype=np.float32)
+    gates[0, 2] = 9.0                      # ignored: i <= 4
+    gates[0, 10:] = 9.0
+    gates[1, 17] = 9.0                     # second item crosses at step 17 -> break_point = 17 + delay
+    for delay in (0, 3):
+        want = to.stop_step(gates, 0.5, delay, 1000)
+        assert want == 17 + delay + 1
+        n, state = None, None
+        for c0 in range(0, 40, 7):         # fed in blocks, like the device loop
+            n, state = stop_step(torch.from_numpy(gates[:, c0:c0 + 7]), 0.5, delay, 1000, state)
+            if n is not None:
+                break
+        assert n == want
+    assert to.stop_step(np.full((1, 12), -9.0, np.float32), 0.5, 0, 10) == 10      # max_decoder_steps cap
+
+
+def test_unsupported_hparams_fail_loudly():
+    from cookietts_amd.tacotron2 import Tacotron2
+    with pytest.raises(NotImplementedError):
+        Tacotron2(synthetic.tacotron_hparams(attention_type=1))
+    with pytest.raises(NotImplementedError):
+        Tacotron2(synthetic.tacotron_hparams(windowed_attention_range=0))
+
+
+def _model():
+    from cookietts_amd.tacotron2 import Tacotron2
+    g, hp, sd, _ = _golden()
+    m = Tacotron2(hp)
+    m.load_state_dict(synthetic.to_torch(sd))
+    return m.cuda().eval(), g, hp, sd
+
+
+@pytest.mark.gpu
+def test_hip_decoder_matches_reference_golden(hip_lib_path):
+    m, g, hp, sd = _model()
+    n = g["masks"].shape[0]
+    mel, gate, align, _ = m.decoder.inference(torch.from_numpy(g["memory_in"]).cuda(),
+                                              torch.from_numpy(g["lengths"]).cuda(),
+                                              keep_masks=g["masks"], fixed_steps=n)
+    mel, gate, align = mel.cpu().numpy(), gate.cpu().numpy(), align.cpu().numpy()
+    print("mel Linf vs reference:", np.abs(mel - g["mel"]).max())
+    assert np.abs(mel - g["mel"]).max() < MEL_TOL
+    assert np.abs(gate - g["gate_sigmoid"]).max() < MEL_TOL
+    assert np.abs(align - g["alignments"]).max() < MEL_TOL
+    assert ((align > 0).sum(axis=2) <= 33).all() and np.allclose(align.sum(axis=2), 1.0, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,lens", [(1, 20, [20]), (3, 45, [45, 17, 33]), (4, 200, [200, 195, 150, 100])])
+def test_hip_decoder_matches_oracle_shapes(hip_lib_path, B, T, lens):
+    """Short texts (window clamps: len-17 < 16), odd batch (padded to 4 internally), config-5 lengths."""
+    m, g, hp, sd = _model()
+    rng = np.random.default_rng(B * 1000 + T)
+    memory_in = (rng.standard_normal((B, T, synthetic.tacotron_memory_in_dim(hp))) * 0.5).astype(np.float32)
+    lengths = np.array(lens, dtype=np.int64)
+    n = 9
+    masks = synthetic.prenet_dropout_masks(n, B, seed=T)
+    ref_mel, ref_gate, ref_align = to.decoder_inference_steps(sd, hp, memory_in, lengths, masks, n)
+    mel, gate, align, _ = m.decoder.inference(torch.from_numpy(memory_in).cuda(), torch.from_numpy(lengths).cuda(),
+                                              keep_masks=masks, fixed_steps=n)
+    assert np.abs(mel.cpu().numpy() - ref_mel).max() < MEL_TOL
+    assert np.abs(align.cpu().numpy() - ref_align).max() < MEL_TOL
+    assert np.abs(gate.cpu().numpy() - 1 / (1 + np.exp(-ref_gate))).max() < MEL_TOL
+
+
+@pytest.mark.gpu
+def test_hip_decoder_stop_rule_and_chunking(hip_lib_path):
+    """Free-running inference: the device loop is cut at the step the reference's rule would stop at, and
+    chunked execution (stop check every 32 steps) equals one fixed run of the same length."""
+    m, g, hp, sd = _model()
+    with torch.no_grad():
+        m.decoder.gate_layer.linear_layer.bias.fill_(3.0)     # every gate > threshold -> stops at i = 5 + delay
+    m.decoder._invalidate()
+    m.decoder.gate_delay = 4
+    m.decoder.max_decoder_steps = 100
+    mem = torch.from_numpy(g["memory_in"]).cuda()
+    lens = torch.from_numpy(g["lengths"]).cuda()
+    masks = synthetic.prenet_dropout_masks(100, 2, seed=3)
+    mel, gate, align, _ = m.decoder.inference(mem, lens, keep_masks=masks)
+    assert mel.shape[2] == 5 + 4 + 1 and gate.shape == (2, 10) and align.shape == (2, 10, 60)
+    m.decoder.gate_threshold = 2.0                             # never stops: runs to max_decoder_steps in chunks
+    m.decoder.max_decoder_steps = 70
+    a = m.decoder.inference(mem, lens, keep_masks=masks)
+    b = m.decoder.inference(mem, lens, keep_masks=masks, fixed_steps=70)
+    assert a[0].shape[2] == 70 and torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+
+
+@pytest.mark.gpu
+def test_full_tacotron_inference_contract(hip_lib_path):
+    """Tacotron2.inference drop-in contract (model.py:1044-1080): dict keys and shapes."""
+    m, g, hp, sd = _model()
+    B, T = 2, 30
+    rng = np.random.default_rng(0)
+    text = torch.from_numpy(rng.integers(1, 179, size=(B, T))).cuda()
+    lens = torch.tensor([30, 22]).cuda()
+    spk = torch.tensor([0, 1]).cuda()
+    tm = torch.from_numpy(rng.standard_normal((B, 2304)).astype(np.float32)).cuda()
+    out = m.inference(text, lens, spk, tm, fixed_steps=12)
+    assert out["pred_mel_postnet"].shape == (B, 80, 12) and out["pred_gate"].shape == (B, 12)
+    assert out["alignments"].shape == (B, 12, T) and out["pred_sylps"].shape == (B, 1)
+    assert all(torch.isfinite(out[k]).all() for k in ("pred_mel_postnet", "pred_gate", "alignments"))
