@@ -24,7 +24,7 @@ constexpr int MAX_NB = 4;
 struct DecPlan {
     ctts_taco_decoder_config c;
     int I_att, I_dec, I_d2, Dproj;
-    size_t bottleneck_wT, memory_wT, query_w, v_w, loc_conv_w, loc_dense_w, prenet_w1T, prenet_w2T;
+    size_t bottleneck_wT, memory_wT, query_w, v_w, loc_conv_w, loc_dense_w, prenet_w1, prenet_w2;
     size_t att[4], dec[4], d2[4];
     size_t proj_w, proj_b, scalars;   // proj rows: n_mel mel rows then the gate row; scalars: offset, smoothing
     size_t total;
@@ -35,9 +35,11 @@ int make_dec_plan(const ctts_taco_decoder_config* cfg, DecPlan& p) {
     p.c = *cfg;
     const auto& c = p.c;
     CTTS_CHECK_ARG(c.n_mel_channels >= 1 && c.n_mel_channels <= 256, "n_mel_channels=%d", c.n_mel_channels);
-    CTTS_CHECK_ARG(c.prenet_dim == 256, "prenet_dim=%d (kernel is built for 256)", c.prenet_dim);
+    CTTS_CHECK_ARG(c.prenet_dim >= 4 && c.prenet_dim <= 256 && c.prenet_dim % 4 == 0 && c.n_mel_channels % 4 == 0,
+                   "prenet_dim=%d n_mel=%d (multiples of 4, prenet <= 256)", c.prenet_dim, c.n_mel_channels);
     CTTS_CHECK_ARG(c.memory_dim % 4 == 0 && c.attention_rnn_dim % 4 == 0 && c.decoder_rnn_dim % 4 == 0 &&
                    c.second_decoder_rnn_dim == c.decoder_rnn_dim, "rnn dims must be multiples of 4 and Rd2 == Rd");
+    CTTS_CHECK_ARG(c.attention_rnn_dim <= 1536 && c.second_decoder_rnn_dim + c.memory_dim <= 1536, "rnn dims exceed the 1536-wide staging");
     CTTS_CHECK_ARG(c.attention_dim >= 1 && c.attention_dim <= 256 && c.location_n_filters >= 1 &&
                    c.location_n_filters <= 64 && c.location_kernel_size % 2 == 1 && c.location_kernel_size <= 63,
                    "attention shape");
@@ -55,8 +57,8 @@ int make_dec_plan(const ctts_taco_decoder_config* cfg, DecPlan& p) {
     p.v_w = take(c.attention_dim);
     p.loc_conv_w = take((size_t)c.location_n_filters * 2 * c.location_kernel_size);
     p.loc_dense_w = take((size_t)c.attention_dim * c.location_n_filters);
-    p.prenet_w1T = take((size_t)c.n_mel_channels * c.prenet_dim);
-    p.prenet_w2T = take((size_t)c.prenet_dim * c.prenet_dim);
+    p.prenet_w1 = take((size_t)c.n_mel_channels * c.prenet_dim);
+    p.prenet_w2 = take((size_t)c.prenet_dim * c.prenet_dim);
     auto lstm = [&](size_t* a, int I, int H) {
         a[0] = take((size_t)4 * H * I); a[1] = take((size_t)4 * H * H); a[2] = take(4 * H); a[3] = take(4 * H);
     };
@@ -99,6 +101,14 @@ void dec_carve(const DecPlan& p, int batch, int T, float* base, DecWs& w) {
     w.total = o;
 }
 
+typedef float vfloat4 __attribute__((ext_vector_type(4)));
+// streaming (non-temporal) 16-byte load: the LSTM weight streams are read once per step and must not
+// evict the small re-used matrices (query / projection / prenet) from L2
+__device__ __forceinline__ float4 load4_nt(const float* p) {
+    const vfloat4 v = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -110,6 +120,41 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
     return v;
+}
+
+// y[r] = dot(W[r][:], x) for rows r0..r0+RB-1 at once: all RB*ceil(K/256) 16-byte weight loads of the
+// wave are issued before the first use, so the batch costs ~one memory latency instead of RB.
+// x lives in LDS.  K % 4 == 0.  Result valid in every lane.
+template <int RB, int KMAX>
+__device__ __forceinline__ void wave_dots(const float* __restrict__ W, size_t ldw, int r0, int rows, int K,
+                                          const float* xs, int lane, float (&out)[RB]) {
+    constexpr int NK = (KMAX + 255) / 256;
+    float4 w[RB][NK];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < NK; ++j) {
+            const int k = lane * 4 + j * 256;
+            w[i][j] = (r0 + i < rows && k < K) ? *reinterpret_cast<const float4*>(W + (size_t)(r0 + i) * ldw + k)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NK; ++j) {
+            const int k = lane * 4 + j * 256;
+            if (k < K) {
+                const float4 x = *reinterpret_cast<const float4*>(xs + k);
+                acc += w[i][j].x * x.x + w[i][j].y * x.y + w[i][j].z * x.z + w[i][j].w * x.w;
+            }
+        }
+        out[i] = acc;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int i = 0; i < RB; ++i) out[i] += __shfl_xor(out[i], off);
 }
 
 // dst[k][o] = src[o][k]
@@ -161,14 +206,31 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
     float* gates = smem + NB * K;           // [4][R][NB]
     const int t = threadIdx.x, lane = t & 63, g = t >> 6;
     const int u0 = blockIdx.x * R;
-    for (int i = t; i < NB * K; i += 256) {
-        const int b = i / K, k = i % K;
-        float v;
-        if (k < n0) v = in0[b * n0 + k];
-        else if (k < n0 + n1) v = in1[b * n1 + (k - n0)];
-        else if (k < I) v = in2[b * n2 + (k - n0 - n1)];
-        else v = h_old[b * H + (k - I)];
-        xs[i] = v;
+    // stage [cell input | previous hidden] for all NB items: 16-byte loads, SB of them in flight per thread
+    // (piece boundaries n0, n0+n1, I are multiples of 4)
+    {
+        constexpr int SB = 6;
+        const int K4 = K / 4, total4 = NB * K4;
+        for (int base = t; base < total4; base += 256 * SB) {
+            float4 v[SB];
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                const int i4 = base + j * 256;
+                const int ic = i4 < total4 ? i4 : 0;
+                const int b = ic / K4, k = (ic % K4) * 4;
+                const float* src;
+                if (k < n0) src = in0 + b * n0 + k;
+                else if (k < n0 + n1) src = in1 + b * n1 + (k - n0);
+                else if (k < I) src = in2 + b * n2 + (k - n0 - n1);
+                else src = h_old + b * H + (k - I);
+                v[j] = *reinterpret_cast<const float4*>(src);
+            }
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                const int i4 = base + j * 256;
+                if (i4 < total4) *reinterpret_cast<float4*>(xs + (size_t)i4 * 4) = v[j];
+            }
+        }
     }
     __syncthreads();
     float acc[R][NB];
@@ -176,32 +238,39 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
-    const float* wr = Wih + (size_t)(g * H + u0) * I;
-    for (int k = lane * 4; k < I; k += 256) {
-        float4 xv[NB];
+    // Weight streaming: CH k-slabs x R rows of 16-byte non-temporal loads are issued back to back before
+    // the first FMA (CH*R*16 B = 256-320 B per lane, ~80 KB per CU in flight), which is what it takes to
+    // cover HBM latency with one workgroup per CU.
+    constexpr int CH = 4;
+    auto stream = [&](const float* wbase, int ldw, int klen, int xoff) {
+        for (int k0 = lane * 4; k0 < klen; k0 += 256 * CH) {
+            float4 wv[CH][R];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) xv[b] = *reinterpret_cast<const float4*>(xs + b * K + k);
+            for (int j = 0; j < CH; ++j) {
+                const int k = k0 + j * 256;
+                const int kc = k < klen ? k : 0;                 // clamped: the tail slab re-reads slab 0
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const float4 w = *reinterpret_cast<const float4*>(wr + (size_t)r * I + k);
+                for (int r = 0; r < R; ++r) wv[j][r] = load4_nt(wbase + (size_t)r * ldw + kc);
+            }
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
-                acc[r][b] += w.x * xv[b].x + w.y * xv[b].y + w.z * xv[b].z + w.w * xv[b].w;
+            for (int j = 0; j < CH; ++j) {
+                const int k = k0 + j * 256;
+                if (k < klen) {
+                    float4 xv[NB];
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) xv[b] = *reinterpret_cast<const float4*>(xs + b * K + xoff + k);
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int b = 0; b < NB; ++b)
+                            acc[r][b] += wv[j][r].x * xv[b].x + wv[j][r].y * xv[b].y + wv[j][r].z * xv[b].z +
+                                         wv[j][r].w * xv[b].w;
+                }
+            }
         }
-    }
-    const float* wh = Whh + (size_t)(g * H + u0) * H;
-    for (int k = lane * 4; k < H; k += 256) {
-        float4 xv[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) xv[b] = *reinterpret_cast<const float4*>(xs + b * K + I + k);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const float4 w = *reinterpret_cast<const float4*>(wh + (size_t)r * H + k);
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-                acc[r][b] += w.x * xv[b].x + w.y * xv[b].y + w.z * xv[b].z + w.w * xv[b].w;
-        }
-    }
+    };
+    stream(Wih + (size_t)(g * H + u0) * I, I, I, 0);
+    stream(Whh + (size_t)(g * H + u0) * H, H, H, I);
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -232,8 +301,10 @@ struct AttnArgs {
     int T, A, Ra, Dm, F, K, R, step, max_steps;
 };
 
+template <int FMAX>
 __global__ __launch_bounds__(256) void attention_step_kernel(const AttnArgs a) {
     __shared__ float q[256];
+    __shared__ __attribute__((aligned(16))) float hs[1536];
     __shared__ float wcat[2][128];
     __shared__ float wloc[64 * 2 * 63];
     __shared__ float loc[64][65];
@@ -248,19 +319,18 @@ __global__ __launch_bounds__(256) void attention_step_kernel(const AttnArgs a) {
     if (off != 0.f) cur += off;
     cur = fminf(fmaxf(cur, (float)a.R), (float)(len - 1 - a.R));
     const int s = (int)rintf(fmaxf(cur - (float)a.R, 0.f));
-    // query projection: wave per row
+    // query projection: each wave owns rows wv*RQ.. in batches of 8 (att_h staged in LDS)
+    for (int i = t; i < a.Ra; i += 256) hs[i] = a.att_h[(size_t)b * a.Ra + i];
+    __syncthreads();
     {
-        const float* h = a.att_h + (size_t)b * a.Ra;
-        for (int r = wv; r < a.A; r += 4) {
-            const float* wr = a.Wq + (size_t)r * a.Ra;
-            float acc = 0.f;
-            for (int k = lane * 4; k < a.Ra; k += 256) {
-                const float4 w = *reinterpret_cast<const float4*>(wr + k);
-                const float4 x = *reinterpret_cast<const float4*>(h + k);
-                acc += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w;
-            }
-            acc = wave_sum(acc);
-            if (lane == 0) q[r] = acc;
+        const int per = (a.A + 3) / 4;
+        for (int r0 = wv * per; r0 < (wv + 1) * per && r0 < a.A; r0 += 8) {
+            float o[8];
+            const int lim = min(a.A, (wv + 1) * per);
+            wave_dots<8, 1536>(a.Wq, a.Ra, r0, lim, a.Ra, hs, lane, o);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (lane == i && r0 + i < lim) q[r0 + i] = o[i];
         }
     }
     // previous / cumulative weights around the window, location conv filters
@@ -280,24 +350,45 @@ __global__ __launch_bounds__(256) void attention_step_kernel(const AttnArgs a) {
         loc[tt][f] = acc;
     }
     __syncthreads();
-    // energies: one wave per window position, lanes over attention dims
-    for (int tt = wv; tt < W; tt += 4) {
-        const int pos = s + tt;
-        float e = 0.f;
-        if (pos < len && pos < a.T) {
-            for (int ad = lane; ad < a.A; ad += 64) {
-                const float* wd = a.Wd + (size_t)ad * a.F;
-                float acc = 0.f;
-                for (int f = 0; f < a.F; ++f) acc = fmaf(wd[f], loc[tt][f], acc);
-                acc += q[ad];
-                acc += a.pm[((size_t)b * a.T + pos) * a.A + ad];
-                e = fmaf(a.v[ad], tanhf(acc), e);
+    // energies: wave wv owns window positions wv, wv+4, ...; lane owns attention dims lane, lane+64, ...
+    // The lane's rows of the location-dense weight (coalesced, from the transposed copy WdT[f][a]) and the
+    // processed-memory values of its positions are loaded up front, unconditionally (positions are clamped,
+    // masked ones are overwritten with -inf afterwards), so all global loads of a pass are in flight together.
+    {
+        constexpr int MAXP = 16;                 // ceil(63 / 4) window positions per wave
+        float epart[MAXP];
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) epart[i] = 0.f;
+        for (int ad = lane; ad < a.A; ad += 64) {
+            float wd[FMAX], pmv[MAXP];
+#pragma unroll
+            for (int f = 0; f < FMAX; ++f) wd[f] = a.Wd[(size_t)min(f, a.F - 1) * a.A + ad];
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) {
+                const int pos = min(s + min(wv + 4 * i, W - 1), a.T - 1);
+                pmv[i] = a.pm[((size_t)b * a.T + pos) * a.A + ad];
             }
-            e = wave_sum(e);
-        } else {
-            e = -INFINITY;
+            const float qa = q[ad], va = a.v[ad];
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) {
+                const int tt = min(wv + 4 * i, W - 1);
+                float acc = 0.f;
+#pragma unroll
+                for (int f = 0; f < FMAX; ++f) acc = fmaf(f < a.F ? wd[f] : 0.f, loc[tt][f], acc);
+                acc += qa;
+                acc += pmv[i];
+                epart[i] = fmaf(va, tanhf(acc), epart[i]);
+            }
         }
-        if (lane == 0) en[tt] = e;
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int tt = wv + 4 * i;
+            const float e = wave_sum(epart[i]);
+            if (tt < W && lane == 0) {
+                const int pos = s + tt;
+                en[tt] = (pos < len && pos < a.T) ? e : -INFINITY;
+            }
+        }
     }
     __syncthreads();
     if (wv == 0) {     // softmax over the window with wave-level reductions
@@ -314,11 +405,15 @@ __global__ __launch_bounds__(256) void attention_step_kernel(const AttnArgs a) {
         }
     }
     __syncthreads();
+    // context = sum_t w[t] * memory[t]: positions clamped (their weight is exactly 0 when masked) so the
+    // loads are unconditional and an unrolled slab of them is in flight at once
     for (int d = t; d < a.Dm; d += 256) {
+        const float* mp = a.memory + (size_t)b * a.T * a.Dm + d;
         float acc = 0.f;
+#pragma unroll 11
         for (int tt = 0; tt < W; ++tt) {
-            const int pos = s + tt;
-            if (pos < a.T) acc = fmaf(wts[tt], a.memory[((size_t)b * a.T + pos) * a.Dm + d], acc);
+            const int pos = min(s + tt, a.T - 1);
+            acc = fmaf(s + tt < a.T ? wts[tt] : 0.f, mp[(size_t)pos * a.Dm], acc);
         }
         a.ctx[(size_t)b * a.Dm + d] = acc;
     }
@@ -348,35 +443,55 @@ __global__ __launch_bounds__(256) void project_prenet_kernel(const ProjArgs a) {
     for (int i = t; i < D; i += 256)
         v[i] = i < a.Rd ? a.dec_h[(size_t)b * a.Rd + i] + a.d2_h[(size_t)b * a.Rd + i] : a.ctx[(size_t)b * a.Dm + (i - a.Rd)];
     __syncthreads();
-    for (int r = wv; r <= a.n_mel; r += 4) {        // rows 0..n_mel-1 = mel, row n_mel = gate
-        const float* wr = a.Wp + (size_t)r * D;
-        float acc = 0.f;
-        for (int k = lane * 4; k < D; k += 256) {
-            const float4 w = *reinterpret_cast<const float4*>(wr + k);
-            const float4 x = *reinterpret_cast<const float4*>(v + k);
-            acc += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w;
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            acc += a.bp[r];
-            if (r < a.n_mel) {
-                mel[r] = acc;
-                a.mel_out[((size_t)b * a.n_mel + r) * a.max_steps + a.step] = acc;
-            } else {
-                a.gate_out[(size_t)b * a.max_steps + a.step] = acc;
+    {   // rows 0..n_mel-1 = mel, row n_mel = gate; each wave owns a contiguous quarter, 8 rows per batch
+        const int rows = a.n_mel + 1, per = (rows + 3) / 4, lim = min(rows, (wv + 1) * per);
+        for (int r0 = wv * per; r0 < lim; r0 += 8) {
+            float o[8];
+            wave_dots<8, 1536>(a.Wp, D, r0, lim, D, v, lane, o);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = r0 + i;
+                if (lane == i && r < lim) {
+                    const float val = o[i] + a.bp[r];
+                    if (r < a.n_mel) {
+                        mel[r] = val;
+                        a.mel_out[((size_t)b * a.n_mel + r) * a.max_steps + a.step] = val;
+                    } else {
+                        a.gate_out[(size_t)b * a.max_steps + a.step] = val;
+                    }
+                }
             }
         }
     }
     __syncthreads();
     if (a.keep == nullptr) return;
-    // prenet of the next step: relu(W . x) * keep * 2 twice (model.py:187-190), P == 256 == blockDim
-    float acc = 0.f;
-    for (int k = 0; k < a.n_mel; ++k) acc = fmaf(a.W1T[(size_t)k * a.P + t], mel[k], acc);
-    a1[t] = fmaxf(acc, 0.f) * (a.keep[(size_t)b * a.P + t] ? 2.0f : 0.0f);
+    // prenet of the next step: relu(W . x) * keep * 2 twice (model.py:187-190).  Thread j owns output j;
+    // weights are stored transposed ([in][out]) so every load is coalesced, and the loads of a 32-deep
+    // slab are independent of the running sums (4 accumulators) so they are all in flight together.
+    if (t < a.P) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int k = 0; k < a.n_mel; k += 4) {
+            acc[0] = fmaf(a.W1T[(size_t)(k + 0) * a.P + t], mel[k + 0], acc[0]);
+            acc[1] = fmaf(a.W1T[(size_t)(k + 1) * a.P + t], mel[k + 1], acc[1]);
+            acc[2] = fmaf(a.W1T[(size_t)(k + 2) * a.P + t], mel[k + 2], acc[2]);
+            acc[3] = fmaf(a.W1T[(size_t)(k + 3) * a.P + t], mel[k + 3], acc[3]);
+        }
+        a1[t] = fmaxf((acc[0] + acc[1]) + (acc[2] + acc[3]), 0.f) * (a.keep[(size_t)b * a.P + t] ? 2.0f : 0.0f);
+    }
     __syncthreads();
-    acc = 0.f;
-    for (int k = 0; k < a.P; ++k) acc = fmaf(a.W2T[(size_t)k * a.P + t], a1[k], acc);
-    a.prenet_out[(size_t)b * a.P + t] = fmaxf(acc, 0.f) * (a.keep[((size_t)a.B + b) * a.P + t] ? 2.0f : 0.0f);
+    if (t < a.P) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int k = 0; k < a.P; k += 4) {
+            acc[0] = fmaf(a.W2T[(size_t)(k + 0) * a.P + t], a1[k + 0], acc[0]);
+            acc[1] = fmaf(a.W2T[(size_t)(k + 1) * a.P + t], a1[k + 1], acc[1]);
+            acc[2] = fmaf(a.W2T[(size_t)(k + 2) * a.P + t], a1[k + 2], acc[2]);
+            acc[3] = fmaf(a.W2T[(size_t)(k + 3) * a.P + t], a1[k + 3], acc[3]);
+        }
+        a.prenet_out[(size_t)b * a.P + t] =
+            fmaxf((acc[0] + acc[1]) + (acc[2] + acc[3]), 0.f) * (a.keep[((size_t)a.B + b) * a.P + t] ? 2.0f : 0.0f);
+    }
 }
 
 template <int NB>
@@ -384,7 +499,7 @@ int launch_lstm(const float* blob, const size_t* off, const float* in0, int n0, 
                 const float* in2, int n2, const float* h_old, float* h_new, float* c, int I, int H, hipStream_t s) {
     const size_t smem_base = (size_t)NB * (I + H) * sizeof(float);
 #define CTTS_LSTM_CASE(RR)                                                                                         \
-    if (H % RR == 0 && H / RR <= 320) {                                                                           \
+    if (H % RR == 0 && H / RR <= 256) {                                                                           \
         const size_t smem = smem_base + 4 * RR * NB * sizeof(float);                                              \
         hipLaunchKernelGGL((lstm_step_kernel<NB, RR>), dim3(H / RR), dim3(256), smem, s, blob + off[0],           \
                            blob + off[1], blob + off[2], blob + off[3], in0, n0, in1, n1, in2, n2, h_old, h_new, c, \
@@ -446,9 +561,9 @@ int ctts_taco_decoder_pack(const ctts_taco_decoder_config* cfg, const ctts_taco_
     if ((rc = copy(p.query_w, w->query_w, (size_t)c.attention_dim * c.attention_rnn_dim))) return rc;
     if ((rc = copy(p.v_w, w->v_w, c.attention_dim))) return rc;
     if ((rc = copy(p.loc_conv_w, w->loc_conv_w, (size_t)c.location_n_filters * 2 * c.location_kernel_size))) return rc;
-    if ((rc = copy(p.loc_dense_w, w->loc_dense_w, (size_t)c.attention_dim * c.location_n_filters))) return rc;
-    if ((rc = transpose(p.prenet_w1T, w->prenet_w1, c.prenet_dim, c.n_mel_channels))) return rc;
-    if ((rc = transpose(p.prenet_w2T, w->prenet_w2, c.prenet_dim, c.prenet_dim))) return rc;
+    if ((rc = transpose(p.loc_dense_w, w->loc_dense_w, c.attention_dim, c.location_n_filters))) return rc;   // -> [F][A]
+    if ((rc = transpose(p.prenet_w1, w->prenet_w1, c.prenet_dim, c.n_mel_channels))) return rc;   // -> [n_mel][P]
+    if ((rc = transpose(p.prenet_w2, w->prenet_w2, c.prenet_dim, c.prenet_dim))) return rc;       // -> [P][P]^T
     auto lstm = [&](const size_t* off, const ctts_lstm_weights& l, int I, int H) -> int {
         int r;
         if ((r = copy(off[0], l.w_ih, (size_t)4 * H * I))) return r;
@@ -532,7 +647,8 @@ int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void*
         a.T = text_len; a.A = c.attention_dim; a.Ra = c.attention_rnn_dim; a.Dm = c.memory_dim;
         a.F = c.location_n_filters; a.K = c.location_kernel_size; a.R = c.window_range;
         a.step = step; a.max_steps = max_steps;
-        hipLaunchKernelGGL(attention_step_kernel, dim3(batch), dim3(256), 0, s, a);
+        if (c.location_n_filters <= 32) hipLaunchKernelGGL(attention_step_kernel<32>, dim3(batch), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(attention_step_kernel<64>, dim3(batch), dim3(256), 0, s, a);
         CTTS_CHECK_LAUNCH("attention_step");
         // decoder RNN on [attention hidden | context], second decoder RNN on the first's output
         rc = launch_lstm_nb(NB, blob, p.dec, w.att_h[nxt], c.attention_rnn_dim, w.ctx, c.memory_dim, nullptr, 0,
@@ -542,7 +658,7 @@ int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void*
                             w.d2_h[nxt], w.d2_c, p.I_d2, c.second_decoder_rnn_dim, s);
         if (rc) return rc;
         ProjArgs q{};
-        q.Wp = blob + p.proj_w; q.bp = blob + p.proj_b; q.W1T = blob + p.prenet_w1T; q.W2T = blob + p.prenet_w2T;
+        q.Wp = blob + p.proj_w; q.bp = blob + p.proj_b; q.W1T = blob + p.prenet_w1; q.W2T = blob + p.prenet_w2;
         q.dec_h = w.dec_h[nxt]; q.d2_h = w.d2_h[nxt]; q.ctx = w.ctx;
         q.keep = step + 1 < max_steps ? keep_masks + (size_t)(step + 1) * 2 * batch * c.prenet_dim : nullptr;
         q.mel_out = mel_out; q.gate_out = gate_out; q.prenet_out = w.prenet;

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Secondary measurements for SURVEY.md 8 rows B (WaveFlow, config 4), C (Tacotron2 decoder, config 5)
+and D (STFT/mel).  bench.py stays the headline (config 2); this prints one JSON line per row."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cookietts_amd import synthetic  # noqa: E402
+
+
+def timed(fn, warmup, steps):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def row_waveflow(args):
+    from cookietts_amd.waveglow_ax import WaveGlow
+    cfg = synthetic.WAVEFLOW_CONFIGS["full"]
+    m = WaveGlow(**cfg)
+    m.load_state_dict(synthetic.to_torch(synthetic.waveflow_state_dict(cfg, seed=1234)))
+    m = m.cuda().eval()
+    B, F = 8, 900
+    mel = torch.from_numpy(synthetic.synthetic_mel(B, F)).cuda()
+    dt = timed(lambda: m.infer(mel, sigma=0.6, return_CPU=False), args.warmup, args.steps)
+    samples = B * (F - 1) * 256
+    wn = cfg["WN_config"]
+    C, G = wn["n_channels"], cfg["n_group"]
+    launches = cfg["n_flows"] * (G - 1) * wn["n_layers"]
+    mac = 0.6515e6 * (G - 1) * cfg["n_flows"] / G          # per output sample
+    return {"row": "B/config4", "metric": "audio samples/sec (22.05kHz) WaveFlow infer (8 flows, 64 ch, h=16), 80x900 mel",
+            "value": samples / dt, "unit": "samples/s", "rtf": samples / dt / 22050, "ms_per_call": dt * 1e3,
+            "dtype": "f32", "batch": B, "frames": F, "gemm_launches_per_call": 2 * launches,
+            "achieved_tflops_algorithmic": 2 * mac * samples / dt / 1e12}
+
+
+def row_tacotron(args):
+    from cookietts_amd.tacotron2 import Tacotron2
+    hp = synthetic.tacotron_hparams()
+    m = Tacotron2(hp)
+    m.load_state_dict(synthetic.to_torch(synthetic.tacotron_state_dict(hp, seed=1234)))
+    m = m.cuda().eval()
+    B, T, steps = 4, 200, 900
+    rng = np.random.default_rng(1234)
+    text = torch.from_numpy(rng.integers(1, 179, size=(B, T))).cuda()
+    lens = torch.tensor([200, 195, 150, 100]).cuda()
+    spk = torch.arange(B).cuda()
+    tm = torch.from_numpy(rng.standard_normal((B, 2304)).astype(np.float32)).cuda()
+    dt = timed(lambda: m.inference(text, lens, spk, tm, fixed_steps=steps), args.warmup, args.steps)
+    mem = torch.from_numpy((rng.standard_normal((B, T, 1313)) * 0.5).astype(np.float32)).cuda()
+    dd = timed(lambda: m.decoder.inference(mem, lens, fixed_steps=steps), 1, args.steps)
+    weights_mb = sum(p.numel() for n, p in m.decoder.named_parameters()
+                     if "rnn" in n or "projection" in n or "gate" in n or "query" in n or "prenet" in n) * 4 / 1e6
+    return {"row": "C/config5", "metric": "Tacotron2-TM decoder step time, B=4, 200 symbols, 900 forced steps",
+            "value": dd / steps * 1e6, "unit": "us/step", "higher_is_better": False,
+            "mel_frames_per_s_batch": B * steps / dd, "end_to_end_ms_incl_encoder_postnet": dt * 1e3,
+            "dtype": "f32", "weights_streamed_per_step_MB": weights_mb,
+            "achieved_weight_stream_GBps": weights_mb / 1e3 / (dd / steps)}
+
+
+def row_stft(args):
+    from cookietts_amd import TacotronSTFT
+    taco = TacotronSTFT().cuda()
+    B, T = 8, 230400
+    y = (torch.rand(B, T, device="cuda") * 2 - 1) * 0.5
+    dt = timed(lambda: taco.mel_spectrogram(y), args.warmup, args.steps)
+    frames = T // 256 + 1
+    flop = 2.0 * B * frames * (1026 * 1024 + 80 * 513)
+    return {"row": "D/stft", "metric": "TacotronSTFT.mel_spectrogram, 8 x 230400 samples (1024/256/1024, 80 mel)",
+            "value": B * T / dt, "unit": "samples/s", "ms_per_call": dt * 1e3, "dtype": "f32",
+            "achieved_tflops_algorithmic": flop / dt / 1e12}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", default="waveflow,tacotron,stft")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    args = ap.parse_args()
+    fns = {"waveflow": row_waveflow, "tacotron": row_tacotron, "stft": row_stft}
+    for r in args.rows.split(","):
+        print(json.dumps(fns[r](args)), flush=True)
