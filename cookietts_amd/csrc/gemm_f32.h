@@ -50,6 +50,8 @@ struct GemmArgs {
     const float* bias;    // [MB*bm] in block-local row order
     GemmSeg seg[GEMM_MAX_SEG];
     int nseg;
+    int interleave;       // G > 1: segments 0..G-1 (equal nch) are consumed round-robin, one chunk each, so the
+                          // taps of one 16-channel slab are read back to back (L2 reuse); the rest sequentially
     int nch_total;        // K chunks used by this launch (sum of seg[].nch)
     int a_nch_alloc;      // K chunks per M-block in the packed A (>= a_ch_off + nch_total); 0 = nch_total
     int a_ch_off;         // first chunk of A to use (skips leading taps, e.g. WaveFlow rows 0/1)

@@ -105,6 +105,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
     // named registers (arrays indexed inside the pipelined loop end up in scratch)
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
     int seg = 0, local = 0;
+    const int ilv = a.interleave > 1 ? a.interleave : 0;
+    bool in_ilv = ilv > 0;
     __syncthreads();                    // segment table visible
 
 #define CTTS_ISSUE_LOADS()                                                                      \
@@ -125,7 +127,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
             rb2 = load4u(bp + 128);                                                             \
             rb3 = load4u(bp + 192);                                                             \
         }                                                                                       \
-        if (++local == (int)e.z) { local = 0; ++seg; }                                          \
+        if (in_ilv) {                                                                           \
+            if (++seg == ilv) { seg = 0; if (++local == (int)e.z) { local = 0; seg = ilv; in_ilv = false; } } \
+        } else if (++local == (int)e.z) { local = 0; ++seg; }                                   \
     } while (0)
 
 #define CTTS_STORE_LDS(buf)                                                                     \
@@ -286,6 +290,11 @@ int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
         nch += a.seg[s].nch;
     }
     CTTS_CHECK_ARG(nch == a.nch_total, "gemm: chunk count mismatch %d vs %d", nch, a.nch_total);
+    if (a.interleave > 1) {
+        CTTS_CHECK_ARG(a.interleave <= a.nseg, "gemm: interleave %d > nseg %d", a.interleave, a.nseg);
+        for (int s = 1; s < a.interleave; ++s)
+            CTTS_CHECK_ARG(a.seg[s].nch == a.seg[0].nch, "gemm: interleaved segments must have equal length");
+    }
     CTTS_CHECK_ARG(a.a_nch_alloc == 0 || a.a_ch_off + a.nch_total <= a.a_nch_alloc, "gemm: A chunk window");
     CTTS_CHECK_ARG(a.ld % 4 == 0 && a.ntiles * bn + 2 * a.pad <= a.ld && a.L <= a.ntiles * bn,
                    "gemm: bad geometry ld=%d pad=%d L=%d ntiles=%d bn=%d", a.ld, a.pad, a.L, a.ntiles, bn);

@@ -200,7 +200,7 @@ int run_wn_stack(const Plan& p, const Geom& g, const float* blob, int k, const f
         {
             GemmArgs a = base_args(g, batch);
             a.A = blob + f.in_A[i]; a.bias = blob + f.in_b[i];
-            a.nseg = 4; a.nch_total = p.nch_in; a.MB = p.mb_in;
+            a.nseg = 4; a.interleave = 3; a.nch_total = p.nch_in; a.MB = p.mb_in;
             a.seg[0] = {x, cstride, ncx, -dil, 0, 0};
             a.seg[1] = {x, cstride, ncx, 0, 0, 0};
             a.seg[2] = {x, cstride, ncx, dil, 0, 0};
@@ -314,10 +314,10 @@ int ctts_waveglow_pack_flow(const ctts_waveglow_config* cfg, int32_t k, const ct
                                GEMM_EPI_SPLIT, C, H, s))) return rc;
     for (int i = 0; i < p.c.n_layers; ++i) {
         CTTS_CHECK_ARG(w->in_w[i] && w->in_b[i] && w->rs_w[i] && w->rs_b[i], "pack_flow: NULL layer %d weights", i);
-        // in-layer: K = [tap0 | tap1 | tap2 | cond];  in_w[i] is [2C][C][ks]
+        // in-layer: K = [per 16-channel slab: tap0, tap1, tap2] then [cond];  in_w[i] is [2C][C][ks]
         for (int t = 0; t < ks; ++t)
-            if ((rc = launch_pack_a(blob + f.in_A[i], w->in_w[i] + t, GEMM_BM, p.mb_in, p.nch_in, t * C, C, GEMM_EPI_GATE, C,
-                                    2 * C, 0, (long long)C * ks, ks, s))) return rc;
+            if ((rc = launch_pack_a(blob + f.in_A[i], w->in_w[i] + t, GEMM_BM, p.mb_in, p.nch_in, 0, C, GEMM_EPI_GATE, C,
+                                    2 * C, 0, (long long)C * ks, ks, s, ks, t))) return rc;
         // cond layer 2 rows [2C*i, 2C*(i+1)) of [2C*n_layers][H]
         if ((rc = launch_pack_a(blob + f.in_A[i], w->cond_w[2], GEMM_BM, p.mb_in, p.nch_in, ks * C, H, GEMM_EPI_GATE, C,
                                 2 * C, (long long)2 * C * i, H, 1, s))) return rc;

@@ -8,7 +8,8 @@ namespace ctts {
 
 int launch_fold_weightnorm(const float* v, const float* g, float* w, int out_ch, int fan, hipStream_t s);
 int launch_pack_a(float* dst, const float* src, int bm, int MB, int nch_total, int k_off, int ksrc, int epi, int C, int M,
-                  long long src_row_off, long long src_row_stride, int src_k_stride, hipStream_t s);
+                  long long src_row_off, long long src_row_stride, int src_k_stride, hipStream_t s, int k_group = 1,
+                  int k_member = 0);
 int launch_pack_bias(float* dst, int bm, int MB, const float* src0, long long off0, const float* src1, long long off1,
                      int epi, int C, int M, hipStream_t s);
 int launch_upsample_squeeze(const float* mel, const float* W, const float* bias, float* spect, int batch,

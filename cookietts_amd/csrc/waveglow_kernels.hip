@@ -31,13 +31,15 @@ __global__ __launch_bounds__(256) void fold_weightnorm_kernel(const float* __res
 __global__ __launch_bounds__(256) void pack_a_kernel(float* __restrict__ dst, const float* __restrict__ src, int bm,
                                                      int nch_total, int k_off, int ksrc, int epi, int C, int M,
                                                      long long src_row_off, long long src_row_stride,
-                                                     int src_k_stride) {
+                                                     int src_k_stride, int k_group, int k_member) {
     const int mb = blockIdx.y;
     const int k = blockIdx.x;  // 0..ksrc-1
     const int r = threadIdx.x;
     if (r >= bm) return;
     const int drow = gemm_dense_row(epi, bm, mb, r, C, M);
-    const int kk = k_off + k;
+    // k_group > 1: this source is member k_member of a round-robin group (GemmArgs::interleave): its
+    // chunk j lands at chunk j*k_group + k_member of the group's K range starting at k_off
+    const int kk = k_group > 1 ? k_off + ((k / GEMM_KC) * k_group + k_member) * GEMM_KC + k % GEMM_KC : k_off + k;
     dst[((size_t)mb * nch_total + kk / GEMM_KC) * (GEMM_KC * bm) + (kk % GEMM_KC) * bm + r] =
         drow >= 0 ? src[(src_row_off + drow) * src_row_stride + (long long)k * src_k_stride] : 0.f;
 }
@@ -270,10 +272,13 @@ int launch_fold_weightnorm(const float* v, const float* g, float* w, int out_ch,
 }
 
 int launch_pack_a(float* dst, const float* src, int bm, int MB, int nch_total, int k_off, int ksrc, int epi, int C, int M,
-                  long long src_row_off, long long src_row_stride, int src_k_stride, hipStream_t s) {
-    CTTS_CHECK_ARG(k_off >= 0 && ksrc > 0 && k_off + ksrc <= nch_total * GEMM_KC, "pack_a: k range");
+                  long long src_row_off, long long src_row_stride, int src_k_stride, hipStream_t s, int k_group,
+                  int k_member) {
+    CTTS_CHECK_ARG(k_off >= 0 && ksrc > 0 && k_off + ksrc * (k_group > 1 ? k_group : 1) <= nch_total * GEMM_KC,
+                   "pack_a: k range");
+    CTTS_CHECK_ARG(k_group <= 1 || (ksrc % GEMM_KC == 0 && k_member >= 0 && k_member < k_group), "pack_a: k group");
     hipLaunchKernelGGL(pack_a_kernel, dim3(ksrc, MB), dim3(256), 0, s, dst, src, bm, nch_total, k_off, ksrc, epi, C, M,
-                       src_row_off, src_row_stride, src_k_stride);
+                       src_row_off, src_row_stride, src_k_stride, k_group, k_member);
     CTTS_CHECK_LAUNCH("pack_a");
     return CTTS_OK;
 }
