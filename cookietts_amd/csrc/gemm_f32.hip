@@ -35,13 +35,19 @@ __device__ __forceinline__ float fast_tanh(float u) {
 
 // 16 bytes from a 4-byte-aligned address (dilation 1 and 2 taps): the backend emits one
 // global_load_dwordx4, which gfx950 serves unaligned.
-__device__ __forceinline__ float4 load4u(const float* p) {
+// The pointer is rebuilt from the LDS segment table, so it is cast to the global address space
+// explicitly: a generic (flat) load would also count on lgkmcnt and every LDS fragment wait in the
+// MFMA loop would then drain the prefetch of the next chunk.
+typedef const __attribute__((address_space(1))) float* gfloat_ptr;
+__device__ __forceinline__ float4 load4u(gfloat_ptr p) {
     float4 v;
     v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3];
     return v;
 }
 
-template <int EPI, int WM>
+// SEGS = 4: segment bases live in registers and are picked with a scalar-compare select chain (no LDS
+// round trip at the top of a chunk); SEGS = GEMM_MAX_SEG: bases come from the LDS segment table.
+template <int EPI, int WM, int SEGS>
 __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a) {
     constexpr int BM = 128 * WM;
     constexpr int WN = 4 / WM;
@@ -66,23 +72,36 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
     const int b = id / a.ntiles;
     const int n0 = tile * BN;
 
-    // segment table -> LDS (a dynamically indexed kernarg struct would be copied to scratch)
+    // segment bases: everything except the k-row of the chunk and the per-thread (row, column) offset
+    gfloat_ptr sbase[4];
+    int snch[4];
+    if constexpr (SEGS == 4) {
 #pragma unroll
-    for (int sidx = 0; sidx < GEMM_MAX_SEG; ++sidx) {      // static kernarg indices only
-        if (t == sidx) {
+        for (int sidx = 0; sidx < 4; ++sidx) {                 // static kernarg indices only
             const GemmSeg& g = a.seg[sidx];
-            unsigned int* e = reinterpret_cast<unsigned int*>(lds + SEGTAB + sidx * 4);
-            if (sidx < a.nseg) {
-                const float* base = g.base + (size_t)b * g.bstride + (size_t)(mb * g.mb_rows) * a.ld +
-                                    (a.pad + n0 + g.shift);
-                const unsigned long long u = reinterpret_cast<unsigned long long>(base);
-                e[0] = (unsigned int)u;
-                e[1] = (unsigned int)(u >> 32);
-                e[2] = (unsigned int)g.nch;
-            } else {
-                e[0] = 0; e[1] = 0; e[2] = 0x7fffffffu;
+            sbase[sidx] = (gfloat_ptr)(g.base + (size_t)b * g.bstride + (size_t)(mb * g.mb_rows) * a.ld +
+                                       (a.pad + n0 + g.shift));
+            snch[sidx] = sidx < a.nseg ? g.nch : 0x7fffffff;
+        }
+    } else {
+        // segment table -> LDS (a dynamically indexed kernarg struct would be copied to scratch)
+#pragma unroll
+        for (int sidx = 0; sidx < GEMM_MAX_SEG; ++sidx) {      // static kernarg indices only
+            if (t == sidx) {
+                const GemmSeg& g = a.seg[sidx];
+                unsigned int* e = reinterpret_cast<unsigned int*>(lds + SEGTAB + sidx * 4);
+                if (sidx < a.nseg) {
+                    const float* base = g.base + (size_t)b * g.bstride + (size_t)(mb * g.mb_rows) * a.ld +
+                                        (a.pad + n0 + g.shift);
+                    const unsigned long long u = reinterpret_cast<unsigned long long>(base);
+                    e[0] = (unsigned int)u;
+                    e[1] = (unsigned int)(u >> 32);
+                    e[2] = (unsigned int)g.nch;
+                } else {
+                    e[0] = 0; e[1] = 0; e[2] = 0x7fffffffu;
+                }
+                e[3] = 0;
             }
-            e[3] = 0;
         }
     }
 
@@ -107,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
     int seg = 0, local = 0;
     const int ilv = a.interleave > 1 ? a.interleave : 0;
     bool in_ilv = ilv > 0;
-    __syncthreads();                    // segment table visible
+    if constexpr (SEGS != 4) __syncthreads();   // segment table visible
 
 #define CTTS_ISSUE_LOADS()                                                                      \
     do {                                                                                        \
@@ -118,9 +137,17 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
             ra3 = *reinterpret_cast<const float4*>(ap + 3072);                                  \
         }                                                                                       \
         ap += A_STAGE;                                                                          \
-        const uint4 e = *reinterpret_cast<const uint4*>(lds + SEGTAB + seg * 4);                \
-        const float* bp = reinterpret_cast<const float*>(((unsigned long long)e.y << 32) | e.x) + \
-                          (size_t)local * chunk_rows + thread_off;                              \
+        gfloat_ptr sb_;                                                                         \
+        int sn_;                                                                                \
+        if constexpr (SEGS == 4) {                                                              \
+            sb_ = seg == 0 ? sbase[0] : seg == 1 ? sbase[1] : seg == 2 ? sbase[2] : sbase[3];   \
+            sn_ = seg == 0 ? snch[0] : seg == 1 ? snch[1] : seg == 2 ? snch[2] : snch[3];       \
+        } else {                                                                                \
+            const uint4 e = *reinterpret_cast<const uint4*>(lds + SEGTAB + seg * 4);            \
+            sb_ = reinterpret_cast<gfloat_ptr>(((unsigned long long)e.y << 32) | e.x);          \
+            sn_ = (int)e.z;                                                                     \
+        }                                                                                       \
+        gfloat_ptr bp = sb_ + (size_t)local * chunk_rows + thread_off;                          \
         rb0 = load4u(bp);                                                                       \
         rb1 = load4u(bp + 64);                                                                  \
         if constexpr (NB > 2) {                                                                 \
@@ -128,8 +155,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
             rb3 = load4u(bp + 192);                                                             \
         }                                                                                       \
         if (in_ilv) {                                                                           \
-            if (++seg == ilv) { seg = 0; if (++local == (int)e.z) { local = 0; seg = ilv; in_ilv = false; } } \
-        } else if (++local == (int)e.z) { local = 0; ++seg; }                                   \
+            if (++seg == ilv) { seg = 0; if (++local == sn_) { local = 0; seg = ilv; in_ilv = false; } } \
+        } else if (++local == sn_) { local = 0; ++seg; }                                        \
     } while (0)
 
 #define CTTS_STORE_LDS(buf)                                                                     \
@@ -270,8 +297,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
 
 template <int EPI>
 void launch_shape(int bm, dim3 grid, hipStream_t stream, const GemmArgs& a) {
-    if (bm == 128) hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 1>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 2>), grid, dim3(256), 0, stream, a);
+    const bool few = a.nseg <= 4;
+    if (bm == 128) {
+        if (few) hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 1, 4>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 1, GEMM_MAX_SEG>), grid, dim3(256), 0, stream, a);
+    } else {
+        if (few) hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 2, 4>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 2, GEMM_MAX_SEG>), grid, dim3(256), 0, stream, a);
+    }
 }
 
 }  // namespace
