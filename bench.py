@@ -34,6 +34,15 @@ sys.path.insert(0, REPO)
 
 METRIC = "audio samples/sec (22.05kHz) WaveGlow infer, 80×900 mel, 1/2/4/8 GPU; real-time factor"
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
+# HBM bytes per in-layer launch from the committed PMC passes (profiles/r1_05_pmc_traffic.json:
+# 2 x FETCH_SIZE (gfx950 half-count correction, calibrated on flow_tail) + WRITE_SIZE), config 2 shapes only
+TRAFFIC = {}
+try:
+    with open(os.path.join(REPO, "profiles", "r1_05_pmc_traffic.json")) as _f:
+        TRAFFIC = {k: v.get("hbm_bytes_per_launch") for k, v in json.load(_f).items()}
+except Exception:
+    pass
 
 
 def cpu_baseline(cfg, sd, frames, seed):
@@ -67,6 +76,8 @@ def main():
     ap.add_argument("--config", default="full", help="key of cookietts_amd.synthetic.WAVEGLOW_CONFIGS")
     ap.add_argument("--cpu-frames", type=int, default=48, help="mel frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 = BASELINE config 2 (default, the headline); bf16 = config 3 (use --batch 32)")
     args = ap.parse_args()
 
     import torch
@@ -91,6 +102,9 @@ def main():
     model = WaveGlow(**cfg)
     model.load_state_dict(synthetic.to_torch(sd))
     model = model.to(device).eval()
+    if args.dtype == "bf16":
+        import torch as _t
+        model.set_compute_dtype(_t.bfloat16)
     B, F = args.batch, args.frames
     mel = torch.from_numpy(synthetic.synthetic_mel(B, F, seed=seed + rank)).to(device)   # resident in HBM
     T = F * cfg["hop_length"]
@@ -141,21 +155,29 @@ def main():
             flop_per_launch = 2.0 * mac * B * L
             mean_s = ms.value / max(n.value, 1) * 1e-3
             achieved = flop_per_launch / mean_s / 1e12
-            roofline = {"kernel": "conv_gemm_f32_kernel<GATE> (WN in-layer: dilated conv + cond + tanh*sigmoid)",
-                        "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
+            kname = "conv_gemm_f32_kernel<GATE>" if args.dtype == "f32" else "conv_gemm_bf16_kernel<GATE>"
+            roofline = {"kernel": kname + " (WN in-layer: dilated conv + cond + tanh*sigmoid)",
+                        "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
+                        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": TRAFFIC.get(args.dtype),
                         "launches": int(n.value), "mean_launch_ms": round(mean_s * 1e3, 4),
                         "flop_per_launch": flop_per_launch}
+            if args.dtype == "bf16":
+                # the bf16 kernel sits near the ridge: also report it against HBM with its algorithmic bytes
+                # (read x C*2 + cond hidden 256*2, write act C*2 per time step)
+                bytes_per_launch = float((2 * C + 256) * 2) * B * L
+                roofline["hbm"] = {"achieved": round(bytes_per_launch / mean_s / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                   "frac": round(bytes_per_launch / mean_s / 8e12, 4), "bytes_per_launch": bytes_per_launch}
         cpu = None
         if world == 1 and args.cpu_frames > 0:
             cpu = cpu_baseline(cfg, sd, args.cpu_frames, seed)
         line = {
             "metric": METRIC, "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "rtf": value / 22050.0,
             "config": {"workload": f"WaveGlow {args.config} ({cfg['n_flows']} flows, {C} WN ch, "
-                                   f"{cfg['n_group']} groups, {n_layers} layers) fp32 infer, batch {B} x (80x{F}) "
+                                   f"{cfg['n_group']} groups, {n_layers} layers) {'fp32' if args.dtype == 'f32' else 'bf16-MFMA'} infer, batch {B} x (80x{F}) "
                                    f"mel per GPU, sigma 0.6, random-init weights",
                        "batch_per_gpu": B, "frames": F, "samples_per_step": world * B * T,
                        "parallelism": f"utterance-batch shard x{world}"},

@@ -89,6 +89,10 @@ SIGNATURES = {
     "ctts_waveglow_pack_flow": (C.c_int, [_CFG, C.c_int32, C.POINTER(WaveGlowFlowWeights), _FP, _FP]),
     "ctts_waveglow_workspace_bytes": (C.c_size_t, [_CFG, C.c_int32, C.c_int32]),
     "ctts_waveglow_infer_f32": (C.c_int, [_CFG, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP, C.c_size_t, _FP]),
+    "ctts_waveglow_packed_bf16_bytes": (C.c_size_t, [_CFG]),
+    "ctts_waveglow_pack_flow_bf16": (C.c_int, [_CFG, C.c_int32, C.POINTER(WaveGlowFlowWeights), _FP, _FP]),
+    "ctts_waveglow_workspace_bf16_bytes": (C.c_size_t, [_CFG, C.c_int32, C.c_int32]),
+    "ctts_waveglow_infer_bf16": (C.c_int, [_CFG, _FP, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP, C.c_size_t, _FP]),
     "ctts_upsample_squeeze_f32": (C.c_int, [_CFG, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP]),
     "ctts_wn_cond_f32": (C.c_int, [_CFG, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP]),
     "ctts_wn_stack_f32": (C.c_int, [_CFG, _FP, C.c_int32, _FP, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP]),

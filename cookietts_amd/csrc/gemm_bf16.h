@@ -1,0 +1,77 @@
+// bf16 MFMA conv-GEMM (fp32 accumulate) for the WN in-layer and res/skip contractions (config 3).
+//
+// Same contract as gemm_f32.h, different storage:
+//   * activations are "K8-blocked" bf16: [B][C/8][ld][8] - the 8 channels of a group are the 16 bytes of
+//     one time step, so an MFMA B fragment (8 consecutive k for one column) is ONE 16-byte load, a
+//     dilated tap is a whole-unit column shift (always 16-byte aligned), and the 32x32 accumulator tile
+//     stores 8-byte runs that pair up into contiguous 512-byte rows;
+//   * weights are packed [MB][K/32][4][256][8] bf16 = the LDS image of one A stage.
+// v_mfma_f32_32x32x16_bf16: bf16 inputs, exact fp32 accumulation.
+#pragma once
+
+#include "common.h"
+
+namespace ctts {
+
+constexpr int BGEMM_BM = 256;
+constexpr int BGEMM_BN = 128;
+constexpr int BGEMM_KC = 32;     // K per LDS stage (two 32x32x16 MFMA k-steps)
+constexpr int BGEMM_MAX_SEG = 4;
+
+enum BGemmEpilogue : int { BGEMM_EPI_SPLIT = 0, BGEMM_EPI_GATE = 1 };
+
+typedef unsigned short bf16_t;   // raw bits
+
+struct BGemmSeg {
+    const bf16_t* base;   // K8-blocked [B][rows/8][ld][8]
+    long long bstride;    // elements between batch items
+    int nch;              // K chunks (32 channels each)
+    int shift;            // column shift (time steps)
+};
+
+struct BGemmArgs {
+    const bf16_t* A;      // packed [MB][nch_total][4][256][8]
+    const float* bias;    // fp32 [MB*256], block-local row order
+    BGemmSeg seg[BGEMM_MAX_SEG];
+    int nseg, interleave, nch_total;
+    int ld, pad, L, ntiles, MB, batch;
+    int M;                // valid rows (multiple of 32)
+    bf16_t* dst0; long long dst0_bstride; int acc0;
+    bf16_t* dst1; long long dst1_bstride; int acc1;
+    int split;            // SPLIT: rows < split -> dst0, else dst1[row - split] (multiple of 32)
+    int pairC;            // GATE: channels (dense rows c and pairC + c)
+};
+
+// dense weight row of block-local row r of M-block mb (same pairing as the fp32 kernel), -1 = padding
+__host__ __device__ inline int bgemm_dense_row(int epi, int mb, int r, int C, int M) {
+    if (epi == BGEMM_EPI_GATE) {
+        const int wm = r >> 7, rr = r & 127;
+        const int c = (mb * 2 + wm) * 64 + (rr & 63);
+        if (c >= C) return -1;
+        return (rr < 64) ? c : C + c;
+    }
+    const int row = mb * BGEMM_BM + r;
+    return row < M ? row : -1;
+}
+
+int launch_gemm_bf16(int epi, const BGemmArgs& a, hipStream_t stream);
+
+// fp32 dense weights -> packed bf16 A (same source addressing as launch_pack_a of the fp32 path; K slabs
+// are 32 wide here, so an interleaved member's slab j lands at slab j*k_group + k_member)
+int launch_pack_a_bf16(bf16_t* dst, const float* src, int MB, int nch_total, int k_off, int ksrc, int epi, int C,
+                       int M, long long src_row_off, long long src_row_stride, int src_k_stride, hipStream_t s,
+                       int k_group = 1, int k_member = 0);
+
+__host__ __device__ inline bf16_t f32_to_bf16_rne(float f) {
+    union { float f; unsigned int u; } v;
+    v.f = f;
+    if ((v.u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((v.u >> 16) | 0x40);   // NaN stays NaN
+    return (bf16_t)((v.u + 0x7fffu + ((v.u >> 16) & 1u)) >> 16);
+}
+__host__ __device__ inline float bf16_to_f32(bf16_t h) {
+    union { float f; unsigned int u; } v;
+    v.u = (unsigned int)h << 16;
+    return v.f;
+}
+
+}  // namespace ctts

@@ -1,0 +1,277 @@
+// bf16 MFMA conv-GEMM for gfx950 (contract: gemm_bf16.h).
+//
+// 256 threads = 4 waves as 2(M) x 2(N); block tile 256 x 128, K chunk 32; wave tile 128 x 64 =
+// 4 x 2 tiles of v_mfma_f32_32x32x16_bf16 (128 accumulator VGPRs).  LDS stage = A [4][256] + B [4][128]
+// 16-byte units (24 KiB), double buffered; every fragment is one ds_read_b128 per lane with consecutive
+// lanes on consecutive units (conflict-free).  Global->LDS staging through registers one chunk ahead.
+#include "gemm_bf16.h"
+
+namespace ctts {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int A_UNITS = 4 * BGEMM_BM;                   // 1024 x 16 B
+constexpr int B_UNITS = 4 * BGEMM_BN;                   // 512 x 16 B
+constexpr int STAGE_UNITS = A_UNITS + B_UNITS;          // 24 KiB
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // one 16-byte K8 unit
+typedef const __attribute__((address_space(1))) u32x4* gunit_ptr;
+
+__device__ __forceinline__ float fast_sigmoid(float u) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f));
+}
+__device__ __forceinline__ float fast_tanh(float u) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * 2.8853900817779268f));
+}
+__device__ __forceinline__ unsigned int pack2(float lo, float hi) {
+    return (unsigned int)f32_to_bf16_rne(lo) | ((unsigned int)f32_to_bf16_rne(hi) << 16);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void conv_gemm_bf16_kernel(const BGemmArgs a) {
+    __shared__ __attribute__((aligned(16))) u32x4 lds[2 * STAGE_UNITS + 16];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    int id = blockIdx.x;
+    const int mb = id % a.MB;
+    id /= a.MB;
+    const int tile = id % a.ntiles;
+    const int b = id / a.ntiles;
+    const int n0 = tile * BGEMM_BN;
+
+    // per-thread B staging: units (g, n) with g = t>>7 (+2), n = t & 127
+    const int bg = t >> 7, bn = t & 127;
+    gunit_ptr sbase[4];
+    int snch[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const BGemmSeg& g = a.seg[s];
+        sbase[s] = (gunit_ptr)(g.base + (size_t)b * g.bstride) + ((size_t)bg * a.ld + a.pad + n0 + g.shift + bn);
+        snch[s] = s < a.nseg ? g.nch : 0x7fffffff;
+    }
+    const size_t chunk_units = (size_t)4 * a.ld;        // 4 channel groups per chunk
+    const size_t g2_units = (size_t)2 * a.ld;
+
+    gunit_ptr ap = (gunit_ptr)a.A + (size_t)mb * a.nch_total * A_UNITS + t;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    u32x4 ra0, ra1, ra2, ra3, rb0, rb1;
+    int seg = 0, local = 0;
+    const int ilv = a.interleave > 1 ? a.interleave : 0;
+    bool in_ilv = ilv > 0;
+
+#define CTTS_ISSUE_LOADS()                                                                      \
+    do {                                                                                        \
+        ra0 = ap[0]; ra1 = ap[256]; ra2 = ap[512]; ra3 = ap[768];                               \
+        ap += A_UNITS;                                                                          \
+        gunit_ptr sb_ = seg == 0 ? sbase[0] : seg == 1 ? sbase[1] : seg == 2 ? sbase[2] : sbase[3]; \
+        const int sn_ = seg == 0 ? snch[0] : seg == 1 ? snch[1] : seg == 2 ? snch[2] : snch[3]; \
+        gunit_ptr bp = sb_ + (size_t)local * chunk_units;                                       \
+        rb0 = bp[0];                                                                            \
+        rb1 = bp[g2_units];                                                                     \
+        if (in_ilv) {                                                                           \
+            if (++seg == ilv) { seg = 0; if (++local == sn_) { local = 0; seg = ilv; in_ilv = false; } } \
+        } else if (++local == sn_) { local = 0; ++seg; }                                        \
+    } while (0)
+
+#define CTTS_STORE_LDS(buf)                                                                     \
+    do {                                                                                        \
+        u32x4* As_ = lds + (buf) * STAGE_UNITS + t;                                             \
+        u32x4* Bs_ = lds + (buf) * STAGE_UNITS + A_UNITS + bg * BGEMM_BN + bn;                  \
+        As_[0] = ra0; As_[256] = ra1; As_[512] = ra2; As_[768] = ra3;                           \
+        Bs_[0] = rb0; Bs_[2 * BGEMM_BN] = rb1;                                                  \
+    } while (0)
+
+    CTTS_ISSUE_LOADS();
+    CTTS_STORE_LDS(0);
+    __syncthreads();
+
+    const int nch = a.nch_total;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int cur = ch & 1;
+        const bool more = ch + 1 < nch;
+        if (more) CTTS_ISSUE_LOADS();
+        const u32x4* As = lds + cur * STAGE_UNITS + wm * 128 + l31;
+        const u32x4* Bs = lds + cur * STAGE_UNITS + A_UNITS + wn * 64 + l31;
+        u32x4 av[2][4], bv[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int grp = 2 * ks + lhi;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) av[ks][mt] = As[grp * BGEMM_BM + mt * 32];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) bv[ks][nt] = Bs[grp * BGEMM_BN + nt * 32];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        *reinterpret_cast<const bf16x8*>(&av[ks][mt]), *reinterpret_cast<const bf16x8*>(&bv[ks][nt]),
+                        acc[mt][nt], 0, 0, 0);
+        if (more) CTTS_STORE_LDS(cur ^ 1);
+        __syncthreads();
+    }
+#undef CTTS_ISSUE_LOADS
+#undef CTTS_STORE_LDS
+
+    // ---- epilogue.  32x32 C/D layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5): for a fixed
+    // register group q = r>>2 the lane holds 4 consecutive channels (8q + 4*lhi + 0..3) of one column, i.e.
+    // half of a 16-byte K8 unit; lanes l and l+32 complete the unit and lanes 0..31 are consecutive columns.
+    float* bias_s = reinterpret_cast<float*>(lds);
+    bias_s[t] = a.bias[mb * BGEMM_BM + t];
+    __syncthreads();
+    const float* bias = bias_s + wm * 128;
+    if constexpr (EPI == BGEMM_EPI_GATE) {
+        bf16_t* dst = a.dst0 + (size_t)b * a.dst0_bstride;
+        const int cbase = (mb * 2 + wm) * 64;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            if (cbase + mt * 32 >= a.pairC) continue;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int n = n0 + wn * 64 + nt * 32 + l31;
+                if (n < a.L) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int row = 8 * q + 4 * lhi + j;
+                            const float u0 = acc[mt][nt][4 * q + j] + bias[mt * 32 + row];
+                            const float u1 = acc[mt + 2][nt][4 * q + j] + bias[64 + mt * 32 + row];
+                            v[j] = fast_tanh(u0) * fast_sigmoid(u1);
+                        }
+                        const int cg = (cbase + mt * 32) / 8 + q;
+                        uint2 pk = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+                        *reinterpret_cast<uint2*>(dst + ((size_t)cg * a.ld + a.pad + n) * 8 + 4 * lhi) = pk;
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int rbase = mb * BGEMM_BM + wm * 128 + mt * 32;
+            if (rbase >= a.M) continue;
+            const bool second = rbase >= a.split;
+            bf16_t* dst = second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride;
+            const int accum = second ? a.acc1 : a.acc0;
+            const int cg0 = (second ? rbase - a.split : rbase) / 8;
+            uint2 old[2][4];
+            if (accum) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        old[nt][q] = *reinterpret_cast<const uint2*>(
+                            dst + ((size_t)(cg0 + q) * a.ld + a.pad + n0 + wn * 64 + nt * 32 + l31) * 8 + 4 * lhi);
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) old[nt][q] = make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int n = n0 + wn * 64 + nt * 32 + l31;
+                if (n < a.L) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v[4];
+                        const float o[4] = {bf16_to_f32((bf16_t)(old[nt][q].x & 0xffff)), bf16_to_f32((bf16_t)(old[nt][q].x >> 16)),
+                                            bf16_to_f32((bf16_t)(old[nt][q].y & 0xffff)), bf16_to_f32((bf16_t)(old[nt][q].y >> 16))};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            v[j] = acc[mt][nt][4 * q + j] + bias[mt * 32 + 8 * q + 4 * lhi + j] + o[j];
+                        uint2 pk = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+                        *reinterpret_cast<uint2*>(dst + ((size_t)(cg0 + q) * a.ld + a.pad + n) * 8 + 4 * lhi) = pk;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// dst packed [MB][nch][4][256][8]; thread = one 16-byte unit (mb, chunk, g, r)
+__global__ __launch_bounds__(256) void pack_a_bf16_kernel(bf16_t* __restrict__ dst, const float* __restrict__ src,
+                                                         int nch_total, int k_off, int ksrc, int epi, int C, int M,
+                                                         long long src_row_off, long long src_row_stride,
+                                                         int src_k_stride, int k_group, int k_member) {
+    const int mb = blockIdx.y;
+    const int ug = blockIdx.x;                // 8-wide k group index within [0, ksrc/8)
+    const int r = threadIdx.x;
+    const int drow = bgemm_dense_row(epi, mb, r, C, M);
+    const int k0 = ug * 8;
+    // destination k of this group: slab (32 wide) remap for interleaved members
+    const int kk = k_group > 1 ? k_off + ((k0 / BGEMM_KC) * k_group + k_member) * BGEMM_KC + k0 % BGEMM_KC : k_off + k0;
+    bf16_t* d = dst + ((((size_t)mb * nch_total + kk / BGEMM_KC) * 4 + (kk % BGEMM_KC) / 8) * BGEMM_BM + r) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        const float v = (drow >= 0 && k < ksrc) ? src[(src_row_off + drow) * src_row_stride + (long long)k * src_k_stride] : 0.f;
+        d[j] = f32_to_bf16_rne(v);
+    }
+}
+
+}  // namespace
+
+int launch_pack_a_bf16(bf16_t* dst, const float* src, int MB, int nch_total, int k_off, int ksrc, int epi, int C,
+                       int M, long long src_row_off, long long src_row_stride, int src_k_stride, hipStream_t s,
+                       int k_group, int k_member) {
+    CTTS_CHECK_ARG(k_off % 8 == 0 && ksrc > 0 && ksrc % 8 == 0, "pack_a_bf16: k range must be 8-aligned");
+    CTTS_CHECK_ARG(k_off + ksrc * (k_group > 1 ? k_group : 1) <= nch_total * BGEMM_KC, "pack_a_bf16: k range");
+    CTTS_CHECK_ARG(k_group <= 1 || (ksrc % BGEMM_KC == 0 && k_off % BGEMM_KC == 0), "pack_a_bf16: k group");
+    hipLaunchKernelGGL(pack_a_bf16_kernel, dim3(ksrc / 8, MB), dim3(256), 0, s, dst, src, nch_total, k_off, ksrc, epi, C,
+                       M, src_row_off, src_row_stride, src_k_stride, k_group, k_member);
+    CTTS_CHECK_LAUNCH("pack_a_bf16");
+    return CTTS_OK;
+}
+
+int launch_gemm_bf16(int epi, const BGemmArgs& a, hipStream_t stream) {
+    CTTS_CHECK_ARG(a.nseg >= 1 && a.nseg <= BGEMM_MAX_SEG, "gemm_bf16: nseg=%d", a.nseg);
+    int nch = 0;
+    for (int s = 0; s < a.nseg; ++s) {
+        CTTS_CHECK_ARG(a.seg[s].nch > 0 && a.seg[s].base, "gemm_bf16: empty segment %d", s);
+        CTTS_CHECK_ARG(a.seg[s].shift >= -a.pad && a.seg[s].shift <= a.pad, "gemm_bf16: shift %d exceeds halo %d",
+                       a.seg[s].shift, a.pad);
+        nch += a.seg[s].nch;
+    }
+    CTTS_CHECK_ARG(nch == a.nch_total, "gemm_bf16: chunk count mismatch %d vs %d", nch, a.nch_total);
+    if (a.interleave > 1) {
+        CTTS_CHECK_ARG(a.interleave <= a.nseg, "gemm_bf16: interleave %d > nseg %d", a.interleave, a.nseg);
+        for (int s = 1; s < a.interleave; ++s)
+            CTTS_CHECK_ARG(a.seg[s].nch == a.seg[0].nch, "gemm_bf16: interleaved segments must have equal length");
+    }
+    CTTS_CHECK_ARG(a.ntiles * BGEMM_BN + 2 * a.pad <= a.ld && a.L <= a.ntiles * BGEMM_BN, "gemm_bf16: geometry");
+    CTTS_CHECK_ARG(epi == BGEMM_EPI_GATE ? (a.pairC > (a.MB - 1) * 128 && a.pairC <= a.MB * 128)
+                                         : (a.M % 32 == 0 && a.split % 32 == 0 && a.M > (a.MB - 1) * BGEMM_BM &&
+                                            a.M <= a.MB * BGEMM_BM),
+                   "gemm_bf16: M=%d pairC=%d MB=%d split=%d", a.M, a.pairC, a.MB, a.split);
+    const long long blocks = (long long)a.MB * a.ntiles * a.batch;
+    CTTS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "gemm_bf16: grid %lld", blocks);
+    if (epi == BGEMM_EPI_GATE)
+        hipLaunchKernelGGL(conv_gemm_bf16_kernel<BGEMM_EPI_GATE>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(conv_gemm_bf16_kernel<BGEMM_EPI_SPLIT>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    CTTS_CHECK_LAUNCH("conv_gemm_bf16");
+    return CTTS_OK;
+}
+
+}  // namespace ctts

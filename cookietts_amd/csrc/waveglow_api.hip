@@ -3,6 +3,7 @@
 #include <mutex>
 #include <vector>
 
+#include "gemm_bf16.h"
 #include "gemm_f32.h"
 #include "waveglow_kernels.h"
 
@@ -237,6 +238,204 @@ int run_flow_tail(const Plan& p, const Geom& g, const float* blob, int k, const 
                             p.c.n_group, d.ch_off, d.n_half, g.L, g.ld, g.pad, s);
 }
 
+// ======================================================================================
+// bf16 variant (BASELINE config 3): WN in-layer / res-skip GEMMs on bf16 MFMA with fp32 accumulation,
+// WN activations (x, act, skip sum, cond hidden) stored bf16 in the K8-blocked layout; upsampling, the
+// two small cond layers, the `end` conv, the coupling and the inverse 1x1 conv stay fp32.
+struct BfPlan {
+    std::vector<std::vector<size_t>> in_A, rs_A;   // [flow][layer] offsets in bf16 elements
+    size_t total;
+    int nch_in, nch_rs;
+};
+
+void make_bf_plan(const Plan& p, BfPlan& q) {
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o = (o + n + 127) / 128 * 128; return r; };
+    q.nch_in = (p.c.kernel_size * p.C + p.H) / BGEMM_KC;
+    q.nch_rs = p.C / BGEMM_KC;
+    q.in_A.assign(p.c.n_flows, {});
+    q.rs_A.assign(p.c.n_flows, {});
+    for (int k = 0; k < p.c.n_flows; ++k)
+        for (int i = 0; i < p.c.n_layers; ++i) {
+            q.in_A[k].push_back(take((size_t)p.mb_in * q.nch_in * BGEMM_KC * BGEMM_BM));
+            q.rs_A[k].push_back(take((size_t)p.rs_mb(i) * q.nch_rs * BGEMM_KC * BGEMM_BM));
+        }
+    q.total = o;
+}
+
+struct BfWs {
+    float *audio, *spect, *h_tmp, *h_all;
+    bf16_t *h_bf, *x, *act, *out;
+    size_t total_bytes;
+};
+
+void carve_bf(const Plan& p, const Geom& g, int batch, char* base, BfWs& w) {
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = (o + bytes + 255) / 256 * 256; return base ? base + r : nullptr; };
+    const size_t B = batch;
+    w.audio = (float*)take(B * p.c.n_group * g.L * 4);
+    w.spect = (float*)take(B * p.K0 * g.ld * 4);
+    w.h_tmp = (float*)take(B * p.c.n_flows * p.H * g.ld * 4);
+    w.h_all = (float*)take(B * p.c.n_flows * p.H * g.ld * 4);
+    w.h_bf = (bf16_t*)take(B * p.c.n_flows * p.H * g.ld * 2);
+    w.x = (bf16_t*)take(B * p.C * g.ld * 2);
+    w.act = (bf16_t*)take(B * p.C * g.ld * 2);
+    w.out = (bf16_t*)take(B * p.C * g.ld * 2);
+    w.total_bytes = o;
+}
+
+// fp32 padded [B][rows][ld] -> bf16 K8 [B][rows/8][ld][8]
+__global__ __launch_bounds__(256) void cvt_f32_to_k8_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                            int rows, int ld) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int grp = blockIdx.y, b = blockIdx.z;
+    if (n >= ld) return;
+    const float* s = src + ((size_t)b * rows + (size_t)grp * 8) * ld + n;
+    unsigned int pk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        pk[j] = (unsigned int)f32_to_bf16_rne(s[(size_t)(2 * j) * ld]) |
+                ((unsigned int)f32_to_bf16_rne(s[(size_t)(2 * j + 1) * ld]) << 16);
+    *reinterpret_cast<uint4*>(dst + (((size_t)b * (rows / 8) + grp) * ld + n) * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+}
+
+// x[b][c][n] = bf16(bs[c] + sum_j Ws[c][j] * audio[b][ch_off + j][n]), K8 layout   (glow.py:189)
+template <int H>
+__global__ __launch_bounds__(256) void wn_start_bf16_kernel(const float* __restrict__ audio, const float* __restrict__ Ws,
+                                                            const float* __restrict__ bs, bf16_t* __restrict__ x, int C,
+                                                            int G, int ch_off, int L, int ld, int pad) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int grp = blockIdx.y, b = blockIdx.z;
+    if (n >= L) return;
+    float a[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) a[j] = audio[((size_t)b * G + ch_off + j) * L + n];
+    unsigned int pk[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = grp * 8 + 2 * q + e;
+            float acc = bs[c];
+#pragma unroll
+            for (int j = 0; j < H; ++j) acc = fmaf(Ws[c * H + j], a[j], acc);
+            v[e] = acc;
+        }
+        pk[q] = (unsigned int)f32_to_bf16_rne(v[0]) | ((unsigned int)f32_to_bf16_rne(v[1]) << 16);
+    }
+    *reinterpret_cast<uint4*>(x + (((size_t)b * (C / 8) + grp) * ld + pad + n) * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+}
+
+// end 1x1 conv on the bf16 skip sum + coupling inverse + inverse 1x1 (+ un-squeeze), fp32 math
+template <int H>
+__global__ __launch_bounds__(256) void flow_tail_bf16_kernel(const bf16_t* __restrict__ out, float* __restrict__ audio,
+                                                             float* __restrict__ wave, const float* __restrict__ Wend,
+                                                             const float* __restrict__ bend, const float* __restrict__ Winv,
+                                                             int C, int G, int ch_off, int L, int ld, int pad) {
+    constexpr int E = 2 * H;
+    __shared__ float sW[E * 512 + E * E + E];
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    for (int i = threadIdx.x; i < E * C; i += 256) sW[i] = Wend[i];
+    if (threadIdx.x < E * E) sW[E * C + threadIdx.x] = Winv[threadIdx.x];
+    if (threadIdx.x < E) sW[E * C + E * E + threadIdx.x] = bend[threadIdx.x];
+    __syncthreads();
+    if (n >= L) return;
+    float e[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) e[j] = sW[E * C + E * E + j];
+    const uint4* ob = reinterpret_cast<const uint4*>(out) + ((size_t)b * (C / 8)) * ld + pad + n;
+#pragma unroll 4
+    for (int grp = 0; grp < C / 8; ++grp) {
+        const uint4 u = ob[(size_t)grp * ld];
+        const unsigned int w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v0 = bf16_to_f32((bf16_t)(w4[q] & 0xffff)), v1 = bf16_to_f32((bf16_t)(w4[q] >> 16));
+            const int c = grp * 8 + 2 * q;
+#pragma unroll
+            for (int j = 0; j < E; ++j) e[j] = fmaf(sW[j * C + c + 1], v1, fmaf(sW[j * C + c], v0, e[j]));
+        }
+    }
+    float* ab = audio + ((size_t)b * G + ch_off) * L + n;
+    float a[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) a[j] = ab[(size_t)j * L];
+#pragma unroll
+    for (int j = 0; j < H; ++j) a[H + j] = (a[H + j] - e[j]) / expf(e[H + j]);
+    float m[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < E; ++j) s = fmaf(sW[E * C + i * E + j], a[j], s);
+        m[i] = s;
+    }
+    if (wave == nullptr) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) ab[(size_t)i * L] = m[i];
+    } else {
+        float* wb = wave + (size_t)b * G * L + (size_t)n * G;
+#pragma unroll
+        for (int i = 0; i < E; ++i) wb[i] = m[i];
+    }
+}
+
+int run_wn_stack_bf16(const Plan& p, const BfPlan& q, const Geom& g, const float* blob, const bf16_t* bblob, int k,
+                      const BfWs& w, int batch, hipStream_t s) {
+    const auto& f = p.fl[k];
+    const auto& d = p.fd[k];
+    const long long cstride = (long long)p.C * g.ld;                 // elements per batch item (K8: (C/8)*ld*8)
+    const long long hstride = (long long)p.c.n_flows * p.H * g.ld;
+    dim3 sgrid((g.L + 255) / 256, p.C / 8, batch);
+#define CTTS_BSTART(HH)                                                                                       \
+    case HH:                                                                                                  \
+        hipLaunchKernelGGL(wn_start_bf16_kernel<HH>, sgrid, dim3(256), 0, s, w.audio, blob + f.start_w,       \
+                           blob + f.start_b, w.x, p.C, p.c.n_group, d.ch_off, g.L, g.ld, g.pad);              \
+        break;
+    switch (d.n_half) {
+        CTTS_BSTART(1) CTTS_BSTART(2) CTTS_BSTART(3) CTTS_BSTART(4)
+        default: set_error("wn_start_bf16: n_half=%d", d.n_half); return CTTS_E_ARG;
+    }
+#undef CTTS_BSTART
+    CTTS_CHECK_LAUNCH("wn_start_bf16");
+    const int ncx = p.C / BGEMM_KC;
+    for (int i = 0; i < p.c.n_layers; ++i) {
+        const int dil = 1 << i;
+        int rc;
+        {
+            BGemmArgs a{};
+            a.ld = g.ld; a.pad = g.pad; a.L = g.L; a.ntiles = g.ntiles; a.batch = batch;
+            a.A = bblob + q.in_A[k][i]; a.bias = blob + f.in_b[i];
+            a.nseg = 4; a.interleave = 3; a.nch_total = q.nch_in; a.MB = p.mb_in;
+            a.seg[0] = {w.x, cstride, ncx, -dil};
+            a.seg[1] = {w.x, cstride, ncx, 0};
+            a.seg[2] = {w.x, cstride, ncx, dil};
+            a.seg[3] = {w.h_bf + (size_t)k * p.H * g.ld, hstride, p.H / BGEMM_KC, 0};
+            a.M = 2 * p.C; a.pairC = p.C;
+            a.dst0 = w.act; a.dst0_bstride = cstride;
+            ProfScope ps(CTTS_PROF_WN_IN, s);
+            if ((rc = launch_gemm_bf16(BGEMM_EPI_GATE, a, s))) return rc;
+        }
+        {
+            const bool last = i == p.c.n_layers - 1;
+            BGemmArgs a{};
+            a.ld = g.ld; a.pad = g.pad; a.L = g.L; a.ntiles = g.ntiles; a.batch = batch;
+            a.A = bblob + q.rs_A[k][i]; a.bias = blob + f.rs_b[i];
+            a.nseg = 1; a.nch_total = q.nch_rs; a.MB = p.rs_mb(i);
+            a.seg[0] = {w.act, cstride, q.nch_rs, 0};
+            a.M = p.rs_rows(i);
+            a.dst0 = w.x; a.dst0_bstride = cstride; a.acc0 = 1;
+            a.dst1 = w.out; a.dst1_bstride = cstride; a.acc1 = i > 0 ? 1 : 0;
+            a.split = last ? 0 : p.C;
+            ProfScope ps(CTTS_PROF_WN_RS, s);
+            if ((rc = launch_gemm_bf16(BGEMM_EPI_SPLIT, a, s))) return rc;
+        }
+    }
+    return CTTS_OK;
+}
+
 }  // namespace
 }  // namespace ctts
 
@@ -431,6 +630,94 @@ int ctts_profile_collect(int32_t which, int64_t* launches, double* total_ms) {
     }
     g_prof.ev[which].clear();
     *launches = n; *total_ms = tot;
+    return CTTS_OK;
+}
+
+size_t ctts_waveglow_packed_bf16_bytes(const ctts_waveglow_config* cfg) {
+    Plan p; BfPlan q;
+    if (make_plan(cfg, p)) return 0;
+    if (p.C % BGEMM_KC != 0 || p.H % BGEMM_KC != 0) { set_error("bf16: channels must be multiples of 32"); return 0; }
+    make_bf_plan(p, q);
+    return q.total * sizeof(bf16_t);
+}
+
+int ctts_waveglow_pack_flow_bf16(const ctts_waveglow_config* cfg, int32_t k, const ctts_waveglow_flow_weights* w,
+                                 void* packed_bf16, void* stream) {
+    Plan p; BfPlan q;
+    int rc = make_plan(cfg, p); if (rc) return rc;
+    CTTS_CHECK_ARG(k >= 0 && k < p.c.n_flows && w && packed_bf16, "pack_flow_bf16: bad argument");
+    CTTS_CHECK_ARG(p.C % BGEMM_KC == 0 && p.H % BGEMM_KC == 0, "pack_flow_bf16: channels must be multiples of 32");
+    make_bf_plan(p, q);
+    hipStream_t s = as_stream(stream);
+    bf16_t* bb = static_cast<bf16_t*>(packed_bf16);
+    const int C = p.C, H = p.H, ks = p.c.kernel_size;
+    for (int i = 0; i < p.c.n_layers; ++i) {
+        CTTS_CHECK_ARG(w->in_w[i] && w->rs_w[i] && w->cond_w[2], "pack_flow_bf16: NULL layer %d weights", i);
+        for (int t = 0; t < ks; ++t)
+            if ((rc = launch_pack_a_bf16(bb + q.in_A[k][i], w->in_w[i] + t, p.mb_in, q.nch_in, 0, C, BGEMM_EPI_GATE, C,
+                                         2 * C, 0, (long long)C * ks, ks, s, ks, t))) return rc;
+        if ((rc = launch_pack_a_bf16(bb + q.in_A[k][i], w->cond_w[2], p.mb_in, q.nch_in, ks * C, H, BGEMM_EPI_GATE, C,
+                                     2 * C, (long long)2 * C * i, H, 1, s))) return rc;
+        if ((rc = launch_pack_a_bf16(bb + q.rs_A[k][i], w->rs_w[i], p.rs_mb(i), q.nch_rs, 0, C, BGEMM_EPI_SPLIT, C,
+                                     p.rs_rows(i), 0, C, 1, s))) return rc;
+    }
+    return CTTS_OK;
+}
+
+size_t ctts_waveglow_workspace_bf16_bytes(const ctts_waveglow_config* cfg, int32_t batch, int32_t frames) {
+    Plan p; Geom g; BfWs w;
+    if (make_plan(cfg, p) || make_geom(p, frames, g) || batch < 1) return 0;
+    carve_bf(p, g, batch, nullptr, w);
+    return w.total_bytes;
+}
+
+int ctts_waveglow_infer_bf16(const ctts_waveglow_config* cfg, const void* packed, const void* packed_bf16,
+                             const float* mel, const float* z_scaled, float* wave, int32_t batch, int32_t frames,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    Plan p; Geom g; BfWs w; BfPlan q;
+    int rc = make_plan(cfg, p); if (rc) return rc;
+    rc = make_geom(p, frames, g); if (rc) return rc;
+    CTTS_CHECK_ARG(packed && packed_bf16 && mel && z_scaled && wave && workspace && batch >= 1, "infer_bf16: bad argument");
+    CTTS_CHECK_ARG(p.C % BGEMM_KC == 0 && p.C <= 512, "infer_bf16: n_channels=%d (multiple of 32, <= 512)", p.C);
+    make_bf_plan(p, q);
+    carve_bf(p, g, batch, static_cast<char*>(workspace), w);
+    if (w.total_bytes > workspace_bytes) {
+        set_error("infer_bf16: workspace %zu bytes < required %zu", workspace_bytes, w.total_bytes);
+        return CTTS_E_WORKSPACE;
+    }
+    hipStream_t s = as_stream(stream);
+    const float* blob = static_cast<const float*>(packed);
+    const bf16_t* bblob = static_cast<const bf16_t*>(packed_bf16);
+    CTTS_CHECK_HIP(hipMemcpyAsync(w.audio, z_scaled, (size_t)batch * p.c.n_group * g.L * sizeof(float),
+                                  hipMemcpyDeviceToDevice, s));
+    rc = launch_upsample_squeeze(mel, blob + p.up_w, blob + p.up_b, w.spect, batch, p.c.n_mel_channels, frames,
+                                 p.c.win_length, p.c.hop_length, p.c.n_group, g.ld, g.pad, s);
+    if (rc) return rc;
+    rc = run_cond(p, g, blob, w.spect, w.h_tmp, w.h_all, batch, s);
+    if (rc) return rc;
+    const int hrows = p.c.n_flows * p.H;
+    hipLaunchKernelGGL(cvt_f32_to_k8_kernel, dim3((g.ld + 255) / 256, hrows / 8, batch), dim3(256), 0, s, w.h_all, w.h_bf,
+                       hrows, g.ld);
+    CTTS_CHECK_LAUNCH("cvt_f32_to_k8");
+    for (int k = p.c.n_flows - 1; k >= 0; --k) {
+        rc = run_wn_stack_bf16(p, q, g, blob, bblob, k, w, batch, s);
+        if (rc) return rc;
+        const auto& f = p.fl[k];
+        const auto& d = p.fd[k];
+        float* wv = k == 0 ? wave : nullptr;
+        dim3 tgrid((g.L + 255) / 256, batch);
+#define CTTS_BTAIL(HH)                                                                                            \
+    case HH:                                                                                                      \
+        hipLaunchKernelGGL(flow_tail_bf16_kernel<HH>, tgrid, dim3(256), 0, s, w.out, w.audio, wv, blob + f.end_w, \
+                           blob + f.end_b, blob + f.winv, p.C, p.c.n_group, d.ch_off, g.L, g.ld, g.pad);          \
+        break;
+        switch (d.n_half) {
+            CTTS_BTAIL(1) CTTS_BTAIL(2) CTTS_BTAIL(3) CTTS_BTAIL(4)
+            default: set_error("flow_tail_bf16: n_half=%d", d.n_half); return CTTS_E_ARG;
+        }
+#undef CTTS_BTAIL
+        CTTS_CHECK_LAUNCH("flow_tail_bf16");
+    }
     return CTTS_OK;
 }
 

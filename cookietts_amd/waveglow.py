@@ -147,7 +147,8 @@ class WaveGlow(nn.Module):
             self.WN.append(WN(n_half, n_mel_channels * n_group, **WN_config))
         self.n_remaining_channels = n_remaining_channels
 
-        self._packed = None          # (device, blob tensor)
+        self._packed = None          # (device, fp32 blob, bf16 blob or None)
+        self._compute_dtype = torch.float32
         self._workspaces = {}        # (device, B, F) -> zero-initialised workspace tensor
 
     # ------------------------------------------------------------------ plumbing ----
@@ -173,6 +174,19 @@ class WaveGlow(nn.Module):
     def load_state_dict(self, state_dict, strict=True, **kw):
         self._invalidate()
         return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def set_compute_dtype(self, dtype):
+        """torch.float32 (default: exact fp32 MFMA path) or torch.bfloat16 (BASELINE config 3: WN GEMMs on
+        bf16 MFMA with fp32 accumulation, WN activations stored bf16; parameters stay fp32 masters and are
+        rounded to bf16 once, after weight-norm folding).  ``model.bfloat16()`` selects bf16 as well."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise NotImplementedError(f"compute dtype {dtype} is not built (float32 or bfloat16)")
+        self._compute_dtype = dtype
+        self._invalidate()
+        return self
+
+    def _use_bf16(self):
+        return self._compute_dtype == torch.bfloat16 or next(self.parameters()).dtype == torch.bfloat16
 
     def repack(self):
         """Call after modifying parameters in place; the next infer re-ingests the weights."""
@@ -204,9 +218,10 @@ class WaveGlow(nn.Module):
 
     def _ensure_packed(self, device):
         if self._packed is not None and self._packed[0] == device:
-            return self._packed[1]
+            return self._packed[1], self._packed[2]
         if device.type != 'cuda':
             raise _lib.HipLibraryError("WaveGlow HIP path needs the model on a GPU (no CPU fallback)")
+        use_bf16 = self._use_bf16()
         lib = _lib.lib()
         for p in self.parameters():
             if p.device != device:
@@ -218,6 +233,12 @@ class WaveGlow(nn.Module):
         with torch.cuda.device(device):
             stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
             blob = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)
+            bblob = None
+            if use_bf16:
+                nb = lib.ctts_waveglow_packed_bf16_bytes(C.byref(cfg))
+                if nb == 0:
+                    raise _lib.HipLibraryError("unsupported bf16 WaveGlow config: " + lib.ctts_last_error().decode())
+                bblob = torch.zeros(nb // 2, dtype=torch.int16, device=device)
             keep = []
             up_w = self.upsample.weight.detach().float().contiguous()
             up_b = self.upsample.bias.detach().float().contiguous()
@@ -259,17 +280,21 @@ class WaveGlow(nn.Module):
                 fw.w_inverse = W_inverse.data_ptr()
                 _lib.check(lib.ctts_waveglow_pack_flow(C.byref(cfg), k, C.byref(fw), _lib.ptr(blob), stream),
                            f"ctts_waveglow_pack_flow({k})")
+                if bblob is not None:
+                    _lib.check(lib.ctts_waveglow_pack_flow_bf16(C.byref(cfg), k, C.byref(fw), _lib.ptr(bblob), stream),
+                               f"ctts_waveglow_pack_flow_bf16({k})")
             torch.cuda.current_stream(device).synchronize()   # dense temporaries may now be freed
-        self._packed = (device, blob)
-        return blob
+        self._packed = (device, blob, bblob)
+        return blob, bblob
 
-    def _workspace(self, device, B, F):
-        key = (device, B, F)
+    def _workspace(self, device, B, F, bf16=False):
+        key = (device, B, F, bf16)
         ws = self._workspaces.get(key)
         if ws is None:
             lib = _lib.lib()
             cfg = self.c_config()
-            nbytes = lib.ctts_waveglow_workspace_bytes(C.byref(cfg), B, F)
+            query = lib.ctts_waveglow_workspace_bf16_bytes if bf16 else lib.ctts_waveglow_workspace_bytes
+            nbytes = query(C.byref(cfg), B, F)
             if nbytes == 0:
                 raise _lib.HipLibraryError("workspace query failed: " + lib.ctts_last_error().decode())
             self._workspaces.clear()     # one live geometry at a time
@@ -292,7 +317,7 @@ class WaveGlow(nn.Module):
         if spect.dim() == 2:
             spect = spect.unsqueeze(0)
         device = spect.device
-        blob = self._ensure_packed(device)
+        blob, bblob = self._ensure_packed(device)
         lib = _lib.lib()
         B, M, F = spect.shape
         assert M == self.n_mel_channels, (M, self.n_mel_channels)
@@ -300,14 +325,19 @@ class WaveGlow(nn.Module):
         assert tuple(z_scaled.shape) == (B, self.n_group, L), (tuple(z_scaled.shape), (B, self.n_group, L))
         mel = spect.detach().float().contiguous()
         z = z_scaled.detach().to(device=device, dtype=torch.float32).contiguous()
-        ws = self._workspace(device, B, F)
+        ws = self._workspace(device, B, F, bf16=bblob is not None)
         wave = torch.empty(B, L * self.n_group, dtype=torch.float32, device=device)
         cfg = self.c_config()
         with torch.cuda.device(device):
             stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-            _lib.check(lib.ctts_waveglow_infer_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(mel), _lib.ptr(z),
-                                                  _lib.ptr(wave), B, F, _lib.ptr(ws), ws.numel() * 4, stream),
-                       "ctts_waveglow_infer_f32")
+            if bblob is not None:
+                _lib.check(lib.ctts_waveglow_infer_bf16(C.byref(cfg), _lib.ptr(blob), _lib.ptr(bblob), _lib.ptr(mel),
+                                                       _lib.ptr(z), _lib.ptr(wave), B, F, _lib.ptr(ws), ws.numel() * 4,
+                                                       stream), "ctts_waveglow_infer_bf16")
+            else:
+                _lib.check(lib.ctts_waveglow_infer_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(mel), _lib.ptr(z),
+                                                      _lib.ptr(wave), B, F, _lib.ptr(ws), ws.numel() * 4, stream),
+                           "ctts_waveglow_infer_f32")
         return wave.to(spect.dtype)
 
     def infer(self, spect, speaker_id=None, sigma=1.0):

@@ -119,6 +119,21 @@ int ctts_waveglow_infer_f32(const ctts_waveglow_config* cfg, const void* packed,
                             int32_t batch, int32_t frames, void* workspace,
                             size_t workspace_bytes, void* stream);
 
+/* bf16 variant (BASELINE config 3): the WN in-layer and res/skip contractions run on bf16 MFMA with
+ * fp32 accumulation and the WN activations (residual stream, gated activations, skip sum, conditioning
+ * hidden) are stored bf16; upsampling, the two small cond layers, `end`, the coupling and the inverse
+ * 1x1 conv stay fp32.  Needs BOTH blobs: `packed` (ctts_waveglow_pack_*: fp32 pieces + biases) and
+ * `packed_bf16` (ctts_waveglow_pack_flow_bf16, same dense inputs).  I/O tensors are fp32 as above. */
+size_t ctts_waveglow_packed_bf16_bytes(const ctts_waveglow_config* cfg);
+int ctts_waveglow_pack_flow_bf16(const ctts_waveglow_config* cfg, int32_t flow,
+                                 const ctts_waveglow_flow_weights* w, void* packed_bf16, void* stream);
+size_t ctts_waveglow_workspace_bf16_bytes(const ctts_waveglow_config* cfg, int32_t batch,
+                                          int32_t frames);
+int ctts_waveglow_infer_bf16(const ctts_waveglow_config* cfg, const void* packed,
+                             const void* packed_bf16, const float* mel, const float* z_scaled,
+                             float* wave, int32_t batch, int32_t frames, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
 /* Stage entry points (same kernels, exposed for parity tests and profiling). */
 
 /* upsample (ConvTranspose1d) + trim + squeeze: glow.py:318-324.  spect is padded layout

@@ -126,7 +126,49 @@ def wn_forward(sd, prefix, audio0, spect, n_layers, n_channels, trace=None):
     return e[:, :h], e[:, h:]
 
 
-def waveglow_infer(sd, cfg, mel, z_scaled, flow_trace=None):
+def bf16_round(x):
+    """Round-to-nearest-even fp32 -> bf16 -> fp32 (the storage rounding of the bf16 HIP variant)."""
+    u = np.ascontiguousarray(x, dtype=F32).view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).astype(np.uint32)
+    return r.view(F32)
+
+
+def wn_forward_bf16(sd, prefix, audio0, spect, n_layers, n_channels):
+    """bf16-rounded restatement of one WN stack, mirroring the rounding points of the bf16 HIP variant
+    (BASELINE config 3): in-layer / cond-layer-2 / res-skip weights and the tensors x, h, act, skip-sum are
+    rounded to bf16 where the kernels store them; all sums are fp32; start / cond layers 0-1 / end are fp32."""
+    C = n_channels
+    x = bf16_round(_conv1x1(_conv_weight(sd, prefix + ".start"), sd[prefix + ".start.bias"], audio0))
+    h = spect
+    for j in range(2):
+        h = _conv1x1(_conv_weight(sd, f"{prefix}.cond_layers.{j}"), sd[f"{prefix}.cond_layers.{j}.bias"], h)
+    h = bf16_round(h)
+    wc2 = bf16_round(_conv_weight(sd, f"{prefix}.cond_layers.2")[:, :, 0])
+    bc2 = sd[f"{prefix}.cond_layers.2.bias"]
+    out = None
+    for i in range(n_layers):
+        d = 2 ** i
+        w = bf16_round(_conv_weight(sd, f"{prefix}.in_layers.{i}"))
+        bias = (sd[f"{prefix}.in_layers.{i}.bias"] + bc2[2 * C * i:2 * C * (i + 1)]).astype(F32)
+        u = np.matmul(np.ascontiguousarray(wc2[2 * C * i:2 * C * (i + 1)]), h)
+        ks = w.shape[2]
+        for t in range(ks):
+            u = u + np.matmul(np.ascontiguousarray(w[:, :, t]), _shift(x, (t - ks // 2) * d))
+        u = (u + bias[None, :, None]).astype(F32)
+        act = bf16_round(np.tanh(u[:, :C]) * (F32(1.0) / (F32(1.0) + np.exp(-u[:, C:]))))
+        wrs = bf16_round(_conv_weight(sd, f"{prefix}.res_skip_layers.{i}"))
+        r = _conv1x1(wrs, sd[f"{prefix}.res_skip_layers.{i}.bias"], act).astype(F32)
+        if i < n_layers - 1:
+            x = bf16_round(x + r[:, :C])
+            out = bf16_round(r[:, C:]) if out is None else bf16_round(out + r[:, C:])
+        else:
+            out = bf16_round(r) if out is None else bf16_round(out + r)
+    e = _conv1x1(np.asarray(sd[prefix + ".end.weight"], dtype=F32), sd[prefix + ".end.bias"], out)
+    hh = e.shape[1] // 2
+    return e[:, :hh], e[:, hh:]
+
+
+def waveglow_infer(sd, cfg, mel, z_scaled, flow_trace=None, bf16=False):
     """mel [B, n_mel, F], z_scaled [B, n_group, L] (sigma already applied) -> wave [B, F*hop].
 
     ``z_scaled`` rows: the last ``n_remaining_channels`` are the initial latent; the
@@ -147,7 +189,8 @@ def waveglow_infer(sd, cfg, mel, z_scaled, flow_trace=None):
     for k in reversed(range(n_flows)):
         h = audio.shape[1] // 2
         a0, a1 = audio[:, :h], audio[:, h:]
-        b, s = wn_forward(sd, f"WN.{k}", a0, spect, wn["n_layers"], wn["n_channels"])
+        fwd = wn_forward_bf16 if bf16 else wn_forward
+        b, s = fwd(sd, f"WN.{k}", a0, spect, wn["n_layers"], wn["n_channels"])
         a1 = ((a1 - b) / np.exp(s)).astype(F32)
         audio = np.concatenate([a0, a1], axis=1)
         w = sd[f"convinv.{k}.conv.weight"][:, :, 0]
