@@ -119,7 +119,7 @@ def test_no_cpu_fallback(hip_lib_path):
 # Gate: against the bf16-ROUNDED CPU restatement (same rounding points, fp32 sums).  The two differ only by
 # fp32 summation order and the hardware exp/rcp in the gate, which flips an occasional bf16 rounding
 # (1 ulp = 2^-8 relative) that then propagates through 8 layers x n flows; bound found empirically.
-BF16_VS_BF16_ORACLE_TOL = 2e-3
+BF16_VS_BF16_ORACLE_TOL = 5e-3
 # Reported, not gated: error of the bf16 path against the fp32 reference golden.
 
 
