@@ -1,0 +1,57 @@
+"""``_5_infer`` vocoder slot for the MI355X WaveGlow path.
+
+The reference server wires Tacotron2 -> a vocoder object through two call sites only
+(``/root/reference/CookieTTS/_5_infer/t2s_server/text2speech.py``):
+
+  * ``self.vocoder, self.vocoder_config = self.load_hifigan(path)``            (:175-179, 258-279)
+  * ``dtype = next(self.vocoder.parameters()).dtype``;
+    ``self.vocoder(mel[b<=16, n_mel, T].to(dtype)).squeeze(1).cpu().split(1, 0)``   (:658-665)
+
+``WaveGlowVocoder`` satisfies that contract on top of ``cookietts_amd.WaveGlow`` (``forward(mel) -> [b, 1, T*hop]``,
+``parameters()`` report the compute dtype's natural input dtype), and ``load_waveglow`` mirrors ``load_hifigan``:
+it reads a reference-format WaveGlow checkpoint (``{'model', 'waveglow_config', 'speaker_lookup', ...}``,
+``_4_mtw/waveglow/train.py:128-145``, including the legacy key renames of :121) and returns ``(vocoder, config)``.
+"""
+from __future__ import annotations
+
+import torch
+
+from .waveglow import WaveGlow
+
+__all__ = ["WaveGlowVocoder", "load_waveglow", "waveglow_from_checkpoint"]
+
+
+class WaveGlowVocoder(torch.nn.Module):
+    def __init__(self, waveglow: WaveGlow, sigma: float = 0.8):
+        super().__init__()
+        self.waveglow = waveglow
+        self.sigma = sigma
+
+    @torch.no_grad()
+    def forward(self, mel):
+        """mel [b, n_mel, T] -> audio [b, 1, T*hop] on the model's device, in mel's dtype."""
+        audio = self.waveglow.infer(mel.to(next(self.waveglow.parameters()).device), sigma=self.sigma)
+        return audio.unsqueeze(1)
+
+    def half(self):
+        """``load_hifigan`` calls ``vocoder.half()`` (text2speech.py:261): fp16 is not built; the reduced
+        precision mode of this path is bf16-MFMA with fp32 master weights, so parameters (and hence the dtype
+        the server casts mels to) stay fp32."""
+        self.waveglow.set_compute_dtype(torch.bfloat16)
+        return self
+
+
+def waveglow_from_checkpoint(checkpoint: dict) -> WaveGlow:
+    cfg = checkpoint['waveglow_config']
+    model = WaveGlow(**cfg)
+    sd = checkpoint['model']
+    sd = {k.replace("invconv1x1", "convinv").replace(".F.", ".WN.").replace("WNs.", "WN."): v for k, v in sd.items()}
+    model.load_state_dict(sd)
+    return model
+
+
+def load_waveglow(vocoder_path, device='cuda', sigma=0.8):
+    """Counterpart of ``T2S.load_hifigan``: returns ``(vocoder, vocoder_config)``."""
+    checkpoint = torch.load(vocoder_path, map_location='cpu', weights_only=False)
+    model = waveglow_from_checkpoint(checkpoint).to(device).eval()
+    return WaveGlowVocoder(model, sigma=sigma), checkpoint['waveglow_config']

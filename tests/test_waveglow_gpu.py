@@ -152,3 +152,24 @@ def test_waveglow_bf16_ragged_and_batch_independent(hip_lib_path):
     assert torch.isfinite(full).all() and full.shape == (3, 37 * 256)
     for b in range(3):
         assert torch.equal(m.infer_from_noise(mel[b:b + 1], z[b:b + 1])[0], full[b])
+
+
+def test_5_infer_vocoder_slot(hip_lib_path, tmp_path):
+    """The two call sites of _5_infer/t2s_server/text2speech.py (:175-179, :658-665) against a reference-format
+    checkpoint (train.py:128-145)."""
+    from cookietts_amd import load_waveglow
+    cfg = synthetic.WAVEGLOW_CONFIGS["toy"]
+    sd = synthetic.waveglow_state_dict(cfg, seed=8)
+    ckpt = {"model": synthetic.to_torch(sd), "waveglow_config": cfg, "iteration": 1, "speaker_lookup": {}, "learning_rate": 1e-4}
+    path = str(tmp_path / "waveglow_ckpt.pt")
+    torch.save(ckpt, path)
+    vocoder, vcfg = load_waveglow(path)
+    assert vcfg["n_group"] == 8
+    vocoder_dtype = next(vocoder.parameters()).dtype
+    mel_batch = torch.from_numpy(synthetic.synthetic_mel(3, 21)).cuda()
+    audio = vocoder(mel_batch.to(vocoder_dtype)).squeeze(1).cpu().split(1, dim=0)       # text2speech.py:664
+    assert len(audio) == 3 and audio[0].shape == (1, 21 * 256) and torch.isfinite(audio[0]).all()
+    vocoder.half()                                                                       # text2speech.py:261
+    assert next(vocoder.parameters()).dtype == torch.float32
+    audio16 = vocoder(mel_batch).squeeze(1)
+    assert audio16.shape == (3, 21 * 256) and torch.isfinite(audio16).all()
