@@ -76,6 +76,17 @@ class TacoDecoderWeights(C.Structure):
                 ("windowed_att_pos_offset", C.c_float), ("exp_smoothing_factor", C.c_float)]
 
 
+class Conv1dDesc(C.Structure):
+    """``ctts_conv1d_desc``."""
+    _fields_ = [("c_in", C.c_int32), ("c_out", C.c_int32), ("kernel_size", C.c_int32), ("act", C.c_int32),
+                ("slope", C.c_float)]
+
+
+class TacoMemoryWeights(C.Structure):
+    _fields_ = [(n, _FP) for n in ("sylps_w", "sylps_b", "speaker_embedding", "syl_w0", "syl_b0", "syl_w2", "syl_b2",
+                                   "syl_res_weight", "tm_gamma", "tm_beta", "tm_mean", "tm_var", "tm_w", "tm_b")]
+
+
 # name -> (restype, argtypes); kept in one table so tests can check every symbol the
 # header declares is exported.
 _CFG = C.POINTER(WaveGlowConfig)
@@ -109,6 +120,24 @@ SIGNATURES = {
                                              C.c_size_t, _FP]),
     "ctts_taco_decoder_steps_f32": (C.c_int, [C.POINTER(TacoDecoderConfig), _FP, _FP, _FP, _FP, _FP, C.c_int32,
                                               C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP, _FP]),
+    "ctts_conv1d_packed_bytes": (C.c_size_t, [C.POINTER(Conv1dDesc)]),
+    "ctts_conv1d_pack_f32": (C.c_int, [C.POINTER(Conv1dDesc), _FP, _FP, _FP, _FP, _FP, _FP, C.c_float, _FP, _FP]),
+    "ctts_conv1d_f32": (C.c_int, [C.POINTER(Conv1dDesc), _FP, _FP, _FP, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_int32, _FP]),
+    "ctts_lstm_seq_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "ctts_lstm_seq_pack_f32": (C.c_int, [C.POINTER(LstmWeights), C.c_int32, C.c_int32, _FP, _FP]),
+    "ctts_lstm_seq_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "ctts_lstm_seq_f32": (C.c_int, [_FP, _FP, _FP, C.c_int32, _FP, C.c_int64, C.c_int32, C.c_int32, _FP, C.c_int32,
+                                    C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP,
+                                    C.c_size_t, _FP]),
+    "ctts_taco_embed_f32": (C.c_int, [_FP, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_int32, _FP]),
+    "ctts_taco_memory_f32": (C.c_int, [C.POINTER(TacoMemoryWeights), _FP, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP]),
+    "ctts_pad_rows_f32": (C.c_int, [_FP, C.c_int64, C.c_int32, _FP, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int32, _FP]),
+    "ctts_unpad_rows_f32": (C.c_int, [_FP, _FP, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_int32, _FP]),
     "ctts_stft_packed_bytes": (C.c_size_t, [C.POINTER(StftConfig)]),
     "ctts_stft_pack": (C.c_int, [C.POINTER(StftConfig), _FP, _FP, _FP, _FP]),
     "ctts_stft_workspace_bytes": (C.c_size_t, [C.POINTER(StftConfig), C.c_int32, C.c_int32]),

@@ -32,6 +32,9 @@ enum GemmEpilogue : int {
     GEMM_EPI_MAG = 2,
     // dst0[row] = log(max(acc + bias, clip))                                 (mel projection + log)
     GEMM_EPI_LOG = 3,
+    // dst0[row] = leaky_relu(acc + bias, clip as slope) / tanh(acc + bias)    (Tacotron encoder / postnet convs)
+    GEMM_EPI_LRELU = 4,
+    GEMM_EPI_TANH = 5,
 };
 
 __host__ __device__ inline bool gemm_epi_is_pair(int epi) { return epi == GEMM_EPI_GATE || epi == GEMM_EPI_MAG; }
@@ -65,7 +68,7 @@ struct GemmArgs {
     int split;            // GEMM_EPI_SPLIT row split (multiple of 32); pair epilogues: unused
     int pairC;            // pair epilogues: number of valid channels (dense rows c and pairC + c)
     int dst_ld, dst_pad;  // row stride / left pad of the destination tensors (usually == ld, pad)
-    float clip;           // GEMM_EPI_LOG clamp
+    float clip;           // GEMM_EPI_LOG clamp / GEMM_EPI_LRELU negative slope
 };
 
 // Row of the dense weight matrix held by block-local row r of M-block mb, or -1 for padding

@@ -287,6 +287,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
                         float v = acc[mt][nt][r] + bias[mt * 32 + row] + old[nt][r];
                         if constexpr (EPI == GEMM_EPI_LOG) v = logf(fmaxf(v, a.clip));
+                        if constexpr (EPI == GEMM_EPI_LRELU) v = v > 0.f ? v : a.clip * v;
+                        if constexpr (EPI == GEMM_EPI_TANH) v = tanhf(v);
                         if (rbase + row < a.M) dst[(size_t)(rdst + row) * a.dst_ld + a.dst_pad + n] = v;
                     }
                 }
@@ -344,6 +346,8 @@ int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
         case GEMM_EPI_GATE: launch_shape<GEMM_EPI_GATE>(a.bm, grid, stream, a); break;
         case GEMM_EPI_MAG: launch_shape<GEMM_EPI_MAG>(a.bm, grid, stream, a); break;
         case GEMM_EPI_LOG: launch_shape<GEMM_EPI_LOG>(a.bm, grid, stream, a); break;
+        case GEMM_EPI_LRELU: launch_shape<GEMM_EPI_LRELU>(a.bm, grid, stream, a); break;
+        case GEMM_EPI_TANH: launch_shape<GEMM_EPI_TANH>(a.bm, grid, stream, a); break;
         case GEMM_EPI_SPLIT: launch_shape<GEMM_EPI_SPLIT>(a.bm, grid, stream, a); break;
         default: set_error("gemm: unknown epilogue %d", epi); return CTTS_E_ARG;
     }

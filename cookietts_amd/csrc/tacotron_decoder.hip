@@ -12,7 +12,8 @@
 //   attention_step: one workgroup per utterance; windowed attention (+-16 tokens) means only 33
 //   energies are finite, so location conv, energies, softmax (wave-level reductions), context and the
 //   expected position are computed for the window only; weights outside it are exact zeros.
-#include "common.h"
+#include "gemm_f32.h"
+#include "waveglow_kernels.h"
 
 namespace ctts {
 namespace {
@@ -190,6 +191,17 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restric
 }
 
 // ---- LSTM cell step ------------------------------------------------------------------
+// Sequence mode (packed-sequence nn.LSTM, one direction): the input projection W_ih x_t + b was computed for
+// all t by one GEMM (gadd), item b is active while step < lengths[b] and reads/writes time index
+// t_b = step (forward) or lengths[b]-1-step (reverse); inactive items keep their state.
+struct LstmSeq {
+    const float* gadd;        // [B][4H][ld] padded layout, NULL = decoder mode
+    long long ga_bstride; int ga_ld, ga_pad;
+    const int* lengths; int step, reverse;
+    float* out; long long out_bstride; int out_tstride, out_col;
+    float* hn; int hn_stride, hn_col;
+};
+
 // inputs in0|in1|in2 are [NB][n_i] row-major pieces of the concatenated cell input.
 template <int NB, int R>
 __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict__ Wih, const float* __restrict__ Whh,
@@ -198,8 +210,8 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
                                                         const float* __restrict__ in1, int n1,
                                                         const float* __restrict__ in2, int n2,
                                                         const float* __restrict__ h_old, float* __restrict__ h_new,
-                                                        float* __restrict__ c, const float* __restrict__ h_add,
-                                                        int I, int H) {
+                                                        float* __restrict__ c, const LstmSeq sq,
+                                                        int I, int H, int batch) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = I + H;
     float* xs = smem;                       // [NB][K]   cell input | previous hidden
@@ -276,19 +288,40 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const float s = wave_sum(acc[r][b]);
-            if (lane == 0) gates[(g * R + r) * NB + b] = s + bih[g * H + u0 + r] + bhh[g * H + u0 + r];
+            if (lane == 0) gates[(g * R + r) * NB + b] = s + (bih ? bih[g * H + u0 + r] + bhh[g * H + u0 + r] : 0.f);
         }
     __syncthreads();
     if (t < R * NB) {
         const int r = t / NB, b = t % NB;
-        const float ig = sigmoidf_(gates[(0 * R + r) * NB + b]);
-        const float fg = sigmoidf_(gates[(1 * R + r) * NB + b]);
-        const float gg = tanhf(gates[(2 * R + r) * NB + b]);
-        const float og = sigmoidf_(gates[(3 * R + r) * NB + b]);
         const int idx = b * H + u0 + r;
-        const float cy = fg * c[idx] + ig * gg;
-        c[idx] = cy;
-        h_new[idx] = og * tanhf(cy);
+        float pre[4];
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) pre[gg] = gates[(gg * R + r) * NB + b];
+        bool active = true;
+        int tb = 0;
+        if (sq.gadd) {
+            const int len = b < batch ? sq.lengths[b] : 0;
+            active = sq.step < len;
+            tb = sq.reverse ? len - 1 - sq.step : sq.step;
+            if (active) {
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg)
+                    pre[gg] += sq.gadd[(size_t)b * sq.ga_bstride + (size_t)(gg * H + u0 + r) * sq.ga_ld + sq.ga_pad + tb];
+            }
+        }
+        if (active) {
+            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+            const float cy = fg * c[idx] + ig * gg;
+            const float hy = og * tanhf(cy);
+            c[idx] = cy;
+            h_new[idx] = hy;
+            if (sq.gadd) {
+                sq.out[(size_t)b * sq.out_bstride + (size_t)tb * sq.out_tstride + sq.out_col + u0 + r] = hy;
+                if (sq.step == sq.lengths[b] - 1) sq.hn[(size_t)b * sq.hn_stride + sq.hn_col + u0 + r] = hy;
+            }
+        } else {
+            h_new[idx] = h_old[idx];
+        }
     }
 }
 
@@ -495,15 +528,15 @@ __global__ __launch_bounds__(256) void project_prenet_kernel(const ProjArgs a) {
 }
 
 template <int NB>
-int launch_lstm(const float* blob, const size_t* off, const float* in0, int n0, const float* in1, int n1,
-                const float* in2, int n2, const float* h_old, float* h_new, float* c, int I, int H, hipStream_t s) {
+int launch_lstm(const float* wih, const float* whh, const float* bih, const float* bhh, const float* in0, int n0,
+                const float* in1, int n1, const float* in2, int n2, const float* h_old, float* h_new, float* c, int I,
+                int H, int batch, const LstmSeq& sq, hipStream_t s) {
     const size_t smem_base = (size_t)NB * (I + H) * sizeof(float);
 #define CTTS_LSTM_CASE(RR)                                                                                         \
     if (H % RR == 0 && H / RR <= 256) {                                                                           \
         const size_t smem = smem_base + 4 * RR * NB * sizeof(float);                                              \
-        hipLaunchKernelGGL((lstm_step_kernel<NB, RR>), dim3(H / RR), dim3(256), smem, s, blob + off[0],           \
-                           blob + off[1], blob + off[2], blob + off[3], in0, n0, in1, n1, in2, n2, h_old, h_new, c, \
-                           nullptr, I, H);                                                                         \
+        hipLaunchKernelGGL((lstm_step_kernel<NB, RR>), dim3(H / RR), dim3(256), smem, s, wih, whh, bih, bhh, in0, \
+                           n0, in1, n1, in2, n2, h_old, h_new, c, sq, I, H, batch);                                \
         CTTS_CHECK_LAUNCH("lstm_step");                                                                            \
         return CTTS_OK;                                                                                            \
     }
@@ -514,13 +547,21 @@ int launch_lstm(const float* blob, const size_t* off, const float* in0, int n0, 
     return CTTS_E_ARG;
 }
 
+int launch_lstm_raw(int NB, const float* wih, const float* whh, const float* bih, const float* bhh, const float* in0,
+                    int n0, const float* in1, int n1, const float* in2, int n2, const float* h_old, float* h_new, float* c,
+                    int I, int H, int batch, const LstmSeq& sq, hipStream_t s) {
+    switch (NB) {
+        case 1: return launch_lstm<1>(wih, whh, bih, bhh, in0, n0, in1, n1, in2, n2, h_old, h_new, c, I, H, batch, sq, s);
+        case 2: return launch_lstm<2>(wih, whh, bih, bhh, in0, n0, in1, n1, in2, n2, h_old, h_new, c, I, H, batch, sq, s);
+        default: return launch_lstm<4>(wih, whh, bih, bhh, in0, n0, in1, n1, in2, n2, h_old, h_new, c, I, H, batch, sq, s);
+    }
+}
+
 int launch_lstm_nb(int NB, const float* blob, const size_t* off, const float* in0, int n0, const float* in1, int n1,
                    const float* in2, int n2, const float* h_old, float* h_new, float* c, int I, int H, hipStream_t s) {
-    switch (NB) {
-        case 1: return launch_lstm<1>(blob, off, in0, n0, in1, n1, in2, n2, h_old, h_new, c, I, H, s);
-        case 2: return launch_lstm<2>(blob, off, in0, n0, in1, n1, in2, n2, h_old, h_new, c, I, H, s);
-        default: return launch_lstm<4>(blob, off, in0, n0, in1, n1, in2, n2, h_old, h_new, c, I, H, s);
-    }
+    LstmSeq none{};
+    return launch_lstm_raw(NB, blob + off[0], blob + off[1], blob + off[2], blob + off[3], in0, n0, in1, n1, in2, n2, h_old,
+                           h_new, c, I, H, NB, none, s);
 }
 
 }  // namespace
@@ -666,6 +707,95 @@ int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void*
         q.B = batch; q.step = step; q.max_steps = max_steps;
         hipLaunchKernelGGL(project_prenet_kernel, dim3(batch), dim3(256), 0, s, q);
         CTTS_CHECK_LAUNCH("project_prenet");
+    }
+    return CTTS_OK;
+}
+
+// ---- packed-sequence LSTM (encoder BiLSTM, model.py:299-309) ---------------------------------------
+namespace {
+struct SeqPlan { int I, H, mb, nch; size_t A, bias, whh, total; };
+int make_seq_plan(int I, int H, SeqPlan& p) {
+    CTTS_CHECK_ARG(I >= 16 && I % 16 == 0 && H >= 4 && H % 4 == 0, "lstm_seq: input_size=%d hidden_size=%d", I, H);
+    p.I = I; p.H = H;
+    p.mb = (4 * H + 255) / 256; p.nch = I / 16;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o = align_up(o + n); return r; };
+    p.A = take((size_t)p.mb * p.nch * 16 * 256);
+    p.bias = take((size_t)p.mb * 256);
+    p.whh = take((size_t)4 * H * H);
+    p.total = o;
+    return CTTS_OK;
+}
+}  // namespace
+
+size_t ctts_lstm_seq_packed_bytes(int32_t input_size, int32_t hidden_size) {
+    SeqPlan p;
+    if (make_seq_plan(input_size, hidden_size, p)) return 0;
+    return p.total * sizeof(float);
+}
+
+int ctts_lstm_seq_pack_f32(const ctts_lstm_weights* w, int32_t input_size, int32_t hidden_size, void* packed, void* stream) {
+    SeqPlan p;
+    int rc = make_seq_plan(input_size, hidden_size, p); if (rc) return rc;
+    CTTS_CHECK_ARG(w && w->w_ih && w->w_hh && w->b_ih && w->b_hh && packed, "lstm_seq_pack: NULL pointer");
+    hipStream_t s = as_stream(stream);
+    float* blob = static_cast<float*>(packed);
+    rc = launch_pack_a(blob + p.A, w->w_ih, 256, p.mb, p.nch, 0, p.I, GEMM_EPI_SPLIT, 0, 4 * p.H, 0, p.I, 1, s);
+    if (rc) return rc;
+    rc = launch_pack_bias(blob + p.bias, 256, p.mb, w->b_ih, 0, w->b_hh, 0, GEMM_EPI_SPLIT, 0, 4 * p.H, s);
+    if (rc) return rc;
+    CTTS_CHECK_HIP(hipMemcpyAsync(blob + p.whh, w->w_hh, (size_t)4 * p.H * p.H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return CTTS_OK;
+}
+
+size_t ctts_lstm_seq_workspace_bytes(int32_t hidden_size, int32_t batch, int32_t ld) {
+    if (hidden_size < 4 || batch < 1 || batch > MAX_NB || ld < 4) return 0;
+    const size_t NB = pad_batch(batch);
+    return (align_up((size_t)batch * 4 * hidden_size * ld) + 3 * align_up(NB * hidden_size)) * sizeof(float);
+}
+
+int ctts_lstm_seq_f32(const void* packed, const float* x, const int32_t* lengths, int32_t reverse, float* out,
+                      int64_t out_bstride, int32_t out_tstride, int32_t out_col, float* hn, int32_t hn_stride,
+                      int32_t hn_col, int32_t batch, int32_t T, int32_t input_size, int32_t hidden_size, int32_t ld,
+                      int32_t pad, void* workspace, size_t workspace_bytes, void* stream) {
+    SeqPlan p;
+    int rc = make_seq_plan(input_size, hidden_size, p); if (rc) return rc;
+    CTTS_CHECK_ARG(packed && x && lengths && out && hn && workspace, "lstm_seq: NULL pointer");
+    CTTS_CHECK_ARG(batch >= 1 && batch <= MAX_NB && T >= 1, "lstm_seq: batch=%d (1..%d) T=%d", batch, MAX_NB, T);
+    const int ntiles = (T + 127) / 128;
+    CTTS_CHECK_ARG(ld % 4 == 0 && ntiles * 128 + 2 * pad <= ld, "lstm_seq: geometry T=%d ld=%d pad=%d", T, ld, pad);
+    const size_t need = ctts_lstm_seq_workspace_bytes(hidden_size, batch, ld);
+    if (need > workspace_bytes) { set_error("lstm_seq: workspace %zu bytes < required %zu", workspace_bytes, need); return CTTS_E_WORKSPACE; }
+    hipStream_t s = as_stream(stream);
+    const float* blob = static_cast<const float*>(packed);
+    const int H = p.H, NB = pad_batch(batch);
+    float* xp = static_cast<float*>(workspace);
+    float* h0 = xp + align_up((size_t)batch * 4 * H * ld);
+    float* h1 = h0 + align_up((size_t)NB * H);
+    float* c = h1 + align_up((size_t)NB * H);
+    CTTS_CHECK_HIP(hipMemsetAsync(h0, 0, 3 * align_up((size_t)NB * H) * sizeof(float), s));
+    // input projection for every time step: Xp[b][4H][t] = W_ih x_t + b_ih + b_hh
+    GemmArgs a{};
+    a.ld = ld; a.pad = pad; a.L = T; a.ntiles = ntiles; a.batch = batch; a.dst_ld = ld; a.dst_pad = pad;
+    a.A = blob + p.A; a.bias = blob + p.bias;
+    a.nseg = 1; a.nch_total = p.nch; a.MB = p.mb; a.M = 4 * H;
+    a.seg[0] = {x, (long long)p.I * ld, p.nch, 0, 0, 0};
+    a.dst0 = xp; a.dst0_bstride = (long long)4 * H * ld; a.dst1 = xp; a.dst1_bstride = a.dst0_bstride;
+    a.split = p.mb * 256;
+    rc = launch_gemm_f32(GEMM_EPI_SPLIT, a, s);
+    if (rc) return rc;
+    LstmSeq sq{};
+    sq.gadd = xp; sq.ga_bstride = (long long)4 * H * ld; sq.ga_ld = ld; sq.ga_pad = pad;
+    sq.lengths = lengths; sq.reverse = reverse;
+    sq.out = out; sq.out_bstride = out_bstride; sq.out_tstride = out_tstride; sq.out_col = out_col;
+    sq.hn = hn; sq.hn_stride = hn_stride; sq.hn_col = hn_col;
+    for (int step = 0; step < T; ++step) {
+        sq.step = step;
+        float* hold = (step & 1) ? h1 : h0;
+        float* hnew = (step & 1) ? h0 : h1;
+        rc = launch_lstm_raw(NB, nullptr, blob + p.whh, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, hold, hnew, c,
+                             0, H, batch, sq, s);
+        if (rc) return rc;
     }
     return CTTS_OK;
 }

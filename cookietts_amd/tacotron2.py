@@ -12,9 +12,11 @@ What runs where:
     model.py:898-904) is evaluated on the host every ``STOP_CHECK_EVERY`` steps instead of after every
     step (the reference syncs the device each step); the result is trimmed to the exact stop step, so
     outputs are identical.
-  * one-shot stages - embedding, encoder (T2), memory assembly (T3), postnet (T10): NOT yet native HIP;
-    they run as PyTorch-ROCm library ops on the GPU (marked "next-tier" in SURVEY.md §2.2, <1 % of the
-    time).  No CPU fallback: CPU tensors raise.
+  * one-shot stages - embedding, encoder (T2), memory assembly (T3), postnet (T10): composed here, in the
+    reference's own order, from operator-level HIP primitives of the same library: ``ctts_conv1d_f32`` (same-padded
+    Conv1d with the eval-mode BatchNorm folded in and LeakyReLU/tanh fused, on the fp32 MFMA conv-GEMM),
+    ``ctts_lstm_seq_f32`` (packed-sequence LSTM, one direction), ``ctts_taco_embed_f32``, ``ctts_taco_memory_f32``.
+    PyTorch only allocates the buffers.  No CPU fallback: CPU tensors raise.
 
 Reference quirks handled (SURVEY.md §8a "Quirks"): prenet dropout is ALWAYS on (model.py:189-190) - masks
 are drawn on the device per call, or passed explicitly (``keep_masks``) for deterministic parity;
@@ -286,8 +288,46 @@ class Decoder(nn.Module):
         return (mel[:, :, :n_total].contiguous(), torch.sigmoid(gate[:, :n_total]), align[:, :n_total].contiguous(), None)
 
 
+PAD = 8            # halo of the padded [B][C][ld] layout used by the conv primitives (>= kernel_size // 2)
+
+
+def _ld_for(T):
+    return (T + 127) // 128 * 128 + 2 * PAD
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _HipConv1d:
+    """One packed ``ctts_conv1d`` operator: Conv1d (+ eval BatchNorm1d folded) + activation."""
+
+    def __init__(self, conv, bn, act, slope, device):
+        lib = _lib.lib()
+        w = conv.weight.detach().float().contiguous()
+        b = conv.bias.detach().float().contiguous() if conv.bias is not None else None
+        self.desc = _lib.Conv1dDesc(c_in=w.shape[1], c_out=w.shape[0], kernel_size=w.shape[2], act=act, slope=slope)
+        nbytes = lib.ctts_conv1d_packed_bytes(C.byref(self.desc))
+        if nbytes == 0:
+            raise _lib.HipLibraryError("unsupported conv1d: " + lib.ctts_last_error().decode())
+        self.blob = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)
+        bn_t = [None] * 4
+        eps = 1e-5
+        if bn is not None:
+            bn_t = [t.detach().float().contiguous() for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
+            eps = bn.eps
+        with torch.cuda.device(device):
+            _lib.check(lib.ctts_conv1d_pack_f32(C.byref(self.desc), _lib.ptr(w), _lib.ptr(b), *[_lib.ptr(t) for t in bn_t],
+                                               eps, _lib.ptr(self.blob), _stream(device)), "ctts_conv1d_pack_f32")
+            torch.cuda.current_stream(device).synchronize()
+
+    def __call__(self, x, y, accumulate, B, T, ld):
+        _lib.check(_lib.lib().ctts_conv1d_f32(C.byref(self.desc), _lib.ptr(self.blob), _lib.ptr(x), _lib.ptr(y),
+                                             1 if accumulate else 0, B, T, ld, PAD, _stream(x.device)), "ctts_conv1d_f32")
+
+
 class Postnet(nn.Module):
-    """model.py:196-228 (one-shot stage, PyTorch-ROCm library ops for now)."""
+    """model.py:196-228; ``forward`` runs the 6 convs (+BN+tanh, residual every 3) as ``ctts_conv1d`` operators."""
 
     def __init__(self, hparams):
         super().__init__()
@@ -307,20 +347,57 @@ class Postnet(nn.Module):
             prev_output_layer = is_out
             self.convolutions.append(nn.Sequential(*layers))
 
+    def _ops(self, device):
+        if getattr(self, "_hip_ops", None) is None or self._hip_ops[0] != device:
+            n = len(self.convolutions)
+            ops = []
+            for i, seq in enumerate(self.convolutions):
+                is_out = (bool(self.b_res) and bool(i % self.b_res == 0)) or (i + 1 == n)
+                ops.append(_HipConv1d(seq[0].conv, None if is_out else seq[1], 0 if is_out else 2, 0.0, device))
+            self._hip_ops = (device, ops)
+        return self._hip_ops[1]
+
+    def _apply(self, fn, *a, **kw):
+        self._hip_ops = None
+        return super()._apply(fn, *a, **kw)
+
+    @torch.no_grad()
     def forward(self, x):
-        x_orig = x.clone()
+        """x [B, n_mel, T] (device) -> x + postnet residuals, eval mode."""
+        if self.training:
+            raise RuntimeError("Postnet HIP path is inference-only: call .eval()")
+        device = x.device
+        if device.type != 'cuda':
+            raise _lib.HipLibraryError("Tacotron2 HIP path needs GPU tensors (no CPU fallback)")
+        ops = self._ops(device)
+        lib = _lib.lib()
+        B, M, T = x.shape
+        ld = _ld_for(T)
+        xd = x.detach().float().contiguous()
         n = len(self.convolutions)
-        for i, conv in enumerate(self.convolutions):
-            if (bool(self.b_res) and bool(i % self.b_res == 0)) or (i + 1 == n):
-                x_orig = x_orig + conv(x)
-                x = x_orig
-            else:
-                x = F.dropout(torch.tanh(conv(x)), drop_rate, self.training)
-        return x_orig
+        with torch.cuda.device(device):
+            x_orig = torch.zeros(B, M, ld, dtype=torch.float32, device=device)
+            _lib.check(lib.ctts_pad_rows_f32(_lib.ptr(xd), M * T, T, _lib.ptr(x_orig), B, M, T, ld, PAD, _stream(device)),
+                       "ctts_pad_rows_f32")
+            cur = x_orig
+            for i, op in enumerate(ops):
+                if (bool(self.b_res) and bool(i % self.b_res == 0)) or (i + 1 == n):
+                    y = x_orig.clone()                     # x_orig + conv(cur), without aliasing the conv's input halo
+                    op(cur, y, True, B, T, ld)
+                    x_orig = cur = y
+                else:
+                    y = torch.zeros(B, op.desc.c_out, ld, dtype=torch.float32, device=device)
+                    op(cur, y, False, B, T, ld)
+                    cur = y
+            out = torch.empty(B, M, T, dtype=torch.float32, device=device)
+            _lib.check(lib.ctts_unpad_rows_f32(_lib.ptr(x_orig), _lib.ptr(out), M * T, T, B, M, T, ld, PAD, _stream(device)),
+                       "ctts_unpad_rows_f32")
+        return out.to(x.dtype)
 
 
 class Encoder(nn.Module):
-    """model.py:231-316 (one-shot stage, PyTorch-ROCm library ops for now)."""
+    """model.py:231-316; ``forward`` runs embedding gather, 3 x (conv + BN + LeakyReLU) and the packed BiLSTM as
+    HIP operators and returns the memory tensor's encoder part in place."""
 
     def __init__(self, hparams):
         super().__init__()
@@ -342,22 +419,66 @@ class Encoder(nn.Module):
         self.LReLU = nn.LeakyReLU(negative_slope=0.01)
         self.sylps_layer = LinearNorm(hp.encoder_LSTM_dim, 1)
 
-    def forward(self, text, text_lengths=None, speaker_ids=None):
-        if self.encoder_speaker_embed_dim:
-            emb = self.encoder_speaker_embedding(speaker_ids)[:, None].transpose(1, 2)
-            text = torch.cat((text, emb.repeat(1, 1, text.size(2))), dim=1)
-        for conv in self.convolutions:
-            text = F.dropout(self.LReLU(conv(text)), drop_rate, self.training)
-        text = text.transpose(1, 2)
-        if text_lengths is not None:
-            text = nn.utils.rnn.pack_padded_sequence(text, text_lengths.cpu().numpy(), batch_first=True,
-                                                     enforce_sorted=False)
-        self.lstm.flatten_parameters()
-        outputs, (hidden_state, _) = self.lstm(text)
-        if text_lengths is not None:
-            outputs, _ = nn.utils.rnn.pad_packed_sequence(outputs, batch_first=True)
-        hidden_state = hidden_state.transpose(0, 1).contiguous().view(hidden_state.shape[1], -1)
-        return outputs, hidden_state, self.sylps_layer(hidden_state)
+    def _apply(self, fn, *a, **kw):
+        self._hip_ops = None
+        return super()._apply(fn, *a, **kw)
+
+    def _ops(self, device):
+        if getattr(self, "_hip_ops", None) is None or self._hip_ops[0] != device:
+            lib = _lib.lib()
+            convs = [_HipConv1d(seq[0].conv, seq[1], 1, 0.01, device) for seq in self.convolutions]
+            I, H = self.lstm.input_size, self.lstm.hidden_size
+            packs = []
+            with torch.cuda.device(device):
+                for sfx in ("", "_reverse"):
+                    ts = [getattr(self.lstm, n + "_l0" + sfx).detach().float().contiguous()
+                          for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+                    w = _lib.LstmWeights(*[t.data_ptr() for t in ts])
+                    blob = torch.zeros(lib.ctts_lstm_seq_packed_bytes(I, H) // 4, dtype=torch.float32, device=device)
+                    _lib.check(lib.ctts_lstm_seq_pack_f32(C.byref(w), I, H, _lib.ptr(blob), _stream(device)),
+                               "ctts_lstm_seq_pack_f32")
+                    torch.cuda.current_stream(device).synchronize()
+                    packs.append(blob)
+            self._hip_ops = (device, convs, packs)
+        return self._hip_ops[1], self._hip_ops[2]
+
+    @torch.no_grad()
+    def forward_into_memory(self, embedding_weight, text_seq, text_lengths, speaker_ids, memory_in, hn):
+        """Writes encoder outputs into memory_in[:, :, :encoder_LSTM_dim] (zeros beyond each length, as
+        pad_packed_sequence leaves them) and the final hidden states [fwd | bwd] into hn."""
+        if self.training:
+            raise RuntimeError("Encoder HIP path is inference-only: call .eval()")
+        device = text_seq.device
+        convs, packs = self._ops(device)
+        lib = _lib.lib()
+        B, T = text_seq.shape
+        ld = _ld_for(T)
+        E = embedding_weight.shape[1]
+        S = self.encoder_speaker_embed_dim
+        I, H = self.lstm.input_size, self.lstm.hidden_size
+        with torch.cuda.device(device):
+            st = _stream(device)
+            x = torch.zeros(B, E + S, ld, dtype=torch.float32, device=device)
+            spk_w = self.encoder_speaker_embedding.weight.detach().float().contiguous() if S else None
+            emb_w = embedding_weight.detach().float().contiguous()
+            text64 = text_seq.to(torch.int64).contiguous()
+            spk64 = speaker_ids.to(torch.int64).contiguous()
+            _lib.check(lib.ctts_taco_embed_f32(_lib.ptr(emb_w), _lib.ptr(spk_w), _lib.ptr(text64), _lib.ptr(spk64), _lib.ptr(x),
+                                              B, T, E, S, ld, PAD, st), "ctts_taco_embed_f32")
+            for op in convs:
+                y = torch.zeros(B, op.desc.c_out, ld, dtype=torch.float32, device=device)
+                op(x, y, False, B, T, ld)
+                x = y
+            lens = text_lengths.to(device=device, dtype=torch.int32).contiguous()
+            nbytes = lib.ctts_lstm_seq_workspace_bytes(H, B, ld)
+            if nbytes == 0:
+                raise _lib.HipLibraryError("lstm_seq workspace query failed (batch <= 4): " + lib.ctts_last_error().decode())
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+            row = memory_in.shape[2]
+            for d, blob in enumerate(packs):
+                _lib.check(lib.ctts_lstm_seq_f32(_lib.ptr(blob), _lib.ptr(x), _lib.ptr(lens), d, _lib.ptr(memory_in), T * row,
+                                                row, d * H, _lib.ptr(hn), 2 * H, d * H, B, T, I, H, ld, PAD, _lib.ptr(ws),
+                                                ws.numel() * 4, st), "ctts_lstm_seq_f32")
 
 
 class SylpsNet(nn.Module):
@@ -410,22 +531,50 @@ class Tacotron2(nn.Module):
         """model.py:1044-1080.  Returns the reference's dict (pred_mel_postnet, pred_gate, alignments, pred_sylps)."""
         if self.training:
             raise RuntimeError("call .eval() first: inference uses eval-mode batch norm / no dropout but the prenet's")
-        memory = []
-        embedded_text = self.embedding(text_seq).transpose(1, 2)
-        encoder_outputs, _, pred_sylps = self.encoder(embedded_text, text_lengths, speaker_ids=speaker_id)
-        memory.append(encoder_outputs)
-        txt_T = encoder_outputs.size(1)
-        memory.append(self.speaker_embedding(speaker_id)[:, None].repeat(1, txt_T, 1))
-        sylzu = self.sylps_net.infer_auto(gt_sylps if gt_sylps is not None else pred_sylps, rand_sampling=False)
-        memory.append(sylzu[:, None].repeat(1, txt_T, 1))
-        tm = self.tm_bn(torchmoji_hdn).to(sylzu) if hasattr(self, 'tm_bn') else torchmoji_hdn
-        memory.append(self.tm_linear(tm)[:, None].repeat(1, txt_T, 1))
-        memory = torch.cat(memory, dim=2)
+        if gt_sylps is not None:
+            raise NotImplementedError("gt_sylps override is not built on the HIP path")
+        device = text_seq.device
+        if device.type != 'cuda':
+            raise _lib.HipLibraryError("Tacotron2 HIP path needs GPU tensors (no CPU fallback)")
+        lib = _lib.lib()
+        B, txt_T = text_seq.shape
+        enc_dim = self.encoder.lstm.hidden_size * 2
+        row = self.decoder._memory_in_dim
+        memory = torch.zeros(B, txt_T, row, dtype=torch.float32, device=device)
+        hn = torch.zeros(B, enc_dim, dtype=torch.float32, device=device)
+        pred_sylps = torch.empty(B, 1, dtype=torch.float32, device=device)
+        # (Encoder) text -> memory[:, :, :enc_dim], final hidden states
+        self.encoder.forward_into_memory(self.embedding.weight, text_seq, text_lengths, speaker_id, memory, hn)
+        # (Speaker / SylpsNet / torchMoji) per-utterance columns of the memory, pred_sylps
+        keep = []
+
+        def dev(t):
+            t = t.detach().float().contiguous()
+            keep.append(t)
+            return t.data_ptr()
+        sn = self.sylps_net.seq_layers
+        mw = _lib.TacoMemoryWeights(
+            sylps_w=dev(self.encoder.sylps_layer.linear_layer.weight), sylps_b=dev(self.encoder.sylps_layer.linear_layer.bias),
+            speaker_embedding=dev(self.speaker_embedding.weight),
+            syl_w0=dev(sn[0].linear_layer.weight), syl_b0=dev(sn[0].linear_layer.bias),
+            syl_w2=dev(sn[2].linear_layer.weight), syl_b2=dev(sn[2].linear_layer.bias),
+            syl_res_weight=dev(self.sylps_net.res_weight.reshape(1)),
+            tm_w=dev(self.tm_linear.weight), tm_b=dev(self.tm_linear.bias))
+        if hasattr(self, 'tm_bn'):
+            mw.tm_gamma, mw.tm_beta = dev(self.tm_bn.weight), dev(self.tm_bn.bias)
+            mw.tm_mean, mw.tm_var = dev(self.tm_bn.running_mean), dev(self.tm_bn.running_var)
+        tmh = torchmoji_hdn.detach().to(device=device, dtype=torch.float32).contiguous()
+        spk64 = speaker_id.to(torch.int64).contiguous()
+        with torch.cuda.device(device):
+            _lib.check(lib.ctts_taco_memory_f32(C.byref(mw), _lib.ptr(hn), _lib.ptr(spk64), _lib.ptr(tmh), _lib.ptr(memory),
+                                               _lib.ptr(pred_sylps), B, txt_T, enc_dim, self.speaker_embedding_dim,
+                                               sn[0].linear_layer.out_features, tmh.shape[1], self.tm_linear.out_features,
+                                               _stream(device)), "ctts_taco_memory_f32")
         pred_mel, pred_gate, alignments, _ = self.decoder.inference(memory, memory_lengths=text_lengths,
                                                                     keep_masks=keep_masks, fixed_steps=fixed_steps)
         pred_mel_postnet = self.postnet(pred_mel) if hasattr(self, 'postnet') else pred_mel
         return {"pred_mel_postnet": pred_mel_postnet, "pred_gate": pred_gate, "alignments": alignments,
-                "pred_sylps": pred_sylps, "pred_mel": pred_mel}
+                "pred_sylps": pred_sylps, "pred_mel": pred_mel, "encoder_outputs": memory[:, :, :enc_dim]}
 
 
 def load_model(hparams):

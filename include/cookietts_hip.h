@@ -268,6 +268,67 @@ int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void*
                                 float* align_out, int32_t batch, int32_t text_len, int32_t step0,
                                 int32_t n_steps, int32_t max_steps, void* workspace, void* stream);
 
+/* ---- Tacotron2-TM one-shot stages: operator-level primitives ------------------------------- */
+/* The encoder (model.py:283-316) and postnet (:218-228) are stacks of "same"-padded Conv1d (+ eval-mode
+ * BatchNorm1d, folded into the weights at pack time) + LeakyReLU / tanh, a packed-sequence BiLSTM, and a
+ * handful of per-utterance vectors.  They are exposed as three primitives the Python host composes in the
+ * reference's own order; all arithmetic is in the library.
+ * Padded layout here: x [B][C][ld], valid columns [pad, pad+T), zeros elsewhere, ld % 4 == 0,
+ * ld >= roundup(T,128) + 2*pad, pad >= kernel_size/2. */
+typedef struct ctts_conv1d_desc {
+    int32_t c_in;         /* multiple of 16 */
+    int32_t c_out;
+    int32_t kernel_size;  /* odd, <= 11 */
+    int32_t act;          /* 0 none, 1 LeakyReLU(slope), 2 tanh */
+    float slope;
+} ctts_conv1d_desc;
+size_t ctts_conv1d_packed_bytes(const ctts_conv1d_desc* d);
+/* w [c_out][c_in][k], b [c_out]; bn_* [c_out] or all NULL (eval BatchNorm1d folded: w*s, (b-mean)*s+beta). */
+int ctts_conv1d_pack_f32(const ctts_conv1d_desc* d, const float* w, const float* b, const float* bn_gamma,
+                         const float* bn_beta, const float* bn_mean, const float* bn_var, float bn_eps,
+                         void* packed, void* stream);
+/* y = act(conv1d(x)) (accumulate == 0) or y += conv1d(x) (accumulate != 0, act must be 0). */
+int ctts_conv1d_f32(const ctts_conv1d_desc* d, const void* packed, const float* x, float* y,
+                    int32_t accumulate, int32_t batch, int32_t T, int32_t ld, int32_t pad, void* stream);
+
+/* Packed-sequence LSTM, one direction (nn.LSTM + pack_padded_sequence semantics, model.py:299-309):
+ * item b runs len[b] steps (forward: t = 0..len-1, reverse: t = len-1..0); outputs beyond len are untouched. */
+size_t ctts_lstm_seq_packed_bytes(int32_t input_size, int32_t hidden_size);
+int ctts_lstm_seq_pack_f32(const ctts_lstm_weights* w, int32_t input_size, int32_t hidden_size, void* packed,
+                           void* stream);
+size_t ctts_lstm_seq_workspace_bytes(int32_t hidden_size, int32_t batch, int32_t ld);
+/*   x [B][I][ld] padded; out[b][t][out_col + u] (row stride out_tstride, batch stride out_bstride) = h_t;
+ *   hn[b][hn_col + u] (row stride hn_stride) = final hidden state; lengths int32 device; batch <= 4. */
+int ctts_lstm_seq_f32(const void* packed, const float* x, const int32_t* lengths, int32_t reverse, float* out,
+                      int64_t out_bstride, int32_t out_tstride, int32_t out_col, float* hn, int32_t hn_stride,
+                      int32_t hn_col, int32_t batch, int32_t T, int32_t input_size, int32_t hidden_size, int32_t ld,
+                      int32_t pad, void* workspace, size_t workspace_bytes, void* stream);
+
+/* x0[b][c][pad+t] = c < E ? embedding[text[b][t]][c] : spk_table[speaker[b]][c - E]   (model.py:1049, 284-288) */
+int ctts_taco_embed_f32(const float* embedding, const float* spk_table, const int64_t* text,
+                        const int64_t* speakers, float* x0, int32_t batch, int32_t T, int32_t E, int32_t S,
+                        int32_t ld, int32_t pad, void* stream);
+/* Per-utterance memory columns (model.py:1052-1066 + SylpsNet.infer_auto + tm_bn/tm_linear):
+ * pred_sylps[b] = sylps_w . hn[b] + sylps_b;  memory_in[b][t][enc_dim:] = [speaker embed | sylzu | torchMoji crushed]. */
+typedef struct ctts_taco_memory_weights {
+    const float* sylps_w; const float* sylps_b;              /* encoder.sylps_layer [1][enc_dim], [1] */
+    const float* speaker_embedding;                          /* [n_speakers][spk_dim] */
+    const float* syl_w0; const float* syl_b0;                /* sylps_net.seq_layers.0 [hid][2], [hid] */
+    const float* syl_w2; const float* syl_b2;                /* sylps_net.seq_layers.2 [1][hid], [1] */
+    const float* syl_res_weight;                             /* [1] */
+    const float* tm_gamma; const float* tm_beta; const float* tm_mean; const float* tm_var;  /* tm_bn (or NULL) */
+    const float* tm_w; const float* tm_b;                    /* tm_linear [crushed][tm_dim], [crushed] */
+} ctts_taco_memory_weights;
+int ctts_taco_memory_f32(const ctts_taco_memory_weights* w, const float* hn, const int64_t* speakers,
+                         const float* torchmoji, float* memory_in, float* pred_sylps, int32_t batch, int32_t T,
+                         int32_t enc_dim, int32_t spk_dim, int32_t syl_hidden, int32_t tm_dim, int32_t tm_crushed,
+                         void* stream);
+/* dense [B][C][src_ld] (first T columns) <-> padded [B][C][ld] copies */
+int ctts_pad_rows_f32(const float* src, int64_t src_bstride, int32_t src_ld, float* dst, int32_t batch,
+                      int32_t C, int32_t T, int32_t ld, int32_t pad, void* stream);
+int ctts_unpad_rows_f32(const float* src, float* dst, int64_t dst_bstride, int32_t dst_ld, int32_t batch,
+                        int32_t C, int32_t T, int32_t ld, int32_t pad, void* stream);
+
 /* ---- STFT / mel frontend (utils/audio/stft.py) ------------------------------------------- */
 
 /* STFT.__init__ (stft.py:46-77) / TacotronSTFT.__init__ (:155-166) arguments that shape the path. */

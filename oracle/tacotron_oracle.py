@@ -143,3 +143,93 @@ def stop_step(gate_logits, gate_threshold, gate_delay, max_decoder_steps):
         if i >= break_point:
             return i + 1
     return min(n, max_decoder_steps)
+
+
+# ------------------------------------------------------------------ one-shot stages (T2, T3, T10) ----
+def _conv1d_same(x, w, b):
+    """x [B, Cin, T], w [Cout, Cin, K] (odd K, zero 'same' padding), b [Cout]."""
+    K = w.shape[2]
+    p = (K - 1) // 2
+    xp = np.pad(x, ((0, 0), (0, 0), (p, p)))
+    T = x.shape[2]
+    y = np.zeros((x.shape[0], w.shape[0], T), dtype=F32)
+    for j in range(K):
+        y += np.einsum("oc,bct->bot", w[:, :, j], xp[:, :, j:j + T]).astype(F32)
+    return (y + b[None, :, None]).astype(F32)
+
+
+def _bn_eval(x, sd, prefix, eps=1e-5):
+    g, b = sd[prefix + ".weight"], sd[prefix + ".bias"]
+    m, v = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+    shape = (1, -1, 1) if x.ndim == 3 else (1, -1)
+    return ((x - m.reshape(shape)) / np.sqrt(v.reshape(shape) + F32(eps)) * g.reshape(shape) + b.reshape(shape)).astype(F32)
+
+
+def encoder(sd, hp, text, lengths, speaker_ids):
+    """model.py:283-316 in eval mode.  Returns (outputs [B, T, 1024] zero beyond each length, pred_sylps [B, 1])."""
+    emb = sd["embedding.weight"][text].transpose(0, 2, 1)                        # [B, 512, T]
+    spk = sd["encoder.encoder_speaker_embedding.weight"][speaker_ids][:, :, None]
+    x = np.concatenate([emb, np.repeat(spk, emb.shape[2], axis=2)], axis=1).astype(F32)
+    for i in range(hp.encoder_n_convolutions):
+        p = f"encoder.convolutions.{i}"
+        x = _bn_eval(_conv1d_same(x, sd[p + ".0.conv.weight"], sd[p + ".0.conv.bias"]), sd, p + ".1")
+        x = np.where(x > 0, x, F32(0.01) * x).astype(F32)                        # LeakyReLU(0.01)
+    x = x.transpose(0, 2, 1)                                                     # [B, T, 1024]
+    B, T, _ = x.shape
+    H = hp.encoder_LSTM_dim // 2
+    out = np.zeros((B, T, 2 * H), dtype=F32)
+    hn = np.zeros((B, 2 * H), dtype=F32)
+    for d, sfx in enumerate(["", "_reverse"]):
+        wih, whh = sd["encoder.lstm.weight_ih_l0" + sfx], sd["encoder.lstm.weight_hh_l0" + sfx]
+        bih, bhh = sd["encoder.lstm.bias_ih_l0" + sfx], sd["encoder.lstm.bias_hh_l0" + sfx]
+        for b in range(B):                                                       # packed semantics: per-item walk
+            h = np.zeros((1, H), F32); c = np.zeros((1, H), F32)
+            order = range(int(lengths[b])) if d == 0 else range(int(lengths[b]) - 1, -1, -1)
+            for t in order:
+                h, c = lstm_cell(x[b:b + 1, t], h, c, wih, whh, bih, bhh)
+                out[b, t, d * H:(d + 1) * H] = h[0]
+            hn[b, d * H:(d + 1) * H] = h[0]
+    sylps = (hn @ sd["encoder.sylps_layer.linear_layer.weight"].T + sd["encoder.sylps_layer.linear_layer.bias"]).astype(F32)
+    return out, sylps
+
+
+def memory_assemble(sd, hp, enc_out, pred_sylps, speaker_ids, torchmoji_hdn):
+    """model.py:1051-1068 (+ SylpsNet.infer_auto, tm_bn eval, tm_linear)."""
+    B, T, _ = enc_out.shape
+    spk = sd["speaker_embedding.weight"][speaker_ids]
+    cat = np.concatenate([pred_sylps, np.log(pred_sylps)], axis=1).astype(F32)   # [B, 2]
+    h = cat @ sd["sylps_net.seq_layers.0.linear_layer.weight"].T + sd["sylps_net.seq_layers.0.linear_layer.bias"]
+    h = np.where(h > 0, h, F32(0.05) * h).astype(F32)
+    res = h @ sd["sylps_net.seq_layers.2.linear_layer.weight"].T + sd["sylps_net.seq_layers.2.linear_layer.bias"]
+    sylzu = (cat + sd["sylps_net.res_weight"].reshape(()) * res)[:, 0:1].astype(F32)
+    tm = _bn_eval(np.asarray(torchmoji_hdn, F32), sd, "tm_bn")
+    tm = (tm @ sd["tm_linear.weight"].T + sd["tm_linear.bias"]).astype(F32)
+    rep = lambda v: np.repeat(v[:, None, :], T, axis=1)
+    return np.concatenate([enc_out, rep(spk), rep(sylzu), rep(tm)], axis=2).astype(F32)
+
+
+def postnet(sd, hp, mel):
+    """model.py:218-228 in eval mode."""
+    n = hp.postnet_n_convolutions
+    b_res = hp.postnet_residual_connections
+    x_orig = mel.astype(F32).copy()
+    x = mel
+    for i in range(n):
+        p = f"postnet.convolutions.{i}"
+        y = _conv1d_same(x, sd[p + ".0.conv.weight"], sd[p + ".0.conv.bias"])
+        if (bool(b_res) and i % b_res == 0) or i + 1 == n:
+            x_orig = (x_orig + y).astype(F32)
+            x = x_orig
+        else:
+            x = np.tanh(_bn_eval(y, sd, p + ".1")).astype(F32)
+    return x_orig
+
+
+def tacotron_inference_steps(sd, hp, text, lengths, speaker_ids, torchmoji_hdn, keep_masks, n_steps):
+    """Tacotron2.inference (model.py:1044-1080) for a fixed number of decoder steps."""
+    sd = {k: np.asarray(v) for k, v in sd.items()}
+    enc_out, sylps = encoder(sd, hp, np.asarray(text), lengths, np.asarray(speaker_ids))
+    memory_in = memory_assemble(sd, hp, enc_out, sylps, np.asarray(speaker_ids), torchmoji_hdn)
+    mel, gate, align = decoder_inference_steps(sd, hp, memory_in, lengths, keep_masks, n_steps)
+    return dict(encoder_outputs=enc_out, pred_sylps=sylps, memory_in=memory_in, pred_mel=mel,
+                pred_mel_postnet=postnet(sd, hp, mel), gate_logits=gate, alignments=align)

@@ -268,6 +268,34 @@ def make_tacotron():
     print(f"[golden] tacotron_decoder: mel {tuple(mel.shape)} align {tuple(align.shape)} "
           f"-> {os.path.getsize(path) / 1024:.0f} KiB")
 
+    # ---- full model golden: Tacotron2.inference (embedding, encoder, memory, decoder, postnet)
+    B, T_txt, n_steps = 3, 30, 10
+    text = rng.integers(1, hp.n_symbols, size=(B, T_txt)).astype(np.int64)
+    lengths = np.array([30, 22, 9], dtype=np.int64)
+    for b in range(B):
+        text[b, lengths[b]:] = 0                                   # pad symbol id beyond each length
+    speakers = np.array([0, 5, 17], dtype=np.int64)
+    tm = rng.standard_normal((B, hp.torchMoji_attDim)).astype(np.float32)
+    masks = synthetic.prenet_dropout_masks(n_steps, B, hp.prenet_dim, seed=seed + 1)
+    ref_model.F.dropout = _MaskedDropout(masks)
+    try:
+        model.decoder.max_decoder_steps = n_steps
+        with torch.no_grad():
+            enc_out, _, sylps = model.encoder(model.embedding(torch.from_numpy(text)).transpose(1, 2),
+                                              torch.from_numpy(lengths), speaker_ids=torch.from_numpy(speakers))
+            out = model.inference(torch.from_numpy(text), torch.from_numpy(lengths), torch.from_numpy(speakers),
+                                  torch.from_numpy(tm))
+    finally:
+        ref_model.F.dropout = saved
+    path = os.path.join(HERE, "tacotron_full.npz")
+    np.savez_compressed(path, seed=seed, text=text, lengths=lengths, speakers=speakers, torchmoji=tm, masks=masks,
+                        encoder_outputs=enc_out.numpy().astype(np.float32), pred_sylps=sylps.numpy().astype(np.float32),
+                        pred_mel_postnet=out["pred_mel_postnet"].numpy().astype(np.float32),
+                        pred_gate=out["pred_gate"].numpy().astype(np.float32),
+                        alignments=out["alignments"].numpy().astype(np.float32))
+    print(f"[golden] tacotron_full: postnet mel {tuple(out['pred_mel_postnet'].shape)} enc {tuple(enc_out.shape)} "
+          f"-> {os.path.getsize(path) / 1024:.0f} KiB")
+
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["waveglow", "stft", "waveflow", "tacotron"]

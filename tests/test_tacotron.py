@@ -145,3 +145,35 @@ def test_full_tacotron_inference_contract(hip_lib_path):
     assert out["pred_mel_postnet"].shape == (B, 80, 12) and out["pred_gate"].shape == (B, 12)
     assert out["alignments"].shape == (B, 12, T) and out["pred_sylps"].shape == (B, 1)
     assert all(torch.isfinite(out[k]).all() for k in ("pred_mel_postnet", "pred_gate", "alignments"))
+
+
+@pytest.mark.gpu
+def test_full_model_matches_reference_golden(hip_lib_path):
+    """Tacotron2.inference end to end (embedding, encoder convs+BN+LeakyReLU, packed BiLSTM, memory assembly,
+    decoder loop, postnet) against the reference's own outputs."""
+    m, _, hp, sd = _model()
+    g = np.load(os.path.join(GOLDEN, "tacotron_full.npz"))
+    n = g["masks"].shape[0]
+    out = m.inference(torch.from_numpy(g["text"]).cuda(), torch.from_numpy(g["lengths"]).cuda(),
+                      torch.from_numpy(g["speakers"]).cuda(), torch.from_numpy(g["torchmoji"]).cuda(),
+                      keep_masks=g["masks"], fixed_steps=n)
+    enc = out["encoder_outputs"].cpu().numpy()
+    print("encoder Linf:", np.abs(enc - g["encoder_outputs"]).max(),
+          " postnet mel Linf:", np.abs(out["pred_mel_postnet"].cpu().numpy() - g["pred_mel_postnet"]).max())
+    assert np.abs(enc - g["encoder_outputs"]).max() < MEL_TOL
+    assert (enc[1, 22:] == 0).all() and (enc[2, 9:] == 0).all()            # pad_packed_sequence zeros
+    assert np.abs(out["pred_sylps"].cpu().numpy() - g["pred_sylps"]).max() < MEL_TOL
+    assert np.abs(out["pred_mel_postnet"].cpu().numpy() - g["pred_mel_postnet"]).max() < MEL_TOL
+    assert np.abs(out["pred_gate"].cpu().numpy() - g["pred_gate"]).max() < MEL_TOL
+    assert np.abs(out["alignments"].cpu().numpy() - g["alignments"]).max() < MEL_TOL
+
+
+def test_oracle_full_model_matches_reference_golden():
+    g = np.load(os.path.join(GOLDEN, "tacotron_full.npz"))
+    _, hp, sd, _ = _golden()
+    o = to.tacotron_inference_steps(sd, hp, g["text"], g["lengths"], g["speakers"], g["torchmoji"], g["masks"],
+                                    g["masks"].shape[0])
+    assert np.abs(o["encoder_outputs"] - g["encoder_outputs"]).max() < 1e-6
+    assert np.abs(o["pred_sylps"] - g["pred_sylps"]).max() < 1e-6
+    assert np.abs(o["pred_mel_postnet"] - g["pred_mel_postnet"]).max() < 1e-5
+    assert np.abs(o["alignments"] - g["alignments"]).max() < 1e-6
