@@ -74,7 +74,7 @@ int make_dec_plan(const ctts_taco_decoder_config* cfg, DecPlan& p) {
 }
 
 struct DecWs {
-    float *memory, *pm, *att_h[2], *att_c, *dec_h[2], *dec_c, *d2_h[2], *d2_c, *w, *cum, *ctx, *pos, *prenet;
+    float *memory, *pm, *att_h[2], *att_c, *dec_h[2], *dec_c, *d2_h[2], *d2_c, *w, *cum, *ctx, *pos, *prenet, *qbuf;
     int* lengths;
     size_t total;
 };
@@ -98,6 +98,7 @@ void dec_carve(const DecPlan& p, int batch, int T, float* base, DecWs& w) {
     w.ctx = take(NB * c.memory_dim);
     w.pos = take(NB);
     w.prenet = take(NB * c.prenet_dim);
+    w.qbuf = take(NB * c.attention_dim);
     w.lengths = reinterpret_cast<int*>(take(NB));
     w.total = o;
 }
@@ -218,6 +219,18 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
     float* gates = smem + NB * K;           // [4][R][NB]
     const int t = threadIdx.x, lane = t & 63, g = t >> 6;
     const int u0 = blockIdx.x * R;
+    // first weight slab group: issued now, consumed after the staging barrier
+    constexpr int CH = 4;
+    float4 pre[CH][R];
+    const float* pre_base = I > 0 ? Wih + (size_t)(g * H + u0) * I : Whh + (size_t)(g * H + u0) * H;
+    const int pre_len = I > 0 ? I : H, pre_xoff = I > 0 ? 0 : I;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const int k = lane * 4 + j * 256;
+        const int kc = k < pre_len ? k : 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) pre[j][r] = load4_nt(pre_base + (size_t)r * pre_len + kc);
+    }
     // stage [cell input | previous hidden] for all NB items: 16-byte loads, SB of them in flight per thread
     // (piece boundaries n0, n0+n1, I are multiples of 4)
     {
@@ -252,10 +265,23 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
         for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
     // Weight streaming: CH k-slabs x R rows of 16-byte non-temporal loads are issued back to back before
     // the first FMA (CH*R*16 B = 256-320 B per lane, ~80 KB per CU in flight), which is what it takes to
-    // cover HBM latency with one workgroup per CU.
-    constexpr int CH = 4;
-    auto stream = [&](const float* wbase, int ldw, int klen, int xoff) {
-        for (int k0 = lane * 4; k0 < klen; k0 += 256 * CH) {
+    // cover HBM latency with one workgroup per CU.  The first slab group was issued before the input
+    // staging (`pre`), so the weight stream is already in flight while x is being staged.
+#define CTTS_CONSUME(WV, K0, KLEN, XOFF)                                                                    \
+    _Pragma("unroll") for (int j = 0; j < CH; ++j) {                                                        \
+        const int k = (K0) + j * 256;                                                                       \
+        if (k < (KLEN)) {                                                                                   \
+            float4 xv[NB];                                                                                  \
+            _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                  \
+                xv[b] = *reinterpret_cast<const float4*>(xs + b * K + (XOFF) + k);                          \
+            _Pragma("unroll") for (int r = 0; r < R; ++r)                                                   \
+                _Pragma("unroll") for (int b = 0; b < NB; ++b)                                              \
+                    acc[r][b] += WV[j][r].x * xv[b].x + WV[j][r].y * xv[b].y + WV[j][r].z * xv[b].z +       \
+                                 WV[j][r].w * xv[b].w;                                                      \
+        }                                                                                                   \
+    }
+    auto stream = [&](const float* wbase, int ldw, int klen, int xoff, int kstart) {
+        for (int k0 = kstart + lane * 4; k0 < klen; k0 += 256 * CH) {
             float4 wv[CH][R];
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
@@ -264,25 +290,16 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
 #pragma unroll
                 for (int r = 0; r < R; ++r) wv[j][r] = load4_nt(wbase + (size_t)r * ldw + kc);
             }
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const int k = k0 + j * 256;
-                if (k < klen) {
-                    float4 xv[NB];
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) xv[b] = *reinterpret_cast<const float4*>(xs + b * K + xoff + k);
-#pragma unroll
-                    for (int r = 0; r < R; ++r)
-#pragma unroll
-                        for (int b = 0; b < NB; ++b)
-                            acc[r][b] += wv[j][r].x * xv[b].x + wv[j][r].y * xv[b].y + wv[j][r].z * xv[b].z +
-                                         wv[j][r].w * xv[b].w;
-                }
-            }
+            CTTS_CONSUME(wv, k0, klen, xoff)
         }
     };
-    stream(Wih + (size_t)(g * H + u0) * I, I, I, 0);
-    stream(Whh + (size_t)(g * H + u0) * H, H, H, I);
+    CTTS_CONSUME(pre, lane * 4, pre_len, pre_xoff)
+    if (I > 0) {
+        stream(Wih + (size_t)(g * H + u0) * I, I, I, 0, 256 * CH);
+        stream(Whh + (size_t)(g * H + u0) * H, H, H, I, 0);
+    } else {
+        stream(Whh + (size_t)(g * H + u0) * H, H, H, I, 256 * CH);
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -448,6 +465,140 @@ __global__ __launch_bounds__(256) void attention_step_kernel(const AttnArgs a) {
             const int pos = min(s + tt, a.T - 1);
             acc = fmaf(s + tt < a.T ? wts[tt] : 0.f, mp[(size_t)pos * a.Dm], acc);
         }
+        a.ctx[(size_t)b * a.Dm + d] = acc;
+    }
+    for (int p = t; p < a.T; p += 256) {
+        const float wgt = (p >= s && p < s + W) ? wts[p - s] : 0.f;
+        a.w[(size_t)b * a.T + p] = wgt;
+        a.cum[(size_t)b * a.T + p] += wgt;
+        a.align_out[((size_t)b * a.max_steps + a.step) * a.T + p] = wgt;
+    }
+}
+
+// ---- multi-workgroup GEMV: y[b][r] = sum_k W[r][k] x[b][k] for all NB items at once (query projection) ------
+template <int NB>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ W, const float* __restrict__ x,
+                                                        float* __restrict__ y, int rows, int K) {
+    __shared__ __attribute__((aligned(16))) float xs[NB * 1536];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    for (int i = t * 4; i < NB * K; i += 1024) *reinterpret_cast<float4*>(xs + i) = *reinterpret_cast<const float4*>(x + i);
+    __syncthreads();
+    const int r0 = (blockIdx.x * 4 + wv) * 2;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float o[2];
+        wave_dots<2, 1536>(W, K, r0, rows, K, xs + b * K, lane, o);
+        if (lane < 2 && r0 + lane < rows) y[(size_t)b * rows + r0 + lane] = lane == 0 ? o[0] : o[1];
+    }
+}
+
+// ---- attention step, window fast path -------------------------------------------------------------------
+// Same math as attention_step_kernel, for window_range <= 16, memory_dim <= 512, attention_dim <= 256,
+// <= 32 location filters of <= 31 taps.  The window start depends only on the PREVIOUS step's position, so every
+// global operand (query from gemv_rows_kernel, previous/cumulative weights, the 33-row windows of the processed
+// memory and of the memory itself) is fetched up front into LDS in one burst; the rest runs out of LDS.
+constexpr int AW = 33, ADM = 512, AAD = 256, AF = 32, AK = 31;
+
+__global__ __launch_bounds__(256) void attention_window_kernel(const AttnArgs a, const float* __restrict__ qbuf) {
+    __shared__ __attribute__((aligned(16))) float memw[AW * ADM];
+    __shared__ __attribute__((aligned(16))) float pmw[AW * AAD];
+    __shared__ float wloc[AF * 2 * AK];
+    __shared__ float loc[AW][AF + 1];
+    __shared__ float wcat[2][AW + AK - 1];
+    __shared__ float q[AAD];
+    __shared__ float en[64];
+    __shared__ float wts[64];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int W = 2 * a.R + 1, padk = (a.K - 1) / 2;
+    const int len = a.lengths[b];
+    float cur = a.pos[b];
+    const float off = a.scalars[0];
+    if (off != 0.f) cur += off;
+    cur = fminf(fmaxf(cur, (float)a.R), (float)(len - 1 - a.R));
+    const int s = (int)rintf(fmaxf(cur - (float)a.R, 0.f));
+    // ---- one burst of loads (rows clamped to T-1: their weights are exactly 0 when masked)
+    {
+        const int dm4 = a.Dm / 4, a4 = a.A / 4;
+        for (int i = t; i < W * dm4; i += 256) {
+            const int tt = i / dm4, d4 = i % dm4;
+            const int pos = min(s + tt, a.T - 1);
+            *reinterpret_cast<float4*>(memw + tt * a.Dm + d4 * 4) =
+                *reinterpret_cast<const float4*>(a.memory + ((size_t)b * a.T + pos) * a.Dm + d4 * 4);
+        }
+        for (int i = t; i < W * a4; i += 256) {
+            const int tt = i / a4, c4 = i % a4;
+            const int pos = min(s + tt, a.T - 1);
+            *reinterpret_cast<float4*>(pmw + tt * a.A + c4 * 4) =
+                *reinterpret_cast<const float4*>(a.pm + ((size_t)b * a.T + pos) * a.A + c4 * 4);
+        }
+        for (int i = t; i < 2 * (W + a.K - 1); i += 256) {
+            const int c = i / (W + a.K - 1), j = i % (W + a.K - 1);
+            const int pos = s - padk + j;
+            const float* src = c == 0 ? a.w : a.cum;
+            wcat[c][j] = (pos >= 0 && pos < a.T) ? src[(size_t)b * a.T + pos] : 0.f;
+        }
+        for (int i = t; i < a.F * 2 * a.K; i += 256) wloc[i] = a.Wloc[i];
+        if (t < a.A) q[t] = qbuf[(size_t)b * a.A + t];
+    }
+    __syncthreads();
+    for (int i = t; i < W * a.F; i += 256) {
+        const int tt = i / a.F, f = i % a.F;
+        float acc = 0.f;
+        for (int c = 0; c < 2; ++c)
+            for (int j = 0; j < a.K; ++j) acc = fmaf(wloc[(f * 2 + c) * a.K + j], wcat[c][tt + j], acc);
+        loc[tt][f] = acc;
+    }
+    __syncthreads();
+    {
+        constexpr int MAXP = 9;                  // ceil(33 / 4) window positions per wave
+        float epart[MAXP];
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) epart[i] = 0.f;
+        for (int ad = lane; ad < a.A; ad += 64) {
+            float wd[AF];
+#pragma unroll
+            for (int f = 0; f < AF; ++f) wd[f] = a.Wd[(size_t)min(f, a.F - 1) * a.A + ad];
+            const float qa = q[ad], va = a.v[ad];
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) {
+                const int tt = min(wv + 4 * i, W - 1);
+                float acc = 0.f;
+#pragma unroll
+                for (int f = 0; f < AF; ++f) acc = fmaf(f < a.F ? wd[f] : 0.f, loc[tt][f], acc);
+                acc += qa;
+                acc += pmw[tt * a.A + ad];
+                epart[i] = fmaf(va, tanhf(acc), epart[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int tt = wv + 4 * i;
+            const float e = wave_sum(epart[i]);
+            if (tt < W && lane == 0) {
+                const int pos = s + tt;
+                en[tt] = (pos < len && pos < a.T) ? e : -INFINITY;
+            }
+        }
+    }
+    __syncthreads();
+    if (wv == 0) {
+        const float e = lane < W ? en[lane] : -INFINITY;
+        const float m = wave_max(e);
+        const float pexp = lane < W ? expf(e - m) : 0.f;
+        const float sum = wave_sum(pexp);
+        const float wgt = pexp / sum;
+        if (lane < W) wts[lane] = wgt;
+        const float np = wave_sum(lane < W ? wgt * (float)(s + lane) : 0.f);
+        if (lane == 0) {
+            const float sf = sigmoidf_(a.scalars[1]);
+            a.pos[b] = a.pos[b] * sf + np * (1.0f - sf);
+        }
+    }
+    __syncthreads();
+    for (int d = t; d < a.Dm; d += 256) {
+        float acc = 0.f;
+#pragma unroll 11
+        for (int tt = 0; tt < W; ++tt) acc = fmaf(s + tt < a.T ? wts[tt] : 0.f, memw[tt * a.Dm + d], acc);
         a.ctx[(size_t)b * a.Dm + d] = acc;
     }
     for (int p = t; p < a.T; p += 256) {
@@ -688,8 +839,20 @@ int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void*
         a.T = text_len; a.A = c.attention_dim; a.Ra = c.attention_rnn_dim; a.Dm = c.memory_dim;
         a.F = c.location_n_filters; a.K = c.location_kernel_size; a.R = c.window_range;
         a.step = step; a.max_steps = max_steps;
-        if (c.location_n_filters <= 32) hipLaunchKernelGGL(attention_step_kernel<32>, dim3(batch), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(attention_step_kernel<64>, dim3(batch), dim3(256), 0, s, a);
+        const bool fast = c.window_range <= 16 && c.memory_dim <= ADM && c.attention_dim <= AAD && c.attention_dim % 4 == 0 &&
+                          c.location_n_filters <= AF && c.location_kernel_size <= AK && c.attention_rnn_dim <= 1536;
+        if (fast) {
+            const int gblocks = (c.attention_dim + 7) / 8;
+            if (NB == 1) hipLaunchKernelGGL(gemv_rows_kernel<1>, dim3(gblocks), dim3(256), 0, s, a.Wq, a.att_h, w.qbuf, c.attention_dim, c.attention_rnn_dim);
+            else if (NB == 2) hipLaunchKernelGGL(gemv_rows_kernel<2>, dim3(gblocks), dim3(256), 0, s, a.Wq, a.att_h, w.qbuf, c.attention_dim, c.attention_rnn_dim);
+            else hipLaunchKernelGGL(gemv_rows_kernel<4>, dim3(gblocks), dim3(256), 0, s, a.Wq, a.att_h, w.qbuf, c.attention_dim, c.attention_rnn_dim);
+            CTTS_CHECK_LAUNCH("gemv_rows");
+            hipLaunchKernelGGL(attention_window_kernel, dim3(batch), dim3(256), 0, s, a, w.qbuf);
+        } else if (c.location_n_filters <= 32) {
+            hipLaunchKernelGGL(attention_step_kernel<32>, dim3(batch), dim3(256), 0, s, a);
+        } else {
+            hipLaunchKernelGGL(attention_step_kernel<64>, dim3(batch), dim3(256), 0, s, a);
+        }
         CTTS_CHECK_LAUNCH("attention_step");
         // decoder RNN on [attention hidden | context], second decoder RNN on the first's output
         rc = launch_lstm_nb(NB, blob, p.dec, w.att_h[nxt], c.attention_rnn_dim, w.ctx, c.memory_dim, nullptr, 0,
