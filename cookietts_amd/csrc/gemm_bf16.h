@@ -27,6 +27,7 @@ struct BGemmSeg {
     long long bstride;    // elements between batch items
     int nch;              // K chunks (32 channels each)
     int shift;            // column shift (time steps)
+    int mb_rows;          // extra channel offset per M-block (multiple of 8; block-diagonal batched GEMMs)
 };
 
 struct BGemmArgs {

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf16_kernel(const BGemmArgs 
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const BGemmSeg& g = a.seg[s];
-        sbase[s] = (gunit_ptr)(g.base + (size_t)b * g.bstride) + ((size_t)bg * a.ld + a.pad + n0 + g.shift + bn);
+        sbase[s] = (gunit_ptr)(g.base + (size_t)b * g.bstride) +
+                   ((size_t)(bg + mb * (g.mb_rows / 8)) * a.ld + a.pad + n0 + g.shift + bn);
         snch[s] = s < a.nseg ? g.nch : 0x7fffffff;
     }
     const size_t chunk_units = (size_t)4 * a.ld;        // 4 channel groups per chunk
@@ -125,6 +126,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf16_kernel(const BGemmArgs 
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         *reinterpret_cast<const bf16x8*>(&av[ks][mt]), *reinterpret_cast<const bf16x8*>(&bv[ks][nt]),
                         acc[mt][nt], 0, 0, 0);
+        // pin the LDS->MFMA pipeline: fragments of k-step 1 are read while k-step 0 runs on the matrix pipe
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
         if (more) CTTS_STORE_LDS(cur ^ 1);
         __syncthreads();
     }

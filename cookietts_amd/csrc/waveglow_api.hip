@@ -244,8 +244,9 @@ int run_flow_tail(const Plan& p, const Geom& g, const float* blob, int k, const 
 // two small cond layers, the `end` conv, the coupling and the inverse 1x1 conv stay fp32.
 struct BfPlan {
     std::vector<std::vector<size_t>> in_A, rs_A;   // [flow][layer] offsets in bf16 elements
+    size_t cond0_A, cond1_A;                       // flow-batched cond layers 0 / 1 (M-block k = flow k)
     size_t total;
-    int nch_in, nch_rs;
+    int nch_in, nch_rs, nch_c0, nch_c1;
 };
 
 void make_bf_plan(const Plan& p, BfPlan& q) {
@@ -253,6 +254,10 @@ void make_bf_plan(const Plan& p, BfPlan& q) {
     auto take = [&](size_t n) { size_t r = o; o = (o + n + 127) / 128 * 128; return r; };
     q.nch_in = (p.c.kernel_size * p.C + p.H) / BGEMM_KC;
     q.nch_rs = p.C / BGEMM_KC;
+    q.nch_c0 = p.K0 / BGEMM_KC;
+    q.nch_c1 = p.H / BGEMM_KC;
+    q.cond0_A = take((size_t)p.c.n_flows * q.nch_c0 * BGEMM_KC * BGEMM_BM);
+    q.cond1_A = take((size_t)p.c.n_flows * q.nch_c1 * BGEMM_KC * BGEMM_BM);
     q.in_A.assign(p.c.n_flows, {});
     q.rs_A.assign(p.c.n_flows, {});
     for (int k = 0; k < p.c.n_flows; ++k)
@@ -264,8 +269,8 @@ void make_bf_plan(const Plan& p, BfPlan& q) {
 }
 
 struct BfWs {
-    float *audio, *spect, *h_tmp, *h_all;
-    bf16_t *h_bf, *x, *act, *out;
+    float *audio, *spect;
+    bf16_t *spect_bf, *h_tmp_bf, *h_bf, *x, *act, *out;
     size_t total_bytes;
 };
 
@@ -275,8 +280,8 @@ void carve_bf(const Plan& p, const Geom& g, int batch, char* base, BfWs& w) {
     const size_t B = batch;
     w.audio = (float*)take(B * p.c.n_group * g.L * 4);
     w.spect = (float*)take(B * p.K0 * g.ld * 4);
-    w.h_tmp = (float*)take(B * p.c.n_flows * p.H * g.ld * 4);
-    w.h_all = (float*)take(B * p.c.n_flows * p.H * g.ld * 4);
+    w.spect_bf = (bf16_t*)take(B * p.K0 * g.ld * 2);
+    w.h_tmp_bf = (bf16_t*)take(B * p.c.n_flows * p.H * g.ld * 2);
     w.h_bf = (bf16_t*)take(B * p.c.n_flows * p.H * g.ld * 2);
     w.x = (bf16_t*)take(B * p.C * g.ld * 2);
     w.act = (bf16_t*)take(B * p.C * g.ld * 2);
@@ -409,10 +414,10 @@ int run_wn_stack_bf16(const Plan& p, const BfPlan& q, const Geom& g, const float
             a.ld = g.ld; a.pad = g.pad; a.L = g.L; a.ntiles = g.ntiles; a.batch = batch;
             a.A = bblob + q.in_A[k][i]; a.bias = blob + f.in_b[i];
             a.nseg = 4; a.interleave = 3; a.nch_total = q.nch_in; a.MB = p.mb_in;
-            a.seg[0] = {w.x, cstride, ncx, -dil};
-            a.seg[1] = {w.x, cstride, ncx, 0};
-            a.seg[2] = {w.x, cstride, ncx, dil};
-            a.seg[3] = {w.h_bf + (size_t)k * p.H * g.ld, hstride, p.H / BGEMM_KC, 0};
+            a.seg[0] = {w.x, cstride, ncx, -dil, 0};
+            a.seg[1] = {w.x, cstride, ncx, 0, 0};
+            a.seg[2] = {w.x, cstride, ncx, dil, 0};
+            a.seg[3] = {w.h_bf + (size_t)k * p.H * g.ld, hstride, p.H / BGEMM_KC, 0, 0};
             a.M = 2 * p.C; a.pairC = p.C;
             a.dst0 = w.act; a.dst0_bstride = cstride;
             ProfScope ps(CTTS_PROF_WN_IN, s);
@@ -424,7 +429,7 @@ int run_wn_stack_bf16(const Plan& p, const BfPlan& q, const Geom& g, const float
             a.ld = g.ld; a.pad = g.pad; a.L = g.L; a.ntiles = g.ntiles; a.batch = batch;
             a.A = bblob + q.rs_A[k][i]; a.bias = blob + f.rs_b[i];
             a.nseg = 1; a.nch_total = q.nch_rs; a.MB = p.rs_mb(i);
-            a.seg[0] = {w.act, cstride, q.nch_rs, 0};
+            a.seg[0] = {w.act, cstride, q.nch_rs, 0, 0};
             a.M = p.rs_rows(i);
             a.dst0 = w.x; a.dst0_bstride = cstride; a.acc0 = 1;
             a.dst1 = w.out; a.dst1_bstride = cstride; a.acc1 = i > 0 ? 1 : 0;
@@ -651,6 +656,11 @@ int ctts_waveglow_pack_flow_bf16(const ctts_waveglow_config* cfg, int32_t k, con
     hipStream_t s = as_stream(stream);
     bf16_t* bb = static_cast<bf16_t*>(packed_bf16);
     const int C = p.C, H = p.H, ks = p.c.kernel_size;
+    CTTS_CHECK_ARG(w->cond_w[0] && w->cond_w[1] && p.K0 % BGEMM_KC == 0, "pack_flow_bf16: cond weights / n_mel*n_group %% 32");
+    if ((rc = launch_pack_a_bf16(bb + q.cond0_A + (size_t)k * q.nch_c0 * BGEMM_KC * BGEMM_BM, w->cond_w[0], 1, q.nch_c0, 0,
+                                 p.K0, BGEMM_EPI_SPLIT, C, H, 0, p.K0, 1, s))) return rc;
+    if ((rc = launch_pack_a_bf16(bb + q.cond1_A + (size_t)k * q.nch_c1 * BGEMM_KC * BGEMM_BM, w->cond_w[1], 1, q.nch_c1, 0,
+                                 H, BGEMM_EPI_SPLIT, C, H, 0, H, 1, s))) return rc;
     for (int i = 0; i < p.c.n_layers; ++i) {
         CTTS_CHECK_ARG(w->in_w[i] && w->rs_w[i] && w->cond_w[2], "pack_flow_bf16: NULL layer %d weights", i);
         for (int t = 0; t < ks; ++t)
@@ -693,12 +703,28 @@ int ctts_waveglow_infer_bf16(const ctts_waveglow_config* cfg, const void* packed
     rc = launch_upsample_squeeze(mel, blob + p.up_w, blob + p.up_b, w.spect, batch, p.c.n_mel_channels, frames,
                                  p.c.win_length, p.c.hop_length, p.c.n_group, g.ld, g.pad, s);
     if (rc) return rc;
-    rc = run_cond(p, g, blob, w.spect, w.h_tmp, w.h_all, batch, s);
-    if (rc) return rc;
-    const int hrows = p.c.n_flows * p.H;
-    hipLaunchKernelGGL(cvt_f32_to_k8_kernel, dim3((g.ld + 255) / 256, hrows / 8, batch), dim3(256), 0, s, w.h_all, w.h_bf,
-                       hrows, g.ld);
+    // cond layers 0 / 1 for all flows on bf16 MFMA: spect -> bf16 K8, then two flow-batched GEMMs whose
+    // epilogues write the conditioning hidden directly in bf16 K8
+    hipLaunchKernelGGL(cvt_f32_to_k8_kernel, dim3((g.ld + 255) / 256, p.K0 / 8, batch), dim3(256), 0, s, w.spect,
+                       w.spect_bf, p.K0, g.ld);
     CTTS_CHECK_LAUNCH("cvt_f32_to_k8");
+    {
+        const long long hstride = (long long)p.c.n_flows * p.H * g.ld;
+        BGemmArgs a{};
+        a.ld = g.ld; a.pad = g.pad; a.L = g.L; a.ntiles = g.ntiles; a.batch = batch;
+        a.A = bblob + q.cond0_A; a.bias = blob + p.cond0_b;
+        a.nseg = 1; a.nch_total = q.nch_c0; a.MB = p.c.n_flows; a.M = p.c.n_flows * BGEMM_BM;
+        a.seg[0] = {w.spect_bf, (long long)p.K0 * g.ld, q.nch_c0, 0, 0};
+        a.dst0 = w.h_tmp_bf; a.dst0_bstride = hstride; a.acc0 = 0;
+        a.dst1 = w.h_tmp_bf; a.dst1_bstride = hstride; a.acc1 = 0;
+        a.split = a.M;
+        if ((rc = launch_gemm_bf16(BGEMM_EPI_SPLIT, a, s))) return rc;
+        a.A = bblob + q.cond1_A; a.bias = blob + p.cond1_b;
+        a.nch_total = q.nch_c1;
+        a.seg[0] = {w.h_tmp_bf, hstride, q.nch_c1, 0, BGEMM_BM};
+        a.dst0 = w.h_bf; a.dst1 = w.h_bf;
+        if ((rc = launch_gemm_bf16(BGEMM_EPI_SPLIT, a, s))) return rc;
+    }
     for (int k = p.c.n_flows - 1; k >= 0; --k) {
         rc = run_wn_stack_bf16(p, q, g, blob, bblob, k, w, batch, s);
         if (rc) return rc;

@@ -136,13 +136,14 @@ def bf16_round(x):
 def wn_forward_bf16(sd, prefix, audio0, spect, n_layers, n_channels):
     """bf16-rounded restatement of one WN stack, mirroring the rounding points of the bf16 HIP variant
     (BASELINE config 3): in-layer / cond-layer-2 / res-skip weights and the tensors x, h, act, skip-sum are
-    rounded to bf16 where the kernels store them; all sums are fp32; start / cond layers 0-1 / end are fp32."""
+    rounded to bf16 where the kernels store them (incl. the squeezed spectrogram and cond layers 0-1); all sums
+    are fp32; upsampling, start and end are fp32."""
     C = n_channels
     x = bf16_round(_conv1x1(_conv_weight(sd, prefix + ".start"), sd[prefix + ".start.bias"], audio0))
-    h = spect
+    h = bf16_round(spect)
     for j in range(2):
-        h = _conv1x1(_conv_weight(sd, f"{prefix}.cond_layers.{j}"), sd[f"{prefix}.cond_layers.{j}.bias"], h)
-    h = bf16_round(h)
+        h = bf16_round(_conv1x1(bf16_round(_conv_weight(sd, f"{prefix}.cond_layers.{j}")),
+                                sd[f"{prefix}.cond_layers.{j}.bias"], h))
     wc2 = bf16_round(_conv_weight(sd, f"{prefix}.cond_layers.2")[:, :, 0])
     bc2 = sd[f"{prefix}.cond_layers.2.bias"]
     out = None
