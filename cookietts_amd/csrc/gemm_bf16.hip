@@ -4,6 +4,8 @@
 // 4 x 2 tiles of v_mfma_f32_32x32x16_bf16 (128 accumulator VGPRs).  LDS stage = A [4][256] + B [4][128]
 // 16-byte units (24 KiB), double buffered; every fragment is one ds_read_b128 per lane with consecutive
 // lanes on consecutive units (conflict-free).  Global->LDS staging through registers one chunk ahead.
+#include <cstdlib>
+
 #include "gemm_bf16.h"
 
 namespace ctts {
@@ -14,8 +16,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 namespace {
 
 constexpr int A_UNITS = 4 * BGEMM_BM;                   // 1024 x 16 B
-constexpr int B_UNITS = 4 * BGEMM_BN;                   // 512 x 16 B
-constexpr int STAGE_UNITS = A_UNITS + B_UNITS;          // 24 KiB
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // one 16-byte K8 unit
 typedef const __attribute__((address_space(1))) u32x4* gunit_ptr;
@@ -30,13 +30,23 @@ __device__ __forceinline__ unsigned int pack2(float lo, float hi) {
     return (unsigned int)f32_to_bf16_rne(lo) | ((unsigned int)f32_to_bf16_rne(hi) << 16);
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void conv_gemm_bf16_kernel(const BGemmArgs a) {
-    __shared__ __attribute__((aligned(16))) u32x4 lds[2 * STAGE_UNITS + 16];
+// NW = waves along N: 2 -> 256 threads, block tile 256 x 128; 4 -> 512 threads, block tile 256 x 256 (one
+// workgroup per CU).  The wide tile stages 1/3 fewer bytes per FLOP: at bf16 MFMA rates the CU's vector-memory
+// path (64 B/clk) is the co-bottleneck of the narrow tile (PMC: MFMA busy 44 %, issue-stalled 48 %).
+template <int EPI, bool GLDS, int NW>
+__global__ __launch_bounds__(128 * NW, 2) void conv_gemm_bf16_kernel(const BGemmArgs a) {
+    constexpr int NT = 128 * NW;                            // threads
+    constexpr int BN = 64 * NW;
+    constexpr int B_UNITS = 4 * BN;
+    constexpr int STAGE_UNITS = A_UNITS + B_UNITS;
+    constexpr int NA = A_UNITS / NT;                        // 16-byte units per thread per stage (A)
+    constexpr int NB_ = B_UNITS / NT;                       // (B) == 2 for both shapes
+    static_assert(NB_ == 2, "B staging assumes 2 units per thread");
+    __shared__ __attribute__((aligned(16))) u32x4 lds[(GLDS ? 3 : 2) * STAGE_UNITS + 16];
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NW, wn = wave % NW;
     const int l31 = lane & 31, lhi = lane >> 5;
 
     int id = blockIdx.x;
@@ -44,10 +54,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf16_kernel(const BGemmArgs 
     id /= a.MB;
     const int tile = id % a.ntiles;
     const int b = id / a.ntiles;
-    const int n0 = tile * BGEMM_BN;
+    const int n0 = tile * BN;
 
-    // per-thread B staging: units (g, n) with g = t>>7 (+2), n = t & 127
-    const int bg = t >> 7, bn = t & 127;
+    // per-thread B staging: units (g, n) with g = t / BN (+2), n = t % BN
+    const int bg = t / BN, bn = t % BN;
     gunit_ptr sbase[4];
     int snch[4];
 #pragma unroll
@@ -77,7 +87,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf16_kernel(const BGemmArgs 
 
 #define CTTS_ISSUE_LOADS()                                                                      \
     do {                                                                                        \
-        ra0 = ap[0]; ra1 = ap[256]; ra2 = ap[512]; ra3 = ap[768];                               \
+        ra0 = ap[0]; ra1 = ap[NT];                                                              \
+        if constexpr (NA > 2) { ra2 = ap[2 * NT]; ra3 = ap[3 * NT]; }                           \
         ap += A_UNITS;                                                                          \
         gunit_ptr sb_ = seg == 0 ? sbase[0] : seg == 1 ? sbase[1] : seg == 2 ? sbase[2] : sbase[3]; \
         const int sn_ = seg == 0 ? snch[0] : seg == 1 ? snch[1] : seg == 2 ? snch[2] : snch[3]; \
@@ -92,20 +103,61 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf16_kernel(const BGemmArgs 
 #define CTTS_STORE_LDS(buf)                                                                     \
     do {                                                                                        \
         u32x4* As_ = lds + (buf) * STAGE_UNITS + t;                                             \
-        u32x4* Bs_ = lds + (buf) * STAGE_UNITS + A_UNITS + bg * BGEMM_BN + bn;                  \
-        As_[0] = ra0; As_[256] = ra1; As_[512] = ra2; As_[768] = ra3;                           \
-        Bs_[0] = rb0; Bs_[2 * BGEMM_BN] = rb1;                                                  \
+        u32x4* Bs_ = lds + (buf) * STAGE_UNITS + A_UNITS + t;                                   \
+        As_[0] = ra0; As_[NT] = ra1;                                                            \
+        if constexpr (NA > 2) { As_[2 * NT] = ra2; As_[3 * NT] = ra3; }                         \
+        Bs_[0] = rb0; Bs_[NT] = rb1;                                                            \
     } while (0)
 
-    CTTS_ISSUE_LOADS();
-    CTTS_STORE_LDS(0);
-    __syncthreads();
+    // Direct global->LDS staging (global_load_lds_dwordx4): no VGPR round trip, no ds_write pass.  The LDS image
+    // is lane-linear by construction (unit index == thread index + 256 j), which is what the DMA needs: the
+    // destination is a wave-uniform base + lane * 16 B.
+    typedef __attribute__((address_space(3))) u32x4* lds_ptr;
+#define CTTS_ISSUE_GLDS(buf)                                                                    \
+    do {                                                                                        \
+        lds_ptr la_ = (lds_ptr)(lds + (buf) * STAGE_UNITS + (t & ~63));                         \
+        __builtin_amdgcn_global_load_lds(ap, la_, 16, 0, 0);                                    \
+        __builtin_amdgcn_global_load_lds(ap + NT, la_ + NT, 16, 0, 0);                          \
+        if constexpr (NA > 2) {                                                                 \
+            __builtin_amdgcn_global_load_lds(ap + 2 * NT, la_ + 2 * NT, 16, 0, 0);              \
+            __builtin_amdgcn_global_load_lds(ap + 3 * NT, la_ + 3 * NT, 16, 0, 0);              \
+        }                                                                                       \
+        ap += A_UNITS;                                                                          \
+        gunit_ptr sb_ = seg == 0 ? sbase[0] : seg == 1 ? sbase[1] : seg == 2 ? sbase[2] : sbase[3]; \
+        const int sn_ = seg == 0 ? snch[0] : seg == 1 ? snch[1] : seg == 2 ? snch[2] : snch[3]; \
+        gunit_ptr bp = sb_ + (size_t)local * chunk_units;                                       \
+        __builtin_amdgcn_global_load_lds(bp, la_ + A_UNITS, 16, 0, 0);                          \
+        __builtin_amdgcn_global_load_lds(bp + g2_units, la_ + A_UNITS + NT, 16, 0, 0);          \
+        if (in_ilv) {                                                                           \
+            if (++seg == ilv) { seg = 0; if (++local == sn_) { local = 0; seg = ilv; in_ilv = false; } } \
+        } else if (++local == sn_) { local = 0; ++seg; }                                        \
+    } while (0)
 
     const int nch = a.nch_total;
+    if constexpr (GLDS) {
+        // 3 LDS stages, DMA issued TWO chunks ahead: a bf16 chunk is only ~0.5k MFMA cycles per wave, far less than
+        // the loaded-memory latency, so a one-chunk prefetch leaves the matrix pipe waiting on vmcnt.  Six DMAs per
+        // thread per chunk -> `vmcnt(6)` = "everything but the newest chunk has landed".  Raw s_barrier: a
+        // __syncthreads() would add vmcnt(0) and drain the DMA queue.
+        CTTS_ISSUE_GLDS(0);
+        if (nch > 1) CTTS_ISSUE_GLDS(1);
+        if (nch > 1) { if constexpr (NA > 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+        CTTS_ISSUE_LOADS();
+        CTTS_STORE_LDS(0);
+        __syncthreads();
+    }
+
+    int cur = 0;
     for (int ch = 0; ch < nch; ++ch) {
-        const int cur = ch & 1;
-        const bool more = ch + 1 < nch;
-        if (more) CTTS_ISSUE_LOADS();
+        const bool more = GLDS ? ch + 2 < nch : ch + 1 < nch;
+        if (more) {
+            if constexpr (GLDS) { const int nb = cur >= 1 ? cur - 1 : 2; CTTS_ISSUE_GLDS(nb); }   // (cur + 2) % 3
+            else CTTS_ISSUE_LOADS();
+        }
         const u32x4* As = lds + cur * STAGE_UNITS + wm * 128 + l31;
         const u32x4* Bs = lds + cur * STAGE_UNITS + A_UNITS + wn * 64 + l31;
         u32x4 av[2][4], bv[2][2];
@@ -115,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf16_kernel(const BGemmArgs 
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) av[ks][mt] = As[grp * BGEMM_BM + mt * 32];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) bv[ks][nt] = Bs[grp * BGEMM_BN + nt * 32];
+            for (int nt = 0; nt < 2; ++nt) bv[ks][nt] = Bs[grp * BN + nt * 32];
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -131,17 +183,27 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf16_kernel(const BGemmArgs 
         __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-        if (more) CTTS_STORE_LDS(cur ^ 1);
-        __syncthreads();
+        if constexpr (GLDS) {
+            if (more) { if constexpr (NA > 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }   // chunk ch+1 landed, ch+2 in flight
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            cur = cur == 2 ? 0 : cur + 1;
+        } else {
+            if (more) CTTS_STORE_LDS(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
     }
 #undef CTTS_ISSUE_LOADS
 #undef CTTS_STORE_LDS
+#undef CTTS_ISSUE_GLDS
 
     // ---- epilogue.  32x32 C/D layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5): for a fixed
     // register group q = r>>2 the lane holds 4 consecutive channels (8q + 4*lhi + 0..3) of one column, i.e.
     // half of a 16-byte K8 unit; lanes l and l+32 complete the unit and lanes 0..31 are consecutive columns.
     float* bias_s = reinterpret_cast<float*>(lds);
-    bias_s[t] = a.bias[mb * BGEMM_BM + t];
+    if (t < BGEMM_BM) bias_s[t] = a.bias[mb * BGEMM_BM + t];
     __syncthreads();
     const float* bias = bias_s + wm * 128;
     if constexpr (EPI == BGEMM_EPI_GATE) {
@@ -265,17 +327,31 @@ int launch_gemm_bf16(int epi, const BGemmArgs& a, hipStream_t stream) {
         for (int s = 1; s < a.interleave; ++s)
             CTTS_CHECK_ARG(a.seg[s].nch == a.seg[0].nch, "gemm_bf16: interleaved segments must have equal length");
     }
-    CTTS_CHECK_ARG(a.ntiles * BGEMM_BN + 2 * a.pad <= a.ld && a.L <= a.ntiles * BGEMM_BN, "gemm_bf16: geometry");
-    CTTS_CHECK_ARG(epi == BGEMM_EPI_GATE ? (a.pairC > (a.MB - 1) * 128 && a.pairC <= a.MB * 128)
-                                         : (a.M % 32 == 0 && a.split % 32 == 0 && a.M > (a.MB - 1) * BGEMM_BM &&
-                                            a.M <= a.MB * BGEMM_BM),
-                   "gemm_bf16: M=%d pairC=%d MB=%d split=%d", a.M, a.pairC, a.MB, a.split);
-    const long long blocks = (long long)a.MB * a.ntiles * a.batch;
+    static const bool use_glds = getenv("CTTS_BF16_NO_GLDS") == nullptr;
+    static const bool no_wide = getenv("CTTS_BF16_NO_WIDE") != nullptr;
+    // wide (256 x 256, 512 threads) tiles when the problem has enough of them to fill the chip
+    const int ntiles_w = (a.L + 255) / 256;
+    const bool wide = use_glds && !no_wide && (long long)a.MB * ntiles_w * a.batch >= 512 && ntiles_w * 256 + 2 * a.pad <= a.ld;
+    BGemmArgs b = a;
+    if (wide) b.ntiles = ntiles_w;
+    const int bn = wide ? 256 : BGEMM_BN;
+    CTTS_CHECK_ARG(b.ntiles * bn + 2 * b.pad <= b.ld && b.L <= b.ntiles * bn, "gemm_bf16: geometry");
+    CTTS_CHECK_ARG(epi == BGEMM_EPI_GATE ? (b.pairC > (b.MB - 1) * 128 && b.pairC <= b.MB * 128)
+                                         : (b.M % 32 == 0 && b.split % 32 == 0 && b.M > (b.MB - 1) * BGEMM_BM &&
+                                            b.M <= b.MB * BGEMM_BM),
+                   "gemm_bf16: M=%d pairC=%d MB=%d split=%d", b.M, b.pairC, b.MB, b.split);
+    const long long blocks = (long long)b.MB * b.ntiles * b.batch;
     CTTS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "gemm_bf16: grid %lld", blocks);
-    if (epi == BGEMM_EPI_GATE)
-        hipLaunchKernelGGL(conv_gemm_bf16_kernel<BGEMM_EPI_GATE>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
-    else
-        hipLaunchKernelGGL(conv_gemm_bf16_kernel<BGEMM_EPI_SPLIT>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    const dim3 grid((unsigned)blocks);
+    if (epi == BGEMM_EPI_GATE) {
+        if (wide) hipLaunchKernelGGL((conv_gemm_bf16_kernel<BGEMM_EPI_GATE, true, 4>), grid, dim3(512), 0, stream, b);
+        else if (use_glds) hipLaunchKernelGGL((conv_gemm_bf16_kernel<BGEMM_EPI_GATE, true, 2>), grid, dim3(256), 0, stream, b);
+        else hipLaunchKernelGGL((conv_gemm_bf16_kernel<BGEMM_EPI_GATE, false, 2>), grid, dim3(256), 0, stream, b);
+    } else {
+        if (wide) hipLaunchKernelGGL((conv_gemm_bf16_kernel<BGEMM_EPI_SPLIT, true, 4>), grid, dim3(512), 0, stream, b);
+        else if (use_glds) hipLaunchKernelGGL((conv_gemm_bf16_kernel<BGEMM_EPI_SPLIT, true, 2>), grid, dim3(256), 0, stream, b);
+        else hipLaunchKernelGGL((conv_gemm_bf16_kernel<BGEMM_EPI_SPLIT, false, 2>), grid, dim3(256), 0, stream, b);
+    }
     CTTS_CHECK_LAUNCH("conv_gemm_bf16");
     return CTTS_OK;
 }

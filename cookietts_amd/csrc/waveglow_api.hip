@@ -111,7 +111,7 @@ int make_geom(const Plan& p, int frames, Geom& g) {
     int maxd = 1 << (p.c.n_layers - 1);
     g.pad = round_up(maxd > 128 ? maxd : 128, 32);
     g.ntiles = (g.L + GEMM_BN - 1) / GEMM_BN;
-    g.ld = g.ntiles * GEMM_BN + 2 * g.pad;
+    g.ld = round_up(g.L, 256) + 2 * g.pad;          // room for the 256-wide tiles of the bf16 GEMM
     return CTTS_OK;
 }
 

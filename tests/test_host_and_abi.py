@@ -35,7 +35,7 @@ def test_host_side_queries_run_without_gpu(hip_lib_path):
     c = m.c_config()
     geo = _lib.WaveGlowGeometry()
     assert lib.ctts_waveglow_geometry_for(ctypes.byref(c), 900, ctypes.byref(geo)) == 0
-    assert geo.steps == 28800 and geo.pad == 128 and geo.ld == 28800 + 256 and geo.n_remaining == 8
+    assert geo.steps == 28800 and geo.pad == 128 and geo.ld == 28928 + 256 and geo.n_remaining == 8
     assert lib.ctts_waveglow_packed_bytes(ctypes.byref(c)) > 0
     assert lib.ctts_waveglow_workspace_bytes(ctypes.byref(c), 2, 10) > 0
     bad = m.c_config()
