@@ -143,6 +143,11 @@ SIGNATURES = {
     "ctts_stft_workspace_bytes": (C.c_size_t, [C.POINTER(StftConfig), C.c_int32, C.c_int32]),
     "ctts_stft_mel_f32": (C.c_int, [C.POINTER(StftConfig), _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP,
                                     C.c_size_t, _FP]),
+    "ctts_stft_pack_inverse": (C.c_int, [C.POINTER(StftConfig), _FP, _FP, _FP, _FP]),
+    "ctts_stft_transform_f32": (C.c_int, [C.POINTER(StftConfig), _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP,
+                                          C.c_size_t, _FP]),
+    "ctts_stft_inverse_f32": (C.c_int, [C.POINTER(StftConfig), _FP, _FP, _FP, _FP, C.c_float, _FP, C.c_int32,
+                                        C.c_int32, _FP, C.c_size_t, _FP]),
     "ctts_profile_enable": (C.c_int, [C.c_int32]),
     "ctts_profile_collect": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }

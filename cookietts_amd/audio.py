@@ -8,7 +8,9 @@ C-ABI HIP library (``ctts_stft_mel_f32``); there is no CPU fallback.
 The reference takes its mel filterbank from ``librosa.filters.mel`` (stft.py:163-164, a
 third-party dependency that is not vendored); ``slaney_mel_filterbank`` restates that published
 algorithm (Slaney scale, area normalisation) - constructor-time host code, like the reference's.
-Not built yet (next row): ``STFT.inverse`` / phase output (used by the Denoiser).
+``STFT.transform(return_phase=True)`` / ``STFT.inverse`` (stft.py:99-146) and ``Denoiser``
+(``_4_mtw/waveglow/denoiser.py:7-72``) are built on the same library (``ctts_stft_transform_f32`` /
+``ctts_stft_inverse_f32``).
 """
 from __future__ import annotations
 
@@ -19,7 +21,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["STFT", "TacotronSTFT", "slaney_mel_filterbank"]
+__all__ = ["STFT", "TacotronSTFT", "Denoiser", "slaney_mel_filterbank"]
 
 
 def _hz_to_mel(f):
@@ -74,6 +76,11 @@ class STFT(torch.nn.Module):
         fft_window[lpad:lpad + win_length] = win
         forward_basis *= torch.from_numpy(fft_window).float()
         self.register_buffer('forward_basis', forward_basis.float())
+        scale = filter_length / hop_length
+        inverse_basis = torch.FloatTensor(np.linalg.pinv(scale * fourier_basis).T[:, None, :])
+        inverse_basis *= torch.from_numpy(fft_window).float()
+        self.register_buffer('inverse_basis', inverse_basis.float())
+        self._window_sq = torch.from_numpy((fft_window ** 2).astype(np.float32))   # audio_processing.py:47-50
         self._mel_basis_for_pack = None
         self._packed = None
         self._ws = {}
@@ -107,6 +114,10 @@ class STFT(torch.nn.Module):
                 mb = None if mel_basis is None else mel_basis.detach().float().contiguous().to(device)
                 _lib.check(lib.ctts_stft_pack(C.byref(cfg), _lib.ptr(fb), _lib.ptr(mb), _lib.ptr(blob), stream),
                            "ctts_stft_pack")
+                ib = self.inverse_basis.detach().float().squeeze(1).contiguous().to(device)
+                wsq = self._window_sq.to(device)
+                _lib.check(lib.ctts_stft_pack_inverse(C.byref(cfg), _lib.ptr(ib), _lib.ptr(wsq), _lib.ptr(blob), stream),
+                           "ctts_stft_pack_inverse")
                 torch.cuda.current_stream(device).synchronize()
                 self._packed = (key, blob)
             blob = self._packed[1]
@@ -126,15 +137,66 @@ class STFT(torch.nn.Module):
                                             B, T, _lib.ptr(ws), ws.numel() * 4, stream), "ctts_stft_mel_f32")
         return mag, mel
 
-    def transform(self, input_data, return_phase=True):
-        """[B, T] -> (magnitude [B, N/2+1, T//hop+1], phase)   (stft.py:113-115)"""
-        if return_phase:
-            raise NotImplementedError("phase output is not built yet (needed only by STFT.inverse / Denoiser)")
-        mag, _ = self._run(input_data, want_mag=True)
-        return mag, None
+    def _blob_ws(self, device, B, T):
+        """Packed blob + workspace for (B, T) without running anything (shared by transform/inverse)."""
+        lib = _lib.lib()
+        cfg = self._c_config(0)
+        with torch.cuda.device(device):
+            stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            key = (device, 0)
+            if self._packed is None or self._packed[0] != key:
+                self._run(torch.zeros(1, max(self.filter_length, self.hop_length * 2), device=device), want_mag=True)
+            wkey = (device, B, T)
+            ws = self._ws.get(wkey)
+            if ws is None:
+                nbytes = lib.ctts_stft_workspace_bytes(C.byref(cfg), B, T)
+                if nbytes == 0:
+                    raise _lib.HipLibraryError("STFT workspace query failed: " + lib.ctts_last_error().decode())
+                self._ws = {wkey: torch.zeros(nbytes // 4, dtype=torch.float32, device=device)}
+                ws = self._ws[wkey]
+        return cfg, self._packed[1], ws, stream
 
-    def inverse(self, magnitude, phase):
-        raise NotImplementedError("STFT.inverse is a next-row item (SURVEY.md §8f)")
+    def transform(self, input_data, return_phase=True):
+        """[B, T] -> (magnitude [B, N/2+1, T//hop+1], phase or None)   (stft.py:99-115)"""
+        if not return_phase:
+            mag, _ = self._run(input_data, want_mag=True)
+            return mag, None
+        if input_data.device.type != 'cuda':
+            raise _lib.HipLibraryError("STFT HIP path needs GPU tensors (no CPU fallback)")
+        device = input_data.device
+        y = input_data.detach().float().contiguous()
+        B, T = y.shape
+        cfg, blob, ws, stream = self._blob_ws(device, B, T)
+        frames, cutoff = T // self.hop_length + 1, self.filter_length // 2 + 1
+        mag = torch.empty(B, cutoff, frames, dtype=torch.float32, device=device)
+        phase = torch.empty_like(mag)
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().ctts_stft_transform_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(y), _lib.ptr(mag),
+                                                         _lib.ptr(phase), B, T, _lib.ptr(ws), ws.numel() * 4, stream),
+                       "ctts_stft_transform_f32")
+        return mag, phase
+
+    def inverse(self, magnitude, phase, _bias_spec=None, _strength=0.0):
+        """(magnitude, phase) [B, N/2+1, frames] -> audio [B, 1, (frames-1)*hop]   (stft.py:117-146)"""
+        device = magnitude.device
+        if device.type != 'cuda':
+            raise _lib.HipLibraryError("STFT HIP path needs GPU tensors (no CPU fallback)")
+        mag = magnitude.detach().float().contiguous()
+        ph = phase.detach().to(device).float().contiguous()
+        B, cutoff, frames = mag.shape
+        T = (frames - 1) * self.hop_length
+        cfg, blob, ws, stream = self._blob_ws(device, B, max(T, self.filter_length))
+        out = torch.empty(B, 1, T, dtype=torch.float32, device=device)
+        bias = None if _bias_spec is None else _bias_spec.detach().to(device).float().reshape(-1).contiguous()
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().ctts_stft_inverse_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(mag), _lib.ptr(ph),
+                                                       _lib.ptr(bias), float(_strength), _lib.ptr(out), B, frames,
+                                                       _lib.ptr(ws), ws.numel() * 4, stream), "ctts_stft_inverse_f32")
+        return out
+
+    def forward(self, input_data):
+        self.magnitude, self.phase = self.transform(input_data)
+        return self.inverse(self.magnitude, self.phase)
 
 
 class TacotronSTFT(torch.nn.Module):
@@ -155,3 +217,39 @@ class TacotronSTFT(torch.nn.Module):
         assert torch.max(y) <= 1., f'Tensor.max() of {torch.max(y).item()} is greater than 1.0'
         _, mel = self.stft_fn._run(y, want_mag=False, mel_basis=self.mel_basis, clamp=self.clip_val)
         return mel
+
+
+class Denoiser(torch.nn.Module):
+    """Removes the vocoder's bias spectrum from generated audio (``_4_mtw/waveglow/denoiser.py:7-72``).
+
+    Same constructor arguments; ``stft_device`` is ignored (everything runs on the vocoder's GPU).  The bias
+    subtraction + clamp is fused into the inverse STFT's recombination kernel.  Only the shared-bias mode is
+    built (``speaker_dependant=True`` raises)."""
+
+    def __init__(self, waveglow, sampling_rate=48000, filter_length=None, hop_length=None, win_length=None,
+                 n_mel_channels=160, n_frames=20, mu=0, var=0.01, wg_sigma=0.01, stft_device='cpu',
+                 speaker_dependant=False, speaker_id=0):
+        super().__init__()
+        if speaker_dependant:
+            raise NotImplementedError("speaker_dependant bias spectra are not built")
+        filter_length = filter_length or sampling_rate // 40
+        win_length = win_length or sampling_rate // 40
+        hop_length = hop_length or sampling_rate // 400
+        p = next(waveglow.parameters())
+        self.stft = STFT(filter_length=filter_length, hop_length=hop_length, win_length=win_length).to(p.device)
+        mel_input = torch.randn((1, n_mel_channels, n_frames), dtype=p.dtype, device=p.device) * float(var) + float(mu)
+        with torch.no_grad():
+            try:
+                bias_audio = waveglow.infer(mel_input, speaker_ids=torch.tensor([speaker_id], device=p.device), sigma=wg_sigma)
+            except TypeError:      # glow.py's signature has no speaker_ids keyword (glow.py:314)
+                bias_audio = waveglow.infer(mel_input, sigma=wg_sigma)
+            bias_audio = bias_audio.to(device=p.device, dtype=torch.float)
+            assert torch.isfinite(bias_audio).all(), 'Inf/NaN elements found in Vocoder Output'
+            bias_spec, _ = self.stft.transform(bias_audio, return_phase=False)
+        self.register_buffer('bias_spec', bias_spec.mean(dim=2, keepdim=True))      # [1, cutoff, 1]
+
+    @torch.no_grad()
+    def forward(self, wg_audio, speaker_ids=None, strength=0.1):
+        audio = wg_audio.to(self.bias_spec.device).float()
+        audio_spec, audio_angles = self.stft.transform(audio, return_phase=True)
+        return self.stft.inverse(audio_spec, audio_angles, _bias_spec=self.bias_spec[0], _strength=strength)

@@ -18,7 +18,8 @@ inline size_t align_up(size_t v) { return (v + ALIGN_F - 1) / ALIGN_F * ALIGN_F;
 struct StftPlan {
     ctts_stft_config c;
     int N, cutoff, kmel, mb_mag, mb_mel;
-    size_t basis_A, zero_bias, mel_A, total;
+    size_t basis_A, zero_bias, mel_A, lin_A, inv_A, win_sq, total;
+    int mb_lin, mb_inv, kinv;
 };
 
 int make_stft_plan(const ctts_stft_config* cfg, StftPlan& p) {
@@ -36,9 +37,19 @@ int make_stft_plan(const ctts_stft_config* cfg, StftPlan& p) {
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o = align_up(o + n); return r; };
     p.basis_A = take((size_t)p.mb_mag * (p.N / GEMM_KC) * A_TILE);
-    const int mbmax = p.mb_mag > p.mb_mel ? p.mb_mag : p.mb_mel;
+    int mbmax = p.mb_mag > p.mb_mel ? p.mb_mag : p.mb_mel;
+    const int mb_lin_ = (2 * p.cutoff + GEMM_BM - 1) / GEMM_BM, mb_inv_ = (p.N + GEMM_BM - 1) / GEMM_BM;
+    if (mb_lin_ > mbmax) mbmax = mb_lin_;
+    if (mb_inv_ > mbmax) mbmax = mb_inv_;
     p.zero_bias = take((size_t)mbmax * GEMM_BM);
     p.mel_A = take((size_t)p.mb_mel * (p.kmel / GEMM_KC) * A_TILE);
+    // phase / inverse path: [Re; Im] rows in dense order, and the transposed inverse basis (N rows x 2*cutoff)
+    p.mb_lin = (2 * p.cutoff + GEMM_BM - 1) / GEMM_BM;
+    p.lin_A = take((size_t)p.mb_lin * (p.N / GEMM_KC) * A_TILE);
+    p.kinv = round_up(2 * p.cutoff, GEMM_KC);
+    p.mb_inv = (p.N + GEMM_BM - 1) / GEMM_BM;
+    p.inv_A = take((size_t)p.mb_inv * (p.kinv / GEMM_KC) * A_TILE);
+    p.win_sq = take(p.N);
     p.total = o;
     return CTTS_OK;
 }
@@ -75,6 +86,53 @@ __global__ __launch_bounds__(256) void stft_frames_kernel(const float* __restric
     }
 }
 
+// (re, im) rows [B][kinv][ld] -> magnitude / phase dense [B][cutoff][frames]   (stft.py:107-110)
+__global__ __launch_bounds__(256) void stft_polar_kernel(const float* __restrict__ ri, float* __restrict__ mag,
+                                                         float* __restrict__ phase, int cutoff, int kinv, int frames, int ld) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (n >= frames) return;
+    const float re = ri[((size_t)b * kinv + c) * ld + n], im = ri[((size_t)b * kinv + cutoff + c) * ld + n];
+    const size_t o = ((size_t)b * cutoff + c) * frames + n;
+    mag[o] = sqrtf(re * re + im * im);
+    if (phase) phase[o] = atan2f(im, re);
+}
+
+// R[b][c][n] = m cos(phase), R[b][cutoff + c][n] = m sin(phase), m = bias ? max(mag - bias[c]*strength, 0) : mag
+// (stft.py:118-119; denoiser.py:62-67)
+__global__ __launch_bounds__(256) void stft_recombine_kernel(const float* __restrict__ mag, const float* __restrict__ phase,
+                                                             const float* __restrict__ bias, float strength,
+                                                             float* __restrict__ R, int cutoff, int kinv, int frames, int ld) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (n >= frames) return;
+    const size_t i = ((size_t)b * cutoff + c) * frames + n;
+    float m = mag[i];
+    if (bias) m = fmaxf(m - bias[c] * strength, 0.f);
+    const float ph = phase[i];
+    R[((size_t)b * kinv + c) * ld + n] = m * cosf(ph);
+    R[((size_t)b * kinv + cutoff + c) * ld + n] = m * sinf(ph);
+}
+
+// overlap-add of Y[b][k][n] (conv_transpose1d, stride hop) + window-sum-square normalisation + N/hop scaling +
+// crop N/2 on both sides (stft.py:121-146, audio_processing.py:7-56)
+__global__ __launch_bounds__(256) void stft_ola_kernel(const float* __restrict__ Y, const float* __restrict__ win_sq,
+                                                       float* __restrict__ out, int N, int hop, int frames, int ld, int T_out) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (t >= T_out) return;
+    const int tt = t + N / 2;                       // position in the un-cropped signal
+    float acc = 0.f, wss = 0.f;
+    const int n_hi = min(frames - 1, tt / hop);
+    for (int n = n_hi; n >= 0 && tt - n * hop < N; --n) {
+        const int k = tt - n * hop;
+        acc += Y[((size_t)b * N + k) * ld + n];
+        wss += win_sq[k];
+    }
+    if (wss > 1.17549435e-38f) acc /= wss;          // librosa.util.tiny(float32)
+    out[(size_t)b * T_out + t] = acc * ((float)N / (float)hop);
+}
+
 }  // namespace
 }  // namespace ctts
 
@@ -103,13 +161,31 @@ int ctts_stft_pack(const ctts_stft_config* cfg, const float* forward_basis, cons
     if (p.c.n_mel_channels > 0)
         rc = launch_pack_a(blob + p.mel_A, mel_basis, GEMM_BM, p.mb_mel, p.kmel / GEMM_KC, 0, p.cutoff, GEMM_EPI_LOG, 0,
                            p.c.n_mel_channels, 0, p.cutoff, 1, s);
-    return rc;
+    if (rc) return rc;
+    return launch_pack_a(blob + p.lin_A, forward_basis, GEMM_BM, p.mb_lin, p.N / GEMM_KC, 0, p.N, GEMM_EPI_SPLIT, 0,
+                         2 * p.cutoff, 0, p.N, 1, s);
+}
+
+int ctts_stft_pack_inverse(const ctts_stft_config* cfg, const float* inverse_basis, const float* window_sq, void* packed,
+                           void* stream) {
+    StftPlan p;
+    int rc = make_stft_plan(cfg, p); if (rc) return rc;
+    CTTS_CHECK_ARG(inverse_basis && window_sq && packed, "stft_pack_inverse: NULL pointer");
+    hipStream_t s = as_stream(stream);
+    float* blob = static_cast<float*>(packed);
+    // A_inv[k][m] = inverse_basis[m][k]: dense row k (N rows), K index m (2*cutoff): source strides (1, N)
+    rc = launch_pack_a(blob + p.inv_A, inverse_basis, GEMM_BM, p.mb_inv, p.kinv / GEMM_KC, 0, 2 * p.cutoff, GEMM_EPI_SPLIT, 0,
+                       p.N, 0, 1, p.N, s);
+    if (rc) return rc;
+    CTTS_CHECK_HIP(hipMemcpyAsync(blob + p.win_sq, window_sq, p.N * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return CTTS_OK;
 }
 
 size_t ctts_stft_workspace_bytes(const ctts_stft_config* cfg, int32_t batch, int32_t samples) {
     StftPlan p; StftGeom g;
     if (make_stft_plan(cfg, p) || make_stft_geom(p, samples, g) || batch < 1) return 0;
-    return (align_up((size_t)batch * p.N * g.ld) + align_up((size_t)batch * p.kmel * g.ld)) * sizeof(float);
+    // frames matrix / overlap-add input [B][N][ld] + (magnitude [B][kmel][ld] | re,im [B][kinv][ld])
+    return (align_up((size_t)batch * p.N * g.ld) + align_up((size_t)batch * p.kinv * g.ld)) * sizeof(float);
 }
 
 int ctts_stft_mel_f32(const ctts_stft_config* cfg, const void* packed, const float* y, float* mag, float* mel,
@@ -160,6 +236,68 @@ int ctts_stft_mel_f32(const ctts_stft_config* cfg, const void* packed, const flo
         rc = launch_gemm_f32(GEMM_EPI_LOG, m, s);
         if (rc) return rc;
     }
+    return CTTS_OK;
+}
+
+int ctts_stft_transform_f32(const ctts_stft_config* cfg, const void* packed, const float* y, float* mag, float* phase,
+                            int32_t batch, int32_t samples, void* workspace, size_t workspace_bytes, void* stream) {
+    StftPlan p; StftGeom g;
+    int rc = make_stft_plan(cfg, p); if (rc) return rc;
+    rc = make_stft_geom(p, samples, g); if (rc) return rc;
+    CTTS_CHECK_ARG(packed && y && mag && workspace && batch >= 1, "stft_transform: bad argument");
+    const size_t need = ctts_stft_workspace_bytes(cfg, batch, samples);
+    if (need > workspace_bytes) { set_error("stft_transform: workspace %zu bytes < required %zu", workspace_bytes, need); return CTTS_E_WORKSPACE; }
+    hipStream_t s = as_stream(stream);
+    const float* blob = static_cast<const float*>(packed);
+    float* xf = static_cast<float*>(workspace);
+    float* ri = xf + align_up((size_t)batch * p.N * g.ld);
+    hipLaunchKernelGGL(stft_frames_kernel, dim3((g.ld + 63) / 64, (p.N + 63) / 64, batch), dim3(256), 0, s, y, xf, samples,
+                       p.N, p.c.hop_length, g.frames, g.ld);
+    CTTS_CHECK_LAUNCH("stft_frames");
+    GemmArgs a{};
+    a.ld = g.ld; a.pad = 0; a.L = g.frames; a.ntiles = g.ntiles; a.batch = batch; a.dst_ld = g.ld; a.dst_pad = 0;
+    a.A = blob + p.lin_A; a.bias = blob + p.zero_bias;
+    a.nseg = 1; a.nch_total = p.N / GEMM_KC; a.MB = p.mb_lin; a.M = 2 * p.cutoff;
+    a.seg[0] = {xf, (long long)p.N * g.ld, p.N / GEMM_KC, 0, 0, 0};
+    a.dst0 = ri; a.dst0_bstride = (long long)p.kinv * g.ld; a.dst1 = ri; a.dst1_bstride = a.dst0_bstride;
+    a.split = p.mb_lin * GEMM_BM;
+    if ((rc = launch_gemm_f32(GEMM_EPI_SPLIT, a, s))) return rc;
+    hipLaunchKernelGGL(stft_polar_kernel, dim3((g.frames + 255) / 256, p.cutoff, batch), dim3(256), 0, s, ri, mag, phase,
+                       p.cutoff, p.kinv, g.frames, g.ld);
+    CTTS_CHECK_LAUNCH("stft_polar");
+    return CTTS_OK;
+}
+
+int ctts_stft_inverse_f32(const ctts_stft_config* cfg, const void* packed, const float* mag, const float* phase,
+                          const float* bias_spec, float strength, float* out, int32_t batch, int32_t frames,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    StftPlan p; StftGeom g;
+    int rc = make_stft_plan(cfg, p); if (rc) return rc;
+    CTTS_CHECK_ARG(packed && mag && phase && out && workspace && batch >= 1 && frames >= 2, "stft_inverse: bad argument");
+    const int T_out = (frames - 1) * p.c.hop_length;
+    rc = make_stft_geom(p, T_out > p.N / 2 ? T_out : p.N, g); if (rc) return rc;
+    g.frames = frames; g.ntiles = (frames + GEMM_BN - 1) / GEMM_BN; g.ld = g.ntiles * GEMM_BN;
+    const size_t need = (align_up((size_t)batch * p.N * g.ld) + align_up((size_t)batch * p.kinv * g.ld)) * sizeof(float);
+    if (need > workspace_bytes) { set_error("stft_inverse: workspace %zu bytes < required %zu", workspace_bytes, need); return CTTS_E_WORKSPACE; }
+    hipStream_t s = as_stream(stream);
+    const float* blob = static_cast<const float*>(packed);
+    float* Y = static_cast<float*>(workspace);
+    float* R = Y + align_up((size_t)batch * p.N * g.ld);
+    CTTS_CHECK_HIP(hipMemsetAsync(R, 0, (size_t)batch * p.kinv * g.ld * sizeof(float), s));   // K padding rows / tile tail
+    hipLaunchKernelGGL(stft_recombine_kernel, dim3((frames + 255) / 256, p.cutoff, batch), dim3(256), 0, s, mag, phase,
+                       bias_spec, strength, R, p.cutoff, p.kinv, frames, g.ld);
+    CTTS_CHECK_LAUNCH("stft_recombine");
+    GemmArgs a{};
+    a.ld = g.ld; a.pad = 0; a.L = frames; a.ntiles = g.ntiles; a.batch = batch; a.dst_ld = g.ld; a.dst_pad = 0;
+    a.A = blob + p.inv_A; a.bias = blob + p.zero_bias;
+    a.nseg = 1; a.nch_total = p.kinv / GEMM_KC; a.MB = p.mb_inv; a.M = p.N;
+    a.seg[0] = {R, (long long)p.kinv * g.ld, p.kinv / GEMM_KC, 0, 0, 0};
+    a.dst0 = Y; a.dst0_bstride = (long long)p.N * g.ld; a.dst1 = Y; a.dst1_bstride = a.dst0_bstride;
+    a.split = p.mb_inv * GEMM_BM;
+    if ((rc = launch_gemm_f32(GEMM_EPI_SPLIT, a, s))) return rc;
+    hipLaunchKernelGGL(stft_ola_kernel, dim3((T_out + 255) / 256, batch), dim3(256), 0, s, Y, blob + p.win_sq, out, p.N,
+                       p.c.hop_length, frames, g.ld, T_out);
+    CTTS_CHECK_LAUNCH("stft_ola");
     return CTTS_OK;
 }
 

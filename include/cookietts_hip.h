@@ -354,6 +354,23 @@ int ctts_stft_mel_f32(const ctts_stft_config* cfg, const void* packed, const flo
                       float* mel, int32_t batch, int32_t samples, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* Phase / inverse path (used by the Denoiser, _4_mtw/waveglow/denoiser.py:55-72):
+ *   inverse_basis [2*(N/2+1)][N] = the module buffer of stft.py:62-63,74 (pinv of the scaled DFT basis x window),
+ *   window_sq [N] = the zero-centre-padded squared window of audio_processing.py:47-50. */
+int ctts_stft_pack_inverse(const ctts_stft_config* cfg, const float* inverse_basis, const float* window_sq,
+                           void* packed, void* stream);
+/* STFT.transform_jit with phase (stft.py:99-111): mag, phase [B][N/2+1][frames] (phase may be NULL). */
+int ctts_stft_transform_f32(const ctts_stft_config* cfg, const void* packed, const float* y, float* mag,
+                            float* phase, int32_t batch, int32_t samples, void* workspace,
+                            size_t workspace_bytes, void* stream);
+/* STFT.inverse (stft.py:117-146): conv_transpose1d with the inverse basis, window-sum-square normalisation,
+ * N/hop scaling, crop N/2 each side -> out [B][(frames-1)*hop].  If bias_spec [N/2+1] is non-NULL the magnitude
+ * is first replaced by max(mag - bias_spec*strength, 0) (Denoiser.forward, denoiser.py:62-67).
+ * workspace: ctts_stft_workspace_bytes(cfg, batch, (frames-1)*hop). */
+int ctts_stft_inverse_f32(const ctts_stft_config* cfg, const void* packed, const float* mag, const float* phase,
+                          const float* bias_spec, float strength, float* out, int32_t batch, int32_t frames,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- in-library kernel timing (bench.py roofline leg) --------------------------------- */
 /* When enabled, ctts_waveglow_infer_f32 brackets every launch of the dominant kernel
  * (WN in-layer GEMM: dilated conv + cond + gate) with hipEvents on `stream`. */

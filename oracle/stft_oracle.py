@@ -105,3 +105,58 @@ def mel_spectrogram(y, filter_length=1024, hop_length=256, win_length=1024, n_me
         mel_basis = slaney_mel_filterbank(sampling_rate, filter_length, n_mel_channels, mel_fmin, mel_fmax)
     mel = np.matmul(mel_basis.astype(F32), mag)
     return np.log(np.maximum(mel, F32(clamp_val))).astype(F32)
+
+
+# ---------------------------------------------------------------- phase / inverse / denoiser ----
+def stft_transform(y, filter_length, hop_length, win_length):
+    """(magnitude, phase) as STFT.transform(return_phase=True) (stft.py:99-111)."""
+    y = np.asarray(y, dtype=F32)
+    B, T = y.shape
+    half = filter_length // 2
+    yp = np.pad(y, ((0, 0), (half, half)), mode="reflect")
+    n_frames = T // hop_length + 1
+    idx = np.arange(n_frames)[:, None] * hop_length + np.arange(filter_length)[None, :]
+    spec = np.matmul(yp[:, idx], forward_basis(filter_length, win_length).T)
+    c = filter_length // 2 + 1
+    re, im = spec[..., :c].transpose(0, 2, 1), spec[..., c:].transpose(0, 2, 1)
+    return np.sqrt(re * re + im * im).astype(F32), np.arctan2(im, re).astype(F32)
+
+
+def inverse_basis(filter_length, hop_length, win_length):
+    """[2*cutoff, filter_length]: pinv(scale * fourier_basis).T times the window (stft.py:62-63, 74)."""
+    N = filter_length
+    scale = N / hop_length
+    fb = np.fft.fft(np.eye(N))
+    c = N // 2 + 1
+    fb = np.vstack([np.real(fb[:c, :]), np.imag(fb[:c, :])])
+    inv = np.linalg.pinv(scale * fb).T.astype(F32)
+    win = pad_center(hann_periodic(win_length), N).astype(F32)
+    return (inv * win[None, :]).astype(F32)
+
+
+def stft_inverse(mag, phase, filter_length, hop_length, win_length):
+    """STFT.inverse (stft.py:117-146): [B, c, frames] x2 -> [B, 1, (frames-1)*hop]."""
+    mag, phase = np.asarray(mag, F32), np.asarray(phase, F32)
+    B, c, frames = mag.shape
+    N = filter_length
+    rec = np.concatenate([mag * np.cos(phase), mag * np.sin(phase)], axis=1).astype(F32)     # [B, 2c, frames]
+    ib = inverse_basis(N, hop_length, win_length)                                            # [2c, N]
+    Y = np.einsum("bmn,mk->bkn", rec, ib).astype(F32)                                        # [B, N, frames]
+    total = N + hop_length * (frames - 1)
+    out = np.zeros((B, total), dtype=F32)
+    wss = np.zeros(total, dtype=F32)
+    win_sq = pad_center((hann_periodic(win_length) ** 2), N).astype(F32)
+    for n in range(frames):
+        out[:, n * hop_length:n * hop_length + N] += Y[:, :, n]
+        wss[n * hop_length:n * hop_length + N] += win_sq
+    nz = wss > np.finfo(np.float32).tiny
+    out[:, nz] /= wss[nz]
+    out *= F32(N) / F32(hop_length)
+    return out[:, None, N // 2:-(N // 2)]
+
+
+def denoise(audio, bias_spec, strength, filter_length, hop_length, win_length):
+    """Denoiser.forward (denoiser.py:55-72) for one shared bias spectrum [c]."""
+    mag, phase = stft_transform(audio, filter_length, hop_length, win_length)
+    den = np.maximum(mag - bias_spec[None, :, None] * F32(strength), 0).astype(F32)
+    return stft_inverse(den, phase, filter_length, hop_length, win_length)

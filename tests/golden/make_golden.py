@@ -160,6 +160,35 @@ def make_stft():
                         mag800=mag2.numpy().astype(np.float32))
     print(f"[golden] stft_mel: mel {mel.shape} mag {tuple(mag.shape)} -> {os.path.getsize(path) / 1024:.0f} KiB")
 
+    # phase / inverse / denoiser (the reference Denoiser with a FIXED bias spectrum: its constructor draws
+    # random mels and vocoder noise, which is not what is being pinned)
+    from CookieTTS._4_mtw.waveglow import denoiser as ref_den
+    N, hop = 1024, 256
+    st = STFT(N, hop, N)
+    y3 = y[:, :8192]
+    with torch.no_grad():
+        m3, p3 = st.transform(torch.from_numpy(y3), return_phase=True)
+        rt = st.inverse(m3, p3)
+
+        class _FakeVocoder(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.w = torch.nn.Parameter(torch.zeros(1))
+
+            def infer(self, mel, speaker_ids=None, sigma=1.0):
+                return torch.zeros(mel.shape[0], mel.shape[2] * hop)
+        den = ref_den.Denoiser(_FakeVocoder(), sampling_rate=22050, filter_length=N, hop_length=hop, win_length=N,
+                               n_mel_channels=80)
+        bias = (np.abs(rng.standard_normal(N // 2 + 1)) * 0.5).astype(np.float32)
+        den.bias_spec = torch.from_numpy(bias)[None, :, None]
+        dn = den(torch.from_numpy(y3), strength=0.3)
+    path = os.path.join(HERE, "stft_inverse.npz")
+    np.savez_compressed(path, y=y3, mag=m3.numpy().astype(np.float32), phase=p3.numpy().astype(np.float32),
+                        roundtrip=rt.numpy().astype(np.float32), bias_spec=bias, strength=np.float32(0.3),
+                        denoised=dn.numpy().astype(np.float32))
+    print(f"[golden] stft_inverse: roundtrip {tuple(rt.shape)} max err vs input "
+          f"{float(np.abs(rt.numpy()[:, 0] - y3).max()):.2e} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
 
 def _ref_waveflow(cfg, sd_np):
     """Import the reference's ax core (needs librosa / iso226 stand-ins and np.product)."""

@@ -84,3 +84,54 @@ def test_hip_stft_matches_oracle_shapes(hip_lib_path, N, hop, T, B):
         g = _golden()
         m8, _ = st.transform(torch.from_numpy(g["y"][:, :5000]).cuda(), return_phase=False)
         assert np.abs(m8.cpu().numpy() - g["mag800"]).max() < 2e-6 * float(g["mag800"].max())
+
+
+def _inv_golden():
+    return np.load(os.path.join(GOLDEN, "stft_inverse.npz"))
+
+
+def _phase_err(a, b, mag, thr=1e-2):
+    d = np.abs(np.angle(np.exp(1j * (a.astype(np.float64) - b))))
+    return float(d[mag > thr].max())
+
+
+def test_oracle_inverse_and_denoiser_match_reference():
+    g = _inv_golden()
+    mag, ph = so.stft_transform(g["y"], 1024, 256, 1024)
+    assert np.abs(mag - g["mag"]).max() < 1e-6 * float(g["mag"].max()) + 1e-6
+    assert _phase_err(ph, g["phase"], g["mag"]) < 1e-3
+    rt = so.stft_inverse(g["mag"], g["phase"], 1024, 256, 1024)
+    assert rt.shape == g["roundtrip"].shape and np.abs(rt - g["roundtrip"]).max() < 1e-5
+    assert np.abs(rt[:, 0] - g["y"]).max() < 1e-5                      # STFT -> ISTFT reconstructs the input
+    dn = so.denoise(g["y"], g["bias_spec"], float(g["strength"]), 1024, 256, 1024)
+    assert np.abs(dn - g["denoised"]).max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_hip_phase_inverse_denoiser_match_reference(hip_lib_path):
+    from cookietts_amd import STFT, Denoiser
+    g = _inv_golden()
+    st = STFT(1024, 256, 1024).cuda()
+    y = torch.from_numpy(g["y"]).cuda()
+    mag, ph = st.transform(y, return_phase=True)
+    assert np.abs(mag.cpu().numpy() - g["mag"]).max() < 2e-6 * float(g["mag"].max()) + 1e-6
+    assert _phase_err(ph.cpu().numpy(), g["phase"], g["mag"]) < 1e-3
+    rt = st.inverse(torch.from_numpy(g["mag"]).cuda(), torch.from_numpy(g["phase"]).cuda()).cpu().numpy()
+    print("inverse Linf vs reference:", np.abs(rt - g["roundtrip"]).max())
+    assert rt.shape == g["roundtrip"].shape and np.abs(rt - g["roundtrip"]).max() < MEL_TOL
+    assert np.abs(st(y).cpu().numpy()[:, 0] - g["y"]).max() < MEL_TOL                  # forward(): round trip
+
+    class _Vocoder(torch.nn.Module):                 # the Denoiser only needs .parameters() and .infer()
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1))
+
+        def infer(self, mel, sigma=1.0):
+            return torch.rand(mel.shape[0], mel.shape[2] * 256, device=mel.device) * 0.1
+    den = Denoiser(_Vocoder().cuda(), sampling_rate=22050, filter_length=1024, hop_length=256, win_length=1024,
+                   n_mel_channels=80)
+    assert den.bias_spec.shape == (1, 513, 1) and torch.isfinite(den.bias_spec).all()
+    den.bias_spec = torch.from_numpy(g["bias_spec"]).cuda()[None, :, None]
+    dn = den(y, strength=float(g["strength"])).cpu().numpy()
+    print("denoiser Linf vs reference:", np.abs(dn - g["denoised"]).max())
+    assert dn.shape == g["denoised"].shape and np.abs(dn - g["denoised"]).max() < MEL_TOL
