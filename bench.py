@@ -163,11 +163,19 @@ def main():
                         "launches": int(n.value), "mean_launch_ms": round(mean_s * 1e3, 4),
                         "flop_per_launch": flop_per_launch}
             if args.dtype == "bf16":
-                # the bf16 kernel sits near the ridge: also report it against HBM with its algorithmic bytes
-                # (read x C*2 + cond hidden 256*2, write act C*2 per time step)
-                bytes_per_launch = float((2 * C + 256) * 2) * B * L
-                roofline["hbm"] = {"achieved": round(bytes_per_launch / mean_s / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                                   "frac": round(bytes_per_launch / mean_s / 8e12, 4), "bytes_per_launch": bytes_per_launch}
+                # In bf16 the in-layer GEMM stays MFMA-bound (1430 FLOP/B vs a ridge of ~312); the memory-bound WN
+                # kernel is the res/skip GEMM (K = C): 2*C*2C FLOP against act read + x and skip-sum read-modify-write
+                # = 5*C*2 B per time step (205 FLOP/B).  Report it against HBM.
+                n2 = ctypes.c_int64()
+                ms2 = ctypes.c_double()
+                _lib.check(lib.ctts_profile_collect(_lib.PROF_WN_RS, ctypes.byref(n2), ctypes.byref(ms2)), "profile")
+                mean2 = ms2.value / max(n2.value, 1) * 1e-3
+                bytes2 = float(5 * C * 2) * B * L
+                roofline["res_skip_hbm"] = {
+                    "kernel": "conv_gemm_bf16_kernel<SPLIT> (WN res/skip 1x1 + residual/skip accumulate)", "bound": "hbm",
+                    "achieved": round(bytes2 / mean2 / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(bytes2 / mean2 / 8e12, 4), "launches": int(n2.value),
+                    "mean_launch_ms": round(mean2 * 1e3, 4), "bytes_per_launch": bytes2}
         cpu = None
         if world == 1 and args.cpu_frames > 0:
             cpu = cpu_baseline(cfg, sd, args.cpu_frames, seed)

@@ -35,9 +35,16 @@ enum GemmEpilogue : int {
     // dst0[row] = leaky_relu(acc + bias, clip as slope) / tanh(acc + bias)    (Tacotron encoder / postnet convs)
     GEMM_EPI_LRELU = 4,
     GEMM_EPI_TANH = 5,
+    // GATE followed, in the same workgroup, by the res/skip 1x1 GEMM on the gated tile held in registers
+    // (bm = 128 shape with all pairC <= 64 channels in one wave-row): the activations never touch HBM.
+    //   rows < split of  rs_w . act + rs_b  -> dst0 = src0 + .   (next layer's input)
+    //   rows >= split                       -> dst1 (+)= .       (skip sum)
+    GEMM_EPI_GATE_RS = 6,
 };
 
-__host__ __device__ inline bool gemm_epi_is_pair(int epi) { return epi == GEMM_EPI_GATE || epi == GEMM_EPI_MAG; }
+__host__ __device__ inline bool gemm_epi_is_pair(int epi) {
+    return epi == GEMM_EPI_GATE || epi == GEMM_EPI_MAG || epi == GEMM_EPI_GATE_RS;
+}
 
 struct GemmSeg {
     const float* base;    // [B][rows][ld] padded layout
@@ -69,6 +76,9 @@ struct GemmArgs {
     int pairC;            // pair epilogues: number of valid channels (dense rows c and pairC + c)
     int dst_ld, dst_pad;  // row stride / left pad of the destination tensors (usually == ld, pad)
     float clip;           // GEMM_EPI_LOG clamp / GEMM_EPI_LRELU negative slope
+    const float* rs_wT;   // GEMM_EPI_GATE_RS: res/skip weight transposed and row-padded: [64][128]
+    const float* rs_bias; // [128] (rows >= rs_rows zero)
+    int rs_rows;          // 128 (res + skip) or 64 (last layer: skip only)
 };
 
 // Row of the dense weight matrix held by block-local row r of M-block mb, or -1 for padding

@@ -45,6 +45,56 @@ __device__ __forceinline__ float4 load4u(gfloat_ptr p) {
     return v;
 }
 
+// Store / read-modify-write epilogue of one wave tile (4 x 2 MFMA tiles = 128 rows x 64 columns).
+// rows < split -> dst0 (= src0 + v when acc0), rows >= split -> dst1[row - split] (+= when acc1).
+template <int EPI>
+__device__ __forceinline__ void split_epilogue(const GemmArgs& a, f32x16 (&acc)[4][2], const float* bias, int M, int row0,
+                                               int b, int ncol0, int l31, int lhi) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int rbase = row0 + mt * 32;                        // uniform per tile
+        if (rbase >= M) continue;                                // zero-padded rows of a ragged M
+        const bool second = rbase >= a.split;                    // split is a multiple of 32
+        float* dst = second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride;
+        const float* src = second ? dst : (a.src0 ? a.src0 + (size_t)b * a.src0_bstride : dst);
+        const int accum = second ? a.acc1 : a.acc0;
+        const int rdst = second ? rbase - a.split : rbase;
+        // read-modify-write: issue all 32 loads of this row-tile before the first store so
+        // the wave pays one memory latency per tile, not one per element (the compiler must
+        // otherwise order every load behind the previous, possibly aliasing, store).
+        float old[2][16];
+        if (accum) {   // uniform; columns >= L of a padded row are readable, so no per-lane guard
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    old[nt][r] = src[(size_t)(rdst + row) * a.dst_ld + a.dst_pad + ncol0 + nt * 32 + l31];
+                }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) old[nt][r] = 0.0f;
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = ncol0 + nt * 32 + l31;
+            if (n < a.L) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    float v = acc[mt][nt][r] + bias[(rbase - row0) + row] + old[nt][r];
+                    if constexpr (EPI == GEMM_EPI_LOG) v = logf(fmaxf(v, a.clip));
+                    if constexpr (EPI == GEMM_EPI_LRELU) v = v > 0.f ? v : a.clip * v;
+                    if constexpr (EPI == GEMM_EPI_TANH) v = tanhf(v);
+                    if (rbase + row < M) dst[(size_t)(rdst + row) * a.dst_ld + a.dst_pad + n] = v;
+                }
+            }
+        }
+    }
+}
+
 // SEGS = 4: segment bases live in registers and are picked with a scalar-compare select chain (no LDS
 // round trip at the top of a chunk); SEGS = GEMM_MAX_SEG: bases come from the LDS segment table.
 template <int EPI, int WM, int SEGS>
@@ -250,50 +300,54 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
                 }
             }
         }
-    } else {
+    } else if constexpr (EPI == GEMM_EPI_GATE_RS) {
+        static_assert(EPI != GEMM_EPI_GATE_RS || WM == 1, "fused res/skip needs the 128-row block shape");
+        // 1. gated activations of this wave's 64 channels x 64 columns, kept in registers
+        float actv[2][2][16];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int rbase = mb * BM + wm * 128 + mt * 32;          // uniform per tile
-            if (rbase >= a.M) continue;                              // zero-padded rows of a ragged M
-            const bool second = rbase >= a.split;                    // split is a multiple of 32
-            float* dst = second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride;
-            const float* src = second ? dst : (a.src0 ? a.src0 + (size_t)b * a.src0_bstride : dst);
-            const int accum = second ? a.acc1 : a.acc0;
-            const int rdst = second ? rbase - a.split : rbase;
-            // read-modify-write: issue all 32 loads of this row-tile before the first store so
-            // the wave pays one memory latency per tile, not one per element (the compiler must
-            // otherwise order every load behind the previous, possibly aliasing, store).
-            float old[2][16];
-            if (accum) {   // uniform; columns >= L of a padded row are readable, so no per-lane guard
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                        old[nt][r] = src[(size_t)(rdst + row) * a.dst_ld + a.dst_pad + n0 + wn * 64 + nt * 32 + l31];
-                    }
-            } else {
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) old[nt][r] = 0.0f;
-            }
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int n = n0 + wn * 64 + nt * 32 + l31;
-                if (n < a.L) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                        float v = acc[mt][nt][r] + bias[mt * 32 + row] + old[nt][r];
-                        if constexpr (EPI == GEMM_EPI_LOG) v = logf(fmaxf(v, a.clip));
-                        if constexpr (EPI == GEMM_EPI_LRELU) v = v > 0.f ? v : a.clip * v;
-                        if constexpr (EPI == GEMM_EPI_TANH) v = tanhf(v);
-                        if (rbase + row < a.M) dst[(size_t)(rdst + row) * a.dst_ld + a.dst_pad + n] = v;
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const bool ok = mt * 32 + row < a.pairC;
+                    const float u0 = acc[mt][nt][r] + bias[mt * 32 + row];
+                    const float u1 = acc[mt + 2][nt][r] + bias[64 + mt * 32 + row];
+                    actv[mt][nt][r] = ok ? fast_tanh(u0) * fast_sigmoid(u1) : 0.0f;
                 }
-            }
+        __syncthreads();                                   // everyone is done with the bias copy in LDS
+        // 2. res/skip weights (transposed, [channel][128 rows]) and bias -> LDS
+        for (int i = t * 4; i < 64 * 128; i += 1024)
+            *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(a.rs_wT + i);
+        if (t < 128) lds[64 * 128 + t] = a.rs_bias[t];
+        __syncthreads();
+        // 3. second GEMM, wave-local: B operand = the activation registers.  The MFMA k index is free to be any
+        // permutation of the channels as long as A agrees: k-step s pairs the channel each half-wave already holds
+        // in accumulator register s of its C/D layout, so no cross-lane movement is needed.
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int r = s & 15;
+            const int ch = (s >> 4) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            float a2[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) a2[mt] = lds[ch * 128 + mt * 32 + l31];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[mt], actv[s >> 4][nt][r], acc[mt][nt], 0, 0, 0);
         }
+        // 4. residual / skip epilogue
+        split_epilogue<GEMM_EPI_SPLIT>(a, acc, lds + 64 * 128, a.rs_rows, /*row0=*/0, b, n0 + wn * 64, l31, lhi);
+    } else {
+        split_epilogue<EPI>(a, acc, bias, a.M, mb * BM + wm * 128, b, n0 + wn * 64, l31, lhi);
     }
 }
 
@@ -344,6 +398,12 @@ int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
     dim3 grid((unsigned)blocks);
     switch (epi) {
         case GEMM_EPI_GATE: launch_shape<GEMM_EPI_GATE>(a.bm, grid, stream, a); break;
+        case GEMM_EPI_GATE_RS:
+            CTTS_CHECK_ARG(a.bm == 128 && a.pairC <= 64 && a.MB == 1 && a.rs_wT && a.rs_bias && (a.rs_rows == 64 || a.rs_rows == 128),
+                           "gemm: fused res/skip needs bm=128, <= 64 channels");
+            if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, 4>), grid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, GEMM_MAX_SEG>), grid, dim3(256), 0, stream, a);
+            break;
         case GEMM_EPI_MAG: launch_shape<GEMM_EPI_MAG>(a.bm, grid, stream, a); break;
         case GEMM_EPI_LOG: launch_shape<GEMM_EPI_LOG>(a.bm, grid, stream, a); break;
         case GEMM_EPI_LRELU: launch_shape<GEMM_EPI_LRELU>(a.bm, grid, stream, a); break;

@@ -11,6 +11,7 @@
 // commutes with the 1x1 conv), so mel is interpolated ONCE to L steps and the cond layer becomes
 // extra K of every in-layer GEMM (the [B, 2*C*n_layers, L] tensor is never materialised).
 // PermuteHeight (efficient_modules.py:360-403) is folded into a logical->physical row map.
+#include <cstdlib>
 #include <vector>
 
 #include "gemm_f32.h"
@@ -26,12 +27,14 @@ constexpr int WF_BM = 128;
 struct WfPlan {
     ctts_waveflow_config c;
     int C, kmel, nch_in, nch_c;      // nch_c = chunks per (tap) segment
-    struct Flow { size_t start_w, start_b, end_w, end_b; std::vector<size_t> in_A, in_b, rs_A, rs_b; };
+    struct Flow { size_t start_w, start_b, end_w, end_b; std::vector<size_t> in_A, in_b, rs_A, rs_b, rs_T, rs_Tb; };
     std::vector<Flow> fl;
     size_t total;
     int rs_rows(int i) const { return i < c.n_layers - 1 ? 2 * C : C; }
     int rs_mb(int i) const { return (rs_rows(i) + WF_BM - 1) / WF_BM; }
     int in_mb() const { return (C + 63) / 64; }
+    // one 128-row block holds every gate pair: the res/skip GEMM runs inside the in-layer kernel (GEMM_EPI_GATE_RS)
+    bool fused() const { return C == 64; }
 };
 
 int make_wf_plan(const ctts_waveflow_config* cfg, WfPlan& p) {
@@ -63,10 +66,25 @@ int make_wf_plan(const ctts_waveflow_config* cfg, WfPlan& p) {
             f.in_b.push_back(take((size_t)p.in_mb() * WF_BM));
             f.rs_A.push_back(take((size_t)p.rs_mb(i) * p.nch_c * GEMM_KC * WF_BM));
             f.rs_b.push_back(take((size_t)p.rs_mb(i) * WF_BM));
+            f.rs_T.push_back(take(p.fused() ? 64 * 128 : 0));
+            f.rs_Tb.push_back(take(p.fused() ? 128 : 0));
         }
     }
     p.total = o;
     return CTTS_OK;
+}
+
+// res/skip weight [rows][64] -> transposed, row-padded [64][128] (+ bias [128]) for the fused epilogue
+__global__ void wf_pack_rs_t_kernel(const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ wT,
+                                    float* __restrict__ bT, int rows) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 64 * 128) {
+        const int ch = i >> 7, row = i & 127;
+        wT[i] = row < rows ? w[row * 64 + ch] : 0.0f;
+    } else if (i < 64 * 128 + 128) {
+        const int row = i - 64 * 128;
+        bT[row] = row < rows ? b[row] : 0.0f;
+    }
 }
 
 struct WfGeom { int L, ld, pad, ntiles; };
@@ -271,6 +289,11 @@ int ctts_waveflow_pack_flow(const ctts_waveflow_config* cfg, int32_t k, const ct
                                 0, C, 1, s))) return rc;
         if ((rc = launch_pack_bias(blob + f.rs_b[i], WF_BM, p.rs_mb(i), w->rs_b[i], 0, nullptr, 0, GEMM_EPI_SPLIT, C,
                                    rows, s))) return rc;
+        if (p.fused()) {
+            hipLaunchKernelGGL(wf_pack_rs_t_kernel, dim3(33), dim3(256), 0, s, w->rs_w[i], w->rs_b[i], blob + f.rs_T[i],
+                               blob + f.rs_Tb[i], rows);
+            CTTS_CHECK_LAUNCH("wf_pack_rs_t");
+        }
     }
     return CTTS_OK;
 }
@@ -310,6 +333,7 @@ int ctts_waveflow_inverse_f32(const ctts_waveflow_config* cfg, const void* packe
     int phys[64], perm[64], tmp[64];
     for (int i = 0; i < G; ++i) phys[i] = i;
     auto X = [&](int layer, int slot) { return w.X + ((size_t)layer * kh + slot) * w.xslot; };
+    const bool fuse = p.fused() && !getenv("CTTS_WF_NO_FUSE");
 
     for (int k = p.c.n_flows - 1; k >= 0; --k) {
         const auto& f = p.fl[k];
@@ -340,10 +364,20 @@ int ctts_waveflow_inverse_f32(const ctts_waveflow_config* cfg, const void* packe
                 a.seg[ns++] = {w.mel_up, (long long)p.kmel * g.ld, p.kmel / GEMM_KC, 0, 0, 0};
                 a.nseg = ns;
                 a.nch_total = (kh - a_min) * kw * p.nch_c + p.kmel / GEMM_KC;
+                const bool last = i == p.c.n_layers - 1;
+                if (fuse) {
+                    // x_{i+1}[row r] = x_i[row r] + res -> layer i+1's ring slot;  skip rows (+)= into w.out
+                    a.rs_wT = blob + f.rs_T[i]; a.rs_bias = blob + f.rs_Tb[i]; a.rs_rows = p.rs_rows(i);
+                    a.dst0 = last ? w.out : X(i + 1, slot); a.dst0_bstride = cstride; a.acc0 = 1;
+                    a.src0 = X(i, slot); a.src0_bstride = cstride;
+                    a.dst1 = w.out; a.dst1_bstride = cstride; a.acc1 = i > 0 ? 1 : 0;
+                    a.split = last ? 0 : C;
+                    if ((rc = launch_gemm_f32(GEMM_EPI_GATE_RS, a, s))) return rc;
+                    continue;
+                }
                 a.dst0 = w.act; a.dst0_bstride = cstride;
                 if ((rc = launch_gemm_f32(GEMM_EPI_GATE, a, s))) return rc;
 
-                const bool last = i == p.c.n_layers - 1;
                 GemmArgs q{};
                 q.bm = WF_BM;
                 q.ld = g.ld; q.pad = g.pad; q.L = L; q.ntiles = g.ntiles; q.batch = batch;

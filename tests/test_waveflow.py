@@ -101,3 +101,17 @@ def test_hip_infer_contract_and_ragged_vs_oracle(hip_lib_path):
     z2[0, 100] = np.nan
     got2, _ = m.inverse(torch.from_numpy(z2).cuda(), torch.from_numpy(melp).cuda())
     assert torch.isfinite(got2).all()
+
+
+@pytest.mark.gpu
+def test_fused_res_skip_epilogue_matches_two_kernel_path(hip_lib_path, monkeypatch):
+    """C = 64 runs the res/skip GEMM inside the in-layer kernel; CTTS_WF_NO_FUSE keeps the two-launch path."""
+    g, cfg, _ = _load("toy")
+    m, _, _ = _model(str(g["config_key"]), int(g["seed"]))
+    melp = torch.from_numpy(np.pad(g["mel"], ((0, 0), (0, 0), (0, 1)))).cuda()
+    z = torch.from_numpy(g["z"]).cuda()
+    fused, _ = m.inverse(z, melp)
+    monkeypatch.setenv("CTTS_WF_NO_FUSE", "1")
+    plain, _ = m.inverse(z, melp)
+    assert rms_rel_err(plain.numpy(), g["inverse_full"]) < WAVE_TOL
+    assert rms_rel_err(fused.numpy(), plain.numpy()) < 1e-5
