@@ -75,4 +75,17 @@ __host__ __device__ inline float bf16_to_f32(bf16_t h) {
     return v.f;
 }
 
+// two fp32 -> packed bf16 (round to nearest even): one v_cvt_pk_bf16_f32 on the device
+__host__ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {lo, hi};
+    const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+    return __builtin_bit_cast(unsigned int, b);
+#else
+    return (unsigned int)f32_to_bf16_rne(lo) | ((unsigned int)f32_to_bf16_rne(hi) << 16);
+#endif
+}
+
 }  // namespace ctts

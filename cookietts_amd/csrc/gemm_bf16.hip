@@ -16,6 +16,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 namespace {
 
 constexpr int A_UNITS = 4 * BGEMM_BM;                   // 1024 x 16 B
+constexpr int BGEMM_PP_MAX_CHUNKS = 128;                // ping-pong kernel: chunk address table entries
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // one 16-byte K8 unit
 typedef const __attribute__((address_space(1))) u32x4* gunit_ptr;
@@ -26,8 +27,95 @@ __device__ __forceinline__ float fast_sigmoid(float u) {
 __device__ __forceinline__ float fast_tanh(float u) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * 2.8853900817779268f));
 }
-__device__ __forceinline__ unsigned int pack2(float lo, float hi) {
-    return (unsigned int)f32_to_bf16_rne(lo) | ((unsigned int)f32_to_bf16_rne(hi) << 16);
+__device__ __forceinline__ unsigned int pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+// tanh(u0) * sigmoid(u1) = (e^{2 u0} - 1) / ((e^{2 u0} + 1)(1 + e^{-u1})): three transcendentals instead of four.
+// u0 is clamped to +-10 (tanh is 1 to fp32 precision there) so the numerator stays finite; a huge e^{-u1} drives
+// the reciprocal to 0, which is the limit.
+__device__ __forceinline__ float fast_gate(float u0, float u1) {
+    const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(u0, -10.0f, 10.0f) * 2.8853900817779268f);
+    const float q = __builtin_amdgcn_exp2f(u1 * -1.4426950408889634f);
+    return (e - 1.0f) * __builtin_amdgcn_rcpf((e + 1.0f) * (1.0f + q));
+}
+
+// Epilogue shared by the block shapes.  32x32 C/D layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5):
+// for a fixed register group q = r>>2 the lane holds 4 consecutive channels (8q + 4*lhi + 0..3) of one column,
+// i.e. half of a 16-byte K8 unit; lanes l and l+32 complete the unit and lanes 0..31 are consecutive columns.
+template <int EPI>
+__device__ __forceinline__ void bf16_epilogue(const BGemmArgs& a, f32x16 (&acc)[4][2], u32x4* lds, int t, int mb, int wm,
+                                              int wn, int b, int n0, int l31, int lhi) {
+    float* bias_s = reinterpret_cast<float*>(lds);
+    if (t < BGEMM_BM) bias_s[t] = a.bias[mb * BGEMM_BM + t];
+    __syncthreads();
+    const float* bias = bias_s + wm * 128;
+    if constexpr (EPI == BGEMM_EPI_GATE) {
+        bf16_t* dst = a.dst0 + (size_t)b * a.dst0_bstride;
+        const int cbase = (mb * 2 + wm) * 64;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            if (cbase + mt * 32 >= a.pairC) continue;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int n = n0 + wn * 64 + nt * 32 + l31;
+                if (n < a.L) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int row = 8 * q + 4 * lhi + j;
+                            const float u0 = acc[mt][nt][4 * q + j] + bias[mt * 32 + row];
+                            const float u1 = acc[mt + 2][nt][4 * q + j] + bias[64 + mt * 32 + row];
+                            v[j] = fast_gate(u0, u1);
+                        }
+                        const int cg = (cbase + mt * 32) / 8 + q;
+                        uint2 pk = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+                        *reinterpret_cast<uint2*>(dst + ((size_t)cg * a.ld + a.pad + n) * 8 + 4 * lhi) = pk;
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int rbase = mb * BGEMM_BM + wm * 128 + mt * 32;
+            if (rbase >= a.M) continue;
+            const bool second = rbase >= a.split;
+            bf16_t* dst = second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride;
+            const int accum = second ? a.acc1 : a.acc0;
+            const int cg0 = (second ? rbase - a.split : rbase) / 8;
+            uint2 old[2][4];
+            if (accum) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        old[nt][q] = *reinterpret_cast<const uint2*>(
+                            dst + ((size_t)(cg0 + q) * a.ld + a.pad + n0 + wn * 64 + nt * 32 + l31) * 8 + 4 * lhi);
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) old[nt][q] = make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int n = n0 + wn * 64 + nt * 32 + l31;
+                if (n < a.L) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v[4];
+                        const float o[4] = {bf16_to_f32((bf16_t)(old[nt][q].x & 0xffff)), bf16_to_f32((bf16_t)(old[nt][q].x >> 16)),
+                                            bf16_to_f32((bf16_t)(old[nt][q].y & 0xffff)), bf16_to_f32((bf16_t)(old[nt][q].y >> 16))};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            v[j] = acc[mt][nt][4 * q + j] + bias[mt * 32 + 8 * q + 4 * lhi + j] + o[j];
+                        uint2 pk = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+                        *reinterpret_cast<uint2*>(dst + ((size_t)(cg0 + q) * a.ld + a.pad + n) * 8 + 4 * lhi) = pk;
+                    }
+                }
+            }
+        }
+    }
 }
 
 // NW = waves along N: 2 -> 256 threads, block tile 256 x 128; 4 -> 512 threads, block tile 256 x 256 (one
@@ -199,82 +287,164 @@ __global__ __launch_bounds__(128 * NW, 2) void conv_gemm_bf16_kernel(const BGemm
 #undef CTTS_STORE_LDS
 #undef CTTS_ISSUE_GLDS
 
-    // ---- epilogue.  32x32 C/D layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5): for a fixed
-    // register group q = r>>2 the lane holds 4 consecutive channels (8q + 4*lhi + 0..3) of one column, i.e.
-    // half of a 16-byte K8 unit; lanes l and l+32 complete the unit and lanes 0..31 are consecutive columns.
-    float* bias_s = reinterpret_cast<float*>(lds);
-    if (t < BGEMM_BM) bias_s[t] = a.bias[mb * BGEMM_BM + t];
-    __syncthreads();
-    const float* bias = bias_s + wm * 128;
-    if constexpr (EPI == BGEMM_EPI_GATE) {
-        bf16_t* dst = a.dst0 + (size_t)b * a.dst0_bstride;
-        const int cbase = (mb * 2 + wm) * 64;
+    bf16_epilogue<EPI>(a, acc, lds, t, mb, wm, wn, b, n0, l31, lhi);
+}
+
+// Ping-pong form of the 256 x 256 block (512 threads = 8 waves, one workgroup per CU, two waves per SIMD).
+// The waves of rows 0..127 (waves 0-3, one per SIMD) and of rows 128..255 (waves 4-7) run the same
+// [LOAD k | COMPUTE k] sequence one phase apart, every phase closed by s_barrier: while one half issues its 16
+// MFMAs (512 matrix-pipe cycles) out of registers, its SIMD partner reads the 12 fragments of its next chunk from
+// LDS and issues the DMA for chunk k+2 - so LDS latency, DMA issue and barrier skew sit beside MFMAs instead of
+// in front of them (the barrier-per-chunk form left the matrix pipe idle for all of that: 40 % of peak).
+// LDS: 3 stages x 32 KiB.  Buffer of chunk k-1 is rewritten (chunk k+2) only after both halves have read it; a
+// chunk is read only after both halves have waited for their own DMAs of it (counted vmcnt) and met at a barrier.
+template <int EPI, int NS>
+__global__ __launch_bounds__(512, 2) void conv_gemm_bf16_pp_kernel(const BGemmArgs a) {
+    constexpr int NT = 512, BN = 256;
+    constexpr int B_UNITS = 4 * BN;
+    constexpr int STAGE_UNITS = A_UNITS + B_UNITS;
+    // NS stages + the chunk address table (8 B per chunk, <= BGEMM_PP_MAX_CHUNKS)
+    __shared__ __attribute__((aligned(16))) u32x4 lds[NS * STAGE_UNITS + BGEMM_PP_MAX_CHUNKS / 2];
+    typedef unsigned long long u64;
+    u64* tab = reinterpret_cast<u64*>(lds + NS * STAGE_UNITS);
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform -> SALU address math, scalar branches
+    const int wm = wave >> 2, wn = wave & 3;                // wm = which half (leading 0 / lagging 1)
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    int id = blockIdx.x;
+    const int mb = id % a.MB;
+    id /= a.MB;
+    const int tile = id % a.ntiles;
+    const int b = id / a.ntiles;
+    const int n0 = tile * BN;
+    const int nch = a.nch_total;
+
+    // Chunk c -> global byte address of its B rows (channel group 0, column n0 + shift): the segment / tap
+    // sequencing is resolved ONCE here, so the steady-state DMA issue is four instructions with scalar bases.
+    if (t < nch) {
+        const int ilv = a.interleave > 1 ? a.interleave : 0;
+        const int n_il = ilv * a.seg[0].nch;
+        int c = t, s, local;
+        if (c < n_il) {
+            s = c % ilv;
+            local = c / ilv;
+        } else {
+            c -= n_il;
+            s = ilv;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            if (cbase + mt * 32 >= a.pairC) continue;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int n = n0 + wn * 64 + nt * 32 + l31;
-                if (n < a.L) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float v[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int row = 8 * q + 4 * lhi + j;
-                            const float u0 = acc[mt][nt][4 * q + j] + bias[mt * 32 + row];
-                            const float u1 = acc[mt + 2][nt][4 * q + j] + bias[64 + mt * 32 + row];
-                            v[j] = fast_tanh(u0) * fast_sigmoid(u1);
-                        }
-                        const int cg = (cbase + mt * 32) / 8 + q;
-                        uint2 pk = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
-                        *reinterpret_cast<uint2*>(dst + ((size_t)cg * a.ld + a.pad + n) * 8 + 4 * lhi) = pk;
-                    }
-                }
-            }
+            for (int k = 0; k < BGEMM_MAX_SEG - 1; ++k)     // static indices: a dynamically indexed kernarg goes to scratch
+                if (s == k && k < a.nseg - 1 && c >= a.seg[k].nch) { c -= a.seg[k].nch; s = k + 1; }
+            local = c;
         }
-    } else {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int rbase = mb * BGEMM_BM + wm * 128 + mt * 32;
-            if (rbase >= a.M) continue;
-            const bool second = rbase >= a.split;
-            bf16_t* dst = second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride;
-            const int accum = second ? a.acc1 : a.acc0;
-            const int cg0 = (second ? rbase - a.split : rbase) / 8;
-            uint2 old[2][4];
-            if (accum) {
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        old[nt][q] = *reinterpret_cast<const uint2*>(
-                            dst + ((size_t)(cg0 + q) * a.ld + a.pad + n0 + wn * 64 + nt * 32 + l31) * 8 + 4 * lhi);
-            } else {
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) old[nt][q] = make_uint2(0u, 0u);
-            }
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int n = n0 + wn * 64 + nt * 32 + l31;
-                if (n < a.L) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float v[4];
-                        const float o[4] = {bf16_to_f32((bf16_t)(old[nt][q].x & 0xffff)), bf16_to_f32((bf16_t)(old[nt][q].x >> 16)),
-                                            bf16_to_f32((bf16_t)(old[nt][q].y & 0xffff)), bf16_to_f32((bf16_t)(old[nt][q].y >> 16))};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            v[j] = acc[mt][nt][4 * q + j] + bias[mt * 32 + 8 * q + 4 * lhi + j] + o[j];
-                        uint2 pk = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
-                        *reinterpret_cast<uint2*>(dst + ((size_t)(cg0 + q) * a.ld + a.pad + n) * 8 + 4 * lhi) = pk;
-                    }
-                }
-            }
-        }
+#define CTTS_SEGF(f) (s == 0 ? a.seg[0].f : s == 1 ? a.seg[1].f : s == 2 ? a.seg[2].f : a.seg[3].f)
+        const bf16_t* base = CTTS_SEGF(base);
+        const long long bstride = CTTS_SEGF(bstride);
+        const int shift = CTTS_SEGF(shift), mbr = CTTS_SEGF(mb_rows);
+#undef CTTS_SEGF
+        tab[t] = (u64)(base + (size_t)b * bstride) +
+                 16ull * ((size_t)(mb * (mbr / 8) + 4 * local) * a.ld + a.pad + n0 + shift);
     }
+    // per-thread byte offsets inside a chunk: B unit (g, n) with g = t / 256 (+2), n = t % 256; A unit t (+512)
+    const unsigned boff0 = (unsigned)(((t >> 8) * a.ld + (t & 255)) * 16);
+    const unsigned boff1 = boff0 + (unsigned)(2 * a.ld * 16);
+    const unsigned aoff0 = (unsigned)(t * 16), aoff1 = aoff0 + NT * 16;
+    typedef const __attribute__((address_space(1))) char* gbyte_ptr;
+    const gbyte_ptr abase = (gbyte_ptr)a.A + (size_t)mb * nch * (A_UNITS * 16);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    typedef __attribute__((address_space(3))) u32x4* lds_ptr;
+    // chunk c -> LDS stage buf; ub = wave-uniform address of the chunk's B rows
+#define CTTS_PP_DMA(buf, c, ub)                                                                 \
+    do {                                                                                        \
+        lds_ptr la_ = (lds_ptr)(lds + (buf) * STAGE_UNITS + wave * 64);                         \
+        const gbyte_ptr ac_ = abase + (size_t)(c) * (A_UNITS * 16);                             \
+        __builtin_amdgcn_global_load_lds((gunit_ptr)(ac_ + aoff0), la_, 16, 0, 0);              \
+        __builtin_amdgcn_global_load_lds((gunit_ptr)(ac_ + aoff1), la_ + NT, 16, 0, 0);         \
+        const gbyte_ptr bc_ = (gbyte_ptr)(ub);                                                  \
+        __builtin_amdgcn_global_load_lds((gunit_ptr)(bc_ + boff0), la_ + A_UNITS, 16, 0, 0);    \
+        __builtin_amdgcn_global_load_lds((gunit_ptr)(bc_ + boff1), la_ + A_UNITS + NT, 16, 0, 0); \
+    } while (0)
+#define CTTS_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define CTTS_UNIFORM64(v) \
+    (((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)((v) >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(v)))
+
+    __syncthreads();                                        // table visible
+    // prologue: chunks 0 .. NS-2 in flight, chunk 0 landed.  Every wait below is "all but the newest N DMAs":
+    // 4 DMAs per thread per chunk, in order.
+    u64 ub;
+#pragma unroll
+    for (int c = 0; c < NS - 1; ++c)
+        if (c < nch) { ub = CTTS_UNIFORM64(tab[c]); CTTS_PP_DMA(c, c, ub); }
+    if (nch >= NS - 1) CTTS_WAIT_VM(4 * (NS - 2));
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ub = CTTS_UNIFORM64(tab[NS - 1]);                       // (entries >= nch are never used)
+    __builtin_amdgcn_s_barrier();                           // chunk 0 is in LDS
+    if (wm) {
+        __builtin_amdgcn_s_setprio(1);                      // the later-dispatched half loses every arbitration otherwise
+        __builtin_amdgcn_s_barrier();                       // lagging half: idle through phase 0
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    int cur = 0;
+    for (int ch = 0; ch < nch; ++ch) {
+        // ---- LOAD(ch): fragments of this wave's 128 x 64 tile -> registers; DMA for chunk ch+2
+        const u32x4* As = lds + cur * STAGE_UNITS + wm * 128 + l31;
+        const u32x4* Bs = lds + cur * STAGE_UNITS + A_UNITS + wn * 64 + l31;
+        u32x4 av[2][4], bv[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int grp = 2 * ks + lhi;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) av[ks][mt] = As[grp * BGEMM_BM + mt * 32];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) bv[ks][nt] = Bs[grp * BN + nt * 32];
+        }
+        const u64 tnext = tab[ch + NS < BGEMM_PP_MAX_CHUNKS ? ch + NS : 0];
+        const bool more = ch + NS - 1 < nch;
+        if (more) {
+            const int nb = cur >= 1 ? cur - 1 : NS - 1;     // (cur + NS - 1) % NS: the buffer of chunk ch-1
+            CTTS_PP_DMA(nb, ch + NS - 1, ub);
+            CTTS_WAIT_VM(4 * (NS - 2));                     // own DMAs of chunk ch+1 landed
+        } else if (NS > 3 && nch - ch - 2 == 1) {
+            CTTS_WAIT_VM(4);                                // tail: exactly one chunk was issued after ch+1
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments landed
+        ub = CTTS_UNIFORM64(tnext);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- COMPUTE(ch): registers only
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        *reinterpret_cast<const bf16x8*>(&av[ks][mt]), *reinterpret_cast<const bf16x8*>(&bv[ks][nt]),
+                        acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(wm && ch == nch - 1)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        cur = cur == NS - 1 ? 0 : cur + 1;
+    }
+#undef CTTS_PP_DMA
+#undef CTTS_UNIFORM64
+#undef CTTS_WAIT_VM
+    if (wm) __builtin_amdgcn_s_setprio(0);
+    bf16_epilogue<EPI>(a, acc, lds, t, mb, wm, wn, b, n0, l31, lhi);
 }
 
 // dst packed [MB][nch][4][256][8]; thread = one 16-byte unit (mb, chunk, g, r)
@@ -329,8 +499,11 @@ int launch_gemm_bf16(int epi, const BGemmArgs& a, hipStream_t stream) {
     }
     static const bool use_glds = getenv("CTTS_BF16_NO_GLDS") == nullptr;
     static const bool no_wide = getenv("CTTS_BF16_NO_WIDE") != nullptr;
+    static const bool no_pp = getenv("CTTS_BF16_NO_PP") != nullptr;
+    static const int pp_stages = getenv("CTTS_BF16_PP_STAGES") ? atoi(getenv("CTTS_BF16_PP_STAGES")) : 3;
     // wide (256 x 256, 512 threads) tiles when the problem has enough of them to fill the chip
     const int ntiles_w = (a.L + 255) / 256;
+    const bool pp = !no_pp && a.nch_total + 3 <= BGEMM_PP_MAX_CHUNKS;
     const bool wide = use_glds && !no_wide && (long long)a.MB * ntiles_w * a.batch >= 512 && ntiles_w * 256 + 2 * a.pad <= a.ld;
     BGemmArgs b = a;
     if (wide) b.ntiles = ntiles_w;
@@ -344,11 +517,15 @@ int launch_gemm_bf16(int epi, const BGemmArgs& a, hipStream_t stream) {
     CTTS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "gemm_bf16: grid %lld", blocks);
     const dim3 grid((unsigned)blocks);
     if (epi == BGEMM_EPI_GATE) {
-        if (wide) hipLaunchKernelGGL((conv_gemm_bf16_kernel<BGEMM_EPI_GATE, true, 4>), grid, dim3(512), 0, stream, b);
+        if (wide && pp && pp_stages == 4) hipLaunchKernelGGL((conv_gemm_bf16_pp_kernel<BGEMM_EPI_GATE, 4>), grid, dim3(512), 0, stream, b);
+        else if (wide && pp) hipLaunchKernelGGL((conv_gemm_bf16_pp_kernel<BGEMM_EPI_GATE, 3>), grid, dim3(512), 0, stream, b);
+        else if (wide) hipLaunchKernelGGL((conv_gemm_bf16_kernel<BGEMM_EPI_GATE, true, 4>), grid, dim3(512), 0, stream, b);
         else if (use_glds) hipLaunchKernelGGL((conv_gemm_bf16_kernel<BGEMM_EPI_GATE, true, 2>), grid, dim3(256), 0, stream, b);
         else hipLaunchKernelGGL((conv_gemm_bf16_kernel<BGEMM_EPI_GATE, false, 2>), grid, dim3(256), 0, stream, b);
     } else {
-        if (wide) hipLaunchKernelGGL((conv_gemm_bf16_kernel<BGEMM_EPI_SPLIT, true, 4>), grid, dim3(512), 0, stream, b);
+        if (wide && pp && pp_stages == 4) hipLaunchKernelGGL((conv_gemm_bf16_pp_kernel<BGEMM_EPI_SPLIT, 4>), grid, dim3(512), 0, stream, b);
+        else if (wide && pp) hipLaunchKernelGGL((conv_gemm_bf16_pp_kernel<BGEMM_EPI_SPLIT, 3>), grid, dim3(512), 0, stream, b);
+        else if (wide) hipLaunchKernelGGL((conv_gemm_bf16_kernel<BGEMM_EPI_SPLIT, true, 4>), grid, dim3(512), 0, stream, b);
         else if (use_glds) hipLaunchKernelGGL((conv_gemm_bf16_kernel<BGEMM_EPI_SPLIT, true, 2>), grid, dim3(256), 0, stream, b);
         else hipLaunchKernelGGL((conv_gemm_bf16_kernel<BGEMM_EPI_SPLIT, false, 2>), grid, dim3(256), 0, stream, b);
     }

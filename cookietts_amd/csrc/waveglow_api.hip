@@ -299,8 +299,7 @@ __global__ __launch_bounds__(256) void cvt_f32_to_k8_kernel(const float* __restr
     unsigned int pk[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        pk[j] = (unsigned int)f32_to_bf16_rne(s[(size_t)(2 * j) * ld]) |
-                ((unsigned int)f32_to_bf16_rne(s[(size_t)(2 * j + 1) * ld]) << 16);
+        pk[j] = pack_bf16x2(s[(size_t)(2 * j) * ld], s[(size_t)(2 * j + 1) * ld]);
     *reinterpret_cast<uint4*>(dst + (((size_t)b * (rows / 8) + grp) * ld + n) * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
 }
 
@@ -327,7 +326,7 @@ __global__ __launch_bounds__(256) void wn_start_bf16_kernel(const float* __restr
             for (int j = 0; j < H; ++j) acc = fmaf(Ws[c * H + j], a[j], acc);
             v[e] = acc;
         }
-        pk[q] = (unsigned int)f32_to_bf16_rne(v[0]) | ((unsigned int)f32_to_bf16_rne(v[1]) << 16);
+        pk[q] = pack_bf16x2(v[0], v[1]);
     }
     *reinterpret_cast<uint4*>(x + (((size_t)b * (C / 8) + grp) * ld + pad + n) * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
 }
