@@ -37,9 +37,25 @@ __device__ __forceinline__ float fast_gate(float u0, float u1) {
     return (e - 1.0f) * __builtin_amdgcn_rcpf((e + 1.0f) * (1.0f + q));
 }
 
+// Half-wave exchange (v_permlane32_swap): lanes 32..63 of x swap with lanes 0..31 of y.
+__device__ __forceinline__ void swap_halves(unsigned int& x, unsigned int& y) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    x = r[0];
+    y = r[1];
+}
+__device__ __forceinline__ void swap_halves(float& x, float& y) {
+    unsigned int a = __builtin_bit_cast(unsigned int, x), b = __builtin_bit_cast(unsigned int, y);
+    swap_halves(a, b);
+    x = __builtin_bit_cast(float, a);
+    y = __builtin_bit_cast(float, b);
+}
+
 // Epilogue shared by the block shapes.  32x32 C/D layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5):
 // for a fixed register group q = r>>2 the lane holds 4 consecutive channels (8q + 4*lhi + 0..3) of one column,
-// i.e. half of a 16-byte K8 unit; lanes l and l+32 complete the unit and lanes 0..31 are consecutive columns.
+// i.e. half of a 16-byte K8 unit, lanes l and l+32 complete the unit.  The natural 8-byte accesses are
+// issue-bound (16 per lane per tile), so groups are handled in pairs (q, q+1) with one half-wave exchange per
+// dword: afterwards lane l holds all 8 channels of unit q and lane l+32 all 8 of unit q+1 for column l, and every
+// global access is one 16-byte unit per lane (consecutive lanes -> consecutive units).
 template <int EPI>
 __device__ __forceinline__ void bf16_epilogue(const BGemmArgs& a, f32x16 (&acc)[4][2], u32x4* lds, int t, int mb, int wm,
                                               int wn, int b, int n0, int l31, int lhi) {
@@ -56,9 +72,12 @@ __device__ __forceinline__ void bf16_epilogue(const BGemmArgs& a, f32x16 (&acc)[
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const int n = n0 + wn * 64 + nt * 32 + l31;
-                if (n < a.L) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                for (int qp = 0; qp < 2; ++qp) {
+                    unsigned int pk[2][2];                   // [group of the pair][dword]
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int q = 2 * qp + h;
                         float v[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -67,10 +86,15 @@ __device__ __forceinline__ void bf16_epilogue(const BGemmArgs& a, f32x16 (&acc)[
                             const float u1 = acc[mt + 2][nt][4 * q + j] + bias[64 + mt * 32 + row];
                             v[j] = fast_gate(u0, u1);
                         }
-                        const int cg = (cbase + mt * 32) / 8 + q;
-                        uint2 pk = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
-                        *reinterpret_cast<uint2*>(dst + ((size_t)cg * a.ld + a.pad + n) * 8 + 4 * lhi) = pk;
+                        pk[h][0] = pack2(v[0], v[1]);
+                        pk[h][1] = pack2(v[2], v[3]);
                     }
+                    swap_halves(pk[0][0], pk[1][0]);
+                    swap_halves(pk[0][1], pk[1][1]);
+                    const int cg = (cbase + mt * 32) / 8 + 2 * qp + lhi;
+                    if (n < a.L)
+                        *reinterpret_cast<u32x4*>(dst + ((size_t)cg * a.ld + a.pad + n) * 8) =
+                            u32x4{pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
                 }
             }
         }
@@ -83,35 +107,43 @@ __device__ __forceinline__ void bf16_epilogue(const BGemmArgs& a, f32x16 (&acc)[
             bf16_t* dst = second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride;
             const int accum = second ? a.acc1 : a.acc0;
             const int cg0 = (second ? rbase - a.split : rbase) / 8;
-            uint2 old[2][4];
-            if (accum) {
+            // read-modify-write: all four 16-byte loads of the row tile are issued before the first store
+            u32x4 old[2][2];
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        old[nt][q] = *reinterpret_cast<const uint2*>(
-                            dst + ((size_t)(cg0 + q) * a.ld + a.pad + n0 + wn * 64 + nt * 32 + l31) * 8 + 4 * lhi);
-            } else {
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) old[nt][q] = make_uint2(0u, 0u);
-            }
+                for (int qp = 0; qp < 2; ++qp) {
+                    if (accum)   // uniform; columns >= L of a padded row are readable
+                        old[nt][qp] = *reinterpret_cast<const u32x4*>(
+                            dst + ((size_t)(cg0 + 2 * qp + lhi) * a.ld + a.pad + n0 + wn * 64 + nt * 32 + l31) * 8);
+                    else
+                        old[nt][qp] = u32x4{0u, 0u, 0u, 0u};
+                }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const int n = n0 + wn * 64 + nt * 32 + l31;
-                if (n < a.L) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float v[4];
-                        const float o[4] = {bf16_to_f32((bf16_t)(old[nt][q].x & 0xffff)), bf16_to_f32((bf16_t)(old[nt][q].x >> 16)),
-                                            bf16_to_f32((bf16_t)(old[nt][q].y & 0xffff)), bf16_to_f32((bf16_t)(old[nt][q].y >> 16))};
+                for (int qp = 0; qp < 2; ++qp) {
+                    float v[2][4];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            v[j] = acc[mt][nt][4 * q + j] + bias[mt * 32 + 8 * q + 4 * lhi + j] + o[j];
-                        uint2 pk = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
-                        *reinterpret_cast<uint2*>(dst + ((size_t)(cg0 + q) * a.ld + a.pad + n) * 8 + 4 * lhi) = pk;
+                            v[h][j] = acc[mt][nt][4 * (2 * qp + h) + j] + bias[mt * 32 + 8 * (2 * qp + h) + 4 * lhi + j];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) swap_halves(v[0][j], v[1][j]);
+                    // v[0] = channels 0..3, v[1] = channels 4..7 of this lane's unit
+                    const u32x4 o = old[nt][qp];
+                    unsigned int pk[4];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const float lo = v[d >> 1][2 * (d & 1)] + bf16_to_f32((bf16_t)(o[d] & 0xffff));
+                        const float hi = v[d >> 1][2 * (d & 1) + 1] + bf16_to_f32((bf16_t)(o[d] >> 16));
+                        pk[d] = pack2(lo, hi);
                     }
+                    if (n < a.L)
+                        *reinterpret_cast<u32x4*>(dst + ((size_t)(cg0 + 2 * qp + lhi) * a.ld + a.pad + n) * 8) =
+                            u32x4{pk[0], pk[1], pk[2], pk[3]};
                 }
             }
         }
@@ -290,14 +322,16 @@ __global__ __launch_bounds__(128 * NW, 2) void conv_gemm_bf16_kernel(const BGemm
     bf16_epilogue<EPI>(a, acc, lds, t, mb, wm, wn, b, n0, l31, lhi);
 }
 
-// Ping-pong form of the 256 x 256 block (512 threads = 8 waves, one workgroup per CU, two waves per SIMD).
-// The waves of rows 0..127 (waves 0-3, one per SIMD) and of rows 128..255 (waves 4-7) run the same
-// [LOAD k | COMPUTE k] sequence one phase apart, every phase closed by s_barrier: while one half issues its 16
-// MFMAs (512 matrix-pipe cycles) out of registers, its SIMD partner reads the 12 fragments of its next chunk from
-// LDS and issues the DMA for chunk k+2 - so LDS latency, DMA issue and barrier skew sit beside MFMAs instead of
-// in front of them (the barrier-per-chunk form left the matrix pipe idle for all of that: 40 % of peak).
-// LDS: 3 stages x 32 KiB.  Buffer of chunk k-1 is rewritten (chunk k+2) only after both halves have read it; a
-// chunk is read only after both halves have waited for their own DMAs of it (counted vmcnt) and met at a barrier.
+// Skewed ("ping-pong") form of the 256 x 256 block (512 threads = 8 waves, one workgroup per CU, two waves per
+// SIMD).  ONE barrier per K chunk; inside a barrier interval the waves of rows 0..127 (waves 0-3, one per SIMD) run
+// [LOAD k | COMPUTE k] while the waves of rows 128..255 (waves 4-7) run [COMPUTE k-1 | LOAD k]: each SIMD always
+// has one wave issuing its 16 MFMAs (512 matrix-pipe cycles) out of registers while its partner reads its 12
+// fragments from LDS and issues its share of the DMA for chunk k+2.  Measured with s_memtime stamps: LOAD ~570 and
+// COMPUTE ~520 cycles, a barrier release ~100; the barrier-per-phase form spent 1640 cycles per chunk, the
+// barrier-per-chunk form with both halves in phase 2400.
+// LDS: NS stages x 32 KiB (NS - 1 chunks of DMA in flight).  Both halves read chunk k inside interval k; the DMA
+// issued in interval k (chunk k+NS-1) rewrites the buffer of chunk k-1, read by both before the closing barrier of
+// interval k-1; a thread passes that barrier only after its own DMAs of chunk k have landed (counted vmcnt).
 template <int EPI, int NS>
 __global__ __launch_bounds__(512, 2) void conv_gemm_bf16_pp_kernel(const BGemmArgs a) {
     constexpr int NT = 512, BN = 256;
@@ -389,57 +423,84 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_bf16_pp_kernel(const BGemmAr
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ub = CTTS_UNIFORM64(tab[NS - 1]);                       // (entries >= nch are never used)
     __builtin_amdgcn_s_barrier();                           // chunk 0 is in LDS
-    if (wm) {
-        __builtin_amdgcn_s_setprio(1);                      // the later-dispatched half loses every arbitration otherwise
-        __builtin_amdgcn_s_barrier();                       // lagging half: idle through phase 0
-    }
+    if (wm) __builtin_amdgcn_s_setprio(1);                  // the later-dispatched half loses every arbitration otherwise
     __builtin_amdgcn_sched_barrier(0);
 
+    u32x4 av[2][4], bv[2][2];
+    // fragments of this wave's 128 x 64 tile of chunk ch (stage cur) -> registers
+#define CTTS_LOAD_FRAGS()                                                                       \
+    do {                                                                                        \
+        const u32x4* As = lds + cur * STAGE_UNITS + wm * 128 + l31;                             \
+        const u32x4* Bs = lds + cur * STAGE_UNITS + A_UNITS + wn * 64 + l31;                    \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                      \
+            const int grp = 2 * ks + lhi;                                                       \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) av[ks][mt] = As[grp * BGEMM_BM + mt * 32]; \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) bv[ks][nt] = Bs[grp * BN + nt * 32];      \
+        }                                                                                       \
+    } while (0)
+#define CTTS_MFMA16()                                                                           \
+    do {                                                                                        \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                    \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                \
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                      \
+                        *reinterpret_cast<const bf16x8*>(&av[ks][mt]),                          \
+                        *reinterpret_cast<const bf16x8*>(&bv[ks][nt]), acc[mt][nt], 0, 0, 0);   \
+    } while (0)
+    // DMA of chunk ch+NS-1 into the buffer of chunk ch-1, then: own DMAs of chunk ch+1 landed
+#define CTTS_DMA_AND_WAIT()                                                                     \
+    do {                                                                                        \
+        if (ch + NS - 1 < nch) {                                                                \
+            const int nb = cur >= 1 ? cur - 1 : NS - 1;     /* (cur + NS - 1) % NS */           \
+            CTTS_PP_DMA(nb, ch + NS - 1, ub);                                                   \
+        }                                                                                       \
+    } while (0)
+#define CTTS_WAIT_NEXT_CHUNK()                                                                  \
+    do {                                                                                        \
+        if (ch + NS - 1 < nch) CTTS_WAIT_VM(4 * (NS - 2));                                      \
+        else if (NS > 3 && nch - ch - 2 == 1) CTTS_WAIT_VM(4);   /* tail: one chunk was issued after ch+1 */ \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
+    } while (0)
+
     int cur = 0;
-    for (int ch = 0; ch < nch; ++ch) {
-        // ---- LOAD(ch): fragments of this wave's 128 x 64 tile -> registers; DMA for chunk ch+2
-        const u32x4* As = lds + cur * STAGE_UNITS + wm * 128 + l31;
-        const u32x4* Bs = lds + cur * STAGE_UNITS + A_UNITS + wn * 64 + l31;
-        u32x4 av[2][4], bv[2][2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int grp = 2 * ks + lhi;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) av[ks][mt] = As[grp * BGEMM_BM + mt * 32];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) bv[ks][nt] = Bs[grp * BN + nt * 32];
+    if (!wm) {
+        // leading half: [LOAD ch | COMPUTE ch] per interval
+        for (int ch = 0; ch < nch; ++ch) {
+            CTTS_LOAD_FRAGS();
+            const u64 tnext = tab[ch + NS < BGEMM_PP_MAX_CHUNKS ? ch + NS : 0];
+            CTTS_DMA_AND_WAIT();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            CTTS_MFMA16();
+            ub = CTTS_UNIFORM64(tnext);
+            __builtin_amdgcn_sched_barrier(0);
+            CTTS_WAIT_NEXT_CHUNK();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            cur = cur == NS - 1 ? 0 : cur + 1;
         }
-        const u64 tnext = tab[ch + NS < BGEMM_PP_MAX_CHUNKS ? ch + NS : 0];
-        const bool more = ch + NS - 1 < nch;
-        if (more) {
-            const int nb = cur >= 1 ? cur - 1 : NS - 1;     // (cur + NS - 1) % NS: the buffer of chunk ch-1
-            CTTS_PP_DMA(nb, ch + NS - 1, ub);
-            CTTS_WAIT_VM(4 * (NS - 2));                     // own DMAs of chunk ch+1 landed
-        } else if (NS > 3 && nch - ch - 2 == 1) {
-            CTTS_WAIT_VM(4);                                // tail: exactly one chunk was issued after ch+1
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        // lagging half: [COMPUTE ch-1 | LOAD ch] per interval; its last COMPUTE runs beside the leading half's epilogue
+        for (int ch = 0; ch < nch; ++ch) {
+            if (ch > 0) CTTS_MFMA16();
+            __builtin_amdgcn_sched_barrier(0);
+            CTTS_LOAD_FRAGS();
+            const u64 tnext = tab[ch + NS < BGEMM_PP_MAX_CHUNKS ? ch + NS : 0];
+            CTTS_DMA_AND_WAIT();
+            CTTS_WAIT_NEXT_CHUNK();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this half's reads of the stage are complete
+            ub = CTTS_UNIFORM64(tnext);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            cur = cur == NS - 1 ? 0 : cur + 1;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments landed
-        ub = CTTS_UNIFORM64(tnext);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- COMPUTE(ch): registers only
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        *reinterpret_cast<const bf16x8*>(&av[ks][mt]), *reinterpret_cast<const bf16x8*>(&bv[ks][nt]),
-                        acc[mt][nt], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(wm && ch == nch - 1)) __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        cur = cur == NS - 1 ? 0 : cur + 1;
+        CTTS_MFMA16();
     }
+#undef CTTS_LOAD_FRAGS
+#undef CTTS_MFMA16
+#undef CTTS_DMA_AND_WAIT
+#undef CTTS_WAIT_NEXT_CHUNK
 #undef CTTS_PP_DMA
 #undef CTTS_UNIFORM64
 #undef CTTS_WAIT_VM
@@ -497,10 +558,11 @@ int launch_gemm_bf16(int epi, const BGemmArgs& a, hipStream_t stream) {
         for (int s = 1; s < a.interleave; ++s)
             CTTS_CHECK_ARG(a.seg[s].nch == a.seg[0].nch, "gemm_bf16: interleaved segments must have equal length");
     }
-    static const bool use_glds = getenv("CTTS_BF16_NO_GLDS") == nullptr;
-    static const bool no_wide = getenv("CTTS_BF16_NO_WIDE") != nullptr;
-    static const bool no_pp = getenv("CTTS_BF16_NO_PP") != nullptr;
-    static const int pp_stages = getenv("CTTS_BF16_PP_STAGES") ? atoi(getenv("CTTS_BF16_PP_STAGES")) : 3;
+    // block-shape overrides for A/B tests (read per launch so a test can flip them in-process)
+    const bool use_glds = getenv("CTTS_BF16_NO_GLDS") == nullptr;
+    const bool no_wide = getenv("CTTS_BF16_NO_WIDE") != nullptr;
+    const bool no_pp = getenv("CTTS_BF16_NO_PP") != nullptr;
+    const int pp_stages = getenv("CTTS_BF16_PP_STAGES") ? atoi(getenv("CTTS_BF16_PP_STAGES")) : 3;
     // wide (256 x 256, 512 threads) tiles when the problem has enough of them to fill the chip
     const int ntiles_w = (a.L + 255) / 256;
     const bool pp = !no_pp && a.nch_total + 3 <= BGEMM_PP_MAX_CHUNKS;

@@ -154,6 +154,22 @@ def test_waveglow_bf16_ragged_and_batch_independent(hip_lib_path):
         assert torch.equal(m.infer_from_noise(mel[b:b + 1], z[b:b + 1])[0], full[b])
 
 
+@pytest.mark.parametrize("knob", ["CTTS_BF16_NO_WIDE", "CTTS_BF16_NO_PP", "CTTS_BF16_NO_GLDS"])
+def test_waveglow_bf16_block_shapes_agree(hip_lib_path, monkeypatch, knob):
+    """Full model at a size that selects the 256x256 skewed 8-wave kernel (>= 512 workgroups, ragged last tile):
+    every block shape / staging variant accumulates K in the same order, so the waveforms must be identical."""
+    m, cfg, sd = _model("full", 5)
+    m.set_compute_dtype(torch.bfloat16)
+    B, F = 8, 131
+    mel = torch.from_numpy(synthetic.synthetic_mel(B, F, seed=6)).cuda()
+    z = torch.from_numpy(synthetic.synthetic_noise(B, 8, F * 32, seed=6) * np.float32(0.6)).cuda()
+    default = m.infer_from_noise(mel, z)
+    assert torch.isfinite(default).all()
+    monkeypatch.setenv(knob, "1")
+    other = m.infer_from_noise(mel, z)
+    assert torch.equal(default, other)
+
+
 def test_5_infer_vocoder_slot(hip_lib_path, tmp_path):
     """The two call sites of _5_infer/t2s_server/text2speech.py (:175-179, :658-665) against a reference-format
     checkpoint (train.py:128-145)."""
