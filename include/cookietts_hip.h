@@ -371,6 +371,21 @@ int ctts_stft_inverse_f32(const ctts_stft_config* cfg, const void* packed, const
                           const float* bias_spec, float strength, float* out, int32_t batch, int32_t frames,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- attention-alignment scoring (T2S retry loop) -------------------- */
+
+/* utils/model/utils.py:59-120 `alignment_metric(alignments, input_lengths, output_lengths, enc_min_thresh)`:
+ * alignments [batch][dec][enc] fp32 (device); lengths are device fp32 [batch] or NULL (reference defaults:
+ * enc-1 / dec-1).  out: device double [batch][6] = diagonalitys, avg_prob, encoder_max_focus,
+ * encoder_min_focus, encoder_avg_focus, p_missing_enc.  The input is not modified (the reference zeroes the
+ * padded decoder steps of its argument in place, :81). */
+size_t ctts_alignment_workspace_bytes(int32_t batch, int32_t dec, int32_t enc);
+int ctts_alignment_metric_f32(const float* alignments, const float* input_lengths, const float* output_lengths,
+                              int32_t batch, int32_t dec, int32_t enc, float enc_min_thresh, double* out,
+                              void* workspace, size_t workspace_bytes, void* stream);
+/* utils/model/utils.py:47-56 (= text2speech.py:152-161) `get_first_over_thresh(x, threshold)`:
+ * x [batch][T] fp32 -> out int32 [batch], first step with x >= threshold, else T-1. */
+int ctts_first_over_thresh_f32(const float* x, int32_t batch, int32_t T, float threshold, int32_t* out, void* stream);
+
 /* ---- in-library kernel timing (bench.py roofline leg) --------------------------------- */
 /* When enabled, ctts_waveglow_infer_f32 brackets every launch of the dominant kernel
  * (WN in-layer GEMM: dilated conv + cond + gate) with hipEvents on `stream`. */

@@ -326,8 +326,50 @@ def make_tacotron():
           f"-> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def make_alignment():
+    """utils/model/utils.py:47-120 run here on seeded attention maps (data only)."""
+    from CookieTTS.utils.model.utils import alignment_metric, get_first_over_thresh
+    rng = np.random.default_rng(77)
+    out = {}
+    for tag, (B, dec, enc) in {"small": (3, 57, 23), "wide": (2, 130, 300)}.items():
+        # peaked, roughly monotonic maps with noise: what a decoder run produces
+        pos = np.linspace(0, enc - 1, dec)[None, :, None] * rng.uniform(0.6, 1.1, (B, 1, 1))
+        e = np.arange(enc)[None, None, :]
+        logits = -0.5 * ((e - pos) / rng.uniform(0.5, 2.0, (B, 1, 1))) ** 2 + rng.normal(0, 0.3, (B, dec, enc))
+        al = np.exp(logits - logits.max(-1, keepdims=True))
+        al = (al / al.sum(-1, keepdims=True)).astype(np.float32)
+        in_len = rng.integers(enc // 2, enc + 1, B).astype(np.int32)
+        out_len = rng.integers(dec // 2, dec + 1, B).astype(np.int32)
+        in_len[0], out_len[0] = enc, dec
+        out[f"{tag}_alignments"], out[f"{tag}_in_len"], out[f"{tag}_out_len"] = al, in_len, out_len
+        for lens, key in ((True, "lens"), (False, "nolens")):
+            r = alignment_metric(torch.from_numpy(al.copy()),
+                                 input_lengths=torch.from_numpy(in_len) if lens else None,
+                                 output_lengths=torch.from_numpy(out_len) if lens else None)
+            for k, v in r.items():
+                out[f"{tag}_{key}_{k}"] = v.numpy()
+    gate = rng.uniform(0, 0.45, (5, 41)).astype(np.float32)
+    gate[0, 17] = 0.9; gate[0, 30] = 0.95          # first crossing wins
+    gate[1, 40] = 0.1                               # never crosses -> T-1
+    gate[2, 0] = 0.7                                # immediately
+    gate[3, 9] = 0.5                                # exactly the threshold counts (arg-max of the clamped row)
+    out["gate"], out["gate_threshold"] = gate, np.float32(0.5)
+    gate[4] = np.minimum(gate[4], 0.49)
+    # shim: utils.py:53 parses torch.__version__ with int(); the "+rocm" local tag of this build breaks that parse
+    real_version, torch.__version__ = torch.__version__, torch.__version__.split("+")[0]
+    try:
+        out["gate_first"] = get_first_over_thresh(torch.from_numpy(gate.copy()), 0.5).numpy()
+    finally:
+        torch.__version__ = real_version
+    path = os.path.join(HERE, "alignment.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, {k: v.shape for k, v in out.items() if "alignments" in k or k.startswith("gate")})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["waveglow", "stft", "waveflow", "tacotron"]
+    which = sys.argv[1:] or ["waveglow", "stft", "waveflow", "tacotron", "alignment"]
+    if "alignment" in which:
+        make_alignment()
     if "tacotron" in which:
         make_tacotron()
     if "waveflow" in which:
