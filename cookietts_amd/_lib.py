@@ -48,13 +48,14 @@ class WaveGlowFlowWeights(C.Structure):
 class WaveFlowConfig(C.Structure):
     """``ctts_waveflow_config``."""
     _fields_ = [(n, C.c_int32) for n in ("n_mel_channels", "n_flows", "n_group", "n_layers", "n_channels",
-                                         "kernel_size_w", "kernel_size_h", "dilation_h")]
+                                         "kernel_size_w", "kernel_size_h", "dilation_h", "seperable_conv",
+                                         "cond_precomputed")]
 
 
 class WaveFlowFlowWeights(C.Structure):
     _fields_ = [("start_w", _FP), ("start_b", _FP), ("cond_w", _FP), ("cond_b", _FP),
                 ("in_w", C.POINTER(_FP)), ("in_b", C.POINTER(_FP)), ("rs_w", C.POINTER(_FP)), ("rs_b", C.POINTER(_FP)),
-                ("end_w", _FP), ("end_b", _FP)]
+                ("end_w", _FP), ("end_b", _FP), ("dw_w", C.POINTER(_FP)), ("dw_b", C.POINTER(_FP))]
 
 
 class TacoDecoderConfig(C.Structure):
@@ -148,6 +149,13 @@ SIGNATURES = {
                                           C.c_size_t, _FP]),
     "ctts_stft_inverse_f32": (C.c_int, [C.POINTER(StftConfig), _FP, _FP, _FP, _FP, C.c_float, _FP, C.c_int32,
                                         C.c_int32, _FP, C.c_size_t, _FP]),
+    "ctts_waveflow_inverse_cond_f32": (C.c_int, [C.POINTER(WaveFlowConfig), _FP, _FP, _FP, C.c_int32, C.c_int32, _FP,
+                                                 C.c_int32, C.c_int32, C.c_int32, _FP, C.c_size_t, _FP]),
+    "ctts_embed_rows_f32": (C.c_int, [_FP, _FP, _FP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_int32, _FP]),
+    "ctts_scale_add_rows_f32": (C.c_int, [_FP, _FP, _FP, _FP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                          _FP]),
+    "ctts_deemphasis_f32": (C.c_int, [_FP, _FP, C.c_int32, C.c_int32, C.c_double, _FP]),
     "ctts_alignment_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "ctts_alignment_metric_f32": (C.c_int, [_FP, _FP, _FP, C.c_int32, C.c_int32, C.c_int32, C.c_float, _FP, _FP,
                                             C.c_size_t, _FP]),

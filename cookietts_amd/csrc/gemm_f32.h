@@ -76,6 +76,9 @@ struct GemmArgs {
     int pairC;            // pair epilogues: number of valid channels (dense rows c and pairC + c)
     int dst_ld, dst_pad;  // row stride / left pad of the destination tensors (usually == ld, pad)
     float clip;           // GEMM_EPI_LOG clamp / GEMM_EPI_LRELU negative slope
+    // GATE / GATE_RS: optional per-element addend before the gate (conditioning computed elsewhere), padded layout
+    // [B][2*pairC][ld] in DENSE row order (row c -> tanh input, row pairC + c -> sigmoid input), same ld / pad as B
+    const float* addend; long long addend_bstride;
     const float* rs_wT;   // GEMM_EPI_GATE_RS: res/skip weight transposed and row-padded: [64][128]
     const float* rs_bias; // [128] (rows >= rs_rows zero)
     int rs_rows;          // 128 (res + skip) or 64 (last layer: skip only)

@@ -286,12 +286,25 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
             for (int nt = 0; nt < 2; ++nt) {
                 const int n = n0 + wn * 64 + nt * 32 + l31;
                 if (n < a.L) {
+                    float add0[16], add1[16];
+                    if (EPI == GEMM_EPI_GATE && a.addend) {       // uniform
+                        const float* ad = a.addend + (size_t)b * a.addend_bstride + a.pad + n;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int c = min(cbase + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi, a.pairC - 1);
+                            add0[r] = ad[(size_t)c * a.ld];
+                            add1[r] = ad[(size_t)(a.pairC + c) * a.ld];
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) add0[r] = add1[r] = 0.0f;
+                    }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
                         const int c = cbase + mt * 32 + row;
-                        const float u0 = acc[mt][nt][r] + bias[mt * 32 + row];
-                        const float u1 = acc[mt + 2][nt][r] + bias[64 + mt * 32 + row];
+                        const float u0 = acc[mt][nt][r] + bias[mt * 32 + row] + add0[r];
+                        const float u1 = acc[mt + 2][nt][r] + bias[64 + mt * 32 + row] + add1[r];
                         float v;
                         if constexpr (EPI == GEMM_EPI_GATE) v = fast_tanh(u0) * fast_sigmoid(u1);
                         else v = sqrtf(u0 * u0 + u1 * u1);
@@ -312,8 +325,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
                     const bool ok = mt * 32 + row < a.pairC;
-                    const float u0 = acc[mt][nt][r] + bias[mt * 32 + row];
-                    const float u1 = acc[mt + 2][nt][r] + bias[64 + mt * 32 + row];
+                    float u0 = acc[mt][nt][r] + bias[mt * 32 + row];
+                    float u1 = acc[mt + 2][nt][r] + bias[64 + mt * 32 + row];
+                    if (a.addend) {                                // uniform; columns >= L of a padded row are readable
+                        const float* ad = a.addend + (size_t)b * a.addend_bstride + a.pad + n0 + wn * 64 + nt * 32 + l31;
+                        const int c = min(mt * 32 + row, a.pairC - 1);
+                        u0 += ad[(size_t)c * a.ld];
+                        u1 += ad[(size_t)(a.pairC + c) * a.ld];
+                    }
                     actv[mt][nt][r] = ok ? fast_tanh(u0) * fast_sigmoid(u1) : 0.0f;
                 }
         __syncthreads();                                   // everyone is done with the bias copy in LDS

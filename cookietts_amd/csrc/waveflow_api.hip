@@ -23,11 +23,17 @@ namespace {
 constexpr size_t ALIGN_F = 64;
 inline size_t align_up(size_t v) { return (v + ALIGN_F - 1) / ALIGN_F * ALIGN_F; }
 constexpr int WF_BM = 128;
+constexpr int WF_MAX_KH = 8;
 
 struct WfPlan {
     ctts_waveflow_config c;
     int C, kmel, nch_in, nch_c;      // nch_c = chunks per (tap) segment
-    struct Flow { size_t start_w, start_b, end_w, end_b; std::vector<size_t> in_A, in_b, rs_A, rs_b, rs_T, rs_Tb; };
+    bool sep, precond;               // separable in-layers; conditioning handed over per flow at frame rate
+    int taps;                        // GEMM taps: kh*kw, or 1 behind the depthwise stage
+    struct Flow {
+        size_t start_w, start_b, end_w, end_b;
+        std::vector<size_t> in_A, in_b, rs_A, rs_b, rs_T, rs_Tb, dw_w, dw_b;
+    };
     std::vector<Flow> fl;
     size_t total;
     int rs_rows(int i) const { return i < c.n_layers - 1 ? 2 * C : C; }
@@ -47,13 +53,17 @@ int make_wf_plan(const ctts_waveflow_config* cfg, WfPlan& p) {
     CTTS_CHECK_ARG(c.kernel_size_w % 2 == 1 && c.kernel_size_w >= 1 && c.kernel_size_h >= 1, "kernel %dx%d",
                    c.kernel_size_h, c.kernel_size_w);
     CTTS_CHECK_ARG(c.dilation_h == 1, "dilation_h=%d (only 1 built)", c.dilation_h);
-    CTTS_CHECK_ARG(c.kernel_size_h * c.kernel_size_w + 1 <= GEMM_MAX_SEG, "kernel %dx%d needs more than %d segments",
+    p.sep = c.seperable_conv != 0 && !(c.kernel_size_h == 1 && c.kernel_size_w == 1);   // glow_ax.py:521
+    p.precond = c.cond_precomputed != 0;
+    p.taps = p.sep ? 1 : c.kernel_size_h * c.kernel_size_w;
+    CTTS_CHECK_ARG(p.taps + 1 <= GEMM_MAX_SEG, "dense kernel %dx%d needs more than %d segments (use seperable_conv)",
                    c.kernel_size_h, c.kernel_size_w, GEMM_MAX_SEG);
-    CTTS_CHECK_ARG(c.n_mel_channels >= 1, "n_mel_channels=%d", c.n_mel_channels);
+    CTTS_CHECK_ARG(c.kernel_size_h <= WF_MAX_KH, "kernel_size_h=%d (<= %d)", c.kernel_size_h, WF_MAX_KH);
+    CTTS_CHECK_ARG(p.precond || c.n_mel_channels >= 1, "n_mel_channels=%d", c.n_mel_channels);
     p.C = c.n_channels;
-    p.kmel = round_up(c.n_mel_channels, GEMM_KC);
+    p.kmel = p.precond ? 0 : round_up(c.n_mel_channels, GEMM_KC);
     p.nch_c = p.C / GEMM_KC;
-    p.nch_in = c.kernel_size_h * c.kernel_size_w * p.nch_c + p.kmel / GEMM_KC;
+    p.nch_in = p.taps * p.nch_c + p.kmel / GEMM_KC;
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o = align_up(o + n); return r; };
     p.fl.resize(c.n_flows);
@@ -68,6 +78,8 @@ int make_wf_plan(const ctts_waveflow_config* cfg, WfPlan& p) {
             f.rs_b.push_back(take((size_t)p.rs_mb(i) * WF_BM));
             f.rs_T.push_back(take(p.fused() ? 64 * 128 : 0));
             f.rs_Tb.push_back(take(p.fused() ? 128 : 0));
+            f.dw_w.push_back(take(p.sep ? (size_t)p.C * c.kernel_size_h * c.kernel_size_w : 0));
+            f.dw_b.push_back(take(p.sep ? p.C : 0));
         }
     }
     p.total = o;
@@ -87,13 +99,13 @@ __global__ void wf_pack_rs_t_kernel(const float* __restrict__ w, const float* __
     }
 }
 
-struct WfGeom { int L, ld, pad, ntiles; };
+struct WfGeom { int L, Lr, ld, pad, ntiles; };   // Lr: row stride of the dense `rows` buffer (16-byte rows)
 
 int make_wf_geom(const WfPlan& p, int samples, WfGeom& g) {
     CTTS_CHECK_ARG(samples >= p.c.n_group && samples % p.c.n_group == 0, "samples=%d not a multiple of n_group=%d",
                    samples, p.c.n_group);
     g.L = samples / p.c.n_group;
-    CTTS_CHECK_ARG(g.L % 4 == 0, "samples/n_group=%d must be a multiple of 4", g.L);
+    g.Lr = round_up(g.L, 4);
     const int maxshift = (p.c.kernel_size_w / 2) << (p.c.n_layers - 1);
     g.pad = round_up(maxshift > 128 ? maxshift : 128, 32);
     const int bn = gemm_bn(WF_BM);
@@ -102,14 +114,17 @@ int make_wf_geom(const WfPlan& p, int samples, WfGeom& g) {
     return CTTS_OK;
 }
 
-struct WfWs { float *rows, *mel_up, *X, *act, *out; size_t total, xslot; };
+struct WfWs { float *rows, *mel_up, *cond_up, *dwout, *X, *act, *out; size_t total, xslot, cond_slot; };
 
 void wf_carve(const WfPlan& p, const WfGeom& g, int batch, float* base, WfWs& w) {
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o = align_up(o + n); return base ? base + r : nullptr; };
     const size_t B = batch;
-    w.rows = take(B * p.c.n_group * g.L);
+    w.rows = take(B * p.c.n_group * g.Lr);
     w.mel_up = take(B * p.kmel * g.ld);
+    w.cond_slot = align_up(B * 2 * p.C * g.ld);              // upsampled conditioning of one layer
+    w.cond_up = take(p.precond ? w.cond_slot * p.c.n_layers : 0);
+    w.dwout = take(p.sep ? B * p.C * g.ld : 0);
     w.xslot = align_up(B * p.C * g.ld);
     w.X = take(w.xslot * p.c.n_layers * p.c.kernel_size_h);
     w.act = take(B * p.C * g.ld);
@@ -119,26 +134,26 @@ void wf_carve(const WfPlan& p, const WfGeom& g, int batch, float* base, WfWs& w)
 
 // rows[b][g][l] = z[b][G*l + g]   (efficient_model_ax.py:310)
 __global__ __launch_bounds__(256) void wf_squeeze_kernel(const float* __restrict__ z, float* __restrict__ rows,
-                                                         int G, int L) {
+                                                         int G, int L, int Lr) {
     const int l = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
-    if (l >= L) return;
+    if (l >= Lr) return;
     const float* zb = z + (size_t)b * G * L + (size_t)l * G;
-    float* rb = rows + (size_t)b * G * L + l;
-    for (int g = 0; g < G; ++g) rb[(size_t)g * L] = zb[g];
+    float* rb = rows + (size_t)b * G * Lr + l;
+    for (int g = 0; g < G; ++g) rb[(size_t)g * Lr] = l < L ? zb[g] : 0.f;   // row tail (l >= L) stays zero
 }
 
 struct RowMap { int phys[64]; };
 
 // audio[b][G*l + g] = rows[b][phys[g]][l]   (ax:346, with the accumulated PermuteHeight map)
 __global__ __launch_bounds__(256) void wf_unsqueeze_kernel(const float* __restrict__ rows, float* __restrict__ audio,
-                                                           int G, int L, RowMap map) {
+                                                           int G, int L, int Lr, RowMap map) {
     const int l = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     if (l >= L) return;
-    const float* rb = rows + (size_t)b * G * L + l;
+    const float* rb = rows + (size_t)b * G * Lr + l;
     float* ab = audio + (size_t)b * G * L + (size_t)l * G;
-    for (int g = 0; g < G; ++g) ab[g] = rb[(size_t)map.phys[g] * L];
+    for (int g = 0; g < G; ++g) ab[g] = rb[(size_t)map.phys[g] * Lr];
 }
 
 // rows: NaN -> 0 in place   (ax:13-16, 333-334)
@@ -177,17 +192,19 @@ __global__ __launch_bounds__(256) void wf_interp_kernel(const float* __restrict_
 // X0[b][c][pad + l] = ws[c] * rows[b][row][l] + bs[c]   (Conv2d(1->C, 1x1), glow_ax.py:558)
 __global__ __launch_bounds__(256) void wf_start_kernel(const float* __restrict__ rows, const float* __restrict__ ws,
                                                        const float* __restrict__ bs, float* __restrict__ x, int C,
-                                                       int G, int row, int L, int ld, int pad) {
+                                                       int G, int row, int L, int Lr, int ld, int pad) {
     const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
     const int b = blockIdx.z;
     if (n >= L) return;
-    const float4 a = *reinterpret_cast<const float4*>(rows + ((size_t)b * G + row) * L + n);
+    const float4 a = *reinterpret_cast<const float4*>(rows + ((size_t)b * G + row) * Lr + n);
     const int c0 = blockIdx.y * 16;
     float* xb = x + (size_t)b * C * ld + pad + n;
+    const bool k1 = n + 1 < L, k2 = n + 2 < L, k3 = n + 3 < L;      // columns >= L are halo: keep them zero
     for (int c = c0; c < c0 + 16 && c < C; ++c) {
         const float w = ws[c], bias = bs[c];
         float4 v;
-        v.x = w * a.x + bias; v.y = w * a.y + bias; v.z = w * a.z + bias; v.w = w * a.w + bias;
+        v.x = w * a.x + bias;
+        v.y = k1 ? w * a.y + bias : 0.f; v.z = k2 ? w * a.z + bias : 0.f; v.w = k3 ? w * a.w + bias : 0.f;
         *reinterpret_cast<float4*>(xb + (size_t)c * ld) = v;
     }
 }
@@ -196,7 +213,7 @@ __global__ __launch_bounds__(256) void wf_start_kernel(const float* __restrict__
 // (glow_ax.py:628, efficient_modules.py:61-62).  4 waves x 256 steps, each wave reduces C/4 channels.
 __global__ __launch_bounds__(256) void wf_tail_kernel(const float* __restrict__ out, float* __restrict__ rows,
                                                       const float* __restrict__ Wend, const float* __restrict__ bend,
-                                                      int C, int G, int row, int L, int ld, int pad) {
+                                                      int C, int G, int row, int L, int Lr, int ld, int pad) {
     __shared__ __attribute__((aligned(16))) float part[3][2][256];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.y;
@@ -225,13 +242,106 @@ __global__ __launch_bounds__(256) void wf_tail_kernel(const float* __restrict__ 
         e1.x += p1.x; e1.y += p1.y; e1.z += p1.z; e1.w += p1.w;
     }
     const float b0 = bend[0], b1 = bend[1];
-    float* rp = rows + ((size_t)b * G + row) * L + n;
+    float* rp = rows + ((size_t)b * G + row) * Lr + n;
     float4 a = *reinterpret_cast<const float4*>(rp);
     a.x = (a.x - (e1.x + b1)) / expf(e0.x + b0);
-    a.y = (a.y - (e1.y + b1)) / expf(e0.y + b0);
-    a.z = (a.z - (e1.z + b1)) / expf(e0.z + b0);
-    a.w = (a.w - (e1.w + b1)) / expf(e0.w + b0);
+    a.y = n + 1 < L ? (a.y - (e1.y + b1)) / expf(e0.y + b0) : 0.f;       // row tail stays zero
+    a.z = n + 2 < L ? (a.z - (e1.z + b1)) / expf(e0.z + b0) : 0.f;
+    a.w = n + 3 < L ? (a.w - (e1.w + b1)) / expf(e0.w + b0) : 0.f;
     *reinterpret_cast<float4*>(rp) = a;
+}
+
+// Upsampled conditioning of every layer of one flow (glow_ax.py:545-554, 564-592): frames [B][2C*n_layers] rows of a
+// padded frame-rate tensor -> up[layer][b][2C][pad + l], linear interpolation with align_corners=True, fp32 like ATen.
+__global__ __launch_bounds__(256) void wf_interp_cond_kernel(const float* __restrict__ frames, float* __restrict__ up,
+                                                             int rows2c, int n_layers, int F, int f_ld, int f_pad,
+                                                             int L, int ld, int pad, size_t slot) {
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    const int ch = blockIdx.y, b = blockIdx.z;                 // ch in [0, 2C*n_layers)
+    if (l >= L) return;
+    const float* src = frames + ((size_t)b * rows2c * n_layers + ch) * f_ld + f_pad;
+    float v;
+    if (F == L) {
+        v = src[l];
+    } else {
+        const float scale = L > 1 ? (float)(F - 1) / (float)(L - 1) : 0.f;
+        const float real = scale * (float)l;
+        const int i0 = (int)real;
+        const int i1 = i0 + 1 < F ? i0 + 1 : F - 1;
+        const float l1 = real - (float)i0;
+        const float l0 = 1.0f - l1;
+        v = l0 * src[i0] + l1 * src[i1];
+    }
+    const int layer = ch / rows2c, r = ch % rows2c;
+    up[(size_t)layer * slot + ((size_t)b * rows2c + r) * ld + pad + l] = v;
+}
+
+struct WfSlots { const float* p[WF_MAX_KH]; };
+
+// Depthwise stage of a separable in-layer (glow_ax.py:525-527: Conv2d(C, C, (kh, kw), groups=C), width dilation dw,
+// causal in height): y[b][c][l] = bias[c] + sum_{a >= a_min} sum_j w[c][a][j] * x_a[b][c][l + (j - kw/2) * dw], where
+// x_a is the ring slot of height tap a (taps a < a_min reach above the first row: zeros, skipped).
+__global__ __launch_bounds__(256) void wf_depthwise_kernel(WfSlots x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int C,
+                                                           int kh, int kw, int dw, int a_min, int L, int ld, int pad) {
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (l >= L) return;
+    const size_t row = ((size_t)b * C + c) * ld + pad + l;
+    const float* wc = w + (size_t)c * kh * kw;
+    float acc = bias[c];
+    for (int a = a_min; a < kh; ++a) {
+        const float* xa = x.p[a] + row;
+        for (int j = 0; j < kw; ++j) acc = fmaf(wc[a * kw + j], xa[(j - kw / 2) * dw], acc);
+    }
+    y[row] = acc;
+}
+
+// x[b][row0 + e][pad + t] = table[ids[b]][e]   (speaker embedding repeated over frames and concatenated, ax:286-291)
+__global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict__ table, const int64_t* __restrict__ ids,
+                                                         float* __restrict__ x, int row0, int E, int C, int T, int ld,
+                                                         int pad) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int e = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    x[((size_t)b * C + row0 + e) * ld + pad + t] = table[(size_t)ids[b] * E + e];
+}
+
+// y = alpha * x + r on the valid columns (rezero + residual of the model-level cond stack, ax:299-307)
+__global__ __launch_bounds__(256) void scale_add_rows_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                             const float* __restrict__ r, float* __restrict__ y, int C,
+                                                             int T, int ld, int pad) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    const size_t i = ((size_t)b * C + c) * ld + pad + t;
+    const float a = alpha ? alpha[0] : 1.0f;
+    y[i] = r ? a * x[i] + r[i] : a * x[i];
+}
+
+// y[n] = x[n] + p * y[n-1], one workgroup per utterance, fp64 state (scipy.signal.lfilter([1],[1,-p]) runs in
+// float64 on the reference's CPU path, ax:351-355).  Thread t owns one contiguous span: pass 1 runs the recurrence
+// from a zero state to get the span's own contribution, thread 0 chains the 256 span ends
+// (carry_out = end + p^len * carry_in), pass 2 re-runs each span from its true incoming state.
+__global__ __launch_bounds__(256) void deemphasis_kernel(const float* __restrict__ x, float* __restrict__ y, int T,
+                                                         double p) {
+    __shared__ double ends[256], gains[256], carry[256];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int span = (T + 255) / 256;
+    const int n0 = min(t * span, T), n1 = min(n0 + span, T);
+    const float* xb = x + (size_t)b * T;
+    float* yb = y + (size_t)b * T;
+    double s = 0.0, gpow = 1.0;
+    for (int n = n0; n < n1; ++n) { s = (double)xb[n] + p * s; gpow *= p; }
+    ends[t] = s; gains[t] = gpow;
+    __syncthreads();
+    if (t == 0) {
+        double c = 0.0;
+        for (int i = 0; i < 256; ++i) { carry[i] = c; c = ends[i] + gains[i] * c; }
+    }
+    __syncthreads();
+    s = carry[t];
+    for (int n = n0; n < n1; ++n) { s = (double)xb[n] + p * s; yb[n] = (float)s; }
 }
 
 void wf_permutation(int k, int G, int* perm) {
@@ -248,70 +358,17 @@ void wf_permutation(int k, int G, int* perm) {
 
 using namespace ctts;
 
-extern "C" {
+namespace {
 
-size_t ctts_waveflow_packed_bytes(const ctts_waveflow_config* cfg) {
-    WfPlan p;
-    if (make_wf_plan(cfg, p)) return 0;
-    return p.total * sizeof(float);
-}
-
-int ctts_waveflow_pack_flow(const ctts_waveflow_config* cfg, int32_t k, const ctts_waveflow_flow_weights* w,
-                            void* packed, void* stream) {
-    WfPlan p;
-    int rc = make_wf_plan(cfg, p); if (rc) return rc;
-    CTTS_CHECK_ARG(k >= 0 && k < p.c.n_flows && w && packed, "waveflow pack_flow: bad argument");
-    CTTS_CHECK_ARG(w->start_w && w->start_b && w->cond_w && w->cond_b && w->in_w && w->in_b && w->rs_w && w->rs_b &&
-                   w->end_w && w->end_b, "waveflow pack_flow: NULL weight pointer");
-    hipStream_t s = as_stream(stream);
-    float* blob = static_cast<float*>(packed);
-    const auto& f = p.fl[k];
-    const int C = p.C, kh = p.c.kernel_size_h, kw = p.c.kernel_size_w, nm = p.c.n_mel_channels;
-    CTTS_CHECK_HIP(hipMemcpyAsync(blob + f.start_w, w->start_w, C * sizeof(float), hipMemcpyDeviceToDevice, s));
-    CTTS_CHECK_HIP(hipMemcpyAsync(blob + f.start_b, w->start_b, C * sizeof(float), hipMemcpyDeviceToDevice, s));
-    CTTS_CHECK_HIP(hipMemcpyAsync(blob + f.end_w, w->end_w, 2 * C * sizeof(float), hipMemcpyDeviceToDevice, s));
-    CTTS_CHECK_HIP(hipMemcpyAsync(blob + f.end_b, w->end_b, 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    for (int i = 0; i < p.c.n_layers; ++i) {
-        CTTS_CHECK_ARG(w->in_w[i] && w->in_b[i] && w->rs_w[i] && w->rs_b[i], "waveflow pack_flow: NULL layer %d", i);
-        CTTS_CHECK_HIP(hipMemsetAsync(blob + f.in_A[i], 0, (size_t)p.in_mb() * p.nch_in * GEMM_KC * WF_BM * sizeof(float), s));
-        // K = [height tap a][width tap j][channel] then the cond rows;  in_w[i] is [2C][C][kh][kw]
-        for (int a = 0; a < kh; ++a)
-            for (int j = 0; j < kw; ++j)
-                if ((rc = launch_pack_a(blob + f.in_A[i], w->in_w[i] + a * kw + j, WF_BM, p.in_mb(), p.nch_in,
-                                        (a * kw + j) * C, C, GEMM_EPI_GATE, C, 2 * C, 0, (long long)C * kh * kw,
-                                        kh * kw, s))) return rc;
-        if ((rc = launch_pack_a(blob + f.in_A[i], w->cond_w, WF_BM, p.in_mb(), p.nch_in, kh * kw * C, nm,
-                                GEMM_EPI_GATE, C, 2 * C, (long long)2 * C * i, nm, 1, s))) return rc;
-        if ((rc = launch_pack_bias(blob + f.in_b[i], WF_BM, p.in_mb(), w->in_b[i], 0, w->cond_b, (long long)2 * C * i,
-                                   GEMM_EPI_GATE, C, 2 * C, s))) return rc;
-        const int rows = p.rs_rows(i);
-        if ((rc = launch_pack_a(blob + f.rs_A[i], w->rs_w[i], WF_BM, p.rs_mb(i), p.nch_c, 0, C, GEMM_EPI_SPLIT, C, rows,
-                                0, C, 1, s))) return rc;
-        if ((rc = launch_pack_bias(blob + f.rs_b[i], WF_BM, p.rs_mb(i), w->rs_b[i], 0, nullptr, 0, GEMM_EPI_SPLIT, C,
-                                   rows, s))) return rc;
-        if (p.fused()) {
-            hipLaunchKernelGGL(wf_pack_rs_t_kernel, dim3(33), dim3(256), 0, s, w->rs_w[i], w->rs_b[i], blob + f.rs_T[i],
-                               blob + f.rs_Tb[i], rows);
-            CTTS_CHECK_LAUNCH("wf_pack_rs_t");
-        }
-    }
-    return CTTS_OK;
-}
-
-size_t ctts_waveflow_workspace_bytes(const ctts_waveflow_config* cfg, int32_t batch, int32_t samples) {
-    WfPlan p; WfGeom g; WfWs w;
-    if (make_wf_plan(cfg, p) || make_wf_geom(p, samples, g) || batch < 1) return 0;
-    wf_carve(p, g, batch, nullptr, w);
-    return w.total * sizeof(float);
-}
-
-int ctts_waveflow_inverse_f32(const ctts_waveflow_config* cfg, const void* packed, const float* z, const float* mel,
-                              float* audio, int32_t batch, int32_t samples, int32_t frames, void* workspace,
-                              size_t workspace_bytes, void* stream) {
+// Shared body of the two entry points.  cond = mel [B][n_mel][frames] (dense) when the single linear cond layer is
+// folded into the GEMM, or the per-flow frame-rate conditioning [n_flows][B][2C*n_layers][cond_ld] (padded rows).
+int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float* z, const float* cond, int cond_ld,
+               int cond_pad, float* audio, int batch, int samples, int frames, void* workspace, size_t workspace_bytes,
+               void* stream) {
     WfPlan p; WfGeom g; WfWs w;
     int rc = make_wf_plan(cfg, p); if (rc) return rc;
     rc = make_wf_geom(p, samples, g); if (rc) return rc;
-    CTTS_CHECK_ARG(packed && z && mel && audio && workspace && batch >= 1 && frames >= 1, "waveflow inverse: bad argument");
+    CTTS_CHECK_ARG(packed && z && cond && audio && workspace && batch >= 1 && frames >= 1, "waveflow inverse: bad argument");
     wf_carve(p, g, batch, static_cast<float*>(workspace), w);
     if (w.total * sizeof(float) > workspace_bytes) {
         set_error("waveflow inverse: workspace %zu bytes < required %zu", workspace_bytes, w.total * sizeof(float));
@@ -320,14 +377,17 @@ int ctts_waveflow_inverse_f32(const ctts_waveflow_config* cfg, const void* packe
     hipStream_t s = as_stream(stream);
     const float* blob = static_cast<const float*>(packed);
     const int G = p.c.n_group, C = p.C, L = g.L, kh = p.c.kernel_size_h, kw = p.c.kernel_size_w;
+    const int gkh = p.sep ? 1 : kh, gkw = p.sep ? 1 : kw;
     const long long cstride = (long long)C * g.ld;
-    const dim3 lgrid((L + 255) / 256, batch);
+    const dim3 lgrid((g.Lr + 255) / 256, batch);
 
-    hipLaunchKernelGGL(wf_squeeze_kernel, lgrid, dim3(256), 0, s, z, w.rows, G, L);
+    hipLaunchKernelGGL(wf_squeeze_kernel, lgrid, dim3(256), 0, s, z, w.rows, G, L, g.Lr);
     CTTS_CHECK_LAUNCH("wf_squeeze");
-    hipLaunchKernelGGL(wf_interp_kernel, dim3((L + 255) / 256, p.c.n_mel_channels, batch), dim3(256), 0, s, mel,
-                       w.mel_up, p.c.n_mel_channels, p.kmel, frames, L, g.ld, g.pad);
-    CTTS_CHECK_LAUNCH("wf_interp");
+    if (!p.precond) {
+        hipLaunchKernelGGL(wf_interp_kernel, dim3((L + 255) / 256, p.c.n_mel_channels, batch), dim3(256), 0, s, cond,
+                           w.mel_up, p.c.n_mel_channels, p.kmel, frames, L, g.ld, g.pad);
+        CTTS_CHECK_LAUNCH("wf_interp");
+    }
 
     // logical row g of the current flow lives in physical row phys[g] of w.rows
     int phys[64], perm[64], tmp[64];
@@ -340,10 +400,16 @@ int ctts_waveflow_inverse_f32(const ctts_waveflow_config* cfg, const void* packe
         wf_permutation(k, G, perm);
         for (int i = 0; i < G; ++i) tmp[i] = phys[perm[i]];
         for (int i = 0; i < G; ++i) phys[i] = tmp[i];
+        if (p.precond) {   // this flow's conditioning, upsampled once for all rows and layers
+            const float* fr = cond + (size_t)k * batch * 2 * C * p.c.n_layers * cond_ld;
+            hipLaunchKernelGGL(wf_interp_cond_kernel, dim3((L + 255) / 256, 2 * C * p.c.n_layers, batch), dim3(256), 0, s,
+                               fr, w.cond_up, 2 * C, p.c.n_layers, frames, cond_ld, cond_pad, L, g.ld, g.pad, w.cond_slot);
+            CTTS_CHECK_LAUNCH("wf_interp_cond");
+        }
         for (int r = 0; r < G - 1; ++r) {
             const int slot = r % kh;
-            hipLaunchKernelGGL(wf_start_kernel, dim3((L / 4 + 255) / 256, (C + 15) / 16, batch), dim3(256), 0, s,
-                               w.rows, blob + f.start_w, blob + f.start_b, X(0, slot), C, G, phys[r], L, g.ld, g.pad);
+            hipLaunchKernelGGL(wf_start_kernel, dim3(((L + 3) / 4 + 255) / 256, (C + 15) / 16, batch), dim3(256), 0, s,
+                               w.rows, blob + f.start_w, blob + f.start_b, X(0, slot), C, G, phys[r], L, g.Lr, g.ld, g.pad);
             CTTS_CHECK_LAUNCH("wf_start");
             const int a_min = (kh - 1 - r) > 0 ? (kh - 1 - r) : 0;   // earlier rows do not exist: skip those taps
             for (int i = 0; i < p.c.n_layers; ++i) {
@@ -353,17 +419,35 @@ int ctts_waveflow_inverse_f32(const ctts_waveflow_config* cfg, const void* packe
                 a.ld = g.ld; a.pad = g.pad; a.L = L; a.ntiles = g.ntiles; a.batch = batch;
                 a.dst_ld = g.ld; a.dst_pad = g.pad;
                 a.A = blob + f.in_A[i]; a.bias = blob + f.in_b[i];
-                a.a_nch_alloc = p.nch_in; a.a_ch_off = a_min * kw * p.nch_c;
+                a.a_nch_alloc = p.nch_in;
                 a.MB = p.in_mb(); a.M = 2 * C; a.pairC = C;
                 int ns = 0;
-                for (int ah = a_min; ah < kh; ++ah) {
-                    const int src_row = r - (kh - 1 - ah);
-                    for (int j = 0; j < kw; ++j)
-                        a.seg[ns++] = {X(i, src_row % kh), cstride, p.nch_c, (j - kw / 2) * dw, 0, 0};
+                if (p.sep) {
+                    WfSlots xs{};
+                    for (int ah = a_min; ah < kh; ++ah) xs.p[ah] = X(i, (r - (kh - 1 - ah)) % kh);
+                    hipLaunchKernelGGL(wf_depthwise_kernel, dim3((L + 255) / 256, C, batch), dim3(256), 0, s, xs,
+                                       blob + f.dw_w[i], blob + f.dw_b[i], w.dwout, C, kh, kw, dw, a_min, L, g.ld, g.pad);
+                    CTTS_CHECK_LAUNCH("wf_depthwise");
+                    a.a_ch_off = 0;
+                    a.seg[ns++] = {w.dwout, cstride, p.nch_c, 0, 0, 0};
+                    a.nch_total = p.nch_c;
+                } else {
+                    a.a_ch_off = a_min * kw * p.nch_c;
+                    for (int ah = a_min; ah < gkh; ++ah) {
+                        const int src_row = r - (kh - 1 - ah);
+                        for (int j = 0; j < gkw; ++j)
+                            a.seg[ns++] = {X(i, src_row % kh), cstride, p.nch_c, (j - kw / 2) * dw, 0, 0};
+                    }
+                    a.nch_total = (kh - a_min) * kw * p.nch_c;
                 }
-                a.seg[ns++] = {w.mel_up, (long long)p.kmel * g.ld, p.kmel / GEMM_KC, 0, 0, 0};
+                if (p.precond) {
+                    a.addend = w.cond_up + (size_t)i * w.cond_slot;
+                    a.addend_bstride = (long long)2 * C * g.ld;
+                } else {
+                    a.seg[ns++] = {w.mel_up, (long long)p.kmel * g.ld, p.kmel / GEMM_KC, 0, 0, 0};
+                    a.nch_total += p.kmel / GEMM_KC;
+                }
                 a.nseg = ns;
-                a.nch_total = (kh - a_min) * kw * p.nch_c + p.kmel / GEMM_KC;
                 const bool last = i == p.c.n_layers - 1;
                 if (fuse) {
                     // x_{i+1}[row r] = x_i[row r] + res -> layer i+1's ring slot;  skip rows (+)= into w.out
@@ -392,18 +476,133 @@ int ctts_waveflow_inverse_f32(const ctts_waveflow_config* cfg, const void* packe
                 q.split = last ? 0 : C;
                 if ((rc = launch_gemm_f32(GEMM_EPI_SPLIT, q, s))) return rc;
             }
-            hipLaunchKernelGGL(wf_tail_kernel, lgrid, dim3(256), 0, s, w.out, w.rows, blob + f.end_w, blob + f.end_b, C,
-                               G, phys[r + 1], L, g.ld, g.pad);
+            hipLaunchKernelGGL(wf_tail_kernel, dim3((g.Lr + 255) / 256, batch), dim3(256), 0, s, w.out, w.rows,
+                               blob + f.end_w, blob + f.end_b, C, G, phys[r + 1], L, g.Lr, g.ld, g.pad);
             CTTS_CHECK_LAUNCH("wf_tail");
         }
-        const size_t n4 = (size_t)batch * G * L / 4;
+        const size_t n4 = (size_t)batch * G * g.Lr / 4;
         hipLaunchKernelGGL(wf_nan_to_zero_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, w.rows, n4);
         CTTS_CHECK_LAUNCH("wf_nan_to_zero");
     }
     RowMap map;
     for (int i = 0; i < 64; ++i) map.phys[i] = i < G ? phys[i] : 0;
-    hipLaunchKernelGGL(wf_unsqueeze_kernel, lgrid, dim3(256), 0, s, w.rows, audio, G, L, map);
+    hipLaunchKernelGGL(wf_unsqueeze_kernel, dim3((L + 255) / 256, batch), dim3(256), 0, s, w.rows, audio, G, L, g.Lr, map);
     CTTS_CHECK_LAUNCH("wf_unsqueeze");
+    return CTTS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ctts_waveflow_packed_bytes(const ctts_waveflow_config* cfg) {
+    WfPlan p;
+    if (make_wf_plan(cfg, p)) return 0;
+    return p.total * sizeof(float);
+}
+
+int ctts_waveflow_pack_flow(const ctts_waveflow_config* cfg, int32_t k, const ctts_waveflow_flow_weights* w,
+                            void* packed, void* stream) {
+    WfPlan p;
+    int rc = make_wf_plan(cfg, p); if (rc) return rc;
+    CTTS_CHECK_ARG(k >= 0 && k < p.c.n_flows && w && packed, "waveflow pack_flow: bad argument");
+    CTTS_CHECK_ARG(w->start_w && w->start_b && w->in_w && w->in_b && w->rs_w && w->rs_b && w->end_w && w->end_b,
+                   "waveflow pack_flow: NULL weight pointer");
+    CTTS_CHECK_ARG(p.precond || (w->cond_w && w->cond_b), "waveflow pack_flow: NULL cond layer");
+    CTTS_CHECK_ARG(!p.sep || (w->dw_w && w->dw_b), "waveflow pack_flow: NULL depthwise weights");
+    hipStream_t s = as_stream(stream);
+    float* blob = static_cast<float*>(packed);
+    const auto& f = p.fl[k];
+    const int C = p.C, kh = p.c.kernel_size_h, kw = p.c.kernel_size_w, nm = p.c.n_mel_channels;
+    const int gkh = p.sep ? 1 : kh, gkw = p.sep ? 1 : kw;      // taps of the GEMM stage
+    CTTS_CHECK_HIP(hipMemcpyAsync(blob + f.start_w, w->start_w, C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    CTTS_CHECK_HIP(hipMemcpyAsync(blob + f.start_b, w->start_b, C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    CTTS_CHECK_HIP(hipMemcpyAsync(blob + f.end_w, w->end_w, 2 * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    CTTS_CHECK_HIP(hipMemcpyAsync(blob + f.end_b, w->end_b, 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    for (int i = 0; i < p.c.n_layers; ++i) {
+        CTTS_CHECK_ARG(w->in_w[i] && w->in_b[i] && w->rs_w[i] && w->rs_b[i], "waveflow pack_flow: NULL layer %d", i);
+        CTTS_CHECK_HIP(hipMemsetAsync(blob + f.in_A[i], 0, (size_t)p.in_mb() * p.nch_in * GEMM_KC * WF_BM * sizeof(float), s));
+        // K = [height tap a][width tap j][channel] then the cond rows;  in_w[i] is [2C][C][gkh][gkw]
+        for (int a = 0; a < gkh; ++a)
+            for (int j = 0; j < gkw; ++j)
+                if ((rc = launch_pack_a(blob + f.in_A[i], w->in_w[i] + a * gkw + j, WF_BM, p.in_mb(), p.nch_in,
+                                        (a * gkw + j) * C, C, GEMM_EPI_GATE, C, 2 * C, 0, (long long)C * gkh * gkw,
+                                        gkh * gkw, s))) return rc;
+        if (!p.precond)
+            if ((rc = launch_pack_a(blob + f.in_A[i], w->cond_w, WF_BM, p.in_mb(), p.nch_in, gkh * gkw * C, nm,
+                                    GEMM_EPI_GATE, C, 2 * C, (long long)2 * C * i, nm, 1, s))) return rc;
+        if ((rc = launch_pack_bias(blob + f.in_b[i], WF_BM, p.in_mb(), w->in_b[i], 0, p.precond ? nullptr : w->cond_b,
+                                   (long long)2 * C * i, GEMM_EPI_GATE, C, 2 * C, s))) return rc;
+        if (p.sep) {
+            CTTS_CHECK_ARG(w->dw_w[i] && w->dw_b[i], "waveflow pack_flow: NULL depthwise layer %d", i);
+            CTTS_CHECK_HIP(hipMemcpyAsync(blob + f.dw_w[i], w->dw_w[i], (size_t)C * kh * kw * sizeof(float),
+                                          hipMemcpyDeviceToDevice, s));
+            CTTS_CHECK_HIP(hipMemcpyAsync(blob + f.dw_b[i], w->dw_b[i], C * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+        const int rows = p.rs_rows(i);
+        if ((rc = launch_pack_a(blob + f.rs_A[i], w->rs_w[i], WF_BM, p.rs_mb(i), p.nch_c, 0, C, GEMM_EPI_SPLIT, C, rows,
+                                0, C, 1, s))) return rc;
+        if ((rc = launch_pack_bias(blob + f.rs_b[i], WF_BM, p.rs_mb(i), w->rs_b[i], 0, nullptr, 0, GEMM_EPI_SPLIT, C,
+                                   rows, s))) return rc;
+        if (p.fused()) {
+            hipLaunchKernelGGL(wf_pack_rs_t_kernel, dim3(33), dim3(256), 0, s, w->rs_w[i], w->rs_b[i], blob + f.rs_T[i],
+                               blob + f.rs_Tb[i], rows);
+            CTTS_CHECK_LAUNCH("wf_pack_rs_t");
+        }
+    }
+    return CTTS_OK;
+}
+
+size_t ctts_waveflow_workspace_bytes(const ctts_waveflow_config* cfg, int32_t batch, int32_t samples) {
+    WfPlan p; WfGeom g; WfWs w;
+    if (make_wf_plan(cfg, p) || make_wf_geom(p, samples, g) || batch < 1) return 0;
+    wf_carve(p, g, batch, nullptr, w);
+    return w.total * sizeof(float);
+}
+
+int ctts_waveflow_inverse_f32(const ctts_waveflow_config* cfg, const void* packed, const float* z, const float* mel,
+                              float* audio, int32_t batch, int32_t samples, int32_t frames, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    CTTS_CHECK_ARG(cfg && !cfg->cond_precomputed, "waveflow inverse: this model takes per-flow conditioning "
+                                                  "(ctts_waveflow_inverse_cond_f32)");
+    return wf_inverse(cfg, packed, z, mel, 0, 0, audio, batch, samples, frames, workspace, workspace_bytes, stream);
+}
+
+int ctts_waveflow_inverse_cond_f32(const ctts_waveflow_config* cfg, const void* packed, const float* z,
+                                   const float* cond, int32_t cond_ld, int32_t cond_pad, float* audio, int32_t batch,
+                                   int32_t samples, int32_t frames, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+    CTTS_CHECK_ARG(cfg && cfg->cond_precomputed, "waveflow inverse_cond: the model folds its cond layer "
+                                                 "(ctts_waveflow_inverse_f32)");
+    CTTS_CHECK_ARG(cond_pad >= 0 && cond_ld >= cond_pad + frames, "waveflow inverse_cond: cond_ld=%d pad=%d frames=%d",
+                   cond_ld, cond_pad, frames);
+    return wf_inverse(cfg, packed, z, cond, cond_ld, cond_pad, audio, batch, samples, frames, workspace,
+                      workspace_bytes, stream);
+}
+
+int ctts_embed_rows_f32(const float* table, const int64_t* ids, float* x, int32_t row0, int32_t embed_dim,
+                        int32_t batch, int32_t C, int32_t T, int32_t ld, int32_t pad, void* stream) {
+    CTTS_CHECK_ARG(table && ids && x && embed_dim >= 1 && row0 >= 0 && row0 + embed_dim <= C && batch >= 1 && T >= 1 &&
+                   ld >= pad + T, "embed_rows: bad argument");
+    hipLaunchKernelGGL(embed_rows_kernel, dim3((T + 255) / 256, embed_dim, batch), dim3(256), 0, as_stream(stream), table,
+                       ids, x, row0, embed_dim, C, T, ld, pad);
+    CTTS_CHECK_LAUNCH("embed_rows");
+    return CTTS_OK;
+}
+
+int ctts_scale_add_rows_f32(const float* x, const float* alpha_dev, const float* r, float* y, int32_t batch, int32_t C,
+                            int32_t T, int32_t ld, int32_t pad, void* stream) {
+    CTTS_CHECK_ARG(x && y && batch >= 1 && C >= 1 && T >= 1 && ld >= pad + T, "scale_add_rows: bad argument");
+    hipLaunchKernelGGL(scale_add_rows_kernel, dim3((T + 255) / 256, C, batch), dim3(256), 0, as_stream(stream), x,
+                       alpha_dev, r, y, C, T, ld, pad);
+    CTTS_CHECK_LAUNCH("scale_add_rows");
+    return CTTS_OK;
+}
+
+int ctts_deemphasis_f32(const float* x, float* y, int32_t batch, int32_t T, double p, void* stream) {
+    CTTS_CHECK_ARG(x && y && batch >= 1 && T >= 1, "deemphasis: bad argument");
+    hipLaunchKernelGGL(deemphasis_kernel, dim3(batch), dim3(256), 0, as_stream(stream), x, y, T, p);
+    CTTS_CHECK_LAUNCH("deemphasis");
     return CTTS_OK;
 }
 

@@ -74,38 +74,77 @@ def waveglow_flow_channels(cfg):
 
 
 def waveflow_config(n_flows=8, n_group=16, n_channels=64, n_layers=8, kernel_size_w=3, kernel_size_h=3,
-                    n_mel_channels=80, hop_length=256):
+                    n_mel_channels=80, hop_length=256, win_length=1024, sampling_rate=22050, **over):
     """Constructor kwargs of the reference ``efficient_model_ax.WaveGlow`` for BASELINE config 4
-    (SURVEY.md 8d row 4)."""
-    return dict(n_mel_channels=n_mel_channels, n_flows=n_flows, n_group=n_group, n_early_every=100,
-                n_early_size=2, memory_efficient=0.0, spect_scaling=False, upsample_mode='normal',
-                upsample_first=False, speaker_embed=0, cond_layers=0, cond_hidden_channels=256,
-                cond_output_channels=256, cond_kernel_size=1, cond_residual=False, cond_padding_mode='zeros',
-                waveflow=True, channel_mixing='permuteheight', mix_first=False, win_length=1024,
-                hop_length=hop_length, sampling_rate=22050,
-                WN_config=dict(n_layers=n_layers, n_channels=n_channels, kernel_size_w=kernel_size_w,
-                               kernel_size_h=kernel_size_h, n_layers_dilations_w=None,
-                               n_layers_dilations_h=[1] * n_layers, speaker_embed_dim=0, rezero=False,
-                               cond_layers=1, cond_activation_func='none', negative_slope=None,
-                               cond_hidden_channels=256, cond_padding_mode='zeros', seperable_conv=False,
-                               res_skip=True, merge_res_skip=False, upsample_mode='linear', cond_kernel_size=1))
+    (SURVEY.md 8d row 4).  ``over``: model-level kwargs to replace; ``WN`` = dict of WN_config entries to replace."""
+    wn_over = over.pop("WN", {})
+    cfg = dict(n_mel_channels=n_mel_channels, n_flows=n_flows, n_group=n_group, n_early_every=100,
+               n_early_size=2, memory_efficient=0.0, spect_scaling=False, upsample_mode='normal',
+               upsample_first=False, speaker_embed=0, cond_layers=0, cond_hidden_channels=256,
+               cond_output_channels=256, cond_kernel_size=1, cond_residual=False, cond_padding_mode='zeros',
+               waveflow=True, channel_mixing='permuteheight', mix_first=False, win_length=win_length,
+               hop_length=hop_length, sampling_rate=sampling_rate,
+               WN_config=dict(n_layers=n_layers, n_channels=n_channels, kernel_size_w=kernel_size_w,
+                              kernel_size_h=kernel_size_h, n_layers_dilations_w=None,
+                              n_layers_dilations_h=[1] * n_layers, speaker_embed_dim=0, rezero=False,
+                              cond_layers=1, cond_activation_func='none', negative_slope=None,
+                              cond_hidden_channels=256, cond_padding_mode='zeros', seperable_conv=False,
+                              res_skip=True, merge_res_skip=False, upsample_mode='linear', cond_kernel_size=1))
+    cfg.update(over)
+    cfg["WN_config"].update(wn_over)
+    return cfg
+
+
+def waveflow_author_config(n_flows=8, n_group=20, n_channels=128, n_layers=8, kernel=7, n_mel_channels=160,
+                           hop_length=600, win_length=2400, speaker_embed=96, cond_layers=5, cond_hidden=512,
+                           wn_cond_hidden=256):
+    """The option set of the author's own WaveFlow checkpoints (printed by
+    scripts/"WaveGlow from Ground Truth.ipynb" cell 2): separable 7x7 in-layers, speaker embeddings at model and
+    WN level, a 5-layer k=9 (cond_kernel_size 5 -> 2k-1) residual + rezero conditioning stack, a 3-layer 1x1 WN
+    conditioning stack with output activation, log-variance mel channels, pre-emphasis 0.9."""
+    return waveflow_config(
+        n_flows=n_flows, n_group=n_group, n_channels=n_channels, n_layers=n_layers, kernel_size_w=kernel,
+        kernel_size_h=kernel, n_mel_channels=n_mel_channels, hop_length=hop_length, win_length=win_length,
+        sampling_rate=48000, n_early_every=16, channel_mixing='permute', speaker_embed=speaker_embed,
+        cond_layers=cond_layers, cond_activation_func='lrelu', negative_slope=0.25, cond_hidden_channels=cond_hidden,
+        cond_output_channels=256, cond_residual=True, cond_res_rezero=True, cond_kernel_size=5,
+        shift_spect=0.0, scale_spect=1.0, preceived_vol_scaling=False, preempthasis=0.9, use_logvar_channels=True,
+        load_hidden_from_disk=False, iso226_empthasis=False,
+        WN=dict(gated_unit='GTU', n_layers_dilations_h=1, speaker_embed_dim=speaker_embed, cond_layers=3,
+                cond_activation_func='lrelu', cond_out_activation_func=True, negative_slope=0.5,
+                cond_hidden_channels=wn_cond_hidden, cond_kernel_size=1, seperable_conv=True))
 
 
 WAVEFLOW_CONFIGS = {
     "toy": waveflow_config(n_flows=4, n_group=8, n_channels=64, n_layers=3),
     "full": waveflow_config(),                                   # config 4: 8 flows, 64 ch, h = 16
+    # SURVEY 8f.4 option set, scaled down / at the author's size
+    "author_toy": waveflow_author_config(n_flows=4, n_group=10, n_channels=64, n_layers=3, kernel=5,
+                                         n_mel_channels=12, hop_length=40, win_length=160, speaker_embed=8,
+                                         cond_layers=2, cond_hidden=32, wn_cond_hidden=24),
+    "author": waveflow_author_config(),
 }
+
+
+def waveflow_cond_channels(cfg):
+    """(model-level cond input channels, channels handed to every WN) - ax:64-66, 73-74, 96."""
+    c_in = cfg["n_mel_channels"] * (2 if cfg.get("use_logvar_channels") else 1) + cfg["speaker_embed"]
+    c_out = c_in
+    if cfg["cond_layers"]:
+        c_out = c_in if cfg["cond_residual"] in (True, 1) else cfg["cond_output_channels"]
+    return c_in, c_out
 
 
 def waveflow_state_dict(cfg, seed=1234, end_std=None):
     """Random-init state dict with the reference's keys (SURVEY.md 8a "Checkpoint keys"):
-    ``WN.k.WN.{start,in_layers.i,res_skip_layers.i,cond_layers.0}.{bias,weight_g,weight_v}``,
-    ``WN.k.WN.end.{weight,bias}`` (PermuteHeight has no parameters)."""
+    ``WN.k.WN.{start,in_layers.i,res_skip_layers.i,cond_layers.l}.{bias,weight_g,weight_v}``,
+    ``WN.k.WN.end.{weight,bias}`` (PermuteHeight has no parameters); with the 8f.4 options also
+    ``speaker_embed.weight``, ``alpha``, ``cond_layers.l.*``, ``WN.k.WN.speaker_embed.weight`` and separable
+    in-layers ``WN.k.WN.in_layers.i.{0,1}.*`` (depthwise, pointwise)."""
     rng = np.random.default_rng(seed)
     wn = cfg["WN_config"]
     C, n_layers = wn["n_channels"], wn["n_layers"]
     kh, kw = wn["kernel_size_h"], wn["kernel_size_w"]
-    n_mel = cfg["n_mel_channels"]
     if end_std is None:
         end_std = 0.25 / np.sqrt(C)
     sd = {}
@@ -119,14 +158,36 @@ def waveflow_state_dict(cfg, seed=1234, end_std=None):
         sd[prefix + ".weight_g"] = (norm * jitter).astype(np.float32).reshape((shape[0],) + (1,) * (len(shape) - 1))
         sd[prefix + ".bias"] = _uniform(rng, (shape[0],), bound)
 
+    c_in, c_wn = waveflow_cond_channels(cfg)
+    if cfg["speaker_embed"]:
+        sd["speaker_embed.weight"] = rng.standard_normal((512, cfg["speaker_embed"]), dtype=np.float32)
+    if cfg.get("cond_res_rezero"):
+        sd["alpha"] = np.array([0.3], np.float32)          # a trained value; the init (0.01..0.03) would hide the stack
+    if cfg["cond_layers"]:
+        k = 2 * cfg["cond_kernel_size"] - 1
+        dims = [c_in] + [cfg["cond_hidden_channels"]] * (cfg["cond_layers"] - 1) + [c_wn]
+        for l in range(cfg["cond_layers"]):
+            wn_conv(f"cond_layers.{l}", (dims[l + 1], dims[l], k), dims[l] * k)
+    sdim = wn.get("speaker_embed_dim", 0)
     for k in range(cfg["n_flows"]):
         p = f"WN.{k}.WN"
         wn_conv(p + ".start", (C, 1, 1, 1), 1)
         sd[p + ".end.weight"] = rng.standard_normal((2, C, 1, 1), dtype=np.float32) * np.float32(end_std)
         sd[p + ".end.bias"] = rng.standard_normal((2,), dtype=np.float32) * np.float32(0.02)
-        wn_conv(p + ".cond_layers.0", (2 * C * n_layers, n_mel, 1), n_mel * 4)
+        if sdim:
+            sd[p + ".speaker_embed.weight"] = rng.standard_normal((512, sdim), dtype=np.float32)
+        ck = 2 * wn.get("cond_kernel_size", 1) - 1
+        dims = [c_wn + sdim] + [wn["cond_hidden_channels"]] * (wn["cond_layers"] - 1) + [2 * C * n_layers]
+        for l in range(wn["cond_layers"]):
+            # (the single-layer recipe keeps its historical fan so the committed config-4 goldens stay valid)
+            fan = dims[l] * 4 if wn["cond_layers"] == 1 else dims[l] * ck
+            wn_conv(f"{p}.cond_layers.{l}", (dims[l + 1], dims[l], ck), fan)
         for i in range(n_layers):
-            wn_conv(f"{p}.in_layers.{i}", (2 * C, C, kh, kw), C * kh * kw)
+            if wn.get("seperable_conv") and not (kh == 1 and kw == 1):
+                wn_conv(f"{p}.in_layers.{i}.0", (C, 1, kh, kw), kh * kw)
+                wn_conv(f"{p}.in_layers.{i}.1", (2 * C, C, 1, 1), C)
+            else:
+                wn_conv(f"{p}.in_layers.{i}", (2 * C, C, kh, kw), C * kh * kw)
             rs = 2 * C if i < n_layers - 1 else C
             wn_conv(f"{p}.res_skip_layers.{i}", (rs, C, 1, 1), C)
     return sd

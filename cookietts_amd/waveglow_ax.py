@@ -1,10 +1,12 @@
 """WaveFlow / "ax" WaveGlow core on the MI355X HIP path (BASELINE config 4).
 
 Host-side mirror of ``/root/reference/CookieTTS/_4_mtw/waveglow/efficient_model_ax.py``
-``WaveGlow`` (:18-169 constructor, :279-357 ``inverse``, :359-388 ``infer``) for the option subset
-of BASELINE config 4: ``waveflow=True`` (``WaveFlowCoupling`` + ``WN_2d``, efficient_modules.py:19-65,
-glow_ax.py:421-635), ``channel_mixing='permuteheight'``, ``mix_first=False``, no model-level cond
-layers, no speaker embedding, linear-interpolated conditioning.  Same constructor kwargs, same
+``WaveGlow`` (:18-169 constructor, :279-357 ``inverse``, :359-388 ``infer``) for ``waveflow=True``
+(``WaveFlowCoupling`` + ``WN_2d``, efficient_modules.py:19-65, glow_ax.py:421-635),
+``channel_mixing='permuteheight'``, ``mix_first=False``, linear-interpolated conditioning: BASELINE config 4,
+and the option set of the author's own checkpoints: speaker embeddings at model and WN level,
+model-level residual + rezero conv conditioning stack, multi-layer WN conditioning stacks with activations,
+separable (depthwise + pointwise) in-layers, log-variance mel channels, de-emphasis.  Same constructor kwargs, same
 ``state_dict`` keys (``WN.k.WN.{start,cond_layers.0,in_layers.i,res_skip_layers.i}.{weight_g,weight_v,
 bias}``, ``WN.k.WN.end.{weight,bias}``), same ``infer`` / ``inverse`` contracts (output length
 ``(F-1)*hop`` with the default ``artifact_trimming=1``; ``return_CPU=True`` moves the result to
@@ -49,23 +51,87 @@ class _WNConv(nn.Module):
 
 
 class _WN2d(nn.Module):
-    def __init__(self, n_mel, n_layers, n_channels, kh, kw):
+    """Parameter tree of glow_ax.WN_2d (:427-543)."""
+
+    def __init__(self, cond_in, wn):
         super().__init__()
-        self.n_layers, self.n_channels = n_layers, n_channels
-        self.start = _WNConv((n_channels, 1, 1, 1))
+        C_, n_layers = wn['n_channels'], wn['n_layers']
+        kh, kw = wn['kernel_size_h'], wn['kernel_size_w']
+        self.n_layers, self.n_channels = n_layers, C_
+        sdim = wn.get('speaker_embed_dim', 0)
+        self.start = _WNConv((C_, 1, 1, 1))
         self.end = nn.Module()
-        self.end.weight = nn.Parameter(torch.zeros(2, n_channels, 1, 1))        # zero-init, glow_ax.py:454-457
+        self.end.weight = nn.Parameter(torch.zeros(2, C_, 1, 1))                # zero-init, glow_ax.py:454-457
         self.end.bias = nn.Parameter(torch.zeros(2))
-        self.cond_layers = nn.ModuleList([_WNConv((2 * n_channels * n_layers, n_mel, 1))])
-        self.in_layers = nn.ModuleList([_WNConv((2 * n_channels, n_channels, kh, kw)) for _ in range(n_layers)])
+        if sdim:
+            self.speaker_embed = nn.Embedding(512, sdim)                        # glow_ax.py:459-461
+        k = 2 * wn.get('cond_kernel_size', 1) - 1                               # glow_ax.py:474
+        dims = [cond_in + sdim] + [wn['cond_hidden_channels']] * (wn['cond_layers'] - 1) + [2 * C_ * n_layers]
+        self.cond_layers = nn.ModuleList([_WNConv((dims[l + 1], dims[l], k)) for l in range(wn['cond_layers'])])
+        if wn.get('seperable_conv', False) and not (kh == 1 and kw == 1):       # glow_ax.py:521-531
+            self.in_layers = nn.ModuleList([nn.ModuleList([_WNConv((C_, 1, kh, kw)), _WNConv((2 * C_, C_, 1, 1))])
+                                            for _ in range(n_layers)])
+        else:
+            self.in_layers = nn.ModuleList([_WNConv((2 * C_, C_, kh, kw)) for _ in range(n_layers)])
         self.res_skip_layers = nn.ModuleList([
-            _WNConv((2 * n_channels if i < n_layers - 1 else n_channels, n_channels, 1, 1)) for i in range(n_layers)])
+            _WNConv((2 * C_ if i < n_layers - 1 else C_, C_, 1, 1)) for i in range(n_layers)])
 
 
 class _Coupling(nn.Module):
     def __init__(self, wn):
         super().__init__()
         self.WN = wn
+
+
+PAD = 8          # halo of the frame-rate padded rows (>= k/2 of every cond conv, k <= 11)
+
+
+def _act_code(name, negative_slope):
+    """The reference's activation table (ax:100-111 = glow_ax.py:493-504) -> (ctts_conv1d act, slope).
+    As written there, 'lrelu' selects ``F.relu`` and 'relu' selects ``LeakyReLU(negative_slope)``."""
+    name = (name or 'none').lower()
+    if name == 'none':
+        return 0, 0.0
+    if name == 'lrelu':
+        return 1, 0.0
+    if name == 'relu':
+        assert negative_slope, "negative_slope not defined in wn_config"
+        return 1, float(negative_slope)
+    if name == 'tanh':
+        return 2, 0.0
+    raise NotImplementedError(f"cond_activation_func={name!r} is not built on the HIP path")
+
+
+class _CondConv:
+    """One ``ctts_conv1d`` operator of a conditioning stack: dense [out, in, k] weight, input channels zero-padded
+    to the primitive's multiple of 16."""
+
+    def __init__(self, w, b, act, slope, device, stream):
+        lib = _lib.lib()
+        out_c, in_c, k = w.shape
+        self.c_in, self.c_out = -(-in_c // 16) * 16, out_c
+        wp = torch.zeros(out_c, self.c_in, k, dtype=torch.float32, device=device)
+        wp[:, :in_c] = w
+        b = b.detach().float().contiguous()
+        self.desc = _lib.Conv1dDesc(c_in=self.c_in, c_out=out_c, kernel_size=k, act=act, slope=slope)
+        nbytes = lib.ctts_conv1d_packed_bytes(C.byref(self.desc))
+        if nbytes == 0:
+            raise _lib.HipLibraryError("unsupported cond conv: " + lib.ctts_last_error().decode())
+        self.blob = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)
+        _lib.check(lib.ctts_conv1d_pack_f32(C.byref(self.desc), _lib.ptr(wp), _lib.ptr(b), None, None, None, None, 1e-5,
+                                           _lib.ptr(self.blob), stream), "ctts_conv1d_pack_f32")
+        self._keep = (wp, b)
+
+    def __call__(self, x, y, B, T, ld, stream):
+        # x [B][>= c_in rows][ld], y [B][>= c_out rows][ld]: the row counts of the buffers are rounded up to 16, so the
+        # primitive (dense [batch][c][ld] strides) is driven one utterance at a time
+        for b in range(B):
+            _lib.check(_lib.lib().ctts_conv1d_f32(C.byref(self.desc), _lib.ptr(self.blob), _lib.ptr(x[b]), _lib.ptr(y[b]),
+                                                 0, 1, T, ld, PAD, stream), "ctts_conv1d_f32")
+
+
+def _r16(n):
+    return -(-n // 16) * 16
 
 
 class WaveGlow(nn.Module):
@@ -87,24 +153,24 @@ class WaveGlow(nn.Module):
         need(waveflow, "waveflow=False (AffineCouplingBlock + 1-D WN of the ax core)")
         need(channel_mixing.lower() in "waveflowpermuteheightpermutechannelpermute", "channel_mixing='1x1conv'")
         need(not mix_first, "mix_first=True")
-        need(cond_layers == 0 and not cond_residual, "model-level cond_layers / cond_residual")
-        need(speaker_embed == 0 and wn.get('speaker_embed_dim', 0) == 0, "speaker embeddings")
+        need(cond_residual in (False, True, 0, 1), "cond_residual='1x1conv'")
         need(not upsample_first, "upsample_first")
         need(n_early_every > n_flows, "early outputs (n_early_every <= n_flows)")
         need(shift_spect == 0. and scale_spect == 1. and not preceived_vol_scaling, "spect shift/scale, vol scaling")
-        need(not preempthasis and not use_logvar_channels and not load_hidden_from_disk, "preempthasis / logvar / hidden cond")
-        need(not unsupported.get('iso226_empthasis', False) and not unsupported.get('transposed_conv_scales'),
-             "iso226 emphasis / transposed-conv upsampling")
-        need(wn.get('cond_layers', 1) == 1 and wn.get('cond_kernel_size', 1) == 1
-             and wn.get('cond_activation_func', 'none') == 'none', "WN cond stack other than one k=1 layer")
+        need(not load_hidden_from_disk, "hidden cond from disk")
+        need(not unsupported.get('iso226_empthasis', False) and not unsupported.get('transposed_conv_scales')
+             and not unsupported.get('group_conv_output_dim'), "iso226 emphasis / transposed-conv upsampling / grouped cond conv")
+        need(wn.get('cond_layers', 1) >= 1, "WN without cond layers")
         need(wn.get('upsample_mode', 'linear') == 'linear', "WN upsample_mode != 'linear'")
-        need(not wn.get('seperable_conv', False) and wn.get('res_skip', True) and not wn.get('merge_res_skip', False),
-             "seperable_conv / merge_res_skip")
+        need(wn.get('res_skip', True) and not wn.get('merge_res_skip', False), "merge_res_skip")
         need(wn.get('gated_unit', 'GTU') == 'GTU' and not wn.get('rezero', False), "gate other than GTU / rezero")
         need(wn.get('n_layers_dilations_w') is None, "custom width dilations")
         dh = wn.get('n_layers_dilations_h', 1)
         dh = [dh] * wn['n_layers'] if isinstance(dh, int) else list(dh)
         need(all(d == 1 for d in dh), "height dilation != 1")
+        need(wn.get('seperable_conv', False) or wn['kernel_size_h'] * wn['kernel_size_w'] <= 11,
+             "dense in-layer kernels with more than 11 taps (use seperable_conv)")
+        need(2 * cond_kernel_size - 1 <= 11 and 2 * wn.get('cond_kernel_size', 1) - 1 <= 11, "cond kernels wider than 11")
         assert n_flows % 2 == 0, "PermuteHeight requires even n_flows"
 
         self.n_flows, self.n_group = n_flows, n_group
@@ -112,21 +178,46 @@ class WaveGlow(nn.Module):
         self.sampling_rate, self.win_size, self.hop_length = sampling_rate, win_length, hop_length
         self.n_mel_channels = n_mel_channels
         self.channel_mixing, self.mix_first = 'permuteheight', mix_first
-        self.has_logvar_channels = False
-        self.multispeaker = False
+        self.has_logvar_channels = bool(use_logvar_channels)
+        self.preempthasis = preempthasis
+        self.speaker_embed_dim = speaker_embed
+        self.multispeaker = speaker_embed > 0 or wn.get('speaker_embed_dim', 0) > 0
+        self.cond_residual, self.cond_res_rezero = cond_residual, cond_res_rezero
         self.WN_config = wn
-        self.WN = nn.ModuleList([
-            _Coupling(_WN2d(n_mel_channels, wn['n_layers'], wn['n_channels'], wn['kernel_size_h'], wn['kernel_size_w']))
-            for _ in range(n_flows)])
+        # activation tables (validated now so that an unsupported name fails at construction)
+        self._act_model = _act_code(cond_activation_func if cond_layers else 'none', negative_slope)
+        self._act_wn = _act_code(wn.get('cond_activation_func', 'none'), wn.get('negative_slope'))
+
+        if speaker_embed:
+            self.speaker_embed = nn.Embedding(512, speaker_embed)                # ax:59-61
+        self.cond_in_channels = n_mel_channels * (2 if use_logvar_channels else 1) + speaker_embed   # ax:64
+        wn_cond = self.cond_in_channels
+        if cond_res_rezero:
+            self.alpha = nn.Parameter(torch.rand(1) * 0.02 + 0.01)               # ax:75-76
+        self.cond_layers = nn.ModuleList()
+        if cond_layers:
+            out_c = self.cond_in_channels if cond_residual in (True, 1) else cond_output_channels   # ax:72-73
+            k = 2 * cond_kernel_size - 1                                         # ax:83
+            dims = [self.cond_in_channels] + [cond_hidden_channels] * (cond_layers - 1) + [out_c]
+            self.cond_layers = nn.ModuleList([_WNConv((dims[l + 1], dims[l], k)) for l in range(cond_layers)])
+            wn_cond = out_c
+        self.wn_cond_channels = wn_cond
+        self.WN = nn.ModuleList([_Coupling(_WN2d(wn_cond, wn)) for _ in range(n_flows)])
+        # one k=1 linear WN cond layer on the bare mel commutes with the interpolation: folded into the in-layer GEMM
+        self._folded = (not cond_layers and not speaker_embed and not wn.get('speaker_embed_dim', 0)
+                        and wn.get('cond_layers', 1) == 1 and wn.get('cond_kernel_size', 1) == 1
+                        and self._act_wn[0] == 0)
         self._packed = None
         self._ws = {}
 
     # ------------------------------------------------------------------ plumbing ----
     def c_config(self):
         wn = self.WN_config
-        return _lib.WaveFlowConfig(n_mel_channels=self.n_mel_channels, n_flows=self.n_flows, n_group=self.n_group,
+        return _lib.WaveFlowConfig(n_mel_channels=self.cond_in_channels, n_flows=self.n_flows, n_group=self.n_group,
                                    n_layers=wn['n_layers'], n_channels=wn['n_channels'],
-                                   kernel_size_w=wn['kernel_size_w'], kernel_size_h=wn['kernel_size_h'], dilation_h=1)
+                                   kernel_size_w=wn['kernel_size_w'], kernel_size_h=wn['kernel_size_h'], dilation_h=1,
+                                   seperable_conv=1 if wn.get('seperable_conv', False) else 0,
+                                   cond_precomputed=0 if self._folded else 1)
 
     def _invalidate(self):
         self._packed, self._ws = None, {}
@@ -163,8 +254,10 @@ class WaveGlow(nn.Module):
         return w
 
     def _ensure_packed(self, device):
+        """-> (blob, cond_ops): packed WaveFlow weights, and (unless the cond layer is folded) the conv operators
+        of the conditioning stacks {'model': [...], 'wn': [[...] per flow]}."""
         if self._packed is not None and self._packed[0] == device:
-            return self._packed[1]
+            return self._packed[1], self._packed[2]
         if device.type != 'cuda':
             raise _lib.HipLibraryError("WaveFlow HIP path needs the model on a GPU (no CPU fallback)")
         lib = _lib.lib()
@@ -172,7 +265,9 @@ class WaveGlow(nn.Module):
         nbytes = lib.ctts_waveflow_packed_bytes(C.byref(cfg))
         if nbytes == 0:
             raise _lib.HipLibraryError("unsupported WaveFlow config: " + lib.ctts_last_error().decode())
-        n_layers = self.WN_config['n_layers']
+        wn_cfg = self.WN_config
+        n_layers = wn_cfg['n_layers']
+        sep = isinstance(self.WN[0].WN.in_layers[0], nn.ModuleList)
         with torch.cuda.device(device):
             stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
             blob = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)
@@ -182,41 +277,109 @@ class WaveGlow(nn.Module):
                 t = t.detach().float().contiguous()
                 keep.append(t)
                 return t.data_ptr()
+
+            def arr(fn):
+                a = (C.c_void_p * n_layers)()
+                for i in range(n_layers):
+                    a[i] = fn(i)
+                return a
             for k in range(self.n_flows):
                 wn = self.WN[k].WN
                 fw = _lib.WaveFlowFlowWeights()
                 fw.start_w = self._dense(wn.start, stream, keep).data_ptr()
                 fw.start_b = dev(wn.start.bias)
-                fw.cond_w = self._dense(wn.cond_layers[0], stream, keep).data_ptr()
-                fw.cond_b = dev(wn.cond_layers[0].bias)
-                arrs = {}
-                for name, layers in (("in", wn.in_layers), ("rs", wn.res_skip_layers)):
-                    wa, ba = (C.c_void_p * n_layers)(), (C.c_void_p * n_layers)()
-                    for i in range(n_layers):
-                        wa[i] = self._dense(layers[i], stream, keep).data_ptr()
-                        ba[i] = dev(layers[i].bias)
-                    arrs[name] = (wa, ba)
-                fw.in_w, fw.in_b = arrs["in"]
-                fw.rs_w, fw.rs_b = arrs["rs"]
+                if self._folded:
+                    fw.cond_w = self._dense(wn.cond_layers[0], stream, keep).data_ptr()
+                    fw.cond_b = dev(wn.cond_layers[0].bias)
+                gemm = (lambda i: wn.in_layers[i][1]) if sep else (lambda i: wn.in_layers[i])
+                fw.in_w = arr(lambda i: self._dense(gemm(i), stream, keep).data_ptr())
+                fw.in_b = arr(lambda i: dev(gemm(i).bias))
+                if sep:
+                    fw.dw_w = arr(lambda i: self._dense(wn.in_layers[i][0], stream, keep).data_ptr())
+                    fw.dw_b = arr(lambda i: dev(wn.in_layers[i][0].bias))
+                fw.rs_w = arr(lambda i: self._dense(wn.res_skip_layers[i], stream, keep).data_ptr())
+                fw.rs_b = arr(lambda i: dev(wn.res_skip_layers[i].bias))
                 fw.end_w = dev(wn.end.weight)
                 fw.end_b = dev(wn.end.bias)
                 _lib.check(lib.ctts_waveflow_pack_flow(C.byref(cfg), k, C.byref(fw), _lib.ptr(blob), stream),
                            f"ctts_waveflow_pack_flow({k})")
+            ops = None
+            if not self._folded:
+                def stack(layers, act, act_last):
+                    out = []
+                    for l, layer in enumerate(layers):
+                        a = act if (act_last or l != len(layers) - 1) else (0, 0.0)
+                        out.append(_CondConv(self._dense(layer, stream, keep), layer.bias, a[0], a[1], device, stream))
+                    return out
+                ops = {'model': stack(self.cond_layers, self._act_model, True),          # ax:293-297: every layer
+                       'wn': [stack(c.WN.cond_layers, self._act_wn, wn_cfg.get('cond_out_activation_func', True))
+                              for c in self.WN]}                                       # glow_ax.py:573-577
             torch.cuda.current_stream(device).synchronize()
-        self._packed = (device, blob)
-        return blob
+        self._packed = (device, blob, ops)
+        return blob, ops
+
+    def _cond_frames(self, ops, cond, speaker_ids, stream):
+        """ax:286-307 + glow_ax.py:566-577 at frame rate -> [n_flows][B][2C*n_layers][ld] padded rows."""
+        lib = _lib.lib()
+        dev = cond.device
+        B, Cm, Fr = cond.shape
+        ld = -(-Fr // 128) * 128 + 2 * PAD
+        if self.multispeaker:
+            if speaker_ids is None:
+                raise Exception("This WaveFlow/WaveGlow model requires speaker ids or speaker embeddings.")   # ax:288
+            ids = speaker_ids.to(device=dev, dtype=torch.int64).contiguous()
+
+        def rows(c):
+            return torch.zeros(B, _r16(c), ld, dtype=torch.float32, device=dev)
+        # model-level input: [mel (+logvar) | speaker embedding]
+        x0 = rows(self.cond_in_channels)
+        for b in range(B):
+            _lib.check(lib.ctts_pad_rows_f32(_lib.ptr(cond[b]), 0, Fr, _lib.ptr(x0[b]), 1, Cm, Fr, ld, PAD, stream),
+                       "ctts_pad_rows_f32")
+        if self.speaker_embed_dim:
+            tab = self.speaker_embed.weight.detach().float().contiguous()
+            _lib.check(lib.ctts_embed_rows_f32(_lib.ptr(tab), _lib.ptr(ids), _lib.ptr(x0), Cm, self.speaker_embed_dim, B,
+                                               x0.shape[1], Fr, ld, PAD, stream), "ctts_embed_rows_f32")
+        # conv stack, rezero, residual
+        sdim = self.WN_config.get('speaker_embed_dim', 0)
+        xw = rows(self.wn_cond_channels + sdim)
+        h = x0
+        for op in ops['model']:
+            y = rows(op.c_out)
+            op(h, y, B, Fr, ld, stream)
+            h = y
+        alpha = self.alpha.detach().float().contiguous() if (self.cond_res_rezero and len(ops['model'])) else None
+        resid = x0 if (self.cond_residual and len(ops['model'])) else None
+        for b in range(B):     # row counts differ between the buffers: one utterance per call
+            _lib.check(lib.ctts_scale_add_rows_f32(_lib.ptr(h[b]), _lib.ptr(alpha), _lib.ptr(None if resid is None else resid[b]),
+                                                   _lib.ptr(xw[b]), 1, self.wn_cond_channels, Fr, ld, PAD, stream),
+                       "ctts_scale_add_rows_f32")
+        # per flow: WN speaker embedding, conv stack -> 2C*n_layers rows
+        C2L = 2 * self.WN_config['n_channels'] * self.WN_config['n_layers']
+        frames = torch.zeros(self.n_flows, B, C2L, ld, dtype=torch.float32, device=dev)
+        for k in range(self.n_flows):
+            if sdim:
+                tab = self.WN[k].WN.speaker_embed.weight.detach().float().contiguous()
+                _lib.check(lib.ctts_embed_rows_f32(_lib.ptr(tab), _lib.ptr(ids), _lib.ptr(xw), self.wn_cond_channels, sdim,
+                                                   B, xw.shape[1], Fr, ld, PAD, stream), "ctts_embed_rows_f32")
+            h = xw
+            for l, op in enumerate(ops['wn'][k]):
+                y = frames[k] if l == len(ops['wn'][k]) - 1 else rows(op.c_out)
+                op(h, y, B, Fr, ld, stream)
+                h = y
+        return frames, ld
 
     # --------------------------------------------------------------------- the path ----
     def inverse(self, z, cond, speaker_ids=None, return_CPU=True):
-        """efficient_model_ax.py:279-357: z [B, T] (noise, sigma applied), cond [B, n_mel, frames]."""
+        """efficient_model_ax.py:279-357: z [B, T] (noise, sigma applied), cond [B, n_mel(*2), frames]."""
         device = cond.device
-        blob = self._ensure_packed(device)
+        blob, ops = self._ensure_packed(device)
         lib = _lib.lib()
         cfg = self.c_config()
         mel = cond.detach().float().contiguous()
         zz = z.detach().to(device=device, dtype=torch.float32).contiguous()
         B, T = zz.shape
-        assert mel.shape[0] == B and mel.shape[1] == self.n_mel_channels
+        assert mel.shape[0] == B and mel.shape[1] == self.n_mel_channels * (2 if self.has_logvar_channels else 1)
         key = (device, B, T)
         ws = self._ws.get(key)
         if ws is None:
@@ -228,9 +391,18 @@ class WaveGlow(nn.Module):
         audio = torch.empty(B, T, dtype=torch.float32, device=device)
         with torch.cuda.device(device):
             stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-            _lib.check(lib.ctts_waveflow_inverse_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(zz), _lib.ptr(mel),
-                                                    _lib.ptr(audio), B, T, mel.shape[2], _lib.ptr(ws),
-                                                    ws.numel() * 4, stream), "ctts_waveflow_inverse_f32")
+            if self._folded:
+                _lib.check(lib.ctts_waveflow_inverse_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(zz), _lib.ptr(mel),
+                                                        _lib.ptr(audio), B, T, mel.shape[2], _lib.ptr(ws),
+                                                        ws.numel() * 4, stream), "ctts_waveflow_inverse_f32")
+            else:
+                frames, ld = self._cond_frames(ops, mel, speaker_ids, stream)
+                _lib.check(lib.ctts_waveflow_inverse_cond_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(zz), _lib.ptr(frames),
+                                                             ld, PAD, _lib.ptr(audio), B, T, mel.shape[2], _lib.ptr(ws),
+                                                             ws.numel() * 4, stream), "ctts_waveflow_inverse_cond_f32")
+            if self.preempthasis:      # ax:351-355 (scipy lfilter on the host there; here on the device, in place)
+                _lib.check(lib.ctts_deemphasis_f32(_lib.ptr(audio), _lib.ptr(audio), B, T, float(self.preempthasis),
+                                                  stream), "ctts_deemphasis_f32")
         if return_CPU:
             audio = audio.cpu()
         return audio, None

@@ -159,9 +159,12 @@ int ctts_flow_tail_f32(const ctts_waveglow_config* cfg, const void* packed, int3
 /* ---- WaveFlow ("ax" core, waveflow=True): _4_mtw/waveglow/efficient_model_ax.py --------- */
 
 /* Constructor arguments that shape the path (efficient_model_ax.py:19-169, glow_ax.py:427-543).
- * Built option subset = BASELINE config 4: channel_mixing='permuteheight', mix_first=False, no
- * model-level cond layers / speaker embedding, WN_2d with one k=1 cond layer + linear upsampling,
- * GTU gate, res_skip=True, merge_res_skip=False, no separable conv, n_early_every > n_flows. */
+ * Built: channel_mixing='permuteheight', mix_first=False, GTU gate, res_skip=True, merge_res_skip=False,
+ * n_early_every > n_flows, linear upsampling; in-layers dense (kh*kw <= 11 taps) or separable (depthwise kh x kw
+ * + pointwise, glow_ax.py:525-531); conditioning either ONE k=1 linear WN cond layer on the mel, folded into the
+ * in-layer GEMM (BASELINE config 4), or an arbitrary per-flow stack evaluated by the caller at frame rate and
+ * handed over (cond_precomputed; SURVEY 8f.4: speaker embeddings, model-level and WN-level conv stacks with
+ * activations - composed from ctts_conv1d_f32 / ctts_embed_rows_f32 / ctts_scale_add_rows_f32). */
 typedef struct ctts_waveflow_config {
     int32_t n_mel_channels;  /* 80 */
     int32_t n_flows;         /* 8 (even) */
@@ -171,6 +174,8 @@ typedef struct ctts_waveflow_config {
     int32_t kernel_size_w;   /* 3 (odd) */
     int32_t kernel_size_h;   /* 3 */
     int32_t dilation_h;      /* 1 (all layers) */
+    int32_t seperable_conv;  /* 0 | 1  (WN_config['seperable_conv'], the reference's spelling) */
+    int32_t cond_precomputed;/* 0: mel + folded cond layer;  1: ctts_waveflow_inverse_cond_f32 */
 } ctts_waveflow_config;
 
 /* Dense, weight-norm-folded fp32 weights of one flow in checkpoint layouts
@@ -178,14 +183,16 @@ typedef struct ctts_waveflow_config {
 typedef struct ctts_waveflow_flow_weights {
     const float* start_w;      /* [C]                 WN.start (Conv2d 1->C, 1x1) */
     const float* start_b;      /* [C] */
-    const float* cond_w;       /* [2*C*n_layers][n_mel]   WN.cond_layers.0 (k=1) */
+    const float* cond_w;       /* [2*C*n_layers][n_mel]   WN.cond_layers.0 (k=1); NULL if cond_precomputed */
     const float* cond_b;       /* [2*C*n_layers] */
-    const float* const* in_w;  /* n_layers x [2C][C][kh][kw] */
+    const float* const* in_w;  /* n_layers x [2C][C][kh][kw]; separable: the pointwise [2C][C] (in_layers.i.1) */
     const float* const* in_b;  /* n_layers x [2C] */
     const float* const* rs_w;  /* n_layers x [2C or C][C] */
     const float* const* rs_b;
     const float* end_w;        /* [2][C] (row 0 = log_s, row 1 = t; efficient_modules.py:61) */
     const float* end_b;        /* [2] */
+    const float* const* dw_w;  /* separable only: n_layers x [C][kh][kw]  depthwise (in_layers.i.0), else NULL */
+    const float* const* dw_b;  /* n_layers x [C] */
 } ctts_waveflow_flow_weights;
 
 size_t ctts_waveflow_packed_bytes(const ctts_waveflow_config* cfg);
@@ -201,6 +208,26 @@ int ctts_waveflow_inverse_f32(const ctts_waveflow_config* cfg, const void* packe
                               const float* mel, float* audio, int32_t batch, int32_t samples,
                               int32_t frames, void* workspace, size_t workspace_bytes,
                               void* stream);
+
+/* Same, for cond_precomputed models: cond [n_flows][B][2*C*n_layers][cond_ld] fp32 = the output of each flow's
+ * WN conditioning stack at FRAME rate (glow_ax.py:566-577), valid frames at columns [cond_pad, cond_pad+frames);
+ * upsampling (gax:545-554) and the per-layer slicing (gax:580-592) happen inside. */
+int ctts_waveflow_inverse_cond_f32(const ctts_waveflow_config* cfg, const void* packed, const float* z,
+                                   const float* cond, int32_t cond_ld, int32_t cond_pad, float* audio,
+                                   int32_t batch, int32_t samples, int32_t frames, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+
+/* Small operators the conditioning stacks and the output stage are composed from (padded row layout as for
+ * ctts_conv1d_f32: x [B][C][ld], valid columns [pad, pad+T)):
+ *   embed_rows:     x[b][row0 + e][pad .. pad+T) = table[ids[b]][e]          (speaker embedding concat, ax:286-291)
+ *   scale_add_rows: y = alpha * x + r   (r may be NULL; alpha read from the device: the rezero parameter, ax:299-307)
+ *   deemphasis:     y[n] = x[n] + p * y[n-1] per utterance, fp64 recurrence like scipy.signal.lfilter (ax:351-355);
+ *                   in place (y == x) allowed */
+int ctts_embed_rows_f32(const float* table, const int64_t* ids, float* x, int32_t row0, int32_t embed_dim,
+                        int32_t batch, int32_t C, int32_t T, int32_t ld, int32_t pad, void* stream);
+int ctts_scale_add_rows_f32(const float* x, const float* alpha_dev, const float* r, float* y, int32_t batch,
+                            int32_t C, int32_t T, int32_t ld, int32_t pad, void* stream);
+int ctts_deemphasis_f32(const float* x, float* y, int32_t batch, int32_t T, double p, void* stream);
 
 /* ---- Tacotron2-TM decoder loop: _2_ttm/tacotron2_tm/model.py:668-767, 851-916 -------------- */
 

@@ -12,11 +12,19 @@ Reference lines followed (relative to /root/reference/CookieTTS/_4_mtw/waveglow/
                      :36-43, res/skip :615-626, end :628)
   waveflow_infer     efficient_model_ax.py:359-388 (pad one zero frame, samples, trim hop)
 
+  model-level cond   efficient_model_ax.py:280-306 (shift/scale :280-283, speaker embedding concat :286-291, conv
+                     stack + activation after EVERY layer :293-297, rezero alpha :299-300, residual :302-307)
+  activation names   efficient_model_ax.py:100-111 = glow_ax.py:493-504: 'lrelu' selects F.relu and 'relu' selects
+                     LeakyReLU(negative_slope) - the reference's own (swapped) mapping, restated as is
+  WN-level cond      glow_ax.py:566-577 (WN speaker embedding concat, stack, activation after the last layer only if
+                     cond_out_activation_func)
+  separable in-layer glow_ax.py:525-531 (depthwise Conv2d groups=C, then pointwise 1x1 C->2C, both weight-normed)
+  de-emphasis        efficient_model_ax.py:351-355 (scipy.signal.lfilter([1],[1,-p]) in float64, cast back)
+
 Parity pin: tests/golden/waveflow_*.npz = outputs of the reference's own ``inverse(z, cond)`` /
-``infer`` (tests/golden/make_golden.py).  Restrictions (config 4's option subset): waveflow=True,
-channel_mixing='permuteheight', mix_first=False, model-level cond_layers=0, no speaker embedding,
-WN cond_layers=1 with kernel 1, no separable conv, res_skip=True, merge_res_skip=False, GTU gate,
-n_early_every > n_flows.
+``infer`` (tests/golden/make_golden.py).  Restrictions: waveflow=True, channel_mixing='permuteheight',
+mix_first=False, res_skip=True, merge_res_skip=False, GTU gate, n_early_every > n_flows, no transposed-conv
+upsampling, height dilation as configured.
 """
 from __future__ import annotations
 
@@ -58,6 +66,65 @@ def lerp_align_corners(x, out_len):
     return (l0 * x[..., i0] + l1 * x[..., i1]).astype(F32)
 
 
+def activation(name, negative_slope):
+    """The reference's name -> function table (ax:100-111, gax:493-504), quirk included."""
+    name = (name or 'none').lower()
+    if name == 'none':
+        return None
+    if name == 'lrelu':
+        return lambda x: np.maximum(x, F32(0))
+    if name == 'relu':
+        return lambda x: np.where(x >= 0, x, x * F32(negative_slope)).astype(F32)
+    if name == 'tanh':
+        return np.tanh
+    if name == 'sigmoid':
+        return lambda x: (F32(1) / (F32(1) + np.exp(-x))).astype(F32)
+    raise NotImplementedError(name)
+
+
+def conv1d_same(x, w, b):
+    """Conv1d, odd kernel, zero padding (k-1)/2: x [B, Cin, T], w [Cout, Cin, k] -> [B, Cout, T]."""
+    k = w.shape[2]
+    y = np.zeros((x.shape[0], w.shape[0], x.shape[2]), F32) + b[None, :, None]
+    for j in range(k):
+        y = y + np.matmul(np.ascontiguousarray(w[:, :, j]), _shift(x, j - k // 2))
+    return y.astype(F32)
+
+
+def model_cond(sd, cfg, mel, speaker_ids=None):
+    """efficient_model_ax.py:280-307: what every flow's WN receives as `cond` (frame rate)."""
+    cond = np.asarray(mel, dtype=F32)
+    if cfg.get("shift_spect", 0.) != 0.:
+        cond = cond + F32(cfg["shift_spect"])
+    if cfg.get("scale_spect", 1.) != 1.:
+        cond = cond * F32(cfg["scale_spect"])
+    if cfg["speaker_embed"]:
+        emb = sd["speaker_embed.weight"][np.asarray(speaker_ids)]
+        cond = np.concatenate([cond, np.repeat(emb[:, :, None], cond.shape[2], axis=2)], axis=1)
+    if not cfg["cond_layers"]:
+        return cond.astype(F32)                                   # empty stack: cond_res is cond itself
+    act = activation(cfg.get("cond_activation_func", 'none'), cfg.get("negative_slope"))
+    res = cond
+    for l in range(cfg["cond_layers"]):
+        res = conv1d_same(res, _w(sd, f"cond_layers.{l}"), sd[f"cond_layers.{l}.bias"])
+        if act is not None:
+            res = act(res).astype(F32)
+    if "alpha" in sd:
+        res = res * sd["alpha"][0]
+    return (cond + res if cfg["cond_residual"] else res).astype(F32)
+
+
+def deemphasis(x, p):
+    """y[n] = x[n] + p*y[n-1] in float64 like scipy.signal.lfilter([1],[1,-p]) (ax:351-355)."""
+    y = np.empty(x.shape, np.float64)
+    acc = np.zeros(x.shape[0], np.float64)
+    xd = x.astype(np.float64)
+    for n in range(x.shape[1]):
+        acc = xd[:, n] + float(p) * acc
+        y[:, n] = acc
+    return y.astype(F32)
+
+
 def _shift(x, s):
     if s == 0:
         return x
@@ -69,7 +136,7 @@ def _shift(x, s):
     return y
 
 
-def waveflow_inverse(sd, cfg, z, mel):
+def waveflow_inverse(sd, cfg, z, mel, speaker_ids=None):
     """z [B, T] (sigma applied), mel [B, n_mel, F'] (already padded by infer) -> audio [B, T]."""
     sd = {k: np.asarray(v, dtype=F32) for k, v in sd.items()}
     G, n_flows = cfg["n_group"], cfg["n_flows"]
@@ -82,14 +149,28 @@ def waveflow_inverse(sd, cfg, z, mel):
     B, T = z.shape
     L = T // G
     a = np.ascontiguousarray(z.reshape(B, L, G).transpose(0, 2, 1))        # a[b, g, l] = z[b, G*l + g]
+    frames = model_cond(sd, cfg, mel, speaker_ids)
+    wn_act = activation(wn.get("cond_activation_func", 'none'), wn.get("negative_slope"))
+    sep = bool(wn.get("seperable_conv")) and not (kh == 1 and kw == 1)
     for k in reversed(range(n_flows)):
         p = f"WN.{k}.WN"
         a = a[:, permutation(k, G), :]
-        wc = _w(sd, p + ".cond_layers.0")[:, :, 0]
-        cond = lerp_align_corners(np.matmul(wc, mel) + sd[p + ".cond_layers.0.bias"][None, :, None], L)
+        spect = frames
+        if wn.get("speaker_embed_dim", 0):
+            emb = sd[p + ".speaker_embed.weight"][np.asarray(speaker_ids)]
+            spect = np.concatenate([spect, np.repeat(emb[:, :, None], spect.shape[2], axis=2)], axis=1)
+        for l in range(wn["cond_layers"]):
+            spect = conv1d_same(spect, _w(sd, f"{p}.cond_layers.{l}"), sd[f"{p}.cond_layers.{l}.bias"])
+            if wn_act is not None and (wn.get("cond_out_activation_func", True) or l != wn["cond_layers"] - 1):
+                spect = wn_act(spect).astype(F32)
+        cond = lerp_align_corners(spect, L)
         ws = _w(sd, p + ".start").reshape(C)
         bs = sd[p + ".start.bias"]
-        win = [_w(sd, f"{p}.in_layers.{i}") for i in range(n_layers)]          # [2C, C, kh, kw]
+        if sep:
+            wdw = [_w(sd, f"{p}.in_layers.{i}.0")[:, 0] for i in range(n_layers)]            # [C, kh, kw]
+            wpw = [_w(sd, f"{p}.in_layers.{i}.1")[:, :, 0, 0] for i in range(n_layers)]      # [2C, C]
+        else:
+            win = [_w(sd, f"{p}.in_layers.{i}") for i in range(n_layers)]      # [2C, C, kh, kw]
         wrs = [_w(sd, f"{p}.res_skip_layers.{i}")[:, :, 0, 0] for i in range(n_layers)]
         wend = sd[p + ".end.weight"][:, :, 0, 0]
         bend = sd[p + ".end.bias"]
@@ -103,11 +184,20 @@ def waveflow_inverse(sd, cfg, z, mel):
                 pad = ((kw - 1) * dw) // 2
                 Q = np.concatenate([queues[i], x[:, :, None, :]], axis=2)      # [B, C, (kh-1)dh+1, L]
                 queues[i] = Q[:, :, 1:, :] if (kh - 1) * dh > 0 else queues[i]
-                u = (sd[f"{p}.in_layers.{i}.bias"][None, :, None] + cond[:, 2 * C * i:2 * C * (i + 1), :]).astype(F32)
-                for ah in range(kh):
-                    row = Q[:, :, ah * dh, :]
-                    for j in range(kw):
-                        u = u + np.matmul(np.ascontiguousarray(win[i][:, :, ah, j]), _shift(row, j * dw - pad))
+                if sep:
+                    d = np.zeros((B, C, L), F32) + sd[f"{p}.in_layers.{i}.0.bias"][None, :, None]
+                    for ah in range(kh):
+                        row = Q[:, :, ah * dh, :]
+                        for j in range(kw):
+                            d = d + wdw[i][None, :, ah, j, None] * _shift(row, j * dw - pad)
+                    u = (np.matmul(wpw[i], d.astype(F32)) + sd[f"{p}.in_layers.{i}.1.bias"][None, :, None]
+                         + cond[:, 2 * C * i:2 * C * (i + 1), :])
+                else:
+                    u = (sd[f"{p}.in_layers.{i}.bias"][None, :, None] + cond[:, 2 * C * i:2 * C * (i + 1), :]).astype(F32)
+                    for ah in range(kh):
+                        row = Q[:, :, ah * dh, :]
+                        for j in range(kw):
+                            u = u + np.matmul(np.ascontiguousarray(win[i][:, :, ah, j]), _shift(row, j * dw - pad))
                 u = u.astype(F32)
                 act = (np.tanh(u[:, :C]) * (F32(1.0) / (F32(1.0) + np.exp(-u[:, C:])))).astype(F32)
                 rs = np.matmul(wrs[i], act) + sd[f"{p}.res_skip_layers.{i}.bias"][None, :, None]
@@ -122,10 +212,13 @@ def waveflow_inverse(sd, cfg, z, mel):
                 y.append(((a[:, r + 1, :] - t) / np.exp(log_s)).astype(F32))
         a = np.stack(y, axis=1)
         a = np.where(np.isnan(a), F32(0), a).astype(F32)
-    return np.ascontiguousarray(a.transpose(0, 2, 1)).reshape(B, T)
+    audio = np.ascontiguousarray(a.transpose(0, 2, 1)).reshape(B, T)
+    if cfg.get("preempthasis"):
+        audio = deemphasis(audio, cfg["preempthasis"])
+    return audio
 
 
-def waveflow_infer(sd, cfg, mel, z, artifact_trimming=1):
+def waveflow_infer(sd, cfg, mel, z, artifact_trimming=1, speaker_ids=None):
     """infer() wrapper: pad `artifact_trimming` zero frames, z [B, F*hop], drop the last hop samples."""
     mel = np.asarray(mel, dtype=F32)
     hop = cfg["hop_length"]
@@ -133,5 +226,5 @@ def waveflow_infer(sd, cfg, mel, z, artifact_trimming=1):
     samples = (melp.shape[2] - 1) * hop
     samples -= samples % cfg["n_group"]
     assert z.shape == (mel.shape[0], samples), (z.shape, samples)
-    audio = waveflow_inverse(sd, cfg, z, melp)
+    audio = waveflow_inverse(sd, cfg, z, melp, speaker_ids)
     return audio[:, :-artifact_trimming * hop] if artifact_trimming > 0 else audio

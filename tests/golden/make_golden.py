@@ -210,26 +210,36 @@ def _ref_waveflow(cfg, sd_np):
 def make_waveflow():
     import copy
     torch.set_num_threads(8)
-    cases = [("toy", "toy", 2, 6, 0.7, 5), ("toy_odd", "toy", 1, 11, 1.0, 6), ("full_short", "full", 1, 5, 0.6, 1234)]
+    cases = [("toy", "toy", 2, 6, 0.7, 5), ("toy_odd", "toy", 1, 11, 1.0, 6), ("full_short", "full", 1, 5, 0.6, 1234),
+             # SURVEY 8f.4 option set: speaker ids, cond stacks, separable in-layers, logvar channels, de-emphasis
+             ("author_toy", "author_toy", 2, 6, 0.7, 3), ("author_short", "author", 1, 3, 0.6, 4)]
+    only = [a for a in sys.argv[2:]]
     for name, key, B, F, sigma, seed in cases:
+        if only and name not in only:
+            continue
         cfg = synthetic.WAVEFLOW_CONFIGS[key]
         sd = synthetic.waveflow_state_dict(cfg, seed=seed)
         model = _ref_waveflow(copy.deepcopy(cfg), sd)
-        mel = synthetic.synthetic_mel(B, F, cfg["n_mel_channels"], seed=seed)
+        n_in = cfg["n_mel_channels"] * (2 if cfg.get("use_logvar_channels") else 1)
+        mel = synthetic.synthetic_mel(B, F, n_in, seed=seed)
+        multispeaker = bool(cfg["speaker_embed"] or cfg["WN_config"]["speaker_embed_dim"])
+        ids = np.array([3, 17, 250, 511][:B], np.int64) if multispeaker else None
+        tids = None if ids is None else torch.from_numpy(ids)
         # the reference's own infer() (ax:359-388); the noise it draws is replayed from the same seed
         torch.manual_seed(seed)
         z = torch.empty(B, F * cfg["hop_length"]).normal_(std=sigma).numpy()
         torch.manual_seed(seed)
         with torch.no_grad():
-            audio = model.infer(torch.from_numpy(mel.copy()), sigma=sigma).numpy()
+            audio = model.infer(torch.from_numpy(mel.copy()), speaker_ids=tids, sigma=sigma).numpy()
             melp = np.pad(mel, ((0, 0), (0, 0), (0, 1)))
-            inv, _ = model.inverse(torch.from_numpy(z.copy()), torch.from_numpy(melp.copy()))
+            inv, _ = model.inverse(torch.from_numpy(z.copy()), torch.from_numpy(melp.copy()), speaker_ids=tids)
         inv = inv.numpy()
         assert audio.shape == (B, (F - 1) * cfg["hop_length"]) and np.isfinite(audio).all()
         assert np.array_equal(inv[:, :audio.shape[1]], audio), "noise replay out of sync with infer()"
         path = os.path.join(HERE, f"waveflow_{name}.npz")
+        extra = {} if ids is None else {"speaker_ids": ids}
         np.savez_compressed(path, config_key=key, seed=seed, sigma=np.float32(sigma), mel=mel, z=z, audio=audio,
-                            inverse_full=inv.astype(np.float32))
+                            inverse_full=inv.astype(np.float32), **extra)
         print(f"[golden] waveflow {name}: audio {audio.shape} rms={audio.std():.4f} -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 

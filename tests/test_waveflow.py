@@ -19,14 +19,30 @@ def _load(name):
     return g, cfg, synthetic.waveflow_state_dict(cfg, seed=int(g["seed"]))
 
 
-@pytest.mark.parametrize("name", ["toy", "toy_odd", "full_short"])
+ALL = ["toy", "toy_odd", "full_short", "author_toy", "author_short"]     # author_*: SURVEY 8f.4 option set
+
+
+def _ids(g):
+    return g["speaker_ids"] if "speaker_ids" in g.files else None
+
+
+@pytest.mark.parametrize("name", ALL)
 def test_oracle_matches_reference(name):
     g, cfg, sd = _load(name)
-    out = wf.waveflow_infer(sd, cfg, g["mel"], g["z"])
+    out = wf.waveflow_infer(sd, cfg, g["mel"], g["z"], speaker_ids=_ids(g))
     assert out.shape == g["audio"].shape                       # (F-1)*hop samples
     assert rms_rel_err(out, g["audio"]) < ORACLE_TOL
     melp = np.pad(g["mel"], ((0, 0), (0, 0), (0, 1)))
-    assert rms_rel_err(wf.waveflow_inverse(sd, cfg, g["z"], melp), g["inverse_full"]) < ORACLE_TOL
+    assert rms_rel_err(wf.waveflow_inverse(sd, cfg, g["z"], melp, _ids(g)), g["inverse_full"]) < ORACLE_TOL
+
+
+def test_activation_table_restates_the_reference_mapping():
+    """ax:100-111: 'lrelu' is F.relu, 'relu' is LeakyReLU(negative_slope) - as written in the reference."""
+    x = np.array([-2.0, 3.0], np.float32)
+    assert list(wf.activation('lrelu', 0.25)(x)) == [0.0, 3.0]
+    assert list(wf.activation('relu', 0.25)(x)) == [-0.5, 3.0]
+    from cookietts_amd.waveglow_ax import _act_code
+    assert _act_code('lrelu', 0.25) == (1, 0.0) and _act_code('relu', 0.25) == (1, 0.25) and _act_code('none', None) == (0, 0.0)
 
 
 def test_permutation_is_involution_and_matches_reference_pattern():
@@ -48,7 +64,7 @@ def test_nan_is_zeroed_per_flow():
 
 def test_host_state_dict_keys_match_reference_format():
     from cookietts_amd.waveglow_ax import WaveGlow
-    for key in ("toy", "full"):
+    for key in ("toy", "full", "author_toy", "author"):
         cfg = synthetic.WAVEFLOW_CONFIGS[key]
         sd = synthetic.waveflow_state_dict(cfg, seed=1)
         m = WaveGlow(**cfg)
@@ -71,12 +87,13 @@ def _model(key, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["toy", "toy_odd", "full_short"])
+@pytest.mark.parametrize("name", ALL)
 def test_hip_matches_reference_golden(hip_lib_path, name):
     g, cfg, _ = _load(name)
     m, _, _ = _model(str(g["config_key"]), int(g["seed"]))
     melp = torch.from_numpy(np.pad(g["mel"], ((0, 0), (0, 0), (0, 1)))).cuda()
-    audio, _ = m.inverse(torch.from_numpy(g["z"]).cuda(), melp)
+    ids = None if _ids(g) is None else torch.from_numpy(_ids(g)).cuda()
+    audio, _ = m.inverse(torch.from_numpy(g["z"]).cuda(), melp, speaker_ids=ids)
     assert not audio.is_cuda                                   # return_CPU=True default (ax:348-349)
     err = rms_rel_err(audio.numpy(), g["inverse_full"])
     print(f"waveflow {name}: rms rel err vs reference = {err:.3e}")
@@ -115,3 +132,28 @@ def test_fused_res_skip_epilogue_matches_two_kernel_path(hip_lib_path, monkeypat
     plain, _ = m.inverse(z, melp)
     assert rms_rel_err(plain.numpy(), g["inverse_full"]) < WAVE_TOL
     assert rms_rel_err(fused.numpy(), plain.numpy()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_author_options_ragged_vs_oracle_and_speaker_requirement(hip_lib_path):
+    """8f.4 option set at a width that is not a multiple of 4 or of the 256-column tile, batch 3, both fused
+    (C = 64) and two-kernel res/skip paths; a multispeaker model refuses to run without speaker ids (ax:288)."""
+    m, cfg, sd = _model("author_toy", 12)
+    B, Fr = 3, 71
+    n_in = cfg["n_mel_channels"] * 2
+    mel = synthetic.synthetic_mel(B, Fr, n_in, seed=8)
+    ids = np.array([0, 511, 42], np.int64)
+    z = (np.random.default_rng(9).standard_normal((B, (Fr - 1) * cfg["hop_length"])) * 0.8).astype(np.float32)
+    ref = wf.waveflow_inverse(sd, cfg, z, mel, ids)
+    got, _ = m.inverse(torch.from_numpy(z).cuda(), torch.from_numpy(mel).cuda(), speaker_ids=torch.from_numpy(ids).cuda())
+    assert rms_rel_err(got.numpy(), ref) < WAVE_TOL
+    os.environ["CTTS_WF_NO_FUSE"] = "1"
+    try:
+        plain, _ = m.inverse(torch.from_numpy(z).cuda(), torch.from_numpy(mel).cuda(), speaker_ids=torch.from_numpy(ids).cuda())
+    finally:
+        del os.environ["CTTS_WF_NO_FUSE"]
+    assert rms_rel_err(plain.numpy(), ref) < WAVE_TOL
+    with pytest.raises(Exception, match="requires speaker ids"):
+        m.inverse(torch.from_numpy(z).cuda(), torch.from_numpy(mel).cuda())
+    out = m.infer(torch.from_numpy(mel).cuda(), speaker_ids=torch.from_numpy(ids).cuda(), sigma=0.7, return_CPU=False)
+    assert out.is_cuda and out.shape == (B, (Fr - 1) * cfg["hop_length"]) and torch.isfinite(out).all()
