@@ -344,6 +344,62 @@ __global__ __launch_bounds__(256) void deemphasis_kernel(const float* __restrict
     for (int n = n0; n < n1; ++n) { s = (double)xb[n] + p * s; yb[n] = (float)s; }
 }
 
+// Vector form: a thread owns 4 consecutive columns (16-byte aligned) of one channel.  DW = 0 stands for any width
+// dilation that is a multiple of 4: every tap is then ONE aligned 16-byte load for the 4 columns; for DW = 1, 2 the
+// taps of the 4 columns overlap, so an aligned window [l - 4*HW, l + 4 + 4*HW) is loaded once per height tap and the
+// taps are picked out of registers (compile-time indices).
+template <int KW, int DW>
+__global__ __launch_bounds__(256) void wf_depthwise_vec_kernel(WfSlots x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                               int C, int kh, int dw, int a_min, int L, int ld, int pad) {
+    const int l = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (l >= L) return;
+    const size_t row = ((size_t)b * C + c) * ld + pad + l;
+    const float* wc = w + (size_t)c * kh * KW;
+    const float bc = bias[c];
+    float acc[4] = {bc, bc, bc, bc};
+    for (int a = a_min; a < kh; ++a) {
+        const float* xa = x.p[a] + row;
+        if constexpr (DW == 0) {
+#pragma unroll
+            for (int j = 0; j < KW; ++j) {
+                const float4 v = *reinterpret_cast<const float4*>(xa + (j - KW / 2) * dw);
+                const float wj = wc[a * KW + j];
+                acc[0] = fmaf(wj, v.x, acc[0]); acc[1] = fmaf(wj, v.y, acc[1]);
+                acc[2] = fmaf(wj, v.z, acc[2]); acc[3] = fmaf(wj, v.w, acc[3]);
+            }
+        } else {
+            constexpr int HW = ((KW / 2) * DW + 3) / 4;          // float4s on each side of the centre one
+            float win[4 * (2 * HW + 1)];
+#pragma unroll
+            for (int q = 0; q < 2 * HW + 1; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(xa + 4 * (q - HW));
+                win[4 * q] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < KW; ++j) {
+                const float wj = wc[a * KW + j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(wj, win[4 * HW + e + (j - KW / 2) * DW], acc[e]);
+            }
+        }
+    }
+    // columns >= L are halo and must stay zero
+    float4 o;
+    o.x = acc[0];
+    o.y = l + 1 < L ? acc[1] : 0.f; o.z = l + 2 < L ? acc[2] : 0.f; o.w = l + 3 < L ? acc[3] : 0.f;
+    *reinterpret_cast<float4*>(y + row) = o;
+}
+
+template <int KW>
+void launch_depthwise_vec(dim3 grid, hipStream_t s, const WfSlots& xs, const float* w, const float* b, float* y, int C,
+                          int kh, int dw, int a_min, int L, int ld, int pad) {
+    if (dw == 1) hipLaunchKernelGGL((wf_depthwise_vec_kernel<KW, 1>), grid, dim3(256), 0, s, xs, w, b, y, C, kh, dw, a_min, L, ld, pad);
+    else if (dw == 2) hipLaunchKernelGGL((wf_depthwise_vec_kernel<KW, 2>), grid, dim3(256), 0, s, xs, w, b, y, C, kh, dw, a_min, L, ld, pad);
+    else hipLaunchKernelGGL((wf_depthwise_vec_kernel<KW, 0>), grid, dim3(256), 0, s, xs, w, b, y, C, kh, dw, a_min, L, ld, pad);
+}
+
 void wf_permutation(int k, int G, int* perm) {
     for (int g = 0; g < G; ++g) perm[g] = G - 1 - g;                       // reverse (k % 4 in {0,1})
     if (k % 4 == 2 || k % 4 == 3) {                                        // reverse each half separately
@@ -425,8 +481,14 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
                 if (p.sep) {
                     WfSlots xs{};
                     for (int ah = a_min; ah < kh; ++ah) xs.p[ah] = X(i, (r - (kh - 1 - ah)) % kh);
-                    hipLaunchKernelGGL(wf_depthwise_kernel, dim3((L + 255) / 256, C, batch), dim3(256), 0, s, xs,
-                                       blob + f.dw_w[i], blob + f.dw_b[i], w.dwout, C, kh, kw, dw, a_min, L, g.ld, g.pad);
+                    const dim3 vgrid(((L + 3) / 4 + 255) / 256, C, batch);
+                    const bool vec = g.pad % 4 == 0 && g.ld % 4 == 0 && (dw <= 2 || dw % 4 == 0);
+                    if (vec && kw == 7) launch_depthwise_vec<7>(vgrid, s, xs, blob + f.dw_w[i], blob + f.dw_b[i], w.dwout, C, kh, dw, a_min, L, g.ld, g.pad);
+                    else if (vec && kw == 5) launch_depthwise_vec<5>(vgrid, s, xs, blob + f.dw_w[i], blob + f.dw_b[i], w.dwout, C, kh, dw, a_min, L, g.ld, g.pad);
+                    else if (vec && kw == 3) launch_depthwise_vec<3>(vgrid, s, xs, blob + f.dw_w[i], blob + f.dw_b[i], w.dwout, C, kh, dw, a_min, L, g.ld, g.pad);
+                    else
+                        hipLaunchKernelGGL(wf_depthwise_kernel, dim3((L + 255) / 256, C, batch), dim3(256), 0, s, xs,
+                                           blob + f.dw_w[i], blob + f.dw_b[i], w.dwout, C, kh, kw, dw, a_min, L, g.ld, g.pad);
                     CTTS_CHECK_LAUNCH("wf_depthwise");
                     a.a_ch_off = 0;
                     a.seg[ns++] = {w.dwout, cstride, p.nch_c, 0, 0, 0};

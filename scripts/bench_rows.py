@@ -45,6 +45,25 @@ def row_waveflow(args):
             "achieved_tflops_algorithmic": 2 * mac * samples / dt / 1e12}
 
 
+def row_waveflow_author(args):
+    """the option set / sizes of the author's own WaveFlow checkpoints (48 kHz, hop 600, n_group 20,
+    128 channels, separable 7x7 in-layers, speaker embeddings, 5 + 3 layer conditioning stacks, de-emphasis)."""
+    from cookietts_amd.waveglow_ax import WaveGlow
+    cfg = synthetic.WAVEFLOW_CONFIGS["author"]
+    m = WaveGlow(**cfg)
+    m.load_state_dict(synthetic.to_torch(synthetic.waveflow_state_dict(cfg, seed=1234)))
+    m = m.cuda().eval()
+    B, F = 8, 400
+    mel = torch.from_numpy(synthetic.synthetic_mel(B, F, cfg["n_mel_channels"] * 2)).cuda()
+    ids = torch.arange(B).cuda()
+    dt = timed(lambda: m.infer(mel, speaker_ids=ids, sigma=0.6, return_CPU=False), args.warmup, args.steps)
+    samples = B * (F - 1) * cfg["hop_length"]
+    return {"row": "B/8f.4", "metric": "audio samples/sec (48kHz) WaveFlow infer, author's option set (8 flows, 128 ch, "
+                                       "h=20, separable 7x7, speaker + cond stacks), 320x400 mel",
+            "value": samples / dt, "unit": "samples/s", "rtf": samples / dt / cfg["sampling_rate"],
+            "ms_per_call": dt * 1e3, "dtype": "f32", "batch": B, "frames": F}
+
+
 def row_tacotron(args):
     from cookietts_amd.tacotron2 import Tacotron2
     hp = synthetic.tacotron_hparams()
@@ -88,6 +107,6 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     args = ap.parse_args()
-    fns = {"waveflow": row_waveflow, "tacotron": row_tacotron, "stft": row_stft}
+    fns = {"waveflow": row_waveflow, "waveflow_author": row_waveflow_author, "tacotron": row_tacotron, "stft": row_stft}
     for r in args.rows.split(","):
         print(json.dumps(fns[r](args)), flush=True)
