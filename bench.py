@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="utterances per GPU (config 2: 8)")
     ap.add_argument("--frames", type=int, default=900)
     ap.add_argument("--config", default="full", help="key of cookietts_amd.synthetic.WAVEGLOW_CONFIGS")
-    ap.add_argument("--cpu-frames", type=int, default=48, help="mel frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=128, help="mel frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = BASELINE config 2 (default, the headline); bf16 = config 3 (use --batch 32)")
