@@ -41,6 +41,7 @@ struct BGemmArgs {
     bf16_t* dst1; long long dst1_bstride; int acc1;
     int split;            // SPLIT: rows < split -> dst0, else dst1[row - split] (multiple of 32)
     int pairC;            // GATE: channels (dense rows c and pairC + c)
+    int map_mode;         // block id -> (m-block, tile, batch) mapping, chosen by the launcher
 };
 
 // dense weight row of block-local row r of M-block mb (same pairing as the fp32 kernel), -1 = padding

@@ -170,10 +170,22 @@ __global__ __launch_bounds__(128 * NW, 2) void conv_gemm_bf16_kernel(const BGemm
     const int l31 = lane & 31, lhi = lane >> 5;
 
     int id = blockIdx.x;
-    const int mb = id % a.MB;
-    id /= a.MB;
-    const int tile = id % a.ntiles;
-    const int b = id / a.ntiles;
+    int mb, tile, b;
+    if (a.map_mode == 1) {
+        // MB == 4: XCD x (= id % 8) owns the m-block pair {2(x&1), 2(x&1)+1} of the column tiles t = 4q + (x>>1), the
+        // two m-blocks of a tile on consecutive ids: the B tile goes through 2 private L2s instead of 4
+        const int x = id & 7, j = id >> 3;
+        mb = 2 * (x & 1) + (j & 1);
+        const int gt = (j >> 1) * 4 + (x >> 1);
+        if (gt >= a.ntiles * a.batch) return;            // whole workgroup: the grid is rounded up to 4 tiles
+        tile = gt % a.ntiles;
+        b = gt / a.ntiles;
+    } else {
+        mb = id % a.MB;
+        id /= a.MB;
+        tile = id % a.ntiles;
+        b = id / a.ntiles;
+    }
     const int n0 = tile * BN;
 
     // per-thread B staging: units (g, n) with g = t / BN (+2), n = t % BN
@@ -349,10 +361,22 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_bf16_pp_kernel(const BGemmAr
     const int l31 = lane & 31, lhi = lane >> 5;
 
     int id = blockIdx.x;
-    const int mb = id % a.MB;
-    id /= a.MB;
-    const int tile = id % a.ntiles;
-    const int b = id / a.ntiles;
+    int mb, tile, b;
+    if (a.map_mode == 1) {
+        // MB == 4: XCD x (= id % 8) owns the m-block pair {2(x&1), 2(x&1)+1} of the column tiles t = 4q + (x>>1), the
+        // two m-blocks of a tile on consecutive ids: the B tile goes through 2 private L2s instead of 4
+        const int x = id & 7, j = id >> 3;
+        mb = 2 * (x & 1) + (j & 1);
+        const int gt = (j >> 1) * 4 + (x >> 1);
+        if (gt >= a.ntiles * a.batch) return;            // whole workgroup: the grid is rounded up to 4 tiles
+        tile = gt % a.ntiles;
+        b = gt / a.ntiles;
+    } else {
+        mb = id % a.MB;
+        id /= a.MB;
+        tile = id % a.ntiles;
+        b = id / a.ntiles;
+    }
     const int n0 = tile * BN;
     const int nch = a.nch_total;
 
@@ -575,7 +599,12 @@ int launch_gemm_bf16(int epi, const BGemmArgs& a, hipStream_t stream) {
                                          : (b.M % 32 == 0 && b.split % 32 == 0 && b.M > (b.MB - 1) * BGEMM_BM &&
                                             b.M <= b.MB * BGEMM_BM),
                    "gemm_bf16: M=%d pairC=%d MB=%d split=%d", b.M, b.pairC, b.MB, b.split);
-    const long long blocks = (long long)b.MB * b.ntiles * b.batch;
+    long long blocks = (long long)b.MB * b.ntiles * b.batch;
+    b.map_mode = 0;
+    if (b.MB == 4 && !getenv("CTTS_GEMM_NO_XCD_PAIR")) {
+        b.map_mode = 1;
+        blocks = 16ll * (((long long)b.ntiles * b.batch + 3) / 4);
+    }
     CTTS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "gemm_bf16: grid %lld", blocks);
     const dim3 grid((unsigned)blocks);
     if (epi == BGEMM_EPI_GATE) {

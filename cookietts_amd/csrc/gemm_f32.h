@@ -79,6 +79,7 @@ struct GemmArgs {
     // GATE / GATE_RS: optional per-element addend before the gate (conditioning computed elsewhere), padded layout
     // [B][2*pairC][ld] in DENSE row order (row c -> tanh input, row pairC + c -> sigmoid input), same ld / pad as B
     const float* addend; long long addend_bstride;
+    int map_mode;         // block id -> (m-block, tile, batch) mapping, chosen by the launcher (see gemm_f32.hip)
     const float* rs_wT;   // GEMM_EPI_GATE_RS: res/skip weight transposed and row-padded: [64][128]
     const float* rs_bias; // [128] (rows >= rs_rows zero)
     int rs_rows;          // 128 (res + skip) or 64 (last layer: skip only)

@@ -11,6 +11,8 @@
 //   Global->LDS staging goes through registers and is issued one chunk ahead of the MFMAs
 //   (the f32 MFMA rate leaves >10x headroom on the load path); the LDS->MFMA software
 //   pipeline is pinned with sched_group_barrier.
+#include <cstdlib>
+
 #include "gemm_f32.h"
 
 namespace ctts {
@@ -116,10 +118,22 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
     // block -> (m-block, n-tile, batch).  Dispatch places block id on XCD id % 8, so with
     // mb = id % MB an XCD keeps re-using the same 1-2 weight slices in its private L2.
     int id = blockIdx.x;
-    const int mb = id % a.MB;
-    id /= a.MB;
-    const int tile = id % a.ntiles;
-    const int b = id / a.ntiles;
+    int mb, tile, b;
+    if (a.map_mode == 1) {
+        // MB == 4 variant: XCD x owns the m-block PAIR {2(x&1), 2(x&1)+1} of the column tiles t = 4q + (x>>1); the
+        // two m-blocks of one tile are consecutive ids of that XCD, so the B tile is fetched into 2 L2s, not 4.
+        const int x = id & 7, j = id >> 3;
+        mb = 2 * (x & 1) + (j & 1);
+        const int gt = (j >> 1) * 4 + (x >> 1);
+        if (gt >= a.ntiles * a.batch) return;            // whole workgroup: grid is rounded up to 4 tiles
+        tile = gt % a.ntiles;
+        b = gt / a.ntiles;
+    } else {
+        mb = id % a.MB;
+        id /= a.MB;
+        tile = id % a.ntiles;
+        b = id / a.ntiles;
+    }
     const int n0 = tile * BN;
 
     // segment bases: everything except the k-row of the chunk and the per-thread (row, column) offset
@@ -412,7 +426,13 @@ int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
                                          : (a.M > (a.MB - 1) * a.bm && a.M <= a.MB * a.bm),
                    "gemm: M=%d pairC=%d MB=%d bm=%d", a.M, a.pairC, a.MB, a.bm);
     CTTS_CHECK_ARG(a.dst_ld > 0 && a.dst0, "gemm: destination not set");
-    const long long blocks = (long long)a.MB * a.ntiles * a.batch;
+    long long blocks = (long long)a.MB * a.ntiles * a.batch;
+    a.map_mode = 0;
+    // measured on config 2 (PMC FETCH_SIZE per in-layer launch): 4.2 GB -> 2.5 GB at unchanged speed
+    if (a.MB == 4 && epi != GEMM_EPI_GATE_RS && !getenv("CTTS_GEMM_NO_XCD_PAIR")) {
+        a.map_mode = 1;
+        blocks = 16ll * (((long long)a.ntiles * a.batch + 3) / 4);
+    }
     CTTS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "gemm: grid %lld", blocks);
     dim3 grid((unsigned)blocks);
     switch (epi) {
