@@ -74,7 +74,7 @@ int make_dec_plan(const ctts_taco_decoder_config* cfg, DecPlan& p) {
 }
 
 struct DecWs {
-    float *memory, *pm, *att_h[2], *att_c, *dec_h[2], *dec_c, *d2_h[2], *d2_c, *w, *cum, *ctx, *pos, *prenet, *qbuf;
+    float *memory, *pm, *att_h[2], *att_c, *dec_h[2], *dec_c, *d2_h[2], *d2_c, *w, *cum, *ctx, *pos, *prenet, *qbuf, *gp_att, *gp_dec, *gp_d2;
     int* lengths;
     size_t total;
 };
@@ -99,6 +99,9 @@ void dec_carve(const DecPlan& p, int batch, int T, float* base, DecWs& w) {
     w.pos = take(NB);
     w.prenet = take(NB * c.prenet_dim);
     w.qbuf = take(NB * c.attention_dim);
+    w.gp_att = take(NB * 4 * c.attention_rnn_dim);          // early partial pre-activations of the three cells
+    w.gp_dec = take(NB * 4 * c.decoder_rnn_dim);
+    w.gp_d2 = take(NB * 4 * c.second_decoder_rnn_dim);
     w.lengths = reinterpret_cast<int*>(take(NB));
     w.total = o;
 }
@@ -203,6 +206,17 @@ struct LstmSeq {
     float* hn; int hn_stride, hn_col;
 };
 
+// Column window of one launch.  The decoder splits every cell's matvec in two: the columns whose inputs are known
+// early (recurrent state, previous context) are summed by a `gout` launch on a side stream while the few-workgroup
+// attention / projection kernels hold the critical path, and the cell launch streams only the fresh columns and adds
+// those partial pre-activations (`gin`).  Default {nullptr, nullptr, 0, I, 1} = the whole cell in one launch.
+struct LstmPart {
+    const float* gin;   // [NB][4H] partial pre-activations to add, or NULL
+    float* gout;        // if set: write this launch's raw partial sums [NB][4H] and stop (no bias, no cell update)
+    int ih_k0, ih_k1;   // W_ih columns [ih_k0, ih_k1) (multiples of 4)
+    int do_hh;          // W_hh . h_old
+};
+
 // inputs in0|in1|in2 are [NB][n_i] row-major pieces of the concatenated cell input.
 template <int NB, int R>
 __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict__ Wih, const float* __restrict__ Whh,
@@ -211,7 +225,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
                                                         const float* __restrict__ in1, int n1,
                                                         const float* __restrict__ in2, int n2,
                                                         const float* __restrict__ h_old, float* __restrict__ h_new,
-                                                        float* __restrict__ c, const LstmSeq sq,
+                                                        float* __restrict__ c, const LstmSeq sq, const LstmPart pt,
                                                         int I, int H, int batch) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = I + H;
@@ -222,17 +236,19 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
     // first weight slab group: issued now, consumed after the staging barrier
     constexpr int CH = 4;
     float4 pre[CH][R];
-    const float* pre_base = I > 0 ? Wih + (size_t)(g * H + u0) * I : Whh + (size_t)(g * H + u0) * H;
-    const int pre_len = I > 0 ? I : H, pre_xoff = I > 0 ? 0 : I;
+    const bool use_ih = pt.ih_k1 > pt.ih_k0;
+    const float* pre_base = use_ih ? Wih + (size_t)(g * H + u0) * I + pt.ih_k0 : Whh + (size_t)(g * H + u0) * H;
+    const int pre_ld = use_ih ? I : H;
+    const int pre_len = use_ih ? pt.ih_k1 - pt.ih_k0 : (pt.do_hh ? H : 0), pre_xoff = use_ih ? pt.ih_k0 : I;
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
         const int k = lane * 4 + j * 256;
         const int kc = k < pre_len ? k : 0;
 #pragma unroll
-        for (int r = 0; r < R; ++r) pre[j][r] = load4_nt(pre_base + (size_t)r * pre_len + kc);
+        for (int r = 0; r < R; ++r) pre[j][r] = load4_nt(pre_base + (size_t)r * pre_ld + kc);
     }
-    // stage [cell input | previous hidden] for all NB items: 16-byte loads, SB of them in flight per thread
-    // (piece boundaries n0, n0+n1, I are multiples of 4)
+    // stage the needed columns of [cell input | previous hidden] for all NB items: 16-byte loads, SB of them in
+    // flight per thread (piece boundaries n0, n0+n1, I and the window bounds are multiples of 4)
     {
         constexpr int SB = 6;
         const int K4 = K / 4, total4 = NB * K4;
@@ -243,12 +259,13 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
                 const int i4 = base + j * 256;
                 const int ic = i4 < total4 ? i4 : 0;
                 const int b = ic / K4, k = (ic % K4) * 4;
+                const bool need = k < I ? (k >= pt.ih_k0 && k < pt.ih_k1) : pt.do_hh != 0;
                 const float* src;
                 if (k < n0) src = in0 + b * n0 + k;
                 else if (k < n0 + n1) src = in1 + b * n1 + (k - n0);
                 else if (k < I) src = in2 + b * n2 + (k - n0 - n1);
                 else src = h_old + b * H + (k - I);
-                v[j] = *reinterpret_cast<const float4*>(src);
+                v[j] = need ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int j = 0; j < SB; ++j) {
@@ -294,11 +311,21 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
         }
     };
     CTTS_CONSUME(pre, lane * 4, pre_len, pre_xoff)
-    if (I > 0) {
-        stream(Wih + (size_t)(g * H + u0) * I, I, I, 0, 256 * CH);
-        stream(Whh + (size_t)(g * H + u0) * H, H, H, I, 0);
-    } else {
-        stream(Whh + (size_t)(g * H + u0) * H, H, H, I, 256 * CH);
+    if (use_ih) {
+        stream(pre_base, I, pre_len, pt.ih_k0, 256 * CH);
+        if (pt.do_hh) stream(Whh + (size_t)(g * H + u0) * H, H, H, I, 0);
+    } else if (pt.do_hh) {
+        stream(pre_base, H, H, I, 256 * CH);
+    }
+    if (pt.gout) {      // partial launch: raw sums only
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const float s = wave_sum(acc[r][b]);
+                if (lane == 0) pt.gout[(size_t)b * 4 * H + g * H + u0 + r] = s;
+            }
+        return;
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -314,6 +341,10 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
         float pre[4];
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg) pre[gg] = gates[(gg * R + r) * NB + b];
+        if (pt.gin) {
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) pre[gg] += pt.gin[(size_t)b * 4 * H + gg * H + u0 + r];
+        }
         bool active = true;
         int tb = 0;
         if (sq.gadd) {
@@ -508,6 +539,7 @@ __global__ __launch_bounds__(256) void attention_window_kernel(const AttnArgs a,
     __shared__ float q[AAD];
     __shared__ float en[64];
     __shared__ float wts[64];
+    __shared__ float wds[AF * AAD];          // location-dense weight [F][A] (was a dependent global load mid-kernel)
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int W = 2 * a.R + 1, padk = (a.K - 1) / 2;
     const int len = a.lengths[b];
@@ -538,6 +570,7 @@ __global__ __launch_bounds__(256) void attention_window_kernel(const AttnArgs a,
             wcat[c][j] = (pos >= 0 && pos < a.T) ? src[(size_t)b * a.T + pos] : 0.f;
         }
         for (int i = t; i < a.F * 2 * a.K; i += 256) wloc[i] = a.Wloc[i];
+        for (int i = t; i < a.F * a.A; i += 256) wds[i] = a.Wd[i];
         if (t < a.A) q[t] = qbuf[(size_t)b * a.A + t];
     }
     __syncthreads();
@@ -557,7 +590,7 @@ __global__ __launch_bounds__(256) void attention_window_kernel(const AttnArgs a,
         for (int ad = lane; ad < a.A; ad += 64) {
             float wd[AF];
 #pragma unroll
-            for (int f = 0; f < AF; ++f) wd[f] = a.Wd[(size_t)min(f, a.F - 1) * a.A + ad];
+            for (int f = 0; f < AF; ++f) wd[f] = wds[min(f, a.F - 1) * a.A + ad];
             const float qa = q[ad], va = a.v[ad];
 #pragma unroll
             for (int i = 0; i < MAXP; ++i) {
@@ -567,7 +600,9 @@ __global__ __launch_bounds__(256) void attention_window_kernel(const AttnArgs a,
                 for (int f = 0; f < AF; ++f) acc = fmaf(f < a.F ? wd[f] : 0.f, loc[tt][f], acc);
                 acc += qa;
                 acc += pmw[tt * a.A + ad];
-                epart[i] = fmaf(va, tanhf(acc), epart[i]);
+                // tanh through the hardware exp2 / rcp (abs error ~1e-7; the libm call is ~40 instructions)
+                const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc * 2.8853900817779268f));
+                epart[i] = fmaf(va, th, epart[i]);
             }
         }
 #pragma unroll
@@ -681,13 +716,13 @@ __global__ __launch_bounds__(256) void project_prenet_kernel(const ProjArgs a) {
 template <int NB>
 int launch_lstm(const float* wih, const float* whh, const float* bih, const float* bhh, const float* in0, int n0,
                 const float* in1, int n1, const float* in2, int n2, const float* h_old, float* h_new, float* c, int I,
-                int H, int batch, const LstmSeq& sq, hipStream_t s) {
+                int H, int batch, const LstmSeq& sq, const LstmPart& pt, hipStream_t s) {
     const size_t smem_base = (size_t)NB * (I + H) * sizeof(float);
 #define CTTS_LSTM_CASE(RR)                                                                                         \
     if (H % RR == 0 && H / RR <= 256) {                                                                           \
         const size_t smem = smem_base + 4 * RR * NB * sizeof(float);                                              \
         hipLaunchKernelGGL((lstm_step_kernel<NB, RR>), dim3(H / RR), dim3(256), smem, s, wih, whh, bih, bhh, in0, \
-                           n0, in1, n1, in2, n2, h_old, h_new, c, sq, I, H, batch);                                \
+                           n0, in1, n1, in2, n2, h_old, h_new, c, sq, pt, I, H, batch);                            \
         CTTS_CHECK_LAUNCH("lstm_step");                                                                            \
         return CTTS_OK;                                                                                            \
     }
@@ -700,19 +735,43 @@ int launch_lstm(const float* wih, const float* whh, const float* bih, const floa
 
 int launch_lstm_raw(int NB, const float* wih, const float* whh, const float* bih, const float* bhh, const float* in0,
                     int n0, const float* in1, int n1, const float* in2, int n2, const float* h_old, float* h_new, float* c,
-                    int I, int H, int batch, const LstmSeq& sq, hipStream_t s) {
+                    int I, int H, int batch, const LstmSeq& sq, hipStream_t s, const LstmPart* part = nullptr) {
+    const LstmPart whole{nullptr, nullptr, 0, I, 1};
+    const LstmPart& pt = part ? *part : whole;
     switch (NB) {
-        case 1: return launch_lstm<1>(wih, whh, bih, bhh, in0, n0, in1, n1, in2, n2, h_old, h_new, c, I, H, batch, sq, s);
-        case 2: return launch_lstm<2>(wih, whh, bih, bhh, in0, n0, in1, n1, in2, n2, h_old, h_new, c, I, H, batch, sq, s);
-        default: return launch_lstm<4>(wih, whh, bih, bhh, in0, n0, in1, n1, in2, n2, h_old, h_new, c, I, H, batch, sq, s);
+        case 1: return launch_lstm<1>(wih, whh, bih, bhh, in0, n0, in1, n1, in2, n2, h_old, h_new, c, I, H, batch, sq, pt, s);
+        case 2: return launch_lstm<2>(wih, whh, bih, bhh, in0, n0, in1, n1, in2, n2, h_old, h_new, c, I, H, batch, sq, pt, s);
+        default: return launch_lstm<4>(wih, whh, bih, bhh, in0, n0, in1, n1, in2, n2, h_old, h_new, c, I, H, batch, sq, pt, s);
     }
 }
 
 int launch_lstm_nb(int NB, const float* blob, const size_t* off, const float* in0, int n0, const float* in1, int n1,
-                   const float* in2, int n2, const float* h_old, float* h_new, float* c, int I, int H, hipStream_t s) {
+                   const float* in2, int n2, const float* h_old, float* h_new, float* c, int I, int H, hipStream_t s,
+                   const LstmPart* part = nullptr) {
     LstmSeq none{};
     return launch_lstm_raw(NB, blob + off[0], blob + off[1], blob + off[2], blob + off[3], in0, n0, in1, n1, in2, n2, h_old,
-                           h_new, c, I, H, NB, none, s);
+                           h_new, c, I, H, NB, none, s, part);
+}
+
+// Side stream + events for the early partial sums of the decoder cells (one set per device, created on first use).
+struct SideLane {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2][4] = {};        // [step parity][att_h ready, partials A ready, dec_h ready, partial B ready]
+    bool ok = false;
+};
+SideLane* side_lane() {
+    static SideLane lanes[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    SideLane& l = lanes[dev];
+    if (!l.ok) {
+        if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        for (auto& row : l.ev)
+            for (auto& e : row)
+                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        l.ok = true;
+    }
+    return &l;
 }
 
 }  // namespace
@@ -825,12 +884,47 @@ int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void*
     const int NB = pad_batch(batch);
     hipStream_t s = as_stream(stream);
     const float* blob = static_cast<const float*>(packed);
+    // Early partial sums (see LstmPart): `split` = run them on the side lane.  Column windows of the three cells:
+    //   attention RNN  input [prenet | ctx | dec_h]: fresh = prenet, early = ctx, dec_h and W_hh.att_h
+    //   decoder RNN    input [att_h | ctx]:          fresh = ctx,    early = att_h (known after the attention RNN)
+    //                                                                        and W_hh.dec_h
+    //   2nd decoder    input [dec_h]:                fresh = dec_h,  early = W_hh.d2_h
+    // Measured (config 5): 121 us/step with the side lane vs 100 us without - the two cross-stream waits per step cost
+    // more than the ~20 us of weight streaming they take off the critical path.  Kept behind a knob as the reference
+    // point for the single-stream fused form.
+    SideLane* lane = getenv("CTTS_TACO_SPLIT_STREAMS") ? side_lane() : nullptr;
+    const bool split = lane != nullptr && n_steps > 0;
+    hipStream_t s2 = split ? lane->stream : nullptr;
+    const int Pn = c.prenet_dim, Ra = c.attention_rnn_dim, Rd = c.decoder_rnn_dim;
+    const LstmPart att_early{nullptr, w.gp_att, Pn, p.I_att, 1}, att_fresh{w.gp_att, nullptr, 0, Pn, 0};
+    const LstmPart dec_early{nullptr, w.gp_dec, 0, Ra, 1}, dec_fresh{w.gp_dec, nullptr, Ra, p.I_dec, 0};
+    const LstmPart d2_early{nullptr, w.gp_d2, 0, 0, 1}, d2_fresh{w.gp_d2, nullptr, 0, p.I_d2, 0};
+    if (split) {   // the first step of this call has nothing to hide behind: its early part runs in line
+        const int cur = step0 & 1;
+        rc = launch_lstm_nb(NB, blob, p.att, w.prenet, Pn, w.ctx, c.memory_dim, w.dec_h[cur], Rd, w.att_h[cur], nullptr,
+                            nullptr, p.I_att, Ra, s, &att_early);
+        if (rc) return rc;
+    }
     for (int step = step0; step < step0 + n_steps; ++step) {
         const int cur = step & 1, nxt = cur ^ 1;    // h ping-pong: read [cur], write [nxt]
+        hipEvent_t* ev = split ? lane->ev[cur] : nullptr;
         // attention RNN on [prenet | context | decoder hidden]   (model.py:707-717)
-        rc = launch_lstm_nb(NB, blob, p.att, w.prenet, c.prenet_dim, w.ctx, c.memory_dim, w.dec_h[cur], c.decoder_rnn_dim,
-                            w.att_h[cur], w.att_h[nxt], w.att_c, p.I_att, c.attention_rnn_dim, s);
+        if (split && step > step0) CTTS_CHECK_HIP(hipStreamWaitEvent(s, lane->ev[nxt][3], 0));   // its early part (side lane)
+        rc = launch_lstm_nb(NB, blob, p.att, w.prenet, Pn, w.ctx, c.memory_dim, w.dec_h[cur], Rd,
+                            w.att_h[cur], w.att_h[nxt], w.att_c, p.I_att, Ra, s, split ? &att_fresh : nullptr);
         if (rc) return rc;
+        if (split) {
+            // side lane, behind the query projection + attention (4 workgroups, ~33 us): early parts of both decoder cells
+            CTTS_CHECK_HIP(hipEventRecord(ev[0], s));
+            CTTS_CHECK_HIP(hipStreamWaitEvent(s2, ev[0], 0));
+            rc = launch_lstm_nb(NB, blob, p.dec, w.att_h[nxt], Ra, w.ctx, c.memory_dim, nullptr, 0, w.dec_h[cur], nullptr,
+                                nullptr, p.I_dec, Rd, s2, &dec_early);
+            if (rc) return rc;
+            rc = launch_lstm_nb(NB, blob, p.d2, w.dec_h[nxt], Rd, nullptr, 0, nullptr, 0, w.d2_h[cur], nullptr, nullptr,
+                                p.I_d2, c.second_decoder_rnn_dim, s2, &d2_early);
+            if (rc) return rc;
+            CTTS_CHECK_HIP(hipEventRecord(ev[1], s2));
+        }
         AttnArgs a{};
         a.Wq = blob + p.query_w; a.v = blob + p.v_w; a.Wloc = blob + p.loc_conv_w; a.Wd = blob + p.loc_dense_w;
         a.scalars = blob + p.scalars;
@@ -855,11 +949,21 @@ int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void*
         }
         CTTS_CHECK_LAUNCH("attention_step");
         // decoder RNN on [attention hidden | context], second decoder RNN on the first's output
+        if (split) CTTS_CHECK_HIP(hipStreamWaitEvent(s, ev[1], 0));
         rc = launch_lstm_nb(NB, blob, p.dec, w.att_h[nxt], c.attention_rnn_dim, w.ctx, c.memory_dim, nullptr, 0,
-                            w.dec_h[cur], w.dec_h[nxt], w.dec_c, p.I_dec, c.decoder_rnn_dim, s);
+                            w.dec_h[cur], w.dec_h[nxt], w.dec_c, p.I_dec, c.decoder_rnn_dim, s, split ? &dec_fresh : nullptr);
         if (rc) return rc;
+        if (split && step + 1 < step0 + n_steps) {
+            // side lane, behind the 2nd decoder cell + projection/prenet: early part of the NEXT step's attention RNN
+            CTTS_CHECK_HIP(hipEventRecord(ev[2], s));
+            CTTS_CHECK_HIP(hipStreamWaitEvent(s2, ev[2], 0));
+            rc = launch_lstm_nb(NB, blob, p.att, w.prenet, Pn, w.ctx, c.memory_dim, w.dec_h[nxt], Rd, w.att_h[nxt], nullptr,
+                                nullptr, p.I_att, Ra, s2, &att_early);
+            if (rc) return rc;
+            CTTS_CHECK_HIP(hipEventRecord(ev[3], s2));
+        }
         rc = launch_lstm_nb(NB, blob, p.d2, w.dec_h[nxt], c.decoder_rnn_dim, nullptr, 0, nullptr, 0, w.d2_h[cur],
-                            w.d2_h[nxt], w.d2_c, p.I_d2, c.second_decoder_rnn_dim, s);
+                            w.d2_h[nxt], w.d2_c, p.I_d2, c.second_decoder_rnn_dim, s, split ? &d2_fresh : nullptr);
         if (rc) return rc;
         ProjArgs q{};
         q.Wp = blob + p.proj_w; q.bp = blob + p.proj_b; q.W1T = blob + p.prenet_w1; q.W2T = blob + p.prenet_w2;
@@ -868,6 +972,8 @@ int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void*
         q.mel_out = mel_out; q.gate_out = gate_out; q.prenet_out = w.prenet;
         q.n_mel = c.n_mel_channels; q.Rd = c.second_decoder_rnn_dim; q.Dm = c.memory_dim; q.P = c.prenet_dim;
         q.B = batch; q.step = step; q.max_steps = max_steps;
+        // (splitting this into three multi-workgroup GEMV launches was measured: 12.8 + 5.2 + 5.2 us vs 22 us here -
+        // every dependent launch costs ~5 us before its first useful byte, so fewer launches win)
         hipLaunchKernelGGL(project_prenet_kernel, dim3(batch), dim3(256), 0, s, q);
         CTTS_CHECK_LAUNCH("project_prenet");
     }
