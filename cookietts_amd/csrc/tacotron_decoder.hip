@@ -217,22 +217,32 @@ struct LstmPart {
     int do_hh;          // W_hh . h_old
 };
 
-// inputs in0|in1|in2 are [NB][n_i] row-major pieces of the concatenated cell input.
+// Everything one LSTM-step workgroup needs (the cell input is the concatenation in0|in1|in2 of [NB][n_i] pieces).
+struct LstmCall {
+    const float *Wih, *Whh, *bih, *bhh;
+    const float *in0; int n0;
+    const float *in1; int n1;
+    const float *in2; int n2;
+    const float* h_old; float* h_new; float* c;
+    LstmSeq sq; LstmPart pt;
+    int I, H, batch;
+};
+
+// One workgroup = R hidden units x 4 gates x NB items; `blk` = which R units; smem >= NB*(I+H) + 4*R*NB floats.
 template <int NB, int R>
-__global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict__ Wih, const float* __restrict__ Whh,
-                                                        const float* __restrict__ bih, const float* __restrict__ bhh,
-                                                        const float* __restrict__ in0, int n0,
-                                                        const float* __restrict__ in1, int n1,
-                                                        const float* __restrict__ in2, int n2,
-                                                        const float* __restrict__ h_old, float* __restrict__ h_new,
-                                                        float* __restrict__ c, const LstmSeq sq, const LstmPart pt,
-                                                        int I, int H, int batch) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void lstm_body(const LstmCall& q, float* __restrict__ smem, int blk) {
+    const float* __restrict__ Wih = q.Wih; const float* __restrict__ Whh = q.Whh;
+    const float* __restrict__ bih = q.bih; const float* __restrict__ bhh = q.bhh;
+    const float* __restrict__ in0 = q.in0; const float* __restrict__ in1 = q.in1; const float* __restrict__ in2 = q.in2;
+    const int n0 = q.n0, n1 = q.n1, n2 = q.n2;
+    const float* __restrict__ h_old = q.h_old; float* __restrict__ h_new = q.h_new; float* __restrict__ c = q.c;
+    const LstmSeq& sq = q.sq; const LstmPart& pt = q.pt;
+    const int I = q.I, H = q.H, batch = q.batch;
     const int K = I + H;
     float* xs = smem;                       // [NB][K]   cell input | previous hidden
     float* gates = smem + NB * K;           // [4][R][NB]
     const int t = threadIdx.x, lane = t & 63, g = t >> 6;
-    const int u0 = blockIdx.x * R;
+    const int u0 = blk * R;
     // first weight slab group: issued now, consumed after the staging barrier
     constexpr int CH = 4;
     float4 pre[CH][R];
@@ -371,6 +381,12 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
             h_new[idx] = h_old[idx];
         }
     }
+}
+
+template <int NB, int R>
+__global__ __launch_bounds__(256) void lstm_step_kernel(const LstmCall q) {
+    extern __shared__ __attribute__((aligned(16))) float lstm_smem[];
+    lstm_body<NB, R>(q, lstm_smem, blockIdx.x);
 }
 
 // ---- attention step --------------------------------------------------------------------
@@ -530,17 +546,20 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict_
 // memory and of the memory itself) is fetched up front into LDS in one burst; the rest runs out of LDS.
 constexpr int AW = 33, ADM = 512, AAD = 256, AF = 32, AK = 31;
 
-__global__ __launch_bounds__(256) void attention_window_kernel(const AttnArgs a, const float* __restrict__ qbuf) {
-    __shared__ __attribute__((aligned(16))) float memw[AW * ADM];
-    __shared__ __attribute__((aligned(16))) float pmw[AW * AAD];
-    __shared__ float wloc[AF * 2 * AK];
-    __shared__ float loc[AW][AF + 1];
-    __shared__ float wcat[2][AW + AK - 1];
-    __shared__ float q[AAD];
-    __shared__ float en[64];
-    __shared__ float wts[64];
-    __shared__ float wds[AF * AAD];          // location-dense weight [F][A] (was a dependent global load mid-kernel)
-    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+constexpr int ATTN_SMEM_FLOATS = AW * ADM + AW * AAD + AF * 2 * AK + AW * (AF + 1) + 2 * (AW + AK - 1) + 2 + AAD + 64 + 64 + AF * AAD;
+
+__device__ __forceinline__ void attention_window_body(const AttnArgs& a, const float* __restrict__ qbuf,
+                                                      float* __restrict__ smem, int b) {
+    float* memw = smem;                                   // [AW][ADM]   (16-byte aligned)
+    float* pmw = memw + AW * ADM;                         // [AW][AAD]
+    float* wloc = pmw + AW * AAD;                         // [AF*2*AK]
+    float (*loc)[AF + 1] = reinterpret_cast<float (*)[AF + 1]>(wloc + AF * 2 * AK);       // [AW][AF+1]
+    float (*wcat)[AW + AK - 1] = reinterpret_cast<float (*)[AW + AK - 1]>(&loc[AW][0]);   // [2][AW+AK-1]
+    float* q = &wcat[2][0] + 2;                           // [AAD]
+    float* en = q + AAD;                                  // [64]
+    float* wts = en + 64;                                 // [64]
+    float* wds = wts + 64;                                // [AF*AAD] location-dense weight [F][A]
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int W = 2 * a.R + 1, padk = (a.K - 1) / 2;
     const int len = a.lengths[b];
     float cur = a.pos[b];
@@ -644,6 +663,11 @@ __global__ __launch_bounds__(256) void attention_window_kernel(const AttnArgs a,
     }
 }
 
+__global__ __launch_bounds__(256) void attention_window_kernel(const AttnArgs a, const float* __restrict__ qbuf) {
+    __shared__ __attribute__((aligned(16))) float smem[ATTN_SMEM_FLOATS];
+    attention_window_body(a, qbuf, smem, blockIdx.x);
+}
+
 // ---- projection + next prenet ------------------------------------------------------------
 struct ProjArgs {
     const float *Wp, *bp, *W1T, *W2T;
@@ -653,11 +677,13 @@ struct ProjArgs {
     int n_mel, Rd, Dm, P, B, step, max_steps;
 };
 
-__global__ __launch_bounds__(256) void project_prenet_kernel(const ProjArgs a) {
-    __shared__ __attribute__((aligned(16))) float v[2048];
-    __shared__ float mel[256];
-    __shared__ float a1[256];
-    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+constexpr int PROJ_SMEM_FLOATS = 2048 + 256 + 256;
+
+__device__ __forceinline__ void project_prenet_body(const ProjArgs& a, float* __restrict__ smem, int b) {
+    float* v = smem;            // [2048] (16-byte aligned)
+    float* mel = v + 2048;      // [256]
+    float* a1 = mel + 256;      // [256]
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int D = a.Rd + a.Dm;
     for (int i = t; i < D; i += 256)
         v[i] = i < a.Rd ? a.dec_h[(size_t)b * a.Rd + i] + a.d2_h[(size_t)b * a.Rd + i] : a.ctx[(size_t)b * a.Dm + (i - a.Rd)];
@@ -713,6 +739,38 @@ __global__ __launch_bounds__(256) void project_prenet_kernel(const ProjArgs a) {
     }
 }
 
+__global__ __launch_bounds__(256) void project_prenet_kernel(const ProjArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[PROJ_SMEM_FLOATS];
+    project_prenet_body(a, smem, blockIdx.x);
+}
+
+// ---- heterogeneous launches: critical-path stage + early partial sums of the next cells ----------------------------
+// The window attention and the projection/prenet stages are one workgroup per utterance (4 of 256 CUs busy for
+// ~25 us each).  The other CUs use that time to stream the part of the NEXT cells' weights whose inputs are already
+// known (LstmPart), so the cell launches that follow only touch the fresh columns.  One launch, one stream: workgroups
+// [0, n_head) run the head stage, the rest the partial matvecs.  (The same split over two streams with events was
+// measured slower than no split: 121 vs 100 us per step.)
+template <int NB, int R1, int R2>
+__global__ __launch_bounds__(256) void attention_partials_kernel(const AttnArgs a, const float* __restrict__ qbuf,
+                                                                 int n_head, const LstmCall p1, int n1, const LstmCall p2) {
+    __shared__ __attribute__((aligned(16))) float smem[ATTN_SMEM_FLOATS];
+    const int blk = blockIdx.x;
+    if (blk < n_head) attention_window_body(a, qbuf, smem, blk);
+    else if (blk < n_head + n1) lstm_body<NB, R1>(p1, smem, blk - n_head);
+    else lstm_body<NB, R2>(p2, smem, blk - n_head - n1);
+}
+
+constexpr int PROJ_FUSED_SMEM_FLOATS = 4 * (1536 + 1280) + 4 * 8 * 4;   // the attention RNN's staging: NB * (I + H) + gates
+
+template <int NB, int R>
+__global__ __launch_bounds__(256) void project_partial_kernel(const ProjArgs a, int n_head, const LstmCall p1) {
+    __shared__ __attribute__((aligned(16))) float smem[PROJ_FUSED_SMEM_FLOATS];
+    static_assert(PROJ_FUSED_SMEM_FLOATS >= PROJ_SMEM_FLOATS, "projection stage does not fit");
+    const int blk = blockIdx.x;
+    if (blk < n_head) project_prenet_body(a, smem, blk);
+    else lstm_body<NB, R>(p1, smem, blk - n_head);
+}
+
 template <int NB>
 int launch_lstm(const float* wih, const float* whh, const float* bih, const float* bhh, const float* in0, int n0,
                 const float* in1, int n1, const float* in2, int n2, const float* h_old, float* h_new, float* c, int I,
@@ -721,8 +779,8 @@ int launch_lstm(const float* wih, const float* whh, const float* bih, const floa
 #define CTTS_LSTM_CASE(RR)                                                                                         \
     if (H % RR == 0 && H / RR <= 256) {                                                                           \
         const size_t smem = smem_base + 4 * RR * NB * sizeof(float);                                              \
-        hipLaunchKernelGGL((lstm_step_kernel<NB, RR>), dim3(H / RR), dim3(256), smem, s, wih, whh, bih, bhh, in0, \
-                           n0, in1, n1, in2, n2, h_old, h_new, c, sq, pt, I, H, batch);                            \
+        const LstmCall q{wih, whh, bih, bhh, in0, n0, in1, n1, in2, n2, h_old, h_new, c, sq, pt, I, H, batch};    \
+        hipLaunchKernelGGL((lstm_step_kernel<NB, RR>), dim3(H / RR), dim3(256), smem, s, q);                      \
         CTTS_CHECK_LAUNCH("lstm_step");                                                                            \
         return CTTS_OK;                                                                                            \
     }
@@ -753,25 +811,11 @@ int launch_lstm_nb(int NB, const float* blob, const size_t* off, const float* in
                            h_new, c, I, H, NB, none, s, part);
 }
 
-// Side stream + events for the early partial sums of the decoder cells (one set per device, created on first use).
-struct SideLane {
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[2][4] = {};        // [step parity][att_h ready, partials A ready, dec_h ready, partial B ready]
-    bool ok = false;
-};
-SideLane* side_lane() {
-    static SideLane lanes[16];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    SideLane& l = lanes[dev];
-    if (!l.ok) {
-        if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        for (auto& row : l.ev)
-            for (auto& e : row)
-                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-        l.ok = true;
-    }
-    return &l;
+LstmCall make_call(const float* blob, const size_t* off, const float* in0, int n0, const float* in1, int n1, const float* in2,
+                   int n2, const float* h_old, int I, int H, int NB, const LstmPart& pt) {
+    LstmSeq none{};
+    return LstmCall{blob + off[0], blob + off[1], blob + off[2], blob + off[3], in0, n0, in1, n1, in2, n2, h_old, nullptr,
+                    nullptr, none, pt, I, H, NB};
 }
 
 }  // namespace
@@ -884,22 +928,22 @@ int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void*
     const int NB = pad_batch(batch);
     hipStream_t s = as_stream(stream);
     const float* blob = static_cast<const float*>(packed);
-    // Early partial sums (see LstmPart): `split` = run them on the side lane.  Column windows of the three cells:
-    //   attention RNN  input [prenet | ctx | dec_h]: fresh = prenet, early = ctx, dec_h and W_hh.att_h
-    //   decoder RNN    input [att_h | ctx]:          fresh = ctx,    early = att_h (known after the attention RNN)
-    //                                                                        and W_hh.dec_h
-    //   2nd decoder    input [dec_h]:                fresh = dec_h,  early = W_hh.d2_h
-    // Measured (config 5): 121 us/step with the side lane vs 100 us without - the two cross-stream waits per step cost
-    // more than the ~20 us of weight streaming they take off the critical path.  Kept behind a knob as the reference
-    // point for the single-stream fused form.
-    SideLane* lane = getenv("CTTS_TACO_SPLIT_STREAMS") ? side_lane() : nullptr;
-    const bool split = lane != nullptr && n_steps > 0;
-    hipStream_t s2 = split ? lane->stream : nullptr;
-    const int Pn = c.prenet_dim, Ra = c.attention_rnn_dim, Rd = c.decoder_rnn_dim;
+    // Early partial sums (see LstmPart and the heterogeneous kernels above).  Column windows of the three cells:
+    //   attention RNN  input [prenet | ctx | dec_h]: fresh = prenet, early = ctx, dec_h and W_hh.att_h  (behind project/prenet)
+    //   decoder RNN    input [att_h | ctx]:          fresh = ctx,    early = att_h and W_hh.dec_h       (behind the attention)
+    //   2nd decoder    input [dec_h]:                fresh = dec_h,  early = W_hh.d2_h                  (behind the attention)
+    const int Pn = c.prenet_dim, Ra = c.attention_rnn_dim, Rd = c.decoder_rnn_dim, Rd2 = c.second_decoder_rnn_dim;
+    const bool fast = c.window_range <= 16 && c.memory_dim <= ADM && c.attention_dim <= AAD && c.attention_dim % 4 == 0 &&
+                      c.location_n_filters <= AF && c.location_kernel_size <= AK && c.attention_rnn_dim <= 1536;
+    constexpr int R_DEC = 6, R_D2 = 8, R_ATT = 8;     // units per partial workgroup: 4 + 128 + 96 <= 256 CUs at config 5
+    const bool fuse = fast && n_steps > 0 && Rd % R_DEC == 0 && Rd2 % R_D2 == 0 && Ra % R_ATT == 0 &&
+                      NB * (p.I_dec + Rd) + 4 * R_DEC * NB <= ATTN_SMEM_FLOATS &&
+                      NB * (p.I_d2 + Rd2) + 4 * R_D2 * NB <= ATTN_SMEM_FLOATS &&
+                      NB * (p.I_att + Ra) + 4 * R_ATT * NB <= PROJ_FUSED_SMEM_FLOATS && !getenv("CTTS_TACO_NO_FUSE");
     const LstmPart att_early{nullptr, w.gp_att, Pn, p.I_att, 1}, att_fresh{w.gp_att, nullptr, 0, Pn, 0};
     const LstmPart dec_early{nullptr, w.gp_dec, 0, Ra, 1}, dec_fresh{w.gp_dec, nullptr, Ra, p.I_dec, 0};
     const LstmPart d2_early{nullptr, w.gp_d2, 0, 0, 1}, d2_fresh{w.gp_d2, nullptr, 0, p.I_d2, 0};
-    if (split) {   // the first step of this call has nothing to hide behind: its early part runs in line
+    if (fuse) {   // the first step of this call has nothing to hide behind: its early part runs in line
         const int cur = step0 & 1;
         rc = launch_lstm_nb(NB, blob, p.att, w.prenet, Pn, w.ctx, c.memory_dim, w.dec_h[cur], Rd, w.att_h[cur], nullptr,
                             nullptr, p.I_att, Ra, s, &att_early);
@@ -907,24 +951,10 @@ int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void*
     }
     for (int step = step0; step < step0 + n_steps; ++step) {
         const int cur = step & 1, nxt = cur ^ 1;    // h ping-pong: read [cur], write [nxt]
-        hipEvent_t* ev = split ? lane->ev[cur] : nullptr;
         // attention RNN on [prenet | context | decoder hidden]   (model.py:707-717)
-        if (split && step > step0) CTTS_CHECK_HIP(hipStreamWaitEvent(s, lane->ev[nxt][3], 0));   // its early part (side lane)
         rc = launch_lstm_nb(NB, blob, p.att, w.prenet, Pn, w.ctx, c.memory_dim, w.dec_h[cur], Rd,
-                            w.att_h[cur], w.att_h[nxt], w.att_c, p.I_att, Ra, s, split ? &att_fresh : nullptr);
+                            w.att_h[cur], w.att_h[nxt], w.att_c, p.I_att, Ra, s, fuse ? &att_fresh : nullptr);
         if (rc) return rc;
-        if (split) {
-            // side lane, behind the query projection + attention (4 workgroups, ~33 us): early parts of both decoder cells
-            CTTS_CHECK_HIP(hipEventRecord(ev[0], s));
-            CTTS_CHECK_HIP(hipStreamWaitEvent(s2, ev[0], 0));
-            rc = launch_lstm_nb(NB, blob, p.dec, w.att_h[nxt], Ra, w.ctx, c.memory_dim, nullptr, 0, w.dec_h[cur], nullptr,
-                                nullptr, p.I_dec, Rd, s2, &dec_early);
-            if (rc) return rc;
-            rc = launch_lstm_nb(NB, blob, p.d2, w.dec_h[nxt], Rd, nullptr, 0, nullptr, 0, w.d2_h[cur], nullptr, nullptr,
-                                p.I_d2, c.second_decoder_rnn_dim, s2, &d2_early);
-            if (rc) return rc;
-            CTTS_CHECK_HIP(hipEventRecord(ev[1], s2));
-        }
         AttnArgs a{};
         a.Wq = blob + p.query_w; a.v = blob + p.v_w; a.Wloc = blob + p.loc_conv_w; a.Wd = blob + p.loc_dense_w;
         a.scalars = blob + p.scalars;
@@ -933,15 +963,25 @@ int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void*
         a.T = text_len; a.A = c.attention_dim; a.Ra = c.attention_rnn_dim; a.Dm = c.memory_dim;
         a.F = c.location_n_filters; a.K = c.location_kernel_size; a.R = c.window_range;
         a.step = step; a.max_steps = max_steps;
-        const bool fast = c.window_range <= 16 && c.memory_dim <= ADM && c.attention_dim <= AAD && c.attention_dim % 4 == 0 &&
-                          c.location_n_filters <= AF && c.location_kernel_size <= AK && c.attention_rnn_dim <= 1536;
         if (fast) {
             const int gblocks = (c.attention_dim + 7) / 8;
             if (NB == 1) hipLaunchKernelGGL(gemv_rows_kernel<1>, dim3(gblocks), dim3(256), 0, s, a.Wq, a.att_h, w.qbuf, c.attention_dim, c.attention_rnn_dim);
             else if (NB == 2) hipLaunchKernelGGL(gemv_rows_kernel<2>, dim3(gblocks), dim3(256), 0, s, a.Wq, a.att_h, w.qbuf, c.attention_dim, c.attention_rnn_dim);
             else hipLaunchKernelGGL(gemv_rows_kernel<4>, dim3(gblocks), dim3(256), 0, s, a.Wq, a.att_h, w.qbuf, c.attention_dim, c.attention_rnn_dim);
             CTTS_CHECK_LAUNCH("gemv_rows");
-            hipLaunchKernelGGL(attention_window_kernel, dim3(batch), dim3(256), 0, s, a, w.qbuf);
+            if (fuse) {
+                const LstmCall e1 = make_call(blob, p.dec, w.att_h[nxt], Ra, w.ctx, c.memory_dim, nullptr, 0, w.dec_h[cur],
+                                              p.I_dec, Rd, NB, dec_early);
+                const LstmCall e2 = make_call(blob, p.d2, w.dec_h[nxt], Rd, nullptr, 0, nullptr, 0, w.d2_h[cur], p.I_d2, Rd2,
+                                              NB, d2_early);
+                const int n1 = Rd / R_DEC, n2 = Rd2 / R_D2;
+                const dim3 grid(batch + n1 + n2);
+                if (NB == 1) hipLaunchKernelGGL((attention_partials_kernel<1, R_DEC, R_D2>), grid, dim3(256), 0, s, a, w.qbuf, batch, e1, n1, e2);
+                else if (NB == 2) hipLaunchKernelGGL((attention_partials_kernel<2, R_DEC, R_D2>), grid, dim3(256), 0, s, a, w.qbuf, batch, e1, n1, e2);
+                else hipLaunchKernelGGL((attention_partials_kernel<4, R_DEC, R_D2>), grid, dim3(256), 0, s, a, w.qbuf, batch, e1, n1, e2);
+            } else {
+                hipLaunchKernelGGL(attention_window_kernel, dim3(batch), dim3(256), 0, s, a, w.qbuf);
+            }
         } else if (c.location_n_filters <= 32) {
             hipLaunchKernelGGL(attention_step_kernel<32>, dim3(batch), dim3(256), 0, s, a);
         } else {
@@ -949,21 +989,11 @@ int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void*
         }
         CTTS_CHECK_LAUNCH("attention_step");
         // decoder RNN on [attention hidden | context], second decoder RNN on the first's output
-        if (split) CTTS_CHECK_HIP(hipStreamWaitEvent(s, ev[1], 0));
         rc = launch_lstm_nb(NB, blob, p.dec, w.att_h[nxt], c.attention_rnn_dim, w.ctx, c.memory_dim, nullptr, 0,
-                            w.dec_h[cur], w.dec_h[nxt], w.dec_c, p.I_dec, c.decoder_rnn_dim, s, split ? &dec_fresh : nullptr);
+                            w.dec_h[cur], w.dec_h[nxt], w.dec_c, p.I_dec, c.decoder_rnn_dim, s, fuse ? &dec_fresh : nullptr);
         if (rc) return rc;
-        if (split && step + 1 < step0 + n_steps) {
-            // side lane, behind the 2nd decoder cell + projection/prenet: early part of the NEXT step's attention RNN
-            CTTS_CHECK_HIP(hipEventRecord(ev[2], s));
-            CTTS_CHECK_HIP(hipStreamWaitEvent(s2, ev[2], 0));
-            rc = launch_lstm_nb(NB, blob, p.att, w.prenet, Pn, w.ctx, c.memory_dim, w.dec_h[nxt], Rd, w.att_h[nxt], nullptr,
-                                nullptr, p.I_att, Ra, s2, &att_early);
-            if (rc) return rc;
-            CTTS_CHECK_HIP(hipEventRecord(ev[3], s2));
-        }
         rc = launch_lstm_nb(NB, blob, p.d2, w.dec_h[nxt], c.decoder_rnn_dim, nullptr, 0, nullptr, 0, w.d2_h[cur],
-                            w.d2_h[nxt], w.d2_c, p.I_d2, c.second_decoder_rnn_dim, s, split ? &d2_fresh : nullptr);
+                            w.d2_h[nxt], w.d2_c, p.I_d2, c.second_decoder_rnn_dim, s, fuse ? &d2_fresh : nullptr);
         if (rc) return rc;
         ProjArgs q{};
         q.Wp = blob + p.proj_w; q.bp = blob + p.proj_b; q.W1T = blob + p.prenet_w1; q.W2T = blob + p.prenet_w2;
@@ -972,9 +1002,19 @@ int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void*
         q.mel_out = mel_out; q.gate_out = gate_out; q.prenet_out = w.prenet;
         q.n_mel = c.n_mel_channels; q.Rd = c.second_decoder_rnn_dim; q.Dm = c.memory_dim; q.P = c.prenet_dim;
         q.B = batch; q.step = step; q.max_steps = max_steps;
-        // (splitting this into three multi-workgroup GEMV launches was measured: 12.8 + 5.2 + 5.2 us vs 22 us here -
-        // every dependent launch costs ~5 us before its first useful byte, so fewer launches win)
-        hipLaunchKernelGGL(project_prenet_kernel, dim3(batch), dim3(256), 0, s, q);
+        // (splitting this stage into three multi-workgroup GEMV launches was measured: 12.8 + 5.2 + 5.2 us vs 22 us
+        // here - every dependent launch costs ~5 us before its first useful byte, so fewer launches win)
+        if (fuse && step + 1 < step0 + n_steps) {
+            // ... and behind it, the early part of the NEXT step's attention RNN
+            const LstmCall e = make_call(blob, p.att, w.prenet, Pn, w.ctx, c.memory_dim, w.dec_h[nxt], Rd, w.att_h[nxt],
+                                         p.I_att, Ra, NB, att_early);
+            const dim3 grid(batch + Ra / R_ATT);
+            if (NB == 1) hipLaunchKernelGGL((project_partial_kernel<1, R_ATT>), grid, dim3(256), 0, s, q, batch, e);
+            else if (NB == 2) hipLaunchKernelGGL((project_partial_kernel<2, R_ATT>), grid, dim3(256), 0, s, q, batch, e);
+            else hipLaunchKernelGGL((project_partial_kernel<4, R_ATT>), grid, dim3(256), 0, s, q, batch, e);
+        } else {
+            hipLaunchKernelGGL(project_prenet_kernel, dim3(batch), dim3(256), 0, s, q);
+        }
         CTTS_CHECK_LAUNCH("project_prenet");
     }
     return CTTS_OK;
