@@ -16,6 +16,7 @@
 
 #include "gemm_f32.h"
 #include "waveglow_kernels.h"
+#include "waveflow_sep.h"
 
 namespace ctts {
 namespace {
@@ -23,7 +24,6 @@ namespace {
 constexpr size_t ALIGN_F = 64;
 inline size_t align_up(size_t v) { return (v + ALIGN_F - 1) / ALIGN_F * ALIGN_F; }
 constexpr int WF_BM = 128;
-constexpr int WF_MAX_KH = 8;
 
 struct WfPlan {
     ctts_waveflow_config c;
@@ -32,7 +32,7 @@ struct WfPlan {
     int taps;                        // GEMM taps: kh*kw, or 1 behind the depthwise stage
     struct Flow {
         size_t start_w, start_b, end_w, end_b;
-        std::vector<size_t> in_A, in_b, rs_A, rs_b, rs_T, rs_Tb, dw_w, dw_b;
+        std::vector<size_t> in_A, in_b, rs_A, rs_b, rs_T, rs_Tb, dw_w, dw_b, sA1, sb1, sA2, sb2;
     };
     std::vector<Flow> fl;
     size_t total;
@@ -41,6 +41,10 @@ struct WfPlan {
     int in_mb() const { return (C + 63) / 64; }
     // one 128-row block holds every gate pair: the res/skip GEMM runs inside the in-layer kernel (GEMM_EPI_GATE_RS)
     bool fused() const { return C == 64; }
+    // both 1x1 stages of a separable layer in one launch (waveflow_sep.hip): pointwise/gate + res/skip, C = 128
+    bool sep_fused() const {
+        return sep && precond && wf_sep_supported(C);
+    }
 };
 
 int make_wf_plan(const ctts_waveflow_config* cfg, WfPlan& p) {
@@ -80,6 +84,10 @@ int make_wf_plan(const ctts_waveflow_config* cfg, WfPlan& p) {
             f.rs_Tb.push_back(take(p.fused() ? 128 : 0));
             f.dw_w.push_back(take(p.sep ? (size_t)p.C * c.kernel_size_h * c.kernel_size_w : 0));
             f.dw_b.push_back(take(p.sep ? p.C : 0));
+            f.sA1.push_back(take(p.sep_fused() ? 128 * 256 : 0));
+            f.sb1.push_back(take(p.sep_fused() ? 256 : 0));
+            f.sA2.push_back(take(p.sep_fused() ? 128 * 256 : 0));
+            f.sb2.push_back(take(p.sep_fused() ? 256 : 0));
         }
     }
     p.total = o;
@@ -276,7 +284,6 @@ __global__ __launch_bounds__(256) void wf_interp_cond_kernel(const float* __rest
     up[(size_t)layer * slot + ((size_t)b * rows2c + r) * ld + pad + l] = v;
 }
 
-struct WfSlots { const float* p[WF_MAX_KH]; };
 
 // Depthwise stage of a separable in-layer (glow_ax.py:525-527: Conv2d(C, C, (kh, kw), groups=C), width dilation dw,
 // causal in height): y[b][c][l] = bias[c] + sum_{a >= a_min} sum_j w[c][a][j] * x_a[b][c][l + (j - kw/2) * dw], where
@@ -450,6 +457,7 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
     for (int i = 0; i < G; ++i) phys[i] = i;
     auto X = [&](int layer, int slot) { return w.X + ((size_t)layer * kh + slot) * w.xslot; };
     const bool fuse = p.fused() && !getenv("CTTS_WF_NO_FUSE");
+    const bool sep_fuse = p.sep_fused() && !getenv("CTTS_WF_NO_FUSE");
 
     for (int k = p.c.n_flows - 1; k >= 0; --k) {
         const auto& f = p.fl[k];
@@ -490,6 +498,18 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
                         hipLaunchKernelGGL(wf_depthwise_kernel, dim3((L + 255) / 256, C, batch), dim3(256), 0, s, xs,
                                            blob + f.dw_w[i], blob + f.dw_b[i], w.dwout, C, kh, kw, dw, a_min, L, g.ld, g.pad);
                     CTTS_CHECK_LAUNCH("wf_depthwise");
+                    if (sep_fuse) {
+                        WfSepArgs q{};
+                        q.dwout = w.dwout;
+                        q.A1 = blob + f.sA1[i]; q.b1 = blob + f.sb1[i]; q.A2 = blob + f.sA2[i]; q.b2 = blob + f.sb2[i];
+                        q.cond = w.cond_up + (size_t)i * w.cond_slot;
+                        q.xin = X(i, slot);
+                        q.xout = i == p.c.n_layers - 1 ? nullptr : X(i + 1, slot);
+                        q.out = w.out; q.acc_out = i > 0 ? 1 : 0; q.rs_rows = p.rs_rows(i);
+                        q.L = L; q.ld = g.ld; q.pad = g.pad; q.ntiles = (L + 63) / 64;
+                        if ((rc = launch_wf_sep_layer(q, batch, s))) return rc;
+                        continue;
+                    }
                     a.a_ch_off = 0;
                     a.seg[ns++] = {w.dwout, cstride, p.nch_c, 0, 0, 0};
                     a.nch_total = p.nch_c;
@@ -611,6 +631,9 @@ int ctts_waveflow_pack_flow(const ctts_waveflow_config* cfg, int32_t k, const ct
                                blob + f.rs_Tb[i], rows);
             CTTS_CHECK_LAUNCH("wf_pack_rs_t");
         }
+        if (p.sep_fused())
+            if ((rc = launch_wf_sep_pack(w->in_w[i], w->in_b[i], w->rs_w[i], w->rs_b[i], blob + f.sA1[i], blob + f.sb1[i],
+                                         blob + f.sA2[i], blob + f.sb2[i], rows, s))) return rc;
     }
     return CTTS_OK;
 }
