@@ -157,3 +157,25 @@ def test_author_options_ragged_vs_oracle_and_speaker_requirement(hip_lib_path):
         m.inverse(torch.from_numpy(z).cuda(), torch.from_numpy(mel).cuda())
     out = m.infer(torch.from_numpy(mel).cuda(), speaker_ids=torch.from_numpy(ids).cuda(), sigma=0.7, return_CPU=False)
     assert out.is_cuda and out.shape == (B, (Fr - 1) * cfg["hop_length"]) and torch.isfinite(out).all()
+
+
+@pytest.mark.gpu
+def test_author_full_width_fused_1x1_stages_vs_oracle(hip_lib_path):
+    """The author's full option set (C = 128: depthwise launch + fused pointwise/gate/res-skip kernel), two utterances,
+    L = 150 (three 64-column tiles, ragged, not a multiple of 4), against the oracle and against the unfused launches."""
+    m, cfg, sd = _model("author", 31)
+    B, Fr = 2, 6
+    mel = synthetic.synthetic_mel(B, Fr, cfg["n_mel_channels"] * 2, seed=5)
+    ids = np.array([7, 300], np.int64)
+    z = (np.random.default_rng(6).standard_normal((B, (Fr - 1) * cfg["hop_length"])) * 0.7).astype(np.float32)
+    ref = wf.waveflow_inverse(sd, cfg, z, mel, ids)
+    args = (torch.from_numpy(z).cuda(), torch.from_numpy(mel).cuda())
+    got, _ = m.inverse(*args, speaker_ids=torch.from_numpy(ids).cuda())
+    assert rms_rel_err(got.numpy(), ref) < WAVE_TOL
+    os.environ["CTTS_WF_NO_FUSE"] = "1"
+    try:
+        plain, _ = m.inverse(*args, speaker_ids=torch.from_numpy(ids).cuda())
+    finally:
+        del os.environ["CTTS_WF_NO_FUSE"]
+    assert rms_rel_err(plain.numpy(), ref) < WAVE_TOL
+    assert rms_rel_err(got.numpy(), plain.numpy()) < 1e-5
