@@ -156,7 +156,7 @@ def main():
             mean_s = ms.value / max(n.value, 1) * 1e-3
             achieved = flop_per_launch / mean_s / 1e12
             peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
-            kname = "conv_gemm_f32_kernel<GATE>" if args.dtype == "f32" else "conv_gemm_bf16_kernel<GATE>"
+            kname = "conv_gemm_f32_kernel<GATE>" if args.dtype == "f32" else "conv_gemm_bf16_pp_kernel<GATE>"
             roofline = {"kernel": kname + " (WN in-layer: dilated conv + cond + tanh*sigmoid)",
                         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": TRAFFIC.get(args.dtype),
@@ -172,7 +172,7 @@ def main():
                 mean2 = ms2.value / max(n2.value, 1) * 1e-3
                 bytes2 = float(5 * C * 2) * B * L
                 roofline["res_skip_hbm"] = {
-                    "kernel": "conv_gemm_bf16_kernel<SPLIT> (WN res/skip 1x1 + residual/skip accumulate)", "bound": "hbm",
+                    "kernel": "conv_gemm_bf16_pp_kernel<SPLIT> (WN res/skip 1x1 + residual/skip accumulate)", "bound": "hbm",
                     "achieved": round(bytes2 / mean2 / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(bytes2 / mean2 / 8e12, 4), "launches": int(n2.value),
                     "mean_launch_ms": round(mean2 * 1e3, 4), "bytes_per_launch": bytes2}
