@@ -255,28 +255,37 @@ class Decoder(nn.Module):
             keep_masks = torch.as_tensor(keep_masks).to(device=device, dtype=torch.uint8).contiguous()
             assert keep_masks.shape[0] >= max_steps and tuple(keep_masks.shape[1:]) == (2, B, self.prenet_dim)
             keep_masks = keep_masks[:max_steps].contiguous()
+        # the device loop holds <= MAX_GROUP utterances per workspace: larger batches run as groups in lockstep (same
+        # chunk of steps for every group, then ONE stop-rule evaluation over the whole batch, like model.py:898-904)
+        groups = [(g0, min(g0 + MAX_GROUP, B)) for g0 in range(0, B, MAX_GROUP)]
         key = (device, B, T)
-        ws = self._ws.get(key)
-        if ws is None:
-            nbytes = lib.ctts_taco_decoder_workspace_bytes(C.byref(cfg), B, T)
-            if nbytes == 0:
-                raise _lib.HipLibraryError("decoder workspace query failed: " + lib.ctts_last_error().decode())
-            self._ws = {key: torch.empty(nbytes // 4, dtype=torch.float32, device=device)}
-            ws = self._ws[key]
+        wss = self._ws.get(key)
+        if wss is None:
+            wss = []
+            for g0, g1 in groups:
+                nbytes = lib.ctts_taco_decoder_workspace_bytes(C.byref(cfg), g1 - g0, T)
+                if nbytes == 0:
+                    raise _lib.HipLibraryError("decoder workspace query failed: " + lib.ctts_last_error().decode())
+                wss.append(torch.empty(nbytes // 4, dtype=torch.float32, device=device))
+            self._ws = {key: wss}
+        masks = [keep_masks if len(groups) == 1 else keep_masks[:, :, g0:g1].contiguous() for g0, g1 in groups]
         mel = torch.zeros(B, self.n_mel_channels, max_steps, dtype=torch.float32, device=device)
         gate = torch.zeros(B, max_steps, dtype=torch.float32, device=device)
         align = torch.zeros(B, max_steps, T, dtype=torch.float32, device=device)
         with torch.cuda.device(device):
             stream_obj = torch.cuda.current_stream(device)
             stream = C.c_void_p(stream_obj.cuda_stream)
-            _lib.check(lib.ctts_taco_decoder_init_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(mem), _lib.ptr(lens), B, T,
-                                                     _lib.ptr(ws), ws.numel() * 4, stream), "ctts_taco_decoder_init_f32")
+            for (g0, g1), ws in zip(groups, wss):
+                _lib.check(lib.ctts_taco_decoder_init_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(mem[g0:g1]), _lib.ptr(lens[g0:g1]),
+                                                         g1 - g0, T, _lib.ptr(ws), ws.numel() * 4, stream),
+                           "ctts_taco_decoder_init_f32")
             done, n_total, state = 0, None, None
             while done < max_steps and n_total is None:
                 n = min(STOP_CHECK_EVERY if fixed_steps is None else max_steps, max_steps - done)
-                _lib.check(lib.ctts_taco_decoder_steps_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(keep_masks),
-                                                          _lib.ptr(mel), _lib.ptr(gate), _lib.ptr(align), B, T, done, n,
-                                                          max_steps, _lib.ptr(ws), stream), "ctts_taco_decoder_steps_f32")
+                for (g0, g1), ws, km in zip(groups, wss, masks):
+                    _lib.check(lib.ctts_taco_decoder_steps_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(km), _lib.ptr(mel[g0:g1]),
+                                                              _lib.ptr(gate[g0:g1]), _lib.ptr(align[g0:g1]), g1 - g0, T, done,
+                                                              n, max_steps, _lib.ptr(ws), stream), "ctts_taco_decoder_steps_f32")
                 if fixed_steps is None:
                     n_total, state = stop_step(gate[:, done:done + n].cpu(), self.gate_threshold, self.gate_delay,
                                                max_steps, state)
@@ -288,6 +297,7 @@ class Decoder(nn.Module):
         return (mel[:, :, :n_total].contiguous(), torch.sigmoid(gate[:, :n_total]), align[:, :n_total].contiguous(), None)
 
 
+MAX_GROUP = 4      # utterances per decoder / packed-LSTM workspace (ctts_taco_decoder_*, ctts_lstm_seq_*: batch <= 4)
 PAD = 8            # halo of the padded [B][C][ld] layout used by the conv primitives (>= kernel_size // 2)
 
 
@@ -470,15 +480,18 @@ class Encoder(nn.Module):
                 op(x, y, False, B, T, ld)
                 x = y
             lens = text_lengths.to(device=device, dtype=torch.int32).contiguous()
-            nbytes = lib.ctts_lstm_seq_workspace_bytes(H, B, ld)
-            if nbytes == 0:
-                raise _lib.HipLibraryError("lstm_seq workspace query failed (batch <= 4): " + lib.ctts_last_error().decode())
-            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
             row = memory_in.shape[2]
-            for d, blob in enumerate(packs):
-                _lib.check(lib.ctts_lstm_seq_f32(_lib.ptr(blob), _lib.ptr(x), _lib.ptr(lens), d, _lib.ptr(memory_in), T * row,
-                                                row, d * H, _lib.ptr(hn), 2 * H, d * H, B, T, I, H, ld, PAD, _lib.ptr(ws),
-                                                ws.numel() * 4, st), "ctts_lstm_seq_f32")
+            for g0 in range(0, B, MAX_GROUP):                  # the packed-sequence LSTM runs <= MAX_GROUP utterances per call
+                g1 = min(g0 + MAX_GROUP, B)
+                nbytes = lib.ctts_lstm_seq_workspace_bytes(H, g1 - g0, ld)
+                if nbytes == 0:
+                    raise _lib.HipLibraryError("lstm_seq workspace query failed: " + lib.ctts_last_error().decode())
+                ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+                for d, blob in enumerate(packs):
+                    _lib.check(lib.ctts_lstm_seq_f32(_lib.ptr(blob), _lib.ptr(x[g0:g1]), _lib.ptr(lens[g0:g1]), d,
+                                                    _lib.ptr(memory_in[g0:g1]), T * row, row, d * H, _lib.ptr(hn[g0:g1]), 2 * H,
+                                                    d * H, g1 - g0, T, I, H, ld, PAD, _lib.ptr(ws), ws.numel() * 4, st),
+                               "ctts_lstm_seq_f32")
 
 
 class SylpsNet(nn.Module):

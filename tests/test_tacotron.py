@@ -177,3 +177,33 @@ def test_oracle_full_model_matches_reference_golden():
     assert np.abs(o["pred_sylps"] - g["pred_sylps"]).max() < 1e-6
     assert np.abs(o["pred_mel_postnet"] - g["pred_mel_postnet"]).max() < 1e-5
     assert np.abs(o["alignments"] - g["alignments"]).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_batches_larger_than_a_device_group_run_in_lockstep(hip_lib_path):
+    """The device loop holds 4 utterances per workspace; the host runs larger batches as groups that advance together
+    (one stop-rule evaluation over the whole batch, model.py:898-904).  7 utterances = groups of 4 + 3."""
+    m, g, hp, sd = _model()
+    B, T, n = 7, 37, 14
+    rng = np.random.default_rng(77)
+    memory_in = (rng.standard_normal((B, T, synthetic.tacotron_memory_in_dim(hp))) * 0.5).astype(np.float32)
+    lengths = np.array([37, 30, 21, 37, 18, 25, 33], dtype=np.int64)
+    masks = synthetic.prenet_dropout_masks(n, B, seed=8)
+    mem, lens = torch.from_numpy(memory_in).cuda(), torch.from_numpy(lengths).cuda()
+    mel, gate, align, _ = m.decoder.inference(mem, lens, keep_masks=masks, fixed_steps=n)
+    ref_mel, ref_gate, ref_align = to.decoder_inference_steps(sd, hp, memory_in, lengths, masks, n)
+    assert np.abs(mel.cpu().numpy() - ref_mel).max() < MEL_TOL
+    assert np.abs(align.cpu().numpy() - ref_align).max() < MEL_TOL
+    for g0, g1 in ((0, 4), (4, 7)):                       # each group alone reproduces its rows bit for bit
+        one = m.decoder.inference(mem[g0:g1].contiguous(), lens[g0:g1], keep_masks=np.ascontiguousarray(masks[:, :, g0:g1]),
+                                  fixed_steps=n)
+        assert torch.equal(one[0], mel[g0:g1]) and torch.equal(one[2], align[g0:g1])
+    # free-running: every item past the threshold -> the batch stops together, 5 utterances through the whole model
+    text = torch.from_numpy(rng.integers(1, 179, size=(5, 30))).cuda()
+    tl = torch.tensor([30, 22, 17, 30, 9]).cuda()
+    tm = torch.from_numpy(rng.standard_normal((5, 2304)).astype(np.float32)).cuda()
+    spk = torch.arange(5).cuda()
+    out = m.inference(text, tl, spk, tm, fixed_steps=6)
+    assert out["pred_mel_postnet"].shape == (5, 80, 6) and torch.isfinite(out["pred_mel_postnet"]).all()
+    part = m.inference(text[4:], tl[4:], spk[4:], tm[4:], keep_masks=None, fixed_steps=6)
+    assert np.abs(out["encoder_outputs"][4].cpu().numpy() - part["encoder_outputs"][0].cpu().numpy()).max() < 1e-6
