@@ -22,8 +22,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int STAGE = GEMM_KC * (256 + 128);            // 6144 floats = 24 KiB for both shapes
-constexpr int SEGTAB = 2 * STAGE;                       // segment table: GEMM_MAX_SEG x 4 dwords
-constexpr int LDS_FLOATS = SEGTAB + GEMM_MAX_SEG * 4;
+// (the segment table, GEMM_MAX_SEG x 4 dwords, sits behind the last stage)
+constexpr int GEMM_GLDS_MAX_CHUNKS = 256;               // DMA-staged kernels: chunk address table entries
 
 // Gate math on the hardware transcendental unit: exp via v_exp_f32 (2^x), reciprocal via
 // v_rcp_f32 (1 ulp).  Absolute error of tanh/sigmoid <= ~3e-7, far inside the parity budget.
@@ -99,8 +99,17 @@ __device__ __forceinline__ void split_epilogue(const GemmArgs& a, f32x16 (&acc)[
 
 // SEGS = 4: segment bases live in registers and are picked with a scalar-compare select chain (no LDS
 // round trip at the top of a chunk); SEGS = GEMM_MAX_SEG: bases come from the LDS segment table.
-template <int EPI, int WM, int SEGS>
+// GLDS: global -> LDS staging by direct DMA (global_load_lds, 16 B per lane), three stages, two chunks ahead, counted
+// vmcnt + raw s_barrier.  Measured on the config-2 in-layer launch: with staging through registers (6 x 16-byte
+// global loads + 6 x ds_write_b128 per thread per chunk) the kernel ran at 81.6 % of the MFMA peak, with the staging
+// removed altogether (stale operands) at 89.9 %: the LDS write port and the VGPR round trip were delaying the
+// fragment reads that feed the matrix pipe.
+template <int EPI, int WM, int SEGS, bool GLDS>
 __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a) {
+    constexpr int NST = GLDS ? 3 : 2;
+    constexpr int SEGTAB = NST * STAGE;
+    constexpr int CHTAB = SEGTAB + GEMM_MAX_SEG * 4;         // GLDS: chunk -> B base address table (8 B per chunk)
+    constexpr int LDS_FLOATS = CHTAB + (GLDS ? 2 * GEMM_GLDS_MAX_CHUNKS : 0);
     constexpr int BM = 128 * WM;
     constexpr int WN = 4 / WM;
     constexpr int BN = 64 * WN;
@@ -111,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
 
     const int t = threadIdx.x;
     const int lane = t & 63;
-    const int wave = t >> 6;
+    const int wave = GLDS ? __builtin_amdgcn_readfirstlane(t >> 6) : (t >> 6);   // scalar for the DMA's LDS bases
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lhi = lane >> 5;
 
@@ -172,9 +181,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
     const int nalloc = a.a_nch_alloc ? a.a_nch_alloc : a.nch_total;
     const float* ap = a.A + ((size_t)mb * nalloc + a.a_ch_off) * A_STAGE + t * 4;
 
-    const int brow = t >> 4;            // 0..15  (k row of the B chunk)
-    const int bcol = (t & 15) * 4;      // 0..60  (+64 j)
+    // register staging: thread -> (k row t/16, columns 4(t%16) + 64j).  DMA staging: a wave instruction fills 1 KiB of
+    // LDS linearly in lane order = 256/BN whole k-rows, piece (wave + 4j) of the stage.
+    constexpr int UPR = BN / 4;                              // 16-byte units per k-row of the B stage
+    constexpr int RPP = 64 / UPR;                            // k-rows per DMA piece (2 or 1)
+    const int brow = GLDS ? wave * RPP + lane / UPR : t >> 4;
+    const int bcol = GLDS ? (lane % UPR) * 4 : (t & 15) * 4;
     const size_t thread_off = (size_t)brow * a.ld + bcol;
+    const size_t piece_stride = (size_t)4 * RPP * a.ld;      // DMA: next piece of the same thread
     const size_t chunk_rows = (size_t)GEMM_KC * a.ld;
 
     f32x16 acc[4][2];
@@ -191,6 +205,35 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
     const int ilv = a.interleave > 1 ? a.interleave : 0;
     bool in_ilv = ilv > 0;
     if constexpr (SEGS != 4) __syncthreads();   // segment table visible
+    if constexpr (GLDS) {
+        // chunk c -> address of its B rows (k row 0, column n0 + shift): the segment / interleave sequencing is
+        // resolved once, so the loop body below is one basic block the scheduler can weave DMA issues into
+        unsigned long long* tab = reinterpret_cast<unsigned long long*>(lds + CHTAB);
+        const int ilv0 = a.interleave > 1 ? a.interleave : 0;
+        const int n_il = ilv0 * a.seg[0].nch;
+        for (int c0 = t; c0 < a.nch_total; c0 += 256) {
+            int c = c0, sg, loc;
+            if (c < n_il) {
+                sg = c % ilv0;
+                loc = c / ilv0;
+            } else {
+                c -= n_il;
+                sg = ilv0;
+#pragma unroll
+                for (int k = 0; k < GEMM_MAX_SEG - 1; ++k)   // static kernarg indices only
+                    if (k < SEGS - 1 && sg == k && k < a.nseg - 1 && c >= a.seg[k].nch) { c -= a.seg[k].nch; sg = k + 1; }
+                loc = c;
+            }
+            const float* base = nullptr;
+#pragma unroll
+            for (int k = 0; k < GEMM_MAX_SEG; ++k)
+                if (k < SEGS && sg == k)
+                    base = a.seg[k].base + (size_t)b * a.seg[k].bstride + (size_t)(mb * a.seg[k].mb_rows) * a.ld +
+                           (a.pad + n0 + a.seg[k].shift);
+            tab[c0] = reinterpret_cast<unsigned long long>(base + (size_t)loc * GEMM_KC * a.ld);
+        }
+        __syncthreads();
+    }
 
 #define CTTS_ISSUE_LOADS()                                                                      \
     do {                                                                                        \
@@ -241,45 +284,120 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
         }                                                                                       \
     } while (0)
 
-    CTTS_ISSUE_LOADS();
-    CTTS_STORE_LDS(0);
-    __syncthreads();
+    typedef __attribute__((address_space(3))) float* lds_fptr;
+    const gfloat_ptr apg = (gfloat_ptr)ap;
+    const unsigned long long* ctab = reinterpret_cast<const unsigned long long*>(lds + CHTAB);
+    // DMA piece p (0..5) of chunk c into stage buf: pieces [0, NA) = A, [NA, 6) = B; `bp_` = this thread's B address
+#define CTTS_GLDS_PIECE(p, la_, ac_, bp_)                                                                   \
+    do {                                                                                                    \
+        if constexpr ((p) < NA) __builtin_amdgcn_global_load_lds((ac_) + 1024 * (p), (la_) + 1024 * (p), 16, 0, 0); \
+        else __builtin_amdgcn_global_load_lds((bp_) + ((p) - NA) * piece_stride, (la_) + A_STAGE + 1024 * ((p) - NA), 16, 0, 0); \
+    } while (0)
+#define CTTS_GLDS_ADDR(buf, c)                                                                              \
+    lds_fptr la_ = (lds_fptr)(lds + (buf) * STAGE + wave * 256);                                            \
+    const gfloat_ptr ac_ = apg + (size_t)(c) * A_STAGE;                                                     \
+    const unsigned long long ub_ = ctab[c];                                                                 \
+    const unsigned long long us_ =                                                                          \
+        ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |            \
+        (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                                 \
+    const gfloat_ptr bp_ = reinterpret_cast<gfloat_ptr>(us_) + thread_off;
+#define CTTS_ISSUE_GLDS(buf, c)                                                                             \
+    do {                                                                                                    \
+        CTTS_GLDS_ADDR(buf, c)                                                                              \
+        CTTS_GLDS_PIECE(0, la_, ac_, bp_); CTTS_GLDS_PIECE(1, la_, ac_, bp_); CTTS_GLDS_PIECE(2, la_, ac_, bp_); \
+        CTTS_GLDS_PIECE(3, la_, ac_, bp_); CTTS_GLDS_PIECE(4, la_, ac_, bp_); CTTS_GLDS_PIECE(5, la_, ac_, bp_); \
+    } while (0)
 
     const int nch = a.nch_total;
+    if constexpr (GLDS) {
+        // six DMAs per thread per chunk, in order: vmcnt(6) = "everything but the newest chunk has landed"
+        // (the last two iterations re-issue the final chunk into a stage nobody reads any more: the body stays
+        // branch-free and the DMA count per iteration constant)
+        CTTS_ISSUE_GLDS(0, 0);
+        CTTS_ISSUE_GLDS(1, nch > 1 ? 1 : 0);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+        CTTS_ISSUE_LOADS();
+        CTTS_STORE_LDS(0);
+        __syncthreads();
+    }
+
+    int cur = 0;
     for (int ch = 0; ch < nch; ++ch) {
-        const int cur = ch & 1;
         const bool more = ch + 1 < nch;
-        if (more) CTTS_ISSUE_LOADS();
         const float* As = lds + cur * STAGE + wm * 128 + l31;
         const float* Bs = lds + cur * STAGE + A_STAGE + wn * 64 + l31;
-        // k-step ks+1's fragments are read from LDS while ks runs on the MFMA pipe; the
-        // sched_group_barrier sequence pins that software pipeline (hipcc otherwise sinks every
-        // ds_read to just before its first use and exposes the LDS latency 16x per chunk).
         float av[GEMM_KC / 2][4], bv[GEMM_KC / 2][2];
-#pragma unroll
-        for (int ks = 0; ks < GEMM_KC / 2; ++ks) {
-            const int krow = 2 * ks + lhi;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) av[ks][mt] = As[krow * BM + mt * 32];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) bv[ks][nt] = Bs[krow * BN + nt * 32];
-        }
-#pragma unroll
-        for (int ks = 0; ks < GEMM_KC / 2; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+        if constexpr (GLDS) {
+            // One region per k-step, fenced: [fragments of k-step ks+1 | 8 MFMAs of k-step ks | one DMA piece of chunk
+            // ch+2].  The DMA issue (~60 cycles of this wave's instruction stream) sits behind eight 64-cycle MFMAs
+            // already queued on the matrix pipe instead of in front of the chunk.
+            const int nb = cur >= 1 ? cur - 1 : 2;          // (cur + 2) % 3: the stage of chunk ch-1
+            const int cn = ch + 2 < nch ? ch + 2 : nch - 1;
+            CTTS_GLDS_ADDR(nb, cn)
+#define CTTS_READ_FRAGS(ks)                                                                     \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) av[ks][mt] = As[(2 * (ks) + lhi) * BM + mt * 32]; \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) bv[ks][nt] = Bs[(2 * (ks) + lhi) * BN + nt * 32];
+#define CTTS_MFMA8(ks)                                                                          \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                    \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                \
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks][mt], bv[ks][nt], acc[mt][nt], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);      // 3 x ds_read2_b32: fragments of k-step 0
+#define CTTS_REGION(ks, p)                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                  \
+            if constexpr ((ks) + 1 < GEMM_KC / 2) { CTTS_READ_FRAGS((ks) + 1) }                 \
+            CTTS_MFMA8(ks)                                                                      \
+            if constexpr ((p) >= 0) CTTS_GLDS_PIECE((p) < 0 ? 0 : (p), la_, ac_, bp_);
+            CTTS_READ_FRAGS(0)
+            CTTS_REGION(0, 0) CTTS_REGION(1, 1) CTTS_REGION(2, 2) CTTS_REGION(3, 3)
+            CTTS_REGION(4, 4) CTTS_REGION(5, 5) CTTS_REGION(6, -1) CTTS_REGION(7, -1)
+#undef CTTS_REGION
+#undef CTTS_MFMA8
+#undef CTTS_READ_FRAGS
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                // chunk ch+1 landed, the newest in flight
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            cur = cur == 2 ? 0 : cur + 1;
+        } else {
+            if (more) CTTS_ISSUE_LOADS();
+            // k-step ks+1's fragments are read from LDS while ks runs on the MFMA pipe; the
+            // sched_group_barrier sequence pins that software pipeline (hipcc otherwise sinks every
+            // ds_read to just before its first use and exposes the LDS latency 16x per chunk).
 #pragma unroll
-        for (int ks = 0; ks < GEMM_KC / 2 - 1; ++ks) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // fragments of k-step ks+1
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);  // 8 MFMAs of k-step ks
+            for (int ks = 0; ks < GEMM_KC / 2; ++ks) {
+                const int krow = 2 * ks + lhi;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) av[ks][mt] = As[krow * BM + mt * 32];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) bv[ks][nt] = Bs[krow * BN + nt * 32];
+            }
+#pragma unroll
+            for (int ks = 0; ks < GEMM_KC / 2; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks][mt], bv[ks][nt], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);      // 3 x ds_read2_b32: fragments of k-step 0
+#pragma unroll
+            for (int ks = 0; ks < GEMM_KC / 2 - 1; ++ks) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // fragments of k-step ks+1
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);  // 8 MFMAs of k-step ks
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            if (more) CTTS_STORE_LDS(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-        if (more) CTTS_STORE_LDS(cur ^ 1);
-        __syncthreads();
+    }
+#undef CTTS_ISSUE_GLDS
+#undef CTTS_GLDS_ADDR
+#undef CTTS_GLDS_PIECE
+    if constexpr (GLDS) {                                   // the re-issued tail DMAs still target LDS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 #undef CTTS_ISSUE_LOADS
 #undef CTTS_STORE_LDS
@@ -384,16 +502,22 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
     }
 }
 
-template <int EPI>
-void launch_shape(int bm, dim3 grid, hipStream_t stream, const GemmArgs& a) {
+template <int EPI, bool GLDS>
+void launch_shape_g(int bm, dim3 grid, hipStream_t stream, const GemmArgs& a) {
     const bool few = a.nseg <= 4;
     if (bm == 128) {
-        if (few) hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 1, 4>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 1, GEMM_MAX_SEG>), grid, dim3(256), 0, stream, a);
+        if (few) hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 1, 4, GLDS>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 1, GEMM_MAX_SEG, GLDS>), grid, dim3(256), 0, stream, a);
     } else {
-        if (few) hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 2, 4>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 2, GEMM_MAX_SEG>), grid, dim3(256), 0, stream, a);
+        if (few) hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 2, 4, GLDS>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 2, GEMM_MAX_SEG, GLDS>), grid, dim3(256), 0, stream, a);
     }
+}
+
+template <int EPI>
+void launch_shape(int bm, dim3 grid, hipStream_t stream, const GemmArgs& a) {
+    if (getenv("CTTS_F32_NO_GLDS") || a.nch_total > GEMM_GLDS_MAX_CHUNKS) launch_shape_g<EPI, false>(bm, grid, stream, a);
+    else launch_shape_g<EPI, true>(bm, grid, stream, a);
 }
 
 }  // namespace
@@ -440,8 +564,13 @@ int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
         case GEMM_EPI_GATE_RS:
             CTTS_CHECK_ARG(a.bm == 128 && a.pairC <= 64 && a.MB == 1 && a.rs_wT && a.rs_bias && (a.rs_rows == 64 || a.rs_rows == 128),
                            "gemm: fused res/skip needs bm=128, <= 64 channels");
-            if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, 4>), grid, dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, GEMM_MAX_SEG>), grid, dim3(256), 0, stream, a);
+            if (getenv("CTTS_F32_NO_GLDS") || a.nch_total > GEMM_GLDS_MAX_CHUNKS) {
+                if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, 4, false>), grid, dim3(256), 0, stream, a);
+                else hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, GEMM_MAX_SEG, false>), grid, dim3(256), 0, stream, a);
+            } else {
+                if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, 4, true>), grid, dim3(256), 0, stream, a);
+                else hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, GEMM_MAX_SEG, true>), grid, dim3(256), 0, stream, a);
+            }
             break;
         case GEMM_EPI_MAG: launch_shape<GEMM_EPI_MAG>(a.bm, grid, stream, a); break;
         case GEMM_EPI_LOG: launch_shape<GEMM_EPI_LOG>(a.bm, grid, stream, a); break;
