@@ -35,11 +35,11 @@ sys.path.insert(0, REPO)
 METRIC = "audio samples/sec (22.05kHz) WaveGlow infer, 80×900 mel, 1/2/4/8 GPU; real-time factor"
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
-# HBM bytes per in-layer launch from the committed PMC passes (profiles/r1_12_pmc_traffic.json:
+# HBM bytes per in-layer launch from the committed PMC passes (profiles/r1_17_pmc_traffic.json:
 # 2 x FETCH_SIZE (gfx950 half-count correction, calibrated on flow_tail) + WRITE_SIZE), config 2 shapes only
 TRAFFIC = {}
 try:
-    with open(os.path.join(REPO, "profiles", "r1_12_pmc_traffic.json")) as _f:
+    with open(os.path.join(REPO, "profiles", "r1_17_pmc_traffic.json")) as _f:
         TRAFFIC = {k: v.get("hbm_bytes_per_launch") for k, v in json.load(_f).items()}
 except Exception:
     pass
