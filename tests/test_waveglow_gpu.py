@@ -170,6 +170,20 @@ def test_waveglow_bf16_block_shapes_agree(hip_lib_path, monkeypatch, knob):
     assert torch.equal(default, other)
 
 
+@pytest.mark.parametrize("knob", ["CTTS_F32_NO_GLDS", "CTTS_GEMM_NO_XCD_PAIR"])
+def test_waveglow_fp32_staging_variants_agree(hip_lib_path, monkeypatch, knob):
+    """fp32 conv-GEMM: DMA-staged 3-stage kernel (default) vs the register-staged one, and both block mappings:
+    same K order, so the waveforms are identical (full model, ragged width, enough tiles for every path)."""
+    m, cfg, sd = _model("full", 5)
+    B, F = 2, 37
+    mel = torch.from_numpy(synthetic.synthetic_mel(B, F, seed=6)).cuda()
+    z = torch.from_numpy(synthetic.synthetic_noise(B, 8, F * 32, seed=6) * np.float32(0.6)).cuda()
+    default = m.infer_from_noise(mel, z)
+    assert torch.isfinite(default).all()
+    monkeypatch.setenv(knob, "1")
+    assert torch.equal(default, m.infer_from_noise(mel, z))
+
+
 def test_5_infer_vocoder_slot(hip_lib_path, tmp_path):
     """The two call sites of _5_infer/t2s_server/text2speech.py (:175-179, :658-665) against a reference-format
     checkpoint (train.py:128-145)."""
