@@ -176,6 +176,11 @@ def main():
                     "achieved": round(bytes2 / mean2 / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(bytes2 / mean2 / 8e12, 4), "launches": int(n2.value),
                     "mean_launch_ms": round(mean2 * 1e3, 4), "bytes_per_launch": bytes2}
+                # whole step against HBM with SURVEY 8d's per-layer-kernel byte count (7*C*2 B per step per layer)
+                step_bytes = 7.0 * C * 2 * n_layers * cfg["n_flows"] * B * L
+                roofline["step_hbm_algorithmic"] = {"bytes_per_step": step_bytes, "achieved": round(step_bytes * args.steps / elapsed / 1e9, 1),
+                                                    "peak": 8000.0, "unit": "GB/s",
+                                                    "frac": round(step_bytes * args.steps / elapsed / 8e12, 4)}
         cpu = None
         if world == 1 and args.cpu_frames > 0:
             cpu = cpu_baseline(cfg, sd, args.cpu_frames, seed)

@@ -41,8 +41,11 @@ def row_waveflow(args):
     mac = 0.6515e6 * (G - 1) * cfg["n_flows"] / G          # per output sample
     return {"row": "B/config4", "metric": "audio samples/sec (22.05kHz) WaveFlow infer (8 flows, 64 ch, h=16), 80x900 mel",
             "value": samples / dt, "unit": "samples/s", "rtf": samples / dt / 22050, "ms_per_call": dt * 1e3,
-            "dtype": "f32", "batch": B, "frames": F, "gemm_launches_per_call": 2 * launches,
-            "achieved_tflops_algorithmic": 2 * mac * samples / dt / 1e12}
+            "dtype": "f32", "batch": B, "frames": F, "kernel_launches_per_utterance_batch": launches + 2 * cfg["n_flows"] * (G - 1),
+            "achieved_tflops_algorithmic": 2 * mac * samples / dt / 1e12,
+            # 138 KB of per-layer-kernel traffic per output sample (2304 B per row, step, layer)
+            "achieved_GBps_vs_138KB_per_sample": 138e3 * samples / dt / 1e9,
+            "hbm_frac_vs_138KB_per_sample": 138e3 * samples / dt / 8e12}
 
 
 def row_waveflow_author(args):
@@ -81,11 +84,23 @@ def row_tacotron(args):
     dd = timed(lambda: m.decoder.inference(mem, lens, fixed_steps=steps), 1, args.steps)
     weights_mb = sum(p.numel() for n, p in m.decoder.named_parameters()
                      if "rnn" in n or "projection" in n or "gate" in n or "query" in n or "prenet" in n) * 4 / 1e6
+    # chained vocoder: WaveGlow config 2 weights on the B=4 x 900-frame mel the model just produced
+    from cookietts_amd import WaveGlow
+    wcfg = synthetic.WAVEGLOW_CONFIGS["full"]
+    wg = WaveGlow(**wcfg)
+    wg.load_state_dict(synthetic.to_torch(synthetic.waveglow_state_dict(wcfg, seed=1234)))
+    wg = wg.cuda().eval()
+    mel = m.inference(text, lens, spk, tm, fixed_steps=steps)["pred_mel_postnet"].clamp(-11.52, 2.0)
+    dv = timed(lambda: wg.infer(mel, sigma=0.6), 1, max(1, args.steps - 1))
+    samples = B * steps * 256
     return {"row": "C/config5", "metric": "Tacotron2-TM decoder step time, B=4, 200 symbols, 900 forced steps",
             "value": dd / steps * 1e6, "unit": "us/step", "higher_is_better": False,
             "mel_frames_per_s_batch": B * steps / dd, "end_to_end_ms_incl_encoder_postnet": dt * 1e3,
             "dtype": "f32", "weights_streamed_per_step_MB": weights_mb,
-            "achieved_weight_stream_GBps": weights_mb / 1e3 / (dd / steps)}
+            "achieved_weight_stream_GBps": weights_mb / 1e3 / (dd / steps),
+            "hbm_frac_weight_stream": weights_mb / 1e3 / (dd / steps) / 8000.0,
+            "chained_vocoder_samples_per_s": samples / dv, "chained_vocoder_ms": dv * 1e3,
+            "text_to_wave_rtf": samples / (dt + dv) / 22050.0}
 
 
 def row_stft(args):
