@@ -258,30 +258,33 @@ __device__ __forceinline__ void lstm_body(const LstmCall& q, float* __restrict__
         for (int r = 0; r < R; ++r) pre[j][r] = load4_nt(pre_base + (size_t)r * pre_ld + kc);
     }
     // stage the needed columns of [cell input | previous hidden] for all NB items: 16-byte loads, SB of them in
-    // flight per thread (piece boundaries n0, n0+n1, I and the window bounds are multiples of 4)
+    // flight per thread (piece boundaries n0, n0+n1, I and the window bounds are multiples of 4).  Only the launch's
+    // column window is walked: a "fresh columns" launch of the decoder touches 256 of 2816 columns.
     {
         constexpr int SB = 6;
-        const int K4 = K / 4, total4 = NB * K4;
+        const int nih4 = use_ih ? (pt.ih_k1 - pt.ih_k0) / 4 : 0;
+        const int per4 = nih4 + (pt.do_hh ? H / 4 : 0);      // 16-byte units per item
+        const int total4 = NB * per4;
         for (int base = t; base < total4; base += 256 * SB) {
             float4 v[SB];
+            int kk[SB];
 #pragma unroll
             for (int j = 0; j < SB; ++j) {
                 const int i4 = base + j * 256;
                 const int ic = i4 < total4 ? i4 : 0;
-                const int b = ic / K4, k = (ic % K4) * 4;
-                const bool need = k < I ? (k >= pt.ih_k0 && k < pt.ih_k1) : pt.do_hh != 0;
+                const int b = ic / per4, u = ic % per4;
+                const int k = u < nih4 ? pt.ih_k0 + 4 * u : I + 4 * (u - nih4);
                 const float* src;
                 if (k < n0) src = in0 + b * n0 + k;
                 else if (k < n0 + n1) src = in1 + b * n1 + (k - n0);
                 else if (k < I) src = in2 + b * n2 + (k - n0 - n1);
                 else src = h_old + b * H + (k - I);
-                v[j] = need ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[j] = *reinterpret_cast<const float4*>(src);
+                kk[j] = b * K + k;
             }
 #pragma unroll
-            for (int j = 0; j < SB; ++j) {
-                const int i4 = base + j * 256;
-                if (i4 < total4) *reinterpret_cast<float4*>(xs + (size_t)i4 * 4) = v[j];
-            }
+            for (int j = 0; j < SB; ++j)
+                if (base + j * 256 < total4) *reinterpret_cast<float4*>(xs + kk[j]) = v[j];
         }
     }
     __syncthreads();
