@@ -88,3 +88,39 @@ def test_synthetic_recipe_is_deterministic():
     assert np.abs(a["WN.0.end.weight"]).max() > 0
     z = synthetic.synthetic_noise(2, 8, 64, seed=3)
     assert z.shape == (2, 8, 64) and abs(float(z.std()) - 1.0) < 0.1
+
+
+def test_host_side_queries_of_the_other_families(hip_lib_path):
+    """Size queries and argument validation of the WaveFlow / Tacotron / STFT / conv1d / alignment entry points are host
+    code too: they answer (or refuse with a message) without a GPU."""
+    from cookietts_amd.waveglow_ax import WaveGlow as WaveFlow
+    lib = _lib.lib()
+    for key, folded in (("full", True), ("author", False)):
+        m = WaveFlow(**synthetic.WAVEFLOW_CONFIGS[key])
+        c = m.c_config()
+        assert bool(c.cond_precomputed) != folded and bool(c.seperable_conv) == (key == "author")
+        assert lib.ctts_waveflow_packed_bytes(ctypes.byref(c)) > 0
+        hop = synthetic.WAVEFLOW_CONFIGS[key]["hop_length"]
+        assert lib.ctts_waveflow_workspace_bytes(ctypes.byref(c), 2, 7 * hop) > 0      # L not a multiple of 4 is fine
+    bad = m.c_config()
+    bad.seperable_conv = 0                                  # dense 7x7 = 49 taps: more segments than the GEMM takes
+    assert lib.ctts_waveflow_packed_bytes(ctypes.byref(bad)) == 0 and b"seperable_conv" in lib.ctts_last_error()
+    bad = m.c_config()
+    bad.n_channels = 96
+    assert lib.ctts_waveflow_packed_bytes(ctypes.byref(bad)) == 0 and b"n_channels" in lib.ctts_last_error()
+    # conv1d primitive: c_in must be a multiple of 16, odd kernel <= 11
+    ok = _lib.Conv1dDesc(c_in=32, c_out=24, kernel_size=9, act=1, slope=0.0)
+    assert lib.ctts_conv1d_packed_bytes(ctypes.byref(ok)) > 0
+    for kw in (dict(c_in=40), dict(kernel_size=4), dict(kernel_size=13)):
+        d = _lib.Conv1dDesc(**{**dict(c_in=32, c_out=24, kernel_size=9, act=1, slope=0.0), **kw})
+        assert lib.ctts_conv1d_packed_bytes(ctypes.byref(d)) == 0
+    # alignment scoring and packed-sequence LSTM workspaces
+    assert lib.ctts_alignment_workspace_bytes(4, 900, 200) == (4 * 900 * 2 + 4 * 29 * 200) * 4
+    assert lib.ctts_alignment_workspace_bytes(0, 900, 200) == 0
+    assert lib.ctts_lstm_seq_workspace_bytes(512, 4, 256) > 0 and lib.ctts_lstm_seq_workspace_bytes(512, 5, 256) == 0
+    # Tacotron decoder: batch 1..4 per workspace
+    from cookietts_amd.tacotron2 import Tacotron2
+    dc = Tacotron2(synthetic.tacotron_hparams()).decoder.c_config()
+    assert lib.ctts_taco_decoder_packed_bytes(ctypes.byref(dc)) > 0
+    assert lib.ctts_taco_decoder_workspace_bytes(ctypes.byref(dc), 4, 200) > 0
+    assert lib.ctts_taco_decoder_workspace_bytes(ctypes.byref(dc), 5, 200) == 0
