@@ -293,14 +293,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
         if constexpr ((p) < NA) __builtin_amdgcn_global_load_lds((ac_) + 1024 * (p), (la_) + 1024 * (p), 16, 0, 0); \
         else __builtin_amdgcn_global_load_lds((bp_) + ((p) - NA) * piece_stride, (la_) + A_STAGE + 1024 * ((p) - NA), 16, 0, 0); \
     } while (0)
-#define CTTS_GLDS_ADDR(buf, c)                                                                              \
+#define CTTS_GLDS_ADDR_A(buf, c)                                                                            \
     lds_fptr la_ = (lds_fptr)(lds + (buf) * STAGE + wave * 256);                                            \
     const gfloat_ptr ac_ = apg + (size_t)(c) * A_STAGE;                                                     \
-    const unsigned long long ub_ = ctab[c];                                                                 \
+    const unsigned long long ub_ = ctab[c];
+#define CTTS_GLDS_ADDR_B()                                                                                  \
     const unsigned long long us_ =                                                                          \
         ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |            \
         (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                                 \
     const gfloat_ptr bp_ = reinterpret_cast<gfloat_ptr>(us_) + thread_off;
+#define CTTS_GLDS_ADDR(buf, c) CTTS_GLDS_ADDR_A(buf, c) CTTS_GLDS_ADDR_B()
 #define CTTS_ISSUE_GLDS(buf, c)                                                                             \
     do {                                                                                                    \
         CTTS_GLDS_ADDR(buf, c)                                                                              \
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
             // already queued on the matrix pipe instead of in front of the chunk.
             const int nb = cur >= 1 ? cur - 1 : 2;          // (cur + 2) % 3: the stage of chunk ch-1
             const int cn = ch + 2 < nch ? ch + 2 : nch - 1;
-            CTTS_GLDS_ADDR(nb, cn)
+            CTTS_GLDS_ADDR_A(nb, cn)        // (the table entry is only needed by the B pieces: resolved after region 1)
 #define CTTS_READ_FRAGS(ks)                                                                     \
             _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) av[ks][mt] = As[(2 * (ks) + lhi) * BM + mt * 32]; \
             _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) bv[ks][nt] = Bs[(2 * (ks) + lhi) * BN + nt * 32];
@@ -344,14 +346,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
             _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                    \
                 _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                \
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks][mt], bv[ks][nt], acc[mt][nt], 0, 0, 0);
-#define CTTS_REGION(ks, p)                                                                      \
+#define CTTS_REGION(ks, p, BP)                                                                  \
             __builtin_amdgcn_sched_barrier(0);                                                  \
             if constexpr ((ks) + 1 < GEMM_KC / 2) { CTTS_READ_FRAGS((ks) + 1) }                 \
             CTTS_MFMA8(ks)                                                                      \
-            if constexpr ((p) >= 0) CTTS_GLDS_PIECE((p) < 0 ? 0 : (p), la_, ac_, bp_);
+            if constexpr ((p) >= 0) CTTS_GLDS_PIECE((p) < 0 ? 0 : (p), la_, ac_, BP);
             CTTS_READ_FRAGS(0)
-            CTTS_REGION(0, 0) CTTS_REGION(1, 1) CTTS_REGION(2, 2) CTTS_REGION(3, 3)
-            CTTS_REGION(4, 4) CTTS_REGION(5, 5) CTTS_REGION(6, -1) CTTS_REGION(7, -1)
+            // pieces 0, 1 are A pieces for both block shapes; the B address comes out of the table after them
+            CTTS_REGION(0, 0, ac_) CTTS_REGION(1, 1, ac_)
+            __builtin_amdgcn_sched_barrier(0);
+            CTTS_GLDS_ADDR_B()
+            CTTS_REGION(2, 2, bp_) CTTS_REGION(3, 3, bp_)
+            CTTS_REGION(4, 4, bp_) CTTS_REGION(5, 5, bp_) CTTS_REGION(6, -1, bp_) CTTS_REGION(7, -1, bp_)
 #undef CTTS_REGION
 #undef CTTS_MFMA8
 #undef CTTS_READ_FRAGS
@@ -394,6 +400,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
     }
 #undef CTTS_ISSUE_GLDS
 #undef CTTS_GLDS_ADDR
+#undef CTTS_GLDS_ADDR_A
+#undef CTTS_GLDS_ADDR_B
 #undef CTTS_GLDS_PIECE
     if constexpr (GLDS) {                                   // the re-issued tail DMAs still target LDS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
