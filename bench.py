@@ -6,28 +6,40 @@
 A "step" is one pass of the hot path - ``WaveGlow.infer`` (glow.py:314-350 semantics) of
 BASELINE.json config 2: full WaveGlow (12 flows, 512 WN channels, 8 groups), fp32, on a batch
 of 8 synthetic 80x900 mels already resident in HBM, random-init weights from the deterministic
-recipe in cookietts_amd/synthetic.py.  For N > 1 (launched by torch.distributed.run, one rank
-per GPU over RCCL) every rank runs its own batch of 8 (utterance-batch sharding, weak scaling,
-no data-path collective); the timed region is bracketed by barrier + synchronize and the MAX
-over ranks is used.  Rank 0 prints ONE JSON line.
+recipe in cookietts_amd/synthetic.py.  ``--dtype bf16 --batch 32`` is config 3.
+
+Multi-GPU (one process per GPU, RCCL): for N > 1 every rank runs its own batch (utterance-batch
+sharding, weak scaling, no data-path collective); the timed region is bracketed by barrier +
+synchronize and the MAX over ranks is used.  Rank 0 prints ONE JSON line.  Two ways in:
+
+  * ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` (WORLD_SIZE set), or
+  * plain ``python bench.py --gpus N``: this process then acts as the launcher - it starts N fresh
+    rank processes BEFORE touching torch/HIP itself, relays rank 0's JSON line and exits non-zero if
+    any rank fails.
+
+Rank 0 synthesises the weights; for N > 1 the other ranks receive them through
+``cookietts_amd.sharding.broadcast_state_dict`` (the once-per-model RCCL broadcast of SURVEY.md §8e).
+Beside the timed weak-scaling steps the per-request exchange of §8e is timed once per run:
+``scatter_mels`` (rank 0 -> ranks) and ``gather_waves`` (direct point-to-point into rank 0), reported as
+``exchange.{broadcast_ms, scatter_ms, gather_ms}``.
 
 Extra objects on the line:
   roofline     - the dominant kernel (WN in-layer conv-GEMM: dilated conv + cond + gate),
                  algorithmic FLOPs per launch / mean launch time measured with HIP events
-                 inside the library on the launch stream, vs the fp32 MFMA peak.
-  cpu_baseline - the numpy CPU oracle (a port, test infrastructure) timed on this box's host
-                 cores on a bounded sample of the same model (rank 0, N=1 only).
+                 inside the library on the launch stream, vs the MFMA peak of the dtype.
+  cpu_baseline - oracle/waveglow_torch_cpu.py (a reference-free torch-CPU restatement pinned to the
+                 reference's goldens; test infrastructure) timed on this box's physical cores on ONE
+                 full 80x900 utterance of the same model: 1 warm-up + best-of-N (rank 0, N=1 only).
 """
 from __future__ import annotations
 
 import argparse
-import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
@@ -35,108 +47,239 @@ sys.path.insert(0, REPO)
 METRIC = "audio samples/sec (22.05kHz) WaveGlow infer, 80×900 mel, 1/2/4/8 GPU; real-time factor"
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
-# HBM bytes per in-layer launch from the committed PMC passes (profiles/r1_17_pmc_traffic.json:
-# 2 x FETCH_SIZE (gfx950 half-count correction, calibrated on flow_tail) + WRITE_SIZE), config 2 shapes only
-TRAFFIC = {}
-try:
-    with open(os.path.join(REPO, "profiles", "r1_17_pmc_traffic.json")) as _f:
-        TRAFFIC = {k: v.get("hbm_bytes_per_launch") for k, v in json.load(_f).items()}
-except Exception:
-    pass
+# HBM bytes per in-layer launch from committed PMC passes (2 x FETCH_SIZE (gfx950 half-count correction,
+# calibrated on flow_tail) + WRITE_SIZE), config 2 shapes only; not re-measured inside a bench run.
+TRAFFIC_FILES = ["r2_pmc_traffic.json", "r1_17_pmc_traffic.json"]
 
 
-def cpu_baseline(cfg, sd, frames, seed):
-    """Oracle (numpy) on host cores: one utterance of `frames` mel frames through the full model."""
-    from oracle import waveglow_oracle as wo
-    from cookietts_amd import synthetic
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    folded = wo.fold_state_dict(sd)
-    mel = synthetic.synthetic_mel(1, frames, seed=seed)
-    z = synthetic.synthetic_noise(1, cfg["n_group"], frames * cfg["hop_length"] // cfg["n_group"], seed=seed)
-    z = z * np.float32(0.6)
-    t0 = time.perf_counter()
-    wave = wo.waveglow_infer(folded, cfg, mel, z)
-    dt = time.perf_counter() - t0
-    return {"value": wave.size / dt, "unit": "samples/s", "cores": int(cores), "kind": "port",
-            "sample": f"numpy oracle, same 12x512 model, 1 utterance x {frames} mel frames "
-                      f"({wave.size} samples) in {dt:.1f} s"}
+def load_traffic():
+    for name in TRAFFIC_FILES:
+        try:
+            with open(os.path.join(REPO, "profiles", name)) as f:
+                return {k: v.get("hbm_bytes_per_launch") for k, v in json.load(f).items()}, "profiles/" + name
+        except Exception:
+            continue
+    return {}, None
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="utterances per GPU (config 2: 8)")
+    ap.add_argument("--batch", type=int, default=8, help="utterances per GPU (config 2: 8; config 3: 32)")
     ap.add_argument("--frames", type=int, default=900)
     ap.add_argument("--config", default="full", help="key of cookietts_amd.synthetic.WAVEGLOW_CONFIGS")
-    ap.add_argument("--cpu-frames", type=int, default=128, help="mel frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=900,
+                    help="mel frames of the CPU-baseline utterance (0 = skip; default = the metric's 900)")
+    ap.add_argument("--cpu-budget", type=float, default=40.0, help="wall-time budget (s) of the CPU-baseline repeats")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-exchange", action="store_true", help="skip the scatter/gather timing for N > 1")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = BASELINE config 2 (default, the headline); bf16 = config 3 (use --batch 32)")
-    args = ap.parse_args()
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="test hook for tests/test_bench_launcher.py: gloo on CPU with a stand-in step function; "
+                         "exercises the launcher, the rank plumbing and sharding.py only - measures nothing")
+    return ap.parse_args(argv)
 
+
+# ----------------------------------------------------------------------------- launcher ----
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Start ``n`` fresh rank processes of this script.  The parent has not imported torch and makes
+    no HIP call, so nothing GPU-initialised is ever forked or exec'd.  Returns the exit code."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      stderr=None, text=True))
+    failed = None
+    out0 = None
+    pending = set(range(n))
+    while pending and failed is None:
+        for r in sorted(pending):
+            if r == 0 and out0 is None and procs[0].poll() is not None:
+                out0 = procs[0].stdout.read()
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0:
+                failed = (r, rc)
+                break
+        if pending and failed is None:
+            time.sleep(0.2)
+            if out0 is None and procs[0].poll() is not None:
+                out0 = procs[0].stdout.read()
+    if failed is not None:
+        for r in pending:                     # the others would hang in a collective: end exactly these PIDs
+            procs[r].terminate()
+        for r in pending:
+            try:
+                procs[r].wait(20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        sys.stderr.write(f"[bench launcher] rank {failed[0]} exited with code {failed[1]}\n")
+        if out0 is None and procs[0].stdout is not None:
+            try:
+                out0 = procs[0].stdout.read()
+            except Exception:
+                out0 = ""
+        sys.stdout.write(out0 or "")
+        return failed[1] if failed[1] > 0 else 1
+    if out0 is None:
+        out0 = procs[0].stdout.read()
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    for ln in out0.splitlines():
+        if not ln.startswith("{"):
+            sys.stderr.write(ln + "\n")
+    if not lines:
+        sys.stderr.write("[bench launcher] rank 0 printed no JSON line\n")
+        return 1
+    print(lines[-1])
+    return 0
+
+
+# ------------------------------------------------------------------------------- worker ----
+def cpu_baseline(cfg, sd, frames, seed, budget_s):
+    from oracle import waveglow_torch_cpu as wt
+    r = wt.timed_baseline(sd, cfg, frames, seed, budget_s=budget_s)
+    return {"value": r["value"], "unit": "samples/s", "cores": r["cores"], "kind": "port",
+            "sample": f"oracle/waveglow_torch_cpu.py (torch CPU conv ops, reference-free restatement pinned to the "
+                      f"reference goldens), same 12x512 model, 1 utterance x {frames} mel frames ({r['samples']} samples), "
+                      f"torch.set_num_threads({r['threads_set']}) = physical cores, 1 warm-up + best of {r['runs']} "
+                      f"= {r['best_s']:.2f} s"}
+
+
+def worker(args):
+    import ctypes
+    import numpy as np
     import torch
     import torch.distributed as dist
-    from cookietts_amd import WaveGlow, _lib, synthetic
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
-                         f"--nproc-per-node {args.gpus}")
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    selftest = args.selftest_launcher
+    from cookietts_amd import sharding, synthetic
+    if selftest:
+        device = torch.device("cpu")
+    else:
+        device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if selftest:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    seed = 1234
-    cfg = synthetic.WAVEGLOW_CONFIGS[args.config]
-    sd = synthetic.waveglow_state_dict(cfg, seed=seed)          # every rank: full replica, same weights
-    model = WaveGlow(**cfg)
-    model.load_state_dict(synthetic.to_torch(sd))
-    model = model.to(device).eval()
-    if args.dtype == "bf16":
-        import torch as _t
-        model.set_compute_dtype(_t.bfloat16)
-    B, F = args.batch, args.frames
-    mel = torch.from_numpy(synthetic.synthetic_mel(B, F, seed=seed + rank)).to(device)   # resident in HBM
-    T = F * cfg["hop_length"]
-
-    def step():
-        return model.infer(mel, sigma=0.6)
-
-    def fence():
-        torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
+    def sync():
+        if not selftest:
             torch.cuda.synchronize(device)
 
-    lib = _lib.lib()
+    def fence():
+        sync()
+        if world > 1:
+            dist.barrier()
+            sync()
+
+    seed = 1234
+    cfg = synthetic.WAVEGLOW_CONFIGS["toy" if selftest else args.config]
+    B, F = args.batch, args.frames
+    T = F * cfg["hop_length"]
+    exchange = None
+    sd = None
+    if selftest:
+        lib = None
+        model = torch.nn.Linear(8, 8)                      # something to broadcast
+        if os.environ.get("CTTS_BENCH_SELFTEST_FAIL_RANK") == str(rank):
+            raise SystemExit(7)                            # lets the test see a rank failure propagate
+
+        def step_on(m):                                   # stand-in with the vocoder's shape contract
+            return m.mean(dim=1, keepdim=True).repeat_interleave(cfg["hop_length"], dim=2).reshape(m.shape[0], -1)
+    else:
+        from cookietts_amd import WaveGlow, _lib
+        lib = _lib.lib()
+        model = WaveGlow(**cfg)
+        if rank == 0:                                      # rank 0 owns the checkpoint ...
+            sd = synthetic.waveglow_state_dict(cfg, seed=seed)
+            model.load_state_dict(synthetic.to_torch(sd))
+        model = model.to(device).eval()
+        if args.dtype == "bf16":
+            model.set_compute_dtype(torch.bfloat16)
+
+        def step_on(m):
+            return model.infer(m, sigma=0.6)
+
+    if world > 1:                                          # ... every other rank gets it over xGMI (SURVEY 8e)
+        fence()
+        t0 = time.perf_counter()
+        nbytes = sharding.broadcast_state_dict(model, src=0)
+        fence()
+        exchange = {"broadcast_ms": (time.perf_counter() - t0) * 1e3, "broadcast_bytes": int(nbytes)}
+
+    mel = torch.from_numpy(synthetic.synthetic_mel(B, F, seed=seed + rank)).to(device)   # resident in HBM
+
     for _ in range(args.warmup):
-        out = step()
+        out = step_on(mel)
     fence()
-    timing = not args.no_kernel_timing
+    timing = not args.no_kernel_timing and lib is not None
     if timing:
         lib.ctts_profile_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
+        out = step_on(mel)
     fence()
     elapsed = time.perf_counter() - t0
-    lib.ctts_profile_enable(0)
+    if lib is not None:
+        lib.ctts_profile_enable(0)
     assert out.shape == (B, T) and bool(torch.isfinite(out).all())
 
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    # the per-request exchange of SURVEY 8e, outside the timed steps: rank 0 holds world*B mels, scatters the
+    # slices, every rank vocodes its slice, waves are gathered point-to-point into rank 0
+    if world > 1 and not args.no_exchange:
+        n_mel = cfg["n_mel_channels"]
+        all_mels = None
+        if rank == 0:
+            all_mels = torch.cat([torch.from_numpy(synthetic.synthetic_mel(B, F, seed=seed + r)) for r in range(world)]).to(device)
+        for it in range(2):                                # pass 0 opens the point-to-point connections
+            fence()
+            t0 = time.perf_counter()
+            local, counts = sharding.scatter_mels(all_mels, n_mel, device, src=0)
+            fence()
+            t1 = time.perf_counter()
+            wave = step_on(local)
+            fence()
+            t2 = time.perf_counter()
+            waves = sharding.gather_waves(wave, counts, dst=0)
+            fence()
+            t3 = time.perf_counter()
+        if rank == 0:
+            assert waves.shape == (world * B, T) and bool(torch.isfinite(waves).all())
+            if selftest:
+                assert torch.equal(waves, step_on(all_mels))
+        exchange.update(scatter_ms=(t1 - t0) * 1e3, infer_ms=(t2 - t1) * 1e3, gather_ms=(t3 - t2) * 1e3,
+                        scatter_bytes=int(world * B * n_mel * F * 4), gather_bytes=int(world * B * T * 4),
+                        note="steady state (second pass; the first opens the RCCL point-to-point channels); "
+                             "barrier + synchronize on both sides of each leg, so each figure includes one barrier")
 
     if rank == 0:
         samples = world * B * T * args.steps
@@ -146,6 +289,8 @@ def main():
         L = T // cfg["n_group"]
         roofline = None
         if timing:
+            from cookietts_amd import _lib
+            traffic, traffic_src = load_traffic()
             n = ctypes.c_int64()
             ms = ctypes.c_double()
             _lib.check(lib.ctts_profile_collect(_lib.PROF_WN_IN, ctypes.byref(n), ctypes.byref(ms)), "profile")
@@ -159,7 +304,10 @@ def main():
             kname = "conv_gemm_f32_kernel<GATE>" if args.dtype == "f32" else "conv_gemm_bf16_pp_kernel<GATE>"
             roofline = {"kernel": kname + " (WN in-layer: dilated conv + cond + tanh*sigmoid)",
                         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
-                        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": TRAFFIC.get(args.dtype),
+                        "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                        "traffic": traffic.get(args.dtype) if (B, F, args.config) == (8, 900, "full") else None,
+                        "traffic_source": (f"{traffic_src}: committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this "
+                                           f"launch shape, not re-measured in this run") if traffic_src else None,
                         "launches": int(n.value), "mean_launch_ms": round(mean_s * 1e3, 4),
                         "flop_per_launch": flop_per_launch}
             if args.dtype == "bf16":
@@ -169,37 +317,47 @@ def main():
                 n2 = ctypes.c_int64()
                 ms2 = ctypes.c_double()
                 _lib.check(lib.ctts_profile_collect(_lib.PROF_WN_RS, ctypes.byref(n2), ctypes.byref(ms2)), "profile")
-                mean2 = ms2.value / max(n2.value, 1) * 1e-3
-                bytes2 = float(5 * C * 2) * B * L
-                roofline["res_skip_hbm"] = {
-                    "kernel": "conv_gemm_bf16_pp_kernel<SPLIT> (WN res/skip 1x1 + residual/skip accumulate)", "bound": "hbm",
-                    "achieved": round(bytes2 / mean2 / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(bytes2 / mean2 / 8e12, 4), "launches": int(n2.value),
-                    "mean_launch_ms": round(mean2 * 1e3, 4), "bytes_per_launch": bytes2}
+                if n2.value > 0:
+                    mean2 = ms2.value / n2.value * 1e-3
+                    bytes2 = float(5 * C * 2) * B * L
+                    roofline["res_skip_hbm"] = {
+                        "kernel": "conv_gemm_bf16_pp_kernel<SPLIT> (WN res/skip 1x1 + residual/skip accumulate)", "bound": "hbm",
+                        "achieved": round(bytes2 / mean2 / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(bytes2 / mean2 / 8e12, 4), "launches": int(n2.value),
+                        "mean_launch_ms": round(mean2 * 1e3, 4), "bytes_per_launch": bytes2}
                 # whole step against HBM with SURVEY 8d's per-layer-kernel byte count (7*C*2 B per step per layer)
                 step_bytes = 7.0 * C * 2 * n_layers * cfg["n_flows"] * B * L
                 roofline["step_hbm_algorithmic"] = {"bytes_per_step": step_bytes, "achieved": round(step_bytes * args.steps / elapsed / 1e9, 1),
                                                     "peak": 8000.0, "unit": "GB/s",
                                                     "frac": round(step_bytes * args.steps / elapsed / 8e12, 4)}
         cpu = None
-        if world == 1 and args.cpu_frames > 0:
-            cpu = cpu_baseline(cfg, sd, args.cpu_frames, seed)
+        if world == 1 and args.cpu_frames > 0 and not selftest:
+            cpu = cpu_baseline(cfg, sd, args.cpu_frames, seed, args.cpu_budget)
         line = {
             "metric": METRIC, "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic" if not selftest else "LAUNCHER SELF-TEST (gloo/CPU stand-in step; not a measurement)",
             "rtf": value / 22050.0,
             "config": {"workload": f"WaveGlow {args.config} ({cfg['n_flows']} flows, {C} WN ch, "
                                    f"{cfg['n_group']} groups, {n_layers} layers) {'fp32' if args.dtype == 'f32' else 'bf16-MFMA'} infer, batch {B} x (80x{F}) "
                                    f"mel per GPU, sigma 0.6, random-init weights",
                        "batch_per_gpu": B, "frames": F, "samples_per_step": world * B * T,
                        "parallelism": f"utterance-batch shard x{world}"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "exchange": exchange,
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launcher role: nothing below this line in THIS process imports torch or touches HIP
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    worker(args)
 
 
 if __name__ == "__main__":

@@ -30,12 +30,44 @@ def shard_counts(n_items: int, world: int) -> List[int]:
     return [base + (1 if r < extra else 0) for r in range(world)]
 
 
-def broadcast_state_dict(module: torch.nn.Module, src: int = 0, group=None) -> None:
-    """Make every rank's parameters/buffers equal to rank ``src``'s (in place)."""
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+def broadcast_state_dict(module: torch.nn.Module, src: int = 0, group=None, bucket_bytes: int = 256 << 20) -> int:
+    """Make every rank's parameters/buffers equal to rank ``src``'s (in place); returns the bytes broadcast.
+
+    Tensors are coalesced per dtype into flat buckets of up to ``bucket_bytes`` so the 905 MB fp32 WaveGlow
+    replica goes out as four large RCCL broadcasts instead of ~500 small ones (xGMI is per-link bound:
+    few, large messages).  Packed-weight caches of the module are dropped afterwards.
+    """
+    rank = dist.get_rank(group)
+    tensors = [t.data for t in list(module.parameters()) + list(module.buffers())]
+    total = 0
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault((t.dtype, t.device), []).append(t)
+    for (dtype, device), ts in by_dtype.items():
+        cap = max(bucket_bytes // max(ts[0].element_size(), 1), 1)
+        i = 0
+        while i < len(ts):
+            j, n = i, 0
+            while j < len(ts) and (j == i or n + ts[j].numel() <= cap):
+                n += ts[j].numel()
+                j += 1
+            if j - i == 1 and ts[i].is_contiguous():
+                dist.broadcast(ts[i], src=src, group=group)
+            else:
+                flat = torch.empty(n, dtype=dtype, device=device)
+                if rank == src:
+                    torch.cat([t.reshape(-1) for t in ts[i:j]], out=flat)
+                dist.broadcast(flat, src=src, group=group)
+                if rank != src:
+                    off = 0
+                    for t in ts[i:j]:
+                        t.copy_(flat[off:off + t.numel()].view_as(t))
+                        off += t.numel()
+            total += n * ts[i].element_size()
+            i = j
     if hasattr(module, "repack"):
         module.repack()
+    return total
 
 
 def scatter_mels(mels: Optional[torch.Tensor], n_mel: int, device, src: int = 0, group=None):

@@ -1,0 +1,140 @@
+"""Multi-threaded CPU restatement of WaveGlow inference (``glow.py`` topology) on torch CPU ops.
+
+TEST INFRASTRUCTURE ONLY - this is the ``cpu_baseline`` harness BASELINE.md §4 / SURVEY.md §8(d)
+describe: the same algorithm as ``oracle/waveglow_oracle.py`` (numpy), but expressed with
+``F.conv_transpose1d`` / ``F.conv1d`` so that the host's cores are actually used the way the
+reference's CPU path uses them (oneDNN convolutions, intra-op thread pool).  It contains no
+reference code: it is written from the equations of SURVEY.md §8(a) "Verified restatement of rows
+G2-G8".  Only ``tests/`` and ``bench.py``'s ``cpu_baseline`` leg import it; the product path
+(``cookietts_amd``) never does.
+
+Parity pin: ``tests/test_oracle_golden.py`` checks it against the reference's own outputs in
+``tests/golden/waveglow_*.npz`` (same bound as the numpy oracle).
+
+Reference lines each step follows (relative to /root/reference/CookieTTS/_4_mtw/waveglow):
+  upsample + trim + unfold     glow.py:318-324
+  WN stack                     glow.py:188-222, gate glow.py:34-41
+  coupling inverse / inv 1x1   glow.py:337-340, :85-99
+  early outputs / un-squeeze   glow.py:342-349
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def physical_cores() -> int:
+    """Physical cores this process may run on (affinity- and SMT-aware)."""
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = os.cpu_count() or 1
+    phys = None
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False)
+    except Exception:
+        pass
+    if not phys:
+        phys = allowed
+    return max(1, min(int(phys), int(allowed)))
+
+
+def fold(sd):
+    """numpy state dict (weight_g / weight_v pairs) -> dict of torch fp32 effective weights."""
+    out = {}
+    for k, v in sd.items():
+        if k.endswith(".weight_v"):
+            v = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+            g = torch.from_numpy(np.ascontiguousarray(sd[k[:-2] + "_g"], dtype=np.float32))
+            norm = v.flatten(1).norm(dim=1).view(-1, *([1] * (v.dim() - 1)))
+            out[k[:-2]] = v * (g.view_as(norm) / norm)
+        elif not k.endswith(".weight_g"):
+            out[k] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+    return out
+
+
+@torch.no_grad()
+def waveglow_infer(w, cfg, mel, z_scaled):
+    """w = fold(state_dict); mel [B, n_mel, F]; z_scaled [B, n_group, L] (sigma applied) -> wave [B, F*hop]."""
+    mel = torch.as_tensor(mel, dtype=torch.float32)
+    z = torch.as_tensor(z_scaled, dtype=torch.float32)
+    G, hop = cfg["n_group"], cfg["hop_length"]
+    wn = cfg["WN_config"]
+    C, n_layers = wn["n_channels"], wn["n_layers"]
+    n_flows, every, esize = cfg["n_flows"], cfg["n_early_every"], cfg["n_early_size"]
+    B, _, Fr = mel.shape
+    y = F.conv_transpose1d(mel, w["upsample.weight"], w["upsample.bias"], stride=hop)[:, :, :Fr * hop]
+    L = Fr * hop // G
+    spect = y.reshape(B, -1, L, G).permute(0, 1, 3, 2).reshape(B, -1, L)
+    n_early = sum(1 for k in range(1, n_flows) if k % every == 0)
+    lo = n_early * esize
+    audio = z[:, lo:, :]
+    for k in reversed(range(n_flows)):
+        p = f"WN.{k}"
+        h = audio.shape[1] // 2
+        a0, a1 = audio[:, :h], audio[:, h:]
+        x = F.conv1d(a0, w[p + ".start.weight"], w[p + ".start.bias"])
+        c = spect
+        j = 0
+        while f"{p}.cond_layers.{j}.bias" in w:
+            c = F.conv1d(c, w[f"{p}.cond_layers.{j}.weight"], w[f"{p}.cond_layers.{j}.bias"])
+            j += 1
+        out = None
+        for i in range(n_layers):
+            d = 2 ** i
+            u = F.conv1d(x, w[f"{p}.in_layers.{i}.weight"], w[f"{p}.in_layers.{i}.bias"], dilation=d, padding=d)
+            u = u + c[:, 2 * C * i:2 * C * (i + 1)]
+            act = torch.tanh(u[:, :C]) * torch.sigmoid(u[:, C:])
+            r = F.conv1d(act, w[f"{p}.res_skip_layers.{i}.weight"], w[f"{p}.res_skip_layers.{i}.bias"])
+            if i < n_layers - 1:
+                x = x + r[:, :C]
+                skip = r[:, C:]
+            else:
+                skip = r
+            out = skip if out is None else out + skip
+        e = F.conv1d(out, w[p + ".end.weight"], w[p + ".end.bias"])
+        b, log_s = e[:, :h], e[:, h:]
+        a1 = (a1 - b) / torch.exp(log_s)
+        audio = torch.cat([a0, a1], dim=1)
+        w_inv = torch.linalg.inv(w[f"convinv.{k}.conv.weight"][:, :, 0])
+        audio = torch.matmul(w_inv, audio)
+        if k % every == 0 and k > 0:
+            lo -= esize
+            audio = torch.cat([z[:, lo:lo + esize, :], audio], dim=1)
+    assert lo == 0
+    return audio.permute(0, 2, 1).reshape(B, -1).numpy()
+
+
+def timed_baseline(sd, cfg, frames, seed, budget_s=40.0, max_runs=5):
+    """1 warm-up (short utterance: thread pool + oneDNN primitive creation) then best-of-N full utterances.
+
+    Returns dict(value samples/s, cores, runs, best_s, samples).  N is bounded by ``budget_s`` of wall
+    time (at least one timed run always happens).
+    """
+    from cookietts_amd import synthetic
+    cores = physical_cores()
+    torch.set_num_threads(cores)
+    w = fold(sd)
+    G, hop = cfg["n_group"], cfg["hop_length"]
+
+    def inputs(fr):
+        mel = synthetic.synthetic_mel(1, fr, seed=seed)
+        z = synthetic.synthetic_noise(1, G, fr * hop // G, seed=seed) * np.float32(0.6)
+        return mel, z
+
+    waveglow_infer(w, cfg, *inputs(min(32, frames)))          # warm-up
+    mel, z = inputs(frames)
+    best, runs, t_start = None, 0, time.perf_counter()
+    while runs < max_runs and (runs == 0 or time.perf_counter() - t_start + (best or 0) < budget_s):
+        t0 = time.perf_counter()
+        wave = waveglow_infer(w, cfg, mel, z)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        runs += 1
+    return {"value": wave.size / best, "cores": cores, "threads_set": torch.get_num_threads(), "runs": runs,
+            "best_s": best, "samples": int(wave.size), "frames": frames}

@@ -1,0 +1,63 @@
+"""`python bench.py --gpus 2` with WORLD_SIZE unset must start its own rank processes (fresh children, before the
+parent touches torch/HIP), relay rank 0's JSON line and propagate failures.  Runs here on CPU through the launcher's
+self-test hook (gloo, stand-in step function): the spawn logic, rank plumbing and sharding.py exchange are real."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import REPO
+
+BENCH = os.path.join(REPO, "bench.py")
+
+
+def _env():
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def test_launcher_spawns_ranks_and_reports_exchange():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "3",
+                        "--frames", "5", "--selftest-launcher"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                 # exactly one JSON line, from rank 0
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["samples_per_step"] == 2 * 3 * 5 * 256
+    ex = line["exchange"]
+    for k in ("broadcast_ms", "scatter_ms", "gather_ms"):
+        assert ex[k] >= 0.0
+    assert ex["gather_bytes"] == 2 * 3 * 5 * 256 * 4
+    assert "SELF-TEST" in line["data"]                     # can never be mistaken for a measurement
+
+
+def test_launcher_propagates_rank_failure():
+    # rank 1 dies before the first collective; rank 0 would wait for it forever: the launcher must end it and fail
+    env = _env()
+    env["CTTS_BENCH_SELFTEST_FAIL_RANK"] = "1"
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2",
+                        "--frames", "4", "--selftest-launcher"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 7
+    assert "rank 1 exited with code 7" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_parent_does_not_import_torch_before_spawning():
+    """The launcher role runs before any torch import (a GPU-initialised parent must never fork/exec)."""
+    code = (
+        "import sys; sys.argv = ['bench.py', '--gpus', '2']\n"
+        "import bench\n"
+        "seen = {}\n"
+        "def fake(n, argv):\n"
+        "    seen['n'] = n; seen['torch'] = 'torch' in sys.modules; return 0\n"
+        "bench.launch_ranks = fake\n"
+        "try:\n"
+        "    bench.main()\n"
+        "except SystemExit as e:\n"
+        "    assert e.code == 0\n"
+        "assert seen == {'n': 2, 'torch': False}, seen\n")
+    r = subprocess.run([sys.executable, "-c", code], env=_env(), cwd=REPO, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]

@@ -56,3 +56,14 @@ def test_flow_channels_match_reference_schedule():
     # glow.py:255-265 with n_early_every=4, n_early_size=2, 12 flows (SURVEY.md §8 notation)
     cfg = synthetic.WAVEGLOW_CONFIGS["full"]
     assert [c for c, _ in synthetic.waveglow_flow_channels(cfg)] == [8, 8, 8, 8, 6, 6, 6, 6, 4, 4, 4, 4]
+
+
+@pytest.mark.parametrize("name", ["toy", "toy_early", "small", "full_short"])
+def test_torch_cpu_baseline_matches_reference(name):
+    """bench.py's cpu_baseline harness (torch CPU ops) is pinned to the same reference outputs."""
+    from oracle import waveglow_torch_cpu as wt
+    g, cfg, sd = _load(name)
+    wave = wt.waveglow_infer(wt.fold(sd), cfg, g["mel"], g["z_scaled"])
+    assert wave.shape == g["wave"].shape
+    assert rms_rel_err(wave, g["wave"]) < ORACLE_TOL
+    assert wt.physical_cores() >= 1

@@ -27,12 +27,16 @@ def _worker(rank, world, port, n_items, q):
     try:
         torch.manual_seed(0)
         mels = torch.randn(n_items, 80, 6) if rank == 0 else None
-        lin = torch.nn.Linear(3, 2)
+        lin = torch.nn.Sequential(torch.nn.Linear(3, 2), torch.nn.Linear(2, 2), torch.nn.Linear(2, 7))
+        lin.register_buffer("counter", torch.tensor([rank + 5], dtype=torch.int64))
         torch.manual_seed(100 + rank)
         with torch.no_grad():
-            lin.weight.normal_()
-        sharding.broadcast_state_dict(lin, src=0)
-        w = lin.weight.detach().clone()
+            for p in lin.parameters():
+                p.normal_()
+        # 40-byte buckets: [w0 b0] [w1 b1] coalesced, w2 (14 floats) alone, b2, and the int64 buffer in its own dtype group
+        nbytes = sharding.broadcast_state_dict(lin, src=0, bucket_bytes=40)
+        assert nbytes == sum(t.numel() * t.element_size() for t in list(lin.parameters()) + list(lin.buffers()))
+        w = torch.cat([p.detach().reshape(-1) for p in lin.parameters()] + [lin.counter.float()])
         ws = [torch.empty_like(w) for _ in range(world)]
         dist.all_gather(ws, w)
         same = all(torch.equal(ws[0], x) for x in ws)
