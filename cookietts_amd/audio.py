@@ -82,11 +82,11 @@ class STFT(torch.nn.Module):
         self.register_buffer('inverse_basis', inverse_basis.float())
         self._window_sq = torch.from_numpy((fft_window ** 2).astype(np.float32))   # audio_processing.py:47-50
         self._mel_basis_for_pack = None
-        self._packed = None
-        self._ws = {}
+        self._packed = {}            # (device, n_mel) -> packed blob (forward, inverse and mel parts)
+        self._ws = {}                # (device, n_mel, B, T) -> workspace sized for exactly that config
 
     def _apply(self, fn, *a, **kw):
-        self._packed, self._ws = None, {}
+        self._packed, self._ws = {}, {}
         return super()._apply(fn, *a, **kw)
 
     def _c_config(self, n_mel=0, clamp=1e-5):
@@ -105,7 +105,7 @@ class STFT(torch.nn.Module):
         with torch.cuda.device(device):
             stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
             key = (device, n_mel)
-            if self._packed is None or self._packed[0] != key:
+            if key not in self._packed:
                 nbytes = lib.ctts_stft_packed_bytes(C.byref(cfg))
                 if nbytes == 0:
                     raise _lib.HipLibraryError("unsupported STFT config: " + lib.ctts_last_error().decode())
@@ -119,16 +119,9 @@ class STFT(torch.nn.Module):
                 _lib.check(lib.ctts_stft_pack_inverse(C.byref(cfg), _lib.ptr(ib), _lib.ptr(wsq), _lib.ptr(blob), stream),
                            "ctts_stft_pack_inverse")
                 torch.cuda.current_stream(device).synchronize()
-                self._packed = (key, blob)
-            blob = self._packed[1]
-            wkey = (device, B, T)
-            ws = self._ws.get(wkey)
-            if ws is None:
-                nbytes = lib.ctts_stft_workspace_bytes(C.byref(cfg), B, T)
-                if nbytes == 0:
-                    raise _lib.HipLibraryError("STFT workspace query failed: " + lib.ctts_last_error().decode())
-                self._ws = {wkey: torch.zeros(nbytes // 4, dtype=torch.float32, device=device)}
-                ws = self._ws[wkey]
+                self._packed[key] = blob
+            blob = self._packed[key]
+            ws = self._workspace(cfg, device, n_mel, B, T)
             frames = T // self.hop_length + 1
             cutoff = self.filter_length // 2 + 1
             mag = torch.empty(B, cutoff, frames, dtype=torch.float32, device=device) if want_mag else None
@@ -144,17 +137,25 @@ class STFT(torch.nn.Module):
         with torch.cuda.device(device):
             stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
             key = (device, 0)
-            if self._packed is None or self._packed[0] != key:
+            if key not in self._packed:
                 self._run(torch.zeros(1, max(self.filter_length, self.hop_length * 2), device=device), want_mag=True)
-            wkey = (device, B, T)
-            ws = self._ws.get(wkey)
-            if ws is None:
-                nbytes = lib.ctts_stft_workspace_bytes(C.byref(cfg), B, T)
-                if nbytes == 0:
-                    raise _lib.HipLibraryError("STFT workspace query failed: " + lib.ctts_last_error().decode())
-                self._ws = {wkey: torch.zeros(nbytes // 4, dtype=torch.float32, device=device)}
-                ws = self._ws[wkey]
-        return cfg, self._packed[1], ws, stream
+            ws = self._workspace(cfg, device, 0, B, T)
+        return cfg, self._packed[key], ws, stream
+
+    def _workspace(self, cfg, device, n_mel, B, T):
+        """Workspace for exactly (n_mel, B, T): the size query depends on n_mel, so it is part of the key; the two
+        most recent geometries are kept (mel_spectrogram and transform/inverse alternate on one object)."""
+        wkey = (device, n_mel, B, T)
+        ws = self._ws.pop(wkey, None)
+        if ws is None:
+            nbytes = _lib.lib().ctts_stft_workspace_bytes(C.byref(cfg), B, T)
+            if nbytes == 0:
+                raise _lib.HipLibraryError("STFT workspace query failed: " + _lib.lib().ctts_last_error().decode())
+            ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)
+            while len(self._ws) >= 2:
+                self._ws.pop(next(iter(self._ws)))
+        self._ws[wkey] = ws
+        return ws
 
     def transform(self, input_data, return_phase=True):
         """[B, T] -> (magnitude [B, N/2+1, T//hop+1], phase or None)   (stft.py:99-115)"""

@@ -330,8 +330,9 @@ __global__ __launch_bounds__(256) void scale_add_rows_kernel(const float* __rest
 // float64 on the reference's CPU path, ax:351-355).  Thread t owns one contiguous span: pass 1 runs the recurrence
 // from a zero state to get the span's own contribution, thread 0 chains the 256 span ends
 // (carry_out = end + p^len * carry_in), pass 2 re-runs each span from its true incoming state.
-__global__ __launch_bounds__(256) void deemphasis_kernel(const float* __restrict__ x, float* __restrict__ y, int T,
-                                                         double p) {
+// x and y may alias (the host wrapper filters in place): no __restrict__; every thread reads its whole span in pass 1
+// before any thread writes (barrier), and pass 2 reads element n before writing element n of its own span only.
+__global__ __launch_bounds__(256) void deemphasis_kernel(const float* x, float* y, int T, double p) {
     __shared__ double ends[256], gains[256], carry[256];
     const int b = blockIdx.x, t = threadIdx.x;
     const int span = (T + 255) / 256;

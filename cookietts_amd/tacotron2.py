@@ -32,7 +32,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _lib
+from . import _cache, _lib
 
 __all__ = ["Tacotron2", "Decoder", "load_model", "stop_step"]
 
@@ -166,6 +166,7 @@ class Decoder(nn.Module):
         self._memory_in_dim = hp.encoder_LSTM_dim + hp.speaker_embedding_dim + hp.torchMoji_crushedDim + 1
         self._packed = None
         self._ws = {}
+        _cache.hook_invalidate(self)
 
     # ------------------------------------------------------------------ plumbing ----
     def c_config(self):
@@ -184,7 +185,8 @@ class Decoder(nn.Module):
         return super()._apply(fn, *a, **kw)
 
     def _ensure_packed(self, device):
-        if self._packed is not None and self._packed[0] == device:
+        key = _cache.param_key(self)
+        if self._packed is not None and self._packed[0] == device and self._packed[2] == key:
             return self._packed[1]
         if device.type != 'cuda':
             raise _lib.HipLibraryError("Tacotron2 decoder HIP path needs the model on a GPU (no CPU fallback)")
@@ -228,7 +230,7 @@ class Decoder(nn.Module):
             _lib.check(lib.ctts_taco_decoder_pack(C.byref(cfg), C.byref(w), _lib.ptr(blob), stream),
                        "ctts_taco_decoder_pack")
             torch.cuda.current_stream(device).synchronize()
-        self._packed = (device, blob)
+        self._packed = (device, blob, key)
         return blob
 
     # --------------------------------------------------------------------- the path ----
@@ -357,14 +359,18 @@ class Postnet(nn.Module):
             prev_output_layer = is_out
             self.convolutions.append(nn.Sequential(*layers))
 
+    def _invalidate(self):
+        self._hip_ops = None
+
     def _ops(self, device):
-        if getattr(self, "_hip_ops", None) is None or self._hip_ops[0] != device:
+        key = _cache.param_key(self)
+        if getattr(self, "_hip_ops", None) is None or self._hip_ops[0] != device or self._hip_ops[-1] != key:
             n = len(self.convolutions)
             ops = []
             for i, seq in enumerate(self.convolutions):
                 is_out = (bool(self.b_res) and bool(i % self.b_res == 0)) or (i + 1 == n)
                 ops.append(_HipConv1d(seq[0].conv, None if is_out else seq[1], 0 if is_out else 2, 0.0, device))
-            self._hip_ops = (device, ops)
+            self._hip_ops = (device, ops, key)
         return self._hip_ops[1]
 
     def _apply(self, fn, *a, **kw):
@@ -433,8 +439,12 @@ class Encoder(nn.Module):
         self._hip_ops = None
         return super()._apply(fn, *a, **kw)
 
+    def _invalidate(self):
+        self._hip_ops = None
+
     def _ops(self, device):
-        if getattr(self, "_hip_ops", None) is None or self._hip_ops[0] != device:
+        key = _cache.param_key(self)
+        if getattr(self, "_hip_ops", None) is None or self._hip_ops[0] != device or self._hip_ops[-1] != key:
             lib = _lib.lib()
             convs = [_HipConv1d(seq[0].conv, seq[1], 1, 0.01, device) for seq in self.convolutions]
             I, H = self.lstm.input_size, self.lstm.hidden_size
@@ -449,7 +459,7 @@ class Encoder(nn.Module):
                                "ctts_lstm_seq_pack_f32")
                     torch.cuda.current_stream(device).synchronize()
                     packs.append(blob)
-            self._hip_ops = (device, convs, packs)
+            self._hip_ops = (device, convs, packs, key)
         return self._hip_ops[1], self._hip_ops[2]
 
     @torch.no_grad()

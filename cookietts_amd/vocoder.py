@@ -50,8 +50,17 @@ def waveglow_from_checkpoint(checkpoint: dict) -> WaveGlow:
     return model
 
 
-def load_waveglow(vocoder_path, device='cuda', sigma=0.8):
-    """Counterpart of ``T2S.load_hifigan``: returns ``(vocoder, vocoder_config)``."""
-    checkpoint = torch.load(vocoder_path, map_location='cpu', weights_only=False)
+def load_waveglow(vocoder_path, device='cuda', sigma=0.8, trust_checkpoint=False):
+    """Counterpart of ``T2S.load_hifigan``: returns ``(vocoder, vocoder_config)``.
+
+    A reference checkpoint is a dict of tensors, a config dict and a speaker lookup: it loads with
+    ``weights_only=True`` (no pickle code execution).  Checkpoints that pickle other objects (some training runs
+    store the optimizer / hparams objects) need ``trust_checkpoint=True`` - only for files you produced yourself."""
+    try:
+        checkpoint = torch.load(vocoder_path, map_location='cpu', weights_only=True)
+    except Exception:
+        if not trust_checkpoint:
+            raise
+        checkpoint = torch.load(vocoder_path, map_location='cpu', weights_only=False)
     model = waveglow_from_checkpoint(checkpoint).to(device).eval()
     return WaveGlowVocoder(model, sigma=sigma), checkpoint['waveglow_config']

@@ -25,7 +25,7 @@ import math
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _cache, _lib
 
 __all__ = ["WaveGlow", "Invertible1x1Conv", "WN"]
 
@@ -147,7 +147,8 @@ class WaveGlow(nn.Module):
             self.WN.append(WN(n_half, n_mel_channels * n_group, **WN_config))
         self.n_remaining_channels = n_remaining_channels
 
-        self._packed = None          # (device, fp32 blob, bf16 blob or None)
+        self._packed = None          # (device, fp32 blob, bf16 blob or None, param key)
+        _cache.hook_invalidate(self)
         self._compute_dtype = torch.float32
         self._workspaces = {}        # (device, B, F) -> zero-initialised workspace tensor
 
@@ -217,8 +218,11 @@ class WaveGlow(nn.Module):
         return w
 
     def _ensure_packed(self, device):
-        if self._packed is not None and self._packed[0] == device:
+        key = _cache.param_key(self)
+        if self._packed is not None and self._packed[0] == device and self._packed[3] == key:
             return self._packed[1], self._packed[2]
+        if self._packed is not None:
+            self._invalidate()
         if device.type != 'cuda':
             raise _lib.HipLibraryError("WaveGlow HIP path needs the model on a GPU (no CPU fallback)")
         use_bf16 = self._use_bf16()
@@ -284,7 +288,7 @@ class WaveGlow(nn.Module):
                     _lib.check(lib.ctts_waveglow_pack_flow_bf16(C.byref(cfg), k, C.byref(fw), _lib.ptr(bblob), stream),
                                f"ctts_waveglow_pack_flow_bf16({k})")
             torch.cuda.current_stream(device).synchronize()   # dense temporaries may now be freed
-        self._packed = (device, blob, bblob)
+        self._packed = (device, blob, bblob, key)
         return blob, bblob
 
     def _workspace(self, device, B, F, bf16=False):

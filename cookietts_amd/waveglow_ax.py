@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _lib
+from . import _cache, _lib
 
 __all__ = ["WaveGlow"]
 
@@ -209,6 +209,7 @@ class WaveGlow(nn.Module):
                         and self._act_wn[0] == 0)
         self._packed = None
         self._ws = {}
+        _cache.hook_invalidate(self)
 
     # ------------------------------------------------------------------ plumbing ----
     def c_config(self):
@@ -256,7 +257,8 @@ class WaveGlow(nn.Module):
     def _ensure_packed(self, device):
         """-> (blob, cond_ops): packed WaveFlow weights, and (unless the cond layer is folded) the conv operators
         of the conditioning stacks {'model': [...], 'wn': [[...] per flow]}."""
-        if self._packed is not None and self._packed[0] == device:
+        key = _cache.param_key(self)
+        if self._packed is not None and self._packed[0] == device and self._packed[3] == key:
             return self._packed[1], self._packed[2]
         if device.type != 'cuda':
             raise _lib.HipLibraryError("WaveFlow HIP path needs the model on a GPU (no CPU fallback)")
@@ -315,7 +317,7 @@ class WaveGlow(nn.Module):
                        'wn': [stack(c.WN.cond_layers, self._act_wn, wn_cfg.get('cond_out_activation_func', True))
                               for c in self.WN]}                                       # glow_ax.py:573-577
             torch.cuda.current_stream(device).synchronize()
-        self._packed = (device, blob, ops)
+        self._packed = (device, blob, ops, key)
         return blob, ops
 
     def _cond_frames(self, ops, cond, speaker_ids, stream):

@@ -72,7 +72,7 @@ def _run_ref_infer(model, cfg, mel, sigma, torch_seed):
     return wave.numpy().astype(np.float32), z
 
 
-def make_waveglow():
+def make_waveglow(full_length=False):
     torch.set_num_threads(8)
     cases = [
         # name, config key, batch, frames, sigma, seed
@@ -81,6 +81,10 @@ def make_waveglow():
         ("small", "small", 1, 200, 0.6, 1234),              # BASELINE config 1, end to end
         ("full_short", "full", 1, 16, 0.6, 1234),           # BASELINE config 2 topology, short mel
     ]
+    if full_length:
+        # BASELINE config 2 at the metric's utterance length: one 80x900 mel through the 12x512 model
+        # (~70 s of CPU here).  Only the reference's waveform and the noise it drew are stored.
+        cases = [("full_len", "full", 1, 900, 0.6, 4321)]
     for name, key, B, F, sigma, seed in cases:
         cfg = synthetic.WAVEGLOW_CONFIGS[key]
         sd = synthetic.waveglow_state_dict(cfg, seed=seed)
@@ -105,8 +109,13 @@ def make_waveglow():
                           wn_last_b=b_.numpy().astype(np.float32),
                           wn_last_s=s_.numpy().astype(np.float32))
         path = os.path.join(HERE, f"waveglow_{name}.npz")
-        np.savez_compressed(path, config_key=key, seed=seed, sigma=np.float32(sigma), mel=mel,
-                            z_scaled=z, wave=wave, **extras)
+        if full_length:
+            extras["mel_recipe"] = "cookietts_amd.synthetic.synthetic_mel(B, F, n_mel, seed=seed)"
+            np.savez_compressed(path, config_key=key, seed=seed, sigma=np.float32(sigma), B=B, F=F,
+                                z_scaled=z, wave=wave, **extras)
+        else:
+            np.savez_compressed(path, config_key=key, seed=seed, sigma=np.float32(sigma), mel=mel,
+                                z_scaled=z, wave=wave, **extras)
         rms = float(np.sqrt(np.mean(wave.astype(np.float64) ** 2)))
         print(f"[golden] {name}: wave {wave.shape} rms={rms:.4f} max={np.abs(wave).max():.3f} -> "
               f"{os.path.getsize(path) / 1024:.0f} KiB")
@@ -207,13 +216,16 @@ def _ref_waveflow(cfg, sd_np):
     return model.eval()
 
 
-def make_waveflow():
+def make_waveflow(full_length=False):
     import copy
     torch.set_num_threads(8)
     cases = [("toy", "toy", 2, 6, 0.7, 5), ("toy_odd", "toy", 1, 11, 1.0, 6), ("full_short", "full", 1, 5, 0.6, 1234),
              # SURVEY 8f.4 option set: speaker ids, cond stacks, separable in-layers, logvar channels, de-emphasis
              ("author_toy", "author_toy", 2, 6, 0.7, 3), ("author_short", "author", 1, 3, 0.6, 4)]
     only = [a for a in sys.argv[2:]]
+    if full_length:
+        # BASELINE config 4 at the metric's utterance length: one 80x900 mel (~10 s of CPU here)
+        cases, only = [("full_len", "full", 1, 900, 0.6, 4322)], []
     for name, key, B, F, sigma, seed in cases:
         if only and name not in only:
             continue
@@ -238,8 +250,12 @@ def make_waveflow():
         assert np.array_equal(inv[:, :audio.shape[1]], audio), "noise replay out of sync with infer()"
         path = os.path.join(HERE, f"waveflow_{name}.npz")
         extra = {} if ids is None else {"speaker_ids": ids}
-        np.savez_compressed(path, config_key=key, seed=seed, sigma=np.float32(sigma), mel=mel, z=z, audio=audio,
-                            inverse_full=inv.astype(np.float32), **extra)
+        if full_length:
+            np.savez_compressed(path, config_key=key, seed=seed, sigma=np.float32(sigma), B=B, F=F, z=z, audio=audio,
+                                mel_recipe="cookietts_amd.synthetic.synthetic_mel(B, F, n_mel, seed=seed)")
+        else:
+            np.savez_compressed(path, config_key=key, seed=seed, sigma=np.float32(sigma), mel=mel, z=z, audio=audio,
+                                inverse_full=inv.astype(np.float32), **extra)
         print(f"[golden] waveflow {name}: audio {audio.shape} rms={audio.std():.4f} -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
@@ -388,3 +404,7 @@ if __name__ == "__main__":
         make_waveglow()
     if "stft" in which:
         make_stft()
+    if "waveglow_full_len" in which:       # on request only: minutes of CPU
+        make_waveglow(full_length=True)
+    if "waveflow_full_len" in which:
+        make_waveflow(full_length=True)

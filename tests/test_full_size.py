@@ -78,3 +78,78 @@ def test_config5_tacotron_decoder_full_size_properties(hip_lib_path):
     assert (one[0][0] - mel[2]).abs().max() < 1e-4 and (one[2][0] - align[2]).abs().max() < 1e-4
     rep = m.decoder.inference(mem, lens, keep_masks=masks, fixed_steps=steps)
     assert torch.equal(rep[0], mel)
+
+
+def test_config2_waveglow_full_length_matches_reference_golden(hip_lib_path):
+    """One 80 x 900 mel through the 12 x 512 model vs the reference's own ``glow.WaveGlow.infer`` output
+    (tests/golden/make_golden.py waveglow_full_len): the metric's utterance length, pinned, not just properties."""
+    import os
+    from conftest import GOLDEN
+    from cookietts_amd import WaveGlow
+    g = np.load(os.path.join(GOLDEN, "waveglow_full_len.npz"))
+    cfg = synthetic.WAVEGLOW_CONFIGS[str(g["config_key"])]
+    seed, B, F = int(g["seed"]), int(g["B"]), int(g["F"])
+    m = WaveGlow(**cfg)
+    m.load_state_dict(synthetic.to_torch(synthetic.waveglow_state_dict(cfg, seed=seed)))
+    m = m.cuda().eval()
+    mel = torch.from_numpy(synthetic.synthetic_mel(B, F, cfg["n_mel_channels"], seed=seed)).cuda()
+    wave = m.infer_from_noise(mel, torch.from_numpy(g["z_scaled"]).cuda()).cpu().numpy()
+    assert wave.shape == g["wave"].shape == (1, 900 * 256)
+    err = rms_rel_err(wave, g["wave"])
+    print(f"config 2 full length: rms rel err vs reference = {err:.3e}")
+    assert err < 1e-3                                                          # BASELINE.json waveform bound
+    # the same utterance inside a batch of 8 (the bench's batch): row 3 must be the same arithmetic
+    mel8 = torch.from_numpy(synthetic.synthetic_mel(8, F, cfg["n_mel_channels"], seed=99)).cuda()
+    z8 = torch.from_numpy(synthetic.synthetic_noise(8, cfg["n_group"], F * 32, seed=99)).cuda()
+    mel8[3], z8[3] = mel[0], torch.from_numpy(g["z_scaled"][0]).cuda()
+    assert rms_rel_err(m.infer_from_noise(mel8, z8)[3:4].cpu().numpy(), g["wave"]) < 1e-3
+
+
+def test_config4_waveflow_full_length_matches_reference_golden(hip_lib_path):
+    """One 80 x 900 mel through config 4 vs the reference's own ``efficient_model_ax.WaveGlow.infer`` output."""
+    import os
+    from conftest import GOLDEN
+    from cookietts_amd import WaveFlow
+    g = np.load(os.path.join(GOLDEN, "waveflow_full_len.npz"))
+    cfg = synthetic.WAVEFLOW_CONFIGS[str(g["config_key"])]
+    seed, B, F = int(g["seed"]), int(g["B"]), int(g["F"])
+    m = WaveFlow(**cfg)
+    m.load_state_dict(synthetic.to_torch(synthetic.waveflow_state_dict(cfg, seed=seed)))
+    m = m.cuda().eval()
+    mel = synthetic.synthetic_mel(B, F, cfg["n_mel_channels"], seed=seed)
+    melp = torch.from_numpy(np.pad(mel, ((0, 0), (0, 0), (0, 1)))).cuda()      # infer() pads one frame (ax:370-371)
+    audio, _ = m.inverse(torch.from_numpy(g["z"]).cuda(), melp)
+    audio = audio.numpy()[:, :g["audio"].shape[1]]                             # infer() trims one hop (ax:381-383)
+    assert audio.shape == g["audio"].shape == (1, 899 * 256)
+    err = rms_rel_err(audio, g["audio"])
+    print(f"config 4 full length: rms rel err vs reference = {err:.3e}")
+    assert err < 1e-3
+
+
+def test_config3_bf16_full_size_properties(hip_lib_path):
+    """Config 3's per-GPU shard: 12 x 512, bf16 MFMA path, B = 32 x (80 x 900) mel."""
+    from cookietts_amd import WaveGlow
+    cfg = synthetic.WAVEGLOW_CONFIGS["full"]
+    m = WaveGlow(**cfg)
+    m.load_state_dict(synthetic.to_torch(synthetic.waveglow_state_dict(cfg, seed=77)))
+    m = m.cuda().eval().set_compute_dtype(torch.bfloat16)
+    B, F = 32, 900
+    mel = torch.from_numpy(synthetic.synthetic_mel(B, F, seed=1)).cuda()
+    z = torch.from_numpy(synthetic.synthetic_noise(B, cfg["n_group"], F * 32, seed=1) * np.float32(0.6)).cuda()
+    full = m.infer_from_noise(mel, z)
+    assert full.shape == (B, F * 256) and torch.isfinite(full).all()
+    assert torch.equal(full, m.infer_from_noise(mel, z))                      # deterministic, workspace reused
+    for b in (0, 17, 31):                                                      # utterances do not interact
+        assert torch.equal(m.infer_from_noise(mel[b:b + 1].contiguous(), z[b:b + 1].contiguous())[0], full[b])
+    # locality (receptive field 96 frames): the first 300 frames of a 600-frame cut reproduce the full run
+    cut = m.infer_from_noise(mel[:2, :, :600].contiguous(), z[:2, :, :600 * 32].contiguous())
+    n = 300 * 256
+    assert rms_rel_err(cut[:, :n].float().cpu().numpy(), full[:2, :n].float().cpu().numpy()) < 1e-5
+    # and the bf16 path stays inside its documented distance of the fp32 path at full size (DESIGN 1: ~2e-3)
+    m32 = WaveGlow(**cfg)
+    m32.load_state_dict(synthetic.to_torch(synthetic.waveglow_state_dict(cfg, seed=77)))
+    m32 = m32.cuda().eval()
+    ref = m32.infer_from_noise(mel[:2].contiguous(), z[:2].contiguous())
+    err = rms_rel_err(full[:2].float().cpu().numpy(), ref.cpu().numpy())
+    print(f"config 3 bf16 vs fp32 path at B x 900 frames: rms rel err = {err:.3e}")
+    assert err < 1e-2

@@ -67,3 +67,17 @@ def test_torch_cpu_baseline_matches_reference(name):
     assert wave.shape == g["wave"].shape
     assert rms_rel_err(wave, g["wave"]) < ORACLE_TOL
     assert wt.physical_cores() >= 1
+
+
+def test_torch_cpu_baseline_full_length_matches_reference():
+    """The exact workload bench.py's cpu_baseline times (one 80 x 900 utterance, 12 x 512 model) against the
+    reference's own output for it.  ~1 minute of CPU: the only long test of the CPU suite."""
+    from oracle import waveglow_torch_cpu as wt
+    g = np.load(os.path.join(GOLDEN, "waveglow_full_len.npz"))
+    cfg = synthetic.WAVEGLOW_CONFIGS[str(g["config_key"])]
+    seed = int(g["seed"])
+    sd = synthetic.waveglow_state_dict(cfg, seed=seed)
+    mel = synthetic.synthetic_mel(int(g["B"]), int(g["F"]), cfg["n_mel_channels"], seed=seed)
+    wave = wt.waveglow_infer(wt.fold(sd), cfg, mel, g["z_scaled"])
+    assert wave.shape == g["wave"].shape == (1, 230400)
+    assert rms_rel_err(wave, g["wave"]) < ORACLE_TOL

@@ -66,3 +66,42 @@ def test_shard_counts():
     assert sharding.shard_counts(256, 8) == [32] * 8
     assert sharding.shard_counts(5, 2) == [3, 2]
     assert sharding.shard_counts(1, 4) == [1, 0, 0, 0]
+
+
+_NCCL_WORLD1 = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["CTTS_REPO"])
+from cookietts_amd import WaveGlow, sharding, synthetic
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ["CTTS_PORT"])
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+cfg = synthetic.WAVEGLOW_CONFIGS["toy"]
+m = WaveGlow(**cfg)
+m.load_state_dict(synthetic.to_torch(synthetic.waveglow_state_dict(cfg, seed=3)))
+m = m.to(dev).eval()
+n = sharding.broadcast_state_dict(m, src=0)
+assert n == sum(p.numel() * 4 for p in m.parameters())
+mels = torch.from_numpy(synthetic.synthetic_mel(3, 7, seed=2)).to(dev)
+z = torch.from_numpy(synthetic.synthetic_noise(3, 8, 7 * 32, seed=2)).to(dev)
+fn = lambda mel: m.infer_from_noise(mel, z[:mel.shape[0]])
+out = sharding.sharded_infer(fn, mels, 80, dev, root=0)
+assert torch.equal(out, fn(mels)) and out.shape == (3, 7 * 256)
+dist.destroy_process_group()
+print("NCCL_WORLD1_OK")
+"""
+
+
+@pytest.mark.gpu
+def test_sharding_helpers_on_rccl_single_rank(hip_lib_path):
+    """The box has one GPU: a world of 1 still drives broadcast / scatter / gather through the RCCL backend
+    (device tensors, the NCCL implementations of dist.scatter / dist.gather) around the real HIP vocoder."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, CTTS_REPO=REPO, CTTS_PORT=str(_free_port()))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", _NCCL_WORLD1], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "NCCL_WORLD1_OK" in r.stdout, r.stderr[-3000:]

@@ -207,3 +207,22 @@ def test_batches_larger_than_a_device_group_run_in_lockstep(hip_lib_path):
     assert out["pred_mel_postnet"].shape == (5, 80, 6) and torch.isfinite(out["pred_mel_postnet"]).all()
     part = m.inference(text[4:], tl[4:], spk[4:], tm[4:], keep_masks=None, fixed_steps=6)
     assert np.abs(out["encoder_outputs"][4].cpu().numpy() - part["encoder_outputs"][0].cpu().numpy()).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_packed_weights_follow_load_state_dict_on_the_parent(hip_lib_path):
+    """Decoder / Encoder / Postnet keep packed blobs; Tacotron2.load_state_dict (the parent) must invalidate them."""
+    m, _, hp, sd = _model()
+    g = np.load(os.path.join(GOLDEN, "tacotron_full.npz"))
+    args = (torch.from_numpy(g["text"]).cuda(), torch.from_numpy(g["lengths"]).cuda(),
+            torch.from_numpy(g["speakers"]).cuda(), torch.from_numpy(g["torchmoji"]).cuda())
+    n = g["masks"].shape[0]
+    shapes = json.load(open(os.path.join(GOLDEN, "tacotron_state_shapes.json")))
+    other = synthetic.tacotron_state_dict(hp, seed=4321, shapes=shapes)
+    m.load_state_dict(synthetic.to_torch(other))
+    first = m.inference(*args, keep_masks=g["masks"], fixed_steps=n)["pred_mel_postnet"].cpu().numpy()
+    assert np.abs(first - g["pred_mel_postnet"]).max() > 1e-2                 # different weights, different mel
+    m.load_state_dict(synthetic.to_torch(sd))                                 # back to the golden's weights
+    again = m.inference(*args, keep_masks=g["masks"], fixed_steps=n)
+    assert np.abs(again["pred_mel_postnet"].cpu().numpy() - g["pred_mel_postnet"]).max() < MEL_TOL
+    assert np.abs(again["encoder_outputs"].cpu().numpy() - g["encoder_outputs"]).max() < MEL_TOL

@@ -203,3 +203,30 @@ def test_5_infer_vocoder_slot(hip_lib_path, tmp_path):
     assert next(vocoder.parameters()).dtype == torch.float32
     audio16 = vocoder(mel_batch).squeeze(1)
     assert audio16.shape == (3, 21 * 256) and torch.isfinite(audio16).all()
+
+
+def test_packed_weights_follow_parent_load_state_dict_and_in_place_updates(hip_lib_path):
+    """A parent's load_state_dict never calls the child's override (it recurses through _load_from_state_dict):
+    the packed blob must still be rebuilt, or the second checkpoint would silently play the first one's weights."""
+    from cookietts_amd import WaveGlowVocoder
+    from oracle import waveglow_oracle as wo
+    cfg = synthetic.WAVEGLOW_CONFIGS["toy"]
+    sd_a, sd_b = synthetic.waveglow_state_dict(cfg, seed=31), synthetic.waveglow_state_dict(cfg, seed=32)
+    inner = WaveGlow(**cfg)
+    inner.load_state_dict(synthetic.to_torch(sd_a))
+    voc = WaveGlowVocoder(inner.cuda().eval())
+    mel = synthetic.synthetic_mel(2, 9, seed=1)
+    z = synthetic.synthetic_noise(2, 8, 9 * 32, seed=1) * np.float32(0.7)
+    tm, tz = torch.from_numpy(mel).cuda(), torch.from_numpy(z).cuda()
+    assert rms_rel_err(inner.infer_from_noise(tm, tz).cpu().numpy(), wo.waveglow_infer(sd_a, cfg, mel, z)) < WAVE_TOL
+    voc.load_state_dict({"waveglow." + k: v for k, v in synthetic.to_torch(sd_b).items()})      # through the PARENT
+    ref_b = wo.waveglow_infer(sd_b, cfg, mel, z)
+    assert rms_rel_err(inner.infer_from_noise(tm, tz).cpu().numpy(), ref_b) < WAVE_TOL
+    # in-place update of one tensor (what an optimizer step does): picked up through the version counter
+    with torch.no_grad():
+        inner.WN[1].end.bias.add_(0.05)
+    sd_c = dict(sd_b)
+    sd_c["WN.1.end.bias"] = sd_b["WN.1.end.bias"] + np.float32(0.05)
+    out_c = inner.infer_from_noise(tm, tz).cpu().numpy()
+    assert rms_rel_err(out_c, wo.waveglow_infer(sd_c, cfg, mel, z)) < WAVE_TOL
+    assert rms_rel_err(out_c, ref_b) > 1e-2                                   # and it really changed the output
