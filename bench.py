@@ -157,7 +157,8 @@ def cpu_baseline(cfg, sd, frames, seed, budget_s):
     return {"value": r["value"], "unit": "samples/s", "cores": r["cores"], "kind": "port",
             "sample": f"oracle/waveglow_torch_cpu.py (torch CPU conv ops, reference-free restatement pinned to the "
                       f"reference goldens), same 12x512 model, 1 utterance x {frames} mel frames ({r['samples']} samples), "
-                      f"torch.set_num_threads({r['threads_set']}) = physical cores, 1 warm-up + best of {r['runs']} "
+                      f"torch.set_num_threads({r['threads_set']}) (fastest of a probe over {r['probe']} s per "
+                      f"thread count on a short utterance; {r['physical']} physical cores), warm-up + best of {r['runs']} "
                       f"= {r['best_s']:.2f} s"}
 
 

@@ -58,6 +58,20 @@ class WaveFlowFlowWeights(C.Structure):
                 ("end_w", _FP), ("end_b", _FP), ("dw_w", C.POINTER(_FP)), ("dw_b", C.POINTER(_FP))]
 
 
+class WgaxConfig(C.Structure):
+    """``ctts_wgax_config`` (ax core, waveflow=False)."""
+    _fields_ = [(n, C.c_int32) for n in ("n_flows", "n_group", "n_early_every", "n_early_size", "n_layers",
+                                         "n_channels", "kernel_size", "mixing", "mix_first", "ignore_nan")]
+
+
+class WgaxFlowWeights(C.Structure):
+    _fields_ = [("start_w", _FP), ("start_b", _FP), ("in_w", C.POINTER(_FP)), ("in_b", C.POINTER(_FP)),
+                ("rs_w", C.POINTER(_FP)), ("rs_b", C.POINTER(_FP)), ("end_w", _FP), ("end_b", _FP), ("w_inverse", _FP)]
+
+
+MIX_PERMUTE, MIX_CONV1X1 = 0, 1
+
+
 class TacoDecoderConfig(C.Structure):
     """``ctts_taco_decoder_config``."""
     _fields_ = [(n, C.c_int32) for n in (
@@ -151,6 +165,12 @@ SIGNATURES = {
                                         C.c_int32, _FP, C.c_size_t, _FP]),
     "ctts_waveflow_inverse_cond_f32": (C.c_int, [C.POINTER(WaveFlowConfig), _FP, _FP, _FP, C.c_int32, C.c_int32, _FP,
                                                  C.c_int32, C.c_int32, C.c_int32, _FP, C.c_size_t, _FP]),
+    "ctts_wgax_packed_bytes": (C.c_size_t, [C.POINTER(WgaxConfig)]),
+    "ctts_wgax_pack_flow": (C.c_int, [C.POINTER(WgaxConfig), C.c_int32, C.POINTER(WgaxFlowWeights), _FP, _FP]),
+    "ctts_wgax_workspace_bytes": (C.c_size_t, [C.POINTER(WgaxConfig), C.c_int32, C.c_int64]),
+    "ctts_wgax_inverse_f32": (C.c_int, [C.POINTER(WgaxConfig), _FP, _FP, _FP, C.c_int32, C.c_int32, C.c_int32, _FP,
+                                        C.c_int32, C.c_int64, _FP, C.c_size_t, _FP]),
+    "ctts_replicate_halo_f32": (C.c_int, [_FP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP]),
     "ctts_embed_rows_f32": (C.c_int, [_FP, _FP, _FP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_int32, _FP]),
     "ctts_scale_add_rows_f32": (C.c_int, [_FP, _FP, _FP, _FP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

@@ -126,6 +126,121 @@ WAVEFLOW_CONFIGS = {
 }
 
 
+def waveglow_ax_config(n_flows=4, n_group=8, n_channels=128, n_layers=3, kernel_size_w=3, n_mel_channels=80,
+                       hop_length=256, win_length=1024, sampling_rate=22050, channel_mixing='1x1conv', mix_first=True,
+                       n_early_every=100, n_early_size=2, **over):
+    """Constructor kwargs of the reference ``efficient_model_ax.WaveGlow`` with ``waveflow=False`` (AffineCouplingBlock
+    + 1-D ``glow_ax.WN``).  The 1-D WN takes no ``kernel_size_h``.  ``over`` / ``WN`` as in waveflow_config."""
+    wn_over = over.pop("WN", {})
+    cfg = dict(n_mel_channels=n_mel_channels, n_flows=n_flows, n_group=n_group, n_early_every=n_early_every,
+               n_early_size=n_early_size, memory_efficient=0.0, spect_scaling=False, upsample_mode='normal',
+               upsample_first=False, speaker_embed=0, cond_layers=0, cond_hidden_channels=256,
+               cond_output_channels=256, cond_kernel_size=1, cond_residual=False, cond_padding_mode='zeros',
+               waveflow=False, channel_mixing=channel_mixing, mix_first=mix_first, win_length=win_length,
+               hop_length=hop_length, sampling_rate=sampling_rate,
+               WN_config=dict(n_layers=n_layers, n_channels=n_channels, kernel_size_w=kernel_size_w,
+                              n_layers_dilations_w=None, n_layers_dilations_h=1, speaker_embed_dim=0, rezero=False,
+                              cond_layers=1, cond_activation_func='none', negative_slope=None,
+                              cond_hidden_channels=256, cond_padding_mode='zeros', seperable_conv=False,
+                              res_skip=True, merge_res_skip=False, upsample_mode='linear', cond_kernel_size=1))
+    cfg.update(over)
+    cfg["WN_config"].update(wn_over)
+    return cfg
+
+
+def waveglow_ax_notebook_config(n_flows=48, n_group=24, n_channels=256, n_layers=8, n_mel_channels=160, hop_length=600,
+                                win_length=2400, speaker_embed=96, cond_hidden=256, n_early_every=16):
+    """The config the reference's only recorded WaveGlow timing is for (BASELINE.md section 1:
+    scripts/"WaveGlowFlow Inference Speed Testing.ipynb" cell 2, 4.60x real time at 48 kHz): 48 flows, n_group 24,
+    8 x 256 WN, 'permute' mixing after the coupling, early outputs every 16 flows, speaker embeddings at model and WN
+    level, a 3-layer k=3 replicate-padded residual + rezero conditioning stack, one 1x1 WN cond layer, linear
+    interpolation of the conditioning."""
+    return waveglow_ax_config(
+        n_flows=n_flows, n_group=n_group, n_channels=n_channels, n_layers=n_layers, n_mel_channels=n_mel_channels,
+        hop_length=hop_length, win_length=win_length, sampling_rate=48000, channel_mixing='permute', mix_first=False,
+        n_early_every=n_early_every, n_early_size=2, preceived_vol_scaling=False, speaker_embed=speaker_embed,
+        cond_layers=3, cond_activation_func='lrelu', negative_slope=0.5, cond_hidden_channels=cond_hidden,
+        cond_output_channels=256, cond_residual=True, cond_res_rezero=True, cond_padding_mode='replicate',
+        cond_kernel_size=2,
+        WN=dict(speaker_embed_dim=speaker_embed, cond_layers=1, cond_activation_func='none', negative_slope=0.5,
+                cond_hidden_channels=256, cond_padding_mode='replicate', seperable_conv=0, cond_kernel_size=1))
+
+
+WAVEGLOW_AX_CONFIGS = {
+    # InvertibleConv1x1 mixing (the ax constructor's default), mix before the coupling, early outputs
+    "toy_conv": waveglow_ax_config(n_flows=5, n_group=8, n_early_every=2),
+    # ... mix after the coupling, k = 5 in-layers, 12 latent rows
+    "toy_conv_mixlast": waveglow_ax_config(n_flows=4, n_group=12, n_early_every=3, n_early_size=4, mix_first=False,
+                                           kernel_size_w=5, hop_length=240, win_length=960),
+    # PermuteHeight mixing, both orders
+    "toy_permute": waveglow_ax_config(n_flows=4, n_group=8, channel_mixing='permuteheight', mix_first=False,
+                                      n_early_every=2),
+    "toy_permute_mixfirst": waveglow_ax_config(n_flows=4, n_group=8, channel_mixing='permute', mix_first=True),
+    # the notebook's option set scaled down, and at full size
+    "notebook_toy": waveglow_ax_notebook_config(n_flows=6, n_group=12, n_channels=128, n_layers=3, n_mel_channels=12,
+                                                hop_length=120, win_length=480, speaker_embed=8, cond_hidden=32,
+                                                n_early_every=2),
+    "notebook": waveglow_ax_notebook_config(),
+}
+
+
+def waveglow_ax_flow_channels(cfg):
+    """n_remaining_channels per flow (efficient_model_ax.py:170-189)."""
+    n_rem, out = cfg["n_group"], []
+    for k in range(cfg["n_flows"]):
+        if k % cfg["n_early_every"] == 0 and k > 0:
+            n_rem -= cfg["n_early_size"]
+        out.append(n_rem)
+    return out
+
+
+def waveglow_ax_state_dict(cfg, seed=1234, end_std=None):
+    """Random-init state dict with the reference's keys for ``waveflow=False``: ``WN.k.WN.{start,in_layers.i,
+    res_skip_layers.i,cond_layers.l}.{bias,weight_g,weight_v}`` (3-D conv weights), ``WN.k.WN.end.{weight,bias}``,
+    ``WN.k.WN.speaker_embed.weight``, ``convinv.k.weight`` (1x1conv mixing only), ``speaker_embed.weight``, ``alpha``,
+    ``cond_layers.l.*``."""
+    rng = np.random.default_rng(seed)
+    wn = cfg["WN_config"]
+    C, n_layers = wn["n_channels"], wn["n_layers"]
+    ks = wn.get("kernel_size_w") or wn.get("kernel_size")
+    if end_std is None:
+        end_std = 0.25 / np.sqrt(C)
+    sd = {}
+    c_in, c_wn = waveflow_cond_channels(cfg)
+    if cfg["speaker_embed"]:
+        sd["speaker_embed.weight"] = rng.standard_normal((512, cfg["speaker_embed"]), dtype=np.float32)
+    if cfg.get("cond_res_rezero"):
+        sd["alpha"] = np.array([0.3], np.float32)
+    if cfg["cond_layers"]:
+        k = 2 * cfg["cond_kernel_size"] - 1
+        dims = [c_in] + [cfg["cond_hidden_channels"]] * (cfg["cond_layers"] - 1) + [c_wn]
+        for l in range(cfg["cond_layers"]):
+            _wn_conv(rng, sd, f"cond_layers.{l}", dims[l + 1], dims[l], k)
+    sdim = wn.get("speaker_embed_dim", 0)
+    conv_mix = cfg.get("channel_mixing", '1x1conv').lower() in "1x1convinvertibleconv1x1invconv"
+    for k, n_rem in enumerate(waveglow_ax_flow_channels(cfg)):
+        p = f"WN.{k}.WN"
+        h = n_rem // 2
+        _wn_conv(rng, sd, p + ".start", C, h, 1)
+        sd[p + ".end.weight"] = rng.standard_normal((2 * h, C, 1), dtype=np.float32) * np.float32(end_std)
+        sd[p + ".end.bias"] = rng.standard_normal((2 * h,), dtype=np.float32) * np.float32(0.02)
+        if sdim:
+            sd[p + ".speaker_embed.weight"] = rng.standard_normal((512, sdim), dtype=np.float32)
+        ck = 2 * wn.get("cond_kernel_size", 1) - 1
+        dims = [c_wn + sdim] + [wn["cond_hidden_channels"]] * (wn["cond_layers"] - 1) + [2 * C * n_layers]
+        for l in range(wn["cond_layers"]):
+            _wn_conv(rng, sd, f"{p}.cond_layers.{l}", dims[l + 1], dims[l], ck, gain=0.5)
+        for i in range(n_layers):
+            _wn_conv(rng, sd, f"{p}.in_layers.{i}", 2 * C, C, ks)
+            _wn_conv(rng, sd, f"{p}.res_skip_layers.{i}", 2 * C if i < n_layers - 1 else C, C, 1)
+        if conv_mix:
+            a = rng.standard_normal((n_rem, n_rem)).astype(np.float64)
+            q, _ = np.linalg.qr(a)
+            q = q + 0.05 * rng.standard_normal((n_rem, n_rem))
+            sd[f"convinv.{k}.weight"] = q.astype(np.float32)[:, :, None]
+    return sd
+
+
 def waveflow_cond_channels(cfg):
     """(model-level cond input channels, channels handed to every WN) - ax:64-66, 73-74, 96."""
     c_in = cfg["n_mel_channels"] * (2 if cfg.get("use_logvar_channels") else 1) + cfg["speaker_embed"]

@@ -1,4 +1,5 @@
-"""WaveFlow / "ax" WaveGlow core on the MI355X HIP path (BASELINE config 4).
+"""WaveFlow / "ax" WaveGlow core on the MI355X HIP path (BASELINE config 4, and the ``waveflow=False`` WaveGlow the
+reference's own timing notebook runs).
 
 Host-side mirror of ``/root/reference/CookieTTS/_4_mtw/waveglow/efficient_model_ax.py``
 ``WaveGlow`` (:18-169 constructor, :279-357 ``inverse``, :359-388 ``infer``) for ``waveflow=True``
@@ -11,7 +12,11 @@ separable (depthwise + pointwise) in-layers, log-variance mel channels, de-empha
 bias}``, ``WN.k.WN.end.{weight,bias}``), same ``infer`` / ``inverse`` contracts (output length
 ``(F-1)*hop`` with the default ``artifact_trimming=1``; ``return_CPU=True`` moves the result to
 the host like the reference).  Everything else the constructor accepts raises NotImplementedError.
-All arithmetic runs in the C-ABI HIP library (``ctts_waveflow_inverse_f32``); no CPU fallback.
+``waveflow=False`` selects ``AffineCouplingBlock`` + the 1-D ``WN`` (efficient_modules.py:68-105, glow_ax.py:245-418)
+with ``InvertibleConv1x1`` (efficient_modules.py:235-286) or ``PermuteHeight`` channel mixing in either ``mix_first``
+order and early outputs (``ctts_wgax_inverse_f32``).
+All arithmetic runs in the C-ABI HIP library (``ctts_waveflow_inverse_f32`` / ``ctts_wgax_inverse_f32``); no CPU
+fallback.
 """
 from __future__ import annotations
 
@@ -77,6 +82,42 @@ class _WN2d(nn.Module):
             _WNConv((2 * C_ if i < n_layers - 1 else C_, C_, 1, 1)) for i in range(n_layers)])
 
 
+class _WN1d(nn.Module):
+    """Parameter tree of the 1-D glow_ax.WN (:251-360)."""
+
+    def __init__(self, n_in, cond_in, wn):
+        super().__init__()
+        C_, n_layers = wn['n_channels'], wn['n_layers']
+        ks = wn.get('kernel_size_w') or wn.get('kernel_size')                    # glow_ax.py:256
+        assert ks % 2 == 1 and C_ % 2 == 0
+        self.n_layers, self.n_channels = n_layers, C_
+        sdim = wn.get('speaker_embed_dim', 0)
+        self.start = _WNConv((C_, n_in, 1))
+        self.end = nn.Module()
+        self.end.weight = nn.Parameter(torch.zeros(2 * n_in, C_, 1))            # zero-init, glow_ax.py:278-281
+        self.end.bias = nn.Parameter(torch.zeros(2 * n_in))
+        if sdim:
+            self.speaker_embed = nn.Embedding(512, sdim)                        # glow_ax.py:283-285
+        k = 2 * wn.get('cond_kernel_size', 1) - 1                               # glow_ax.py:299
+        dims = [cond_in + sdim] + [wn['cond_hidden_channels']] * (wn['cond_layers'] - 1) + [2 * C_ * n_layers]
+        self.cond_layers = nn.ModuleList([_WNConv((dims[l + 1], dims[l], k)) for l in range(wn['cond_layers'])])
+        self.in_layers = nn.ModuleList([_WNConv((2 * C_, C_, ks)) for _ in range(n_layers)])
+        self.res_skip_layers = nn.ModuleList([
+            _WNConv((2 * C_ if i < n_layers - 1 else C_, C_, 1)) for i in range(n_layers)])
+
+
+class InvertibleConv1x1(nn.Module):
+    """Parameter holder of efficient_modules.InvertibleConv1x1 (:235-253): ``weight`` [c, c, 1], random orthonormal
+    with det > 0.  ``W_inverse`` is cached on the module after the first inference like the reference (:271-276)."""
+
+    def __init__(self, c):
+        super().__init__()
+        W = torch.linalg.qr(torch.randn(c, c))[0]
+        if torch.det(W) < 0:
+            W[:, 0] = -1 * W[:, 0]
+        self.weight = nn.Parameter(W.view(c, c, 1).contiguous())
+
+
 class _Coupling(nn.Module):
     def __init__(self, wn):
         super().__init__()
@@ -122,9 +163,13 @@ class _CondConv:
                                            _lib.ptr(self.blob), stream), "ctts_conv1d_pack_f32")
         self._keep = (wp, b)
 
-    def __call__(self, x, y, B, T, ld, stream):
+    def __call__(self, x, y, B, T, ld, stream, padding_mode='zeros'):
         # x [B][>= c_in rows][ld], y [B][>= c_out rows][ld]: the row counts of the buffers are rounded up to 16, so the
         # primitive (dense [batch][c][ld] strides) is driven one utterance at a time
+        k = self.desc.kernel_size
+        if padding_mode == 'replicate' and k > 1:      # edge values into the halo the taps reach (nn.Conv1d padding_mode)
+            _lib.check(_lib.lib().ctts_replicate_halo_f32(_lib.ptr(x), B, x.shape[1], T, ld, PAD, k // 2, stream),
+                       "ctts_replicate_halo_f32")
         for b in range(B):
             _lib.check(_lib.lib().ctts_conv1d_f32(C.byref(self.desc), _lib.ptr(self.blob), _lib.ptr(x[b]), _lib.ptr(y[b]),
                                                  0, 1, T, ld, PAD, stream), "ctts_conv1d_f32")
@@ -150,12 +195,22 @@ class WaveGlow(nn.Module):
         def need(cond, what):
             if not cond:
                 raise NotImplementedError(f"ax-core option not built on the HIP path yet: {what}")
-        need(waveflow, "waveflow=False (AffineCouplingBlock + 1-D WN of the ax core)")
-        need(channel_mixing.lower() in "waveflowpermuteheightpermutechannelpermute", "channel_mixing='1x1conv'")
-        need(not mix_first, "mix_first=True")
+        assert any(channel_mixing.lower() in x for x in ("1x1convinvertibleconv1x1invconv",
+                                                         "waveflowpermuteheightpermutechannelpermute")), \
+            "channel_mixing option is invalid. Options are '1x1conv' or 'permuteheight'"          # ax:24
+        mixing = '1x1conv' if channel_mixing.lower() in "1x1convinvertibleconv1x1invconv" else 'permuteheight'   # ax:25
+        if waveflow:       # the WaveFlow kernels fold the row permutation into addressing: these stay unbuilt there
+            need(mixing == 'permuteheight', "waveflow=True with channel_mixing='1x1conv'")
+            need(not mix_first, "waveflow=True with mix_first=True")
+            need(n_early_every > n_flows, "waveflow=True with early outputs (n_early_every <= n_flows)")
+        else:
+            need(not wn.get('seperable_conv', False), "waveflow=False with seperable_conv")
+            need(wn['n_channels'] % 128 == 0, "waveflow=False with n_channels not a multiple of 128")
+            need(n_group <= 32, "waveflow=False with n_group > 32")
         need(cond_residual in (False, True, 0, 1), "cond_residual='1x1conv'")
         need(not upsample_first, "upsample_first")
-        need(n_early_every > n_flows, "early outputs (n_early_every <= n_flows)")
+        need(cond_padding_mode in ('zeros', 'replicate') and wn.get('cond_padding_mode', 'zeros') in ('zeros', 'replicate'),
+             "cond_padding_mode other than 'zeros' / 'replicate'")
         need(shift_spect == 0. and scale_spect == 1. and not preceived_vol_scaling, "spect shift/scale, vol scaling")
         need(not load_hidden_from_disk, "hidden cond from disk")
         need(not unsupported.get('iso226_empthasis', False) and not unsupported.get('transposed_conv_scales')
@@ -165,19 +220,25 @@ class WaveGlow(nn.Module):
         need(wn.get('res_skip', True) and not wn.get('merge_res_skip', False), "merge_res_skip")
         need(wn.get('gated_unit', 'GTU') == 'GTU' and not wn.get('rezero', False), "gate other than GTU / rezero")
         need(wn.get('n_layers_dilations_w') is None, "custom width dilations")
-        dh = wn.get('n_layers_dilations_h', 1)
-        dh = [dh] * wn['n_layers'] if isinstance(dh, int) else list(dh)
-        need(all(d == 1 for d in dh), "height dilation != 1")
-        need(wn.get('seperable_conv', False) or wn['kernel_size_h'] * wn['kernel_size_w'] <= 11,
-             "dense in-layer kernels with more than 11 taps (use seperable_conv)")
+        if waveflow:
+            dh = wn.get('n_layers_dilations_h', 1)
+            dh = [dh] * wn['n_layers'] if isinstance(dh, int) else list(dh)
+            need(all(d == 1 for d in dh), "height dilation != 1")
+            need(wn.get('seperable_conv', False) or wn['kernel_size_h'] * wn['kernel_size_w'] <= 11,
+                 "dense in-layer kernels with more than 11 taps (use seperable_conv)")
+        else:
+            need((wn.get('kernel_size_w') or wn.get('kernel_size')) <= 11, "1-D in-layer kernels wider than 11")
         need(2 * cond_kernel_size - 1 <= 11 and 2 * wn.get('cond_kernel_size', 1) - 1 <= 11, "cond kernels wider than 11")
-        assert n_flows % 2 == 0, "PermuteHeight requires even n_flows"
+        assert mixing != 'permuteheight' or n_flows % 2 == 0, "PermuteHeight requires even n_flows"
 
+        self.waveflow = bool(waveflow)
         self.n_flows, self.n_group = n_flows, n_group
         self.n_early_every, self.n_early_size = n_early_every, n_early_size
         self.sampling_rate, self.win_size, self.hop_length = sampling_rate, win_length, hop_length
         self.n_mel_channels = n_mel_channels
-        self.channel_mixing, self.mix_first = 'permuteheight', mix_first
+        self.channel_mixing, self.mix_first = mixing, bool(mix_first)
+        self.cond_padding_mode = cond_padding_mode
+        self.ignore_nan = True                                                   # ax:50
         self.has_logvar_channels = bool(use_logvar_channels)
         self.preempthasis = preempthasis
         self.speaker_embed_dim = speaker_embed
@@ -202,9 +263,27 @@ class WaveGlow(nn.Module):
             self.cond_layers = nn.ModuleList([_WNConv((dims[l + 1], dims[l], k)) for l in range(cond_layers)])
             wn_cond = out_c
         self.wn_cond_channels = wn_cond
-        self.WN = nn.ModuleList([_Coupling(_WN2d(wn_cond, wn)) for _ in range(n_flows)])
+        if waveflow:
+            self.WN = nn.ModuleList([_Coupling(_WN2d(wn_cond, wn)) for _ in range(n_flows)])
+            self.convinv = []                                                    # PermuteHeight: no parameters (ax:144)
+            self.z_split_sizes = [n_group]
+        else:                                                                    # ax:166-189
+            self.WN = nn.ModuleList()
+            self.convinv = nn.ModuleList() if mixing == '1x1conv' else []
+            n_rem = n_group
+            self.z_split_sizes = []
+            for k in range(n_flows):
+                if k % n_early_every == 0 and k > 0:
+                    n_rem -= n_early_size
+                    self.z_split_sizes.append(n_early_size)
+                assert n_rem > 0, "n_remaining_channels is 0. (increase n_group or decrease n_early_every/n_early_size)"
+                need(n_rem % 2 == 0, "odd number of remaining channels")
+                if mixing == '1x1conv':
+                    self.convinv.append(InvertibleConv1x1(n_rem))
+                self.WN.append(_Coupling(_WN1d(n_rem // 2, wn_cond, wn)))
+            self.z_split_sizes.append(n_rem)
         # one k=1 linear WN cond layer on the bare mel commutes with the interpolation: folded into the in-layer GEMM
-        self._folded = (not cond_layers and not speaker_embed and not wn.get('speaker_embed_dim', 0)
+        self._folded = (bool(waveflow) and not cond_layers and not speaker_embed and not wn.get('speaker_embed_dim', 0)
                         and wn.get('cond_layers', 1) == 1 and wn.get('cond_kernel_size', 1) == 1
                         and self._act_wn[0] == 0)
         self._packed = None
@@ -220,8 +299,19 @@ class WaveGlow(nn.Module):
                                    seperable_conv=1 if wn.get('seperable_conv', False) else 0,
                                    cond_precomputed=0 if self._folded else 1)
 
+    def c_config_1d(self):
+        wn = self.WN_config
+        return _lib.WgaxConfig(n_flows=self.n_flows, n_group=self.n_group, n_early_every=self.n_early_every,
+                               n_early_size=self.n_early_size, n_layers=wn['n_layers'], n_channels=wn['n_channels'],
+                               kernel_size=wn.get('kernel_size_w') or wn.get('kernel_size'),
+                               mixing=_lib.MIX_CONV1X1 if self.channel_mixing == '1x1conv' else _lib.MIX_PERMUTE,
+                               mix_first=1 if self.mix_first else 0, ignore_nan=1 if self.ignore_nan else 0)
+
     def _invalidate(self):
         self._packed, self._ws = None, {}
+        for m in (self.convinv if isinstance(self.convinv, nn.ModuleList) else []):
+            if hasattr(m, 'W_inverse'):
+                del m.W_inverse
 
     def _apply(self, fn, *a, **kw):
         self._invalidate()
@@ -263,13 +353,17 @@ class WaveGlow(nn.Module):
         if device.type != 'cuda':
             raise _lib.HipLibraryError("WaveFlow HIP path needs the model on a GPU (no CPU fallback)")
         lib = _lib.lib()
-        cfg = self.c_config()
-        nbytes = lib.ctts_waveflow_packed_bytes(C.byref(cfg))
-        if nbytes == 0:
-            raise _lib.HipLibraryError("unsupported WaveFlow config: " + lib.ctts_last_error().decode())
         wn_cfg = self.WN_config
         n_layers = wn_cfg['n_layers']
-        sep = isinstance(self.WN[0].WN.in_layers[0], nn.ModuleList)
+        if self.waveflow:
+            cfg = self.c_config()
+            nbytes = lib.ctts_waveflow_packed_bytes(C.byref(cfg))
+        else:
+            cfg = self.c_config_1d()
+            nbytes = lib.ctts_wgax_packed_bytes(C.byref(cfg))
+        if nbytes == 0:
+            raise _lib.HipLibraryError("unsupported ax-core config: " + lib.ctts_last_error().decode())
+        sep = self.waveflow and isinstance(self.WN[0].WN.in_layers[0], nn.ModuleList)
         with torch.cuda.device(device):
             stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
             blob = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)
@@ -287,6 +381,26 @@ class WaveGlow(nn.Module):
                 return a
             for k in range(self.n_flows):
                 wn = self.WN[k].WN
+                if not self.waveflow:
+                    fw = _lib.WgaxFlowWeights()
+                    fw.start_w = self._dense(wn.start, stream, keep).data_ptr()
+                    fw.start_b = dev(wn.start.bias)
+                    fw.in_w = arr(lambda i: self._dense(wn.in_layers[i], stream, keep).data_ptr())
+                    fw.in_b = arr(lambda i: dev(wn.in_layers[i].bias))
+                    fw.rs_w = arr(lambda i: self._dense(wn.res_skip_layers[i], stream, keep).data_ptr())
+                    fw.rs_b = arr(lambda i: dev(wn.res_skip_layers[i].bias))
+                    fw.end_w = dev(wn.end.weight)
+                    fw.end_b = dev(wn.end.bias)
+                    if self.channel_mixing == '1x1conv':
+                        # efficient_modules.py:271-276: W.float().inverse(), cached on the module as W_inverse
+                        W = self.convinv[k].weight.detach().squeeze(-1)
+                        W_inverse = W.float().cpu().inverse().to(device).contiguous()
+                        self.convinv[k].W_inverse = W_inverse[..., None]
+                        keep.append(W_inverse)
+                        fw.w_inverse = W_inverse.data_ptr()
+                    _lib.check(lib.ctts_wgax_pack_flow(C.byref(cfg), k, C.byref(fw), _lib.ptr(blob), stream),
+                               f"ctts_wgax_pack_flow({k})")
+                    continue
                 fw = _lib.WaveFlowFlowWeights()
                 fw.start_w = self._dense(wn.start, stream, keep).data_ptr()
                 fw.start_b = dev(wn.start.bias)
@@ -348,7 +462,7 @@ class WaveGlow(nn.Module):
         h = x0
         for op in ops['model']:
             y = rows(op.c_out)
-            op(h, y, B, Fr, ld, stream)
+            op(h, y, B, Fr, ld, stream, self.cond_padding_mode)
             h = y
         alpha = self.alpha.detach().float().contiguous() if (self.cond_res_rezero and len(ops['model'])) else None
         resid = x0 if (self.cond_residual and len(ops['model'])) else None
@@ -367,13 +481,15 @@ class WaveGlow(nn.Module):
             h = xw
             for l, op in enumerate(ops['wn'][k]):
                 y = frames[k] if l == len(ops['wn'][k]) - 1 else rows(op.c_out)
-                op(h, y, B, Fr, ld, stream)
+                op(h, y, B, Fr, ld, stream, self.WN_config.get('cond_padding_mode', 'zeros'))
                 h = y
         return frames, ld
 
     # --------------------------------------------------------------------- the path ----
     def inverse(self, z, cond, speaker_ids=None, return_CPU=True):
         """efficient_model_ax.py:279-357: z [B, T] (noise, sigma applied), cond [B, n_mel(*2), frames]."""
+        if not self.waveflow:
+            return self._inverse_1d(z, cond, speaker_ids, return_CPU)
         device = cond.device
         blob, ops = self._ensure_packed(device)
         lib = _lib.lib()
@@ -403,6 +519,39 @@ class WaveGlow(nn.Module):
                                                              ld, PAD, _lib.ptr(audio), B, T, mel.shape[2], _lib.ptr(ws),
                                                              ws.numel() * 4, stream), "ctts_waveflow_inverse_cond_f32")
             if self.preempthasis:      # ax:351-355 (scipy lfilter on the host there; here on the device, in place)
+                _lib.check(lib.ctts_deemphasis_f32(_lib.ptr(audio), _lib.ptr(audio), B, T, float(self.preempthasis),
+                                                  stream), "ctts_deemphasis_f32")
+        if return_CPU:
+            audio = audio.cpu()
+        return audio, None
+
+    def _inverse_1d(self, z, cond, speaker_ids, return_CPU):
+        """waveflow=False: efficient_model_ax.py:279-357 with AffineCouplingBlock + 1-D WN (ctts_wgax_inverse_f32)."""
+        device = cond.device
+        blob, ops = self._ensure_packed(device)
+        lib = _lib.lib()
+        cfg = self.c_config_1d()
+        mel = cond.detach().float().contiguous()
+        zz = z.detach().to(device=device, dtype=torch.float32).contiguous()
+        B, T = zz.shape
+        assert mel.shape[0] == B and mel.shape[1] == self.n_mel_channels * (2 if self.has_logvar_channels else 1)
+        assert T % self.n_group == 0, "z length is not a multiple of n_group"
+        key = (device, B, T)
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = lib.ctts_wgax_workspace_bytes(C.byref(cfg), B, T)
+            if nbytes == 0:
+                raise _lib.HipLibraryError("ax WaveGlow workspace query failed: " + lib.ctts_last_error().decode())
+            self._ws = {}
+            ws = self._ws.setdefault(key, torch.zeros(nbytes // 4, dtype=torch.float32, device=device))
+        audio = torch.empty(B, T, dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            frames, ld = self._cond_frames(ops, mel, speaker_ids, stream)
+            _lib.check(lib.ctts_wgax_inverse_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(zz), _lib.ptr(frames), ld, PAD,
+                                                 mel.shape[2], _lib.ptr(audio), B, T, _lib.ptr(ws), ws.numel() * 4,
+                                                 stream), "ctts_wgax_inverse_f32")
+            if self.preempthasis:
                 _lib.check(lib.ctts_deemphasis_f32(_lib.ptr(audio), _lib.ptr(audio), B, T, float(self.preempthasis),
                                                   stream), "ctts_deemphasis_f32")
         if return_CPU:

@@ -229,6 +229,66 @@ int ctts_scale_add_rows_f32(const float* x, const float* alpha_dev, const float*
                             int32_t C, int32_t T, int32_t ld, int32_t pad, void* stream);
 int ctts_deemphasis_f32(const float* x, float* y, int32_t batch, int32_t T, double p, void* stream);
 
+/* ---- "ax" WaveGlow core with waveflow=False: AffineCouplingBlock + 1-D WN ------------------- */
+/* Replaces, for inference, efficient_model_ax.py:309-346 (the flow loop of WaveGlow.inverse) with
+ *   AffineCouplingBlock.inverse   efficient_modules.py:94-105   ((log_s, t) = WN(a0); a1 = (a1 - t) / exp(log_s))
+ *   WN.forward (1-D)              glow_ax.py:375-418            (start, dilated in_layers + GTU gate, res/skip, end;
+ *                                                               conditioning at frame rate, linearly interpolated
+ *                                                               with align_corners=True, glow_ax.py:362-373)
+ *   InvertibleConv1x1.inverse     efficient_modules.py:269-286  (W.float().inverse() taken by the caller)
+ *   PermuteHeight.inverse         efficient_modules.py:376-403
+ *   early outputs                 efficient_model_ax.py:312-316, 340-341;   ignore_nan  :13-16, 333-334
+ *   mix_first ordering            efficient_model_ax.py:324-325, 337-338
+ * Built: GTU gate, res_skip=True, merge_res_skip=False, dense in-layers with width dilation 2^i,
+ * upsample_first=False; the per-flow WN conditioning stack is evaluated by the caller at FRAME rate (composed from
+ * ctts_conv1d_f32 / ctts_embed_rows_f32 / ctts_scale_add_rows_f32 / ctts_replicate_halo_f32) and handed over, like
+ * ctts_waveflow_inverse_cond_f32. */
+#define CTTS_MIX_PERMUTE 0
+#define CTTS_MIX_CONV1X1 1
+typedef struct ctts_wgax_config {
+    int32_t n_flows;         /* 48 in the reference's timed notebook config */
+    int32_t n_group;         /* 24 (even, <= 32) */
+    int32_t n_early_every;   /* 16 */
+    int32_t n_early_size;    /* 2 (even) */
+    int32_t n_layers;        /* 8 */
+    int32_t n_channels;      /* 256 (multiple of 128) */
+    int32_t kernel_size;     /* 3 (odd, <= 11): WN_config kernel_size_w or kernel_size */
+    int32_t mixing;          /* CTTS_MIX_PERMUTE | CTTS_MIX_CONV1X1 */
+    int32_t mix_first;       /* 0 | 1 */
+    int32_t ignore_nan;      /* 1: NaN -> 0 on the latent after every coupling (the reference's default) */
+} ctts_wgax_config;
+
+/* Dense, weight-norm-folded fp32 device weights of one flow in checkpoint layouts (keys WN.k.WN.*, convinv.k.weight) */
+typedef struct ctts_wgax_flow_weights {
+    const float* start_w;      /* [C][n_half_k] */
+    const float* start_b;      /* [C] */
+    const float* const* in_w;  /* n_layers x [2C][C][ks] */
+    const float* const* in_b;  /* n_layers x [2C] */
+    const float* const* rs_w;  /* n_layers x [2C or C][C] */
+    const float* const* rs_b;
+    const float* end_w;        /* [2*n_half_k][C]: rows [0, h) = log_s, [h, 2h) = t (efficient_modules.py:100) */
+    const float* end_b;        /* [2*n_half_k] */
+    const float* w_inverse;    /* [n_rem_k][n_rem_k] = convinv.k.weight[:, :, 0].float().inverse(); NULL for PERMUTE */
+} ctts_wgax_flow_weights;
+
+size_t ctts_wgax_packed_bytes(const ctts_wgax_config* cfg);
+int ctts_wgax_pack_flow(const ctts_wgax_config* cfg, int32_t flow, const ctts_wgax_flow_weights* w,
+                        void* packed, void* stream);
+size_t ctts_wgax_workspace_bytes(const ctts_wgax_config* cfg, int32_t batch, int64_t samples);
+/* The flow loop of WaveGlow.inverse(z, cond):
+ *   z     [B][samples] fp32, sigma applied; samples a multiple of n_group; early-output noise is part of z (ax:312-316)
+ *   cond  [n_flows][B][2*C*n_layers][cond_ld]: each flow's WN conditioning at frame rate, valid frames at columns
+ *         [cond_pad, cond_pad + frames)
+ *   audio [B][samples]
+ * Workspace zero-filled once before first use (halo columns are never written). */
+int ctts_wgax_inverse_f32(const ctts_wgax_config* cfg, const void* packed, const float* z, const float* cond,
+                          int32_t cond_ld, int32_t cond_pad, int32_t frames, float* audio, int32_t batch,
+                          int64_t samples, void* workspace, size_t workspace_bytes, void* stream);
+/* padding_mode='replicate' of the conditioning convs (efficient_model_ax.py:90, glow_ax.py:311): fill the `halo`
+ * columns either side of the valid range of x [B][C][ld] with the edge values, before a ctts_conv1d_f32 reads them. */
+int ctts_replicate_halo_f32(float* x, int32_t batch, int32_t C, int32_t T, int32_t ld, int32_t pad, int32_t halo,
+                            void* stream);
+
 /* ---- Tacotron2-TM decoder loop: _2_ttm/tacotron2_tm/model.py:668-767, 851-916 -------------- */
 
 /* Shapes from hparams.py (:201-258).  Built topology = the repo defaults: attention_type 0 with

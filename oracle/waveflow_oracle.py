@@ -82,12 +82,20 @@ def activation(name, negative_slope):
     raise NotImplementedError(name)
 
 
-def conv1d_same(x, w, b):
-    """Conv1d, odd kernel, zero padding (k-1)/2: x [B, Cin, T], w [Cout, Cin, k] -> [B, Cout, T]."""
+def conv1d_same(x, w, b, padding_mode='zeros'):
+    """Conv1d, odd kernel, padding (k-1)/2 with zeros or edge values ('replicate', the two modes the reference's
+    configs use: efficient_model_ax.py:90, glow_ax.py:311): x [B, Cin, T], w [Cout, Cin, k] -> [B, Cout, T]."""
     k = w.shape[2]
-    y = np.zeros((x.shape[0], w.shape[0], x.shape[2]), F32) + b[None, :, None]
+    T = x.shape[2]
+    h = k // 2
+    if padding_mode == 'replicate':
+        xp = np.pad(x, ((0, 0), (0, 0), (h, h)), mode='edge')
+    else:
+        assert padding_mode == 'zeros', padding_mode
+        xp = np.pad(x, ((0, 0), (0, 0), (h, h)))
+    y = np.zeros((x.shape[0], w.shape[0], T), F32) + b[None, :, None]
     for j in range(k):
-        y = y + np.matmul(np.ascontiguousarray(w[:, :, j]), _shift(x, j - k // 2))
+        y = y + np.matmul(np.ascontiguousarray(w[:, :, j]), xp[:, :, j:j + T])
     return y.astype(F32)
 
 
@@ -106,7 +114,7 @@ def model_cond(sd, cfg, mel, speaker_ids=None):
     act = activation(cfg.get("cond_activation_func", 'none'), cfg.get("negative_slope"))
     res = cond
     for l in range(cfg["cond_layers"]):
-        res = conv1d_same(res, _w(sd, f"cond_layers.{l}"), sd[f"cond_layers.{l}.bias"])
+        res = conv1d_same(res, _w(sd, f"cond_layers.{l}"), sd[f"cond_layers.{l}.bias"], cfg.get("cond_padding_mode", 'zeros'))
         if act is not None:
             res = act(res).astype(F32)
     if "alpha" in sd:
@@ -160,7 +168,8 @@ def waveflow_inverse(sd, cfg, z, mel, speaker_ids=None):
             emb = sd[p + ".speaker_embed.weight"][np.asarray(speaker_ids)]
             spect = np.concatenate([spect, np.repeat(emb[:, :, None], spect.shape[2], axis=2)], axis=1)
         for l in range(wn["cond_layers"]):
-            spect = conv1d_same(spect, _w(sd, f"{p}.cond_layers.{l}"), sd[f"{p}.cond_layers.{l}.bias"])
+            spect = conv1d_same(spect, _w(sd, f"{p}.cond_layers.{l}"), sd[f"{p}.cond_layers.{l}.bias"],
+                                wn.get("cond_padding_mode", 'zeros'))
             if wn_act is not None and (wn.get("cond_out_activation_func", True) or l != wn["cond_layers"] - 1):
                 spect = wn_act(spect).astype(F32)
         cond = lerp_align_corners(spect, L)

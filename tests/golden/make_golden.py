@@ -259,6 +259,45 @@ def make_waveflow(full_length=False):
         print(f"[golden] waveflow {name}: audio {audio.shape} rms={audio.std():.4f} -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def make_waveglow_ax(full_length=False):
+    """efficient_model_ax.WaveGlow with waveflow=False (AffineCouplingBlock + 1-D WN; InvertibleConv1x1 / PermuteHeight
+    mixing in both orders; early outputs; the timed notebook config's option set)."""
+    import copy
+    torch.set_num_threads(8)
+    cases = [("toy_conv", 2, 7, 0.8, 21), ("toy_conv_mixlast", 1, 6, 1.0, 22), ("toy_permute", 2, 5, 0.7, 23),
+             ("toy_permute_mixfirst", 1, 9, 0.9, 24), ("notebook_toy", 2, 6, 0.8, 25)]
+    if full_length:
+        # the notebook config at full width (48 flows x 8 x 256, n_group 24, 160 mel channels), short mel
+        cases = [("notebook", 1, 5, 0.9, 26)]
+    for key, B, F, sigma, seed in cases:
+        cfg = synthetic.WAVEGLOW_AX_CONFIGS[key]
+        sd = synthetic.waveglow_ax_state_dict(cfg, seed=seed)
+        model = _ref_waveflow(copy.deepcopy(cfg), sd)
+        n_in = cfg["n_mel_channels"] * (2 if cfg.get("use_logvar_channels") else 1)
+        mel = synthetic.synthetic_mel(B, F, n_in, seed=seed)
+        multispeaker = bool(cfg["speaker_embed"] or cfg["WN_config"]["speaker_embed_dim"])
+        ids = np.array([3, 17, 250, 511][:B], np.int64) if multispeaker else None
+        tids = None if ids is None else torch.from_numpy(ids)
+        samples = F * cfg["hop_length"]
+        samples -= samples % cfg["n_group"]
+        torch.manual_seed(seed)
+        z = torch.empty(B, samples).normal_(std=sigma).numpy()
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            audio = model.infer(torch.from_numpy(mel.copy()), speaker_ids=tids, sigma=sigma).numpy()
+            melp = np.pad(mel, ((0, 0), (0, 0), (0, 1)))
+            inv, _ = model.inverse(torch.from_numpy(z.copy()), torch.from_numpy(melp.copy()), speaker_ids=tids)
+        inv = inv.numpy()
+        assert audio.shape == (B, samples - cfg["hop_length"]) and np.isfinite(audio).all()
+        assert np.array_equal(inv[:, :audio.shape[1]], audio), "noise replay out of sync with infer()"
+        path = os.path.join(HERE, f"waveglow_ax_{key}.npz")
+        extra = {} if ids is None else {"speaker_ids": ids}
+        np.savez_compressed(path, config_key=key, seed=seed, sigma=np.float32(sigma), mel=mel, z=z, audio=audio,
+                            inverse_full=inv.astype(np.float32), **extra)
+        print(f"[golden] waveglow_ax {key}: audio {audio.shape} rms={audio.std():.4f} max={np.abs(audio).max():.2f} -> "
+              f"{os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def _ref_tacotron(hp, seed):
     """Reference Tacotron2 with the recipe weights.  Shims: no-op RNNCellBase input checks
     (removed in torch 2.x, called at utils/model/layers.py:375-379)."""
@@ -393,7 +432,7 @@ def make_alignment():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["waveglow", "stft", "waveflow", "tacotron", "alignment"]
+    which = sys.argv[1:] or ["waveglow", "stft", "waveflow", "waveglow_ax", "tacotron", "alignment"]
     if "alignment" in which:
         make_alignment()
     if "tacotron" in which:
@@ -404,6 +443,10 @@ if __name__ == "__main__":
         make_waveglow()
     if "stft" in which:
         make_stft()
+    if "waveglow_ax" in which:
+        make_waveglow_ax()
+    if "waveglow_ax_notebook" in which:    # on request only: 272 M parameters
+        make_waveglow_ax(full_length=True)
     if "waveglow_full_len" in which:       # on request only: minutes of CPU
         make_waveglow(full_length=True)
     if "waveflow_full_len" in which:
