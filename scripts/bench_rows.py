@@ -70,7 +70,7 @@ def row_waveflow_author(args):
 def row_waveglow_ax_notebook(args):
     """the ONLY WaveGlow timing recorded in the reference tree - scripts/"WaveGlowFlow Inference
     Speed Testing.ipynb" cells 2-6: ax core, waveflow=False, 48 flows, n_group 24, 8 x 256 WN, 'permute' mixing,
-    speaker embeddings, 3-layer cond stack, batch 1, one 5.8375 s clip at 48 kHz (hop 600 -> 467 mel frames):
+    speaker embeddings, 3-layer cond stack, batch 1, one 5.8375 s clip at 48 kHz (hop 600 -> 468 mel frames):
     1.27 s = 4.60x real time (eager, fp16), 1.125 s = 5.19x (jit-traced), GPU not stated.  Same model shape, same
     clip length, batch 1 here; fp32 (the reference ran .half())."""
     from cookietts_amd.waveglow_ax import WaveGlow
@@ -80,16 +80,16 @@ def row_waveglow_ax_notebook(args):
     m = m.cuda().eval()
     rows = []
     for B in (1, 8):
-        F = 467
+        F = 468                                                   # -> (F - 1) * 600 = 280 200 samples = 5.8375 s
         mel = torch.from_numpy(synthetic.synthetic_mel(B, F, cfg["n_mel_channels"])).cuda()
         ids = torch.zeros(B, dtype=torch.int64).cuda()
         dt = timed(lambda: m.infer(mel, speaker_ids=ids, sigma=1.0, return_CPU=False), args.warmup, args.steps)
-        samples = B * F * cfg["hop_length"]                       # infer() pads one frame and trims one hop
+        samples = B * (F - 1) * cfg["hop_length"]                 # infer() pads one frame and trims one hop
         wn = cfg["WN_config"]
         C, nl = wn["n_channels"], wn["n_layers"]
         flop = 2.0 * cfg["n_flows"] * nl * (3 * C * 2 * C + 2 * C * C) * (samples / cfg["n_group"])   # in + res/skip GEMMs
         rows.append({"row": "W5/notebook", "metric": "real-time factor (48 kHz), ax WaveGlow waveflow=False, 48 flows x 8 x 256, "
-                                                     "n_group 24, 160x467 mel (5.84 s clip)",
+                                                     "n_group 24, 160x468 mel (5.84 s clip)",
                      "value": samples / dt / 48000.0, "unit": "x real time (48 kHz)", "batch": B, "ms_per_call": dt * 1e3,
                      "samples_per_s": samples / dt, "rtf_22k_equiv": samples / dt / 48000.0 * 48 / 22, "dtype": "f32",
                      "reference_published": {"eager_fp16_rtf_48k": 4.5977, "jit_fp16_rtf_48k": 5.1905, "batch": 1,
