@@ -163,6 +163,8 @@ SIGNATURES = {
                                           C.c_size_t, _FP]),
     "ctts_stft_inverse_f32": (C.c_int, [C.POINTER(StftConfig), _FP, _FP, _FP, _FP, C.c_float, _FP, C.c_int32,
                                         C.c_int32, _FP, C.c_size_t, _FP]),
+    "ctts_stft_inverse_bias_f32": (C.c_int, [C.POINTER(StftConfig), _FP, _FP, _FP, _FP, C.c_int32, C.c_float, _FP,
+                                             C.c_int32, C.c_int32, _FP, C.c_size_t, _FP]),
     "ctts_waveflow_inverse_cond_f32": (C.c_int, [C.POINTER(WaveFlowConfig), _FP, _FP, _FP, C.c_int32, C.c_int32, _FP,
                                                  C.c_int32, C.c_int32, C.c_int32, _FP, C.c_size_t, _FP]),
     "ctts_wgax_packed_bytes": (C.c_size_t, [C.POINTER(WgaxConfig)]),

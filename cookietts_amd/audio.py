@@ -188,11 +188,16 @@ class STFT(torch.nn.Module):
         T = (frames - 1) * self.hop_length
         cfg, blob, ws, stream = self._blob_ws(device, B, max(T, self.filter_length))
         out = torch.empty(B, 1, T, dtype=torch.float32, device=device)
-        bias = None if _bias_spec is None else _bias_spec.detach().to(device).float().reshape(-1).contiguous()
+        bias, bstride = None, 0
+        if _bias_spec is not None:      # [cutoff] shared, or [B, cutoff] one spectrum per utterance
+            bias = _bias_spec.detach().to(device).float().reshape(-1, cutoff).contiguous()
+            assert bias.shape[0] in (1, B), (tuple(bias.shape), B)
+            bstride = cutoff if bias.shape[0] == B and B > 1 else 0
         with torch.cuda.device(device):
-            _lib.check(_lib.lib().ctts_stft_inverse_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(mag), _lib.ptr(ph),
-                                                       _lib.ptr(bias), float(_strength), _lib.ptr(out), B, frames,
-                                                       _lib.ptr(ws), ws.numel() * 4, stream), "ctts_stft_inverse_f32")
+            _lib.check(_lib.lib().ctts_stft_inverse_bias_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(mag), _lib.ptr(ph),
+                                                            _lib.ptr(bias), bstride, float(_strength), _lib.ptr(out), B,
+                                                            frames, _lib.ptr(ws), ws.numel() * 4, stream),
+                       "ctts_stft_inverse_bias_f32")
         return out
 
     def forward(self, input_data):
@@ -224,33 +229,50 @@ class Denoiser(torch.nn.Module):
     """Removes the vocoder's bias spectrum from generated audio (``_4_mtw/waveglow/denoiser.py:7-72``).
 
     Same constructor arguments; ``stft_device`` is ignored (everything runs on the vocoder's GPU).  The bias
-    subtraction + clamp is fused into the inverse STFT's recombination kernel.  Only the shared-bias mode is
-    built (``speaker_dependant=True`` raises)."""
+    subtraction + clamp is fused into the inverse STFT's recombination kernel.  ``speaker_dependant=True`` keeps one
+    bias spectrum per speaker id (denoiser.py:29-45) and ``forward(..., speaker_ids=...)`` subtracts each utterance's
+    own (denoiser.py:65-66)."""
 
     def __init__(self, waveglow, sampling_rate=48000, filter_length=None, hop_length=None, win_length=None,
                  n_mel_channels=160, n_frames=20, mu=0, var=0.01, wg_sigma=0.01, stft_device='cpu',
                  speaker_dependant=False, speaker_id=0):
         super().__init__()
-        if speaker_dependant:
-            raise NotImplementedError("speaker_dependant bias spectra are not built")
         filter_length = filter_length or sampling_rate // 40
         win_length = win_length or sampling_rate // 40
         hop_length = hop_length or sampling_rate // 400
         p = next(waveglow.parameters())
         self.stft = STFT(filter_length=filter_length, hop_length=hop_length, win_length=win_length).to(p.device)
         mel_input = torch.randn((1, n_mel_channels, n_frames), dtype=p.dtype, device=p.device) * float(var) + float(mu)
-        with torch.no_grad():
+
+        def infer(ids):
             try:
-                bias_audio = waveglow.infer(mel_input, speaker_ids=torch.tensor([speaker_id], device=p.device), sigma=wg_sigma)
-            except TypeError:      # glow.py's signature has no speaker_ids keyword (glow.py:314)
-                bias_audio = waveglow.infer(mel_input, sigma=wg_sigma)
-            bias_audio = bias_audio.to(device=p.device, dtype=torch.float)
+                return waveglow.infer(mel_input.expand(ids.shape[0], -1, -1).contiguous(), speaker_ids=ids, sigma=wg_sigma)
+            except TypeError:      # glow.py's signature names it speaker_id (glow.py:314)
+                return waveglow.infer(mel_input.expand(ids.shape[0], -1, -1).contiguous(), speaker_id=ids, sigma=wg_sigma)
+        with torch.no_grad():
+            if speaker_dependant:      # denoiser.py:29-45: one vocoder pass per speaker, batched here
+                if hasattr(waveglow, 'speaker_embed'):
+                    n_speakers = waveglow.speaker_embed.num_embeddings
+                elif hasattr(waveglow, 'WN') and hasattr(waveglow.WN[0], 'WN') and hasattr(waveglow.WN[0].WN, 'speaker_embed'):
+                    n_speakers = waveglow.WN[0].WN.speaker_embed.num_embeddings
+                else:
+                    n_speakers = 1
+                chunks = [infer(torch.arange(i, min(i + 64, n_speakers), device=p.device, dtype=torch.int64))
+                          for i in range(0, n_speakers, 64)]
+                bias_audio = torch.cat([c.to(device=p.device, dtype=torch.float) for c in chunks], dim=0)
+            else:
+                bias_audio = infer(torch.tensor([speaker_id], device=p.device, dtype=torch.int64))
+                bias_audio = bias_audio.to(device=p.device, dtype=torch.float)
             assert torch.isfinite(bias_audio).all(), 'Inf/NaN elements found in Vocoder Output'
             bias_spec, _ = self.stft.transform(bias_audio, return_phase=False)
-        self.register_buffer('bias_spec', bias_spec.mean(dim=2, keepdim=True))      # [1, cutoff, 1]
+        self.register_buffer('bias_spec', bias_spec.mean(dim=2, keepdim=True))      # [n_speakers or 1, cutoff, 1]
 
     @torch.no_grad()
     def forward(self, wg_audio, speaker_ids=None, strength=0.1):
         audio = wg_audio.to(self.bias_spec.device).float()
         audio_spec, audio_angles = self.stft.transform(audio, return_phase=True)
-        return self.stft.inverse(audio_spec, audio_angles, _bias_spec=self.bias_spec[0], _strength=strength)
+        if speaker_ids is None or self.bias_spec.shape[0] == 1:
+            bias = self.bias_spec[0]
+        else:
+            bias = self.bias_spec[speaker_ids.to(self.bias_spec.device)]            # [B, cutoff, 1]
+        return self.stft.inverse(audio_spec, audio_angles, _bias_spec=bias, _strength=strength)

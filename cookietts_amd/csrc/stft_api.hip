@@ -101,14 +101,15 @@ __global__ __launch_bounds__(256) void stft_polar_kernel(const float* __restrict
 // R[b][c][n] = m cos(phase), R[b][cutoff + c][n] = m sin(phase), m = bias ? max(mag - bias[c]*strength, 0) : mag
 // (stft.py:118-119; denoiser.py:62-67)
 __global__ __launch_bounds__(256) void stft_recombine_kernel(const float* __restrict__ mag, const float* __restrict__ phase,
-                                                             const float* __restrict__ bias, float strength,
-                                                             float* __restrict__ R, int cutoff, int kinv, int frames, int ld) {
+                                                             const float* __restrict__ bias, int bias_bstride,
+                                                             float strength, float* __restrict__ R, int cutoff, int kinv,
+                                                             int frames, int ld) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int c = blockIdx.y, b = blockIdx.z;
     if (n >= frames) return;
     const size_t i = ((size_t)b * cutoff + c) * frames + n;
     float m = mag[i];
-    if (bias) m = fmaxf(m - bias[c] * strength, 0.f);
+    if (bias) m = fmaxf(m - bias[(size_t)b * bias_bstride + c] * strength, 0.f);
     const float ph = phase[i];
     R[((size_t)b * kinv + c) * ld + n] = m * cosf(ph);
     R[((size_t)b * kinv + cutoff + c) * ld + n] = m * sinf(ph);
@@ -271,9 +272,17 @@ int ctts_stft_transform_f32(const ctts_stft_config* cfg, const void* packed, con
 int ctts_stft_inverse_f32(const ctts_stft_config* cfg, const void* packed, const float* mag, const float* phase,
                           const float* bias_spec, float strength, float* out, int32_t batch, int32_t frames,
                           void* workspace, size_t workspace_bytes, void* stream) {
+    return ctts_stft_inverse_bias_f32(cfg, packed, mag, phase, bias_spec, 0, strength, out, batch, frames, workspace,
+                                      workspace_bytes, stream);
+}
+
+int ctts_stft_inverse_bias_f32(const ctts_stft_config* cfg, const void* packed, const float* mag, const float* phase,
+                               const float* bias_spec, int32_t bias_bstride, float strength, float* out, int32_t batch,
+                               int32_t frames, void* workspace, size_t workspace_bytes, void* stream) {
     StftPlan p; StftGeom g;
     int rc = make_stft_plan(cfg, p); if (rc) return rc;
     CTTS_CHECK_ARG(packed && mag && phase && out && workspace && batch >= 1 && frames >= 2, "stft_inverse: bad argument");
+    CTTS_CHECK_ARG(bias_bstride == 0 || bias_bstride >= p.cutoff, "stft_inverse: bias stride %d < %d bins", bias_bstride, p.cutoff);
     const int T_out = (frames - 1) * p.c.hop_length;
     rc = make_stft_geom(p, T_out > p.N / 2 ? T_out : p.N, g); if (rc) return rc;
     g.frames = frames; g.ntiles = (frames + GEMM_BN - 1) / GEMM_BN; g.ld = g.ntiles * GEMM_BN;
@@ -285,7 +294,7 @@ int ctts_stft_inverse_f32(const ctts_stft_config* cfg, const void* packed, const
     float* R = Y + align_up((size_t)batch * p.N * g.ld);
     CTTS_CHECK_HIP(hipMemsetAsync(R, 0, (size_t)batch * p.kinv * g.ld * sizeof(float), s));   // K padding rows / tile tail
     hipLaunchKernelGGL(stft_recombine_kernel, dim3((frames + 255) / 256, p.cutoff, batch), dim3(256), 0, s, mag, phase,
-                       bias_spec, strength, R, p.cutoff, p.kinv, frames, g.ld);
+                       bias_spec, bias_bstride, strength, R, p.cutoff, p.kinv, frames, g.ld);
     CTTS_CHECK_LAUNCH("stft_recombine");
     GemmArgs a{};
     a.ld = g.ld; a.pad = 0; a.L = frames; a.ntiles = g.ntiles; a.batch = batch; a.dst_ld = g.ld; a.dst_pad = 0;

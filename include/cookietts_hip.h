@@ -457,6 +457,12 @@ int ctts_stft_transform_f32(const ctts_stft_config* cfg, const void* packed, con
 int ctts_stft_inverse_f32(const ctts_stft_config* cfg, const void* packed, const float* mag, const float* phase,
                           const float* bias_spec, float strength, float* out, int32_t batch, int32_t frames,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* Same with one bias spectrum PER UTTERANCE: bias_spec [batch][bias_bstride >= N/2+1] (Denoiser(speaker_dependant=True):
+ * bias_spec[speaker_ids], denoiser.py:29-45, 65-66); bias_bstride = 0 shares one spectrum like ctts_stft_inverse_f32. */
+int ctts_stft_inverse_bias_f32(const ctts_stft_config* cfg, const void* packed, const float* mag, const float* phase,
+                               const float* bias_spec, int32_t bias_bstride, float strength, float* out,
+                               int32_t batch, int32_t frames, void* workspace, size_t workspace_bytes,
+                               void* stream);
 
 /* ---- attention-alignment scoring (T2S retry loop) -------------------- */
 

@@ -156,7 +156,10 @@ def stft_inverse(mag, phase, filter_length, hop_length, win_length):
 
 
 def denoise(audio, bias_spec, strength, filter_length, hop_length, win_length):
-    """Denoiser.forward (denoiser.py:55-72) for one shared bias spectrum [c]."""
+    """Denoiser.forward (denoiser.py:55-72) for one shared bias spectrum [c], or one per utterance [B, c]
+    (speaker_dependant: ``bias_spec[speaker_ids]``, denoiser.py:65-66)."""
     mag, phase = stft_transform(audio, filter_length, hop_length, win_length)
-    den = np.maximum(mag - bias_spec[None, :, None] * F32(strength), 0).astype(F32)
+    bias = np.asarray(bias_spec, dtype=F32)
+    bias = bias[None] if bias.ndim == 1 else bias
+    den = np.maximum(mag - bias[:, :, None] * F32(strength), 0).astype(F32)
     return stft_inverse(den, phase, filter_length, hop_length, win_length)

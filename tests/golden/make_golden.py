@@ -191,10 +191,16 @@ def make_stft():
         bias = (np.abs(rng.standard_normal(N // 2 + 1)) * 0.5).astype(np.float32)
         den.bias_spec = torch.from_numpy(bias)[None, :, None]
         dn = den(torch.from_numpy(y3), strength=0.3)
+        # speaker-dependent mode (denoiser.py:29-45, 65-66): one bias spectrum per speaker id, picked per utterance
+        bias_spk = (np.abs(rng.standard_normal((3, N // 2 + 1))) * 0.5).astype(np.float32)
+        den.bias_spec = torch.from_numpy(bias_spk)[:, :, None]
+        spk = np.array([2, 0], np.int64)
+        dn_spk = den(torch.from_numpy(y3), speaker_ids=torch.from_numpy(spk), strength=0.45)
     path = os.path.join(HERE, "stft_inverse.npz")
     np.savez_compressed(path, y=y3, mag=m3.numpy().astype(np.float32), phase=p3.numpy().astype(np.float32),
                         roundtrip=rt.numpy().astype(np.float32), bias_spec=bias, strength=np.float32(0.3),
-                        denoised=dn.numpy().astype(np.float32))
+                        denoised=dn.numpy().astype(np.float32), bias_spec_spk=bias_spk, speaker_ids=spk,
+                        strength_spk=np.float32(0.45), denoised_spk=dn_spk.numpy().astype(np.float32))
     print(f"[golden] stft_inverse: roundtrip {tuple(rt.shape)} max err vs input "
           f"{float(np.abs(rt.numpy()[:, 0] - y3).max()):.2e} -> {os.path.getsize(path) / 1024:.0f} KiB")
 

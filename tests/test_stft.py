@@ -105,6 +105,8 @@ def test_oracle_inverse_and_denoiser_match_reference():
     assert np.abs(rt[:, 0] - g["y"]).max() < 1e-5                      # STFT -> ISTFT reconstructs the input
     dn = so.denoise(g["y"], g["bias_spec"], float(g["strength"]), 1024, 256, 1024)
     assert np.abs(dn - g["denoised"]).max() < 1e-5
+    dn = so.denoise(g["y"], g["bias_spec_spk"][g["speaker_ids"]], float(g["strength_spk"]), 1024, 256, 1024)
+    assert np.abs(dn - g["denoised_spk"]).max() < 1e-5                 # speaker-dependent bias (denoiser.py:65-66)
 
 
 @pytest.mark.gpu
@@ -135,3 +137,30 @@ def test_hip_phase_inverse_denoiser_match_reference(hip_lib_path):
     dn = den(y, strength=float(g["strength"])).cpu().numpy()
     print("denoiser Linf vs reference:", np.abs(dn - g["denoised"]).max())
     assert dn.shape == g["denoised"].shape and np.abs(dn - g["denoised"]).max() < MEL_TOL
+    # speaker-dependent mode: bias_spec [n_speakers, bins, 1], one row picked per utterance (denoiser.py:29-45, 65-66)
+    den.bias_spec = torch.from_numpy(g["bias_spec_spk"]).cuda()[:, :, None]
+    ids = torch.from_numpy(g["speaker_ids"]).cuda()
+    dn = den(y, speaker_ids=ids, strength=float(g["strength_spk"])).cpu().numpy()
+    print("speaker-dependent denoiser Linf vs reference:", np.abs(dn - g["denoised_spk"]).max())
+    assert np.abs(dn - g["denoised_spk"]).max() < MEL_TOL
+    shared = den(y, speaker_ids=None, strength=float(g["strength_spk"])).cpu().numpy()       # ids None -> row 0 for all
+    assert np.abs(shared[1] - dn[1]).max() < 1e-6 and np.abs(shared[0] - dn[0]).max() > 1e-4
+
+
+@pytest.mark.gpu
+def test_hip_speaker_dependent_denoiser_constructor(hip_lib_path):
+    """Denoiser(speaker_dependant=True) on a multispeaker ax vocoder: one bias spectrum per speaker id, taken from
+    WN[0].WN.speaker_embed.num_embeddings like denoiser.py:33-34."""
+    from cookietts_amd import Denoiser, synthetic
+    from cookietts_amd.waveglow_ax import WaveGlow
+    cfg = synthetic.WAVEGLOW_AX_CONFIGS["notebook_toy"]
+    m = WaveGlow(**cfg)
+    m.load_state_dict(synthetic.to_torch(synthetic.waveglow_ax_state_dict(cfg, seed=5)))
+    m = m.cuda().eval()
+    den = Denoiser(m, sampling_rate=6400, n_mel_channels=cfg["n_mel_channels"], n_frames=12, speaker_dependant=True)
+    assert den.bias_spec.shape == (512, 6400 // 40 // 2 + 1, 1) and torch.isfinite(den.bias_spec).all()
+    assert (den.bias_spec[3] - den.bias_spec[4]).abs().max() > 0                         # per-speaker, not a copy
+    audio = m.infer(torch.from_numpy(synthetic.synthetic_mel(2, 9, cfg["n_mel_channels"])).cuda(),
+                    speaker_ids=torch.tensor([3, 4]).cuda(), sigma=0.5, return_CPU=False)
+    out = den(audio, speaker_ids=torch.tensor([3, 4]).cuda(), strength=0.2)
+    assert out.shape == (2, 1, audio.shape[1] // 16 * 16) and torch.isfinite(out).all()
