@@ -19,7 +19,7 @@ class WaveGlowConfig(C.Structure):
     """``ctts_waveglow_config`` (include/cookietts_hip.h)."""
     _fields_ = [(n, C.c_int32) for n in (
         "n_mel_channels", "n_group", "n_flows", "n_early_every", "n_early_size",
-        "win_length", "hop_length", "n_layers", "n_channels", "kernel_size", "cond_hidden")]
+        "win_length", "hop_length", "n_layers", "n_channels", "kernel_size", "cond_hidden", "speaker_embed_dim")]
 
 
 class StftConfig(C.Structure):
@@ -41,7 +41,7 @@ class WaveGlowFlowWeights(C.Structure):
         ("cond_w", _FP * 3), ("cond_b", _FP * 3),
         ("in_w", C.POINTER(_FP)), ("in_b", C.POINTER(_FP)),
         ("rs_w", C.POINTER(_FP)), ("rs_b", C.POINTER(_FP)),
-        ("end_w", _FP), ("end_b", _FP), ("w_inverse", _FP),
+        ("end_w", _FP), ("end_b", _FP), ("w_inverse", _FP), ("speaker_embed", _FP),
     ]
 
 
@@ -70,6 +70,7 @@ class WgaxFlowWeights(C.Structure):
 
 
 MIX_PERMUTE, MIX_CONV1X1 = 0, 1
+N_SPEAKERS = 512       # CTTS_N_SPEAKERS
 
 
 class TacoDecoderConfig(C.Structure):
@@ -115,12 +116,15 @@ SIGNATURES = {
     "ctts_waveglow_pack_flow": (C.c_int, [_CFG, C.c_int32, C.POINTER(WaveGlowFlowWeights), _FP, _FP]),
     "ctts_waveglow_workspace_bytes": (C.c_size_t, [_CFG, C.c_int32, C.c_int32]),
     "ctts_waveglow_infer_f32": (C.c_int, [_CFG, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP, C.c_size_t, _FP]),
+    "ctts_waveglow_infer_spk_f32": (C.c_int, [_CFG, _FP, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP, C.c_size_t, _FP]),
+    "ctts_waveglow_infer_spk_bf16": (C.c_int, [_CFG, _FP, _FP, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP, C.c_size_t,
+                                              _FP]),
     "ctts_waveglow_packed_bf16_bytes": (C.c_size_t, [_CFG]),
     "ctts_waveglow_pack_flow_bf16": (C.c_int, [_CFG, C.c_int32, C.POINTER(WaveGlowFlowWeights), _FP, _FP]),
     "ctts_waveglow_workspace_bf16_bytes": (C.c_size_t, [_CFG, C.c_int32, C.c_int32]),
     "ctts_waveglow_infer_bf16": (C.c_int, [_CFG, _FP, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP, C.c_size_t, _FP]),
     "ctts_upsample_squeeze_f32": (C.c_int, [_CFG, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP]),
-    "ctts_wn_cond_f32": (C.c_int, [_CFG, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP]),
+    "ctts_wn_cond_f32": (C.c_int, [_CFG, _FP, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP]),
     "ctts_wn_stack_f32": (C.c_int, [_CFG, _FP, C.c_int32, _FP, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP]),
     "ctts_flow_tail_f32": (C.c_int, [_CFG, _FP, C.c_int32, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP]),
     "ctts_waveflow_packed_bytes": (C.c_size_t, [C.POINTER(WaveFlowConfig)]),
@@ -222,7 +226,7 @@ def lib():
                 raise HipLibraryError(f"{path} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
-        if handle.ctts_abi_version() != 1:
+        if handle.ctts_abi_version() != 2:
             raise HipLibraryError(f"ABI version mismatch: library reports {handle.ctts_abi_version()}")
         _LIB = handle
     return _LIB

@@ -29,13 +29,14 @@ struct FlowDims { int n_rem, n_half, ch_off; };
 struct Plan {
     ctts_waveglow_config c;
     int C, H, K0, n_in;                 // WN channels, cond hidden, n_mel*G, flows
+    int S;                              // speaker-embedding rows per flow, padded to a multiple of 32 (0: single speaker)
     int nch0, nch1h, nch_in, nch_rs;    // K chunks: cond0, cond1, in-layer, res/skip
     int mb_in;                          // M-blocks of the in-layer GEMM
     std::vector<FlowDims> fd;
     // packed blob offsets (floats)
     size_t up_w, up_b, cond0_A, cond0_b, cond1_A, cond1_b;
     struct Flow {
-        size_t start_w, start_b, end_w, end_b, winv;
+        size_t start_w, start_b, end_w, end_b, winv, spk_tab;
         std::vector<size_t> in_A, in_b, rs_A, rs_b;
     };
     std::vector<Flow> fl;
@@ -59,10 +60,13 @@ int make_plan(const ctts_waveglow_config* cfg, Plan& p) {
     CTTS_CHECK_ARG((c.n_mel_channels * c.n_group) % GEMM_KC == 0, "n_mel*n_group=%d not a multiple of 16",
                    c.n_mel_channels * c.n_group);
     CTTS_CHECK_ARG(c.n_early_every >= 1 && c.n_early_size >= 0 && c.n_early_size % 2 == 0, "early outputs");
+    CTTS_CHECK_ARG(c.speaker_embed_dim >= 0 && c.speaker_embed_dim <= 1024, "speaker_embed_dim=%d", c.speaker_embed_dim);
     p.C = c.n_channels;
     p.H = c.cond_hidden;
     p.K0 = c.n_mel_channels * c.n_group;
-    p.nch0 = p.K0 / GEMM_KC;
+    p.S = round_up(c.speaker_embed_dim, 32);
+    CTTS_CHECK_ARG(p.S == 0 || p.K0 % 32 == 0, "multispeaker needs n_mel*n_group %% 32 == 0");
+    p.nch0 = (p.K0 + p.S) / GEMM_KC;
     p.nch1h = p.H / GEMM_KC;
     p.nch_in = (c.kernel_size * p.C + p.H) / GEMM_KC;
     p.nch_rs = p.C / GEMM_KC;
@@ -91,6 +95,7 @@ int make_plan(const ctts_waveglow_config* cfg, Plan& p) {
         f.end_w = take((size_t)2 * p.fd[k].n_half * p.C);
         f.end_b = take(2 * p.fd[k].n_half);
         f.winv = take((size_t)p.fd[k].n_rem * p.fd[k].n_rem);
+        f.spk_tab = take((size_t)CTTS_N_SPEAKERS * c.speaker_embed_dim);
         for (int i = 0; i < c.n_layers; ++i) {
             f.in_A.push_back(take((size_t)p.mb_in * p.nch_in * A_TILE));
             f.in_b.push_back(take((size_t)p.mb_in * GEMM_BM));
@@ -116,7 +121,7 @@ int make_geom(const Plan& p, int frames, Geom& g) {
 }
 
 struct Workspace {
-    float *audio, *spect, *h_tmp, *h_all, *x, *act, *out;
+    float *audio, *spect, *spk, *h_tmp, *h_all, *x, *act, *out;
     size_t total;  // floats
 };
 
@@ -126,6 +131,7 @@ void carve(const Plan& p, const Geom& g, int batch, float* base, Workspace& w) {
     const size_t B = batch;
     w.audio = take(B * p.c.n_group * g.L);
     w.spect = take(B * p.K0 * g.ld);
+    w.spk = take(B * p.c.n_flows * p.S * g.ld);          // speaker-embedding rows (glow.py:193-196), per flow
     w.h_tmp = take(B * p.c.n_flows * p.H * g.ld);
     w.h_all = take(B * p.c.n_flows * p.H * g.ld);
     w.x = take(B * p.C * g.ld);
@@ -166,13 +172,43 @@ GemmArgs base_args(const Geom& g, int batch) {
     return a;
 }
 
-int run_cond(const Plan& p, const Geom& g, const float* blob, const float* spect, float* h_tmp, float* h_all,
-             int batch, hipStream_t s) {
+// spk[b][k*S + e][pad + l] = table_k[ids[b]][e]  (e < sdim), zero rows above: the reference concatenates the speaker
+// embedding, repeated over time, under the spectrogram (glow.py:193-196); here it is the second K segment of cond layer 0
+__global__ __launch_bounds__(256) void speaker_rows_kernel(const float* __restrict__ table, const int64_t* __restrict__ ids,
+                                                           float* __restrict__ spk, int k, int n_flows, int S, int sdim,
+                                                           int L, int ld, int pad) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int e = blockIdx.y, b = blockIdx.z;
+    if (n >= ld) return;
+    float v = 0.f;
+    if (e < sdim && n >= pad && n < pad + L) v = table[(size_t)ids[b] * sdim + e];
+    spk[((size_t)b * n_flows * S + (size_t)k * S + e) * ld + n] = v;
+}
+
+int fill_speaker_rows(const Plan& p, const Geom& g, const float* blob, const int64_t* ids, float* spk, int batch,
+                      hipStream_t s) {
+    if (p.S == 0) return CTTS_OK;
+    CTTS_CHECK_ARG(ids != nullptr, "multispeaker model (speaker_embed_dim=%d) needs speaker ids (glow.py:193)",
+                   p.c.speaker_embed_dim);
+    for (int k = 0; k < p.c.n_flows; ++k)
+        hipLaunchKernelGGL(speaker_rows_kernel, dim3((g.ld + 255) / 256, p.S, batch), dim3(256), 0, s,
+                           blob + p.fl[k].spk_tab, ids, spk, k, p.c.n_flows, p.S, p.c.speaker_embed_dim, g.L, g.ld, g.pad);
+    CTTS_CHECK_LAUNCH("speaker_rows");
+    return CTTS_OK;
+}
+
+int run_cond(const Plan& p, const Geom& g, const float* blob, const float* spect, const float* spk, float* h_tmp,
+             float* h_all, int batch, hipStream_t s) {
     const long long hstride = (long long)p.c.n_flows * p.H * g.ld;
     GemmArgs a = base_args(g, batch);
     a.A = blob + p.cond0_A; a.bias = blob + p.cond0_b;
     a.nseg = 1; a.nch_total = p.nch0; a.MB = p.c.n_flows;
-    a.seg[0] = {spect, (long long)p.K0 * g.ld, p.nch0, 0, 0, 0};
+    a.seg[0] = {spect, (long long)p.K0 * g.ld, p.K0 / GEMM_KC, 0, 0, 0};
+    if (p.S) {   // flow k (= M-block k) reads its own S embedding rows
+        CTTS_CHECK_ARG(spk != nullptr, "wn_cond: multispeaker model needs the speaker rows");
+        a.nseg = 2;
+        a.seg[1] = {spk, (long long)p.c.n_flows * p.S * g.ld, p.S / GEMM_KC, 0, p.S, 0};
+    }
     a.dst0 = h_tmp; a.dst0_bstride = hstride; a.acc0 = 0;
     a.dst1 = h_tmp; a.dst1_bstride = hstride; a.acc1 = 0;
     a.split = p.c.n_flows * GEMM_BM;
@@ -254,7 +290,7 @@ void make_bf_plan(const Plan& p, BfPlan& q) {
     auto take = [&](size_t n) { size_t r = o; o = (o + n + 127) / 128 * 128; return r; };
     q.nch_in = (p.c.kernel_size * p.C + p.H) / BGEMM_KC;
     q.nch_rs = p.C / BGEMM_KC;
-    q.nch_c0 = p.K0 / BGEMM_KC;
+    q.nch_c0 = (p.K0 + p.S) / BGEMM_KC;
     q.nch_c1 = p.H / BGEMM_KC;
     q.cond0_A = take((size_t)p.c.n_flows * q.nch_c0 * BGEMM_KC * BGEMM_BM);
     q.cond1_A = take((size_t)p.c.n_flows * q.nch_c1 * BGEMM_KC * BGEMM_BM);
@@ -269,8 +305,8 @@ void make_bf_plan(const Plan& p, BfPlan& q) {
 }
 
 struct BfWs {
-    float *audio, *spect;
-    bf16_t *spect_bf, *h_tmp_bf, *h_bf, *x, *act, *out;
+    float *audio, *spect, *spk;
+    bf16_t *spect_bf, *spk_bf, *h_tmp_bf, *h_bf, *x, *act, *out;
     size_t total_bytes;
 };
 
@@ -281,6 +317,8 @@ void carve_bf(const Plan& p, const Geom& g, int batch, char* base, BfWs& w) {
     w.audio = (float*)take(B * p.c.n_group * g.L * 4);
     w.spect = (float*)take(B * p.K0 * g.ld * 4);
     w.spect_bf = (bf16_t*)take(B * p.K0 * g.ld * 2);
+    w.spk = (float*)take(B * p.c.n_flows * p.S * g.ld * 4);
+    w.spk_bf = (bf16_t*)take(B * p.c.n_flows * p.S * g.ld * 2);
     w.h_tmp_bf = (bf16_t*)take(B * p.c.n_flows * p.H * g.ld * 2);
     w.h_bf = (bf16_t*)take(B * p.c.n_flows * p.H * g.ld * 2);
     w.x = (bf16_t*)take(B * p.C * g.ld * 2);
@@ -507,8 +545,16 @@ int ctts_waveglow_pack_flow(const ctts_waveglow_config* cfg, int32_t k, const ct
     // cond layers 0/1: this flow is M-block k of the flow-batched GEMMs
     CTTS_CHECK_ARG(w->cond_w[0] && w->cond_w[1] && w->cond_w[2] && w->cond_b[0] && w->cond_b[1] && w->cond_b[2],
                    "pack_flow: NULL cond weights");
+    // cond layer 0 is [H][n_mel*G + speaker_embed_dim] (glow.py:155): spectrogram columns, then the embedding columns
+    // (K rows [K0 + sdim, K0 + S) stay zero from the blob's zero fill)
+    const int sdim = p.c.speaker_embed_dim;
     if ((rc = launch_pack_a(blob + p.cond0_A + (size_t)k * p.nch0 * A_TILE, w->cond_w[0], GEMM_BM, 1, p.nch0, 0, p.K0,
-                            GEMM_EPI_SPLIT, C, H, 0, p.K0, 1, s))) return rc;
+                            GEMM_EPI_SPLIT, C, H, 0, p.K0 + sdim, 1, s))) return rc;
+    if (sdim) {
+        if ((rc = launch_pack_a(blob + p.cond0_A + (size_t)k * p.nch0 * A_TILE, w->cond_w[0] + p.K0, GEMM_BM, 1, p.nch0,
+                                p.K0, sdim, GEMM_EPI_SPLIT, C, H, 0, p.K0 + sdim, 1, s))) return rc;
+        if ((rc = d2d(f.spk_tab, w->speaker_embed, (size_t)CTTS_N_SPEAKERS * sdim))) return rc;
+    }
     if ((rc = launch_pack_bias(blob + p.cond0_b + (size_t)k * GEMM_BM, GEMM_BM, 1, w->cond_b[0], 0, nullptr, 0,
                                GEMM_EPI_SPLIT, C, H, s))) return rc;
     if ((rc = launch_pack_a(blob + p.cond1_A + (size_t)k * p.nch1h * A_TILE, w->cond_w[1], GEMM_BM, 1, p.nch1h, 0, H,
@@ -553,13 +599,13 @@ int ctts_upsample_squeeze_f32(const ctts_waveglow_config* cfg, const void* packe
                                    p.c.win_length, p.c.hop_length, p.c.n_group, g.ld, g.pad, as_stream(stream));
 }
 
-int ctts_wn_cond_f32(const ctts_waveglow_config* cfg, const void* packed, const float* spect, float* h_tmp,
-                     float* h_all, int32_t batch, int32_t frames, void* stream) {
+int ctts_wn_cond_f32(const ctts_waveglow_config* cfg, const void* packed, const float* spect, const float* spk_rows,
+                     float* h_tmp, float* h_all, int32_t batch, int32_t frames, void* stream) {
     Plan p; Geom g;
     int rc = make_plan(cfg, p); if (rc) return rc;
     rc = make_geom(p, frames, g); if (rc) return rc;
     CTTS_CHECK_ARG(packed && spect && h_tmp && h_all && batch >= 1, "wn_cond: bad argument");
-    return run_cond(p, g, static_cast<const float*>(packed), spect, h_tmp, h_all, batch, as_stream(stream));
+    return run_cond(p, g, static_cast<const float*>(packed), spect, spk_rows, h_tmp, h_all, batch, as_stream(stream));
 }
 
 int ctts_wn_stack_f32(const ctts_waveglow_config* cfg, const void* packed, int32_t flow, const float* audio,
@@ -587,6 +633,13 @@ int ctts_flow_tail_f32(const ctts_waveglow_config* cfg, const void* packed, int3
 int ctts_waveglow_infer_f32(const ctts_waveglow_config* cfg, const void* packed, const float* mel,
                             const float* z_scaled, float* wave, int32_t batch, int32_t frames, void* workspace,
                             size_t workspace_bytes, void* stream) {
+    return ctts_waveglow_infer_spk_f32(cfg, packed, mel, z_scaled, nullptr, wave, batch, frames, workspace,
+                                       workspace_bytes, stream);
+}
+
+int ctts_waveglow_infer_spk_f32(const ctts_waveglow_config* cfg, const void* packed, const float* mel,
+                                const float* z_scaled, const int64_t* speaker_ids, float* wave, int32_t batch,
+                                int32_t frames, void* workspace, size_t workspace_bytes, void* stream) {
     Plan p; Geom g; Workspace w;
     int rc = make_plan(cfg, p); if (rc) return rc;
     rc = make_geom(p, frames, g); if (rc) return rc;
@@ -603,7 +656,9 @@ int ctts_waveglow_infer_f32(const ctts_waveglow_config* cfg, const void* packed,
     rc = launch_upsample_squeeze(mel, blob + p.up_w, blob + p.up_b, w.spect, batch, p.c.n_mel_channels, frames,
                                  p.c.win_length, p.c.hop_length, p.c.n_group, g.ld, g.pad, s);
     if (rc) return rc;
-    rc = run_cond(p, g, blob, w.spect, w.h_tmp, w.h_all, batch, s);
+    rc = fill_speaker_rows(p, g, blob, speaker_ids, w.spk, batch, s);
+    if (rc) return rc;
+    rc = run_cond(p, g, blob, w.spect, w.spk, w.h_tmp, w.h_all, batch, s);
     if (rc) return rc;
     for (int k = p.c.n_flows - 1; k >= 0; --k) {
         rc = run_wn_stack(p, g, blob, k, w.audio, w.h_all, w.x, w.act, w.out, batch, s);
@@ -656,8 +711,11 @@ int ctts_waveglow_pack_flow_bf16(const ctts_waveglow_config* cfg, int32_t k, con
     bf16_t* bb = static_cast<bf16_t*>(packed_bf16);
     const int C = p.C, H = p.H, ks = p.c.kernel_size;
     CTTS_CHECK_ARG(w->cond_w[0] && w->cond_w[1] && p.K0 % BGEMM_KC == 0, "pack_flow_bf16: cond weights / n_mel*n_group %% 32");
+    const int sdim = p.c.speaker_embed_dim;
     if ((rc = launch_pack_a_bf16(bb + q.cond0_A + (size_t)k * q.nch_c0 * BGEMM_KC * BGEMM_BM, w->cond_w[0], 1, q.nch_c0, 0,
-                                 p.K0, BGEMM_EPI_SPLIT, C, H, 0, p.K0, 1, s))) return rc;
+                                 p.K0, BGEMM_EPI_SPLIT, C, H, 0, p.K0 + sdim, 1, s))) return rc;
+    if (sdim && (rc = launch_pack_a_bf16(bb + q.cond0_A + (size_t)k * q.nch_c0 * BGEMM_KC * BGEMM_BM, w->cond_w[0] + p.K0, 1,
+                                         q.nch_c0, p.K0, sdim, BGEMM_EPI_SPLIT, C, H, 0, p.K0 + sdim, 1, s))) return rc;
     if ((rc = launch_pack_a_bf16(bb + q.cond1_A + (size_t)k * q.nch_c1 * BGEMM_KC * BGEMM_BM, w->cond_w[1], 1, q.nch_c1, 0,
                                  H, BGEMM_EPI_SPLIT, C, H, 0, H, 1, s))) return rc;
     for (int i = 0; i < p.c.n_layers; ++i) {
@@ -683,6 +741,13 @@ size_t ctts_waveglow_workspace_bf16_bytes(const ctts_waveglow_config* cfg, int32
 int ctts_waveglow_infer_bf16(const ctts_waveglow_config* cfg, const void* packed, const void* packed_bf16,
                              const float* mel, const float* z_scaled, float* wave, int32_t batch, int32_t frames,
                              void* workspace, size_t workspace_bytes, void* stream) {
+    return ctts_waveglow_infer_spk_bf16(cfg, packed, packed_bf16, mel, z_scaled, nullptr, wave, batch, frames, workspace,
+                                        workspace_bytes, stream);
+}
+
+int ctts_waveglow_infer_spk_bf16(const ctts_waveglow_config* cfg, const void* packed, const void* packed_bf16,
+                                 const float* mel, const float* z_scaled, const int64_t* speaker_ids, float* wave,
+                                 int32_t batch, int32_t frames, void* workspace, size_t workspace_bytes, void* stream) {
     Plan p; Geom g; BfWs w; BfPlan q;
     int rc = make_plan(cfg, p); if (rc) return rc;
     rc = make_geom(p, frames, g); if (rc) return rc;
@@ -707,13 +772,23 @@ int ctts_waveglow_infer_bf16(const ctts_waveglow_config* cfg, const void* packed
     hipLaunchKernelGGL(cvt_f32_to_k8_kernel, dim3((g.ld + 255) / 256, p.K0 / 8, batch), dim3(256), 0, s, w.spect,
                        w.spect_bf, p.K0, g.ld);
     CTTS_CHECK_LAUNCH("cvt_f32_to_k8");
+    if (p.S) {
+        if ((rc = fill_speaker_rows(p, g, blob, speaker_ids, w.spk, batch, s))) return rc;
+        hipLaunchKernelGGL(cvt_f32_to_k8_kernel, dim3((g.ld + 255) / 256, p.c.n_flows * p.S / 8, batch), dim3(256), 0, s,
+                           w.spk, w.spk_bf, p.c.n_flows * p.S, g.ld);
+        CTTS_CHECK_LAUNCH("cvt_f32_to_k8(speaker rows)");
+    }
     {
         const long long hstride = (long long)p.c.n_flows * p.H * g.ld;
         BGemmArgs a{};
         a.ld = g.ld; a.pad = g.pad; a.L = g.L; a.ntiles = g.ntiles; a.batch = batch;
         a.A = bblob + q.cond0_A; a.bias = blob + p.cond0_b;
         a.nseg = 1; a.nch_total = q.nch_c0; a.MB = p.c.n_flows; a.M = p.c.n_flows * BGEMM_BM;
-        a.seg[0] = {w.spect_bf, (long long)p.K0 * g.ld, q.nch_c0, 0, 0};
+        a.seg[0] = {w.spect_bf, (long long)p.K0 * g.ld, p.K0 / BGEMM_KC, 0, 0};
+        if (p.S) {
+            a.nseg = 2;
+            a.seg[1] = {w.spk_bf, (long long)p.c.n_flows * p.S * g.ld, p.S / BGEMM_KC, 0, p.S};
+        }
         a.dst0 = w.h_tmp_bf; a.dst0_bstride = hstride; a.acc0 = 0;
         a.dst1 = w.h_tmp_bf; a.dst1_bstride = hstride; a.acc1 = 0;
         a.split = a.M;

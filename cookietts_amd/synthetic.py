@@ -36,18 +36,19 @@ __all__ = [
 ]
 
 
-def _wn_config(n_channels, n_layers=8):
+def _wn_config(n_channels, n_layers=8, speaker_embed_dim=0, rezero=False):
     return dict(n_layers=n_layers, n_channels=n_channels, kernel_size=3,
-                speaker_embed_dim=0, rezero=False)
+                speaker_embed_dim=speaker_embed_dim, rezero=rezero)
 
 
 def waveglow_config(n_flows, n_channels, n_group=8, n_layers=8, n_early_every=4,
-                    n_early_size=2, n_mel_channels=80, win_length=1024, hop_length=256):
+                    n_early_size=2, n_mel_channels=80, win_length=1024, hop_length=256, upsample_mode='normal',
+                    speaker_embed_dim=0, rezero=False):
     """Constructor kwargs of the reference ``glow.WaveGlow`` (glow.py:226-227)."""
     return dict(yoyo=False, yoyo_WN=False, n_mel_channels=n_mel_channels, n_flows=n_flows,
                 n_group=n_group, n_early_every=n_early_every, n_early_size=n_early_size,
-                memory_efficient=False, spect_scaling=False, upsample_mode='normal',
-                WN_config=_wn_config(n_channels, n_layers),
+                memory_efficient=False, spect_scaling=False, upsample_mode=upsample_mode,
+                WN_config=_wn_config(n_channels, n_layers, speaker_embed_dim, rezero),
                 win_length=win_length, hop_length=hop_length)
 
 
@@ -57,6 +58,12 @@ WAVEGLOW_CONFIGS = {
     "toy_early": waveglow_config(n_flows=5, n_channels=128, n_layers=2, n_early_every=2),
     "small": waveglow_config(n_flows=4, n_channels=256),     # config 1
     "full": waveglow_config(n_flows=12, n_channels=512),     # configs 2/3
+    # glow.py options: multispeaker (WN speaker embeddings, glow.py:131-133) + ReZero (:127-128), grouped upsampling (:241)
+    "toy_spk_rezero": waveglow_config(n_flows=4, n_channels=128, n_layers=3, n_early_every=2, speaker_embed_dim=20,
+                                      rezero=True),
+    "toy_simple": waveglow_config(n_flows=2, n_channels=128, n_layers=2, n_early_every=4, upsample_mode='simple'),
+    "toy_simple_half": waveglow_config(n_flows=2, n_channels=128, n_layers=2, n_early_every=4,
+                                       upsample_mode='simple_half'),
 }
 
 
@@ -334,16 +341,24 @@ def waveglow_state_dict(cfg, seed=1234, end_std=None, cond_hidden=256):
         end_std = 0.25 / np.sqrt(C)
     sd = {}
     taps = win // hop
-    sd["upsample.weight"] = _uniform(rng, (n_mel, n_mel, win), 1.0 / np.sqrt(n_mel * taps))
+    mode = cfg.get("upsample_mode", "normal")
+    opg = {"normal": n_mel, "simple": 1, "simple_half": 2}[mode]       # ConvTranspose1d weight [in, out/groups, win]
+    sd["upsample.weight"] = _uniform(rng, (n_mel, opg, win), 1.0 / np.sqrt(opg * taps))
     sd["upsample.bias"] = _uniform(rng, (n_mel,), 0.1)
+    sdim = wn.get("speaker_embed_dim", 0)
     for k, (n_rem, n_half) in enumerate(waveglow_flow_channels(cfg)):
         p = f"WN.{k}"
+        if wn.get("rezero"):
+            for i in range(n_layers):                     # trained-looking values (the init is 0.1 +- 0.01, glow.py:182)
+                sd[f"{p}.alpha_i.{i}"] = np.array([0.35 + 0.1 * rng.random()], np.float32)
+        if sdim:
+            sd[p + ".speaker_embed.weight"] = rng.standard_normal((512, sdim), dtype=np.float32) * np.float32(4.0)
         _wn_conv(rng, sd, p + ".start", C, n_half, 1)
         sd[p + ".end.weight"] = (rng.standard_normal((2 * n_half, C, 1), dtype=np.float32)
                                  * np.float32(end_std))
         sd[p + ".end.bias"] = (rng.standard_normal((2 * n_half,), dtype=np.float32)
                                * np.float32(0.02))
-        _wn_conv(rng, sd, p + ".cond_layers.0", cond_hidden, n_mel * G, 1)
+        _wn_conv(rng, sd, p + ".cond_layers.0", cond_hidden, n_mel * G + sdim, 1)
         _wn_conv(rng, sd, p + ".cond_layers.1", cond_hidden, cond_hidden, 1)
         _wn_conv(rng, sd, p + ".cond_layers.2", 2 * C * n_layers, cond_hidden, 1)
         for i in range(n_layers):

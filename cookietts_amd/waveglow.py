@@ -83,20 +83,21 @@ class WN(nn.Module):
         super().__init__()
         assert kernel_size % 2 == 1
         assert n_channels % 2 == 0
-        if speaker_embed_dim:
-            raise NotImplementedError("speaker_embed_dim > 0 is not built on the HIP path yet")
-        if rezero:
-            raise NotImplementedError("rezero=True is not built on the HIP path yet")
         self.n_layers = n_layers
         self.n_channels = n_channels
         self.speaker_embed_dim = speaker_embed_dim
+        if rezero:                                                       # glow.py:127-128, 181-183
+            self.alpha_i = nn.ParameterList([nn.Parameter(torch.rand(1) * 0.02 + 0.09) for _ in range(n_layers)])
+        if speaker_embed_dim:                                            # glow.py:130-133
+            self.speaker_embed = nn.Embedding(_lib.N_SPEAKERS, speaker_embed_dim)
+            self.speaker_embed.weight.data.mul_(0.05)
         hidden = 256  # glow.py:153
         self.start = _WeightNormConv1d(n_in_channels, n_channels, 1)
         self.end = _Conv1dParams(n_channels, 2 * n_in_channels, 1)
         self.end.weight.data.zero_()
         self.end.bias.data.zero_()
         self.cond_layers = nn.ModuleList([
-            _WeightNormConv1d(n_mel_channels, hidden, 1),
+            _WeightNormConv1d(n_mel_channels + speaker_embed_dim, hidden, 1),
             _WeightNormConv1d(hidden, hidden, 1),
             _WeightNormConv1d(hidden, 2 * n_channels * n_layers, 1)])
         self.in_layers = nn.ModuleList()
@@ -111,8 +112,8 @@ class WaveGlow(nn.Module):
     def __init__(self, yoyo, yoyo_WN, n_mel_channels, n_flows, n_group, n_early_every, n_early_size,
                  memory_efficient, spect_scaling, upsample_mode, WN_config, win_length, hop_length):
         super().__init__()
-        if upsample_mode != 'normal':
-            raise NotImplementedError("only upsample_mode='normal' (groups=1) is built")
+        if upsample_mode not in ('normal', 'simple', 'simple_half'):
+            raise ValueError(f"upsample_mode = {upsample_mode} invalid")            # glow.py:241
         if memory_efficient:
             raise NotImplementedError("memory_efficient builds no layers in the reference (glow.py:263)")
         assert n_group % 2 == 0
@@ -127,11 +128,17 @@ class WaveGlow(nn.Module):
         self.hop_length = hop_length
         self.WN_config = dict(WN_config)
 
-        # nn.ConvTranspose1d(n_mel, n_mel, win, stride=hop): weight [in, out, win]
+        # nn.ConvTranspose1d(n_mel, n_mel, win, stride=hop, groups): weight [in, out/groups, win] (glow.py:238-241).
+        # 'simple' = one filter per mel channel; 'simple_half' = pairs of channels (the reference passes the float
+        # n_mel/2 as `groups`, which nn.ConvTranspose1d rejects under torch 2.x; the integer it stands for is used here)
+        self.upsample_mode = upsample_mode
+        self.upsample_groups = {'normal': 1, 'simple': n_mel_channels, 'simple_half': n_mel_channels // 2}[upsample_mode]
+        assert n_mel_channels % self.upsample_groups == 0
         self.upsample = nn.Module()
-        w = torch.empty(n_mel_channels, n_mel_channels, win_length)
+        opg = n_mel_channels // self.upsample_groups
+        w = torch.empty(n_mel_channels, opg, win_length)
         nn.init.kaiming_uniform_(w, a=math.sqrt(5))
-        bound = 1.0 / math.sqrt(n_mel_channels * win_length)
+        bound = 1.0 / math.sqrt(opg * win_length)
         self.upsample.weight = nn.Parameter(w)
         self.upsample.bias = nn.Parameter(torch.empty(n_mel_channels).uniform_(-bound, bound))
 
@@ -159,7 +166,8 @@ class WaveGlow(nn.Module):
             n_mel_channels=self.n_mel_channels, n_group=self.n_group, n_flows=self.n_flows,
             n_early_every=self.n_early_every, n_early_size=self.n_early_size,
             win_length=self.win_length, hop_length=self.hop_length, n_layers=wn['n_layers'],
-            n_channels=wn['n_channels'], kernel_size=wn['kernel_size'], cond_hidden=256)
+            n_channels=wn['n_channels'], kernel_size=wn['kernel_size'], cond_hidden=256,
+            speaker_embed_dim=wn.get('speaker_embed_dim', 0))
 
     def _invalidate(self):
         self._packed = None
@@ -217,6 +225,17 @@ class WaveGlow(nn.Module):
         keep.append(w)
         return w
 
+    @staticmethod
+    def _scaled(t, alpha, stream, keep):
+        """alpha * t on the device (alpha: 1-element parameter, read by the kernel), through ctts_scale_add_rows_f32."""
+        a = alpha.detach().float().contiguous()
+        y = torch.empty_like(t)
+        rows, cols = (t.shape[0], t[0].numel()) if t.dim() > 1 else (1, t.numel())
+        _lib.check(_lib.lib().ctts_scale_add_rows_f32(_lib.ptr(t), _lib.ptr(a), None, _lib.ptr(y), 1, rows, cols, cols, 0,
+                                                      stream), "ctts_scale_add_rows_f32")
+        keep += [a, y, t]
+        return y
+
     def _ensure_packed(self, device):
         key = _cache.param_key(self)
         if self._packed is not None and self._packed[0] == device and self._packed[3] == key:
@@ -245,6 +264,15 @@ class WaveGlow(nn.Module):
                 bblob = torch.zeros(nb // 2, dtype=torch.int16, device=device)
             keep = []
             up_w = self.upsample.weight.detach().float().contiguous()
+            if self.upsample_groups > 1:
+                # grouped transposed conv = the dense one with zeros outside each group's block: input channel i feeds
+                # outputs [g*opg, (g+1)*opg) of its group g = i // (n_mel / groups); x * 0 adds exactly 0
+                n_mel, opg = self.n_mel_channels, self.n_mel_channels // self.upsample_groups
+                ipg = n_mel // self.upsample_groups
+                dense = torch.zeros(n_mel, n_mel, self.win_length, dtype=torch.float32, device=device)
+                for gi in range(self.upsample_groups):
+                    dense[gi * ipg:(gi + 1) * ipg, gi * opg:(gi + 1) * opg] = up_w[gi * ipg:(gi + 1) * ipg]
+                up_w = dense
             up_b = self.upsample.bias.detach().float().contiguous()
             keep += [up_w, up_b]
             _lib.check(lib.ctts_waveglow_pack_upsample(C.byref(cfg), _lib.ptr(up_w), _lib.ptr(up_b),
@@ -269,8 +297,13 @@ class WaveGlow(nn.Module):
                     wa = (C.c_void_p * n_layers)()
                     ba = (C.c_void_p * n_layers)()
                     for i in range(n_layers):
-                        wa[i] = self._dense_weight(layers[i], stream, keep).data_ptr()
-                        ba[i] = dev(layers[i].bias)
+                        wt = self._dense_weight(layers[i], stream, keep)
+                        bt = layers[i].bias.detach().float().contiguous()
+                        if name == "rs" and hasattr(wn, 'alpha_i'):
+                            # ReZero (glow.py:211-212): res_skip(acts) * alpha_i == (alpha*W) acts + alpha*b, folded once
+                            wt, bt = self._scaled(wt, wn.alpha_i[i], stream, keep), self._scaled(bt, wn.alpha_i[i], stream, keep)
+                        keep.append(bt)
+                        wa[i], ba[i] = wt.data_ptr(), bt.data_ptr()
                     arrs[name] = (wa, ba)
                 fw.in_w, fw.in_b = arrs["in"]
                 fw.rs_w, fw.rs_b = arrs["rs"]
@@ -282,6 +315,8 @@ class WaveGlow(nn.Module):
                 self.convinv[k].W_inverse = W_inverse[..., None]
                 keep.append(W_inverse)
                 fw.w_inverse = W_inverse.data_ptr()
+                if wn.speaker_embed_dim:
+                    fw.speaker_embed = dev(wn.speaker_embed.weight)
                 _lib.check(lib.ctts_waveglow_pack_flow(C.byref(cfg), k, C.byref(fw), _lib.ptr(blob), stream),
                            f"ctts_waveglow_pack_flow({k})")
                 if bblob is not None:
@@ -310,7 +345,7 @@ class WaveGlow(nn.Module):
         return frames * self.hop_length // self.n_group
 
     # --------------------------------------------------------------------- the path ----
-    def infer_from_noise(self, spect, z_scaled):
+    def infer_from_noise(self, spect, z_scaled, speaker_id=None):
         """Deterministic entry: ``z_scaled`` [B, n_group, L] already multiplied by sigma.
 
         Rows: the last ``n_remaining_channels`` are the initial latent (glow.py:326), the
@@ -329,30 +364,36 @@ class WaveGlow(nn.Module):
         assert tuple(z_scaled.shape) == (B, self.n_group, L), (tuple(z_scaled.shape), (B, self.n_group, L))
         mel = spect.detach().float().contiguous()
         z = z_scaled.detach().to(device=device, dtype=torch.float32).contiguous()
+        ids = None
+        if self.multispeaker:
+            if speaker_id is None:      # the reference would feed cond_layers[0] too few channels and crash (glow.py:193-198)
+                raise RuntimeError("this WaveGlow is multispeaker (speaker_embed_dim > 0): pass speaker_id")
+            ids = speaker_id.detach().to(device=device, dtype=torch.int64).reshape(-1).contiguous()
+            assert ids.shape[0] == B, (tuple(ids.shape), B)
+            if int(ids.min()) < 0 or int(ids.max()) >= _lib.N_SPEAKERS:
+                raise IndexError("speaker id out of range of the embedding table")
         ws = self._workspace(device, B, F, bf16=bblob is not None)
         wave = torch.empty(B, L * self.n_group, dtype=torch.float32, device=device)
         cfg = self.c_config()
         with torch.cuda.device(device):
             stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
             if bblob is not None:
-                _lib.check(lib.ctts_waveglow_infer_bf16(C.byref(cfg), _lib.ptr(blob), _lib.ptr(bblob), _lib.ptr(mel),
-                                                       _lib.ptr(z), _lib.ptr(wave), B, F, _lib.ptr(ws), ws.numel() * 4,
-                                                       stream), "ctts_waveglow_infer_bf16")
+                _lib.check(lib.ctts_waveglow_infer_spk_bf16(C.byref(cfg), _lib.ptr(blob), _lib.ptr(bblob), _lib.ptr(mel),
+                                                           _lib.ptr(z), _lib.ptr(ids), _lib.ptr(wave), B, F, _lib.ptr(ws),
+                                                           ws.numel() * 4, stream), "ctts_waveglow_infer_spk_bf16")
             else:
-                _lib.check(lib.ctts_waveglow_infer_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(mel), _lib.ptr(z),
-                                                      _lib.ptr(wave), B, F, _lib.ptr(ws), ws.numel() * 4, stream),
-                           "ctts_waveglow_infer_f32")
+                _lib.check(lib.ctts_waveglow_infer_spk_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(mel), _lib.ptr(z),
+                                                          _lib.ptr(ids), _lib.ptr(wave), B, F, _lib.ptr(ws),
+                                                          ws.numel() * 4, stream), "ctts_waveglow_infer_spk_f32")
         return wave.to(spect.dtype)
 
     def infer(self, spect, speaker_id=None, sigma=1.0):
         """``glow.WaveGlow.infer``: spect [B, n_mel, F] -> audio [B, F*hop] on spect's device."""
-        if self.multispeaker and speaker_id is not None:
-            raise NotImplementedError("multispeaker WaveGlow is not built on the HIP path yet")
         if spect.dim() == 2:
             spect = spect.unsqueeze(0)
         B, _, F = spect.shape
         z = torch.randn(B, self.n_group, self.steps_for(F), device=spect.device, dtype=torch.float32)
-        return self.infer_from_noise(spect, z * sigma)
+        return self.infer_from_noise(spect, z * sigma, speaker_id=speaker_id)
 
     def forward(self, spect, audio=None, speaker_id=None):
         raise NotImplementedError("training direction (glow.py:267-312) is outside the inference hot path")

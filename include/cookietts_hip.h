@@ -38,7 +38,8 @@ extern "C" {
 #define CTTS_E_LAUNCH (-2)    /* HIP launch or runtime error */
 #define CTTS_E_WORKSPACE (-3) /* workspace too small */
 
-#define CTTS_ABI_VERSION 1
+#define CTTS_ABI_VERSION 2   /* 2: ctts_waveglow_config.speaker_embed_dim, ctts_waveglow_flow_weights.speaker_embed */
+#define CTTS_N_SPEAKERS 512  /* rows of every speaker-embedding table (glow.py:129, efficient_model_ax.py:60) */
 
 int ctts_abi_version(void);
 const char* ctts_last_error(void);
@@ -57,6 +58,7 @@ typedef struct ctts_waveglow_config {
     int32_t n_channels;     /* 512 WN channels (multiple of 128) */
     int32_t kernel_size;    /* 3 */
     int32_t cond_hidden;    /* 256, hard-coded at glow.py:153 */
+    int32_t speaker_embed_dim; /* WN_config['speaker_embed_dim'] (glow.py:116,129-133): 0 = single speaker */
 } ctts_waveglow_config;
 
 typedef struct ctts_waveglow_geometry {
@@ -90,6 +92,8 @@ typedef struct ctts_waveglow_flow_weights {
     const float* end_w;        /* [2*n_half][C]            WN.k.end */
     const float* end_b;        /* [2*n_half] */
     const float* w_inverse;    /* [c][c] fp32 inverse of convinv.k.conv.weight (glow.py:90-99) */
+    const float* speaker_embed;/* [CTTS_N_SPEAKERS][speaker_embed_dim]  WN.k.speaker_embed.weight (glow.py:130-133);
+                                  NULL when speaker_embed_dim == 0.  cond_w[0] is then [H][n_mel*G + speaker_embed_dim] */
 } ctts_waveglow_flow_weights;
 
 /* Bytes of the packed weight blob (device) for this config. */
@@ -118,6 +122,13 @@ int ctts_waveglow_infer_f32(const ctts_waveglow_config* cfg, const void* packed,
                             const float* mel, const float* z_scaled, float* wave,
                             int32_t batch, int32_t frames, void* workspace,
                             size_t workspace_bytes, void* stream);
+/* Multispeaker form (WN_config['speaker_embed_dim'] > 0, glow.py:131-133, 193-196): speaker_ids [B] int64 on the
+ * device, each in [0, CTTS_N_SPEAKERS).  Every flow's embedding row is appended under the squeezed spectrogram as extra
+ * K rows of that flow's cond layer 0.  speaker_ids == NULL is an error for a multispeaker config and ignored otherwise
+ * (ctts_waveglow_infer_f32 is this call with NULL). */
+int ctts_waveglow_infer_spk_f32(const ctts_waveglow_config* cfg, const void* packed, const float* mel,
+                                const float* z_scaled, const int64_t* speaker_ids, float* wave, int32_t batch,
+                                int32_t frames, void* workspace, size_t workspace_bytes, void* stream);
 
 /* bf16 variant (BASELINE config 3): the WN in-layer and res/skip contractions run on bf16 MFMA with
  * fp32 accumulation and the WN activations (residual stream, gated activations, skip sum, conditioning
@@ -133,6 +144,10 @@ int ctts_waveglow_infer_bf16(const ctts_waveglow_config* cfg, const void* packed
                              const void* packed_bf16, const float* mel, const float* z_scaled,
                              float* wave, int32_t batch, int32_t frames, void* workspace,
                              size_t workspace_bytes, void* stream);
+int ctts_waveglow_infer_spk_bf16(const ctts_waveglow_config* cfg, const void* packed, const void* packed_bf16,
+                                 const float* mel, const float* z_scaled, const int64_t* speaker_ids, float* wave,
+                                 int32_t batch, int32_t frames, void* workspace, size_t workspace_bytes,
+                                 void* stream);
 
 /* Stage entry points (same kernels, exposed for parity tests and profiling). */
 
@@ -145,7 +160,8 @@ int ctts_upsample_squeeze_f32(const ctts_waveglow_config* cfg, const void* packe
  * [ch_off, ch_off+n_half) of audio [B][n_group][L] dense and h_all (cond hidden for all
  * flows, from ctts_wn_cond_f32); leaves the skip sum in `out` (padded [B][C][ld]). */
 int ctts_wn_cond_f32(const ctts_waveglow_config* cfg, const void* packed, const float* spect,
-                     float* h_tmp, float* h_all, int32_t batch, int32_t frames, void* stream);
+                     const float* spk_rows, float* h_tmp, float* h_all, int32_t batch, int32_t frames,
+                     void* stream);   /* spk_rows [B][n_flows*S][ld] (S = speaker_embed_dim rounded up to 32) or NULL */
 int ctts_wn_stack_f32(const ctts_waveglow_config* cfg, const void* packed, int32_t flow,
                       const float* audio, const float* h_all, float* x, float* act, float* out,
                       int32_t batch, int32_t frames, void* stream);

@@ -14,8 +14,10 @@ checks this file against them.
 
 Reference lines each function follows (paths relative to /root/reference/CookieTTS):
   fold_weightnorm   torch ``nn.utils.weight_norm`` as applied at _4_mtw/waveglow/glow.py:135-186
-  upsample_squeeze  glow.py:318-324 (ConvTranspose1d, trim ``win-hop``, unfold to groups)
-  wn_forward        glow.py:188-222 (+ fused gate glow.py:34-41)
+  upsample_squeeze  glow.py:318-324 (ConvTranspose1d, trim ``win-hop``, unfold to groups); grouped weights for
+                    upsample_mode 'simple' / 'simple_half' (glow.py:238-241: groups = n_mel / n_mel/2)
+  wn_forward        glow.py:188-222 (+ fused gate glow.py:34-41); speaker-embedding concat :193-196; ReZero
+                    ``res_skip(acts) * alpha_i`` :211-212
   waveglow_infer    glow.py:314-350 (coupling inverse :337-338, inverse 1x1 conv :85-99,
                     early-output re-injection :342-347, un-squeeze :349)
 """
@@ -80,23 +82,37 @@ def upsample_squeeze(mel, w_up, b_up, hop, n_group):
     win = w_up.shape[2]
     taps = win // hop
     assert taps * hop == win
-    y = np.zeros((B, w_up.shape[1], F + taps - 1, hop), dtype=F32)
-    xt = np.ascontiguousarray(mel.transpose(0, 2, 1))           # [B, F, I]
-    for j in range(taps):
-        wj = w_up[:, :, j * hop:(j + 1) * hop].reshape(M, -1)   # [I, O*hop]
-        contrib = np.matmul(xt, wj).reshape(B, F, w_up.shape[1], hop)
-        y[:, :, j:j + F, :] += contrib.transpose(0, 2, 1, 3)
-    y = y[:, :, :F, :].reshape(B, w_up.shape[1], F * hop) + b_up[None, :, None]
+    opg = w_up.shape[1]                                         # output channels per group (ConvTranspose1d weight
+    n_out = b_up.shape[0]                                       # is [in, out/groups, win])
+    groups = n_out // opg
+    ipg = M // groups
+    y = np.zeros((B, n_out, F + taps - 1, hop), dtype=F32)
+    for gi in range(groups):
+        xt = np.ascontiguousarray(mel[:, gi * ipg:(gi + 1) * ipg].transpose(0, 2, 1))     # [B, F, ipg]
+        wg = w_up[gi * ipg:(gi + 1) * ipg]
+        for j in range(taps):
+            wj = wg[:, :, j * hop:(j + 1) * hop].reshape(ipg, -1)                         # [ipg, opg*hop]
+            contrib = np.matmul(xt, wj).reshape(B, F, opg, hop)
+            y[:, gi * opg:(gi + 1) * opg, j:j + F, :] += contrib.transpose(0, 2, 1, 3)
+    y = y[:, :, :F, :].reshape(B, n_out, F * hop) + b_up[None, :, None]
     L = F * hop // n_group
     y = y.reshape(B, y.shape[1], L, n_group)                    # [B, O, L, G]
     return np.ascontiguousarray(y.transpose(0, 1, 3, 2)).reshape(B, -1, L)
 
 
-def wn_forward(sd, prefix, audio0, spect, n_layers, n_channels, trace=None):
+def _with_speaker(sd, prefix, spect, speaker_ids):
+    """glow.py:193-196: the flow's speaker embedding, repeated over time, concatenated under the spectrogram."""
+    if speaker_ids is None or prefix + ".speaker_embed.weight" not in sd:
+        return spect
+    emb = np.asarray(sd[prefix + ".speaker_embed.weight"], dtype=F32)[np.asarray(speaker_ids)]
+    return np.concatenate([spect, np.repeat(emb[:, :, None], spect.shape[2], axis=2)], axis=1)
+
+
+def wn_forward(sd, prefix, audio0, spect, n_layers, n_channels, trace=None, speaker_ids=None):
     """One WN stack: returns (b, log_s), each [B, n_half, L]."""
     C = n_channels
     x = _conv1x1(_conv_weight(sd, prefix + ".start"), sd[prefix + ".start.bias"], audio0)
-    c = spect
+    c = _with_speaker(sd, prefix, spect, speaker_ids)
     j = 0
     while f"{prefix}.cond_layers.{j}.bias" in sd:               # no nonlinearity between layers
         c = _conv1x1(_conv_weight(sd, f"{prefix}.cond_layers.{j}"),
@@ -114,6 +130,8 @@ def wn_forward(sd, prefix, audio0, spect, n_layers, n_channels, trace=None):
         act = np.tanh(u[:, :C]) * (F32(1.0) / (F32(1.0) + np.exp(-u[:, C:])))
         r = _conv1x1(_conv_weight(sd, f"{prefix}.res_skip_layers.{i}"),
                      sd[f"{prefix}.res_skip_layers.{i}.bias"], act.astype(F32))
+        if f"{prefix}.alpha_i.{i}" in sd:                        # ReZero (glow.py:211-212)
+            r = (r * sd[f"{prefix}.alpha_i.{i}"][0]).astype(F32)
         if i < n_layers - 1:
             x = x + r[:, :C]
             out = out + r[:, C:]
@@ -133,14 +151,14 @@ def bf16_round(x):
     return r.view(F32)
 
 
-def wn_forward_bf16(sd, prefix, audio0, spect, n_layers, n_channels):
+def wn_forward_bf16(sd, prefix, audio0, spect, n_layers, n_channels, speaker_ids=None):
     """bf16-rounded restatement of one WN stack, mirroring the rounding points of the bf16 HIP variant
     (BASELINE config 3): in-layer / cond-layer-2 / res-skip weights and the tensors x, h, act, skip-sum are
     rounded to bf16 where the kernels store them (incl. the squeezed spectrogram and cond layers 0-1); all sums
     are fp32; upsampling, start and end are fp32."""
     C = n_channels
     x = bf16_round(_conv1x1(_conv_weight(sd, prefix + ".start"), sd[prefix + ".start.bias"], audio0))
-    h = bf16_round(spect)
+    h = bf16_round(_with_speaker(sd, prefix, spect, speaker_ids))
     for j in range(2):
         h = bf16_round(_conv1x1(bf16_round(_conv_weight(sd, f"{prefix}.cond_layers.{j}")),
                                 sd[f"{prefix}.cond_layers.{j}.bias"], h))
@@ -157,8 +175,11 @@ def wn_forward_bf16(sd, prefix, audio0, spect, n_layers, n_channels):
             u = u + np.matmul(np.ascontiguousarray(w[:, :, t]), _shift(x, (t - ks // 2) * d))
         u = (u + bias[None, :, None]).astype(F32)
         act = bf16_round(np.tanh(u[:, :C]) * (F32(1.0) / (F32(1.0) + np.exp(-u[:, C:]))))
-        wrs = bf16_round(_conv_weight(sd, f"{prefix}.res_skip_layers.{i}"))
-        r = _conv1x1(wrs, sd[f"{prefix}.res_skip_layers.{i}.bias"], act).astype(F32)
+        wrs = _conv_weight(sd, f"{prefix}.res_skip_layers.{i}")
+        brs = sd[f"{prefix}.res_skip_layers.{i}.bias"]
+        if f"{prefix}.alpha_i.{i}" in sd:                        # the kernels fold alpha into weight and bias at pack time
+            wrs, brs = (wrs * sd[f"{prefix}.alpha_i.{i}"][0]).astype(F32), (brs * sd[f"{prefix}.alpha_i.{i}"][0]).astype(F32)
+        r = _conv1x1(bf16_round(wrs), brs, act).astype(F32)
         if i < n_layers - 1:
             x = bf16_round(x + r[:, :C])
             out = bf16_round(r[:, C:]) if out is None else bf16_round(out + r[:, C:])
@@ -169,7 +190,7 @@ def wn_forward_bf16(sd, prefix, audio0, spect, n_layers, n_channels):
     return e[:, :hh], e[:, hh:]
 
 
-def waveglow_infer(sd, cfg, mel, z_scaled, flow_trace=None, bf16=False):
+def waveglow_infer(sd, cfg, mel, z_scaled, flow_trace=None, bf16=False, speaker_ids=None):
     """mel [B, n_mel, F], z_scaled [B, n_group, L] (sigma already applied) -> wave [B, F*hop].
 
     ``z_scaled`` rows: the last ``n_remaining_channels`` are the initial latent; the
@@ -191,7 +212,7 @@ def waveglow_infer(sd, cfg, mel, z_scaled, flow_trace=None, bf16=False):
         h = audio.shape[1] // 2
         a0, a1 = audio[:, :h], audio[:, h:]
         fwd = wn_forward_bf16 if bf16 else wn_forward
-        b, s = fwd(sd, f"WN.{k}", a0, spect, wn["n_layers"], wn["n_channels"])
+        b, s = fwd(sd, f"WN.{k}", a0, spect, wn["n_layers"], wn["n_channels"], speaker_ids=speaker_ids)
         a1 = ((a1 - b) / np.exp(s)).astype(F32)
         audio = np.concatenate([a0, a1], axis=1)
         w = sd[f"convinv.{k}.conv.weight"][:, :, 0]

@@ -40,7 +40,7 @@ def _ref_waveglow(cfg, sd_np):
     return model.eval()
 
 
-def _run_ref_infer(model, cfg, mel, sigma, torch_seed):
+def _run_ref_infer(model, cfg, mel, sigma, torch_seed, speaker_id=None):
     """Run the reference's own ``infer`` and return (wave, z_scaled[B,G,L]) with the noise it drew."""
     B, _, F = mel.shape
     G = cfg["n_group"]
@@ -65,14 +65,14 @@ def _run_ref_infer(model, cfg, mel, sigma, torch_seed):
     try:
         torch.manual_seed(torch_seed)
         with torch.no_grad():
-            wave = model.infer(torch.from_numpy(mel.copy()), sigma=sigma)
+            wave = model.infer(torch.from_numpy(mel.copy()), speaker_id=speaker_id, sigma=sigma)
     finally:
         if saved is not None:
             torch.cuda.FloatTensor = saved
     return wave.numpy().astype(np.float32), z
 
 
-def make_waveglow(full_length=False):
+def make_waveglow(full_length=False, options=False):
     torch.set_num_threads(8)
     cases = [
         # name, config key, batch, frames, sigma, seed
@@ -81,6 +81,9 @@ def make_waveglow(full_length=False):
         ("small", "small", 1, 200, 0.6, 1234),              # BASELINE config 1, end to end
         ("full_short", "full", 1, 16, 0.6, 1234),           # BASELINE config 2 topology, short mel
     ]
+    if options:
+        # glow.py options: WN speaker embeddings + ReZero (glow.py:127-133, 193-196, 211-212), grouped upsampling (:241)
+        cases = [("toy_spk_rezero", "toy_spk_rezero", 3, 10, 0.8, 31), ("toy_simple", "toy_simple", 2, 7, 1.0, 32)]
     if full_length:
         # BASELINE config 2 at the metric's utterance length: one 80x900 mel through the 12x512 model
         # (~70 s of CPU here).  Only the reference's waveform and the noise it drew are stored.
@@ -90,9 +93,11 @@ def make_waveglow(full_length=False):
         sd = synthetic.waveglow_state_dict(cfg, seed=seed)
         model = _ref_waveglow(cfg, sd)
         mel = synthetic.synthetic_mel(B, F, cfg["n_mel_channels"], seed=seed)
-        wave, z = _run_ref_infer(model, cfg, mel, sigma, torch_seed=seed)
+        ids = np.array([7, 300, 511, 0][:B], np.int64) if cfg["WN_config"]["speaker_embed_dim"] else None
+        wave, z = _run_ref_infer(model, cfg, mel, sigma, torch_seed=seed,
+                                 speaker_id=None if ids is None else torch.from_numpy(ids))
         assert wave.shape == (B, F * cfg["hop_length"]) and np.isfinite(wave).all()
-        extras = {}
+        extras = {} if ids is None else {"speaker_ids": ids}
         if name in ("toy", "small"):
             # per-stage intermediates from the reference's own sub-modules (flow n_flows-1)
             with torch.no_grad():
@@ -449,6 +454,8 @@ if __name__ == "__main__":
         make_waveglow()
     if "stft" in which:
         make_stft()
+    if "waveglow_options" in which or not sys.argv[1:]:
+        make_waveglow(options=True)
     if "waveglow_ax" in which:
         make_waveglow_ax()
     if "waveglow_ax_notebook" in which:    # on request only: 272 M parameters

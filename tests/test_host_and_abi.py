@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(hip_lib_path):
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in include/cookietts_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == declared, "ctypes signature table out of sync with the header"
-    assert handle.ctts_abi_version() == 1
+    assert handle.ctts_abi_version() == 2
 
 
 def test_host_side_queries_run_without_gpu(hip_lib_path):
@@ -47,7 +47,7 @@ def test_host_side_queries_run_without_gpu(hip_lib_path):
     assert lib.ctts_waveglow_geometry_for(ctypes.byref(bad), 10, ctypes.byref(geo)) == -1
 
 
-@pytest.mark.parametrize("key", ["toy", "toy_early", "small"])
+@pytest.mark.parametrize("key", ["toy", "toy_early", "small", "toy_spk_rezero", "toy_simple"])
 def test_state_dict_keys_and_shapes_match_reference_format(key):
     cfg = synthetic.WAVEGLOW_CONFIGS[key]
     sd = synthetic.waveglow_state_dict(cfg, seed=1)
@@ -59,7 +59,7 @@ def test_state_dict_keys_and_shapes_match_reference_format(key):
     m.load_state_dict(synthetic.to_torch(sd))
     assert torch.equal(m.WN[0].start.weight_v, torch.from_numpy(sd["WN.0.start.weight_v"]))
     assert m.n_remaining_channels == synthetic.waveglow_flow_channels(cfg)[-1][0]
-    assert m.multispeaker is False
+    assert m.multispeaker is (cfg["WN_config"]["speaker_embed_dim"] > 0)
 
 
 def test_default_init_matches_reference_conventions():
@@ -73,11 +73,24 @@ def test_default_init_matches_reference_conventions():
 
 def test_unsupported_options_fail_loudly():
     cfg = dict(synthetic.WAVEGLOW_CONFIGS["toy"])
+    with pytest.raises(ValueError):
+        WaveGlow(**dict(cfg, upsample_mode="bilinear"))                   # glow.py:241 prints "invalid" and crashes
     with pytest.raises(NotImplementedError):
-        WaveGlow(**dict(cfg, upsample_mode="simple"))
-    wn = dict(cfg["WN_config"], speaker_embed_dim=16)
+        WaveGlow(**dict(cfg, memory_efficient=True))                      # the reference builds no layers (glow.py:263)
+    m = WaveGlow(**dict(cfg, spect_scaling=True))
     with pytest.raises(NotImplementedError):
-        WaveGlow(**dict(cfg, WN_config=wn))
+        m.infer_from_noise(torch.zeros(1, 80, 4), torch.zeros(1, 8, 128))  # parameters never created (glow.py:233-235)
+
+
+def test_option_parameter_trees():
+    """glow.py:127-133, 181-183, 238-241: ReZero scalars, per-flow speaker tables, grouped upsampling weights."""
+    m = WaveGlow(**synthetic.WAVEGLOW_CONFIGS["toy_spk_rezero"])
+    assert len(m.WN[0].alpha_i) == 3 and 0.09 <= float(m.WN[0].alpha_i[0]) <= 0.11
+    assert tuple(m.WN[1].speaker_embed.weight.shape) == (512, 20)
+    assert tuple(m.WN[0].cond_layers[0].weight_v.shape) == (256, 640 + 20, 1)
+    assert m.c_config().speaker_embed_dim == 20
+    assert tuple(WaveGlow(**synthetic.WAVEGLOW_CONFIGS["toy_simple"]).upsample.weight.shape) == (80, 1, 1024)
+    assert tuple(WaveGlow(**synthetic.WAVEGLOW_CONFIGS["toy_simple_half"]).upsample.weight.shape) == (80, 2, 1024)
 
 
 def test_synthetic_recipe_is_deterministic():

@@ -27,6 +27,34 @@ def test_waveglow_oracle_matches_reference(name):
     assert rms_rel_err(wave, g["wave"]) < ORACLE_TOL
 
 
+@pytest.mark.parametrize("name", ["toy_spk_rezero", "toy_simple"])
+def test_waveglow_oracle_options_match_reference(name):
+    """glow.py options: WN speaker embeddings + ReZero (glow.py:127-133, 193-196, 211-212); upsample_mode='simple'."""
+    g, cfg, sd = _load(name)
+    ids = g["speaker_ids"] if "speaker_ids" in g.files else None
+    wave = wo.waveglow_infer(sd, cfg, g["mel"], g["z_scaled"], speaker_ids=ids)
+    assert rms_rel_err(wave, g["wave"]) < ORACLE_TOL
+    if ids is not None:      # the golden discriminates: other speakers / no ReZero give a different waveform
+        assert rms_rel_err(wo.waveglow_infer(sd, cfg, g["mel"], g["z_scaled"], speaker_ids=ids[::-1].copy()), g["wave"]) > 5e-3
+        plain = {k: v for k, v in sd.items() if "alpha_i" not in k}
+        assert rms_rel_err(wo.waveglow_infer(plain, cfg, g["mel"], g["z_scaled"], speaker_ids=ids), g["wave"]) > 5e-2
+
+
+def test_simple_half_upsampling_matches_torch_grouped_transposed_conv():
+    """upsample_mode='simple_half' cannot be built by the reference under torch 2.x (it passes the float n_mel/2 as
+    `groups`, glow.py:241); the oracle's grouped restatement is pinned to torch's own op with groups = n_mel // 2."""
+    import torch
+    cfg = synthetic.WAVEGLOW_CONFIGS["toy_simple_half"]
+    sd = synthetic.waveglow_state_dict(cfg, seed=5)
+    assert sd["upsample.weight"].shape == (80, 2, 1024)
+    mel = synthetic.synthetic_mel(2, 6, seed=5)
+    ref = torch.nn.functional.conv_transpose1d(torch.from_numpy(mel), torch.from_numpy(sd["upsample.weight"]),
+                                               torch.from_numpy(sd["upsample.bias"]), stride=256, groups=40)[:, :, :6 * 256]
+    ref = ref.reshape(2, 80, -1, 8).permute(0, 1, 3, 2).reshape(2, 640, -1).numpy()
+    got = wo.upsample_squeeze(mel, sd["upsample.weight"], sd["upsample.bias"], 256, 8)
+    assert np.abs(got - ref).max() < 1e-6
+
+
 @pytest.mark.parametrize("name", ["toy", "small"])
 def test_stage_intermediates(name):
     g, cfg, sd = _load(name)

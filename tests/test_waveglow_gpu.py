@@ -230,3 +230,44 @@ def test_packed_weights_follow_parent_load_state_dict_and_in_place_updates(hip_l
     out_c = inner.infer_from_noise(tm, tz).cpu().numpy()
     assert rms_rel_err(out_c, wo.waveglow_infer(sd_c, cfg, mel, z)) < WAVE_TOL
     assert rms_rel_err(out_c, ref_b) > 1e-2                                   # and it really changed the output
+
+
+@pytest.mark.parametrize("name", ["toy_spk_rezero", "toy_simple"])
+def test_waveglow_options_match_reference_golden(hip_lib_path, name):
+    """Multispeaker + ReZero WaveGlow and grouped ('simple') upsampling against the reference's own outputs."""
+    g = np.load(os.path.join(GOLDEN, f"waveglow_{name}.npz"))
+    m, cfg, sd = _model(str(g["config_key"]), int(g["seed"]))
+    ids = torch.from_numpy(g["speaker_ids"]).cuda() if "speaker_ids" in g.files else None
+    mel, z = torch.from_numpy(g["mel"]).cuda(), torch.from_numpy(g["z_scaled"]).cuda()
+    wave = m.infer_from_noise(mel, z, speaker_id=ids).cpu().numpy()
+    err = rms_rel_err(wave, g["wave"])
+    print(f"{name}: rms rel err vs reference = {err:.3e}")
+    assert err < WAVE_TOL
+    if ids is not None:
+        assert m.multispeaker
+        with pytest.raises(RuntimeError):
+            m.infer_from_noise(mel, z)                                      # ids are required (glow.py:193-198)
+        with pytest.raises(IndexError):
+            m.infer_from_noise(mel, z, speaker_id=torch.tensor([0, 1, 512]).cuda())
+        other = m.infer_from_noise(mel, z, speaker_id=ids.flip(0)).cpu().numpy()
+        assert rms_rel_err(other, g["wave"]) > 5e-3                          # the embedding really conditions the flows
+        assert rms_rel_err(other[1], g["wave"][1]) < WAVE_TOL                # ... per utterance: the middle id is unchanged
+        out = m.infer(mel, speaker_id=ids, sigma=0.7)
+        assert out.shape == (3, 10 * 256) and torch.isfinite(out).all()
+        # bf16 MFMA path with the speaker rows as extra K of cond layer 0, against the bf16-rounded oracle
+        from oracle import waveglow_oracle as wo
+        m.set_compute_dtype(torch.bfloat16)
+        w16 = m.infer_from_noise(mel, z, speaker_id=ids).cpu().numpy()
+        ref16 = wo.waveglow_infer(sd, cfg, g["mel"], g["z_scaled"], bf16=True, speaker_ids=g["speaker_ids"])
+        print(f"{name} bf16: vs bf16-rounded oracle {rms_rel_err(w16, ref16):.3e}")
+        assert rms_rel_err(w16, ref16) < BF16_VS_BF16_ORACLE_TOL
+
+
+def test_waveglow_simple_half_upsampling_matches_oracle(hip_lib_path):
+    from oracle import waveglow_oracle as wo
+    m, cfg, sd = _model("toy_simple_half", 5)
+    assert tuple(m.upsample.weight.shape) == (80, 2, 1024)
+    mel = synthetic.synthetic_mel(2, 9, seed=5)
+    z = synthetic.synthetic_noise(2, 8, 9 * 32, seed=5) * np.float32(0.9)
+    wave = m.infer_from_noise(torch.from_numpy(mel).cuda(), torch.from_numpy(z).cuda()).cpu().numpy()
+    assert rms_rel_err(wave, wo.waveglow_infer(sd, cfg, mel, z)) < WAVE_TOL
