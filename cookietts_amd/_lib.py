@@ -186,6 +186,9 @@ SIGNATURES = {
     "ctts_alignment_metric_f32": (C.c_int, [_FP, _FP, _FP, C.c_int32, C.c_int32, C.c_int32, C.c_float, _FP, _FP,
                                             C.c_size_t, _FP]),
     "ctts_first_over_thresh_f32": (C.c_int, [_FP, C.c_int32, C.c_int32, C.c_float, _FP, _FP]),
+    "ctts_taco_stop_state_bytes": (C.c_size_t, [C.c_int32]),
+    "ctts_taco_stop_reset": (C.c_int, [_FP, C.c_int32, C.c_int32, _FP]),
+    "ctts_taco_stop_rule_f32": (C.c_int, [_FP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _FP, _FP]),
     "ctts_profile_enable": (C.c_int, [C.c_int32]),
     "ctts_profile_collect": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }

@@ -135,6 +135,59 @@ __global__ __launch_bounds__(256) void first_over_thresh_kernel(const float* __r
     if (t == 0) out[b] = min(min(red[0], red[1]), min(red[2], red[3]));
 }
 
+
+// Decoder stop rule (model.py:879-904), evaluated on the device for gate logits of steps [step0, step0 + n):
+//   for i > 4:  sig_max[b] = max(sig_max[b], sigmoid(gate[b][i]))            (running max per utterance)
+//   if min_b sig_max[b] > threshold:  break_point = min(break_point, i + delay)
+//   if i >= break_point:  n_total = i + 1, stop
+// state = { float sig_max[batch]; int32 break_point; int32 n_total (-1 while running) } carried between calls.
+// One workgroup; thread t owns utterances t, t + 256, ...; the per-step minimum meets in LDS.
+__global__ __launch_bounds__(256) void stop_rule_kernel(const float* __restrict__ gate, int batch, int gate_ld, int step0,
+                                                        int n, float threshold, int delay, float* __restrict__ sig_max,
+                                                        int* __restrict__ ints) {
+    __shared__ float red[4];
+    __shared__ int s_stop;
+    const int t = threadIdx.x;
+    int break_point = ints[0];
+    if (ints[1] >= 0) return;                              // already stopped in an earlier block
+    for (int j = 0; j < n; ++j) {
+        const int i = step0 + j;
+        float m = INFINITY;
+        for (int b = t; b < batch; b += 256) {
+            float v = sig_max[b];
+            if (i > 4) {
+                const float sg = 1.0f / (1.0f + expf(-gate[(size_t)b * gate_ld + i]));
+                v = fmaxf(sg, v);
+                sig_max[b] = v;
+            }
+            m = fminf(m, v);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off));
+        if ((t & 63) == 0) red[t >> 6] = m;
+        __syncthreads();
+        if (t == 0) {
+            const float mn = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+            if (mn > threshold) break_point = min(break_point, i + delay);
+            s_stop = (i >= break_point) ? i + 1 : -1;
+        }
+        __syncthreads();
+        const int stop = s_stop;
+        if (stop >= 0) {
+            if (t == 0) { ints[0] = break_point; ints[1] = stop; }
+            return;
+        }
+        // every thread mirrors thread 0's break_point only through the stop decision; keep thread 0's copy authoritative
+    }
+    if (t == 0) ints[0] = break_point;
+}
+
+__global__ void stop_reset_kernel(float* sig_max, int* ints, int batch, int max_steps) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < batch) sig_max[t] = 0.f;
+    if (t == 0) { ints[0] = max_steps; ints[1] = -1; }
+}
+
 }  // namespace
 }  // namespace ctts
 
@@ -175,6 +228,31 @@ int ctts_first_over_thresh_f32(const float* x, int32_t batch, int32_t T, float t
     CTTS_CHECK_ARG(x && out && batch >= 1 && T >= 1, "first_over_thresh: bad argument");
     hipLaunchKernelGGL(first_over_thresh_kernel, dim3(batch), dim3(256), 0, as_stream(stream), x, out, T, threshold);
     CTTS_CHECK_LAUNCH("first_over_thresh");
+    return CTTS_OK;
+}
+
+size_t ctts_taco_stop_state_bytes(int32_t batch) {
+    if (batch < 1) return 0;
+    return ((size_t)batch + 2) * sizeof(float);
+}
+
+int ctts_taco_stop_reset(void* state, int32_t batch, int32_t max_decoder_steps, void* stream) {
+    CTTS_CHECK_ARG(state && batch >= 1 && max_decoder_steps >= 1, "stop_reset: bad argument");
+    float* sig = static_cast<float*>(state);
+    hipLaunchKernelGGL(stop_reset_kernel, dim3((batch + 255) / 256), dim3(256), 0, as_stream(stream), sig,
+                       reinterpret_cast<int*>(sig + batch), batch, max_decoder_steps);
+    CTTS_CHECK_LAUNCH("stop_reset");
+    return CTTS_OK;
+}
+
+int ctts_taco_stop_rule_f32(const float* gate_logits, int32_t batch, int32_t gate_ld, int32_t step0, int32_t n_steps,
+                            float gate_threshold, int32_t gate_delay, void* state, void* stream) {
+    CTTS_CHECK_ARG(gate_logits && state && batch >= 1 && step0 >= 0 && n_steps >= 0 && step0 + n_steps <= gate_ld,
+                   "stop_rule: bad argument");
+    float* sig = static_cast<float*>(state);
+    hipLaunchKernelGGL(stop_rule_kernel, dim3(1), dim3(256), 0, as_stream(stream), gate_logits, batch, gate_ld, step0,
+                       n_steps, gate_threshold, gate_delay, sig, reinterpret_cast<int*>(sig + batch));
+    CTTS_CHECK_LAUNCH("stop_rule");
     return CTTS_OK;
 }
 

@@ -3,14 +3,17 @@
 // Tiling (CDNA4-first, 64-wide waves):
 //   workgroup = 256 threads = 4 waves; wave tile 128 x 64 = 4 x 2 tiles of
 //   v_mfma_f32_32x32x2_f32 -> 128 accumulator VGPRs, ~200 VGPRs total, 2 waves per SIMD
-//   (2 workgroups per CU) so one wave's LDS/global/barrier time is covered by the other
+//   (2 workgroups per CU) so one wave's LDS/barrier time is covered by the other
 //   wave's MFMAs; the f32 MFMA pipe (64 cycles per 32x32x2) is the bound.
 //   Block tile 256 x 128 (waves 2x2) or 128 x 256 (waves 1x4); K chunk 16.
-//   LDS: 2 stages x 24 KiB, both operands k-major so a fragment is one conflict-free
-//   ds_read2_b32 per lane pair of tiles (lane l: row/col l&31, k = l>>5).
-//   Global->LDS staging goes through registers and is issued one chunk ahead of the MFMAs
-//   (the f32 MFMA rate leaves >10x headroom on the load path); the LDS->MFMA software
+//   Default kernel (GLDS = true): 3 LDS stages x 24 KiB filled by direct global->LDS DMA
+//   (global_load_lds, 16 B per lane), issued two chunks ahead, one DMA piece per k-step behind that
+//   k-step's eight MFMAs, counted vmcnt + raw s_barrier; a chunk -> B-address table built once per
+//   workgroup keeps the loop body one basic block.  Both operands are k-major so a fragment pair is
+//   one conflict-free ds_read2_b32 (lane l: row/col l & 31, k = l >> 5); the LDS->MFMA software
 //   pipeline is pinned with sched_group_barrier.
+//   GLDS = false (CTTS_F32_NO_GLDS=1, or more K chunks than the address table holds): the older
+//   2-stage variant that stages global->LDS through registers one chunk ahead.
 #include <cstdlib>
 
 #include "gemm_f32.h"

@@ -216,7 +216,7 @@ int run_cond(const Plan& p, const Geom& g, const float* blob, const float* spect
     int rc = launch_gemm_f32(GEMM_EPI_SPLIT, a, s);
     if (rc) return rc;
     a.A = blob + p.cond1_A; a.bias = blob + p.cond1_b;
-    a.nch_total = p.nch1h;
+    a.nseg = 1; a.nch_total = p.nch1h;
     a.seg[0] = {h_tmp, hstride, p.nch1h, 0, GEMM_BM, 0};
     a.dst0 = h_all; a.dst1 = h_all;
     return launch_gemm_f32(GEMM_EPI_SPLIT, a, s);
@@ -794,7 +794,7 @@ int ctts_waveglow_infer_spk_bf16(const ctts_waveglow_config* cfg, const void* pa
         a.split = a.M;
         if ((rc = launch_gemm_bf16(BGEMM_EPI_SPLIT, a, s))) return rc;
         a.A = bblob + q.cond1_A; a.bias = blob + p.cond1_b;
-        a.nch_total = q.nch_c1;
+        a.nseg = 1; a.nch_total = q.nch_c1;
         a.seg[0] = {w.h_tmp_bf, hstride, q.nch_c1, 0, BGEMM_BM};
         a.dst0 = w.h_bf; a.dst1 = w.h_bf;
         if ((rc = launch_gemm_bf16(BGEMM_EPI_SPLIT, a, s))) return rc;

@@ -104,7 +104,9 @@ class MemoryBottleneck(nn.Module):
 
 
 def stop_step(gate_logits, gate_threshold, gate_delay, max_decoder_steps, state=None):
-    """The reference's stop rule (model.py:879-904) over a [B, n] block of gate logits (host tensors).
+    """Host restatement of the block-fed stop rule, kept for the tests that pin ``ctts_taco_stop_rule_f32`` (the
+    product path evaluates the rule on the device, see Decoder.inference).
+    The reference's stop rule (model.py:879-904) over a [B, n] block of gate logits (host tensors).
     ``state`` = (sig_max [B], break_point, first_step) carried between blocks.  Returns (n_total or None, state)."""
     B, n = gate_logits.shape
     sig_max, break_point, i0 = state if state is not None else (torch.zeros(B), max_decoder_steps, 0)
@@ -281,17 +283,37 @@ class Decoder(nn.Module):
                 _lib.check(lib.ctts_taco_decoder_init_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(mem[g0:g1]), _lib.ptr(lens[g0:g1]),
                                                          g1 - g0, T, _lib.ptr(ws), ws.numel() * 4, stream),
                            "ctts_taco_decoder_init_f32")
-            done, n_total, state = 0, None, None
+            # stop rule (model.py:879-904) on the device: after every block of steps one small kernel folds the block's
+            # gate logits into the rule's state and its verdict (n_total or -1) is copied to pinned host memory.  The
+            # host looks at block k-1's verdict only after block k is enqueued, so the GPU never waits for the host;
+            # steps run past the stop are trimmed below (at most 2 * STOP_CHECK_EVERY of them).
+            done, n_total = 0, None
+            if fixed_steps is None:
+                state = torch.empty(lib.ctts_taco_stop_state_bytes(B) // 4, dtype=torch.float32, device=device)
+                _lib.check(lib.ctts_taco_stop_reset(_lib.ptr(state), B, max_steps, stream), "ctts_taco_stop_reset")
+                verdict_dev = state[B + 1:B + 2].view(torch.int32)
+                pending = []                                   # (pinned int32[1], event) per enqueued block
             while done < max_steps and n_total is None:
                 n = min(STOP_CHECK_EVERY if fixed_steps is None else max_steps, max_steps - done)
                 for (g0, g1), ws, km in zip(groups, wss, masks):
                     _lib.check(lib.ctts_taco_decoder_steps_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(km), _lib.ptr(mel[g0:g1]),
                                                               _lib.ptr(gate[g0:g1]), _lib.ptr(align[g0:g1]), g1 - g0, T, done,
                                                               n, max_steps, _lib.ptr(ws), stream), "ctts_taco_decoder_steps_f32")
-                if fixed_steps is None:
-                    n_total, state = stop_step(gate[:, done:done + n].cpu(), self.gate_threshold, self.gate_delay,
-                                               max_steps, state)
                 done += n
+                if fixed_steps is None:
+                    _lib.check(lib.ctts_taco_stop_rule_f32(_lib.ptr(gate), B, max_steps, done - n, n,
+                                                           float(self.gate_threshold), int(self.gate_delay), _lib.ptr(state),
+                                                           stream), "ctts_taco_stop_rule_f32")
+                    host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                    host.copy_(verdict_dev, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(stream_obj)
+                    pending.append((host, ev))
+                    while len(pending) > (1 if done < max_steps else 0) and n_total is None:
+                        host0, ev0 = pending.pop(0)
+                        ev0.synchronize()
+                        if int(host0[0]) >= 0:
+                            n_total = int(host0[0])
             if n_total is None:
                 n_total = max_steps
                 if fixed_steps is None:

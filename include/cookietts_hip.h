@@ -495,6 +495,20 @@ int ctts_alignment_metric_f32(const float* alignments, const float* input_length
  * x [batch][T] fp32 -> out int32 [batch], first step with x >= threshold, else T-1. */
 int ctts_first_over_thresh_f32(const float* x, int32_t batch, int32_t T, float threshold, int32_t* out, void* stream);
 
+/* Decoder.inference's stop rule (_2_ttm/tacotron2_tm/model.py:879-904) on the device.  The reference copies every
+ * step's gate to the host (:885) and evaluates there; here the rule runs over the gate LOGITS the decoder steps wrote,
+ * block of steps by block of steps, and only its verdict (4 bytes) ever crosses to the host.
+ *   state: ctts_taco_stop_state_bytes(batch) device bytes = { float sig_max[batch]; int32 break_point; int32 n_total };
+ *          ctts_taco_stop_reset sets sig_max = 0, break_point = max_decoder_steps, n_total = -1.
+ *   ctts_taco_stop_rule_f32 applies steps [step0, step0 + n_steps) of gate_logits [batch][gate_ld]:
+ *          i > 4: sig_max = max(sig_max, sigmoid(gate)); min over the batch > gate_threshold -> break_point =
+ *          min(break_point, i + gate_delay); i >= break_point -> n_total = i + 1 (sticky; later calls are no-ops).
+ *   n_total is the int32 at byte offset 4 * (batch + 1) of state. */
+size_t ctts_taco_stop_state_bytes(int32_t batch);
+int ctts_taco_stop_reset(void* state, int32_t batch, int32_t max_decoder_steps, void* stream);
+int ctts_taco_stop_rule_f32(const float* gate_logits, int32_t batch, int32_t gate_ld, int32_t step0, int32_t n_steps,
+                            float gate_threshold, int32_t gate_delay, void* state, void* stream);
+
 /* ---- in-library kernel timing (bench.py roofline leg) --------------------------------- */
 /* When enabled, ctts_waveglow_infer_f32 brackets every launch of the dominant kernel
  * (WN in-layer GEMM: dilated conv + cond + gate) with hipEvents on `stream`. */

@@ -164,3 +164,43 @@ def test_hip_speaker_dependent_denoiser_constructor(hip_lib_path):
                     speaker_ids=torch.tensor([3, 4]).cuda(), sigma=0.5, return_CPU=False)
     out = den(audio, speaker_ids=torch.tensor([3, 4]).cuda(), strength=0.2)
     assert out.shape == (2, 1, audio.shape[1] // 16 * 16) and torch.isfinite(out).all()
+
+
+
+def test_slaney_filterbank_against_closed_form_numbers():
+    """Third witness for the one unpinned boundary (librosa.filters.mel is absent and unpinned, stft.py:163-164):
+    numbers worked out here from the PUBLISHED constants of the Slaney scale (200/3 Hz per mel below 1 kHz; above,
+    27 mels per factor 6.4), not by calling either restatement's helpers.  Both restatements must hit them."""
+    import math
+    from cookietts_amd import audio
+    sr, n_fft, n_mels, fmin, fmax = 22050, 1024, 80, 0.0, 8000.0
+    df = sr / n_fft                                                     # 21.533203125 Hz per bin
+    top = 15.0 + 27.0 * math.log(fmax / 1000.0) / math.log(6.4)         # mel(8000 Hz) = 45.2454...
+    assert abs(top - 45.245497) < 1e-5
+    step = top / (n_mels + 1)
+
+    def edge(k):                                                        # k-th of the 82 mel-spaced edges, in Hz
+        m = k * step
+        return m * 200.0 / 3.0 if m < 15.0 else 1000.0 * math.exp((m - 15.0) * math.log(6.4) / 27.0)
+    assert abs(edge(1) - 37.2391) < 1e-3 and abs(edge(81) - 8000.0) < 1e-9
+    k15 = 15.0 / step                                                   # the scale turns logarithmic at edge 26.85
+    assert 26 < k15 < 27 and abs(edge(27) - 1000.0 * 6.4 ** ((27 * step - 15.0) / 27.0)) < 1e-9
+    for name, fb in (("product", audio.slaney_mel_filterbank(sr, n_fft, n_mels, fmin, fmax)),
+                     ("oracle", so.slaney_mel_filterbank(sr, n_fft, n_mels, fmin, fmax))):
+        fb = np.asarray(fb, dtype=np.float64)
+        assert fb.shape == (80, 513), name
+        for i in (0, 1, 13, 26, 27, 40, 60, 79):                        # linear region, the knee, log region, last
+            lo, ce, hi = edge(i), edge(i + 1), edge(i + 2)
+            for k in range(513):
+                f = k * df
+                w = max(0.0, min((f - lo) / (ce - lo), (hi - f) / (hi - ce))) * 2.0 / (hi - lo)
+                assert abs(fb[i, k] - w) <= 1e-7 * max(1.0, w) + 1e-9, (name, i, k, fb[i, k], w)
+            # support is exactly the open interval (lo, hi); the triangle has unit area (area normalisation):
+            # the bin sum times the bin width approximates it to within the kink error of a triangle sampled at df
+            nz = np.nonzero(fb[i])[0]
+            assert nz.min() * df > lo - 1e-9 and nz.max() * df < hi + 1e-9, (name, i)
+            area = fb[i].sum() * df
+            assert abs(area - 1.0) < 0.5 * df / (hi - lo) + 1e-6, (name, i, area)
+        # two hand-checked entries: filter 0 at bin 1 (rising edge from 0 Hz) and the peak height of the last filter
+        assert abs(fb[0, 1] - (df / edge(1)) * 2.0 / edge(2)) < 1e-9, name
+        assert fb[79].max() <= 2.0 / (edge(81) - edge(79)) + 1e-12, name

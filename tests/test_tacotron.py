@@ -132,6 +132,39 @@ def test_hip_decoder_stop_rule_and_chunking(hip_lib_path):
 
 
 @pytest.mark.gpu
+def test_device_stop_rule_matches_reference_semantics(hip_lib_path):
+    """ctts_taco_stop_rule_f32 fed block by block == the per-step rule of model.py:879-904 (oracle restatement), on
+    crafted gate logits: early crossings ignored for i <= 4, the slowest utterance decides, gate_delay, the
+    max_decoder_steps cap, stickiness of the verdict, a batch wider than the workgroup."""
+    import ctypes as C
+    from cookietts_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(5)
+    cases = []
+    g = np.full((2, 40), -5.0, np.float32); g[0, 2] = 9.0; g[0, 10:] = 9.0; g[1, 17] = 9.0
+    cases += [(g, 0.5, 0, 1000), (g, 0.5, 3, 1000), (g, 0.5, 30, 40)]
+    cases += [(np.full((1, 12), -9.0, np.float32), 0.5, 0, 12)]                           # never crosses: cap
+    big = rng.normal(-3.0, 1.0, (300, 90)).astype(np.float32)                             # 300 utterances > 256 threads
+    big[np.arange(300), rng.integers(6, 60, 300)] = 6.0
+    cases += [(big, 0.9, 2, 90)]
+    for gates, thr, delay, max_steps in cases:
+        B, n_all = gates.shape
+        want = to.stop_step(gates, thr, delay, max_steps)
+        gd = torch.from_numpy(gates).cuda()
+        state = torch.empty(lib.ctts_taco_stop_state_bytes(B) // 4, dtype=torch.float32, device="cuda")
+        _lib.check(lib.ctts_taco_stop_reset(_lib.ptr(state), B, max_steps, None), "reset")
+        got = None
+        for c0 in range(0, n_all, 7):                       # blocks of 7 steps, like the device loop's blocks of 32
+            n = min(7, n_all - c0)
+            _lib.check(lib.ctts_taco_stop_rule_f32(_lib.ptr(gd), B, n_all, c0, n, thr, delay, _lib.ptr(state), None), "rule")
+            v = int(state[B + 1:B + 2].view(torch.int32).item())
+            if got is None and v >= 0:
+                got = v
+            assert got is None or v == got                   # sticky once set
+        assert (got if got is not None else max_steps) == want, (want, got, thr, delay)
+
+
+@pytest.mark.gpu
 def test_full_tacotron_inference_contract(hip_lib_path):
     """Tacotron2.inference drop-in contract (model.py:1044-1080): dict keys and shapes."""
     m, g, hp, sd = _model()
