@@ -175,14 +175,14 @@ def test_slaney_filterbank_against_closed_form_numbers():
     from cookietts_amd import audio
     sr, n_fft, n_mels, fmin, fmax = 22050, 1024, 80, 0.0, 8000.0
     df = sr / n_fft                                                     # 21.533203125 Hz per bin
-    top = 15.0 + 27.0 * math.log(fmax / 1000.0) / math.log(6.4)         # mel(8000 Hz) = 45.2454...
-    assert abs(top - 45.245497) < 1e-5
+    top = 15.0 + 27.0 * math.log(fmax / 1000.0) / math.log(6.4)         # mel(8000 Hz) = 15 + 27 * 1.120209 = 45.24564
+    assert abs(top - 45.245640) < 1e-5
     step = top / (n_mels + 1)
 
     def edge(k):                                                        # k-th of the 82 mel-spaced edges, in Hz
         m = k * step
         return m * 200.0 / 3.0 if m < 15.0 else 1000.0 * math.exp((m - 15.0) * math.log(6.4) / 27.0)
-    assert abs(edge(1) - 37.2391) < 1e-3 and abs(edge(81) - 8000.0) < 1e-9
+    assert abs(edge(1) - 37.2392) < 1e-3 and abs(edge(81) - 8000.0) < 1e-9
     k15 = 15.0 / step                                                   # the scale turns logarithmic at edge 26.85
     assert 26 < k15 < 27 and abs(edge(27) - 1000.0 * 6.4 ** ((27 * step - 15.0) / 27.0)) < 1e-9
     for name, fb in (("product", audio.slaney_mel_filterbank(sr, n_fft, n_mels, fmin, fmax)),
