@@ -245,10 +245,14 @@ class Denoiser(torch.nn.Module):
         mel_input = torch.randn((1, n_mel_channels, n_frames), dtype=p.dtype, device=p.device) * float(var) + float(mu)
 
         def infer(ids):
-            try:
-                return waveglow.infer(mel_input.expand(ids.shape[0], -1, -1).contiguous(), speaker_ids=ids, sigma=wg_sigma)
-            except TypeError:      # glow.py's signature names it speaker_id (glow.py:314)
-                return waveglow.infer(mel_input.expand(ids.shape[0], -1, -1).contiguous(), speaker_id=ids, sigma=wg_sigma)
+            mel = mel_input.expand(ids.shape[0], -1, -1).contiguous()
+            for kw in ({"speaker_ids": ids}, {"speaker_id": ids}, {}):      # ax core / glow.py:314 / single-speaker stubs
+                try:
+                    return waveglow.infer(mel, sigma=wg_sigma, **kw)
+                except TypeError as e:
+                    if "unexpected keyword" not in str(e):
+                        raise
+            raise TypeError("vocoder.infer accepts neither speaker_ids nor speaker_id nor a bare call")
         with torch.no_grad():
             if speaker_dependant:      # denoiser.py:29-45: one vocoder pass per speaker, batched here
                 if hasattr(waveglow, 'speaker_embed'):
