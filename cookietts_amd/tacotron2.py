@@ -273,6 +273,21 @@ class Decoder(nn.Module):
                 wss.append(torch.empty(nbytes // 4, dtype=torch.float32, device=device))
             self._ws = {key: wss}
         masks = [keep_masks if len(groups) == 1 else keep_masks[:, :, g0:g1].contiguous() for g0, g1 in groups]
+        # persistent form (one launch per block of steps, weight-stationary fresh columns, granule all-gathers) where the
+        # library builds it for this shape; CTTS_TACO_NO_PERSIST=1 keeps the six-launches-per-step form
+        import os
+        xchg = []
+        for g0, g1 in groups:
+            nb = 0 if os.environ.get("CTTS_TACO_NO_PERSIST") else lib.ctts_taco_decoder_persistent_bytes(C.byref(cfg), g1 - g0, T)
+            xchg.append(torch.zeros(nb // 8, dtype=torch.int64, device=device) if nb else None)
+
+        def check_persistent():
+            for (g0, g1), xb in zip(groups, xchg):
+                if xb is not None:
+                    ctl = xb[-8:-6].view(torch.int32).cpu()
+                    if int(ctl[0]) != 0:
+                        raise _lib.HipLibraryError(
+                            f"persistent decoder gave up waiting (workgroup {int(ctl[1])}, phase {int(ctl[2])}, step {int(ctl[3])})")
         mel = torch.zeros(B, self.n_mel_channels, max_steps, dtype=torch.float32, device=device)
         gate = torch.zeros(B, max_steps, dtype=torch.float32, device=device)
         align = torch.zeros(B, max_steps, T, dtype=torch.float32, device=device)
@@ -295,10 +310,16 @@ class Decoder(nn.Module):
                 pending = []                                   # (pinned int32[1], event) per enqueued block
             while done < max_steps and n_total is None:
                 n = min(STOP_CHECK_EVERY if fixed_steps is None else max_steps, max_steps - done)
-                for (g0, g1), ws, km in zip(groups, wss, masks):
-                    _lib.check(lib.ctts_taco_decoder_steps_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(km), _lib.ptr(mel[g0:g1]),
-                                                              _lib.ptr(gate[g0:g1]), _lib.ptr(align[g0:g1]), g1 - g0, T, done,
-                                                              n, max_steps, _lib.ptr(ws), stream), "ctts_taco_decoder_steps_f32")
+                for (g0, g1), ws, km, xb in zip(groups, wss, masks, xchg):
+                    if xb is not None:
+                        _lib.check(lib.ctts_taco_decoder_steps_persistent_f32(
+                            C.byref(cfg), _lib.ptr(blob), _lib.ptr(km), _lib.ptr(mel[g0:g1]), _lib.ptr(gate[g0:g1]),
+                            _lib.ptr(align[g0:g1]), g1 - g0, T, done, n, max_steps, _lib.ptr(ws), _lib.ptr(xb),
+                            xb.numel() * 8, stream), "ctts_taco_decoder_steps_persistent_f32")
+                    else:
+                        _lib.check(lib.ctts_taco_decoder_steps_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(km), _lib.ptr(mel[g0:g1]),
+                                                                  _lib.ptr(gate[g0:g1]), _lib.ptr(align[g0:g1]), g1 - g0, T, done,
+                                                                  n, max_steps, _lib.ptr(ws), stream), "ctts_taco_decoder_steps_f32")
                 done += n
                 if fixed_steps is None:
                     _lib.check(lib.ctts_taco_stop_rule_f32(_lib.ptr(gate), B, max_steps, done - n, n,
@@ -314,6 +335,11 @@ class Decoder(nn.Module):
                         ev0.synchronize()
                         if int(host0[0]) >= 0:
                             n_total = int(host0[0])
+                    if any(x is not None for x in xchg) and len(pending) == 0:
+                        check_persistent()
+            if any(x is not None for x in xchg):
+                stream_obj.synchronize()
+                check_persistent()
             if n_total is None:
                 n_total = max_steps
                 if fixed_steps is None:

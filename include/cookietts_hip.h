@@ -371,6 +371,24 @@ int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void*
                                 float* align_out, int32_t batch, int32_t text_len, int32_t step0,
                                 int32_t n_steps, int32_t max_steps, void* workspace, void* stream);
 
+/* Persistent form of ctts_taco_decoder_steps_f32: ONE launch of 256 resident workgroups runs all n_steps steps; the
+ * columns of every mat-vec that depend on the current step are weight-stationary in registers, the rest is streamed in
+ * the exchange gaps, and vectors move between workgroups as 8-byte {tag, value} granules (no grid barrier, no per-step
+ * launches).  Same state (workspace), same outputs, same keep_masks contract as ctts_taco_decoder_steps_f32, so the
+ * two can be mixed call by call.  Built for the repo-default decoder shape (attention RNN 1280, decoder RNNs 768,
+ * prenet 256, memory 512, window 16), batch <= 4, text_len <= 1024 on a device with >= 256 CUs:
+ * ctts_taco_decoder_persistent_bytes returns 0 otherwise (use the per-launch form).
+ *   exchange: ctts_taco_decoder_persistent_bytes(...) device bytes, zero-filled ONCE by the caller; the call clears the
+ *   granule tags itself before every launch.  The LAST 64 bytes are control words (uint32): word 0 stays 0 on success;
+ *   non-zero = a bounded wait gave up (words 1..3: workgroup, phase, step), the outputs of that call are invalid and
+ *   every later launch on the same buffer returns immediately (sticky) until the caller zeroes the words. */
+size_t ctts_taco_decoder_persistent_bytes(const ctts_taco_decoder_config* cfg, int32_t batch, int32_t text_len);
+int ctts_taco_decoder_steps_persistent_f32(const ctts_taco_decoder_config* cfg, const void* packed,
+                                           const uint8_t* keep_masks, float* mel_out, float* gate_out,
+                                           float* align_out, int32_t batch, int32_t text_len, int32_t step0,
+                                           int32_t n_steps, int32_t max_steps, void* workspace, void* exchange,
+                                           size_t exchange_bytes, void* stream);
+
 /* ---- Tacotron2-TM one-shot stages: operator-level primitives ------------------------------- */
 /* The encoder (model.py:283-316) and postnet (:218-228) are stacks of "same"-padded Conv1d (+ eval-mode
  * BatchNorm1d, folded into the weights at pack time) + LeakyReLU / tanh, a packed-sequence BiLSTM, and a
