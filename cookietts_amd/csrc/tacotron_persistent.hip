@@ -55,7 +55,7 @@ struct PdArgs {
     unsigned memory, pm, lengths, att_h_in, dec_h_in, d2_h_in, att_h_out, dec_h_out, d2_h_out, att_c, dec_c, d2_c, ctx,
         prenet, w, cum, pos;                                                              // ws offsets
     unsigned g_p, g_atth, g_q, g_ctx, g_dech, g_d2h, g_h1, ctl;                           // xb offsets (u64 words)
-    int A, F, K, R, n_mel, T, batch, step0, n_steps, max_steps, pd_rows;
+    int A, F, K, R, n_mel, T, batch, nbc, step0, n_steps, max_steps, pd_rows;   // nbc: batch rows the workspace holds
 };
 
 __device__ __forceinline__ float pd_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -402,25 +402,40 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
         wsm[0] = *reinterpret_cast<const float4*>((a.blob + a.W2) + (size_t)wg * PD_P + 4 * lane);
     }
 
-    // ---- entry: state of step0 from the workspace (written by the init / the previous launch) ----
-    for (int i = t; i < PD_NB * PD_P; i += PD_T) X[XP + i] = (a.ws + a.prenet)[i];
-    for (int i = t; i < PD_NB * PD_DM; i += PD_T) X[XCTX + i] = (a.ws + a.ctx)[i];
-    for (int i = t; i < PD_NB * PD_RD; i += PD_T) { X[XDEC + i] = (a.ws + a.dec_h_in)[i]; X[XD2 + i] = (a.ws + a.d2_h_in)[i]; }
-    for (int i = t; i < PD_NB * PD_RA; i += PD_T) X[XATT + i] = (a.ws + a.att_h_in)[i];
-    if (t < PD_UA * PD_NB) { const int u = t / PD_NB, b = t % PD_NB; cA[u][b] = (a.ws + a.att_c)[b * PD_RA + wg * PD_UA + u]; hA[u][b] = (a.ws + a.att_h_in)[b * PD_RA + wg * PD_UA + u]; }
+    // ---- entry: state of step0 from the workspace (written by the init / the previous launch).  The workspace holds
+    // nbc <= 4 batch rows per state array; the rows above stay zero here and are never written back.
+    const int nbc = a.nbc;
+    for (int i = t; i < PD_NB * PD_P; i += PD_T) X[XP + i] = i / PD_P < nbc ? (a.ws + a.prenet)[i] : 0.f;
+    for (int i = t; i < PD_NB * PD_DM; i += PD_T) X[XCTX + i] = i / PD_DM < nbc ? (a.ws + a.ctx)[i] : 0.f;
+    for (int i = t; i < PD_NB * PD_RD; i += PD_T) {
+        X[XDEC + i] = i / PD_RD < nbc ? (a.ws + a.dec_h_in)[i] : 0.f;
+        X[XD2 + i] = i / PD_RD < nbc ? (a.ws + a.d2_h_in)[i] : 0.f;
+    }
+    for (int i = t; i < PD_NB * PD_RA; i += PD_T) X[XATT + i] = i / PD_RA < nbc ? (a.ws + a.att_h_in)[i] : 0.f;
+    if (t < PD_UA * PD_NB) {
+        const int u = t / PD_NB, b = t % PD_NB;
+        cA[u][b] = b < nbc ? (a.ws + a.att_c)[b * PD_RA + wg * PD_UA + u] : 0.f;
+        hA[u][b] = b < nbc ? (a.ws + a.att_h_in)[b * PD_RA + wg * PD_UA + u] : 0.f;
+    }
     if (t < PD_UD * PD_NB) {
         const int u = t / PD_NB, b = t % PD_NB;
-        cD[u][b] = (a.ws + a.dec_c)[b * PD_RD + wg * PD_UD + u]; hD[u][b] = (a.ws + a.dec_h_in)[b * PD_RD + wg * PD_UD + u];
-        c2[u][b] = (a.ws + a.d2_c)[b * PD_RD + wg * PD_UD + u]; h2[u][b] = (a.ws + a.d2_h_in)[b * PD_RD + wg * PD_UD + u];
+        cD[u][b] = b < nbc ? (a.ws + a.dec_c)[b * PD_RD + wg * PD_UD + u] : 0.f;
+        hD[u][b] = b < nbc ? (a.ws + a.dec_h_in)[b * PD_RD + wg * PD_UD + u] : 0.f;
+        c2[u][b] = b < nbc ? (a.ws + a.d2_c)[b * PD_RD + wg * PD_UD + u] : 0.f;
+        h2[u][b] = b < nbc ? (a.ws + a.d2_h_in)[b * PD_RD + wg * PD_UD + u] : 0.f;
     }
-    if (t < PD_NB) pown[t] = (a.ws + a.prenet)[t * PD_P + wg];
+    if (t < PD_NB) pown[t] = t < nbc ? (a.ws + a.prenet)[t * PD_P + wg] : 0.f;
     for (int i = t; i < 2 * 4 * PD_UA * PD_NB; i += PD_T) (&gpA[0][0][0])[i] = 0.f;
     for (int i = t; i < 2 * 4 * PD_UD * PD_NB; i += PD_T) { (&gpD[0][0][0])[i] = 0.f; (&gp2[0][0][0])[i] = 0.f; }
     if (is_attn) {
         const int b = wg;
-        for (int p = t; p < a.T; p += PD_T) { att.w[p] = (a.ws + a.w)[(size_t)b * a.T + p]; att.cum[p] = (a.ws + a.cum)[(size_t)b * a.T + p]; }
+        const bool real = b < a.batch;
+        for (int p = t; p < a.T; p += PD_T) {
+            att.w[p] = real ? (a.ws + a.w)[(size_t)b * a.T + p] : 0.f;
+            att.cum[p] = real ? (a.ws + a.cum)[(size_t)b * a.T + p] : 0.f;
+        }
         for (int i = t; i < a.F * 2 * a.K; i += PD_T) att.wloc[i] = (a.blob + a.Wloc)[i];
-        if (t == 0) att.pos = (a.ws + a.pos)[b];
+        if (t == 0) att.pos = real ? (a.ws + a.pos)[b] : 0.f;
     }
     __syncthreads();
     int cur = 0;
@@ -563,17 +578,21 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
     __syncthreads();
     if (t < PD_UA * PD_NB) {
         const int u = t / PD_NB, b = t % PD_NB;
-        (a.ws + a.att_h_out)[b * PD_RA + wg * PD_UA + u] = hA[u][b];
-        (a.ws + a.att_c)[b * PD_RA + wg * PD_UA + u] = cA[u][b];
+        if (b < nbc) {
+            (a.ws + a.att_h_out)[b * PD_RA + wg * PD_UA + u] = hA[u][b];
+            (a.ws + a.att_c)[b * PD_RA + wg * PD_UA + u] = cA[u][b];
+        }
     }
     if (t < PD_UD * PD_NB) {
         const int u = t / PD_NB, b = t % PD_NB;
-        (a.ws + a.dec_h_out)[b * PD_RD + wg * PD_UD + u] = hD[u][b];
-        (a.ws + a.dec_c)[b * PD_RD + wg * PD_UD + u] = cD[u][b];
-        (a.ws + a.d2_h_out)[b * PD_RD + wg * PD_UD + u] = h2[u][b];
-        (a.ws + a.d2_c)[b * PD_RD + wg * PD_UD + u] = c2[u][b];
+        if (b < nbc) {
+            (a.ws + a.dec_h_out)[b * PD_RD + wg * PD_UD + u] = hD[u][b];
+            (a.ws + a.dec_c)[b * PD_RD + wg * PD_UD + u] = cD[u][b];
+            (a.ws + a.d2_h_out)[b * PD_RD + wg * PD_UD + u] = h2[u][b];
+            (a.ws + a.d2_c)[b * PD_RD + wg * PD_UD + u] = c2[u][b];
+        }
     }
-    if (t < PD_NB) (a.ws + a.prenet)[t * PD_P + wg] = pown[t];
+    if (t < nbc) (a.ws + a.prenet)[t * PD_P + wg] = pown[t];
     if (is_attn && wg < a.batch) {
         const int b = wg;
         for (int p = t; p < a.T; p += PD_T) { (a.ws + a.w)[(size_t)b * a.T + p] = att.w[p]; (a.ws + a.cum)[(size_t)b * a.T + p] = att.cum[p]; }
@@ -669,7 +688,7 @@ int ctts_taco_decoder_steps_persistent_f32(const ctts_taco_decoder_config* cfg, 
     a.g_dech = (unsigned)x.dech; a.g_d2h = (unsigned)x.d2h; a.g_h1 = (unsigned)x.h1;
     a.keep = keep_masks; a.mel_out = mel_out; a.gate_out = gate_out; a.align_out = align_out;
     a.A = c.attention_dim; a.F = c.location_n_filters; a.K = c.location_kernel_size; a.R = c.window_range;
-    a.n_mel = c.n_mel_channels; a.T = text_len; a.batch = batch; a.step0 = step0; a.n_steps = n_steps;
+    a.n_mel = c.n_mel_channels; a.T = text_len; a.batch = batch; a.nbc = pad_batch(batch); a.step0 = step0; a.n_steps = n_steps;
     a.max_steps = max_steps; a.pd_rows = p.pd_rows;
     hipLaunchKernelGGL(taco_persistent_kernel, dim3(PD_WG), dim3(PD_T), 0, s, a);
     CTTS_CHECK_LAUNCH("taco_persistent");

@@ -309,7 +309,8 @@ class Decoder(nn.Module):
                 verdict_dev = state[B + 1:B + 2].view(torch.int32)
                 pending = []                                   # (pinned int32[1], event) per enqueued block
             while done < max_steps and n_total is None:
-                n = min(STOP_CHECK_EVERY if fixed_steps is None else max_steps, max_steps - done)
+                chunk = int(os.environ.get("CTTS_TACO_CHUNK", 0)) or (STOP_CHECK_EVERY if fixed_steps is None else max_steps)
+                n = min(chunk, max_steps - done)
                 for (g0, g1), ws, km, xb in zip(groups, wss, masks, xchg):
                     if xb is not None:
                         _lib.check(lib.ctts_taco_decoder_steps_persistent_f32(
