@@ -143,6 +143,7 @@ SIGNATURES = {
     "ctts_taco_decoder_steps_persistent_f32": (C.c_int, [C.POINTER(TacoDecoderConfig), _FP, _FP, _FP, _FP, _FP, C.c_int32,
                                                          C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP, _FP, C.c_size_t,
                                                          _FP]),
+    "ctts_taco_decoder_persistent_debug": (C.c_int, [_FP]),
     "ctts_conv1d_packed_bytes": (C.c_size_t, [C.POINTER(Conv1dDesc)]),
     "ctts_conv1d_pack_f32": (C.c_int, [C.POINTER(Conv1dDesc), _FP, _FP, _FP, _FP, _FP, _FP, C.c_float, _FP, _FP]),
     "ctts_conv1d_f32": (C.c_int, [C.POINTER(Conv1dDesc), _FP, _FP, _FP, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

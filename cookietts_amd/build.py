@@ -17,6 +17,9 @@ LIB_PATH = os.path.join(PKG_DIR, "libcookietts_hip.so")
 OBJ_DIR = os.path.join(PKG_DIR, "build")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# per-file additions.  tacotron_persistent.hip: the SLP vectoriser packs its scalar fp32 FMAs into v_pk_fma_f32, whose
+# register-pair operands cost hundreds of moves and spills in a kernel that keeps ~100 weights resident per lane
+EXTRA_FLAGS = {"tacotron_persistent.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -58,7 +61,7 @@ def build(force=False, verbose=True):
         if (not force and os.path.exists(obj)
                 and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_hdr)):
             continue
-        cmd = [hipcc] + FLAGS + ["-I", INCLUDE, "-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-I", INCLUDE, "-c", src, "-o", obj]
         if verbose:
             print("[build]", " ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

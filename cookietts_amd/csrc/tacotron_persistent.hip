@@ -2,24 +2,25 @@
 // (model.py:668-767 per step) on all 256 CUs, instead of six dependent launches per step.
 //
 // Why: a decoder step is a chain of small dependent mat-vecs (27 M fp32 weights, batch <= 4).  As six launches per
-// step it cost 85 us/step: every launch pays a dependent boundary + a cold ramp of its weight stream, and the two
-// one-workgroup-per-utterance stages serialise the rest.  Here every workgroup (one per CU) owns a fixed slice of
-// the work for the whole block:
-//   * 5 attention-RNN units, 3 decoder-RNN units, 3 second-decoder-RNN units (4 gate rows each),
-//   * one row of the query projection (workgroups < attention_dim), one or two rows of the projection row set
-//     [mel | gate | first prenet layer folded through the mel projection], one row of the second prenet layer,
-//   * workgroups 0..3 additionally run the windowed location-sensitive attention of utterance b = workgroup id.
+// step it costs 85 us/step: every launch pays a dependent boundary + a cold ramp of its weight stream, and the two
+// one-workgroup-per-utterance stages serialise the rest.  Here every workgroup (one per CU) owns a fixed slice of the
+// work for the whole block of steps:
+//   * workgroups 0..251 ("LSTM workgroups"): 5-6 attention-RNN units, 3-4 decoder-RNN units and 3-4 second-decoder-RNN
+//     units each (4 gate rows per unit); plus one row of the query projection (workgroups < attention_dim), one or two
+//     rows of the projection row set [mel | gate | first prenet layer folded through the mel projection] and one or
+//     two rows of the second prenet layer;
+//   * workgroups 252..255: the windowed location-sensitive attention of utterance b = workgroup - 252, nothing else.
 // The columns of every mat-vec whose input is produced in the SAME step ("fresh": prenet -> attention RNN, context ->
-// decoder RNN, decoder hidden -> second decoder RNN, and the small rows) are weight-stationary in registers for the
-// whole launch; the columns whose input was produced earlier (recurrent states, previous context: 79 % of the weights)
-// are streamed from L2 / Infinity Cache in the gaps while the workgroup would otherwise wait for an exchange, into
-// partial pre-activations - so they never sit on the critical path.
+// decoder RNN, decoder hidden -> second decoder RNN, and the small rows) are weight-stationary on the CU for the whole
+// launch (LDS, the second decoder RNN's in registers); the columns whose input was produced earlier (recurrent states,
+// previous context: 79 % of the weights) are streamed from L2 / Infinity Cache after the workgroup has published its
+// result and before it polls for the next vector, into per-lane partial sums - off the critical path.
 // Exchanges: a vector produced by many workgroups and needed by all (att_h, q, ctx, dec_h, d2_h, h1, prenet) is
-// all-gathered through 8-byte {tag = step + 1, value} granules written with ONE agent-scope (write-through) store
-// each and polled with agent-scope loads: the data is the flag, no fences, no grid barrier (MI355X_MICROARCH.md,
-// "handoff"/"allgather" rows; cdna_hip_programming.md Guideline 16 R2).  Every poll loop is bounded; on a timeout
+// all-gathered through 8-byte {tag = step + 1, value} granules written with ONE agent-scope (write-through) store each
+// and polled with agent-scope loads: the data is the flag, no fences, no grid barrier (MI355X_MICROARCH.md
+// "handoff" / "allgather" rows; cdna_hip_programming.md Guideline 16 R2).  Every poll loop is bounded; on a timeout
 // the workgroup records (code, workgroup, phase, step) in the control words and the whole grid drains.
-// Granule buffers and control words are zeroed by the host wrapper before EVERY launch.
+// Granule tags are zeroed by the host wrapper before EVERY launch; the control words are sticky.
 #include "tacotron_plan.h"
 
 namespace ctts {
@@ -28,14 +29,22 @@ namespace {
 using namespace taco;
 
 constexpr int PD_WG = 256;          // workgroups == CUs of an MI355X
+constexpr int PD_LWG = 252;         // LSTM workgroups; the last PD_NB are the attention workgroups
 constexpr int PD_T = 512;           // threads per workgroup (8 waves, 2 per SIMD)
 constexpr int PD_NB = 4;            // batch, padded
-constexpr int PD_UA = 5, PD_UD = 3; // LSTM units per workgroup: 1280 / 256, 768 / 256
-constexpr int PD_RA = PD_UA * PD_WG, PD_RD = PD_UD * PD_WG, PD_P = 256, PD_DM = 512;
-constexpr int PD_AMAX = 256, PD_TMAX = 1024, PD_W = 33, PD_FMAX = 32, PD_KMAX = 31;
-// LDS vector store X: [b][n] per vector
+constexpr int PD_RA = 1280, PD_RD = 768, PD_P = 256, PD_DM = 512;
+constexpr int PD_UA = 6, PD_UD = 4; // max LSTM units per workgroup: ceil(1280 / 252), ceil(768 / 252)
+constexpr int PD_AMAX = 192, PD_TMAX = 1024, PD_W = 33, PD_FMAX = 32, PD_KMAX = 31;
+// LDS vector store X of an LSTM workgroup: [b][n] per vector
 constexpr int XP = 0, XCTX = XP + PD_NB * PD_P, XDEC = XCTX + PD_NB * PD_DM, XATT = XDEC + PD_NB * PD_RD,
               XD2 = XATT + PD_NB * PD_RA, XH1 = XD2 + PD_NB * PD_RD, X_FLOATS = XH1 + PD_NB * PD_P;
+// weight-stationary LDS images, one float4 per lane: [row][j][lane]
+constexpr int WFA = X_FLOATS;                                  // attention RNN, prenet columns: [24][1][64] float4
+constexpr int WFD = WFA + 4 * PD_UA * 1 * 64 * 4;              // decoder RNN, context columns:   [16][2][64] float4
+constexpr int WQ = WFD + 4 * PD_UD * 2 * 64 * 4;               // query row                        [5][64] float4
+constexpr int WPR = WQ + 5 * 64 * 4;                           // two projection rows              [2][5][64] float4
+constexpr int WW2 = WPR + 2 * 5 * 64 * 4;                      // two second-prenet rows           [2][1][64] float4
+constexpr int LSTM_FLOATS = WW2 + 2 * 64 * 4;
 constexpr unsigned PD_SPIN_LIMIT = 400000;   // polls per gather before giving up (~0.5 s)
 
 typedef unsigned long long u64;
@@ -55,10 +64,18 @@ struct PdArgs {
     unsigned memory, pm, lengths, att_h_in, dec_h_in, d2_h_in, att_h_out, dec_h_out, d2_h_out, att_c, dec_c, d2_c, ctx,
         prenet, w, cum, pos;                                                              // ws offsets
     unsigned g_p, g_atth, g_q, g_ctx, g_dech, g_d2h, g_h1, ctl;                           // xb offsets (u64 words)
+    u64* dbg;                   // optional [PD_WG][64 steps][16] stamps of s_memrealtime (100 MHz), NULL = off
     int A, F, K, R, n_mel, T, batch, nbc, step0, n_steps, max_steps, pd_rows;   // nbc: batch rows the workspace holds
 };
 
 __device__ __forceinline__ float pd_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// hardware exp2 / rcp forms (abs error ~1e-7, far inside the 1e-4 mel bound; the libm calls cost ~1 us per cell here)
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.8853900817779268f));
+}
 
 __device__ __forceinline__ void publish(u64* g, int idx, unsigned epoch, float v) {
     __hip_atomic_store((gu64*)g + idx, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
@@ -101,26 +118,44 @@ __device__ __forceinline__ float wave_total(float v) {
     return v;
 }
 
-// This wave's rows of one LSTM cell: local rows r = wave + 8 i (i < NR) of the workgroup's 4 U rows; local row r is
-// gate r / U of unit r % U, i.e. weight row (r / U) * H + wg * U + r % U.
-template <int U>
-__device__ __forceinline__ int cell_row(int r, int wg) { return (r / U) * (U * PD_WG) + wg * U + (r % U); }
+// N independent 64-lane sums, level by level: the N butterflies of a level are independent, so their cross-lane
+// operations pipeline instead of paying the exchange latency N x 6 times in sequence.
+template <int N>
+__device__ __forceinline__ void wave_totals(float (&v)[N]) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        float o[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) o[i] = __shfl_xor(v[i], off);
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] += o[i];
+    }
+}
 
-// acc[i][b] += sum over columns [col0, col0 + 256 NJ) of W[row_i][c] * x[b][c - col0 + xoff] for this lane's columns
-// (no cross-lane reduction).  NJ <= 3: at most NR * 3 sixteen-byte loads per lane in flight (8 waves -> >= 48 KiB per CU).
-template <int U, int NR, int NJ>
-__device__ __forceinline__ void stream_accum(const float* __restrict__ W, int ldw, int col0, const float* xs, int n, int xoff,
-                                             int wg, int wave, int lane, float (&acc)[NR][PD_NB]) {
-    float4 w[NR][NJ];
+// Units of a cell with hidden size H on LSTM workgroup wg: 252 workgroups, the first H - 252 * (H / 252) take one more.
+__device__ __forceinline__ int unit_count(int H, int wg) { return H / PD_LWG + (wg < H % PD_LWG ? 1 : 0); }
+__device__ __forceinline__ int unit_first(int H, int wg) { return wg * (H / PD_LWG) + min(wg, H % PD_LWG); }
+
+// Issue this wave's NR x NJ sixteen-byte weight loads of columns [col0, col0 + 256 NJ) of weight rows `rows` (< 0:
+// the wave has fewer rows); the values are consumed by fma_rows, so the L2 / Infinity-Cache latency of the whole
+// chunk is paid once.
+template <int NR, int NJ>
+__device__ __forceinline__ void issue_rows(const float* __restrict__ W, int ldw, int col0, const int (&rows)[NR], int lane,
+                                           float4 (&w)[NR][NJ]) {
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-        const int r = wave + 8 * i;
-        const bool valid = r < 4 * U;                                   // wave-uniform
-        const float* rp = W + (size_t)cell_row<U>(valid ? r : 0, wg) * ldw + col0 + 4 * lane;
+        const bool valid = rows[i] >= 0;                                  // wave-uniform
+        const float* rp = W + (size_t)(valid ? rows[i] : 0) * ldw + col0 + 4 * lane;
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
             w[i][j] = valid ? *reinterpret_cast<const float4*>(rp + 256 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+}
+
+// acc[i][b] += sum over this lane's columns of w[i][j] . x[b][xoff + c]   (per-lane partial sums, no reduction)
+template <int NR, int NJ>
+__device__ __forceinline__ void fma_rows(const float4 (&w)[NR][NJ], const float* xs, int n, int xoff, int lane,
+                                         float (&acc)[NR][PD_NB]) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         float4 x[PD_NB];
@@ -134,110 +169,112 @@ __device__ __forceinline__ void stream_accum(const float* __restrict__ W, int ld
     }
 }
 
-template <int U, int NR, int NJ>
-__device__ __forceinline__ void stream_rows(const float* __restrict__ W, int ldw, int col0, const float* xs, int n, int wg,
-                                            int wave, int lane, float (&acc)[NR][PD_NB]) {
+template <int NR, int NJ>
+__device__ __forceinline__ void early_rows(const float* __restrict__ W, int ldw, int col0, const int (&rows)[NR],
+                                           const float* xs, int n, int xoff, int lane, float (&acc)[NR][PD_NB]) {
+    float4 w[NR][NJ];
+    issue_rows<NR, NJ>(W, ldw, col0, rows, lane, w);
+    fma_rows<NR, NJ>(w, xs, n, xoff, lane, acc);
+}
+
+// gates[local row][b] = reduce over the wave (early partial sums + fresh columns) + bias
+template <int NR, int NJ>
+__device__ __forceinline__ void fresh_gates(const float4 (&wf)[NR][NJ], const float (&bias)[NR], const float* xs, int n,
+                                            const float (&early)[NR][PD_NB], float (*gates)[PD_NB], int nrows, int wave,
+                                            int lane) {
+    float tot[NR][PD_NB];
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int b = 0; b < PD_NB; ++b) tot[i][b] = early[i][b];
+    fma_rows<NR, NJ>(wf, xs, n, 0, lane, tot);
+    wave_totals<NR * PD_NB>(reinterpret_cast<float (&)[NR * PD_NB]>(tot));
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int r = wave + 8 * i;
+        if (r < nrows && lane < PD_NB)
+            gates[r][lane] = (lane == 0 ? tot[i][0] : lane == 1 ? tot[i][1] : lane == 2 ? tot[i][2] : tot[i][3]) + bias[i];
+    }
+}
+
+template <int NR>
+__device__ __forceinline__ void zero_rows(float (&acc)[NR][PD_NB]) {
 #pragma unroll
     for (int i = 0; i < NR; ++i)
 #pragma unroll
         for (int b = 0; b < PD_NB; ++b) acc[i][b] = 0.f;
-    if constexpr (NJ <= 3) {
-        stream_accum<U, NR, NJ>(W, ldw, col0, xs, n, 0, wg, wave, lane, acc);
-    } else {
-        stream_accum<U, NR, 3>(W, ldw, col0, xs, n, 0, wg, wave, lane, acc);
-        stream_accum<U, NR, NJ - 3>(W, ldw, col0 + 768, xs, n, 768, wg, wave, lane, acc);
-    }
-#pragma unroll
-    for (int i = 0; i < NR; ++i)
-#pragma unroll
-        for (int b = 0; b < PD_NB; ++b) acc[i][b] = wave_total(acc[i][b]);
 }
 
-// lanes 0..3 of the owning wave add the part into the partial pre-activations gp[local row][b]
-template <int U, int NR>
-__device__ __forceinline__ void add_partial(float (*gp)[PD_NB], const float (&acc)[NR][PD_NB], int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const int r = wave + 8 * i;
-        if (r < 4 * U && lane < PD_NB) {
-            const float v = lane == 0 ? acc[i][0] : lane == 1 ? acc[i][1] : lane == 2 ? acc[i][2] : acc[i][3];
-            gp[r][lane] += v;
-        }
-    }
-}
-
-template <int U, int NR, int NJ>
-__device__ __forceinline__ void early_part(const float* __restrict__ W, int ldw, int col0, const float* xs, int n,
-                                           float (*gp)[PD_NB], int wg, int wave, int lane) {
-    float acc[NR][PD_NB];
-    stream_rows<U, NR, NJ>(W, ldw, col0, xs, n, wg, wave, lane, acc);
-    add_partial<U, NR>(gp, acc, wave, lane);
-}
-
-// fresh columns out of registers: gates[r][b] = gp[r][b] + bias[r] + sum_c wf[i][j] . x[b][c]
-template <int U, int NR, int NJ>
-__device__ __forceinline__ void fresh_part(const float4 (&wf)[NR][NJ], const float (&bias)[NR], const float* xs, int n,
-                                           const float (*gp)[PD_NB], float (*gates)[PD_NB], int wave, int lane) {
-    float acc[NR][PD_NB];
-#pragma unroll
-    for (int i = 0; i < NR; ++i)
-#pragma unroll
-        for (int b = 0; b < PD_NB; ++b) acc[i][b] = 0.f;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        float4 x[PD_NB];
-#pragma unroll
-        for (int b = 0; b < PD_NB; ++b) x[b] = *reinterpret_cast<const float4*>(xs + b * n + 4 * (lane + 64 * j));
-#pragma unroll
-        for (int i = 0; i < NR; ++i)
-#pragma unroll
-            for (int b = 0; b < PD_NB; ++b)
-                acc[i][b] += wf[i][j].x * x[b].x + wf[i][j].y * x[b].y + wf[i][j].z * x[b].z + wf[i][j].w * x[b].w;
-    }
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const int r = wave + 8 * i;
-#pragma unroll
-        for (int b = 0; b < PD_NB; ++b) acc[i][b] = wave_total(acc[i][b]);
-        if (r < 4 * U && lane < PD_NB) {
-            const float v = lane == 0 ? acc[i][0] : lane == 1 ? acc[i][1] : lane == 2 ? acc[i][2] : acc[i][3];
-            gates[r][lane] = (gp[r][lane] + v) + bias[i];
-        }
-    }
-}
-
-// LSTM cell update of the workgroup's U units (layers.py:308-372, gate order i, f, g, o); publishes h'.
-template <int U>
+// LSTM cell update of the workgroup's U units (layers.py:308-372, gate order i, f, g, o; local row = gate * U + unit);
+// publishes h' at [b][first + unit].
 __device__ __forceinline__ void cell_update(const float (*gates)[PD_NB], float (*cst)[PD_NB], float (*hown)[PD_NB], u64* g,
-                                            unsigned epoch, int wg, int t) {
+                                            unsigned epoch, int H, int U, int first, int t) {
     if (t < U * PD_NB) {
         const int u = t / PD_NB, b = t % PD_NB;
-        const float gi = pd_sigmoid(gates[0 * U + u][b]), gf = pd_sigmoid(gates[1 * U + u][b]);
-        const float gg = tanhf(gates[2 * U + u][b]), go = pd_sigmoid(gates[3 * U + u][b]);
+        const float gi = fast_sigmoid(gates[0 * U + u][b]), gf = fast_sigmoid(gates[1 * U + u][b]);
+        const float gg = fast_tanh(gates[2 * U + u][b]), go = fast_sigmoid(gates[3 * U + u][b]);
         const float c = gf * cst[u][b] + gi * gg;
-        const float h = go * tanhf(c);
+        const float h = go * fast_tanh(c);
         cst[u][b] = c;
         hown[u][b] = h;
-        publish(g, b * (U * PD_WG) + wg * U + u, epoch, h);
+        publish(g, b * H + first + u, epoch, h);
+    }
+}
+
+// one row (NJ float4 per lane, LDS-resident) against NB staged vectors -> per-lane partial dot products
+template <int NJ>
+__device__ __forceinline__ void row_dots(const float* wrow, const float* xs, int n, int lane, float (&acc)[PD_NB]) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const float4 w = *reinterpret_cast<const float4*>(wrow + (j * 64 + lane) * 4);
+#pragma unroll
+        for (int b = 0; b < PD_NB; ++b) {
+            const float4 x = *reinterpret_cast<const float4*>(xs + b * n + 4 * (lane + 64 * j));
+            acc[b] += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w;
+        }
     }
 }
 
 struct AttnLds {
-    float pmw[PD_W * PD_AMAX];
-    float wloc[PD_FMAX * 2 * PD_KMAX];
-    float loc[PD_W][PD_FMAX + 1];
-    float wcat[2][PD_W + PD_KMAX - 1];
+    __attribute__((aligned(16))) float pmw[PD_W * PD_AMAX];
+    float memw[PD_W * PD_DM];                     // the memory window (context operand), staged before the query arrives
+    float loc[PD_W][PD_FMAX + 4];                 // rows 16-byte aligned: read as float4 broadcasts
+    float wcat[2][PD_W + PD_KMAX - 1 + 1];
+    float epart[3][64];                           // energies of the three 64-wide attention-dim blocks
     float q[PD_AMAX];
     float en[64], wts[64];
     float w[PD_TMAX], cum[PD_TMAX];
+    float cpart[4][PD_DM];                        // context partial sums of the four position groups
+    float ctx[PD_DM];
     float pos;
 };
+static_assert(sizeof(AttnLds) <= LSTM_FLOATS * sizeof(float), "the attention scratch shares the LSTM workgroups' LDS");
 
-// Windowed location-sensitive attention of utterance b (model.py:93-161, 49-65), the arithmetic of
-// attention_window_body (tacotron_decoder.hip) on 512 threads: previous / cumulative weights and the position live in
-// LDS across steps, the memory window is read from L2.  Publishes the context granules of b.
-__device__ __forceinline__ void pd_attention(const PdArgs& a, AttnLds& s, int b, unsigned epoch, int step, u64* g_ctx) {
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+#define PD_STAMP(k)                                                                                         \
+    do {                                                                                                    \
+        if (a.dbg && t == 0 && step - a.step0 < 64)                                                         \
+            a.dbg[((size_t)wg * 64 + (step - a.step0)) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();      \
+    } while (0)
+
+// Windowed location-sensitive attention of utterance b (model.py:93-161, 49-65) on a dedicated 512-thread workgroup.
+// Everything that does not change between steps lives on the CU for the whole launch: previous / cumulative weights and
+// the position in LDS, this thread's 62 location-conv taps (filter t % 32) and this lane's column of the location-dense
+// weight (attention dim `ad`) in registers.  Per step: one burst for the 33-row window of the processed memory, the
+// location conv as 33 x 32 outputs over 16 position groups, the energies as a 33 x 32 x A contraction with the
+// location features read as 16-byte LDS broadcasts, softmax on one wave, the context from a second burst (memory
+// window), published as granules.
+struct AttnRegs {
+    float wl[2 * PD_KMAX];      // location conv taps [c][j] of filter t % 32
+    float wd[PD_FMAX];          // location-dense weight column [f] of attention dim `ad`
+    float va;                   // v[ad]
+    int ad, pg;                 // energies: attention dim, position group (-1: this wave sits the energies out)
+};
+
+// Part 1, BEFORE the query of this step is known (it depends only on the previous step's weights and position, so it
+// runs while the LSTM workgroups are still in their attention-RNN phase): window start, the bursts for the 33-row
+// windows of the processed memory and of the memory, the location conv.  Returns the window start.
+__device__ __forceinline__ int pd_attention_pre(const PdArgs& a, AttnLds& s, const AttnRegs& r, int b) {
+    const int t = threadIdx.x;
     const int W = 2 * a.R + 1, padk = (a.K - 1) / 2;
     const int len = reinterpret_cast<const int*>(a.ws + a.lengths)[b];
     float cur = s.pos;
@@ -253,6 +290,12 @@ __device__ __forceinline__ void pd_attention(const PdArgs& a, AttnLds& s, int b,
             *reinterpret_cast<float4*>(s.pmw + tt * a.A + c4 * 4) =
                 *reinterpret_cast<const float4*>((a.ws + a.pm) + ((size_t)b * a.T + pos) * a.A + c4 * 4);
         }
+        for (int i = t; i < W * (PD_DM / 4); i += PD_T) {      // rows clamped: a masked row has weight exactly 0
+            const int tt = i / (PD_DM / 4), d4 = i % (PD_DM / 4);
+            const int pos = min(s0 + tt, a.T - 1);
+            *reinterpret_cast<float4*>(s.memw + tt * PD_DM + d4 * 4) =
+                *reinterpret_cast<const float4*>((a.ws + a.memory) + ((size_t)b * a.T + pos) * PD_DM + d4 * 4);
+        }
         for (int i = t; i < 2 * (W + a.K - 1); i += PD_T) {
             const int c = i / (W + a.K - 1), j = i % (W + a.K - 1);
             const int pos = s0 - padk + j;
@@ -261,49 +304,63 @@ __device__ __forceinline__ void pd_attention(const PdArgs& a, AttnLds& s, int b,
         }
     }
     __syncthreads();
-    for (int i = t; i < W * a.F; i += PD_T) {
-        const int tt = i / a.F, f = i % a.F;
-        float acc = 0.f;
-        for (int c = 0; c < 2; ++c)
-            for (int j = 0; j < a.K; ++j) acc = fmaf(s.wloc[(f * 2 + c) * a.K + j], s.wcat[c][tt + j], acc);
-        s.loc[tt][f] = acc;
-    }
-    __syncthreads();
-    {
-        constexpr int MAXP = 5;                  // ceil(33 / 8) window positions per wave
-        float epart[MAXP];
+    {   // location conv (model.py:56-60): thread = (filter f, position group g of 16); taps out of registers
+        const int f = t & 31, g = t >> 5;
+        for (int tt = g; tt < W; tt += 16) {
+            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXP; ++i) epart[i] = 0.f;
-        for (int ad = lane; ad < a.A; ad += 64) {
-            float wd[PD_FMAX];
-#pragma unroll
-            for (int f = 0; f < PD_FMAX; ++f) wd[f] = (a.blob + a.Wd)[(size_t)min(f, a.F - 1) * a.A + ad];
-            const float qa = s.q[ad], va = (a.blob + a.v)[ad];
-#pragma unroll
-            for (int i = 0; i < MAXP; ++i) {
-                const int tt = min(wv + 8 * i, W - 1);
-                float acc = 0.f;
-#pragma unroll
-                for (int f = 0; f < PD_FMAX; ++f) acc = fmaf(f < a.F ? wd[f] : 0.f, s.loc[tt][f], acc);
-                acc += qa;
-                acc += s.pmw[tt * a.A + ad];
-                const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc * 2.8853900817779268f));
-                epart[i] = fmaf(va, th, epart[i]);
+            for (int j = 0; j + 1 < PD_KMAX; j += 2) {
+                acc0 = fmaf(r.wl[j], j < a.K ? s.wcat[0][tt + j] : 0.f, acc0);
+                acc1 = fmaf(r.wl[PD_KMAX + j], j < a.K ? s.wcat[1][tt + j] : 0.f, acc1);
+                acc2 = fmaf(r.wl[j + 1], j + 1 < a.K ? s.wcat[0][tt + j + 1] : 0.f, acc2);
+                acc3 = fmaf(r.wl[PD_KMAX + j + 1], j + 1 < a.K ? s.wcat[1][tt + j + 1] : 0.f, acc3);
             }
-        }
-#pragma unroll
-        for (int i = 0; i < MAXP; ++i) {
-            const int tt = wv + 8 * i;
-            const float e = wave_total(epart[i]);
-            if (tt < W && lane == 0) {
-                const int pos = s0 + tt;
-                s.en[tt] = (pos < len && pos < a.T) ? e : -INFINITY;
-            }
+            acc0 = fmaf(r.wl[PD_KMAX - 1], PD_KMAX - 1 < a.K ? s.wcat[0][tt + PD_KMAX - 1] : 0.f, acc0);
+            acc1 = fmaf(r.wl[2 * PD_KMAX - 1], PD_KMAX - 1 < a.K ? s.wcat[1][tt + PD_KMAX - 1] : 0.f, acc1);
+            s.loc[tt][f] = (acc0 + acc2) + (acc1 + acc3);
         }
     }
+    return s0;      // (the caller's q gather ends with a workgroup barrier: loc / pmw / memw are visible after it)
+}
+
+// Part 2, on the critical path between the query and the context: energies, softmax, context, publish.
+__device__ __forceinline__ void pd_attention_post(const PdArgs& a, AttnLds& s, const AttnRegs& r, int b, int s0, unsigned epoch,
+                                                  int step, u64* g_ctx) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int wg = blockIdx.x;
+    const int W = 2 * a.R + 1;
+    const int len = reinterpret_cast<const int*>(a.ws + a.lengths)[b];
+    if (r.pg >= 0) {   // energies (model.py:107-112): wave = (64 attention dims, half of the window positions)
+        const int t0 = r.pg == 0 ? 0 : (W + 1) / 2, t1 = r.pg == 0 ? (W + 1) / 2 : W;
+        const bool live = r.ad < a.A;
+        const float qa = live ? s.q[r.ad] : 0.f;
+        float ev[(PD_W + 1) / 2];
+#pragma unroll
+        for (int i = 0; i < (PD_W + 1) / 2; ++i) {
+            const int tt = min(t0 + i, W - 1);
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;         // four chains: the 32-term dot is latency-bound otherwise
+#pragma unroll
+            for (int f4 = 0; f4 < PD_FMAX / 4; ++f4) {
+                const float4 l = *reinterpret_cast<const float4*>(&s.loc[tt][4 * f4]);     // wave-uniform address: broadcast
+                a0 = fmaf(r.wd[4 * f4 + 0], l.x, a0); a1 = fmaf(r.wd[4 * f4 + 1], l.y, a1);
+                a2 = fmaf(r.wd[4 * f4 + 2], l.z, a2); a3 = fmaf(r.wd[4 * f4 + 3], l.w, a3);
+            }
+            float acc = (a0 + a2) + (a1 + a3);
+            acc += qa;
+            acc += live ? s.pmw[tt * a.A + r.ad] : 0.f;
+            ev[i] = live ? r.va * fast_tanh(acc) : 0.f;
+        }
+        wave_totals<(PD_W + 1) / 2>(ev);
+#pragma unroll
+        for (int i = 0; i < (PD_W + 1) / 2; ++i)
+            if (lane == 0 && t0 + i < t1) s.epart[wv % 3][t0 + i] = ev[i];
+    }
     __syncthreads();
+    PD_STAMP(3);
     if (wv == 0) {
-        const float e = lane < W ? s.en[lane] : -INFINITY;
+        const int pos_l = s0 + lane;
+        float e = -INFINITY;
+        if (lane < W && pos_l < len && pos_l < a.T) e = (s.epart[0][lane] + s.epart[1][lane]) + s.epart[2][lane];
         float m = e;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
@@ -318,15 +375,28 @@ __device__ __forceinline__ void pd_attention(const PdArgs& a, AttnLds& s, int b,
         }
     }
     __syncthreads();
-    for (int d = t; d < PD_DM; d += PD_T) {
-        const float* mp = (a.ws + a.memory) + (size_t)b * a.T * PD_DM + d;
-        float acc = 0.f;
-#pragma unroll 11
-        for (int tt = 0; tt < W; ++tt) {
-            const int pos = min(s0 + tt, a.T - 1);
-            acc = fmaf(s0 + tt < a.T ? s.wts[tt] : 0.f, mp[(size_t)pos * PD_DM], acc);
+    PD_STAMP(4);
+    {   // context = sum_t w[t] * memory[t] out of the staged window: thread = (four dims, one of four position groups)
+        const int d4 = t & 127, grp = t >> 7;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int tt = grp + 4 * k;
+            if (tt < W) {
+                const float wgt = s0 + tt < a.T ? s.wts[tt] : 0.f;
+                const float4 m = *reinterpret_cast<const float4*>(s.memw + tt * PD_DM + 4 * d4);
+                acc.x = fmaf(wgt, m.x, acc.x); acc.y = fmaf(wgt, m.y, acc.y);
+                acc.z = fmaf(wgt, m.z, acc.z); acc.w = fmaf(wgt, m.w, acc.w);
+            }
         }
-        publish(g_ctx, b * PD_DM + d, epoch, acc);
+        *reinterpret_cast<float4*>(&s.cpart[grp][4 * d4]) = acc;
+    }
+    __syncthreads();
+    PD_STAMP(5);
+    for (int d = t; d < PD_DM; d += PD_T) {
+        const float c = (s.cpart[0][d] + s.cpart[1][d]) + (s.cpart[2][d] + s.cpart[3][d]);
+        s.ctx[d] = c;
+        publish(g_ctx, b * PD_DM + d, epoch, c);
     }
     for (int p = t; p < a.T; p += PD_T) {
         const float wgt = (p >= s0 && p < s0 + W) ? s.wts[p - s0] : 0.f;
@@ -337,43 +407,126 @@ __device__ __forceinline__ void pd_attention(const PdArgs& a, AttnLds& s, int b,
     __syncthreads();
 }
 
+// ---- the four attention workgroups --------------------------------------------------------------------------------
+__device__ __forceinline__ void attention_workgroup(const PdArgs& a, AttnLds& att, int wg) {
+    const int t = threadIdx.x;
+    const int b = wg - PD_LWG;
+    const bool real = b < a.batch;
+    unsigned* ctl = reinterpret_cast<unsigned*>(a.xb + a.ctl);
+    for (int p = t; p < a.T; p += PD_T) {
+        att.w[p] = real ? (a.ws + a.w)[(size_t)b * a.T + p] : 0.f;
+        att.cum[p] = real ? (a.ws + a.cum)[(size_t)b * a.T + p] : 0.f;
+    }
+    AttnRegs r;
+    {
+        const int f = t & 31, lane = t & 63, wv = t >> 6;
+#pragma unroll
+        for (int j = 0; j < PD_KMAX; ++j) {
+            r.wl[j] = (f < a.F && j < a.K) ? (a.blob + a.Wloc)[(f * 2 + 0) * a.K + j] : 0.f;
+            r.wl[PD_KMAX + j] = (f < a.F && j < a.K) ? (a.blob + a.Wloc)[(f * 2 + 1) * a.K + j] : 0.f;
+        }
+        r.pg = wv < 6 ? wv / 3 : -1;
+        r.ad = (wv % 3) * 64 + lane;
+        const bool live = r.pg >= 0 && r.ad < a.A;
+#pragma unroll
+        for (int ff = 0; ff < PD_FMAX; ++ff) r.wd[ff] = (live && ff < a.F) ? (a.blob + a.Wd)[(size_t)ff * a.A + r.ad] : 0.f;
+        r.va = live ? (a.blob + a.v)[r.ad] : 0.f;
+    }
+    for (int i = t; i < PD_W * (PD_FMAX + 4); i += PD_T) (&att.loc[0][0])[i] = 0.f;     // filters >= F stay zero
+    for (int d = t; d < PD_DM; d += PD_T) att.ctx[d] = 0.f;
+    if (t == 0) att.pos = real ? (a.ws + a.pos)[b] : 0.f;
+    __syncthreads();
+    for (int step = a.step0; step < a.step0 + a.n_steps; ++step) {
+        const unsigned epoch = (unsigned)step + 1u;
+        const int par = step & 1;
+        PD_STAMP(0);
+        const int s0 = real ? pd_attention_pre(a, att, r, b) : 0;
+        PD_STAMP(1);
+        const bool ok_ = gather<1>((a.xb + a.g_q) + (size_t)par * PD_NB * a.A + (size_t)b * a.A, a.A, att.q, epoch, ctl, t, 2u,
+                                   (unsigned)step);
+        if (__syncthreads_or(ok_ ? 0 : 1)) return;
+        PD_STAMP(2);
+        if (real) {
+            pd_attention_post(a, att, r, b, s0, epoch, step, (a.xb + a.g_ctx) + (size_t)par * PD_NB * PD_DM);
+        } else {
+            for (int d = t; d < PD_DM; d += PD_T) publish((a.xb + a.g_ctx) + (size_t)par * PD_NB * PD_DM, b * PD_DM + d, epoch, 0.f);
+        }
+        PD_STAMP(6);
+    }
+    if (real) {
+        for (int p = t; p < a.T; p += PD_T) { (a.ws + a.w)[(size_t)b * a.T + p] = att.w[p]; (a.ws + a.cum)[(size_t)b * a.T + p] = att.cum[p]; }
+        if (t == 0) (a.ws + a.pos)[b] = att.pos;
+        for (int d = t; d < PD_DM; d += PD_T) (a.ws + a.ctx)[b * PD_DM + d] = att.ctx[d];
+    }
+}
+
 __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a) {
-    __shared__ __attribute__((aligned(16))) float X[X_FLOATS];
-    __shared__ float gpA[2][4 * PD_UA][PD_NB], gpD[2][4 * PD_UD][PD_NB], gp2[2][4 * PD_UD][PD_NB];
+    __shared__ __attribute__((aligned(16))) float L[LSTM_FLOATS];
     __shared__ float gates[4 * PD_UA][PD_NB];
     __shared__ float cA[PD_UA][PD_NB], cD[PD_UD][PD_NB], c2[PD_UD][PD_NB];
     __shared__ float hA[PD_UA][PD_NB], hD[PD_UD][PD_NB], h2[PD_UD][PD_NB];
-    __shared__ float pown[PD_NB];
-    __shared__ AttnLds att;
+    __shared__ float pown[2][PD_NB];
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wg = blockIdx.x;
-    const int I_att = PD_P + PD_DM + PD_RD, I_dec = PD_RA + PD_DM, Dp = PD_RD + PD_DM;
-    const bool is_attn = wg < PD_NB;
-    if (__hip_atomic_load((gu32*)reinterpret_cast<unsigned*>(a.xb + a.ctl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+    unsigned* ctl = reinterpret_cast<unsigned*>(a.xb + a.ctl);
+    if (__hip_atomic_load((gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
         return;                                  // an earlier launch on this exchange buffer gave up: stay down
-
-    // ---- weight-stationary part: the fresh columns and the small rows, in registers for the whole launch ----
-    float4 wfA[3][1], wfD[2][2], wf2[2][3], wsm[5];
-    float bA[3], bD[2], b2[2], bsm = 0.f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int r = wave + 8 * i;
-        const bool valid = r < 4 * PD_UA;
-        const int row = cell_row<PD_UA>(valid ? r : 0, wg);
-        wfA[i][0] = valid ? *reinterpret_cast<const float4*>((a.blob + a.att_wih) + (size_t)row * I_att + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
-        bA[i] = valid ? (a.blob + a.att_bih)[row] + (a.blob + a.att_bhh)[row] : 0.f;
+    if (wg >= PD_LWG) {
+        attention_workgroup(a, *reinterpret_cast<AttnLds*>(L), wg);
+        return;
     }
+    float* X = L;
+    const int I_att = PD_P + PD_DM + PD_RD, I_dec = PD_RA + PD_DM, Dp = PD_RD + PD_DM;
+    const int UA = unit_count(PD_RA, wg), FA = unit_first(PD_RA, wg);
+    const int UD = unit_count(PD_RD, wg), FD = unit_first(PD_RD, wg);
+
+    // this wave's weight rows (row-per-wave: local rows wave, wave + 8, wave + 16; local row r = gate r / U of unit r % U)
+    int rowA[3], rowD[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const int r = wave + 8 * i; rowA[i] = r < 4 * UA ? (r / UA) * PD_RA + FA + r % UA : -1; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int r = wave + 8 * i; rowD[i] = r < 4 * UD ? (r / UD) * PD_RD + FD + r % UD : -1; }
+
+    // ---- weight-stationary part.  LDS: fresh columns of the attention / decoder RNN and the small rows; registers: the
+    // second decoder RNN's fresh columns (its whole W_ih) and the biases.
+    for (int i = t; i < 4 * UA * 64; i += PD_T) {
+        const int r = i >> 6, l = i & 63;
+        const int row = (r / UA) * PD_RA + FA + r % UA;
+        *reinterpret_cast<float4*>(L + WFA + i * 4) = *reinterpret_cast<const float4*>((a.blob + a.att_wih) + (size_t)row * I_att + 4 * l);
+    }
+    for (int i = t; i < 4 * UD * 2 * 64; i += PD_T) {
+        const int r = i >> 7, j = (i >> 6) & 1, l = i & 63;
+        const int row = (r / UD) * PD_RD + FD + r % UD;
+        *reinterpret_cast<float4*>(L + WFD + i * 4) =
+            *reinterpret_cast<const float4*>((a.blob + a.dec_wih) + (size_t)row * I_dec + PD_RA + 4 * (l + 64 * j));
+    }
+    const int q_row = wg < a.A ? wg : -1;
+    const int pr_row0 = wg, pr_row1 = wg + PD_LWG < a.pd_rows ? wg + PD_LWG : -1;
+    const int w2_row0 = wg, w2_row1 = wg + PD_LWG < PD_P ? wg + PD_LWG : -1;
+    for (int i = t; i < 5 * 64; i += PD_T) {
+        const int j = i >> 6, l = i & 63;
+        if (q_row >= 0)
+            *reinterpret_cast<float4*>(L + WQ + i * 4) = *reinterpret_cast<const float4*>((a.blob + a.Wq) + (size_t)q_row * PD_RA + 4 * (l + 64 * j));
+        *reinterpret_cast<float4*>(L + WPR + i * 4) = *reinterpret_cast<const float4*>((a.blob + a.Wproj) + (size_t)pr_row0 * Dp + 4 * (l + 64 * j));
+        if (pr_row1 >= 0)
+            *reinterpret_cast<float4*>(L + WPR + 5 * 64 * 4 + i * 4) =
+                *reinterpret_cast<const float4*>((a.blob + a.Wproj) + (size_t)pr_row1 * Dp + 4 * (l + 64 * j));
+    }
+    if (t < 64) {
+        *reinterpret_cast<float4*>(L + WW2 + t * 4) = *reinterpret_cast<const float4*>((a.blob + a.W2) + (size_t)w2_row0 * PD_P + 4 * t);
+        if (w2_row1 >= 0)
+            *reinterpret_cast<float4*>(L + WW2 + 64 * 4 + t * 4) = *reinterpret_cast<const float4*>((a.blob + a.W2) + (size_t)w2_row1 * PD_P + 4 * t);
+    }
+    float4 wf2[2][3];
+    float bA[3], bD[2], b2[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) bA[i] = rowA[i] >= 0 ? (a.blob + a.att_bih)[rowA[i]] + (a.blob + a.att_bhh)[rowA[i]] : 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int r = wave + 8 * i;
-        const bool valid = r < 4 * PD_UD;
-        const int row = cell_row<PD_UD>(valid ? r : 0, wg);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            wfD[i][j] = valid ? *reinterpret_cast<const float4*>((a.blob + a.dec_wih) + (size_t)row * I_dec + PD_RA + 4 * (lane + 64 * j))
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool valid = rowD[i] >= 0;
+        const int row = valid ? rowD[i] : 0;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
             wf2[i][j] = valid ? *reinterpret_cast<const float4*>((a.blob + a.d2_wih) + (size_t)row * PD_RD + 4 * (lane + 64 * j))
@@ -381,26 +534,7 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
         bD[i] = valid ? (a.blob + a.dec_bih)[row] + (a.blob + a.dec_bhh)[row] : 0.f;
         b2[i] = valid ? (a.blob + a.d2_bih)[row] + (a.blob + a.d2_bhh)[row] : 0.f;
     }
-    // small rows: wave 0 = query row wg; wave 1 = projection row wg; wave 2 = projection row 256 + wg; wave 3 = W2 row wg
-    int sm_row = -1;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) wsm[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (wave == 0 && wg < a.A) {
-        sm_row = wg;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) wsm[j] = *reinterpret_cast<const float4*>((a.blob + a.Wq) + (size_t)wg * PD_RA + 4 * (lane + 64 * j));
-    } else if (wave == 1 || wave == 2) {
-        const int row = wave == 1 ? wg : PD_WG + wg;
-        if (row < a.pd_rows) {
-            sm_row = row;
-#pragma unroll
-            for (int j = 0; j < 5; ++j) wsm[j] = *reinterpret_cast<const float4*>((a.blob + a.Wproj) + (size_t)row * Dp + 4 * (lane + 64 * j));
-            bsm = (a.blob + a.bproj)[row];
-        }
-    } else if (wave == 3) {
-        sm_row = wg;
-        wsm[0] = *reinterpret_cast<const float4*>((a.blob + a.W2) + (size_t)wg * PD_P + 4 * lane);
-    }
+    const float bpr = wave == 1 ? (a.blob + a.bproj)[pr_row0] : (wave == 2 && pr_row1 >= 0) ? (a.blob + a.bproj)[pr_row1] : 0.f;
 
     // ---- entry: state of step0 from the workspace (written by the init / the previous launch).  The workspace holds
     // nbc <= 4 batch rows per state array; the rows above stay zero here and are never written back.
@@ -412,194 +546,193 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
         X[XD2 + i] = i / PD_RD < nbc ? (a.ws + a.d2_h_in)[i] : 0.f;
     }
     for (int i = t; i < PD_NB * PD_RA; i += PD_T) X[XATT + i] = i / PD_RA < nbc ? (a.ws + a.att_h_in)[i] : 0.f;
-    if (t < PD_UA * PD_NB) {
+    if (t < UA * PD_NB) {
         const int u = t / PD_NB, b = t % PD_NB;
-        cA[u][b] = b < nbc ? (a.ws + a.att_c)[b * PD_RA + wg * PD_UA + u] : 0.f;
-        hA[u][b] = b < nbc ? (a.ws + a.att_h_in)[b * PD_RA + wg * PD_UA + u] : 0.f;
+        cA[u][b] = b < nbc ? (a.ws + a.att_c)[b * PD_RA + FA + u] : 0.f;
+        hA[u][b] = b < nbc ? (a.ws + a.att_h_in)[b * PD_RA + FA + u] : 0.f;
     }
-    if (t < PD_UD * PD_NB) {
+    if (t < UD * PD_NB) {
         const int u = t / PD_NB, b = t % PD_NB;
-        cD[u][b] = b < nbc ? (a.ws + a.dec_c)[b * PD_RD + wg * PD_UD + u] : 0.f;
-        hD[u][b] = b < nbc ? (a.ws + a.dec_h_in)[b * PD_RD + wg * PD_UD + u] : 0.f;
-        c2[u][b] = b < nbc ? (a.ws + a.d2_c)[b * PD_RD + wg * PD_UD + u] : 0.f;
-        h2[u][b] = b < nbc ? (a.ws + a.d2_h_in)[b * PD_RD + wg * PD_UD + u] : 0.f;
+        cD[u][b] = b < nbc ? (a.ws + a.dec_c)[b * PD_RD + FD + u] : 0.f;
+        hD[u][b] = b < nbc ? (a.ws + a.dec_h_in)[b * PD_RD + FD + u] : 0.f;
+        c2[u][b] = b < nbc ? (a.ws + a.d2_c)[b * PD_RD + FD + u] : 0.f;
+        h2[u][b] = b < nbc ? (a.ws + a.d2_h_in)[b * PD_RD + FD + u] : 0.f;
     }
-    if (t < PD_NB) pown[t] = t < nbc ? (a.ws + a.prenet)[t * PD_P + wg] : 0.f;
-    for (int i = t; i < 2 * 4 * PD_UA * PD_NB; i += PD_T) (&gpA[0][0][0])[i] = 0.f;
-    for (int i = t; i < 2 * 4 * PD_UD * PD_NB; i += PD_T) { (&gpD[0][0][0])[i] = 0.f; (&gp2[0][0][0])[i] = 0.f; }
-    if (is_attn) {
-        const int b = wg;
-        const bool real = b < a.batch;
-        for (int p = t; p < a.T; p += PD_T) {
-            att.w[p] = real ? (a.ws + a.w)[(size_t)b * a.T + p] : 0.f;
-            att.cum[p] = real ? (a.ws + a.cum)[(size_t)b * a.T + p] : 0.f;
-        }
-        for (int i = t; i < a.F * 2 * a.K; i += PD_T) att.wloc[i] = (a.blob + a.Wloc)[i];
-        if (t == 0) att.pos = real ? (a.ws + a.pos)[b] : 0.f;
+    if (t < 2 * PD_NB) {
+        const int k = t / PD_NB, b = t % PD_NB;
+        const int row = k == 0 ? w2_row0 : w2_row1;
+        pown[k][b] = (row >= 0 && b < nbc) ? (a.ws + a.prenet)[b * PD_P + row] : 0.f;
     }
     __syncthreads();
-    int cur = 0;
-    // early parts of step0, in the order the loop accumulates them
-    early_part<PD_UA, 3, 2>((a.blob + a.att_wih), I_att, PD_P, X + XCTX, PD_DM, gpA[cur], wg, wave, lane);
-    early_part<PD_UA, 3, 3>((a.blob + a.att_wih), I_att, PD_P + PD_DM, X + XDEC, PD_RD, gpA[cur], wg, wave, lane);
-    early_part<PD_UA, 3, 5>((a.blob + a.att_whh), PD_RA, 0, X + XATT, PD_RA, gpA[cur], wg, wave, lane);
-    early_part<PD_UD, 2, 3>((a.blob + a.dec_whh), PD_RD, 0, X + XDEC, PD_RD, gpD[cur], wg, wave, lane);
-    early_part<PD_UD, 2, 3>((a.blob + a.d2_whh), PD_RD, 0, X + XD2, PD_RD, gp2[cur], wg, wave, lane);
+    // per-lane partial sums of the early columns of the next cell evaluations (reduced over the wave only in the fresh
+    // phase): one generation of each is live at a time.  Early parts of step0, in the order the loop accumulates them:
+    float eA[3][PD_NB], eD[2][PD_NB], e2[2][PD_NB];
+    zero_rows<3>(eA); zero_rows<2>(eD); zero_rows<2>(e2);
+    early_rows<3, 2>((a.blob + a.att_wih), I_att, PD_P, rowA, X + XCTX, PD_DM, 0, lane, eA);
+    early_rows<3, 3>((a.blob + a.att_wih), I_att, PD_P + PD_DM, rowA, X + XDEC, PD_RD, 0, lane, eA);
+    early_rows<3, 3>((a.blob + a.att_whh), PD_RA, 0, rowA, X + XATT, PD_RA, 0, lane, eA);
+    early_rows<3, 2>((a.blob + a.att_whh), PD_RA, 768, rowA, X + XATT, PD_RA, 768, lane, eA);
+    early_rows<2, 3>((a.blob + a.dec_whh), PD_RD, 0, rowD, X + XDEC, PD_RD, 0, lane, eD);
+    early_rows<2, 3>((a.blob + a.d2_whh), PD_RD, 0, rowD, X + XD2, PD_RD, 0, lane, e2);
     __syncthreads();
 
     bool fail = false;
 #define PD_GATHER(NPT, buf, count, dst, phase)                                                                       \
     do {                                                                                                               \
-        const bool ok_ = gather<NPT>((buf) + (size_t)par * (count), (count), (dst), epoch, reinterpret_cast<unsigned*>(a.xb + a.ctl), t, (phase), (unsigned)step); \
+        const bool ok_ = gather<NPT>((buf) + (size_t)par * (count), (count), (dst), epoch, ctl, t, (phase), (unsigned)step); \
         if (__syncthreads_or(ok_ ? 0 : 1)) { fail = true; }                                                            \
     } while (0)
 
     for (int step = a.step0; step < a.step0 + a.n_steps && !fail; ++step) {
         const unsigned epoch = (unsigned)step + 1u;
-        const int par = step & 1, nxt = cur ^ 1;
+        const int par = step & 1;
+        PD_STAMP(0);
         // ---- A: attention RNN on the fresh prenet columns (model.py:707-717)
-        fresh_part<PD_UA, 3, 1>(wfA, bA, X + XP, PD_P, gpA[cur], gates, wave, lane);
+        {
+            float4 wf[3][1];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) wf[i][0] = *reinterpret_cast<const float4*>(L + WFA + (((wave + 8 * i) % (4 * PD_UA)) * 64 + lane) * 4);
+            fresh_gates<3, 1>(wf, bA, X + XP, PD_P, eA, gates, 4 * UA, wave, lane);
+        }
+        zero_rows<3>(eA);
         __syncthreads();
-        cell_update<PD_UA>(gates, cA, hA, (a.xb + a.g_atth) + (size_t)par * PD_NB * PD_RA, epoch, wg, t);
-        // reset the partial sums of step + 1 while waiting (own rows only, written by lanes 0..3 of the owning wave later)
-        for (int i = t; i < 4 * PD_UA * PD_NB; i += PD_T) (&gpA[nxt][0][0])[i] = 0.f;
-        for (int i = t; i < 4 * PD_UD * PD_NB; i += PD_T) { (&gpD[nxt][0][0])[i] = 0.f; (&gp2[nxt][0][0])[i] = 0.f; }
+        cell_update(gates, cA, hA, (a.xb + a.g_atth) + (size_t)par * PD_NB * PD_RA, epoch, PD_RA, UA, FA, t);
+        PD_STAMP(1);
         PD_GATHER(10, (a.xb + a.g_atth), PD_NB * PD_RA, X + XATT, 1u);
+        PD_STAMP(2);
         if (fail) break;
-        // ---- B: query row (model.py:126 query_layer), then the decoder RNN's att_h columns as an early part
-        if (wave == 0 && sm_row >= 0) {
-            float q[PD_NB];
+        // ---- B: query row (model.py:126 query_layer); then, while the attention workgroups work, the columns that
+        // multiply att_h(step): the decoder RNN's (needed in C) and the attention RNN's recurrent ones (step + 1)
+        if (wave == 0 && q_row >= 0) {
+            float q[PD_NB] = {0.f, 0.f, 0.f, 0.f};
+            row_dots<5>(L + WQ, X + XATT, PD_RA, lane, q);
 #pragma unroll
-            for (int b = 0; b < PD_NB; ++b) {
-                float acc = 0.f;
-#pragma unroll
-                for (int j = 0; j < 5; ++j) {
-                    const float4 x = *reinterpret_cast<const float4*>(X + XATT + b * PD_RA + 4 * (lane + 64 * j));
-                    acc += wsm[j].x * x.x + wsm[j].y * x.y + wsm[j].z * x.z + wsm[j].w * x.w;
-                }
-                q[b] = wave_total(acc);
-            }
+            for (int b = 0; b < PD_NB; ++b) q[b] = wave_total(q[b]);
             if (lane < PD_NB)
-                publish((a.xb + a.g_q) + (size_t)par * PD_NB * a.A, lane * a.A + sm_row, epoch,
+                publish((a.xb + a.g_q) + (size_t)par * PD_NB * a.A, lane * a.A + q_row, epoch,
                         lane == 0 ? q[0] : lane == 1 ? q[1] : lane == 2 ? q[2] : q[3]);
         }
-        early_part<PD_UD, 2, 5>((a.blob + a.dec_wih), I_dec, 0, X + XATT, PD_RA, gpD[cur], wg, wave, lane);
-        if (is_attn) {
-            const int b = wg;
-            const bool ok_ = gather<1>((a.xb + a.g_q) + (size_t)par * PD_NB * a.A + (size_t)b * a.A, a.A, att.q, epoch, reinterpret_cast<unsigned*>(a.xb + a.ctl), t, 2u, (unsigned)step);
-            if (__syncthreads_or(ok_ ? 0 : 1)) { fail = true; break; }
-            if (b < a.batch) {
-                pd_attention(a, att, b, epoch, step, (a.xb + a.g_ctx) + (size_t)par * PD_NB * PD_DM);
-            } else {
-                for (int d = t; d < PD_DM; d += PD_T) publish((a.xb + a.g_ctx) + (size_t)par * PD_NB * PD_DM, b * PD_DM + d, epoch, 0.f);
-            }
-        }
+        early_rows<2, 3>((a.blob + a.dec_wih), I_dec, 0, rowD, X + XATT, PD_RA, 0, lane, eD);
+        early_rows<2, 2>((a.blob + a.dec_wih), I_dec, 768, rowD, X + XATT, PD_RA, 768, lane, eD);
+        PD_STAMP(3);
         PD_GATHER(4, (a.xb + a.g_ctx), PD_NB * PD_DM, X + XCTX, 3u);
+        PD_STAMP(4);
         if (fail) break;
         // ---- C: decoder RNN on the fresh context columns (model.py:741-747)
-        fresh_part<PD_UD, 2, 2>(wfD, bD, X + XCTX, PD_DM, gpD[cur], gates, wave, lane);
+        {
+            float4 wf[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    wf[i][j] = *reinterpret_cast<const float4*>(L + WFD + ((((wave + 8 * i) % (4 * PD_UD)) * 2 + j) * 64 + lane) * 4);
+            fresh_gates<2, 2>(wf, bD, X + XCTX, PD_DM, eD, gates, 4 * UD, wave, lane);
+        }
+        zero_rows<2>(eD);
         __syncthreads();
-        cell_update<PD_UD>(gates, cD, hD, (a.xb + a.g_dech) + (size_t)par * PD_NB * PD_RD, epoch, wg, t);
-        early_part<PD_UA, 3, 2>((a.blob + a.att_wih), I_att, PD_P, X + XCTX, PD_DM, gpA[nxt], wg, wave, lane);
+        cell_update(gates, cD, hD, (a.xb + a.g_dech) + (size_t)par * PD_NB * PD_RD, epoch, PD_RD, UD, FD, t);
+        early_rows<3, 2>((a.blob + a.att_wih), I_att, PD_P, rowA, X + XCTX, PD_DM, 0, lane, eA);
+        PD_STAMP(5);
         PD_GATHER(6, (a.xb + a.g_dech), PD_NB * PD_RD, X + XDEC, 4u);
+        PD_STAMP(6);
         if (fail) break;
         // ---- D: second decoder RNN on the fresh decoder-hidden columns (model.py:749-755)
-        fresh_part<PD_UD, 2, 3>(wf2, b2, X + XDEC, PD_RD, gp2[cur], gates, wave, lane);
+        fresh_gates<2, 3>(wf2, b2, X + XDEC, PD_RD, e2, gates, 4 * UD, wave, lane);
+        zero_rows<2>(e2);
         __syncthreads();
-        cell_update<PD_UD>(gates, c2, h2, (a.xb + a.g_d2h) + (size_t)par * PD_NB * PD_RD, epoch, wg, t);
-        early_part<PD_UA, 3, 3>((a.blob + a.att_wih), I_att, PD_P + PD_DM, X + XDEC, PD_RD, gpA[nxt], wg, wave, lane);
-        early_part<PD_UD, 2, 3>((a.blob + a.dec_whh), PD_RD, 0, X + XDEC, PD_RD, gpD[nxt], wg, wave, lane);
+        cell_update(gates, c2, h2, (a.xb + a.g_d2h) + (size_t)par * PD_NB * PD_RD, epoch, PD_RD, UD, FD, t);
+        early_rows<3, 3>((a.blob + a.att_wih), I_att, PD_P + PD_DM, rowA, X + XDEC, PD_RD, 0, lane, eA);
+        PD_STAMP(7);
         PD_GATHER(6, (a.xb + a.g_d2h), PD_NB * PD_RD, X + XD2, 5u);
+        PD_STAMP(8);
         if (fail) break;
         // ---- E: projection row set on [dec_h + d2_h | ctx] (model.py:757-765; rows: mel, gate, folded prenet layer 1)
         const bool have_next = step + 1 < a.max_steps;
-        if ((wave == 1 || wave == 2) && sm_row >= 0) {
-            float o[PD_NB];
+        if (wave == 1 || (wave == 2 && pr_row1 >= 0)) {
+            const int row = wave == 1 ? pr_row0 : pr_row1;
+            const float* wrow = L + WPR + (wave == 1 ? 0 : 5 * 64 * 4);
+            float o[PD_NB] = {0.f, 0.f, 0.f, 0.f}, o2[PD_NB] = {0.f, 0.f, 0.f, 0.f};
+            row_dots<3>(wrow, X + XDEC, PD_RD, lane, o);                  // W[:, :768] . dec_h
+            row_dots<3>(wrow, X + XD2, PD_RD, lane, o2);                  // W[:, :768] . d2_h   (the residual sum, model.py:755)
+            row_dots<2>(wrow + 3 * 64 * 4, X + XCTX, PD_DM, lane, o);     // W[:, 768:] . ctx
 #pragma unroll
-            for (int b = 0; b < PD_NB; ++b) {
-                float acc = 0.f;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const float4 x1 = *reinterpret_cast<const float4*>(X + XDEC + b * PD_RD + 4 * (lane + 64 * j));
-                    const float4 x2 = *reinterpret_cast<const float4*>(X + XD2 + b * PD_RD + 4 * (lane + 64 * j));
-                    acc += wsm[j].x * (x1.x + x2.x) + wsm[j].y * (x1.y + x2.y) + wsm[j].z * (x1.z + x2.z) + wsm[j].w * (x1.w + x2.w);
-                }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float4 x = *reinterpret_cast<const float4*>(X + XCTX + b * PD_DM + 4 * (lane + 64 * j));
-                    acc += wsm[3 + j].x * x.x + wsm[3 + j].y * x.y + wsm[3 + j].z * x.z + wsm[3 + j].w * x.w;
-                }
-                o[b] = wave_total(acc) + bsm;
-            }
+            for (int b = 0; b < PD_NB; ++b) o[b] = wave_total(o[b] + o2[b]) + bpr;
             if (lane < PD_NB) {
                 const int b = lane;
                 const float val = lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3];
-                if (sm_row < a.n_mel) {
-                    if (b < a.batch) a.mel_out[((size_t)b * a.n_mel + sm_row) * a.max_steps + step] = val;
-                } else if (sm_row == a.n_mel) {
+                if (row < a.n_mel) {
+                    if (b < a.batch) a.mel_out[((size_t)b * a.n_mel + row) * a.max_steps + step] = val;
+                } else if (row == a.n_mel) {
                     if (b < a.batch) a.gate_out[(size_t)b * a.max_steps + step] = val;
                 } else if (have_next) {     // first prenet layer of step + 1: relu, always-on dropout (model.py:187-190)
-                    const int j = sm_row - a.n_mel - 1;
+                    const int j = row - a.n_mel - 1;
                     const bool kp = b < a.batch && a.keep[(((size_t)(step + 1) * 2 + 0) * a.batch + b) * PD_P + j] != 0;
                     publish((a.xb + a.g_h1) + (size_t)par * PD_NB * PD_P, b * PD_P + j, epoch, kp ? fmaxf(val, 0.f) * 2.0f : 0.0f);
                 }
             }
         }
-        early_part<PD_UD, 2, 3>((a.blob + a.d2_whh), PD_RD, 0, X + XD2, PD_RD, gp2[nxt], wg, wave, lane);
+        early_rows<2, 3>((a.blob + a.d2_whh), PD_RD, 0, rowD, X + XD2, PD_RD, 0, lane, e2);
         if (have_next) {
+            // the two prenet exchanges below are pure latency: the recurrent columns of step + 1 fill them
+            early_rows<3, 3>((a.blob + a.att_whh), PD_RA, 0, rowA, X + XATT, PD_RA, 0, lane, eA);
+            early_rows<3, 2>((a.blob + a.att_whh), PD_RA, 768, rowA, X + XATT, PD_RA, 768, lane, eA);
+            PD_STAMP(9);
             PD_GATHER(2, (a.xb + a.g_h1), PD_NB * PD_P, X + XH1, 6u);
+            PD_STAMP(10);
             if (fail) break;
-            // ---- F: second prenet layer row
-            if (wave == 3) {
-                float o[PD_NB];
+            // ---- F: second prenet layer rows
+            if (wave == 3 || (wave == 4 && w2_row1 >= 0)) {
+                const int k = wave - 3;
+                const int row = k == 0 ? w2_row0 : w2_row1;
+                float o[PD_NB] = {0.f, 0.f, 0.f, 0.f};
+                row_dots<1>(L + WW2 + k * 64 * 4, X + XH1, PD_P, lane, o);
 #pragma unroll
-                for (int b = 0; b < PD_NB; ++b) {
-                    const float4 x = *reinterpret_cast<const float4*>(X + XH1 + b * PD_P + 4 * lane);
-                    o[b] = wave_total(wsm[0].x * x.x + wsm[0].y * x.y + wsm[0].z * x.z + wsm[0].w * x.w);
-                }
+                for (int b = 0; b < PD_NB; ++b) o[b] = wave_total(o[b]);
                 if (lane < PD_NB) {
                     const int b = lane;
                     const float val = lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3];
-                    const bool kp = b < a.batch && a.keep[(((size_t)(step + 1) * 2 + 1) * a.batch + b) * PD_P + sm_row] != 0;
+                    const bool kp = b < a.batch && a.keep[(((size_t)(step + 1) * 2 + 1) * a.batch + b) * PD_P + row] != 0;
                     const float pv = kp ? fmaxf(val, 0.f) * 2.0f : 0.0f;
-                    pown[b] = pv;
-                    publish((a.xb + a.g_p) + (size_t)par * PD_NB * PD_P, b * PD_P + sm_row, epoch, pv);
+                    pown[k][b] = pv;
+                    publish((a.xb + a.g_p) + (size_t)par * PD_NB * PD_P, b * PD_P + row, epoch, pv);
                 }
             }
-            early_part<PD_UA, 3, 5>((a.blob + a.att_whh), PD_RA, 0, X + XATT, PD_RA, gpA[nxt], wg, wave, lane);
+            early_rows<2, 3>((a.blob + a.dec_whh), PD_RD, 0, rowD, X + XDEC, PD_RD, 0, lane, eD);
+            PD_STAMP(11);
             PD_GATHER(2, (a.xb + a.g_p), PD_NB * PD_P, X + XP, 7u);
+            PD_STAMP(12);
             if (fail) break;
         }
-        cur = nxt;
     }
 #undef PD_GATHER
     if (fail) return;
     // ---- exit: this workgroup's slices of the state for the next launch
     __syncthreads();
-    if (t < PD_UA * PD_NB) {
+    if (t < UA * PD_NB) {
         const int u = t / PD_NB, b = t % PD_NB;
         if (b < nbc) {
-            (a.ws + a.att_h_out)[b * PD_RA + wg * PD_UA + u] = hA[u][b];
-            (a.ws + a.att_c)[b * PD_RA + wg * PD_UA + u] = cA[u][b];
+            (a.ws + a.att_h_out)[b * PD_RA + FA + u] = hA[u][b];
+            (a.ws + a.att_c)[b * PD_RA + FA + u] = cA[u][b];
         }
     }
-    if (t < PD_UD * PD_NB) {
+    if (t < UD * PD_NB) {
         const int u = t / PD_NB, b = t % PD_NB;
         if (b < nbc) {
-            (a.ws + a.dec_h_out)[b * PD_RD + wg * PD_UD + u] = hD[u][b];
-            (a.ws + a.dec_c)[b * PD_RD + wg * PD_UD + u] = cD[u][b];
-            (a.ws + a.d2_h_out)[b * PD_RD + wg * PD_UD + u] = h2[u][b];
-            (a.ws + a.d2_c)[b * PD_RD + wg * PD_UD + u] = c2[u][b];
+            (a.ws + a.dec_h_out)[b * PD_RD + FD + u] = hD[u][b];
+            (a.ws + a.dec_c)[b * PD_RD + FD + u] = cD[u][b];
+            (a.ws + a.d2_h_out)[b * PD_RD + FD + u] = h2[u][b];
+            (a.ws + a.d2_c)[b * PD_RD + FD + u] = c2[u][b];
         }
     }
-    if (t < nbc) (a.ws + a.prenet)[t * PD_P + wg] = pown[t];
-    if (is_attn && wg < a.batch) {
-        const int b = wg;
-        for (int p = t; p < a.T; p += PD_T) { (a.ws + a.w)[(size_t)b * a.T + p] = att.w[p]; (a.ws + a.cum)[(size_t)b * a.T + p] = att.cum[p]; }
-        if (t == 0) (a.ws + a.pos)[b] = att.pos;
-        for (int d = t; d < PD_DM; d += PD_T) (a.ws + a.ctx)[b * PD_DM + d] = X[XCTX + b * PD_DM + d];
+    if (t < 2 * PD_NB) {
+        const int k = t / PD_NB, b = t % PD_NB;
+        const int row = k == 0 ? w2_row0 : w2_row1;
+        if (row >= 0 && b < nbc) (a.ws + a.prenet)[b * PD_P + row] = pown[k][b];
     }
 }
+#undef PD_STAMP
+
+void* g_pd_debug = nullptr;      // ctts_taco_decoder_persistent_debug: stamp buffer, not part of the product path
 
 struct Xchg { size_t ctl, p, atth, q, ctx, dech, d2h, h1, total; };   // offsets in u64 words
 
@@ -621,8 +754,8 @@ bool pd_supported(const DecPlan& p, int batch, int T) {
     const auto& c = p.c;
     return c.attention_rnn_dim == PD_RA && c.decoder_rnn_dim == PD_RD && c.second_decoder_rnn_dim == PD_RD &&
            c.prenet_dim == PD_P && c.memory_dim == PD_DM && c.attention_dim <= PD_AMAX && c.attention_dim % 4 == 0 &&
-           c.attention_dim <= PD_WG && c.location_n_filters <= PD_FMAX && c.location_kernel_size <= PD_KMAX &&
-           c.window_range == 16 && p.pd_rows <= 2 * PD_WG && batch >= 1 && batch <= PD_NB && T >= 1 && T <= PD_TMAX;
+           c.location_n_filters <= PD_FMAX && c.location_kernel_size <= PD_KMAX && c.window_range == 16 &&
+           p.pd_rows <= 2 * PD_LWG && c.n_mel_channels + 1 <= PD_LWG && batch >= 1 && batch <= PD_NB && T >= 1 && T <= PD_TMAX;
 }
 
 }  // namespace
@@ -690,8 +823,16 @@ int ctts_taco_decoder_steps_persistent_f32(const ctts_taco_decoder_config* cfg, 
     a.A = c.attention_dim; a.F = c.location_n_filters; a.K = c.location_kernel_size; a.R = c.window_range;
     a.n_mel = c.n_mel_channels; a.T = text_len; a.batch = batch; a.nbc = pad_batch(batch); a.step0 = step0; a.n_steps = n_steps;
     a.max_steps = max_steps; a.pd_rows = p.pd_rows;
+    a.dbg = reinterpret_cast<u64*>(g_pd_debug);
     hipLaunchKernelGGL(taco_persistent_kernel, dim3(PD_WG), dim3(PD_T), 0, s, a);
     CTTS_CHECK_LAUNCH("taco_persistent");
+    return CTTS_OK;
+}
+
+/* Profiling aid: device buffer of 256 x 64 x 16 uint64 that receives s_memrealtime stamps at the phase boundaries of the
+ * first 64 steps of every following persistent launch (NULL switches it off). */
+int ctts_taco_decoder_persistent_debug(void* stamps) {
+    g_pd_debug = stamps;
     return CTTS_OK;
 }
 

@@ -389,6 +389,10 @@ int ctts_taco_decoder_steps_persistent_f32(const ctts_taco_decoder_config* cfg, 
                                            int32_t n_steps, int32_t max_steps, void* workspace, void* exchange,
                                            size_t exchange_bytes, void* stream);
 
+/* Profiling aid for the persistent decoder: `stamps` = device buffer of 256 x 64 x 16 uint64 receiving s_memrealtime
+ * (100 MHz) at the phase boundaries of the first 64 steps of every later launch; NULL switches it off. */
+int ctts_taco_decoder_persistent_debug(void* stamps);
+
 /* ---- Tacotron2-TM one-shot stages: operator-level primitives ------------------------------- */
 /* The encoder (model.py:283-316) and postnet (:218-228) are stacks of "same"-padded Conv1d (+ eval-mode
  * BatchNorm1d, folded into the weights at pack time) + LeakyReLU / tanh, a packed-sequence BiLSTM, and a
