@@ -164,8 +164,9 @@ __device__ __forceinline__ void fma_rows(const float4 (&w)[NR][NJ], const float*
 #pragma unroll
         for (int i = 0; i < NR; ++i)
 #pragma unroll
-            for (int b = 0; b < PD_NB; ++b)
-                acc[i][b] += w[i][j].x * x[b].x + w[i][j].y * x[b].y + w[i][j].z * x[b].z + w[i][j].w * x[b].w;
+            for (int b = 0; b < PD_NB; ++b)     // explicit fma chain: the same arithmetic in every inlined copy, so a block of
+                                                // steps split over several launches reproduces one long launch bit for bit
+                acc[i][b] = fmaf(w[i][j].w, x[b].w, fmaf(w[i][j].z, x[b].z, fmaf(w[i][j].y, x[b].y, fmaf(w[i][j].x, x[b].x, acc[i][b]))));
     }
 }
 
@@ -230,7 +231,7 @@ __device__ __forceinline__ void row_dots(const float* wrow, const float* xs, int
 #pragma unroll
         for (int b = 0; b < PD_NB; ++b) {
             const float4 x = *reinterpret_cast<const float4*>(xs + b * n + 4 * (lane + 64 * j));
-            acc[b] += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w;
+            acc[b] = fmaf(w.w, x.w, fmaf(w.z, x.z, fmaf(w.y, x.y, fmaf(w.x, x.x, acc[b]))));
         }
     }
 }
