@@ -108,7 +108,7 @@ __device__ __forceinline__ bool gather(const u64* g, int count, float* dst, unsi
                 return false;
             }
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(2);
     }
 }
 
@@ -520,7 +520,6 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
         if (w2_row1 >= 0)
             *reinterpret_cast<float4*>(L + WW2 + 64 * 4 + t * 4) = *reinterpret_cast<const float4*>((a.blob + a.W2) + (size_t)w2_row1 * PD_P + 4 * t);
     }
-    float4 wf2[2][3];
     float bA[3], bD[2], b2[2];
 #pragma unroll
     for (int i = 0; i < 3; ++i) bA[i] = rowA[i] >= 0 ? (a.blob + a.att_bih)[rowA[i]] + (a.blob + a.att_bhh)[rowA[i]] : 0.f;
@@ -528,10 +527,6 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
     for (int i = 0; i < 2; ++i) {
         const bool valid = rowD[i] >= 0;
         const int row = valid ? rowD[i] : 0;
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            wf2[i][j] = valid ? *reinterpret_cast<const float4*>((a.blob + a.d2_wih) + (size_t)row * PD_RD + 4 * (lane + 64 * j))
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
         bD[i] = valid ? (a.blob + a.dec_bih)[row] + (a.blob + a.dec_bhh)[row] : 0.f;
         b2[i] = valid ? (a.blob + a.d2_bih)[row] + (a.blob + a.d2_bhh)[row] : 0.f;
     }
@@ -599,6 +594,10 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
         __syncthreads();
         cell_update(gates, cA, hA, (a.xb + a.g_atth) + (size_t)par * PD_NB * PD_RA, epoch, PD_RA, UA, FA, t);
         PD_STAMP(1);
+        // (weight loads whose vector operand is the one being gathered are issued BEFORE the gather: their L2 / Infinity
+        // Cache latency runs out during the wait, the FMAs follow the barrier)
+        float4 pfB[2][3];
+        issue_rows<2, 3>((a.blob + a.dec_wih), I_dec, 0, rowD, lane, pfB);
         PD_GATHER(10, (a.xb + a.g_atth), PD_NB * PD_RA, X + XATT, 1u);
         PD_STAMP(2);
         if (fail) break;
@@ -613,9 +612,11 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
                 publish((a.xb + a.g_q) + (size_t)par * PD_NB * a.A, lane * a.A + q_row, epoch,
                         lane == 0 ? q[0] : lane == 1 ? q[1] : lane == 2 ? q[2] : q[3]);
         }
-        early_rows<2, 3>((a.blob + a.dec_wih), I_dec, 0, rowD, X + XATT, PD_RA, 0, lane, eD);
+        fma_rows<2, 3>(pfB, X + XATT, PD_RA, 0, lane, eD);
         early_rows<2, 2>((a.blob + a.dec_wih), I_dec, 768, rowD, X + XATT, PD_RA, 768, lane, eD);
         PD_STAMP(3);
+        float4 pfC[3][2];
+        issue_rows<3, 2>((a.blob + a.att_wih), I_att, PD_P, rowA, lane, pfC);
         PD_GATHER(4, (a.xb + a.g_ctx), PD_NB * PD_DM, X + XCTX, 3u);
         PD_STAMP(4);
         if (fail) break;
@@ -632,8 +633,11 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
         zero_rows<2>(eD);
         __syncthreads();
         cell_update(gates, cD, hD, (a.xb + a.g_dech) + (size_t)par * PD_NB * PD_RD, epoch, PD_RD, UD, FD, t);
-        early_rows<3, 2>((a.blob + a.att_wih), I_att, PD_P, rowA, X + XCTX, PD_DM, 0, lane, eA);
+        fma_rows<3, 2>(pfC, X + XCTX, PD_DM, 0, lane, eA);
         PD_STAMP(5);
+        float4 pfD[3][3], wf2[2][3];      // the second decoder RNN's fresh columns (its whole W_ih, L2-resident): same trick
+        issue_rows<2, 3>((a.blob + a.d2_wih), PD_RD, 0, rowD, lane, wf2);
+        issue_rows<3, 3>((a.blob + a.att_wih), I_att, PD_P + PD_DM, rowA, lane, pfD);
         PD_GATHER(6, (a.xb + a.g_dech), PD_NB * PD_RD, X + XDEC, 4u);
         PD_STAMP(6);
         if (fail) break;
@@ -642,8 +646,10 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
         zero_rows<2>(e2);
         __syncthreads();
         cell_update(gates, c2, h2, (a.xb + a.g_d2h) + (size_t)par * PD_NB * PD_RD, epoch, PD_RD, UD, FD, t);
-        early_rows<3, 3>((a.blob + a.att_wih), I_att, PD_P + PD_DM, rowA, X + XDEC, PD_RD, 0, lane, eA);
+        fma_rows<3, 3>(pfD, X + XDEC, PD_RD, 0, lane, eA);
         PD_STAMP(7);
+        float4 pfE[2][3];
+        issue_rows<2, 3>((a.blob + a.d2_whh), PD_RD, 0, rowD, lane, pfE);
         PD_GATHER(6, (a.xb + a.g_d2h), PD_NB * PD_RD, X + XD2, 5u);
         PD_STAMP(8);
         if (fail) break;
@@ -672,7 +678,7 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
                 }
             }
         }
-        early_rows<2, 3>((a.blob + a.d2_whh), PD_RD, 0, rowD, X + XD2, PD_RD, 0, lane, e2);
+        fma_rows<2, 3>(pfE, X + XD2, PD_RD, 0, lane, e2);
         if (have_next) {
             // the two prenet exchanges below are pure latency: the recurrent columns of step + 1 fill them
             early_rows<3, 3>((a.blob + a.att_whh), PD_RA, 0, rowA, X + XATT, PD_RA, 0, lane, eA);

@@ -122,6 +122,9 @@ def stop_step(gate_logits, gate_threshold, gate_delay, max_decoder_steps, state=
 
 
 class Decoder(nn.Module):
+    _persistent_probed = False        # process-wide: the first persistent launch is checked synchronously
+    _persistent_disabled = False
+
     def __init__(self, hparams):
         super().__init__()
         hp = hparams
@@ -278,7 +281,8 @@ class Decoder(nn.Module):
         import os
         xchg = []
         for g0, g1 in groups:
-            nb = 0 if os.environ.get("CTTS_TACO_NO_PERSIST") else lib.ctts_taco_decoder_persistent_bytes(C.byref(cfg), g1 - g0, T)
+            off = os.environ.get("CTTS_TACO_NO_PERSIST") or Decoder._persistent_disabled
+            nb = 0 if off else lib.ctts_taco_decoder_persistent_bytes(C.byref(cfg), g1 - g0, T)
             xchg.append(torch.zeros(nb // 8, dtype=torch.int64, device=device) if nb else None)
 
         def check_persistent():
@@ -311,13 +315,25 @@ class Decoder(nn.Module):
             while done < max_steps and n_total is None:
                 chunk = int(os.environ.get("CTTS_TACO_CHUNK", 0)) or (STOP_CHECK_EVERY if fixed_steps is None else max_steps)
                 n = min(chunk, max_steps - done)
-                for (g0, g1), ws, km, xb in zip(groups, wss, masks, xchg):
+                for gi, ((g0, g1), ws, km, xb) in enumerate(zip(groups, wss, masks, xchg)):
                     if xb is not None:
                         _lib.check(lib.ctts_taco_decoder_steps_persistent_f32(
                             C.byref(cfg), _lib.ptr(blob), _lib.ptr(km), _lib.ptr(mel[g0:g1]), _lib.ptr(gate[g0:g1]),
                             _lib.ptr(align[g0:g1]), g1 - g0, T, done, n, max_steps, _lib.ptr(ws), _lib.ptr(xb),
                             xb.numel() * 8, stream), "ctts_taco_decoder_steps_persistent_f32")
-                    else:
+                        if not Decoder._persistent_probed:
+                            # first persistent launch of this process: make sure all 256 workgroups really were resident
+                            # together (a bounded wait gives up otherwise and leaves the decoder state untouched), else
+                            # fall back to the per-launch form for good and redo this block with it
+                            stream_obj.synchronize()
+                            Decoder._persistent_probed = True
+                            if int(xb[-8:-6].view(torch.int32)[0].item()) != 0:
+                                import warnings
+                                warnings.warn("persistent decoder kernel could not run (workgroups not co-resident?); "
+                                              "using the per-launch decoder")
+                                Decoder._persistent_disabled = True
+                                xchg[gi] = xb = None
+                    if xb is None:
                         _lib.check(lib.ctts_taco_decoder_steps_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(km), _lib.ptr(mel[g0:g1]),
                                                                   _lib.ptr(gate[g0:g1]), _lib.ptr(align[g0:g1]), g1 - g0, T, done,
                                                                   n, max_steps, _lib.ptr(ws), stream), "ctts_taco_decoder_steps_f32")

@@ -259,3 +259,46 @@ def test_packed_weights_follow_load_state_dict_on_the_parent(hip_lib_path):
     again = m.inference(*args, keep_masks=g["masks"], fixed_steps=n)
     assert np.abs(again["pred_mel_postnet"].cpu().numpy() - g["pred_mel_postnet"]).max() < MEL_TOL
     assert np.abs(again["encoder_outputs"].cpu().numpy() - g["encoder_outputs"]).max() < MEL_TOL
+
+
+def test_persistent_decoder_size_query(hip_lib_path):
+    """ctts_taco_decoder_persistent_bytes answers on the host: built for the repo-default decoder shape only."""
+    import ctypes as C
+    from cookietts_amd import _lib
+    from cookietts_amd.tacotron2 import Tacotron2
+    lib = _lib.lib()
+    cfg = Tacotron2(synthetic.tacotron_hparams()).decoder.c_config()
+    nb = lib.ctts_taco_decoder_persistent_bytes(C.byref(cfg), 4, 200)
+    # granules: 2 parities x 4 batch rows x (256 + 1280 + 192 + 512 + 768 + 768 + 256) x 8 bytes + control words
+    assert nb >= 2 * 4 * 4032 * 8 and nb % 8 == 0
+    assert lib.ctts_taco_decoder_persistent_bytes(C.byref(cfg), 5, 200) == 0          # batch > 4: per-launch form
+    assert lib.ctts_taco_decoder_persistent_bytes(C.byref(cfg), 4, 5000) == 0         # text longer than the LDS staging
+    other = type(cfg).from_buffer_copy(cfg)
+    other.attention_rnn_dim = 1024
+    assert lib.ctts_taco_decoder_persistent_bytes(C.byref(other), 4, 200) == 0
+
+
+@pytest.mark.gpu
+def test_persistent_decoder_equals_per_launch_decoder(hip_lib_path, monkeypatch):
+    """The persistent kernel (one launch per block of steps) and the six-launches-per-step form implement the same
+    arithmetic in different summation orders: same outputs to fp32 rounding, over a free-running decode that crosses
+    several launch blocks, with ragged lengths, and for a batch of 1 (padded rows of the exchange stay zero)."""
+    m, g, hp, sd = _model()
+    rng = np.random.default_rng(11)
+    for B, T, n in ((4, 200, 150), (1, 33, 40), (3, 64, 70)):
+        mem = torch.from_numpy((rng.standard_normal((B, T, synthetic.tacotron_memory_in_dim(hp))) * 0.5).astype(np.float32)).cuda()
+        lens = torch.from_numpy(rng.integers(T // 2, T + 1, B).astype(np.int64)).cuda()
+        lens[0] = T
+        masks = synthetic.prenet_dropout_masks(n, B, seed=B)
+        m.decoder.gate_threshold, m.decoder.max_decoder_steps = 2.0, n           # runs all n steps, in blocks of 32
+        monkeypatch.delenv("CTTS_TACO_NO_PERSIST", raising=False)
+        a = m.decoder.inference(mem, lens, keep_masks=masks)
+        monkeypatch.setenv("CTTS_TACO_NO_PERSIST", "1")
+        b = m.decoder.inference(mem, lens, keep_masks=masks)
+        monkeypatch.delenv("CTTS_TACO_NO_PERSIST")
+        assert a[0].shape == b[0].shape == (B, 80, n)
+        print(f"B={B} T={T}: mel {float((a[0] - b[0]).abs().max()):.2e} align {float((a[2] - b[2]).abs().max()):.2e}")
+        assert (a[0] - b[0]).abs().max() < MEL_TOL and (a[1] - b[1]).abs().max() < MEL_TOL
+        assert (a[2] - b[2]).abs().max() < MEL_TOL
+    from cookietts_amd.tacotron2 import Decoder
+    assert Decoder._persistent_probed and not Decoder._persistent_disabled       # the persistent path really ran
