@@ -313,20 +313,23 @@ def worker(args):
                         "flop_per_launch": flop_per_launch}
             if args.dtype == "bf16":
                 # In bf16 the in-layer GEMM stays MFMA-bound (1430 FLOP/B vs a ridge of ~312); the memory-bound WN
-                # kernel is the res/skip GEMM (K = C): 2*C*2C FLOP against act read + x and skip-sum read-modify-write
-                # = 5*C*2 B per time step (205 FLOP/B).  Report it against HBM.
-                n2 = ctypes.c_int64()
-                ms2 = ctypes.c_double()
-                _lib.check(lib.ctts_profile_collect(_lib.PROF_WN_RS, ctypes.byref(n2), ctypes.byref(ms2)), "profile")
-                if n2.value > 0:
-                    mean2 = ms2.value / n2.value * 1e-3
-                    bytes2 = float(5 * C * 2) * B * L
-                    roofline["res_skip_hbm"] = {
-                        "kernel": "conv_gemm_bf16_pp_kernel<SPLIT> (WN res/skip 1x1 + residual/skip accumulate)", "bound": "hbm",
-                        "achieved": round(bytes2 / mean2 / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                        "frac": round(bytes2 / mean2 / 8e12, 4), "launches": int(n2.value),
-                        "mean_launch_ms": round(mean2 * 1e3, 4), "bytes_per_launch": bytes2}
-                # whole step against HBM with SURVEY 8d's per-layer-kernel byte count (7*C*2 B per step per layer)
+                # kernels are the res GEMM (K = C, per layer: act read + x read-modify-write = 3*C*2 B per time step)
+                # and the deferred skip GEMM (K = 4*C per launch: 4 act reads + the skip sum written, and re-read by
+                # the second launch = 5.5*C*2 B per time step on average).  Report both against HBM.
+                for key, which, kname2, bpt in (
+                        ("res_hbm", _lib.PROF_WN_RS, "conv_gemm_bf16_pp_kernel<SPLIT> (WN res 1x1: x += W_res act)", 3.0),
+                        ("skip_hbm", _lib.PROF_WN_SKIP, "conv_gemm_bf16_pp_kernel<SPLIT> (WN skip sum over 4 layers' act)", 5.5)):
+                    n2 = ctypes.c_int64()
+                    ms2 = ctypes.c_double()
+                    _lib.check(lib.ctts_profile_collect(which, ctypes.byref(n2), ctypes.byref(ms2)), "profile")
+                    if n2.value > 0:
+                        mean2 = ms2.value / n2.value * 1e-3
+                        bytes2 = float(bpt * C * 2) * B * L
+                        roofline[key] = {
+                            "kernel": kname2, "bound": "hbm", "achieved": round(bytes2 / mean2 / 1e9, 1), "peak": 8000.0,
+                            "unit": "GB/s", "frac": round(bytes2 / mean2 / 8e12, 4), "launches": int(n2.value),
+                            "mean_launch_ms": round(mean2 * 1e3, 4), "bytes_per_launch": bytes2}
+                # whole step against HBM with SURVEY 8d's per-layer-kernel byte count (7*C*2 B per step per layer; the deferred-skip form moves ~5.4*C*2)
                 step_bytes = 7.0 * C * 2 * n_layers * cfg["n_flows"] * B * L
                 roofline["step_hbm_algorithmic"] = {"bytes_per_step": step_bytes, "achieved": round(step_bytes * args.steps / elapsed / 1e9, 1),
                                                     "peak": 8000.0, "unit": "GB/s",

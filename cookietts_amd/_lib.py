@@ -200,6 +200,7 @@ SIGNATURES = {
 
 PROF_WN_IN = 0
 PROF_WN_RS = 1
+PROF_WN_SKIP = 2
 
 
 class HipLibraryError(RuntimeError):

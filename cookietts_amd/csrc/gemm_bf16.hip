@@ -558,10 +558,14 @@ __global__ __launch_bounds__(256) void pack_a_bf16_kernel(bf16_t* __restrict__ d
 int launch_pack_a_bf16(bf16_t* dst, const float* src, int MB, int nch_total, int k_off, int ksrc, int epi, int C,
                        int M, long long src_row_off, long long src_row_stride, int src_k_stride, hipStream_t s,
                        int k_group, int k_member) {
-    CTTS_CHECK_ARG(k_off % 8 == 0 && ksrc > 0 && ksrc % 8 == 0, "pack_a_bf16: k range must be 8-aligned");
-    CTTS_CHECK_ARG(k_off + ksrc * (k_group > 1 ? k_group : 1) <= nch_total * BGEMM_KC, "pack_a_bf16: k range");
+    // a ragged ksrc (e.g. a 20-wide speaker embedding) is zero-filled up to its 32-wide slab boundary
+    const int kfill = (ksrc + BGEMM_KC - 1) / BGEMM_KC * BGEMM_KC;
+    CTTS_CHECK_ARG(k_off % 8 == 0 && ksrc > 0, "pack_a_bf16: k offset must be 8-aligned");
+    CTTS_CHECK_ARG(k_off % BGEMM_KC == 0 || ksrc % 8 == 0, "pack_a_bf16: a ragged k range must start on a slab");
+    const int kspan = k_off % BGEMM_KC == 0 ? kfill : ksrc;
+    CTTS_CHECK_ARG(k_off + kspan * (k_group > 1 ? k_group : 1) <= nch_total * BGEMM_KC, "pack_a_bf16: k range");
     CTTS_CHECK_ARG(k_group <= 1 || (ksrc % BGEMM_KC == 0 && k_off % BGEMM_KC == 0), "pack_a_bf16: k group");
-    hipLaunchKernelGGL(pack_a_bf16_kernel, dim3(ksrc / 8, MB), dim3(256), 0, s, dst, src, nch_total, k_off, ksrc, epi, C,
+    hipLaunchKernelGGL(pack_a_bf16_kernel, dim3(kspan / 8, MB), dim3(256), 0, s, dst, src, nch_total, k_off, ksrc, epi, C,
                        M, src_row_off, src_row_stride, src_k_stride, k_group, k_member);
     CTTS_CHECK_LAUNCH("pack_a_bf16");
     return CTTS_OK;

@@ -278,11 +278,20 @@ int run_flow_tail(const Plan& p, const Geom& g, const float* blob, int k, const 
 // bf16 variant (BASELINE config 3): WN in-layer / res-skip GEMMs on bf16 MFMA with fp32 accumulation,
 // WN activations (x, act, skip sum, cond hidden) stored bf16 in the K8-blocked layout; upsampling, the
 // two small cond layers, the `end` conv, the coupling and the inverse 1x1 conv stay fp32.
+// The res and skip halves of res_skip_layers are separate GEMMs here: the res rows update x after every layer
+// (x feeds the next layer), the skip rows are deferred - every layer's gated activation stays in HBM and the skip
+// sum is ONE contraction over K = n_layers * C at the end of the stack, BF_SKIP_GROUP layers per launch.  The
+// per-layer form re-read and re-wrote the skip sum (2 x B*C*L bf16) in all but one of its n_layers epilogues.
+constexpr int BF_SKIP_GROUP = BGEMM_MAX_SEG;
 struct BfPlan {
-    std::vector<std::vector<size_t>> in_A, rs_A;   // [flow][layer] offsets in bf16 elements
+    std::vector<std::vector<size_t>> in_A, rs_A;   // [flow][layer] offsets in bf16 elements (rs_A: res rows, layers < last)
+    std::vector<std::vector<size_t>> skip_A;       // [flow][group]: skip rows of the group's layers side by side along K
+    std::vector<size_t> skip_b;                    // [flow]: fp32 [2][mb_c*256] = {sum of the skip biases, zeros}
     size_t cond0_A, cond1_A;                       // flow-batched cond layers 0 / 1 (M-block k = flow k)
     size_t total;
     int nch_in, nch_rs, nch_c0, nch_c1;
+    int mb_c, n_groups;                            // M-blocks of a C-row GEMM; skip launches per flow
+    int group_layers(int g, int n_layers) const { return std::min(BF_SKIP_GROUP, n_layers - g * BF_SKIP_GROUP); }
 };
 
 void make_bf_plan(const Plan& p, BfPlan& q) {
@@ -294,13 +303,20 @@ void make_bf_plan(const Plan& p, BfPlan& q) {
     q.nch_c1 = p.H / BGEMM_KC;
     q.cond0_A = take((size_t)p.c.n_flows * q.nch_c0 * BGEMM_KC * BGEMM_BM);
     q.cond1_A = take((size_t)p.c.n_flows * q.nch_c1 * BGEMM_KC * BGEMM_BM);
+    q.mb_c = (p.C + BGEMM_BM - 1) / BGEMM_BM;
+    q.n_groups = (p.c.n_layers + BF_SKIP_GROUP - 1) / BF_SKIP_GROUP;
     q.in_A.assign(p.c.n_flows, {});
     q.rs_A.assign(p.c.n_flows, {});
-    for (int k = 0; k < p.c.n_flows; ++k)
+    q.skip_A.assign(p.c.n_flows, {});
+    for (int k = 0; k < p.c.n_flows; ++k) {
         for (int i = 0; i < p.c.n_layers; ++i) {
             q.in_A[k].push_back(take((size_t)p.mb_in * q.nch_in * BGEMM_KC * BGEMM_BM));
-            q.rs_A[k].push_back(take((size_t)p.rs_mb(i) * q.nch_rs * BGEMM_KC * BGEMM_BM));
+            q.rs_A[k].push_back(i < p.c.n_layers - 1 ? take((size_t)q.mb_c * q.nch_rs * BGEMM_KC * BGEMM_BM) : 0);
         }
+        for (int gi = 0; gi < q.n_groups; ++gi)
+            q.skip_A[k].push_back(take((size_t)q.mb_c * q.group_layers(gi, p.c.n_layers) * q.nch_rs * BGEMM_KC * BGEMM_BM));
+        q.skip_b.push_back(take((size_t)2 * 2 * q.mb_c * BGEMM_BM));        // fp32 pairs of bf16 slots
+    }
     q.total = o;
 }
 
@@ -322,7 +338,7 @@ void carve_bf(const Plan& p, const Geom& g, int batch, char* base, BfWs& w) {
     w.h_tmp_bf = (bf16_t*)take(B * p.c.n_flows * p.H * g.ld * 2);
     w.h_bf = (bf16_t*)take(B * p.c.n_flows * p.H * g.ld * 2);
     w.x = (bf16_t*)take(B * p.C * g.ld * 2);
-    w.act = (bf16_t*)take(B * p.C * g.ld * 2);
+    w.act = (bf16_t*)take(B * p.C * g.ld * 2 * p.c.n_layers);      // one buffer per layer (deferred skip GEMM)
     w.out = (bf16_t*)take(B * p.C * g.ld * 2);
     w.total_bytes = o;
 }
@@ -424,6 +440,15 @@ __global__ __launch_bounds__(256) void flow_tail_bf16_kernel(const bf16_t* __res
     }
 }
 
+// dst[0 .. n) (+)= src[0 .. C) for rows < C; first call clears the whole array (incl. the zero half)
+__global__ __launch_bounds__(256) void skip_bias_kernel(float* __restrict__ dst, const float* __restrict__ src, int C, int n,
+                                                        int first) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = i < C ? src[i] : 0.f;
+    dst[i] = first ? v : dst[i] + v;
+}
+
 int run_wn_stack_bf16(const Plan& p, const BfPlan& q, const Geom& g, const float* blob, const bf16_t* bblob, int k,
                       const BfWs& w, int batch, hipStream_t s) {
     const auto& f = p.fl[k];
@@ -443,9 +468,11 @@ int run_wn_stack_bf16(const Plan& p, const BfPlan& q, const Geom& g, const float
 #undef CTTS_BSTART
     CTTS_CHECK_LAUNCH("wn_start_bf16");
     const int ncx = p.C / BGEMM_KC;
+    const size_t act_layer = (size_t)batch * cstride;
+    int rc;
     for (int i = 0; i < p.c.n_layers; ++i) {
         const int dil = 1 << i;
-        int rc;
+        bf16_t* act = w.act + (size_t)i * act_layer;
         {
             BGemmArgs a{};
             a.ld = g.ld; a.pad = g.pad; a.L = g.L; a.ntiles = g.ntiles; a.batch = batch;
@@ -456,24 +483,40 @@ int run_wn_stack_bf16(const Plan& p, const BfPlan& q, const Geom& g, const float
             a.seg[2] = {w.x, cstride, ncx, dil, 0};
             a.seg[3] = {w.h_bf + (size_t)k * p.H * g.ld, hstride, p.H / BGEMM_KC, 0, 0};
             a.M = 2 * p.C; a.pairC = p.C;
-            a.dst0 = w.act; a.dst0_bstride = cstride;
+            a.dst0 = act; a.dst0_bstride = cstride;
             ProfScope ps(CTTS_PROF_WN_IN, s);
             if ((rc = launch_gemm_bf16(BGEMM_EPI_GATE, a, s))) return rc;
         }
-        {
-            const bool last = i == p.c.n_layers - 1;
+        if (i < p.c.n_layers - 1) {
+            // x += W_res act + b_res   (glow.py:213-217; the skip rows wait for the end of the stack)
             BGemmArgs a{};
             a.ld = g.ld; a.pad = g.pad; a.L = g.L; a.ntiles = g.ntiles; a.batch = batch;
             a.A = bblob + q.rs_A[k][i]; a.bias = blob + f.rs_b[i];
-            a.nseg = 1; a.nch_total = q.nch_rs; a.MB = p.rs_mb(i);
-            a.seg[0] = {w.act, cstride, q.nch_rs, 0, 0};
-            a.M = p.rs_rows(i);
+            a.nseg = 1; a.nch_total = q.nch_rs; a.MB = q.mb_c;
+            a.seg[0] = {act, cstride, q.nch_rs, 0, 0};
+            a.M = p.C; a.split = p.C;
             a.dst0 = w.x; a.dst0_bstride = cstride; a.acc0 = 1;
-            a.dst1 = w.out; a.dst1_bstride = cstride; a.acc1 = i > 0 ? 1 : 0;
-            a.split = last ? 0 : p.C;
+            a.dst1 = w.x; a.dst1_bstride = cstride; a.acc1 = 1;
             ProfScope ps(CTTS_PROF_WN_RS, s);
             if ((rc = launch_gemm_bf16(BGEMM_EPI_SPLIT, a, s))) return rc;
         }
+    }
+    // skip sum = sum_i W_skip_i act_i + sum_i b_skip_i: K = n_layers * C, fp32 accumulation inside a launch, one
+    // bf16 rounding of the running sum per group of BF_SKIP_GROUP layers
+    const float* skip_b = reinterpret_cast<const float*>(bblob + q.skip_b[k]);
+    for (int gi = 0; gi < q.n_groups; ++gi) {
+        const int nl = q.group_layers(gi, p.c.n_layers);
+        BGemmArgs a{};
+        a.ld = g.ld; a.pad = g.pad; a.L = g.L; a.ntiles = g.ntiles; a.batch = batch;
+        a.A = bblob + q.skip_A[k][gi]; a.bias = skip_b + (gi == 0 ? 0 : q.mb_c * BGEMM_BM);
+        a.nseg = nl; a.nch_total = nl * q.nch_rs; a.MB = q.mb_c;
+        for (int j = 0; j < nl; ++j)
+            a.seg[j] = {w.act + (size_t)(gi * BF_SKIP_GROUP + j) * act_layer, cstride, q.nch_rs, 0, 0};
+        a.M = p.C; a.split = p.C;
+        a.dst0 = w.out; a.dst0_bstride = cstride; a.acc0 = gi > 0 ? 1 : 0;
+        a.dst1 = w.out; a.dst1_bstride = cstride; a.acc1 = a.acc0;
+        ProfScope ps(CTTS_PROF_WN_SKIP, s);
+        if ((rc = launch_gemm_bf16(BGEMM_EPI_SPLIT, a, s))) return rc;
     }
     return CTTS_OK;
 }
@@ -725,8 +768,18 @@ int ctts_waveglow_pack_flow_bf16(const ctts_waveglow_config* cfg, int32_t k, con
                                          2 * C, 0, (long long)C * ks, ks, s, ks, t))) return rc;
         if ((rc = launch_pack_a_bf16(bb + q.in_A[k][i], w->cond_w[2], p.mb_in, q.nch_in, ks * C, H, BGEMM_EPI_GATE, C,
                                      2 * C, (long long)2 * C * i, H, 1, s))) return rc;
-        if ((rc = launch_pack_a_bf16(bb + q.rs_A[k][i], w->rs_w[i], p.rs_mb(i), q.nch_rs, 0, C, BGEMM_EPI_SPLIT, C,
-                                     p.rs_rows(i), 0, C, 1, s))) return rc;
+        // res_skip_layers.i is [2C][C] = {res rows, skip rows} for i < last, [C][C] = skip rows for the last layer
+        const bool last = i == p.c.n_layers - 1;
+        CTTS_CHECK_ARG(w->rs_b[i], "pack_flow_bf16: NULL layer %d res/skip bias", i);
+        if (!last && (rc = launch_pack_a_bf16(bb + q.rs_A[k][i], w->rs_w[i], q.mb_c, q.nch_rs, 0, C, BGEMM_EPI_SPLIT, C, C,
+                                              0, C, 1, s))) return rc;
+        const int gi = i / BF_SKIP_GROUP, j = i % BF_SKIP_GROUP;
+        if ((rc = launch_pack_a_bf16(bb + q.skip_A[k][gi], w->rs_w[i], q.mb_c, q.group_layers(gi, p.c.n_layers) * q.nch_rs,
+                                     j * C, C, BGEMM_EPI_SPLIT, C, C, last ? 0 : C, C, 1, s))) return rc;
+        hipLaunchKernelGGL(skip_bias_kernel, dim3((2 * q.mb_c * BGEMM_BM + 255) / 256), dim3(256), 0, s,
+                           reinterpret_cast<float*>(bb + q.skip_b[k]), w->rs_b[i] + (last ? 0 : C), C,
+                           2 * q.mb_c * BGEMM_BM, i == 0 ? 1 : 0);
+        CTTS_CHECK_LAUNCH("skip_bias");
     }
     return CTTS_OK;
 }

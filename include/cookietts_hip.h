@@ -535,8 +535,9 @@ int ctts_taco_stop_rule_f32(const float* gate_logits, int32_t batch, int32_t gat
 /* When enabled, ctts_waveglow_infer_f32 brackets every launch of the dominant kernel
  * (WN in-layer GEMM: dilated conv + cond + gate) with hipEvents on `stream`. */
 #define CTTS_PROF_WN_IN 0
-#define CTTS_PROF_WN_RS 1
-#define CTTS_PROF_N 2
+#define CTTS_PROF_WN_RS 1   /* fp32: res/skip GEMM; bf16: res GEMM (x += W_res act) */
+#define CTTS_PROF_WN_SKIP 2 /* bf16 only: deferred skip GEMM over K = n_layers * C */
+#define CTTS_PROF_N 3
 int ctts_profile_enable(int32_t on);
 /* Synchronises the recorded events and returns launches + summed milliseconds; resets. */
 int ctts_profile_collect(int32_t which, int64_t* launches, double* total_ms);

@@ -151,6 +151,9 @@ def bf16_round(x):
     return r.view(F32)
 
 
+BF16_SKIP_GROUP = 4     # layers per skip-sum launch of the bf16 HIP variant (BF_SKIP_GROUP in waveglow_api.hip)
+
+
 def wn_forward_bf16(sd, prefix, audio0, spect, n_layers, n_channels, speaker_ids=None):
     """bf16-rounded restatement of one WN stack, mirroring the rounding points of the bf16 HIP variant
     (BASELINE config 3): in-layer / cond-layer-2 / res-skip weights and the tensors x, h, act, skip-sum are
@@ -165,6 +168,7 @@ def wn_forward_bf16(sd, prefix, audio0, spect, n_layers, n_channels, speaker_ids
     wc2 = bf16_round(_conv_weight(sd, f"{prefix}.cond_layers.2")[:, :, 0])
     bc2 = sd[f"{prefix}.cond_layers.2.bias"]
     out = None
+    skip, bias_total, pending = None, None, []   # fp32 partial skip sum of the current group of BF16_SKIP_GROUP layers
     for i in range(n_layers):
         d = 2 ** i
         w = bf16_round(_conv_weight(sd, f"{prefix}.in_layers.{i}"))
@@ -179,12 +183,24 @@ def wn_forward_bf16(sd, prefix, audio0, spect, n_layers, n_channels, speaker_ids
         brs = sd[f"{prefix}.res_skip_layers.{i}.bias"]
         if f"{prefix}.alpha_i.{i}" in sd:                        # the kernels fold alpha into weight and bias at pack time
             wrs, brs = (wrs * sd[f"{prefix}.alpha_i.{i}"][0]).astype(F32), (brs * sd[f"{prefix}.alpha_i.{i}"][0]).astype(F32)
-        r = _conv1x1(bf16_round(wrs), brs, act).astype(F32)
+        wq = bf16_round(wrs)
+        zero = np.zeros(C, dtype=F32)
         if i < n_layers - 1:
-            x = bf16_round(x + r[:, :C])
-            out = bf16_round(r[:, C:]) if out is None else bf16_round(out + r[:, C:])
+            x = bf16_round(x + _conv1x1(wq[:C], brs[:C], act).astype(F32))
+            wsk, bsk = wq[C:], brs[C:]
         else:
-            out = bf16_round(r) if out is None else bf16_round(out + r)
+            wsk, bsk = wq, brs
+        # the skip rows are one deferred contraction over the stored activations of BF16_SKIP_GROUP layers per launch:
+        # fp32 sums inside a launch, the running sum rounded to bf16 once per launch, the summed skip biases of ALL
+        # layers added by the first launch
+        s_i = _conv1x1(wsk, zero, act).astype(F32)
+        skip = s_i if skip is None else skip + s_i
+        bias_total = np.asarray(bsk, dtype=F32) if bias_total is None else bias_total + np.asarray(bsk, dtype=F32)
+        if (i + 1) % BF16_SKIP_GROUP == 0 or i == n_layers - 1:
+            pending.append(skip)
+            skip = None
+    for gi, part in enumerate(pending):
+        out = bf16_round(part + bias_total[None, :, None]) if gi == 0 else bf16_round(out + part)
     e = _conv1x1(np.asarray(sd[prefix + ".end.weight"], dtype=F32), sd[prefix + ".end.bias"], out)
     hh = e.shape[1] // 2
     return e[:, :hh], e[:, hh:]
