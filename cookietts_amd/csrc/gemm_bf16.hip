@@ -532,6 +532,214 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_bf16_pp_kernel(const BGemmAr
     bf16_epilogue<EPI>(a, acc, lds, t, mb, wm, wn, b, n0, l31, lhi);
 }
 
+// Four-wave form of the 256 x 256 block: 256 threads = 2(M) x 2(N) waves, ONE wave per SIMD, wave tile 128 x 128 =
+// 4 x 4 tiles of v_mfma_f32_32x32x16_bf16 (256 accumulator registers, the whole AGPR half of the 512-register file).
+// Why: a fragment is one ds_read_b128 per lane = 1 KiB per wave, and the CU's LDS moves 128 B/clk.  The 128 x 64 wave
+// tile of the kernels above reads 12 fragments per 16 MFMAs: 8 waves x 12 KiB = 96 KiB of LDS reads plus 32 KiB of
+// DMA writes per K chunk = 1024 LDS cycles, exactly the 1024 matrix-pipe cycles of the chunk - both pipes would have
+// to run at 100 % at once, and the measured interval is ~1950 cycles.  The 128 x 128 wave tile reads 16 fragments per
+// 32 MFMAs: 64 + 32 KiB = 768 LDS cycles against the same 1024 MFMA cycles.
+// Pipeline: NS = 4 stages of 32 KiB filled by global_load_lds DMA three chunks ahead; per chunk ONE barrier, placed
+// between the two k-steps: [ds_read k-step 1 | 16 MFMAs of k-step 0] barrier [DMA chunk+4, ds_read k-step 0 of the
+// next chunk | 16 MFMAs of k-step 1], so every fragment read has 512 matrix-pipe cycles to land and the stage of
+// chunk c is free for DMA as soon as the barrier inside chunk c has passed (its k-step-1 fragments are in registers).
+__device__ unsigned long long g_w4_stamps[8];   // DBG == 3: {loop cycles, loop 100 MHz ticks, epilogue cycles, prologue cycles}
+
+template <int EPI, int DBG = 0>   // DBG bits (timing experiments only): 1 = no DMA after the prologue, 2 = no MFMA (both: wrong results), 4 = stamps
+__global__ __launch_bounds__(256) void conv_gemm_bf16_w4_kernel(const BGemmArgs a) {
+    constexpr int NT = 256, BN = 256, NS = 4;
+    constexpr int B_UNITS = 4 * BN;
+    constexpr int STAGE_UNITS = A_UNITS + B_UNITS;
+    __shared__ __attribute__((aligned(16))) u32x4 lds[NS * STAGE_UNITS + BGEMM_PP_MAX_CHUNKS / 2];
+    typedef unsigned long long u64;
+    u64* tab = reinterpret_cast<u64*>(lds + NS * STAGE_UNITS);
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    int id = blockIdx.x;
+    int mb, tile, b;
+    if (a.map_mode == 1) {                                  // see conv_gemm_bf16_pp_kernel
+        const int x = id & 7, j = id >> 3;
+        mb = 2 * (x & 1) + (j & 1);
+        const int gt = (j >> 1) * 4 + (x >> 1);
+        if (gt >= a.ntiles * a.batch) return;
+        tile = gt % a.ntiles;
+        b = gt / a.ntiles;
+    } else {
+        mb = id % a.MB;
+        id /= a.MB;
+        tile = id % a.ntiles;
+        b = id / a.ntiles;
+    }
+    const int n0 = tile * BN;
+    const int nch = a.nch_total;
+
+    if (t < nch) {                                          // chunk -> global address of its B rows (as in the pp kernel)
+        const int ilv = a.interleave > 1 ? a.interleave : 0;
+        const int n_il = ilv * a.seg[0].nch;
+        int c = t, s, local;
+        if (c < n_il) {
+            s = c % ilv;
+            local = c / ilv;
+        } else {
+            c -= n_il;
+            s = ilv;
+#pragma unroll
+            for (int k = 0; k < BGEMM_MAX_SEG - 1; ++k)
+                if (s == k && k < a.nseg - 1 && c >= a.seg[k].nch) { c -= a.seg[k].nch; s = k + 1; }
+            local = c;
+        }
+#define CTTS_SEGF(f) (s == 0 ? a.seg[0].f : s == 1 ? a.seg[1].f : s == 2 ? a.seg[2].f : a.seg[3].f)
+        const bf16_t* base = CTTS_SEGF(base);
+        const long long bstride = CTTS_SEGF(bstride);
+        const int shift = CTTS_SEGF(shift), mbr = CTTS_SEGF(mb_rows);
+#undef CTTS_SEGF
+        tab[t] = (u64)(base + (size_t)b * bstride) +
+                 16ull * ((size_t)(mb * (mbr / 8) + 4 * local) * a.ld + a.pad + n0 + shift);
+    }
+    // per-thread byte offsets inside a chunk: B unit (g, n) = (j, t), A unit t + 256 j, j = 0..3
+    const unsigned boff = (unsigned)(t * 16), bstep = (unsigned)(a.ld * 16);
+    const unsigned aoff = (unsigned)(t * 16);
+    typedef const __attribute__((address_space(1))) char* gbyte_ptr;
+    const gbyte_ptr abase = (gbyte_ptr)a.A + (size_t)mb * nch * (A_UNITS * 16);
+
+    f32x16 acc[2][4][2];                                    // [64-column half][mt][nt]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.0f;
+
+    typedef __attribute__((address_space(3))) u32x4* lds_ptr;
+#define CTTS_W4_DMA(buf, c, ub)                                                                     \
+    do {                                                                                            \
+        lds_ptr la_ = (lds_ptr)(lds + (buf) * STAGE_UNITS + wave * 64);                             \
+        const gbyte_ptr ac_ = abase + (size_t)(c) * (A_UNITS * 16) + aoff;                          \
+        const gbyte_ptr bc_ = (gbyte_ptr)(ub) + boff;                                               \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                            \
+            __builtin_amdgcn_global_load_lds((gunit_ptr)(ac_ + j_ * (NT * 16)), la_ + j_ * NT, 16, 0, 0); \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                            \
+            __builtin_amdgcn_global_load_lds((gunit_ptr)(bc_ + j_ * bstep), la_ + A_UNITS + j_ * NT, 16, 0, 0); \
+    } while (0)
+#define CTTS_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define CTTS_UNIFORM64(v) \
+    (((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)((v) >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(v)))
+    // wait until at most `k` chunks (8 DMAs each, in order) of this thread's DMAs are still in flight
+#define CTTS_W4_WAIT_CHUNKS(k)                                                                      \
+    do {                                                                                            \
+        if ((k) >= 3) CTTS_WAIT_VM(24);                                                             \
+        else if ((k) == 2) CTTS_WAIT_VM(16);                                                        \
+        else if ((k) == 1) CTTS_WAIT_VM(8);                                                         \
+        else CTTS_WAIT_VM(0);                                                                       \
+    } while (0)
+
+    const unsigned long long st0 = (DBG & 4) ? __builtin_readcyclecounter() : 0;
+    __syncthreads();                                        // table visible
+    {
+        const int npro = nch < NS ? nch : NS;
+        for (int c = 0; c < npro; ++c) {
+            const u64 ub = CTTS_UNIFORM64(tab[c]);
+            CTTS_W4_DMA(c, c, ub);
+        }
+        CTTS_W4_WAIT_CHUNKS(npro - 1);                      // chunk 0 landed (own DMAs), the rest in flight
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    u32x4 fa[2][4], fb[2][4];                               // [k-step][tile] fragments
+    // With one wave per SIMD nothing else fills the matrix pipe while this wave issues other instructions: every
+    // ds_read / DMA is issued in the 32-cycle shadow of ONE MFMA (order pinned by sched_barrier), never in a burst.
+#define CTTS_W4_FRAG1(ks, i, buf)                                                                   \
+    do {                                                                                            \
+        if ((i) < 4) fa[ks][(i)] = lds[(buf) * STAGE_UNITS + (2 * (ks) + lhi) * BGEMM_BM + wm * 128 + l31 + (i) * 32]; \
+        else fb[ks][(i) - 4] = lds[(buf) * STAGE_UNITS + A_UNITS + (2 * (ks) + lhi) * BN + wn * 128 + l31 + ((i) - 4) * 32]; \
+    } while (0)
+#define CTTS_W4_MFMA1(ks, mt, nt)                                                                   \
+    do {                                                                                            \
+        if ((DBG & 2)) acc[(nt) >> 1][mt][(nt) & 1][0] += __builtin_bit_cast(float, fa[ks][mt][0] ^ fb[ks][nt][0]); \
+        else acc[(nt) >> 1][mt][(nt) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                \
+            *reinterpret_cast<const bf16x8*>(&fa[ks][mt]),                                          \
+            *reinterpret_cast<const bf16x8*>(&fb[ks][nt]), acc[(nt) >> 1][mt][(nt) & 1], 0, 0, 0);  \
+    } while (0)
+#define CTTS_W4_DMA1(buf, c, ub, j)                                                                 \
+    do {                                                                                            \
+        lds_ptr la_ = (lds_ptr)(lds + (buf) * STAGE_UNITS + wave * 64);                             \
+        if ((j) < 4)                                                                                \
+            __builtin_amdgcn_global_load_lds((gunit_ptr)(abase + (size_t)(c) * (A_UNITS * 16) + aoff + (j) * (NT * 16)), \
+                                             la_ + (j) * NT, 16, 0, 0);                             \
+        else                                                                                        \
+            __builtin_amdgcn_global_load_lds((gunit_ptr)((gbyte_ptr)(ub) + boff + ((j) - 4) * bstep), \
+                                             la_ + A_UNITS + ((j) - 4) * NT, 16, 0, 0);             \
+    } while (0)
+#define CTTS_SB() __builtin_amdgcn_sched_barrier(0)
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i) CTTS_W4_FRAG1(0, i, 0);
+    int cur = 0;
+    const unsigned long long st1 = (DBG & 4) ? __builtin_readcyclecounter() : 0;
+    const unsigned long long rt1 = (DBG & 4) ? __builtin_amdgcn_s_memrealtime() : 0;
+    // One chunk.  STEADY: chunk ch + NS exists (DMA issued, constant vmcnt); otherwise the tail (no DMA, draining waits).
+#define CTTS_W4_CHUNK(STEADY)                                                                       \
+    do {                                                                                            \
+        const int nxt = cur == NS - 1 ? 0 : cur + 1;                                                \
+        /* k-step 0: MFMA m (row-major over the 4 x 4 tiles); k-step-1 fragment i is read behind MFMA i + 1 */ \
+        u64 tnext = 0;                                                                              \
+        _Pragma("unroll") for (int m = 0; m < 16; ++m) {                                            \
+            CTTS_W4_MFMA1(0, m >> 2, m & 3);                                                        \
+            CTTS_SB();                                                                              \
+            if (m >= 1 && m <= 8) CTTS_W4_FRAG1(1, m - 1, cur);                                     \
+            if (STEADY && m == 9) tnext = tab[ch + NS];                                             \
+            CTTS_SB();                                                                              \
+        }                                                                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* k-step-1 fragments, table entry */    \
+        if ((DBG & 1)) CTTS_WAIT_VM(0);                                                              \
+        else if (STEADY) CTTS_WAIT_VM(8 * (NS - 2));       /* own DMAs of chunk ch+1 landed */      \
+        else CTTS_W4_WAIT_CHUNKS(nch - ch - 2);                                                     \
+        __builtin_amdgcn_s_barrier();                      /* chunk ch+1 visible; stage `cur` is free */ \
+        CTTS_SB();                                                                                  \
+        /* k-step 1: next chunk's k-step-0 fragments behind MFMAs 1..8, the DMA of chunk ch + NS behind 8..15 */ \
+        const bool more = STEADY || ch + 1 < nch;                                                   \
+        const u64 ub = STEADY ? CTTS_UNIFORM64(tnext) : 0;                                          \
+        _Pragma("unroll") for (int m = 0; m < 16; ++m) {                                            \
+            CTTS_W4_MFMA1(1, m >> 2, m & 3);                                                        \
+            CTTS_SB();                                                                              \
+            if (m >= 1 && m <= 8 && more) CTTS_W4_FRAG1(0, m - 1, nxt);                             \
+            if (STEADY && !(DBG & 1) && m >= 8) CTTS_W4_DMA1(cur, ch + NS, ub, m - 8);                \
+            CTTS_SB();                                                                              \
+        }                                                                                           \
+        cur = nxt;                                                                                  \
+    } while (0)
+    int ch = 0;
+    for (; ch + NS < nch; ++ch) CTTS_W4_CHUNK(true);
+    for (; ch < nch; ++ch) CTTS_W4_CHUNK(false);
+#undef CTTS_W4_CHUNK
+#undef CTTS_W4_FRAG1
+#undef CTTS_W4_MFMA1
+#undef CTTS_W4_DMA1
+#undef CTTS_SB
+#undef CTTS_W4_FRAGS
+#undef CTTS_W4_MFMA
+#undef CTTS_W4_DMA
+#undef CTTS_W4_WAIT_CHUNKS
+#undef CTTS_UNIFORM64
+#undef CTTS_WAIT_VM
+    const unsigned long long st2 = (DBG & 4) ? __builtin_readcyclecounter() : 0;
+    const unsigned long long rt2 = (DBG & 4) ? __builtin_amdgcn_s_memrealtime() : 0;
+    bf16_epilogue<EPI>(a, acc[0], lds, t, mb, wm, 2 * wn, b, n0, l31, lhi);
+    bf16_epilogue<EPI>(a, acc[1], lds, t, mb, wm, 2 * wn + 1, b, n0, l31, lhi);
+    if ((DBG & 4) && blockIdx.x == 1000 && t == 0) {
+        g_w4_stamps[0] = st2 - st1; g_w4_stamps[1] = rt2 - rt1;
+        g_w4_stamps[2] = __builtin_readcyclecounter() - st2; g_w4_stamps[3] = st1 - st0; g_w4_stamps[4] = nch;
+    }
+}
+
 // dst packed [MB][nch][4][256][8]; thread = one 16-byte unit (mb, chunk, g, r)
 __global__ __launch_bounds__(256) void pack_a_bf16_kernel(bf16_t* __restrict__ dst, const float* __restrict__ src,
                                                          int nch_total, int k_off, int ksrc, int epi, int C, int M,
@@ -571,6 +779,10 @@ int launch_pack_a_bf16(bf16_t* dst, const float* src, int MB, int nch_total, int
     return CTTS_OK;
 }
 
+extern "C" int ctts_debug_w4_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w4_stamps), sizeof(g_w4_stamps)) == hipSuccess ? 0 : -1;
+}
+
 int launch_gemm_bf16(int epi, const BGemmArgs& a, hipStream_t stream) {
     CTTS_CHECK_ARG(a.nseg >= 1 && a.nseg <= BGEMM_MAX_SEG, "gemm_bf16: nseg=%d", a.nseg);
     int nch = 0;
@@ -591,6 +803,10 @@ int launch_gemm_bf16(int epi, const BGemmArgs& a, hipStream_t stream) {
     const bool no_wide = getenv("CTTS_BF16_NO_WIDE") != nullptr;
     const bool no_pp = getenv("CTTS_BF16_NO_PP") != nullptr;
     const int pp_stages = getenv("CTTS_BF16_PP_STAGES") ? atoi(getenv("CTTS_BF16_PP_STAGES")) : 3;
+    // four-wave 128 x 128 wave tiles: opt-in.  Measured equal to the skewed 8-wave kernel on the in-layer GEMM (both
+    // are held by the clock the chip sustains under bf16 MFMA + LDS traffic) and slower on the short-K
+    // res GEMM, where its one-wave-per-SIMD epilogue is exposed.
+    const bool w4 = getenv("CTTS_BF16_W4") != nullptr;
     // wide (256 x 256, 512 threads) tiles when the problem has enough of them to fill the chip
     const int ntiles_w = (a.L + 255) / 256;
     const bool pp = !no_pp && a.nch_total + 3 <= BGEMM_PP_MAX_CHUNKS;
@@ -612,13 +828,19 @@ int launch_gemm_bf16(int epi, const BGemmArgs& a, hipStream_t stream) {
     CTTS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "gemm_bf16: grid %lld", blocks);
     const dim3 grid((unsigned)blocks);
     if (epi == BGEMM_EPI_GATE) {
-        if (wide && pp && pp_stages == 4) hipLaunchKernelGGL((conv_gemm_bf16_pp_kernel<BGEMM_EPI_GATE, 4>), grid, dim3(512), 0, stream, b);
+        const int dbg = getenv("CTTS_BF16_W4_DEBUG") ? atoi(getenv("CTTS_BF16_W4_DEBUG")) : 0;
+#define CTTS_W4_DBG(D) if (wide && pp && w4 && dbg == D) hipLaunchKernelGGL((conv_gemm_bf16_w4_kernel<BGEMM_EPI_GATE, D>), grid, dim3(256), 0, stream, b); else
+        CTTS_W4_DBG(1) CTTS_W4_DBG(2) CTTS_W4_DBG(4) CTTS_W4_DBG(5) CTTS_W4_DBG(6)
+#undef CTTS_W4_DBG
+        if (wide && pp && w4) hipLaunchKernelGGL((conv_gemm_bf16_w4_kernel<BGEMM_EPI_GATE>), grid, dim3(256), 0, stream, b);
+        else if (wide && pp && pp_stages == 4) hipLaunchKernelGGL((conv_gemm_bf16_pp_kernel<BGEMM_EPI_GATE, 4>), grid, dim3(512), 0, stream, b);
         else if (wide && pp) hipLaunchKernelGGL((conv_gemm_bf16_pp_kernel<BGEMM_EPI_GATE, 3>), grid, dim3(512), 0, stream, b);
         else if (wide) hipLaunchKernelGGL((conv_gemm_bf16_kernel<BGEMM_EPI_GATE, true, 4>), grid, dim3(512), 0, stream, b);
         else if (use_glds) hipLaunchKernelGGL((conv_gemm_bf16_kernel<BGEMM_EPI_GATE, true, 2>), grid, dim3(256), 0, stream, b);
         else hipLaunchKernelGGL((conv_gemm_bf16_kernel<BGEMM_EPI_GATE, false, 2>), grid, dim3(256), 0, stream, b);
     } else {
-        if (wide && pp && pp_stages == 4) hipLaunchKernelGGL((conv_gemm_bf16_pp_kernel<BGEMM_EPI_SPLIT, 4>), grid, dim3(512), 0, stream, b);
+        if (wide && pp && w4) hipLaunchKernelGGL((conv_gemm_bf16_w4_kernel<BGEMM_EPI_SPLIT>), grid, dim3(256), 0, stream, b);
+        else if (wide && pp && pp_stages == 4) hipLaunchKernelGGL((conv_gemm_bf16_pp_kernel<BGEMM_EPI_SPLIT, 4>), grid, dim3(512), 0, stream, b);
         else if (wide && pp) hipLaunchKernelGGL((conv_gemm_bf16_pp_kernel<BGEMM_EPI_SPLIT, 3>), grid, dim3(512), 0, stream, b);
         else if (wide) hipLaunchKernelGGL((conv_gemm_bf16_kernel<BGEMM_EPI_SPLIT, true, 4>), grid, dim3(512), 0, stream, b);
         else if (use_glds) hipLaunchKernelGGL((conv_gemm_bf16_kernel<BGEMM_EPI_SPLIT, true, 2>), grid, dim3(256), 0, stream, b);
