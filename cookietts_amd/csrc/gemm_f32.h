@@ -79,6 +79,11 @@ struct GemmArgs {
     // GATE / GATE_RS: optional per-element addend before the gate (conditioning computed elsewhere), padded layout
     // [B][2*pairC][ld] in DENSE row order (row c -> tanh input, row pairC + c -> sigmoid input), same ld / pad as B
     const float* addend; long long addend_bstride;
+    int addend_ld, addend_pad;   // row stride / left pad of the addend tensor (0, 0 = ld, pad of the B operand)
+    // GATE only: addend_frames = F > 0: the addend holds F columns per row at a lower rate and is linearly
+    // interpolated to the L columns of the launch (align_corners=True: position n reads n * (F-1)/(L-1)), the
+    // arithmetic of ATen's upsample_linear1d (glow_ax.py:362-373) - the sample-rate tensor is never materialised
+    int addend_frames;
     int map_mode;         // block id -> (m-block, tile, batch) mapping, chosen by the launcher (see gemm_f32.hip)
     const float* rs_wT;   // GEMM_EPI_GATE_RS: res/skip weight transposed and row-padded: [64][128]
     const float* rs_bias; // [128] (rows >= rs_rows zero)

@@ -430,13 +430,39 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
                 const int n = n0 + wn * 64 + nt * 32 + l31;
                 if (n < a.L) {
                     float add0[16], add1[16];
-                    if (EPI == GEMM_EPI_GATE && a.addend) {       // uniform
-                        const float* ad = a.addend + (size_t)b * a.addend_bstride + a.pad + n;
+                    if (EPI == GEMM_EPI_GATE && a.addend && a.addend_frames > 0) {   // uniform: interpolated addend
+                        const int F = a.addend_frames;
+                        const float scale = a.L > 1 ? (float)(F - 1) / (float)(a.L - 1) : 0.f;
+                        const float real = scale * (float)n;
+                        const int i0 = (int)real;
+                        const int i1 = i0 + 1 < F ? i0 + 1 : F - 1;
+                        const float l1 = real - (float)i0;
+                        const float l0 = 1.0f - l1;
+                        const float* ad = a.addend + (size_t)b * a.addend_bstride + a.addend_pad;
+#pragma unroll
+                        for (int hf = 0; hf < 2; ++hf) {            // two halves: 32 loads in flight, not 64
+                            float s00[8], s01[8], s10[8], s11[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const int r = hf * 8 + q;
+                                const int c = min(cbase + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi, a.pairC - 1);
+                                const float* r0 = ad + (size_t)c * a.addend_ld;
+                                const float* r1 = ad + (size_t)(a.pairC + c) * a.addend_ld;
+                                s00[q] = r0[i0]; s01[q] = r0[i1]; s10[q] = r1[i0]; s11[q] = r1[i1];
+                            }
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                add0[hf * 8 + q] = l0 * s00[q] + l1 * s01[q];
+                                add1[hf * 8 + q] = l0 * s10[q] + l1 * s11[q];
+                            }
+                        }
+                    } else if (EPI == GEMM_EPI_GATE && a.addend) {                   // uniform
+                        const float* ad = a.addend + (size_t)b * a.addend_bstride + a.addend_pad + n;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int c = min(cbase + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi, a.pairC - 1);
-                            add0[r] = ad[(size_t)c * a.ld];
-                            add1[r] = ad[(size_t)(a.pairC + c) * a.ld];
+                            add0[r] = ad[(size_t)c * a.addend_ld];
+                            add1[r] = ad[(size_t)(a.pairC + c) * a.addend_ld];
                         }
                     } else {
 #pragma unroll
@@ -471,10 +497,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
                     float u0 = acc[mt][nt][r] + bias[mt * 32 + row];
                     float u1 = acc[mt + 2][nt][r] + bias[64 + mt * 32 + row];
                     if (a.addend) {                                // uniform; columns >= L of a padded row are readable
-                        const float* ad = a.addend + (size_t)b * a.addend_bstride + a.pad + n0 + wn * 64 + nt * 32 + l31;
+                        const float* ad = a.addend + (size_t)b * a.addend_bstride + a.addend_pad + n0 + wn * 64 + nt * 32 + l31;
                         const int c = min(mt * 32 + row, a.pairC - 1);
-                        u0 += ad[(size_t)c * a.ld];
-                        u1 += ad[(size_t)(a.pairC + c) * a.ld];
+                        u0 += ad[(size_t)c * a.addend_ld];
+                        u1 += ad[(size_t)(a.pairC + c) * a.addend_ld];
                     }
                     actv[mt][nt][r] = ok ? fast_tanh(u0) * fast_sigmoid(u1) : 0.0f;
                 }
@@ -561,6 +587,9 @@ int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
                                          : (a.M > (a.MB - 1) * a.bm && a.M <= a.MB * a.bm),
                    "gemm: M=%d pairC=%d MB=%d bm=%d", a.M, a.pairC, a.MB, a.bm);
     CTTS_CHECK_ARG(a.dst_ld > 0 && a.dst0, "gemm: destination not set");
+    if (a.addend_ld == 0) { a.addend_ld = a.ld; a.addend_pad = a.pad; }
+    CTTS_CHECK_ARG(a.addend_frames == 0 || (epi == GEMM_EPI_GATE && a.addend && a.addend_frames <= a.addend_ld - a.addend_pad),
+                   "gemm: interpolated addend needs the GATE epilogue (frames=%d)", a.addend_frames);
     long long blocks = (long long)a.MB * a.ntiles * a.batch;
     a.map_mode = 0;
     // measured on config 2 (PMC FETCH_SIZE per in-layer launch): 4.2 GB -> 2.5 GB at unchanged speed

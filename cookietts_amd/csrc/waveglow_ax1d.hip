@@ -10,9 +10,9 @@
 // Per flow, in the reference's inverse order:
 //   [un-mix]      (mix_first=False: ax:324-325)              ax_mix_kernel, in place on the latent rows
 //   start 1x1                                                  ax_start_kernel
-//   conditioning  frame-rate rows -> linear interpolation     ax_interp_cond_kernel  (glow_ax.py:362-373, 389-390)
+//   conditioning  frame-rate rows, linearly interpolated       inside the GATE epilogue (glow_ax.py:362-373, 389-390)
 //   n_layers x (dilated conv + cond + gate | res/skip 1x1)    conv_gemm_f32<GATE> with the conditioning as
-//                                                             epilogue addend, conv_gemm_f32<SPLIT>
+//                                                             interpolated epilogue addend, conv_gemm_f32<SPLIT>
 //   end 1x1                                                    conv_gemm_f32<SPLIT>, M = 2*n_half
 //   coupling inverse, NaN -> 0, [un-mix if mix_first]          ax_couple_kernel (em:100-104, ax:333-337)
 // `output` starts from the first layer's skip (glow_ax.py:405-410): 0 + r == r exactly, so the SPLIT epilogue's
@@ -105,7 +105,7 @@ int make_ax_geom(const AxPlan& p, long long samples, AxGeom& g) {
     return CTTS_OK;
 }
 
-struct AxWs { float *audio, *x, *act, *out, *e, *cond_up; size_t total, cond_slot; int e_rows; };
+struct AxWs { float *audio, *x, *act, *out, *e; size_t total; int e_rows; };
 
 void ax_carve(const AxPlan& p, const AxGeom& g, int batch, float* base, AxWs& w) {
     size_t o = 0;
@@ -117,8 +117,6 @@ void ax_carve(const AxPlan& p, const AxGeom& g, int batch, float* base, AxWs& w)
     w.act = take(B * p.C * g.ld);
     w.out = take(B * p.C * g.ld);
     w.e = take(B * w.e_rows * g.ld);
-    w.cond_slot = B * 2 * p.C * g.ld;
-    w.cond_up = take((size_t)p.c.n_layers * w.cond_slot);
     w.total = o;
 }
 
@@ -219,31 +217,6 @@ __global__ __launch_bounds__(256) void ax_start_kernel(const float* __restrict__
     float* xb = x + ((size_t)b * C + c0) * ld + pad + l;
 #pragma unroll
     for (int q = 0; q < 8; ++q) xb[(size_t)q * ld] = acc[q];
-}
-
-// Conditioning of one flow: frame-rate rows [B][2C*n_layers][f_ld] -> up[layer][b][2C][pad + l], linear
-// interpolation with align_corners=True in fp32, the arithmetic of ATen's upsample_linear1d (glow_ax.py:362-373).
-__global__ __launch_bounds__(256) void ax_interp_cond_kernel(const float* __restrict__ frames, float* __restrict__ up,
-                                                             int rows2c, int n_layers, int F, int f_ld, int f_pad, int L,
-                                                             int ld, int pad, size_t slot) {
-    const int l = blockIdx.x * 256 + threadIdx.x;
-    const int ch = blockIdx.y, b = blockIdx.z;
-    if (l >= L) return;
-    const float* src = frames + ((size_t)b * rows2c * n_layers + ch) * f_ld + f_pad;
-    float v;
-    if (F == L) {
-        v = src[l];
-    } else {
-        const float scale = L > 1 ? (float)(F - 1) / (float)(L - 1) : 0.f;
-        const float real = scale * (float)l;
-        const int i0 = (int)real;
-        const int i1 = i0 + 1 < F ? i0 + 1 : F - 1;
-        const float l1 = real - (float)i0;
-        const float l0 = 1.0f - l1;
-        v = l0 * src[i0] + l1 * src[i1];
-    }
-    const int layer = ch / rows2c, r = ch % rows2c;
-    up[(size_t)layer * slot + ((size_t)b * rows2c + r) * ld + pad + l] = v;
 }
 
 // (log_s, t) = (e[:h], e[h:]);  a1 = (a1 - t) / exp(log_s)   (efficient_modules.py:100-103; note the order,
@@ -411,9 +384,6 @@ int ctts_wgax_inverse_f32(const ctts_wgax_config* cfg, const void* packed, const
                            blob + f.start_b, w.x, C, G, d.ch_off, d.n_half, L, g.ld, g.pad);
         CTTS_CHECK_LAUNCH("ax_start");
         const float* fr = cond + (size_t)k * batch * 2 * C * nl * cond_ld;
-        hipLaunchKernelGGL(ax_interp_cond_kernel, dim3((L + 255) / 256, 2 * C * nl, batch), dim3(256), 0, s, fr, w.cond_up,
-                           2 * C, nl, frames, cond_ld, cond_pad, L, g.ld, g.pad, w.cond_slot);
-        CTTS_CHECK_LAUNCH("ax_interp_cond");
         for (int i = 0; i < nl; ++i) {
             const int dil = 1 << i;
             {
@@ -423,8 +393,12 @@ int ctts_wgax_inverse_f32(const ctts_wgax_config* cfg, const void* packed, const
                 for (int t = 0; t < ks; ++t) a.seg[t] = {w.x, cstride, p.nch_c, (t - ks / 2) * dil, 0, 0};
                 a.dst0 = w.act; a.dst0_bstride = cstride;
                 a.M = 2 * C; a.pairC = C;
-                a.addend = w.cond_up + (size_t)i * w.cond_slot;
-                a.addend_bstride = (long long)2 * C * g.ld;
+                // frame-rate conditioning rows of this layer, interpolated to sample rate inside the GATE epilogue
+                // (glow_ax.py:362-373, 389-390); read as they are when the rates already agree
+                a.addend = fr + (size_t)i * 2 * C * cond_ld;
+                a.addend_bstride = (long long)2 * C * nl * cond_ld;
+                a.addend_ld = cond_ld; a.addend_pad = cond_pad;
+                a.addend_frames = frames == L ? 0 : frames;
                 if ((rc = launch_gemm_f32(GEMM_EPI_GATE, a, s))) return rc;
             }
             {
