@@ -75,8 +75,10 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-budget", type=float, default=40.0, help="wall-time budget (s) of the CPU-baseline repeats")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-exchange", action="store_true", help="skip the scatter/gather timing for N > 1")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
-                    help="f32 = BASELINE config 2 (default, the headline); bf16 = config 3 (use --batch 32)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "bf16x3"],
+                    help="f32 = BASELINE config 2 (default, the headline); bf16 = config 3 (use --batch 32); bf16x3 = "
+                         "split-bf16 (hi + lo operands, three bf16 MFMA products per contraction, fp32 accumulate): an "
+                         "extra row, never the headline")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="test hook for tests/test_bench_launcher.py: gloo on CPU with a stand-in step function; "
                          "exercises the launcher, the rank plumbing and sharding.py only - measures nothing")
@@ -221,6 +223,8 @@ def worker(args):
         model = model.to(device).eval()
         if args.dtype == "bf16":
             model.set_compute_dtype(torch.bfloat16)
+        elif args.dtype == "bf16x3":
+            model.set_compute_dtype("bf16x3")
 
         def step_on(m):
             return model.infer(m, sigma=0.6)
@@ -298,7 +302,8 @@ def worker(args):
             # algorithmic MACs per time step of ONE in-layer launch: dilated conv
             # C*2C*3 plus this layer's slice of the conditioning projection 256*2C
             mac = 3 * C * 2 * C + 256 * 2 * C
-            flop_per_launch = 2.0 * mac * B * L
+            # bf16x3 executes three bf16 products per algorithmic MAC; the roofline counts the EXECUTED bf16 flops
+            flop_per_launch = 2.0 * mac * B * L * (3 if args.dtype == "bf16x3" else 1)
             mean_s = ms.value / max(n.value, 1) * 1e-3
             achieved = flop_per_launch / mean_s / 1e12
             peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
@@ -311,6 +316,9 @@ def worker(args):
                                            f"launch shape, not re-measured in this run") if traffic_src else None,
                         "launches": int(n.value), "mean_launch_ms": round(mean_s * 1e3, 4),
                         "flop_per_launch": flop_per_launch}
+            if args.dtype == "bf16x3":
+                roofline["note"] = ("flop_per_launch counts the three executed bf16 products per algorithmic MAC; "
+                                    "algorithmic flops are a third of it")
             if args.dtype == "bf16":
                 # In bf16 the in-layer GEMM stays MFMA-bound (1430 FLOP/B vs a ridge of ~312); the memory-bound WN
                 # kernels are the res GEMM (K = C, per layer: act read + x read-modify-write = 3*C*2 B per time step)
@@ -344,7 +352,7 @@ def worker(args):
             "data": "synthetic" if not selftest else "LAUNCHER SELF-TEST (gloo/CPU stand-in step; not a measurement)",
             "rtf": value / 22050.0,
             "config": {"workload": f"WaveGlow {args.config} ({cfg['n_flows']} flows, {C} WN ch, "
-                                   f"{cfg['n_group']} groups, {n_layers} layers) {'fp32' if args.dtype == 'f32' else 'bf16-MFMA'} infer, batch {B} x (80x{F}) "
+                                   f"{cfg['n_group']} groups, {n_layers} layers) { {'f32': 'fp32', 'bf16': 'bf16-MFMA', 'bf16x3': 'split-bf16 (3 bf16 MFMA products, fp32 accumulate)'}[args.dtype] } infer, batch {B} x (80x{F}) "
                                    f"mel per GPU, sigma 0.6, random-init weights",
                        "batch_per_gpu": B, "frames": F, "samples_per_step": world * B * T,
                        "parallelism": f"utterance-batch shard x{world}"},

@@ -16,7 +16,8 @@ namespace ctts {
 constexpr int BGEMM_BM = 256;
 constexpr int BGEMM_BN = 128;
 constexpr int BGEMM_KC = 32;     // K per LDS stage (two 32x32x16 MFMA k-steps)
-constexpr int BGEMM_MAX_SEG = 4;
+constexpr int BGEMM_MAX_SEG = 12;    // split-bf16 in-layer GEMM: 3 taps x 3 (hi/lo) products + 3 cond products
+constexpr int BGEMM_MAX_CHUNKS = 253; // K chunks per launch (chunk -> address table in LDS)
 
 enum BGemmEpilogue : int { BGEMM_EPI_SPLIT = 0, BGEMM_EPI_GATE = 1 };
 
@@ -42,6 +43,11 @@ struct BGemmArgs {
     int split;            // SPLIT: rows < split -> dst0, else dst1[row - split] (multiple of 32)
     int pairC;            // GATE: channels (dense rows c and pairC + c)
     int map_mode;         // block id -> (m-block, tile, batch) mapping, chosen by the launcher
+    // Split-bf16 ("bf16x3") destinations: lo_off != 0 -> every destination tensor is a PAIR of planes, hi at dst and lo
+    // at dst + lo_off (elements): the epilogue stores hi = bf16(v), lo = bf16(v - hi) and read-modify-write
+    // destinations are read as hi + lo.  The K side of the split is expressed with segments (x_hi*W_hi + x_lo*W_hi +
+    // x_hi*W_lo as three segments over the two planes and two packed weight parts).
+    long long lo_off;
 };
 
 // dense weight row of block-local row r of M-block mb (same pairing as the fp32 kernel), -1 = padding
@@ -60,9 +66,10 @@ int launch_gemm_bf16(int epi, const BGemmArgs& a, hipStream_t stream);
 
 // fp32 dense weights -> packed bf16 A (same source addressing as launch_pack_a of the fp32 path; K slabs
 // are 32 wide here, so an interleaved member's slab j lands at slab j*k_group + k_member)
+// part: 0 = bf16(w) (round to nearest even), 1 = bf16(w - bf16(w)) (the low half of the split-bf16 form)
 int launch_pack_a_bf16(bf16_t* dst, const float* src, int MB, int nch_total, int k_off, int ksrc, int epi, int C,
                        int M, long long src_row_off, long long src_row_stride, int src_k_stride, hipStream_t s,
-                       int k_group = 1, int k_member = 0);
+                       int k_group = 1, int k_member = 0, int part = 0);
 
 __host__ __device__ inline bf16_t f32_to_bf16_rne(float f) {
     union { float f; unsigned int u; } v;

@@ -16,7 +16,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 namespace {
 
 constexpr int A_UNITS = 4 * BGEMM_BM;                   // 1024 x 16 B
-constexpr int BGEMM_PP_MAX_CHUNKS = 128;                // ping-pong kernel: chunk address table entries
+constexpr int BGEMM_PP_MAX_CHUNKS = 256;                // chunk address table entries (8 B each, in LDS)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // one 16-byte K8 unit
 typedef const __attribute__((address_space(1))) u32x4* gunit_ptr;
@@ -37,6 +37,11 @@ __device__ __forceinline__ float fast_gate(float u0, float u1) {
     return (e - 1.0f) * __builtin_amdgcn_rcpf((e + 1.0f) * (1.0f + q));
 }
 
+// split-bf16: low halves of two values whose high halves are the packed pair `hi` (lo = bf16(v - float(hi)))
+__device__ __forceinline__ unsigned int pack2_residual(float v0, float v1, unsigned int hi) {
+    return pack2(v0 - __builtin_bit_cast(float, hi << 16), v1 - __builtin_bit_cast(float, hi & 0xffff0000u));
+}
+
 // Half-wave exchange (v_permlane32_swap): lanes 32..63 of x swap with lanes 0..31 of y.
 __device__ __forceinline__ void swap_halves(unsigned int& x, unsigned int& y) {
     const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
@@ -48,6 +53,38 @@ __device__ __forceinline__ void swap_halves(float& x, float& y) {
     swap_halves(a, b);
     x = __builtin_bit_cast(float, a);
     y = __builtin_bit_cast(float, b);
+}
+
+// Chunk c -> global byte address of its B rows (channel group 0, column n0 + shift) for this workgroup: the segment /
+// tap sequencing is resolved ONCE per workgroup into an LDS table, so the steady-state loads are a table read plus a
+// per-thread constant.  Static segment indices only: a dynamically indexed kernarg goes to scratch.
+__device__ __forceinline__ void build_chunk_table(const BGemmArgs& a, unsigned long long* tab, int t, int mb, int b, int n0) {
+    if (t >= a.nch_total) return;
+    const int ilv = a.interleave > 1 ? a.interleave : 0;
+    const int n_il = ilv * a.seg[0].nch;
+    int c = t, s, local;
+    if (c < n_il) {
+        s = c % ilv;
+        local = c / ilv;
+    } else {
+        c -= n_il;
+        s = ilv;
+#pragma unroll
+        for (int k = 0; k < BGEMM_MAX_SEG - 1; ++k)
+            if (s == k && k < a.nseg - 1 && c >= a.seg[k].nch) { c -= a.seg[k].nch; s = k + 1; }
+        local = c;
+    }
+    static_assert(BGEMM_MAX_SEG == 12, "segment select chain below");
+#define CTTS_SEGF(f)                                                                                                  \
+    (s == 0 ? a.seg[0].f : s == 1 ? a.seg[1].f : s == 2 ? a.seg[2].f : s == 3 ? a.seg[3].f : s == 4 ? a.seg[4].f :    \
+     s == 5 ? a.seg[5].f : s == 6 ? a.seg[6].f : s == 7 ? a.seg[7].f : s == 8 ? a.seg[8].f : s == 9 ? a.seg[9].f :    \
+     s == 10 ? a.seg[10].f : a.seg[11].f)
+    const bf16_t* base = CTTS_SEGF(base);
+    const long long bstride = CTTS_SEGF(bstride);
+    const int shift = CTTS_SEGF(shift), mbr = CTTS_SEGF(mb_rows);
+#undef CTTS_SEGF
+    tab[t] = (unsigned long long)(base + (size_t)b * bstride) +
+             16ull * ((size_t)(mb * (mbr / 8) + 4 * local) * a.ld + a.pad + n0 + shift);
 }
 
 // Epilogue shared by the block shapes.  32x32 C/D layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5):
@@ -74,7 +111,7 @@ __device__ __forceinline__ void bf16_epilogue(const BGemmArgs& a, f32x16 (&acc)[
                 const int n = n0 + wn * 64 + nt * 32 + l31;
 #pragma unroll
                 for (int qp = 0; qp < 2; ++qp) {
-                    unsigned int pk[2][2];                   // [group of the pair][dword]
+                    unsigned int pk[2][2], pl[2][2];         // [group of the pair][dword]: high halves, low halves
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int q = 2 * qp + h;
@@ -88,13 +125,21 @@ __device__ __forceinline__ void bf16_epilogue(const BGemmArgs& a, f32x16 (&acc)[
                         }
                         pk[h][0] = pack2(v[0], v[1]);
                         pk[h][1] = pack2(v[2], v[3]);
+                        if (a.lo_off) {                      // uniform
+                            pl[h][0] = pack2_residual(v[0], v[1], pk[h][0]);
+                            pl[h][1] = pack2_residual(v[2], v[3], pk[h][1]);
+                        }
                     }
                     swap_halves(pk[0][0], pk[1][0]);
                     swap_halves(pk[0][1], pk[1][1]);
                     const int cg = (cbase + mt * 32) / 8 + 2 * qp + lhi;
-                    if (n < a.L)
-                        *reinterpret_cast<u32x4*>(dst + ((size_t)cg * a.ld + a.pad + n) * 8) =
-                            u32x4{pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
+                    bf16_t* du = dst + ((size_t)cg * a.ld + a.pad + n) * 8;
+                    if (n < a.L) *reinterpret_cast<u32x4*>(du) = u32x4{pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
+                    if (a.lo_off) {
+                        swap_halves(pl[0][0], pl[1][0]);
+                        swap_halves(pl[0][1], pl[1][1]);
+                        if (n < a.L) *reinterpret_cast<u32x4*>(du + a.lo_off) = u32x4{pl[0][0], pl[0][1], pl[1][0], pl[1][1]};
+                    }
                 }
             }
         }
@@ -108,16 +153,18 @@ __device__ __forceinline__ void bf16_epilogue(const BGemmArgs& a, f32x16 (&acc)[
             const int accum = second ? a.acc1 : a.acc0;
             const int cg0 = (second ? rbase - a.split : rbase) / 8;
             // read-modify-write: all four 16-byte loads of the row tile are issued before the first store
-            u32x4 old[2][2];
+            u32x4 old[2][2], oldl[2][2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int qp = 0; qp < 2; ++qp) {
+                    const bf16_t* du = dst + ((size_t)(cg0 + 2 * qp + lhi) * a.ld + a.pad + n0 + wn * 64 + nt * 32 + l31) * 8;
                     if (accum)   // uniform; columns >= L of a padded row are readable
-                        old[nt][qp] = *reinterpret_cast<const u32x4*>(
-                            dst + ((size_t)(cg0 + 2 * qp + lhi) * a.ld + a.pad + n0 + wn * 64 + nt * 32 + l31) * 8);
+                        old[nt][qp] = *reinterpret_cast<const u32x4*>(du);
                     else
                         old[nt][qp] = u32x4{0u, 0u, 0u, 0u};
+                    if (accum && a.lo_off) oldl[nt][qp] = *reinterpret_cast<const u32x4*>(du + a.lo_off);
+                    else oldl[nt][qp] = u32x4{0u, 0u, 0u, 0u};
                 }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
@@ -133,17 +180,21 @@ __device__ __forceinline__ void bf16_epilogue(const BGemmArgs& a, f32x16 (&acc)[
 #pragma unroll
                     for (int j = 0; j < 4; ++j) swap_halves(v[0][j], v[1][j]);
                     // v[0] = channels 0..3, v[1] = channels 4..7 of this lane's unit
-                    const u32x4 o = old[nt][qp];
-                    unsigned int pk[4];
+                    const u32x4 o = old[nt][qp], ol = oldl[nt][qp];
+                    unsigned int pk[4], pl[4];
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
-                        const float lo = v[d >> 1][2 * (d & 1)] + bf16_to_f32((bf16_t)(o[d] & 0xffff));
-                        const float hi = v[d >> 1][2 * (d & 1) + 1] + bf16_to_f32((bf16_t)(o[d] >> 16));
-                        pk[d] = pack2(lo, hi);
+                        // even / odd channel of the dword; the old value of a split destination is hi + lo
+                        const float ev = v[d >> 1][2 * (d & 1)] +
+                                         (bf16_to_f32((bf16_t)(o[d] & 0xffff)) + bf16_to_f32((bf16_t)(ol[d] & 0xffff)));
+                        const float od = v[d >> 1][2 * (d & 1) + 1] +
+                                         (bf16_to_f32((bf16_t)(o[d] >> 16)) + bf16_to_f32((bf16_t)(ol[d] >> 16)));
+                        pk[d] = pack2(ev, od);
+                        pl[d] = a.lo_off ? pack2_residual(ev, od, pk[d]) : 0u;
                     }
-                    if (n < a.L)
-                        *reinterpret_cast<u32x4*>(dst + ((size_t)(cg0 + 2 * qp + lhi) * a.ld + a.pad + n) * 8) =
-                            u32x4{pk[0], pk[1], pk[2], pk[3]};
+                    bf16_t* du = dst + ((size_t)(cg0 + 2 * qp + lhi) * a.ld + a.pad + n) * 8;
+                    if (n < a.L) *reinterpret_cast<u32x4*>(du) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                    if (a.lo_off && n < a.L) *reinterpret_cast<u32x4*>(du + a.lo_off) = u32x4{pl[0], pl[1], pl[2], pl[3]};
                 }
             }
         }
@@ -162,7 +213,9 @@ __global__ __launch_bounds__(128 * NW, 2) void conv_gemm_bf16_kernel(const BGemm
     constexpr int NA = A_UNITS / NT;                        // 16-byte units per thread per stage (A)
     constexpr int NB_ = B_UNITS / NT;                       // (B) == 2 for both shapes
     static_assert(NB_ == 2, "B staging assumes 2 units per thread");
-    __shared__ __attribute__((aligned(16))) u32x4 lds[(GLDS ? 3 : 2) * STAGE_UNITS + 16];
+    constexpr int NSTAGE = GLDS ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) u32x4 lds[NSTAGE * STAGE_UNITS + BGEMM_PP_MAX_CHUNKS / 2];
+    unsigned long long* tab = reinterpret_cast<unsigned long long*>(lds + NSTAGE * STAGE_UNITS);
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -188,19 +241,13 @@ __global__ __launch_bounds__(128 * NW, 2) void conv_gemm_bf16_kernel(const BGemm
     }
     const int n0 = tile * BN;
 
-    // per-thread B staging: units (g, n) with g = t / BN (+2), n = t % BN
+    // per-thread B staging: units (g, n) with g = t / BN (+2), n = t % BN, relative to the chunk's table entry
     const int bg = t / BN, bn = t % BN;
-    gunit_ptr sbase[4];
-    int snch[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const BGemmSeg& g = a.seg[s];
-        sbase[s] = (gunit_ptr)(g.base + (size_t)b * g.bstride) +
-                   ((size_t)(bg + mb * (g.mb_rows / 8)) * a.ld + a.pad + n0 + g.shift + bn);
-        snch[s] = s < a.nseg ? g.nch : 0x7fffffff;
-    }
-    const size_t chunk_units = (size_t)4 * a.ld;        // 4 channel groups per chunk
+    build_chunk_table(a, tab, t, mb, b, n0);
+    __syncthreads();
+    const size_t boff_units = (size_t)bg * a.ld + bn;
     const size_t g2_units = (size_t)2 * a.ld;
+    int ich = 0;                                            // next chunk to stage
 
     gunit_ptr ap = (gunit_ptr)a.A + (size_t)mb * a.nch_total * A_UNITS + t;
 
@@ -213,23 +260,15 @@ __global__ __launch_bounds__(128 * NW, 2) void conv_gemm_bf16_kernel(const BGemm
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     u32x4 ra0, ra1, ra2, ra3, rb0, rb1;
-    int seg = 0, local = 0;
-    const int ilv = a.interleave > 1 ? a.interleave : 0;
-    bool in_ilv = ilv > 0;
 
 #define CTTS_ISSUE_LOADS()                                                                      \
     do {                                                                                        \
         ra0 = ap[0]; ra1 = ap[NT];                                                              \
         if constexpr (NA > 2) { ra2 = ap[2 * NT]; ra3 = ap[3 * NT]; }                           \
         ap += A_UNITS;                                                                          \
-        gunit_ptr sb_ = seg == 0 ? sbase[0] : seg == 1 ? sbase[1] : seg == 2 ? sbase[2] : sbase[3]; \
-        const int sn_ = seg == 0 ? snch[0] : seg == 1 ? snch[1] : seg == 2 ? snch[2] : snch[3]; \
-        gunit_ptr bp = sb_ + (size_t)local * chunk_units;                                       \
+        gunit_ptr bp = (gunit_ptr)tab[ich++] + boff_units;                                      \
         rb0 = bp[0];                                                                            \
         rb1 = bp[g2_units];                                                                     \
-        if (in_ilv) {                                                                           \
-            if (++seg == ilv) { seg = 0; if (++local == sn_) { local = 0; seg = ilv; in_ilv = false; } } \
-        } else if (++local == sn_) { local = 0; ++seg; }                                        \
     } while (0)
 
 #define CTTS_STORE_LDS(buf)                                                                     \
@@ -255,14 +294,9 @@ __global__ __launch_bounds__(128 * NW, 2) void conv_gemm_bf16_kernel(const BGemm
             __builtin_amdgcn_global_load_lds(ap + 3 * NT, la_ + 3 * NT, 16, 0, 0);              \
         }                                                                                       \
         ap += A_UNITS;                                                                          \
-        gunit_ptr sb_ = seg == 0 ? sbase[0] : seg == 1 ? sbase[1] : seg == 2 ? sbase[2] : sbase[3]; \
-        const int sn_ = seg == 0 ? snch[0] : seg == 1 ? snch[1] : seg == 2 ? snch[2] : snch[3]; \
-        gunit_ptr bp = sb_ + (size_t)local * chunk_units;                                       \
+        gunit_ptr bp = (gunit_ptr)tab[ich++] + boff_units;                                      \
         __builtin_amdgcn_global_load_lds(bp, la_ + A_UNITS, 16, 0, 0);                          \
         __builtin_amdgcn_global_load_lds(bp + g2_units, la_ + A_UNITS + NT, 16, 0, 0);          \
-        if (in_ilv) {                                                                           \
-            if (++seg == ilv) { seg = 0; if (++local == sn_) { local = 0; seg = ilv; in_ilv = false; } } \
-        } else if (++local == sn_) { local = 0; ++seg; }                                        \
     } while (0)
 
     const int nch = a.nch_total;
@@ -380,31 +414,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_bf16_pp_kernel(const BGemmAr
     const int n0 = tile * BN;
     const int nch = a.nch_total;
 
-    // Chunk c -> global byte address of its B rows (channel group 0, column n0 + shift): the segment / tap
-    // sequencing is resolved ONCE here, so the steady-state DMA issue is four instructions with scalar bases.
-    if (t < nch) {
-        const int ilv = a.interleave > 1 ? a.interleave : 0;
-        const int n_il = ilv * a.seg[0].nch;
-        int c = t, s, local;
-        if (c < n_il) {
-            s = c % ilv;
-            local = c / ilv;
-        } else {
-            c -= n_il;
-            s = ilv;
-#pragma unroll
-            for (int k = 0; k < BGEMM_MAX_SEG - 1; ++k)     // static indices: a dynamically indexed kernarg goes to scratch
-                if (s == k && k < a.nseg - 1 && c >= a.seg[k].nch) { c -= a.seg[k].nch; s = k + 1; }
-            local = c;
-        }
-#define CTTS_SEGF(f) (s == 0 ? a.seg[0].f : s == 1 ? a.seg[1].f : s == 2 ? a.seg[2].f : a.seg[3].f)
-        const bf16_t* base = CTTS_SEGF(base);
-        const long long bstride = CTTS_SEGF(bstride);
-        const int shift = CTTS_SEGF(shift), mbr = CTTS_SEGF(mb_rows);
-#undef CTTS_SEGF
-        tab[t] = (u64)(base + (size_t)b * bstride) +
-                 16ull * ((size_t)(mb * (mbr / 8) + 4 * local) * a.ld + a.pad + n0 + shift);
-    }
+    build_chunk_table(a, tab, t, mb, b, n0);
     // per-thread byte offsets inside a chunk: B unit (g, n) with g = t / 256 (+2), n = t % 256; A unit t (+512)
     const unsigned boff0 = (unsigned)(((t >> 8) * a.ld + (t & 255)) * 16);
     const unsigned boff1 = boff0 + (unsigned)(2 * a.ld * 16);
@@ -578,29 +588,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_w4_kernel(const BGemmArgs 
     const int n0 = tile * BN;
     const int nch = a.nch_total;
 
-    if (t < nch) {                                          // chunk -> global address of its B rows (as in the pp kernel)
-        const int ilv = a.interleave > 1 ? a.interleave : 0;
-        const int n_il = ilv * a.seg[0].nch;
-        int c = t, s, local;
-        if (c < n_il) {
-            s = c % ilv;
-            local = c / ilv;
-        } else {
-            c -= n_il;
-            s = ilv;
-#pragma unroll
-            for (int k = 0; k < BGEMM_MAX_SEG - 1; ++k)
-                if (s == k && k < a.nseg - 1 && c >= a.seg[k].nch) { c -= a.seg[k].nch; s = k + 1; }
-            local = c;
-        }
-#define CTTS_SEGF(f) (s == 0 ? a.seg[0].f : s == 1 ? a.seg[1].f : s == 2 ? a.seg[2].f : a.seg[3].f)
-        const bf16_t* base = CTTS_SEGF(base);
-        const long long bstride = CTTS_SEGF(bstride);
-        const int shift = CTTS_SEGF(shift), mbr = CTTS_SEGF(mb_rows);
-#undef CTTS_SEGF
-        tab[t] = (u64)(base + (size_t)b * bstride) +
-                 16ull * ((size_t)(mb * (mbr / 8) + 4 * local) * a.ld + a.pad + n0 + shift);
-    }
+    build_chunk_table(a, tab, t, mb, b, n0);
     // per-thread byte offsets inside a chunk: B unit (g, n) = (j, t), A unit t + 256 j, j = 0..3
     const unsigned boff = (unsigned)(t * 16), bstep = (unsigned)(a.ld * 16);
     const unsigned aoff = (unsigned)(t * 16);
@@ -744,7 +732,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_w4_kernel(const BGemmArgs 
 __global__ __launch_bounds__(256) void pack_a_bf16_kernel(bf16_t* __restrict__ dst, const float* __restrict__ src,
                                                          int nch_total, int k_off, int ksrc, int epi, int C, int M,
                                                          long long src_row_off, long long src_row_stride,
-                                                         int src_k_stride, int k_group, int k_member) {
+                                                         int src_k_stride, int k_group, int k_member, int part) {
     const int mb = blockIdx.y;
     const int ug = blockIdx.x;                // 8-wide k group index within [0, ksrc/8)
     const int r = threadIdx.x;
@@ -757,7 +745,8 @@ __global__ __launch_bounds__(256) void pack_a_bf16_kernel(bf16_t* __restrict__ d
     for (int j = 0; j < 8; ++j) {
         const int k = k0 + j;
         const float v = (drow >= 0 && k < ksrc) ? src[(src_row_off + drow) * src_row_stride + (long long)k * src_k_stride] : 0.f;
-        d[j] = f32_to_bf16_rne(v);
+        const bf16_t hi = f32_to_bf16_rne(v);
+        d[j] = part == 0 ? hi : f32_to_bf16_rne(v - bf16_to_f32(hi));
     }
 }
 
@@ -765,7 +754,7 @@ __global__ __launch_bounds__(256) void pack_a_bf16_kernel(bf16_t* __restrict__ d
 
 int launch_pack_a_bf16(bf16_t* dst, const float* src, int MB, int nch_total, int k_off, int ksrc, int epi, int C,
                        int M, long long src_row_off, long long src_row_stride, int src_k_stride, hipStream_t s,
-                       int k_group, int k_member) {
+                       int k_group, int k_member, int part) {
     // a ragged ksrc (e.g. a 20-wide speaker embedding) is zero-filled up to its 32-wide slab boundary
     const int kfill = (ksrc + BGEMM_KC - 1) / BGEMM_KC * BGEMM_KC;
     CTTS_CHECK_ARG(k_off % 8 == 0 && ksrc > 0, "pack_a_bf16: k offset must be 8-aligned");
@@ -774,7 +763,7 @@ int launch_pack_a_bf16(bf16_t* dst, const float* src, int MB, int nch_total, int
     CTTS_CHECK_ARG(k_off + kspan * (k_group > 1 ? k_group : 1) <= nch_total * BGEMM_KC, "pack_a_bf16: k range");
     CTTS_CHECK_ARG(k_group <= 1 || (ksrc % BGEMM_KC == 0 && k_off % BGEMM_KC == 0), "pack_a_bf16: k group");
     hipLaunchKernelGGL(pack_a_bf16_kernel, dim3(kspan / 8, MB), dim3(256), 0, s, dst, src, nch_total, k_off, ksrc, epi, C,
-                       M, src_row_off, src_row_stride, src_k_stride, k_group, k_member);
+                       M, src_row_off, src_row_stride, src_k_stride, k_group, k_member, part);
     CTTS_CHECK_LAUNCH("pack_a_bf16");
     return CTTS_OK;
 }

@@ -282,7 +282,7 @@ int run_flow_tail(const Plan& p, const Geom& g, const float* blob, int k, const 
 // (x feeds the next layer), the skip rows are deferred - every layer's gated activation stays in HBM and the skip
 // sum is ONE contraction over K = n_layers * C at the end of the stack, BF_SKIP_GROUP layers per launch.  The
 // per-layer form re-read and re-wrote the skip sum (2 x B*C*L bf16) in all but one of its n_layers epilogues.
-constexpr int BF_SKIP_GROUP = BGEMM_MAX_SEG;
+constexpr int BF_SKIP_GROUP = 4;                   // 4 layers x 3 products = BGEMM_MAX_SEG segments in the split form
 struct BfPlan {
     std::vector<std::vector<size_t>> in_A, rs_A;   // [flow][layer] offsets in bf16 elements (rs_A: res rows, layers < last)
     std::vector<std::vector<size_t>> skip_A;       // [flow][group]: skip rows of the group's layers side by side along K
@@ -291,16 +291,18 @@ struct BfPlan {
     size_t total;
     int nch_in, nch_rs, nch_c0, nch_c1;
     int mb_c, n_groups;                            // M-blocks of a C-row GEMM; skip launches per flow
+    int P;                                         // K products per operand pair: 1 = bf16, 3 = split bf16 (hi*hi + lo*hi + hi*lo)
     int group_layers(int g, int n_layers) const { return std::min(BF_SKIP_GROUP, n_layers - g * BF_SKIP_GROUP); }
 };
 
-void make_bf_plan(const Plan& p, BfPlan& q) {
+void make_bf_plan(const Plan& p, BfPlan& q, int P) {
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o = (o + n + 127) / 128 * 128; return r; };
-    q.nch_in = (p.c.kernel_size * p.C + p.H) / BGEMM_KC;
-    q.nch_rs = p.C / BGEMM_KC;
-    q.nch_c0 = (p.K0 + p.S) / BGEMM_KC;
-    q.nch_c1 = p.H / BGEMM_KC;
+    q.P = P;
+    q.nch_in = P * (p.c.kernel_size * p.C + p.H) / BGEMM_KC;
+    q.nch_rs = P * p.C / BGEMM_KC;
+    q.nch_c0 = P * (p.K0 + p.S) / BGEMM_KC;
+    q.nch_c1 = P * p.H / BGEMM_KC;
     q.cond0_A = take((size_t)p.c.n_flows * q.nch_c0 * BGEMM_KC * BGEMM_BM);
     q.cond1_A = take((size_t)p.c.n_flows * q.nch_c1 * BGEMM_KC * BGEMM_BM);
     q.mb_c = (p.C + BGEMM_BM - 1) / BGEMM_BM;
@@ -320,55 +322,80 @@ void make_bf_plan(const Plan& p, BfPlan& q) {
     q.total = o;
 }
 
+// bf16 tensors of the split form are PAIRS of planes: hi at the pointer, lo at pointer + *_lo elements (0 = plain bf16)
 struct BfWs {
     float *audio, *spect, *spk;
     bf16_t *spect_bf, *spk_bf, *h_tmp_bf, *h_bf, *x, *act, *out;
+    long long spect_lo, spk_lo, h_lo, x_lo, act_lo;
     size_t total_bytes;
 };
 
-void carve_bf(const Plan& p, const Geom& g, int batch, char* base, BfWs& w) {
+void carve_bf(const Plan& p, const Geom& g, int batch, char* base, BfWs& w, int P) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = (o + bytes + 255) / 256 * 256; return base ? base + r : nullptr; };
     const size_t B = batch;
+    const size_t planes = P == 3 ? 2 : 1;
     w.audio = (float*)take(B * p.c.n_group * g.L * 4);
     w.spect = (float*)take(B * p.K0 * g.ld * 4);
-    w.spect_bf = (bf16_t*)take(B * p.K0 * g.ld * 2);
+    w.spect_bf = (bf16_t*)take(planes * B * p.K0 * g.ld * 2);
     w.spk = (float*)take(B * p.c.n_flows * p.S * g.ld * 4);
-    w.spk_bf = (bf16_t*)take(B * p.c.n_flows * p.S * g.ld * 2);
-    w.h_tmp_bf = (bf16_t*)take(B * p.c.n_flows * p.H * g.ld * 2);
-    w.h_bf = (bf16_t*)take(B * p.c.n_flows * p.H * g.ld * 2);
-    w.x = (bf16_t*)take(B * p.C * g.ld * 2);
-    w.act = (bf16_t*)take(B * p.C * g.ld * 2 * p.c.n_layers);      // one buffer per layer (deferred skip GEMM)
-    w.out = (bf16_t*)take(B * p.C * g.ld * 2);
+    w.spk_bf = (bf16_t*)take(planes * B * p.c.n_flows * p.S * g.ld * 2);
+    w.h_tmp_bf = (bf16_t*)take(planes * B * p.c.n_flows * p.H * g.ld * 2);
+    w.h_bf = (bf16_t*)take(planes * B * p.c.n_flows * p.H * g.ld * 2);
+    w.x = (bf16_t*)take(planes * B * p.C * g.ld * 2);
+    w.act = (bf16_t*)take(planes * B * p.C * g.ld * 2 * p.c.n_layers);   // one buffer per layer (deferred skip GEMM)
+    w.out = (bf16_t*)take(planes * B * p.C * g.ld * 2);
+    const long long on = P == 3 ? 1 : 0;
+    w.spect_lo = on * (long long)(B * p.K0 * g.ld);
+    w.spk_lo = on * (long long)(B * p.c.n_flows * p.S * g.ld);
+    w.h_lo = on * (long long)(B * p.c.n_flows * p.H * g.ld);
+    w.x_lo = on * (long long)(B * p.C * g.ld);
+    w.act_lo = on * (long long)(B * p.C * g.ld) * p.c.n_layers;
     w.total_bytes = o;
 }
 
+// K segments of one operand: bf16 = the tensor itself; split bf16 = (hi, lo, hi) against the packed (W_hi, W_hi, W_lo)
+int push_segs(BGemmArgs& a, int idx, int P, const bf16_t* base, long long lo_off, long long bstride, int nch, int shift,
+              int mb_rows) {
+    for (int pi = 0; pi < P; ++pi) a.seg[idx++] = {pi == 1 ? base + lo_off : base, bstride, nch, shift, mb_rows};
+    return idx;
+}
+
 // fp32 padded [B][rows][ld] -> bf16 K8 [B][rows/8][ld][8]
+__device__ __forceinline__ unsigned int pack_bf16x2_residual(float v0, float v1, unsigned int hi) {
+    return pack_bf16x2(v0 - __builtin_bit_cast(float, hi << 16), v1 - __builtin_bit_cast(float, hi & 0xffff0000u));
+}
+
 __global__ __launch_bounds__(256) void cvt_f32_to_k8_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
-                                                            int rows, int ld) {
+                                                            int rows, int ld, long long lo_off) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int grp = blockIdx.y, b = blockIdx.z;
     if (n >= ld) return;
     const float* s = src + ((size_t)b * rows + (size_t)grp * 8) * ld + n;
-    unsigned int pk[4];
+    unsigned int pk[4], pl[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        pk[j] = pack_bf16x2(s[(size_t)(2 * j) * ld], s[(size_t)(2 * j + 1) * ld]);
-    *reinterpret_cast<uint4*>(dst + (((size_t)b * (rows / 8) + grp) * ld + n) * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    for (int j = 0; j < 4; ++j) {
+        const float v0 = s[(size_t)(2 * j) * ld], v1 = s[(size_t)(2 * j + 1) * ld];
+        pk[j] = pack_bf16x2(v0, v1);
+        pl[j] = pack_bf16x2_residual(v0, v1, pk[j]);
+    }
+    bf16_t* d = dst + (((size_t)b * (rows / 8) + grp) * ld + n) * 8;
+    *reinterpret_cast<uint4*>(d) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    if (lo_off) *reinterpret_cast<uint4*>(d + lo_off) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
 }
 
 // x[b][c][n] = bf16(bs[c] + sum_j Ws[c][j] * audio[b][ch_off + j][n]), K8 layout   (glow.py:189)
 template <int H>
 __global__ __launch_bounds__(256) void wn_start_bf16_kernel(const float* __restrict__ audio, const float* __restrict__ Ws,
                                                             const float* __restrict__ bs, bf16_t* __restrict__ x, int C,
-                                                            int G, int ch_off, int L, int ld, int pad) {
+                                                            int G, int ch_off, int L, int ld, int pad, long long lo_off) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int grp = blockIdx.y, b = blockIdx.z;
     if (n >= L) return;
     float a[H];
 #pragma unroll
     for (int j = 0; j < H; ++j) a[j] = audio[((size_t)b * G + ch_off + j) * L + n];
-    unsigned int pk[4];
+    unsigned int pk[4], pl[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float v[2];
@@ -381,8 +408,11 @@ __global__ __launch_bounds__(256) void wn_start_bf16_kernel(const float* __restr
             v[e] = acc;
         }
         pk[q] = pack_bf16x2(v[0], v[1]);
+        pl[q] = pack_bf16x2_residual(v[0], v[1], pk[q]);
     }
-    *reinterpret_cast<uint4*>(x + (((size_t)b * (C / 8) + grp) * ld + pad + n) * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    bf16_t* d = x + (((size_t)b * (C / 8) + grp) * ld + pad + n) * 8;
+    *reinterpret_cast<uint4*>(d) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    if (lo_off) *reinterpret_cast<uint4*>(d + lo_off) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
 }
 
 // end 1x1 conv on the bf16 skip sum + coupling inverse + inverse 1x1 (+ un-squeeze), fp32 math
@@ -390,7 +420,8 @@ template <int H>
 __global__ __launch_bounds__(256) void flow_tail_bf16_kernel(const bf16_t* __restrict__ out, float* __restrict__ audio,
                                                              float* __restrict__ wave, const float* __restrict__ Wend,
                                                              const float* __restrict__ bend, const float* __restrict__ Winv,
-                                                             int C, int G, int ch_off, int L, int ld, int pad) {
+                                                             int C, int G, int ch_off, int L, int ld, int pad,
+                                                             long long lo_off) {
     constexpr int E = 2 * H;
     __shared__ float sW[E * 512 + E * E + E];
     const int b = blockIdx.y;
@@ -407,10 +438,13 @@ __global__ __launch_bounds__(256) void flow_tail_bf16_kernel(const bf16_t* __res
 #pragma unroll 4
     for (int grp = 0; grp < C / 8; ++grp) {
         const uint4 u = ob[(size_t)grp * ld];
-        const unsigned int w4[4] = {u.x, u.y, u.z, u.w};
+        const uint4 ul = lo_off ? *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(ob + (size_t)grp * ld) + lo_off)
+                                : make_uint4(0u, 0u, 0u, 0u);
+        const unsigned int w4[4] = {u.x, u.y, u.z, u.w}, l4[4] = {ul.x, ul.y, ul.z, ul.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float v0 = bf16_to_f32((bf16_t)(w4[q] & 0xffff)), v1 = bf16_to_f32((bf16_t)(w4[q] >> 16));
+            const float v0 = bf16_to_f32((bf16_t)(w4[q] & 0xffff)) + bf16_to_f32((bf16_t)(l4[q] & 0xffff));
+            const float v1 = bf16_to_f32((bf16_t)(w4[q] >> 16)) + bf16_to_f32((bf16_t)(l4[q] >> 16));
             const int c = grp * 8 + 2 * q;
 #pragma unroll
             for (int j = 0; j < E; ++j) e[j] = fmaf(sW[j * C + c + 1], v1, fmaf(sW[j * C + c], v0, e[j]));
@@ -459,7 +493,7 @@ int run_wn_stack_bf16(const Plan& p, const BfPlan& q, const Geom& g, const float
 #define CTTS_BSTART(HH)                                                                                       \
     case HH:                                                                                                  \
         hipLaunchKernelGGL(wn_start_bf16_kernel<HH>, sgrid, dim3(256), 0, s, w.audio, blob + f.start_w,       \
-                           blob + f.start_b, w.x, p.C, p.c.n_group, d.ch_off, g.L, g.ld, g.pad);              \
+                           blob + f.start_b, w.x, p.C, p.c.n_group, d.ch_off, g.L, g.ld, g.pad, w.x_lo);      \
         break;
     switch (d.n_half) {
         CTTS_BSTART(1) CTTS_BSTART(2) CTTS_BSTART(3) CTTS_BSTART(4)
@@ -467,7 +501,7 @@ int run_wn_stack_bf16(const Plan& p, const BfPlan& q, const Geom& g, const float
     }
 #undef CTTS_BSTART
     CTTS_CHECK_LAUNCH("wn_start_bf16");
-    const int ncx = p.C / BGEMM_KC;
+    const int ncx = p.C / BGEMM_KC, P = q.P, ks = p.c.kernel_size;
     const size_t act_layer = (size_t)batch * cstride;
     int rc;
     for (int i = 0; i < p.c.n_layers; ++i) {
@@ -477,13 +511,13 @@ int run_wn_stack_bf16(const Plan& p, const BfPlan& q, const Geom& g, const float
             BGemmArgs a{};
             a.ld = g.ld; a.pad = g.pad; a.L = g.L; a.ntiles = g.ntiles; a.batch = batch;
             a.A = bblob + q.in_A[k][i]; a.bias = blob + f.in_b[i];
-            a.nseg = 4; a.interleave = 3; a.nch_total = q.nch_in; a.MB = p.mb_in;
-            a.seg[0] = {w.x, cstride, ncx, -dil, 0};
-            a.seg[1] = {w.x, cstride, ncx, 0, 0};
-            a.seg[2] = {w.x, cstride, ncx, dil, 0};
-            a.seg[3] = {w.h_bf + (size_t)k * p.H * g.ld, hstride, p.H / BGEMM_KC, 0, 0};
+            int ns = 0;
+            for (int t = 0; t < ks; ++t) ns = push_segs(a, ns, P, w.x, w.x_lo, cstride, ncx, (t - ks / 2) * dil, 0);
+            a.interleave = ns;                                        // taps (x products) round-robin per 32-channel slab
+            ns = push_segs(a, ns, P, w.h_bf + (size_t)k * p.H * g.ld, w.h_lo, hstride, p.H / BGEMM_KC, 0, 0);
+            a.nseg = ns; a.nch_total = q.nch_in; a.MB = p.mb_in;
             a.M = 2 * p.C; a.pairC = p.C;
-            a.dst0 = act; a.dst0_bstride = cstride;
+            a.dst0 = act; a.dst0_bstride = cstride; a.lo_off = w.act_lo;
             ProfScope ps(CTTS_PROF_WN_IN, s);
             if ((rc = launch_gemm_bf16(BGEMM_EPI_GATE, a, s))) return rc;
         }
@@ -492,29 +526,31 @@ int run_wn_stack_bf16(const Plan& p, const BfPlan& q, const Geom& g, const float
             BGemmArgs a{};
             a.ld = g.ld; a.pad = g.pad; a.L = g.L; a.ntiles = g.ntiles; a.batch = batch;
             a.A = bblob + q.rs_A[k][i]; a.bias = blob + f.rs_b[i];
-            a.nseg = 1; a.nch_total = q.nch_rs; a.MB = q.mb_c;
-            a.seg[0] = {act, cstride, q.nch_rs, 0, 0};
+            a.nseg = push_segs(a, 0, P, act, w.act_lo, cstride, ncx, 0, 0); a.nch_total = q.nch_rs; a.MB = q.mb_c;
             a.M = p.C; a.split = p.C;
             a.dst0 = w.x; a.dst0_bstride = cstride; a.acc0 = 1;
             a.dst1 = w.x; a.dst1_bstride = cstride; a.acc1 = 1;
+            a.lo_off = w.x_lo;
             ProfScope ps(CTTS_PROF_WN_RS, s);
             if ((rc = launch_gemm_bf16(BGEMM_EPI_SPLIT, a, s))) return rc;
         }
     }
     // skip sum = sum_i W_skip_i act_i + sum_i b_skip_i: K = n_layers * C, fp32 accumulation inside a launch, one
-    // bf16 rounding of the running sum per group of BF_SKIP_GROUP layers
+    // rounding of the running sum per group of BF_SKIP_GROUP layers
     const float* skip_b = reinterpret_cast<const float*>(bblob + q.skip_b[k]);
     for (int gi = 0; gi < q.n_groups; ++gi) {
         const int nl = q.group_layers(gi, p.c.n_layers);
         BGemmArgs a{};
         a.ld = g.ld; a.pad = g.pad; a.L = g.L; a.ntiles = g.ntiles; a.batch = batch;
         a.A = bblob + q.skip_A[k][gi]; a.bias = skip_b + (gi == 0 ? 0 : q.mb_c * BGEMM_BM);
-        a.nseg = nl; a.nch_total = nl * q.nch_rs; a.MB = q.mb_c;
+        int ns = 0;
         for (int j = 0; j < nl; ++j)
-            a.seg[j] = {w.act + (size_t)(gi * BF_SKIP_GROUP + j) * act_layer, cstride, q.nch_rs, 0, 0};
+            ns = push_segs(a, ns, P, w.act + (size_t)(gi * BF_SKIP_GROUP + j) * act_layer, w.act_lo, cstride, ncx, 0, 0);
+        a.nseg = ns; a.nch_total = nl * q.nch_rs; a.MB = q.mb_c;
         a.M = p.C; a.split = p.C;
         a.dst0 = w.out; a.dst0_bstride = cstride; a.acc0 = gi > 0 ? 1 : 0;
         a.dst1 = w.out; a.dst1_bstride = cstride; a.acc1 = a.acc0;
+        a.lo_off = w.x_lo;
         ProfScope ps(CTTS_PROF_WN_SKIP, s);
         if ((rc = launch_gemm_bf16(BGEMM_EPI_SPLIT, a, s))) return rc;
     }
@@ -735,47 +771,62 @@ int ctts_profile_collect(int32_t which, int64_t* launches, double* total_ms) {
     return CTTS_OK;
 }
 
-size_t ctts_waveglow_packed_bf16_bytes(const ctts_waveglow_config* cfg) {
+// ---- bf16 MFMA variants: P = 1 (bf16 storage, config 3) and P = 3 (split bf16: every operand is a hi + lo pair of
+// bf16 planes, every contraction three bf16 MFMA products hi*hi + lo*hi + hi*lo with fp32 accumulation - inputs carry
+// 16 mantissa bits instead of 8, at a third of the bf16 rate) ------------------------------------------------------
+static size_t packed_bf16_bytes_impl(const ctts_waveglow_config* cfg, int P) {
     Plan p; BfPlan q;
     if (make_plan(cfg, p)) return 0;
     if (p.C % BGEMM_KC != 0 || p.H % BGEMM_KC != 0) { set_error("bf16: channels must be multiples of 32"); return 0; }
-    make_bf_plan(p, q);
+    make_bf_plan(p, q, P);
     return q.total * sizeof(bf16_t);
 }
 
-int ctts_waveglow_pack_flow_bf16(const ctts_waveglow_config* cfg, int32_t k, const ctts_waveglow_flow_weights* w,
-                                 void* packed_bf16, void* stream) {
+static int pack_flow_bf16_impl(const ctts_waveglow_config* cfg, int32_t k, const ctts_waveglow_flow_weights* w,
+                               void* packed_bf16, void* stream, int P) {
     Plan p; BfPlan q;
     int rc = make_plan(cfg, p); if (rc) return rc;
     CTTS_CHECK_ARG(k >= 0 && k < p.c.n_flows && w && packed_bf16, "pack_flow_bf16: bad argument");
     CTTS_CHECK_ARG(p.C % BGEMM_KC == 0 && p.H % BGEMM_KC == 0, "pack_flow_bf16: channels must be multiples of 32");
-    make_bf_plan(p, q);
+    make_bf_plan(p, q, P);
+    CTTS_CHECK_ARG(q.nch_in <= BGEMM_MAX_CHUNKS && BF_SKIP_GROUP * q.nch_rs <= BGEMM_MAX_CHUNKS,
+                   "pack_flow_bf16: K of %d chunks exceeds the chunk table", q.nch_in);
     hipStream_t s = as_stream(stream);
     bf16_t* bb = static_cast<bf16_t*>(packed_bf16);
     const int C = p.C, H = p.H, ks = p.c.kernel_size;
     CTTS_CHECK_ARG(w->cond_w[0] && w->cond_w[1] && p.K0 % BGEMM_KC == 0, "pack_flow_bf16: cond weights / n_mel*n_group %% 32");
     const int sdim = p.c.speaker_embed_dim;
-    if ((rc = launch_pack_a_bf16(bb + q.cond0_A + (size_t)k * q.nch_c0 * BGEMM_KC * BGEMM_BM, w->cond_w[0], 1, q.nch_c0, 0,
-                                 p.K0, BGEMM_EPI_SPLIT, C, H, 0, p.K0 + sdim, 1, s))) return rc;
-    if (sdim && (rc = launch_pack_a_bf16(bb + q.cond0_A + (size_t)k * q.nch_c0 * BGEMM_KC * BGEMM_BM, w->cond_w[0] + p.K0, 1,
-                                         q.nch_c0, p.K0, sdim, BGEMM_EPI_SPLIT, C, H, 0, p.K0 + sdim, 1, s))) return rc;
-    if ((rc = launch_pack_a_bf16(bb + q.cond1_A + (size_t)k * q.nch_c1 * BGEMM_KC * BGEMM_BM, w->cond_w[1], 1, q.nch_c1, 0,
-                                 H, BGEMM_EPI_SPLIT, C, H, 0, H, 1, s))) return rc;
+    bf16_t* c0 = bb + q.cond0_A + (size_t)k * q.nch_c0 * BGEMM_KC * BGEMM_BM;
+    bf16_t* c1 = bb + q.cond1_A + (size_t)k * q.nch_c1 * BGEMM_KC * BGEMM_BM;
+    // product pi of an operand pair uses W_hi for pi = 0, 1 (against x_hi, x_lo) and W_lo for pi = 2 (against x_hi)
+    for (int pi = 0; pi < P; ++pi) {
+        const int part = pi == 2;
+        if ((rc = launch_pack_a_bf16(c0, w->cond_w[0], 1, q.nch_c0, pi * p.K0, p.K0, BGEMM_EPI_SPLIT, C, H, 0, p.K0 + sdim, 1,
+                                     s, 1, 0, part))) return rc;
+        if (sdim && (rc = launch_pack_a_bf16(c0, w->cond_w[0] + p.K0, 1, q.nch_c0, P * p.K0 + pi * p.S, sdim, BGEMM_EPI_SPLIT,
+                                             C, H, 0, p.K0 + sdim, 1, s, 1, 0, part))) return rc;
+        if ((rc = launch_pack_a_bf16(c1, w->cond_w[1], 1, q.nch_c1, pi * H, H, BGEMM_EPI_SPLIT, C, H, 0, H, 1, s, 1, 0,
+                                     part))) return rc;
+    }
     for (int i = 0; i < p.c.n_layers; ++i) {
-        CTTS_CHECK_ARG(w->in_w[i] && w->rs_w[i] && w->cond_w[2], "pack_flow_bf16: NULL layer %d weights", i);
-        for (int t = 0; t < ks; ++t)
-            if ((rc = launch_pack_a_bf16(bb + q.in_A[k][i], w->in_w[i] + t, p.mb_in, q.nch_in, 0, C, BGEMM_EPI_GATE, C,
-                                         2 * C, 0, (long long)C * ks, ks, s, ks, t))) return rc;
-        if ((rc = launch_pack_a_bf16(bb + q.in_A[k][i], w->cond_w[2], p.mb_in, q.nch_in, ks * C, H, BGEMM_EPI_GATE, C,
-                                     2 * C, (long long)2 * C * i, H, 1, s))) return rc;
+        CTTS_CHECK_ARG(w->in_w[i] && w->rs_w[i] && w->cond_w[2] && w->rs_b[i], "pack_flow_bf16: NULL layer %d weights", i);
         // res_skip_layers.i is [2C][C] = {res rows, skip rows} for i < last, [C][C] = skip rows for the last layer
         const bool last = i == p.c.n_layers - 1;
-        CTTS_CHECK_ARG(w->rs_b[i], "pack_flow_bf16: NULL layer %d res/skip bias", i);
-        if (!last && (rc = launch_pack_a_bf16(bb + q.rs_A[k][i], w->rs_w[i], q.mb_c, q.nch_rs, 0, C, BGEMM_EPI_SPLIT, C, C,
-                                              0, C, 1, s))) return rc;
         const int gi = i / BF_SKIP_GROUP, j = i % BF_SKIP_GROUP;
-        if ((rc = launch_pack_a_bf16(bb + q.skip_A[k][gi], w->rs_w[i], q.mb_c, q.group_layers(gi, p.c.n_layers) * q.nch_rs,
-                                     j * C, C, BGEMM_EPI_SPLIT, C, C, last ? 0 : C, C, 1, s))) return rc;
+        for (int pi = 0; pi < P; ++pi) {
+            const int part = pi == 2;
+            // in-layer K = [per 32-channel slab: (tap, product) round-robin] then [cond products]
+            for (int t = 0; t < ks; ++t)
+                if ((rc = launch_pack_a_bf16(bb + q.in_A[k][i], w->in_w[i] + t, p.mb_in, q.nch_in, 0, C, BGEMM_EPI_GATE, C,
+                                             2 * C, 0, (long long)C * ks, ks, s, ks * P, t * P + pi, part))) return rc;
+            if ((rc = launch_pack_a_bf16(bb + q.in_A[k][i], w->cond_w[2], p.mb_in, q.nch_in, ks * P * C + pi * H, H,
+                                         BGEMM_EPI_GATE, C, 2 * C, (long long)2 * C * i, H, 1, s, 1, 0, part))) return rc;
+            if (!last && (rc = launch_pack_a_bf16(bb + q.rs_A[k][i], w->rs_w[i], q.mb_c, q.nch_rs, pi * C, C, BGEMM_EPI_SPLIT,
+                                                  C, C, 0, C, 1, s, 1, 0, part))) return rc;
+            if ((rc = launch_pack_a_bf16(bb + q.skip_A[k][gi], w->rs_w[i], q.mb_c, q.group_layers(gi, p.c.n_layers) * q.nch_rs,
+                                         (j * P + pi) * C, C, BGEMM_EPI_SPLIT, C, C, last ? 0 : C, C, 1, s, 1, 0,
+                                         part))) return rc;
+        }
         hipLaunchKernelGGL(skip_bias_kernel, dim3((2 * q.mb_c * BGEMM_BM + 255) / 256), dim3(256), 0, s,
                            reinterpret_cast<float*>(bb + q.skip_b[k]), w->rs_b[i] + (last ? 0 : C), C,
                            2 * q.mb_c * BGEMM_BM, i == 0 ? 1 : 0);
@@ -784,30 +835,23 @@ int ctts_waveglow_pack_flow_bf16(const ctts_waveglow_config* cfg, int32_t k, con
     return CTTS_OK;
 }
 
-size_t ctts_waveglow_workspace_bf16_bytes(const ctts_waveglow_config* cfg, int32_t batch, int32_t frames) {
+static size_t workspace_bf16_bytes_impl(const ctts_waveglow_config* cfg, int32_t batch, int32_t frames, int P) {
     Plan p; Geom g; BfWs w;
     if (make_plan(cfg, p) || make_geom(p, frames, g) || batch < 1) return 0;
-    carve_bf(p, g, batch, nullptr, w);
+    carve_bf(p, g, batch, nullptr, w, P);
     return w.total_bytes;
 }
 
-int ctts_waveglow_infer_bf16(const ctts_waveglow_config* cfg, const void* packed, const void* packed_bf16,
-                             const float* mel, const float* z_scaled, float* wave, int32_t batch, int32_t frames,
-                             void* workspace, size_t workspace_bytes, void* stream) {
-    return ctts_waveglow_infer_spk_bf16(cfg, packed, packed_bf16, mel, z_scaled, nullptr, wave, batch, frames, workspace,
-                                        workspace_bytes, stream);
-}
-
-int ctts_waveglow_infer_spk_bf16(const ctts_waveglow_config* cfg, const void* packed, const void* packed_bf16,
-                                 const float* mel, const float* z_scaled, const int64_t* speaker_ids, float* wave,
-                                 int32_t batch, int32_t frames, void* workspace, size_t workspace_bytes, void* stream) {
+static int infer_bf16_impl(const ctts_waveglow_config* cfg, const void* packed, const void* packed_bf16, const float* mel,
+                           const float* z_scaled, const int64_t* speaker_ids, float* wave, int32_t batch, int32_t frames,
+                           void* workspace, size_t workspace_bytes, void* stream, int P) {
     Plan p; Geom g; BfWs w; BfPlan q;
     int rc = make_plan(cfg, p); if (rc) return rc;
     rc = make_geom(p, frames, g); if (rc) return rc;
     CTTS_CHECK_ARG(packed && packed_bf16 && mel && z_scaled && wave && workspace && batch >= 1, "infer_bf16: bad argument");
     CTTS_CHECK_ARG(p.C % BGEMM_KC == 0 && p.C <= 512, "infer_bf16: n_channels=%d (multiple of 32, <= 512)", p.C);
-    make_bf_plan(p, q);
-    carve_bf(p, g, batch, static_cast<char*>(workspace), w);
+    make_bf_plan(p, q, P);
+    carve_bf(p, g, batch, static_cast<char*>(workspace), w, P);
     if (w.total_bytes > workspace_bytes) {
         set_error("infer_bf16: workspace %zu bytes < required %zu", workspace_bytes, w.total_bytes);
         return CTTS_E_WORKSPACE;
@@ -823,12 +867,12 @@ int ctts_waveglow_infer_spk_bf16(const ctts_waveglow_config* cfg, const void* pa
     // cond layers 0 / 1 for all flows on bf16 MFMA: spect -> bf16 K8, then two flow-batched GEMMs whose
     // epilogues write the conditioning hidden directly in bf16 K8
     hipLaunchKernelGGL(cvt_f32_to_k8_kernel, dim3((g.ld + 255) / 256, p.K0 / 8, batch), dim3(256), 0, s, w.spect,
-                       w.spect_bf, p.K0, g.ld);
+                       w.spect_bf, p.K0, g.ld, w.spect_lo);
     CTTS_CHECK_LAUNCH("cvt_f32_to_k8");
     if (p.S) {
         if ((rc = fill_speaker_rows(p, g, blob, speaker_ids, w.spk, batch, s))) return rc;
         hipLaunchKernelGGL(cvt_f32_to_k8_kernel, dim3((g.ld + 255) / 256, p.c.n_flows * p.S / 8, batch), dim3(256), 0, s,
-                           w.spk, w.spk_bf, p.c.n_flows * p.S, g.ld);
+                           w.spk, w.spk_bf, p.c.n_flows * p.S, g.ld, w.spk_lo);
         CTTS_CHECK_LAUNCH("cvt_f32_to_k8(speaker rows)");
     }
     {
@@ -836,19 +880,17 @@ int ctts_waveglow_infer_spk_bf16(const ctts_waveglow_config* cfg, const void* pa
         BGemmArgs a{};
         a.ld = g.ld; a.pad = g.pad; a.L = g.L; a.ntiles = g.ntiles; a.batch = batch;
         a.A = bblob + q.cond0_A; a.bias = blob + p.cond0_b;
-        a.nseg = 1; a.nch_total = q.nch_c0; a.MB = p.c.n_flows; a.M = p.c.n_flows * BGEMM_BM;
-        a.seg[0] = {w.spect_bf, (long long)p.K0 * g.ld, p.K0 / BGEMM_KC, 0, 0};
-        if (p.S) {
-            a.nseg = 2;
-            a.seg[1] = {w.spk_bf, (long long)p.c.n_flows * p.S * g.ld, p.S / BGEMM_KC, 0, p.S};
-        }
+        a.nch_total = q.nch_c0; a.MB = p.c.n_flows; a.M = p.c.n_flows * BGEMM_BM;
+        int ns = push_segs(a, 0, P, w.spect_bf, w.spect_lo, (long long)p.K0 * g.ld, p.K0 / BGEMM_KC, 0, 0);
+        if (p.S) ns = push_segs(a, ns, P, w.spk_bf, w.spk_lo, (long long)p.c.n_flows * p.S * g.ld, p.S / BGEMM_KC, 0, p.S);
+        a.nseg = ns;
         a.dst0 = w.h_tmp_bf; a.dst0_bstride = hstride; a.acc0 = 0;
         a.dst1 = w.h_tmp_bf; a.dst1_bstride = hstride; a.acc1 = 0;
-        a.split = a.M;
+        a.split = a.M; a.lo_off = w.h_lo;
         if ((rc = launch_gemm_bf16(BGEMM_EPI_SPLIT, a, s))) return rc;
         a.A = bblob + q.cond1_A; a.bias = blob + p.cond1_b;
-        a.nseg = 1; a.nch_total = q.nch_c1;
-        a.seg[0] = {w.h_tmp_bf, hstride, q.nch_c1, 0, BGEMM_BM};
+        a.nch_total = q.nch_c1;
+        a.nseg = push_segs(a, 0, P, w.h_tmp_bf, w.h_lo, hstride, p.H / BGEMM_KC, 0, BGEMM_BM);
         a.dst0 = w.h_bf; a.dst1 = w.h_bf;
         if ((rc = launch_gemm_bf16(BGEMM_EPI_SPLIT, a, s))) return rc;
     }
@@ -862,7 +904,7 @@ int ctts_waveglow_infer_spk_bf16(const ctts_waveglow_config* cfg, const void* pa
 #define CTTS_BTAIL(HH)                                                                                            \
     case HH:                                                                                                      \
         hipLaunchKernelGGL(flow_tail_bf16_kernel<HH>, tgrid, dim3(256), 0, s, w.out, w.audio, wv, blob + f.end_w, \
-                           blob + f.end_b, blob + f.winv, p.C, p.c.n_group, d.ch_off, g.L, g.ld, g.pad);          \
+                           blob + f.end_b, blob + f.winv, p.C, p.c.n_group, d.ch_off, g.L, g.ld, g.pad, w.x_lo);  \
         break;
         switch (d.n_half) {
             CTTS_BTAIL(1) CTTS_BTAIL(2) CTTS_BTAIL(3) CTTS_BTAIL(4)
@@ -872,6 +914,42 @@ int ctts_waveglow_infer_spk_bf16(const ctts_waveglow_config* cfg, const void* pa
         CTTS_CHECK_LAUNCH("flow_tail_bf16");
     }
     return CTTS_OK;
+}
+
+size_t ctts_waveglow_packed_bf16_bytes(const ctts_waveglow_config* cfg) { return packed_bf16_bytes_impl(cfg, 1); }
+int ctts_waveglow_pack_flow_bf16(const ctts_waveglow_config* cfg, int32_t k, const ctts_waveglow_flow_weights* w,
+                                 void* packed_bf16, void* stream) {
+    return pack_flow_bf16_impl(cfg, k, w, packed_bf16, stream, 1);
+}
+size_t ctts_waveglow_workspace_bf16_bytes(const ctts_waveglow_config* cfg, int32_t batch, int32_t frames) {
+    return workspace_bf16_bytes_impl(cfg, batch, frames, 1);
+}
+int ctts_waveglow_infer_bf16(const ctts_waveglow_config* cfg, const void* packed, const void* packed_bf16,
+                             const float* mel, const float* z_scaled, float* wave, int32_t batch, int32_t frames,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    return infer_bf16_impl(cfg, packed, packed_bf16, mel, z_scaled, nullptr, wave, batch, frames, workspace, workspace_bytes,
+                           stream, 1);
+}
+int ctts_waveglow_infer_spk_bf16(const ctts_waveglow_config* cfg, const void* packed, const void* packed_bf16,
+                                 const float* mel, const float* z_scaled, const int64_t* speaker_ids, float* wave,
+                                 int32_t batch, int32_t frames, void* workspace, size_t workspace_bytes, void* stream) {
+    return infer_bf16_impl(cfg, packed, packed_bf16, mel, z_scaled, speaker_ids, wave, batch, frames, workspace,
+                           workspace_bytes, stream, 1);
+}
+
+size_t ctts_waveglow_packed_bf16x3_bytes(const ctts_waveglow_config* cfg) { return packed_bf16_bytes_impl(cfg, 3); }
+int ctts_waveglow_pack_flow_bf16x3(const ctts_waveglow_config* cfg, int32_t k, const ctts_waveglow_flow_weights* w,
+                                   void* packed_bf16x3, void* stream) {
+    return pack_flow_bf16_impl(cfg, k, w, packed_bf16x3, stream, 3);
+}
+size_t ctts_waveglow_workspace_bf16x3_bytes(const ctts_waveglow_config* cfg, int32_t batch, int32_t frames) {
+    return workspace_bf16_bytes_impl(cfg, batch, frames, 3);
+}
+int ctts_waveglow_infer_spk_bf16x3(const ctts_waveglow_config* cfg, const void* packed, const void* packed_bf16x3,
+                                   const float* mel, const float* z_scaled, const int64_t* speaker_ids, float* wave,
+                                   int32_t batch, int32_t frames, void* workspace, size_t workspace_bytes, void* stream) {
+    return infer_bf16_impl(cfg, packed, packed_bf16x3, mel, z_scaled, speaker_ids, wave, batch, frames, workspace,
+                           workspace_bytes, stream, 3);
 }
 
 }  // extern "C"

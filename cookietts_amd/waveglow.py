@@ -185,17 +185,22 @@ class WaveGlow(nn.Module):
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
     def set_compute_dtype(self, dtype):
-        """torch.float32 (default: exact fp32 MFMA path) or torch.bfloat16 (BASELINE config 3: WN GEMMs on
+        """torch.float32 (default: exact fp32 MFMA path), torch.bfloat16 (BASELINE config 3: WN GEMMs on
         bf16 MFMA with fp32 accumulation, WN activations stored bf16; parameters stay fp32 masters and are
-        rounded to bf16 once, after weight-norm folding).  ``model.bfloat16()`` selects bf16 as well."""
-        if dtype not in (torch.float32, torch.bfloat16):
-            raise NotImplementedError(f"compute dtype {dtype} is not built (float32 or bfloat16)")
+        rounded to bf16 once, after weight-norm folding; ``model.bfloat16()`` selects bf16 as well), or the string
+        ``"bf16x3"``: split bf16 - weights and activations carried as hi + lo bf16 pairs (16 mantissa bits), every
+        contraction as three bf16 MFMA products with fp32 accumulation (see ``ctts_waveglow_infer_spk_bf16x3``)."""
+        if dtype not in (torch.float32, torch.bfloat16, "bf16x3"):
+            raise NotImplementedError(f"compute dtype {dtype} is not built (float32, bfloat16 or 'bf16x3')")
         self._compute_dtype = dtype
         self._invalidate()
         return self
 
     def _use_bf16(self):
-        return self._compute_dtype == torch.bfloat16 or next(self.parameters()).dtype == torch.bfloat16
+        """0 = fp32 MFMA, 1 = bf16, 3 = split bf16 (the number of bf16 products per contraction)."""
+        if self._compute_dtype == "bf16x3":
+            return 3
+        return 1 if (self._compute_dtype == torch.bfloat16 or next(self.parameters()).dtype == torch.bfloat16) else 0
 
     def repack(self):
         """Call after modifying parameters in place; the next infer re-ingests the weights."""
@@ -258,7 +263,7 @@ class WaveGlow(nn.Module):
             blob = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)
             bblob = None
             if use_bf16:
-                nb = lib.ctts_waveglow_packed_bf16_bytes(C.byref(cfg))
+                nb = (lib.ctts_waveglow_packed_bf16x3_bytes if use_bf16 == 3 else lib.ctts_waveglow_packed_bf16_bytes)(C.byref(cfg))
                 if nb == 0:
                     raise _lib.HipLibraryError("unsupported bf16 WaveGlow config: " + lib.ctts_last_error().decode())
                 bblob = torch.zeros(nb // 2, dtype=torch.int16, device=device)
@@ -320,7 +325,8 @@ class WaveGlow(nn.Module):
                 _lib.check(lib.ctts_waveglow_pack_flow(C.byref(cfg), k, C.byref(fw), _lib.ptr(blob), stream),
                            f"ctts_waveglow_pack_flow({k})")
                 if bblob is not None:
-                    _lib.check(lib.ctts_waveglow_pack_flow_bf16(C.byref(cfg), k, C.byref(fw), _lib.ptr(bblob), stream),
+                    pack16 = lib.ctts_waveglow_pack_flow_bf16x3 if use_bf16 == 3 else lib.ctts_waveglow_pack_flow_bf16
+                    _lib.check(pack16(C.byref(cfg), k, C.byref(fw), _lib.ptr(bblob), stream),
                                f"ctts_waveglow_pack_flow_bf16({k})")
             torch.cuda.current_stream(device).synchronize()   # dense temporaries may now be freed
         self._packed = (device, blob, bblob, key)
@@ -332,7 +338,8 @@ class WaveGlow(nn.Module):
         if ws is None:
             lib = _lib.lib()
             cfg = self.c_config()
-            query = lib.ctts_waveglow_workspace_bf16_bytes if bf16 else lib.ctts_waveglow_workspace_bytes
+            query = {0: lib.ctts_waveglow_workspace_bytes, 1: lib.ctts_waveglow_workspace_bf16_bytes,
+                     3: lib.ctts_waveglow_workspace_bf16x3_bytes}[int(bf16)]
             nbytes = query(C.byref(cfg), B, F)
             if nbytes == 0:
                 raise _lib.HipLibraryError("workspace query failed: " + lib.ctts_last_error().decode())
@@ -372,15 +379,17 @@ class WaveGlow(nn.Module):
             assert ids.shape[0] == B, (tuple(ids.shape), B)
             if int(ids.min()) < 0 or int(ids.max()) >= _lib.N_SPEAKERS:
                 raise IndexError("speaker id out of range of the embedding table")
-        ws = self._workspace(device, B, F, bf16=bblob is not None)
+        mode = self._use_bf16()
+        ws = self._workspace(device, B, F, bf16=mode)
         wave = torch.empty(B, L * self.n_group, dtype=torch.float32, device=device)
         cfg = self.c_config()
         with torch.cuda.device(device):
             stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
             if bblob is not None:
-                _lib.check(lib.ctts_waveglow_infer_spk_bf16(C.byref(cfg), _lib.ptr(blob), _lib.ptr(bblob), _lib.ptr(mel),
-                                                           _lib.ptr(z), _lib.ptr(ids), _lib.ptr(wave), B, F, _lib.ptr(ws),
-                                                           ws.numel() * 4, stream), "ctts_waveglow_infer_spk_bf16")
+                infer16 = lib.ctts_waveglow_infer_spk_bf16x3 if mode == 3 else lib.ctts_waveglow_infer_spk_bf16
+                _lib.check(infer16(C.byref(cfg), _lib.ptr(blob), _lib.ptr(bblob), _lib.ptr(mel), _lib.ptr(z), _lib.ptr(ids),
+                                   _lib.ptr(wave), B, F, _lib.ptr(ws), ws.numel() * 4, stream),
+                           "ctts_waveglow_infer_spk_bf16x3" if mode == 3 else "ctts_waveglow_infer_spk_bf16")
             else:
                 _lib.check(lib.ctts_waveglow_infer_spk_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(mel), _lib.ptr(z),
                                                           _lib.ptr(ids), _lib.ptr(wave), B, F, _lib.ptr(ws),

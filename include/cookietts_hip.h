@@ -149,6 +149,23 @@ int ctts_waveglow_infer_spk_bf16(const ctts_waveglow_config* cfg, const void* pa
                                  int32_t batch, int32_t frames, void* workspace, size_t workspace_bytes,
                                  void* stream);
 
+/* Split-bf16 variant ("bf16x3"): the same bf16 MFMA kernels with every GEMM operand carried as a hi + lo PAIR of bf16
+ * planes (hi = bf16(v), lo = bf16(v - hi): 16 mantissa bits) and every contraction computed as the three products
+ * hi*hi + lo*hi + hi*lo with fp32 accumulation (the lo*lo term, ~2^-16 of a product, is dropped).  Inputs therefore
+ * carry a relative error of ~2^-17 instead of bf16's 2^-9, at a third of the bf16 MFMA rate - about three times the
+ * fp32 MFMA rate of gfx950.  Same calling convention as the bf16 entry points; `packed_bf16x3` and the workspace have
+ * their own sizes.  Waveform error against the fp32 reference goldens is stated in DESIGN.md and gated in the tests
+ * at the fp32 tolerance (RMS rel <= 1e-3). */
+size_t ctts_waveglow_packed_bf16x3_bytes(const ctts_waveglow_config* cfg);
+int ctts_waveglow_pack_flow_bf16x3(const ctts_waveglow_config* cfg, int32_t flow,
+                                   const ctts_waveglow_flow_weights* w, void* packed_bf16x3, void* stream);
+size_t ctts_waveglow_workspace_bf16x3_bytes(const ctts_waveglow_config* cfg, int32_t batch,
+                                            int32_t frames);
+int ctts_waveglow_infer_spk_bf16x3(const ctts_waveglow_config* cfg, const void* packed, const void* packed_bf16x3,
+                                   const float* mel, const float* z_scaled, const int64_t* speaker_ids, float* wave,
+                                   int32_t batch, int32_t frames, void* workspace, size_t workspace_bytes,
+                                   void* stream);
+
 /* Stage entry points (same kernels, exposed for parity tests and profiling). */
 
 /* upsample (ConvTranspose1d) + trim + squeeze: glow.py:318-324.  spect is padded layout

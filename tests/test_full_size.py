@@ -103,6 +103,11 @@ def test_config2_waveglow_full_length_matches_reference_golden(hip_lib_path):
     z8 = torch.from_numpy(synthetic.synthetic_noise(8, cfg["n_group"], F * 32, seed=99)).cuda()
     mel8[3], z8[3] = mel[0], torch.from_numpy(g["z_scaled"][0]).cuda()
     assert rms_rel_err(m.infer_from_noise(mel8, z8)[3:4].cpu().numpy(), g["wave"]) < 1e-3
+    # the split-bf16 path on the same full-length utterance, held to the same fp32 bar (and an order inside it)
+    m.set_compute_dtype("bf16x3")
+    err3 = rms_rel_err(m.infer_from_noise(mel, torch.from_numpy(g["z_scaled"]).cuda()).cpu().numpy(), g["wave"])
+    print(f"config 2 full length, bf16x3: rms rel err vs reference = {err3:.3e}")
+    assert err3 < 1e-4
 
 
 def test_config4_waveflow_full_length_matches_reference_golden(hip_lib_path):
