@@ -199,9 +199,23 @@ SIGNATURES = {
     "ctts_taco_stop_state_bytes": (C.c_size_t, [C.c_int32]),
     "ctts_taco_stop_reset": (C.c_int, [_FP, C.c_int32, C.c_int32, _FP]),
     "ctts_taco_stop_rule_f32": (C.c_int, [_FP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _FP, _FP]),
+    "ctts_set_f32_gemm_mode": (C.c_int, [C.c_int32]),
+    "ctts_get_f32_gemm_mode": (C.c_int, []),
     "ctts_profile_enable": (C.c_int, [C.c_int32]),
     "ctts_profile_collect": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }
+
+GEMM_MODES = {"f32": 0, "bf16x3": 1}
+
+
+def set_f32_gemm_mode(mode):
+    """Main loop of the fp32 conv-GEMM for the whole process: ``"f32"`` (default, fp32 MFMA) or ``"bf16x3"`` (each
+    operand split in registers into hi + lo bf16, three bf16 MFMA products per pair, fp32 accumulation; tensors and
+    weights stay fp32).  Returns the previous mode name."""
+    prev = {v: k for k, v in GEMM_MODES.items()}[lib().ctts_get_f32_gemm_mode()]
+    check(lib().ctts_set_f32_gemm_mode(GEMM_MODES[mode]), "ctts_set_f32_gemm_mode")
+    return prev
+
 
 PROF_WN_IN = 0
 PROF_WN_RS = 1
@@ -242,6 +256,11 @@ def lib():
             fn.argtypes = args
         if handle.ctts_abi_version() != 2:
             raise HipLibraryError(f"ABI version mismatch: library reports {handle.ctts_abi_version()}")
+        env_mode = os.environ.get("CTTS_F32_GEMM_MODE")          # "f32" (default) or "bf16x3": see set_f32_gemm_mode
+        if env_mode:
+            if env_mode not in GEMM_MODES:
+                raise HipLibraryError(f"CTTS_F32_GEMM_MODE={env_mode!r}: expected one of {sorted(GEMM_MODES)}")
+            handle.ctts_set_f32_gemm_mode(GEMM_MODES[env_mode])
         _LIB = handle
     return _LIB
 

@@ -85,6 +85,8 @@ struct GemmArgs {
     // arithmetic of ATen's upsample_linear1d (glow_ax.py:362-373) - the sample-rate tensor is never materialised
     int addend_frames;
     int map_mode;         // block id -> (m-block, tile, batch) mapping, chosen by the launcher (see gemm_f32.hip)
+    int exact_f32;        // 1 = always the fp32 MFMA main loop, whatever set_gemm_f32_mode says (STFT: its sums cancel,
+                          // so the split-bf16 loop's 2^-17 operand error exceeds the 1e-4 log-mel bound)
     const float* rs_wT;   // GEMM_EPI_GATE_RS: res/skip weight transposed and row-padded: [64][128]
     const float* rs_bias; // [128] (rows >= rs_rows zero)
     int rs_rows;          // 128 (res + skip) or 64 (last layer: skip only)
@@ -106,5 +108,10 @@ __host__ __device__ inline int gemm_dense_row(int epi, int bm, int mb, int r, in
 }
 
 int launch_gemm_f32(int epi, const GemmArgs& a, hipStream_t stream);
+
+// Process-wide main-loop selection of launch_gemm_f32: 0 = fp32 MFMA (default), 1 = split bf16 (three bf16 MFMA products
+// per fp32 operand pair, see conv_gemm_f32_kernel<..., X3>).  Set through ctts_set_f32_gemm_mode.
+int set_gemm_f32_mode(int mode);
+int get_gemm_f32_mode();
 
 }  // namespace ctts

@@ -14,9 +14,11 @@
 //   pipeline is pinned with sched_group_barrier.
 //   GLDS = false (CTTS_F32_NO_GLDS=1, or more K chunks than the address table holds): the older
 //   2-stage variant that stages global->LDS through registers one chunk ahead.
+#include <atomic>
 #include <cstdlib>
 
 #include "gemm_f32.h"
+#include "gemm_bf16.h"   // pack_bf16x2 (split-bf16 main loop)
 
 namespace ctts {
 
@@ -107,8 +109,26 @@ __device__ __forceinline__ void split_epilogue(const GemmArgs& a, f32x16 (&acc)[
 // global loads + 6 x ds_write_b128 per thread per chunk) the kernel ran at 81.6 % of the MFMA peak, with the staging
 // removed altogether (stale operands) at 89.9 %: the LDS write port and the VGPR round trip were delaying the
 // fragment reads that feed the matrix pipe.
-template <int EPI, int WM, int SEGS, bool GLDS>
+//
+// X3 (split-bf16 main loop, GLDS only): the SAME staging, LDS image and fragment reads as the fp32 loop - lane (l31,
+// lhi) reads the 8 values k = 2 ks + lhi of its row / column - but the 8 values become ONE v_mfma_f32_32x32x16_bf16
+// operand: hi = bf16(v), lo = bf16(v - hi), and a 32x32 tile of the chunk is three bf16 MFMAs hi*hi + hi*lo + lo*hi
+// (96 matrix-pipe cycles) instead of eight fp32 MFMAs (512).  Operands carry 16 mantissa bits, accumulation is fp32;
+// tensors, packed weights and epilogues are untouched, so every fp32 path of the library can run on it.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4_t& hi, u32x4_t& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned int h = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+        hi[j] = h;
+        lo[j] = pack_bf16x2(v[2 * j] - __builtin_bit_cast(float, h << 16), v[2 * j + 1] - __builtin_bit_cast(float, h & 0xffff0000u));
+    }
+}
+
+template <int EPI, int WM, int SEGS, bool GLDS, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a) {
+    static_assert(!X3 || GLDS, "the split-bf16 loop is built on the DMA-staged pipeline");
     constexpr int NST = GLDS ? 3 : 2;
     constexpr int SEGTAB = NST * STAGE;
     constexpr int CHTAB = SEGTAB + GEMM_MAX_SEG * 4;         // GLDS: chunk -> B base address table (8 B per chunk)
@@ -334,8 +354,42 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
         const bool more = ch + 1 < nch;
         const float* As = lds + cur * STAGE + wm * 128 + l31;
         const float* Bs = lds + cur * STAGE + A_STAGE + wn * 64 + l31;
-        float av[GEMM_KC / 2][4], bv[GEMM_KC / 2][2];
-        if constexpr (GLDS) {
+        [[maybe_unused]] float av[GEMM_KC / 2][4], bv[GEMM_KC / 2][2];
+        if constexpr (X3) {
+            const int nb = cur >= 1 ? cur - 1 : 2;          // (cur + 2) % 3: the stage of chunk ch-1
+            const int cn = ch + 2 < nch ? ch + 2 : nch - 1;
+            CTTS_GLDS_ADDR(nb, cn)
+            u32x4_t ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                float v[8];
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) v[ks] = As[(2 * ks + lhi) * BM + mt * 32];
+                split8(v, ah[mt], al[mt]);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float v[8];
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) v[ks] = Bs[(2 * ks + lhi) * BN + nt * 32];
+                split8(v, bh[nt], bl[nt]);
+            }
+#define CTTS_X3_MFMA(A_, B_)                                                                    \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                    \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                \
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                      \
+                        __builtin_bit_cast(bf16x8_t, A_[mt]), __builtin_bit_cast(bf16x8_t, B_[nt]), acc[mt][nt], 0, 0, 0);
+            CTTS_X3_MFMA(al, bh)                            // small terms first
+            CTTS_GLDS_PIECE(0, la_, ac_, bp_); CTTS_GLDS_PIECE(1, la_, ac_, bp_);
+            CTTS_X3_MFMA(ah, bl)
+            CTTS_GLDS_PIECE(2, la_, ac_, bp_); CTTS_GLDS_PIECE(3, la_, ac_, bp_);
+            CTTS_X3_MFMA(ah, bh)
+            CTTS_GLDS_PIECE(4, la_, ac_, bp_); CTTS_GLDS_PIECE(5, la_, ac_, bp_);
+#undef CTTS_X3_MFMA
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                // chunk ch+1 landed, the newest in flight
+            __builtin_amdgcn_s_barrier();
+            cur = cur == 2 ? 0 : cur + 1;
+        } else if constexpr (GLDS) {
             // One region per k-step, fenced: [fragments of k-step ks+1 | 8 MFMAs of k-step ks | one DMA piece of chunk
             // ch+2].  The DMA issue (~60 cycles of this wave's instruction stream) sits behind eight 64-cycle MFMAs
             // already queued on the matrix pipe instead of in front of the chunk.
@@ -539,6 +593,21 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
     }
 }
 
+std::atomic<int> g_gemm_mode{0};
+inline int gemm_f32_mode() { return g_gemm_mode.load(std::memory_order_relaxed); }
+
+template <int EPI>
+void launch_shape_x3(int bm, dim3 grid, hipStream_t stream, const GemmArgs& a) {
+    const bool few = a.nseg <= 4;
+    if (bm == 128) {
+        if (few) hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 1, 4, true, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 1, GEMM_MAX_SEG, true, true>), grid, dim3(256), 0, stream, a);
+    } else {
+        if (few) hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 2, 4, true, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 2, GEMM_MAX_SEG, true, true>), grid, dim3(256), 0, stream, a);
+    }
+}
+
 template <int EPI, bool GLDS>
 void launch_shape_g(int bm, dim3 grid, hipStream_t stream, const GemmArgs& a) {
     const bool few = a.nseg <= 4;
@@ -554,10 +623,18 @@ void launch_shape_g(int bm, dim3 grid, hipStream_t stream, const GemmArgs& a) {
 template <int EPI>
 void launch_shape(int bm, dim3 grid, hipStream_t stream, const GemmArgs& a) {
     if (getenv("CTTS_F32_NO_GLDS") || a.nch_total > GEMM_GLDS_MAX_CHUNKS) launch_shape_g<EPI, false>(bm, grid, stream, a);
+    else if (gemm_f32_mode() == 1 && !a.exact_f32) launch_shape_x3<EPI>(bm, grid, stream, a);
     else launch_shape_g<EPI, true>(bm, grid, stream, a);
 }
 
 }  // namespace
+
+int set_gemm_f32_mode(int mode) {
+    if (mode != 0 && mode != 1) return -1;
+    g_gemm_mode.store(mode, std::memory_order_relaxed);
+    return 0;
+}
+int get_gemm_f32_mode() { return gemm_f32_mode(); }
 
 int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
     GemmArgs a = a_in;
@@ -607,6 +684,9 @@ int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
             if (getenv("CTTS_F32_NO_GLDS") || a.nch_total > GEMM_GLDS_MAX_CHUNKS) {
                 if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, 4, false>), grid, dim3(256), 0, stream, a);
                 else hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, GEMM_MAX_SEG, false>), grid, dim3(256), 0, stream, a);
+            } else if (gemm_f32_mode() == 1 && !a.exact_f32) {
+                if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, 4, true, true>), grid, dim3(256), 0, stream, a);
+                else hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, GEMM_MAX_SEG, true, true>), grid, dim3(256), 0, stream, a);
             } else {
                 if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, 4, true>), grid, dim3(256), 0, stream, a);
                 else hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, GEMM_MAX_SEG, true>), grid, dim3(256), 0, stream, a);

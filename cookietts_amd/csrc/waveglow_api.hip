@@ -748,6 +748,12 @@ int ctts_waveglow_infer_spk_f32(const ctts_waveglow_config* cfg, const void* pac
     return CTTS_OK;
 }
 
+int ctts_set_f32_gemm_mode(int32_t mode) {
+    if (set_gemm_f32_mode(mode)) { set_error("set_f32_gemm_mode: unknown mode %d (0 = fp32 MFMA, 1 = split bf16)", mode); return CTTS_E_ARG; }
+    return CTTS_OK;
+}
+int ctts_get_f32_gemm_mode(void) { return get_gemm_f32_mode(); }
+
 int ctts_profile_enable(int32_t on) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     g_prof.on = on != 0;

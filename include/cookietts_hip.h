@@ -548,6 +548,16 @@ int ctts_taco_stop_reset(void* state, int32_t batch, int32_t max_decoder_steps, 
 int ctts_taco_stop_rule_f32(const float* gate_logits, int32_t batch, int32_t gate_ld, int32_t step0, int32_t n_steps,
                             float gate_threshold, int32_t gate_delay, void* state, void* stream);
 
+/* ---- main loop of the fp32 conv-GEMM ------------------------------------------------------------------------
+ * Every fp32 path of the library (WaveGlow fp32, WaveFlow, the ax WaveGlow, conv1d / LSTM input projections, STFT)
+ * goes through one conv-GEMM.  mode 0 (default): v_mfma_f32_32x32x2_f32, exact fp32 products.  mode 1 ("split bf16"):
+ * the same kernel, tensors, packed weights and epilogues, but each operand value is split in registers into
+ * hi = bf16(v), lo = bf16(v - hi) and each product is computed as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16
+ * with fp32 accumulation: operands carry 16 mantissa bits (relative product error ~2^-16), the matrix pipe does
+ * 3/16 of the cycles.  Process-wide; returns 0, or -1 for an unknown mode.  ctts_get_f32_gemm_mode returns the mode. */
+int ctts_set_f32_gemm_mode(int32_t mode);
+int ctts_get_f32_gemm_mode(void);
+
 /* ---- in-library kernel timing (bench.py roofline leg) --------------------------------- */
 /* When enabled, ctts_waveglow_infer_f32 brackets every launch of the dominant kernel
  * (WN in-layer GEMM: dilated conv + cond + gate) with hipEvents on `stream`. */
