@@ -359,14 +359,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
             const int nb = cur >= 1 ? cur - 1 : 2;          // (cur + 2) % 3: the stage of chunk ch-1
             const int cn = ch + 2 < nch ? ch + 2 : nch - 1;
             CTTS_GLDS_ADDR(nb, cn)
-            u32x4_t ah[4], al[4], bh[2], bl[2];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                float v[8];
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) v[ks] = As[(2 * ks + lhi) * BM + mt * 32];
-                split8(v, ah[mt], al[mt]);
-            }
+            // B fragments first, then per row tile: [read + split A(mt + 1) | 6 MFMAs of mt | DMA pieces]: the VALU work
+            // of the next row tile sits in the shadow of this row tile's 192 matrix-pipe cycles
+            u32x4_t ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 float v[8];
@@ -374,18 +369,35 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
                 for (int ks = 0; ks < 8; ++ks) v[ks] = Bs[(2 * ks + lhi) * BN + nt * 32];
                 split8(v, bh[nt], bl[nt]);
             }
-#define CTTS_X3_MFMA(A_, B_)                                                                    \
-            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                    \
-                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                \
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                      \
-                        __builtin_bit_cast(bf16x8_t, A_[mt]), __builtin_bit_cast(bf16x8_t, B_[nt]), acc[mt][nt], 0, 0, 0);
-            CTTS_X3_MFMA(al, bh)                            // small terms first
+#define CTTS_X3_A(mt, slot)                                                                     \
+            {                                                                                   \
+                float v[8];                                                                     \
+                _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) v[ks] = As[(2 * ks + lhi) * BM + (mt) * 32]; \
+                split8(v, ah[slot], al[slot]);                                                  \
+            }
+#define CTTS_X3_MFMA6(mt, slot)                                                                 \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                  \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, al[slot]), __builtin_bit_cast(bf16x8_t, bh[nt]), acc[mt][nt], 0, 0, 0); \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah[slot]), __builtin_bit_cast(bf16x8_t, bl[nt]), acc[mt][nt], 0, 0, 0); \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah[slot]), __builtin_bit_cast(bf16x8_t, bh[nt]), acc[mt][nt], 0, 0, 0); \
+            }
+            CTTS_X3_A(0, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            CTTS_X3_A(1, 1)
+            CTTS_X3_MFMA6(0, 0)
             CTTS_GLDS_PIECE(0, la_, ac_, bp_); CTTS_GLDS_PIECE(1, la_, ac_, bp_);
-            CTTS_X3_MFMA(ah, bl)
+            __builtin_amdgcn_sched_barrier(0);
+            CTTS_X3_A(2, 0)
+            CTTS_X3_MFMA6(1, 1)
             CTTS_GLDS_PIECE(2, la_, ac_, bp_); CTTS_GLDS_PIECE(3, la_, ac_, bp_);
-            CTTS_X3_MFMA(ah, bh)
+            __builtin_amdgcn_sched_barrier(0);
+            CTTS_X3_A(3, 1)
+            CTTS_X3_MFMA6(2, 0)
             CTTS_GLDS_PIECE(4, la_, ac_, bp_); CTTS_GLDS_PIECE(5, la_, ac_, bp_);
-#undef CTTS_X3_MFMA
+            __builtin_amdgcn_sched_barrier(0);
+            CTTS_X3_MFMA6(3, 1)
+#undef CTTS_X3_A
+#undef CTTS_X3_MFMA6
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                // chunk ch+1 landed, the newest in flight
             __builtin_amdgcn_s_barrier();
             cur = cur == 2 ? 0 : cur + 1;
