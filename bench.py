@@ -79,6 +79,11 @@ def parse_args(argv=None):
                     help="f32 = BASELINE config 2 (default, the headline); bf16 = config 3 (use --batch 32); bf16x3 = "
                          "split-bf16 (hi + lo operands, three bf16 MFMA products per contraction, fp32 accumulate): an "
                          "extra row, never the headline")
+    ap.add_argument("--gemm-mode", default="f32", choices=["f32", "bf16x3"],
+                    help="main loop of the fp32 conv-GEMM (--dtype f32 only): f32 = fp32 MFMA products (default, the "
+                         "headline); bf16x3 = operands split in registers into hi + lo bf16, three bf16 MFMA products, "
+                         "fp32 accumulate - an extra row, labelled in the line's dtype.  Set explicitly here; the "
+                         "CTTS_F32_GEMM_MODE environment variable is ignored by bench.py")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="test hook for tests/test_bench_launcher.py: gloo on CPU with a stand-in step function; "
                          "exercises the launcher, the rank plumbing and sharding.py only - measures nothing")
@@ -221,6 +226,8 @@ def worker(args):
             sd = synthetic.waveglow_state_dict(cfg, seed=seed)
             model.load_state_dict(synthetic.to_torch(sd))
         model = model.to(device).eval()
+        import cookietts_amd
+        cookietts_amd.set_f32_gemm_mode(args.gemm_mode)          # explicit: never inherited from the environment
         if args.dtype == "bf16":
             model.set_compute_dtype(torch.bfloat16)
         elif args.dtype == "bf16x3":
@@ -303,11 +310,14 @@ def worker(args):
             # C*2C*3 plus this layer's slice of the conditioning projection 256*2C
             mac = 3 * C * 2 * C + 256 * 2 * C
             # bf16x3 executes three bf16 products per algorithmic MAC; the roofline counts the EXECUTED bf16 flops
-            flop_per_launch = 2.0 * mac * B * L * (3 if args.dtype == "bf16x3" else 1)
+            split = args.dtype == "bf16x3" or (args.dtype == "f32" and args.gemm_mode == "bf16x3")
+            flop_per_launch = 2.0 * mac * B * L * (3 if split else 1)
             mean_s = ms.value / max(n.value, 1) * 1e-3
             achieved = flop_per_launch / mean_s / 1e12
             peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
             kname = "conv_gemm_f32_kernel<GATE>" if args.dtype == "f32" else "conv_gemm_bf16_pp_kernel<GATE>"
+            if args.dtype == "f32" and args.gemm_mode == "bf16x3":
+                kname, peak = "conv_gemm_f32_kernel<GATE, X3>", BF16_MFMA_PEAK_TFLOPS
             roofline = {"kernel": kname + " (WN in-layer: dilated conv + cond + tanh*sigmoid)",
                         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
@@ -316,7 +326,7 @@ def worker(args):
                                            f"launch shape, not re-measured in this run") if traffic_src else None,
                         "launches": int(n.value), "mean_launch_ms": round(mean_s * 1e3, 4),
                         "flop_per_launch": flop_per_launch}
-            if args.dtype == "bf16x3":
+            if split:
                 roofline["note"] = ("flop_per_launch counts the three executed bf16 products per algorithmic MAC; "
                                     "algorithmic flops are a third of it")
             if args.dtype == "bf16":
@@ -348,7 +358,8 @@ def worker(args):
         line = {
             "metric": METRIC, "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype if (args.gemm_mode == "f32" or args.dtype != "f32") else "f32 tensors, split-bf16 GEMM products (bf16x3)",
             "data": "synthetic" if not selftest else "LAUNCHER SELF-TEST (gloo/CPU stand-in step; not a measurement)",
             "rtf": value / 22050.0,
             "config": {"workload": f"WaveGlow {args.config} ({cfg['n_flows']} flows, {C} WN ch, "

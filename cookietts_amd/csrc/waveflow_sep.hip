@@ -17,6 +17,8 @@
 // channels' sigmoid rows (tile row 1): the gate is lane-local.  A is streamed in 16-row K chunks (16 KiB) through one
 // LDS stage with a register prefetch; B is the LDS tile.  50 KiB of LDS -> three workgroups per CU.
 #include "waveflow_sep.h"
+#include "gemm_bf16.h"   // pack_bf16x2
+#include "gemm_f32.h"    // get_gemm_f32_mode
 
 namespace ctts {
 namespace {
@@ -39,6 +41,20 @@ __device__ __forceinline__ float sep_tanh(float u) {
 
 // acc[mt][nt] += A[64w + 32mt .. +32][0..128) . B[0..128)[32nt .. +32]   with A streamed from its packed image
 // ([8 chunks][16][256], contiguous) through `As`, B = the LDS tile `Bs` ([128][64], k-major).
+// X3: the split-bf16 form of the same contraction (see conv_gemm_f32_kernel<..., X3> in gemm_f32.hip): the 8 values a
+// lane reads per fragment become one bf16x8 hi / lo operand pair, 3 bf16 MFMAs per 32x32 tile and chunk instead of 8 fp32.
+typedef __bf16 sep_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int sep_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void sep_split8(const float (&v)[8], sep_u32x4& hi, sep_u32x4& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned int h = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+        hi[j] = h;
+        lo[j] = pack_bf16x2(v[2 * j] - __builtin_bit_cast(float, h << 16), v[2 * j + 1] - __builtin_bit_cast(float, h & 0xffff0000u));
+    }
+}
+
+template <bool X3>
 __device__ __forceinline__ void tile_gemm(f32x16 (&acc)[2][2], const float* __restrict__ Ag, float* __restrict__ As,
                                           const float* __restrict__ Bs, int t, int w, int l31, int lhi, bool active) {
     // named registers: a loop-carried array here is demoted to scratch by hipcc
@@ -52,7 +68,31 @@ __device__ __forceinline__ void tile_gemm(f32x16 (&acc)[2][2], const float* __re
             const float4* nx = Ag4 + (size_t)(ch + 1) * (ASTG_F / 4);
             p0 = nx[0]; p1 = nx[256]; p2 = nx[512]; p3 = nx[768];
         }
-        if (active) {
+        if (X3 && active) {
+            sep_u32x4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                float v[8];
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) v[ks] = As[(2 * ks + lhi) * SM + 64 * w + 32 * mt + l31];
+                sep_split8(v, ah[mt], al[mt]);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float v[8];
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) v[ks] = Bs[(ch * SKC + 2 * ks + lhi) * SN + 32 * nt + l31];
+                sep_split8(v, bh[nt], bl[nt]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sep_bf16x8, al[mt]), __builtin_bit_cast(sep_bf16x8, bh[nt]), acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sep_bf16x8, ah[mt]), __builtin_bit_cast(sep_bf16x8, bl[nt]), acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sep_bf16x8, ah[mt]), __builtin_bit_cast(sep_bf16x8, bh[nt]), acc[mt][nt], 0, 0, 0);
+                }
+        } else if (active) {
             float av[SKC / 2][2], bv[SKC / 2][2];
 #pragma unroll
             for (int ks = 0; ks < SKC / 2; ++ks) {
@@ -82,6 +122,7 @@ __device__ __forceinline__ void tile_gemm(f32x16 (&acc)[2][2], const float* __re
     }
 }
 
+template <bool X3>
 __global__ __launch_bounds__(256, 2) void wf_sep_layer_kernel(const WfSepArgs a) {
     __shared__ __attribute__((aligned(16))) float tile[TILE_F];
     __shared__ __attribute__((aligned(16))) float As[ASTG_F];
@@ -132,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void wf_sep_layer_kernel(const WfSepArgs a)
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    tile_gemm(acc, a.A1, As, tile, t, w, l31, lhi, true);
+    tile_gemm<X3>(acc, a.A1, As, tile, t, w, l31, lhi, true);
     // (tile_gemm ends with a barrier: nobody reads the depthwise tile any more)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
@@ -153,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void wf_sep_layer_kernel(const WfSepArgs a)
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    tile_gemm(acc, a.A2, As, tile, t, w, l31, lhi, active);
+    tile_gemm<X3>(acc, a.A2, As, tile, t, w, l31, lhi, active);
     if (!active) return;
 
     // ---- phase 5: rows < split -> x_{i+1} = x_i + res, rows >= split -> out (+)= skip.  All loads of a row tile
@@ -221,7 +262,8 @@ int launch_wf_sep_pack(const float* pw_w, const float* pw_b, const float* rs_w, 
 int launch_wf_sep_layer(const WfSepArgs& a, int batch, hipStream_t s) {
     CTTS_CHECK_ARG(a.L <= a.ntiles * SN && a.ntiles * SN + a.pad <= a.ld && a.pad % 4 == 0 && a.ld % 4 == 0 && a.dwout &&
                    a.cond && a.xin && a.out, "wf_sep_layer: geometry L=%d ld=%d pad=%d", a.L, a.ld, a.pad);
-    hipLaunchKernelGGL(wf_sep_layer_kernel, dim3((unsigned)(a.ntiles * batch)), dim3(256), 0, s, a);
+    if (get_gemm_f32_mode() == 1) hipLaunchKernelGGL(wf_sep_layer_kernel<true>, dim3((unsigned)(a.ntiles * batch)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(wf_sep_layer_kernel<false>, dim3((unsigned)(a.ntiles * batch)), dim3(256), 0, s, a);
     CTTS_CHECK_LAUNCH("wf_sep_layer");
     return CTTS_OK;
 }

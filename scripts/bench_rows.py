@@ -158,5 +158,8 @@ if __name__ == "__main__":
            "waveglow_ax": row_waveglow_ax_notebook}
     for r in args.rows.split(","):
         out = fns[r](args)
+        from cookietts_amd import _lib
+        mode = {v: k for k, v in _lib.GEMM_MODES.items()}[_lib.lib().ctts_get_f32_gemm_mode()]
         for line in (out if isinstance(out, list) else [out]):
+            line["f32_gemm_mode"] = mode          # "f32" (fp32 MFMA products) or "bf16x3" (CTTS_F32_GEMM_MODE=bf16x3)
             print(json.dumps(line), flush=True)
