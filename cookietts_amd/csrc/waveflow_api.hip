@@ -326,6 +326,59 @@ __global__ __launch_bounds__(256) void scale_add_rows_kernel(const float* __rest
     y[i] = r ? a * x[i] + r[i] : a * x[i];
 }
 
+// x = (x + shift) * scale on the valid columns (shift_spect / scale_spect, ax:206-209, 281-284); the halo stays zero
+__global__ __launch_bounds__(256) void affine_rows_kernel(float* __restrict__ x, int C, int T, int ld, int pad, float shift,
+                                                          float scale) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    const size_t i = ((size_t)b * C + c) * ld + pad + t;
+    x[i] = (x[i] + shift) * scale;
+}
+
+// F.interpolate along time on padded rows, the arithmetic of ATen's upsample kernels:
+//   mode 0 = 'linear', align_corners=True  (glow_ax.py:365 / ax:174): src = n * (Tin - 1) / (Tout - 1)
+//   mode 1 = 'linear', align_corners=False (TransposedUpsampleNet residual, glow_ax.py:231): src = max((n + .5) * s - .5, 0)
+//   mode 2 = 'nearest'                                                          : src = min(floor(n * s), Tin - 1)
+// with s = 1 / scale_factor when a scale factor was given (ATen uses the reciprocal of the given factor), else Tin / Tout.
+__global__ __launch_bounds__(256) void resample_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int Tin,
+                                                            int ld_in, int pad_in, int Tout, int ld_out, int pad_out,
+                                                            int mode, float s) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (n >= Tout) return;
+    const float* src = x + ((size_t)b * C + c) * ld_in + pad_in;
+    float v;
+    if (mode == 2) {
+        const int i = min((int)floorf((float)n * s), Tin - 1);
+        v = src[i];
+    } else {
+        float real;
+        if (mode == 0) real = (Tout > 1 ? (float)(Tin - 1) / (float)(Tout - 1) : 0.f) * (float)n;
+        else real = fmaxf(s * ((float)n + 0.5f) - 0.5f, 0.f);
+        const int i0 = (int)real;
+        const int i1 = i0 + 1 < Tin ? i0 + 1 : Tin - 1;
+        const float l1 = real - (float)i0;
+        const float l0 = 1.0f - l1;
+        v = l0 * src[i0] + l1 * src[i1];
+    }
+    y[((size_t)b * C + c) * ld_out + pad_out + n] = v;
+}
+
+// ConvTranspose1d(stride s, padding p) as s stride-1 convolutions (one per output residue r = (n + p) mod s, evaluated
+// by ctts_conv1d_f32 over the INPUT positions m): out[n] = phase[r][(n + p) / s].  phases: [s][B][C][ld_in].
+__global__ __launch_bounds__(256) void interleave_phases_kernel(const float* __restrict__ ph, float* __restrict__ y, int C,
+                                                                int s, int p, int Tin, int ld_in, int pad_in, int Tout,
+                                                                int ld_out, int pad_out, size_t phase_stride) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (n >= Tout) return;
+    const int q = n + p, r = q % s, m = q / s;
+    float v = 0.f;
+    if (m < Tin) v = ph[(size_t)r * phase_stride + ((size_t)b * C + c) * ld_in + pad_in + m];
+    y[((size_t)b * C + c) * ld_out + pad_out + n] = v;
+}
+
 // y[n] = x[n] + p * y[n-1], one workgroup per utterance, fp64 state (scipy.signal.lfilter([1],[1,-p]) runs in
 // float64 on the reference's CPU path, ax:351-355).  Thread t owns one contiguous span: pass 1 runs the recurrence
 // from a zero state to get the span's own contribution, thread 0 chains the 256 span ends
@@ -682,6 +735,37 @@ int ctts_scale_add_rows_f32(const float* x, const float* alpha_dev, const float*
     hipLaunchKernelGGL(scale_add_rows_kernel, dim3((T + 255) / 256, C, batch), dim3(256), 0, as_stream(stream), x,
                        alpha_dev, r, y, C, T, ld, pad);
     CTTS_CHECK_LAUNCH("scale_add_rows");
+    return CTTS_OK;
+}
+
+int ctts_affine_rows_f32(float* x, int32_t batch, int32_t C, int32_t rows, int32_t T, int32_t ld, int32_t pad, float shift,
+                         float scale, void* stream) {
+    CTTS_CHECK_ARG(x && batch >= 1 && rows >= 1 && rows <= C && T >= 1 && ld >= pad + T, "affine_rows: bad argument");
+    hipLaunchKernelGGL(affine_rows_kernel, dim3((T + 255) / 256, rows, batch), dim3(256), 0, as_stream(stream), x, C, T, ld,
+                       pad, shift, scale);
+    CTTS_CHECK_LAUNCH("affine_rows");
+    return CTTS_OK;
+}
+
+int ctts_resample_rows_f32(const float* x, float* y, int32_t batch, int32_t C, int32_t T_in, int32_t ld_in, int32_t pad_in,
+                           int32_t T_out, int32_t ld_out, int32_t pad_out, int32_t mode, float scale_factor, void* stream) {
+    CTTS_CHECK_ARG(x && y && batch >= 1 && C >= 1 && T_in >= 1 && T_out >= 1 && ld_in >= pad_in + T_in &&
+                   ld_out >= pad_out + T_out && mode >= 0 && mode <= 2, "resample_rows: bad argument");
+    const float s = scale_factor > 0.f ? 1.0f / scale_factor : (float)T_in / (float)T_out;
+    hipLaunchKernelGGL(resample_rows_kernel, dim3((T_out + 255) / 256, C, batch), dim3(256), 0, as_stream(stream), x, y, C,
+                       T_in, ld_in, pad_in, T_out, ld_out, pad_out, mode, s);
+    CTTS_CHECK_LAUNCH("resample_rows");
+    return CTTS_OK;
+}
+
+int ctts_interleave_phases_f32(const float* phases, float* y, int32_t batch, int32_t C, int32_t stride, int32_t padding,
+                               int32_t T_in, int32_t ld_in, int32_t pad_in, int32_t T_out, int32_t ld_out, int32_t pad_out,
+                               void* stream) {
+    CTTS_CHECK_ARG(phases && y && batch >= 1 && C >= 1 && stride >= 1 && padding >= 0 && T_in >= 1 && T_out >= 1 &&
+                   ld_in >= pad_in + T_in && ld_out >= pad_out + T_out, "interleave_phases: bad argument");
+    hipLaunchKernelGGL(interleave_phases_kernel, dim3((T_out + 255) / 256, C, batch), dim3(256), 0, as_stream(stream), phases,
+                       y, C, stride, padding, T_in, ld_in, pad_in, T_out, ld_out, pad_out, (size_t)batch * C * ld_in);
+    CTTS_CHECK_LAUNCH("interleave_phases");
     return CTTS_OK;
 }
 

@@ -130,6 +130,13 @@ WAVEFLOW_CONFIGS = {
                                          n_mel_channels=12, hop_length=40, win_length=160, speaker_embed=8,
                                          cond_layers=2, cond_hidden=32, wn_cond_hidden=24),
     "author": waveflow_author_config(),
+    # the WaveFlow printed by scripts/"UnTTS Inference.ipynb" (cell output at line 64): the same option family with
+    # 12 flows, a 3-layer k=3 cond stack and the mel shifted / scaled on entry (shift_spect 11.52, scale_spect 0.25)
+    "untts_toy": dict(waveflow_author_config(n_flows=4, n_group=10, n_channels=64, n_layers=3, kernel=5, n_mel_channels=12,
+                                             hop_length=40, win_length=160, speaker_embed=8, cond_layers=3, cond_hidden=32,
+                                             wn_cond_hidden=24),
+                      shift_spect=11.52, scale_spect=0.25, cond_kernel_size=2, negative_slope=0.5, preempthasis=None,
+                      use_logvar_channels=False),
 }
 
 
@@ -173,6 +180,29 @@ def waveglow_ax_notebook_config(n_flows=48, n_group=24, n_channels=256, n_layers
                 cond_hidden_channels=256, cond_padding_mode='replicate', seperable_conv=0, cond_kernel_size=1))
 
 
+def waveglow_ax_untts_config(n_flows=24, n_group=24, n_channels=384, n_layers=8, n_mel_channels=256, hop_length=600,
+                             win_length=2400, speaker_embed=32, cond_hidden=1024, cond_output=1024, t_hidden=1024,
+                             t_kernels=(4, 9, 5), t_scales=(2, 3, 5), t_output=512, shift_spect=0.0, scale_spect=1.0):
+    """The vocoder config printed by the reference's ``_2_ttm/untts/inference.ipynb`` (cell output at line 313):
+    ``waveflow=False``, InvertibleConv1x1 mixing before the coupling, 24 flows x 8 layers x 384 channels, n_group 24,
+    256-channel mel, a 4-layer k=1 conditioning stack with a 1x1-conv residual + rezero, and the conditioning
+    upsampled at MODEL level (``upsample_first=True``) by a TransposedUpsampleNet (scales 2*3*5 = 30 != hop / n_group
+    = 25, linear residual + rezero) followed by linear interpolation to the latent length."""
+    return waveglow_ax_config(
+        n_flows=n_flows, n_group=n_group, n_channels=n_channels, n_layers=n_layers, n_mel_channels=n_mel_channels,
+        hop_length=hop_length, win_length=win_length, sampling_rate=48000, channel_mixing='1x1conv', mix_first=True,
+        n_early_every=n_flows, n_early_size=2, speaker_embed=speaker_embed, shift_spect=shift_spect,
+        scale_spect=scale_spect, cond_layers=4 if cond_hidden >= 256 else 2, cond_activation_func='lrelu',
+        negative_slope=0.1, cond_hidden_channels=cond_hidden, cond_output_channels=cond_output, cond_residual='1x1conv',
+        cond_res_rezero=True, cond_kernel_size=1, cond_padding_mode='zeros', upsample_first=True,
+        transposed_conv_hidden_dim=t_hidden, transposed_conv_kernel_size=list(t_kernels),
+        transposed_conv_scales=list(t_scales), transposed_conv_output_dim=t_output, transposed_conv_residual=True,
+        transposed_conv_residual_linear=True, transposed_conv_res_rezero=True,
+        WN=dict(speaker_embed_dim=0, cond_layers=1, cond_activation_func='lrelu', cond_out_activation_func=False,
+                negative_slope=0.5, cond_hidden_channels=256, cond_kernel_size=1, cond_padding_mode='zeros',
+                transposed_conv_scales=None))
+
+
 WAVEGLOW_AX_CONFIGS = {
     # InvertibleConv1x1 mixing (the ax constructor's default), mix before the coupling, early outputs
     "toy_conv": waveglow_ax_config(n_flows=5, n_group=8, n_early_every=2),
@@ -188,6 +218,12 @@ WAVEGLOW_AX_CONFIGS = {
                                                 hop_length=120, win_length=480, speaker_embed=8, cond_hidden=32,
                                                 n_early_every=2),
     "notebook": waveglow_ax_notebook_config(),
+    # the untts notebook's vocoder: model-level transposed-conv upsampling, 1x1-conv cond residual; toy and full size
+    "untts_toy": waveglow_ax_untts_config(n_flows=4, n_group=8, n_channels=128, n_layers=2, n_mel_channels=16,
+                                          hop_length=40, win_length=160, speaker_embed=8, cond_hidden=48, cond_output=48,
+                                          t_hidden=48, t_kernels=(4, 9), t_scales=(2, 3), t_output=32, shift_spect=1.5,
+                                          scale_spect=0.5),
+    "untts": waveglow_ax_untts_config(),
 }
 
 
@@ -223,6 +259,26 @@ def waveglow_ax_state_dict(cfg, seed=1234, end_std=None):
         dims = [c_in] + [cfg["cond_hidden_channels"]] * (cfg["cond_layers"] - 1) + [c_wn]
         for l in range(cfg["cond_layers"]):
             _wn_conv(rng, sd, f"cond_layers.{l}", dims[l + 1], dims[l], k)
+    if cfg["cond_layers"] and cfg["cond_residual"] == '1x1conv':                 # ax:80-81 (plain Conv1d)
+        bound = 1.0 / np.sqrt(c_in)
+        sd["res_conv.weight"] = _uniform(rng, (c_wn, c_in, 1), bound)
+        sd["res_conv.bias"] = _uniform(rng, (c_wn,), bound)
+    if cfg.get("upsample_first") is True:                                        # ax:116-126, glow_ax.py:207-226
+        scales = cfg["transposed_conv_scales"]
+        ksz = cfg["transposed_conv_kernel_size"]
+        hid, t_out = cfg["transposed_conv_hidden_dim"], cfg.get("transposed_conv_output_dim") or c_wn
+        if cfg.get("transposed_conv_res_rezero"):
+            sd["upsample_net.res_weight"] = np.array([0.4], np.float32)
+        idx = 0
+        for i, sc in enumerate(scales):
+            last = i + 1 == len(scales)
+            ind, outd = (c_wn if i == 0 else hid), (t_out if last else hid)
+            kk = ksz[i] if isinstance(ksz, (list, tuple)) else ksz
+            bound = 1.0 / np.sqrt(ind * kk / sc)
+            sd[f"upsample_net.t_convs.{idx}.weight"] = _uniform(rng, (ind, outd, kk), bound)
+            sd[f"upsample_net.t_convs.{idx}.bias"] = _uniform(rng, (outd,), bound)
+            idx += 2                                                             # a LeakyReLU module follows every conv
+        c_wn = t_out
     sdim = wn.get("speaker_embed_dim", 0)
     conv_mix = cfg.get("channel_mixing", '1x1conv').lower() in "1x1convinvertibleconv1x1invconv"
     for k, n_rem in enumerate(waveglow_ax_flow_channels(cfg)):

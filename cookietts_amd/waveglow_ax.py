@@ -23,6 +23,8 @@ from __future__ import annotations
 import ctypes as C
 import math
 
+import numpy as np
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -179,6 +181,75 @@ def _r16(n):
     return -(-n // 16) * 16
 
 
+def _ld_for(T):
+    """Row stride of a padded [B][rows][ld] buffer with T valid columns (a few spare columns for the transposed-conv
+    phases, which run a little past the input length)."""
+    return -(-(T + 8) // 128) * 128 + 2 * PAD
+
+
+class _TransposedConv:
+    """``nn.ConvTranspose1d(in, out, k, stride=s, padding=(k - s) // 2)`` (+ LeakyReLU) of ``TransposedUpsampleNet``
+    (glow_ax.py:222-226) as ``s`` stride-1 convolutions, one per output residue r = (n + p) mod s:
+    out[n] = sum_q W[:, :, r + q s]^T x[(n + p) // s - q], run by ``ctts_conv1d_f32`` over the input positions and
+    interleaved by ``ctts_interleave_phases_f32``."""
+
+    def __init__(self, w, b, s, act, slope, device, stream):
+        in_c, out_c, k = w.shape                                   # ConvTranspose1d weight layout
+        if (k - s) % 2 or k < s:
+            raise NotImplementedError(f"transposed conv with kernel {k}, stride {s}: output length is not stride * T")
+        Q = -(-k // s)
+        wr = torch.zeros(s, out_c, in_c, 2 * Q - 1, dtype=torch.float32, device=device)
+        for r in range(s):
+            for q in range(Q):
+                if r + q * s < k:
+                    wr[r, :, :, Q - 1 - q] = w[:, :, r + q * s].t()   # tap offset -q of a 'same' conv with 2Q-1 taps
+        self.ops = [_CondConv(wr[r], b, act, slope, device, stream) for r in range(s)]
+        self.s, self.p, self.out_c = s, (k - s) // 2, out_c
+        self.extra = (k - self.p - 1) // s                          # phase positions needed past the input length
+
+    def __call__(self, x, B, T, ld, stream):
+        dev = x.device
+        Tp, T_out = T + self.extra, T * self.s
+        assert ld >= PAD + Tp + PAD
+        ph = torch.zeros(self.s, B, _r16(self.out_c), ld, dtype=torch.float32, device=dev)
+        for r, op in enumerate(self.ops):
+            op(x, ph[r], B, Tp, ld, stream)
+        ld_out = _ld_for(T_out)
+        y = torch.zeros(B, _r16(self.out_c), ld_out, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().ctts_interleave_phases_f32(_lib.ptr(ph), _lib.ptr(y), B, y.shape[1], self.s, self.p, Tp, ld,
+                                                         PAD, T_out, ld_out, PAD, stream), "ctts_interleave_phases_f32")
+        return y, T_out, ld_out
+
+
+class _TransposedUpsampleNet(nn.Module):
+    """Parameter holder with the reference's ``state_dict`` layout (glow_ax.py:201-242): ``t_convs`` alternates
+    ConvTranspose1d and LeakyReLU(0.4) modules, ``res_weight`` exists with rezero."""
+
+    def __init__(self, in_channels, out_channels, hidden_channels, kernel_size, scales, use_last_layer_act_func, residual,
+                 residual_linear, rezero):
+        super().__init__()
+        self.residual, self.residual_linear = bool(residual), bool(residual_linear)
+        self.res_weight = nn.Parameter(torch.rand(1) * 0.02 + 0.01) if rezero else None
+        self.scales = list(scales)
+        self.t_convs = nn.ModuleList()
+        self.acts = []
+        for i, scale in enumerate(self.scales):
+            last = i + 1 == len(self.scales)
+            in_dim = in_channels if i == 0 else hidden_channels
+            out_dim = out_channels if last else hidden_channels
+            k = kernel_size[i] if isinstance(kernel_size, (list, tuple)) else kernel_size
+            self.t_convs.append(nn.ConvTranspose1d(in_dim, out_dim, k, scale, padding=(k - scale) // 2))
+            act = (not last) or use_last_layer_act_func
+            if act:
+                self.t_convs.append(nn.LeakyReLU(negative_slope=0.4))
+            self.acts.append(act)
+        self.res_channels = min(in_channels, out_channels)
+        self.out_channels = out_channels
+
+    def convs(self):
+        return [m for m in self.t_convs if isinstance(m, nn.ConvTranspose1d)]
+
+
 class WaveGlow(nn.Module):
     def __init__(self, n_mel_channels, n_flows, n_group, n_early_every, n_early_size, memory_efficient,
                  spect_scaling, upsample_mode, upsample_first, speaker_embed, cond_layers, cond_hidden_channels,
@@ -186,7 +257,10 @@ class WaveGlow(nn.Module):
                  hop_length, sampling_rate=48000, cond_res_rezero=False, cond_activation_func='none',
                  negative_slope=None, channel_mixing='1x1conv', mix_first=True, preceived_vol_scaling=False,
                  waveflow=True, yoyo='depreciated', yoyo_WN='depreciated', shift_spect=0., scale_spect=1.,
-                 preempthasis=None, use_logvar_channels=False, load_hidden_from_disk=False, **unsupported):
+                 preempthasis=None, use_logvar_channels=False, load_hidden_from_disk=False,
+                 transposed_conv_hidden_dim=256, transposed_conv_kernel_size=4, transposed_conv_scales=None,
+                 transposed_conv_output_dim=256, transposed_conv_residual=False, transposed_conv_residual_linear=False,
+                 transposed_conv_res_rezero=False, **unsupported):
         super().__init__()
         assert n_group % 2 == 0
         assert hop_length % n_group == 0, "hop_length is not int divisible by n_group"
@@ -207,14 +281,24 @@ class WaveGlow(nn.Module):
             need(not wn.get('seperable_conv', False), "waveflow=False with seperable_conv")
             need(wn['n_channels'] % 128 == 0, "waveflow=False with n_channels not a multiple of 128")
             need(n_group <= 32, "waveflow=False with n_group > 32")
-        need(cond_residual in (False, True, 0, 1), "cond_residual='1x1conv'")
-        need(not upsample_first, "upsample_first")
+        need(cond_residual in (False, True, 0, 1, '1x1conv'), f"cond_residual={cond_residual!r}")
+        use_tconv = bool(transposed_conv_scales) and bool(transposed_conv_hidden_dim) and bool(transposed_conv_kernel_size)
+        need(upsample_first in (False, None, True), f"upsample_first={upsample_first!r}")
+        if upsample_first is True:                                # ax:121-126, 174-186: cond upsampled at model level
+            need(not waveflow, "upsample_first=True with waveflow=True")
+            need(use_tconv, "upsample_first=True without a TransposedUpsampleNet")
+            need(int(np.prod(transposed_conv_scales)) != hop_length // n_group,
+                 "transposed_conv_scales whose product equals hop_length // n_group (the reference crops to an empty "
+                 "tensor there, ax:180-184)")
+        else:
+            need(not use_tconv, "TransposedUpsampleNet with upsample_first != True")
+        need(not wn.get('transposed_conv_scales'), "WN-level TransposedUpsampleNet")
         need(cond_padding_mode in ('zeros', 'replicate') and wn.get('cond_padding_mode', 'zeros') in ('zeros', 'replicate'),
              "cond_padding_mode other than 'zeros' / 'replicate'")
-        need(shift_spect == 0. and scale_spect == 1. and not preceived_vol_scaling, "spect shift/scale, vol scaling")
+        need(not preceived_vol_scaling, "preceived_vol_scaling")
         need(not load_hidden_from_disk, "hidden cond from disk")
-        need(not unsupported.get('iso226_empthasis', False) and not unsupported.get('transposed_conv_scales')
-             and not unsupported.get('group_conv_output_dim'), "iso226 emphasis / transposed-conv upsampling / grouped cond conv")
+        need(not unsupported.get('iso226_empthasis', False) and not unsupported.get('group_conv_output_dim'),
+             "iso226 emphasis / grouped per-flow cond conv")
         need(wn.get('cond_layers', 1) >= 1, "WN without cond layers")
         need(wn.get('upsample_mode', 'linear') == 'linear', "WN upsample_mode != 'linear'")
         need(wn.get('res_skip', True) and not wn.get('merge_res_skip', False), "merge_res_skip")
@@ -244,6 +328,8 @@ class WaveGlow(nn.Module):
         self.speaker_embed_dim = speaker_embed
         self.multispeaker = speaker_embed > 0 or wn.get('speaker_embed_dim', 0) > 0
         self.cond_residual, self.cond_res_rezero = cond_residual, cond_res_rezero
+        self.shift_spect, self.scale_spect = float(shift_spect), float(scale_spect)
+        self.upsample_early = upsample_first is True
         self.WN_config = wn
         # activation tables (validated now so that an unsupported name fails at construction)
         self._act_model = _act_code(cond_activation_func if cond_layers else 'none', negative_slope)
@@ -257,11 +343,21 @@ class WaveGlow(nn.Module):
             self.alpha = nn.Parameter(torch.rand(1) * 0.02 + 0.01)               # ax:75-76
         self.cond_layers = nn.ModuleList()
         if cond_layers:
-            out_c = self.cond_in_channels if cond_residual in (True, 1) else cond_output_channels   # ax:72-73
+            out_c = self.cond_in_channels if (cond_residual is True or cond_residual == 1) else cond_output_channels  # ax:72-73
+            if cond_residual == '1x1conv':
+                self.res_conv = nn.Conv1d(self.cond_in_channels, out_c, 1)       # ax:80-81
             k = 2 * cond_kernel_size - 1                                         # ax:83
             dims = [self.cond_in_channels] + [cond_hidden_channels] * (cond_layers - 1) + [out_c]
             self.cond_layers = nn.ModuleList([_WNConv((dims[l + 1], dims[l], k)) for l in range(cond_layers)])
             wn_cond = out_c
+        if self.upsample_early:                                                  # ax:116-126
+            t_out = transposed_conv_output_dim if transposed_conv_output_dim is not None else wn_cond
+            self.upsample_net = _TransposedUpsampleNet(wn_cond, t_out, transposed_conv_hidden_dim,
+                                                       transposed_conv_kernel_size, transposed_conv_scales, True,
+                                                       transposed_conv_residual, transposed_conv_residual_linear,
+                                                       transposed_conv_res_rezero)
+            self.model_cond_channels = wn_cond
+            wn_cond = t_out
         self.wn_cond_channels = wn_cond
         if waveflow:
             self.WN = nn.ModuleList([_Coupling(_WN2d(wn_cond, wn)) for _ in range(n_flows)])
@@ -428,48 +524,93 @@ class WaveGlow(nn.Module):
                         out.append(_CondConv(self._dense(layer, stream, keep), layer.bias, a[0], a[1], device, stream))
                     return out
                 ops = {'model': stack(self.cond_layers, self._act_model, True),          # ax:293-297: every layer
+                       'res_conv': (_CondConv(self.res_conv.weight.detach().float(), self.res_conv.bias, 0, 0.0, device, stream)
+                                    if hasattr(self, 'res_conv') else None),            # ax:303-304
+                       'tconv': ([_TransposedConv(m.weight.detach().float(), m.bias, sc, 1 if act else 0, 0.4, device, stream)
+                                  for m, sc, act in zip(self.upsample_net.convs(), self.upsample_net.scales,
+                                                        self.upsample_net.acts)]
+                                 if self.upsample_early else None),                     # glow_ax.py:214-226
                        'wn': [stack(c.WN.cond_layers, self._act_wn, wn_cfg.get('cond_out_activation_func', True))
                               for c in self.WN]}                                       # glow_ax.py:573-577
             torch.cuda.current_stream(device).synchronize()
         self._packed = (device, blob, ops, key)
         return blob, ops
 
-    def _cond_frames(self, ops, cond, speaker_ids, stream):
-        """ax:286-307 + glow_ax.py:566-577 at frame rate -> [n_flows][B][2C*n_layers][ld] padded rows."""
+    def _cond_frames(self, ops, cond, speaker_ids, stream, out_steps=None):
+        """ax:281-307 + glow_ax.py:566-577 -> ([n_flows][B][2C*n_layers][ld] padded rows, ld, T): at frame rate
+        (T = frames), or with ``upsample_first=True`` at the rate of the latent (T = out_steps)."""
         lib = _lib.lib()
         dev = cond.device
         B, Cm, Fr = cond.shape
-        ld = -(-Fr // 128) * 128 + 2 * PAD
+        ld = _ld_for(Fr)
         if self.multispeaker:
             if speaker_ids is None:
                 raise Exception("This WaveFlow/WaveGlow model requires speaker ids or speaker embeddings.")   # ax:288
             ids = speaker_ids.to(device=dev, dtype=torch.int64).contiguous()
 
-        def rows(c):
-            return torch.zeros(B, _r16(c), ld, dtype=torch.float32, device=dev)
-        # model-level input: [mel (+logvar) | speaker embedding]
+        def rows(c, ld_=None):
+            return torch.zeros(B, _r16(c), ld_ or ld, dtype=torch.float32, device=dev)
+        # model-level input: [mel (+logvar), shifted and scaled | speaker embedding]
         x0 = rows(self.cond_in_channels)
         for b in range(B):
             _lib.check(lib.ctts_pad_rows_f32(_lib.ptr(cond[b]), 0, Fr, _lib.ptr(x0[b]), 1, Cm, Fr, ld, PAD, stream),
                        "ctts_pad_rows_f32")
+        if self.shift_spect != 0. or self.scale_spect != 1.:                    # ax:281-284
+            _lib.check(lib.ctts_affine_rows_f32(_lib.ptr(x0), B, x0.shape[1], Cm, Fr, ld, PAD, self.shift_spect,
+                                                self.scale_spect, stream), "ctts_affine_rows_f32")
         if self.speaker_embed_dim:
             tab = self.speaker_embed.weight.detach().float().contiguous()
             _lib.check(lib.ctts_embed_rows_f32(_lib.ptr(tab), _lib.ptr(ids), _lib.ptr(x0), Cm, self.speaker_embed_dim, B,
                                                x0.shape[1], Fr, ld, PAD, stream), "ctts_embed_rows_f32")
-        # conv stack, rezero, residual
+        # conv stack, rezero, residual (identity or 1x1 conv of the input, ax:299-307)
         sdim = self.WN_config.get('speaker_embed_dim', 0)
-        xw = rows(self.wn_cond_channels + sdim)
+        c_model = self.model_cond_channels if self.upsample_early else self.wn_cond_channels
+        xw = rows(c_model + (0 if self.upsample_early else sdim))
         h = x0
         for op in ops['model']:
             y = rows(op.c_out)
             op(h, y, B, Fr, ld, stream, self.cond_padding_mode)
             h = y
         alpha = self.alpha.detach().float().contiguous() if (self.cond_res_rezero and len(ops['model'])) else None
-        resid = x0 if (self.cond_residual and len(ops['model'])) else None
+        resid = None
+        if self.cond_residual and len(ops['model']):
+            resid = x0
+            if ops['res_conv'] is not None:
+                resid = rows(ops['res_conv'].c_out)
+                ops['res_conv'](x0, resid, B, Fr, ld, stream)
         for b in range(B):     # row counts differ between the buffers: one utterance per call
             _lib.check(lib.ctts_scale_add_rows_f32(_lib.ptr(h[b]), _lib.ptr(alpha), _lib.ptr(None if resid is None else resid[b]),
-                                                   _lib.ptr(xw[b]), 1, self.wn_cond_channels, Fr, ld, PAD, stream),
+                                                   _lib.ptr(xw[b]), 1, c_model, Fr, ld, PAD, stream),
                        "ctts_scale_add_rows_f32")
+        T = Fr
+        if self.upsample_early:                                                  # ax:174-186 with TransposedUpsampleNet
+            net = self.upsample_net
+            factor = int(np.prod(net.scales))
+            h, hT, hld = xw, Fr, ld
+            for tc in ops['tconv']:
+                h, hT, hld = tc(h, B, hT, hld, stream)
+            if net.residual:                                                     # glow_ax.py:229-241
+                xi = rows(net.res_channels, hld)
+                for b in range(B):
+                    _lib.check(lib.ctts_resample_rows_f32(_lib.ptr(xw[b]), _lib.ptr(xi[b]), 1, net.res_channels, Fr, ld, PAD,
+                                                          hT, hld, PAD, 1 if net.residual_linear else 2, float(factor),
+                                                          stream), "ctts_resample_rows_f32")
+                rw = net.res_weight.detach().float().contiguous() if net.res_weight is not None else None
+                for b in range(B):
+                    _lib.check(lib.ctts_scale_add_rows_f32(_lib.ptr(h[b]), _lib.ptr(rw), _lib.ptr(xi[b]), _lib.ptr(h[b]), 1,
+                                                           net.res_channels, hT, hld, PAD, stream), "ctts_scale_add_rows_f32")
+                    if net.out_channels > net.res_channels and rw is not None:
+                        tail = h[b][net.res_channels:]
+                        _lib.check(lib.ctts_scale_add_rows_f32(_lib.ptr(tail), _lib.ptr(rw), None, _lib.ptr(tail), 1,
+                                                               net.out_channels - net.res_channels, hT, hld, PAD, stream),
+                                   "ctts_scale_add_rows_f32")
+            # to the length of the latent (ax:177-178: 'linear', align_corners=True)
+            T = out_steps
+            ld = _ld_for(T)
+            xw = rows(self.wn_cond_channels + sdim)
+            for b in range(B):
+                _lib.check(lib.ctts_resample_rows_f32(_lib.ptr(h[b]), _lib.ptr(xw[b]), 1, self.wn_cond_channels, hT, hld, PAD,
+                                                      T, ld, PAD, 0, 0.0, stream), "ctts_resample_rows_f32")
         # per flow: WN speaker embedding, conv stack -> 2C*n_layers rows
         C2L = 2 * self.WN_config['n_channels'] * self.WN_config['n_layers']
         frames = torch.zeros(self.n_flows, B, C2L, ld, dtype=torch.float32, device=dev)
@@ -477,13 +618,13 @@ class WaveGlow(nn.Module):
             if sdim:
                 tab = self.WN[k].WN.speaker_embed.weight.detach().float().contiguous()
                 _lib.check(lib.ctts_embed_rows_f32(_lib.ptr(tab), _lib.ptr(ids), _lib.ptr(xw), self.wn_cond_channels, sdim,
-                                                   B, xw.shape[1], Fr, ld, PAD, stream), "ctts_embed_rows_f32")
+                                                   B, xw.shape[1], T, ld, PAD, stream), "ctts_embed_rows_f32")
             h = xw
             for l, op in enumerate(ops['wn'][k]):
                 y = frames[k] if l == len(ops['wn'][k]) - 1 else rows(op.c_out)
-                op(h, y, B, Fr, ld, stream, self.WN_config.get('cond_padding_mode', 'zeros'))
+                op(h, y, B, T, ld, stream, self.WN_config.get('cond_padding_mode', 'zeros'))
                 h = y
-        return frames, ld
+        return frames, ld, T
 
     # --------------------------------------------------------------------- the path ----
     def inverse(self, z, cond, speaker_ids=None, return_CPU=True):
@@ -514,7 +655,7 @@ class WaveGlow(nn.Module):
                                                         _lib.ptr(audio), B, T, mel.shape[2], _lib.ptr(ws),
                                                         ws.numel() * 4, stream), "ctts_waveflow_inverse_f32")
             else:
-                frames, ld = self._cond_frames(ops, mel, speaker_ids, stream)
+                frames, ld, _ = self._cond_frames(ops, mel, speaker_ids, stream)
                 _lib.check(lib.ctts_waveflow_inverse_cond_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(zz), _lib.ptr(frames),
                                                              ld, PAD, _lib.ptr(audio), B, T, mel.shape[2], _lib.ptr(ws),
                                                              ws.numel() * 4, stream), "ctts_waveflow_inverse_cond_f32")
@@ -547,9 +688,9 @@ class WaveGlow(nn.Module):
         audio = torch.empty(B, T, dtype=torch.float32, device=device)
         with torch.cuda.device(device):
             stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-            frames, ld = self._cond_frames(ops, mel, speaker_ids, stream)
+            frames, ld, n_cond = self._cond_frames(ops, mel, speaker_ids, stream, out_steps=T // self.n_group)
             _lib.check(lib.ctts_wgax_inverse_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(zz), _lib.ptr(frames), ld, PAD,
-                                                 mel.shape[2], _lib.ptr(audio), B, T, _lib.ptr(ws), ws.numel() * 4,
+                                                 n_cond, _lib.ptr(audio), B, T, _lib.ptr(ws), ws.numel() * 4,
                                                  stream), "ctts_wgax_inverse_f32")
             if self.preempthasis:
                 _lib.check(lib.ctts_deemphasis_f32(_lib.ptr(audio), _lib.ptr(audio), B, T, float(self.preempthasis),

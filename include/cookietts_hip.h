@@ -255,7 +255,22 @@ int ctts_waveflow_inverse_cond_f32(const ctts_waveflow_config* cfg, const void* 
  *   embed_rows:     x[b][row0 + e][pad .. pad+T) = table[ids[b]][e]          (speaker embedding concat, ax:286-291)
  *   scale_add_rows: y = alpha * x + r   (r may be NULL; alpha read from the device: the rezero parameter, ax:299-307)
  *   deemphasis:     y[n] = x[n] + p * y[n-1] per utterance, fp64 recurrence like scipy.signal.lfilter (ax:351-355);
- *                   in place (y == x) allowed */
+ *                   in place (y == x) allowed
+ *   affine_rows:    x = (x + shift) * scale on rows [0, rows), valid columns only (shift_spect / scale_spect, ax:206-209)
+ *   resample_rows:  F.interpolate along time, padded rows in and out: mode 0 'linear' align_corners=True to T_out
+ *                   (ax:174, glow_ax.py:365), mode 1 'linear' align_corners=False and mode 2 'nearest' with the given
+ *                   scale_factor (TransposedUpsampleNet residual, glow_ax.py:229-231); scale_factor <= 0: T_in / T_out
+ *   interleave_phases: ConvTranspose1d(stride, padding) (glow_ax.py:222) = `stride` stride-1 convolutions over the
+ *                   input positions, one per output residue r = (n + padding) mod stride, each run with
+ *                   ctts_conv1d_f32 into phases[r] ([stride][B][C][ld_in]); this call writes
+ *                   y[n] = phases[(n + padding) % stride][(n + padding) / stride] for n in [0, T_out) */
+int ctts_affine_rows_f32(float* x, int32_t batch, int32_t C, int32_t rows, int32_t T, int32_t ld, int32_t pad, float shift,
+                         float scale, void* stream);
+int ctts_resample_rows_f32(const float* x, float* y, int32_t batch, int32_t C, int32_t T_in, int32_t ld_in, int32_t pad_in,
+                           int32_t T_out, int32_t ld_out, int32_t pad_out, int32_t mode, float scale_factor, void* stream);
+int ctts_interleave_phases_f32(const float* phases, float* y, int32_t batch, int32_t C, int32_t stride, int32_t padding,
+                               int32_t T_in, int32_t ld_in, int32_t pad_in, int32_t T_out, int32_t ld_out, int32_t pad_out,
+                               void* stream);
 int ctts_embed_rows_f32(const float* table, const int64_t* ids, float* x, int32_t row0, int32_t embed_dim,
                         int32_t batch, int32_t C, int32_t T, int32_t ld, int32_t pad, void* stream);
 int ctts_scale_add_rows_f32(const float* x, const float* alpha_dev, const float* r, float* y, int32_t batch,
@@ -273,9 +288,11 @@ int ctts_deemphasis_f32(const float* x, float* y, int32_t batch, int32_t T, doub
  *   early outputs                 efficient_model_ax.py:312-316, 340-341;   ignore_nan  :13-16, 333-334
  *   mix_first ordering            efficient_model_ax.py:324-325, 337-338
  * Built: GTU gate, res_skip=True, merge_res_skip=False, dense in-layers with width dilation 2^i,
- * upsample_first=False; the per-flow WN conditioning stack is evaluated by the caller at FRAME rate (composed from
- * ctts_conv1d_f32 / ctts_embed_rows_f32 / ctts_scale_add_rows_f32 / ctts_replicate_halo_f32) and handed over, like
- * ctts_waveflow_inverse_cond_f32. */
+ * the per-flow WN conditioning stack is evaluated by the caller (composed from ctts_conv1d_f32 / ctts_embed_rows_f32 /
+ * ctts_scale_add_rows_f32 / ctts_replicate_halo_f32) and handed over, like ctts_waveflow_inverse_cond_f32: at FRAME
+ * rate (upsample_first=False; `frames` columns, interpolated to the latent's rate inside the gate epilogue) or already
+ * at the latent's rate (upsample_first=True, efficient_model_ax.py:116-126, 174-186: model-level TransposedUpsampleNet
+ * via ctts_interleave_phases_f32 + ctts_resample_rows_f32; `frames` == samples / n_group, read as it is). */
 #define CTTS_MIX_PERMUTE 0
 #define CTTS_MIX_CONV1X1 1
 typedef struct ctts_wgax_config {

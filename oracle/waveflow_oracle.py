@@ -119,7 +119,62 @@ def model_cond(sd, cfg, mel, speaker_ids=None):
             res = act(res).astype(F32)
     if "alpha" in sd:
         res = res * sd["alpha"][0]
-    return (cond + res if cfg["cond_residual"] else res).astype(F32)
+    if not cfg["cond_residual"]:
+        return res.astype(F32)
+    if "res_conv.weight" in sd:                                   # cond_residual='1x1conv' (ax:80-81, 303-304)
+        cond = (np.matmul(np.asarray(sd["res_conv.weight"], dtype=F32)[:, :, 0], cond) + sd["res_conv.bias"][None, :, None]).astype(F32)
+    return (cond + res).astype(F32)
+
+
+def conv_transpose1d(x, w, b, stride, padding):
+    """nn.ConvTranspose1d: x [B, Cin, T], w [Cin, Cout, k] -> [B, Cout, (T-1)*stride - 2*padding + k]:
+    out[n] = b + sum_{t, kk: t*stride - padding + kk = n} w[:, :, kk]^T x[:, t]."""
+    B, _, T = x.shape
+    k = w.shape[2]
+    full = np.zeros((B, w.shape[1], (T - 1) * stride + k), F32)
+    for kk in range(k):
+        full[:, :, kk:kk + (T - 1) * stride + 1:stride] += np.matmul(np.ascontiguousarray(w[:, :, kk].T), x)
+    out = full[:, :, padding:full.shape[2] - padding] + b[None, :, None]
+    return out.astype(F32)
+
+
+def interp_scale(x, scale, linear):
+    """F.interpolate(x, scale_factor=scale, mode='linear' (align_corners=False) | 'nearest') on the last axis, the
+    arithmetic of ATen's kernels with a given scale factor: src = max((n + 0.5) / scale - 0.5, 0) | floor(n / scale)."""
+    x = np.asarray(x, dtype=F32)
+    n_in = x.shape[-1]
+    n_out = int(np.floor(n_in * scale))
+    n = np.arange(n_out, dtype=F32)
+    inv = F32(1.0) / F32(scale)
+    if not linear:
+        return x[..., np.minimum(np.floor(n * inv).astype(np.int64), n_in - 1)].astype(F32)
+    real = np.maximum(inv * (n + F32(0.5)) - F32(0.5), F32(0)).astype(F32)
+    i0 = real.astype(np.int64)
+    i1 = np.minimum(i0 + 1, n_in - 1)
+    l1 = (real - i0.astype(F32)).astype(F32)
+    return ((F32(1.0) - l1) * x[..., i0] + l1 * x[..., i1]).astype(F32)
+
+
+def transposed_upsample_net(sd, prefix, x, scales, kernel_size, last_act, residual, residual_linear):
+    """glow_ax.py:201-242 (TransposedUpsampleNet.forward): ConvTranspose1d(stride = scale, padding = (k - scale) // 2)
+    + LeakyReLU(0.4) per scale; with `residual`, rezero weight on the result and the interpolated input added to the
+    first min(in, out) channels."""
+    x = np.asarray(x, dtype=F32)
+    xi = interp_scale(x, int(np.prod(scales)), residual_linear) if residual else None
+    idx = 0
+    for i, sc in enumerate(scales):
+        k = kernel_size[i] if isinstance(kernel_size, (list, tuple)) else kernel_size
+        x = conv_transpose1d(x, np.asarray(sd[f"{prefix}.t_convs.{idx}.weight"], dtype=F32), sd[f"{prefix}.t_convs.{idx}.bias"],
+                             sc, (k - sc) // 2)
+        if i + 1 < len(scales) or last_act:
+            x = np.where(x >= 0, x, x * F32(0.4)).astype(F32)
+        idx += 2
+    if residual:
+        if f"{prefix}.res_weight" in sd:
+            x = (x * sd[f"{prefix}.res_weight"][0]).astype(F32)
+        r = min(xi.shape[1], x.shape[1])
+        x[:, :r] = x[:, :r] + xi[:, :r]
+    return x.astype(F32)
 
 
 def deemphasis(x, p):

@@ -8,6 +8,8 @@ Reference lines followed (relative to /root/reference/CookieTTS/_4_mtw/waveglow/
                        :340-341), per flow: [un-mix if not mix_first :324-325] coupling :328, NaN -> 0 :333-334,
                        [un-mix if mix_first :337-338]; un-squeeze :346; de-emphasis :351-355
   coupling             efficient_modules.py:94-105: (log_s, t) = WN(a0); a1 = (a1 - t) / exp(log_s)
+  model-level upsampling  efficient_model_ax.py:116-126, 174-186, 318-319 (upsample_first=True): TransposedUpsampleNet
+                       glow_ax.py:201-242 then F.interpolate(size = latent length, 'linear', align_corners=True)
   wn1d                 glow_ax.py:375-418: start :376; WN speaker embedding :378-381; cond stack with activation
                        rule :383-387; linear interpolation to the audio length when upsample_first is False :389-390
                        (= _upsample_mels :362-373, align_corners=True); dilated in_layers (kernel_size_w or
@@ -23,7 +25,7 @@ from __future__ import annotations
 import numpy as np
 
 from .waveflow_oracle import (F32, _shift, _w, activation, conv1d_same, deemphasis, lerp_align_corners, model_cond,
-                              permutation)
+                              permutation, transposed_upsample_net)
 
 
 def flow_channels(cfg):
@@ -97,6 +99,14 @@ def waveglow_ax_inverse(sd, cfg, z, mel, speaker_ids=None, flow_trace=None):
     zz = a[:, n_early * esize:]
     assert zz.shape[1] == chans[-1]
     frames = model_cond(sd, cfg, mel, speaker_ids)
+    if cfg.get("upsample_first") is True:
+        # efficient_model_ax.py:318-319 -> _upsample_mels :174-186: TransposedUpsampleNet, then (its length differs
+        # from the latent's) linear interpolation with align_corners=True; the WNs then take it as it is
+        frames = transposed_upsample_net(sd, "upsample_net", frames, cfg["transposed_conv_scales"],
+                                         cfg["transposed_conv_kernel_size"], True, cfg.get("transposed_conv_residual", False),
+                                         cfg.get("transposed_conv_residual_linear", False))
+        assert frames.shape[2] != L, "the reference crops to an empty tensor when no interpolation is required"
+        frames = lerp_align_corners(frames, L)
 
     def unmix(k, v):
         if mix == 'permuteheight':

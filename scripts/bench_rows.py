@@ -148,6 +148,29 @@ def row_stft(args):
             "achieved_tflops_algorithmic": flop / dt / 1e12}
 
 
+def row_waveglow_ax_untts(args):
+    """The vocoder config printed by the reference's _2_ttm/untts/inference.ipynb: ax core, waveflow=False, 24 flows x
+    8 x 384, n_group 24, 256-channel mel, conditioning upsampled at model level by a TransposedUpsampleNet (2*3*5) and
+    handed to the WNs at sample rate.  Same 5.8375 s clip as the notebook row (468 frames, hop 600, 48 kHz)."""
+    from cookietts_amd.waveglow_ax import WaveGlow
+    cfg = synthetic.WAVEGLOW_AX_CONFIGS["untts"]
+    m = WaveGlow(**cfg)
+    m.load_state_dict(synthetic.to_torch(synthetic.waveglow_ax_state_dict(cfg, seed=1234)))
+    m = m.cuda().eval()
+    rows = []
+    for B in (1, 4):
+        F = 468
+        mel = torch.from_numpy(synthetic.synthetic_mel(B, F, cfg["n_mel_channels"])).cuda()
+        ids = torch.zeros(B, dtype=torch.int64).cuda()
+        dt = timed(lambda: m.infer(mel, speaker_ids=ids, sigma=1.0, return_CPU=False), args.warmup, args.steps)
+        samples = B * (F - 1) * cfg["hop_length"]
+        rows.append({"row": "W5/untts", "metric": "real-time factor (48 kHz), ax WaveGlow waveflow=False, 24 flows x 8 x 384, "
+                                                  "upsample_first + TransposedUpsampleNet, 256x468 mel (5.84 s clip)",
+                     "value": samples / dt / 48000.0, "unit": "x real time (48 kHz)", "batch": B, "ms_per_call": dt * 1e3,
+                     "samples_per_s": samples / dt, "dtype": "f32"})
+    return rows
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", default="waveflow,tacotron,stft")
@@ -155,7 +178,7 @@ if __name__ == "__main__":
     ap.add_argument("--warmup", type=int, default=1)
     args = ap.parse_args()
     fns = {"waveflow": row_waveflow, "waveflow_author": row_waveflow_author, "tacotron": row_tacotron, "stft": row_stft,
-           "waveglow_ax": row_waveglow_ax_notebook}
+           "waveglow_ax": row_waveglow_ax_notebook, "waveglow_ax_untts": row_waveglow_ax_untts}
     for r in args.rows.split(","):
         out = fns[r](args)
         from cookietts_amd import _lib

@@ -232,7 +232,9 @@ def make_waveflow(full_length=False):
     torch.set_num_threads(8)
     cases = [("toy", "toy", 2, 6, 0.7, 5), ("toy_odd", "toy", 1, 11, 1.0, 6), ("full_short", "full", 1, 5, 0.6, 1234),
              # SURVEY 8f.4 option set: speaker ids, cond stacks, separable in-layers, logvar channels, de-emphasis
-             ("author_toy", "author_toy", 2, 6, 0.7, 3), ("author_short", "author", 1, 3, 0.6, 4)]
+             ("author_toy", "author_toy", 2, 6, 0.7, 3), ("author_short", "author", 1, 3, 0.6, 4),
+             # the UnTTS notebook's WaveFlow: shift_spect / scale_spect on entry
+             ("untts_toy", "untts_toy", 2, 7, 0.8, 8)]
     only = [a for a in sys.argv[2:]]
     if full_length:
         # BASELINE config 4 at the metric's utterance length: one 80x900 mel (~10 s of CPU here)
@@ -270,7 +272,7 @@ def make_waveflow(full_length=False):
         print(f"[golden] waveflow {name}: audio {audio.shape} rms={audio.std():.4f} -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
-def make_waveglow_ax(full_length=False):
+def make_waveglow_ax(full_length=False, untts=False):
     """efficient_model_ax.WaveGlow with waveflow=False (AffineCouplingBlock + 1-D WN; InvertibleConv1x1 / PermuteHeight
     mixing in both orders; early outputs; the timed notebook config's option set)."""
     import copy
@@ -280,6 +282,10 @@ def make_waveglow_ax(full_length=False):
     if full_length:
         # the notebook config at full width (48 flows x 8 x 256, n_group 24, 160 mel channels), short mel
         cases = [("notebook", 1, 5, 0.9, 26)]
+    if untts:
+        # the untts notebook's vocoder config (model-level TransposedUpsampleNet, 1x1-conv cond residual, spect shift /
+        # scale in the toy), toy and full width (24 flows x 8 x 384, 256 mel channels) on a short mel
+        cases = [("untts_toy", 2, 6, 0.8, 27), ("untts", 1, 4, 0.9, 28)]
     for key, B, F, sigma, seed in cases:
         cfg = synthetic.WAVEGLOW_AX_CONFIGS[key]
         sd = synthetic.waveglow_ax_state_dict(cfg, seed=seed)
@@ -460,6 +466,8 @@ if __name__ == "__main__":
         make_waveglow_ax()
     if "waveglow_ax_notebook" in which:    # on request only: 272 M parameters
         make_waveglow_ax(full_length=True)
+    if "waveglow_ax_untts" in which:       # on request only
+        make_waveglow_ax(untts=True)
     if "waveglow_full_len" in which:       # on request only: minutes of CPU
         make_waveglow(full_length=True)
     if "waveflow_full_len" in which:

@@ -19,7 +19,8 @@ def _load(name):
     return g, cfg, synthetic.waveflow_state_dict(cfg, seed=int(g["seed"]))
 
 
-ALL = ["toy", "toy_odd", "full_short", "author_toy", "author_short"]     # author_*: SURVEY 8f.4 option set
+ALL = ["toy", "toy_odd", "full_short", "author_toy", "author_short", "untts_toy"]   # author_*: SURVEY 8f.4 option set;
+# untts_toy: the same family with shift_spect / scale_spect (scripts/"UnTTS Inference.ipynb")
 
 
 def _ids(g):

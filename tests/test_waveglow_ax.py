@@ -13,7 +13,7 @@ from oracle import waveglow_ax_oracle as ao
 
 WAVE_TOL = 1e-3           # BASELINE.json: waveform RMS relative error
 ORACLE_TOL = 5e-6
-SMALL = ["toy_conv", "toy_conv_mixlast", "toy_permute", "toy_permute_mixfirst", "notebook_toy"]
+SMALL = ["toy_conv", "toy_conv_mixlast", "toy_permute", "toy_permute_mixfirst", "notebook_toy", "untts_toy"]
 
 
 def _load(key):
@@ -59,7 +59,7 @@ def test_host_state_dict_keys_match_reference_format():
     recipe IS equality with the reference's own state_dict keys and shapes."""
     from cookietts_amd.waveglow_ax import WaveGlow
     for key, cfg in synthetic.WAVEGLOW_AX_CONFIGS.items():
-        if key == "notebook":
+        if key in ("notebook", "untts"):
             continue
         sd = synthetic.waveglow_ax_state_dict(cfg, seed=1)
         own = WaveGlow(**cfg).state_dict()
@@ -69,7 +69,12 @@ def test_host_state_dict_keys_match_reference_format():
     assert m.z_split_sizes == [2, 2, 8] and m.channel_mixing == 'permuteheight' and m.mix_first is False
     assert float(m.WN[0].WN.end.weight.abs().max()) == 0.0                  # zero-init end (glow_ax.py:278-281)
     with pytest.raises(NotImplementedError):
-        WaveGlow(**dict(synthetic.WAVEGLOW_AX_CONFIGS["toy_conv"], upsample_first=True))
+        WaveGlow(**dict(synthetic.WAVEGLOW_AX_CONFIGS["toy_conv"], upsample_first=True))       # no TransposedUpsampleNet
+    with pytest.raises(NotImplementedError):                                                    # 2*3 == 48 // 8: the
+        WaveGlow(**dict(synthetic.WAVEGLOW_AX_CONFIGS["untts_toy"], hop_length=48))             # reference crops to nothing
+    u = WaveGlow(**synthetic.WAVEGLOW_AX_CONFIGS["untts_toy"])
+    assert [type(t).__name__ for t in u.upsample_net.t_convs] == ["ConvTranspose1d", "LeakyReLU"] * 2
+    assert tuple(u.res_conv.weight.shape) == (48, 24, 1) and u.upsample_net.res_weight is not None
     with pytest.raises(NotImplementedError):
         WaveGlow(**dict(synthetic.WAVEFLOW_CONFIGS["toy"], channel_mixing='1x1conv'))    # waveflow=True + 1x1conv
     with pytest.raises(AssertionError):
@@ -122,6 +127,43 @@ def test_hip_matches_reference_golden(hip_lib_path, key):
     assert err < WAVE_TOL
     if key.endswith("conv"):
         assert m.convinv[0].W_inverse.shape == (cfg["n_group"], cfg["n_group"], 1)     # cached like em:271-276
+
+
+def test_oracle_transposed_upsampling_pieces():
+    """conv_transpose1d / interp_scale against torch's own operators (the reference calls exactly these)."""
+    import torch.nn.functional as F
+    from oracle.waveflow_oracle import conv_transpose1d, interp_scale
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 5, 7)).astype(np.float32)
+    for k, s in ((4, 2), (9, 3), (5, 5), (3, 1)):
+        w = rng.standard_normal((5, 6, k)).astype(np.float32)
+        b = rng.standard_normal(6).astype(np.float32)
+        ref = F.conv_transpose1d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), stride=s, padding=(k - s) // 2)
+        got = conv_transpose1d(x, w, b, s, (k - s) // 2)
+        assert got.shape == tuple(ref.shape) == (2, 6, 7 * s) and np.abs(got - ref.numpy()).max() < 1e-5
+    for scale in (6, 30):
+        for linear in (True, False):
+            ref = F.interpolate(torch.from_numpy(x), scale_factor=scale, mode='linear' if linear else 'nearest',
+                                **({"align_corners": False} if linear else {}))
+            assert np.abs(interp_scale(x, scale, linear) - ref.numpy()).max() < 1e-6
+
+
+def test_oracle_untts_width_matches_reference():
+    """24 flows x 8 x 384, 256 mel channels, model-level transposed-conv upsampling: the untts notebook's vocoder."""
+    g, cfg, sd = _load("untts")
+    melp = np.pad(g["mel"], ((0, 0), (0, 0), (0, 1)))
+    assert rms_rel_err(ao.waveglow_ax_inverse(sd, cfg, g["z"], melp, _ids(g)), g["inverse_full"]) < ORACLE_TOL
+
+
+@pytest.mark.gpu
+def test_hip_untts_width_matches_reference_golden(hip_lib_path):
+    g, cfg, _ = _load("untts")
+    m, _, _ = _model("untts", int(g["seed"]))
+    melp = torch.from_numpy(np.pad(g["mel"], ((0, 0), (0, 0), (0, 1)))).cuda()
+    audio, _ = m.inverse(torch.from_numpy(g["z"]).cuda(), melp, speaker_ids=torch.from_numpy(g["speaker_ids"]).cuda())
+    err = rms_rel_err(audio.numpy(), g["inverse_full"])
+    print(f"waveglow_ax untts: rms rel err vs reference = {err:.3e}")
+    assert err < WAVE_TOL
 
 
 @pytest.mark.gpu
