@@ -13,6 +13,6 @@ python bench.py --gpus 1 --steps 5 --warmup 2 --dtype bf16x3 --cpu-frames 0 > gp
 cut -c1-600 gpurun_out/r2_full_bench_f32.json; echo; cut -c1-300 gpurun_out/r2_full_bench_bf16_b32.json; echo; cut -c1-300 gpurun_out/r2_full_bench_bf16x3.json; echo
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2_full_prof -o f32 -- python3 bench.py --steps 2 --warmup 1 --cpu-frames 0 > gpurun_out/r2_full_prof.log 2>&1
 ls gpurun_out/r2_full_prof | head
-timeout 900 python scripts/bench_rows.py --rows waveflow,waveflow_author,waveglow_ax,tacotron,stft --steps 3 --warmup 1 2>gpurun_out/r2_full_rows.err > gpurun_out/r2_full_rows.jsonl
+timeout 900 python scripts/bench_rows.py --rows waveflow,waveflow_author,waveglow_ax,waveglow_ax_untts,tacotron,stft --steps 3 --warmup 1 2>gpurun_out/r2_full_rows.err > gpurun_out/r2_full_rows.jsonl
 cut -c1-260 gpurun_out/r2_full_rows.jsonl
 timeout 300 python scripts/profile_persistent.py > gpurun_out/r2_full_persistent_timeline.txt 2>&1; tail -8 gpurun_out/r2_full_persistent_timeline.txt
