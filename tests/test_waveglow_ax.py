@@ -102,6 +102,13 @@ def test_c_abi_size_queries_and_argument_validation(hip_lib_path):
     c3.n_flows = 47                                                                     # PermuteHeight: even n_flows
     assert lib.ctts_wgax_packed_bytes(C.byref(c3)) == 0
     assert lib.ctts_replicate_halo_f32(None, 1, 1, 4, 32, 8, 1, None) != 0
+    # the row operators of the model-level upsampling path validate before they launch (no GPU needed for the refusals)
+    assert lib.ctts_affine_rows_f32(None, 1, 16, 16, 8, 64, 8, 1.0, 1.0, None) != 0
+    assert lib.ctts_resample_rows_f32(None, None, 1, 16, 8, 64, 8, 40, 128, 8, 0, 0.0, None) != 0
+    assert lib.ctts_interleave_phases_f32(None, None, 1, 16, 2, 1, 8, 64, 8, 16, 64, 8, None) != 0
+    assert b"interleave_phases" in lib.ctts_last_error()
+    assert lib.ctts_set_f32_gemm_mode(3) != 0 and b"unknown mode" in lib.ctts_last_error()
+    assert lib.ctts_get_f32_gemm_mode() == 0                              # default: fp32 MFMA products
 
 
 def _model(key, seed):
