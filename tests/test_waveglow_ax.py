@@ -187,6 +187,26 @@ def test_hip_notebook_width_matches_reference_golden(hip_lib_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,Fr", [(3, 5), (1, 1), (2, 37)])
+def test_hip_untts_upsampling_ragged_lengths_vs_oracle(hip_lib_path, B, Fr):
+    """Model-level transposed-conv upsampling at lengths the goldens do not have (a single frame; 37 frames = 1480
+    latent columns, ragged against every tile width), different speakers per utterance, batch independence."""
+    m, cfg, sd = _model("untts_toy", 11)
+    mel = synthetic.synthetic_mel(B, Fr, cfg["n_mel_channels"], seed=Fr)
+    melp = np.pad(mel, ((0, 0), (0, 0), (0, 1)))
+    ids = np.array([5, 400, 77][:B], np.int64)
+    z = np.random.default_rng(Fr).standard_normal((B, Fr * cfg["hop_length"])).astype(np.float32) * np.float32(0.7)
+    ref = ao.waveglow_ax_inverse(sd, cfg, z, melp, ids)
+    tz, tm, ti = torch.from_numpy(z).cuda(), torch.from_numpy(melp).cuda(), torch.from_numpy(ids).cuda()
+    got, _ = m.inverse(tz, tm, speaker_ids=ti, return_CPU=False)
+    err = rms_rel_err(got.cpu().numpy(), ref)
+    print(f"untts_toy B={B} F={Fr}: rms rel err vs oracle = {err:.3e}")
+    assert err < WAVE_TOL
+    one, _ = m.inverse(tz[-1:], tm[-1:], speaker_ids=ti[-1:], return_CPU=False)
+    assert torch.equal(one[0], got[-1])
+
+
+@pytest.mark.gpu
 def test_hip_infer_contract_ragged_nan_and_batch_independence(hip_lib_path):
     m, cfg, sd = _model("toy_conv_mixlast", 9)
     B, Fr = 3, 23                                              # L = 22*240/12 = 440: ragged vs the 128-step tile
