@@ -49,7 +49,7 @@ class WaveFlowConfig(C.Structure):
     """``ctts_waveflow_config``."""
     _fields_ = [(n, C.c_int32) for n in ("n_mel_channels", "n_flows", "n_group", "n_layers", "n_channels",
                                          "kernel_size_w", "kernel_size_h", "dilation_h", "seperable_conv",
-                                         "cond_precomputed")]
+                                         "cond_precomputed", "gated_unit", "merge_res_skip")]
 
 
 class WaveFlowFlowWeights(C.Structure):
@@ -61,7 +61,13 @@ class WaveFlowFlowWeights(C.Structure):
 class WgaxConfig(C.Structure):
     """``ctts_wgax_config`` (ax core, waveflow=False)."""
     _fields_ = [(n, C.c_int32) for n in ("n_flows", "n_group", "n_early_every", "n_early_size", "n_layers",
-                                         "n_channels", "kernel_size", "mixing", "mix_first", "ignore_nan")]
+                                         "n_channels", "kernel_size", "mixing", "mix_first", "ignore_nan", "gated_unit",
+                                         "merge_res_skip")]
+
+
+# WN_config['gated_unit'] -> CTTS_GATE_* (get_gate_func, glow_ax.py:168-198; the reference upper-cases the name)
+GATED_UNITS = {n: i for i, n in enumerate(("GTU", "GTRU", "GTLRU", "GLU", "TTU", "STU", "GTSU", "SPTU", "GSIU", "GSIRU",
+                                           "GTSRU", "GSIRRU", "GSIRLRU", "GSIRRLRU"))}
 
 
 class WgaxFlowWeights(C.Structure):
@@ -258,7 +264,7 @@ def lib():
                 raise HipLibraryError(f"{path} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
-        if handle.ctts_abi_version() != 2:
+        if handle.ctts_abi_version() != 3:
             raise HipLibraryError(f"ABI version mismatch: library reports {handle.ctts_abi_version()}")
         env_mode = os.environ.get("CTTS_F32_GEMM_MODE")          # "f32" (default) or "bf16x3": see set_f32_gemm_mode
         if env_mode:

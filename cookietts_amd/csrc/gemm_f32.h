@@ -35,6 +35,8 @@ enum GemmEpilogue : int {
     // dst0[row] = leaky_relu(acc + bias, clip as slope) / tanh(acc + bias)    (Tacotron encoder / postnet convs)
     GEMM_EPI_LRELU = 4,
     GEMM_EPI_TANH = 5,
+    // GATE with the unit chosen at run time (GemmArgs.gate != GATE_GTU): dst0[c] = gate_eval(gate, u_first, u_second)
+    GEMM_EPI_GATEX = 7,
     // GATE followed, in the same workgroup, by the res/skip 1x1 GEMM on the gated tile held in registers
     // (bm = 128 shape with all pairC <= 64 channels in one wave-row): the activations never touch HBM.
     //   rows < split of  rs_w . act + rs_b  -> dst0 = src0 + .   (next layer's input)
@@ -43,8 +45,52 @@ enum GemmEpilogue : int {
 };
 
 __host__ __device__ inline bool gemm_epi_is_pair(int epi) {
-    return epi == GEMM_EPI_GATE || epi == GEMM_EPI_MAG || epi == GEMM_EPI_GATE_RS;
+    return epi == GEMM_EPI_GATE || epi == GEMM_EPI_MAG || epi == GEMM_EPI_GATE_RS || epi == GEMM_EPI_GATEX;
 }
+
+// The gated units of glow_ax.py:36-165 (get_gate_func :168-198): acts = f(in[:C]) * g(in[C:]).  Kind 0 (GTU) is
+// the hot path with its own epilogue; the others go through GEMM_EPI_GATEX.
+enum GateKind : int {
+    GATE_GTU = 0,      // tanh * sigmoid
+    GATE_GTRU = 1,     // tanh * relu
+    GATE_GTLRU = 2,    // tanh * leaky_relu(0.01)
+    GATE_GLU = 3,      // x * sigmoid
+    GATE_TTU = 4,      // tanh * tanh
+    GATE_STU = 5,      // tanh * selu
+    GATE_GTSU = 6,     // tanhshrink * sigmoid
+    GATE_SPTU = 7,     // tanh * softplus
+    GATE_GSIU = 8,     // sin * sigmoid
+    GATE_GSIRU = 9,    // sin(16 x) * sigmoid
+    GATE_GTSRU = 10,   // tanhshrink * relu
+    GATE_GSIRRU = 11,  // sin(16 x) * relu
+    GATE_GSIRLRU = 12, // sin(16 x) * leaky_relu(0.01)
+    GATE_GSIRRLRU = 13,// sin(16 x) * rrelu(0.01, 0.1) in eval mode = leaky_relu((0.01 + 0.1) / 2)
+    GATE_KINDS = 14
+};
+
+#if defined(__HIPCC__)
+// compile-time unit; callers switch on the run-time kind OUTSIDE their element loops
+template <int KIND>
+__device__ __forceinline__ float gate_eval(float u0, float u1) {
+    float f, g;
+    if constexpr (KIND == GATE_GLU) f = u0;
+    else if constexpr (KIND == GATE_GTSU || KIND == GATE_GTSRU) f = u0 - tanhf(u0);
+    // __sinf: v_sin_f32 on x / 2pi (abs error ~1e-6 for the |arguments| < ~1e2 a WN layer produces); libm's sinf
+    // drags a Payne-Hanek table into scratch
+    else if constexpr (KIND == GATE_GSIU) f = __sinf(u0);
+    else if constexpr (KIND == GATE_GSIRU || KIND == GATE_GSIRRU || KIND == GATE_GSIRLRU || KIND == GATE_GSIRRLRU) f = __sinf(16.0f * u0);
+    else f = tanhf(u0);
+    if constexpr (KIND == GATE_GTRU || KIND == GATE_GTSRU || KIND == GATE_GSIRRU) g = fmaxf(u1, 0.0f);
+    else if constexpr (KIND == GATE_GTLRU || KIND == GATE_GSIRLRU) g = u1 > 0.0f ? u1 : 0.01f * u1;
+    else if constexpr (KIND == GATE_GSIRRLRU) g = u1 >= 0.0f ? u1 : ((0.01f + 0.1f) / 2.0f) * u1;
+    else if constexpr (KIND == GATE_TTU) g = tanhf(u1);
+    else if constexpr (KIND == GATE_STU)
+        g = 1.0507009873554804934193349852946f * (fmaxf(u1, 0.0f) + fminf(0.0f, 1.6732632423543772848170429916717f * expm1f(u1)));
+    else if constexpr (KIND == GATE_SPTU) g = u1 > 20.0f ? u1 : log1pf(expf(u1));
+    else g = 1.0f / (1.0f + expf(-u1));
+    return f * g;
+}
+#endif
 
 struct GemmSeg {
     const float* base;    // [B][rows][ld] padded layout
@@ -85,6 +131,7 @@ struct GemmArgs {
     // arithmetic of ATen's upsample_linear1d (glow_ax.py:362-373) - the sample-rate tensor is never materialised
     int addend_frames;
     int map_mode;         // block id -> (m-block, tile, batch) mapping, chosen by the launcher (see gemm_f32.hip)
+    int gate;             // GateKind of a GATE launch (0 = GTU); != 0 is routed to GEMM_EPI_GATEX by the launcher
     int exact_f32;        // 1 = always the fp32 MFMA main loop, whatever set_gemm_f32_mode says (STFT: its sums cancel,
                           // so the split-bf16 loop's 2^-17 operand error exceeds the 1e-4 log-mel bound)
     const float* rs_wT;   // GEMM_EPI_GATE_RS: res/skip weight transposed and row-padded: [64][128]

@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
     if (t < BM) lds[t] = a.bias[mb * BM + t];
     __syncthreads();
     const float* bias = lds + wm * 128;
-    if constexpr (EPI == GEMM_EPI_GATE || EPI == GEMM_EPI_MAG) {
+    if constexpr (EPI == GEMM_EPI_GATE || EPI == GEMM_EPI_MAG || EPI == GEMM_EPI_GATEX) {
         float* dst = a.dst0 + (size_t)b * a.dst0_bstride;
         const int cbase = (mb * WM + wm) * 64;
 #pragma unroll
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
                 const int n = n0 + wn * 64 + nt * 32 + l31;
                 if (n < a.L) {
                     float add0[16], add1[16];
-                    if (EPI == GEMM_EPI_GATE && a.addend && a.addend_frames > 0) {   // uniform: interpolated addend
+                    if ((EPI == GEMM_EPI_GATE || EPI == GEMM_EPI_GATEX) && a.addend && a.addend_frames > 0) {   // uniform: interpolated addend
                         const int F = a.addend_frames;
                         const float scale = a.L > 1 ? (float)(F - 1) / (float)(a.L - 1) : 0.f;
                         const float real = scale * (float)n;
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
                                 add1[hf * 8 + q] = l0 * s10[q] + l1 * s11[q];
                             }
                         }
-                    } else if (EPI == GEMM_EPI_GATE && a.addend) {                   // uniform
+                    } else if ((EPI == GEMM_EPI_GATE || EPI == GEMM_EPI_GATEX) && a.addend) {   // uniform
                         const float* ad = a.addend + (size_t)b * a.addend_bstride + a.addend_pad + n;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
@@ -534,16 +534,39 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) add0[r] = add1[r] = 0.0f;
                     }
+                    if constexpr (EPI == GEMM_EPI_GATEX) {
+                        // one textual copy of the element loop per unit (a lambda capturing the accumulators by
+                        // reference, or a run-time switch inside the loop, sends the accumulator arrays to scratch)
+#define CTTS_GATEX_LOOP(K)                                                                                        \
+                        case K:                                                                                   \
+                            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                      \
+                                const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;                                 \
+                                const int c = cbase + mt * 32 + row;                                              \
+                                const float u0 = acc[mt][nt][r] + bias[mt * 32 + row] + add0[r];                  \
+                                const float u1 = acc[mt + 2][nt][r] + bias[64 + mt * 32 + row] + add1[r];         \
+                                if (c < a.pairC) dst[(size_t)c * a.dst_ld + a.dst_pad + n] = gate_eval<K>(u0, u1); \
+                            }                                                                                     \
+                            break;
+                        switch (a.gate) {
+                            CTTS_GATEX_LOOP(1) CTTS_GATEX_LOOP(2) CTTS_GATEX_LOOP(3) CTTS_GATEX_LOOP(4) CTTS_GATEX_LOOP(5)
+                            CTTS_GATEX_LOOP(6) CTTS_GATEX_LOOP(7) CTTS_GATEX_LOOP(8) CTTS_GATEX_LOOP(9) CTTS_GATEX_LOOP(10)
+                            CTTS_GATEX_LOOP(11) CTTS_GATEX_LOOP(12) CTTS_GATEX_LOOP(13)
+                            default:
+                            CTTS_GATEX_LOOP(0)
+                        }
+#undef CTTS_GATEX_LOOP
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                        const int c = cbase + mt * 32 + row;
-                        const float u0 = acc[mt][nt][r] + bias[mt * 32 + row] + add0[r];
-                        const float u1 = acc[mt + 2][nt][r] + bias[64 + mt * 32 + row] + add1[r];
-                        float v;
-                        if constexpr (EPI == GEMM_EPI_GATE) v = fast_tanh(u0) * fast_sigmoid(u1);
-                        else v = sqrtf(u0 * u0 + u1 * u1);
-                        if (c < a.pairC) dst[(size_t)c * a.dst_ld + a.dst_pad + n] = v;
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                            const int c = cbase + mt * 32 + row;
+                            const float u0 = acc[mt][nt][r] + bias[mt * 32 + row] + add0[r];
+                            const float u1 = acc[mt + 2][nt][r] + bias[64 + mt * 32 + row] + add1[r];
+                            float v;
+                            if constexpr (EPI == GEMM_EPI_GATE) v = fast_tanh(u0) * fast_sigmoid(u1);
+                            else v = sqrtf(u0 * u0 + u1 * u1);
+                            if (c < a.pairC) dst[(size_t)c * a.dst_ld + a.dst_pad + n] = v;
+                        }
                     }
                 }
             }
@@ -677,7 +700,7 @@ int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
                    "gemm: M=%d pairC=%d MB=%d bm=%d", a.M, a.pairC, a.MB, a.bm);
     CTTS_CHECK_ARG(a.dst_ld > 0 && a.dst0, "gemm: destination not set");
     if (a.addend_ld == 0) { a.addend_ld = a.ld; a.addend_pad = a.pad; }
-    CTTS_CHECK_ARG(a.addend_frames == 0 || (epi == GEMM_EPI_GATE && a.addend && a.addend_frames <= a.addend_ld - a.addend_pad),
+    CTTS_CHECK_ARG(a.addend_frames == 0 || ((epi == GEMM_EPI_GATE || epi == GEMM_EPI_GATEX) && a.addend && a.addend_frames <= a.addend_ld - a.addend_pad),
                    "gemm: interpolated addend needs the GATE epilogue (frames=%d)", a.addend_frames);
     long long blocks = (long long)a.MB * a.ntiles * a.batch;
     a.map_mode = 0;
@@ -688,7 +711,11 @@ int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
     }
     CTTS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "gemm: grid %lld", blocks);
     dim3 grid((unsigned)blocks);
+    CTTS_CHECK_ARG(a.gate >= 0 && a.gate < GATE_KINDS && (a.gate == 0 || epi == GEMM_EPI_GATE), "gemm: gate=%d with epilogue %d",
+                   a.gate, epi);
+    if (epi == GEMM_EPI_GATE && a.gate != GATE_GTU) epi = GEMM_EPI_GATEX;
     switch (epi) {
+        case GEMM_EPI_GATEX: launch_shape<GEMM_EPI_GATEX>(a.bm, grid, stream, a); break;
         case GEMM_EPI_GATE: launch_shape<GEMM_EPI_GATE>(a.bm, grid, stream, a); break;
         case GEMM_EPI_GATE_RS:
             CTTS_CHECK_ARG(a.bm == 128 && a.pairC <= 64 && a.MB == 1 && a.rs_wT && a.rs_bias && (a.rs_rows == 64 || a.rs_rows == 128),

@@ -36,11 +36,11 @@ struct WfPlan {
     };
     std::vector<Flow> fl;
     size_t total;
-    int rs_rows(int i) const { return i < c.n_layers - 1 ? 2 * C : C; }
+    int rs_rows(int i) const { return (i < c.n_layers - 1 && !c.merge_res_skip) ? 2 * C : C; }
     int rs_mb(int i) const { return (rs_rows(i) + WF_BM - 1) / WF_BM; }
     int in_mb() const { return (C + 63) / 64; }
     // one 128-row block holds every gate pair: the res/skip GEMM runs inside the in-layer kernel (GEMM_EPI_GATE_RS)
-    bool fused() const { return C == 64; }
+    bool fused() const { return C == 64 && c.gated_unit == 0; }
     // both 1x1 stages of a separable layer in one launch (waveflow_sep.hip): pointwise/gate + res/skip, C = 128
     bool sep_fused() const {
         return sep && precond && wf_sep_supported(C);
@@ -57,6 +57,8 @@ int make_wf_plan(const ctts_waveflow_config* cfg, WfPlan& p) {
     CTTS_CHECK_ARG(c.kernel_size_w % 2 == 1 && c.kernel_size_w >= 1 && c.kernel_size_h >= 1, "kernel %dx%d",
                    c.kernel_size_h, c.kernel_size_w);
     CTTS_CHECK_ARG(c.dilation_h == 1, "dilation_h=%d (only 1 built)", c.dilation_h);
+    CTTS_CHECK_ARG(c.gated_unit >= 0 && c.gated_unit < GATE_KINDS && (c.merge_res_skip == 0 || c.merge_res_skip == 1),
+                   "gated_unit=%d merge_res_skip=%d", c.gated_unit, c.merge_res_skip);
     p.sep = c.seperable_conv != 0 && !(c.kernel_size_h == 1 && c.kernel_size_w == 1);   // glow_ax.py:521
     p.precond = c.cond_precomputed != 0;
     p.taps = p.sep ? 1 : c.kernel_size_h * c.kernel_size_w;
@@ -532,7 +534,12 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
             const int a_min = (kh - 1 - r) > 0 ? (kh - 1 - r) : 0;   // earlier rows do not exist: skip those taps
             for (int i = 0; i < p.c.n_layers; ++i) {
                 const int dw = 1 << i;
+                // merge_res_skip (glow_ax.py:612-626): no residual into `audio`, so every layer's queue holds the
+                // `start` outputs - layer i reads the ring of layer 0 and nothing is written to ring i+1
+                const bool merge = p.c.merge_res_skip != 0;
+                const int si = merge ? 0 : i;
                 GemmArgs a{};
+                a.gate = p.c.gated_unit;
                 a.bm = WF_BM;
                 a.ld = g.ld; a.pad = g.pad; a.L = L; a.ntiles = g.ntiles; a.batch = batch;
                 a.dst_ld = g.ld; a.dst_pad = g.pad;
@@ -542,7 +549,7 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
                 int ns = 0;
                 if (p.sep) {
                     WfSlots xs{};
-                    for (int ah = a_min; ah < kh; ++ah) xs.p[ah] = X(i, (r - (kh - 1 - ah)) % kh);
+                    for (int ah = a_min; ah < kh; ++ah) xs.p[ah] = X(si, (r - (kh - 1 - ah)) % kh);
                     const dim3 vgrid(((L + 3) / 4 + 255) / 256, C, batch);
                     const bool vec = g.pad % 4 == 0 && g.ld % 4 == 0 && (dw <= 2 || dw % 4 == 0);
                     if (vec && kw == 7) launch_depthwise_vec<7>(vgrid, s, xs, blob + f.dw_w[i], blob + f.dw_b[i], w.dwout, C, kh, dw, a_min, L, g.ld, g.pad);
@@ -557,8 +564,9 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
                         q.dwout = w.dwout;
                         q.A1 = blob + f.sA1[i]; q.b1 = blob + f.sb1[i]; q.A2 = blob + f.sA2[i]; q.b2 = blob + f.sb2[i];
                         q.cond = w.cond_up + (size_t)i * w.cond_slot;
-                        q.xin = X(i, slot);
-                        q.xout = i == p.c.n_layers - 1 ? nullptr : X(i + 1, slot);
+                        q.xin = X(si, slot);
+                        q.xout = (i == p.c.n_layers - 1 || merge) ? nullptr : X(i + 1, slot);
+                        q.gate = p.c.gated_unit;
                         q.out = w.out; q.acc_out = i > 0 ? 1 : 0; q.rs_rows = p.rs_rows(i);
                         q.L = L; q.ld = g.ld; q.pad = g.pad; q.ntiles = (L + 63) / 64;
                         if ((rc = launch_wf_sep_layer(q, batch, s))) return rc;
@@ -572,7 +580,7 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
                     for (int ah = a_min; ah < gkh; ++ah) {
                         const int src_row = r - (kh - 1 - ah);
                         for (int j = 0; j < gkw; ++j)
-                            a.seg[ns++] = {X(i, src_row % kh), cstride, p.nch_c, (j - kw / 2) * dw, 0, 0};
+                            a.seg[ns++] = {X(si, src_row % kh), cstride, p.nch_c, (j - kw / 2) * dw, 0, 0};
                     }
                     a.nch_total = (kh - a_min) * kw * p.nch_c;
                 }
@@ -584,12 +592,12 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
                     a.nch_total += p.kmel / GEMM_KC;
                 }
                 a.nseg = ns;
-                const bool last = i == p.c.n_layers - 1;
+                const bool last = i == p.c.n_layers - 1 || merge;       // all rows of the res/skip GEMM are skip rows
                 if (fuse) {
                     // x_{i+1}[row r] = x_i[row r] + res -> layer i+1's ring slot;  skip rows (+)= into w.out
                     a.rs_wT = blob + f.rs_T[i]; a.rs_bias = blob + f.rs_Tb[i]; a.rs_rows = p.rs_rows(i);
                     a.dst0 = last ? w.out : X(i + 1, slot); a.dst0_bstride = cstride; a.acc0 = 1;
-                    a.src0 = X(i, slot); a.src0_bstride = cstride;
+                    a.src0 = X(si, slot); a.src0_bstride = cstride;
                     a.dst1 = w.out; a.dst1_bstride = cstride; a.acc1 = i > 0 ? 1 : 0;
                     a.split = last ? 0 : C;
                     if ((rc = launch_gemm_f32(GEMM_EPI_GATE_RS, a, s))) return rc;
@@ -607,7 +615,7 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
                 q.seg[0] = {w.act, cstride, p.nch_c, 0, 0, 0};
                 // x_{i+1}[row r] = x_i[row r] + res : written into layer i+1's ring slot (its queue entry)
                 q.dst0 = last ? w.out : X(i + 1, slot); q.dst0_bstride = cstride; q.acc0 = 1;
-                q.src0 = X(i, slot); q.src0_bstride = cstride;
+                q.src0 = X(si, slot); q.src0_bstride = cstride;
                 q.dst1 = w.out; q.dst1_bstride = cstride; q.acc1 = i > 0 ? 1 : 0;
                 q.split = last ? 0 : C;
                 if ((rc = launch_gemm_f32(GEMM_EPI_SPLIT, q, s))) return rc;

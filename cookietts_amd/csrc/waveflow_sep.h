@@ -18,7 +18,8 @@ struct WfSepArgs {
     float* xout;                        // x_{i+1} ring slot (NULL on the last layer)
     float* out;                         // skip accumulator [B][C][ld]
     int acc_out;                        // out += (layers > 0) or out = (layer 0)
-    int rs_rows;                        // 256, or 128 on the last layer (skip only)
+    int rs_rows;                        // 256, or 128 on the last layer / with merge_res_skip (skip only)
+    int gate;                           // GateKind (gemm_f32.h), 0 = GTU
     int L, ld, pad, ntiles;             // ntiles = ceil(L / 64)
 };
 

@@ -175,15 +175,26 @@ __global__ __launch_bounds__(256, 2) void wf_sep_layer_kernel(const WfSepArgs a)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     tile_gemm<X3>(acc, a.A1, As, tile, t, w, l31, lhi, true);
     // (tile_gemm ends with a barrier: nobody reads the depthwise tile any more)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            const float u0 = acc[0][nt][r] + bias1[64 * w + rr] + cnd[0][nt][r];
-            const float u1 = acc[1][nt][r] + bias1[64 * w + 32 + rr] + cnd[1][nt][r];
-            tile[(32 * w + rr) * SN + 32 * nt + l31] = sep_tanh(u0) * sep_sigmoid(u1);
+#define CTTS_SEP_GATE(EXPR)                                                                                  \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                        \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                    \
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * lhi;                                                \
+            const float u0 = acc[0][nt][r] + bias1[64 * w + rr] + cnd[0][nt][r];                            \
+            const float u1 = acc[1][nt][r] + bias1[64 * w + 32 + rr] + cnd[1][nt][r];                       \
+            tile[(32 * w + rr) * SN + 32 * nt + l31] = EXPR;                                                \
         }
+    if (a.gate == GATE_GTU) {                               // uniform
+        CTTS_SEP_GATE(sep_tanh(u0) * sep_sigmoid(u1))
+    } else {                                                // the other gated units (glow_ax.py:45-165), one loop copy each
+        switch (a.gate) {
+#define CTTS_SEP_CASE(K) case K: CTTS_SEP_GATE(gate_eval<K>(u0, u1)) break;
+            CTTS_SEP_CASE(1) CTTS_SEP_CASE(2) CTTS_SEP_CASE(3) CTTS_SEP_CASE(4) CTTS_SEP_CASE(5) CTTS_SEP_CASE(6)
+            CTTS_SEP_CASE(7) CTTS_SEP_CASE(8) CTTS_SEP_CASE(9) CTTS_SEP_CASE(10) CTTS_SEP_CASE(11) CTTS_SEP_CASE(12)
+            default: CTTS_SEP_GATE(gate_eval<13>(u0, u1)) break;
+#undef CTTS_SEP_CASE
+        }
+    }
+#undef CTTS_SEP_GATE
     __syncthreads();
 
     // ---- phase 4: res/skip GEMM on the gated tile

@@ -42,7 +42,7 @@ struct AxPlan {
     };
     std::vector<Flow> fl;
     size_t total;
-    int rs_rows(int layer) const { return layer < c.n_layers - 1 ? 2 * C : C; }
+    int rs_rows(int layer) const { return (layer < c.n_layers - 1 && !c.merge_res_skip) ? 2 * C : C; }
     int rs_mb(int layer) const { return (rs_rows(layer) + GEMM_BM - 1) / GEMM_BM; }
 };
 
@@ -58,6 +58,8 @@ int make_ax_plan(const ctts_wgax_config* cfg, AxPlan& p) {
     CTTS_CHECK_ARG(c.n_early_every >= 1 && c.n_early_size >= 0 && c.n_early_size % 2 == 0, "wgax: early outputs");
     CTTS_CHECK_ARG(c.mixing == CTTS_MIX_PERMUTE || c.mixing == CTTS_MIX_CONV1X1, "wgax: mixing=%d", c.mixing);
     CTTS_CHECK_ARG(c.mixing != CTTS_MIX_PERMUTE || c.n_flows % 2 == 0, "wgax: PermuteHeight requires even n_flows");
+    CTTS_CHECK_ARG(c.gated_unit >= 0 && c.gated_unit < GATE_KINDS && (c.merge_res_skip == 0 || c.merge_res_skip == 1),
+                   "wgax: gated_unit=%d merge_res_skip=%d", c.gated_unit, c.merge_res_skip);
     p.C = c.n_channels;
     p.nch_c = p.C / GEMM_KC;
     p.nch_in = c.kernel_size * p.nch_c;
@@ -399,10 +401,12 @@ int ctts_wgax_inverse_f32(const ctts_wgax_config* cfg, const void* packed, const
                 a.addend_bstride = (long long)2 * C * nl * cond_ld;
                 a.addend_ld = cond_ld; a.addend_pad = cond_pad;
                 a.addend_frames = frames == L ? 0 : frames;
+                a.gate = p.c.gated_unit;
                 if ((rc = launch_gemm_f32(GEMM_EPI_GATE, a, s))) return rc;
             }
             {
-                const bool last = i == nl - 1;
+                // merge_res_skip: every layer's C rows are skip rows and x stays the `start` output (glow_ax.py:401-416)
+                const bool last = i == nl - 1 || p.c.merge_res_skip;
                 GemmArgs a = base_args();
                 a.A = blob + f.rs_A[i]; a.bias = blob + f.rs_b[i];
                 a.nseg = 1; a.nch_total = p.nch_c; a.MB = p.rs_mb(i);

@@ -122,6 +122,11 @@ def waveflow_author_config(n_flows=8, n_group=20, n_channels=128, n_layers=8, ke
                 cond_hidden_channels=wn_cond_hidden, cond_kernel_size=1, seperable_conv=True))
 
 
+def _with_wn(cfg, **wn_over):
+    cfg["WN_config"].update(wn_over)
+    return cfg
+
+
 WAVEFLOW_CONFIGS = {
     "toy": waveflow_config(n_flows=4, n_group=8, n_channels=64, n_layers=3),
     "full": waveflow_config(),                                   # config 4: 8 flows, 64 ch, h = 16
@@ -130,6 +135,12 @@ WAVEFLOW_CONFIGS = {
                                          n_mel_channels=12, hop_length=40, win_length=160, speaker_embed=8,
                                          cond_layers=2, cond_hidden=32, wn_cond_hidden=24),
     "author": waveflow_author_config(),
+    # merge_res_skip and a non-GTU unit on the 2-D core: dense C = 64 (un-fused layer path) and the separable C = 128 path
+    "toy_merge": waveflow_config(n_flows=4, n_group=8, n_channels=64, n_layers=3, WN=dict(merge_res_skip=True, gated_unit='GLU')),
+    "author_toy_gate": _with_wn(waveflow_author_config(n_flows=2, n_group=10, n_channels=128, n_layers=2, kernel=5,
+                                                       n_mel_channels=12, hop_length=40, win_length=160, speaker_embed=8,
+                                                       cond_layers=2, cond_hidden=32, wn_cond_hidden=24),
+                                gated_unit='GSIRRU', merge_res_skip=True),
     # the WaveFlow printed by scripts/"UnTTS Inference.ipynb" (cell output at line 64): the same option family with
     # 12 flows, a 3-layer k=3 cond stack and the mel shifted / scaled on entry (shift_spect 11.52, scale_spect 0.25)
     "untts_toy": dict(waveflow_author_config(n_flows=4, n_group=10, n_channels=64, n_layers=3, kernel=5, n_mel_channels=12,
@@ -218,6 +229,11 @@ WAVEGLOW_AX_CONFIGS = {
                                                 hop_length=120, win_length=480, speaker_embed=8, cond_hidden=32,
                                                 n_early_every=2),
     "notebook": waveglow_ax_notebook_config(),
+    # the other gated units of glow_ax.py:45-165 and merge_res_skip (one config per unit family)
+    **{f"toy_gate_{g.lower()}": waveglow_ax_config(n_flows=2, n_group=8, n_layers=2, WN=dict(gated_unit=g))
+       for g in ("GTRU", "GTLRU", "GLU", "TTU", "STU", "GTSU", "SPTU", "GSIU", "GSIRU", "GTSRU", "GSIRRU", "GSIRLRU", "GSIRRLRU")},
+    "toy_merge": waveglow_ax_config(n_flows=4, n_group=8, channel_mixing='permute', mix_first=False,
+                                    WN=dict(merge_res_skip=True, gated_unit='GTRU')),
     # the untts notebook's vocoder: model-level transposed-conv upsampling, 1x1-conv cond residual; toy and full size
     "untts_toy": waveglow_ax_untts_config(n_flows=4, n_group=8, n_channels=128, n_layers=2, n_mel_channels=16,
                                           hop_length=40, win_length=160, speaker_embed=8, cond_hidden=48, cond_output=48,
@@ -295,7 +311,7 @@ def waveglow_ax_state_dict(cfg, seed=1234, end_std=None):
             _wn_conv(rng, sd, f"{p}.cond_layers.{l}", dims[l + 1], dims[l], ck, gain=0.5)
         for i in range(n_layers):
             _wn_conv(rng, sd, f"{p}.in_layers.{i}", 2 * C, C, ks)
-            _wn_conv(rng, sd, f"{p}.res_skip_layers.{i}", 2 * C if i < n_layers - 1 else C, C, 1)
+            _wn_conv(rng, sd, f"{p}.res_skip_layers.{i}", 2 * C if (i < n_layers - 1 and not wn.get("merge_res_skip")) else C, C, 1)
         if conv_mix:
             a = rng.standard_normal((n_rem, n_rem)).astype(np.float64)
             q, _ = np.linalg.qr(a)
@@ -366,7 +382,7 @@ def waveflow_state_dict(cfg, seed=1234, end_std=None):
                 wn_conv(f"{p}.in_layers.{i}.1", (2 * C, C, 1, 1), C)
             else:
                 wn_conv(f"{p}.in_layers.{i}", (2 * C, C, kh, kw), C * kh * kw)
-            rs = 2 * C if i < n_layers - 1 else C
+            rs = 2 * C if (i < n_layers - 1 and not wn.get("merge_res_skip")) else C
             wn_conv(f"{p}.res_skip_layers.{i}", (rs, C, 1, 1), C)
     return sd
 

@@ -80,8 +80,9 @@ class _WN2d(nn.Module):
                                             for _ in range(n_layers)])
         else:
             self.in_layers = nn.ModuleList([_WNConv((2 * C_, C_, kh, kw)) for _ in range(n_layers)])
+        merge = bool(wn.get('merge_res_skip', False))                            # glow_ax.py:535-538
         self.res_skip_layers = nn.ModuleList([
-            _WNConv((2 * C_ if i < n_layers - 1 else C_, C_, 1, 1)) for i in range(n_layers)])
+            _WNConv((2 * C_ if (i < n_layers - 1 and not merge) else C_, C_, 1, 1)) for i in range(n_layers)])
 
 
 class _WN1d(nn.Module):
@@ -104,8 +105,9 @@ class _WN1d(nn.Module):
         dims = [cond_in + sdim] + [wn['cond_hidden_channels']] * (wn['cond_layers'] - 1) + [2 * C_ * n_layers]
         self.cond_layers = nn.ModuleList([_WNConv((dims[l + 1], dims[l], k)) for l in range(wn['cond_layers'])])
         self.in_layers = nn.ModuleList([_WNConv((2 * C_, C_, ks)) for _ in range(n_layers)])
+        merge = bool(wn.get('merge_res_skip', False))                            # glow_ax.py:352-355
         self.res_skip_layers = nn.ModuleList([
-            _WNConv((2 * C_ if i < n_layers - 1 else C_, C_, 1)) for i in range(n_layers)])
+            _WNConv((2 * C_ if (i < n_layers - 1 and not merge) else C_, C_, 1)) for i in range(n_layers)])
 
 
 class InvertibleConv1x1(nn.Module):
@@ -301,8 +303,10 @@ class WaveGlow(nn.Module):
              "iso226 emphasis / grouped per-flow cond conv")
         need(wn.get('cond_layers', 1) >= 1, "WN without cond layers")
         need(wn.get('upsample_mode', 'linear') == 'linear', "WN upsample_mode != 'linear'")
-        need(wn.get('res_skip', True) and not wn.get('merge_res_skip', False), "merge_res_skip")
-        need(wn.get('gated_unit', 'GTU') == 'GTU' and not wn.get('rezero', False), "gate other than GTU / rezero")
+        need(wn.get('res_skip', True), "res_skip=False")
+        if str(wn.get('gated_unit', 'GTU')).upper() not in _lib.GATED_UNITS:
+            raise Exception("gated_unit is invalid\nOptions are ('GTU','GTRU','GLU').")     # glow_ax.py:198
+        assert not wn.get('rezero', False), "WN ReZero is depreciated"                         # glow_ax.py:272, 450
         need(wn.get('n_layers_dilations_w') is None, "custom width dilations")
         if waveflow:
             dh = wn.get('n_layers_dilations_h', 1)
@@ -393,6 +397,8 @@ class WaveGlow(nn.Module):
                                    n_layers=wn['n_layers'], n_channels=wn['n_channels'],
                                    kernel_size_w=wn['kernel_size_w'], kernel_size_h=wn['kernel_size_h'], dilation_h=1,
                                    seperable_conv=1 if wn.get('seperable_conv', False) else 0,
+                                   gated_unit=_lib.GATED_UNITS[str(wn.get('gated_unit', 'GTU')).upper()],
+                                   merge_res_skip=1 if wn.get('merge_res_skip', False) else 0,
                                    cond_precomputed=0 if self._folded else 1)
 
     def c_config_1d(self):
@@ -401,7 +407,9 @@ class WaveGlow(nn.Module):
                                n_early_size=self.n_early_size, n_layers=wn['n_layers'], n_channels=wn['n_channels'],
                                kernel_size=wn.get('kernel_size_w') or wn.get('kernel_size'),
                                mixing=_lib.MIX_CONV1X1 if self.channel_mixing == '1x1conv' else _lib.MIX_PERMUTE,
-                               mix_first=1 if self.mix_first else 0, ignore_nan=1 if self.ignore_nan else 0)
+                               mix_first=1 if self.mix_first else 0, ignore_nan=1 if self.ignore_nan else 0,
+                               gated_unit=_lib.GATED_UNITS[str(wn.get('gated_unit', 'GTU')).upper()],
+                               merge_res_skip=1 if wn.get('merge_res_skip', False) else 0)
 
     def _invalidate(self):
         self._packed, self._ws = None, {}

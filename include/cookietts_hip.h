@@ -38,7 +38,7 @@ extern "C" {
 #define CTTS_E_LAUNCH (-2)    /* HIP launch or runtime error */
 #define CTTS_E_WORKSPACE (-3) /* workspace too small */
 
-#define CTTS_ABI_VERSION 2   /* 2: ctts_waveglow_config.speaker_embed_dim, ctts_waveglow_flow_weights.speaker_embed */
+#define CTTS_ABI_VERSION 3   /* 2: ctts_waveglow_config.speaker_embed_dim, ctts_waveglow_flow_weights.speaker_embed */
 #define CTTS_N_SPEAKERS 512  /* rows of every speaker-embedding table (glow.py:129, efficient_model_ax.py:60) */
 
 int ctts_abi_version(void);
@@ -192,12 +192,27 @@ int ctts_flow_tail_f32(const ctts_waveglow_config* cfg, const void* packed, int3
 /* ---- WaveFlow ("ax" core, waveflow=True): _4_mtw/waveglow/efficient_model_ax.py --------- */
 
 /* Constructor arguments that shape the path (efficient_model_ax.py:19-169, glow_ax.py:427-543).
- * Built: channel_mixing='permuteheight', mix_first=False, GTU gate, res_skip=True, merge_res_skip=False,
+ * Built: channel_mixing='permuteheight', mix_first=False, all fourteen gated units, res_skip=True, merge_res_skip,
  * n_early_every > n_flows, linear upsampling; in-layers dense (kh*kw <= 11 taps) or separable (depthwise kh x kw
  * + pointwise, glow_ax.py:525-531); conditioning either ONE k=1 linear WN cond layer on the mel, folded into the
  * in-layer GEMM (BASELINE config 4), or an arbitrary per-flow stack evaluated by the caller at frame rate and
  * handed over (cond_precomputed; SURVEY 8f.4: speaker embeddings, model-level and WN-level conv stacks with
  * activations - composed from ctts_conv1d_f32 / ctts_embed_rows_f32 / ctts_scale_add_rows_f32). */
+/* WN_config['gated_unit'] names in the order of get_gate_func (glow_ax.py:168-198) */
+#define CTTS_GATE_GTU 0
+#define CTTS_GATE_GTRU 1
+#define CTTS_GATE_GTLRU 2
+#define CTTS_GATE_GLU 3
+#define CTTS_GATE_TTU 4
+#define CTTS_GATE_STU 5
+#define CTTS_GATE_GTSU 6
+#define CTTS_GATE_SPTU 7
+#define CTTS_GATE_GSIU 8
+#define CTTS_GATE_GSIRU 9
+#define CTTS_GATE_GTSRU 10
+#define CTTS_GATE_GSIRRU 11
+#define CTTS_GATE_GSIRLRU 12
+#define CTTS_GATE_GSIRRLRU 13
 typedef struct ctts_waveflow_config {
     int32_t n_mel_channels;  /* 80 */
     int32_t n_flows;         /* 8 (even) */
@@ -209,6 +224,9 @@ typedef struct ctts_waveflow_config {
     int32_t dilation_h;      /* 1 (all layers) */
     int32_t seperable_conv;  /* 0 | 1  (WN_config['seperable_conv'], the reference's spelling) */
     int32_t cond_precomputed;/* 0: mel + folded cond layer;  1: ctts_waveflow_inverse_cond_f32 */
+    int32_t gated_unit;      /* CTTS_GATE_*: WN_config['gated_unit'] (glow_ax.py:168-198); 0 = 'GTU' */
+    int32_t merge_res_skip;  /* 0 | 1: WN_config['merge_res_skip'] (glow_ax.py:612-626: every res_skip layer has C rows,
+                                all of them skip; the layer input stays the `start` output) */
 } ctts_waveflow_config;
 
 /* Dense, weight-norm-folded fp32 weights of one flow in checkpoint layouts
@@ -287,7 +305,7 @@ int ctts_deemphasis_f32(const float* x, float* y, int32_t batch, int32_t T, doub
  *   PermuteHeight.inverse         efficient_modules.py:376-403
  *   early outputs                 efficient_model_ax.py:312-316, 340-341;   ignore_nan  :13-16, 333-334
  *   mix_first ordering            efficient_model_ax.py:324-325, 337-338
- * Built: GTU gate, res_skip=True, merge_res_skip=False, dense in-layers with width dilation 2^i,
+ * Built: all fourteen gated units, res_skip=True, merge_res_skip, dense in-layers with width dilation 2^i,
  * the per-flow WN conditioning stack is evaluated by the caller (composed from ctts_conv1d_f32 / ctts_embed_rows_f32 /
  * ctts_scale_add_rows_f32 / ctts_replicate_halo_f32) and handed over, like ctts_waveflow_inverse_cond_f32: at FRAME
  * rate (upsample_first=False; `frames` columns, interpolated to the latent's rate inside the gate epilogue) or already
@@ -306,6 +324,8 @@ typedef struct ctts_wgax_config {
     int32_t mixing;          /* CTTS_MIX_PERMUTE | CTTS_MIX_CONV1X1 */
     int32_t mix_first;       /* 0 | 1 */
     int32_t ignore_nan;      /* 1: NaN -> 0 on the latent after every coupling (the reference's default) */
+    int32_t gated_unit;      /* CTTS_GATE_* (0 = 'GTU') */
+    int32_t merge_res_skip;  /* 0 | 1 (glow_ax.py:401-416) */
 } ctts_wgax_config;
 
 /* Dense, weight-norm-folded fp32 device weights of one flow in checkpoint layouts (keys WN.k.WN.*, convinv.k.weight) */

@@ -82,6 +82,27 @@ def activation(name, negative_slope):
     raise NotImplementedError(name)
 
 
+def gated_unit(name, u, C):
+    """glow_ax.py:36-165: acts = f(u[:, :C]) * g(u[:, C:]) for the fourteen units of get_gate_func (:168-198)."""
+    a, b = u[:, :C].astype(F32), u[:, C:].astype(F32)
+    name = (name or 'GTU').upper()
+    sig = lambda v: (F32(1.0) / (F32(1.0) + np.exp(-v))).astype(F32)
+    lrelu = lambda v, s: np.where(v >= 0, v, v * F32(s)).astype(F32)
+    first = {"GLU": lambda v: v, "GTSU": lambda v: v - np.tanh(v), "GTSRU": lambda v: v - np.tanh(v), "GSIU": np.sin,
+             "GSIRU": lambda v: np.sin(F32(16.0) * v), "GSIRRU": lambda v: np.sin(F32(16.0) * v),
+             "GSIRLRU": lambda v: np.sin(F32(16.0) * v), "GSIRRLRU": lambda v: np.sin(F32(16.0) * v)}.get(name, np.tanh)
+    selu = lambda v: (F32(1.0507009873554805) * (np.maximum(v, 0) + np.minimum(0, F32(1.6732632423543772) * np.expm1(v)))).astype(F32)
+    second = {"GTRU": lambda v: np.maximum(v, F32(0)), "GTSRU": lambda v: np.maximum(v, F32(0)),
+              "GSIRRU": lambda v: np.maximum(v, F32(0)), "GTLRU": lambda v: lrelu(v, 0.01), "GSIRLRU": lambda v: lrelu(v, 0.01),
+              "GSIRRLRU": lambda v: lrelu(v, (0.01 + 0.1) / 2),          # F.rrelu outside training: the mean slope
+              "TTU": np.tanh, "STU": selu,
+              "SPTU": lambda v: np.where(v > 20, v, np.log1p(np.exp(np.minimum(v, F32(20)))))}.get(name, sig)
+    if name not in ("GTU", "GTRU", "GTLRU", "GLU", "TTU", "STU", "GTSU", "SPTU", "GSIU", "GSIRU", "GTSRU", "GSIRRU", "GSIRLRU",
+                    "GSIRRLRU"):
+        raise Exception("gated_unit is invalid")
+    return (first(a).astype(F32) * second(b).astype(F32)).astype(F32)
+
+
 def conv1d_same(x, w, b, padding_mode='zeros'):
     """Conv1d, odd kernel, padding (k-1)/2 with zeros or edge values ('replicate', the two modes the reference's
     configs use: efficient_model_ax.py:90, glow_ax.py:311): x [B, Cin, T], w [Cout, Cin, k] -> [B, Cout, T]."""
@@ -263,9 +284,9 @@ def waveflow_inverse(sd, cfg, z, mel, speaker_ids=None):
                         for j in range(kw):
                             u = u + np.matmul(np.ascontiguousarray(win[i][:, :, ah, j]), _shift(row, j * dw - pad))
                 u = u.astype(F32)
-                act = (np.tanh(u[:, :C]) * (F32(1.0) / (F32(1.0) + np.exp(-u[:, C:])))).astype(F32)
+                act = gated_unit(wn.get("gated_unit", 'GTU'), u, C)
                 rs = np.matmul(wrs[i], act) + sd[f"{p}.res_skip_layers.{i}.bias"][None, :, None]
-                if i < n_layers - 1:
+                if i < n_layers - 1 and not wn.get("merge_res_skip", False):     # glow_ax.py:612-626
                     x = x + rs[:, :C]
                     out = rs[:, C:] if out is None else out + rs[:, C:]
                 else:

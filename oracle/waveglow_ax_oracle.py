@@ -24,8 +24,8 @@ from __future__ import annotations
 
 import numpy as np
 
-from .waveflow_oracle import (F32, _shift, _w, activation, conv1d_same, deemphasis, lerp_align_corners, model_cond,
-                              permutation, transposed_upsample_net)
+from .waveflow_oracle import (F32, _shift, _w, activation, conv1d_same, deemphasis, gated_unit, lerp_align_corners,
+                              model_cond, permutation, transposed_upsample_net)
 
 
 def flow_channels(cfg):
@@ -68,10 +68,10 @@ def wn1d(sd, p, wn, a0, frames, speaker_ids, L):
         for t in range(ks):
             u = u + np.matmul(np.ascontiguousarray(w[:, :, t]), _shift(x, (t - ks // 2) * d))
         u = (u.astype(F32) + cond[:, 2 * C * i:2 * C * (i + 1)]).astype(F32)   # GTU: in_act + spect, then gate
-        g = (np.tanh(u[:, :C]) * (F32(1.0) / (F32(1.0) + np.exp(-u[:, C:])))).astype(F32)
+        g = gated_unit(wn.get("gated_unit", 'GTU'), u, C)
         rs = (np.matmul(_w(sd, f"{p}.res_skip_layers.{i}")[:, :, 0], g)
               + sd[f"{p}.res_skip_layers.{i}.bias"][None, :, None]).astype(F32)
-        if i < n_layers - 1:
+        if i < n_layers - 1 and not wn.get("merge_res_skip", False):               # glow_ax.py:401-416
             x = (x + rs[:, :C]).astype(F32)
             out = rs[:, C:] if out is None else (out + rs[:, C:]).astype(F32)
         else:

@@ -234,7 +234,9 @@ def make_waveflow(full_length=False):
              # SURVEY 8f.4 option set: speaker ids, cond stacks, separable in-layers, logvar channels, de-emphasis
              ("author_toy", "author_toy", 2, 6, 0.7, 3), ("author_short", "author", 1, 3, 0.6, 4),
              # the UnTTS notebook's WaveFlow: shift_spect / scale_spect on entry
-             ("untts_toy", "untts_toy", 2, 7, 0.8, 8)]
+             ("untts_toy", "untts_toy", 2, 7, 0.8, 8),
+             # merge_res_skip + GLU on the dense 2-D core; merge_res_skip + GSIRRU on the separable C = 128 core
+             ("toy_merge", "toy_merge", 2, 5, 0.7, 9), ("author_toy_gate", "author_toy_gate", 1, 5, 0.7, 10)]
     only = [a for a in sys.argv[2:]]
     if full_length:
         # BASELINE config 4 at the metric's utterance length: one 80x900 mel (~10 s of CPU here)
@@ -272,7 +274,7 @@ def make_waveflow(full_length=False):
         print(f"[golden] waveflow {name}: audio {audio.shape} rms={audio.std():.4f} -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
-def make_waveglow_ax(full_length=False, untts=False):
+def make_waveglow_ax(full_length=False, untts=False, gates=False):
     """efficient_model_ax.WaveGlow with waveflow=False (AffineCouplingBlock + 1-D WN; InvertibleConv1x1 / PermuteHeight
     mixing in both orders; early outputs; the timed notebook config's option set)."""
     import copy
@@ -282,6 +284,10 @@ def make_waveglow_ax(full_length=False, untts=False):
     if full_length:
         # the notebook config at full width (48 flows x 8 x 256, n_group 24, 160 mel channels), short mel
         cases = [("notebook", 1, 5, 0.9, 26)]
+    if gates:
+        # the thirteen non-GTU gated units (glow_ax.py:45-165) and merge_res_skip, one tiny model each
+        cases = [(k, 1, 4, 0.8, 40 + i) for i, k in enumerate(sorted(
+            k for k in synthetic.WAVEGLOW_AX_CONFIGS if k.startswith("toy_gate_") or k == "toy_merge"))]
     if untts:
         # the untts notebook's vocoder config (model-level TransposedUpsampleNet, 1x1-conv cond residual, spect shift /
         # scale in the toy), toy and full width (24 flows x 8 x 384, 256 mel channels) on a short mel
@@ -468,6 +474,8 @@ if __name__ == "__main__":
         make_waveglow_ax(full_length=True)
     if "waveglow_ax_untts" in which:       # on request only
         make_waveglow_ax(untts=True)
+    if "waveglow_ax_gates" in which:       # on request only
+        make_waveglow_ax(gates=True)
     if "waveglow_full_len" in which:       # on request only: minutes of CPU
         make_waveglow(full_length=True)
     if "waveflow_full_len" in which:

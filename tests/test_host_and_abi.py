@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(hip_lib_path):
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in include/cookietts_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == declared, "ctypes signature table out of sync with the header"
-    assert handle.ctts_abi_version() == 2
+    assert handle.ctts_abi_version() == 3
 
 
 def test_host_side_queries_run_without_gpu(hip_lib_path):

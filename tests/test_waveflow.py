@@ -19,8 +19,9 @@ def _load(name):
     return g, cfg, synthetic.waveflow_state_dict(cfg, seed=int(g["seed"]))
 
 
-ALL = ["toy", "toy_odd", "full_short", "author_toy", "author_short", "untts_toy"]   # author_*: SURVEY 8f.4 option set;
-# untts_toy: the same family with shift_spect / scale_spect (scripts/"UnTTS Inference.ipynb")
+ALL = ["toy", "toy_odd", "full_short", "author_toy", "author_short", "untts_toy", "toy_merge", "author_toy_gate"]   # author_*: SURVEY 8f.4 option set;
+# untts_toy: the same family with shift_spect / scale_spect (scripts/"UnTTS Inference.ipynb"); toy_merge / author_toy_gate:
+# merge_res_skip with the GLU / GSIRRU gated units on the dense and the separable 2-D core
 
 
 def _ids(g):

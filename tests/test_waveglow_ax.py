@@ -13,7 +13,8 @@ from oracle import waveglow_ax_oracle as ao
 
 WAVE_TOL = 1e-3           # BASELINE.json: waveform RMS relative error
 ORACLE_TOL = 5e-6
-SMALL = ["toy_conv", "toy_conv_mixlast", "toy_permute", "toy_permute_mixfirst", "notebook_toy", "untts_toy"]
+SMALL = ["toy_conv", "toy_conv_mixlast", "toy_permute", "toy_permute_mixfirst", "notebook_toy", "untts_toy", "toy_merge"]
+GATES = sorted(k for k in synthetic.WAVEGLOW_AX_CONFIGS if k.startswith("toy_gate_"))       # the 13 non-GTU units
 
 
 def _load(key):
@@ -26,13 +27,15 @@ def _ids(g):
     return g["speaker_ids"] if "speaker_ids" in g.files else None
 
 
-@pytest.mark.parametrize("key", SMALL)
+@pytest.mark.parametrize("key", SMALL + GATES)
 def test_oracle_matches_reference(key):
     g, cfg, sd = _load(key)
     melp = np.pad(g["mel"], ((0, 0), (0, 0), (0, 1)))
-    assert rms_rel_err(ao.waveglow_ax_inverse(sd, cfg, g["z"], melp, _ids(g)), g["inverse_full"]) < ORACLE_TOL
+    # the SIREN units take sin(16 x): the fp32 summation-order noise of x comes out 16 x larger (measured 5e-6 .. 8e-6)
+    tol = 10 * ORACLE_TOL if "gsir" in key else ORACLE_TOL
+    assert rms_rel_err(ao.waveglow_ax_inverse(sd, cfg, g["z"], melp, _ids(g)), g["inverse_full"]) < tol
     audio = ao.waveglow_ax_infer(sd, cfg, g["mel"], g["z"], speaker_ids=_ids(g))
-    assert audio.shape == g["audio"].shape and rms_rel_err(audio, g["audio"]) < ORACLE_TOL
+    assert audio.shape == g["audio"].shape and rms_rel_err(audio, g["audio"]) < tol
 
 
 def test_oracle_pieces():
@@ -59,7 +62,7 @@ def test_host_state_dict_keys_match_reference_format():
     recipe IS equality with the reference's own state_dict keys and shapes."""
     from cookietts_amd.waveglow_ax import WaveGlow
     for key, cfg in synthetic.WAVEGLOW_AX_CONFIGS.items():
-        if key in ("notebook", "untts"):
+        if key in ("notebook", "untts") or key.startswith("toy_gate_"):
             continue
         sd = synthetic.waveglow_ax_state_dict(cfg, seed=1)
         own = WaveGlow(**cfg).state_dict()
@@ -72,6 +75,11 @@ def test_host_state_dict_keys_match_reference_format():
         WaveGlow(**dict(synthetic.WAVEGLOW_AX_CONFIGS["toy_conv"], upsample_first=True))       # no TransposedUpsampleNet
     with pytest.raises(NotImplementedError):                                                    # 2*3 == 48 // 8: the
         WaveGlow(**dict(synthetic.WAVEGLOW_AX_CONFIGS["untts_toy"], hop_length=48))             # reference crops to nothing
+    with pytest.raises(Exception, match="gated_unit is invalid"):                                 # glow_ax.py:198
+        WaveGlow(**synthetic.waveglow_ax_config(WN=dict(gated_unit="GXU")))
+    mg = WaveGlow(**synthetic.WAVEGLOW_AX_CONFIGS["toy_merge"])
+    assert all(tuple(l.weight_v.shape) == (128, 128, 1) for l in mg.WN[0].WN.res_skip_layers)      # merge_res_skip: C rows
+    assert mg.c_config_1d().gated_unit == 1 and mg.c_config_1d().merge_res_skip == 1
     u = WaveGlow(**synthetic.WAVEGLOW_AX_CONFIGS["untts_toy"])
     assert [type(t).__name__ for t in u.upsample_net.t_convs] == ["ConvTranspose1d", "LeakyReLU"] * 2
     assert tuple(u.res_conv.weight.shape) == (48, 24, 1) and u.upsample_net.res_weight is not None
@@ -121,7 +129,7 @@ def _model(key, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("key", SMALL)
+@pytest.mark.parametrize("key", SMALL + GATES)
 def test_hip_matches_reference_golden(hip_lib_path, key):
     g, cfg, _ = _load(key)
     m, _, _ = _model(str(g["config_key"]), int(g["seed"]))
