@@ -122,6 +122,18 @@ def waveflow_author_config(n_flows=8, n_group=20, n_channels=128, n_layers=8, ke
                 cond_hidden_channels=wn_cond_hidden, cond_kernel_size=1, seperable_conv=True))
 
 
+def _group_conv_params(rng, sd, cfg, c_wn):
+    """``n_flow_group_conv`` (ax:131-134): plain Conv1d(c_wn, out * n_flows, 1, groups = n_flows | 1) -> out."""
+    out = cfg.get("group_conv_output_dim")
+    if not out:
+        return c_wn
+    groups = cfg["n_flows"] if cfg.get("group_conv_groupped", True) else 1
+    bound = 1.0 / np.sqrt(c_wn // groups)
+    sd["n_flow_group_conv.weight"] = _uniform(rng, (out * cfg["n_flows"], c_wn // groups, 1), bound)
+    sd["n_flow_group_conv.bias"] = _uniform(rng, (out * cfg["n_flows"],), bound)
+    return out
+
+
 def _with_wn(cfg, **wn_over):
     cfg["WN_config"].update(wn_over)
     return cfg
@@ -137,6 +149,8 @@ WAVEFLOW_CONFIGS = {
     "author": waveflow_author_config(),
     # merge_res_skip and a non-GTU unit on the 2-D core: dense C = 64 (un-fused layer path) and the separable C = 128 path
     "toy_merge": waveflow_config(n_flows=4, n_group=8, n_channels=64, n_layers=3, WN=dict(merge_res_skip=True, gated_unit='GLU')),
+    "toy_groupconv": waveflow_config(n_flows=4, n_group=8, n_channels=64, n_layers=2, group_conv_output_dim=16,
+                                     group_conv_groupped=True),
     "author_toy_gate": _with_wn(waveflow_author_config(n_flows=2, n_group=10, n_channels=128, n_layers=2, kernel=5,
                                                        n_mel_channels=12, hop_length=40, win_length=160, speaker_embed=8,
                                                        cond_layers=2, cond_hidden=32, wn_cond_hidden=24),
@@ -234,6 +248,14 @@ WAVEGLOW_AX_CONFIGS = {
        for g in ("GTRU", "GTLRU", "GLU", "TTU", "STU", "GTSU", "SPTU", "GSIU", "GSIRU", "GTSRU", "GSIRRU", "GSIRLRU", "GSIRRLRU")},
     "toy_merge": waveglow_ax_config(n_flows=4, n_group=8, channel_mixing='permute', mix_first=False,
                                     WN=dict(merge_res_skip=True, gated_unit='GTRU')),
+    # the optional per-flow 1x1 conv of the conditioning (ax:131-134), grouped by flow and dense; on top of the untts
+    # toy's upsampling in the first case
+    "toy_groupconv": dict(waveglow_ax_untts_config(n_flows=4, n_group=8, n_channels=128, n_layers=2, n_mel_channels=16,
+                                                   hop_length=40, win_length=160, speaker_embed=8, cond_hidden=48,
+                                                   cond_output=48, t_hidden=48, t_kernels=(4, 9), t_scales=(2, 3), t_output=32),
+                          group_conv_output_dim=24, group_conv_groupped=True),
+    "toy_groupconv_dense": waveglow_ax_config(n_flows=4, n_group=8, n_mel_channels=20, group_conv_output_dim=12,
+                                              group_conv_groupped=False, WN=dict(speaker_embed_dim=4)),
     # the untts notebook's vocoder: model-level transposed-conv upsampling, 1x1-conv cond residual; toy and full size
     "untts_toy": waveglow_ax_untts_config(n_flows=4, n_group=8, n_channels=128, n_layers=2, n_mel_channels=16,
                                           hop_length=40, win_length=160, speaker_embed=8, cond_hidden=48, cond_output=48,
@@ -295,6 +317,7 @@ def waveglow_ax_state_dict(cfg, seed=1234, end_std=None):
             sd[f"upsample_net.t_convs.{idx}.bias"] = _uniform(rng, (outd,), bound)
             idx += 2                                                             # a LeakyReLU module follows every conv
         c_wn = t_out
+    c_wn = _group_conv_params(rng, sd, cfg, c_wn)
     sdim = wn.get("speaker_embed_dim", 0)
     conv_mix = cfg.get("channel_mixing", '1x1conv').lower() in "1x1convinvertibleconv1x1invconv"
     for k, n_rem in enumerate(waveglow_ax_flow_channels(cfg)):
@@ -362,6 +385,7 @@ def waveflow_state_dict(cfg, seed=1234, end_std=None):
         dims = [c_in] + [cfg["cond_hidden_channels"]] * (cfg["cond_layers"] - 1) + [c_wn]
         for l in range(cfg["cond_layers"]):
             wn_conv(f"cond_layers.{l}", (dims[l + 1], dims[l], k), dims[l] * k)
+    c_wn = _group_conv_params(rng, sd, cfg, c_wn)
     sdim = wn.get("speaker_embed_dim", 0)
     for k in range(cfg["n_flows"]):
         p = f"WN.{k}.WN"

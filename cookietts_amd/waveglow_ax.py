@@ -262,7 +262,7 @@ class WaveGlow(nn.Module):
                  preempthasis=None, use_logvar_channels=False, load_hidden_from_disk=False,
                  transposed_conv_hidden_dim=256, transposed_conv_kernel_size=4, transposed_conv_scales=None,
                  transposed_conv_output_dim=256, transposed_conv_residual=False, transposed_conv_residual_linear=False,
-                 transposed_conv_res_rezero=False, **unsupported):
+                 transposed_conv_res_rezero=False, group_conv_output_dim=None, group_conv_groupped=True, **unsupported):
         super().__init__()
         assert n_group % 2 == 0
         assert hop_length % n_group == 0, "hop_length is not int divisible by n_group"
@@ -299,8 +299,7 @@ class WaveGlow(nn.Module):
              "cond_padding_mode other than 'zeros' / 'replicate'")
         need(not preceived_vol_scaling, "preceived_vol_scaling")
         need(not load_hidden_from_disk, "hidden cond from disk")
-        need(not unsupported.get('iso226_empthasis', False) and not unsupported.get('group_conv_output_dim'),
-             "iso226 emphasis / grouped per-flow cond conv")
+        need(not unsupported.get('iso226_empthasis', False), "iso226 emphasis")
         need(wn.get('cond_layers', 1) >= 1, "WN without cond layers")
         need(wn.get('upsample_mode', 'linear') == 'linear', "WN upsample_mode != 'linear'")
         need(wn.get('res_skip', True), "res_skip=False")
@@ -362,6 +361,13 @@ class WaveGlow(nn.Module):
                                                        transposed_conv_res_rezero)
             self.model_cond_channels = wn_cond
             wn_cond = t_out
+        self.group_conv_in = 0
+        if group_conv_output_dim:                                                # ax:131-134: per-flow 1x1 conv of the cond
+            groups = n_flows if group_conv_groupped else 1
+            assert wn_cond % groups == 0, "in_channels must be divisible by groups"
+            self.n_flow_group_conv = nn.Conv1d(wn_cond, group_conv_output_dim * n_flows, 1, groups=groups)
+            self.group_conv_in = wn_cond
+            wn_cond = group_conv_output_dim
         self.wn_cond_channels = wn_cond
         if waveflow:
             self.WN = nn.ModuleList([_Coupling(_WN2d(wn_cond, wn)) for _ in range(n_flows)])
@@ -384,6 +390,7 @@ class WaveGlow(nn.Module):
             self.z_split_sizes.append(n_rem)
         # one k=1 linear WN cond layer on the bare mel commutes with the interpolation: folded into the in-layer GEMM
         self._folded = (bool(waveflow) and not cond_layers and not speaker_embed and not wn.get('speaker_embed_dim', 0)
+                        and not group_conv_output_dim
                         and wn.get('cond_layers', 1) == 1 and wn.get('cond_kernel_size', 1) == 1
                         and self._act_wn[0] == 0)
         self._packed = None
@@ -534,6 +541,7 @@ class WaveGlow(nn.Module):
                 ops = {'model': stack(self.cond_layers, self._act_model, True),          # ax:293-297: every layer
                        'res_conv': (_CondConv(self.res_conv.weight.detach().float(), self.res_conv.bias, 0, 0.0, device, stream)
                                     if hasattr(self, 'res_conv') else None),            # ax:303-304
+                       'group': self._group_conv_ops(device, stream),                  # ax:131-134, 320-321
                        'tconv': ([_TransposedConv(m.weight.detach().float(), m.bias, sc, 1 if act else 0, 0.4, device, stream)
                                   for m, sc, act in zip(self.upsample_net.convs(), self.upsample_net.scales,
                                                         self.upsample_net.acts)]
@@ -543,6 +551,22 @@ class WaveGlow(nn.Module):
             torch.cuda.current_stream(device).synchronize()
         self._packed = (device, blob, ops, key)
         return blob, ops
+
+    def _group_conv_ops(self, device, stream):
+        """One dense 1x1 operator per flow out of ``n_flow_group_conv``: flow k owns output rows [k*out, (k+1)*out) and,
+        when grouped, reads only its own slice of the input channels -> [(op, first input row)] or None."""
+        if not self.group_conv_in:
+            return None
+        conv = self.n_flow_group_conv
+        w, b = conv.weight.detach().float(), conv.bias.detach().float()
+        out = w.shape[0] // self.n_flows
+        cin_g = w.shape[1]
+        ops = []
+        for k in range(self.n_flows):
+            row0 = k * cin_g if conv.groups > 1 else 0
+            ops.append((_CondConv(w[k * out:(k + 1) * out].contiguous(), b[k * out:(k + 1) * out].contiguous(), 0, 0.0,
+                                  device, stream), row0))
+        return ops
 
     def _cond_frames(self, ops, cond, speaker_ids, stream, out_steps=None):
         """ax:281-307 + glow_ax.py:566-577 -> ([n_flows][B][2C*n_layers][ld] padded rows, ld, T): at frame rate
@@ -572,8 +596,11 @@ class WaveGlow(nn.Module):
                                                x0.shape[1], Fr, ld, PAD, stream), "ctts_embed_rows_f32")
         # conv stack, rezero, residual (identity or 1x1 conv of the input, ax:299-307)
         sdim = self.WN_config.get('speaker_embed_dim', 0)
-        c_model = self.model_cond_channels if self.upsample_early else self.wn_cond_channels
-        xw = rows(c_model + (0 if self.upsample_early else sdim))
+        grp = ops.get('group')
+        c_wn_in = self.group_conv_in if grp else self.wn_cond_channels       # channels of the tensor the flows share
+        c_model = self.model_cond_channels if self.upsample_early else c_wn_in
+        # (+16 spare rows: a grouped per-flow conv reads its input slice rounded up to the primitive's 16 channels)
+        xw = rows(c_model + (0 if (self.upsample_early or grp) else sdim) + (16 if grp else 0))
         h = x0
         for op in ops['model']:
             y = rows(op.c_out)
@@ -615,19 +642,23 @@ class WaveGlow(nn.Module):
             # to the length of the latent (ax:177-178: 'linear', align_corners=True)
             T = out_steps
             ld = _ld_for(T)
-            xw = rows(self.wn_cond_channels + sdim)
+            xw = rows(c_wn_in + (0 if grp else sdim) + (16 if grp else 0))
             for b in range(B):
-                _lib.check(lib.ctts_resample_rows_f32(_lib.ptr(h[b]), _lib.ptr(xw[b]), 1, self.wn_cond_channels, hT, hld, PAD,
+                _lib.check(lib.ctts_resample_rows_f32(_lib.ptr(h[b]), _lib.ptr(xw[b]), 1, c_wn_in, hT, hld, PAD,
                                                       T, ld, PAD, 0, 0.0, stream), "ctts_resample_rows_f32")
         # per flow: WN speaker embedding, conv stack -> 2C*n_layers rows
         C2L = 2 * self.WN_config['n_channels'] * self.WN_config['n_layers']
         frames = torch.zeros(self.n_flows, B, C2L, ld, dtype=torch.float32, device=dev)
+        xk = rows(self.wn_cond_channels + sdim) if grp else xw
         for k in range(self.n_flows):
+            if grp:                                                              # this flow's chunk of the group conv
+                op, row0 = grp[k]
+                op(xw[:, row0:], xk, B, T, ld, stream)
             if sdim:
                 tab = self.WN[k].WN.speaker_embed.weight.detach().float().contiguous()
-                _lib.check(lib.ctts_embed_rows_f32(_lib.ptr(tab), _lib.ptr(ids), _lib.ptr(xw), self.wn_cond_channels, sdim,
-                                                   B, xw.shape[1], T, ld, PAD, stream), "ctts_embed_rows_f32")
-            h = xw
+                _lib.check(lib.ctts_embed_rows_f32(_lib.ptr(tab), _lib.ptr(ids), _lib.ptr(xk), self.wn_cond_channels, sdim,
+                                                   B, xk.shape[1], T, ld, PAD, stream), "ctts_embed_rows_f32")
+            h = xk
             for l, op in enumerate(ops['wn'][k]):
                 y = frames[k] if l == len(ops['wn'][k]) - 1 else rows(op.c_out)
                 op(h, y, B, T, ld, stream, self.WN_config.get('cond_padding_mode', 'zeros'))

@@ -147,6 +147,23 @@ def model_cond(sd, cfg, mel, speaker_ids=None):
     return (cond + res).astype(F32)
 
 
+def flow_conds(sd, cfg, cond):
+    """efficient_model_ax.py:131-134, 320-321: the optional per-flow 1x1 (grouped) conv of the conditioning,
+    ``n_flow_group_conv(cond).chunk(n_flows, dim=1)`` -> list of per-flow tensors; without it every flow gets `cond`."""
+    n_flows = cfg["n_flows"]
+    if "n_flow_group_conv.weight" not in sd:
+        return [cond] * n_flows
+    w = np.asarray(sd["n_flow_group_conv.weight"], dtype=F32)[:, :, 0]      # [out * n_flows, cin / groups]
+    b = np.asarray(sd["n_flow_group_conv.bias"], dtype=F32)
+    out = w.shape[0] // n_flows
+    grouped = w.shape[1] != cond.shape[1]
+    res = []
+    for k in range(n_flows):
+        x = cond[:, k * w.shape[1]:(k + 1) * w.shape[1]] if grouped else cond
+        res.append((np.matmul(w[k * out:(k + 1) * out], x) + b[None, k * out:(k + 1) * out, None]).astype(F32))
+    return res
+
+
 def conv_transpose1d(x, w, b, stride, padding):
     """nn.ConvTranspose1d: x [B, Cin, T], w [Cin, Cout, k] -> [B, Cout, (T-1)*stride - 2*padding + k]:
     out[n] = b + sum_{t, kk: t*stride - padding + kk = n} w[:, :, kk]^T x[:, t]."""
@@ -233,13 +250,13 @@ def waveflow_inverse(sd, cfg, z, mel, speaker_ids=None):
     B, T = z.shape
     L = T // G
     a = np.ascontiguousarray(z.reshape(B, L, G).transpose(0, 2, 1))        # a[b, g, l] = z[b, G*l + g]
-    frames = model_cond(sd, cfg, mel, speaker_ids)
+    frames_k = flow_conds(sd, cfg, model_cond(sd, cfg, mel, speaker_ids))
     wn_act = activation(wn.get("cond_activation_func", 'none'), wn.get("negative_slope"))
     sep = bool(wn.get("seperable_conv")) and not (kh == 1 and kw == 1)
     for k in reversed(range(n_flows)):
         p = f"WN.{k}.WN"
         a = a[:, permutation(k, G), :]
-        spect = frames
+        spect = frames_k[k]
         if wn.get("speaker_embed_dim", 0):
             emb = sd[p + ".speaker_embed.weight"][np.asarray(speaker_ids)]
             spect = np.concatenate([spect, np.repeat(emb[:, :, None], spect.shape[2], axis=2)], axis=1)

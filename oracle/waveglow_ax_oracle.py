@@ -24,7 +24,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .waveflow_oracle import (F32, _shift, _w, activation, conv1d_same, deemphasis, gated_unit, lerp_align_corners,
+from .waveflow_oracle import (F32, _shift, _w, activation, conv1d_same, deemphasis, flow_conds, gated_unit, lerp_align_corners,
                               model_cond, permutation, transposed_upsample_net)
 
 
@@ -107,6 +107,7 @@ def waveglow_ax_inverse(sd, cfg, z, mel, speaker_ids=None, flow_trace=None):
                                          cfg.get("transposed_conv_residual_linear", False))
         assert frames.shape[2] != L, "the reference crops to an empty tensor when no interpolation is required"
         frames = lerp_align_corners(frames, L)
+    frames_k = flow_conds(sd, cfg, frames)
 
     def unmix(k, v):
         if mix == 'permuteheight':
@@ -119,7 +120,7 @@ def waveglow_ax_inverse(sd, cfg, z, mel, speaker_ids=None, flow_trace=None):
         if not mix_first:
             zz = unmix(k, zz)
         h = zz.shape[1] // 2
-        log_s, t = wn1d(sd, f"WN.{k}.WN", wn, zz[:, :h], frames, speaker_ids, L)
+        log_s, t = wn1d(sd, f"WN.{k}.WN", wn, zz[:, :h], frames_k[k], speaker_ids, L)
         with np.errstate(over="ignore", invalid="ignore"):
             a1 = ((zz[:, h:] - t) / np.exp(log_s)).astype(F32)
         zz = np.concatenate([zz[:, :h], a1], axis=1)

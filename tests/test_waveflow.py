@@ -19,7 +19,8 @@ def _load(name):
     return g, cfg, synthetic.waveflow_state_dict(cfg, seed=int(g["seed"]))
 
 
-ALL = ["toy", "toy_odd", "full_short", "author_toy", "author_short", "untts_toy", "toy_merge", "author_toy_gate"]   # author_*: SURVEY 8f.4 option set;
+ALL = ["toy", "toy_odd", "full_short", "author_toy", "author_short", "untts_toy", "toy_merge", "author_toy_gate",
+       "toy_groupconv"]   # author_*: SURVEY 8f.4 option set;
 # untts_toy: the same family with shift_spect / scale_spect (scripts/"UnTTS Inference.ipynb"); toy_merge / author_toy_gate:
 # merge_res_skip with the GLU / GSIRRU gated units on the dense and the separable 2-D core
 
