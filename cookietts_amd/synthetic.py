@@ -122,6 +122,25 @@ def waveflow_author_config(n_flows=8, n_group=20, n_channels=128, n_layers=8, ke
                 cond_hidden_channels=wn_cond_hidden, cond_kernel_size=1, seperable_conv=True))
 
 
+def _wn_tconv(wn):
+    return bool(wn.get("transposed_conv_scales")) and bool(wn.get("transposed_conv_hidden_dim", 256)) \
+        and bool(wn.get("transposed_conv_kernel_size", 4))
+
+
+def _tconv_params(rng, sd, prefix, c_in, c_out, hid, ksz, scales):
+    """TransposedUpsampleNet parameters (glow_ax.py:207-226): t_convs.{0,2,4..} = ConvTranspose1d [in][out][k]
+    (a LeakyReLU module sits between them; none after the last one for the WN-level nets)."""
+    idx = 0
+    for i, sc in enumerate(scales):
+        last = i + 1 == len(scales)
+        ind, outd = (c_in if i == 0 else hid), (c_out if last else hid)
+        kk = ksz[i] if isinstance(ksz, (list, tuple)) else ksz
+        bound = 1.0 / np.sqrt(ind * kk / sc)
+        sd[f"{prefix}.t_convs.{idx}.weight"] = _uniform(rng, (ind, outd, kk), bound)
+        sd[f"{prefix}.t_convs.{idx}.bias"] = _uniform(rng, (outd,), bound)
+        idx += 1 if last else 2
+
+
 def _group_conv_params(rng, sd, cfg, c_wn):
     """``n_flow_group_conv`` (ax:131-134): plain Conv1d(c_wn, out * n_flows, 1, groups = n_flows | 1) -> out."""
     out = cfg.get("group_conv_output_dim")
@@ -151,6 +170,14 @@ WAVEFLOW_CONFIGS = {
     "toy_merge": waveflow_config(n_flows=4, n_group=8, n_channels=64, n_layers=3, WN=dict(merge_res_skip=True, gated_unit='GLU')),
     "toy_groupconv": waveflow_config(n_flows=4, n_group=8, n_channels=64, n_layers=2, group_conv_output_dim=16,
                                      group_conv_groupped=True),
+    # the 2-D WN's own TransposedUpsampleNet: interpolated (factor 6 vs hop / n_group = 5) and cropped (factor 4 == 32 / 8)
+    "toy_wn_tconv": waveflow_config(n_flows=2, n_group=8, n_channels=64, n_layers=2, n_mel_channels=16, hop_length=40,
+                                    win_length=160, WN=dict(cond_layers=2, cond_hidden_channels=32,
+                                                            transposed_conv_hidden_dim=32, transposed_conv_kernel_size=[4, 9],
+                                                            transposed_conv_scales=[2, 3])),
+    "toy_wn_tconv_crop": waveflow_config(n_flows=2, n_group=8, n_channels=64, n_layers=2, n_mel_channels=16, hop_length=32,
+                                         win_length=128, WN=dict(cond_layers=1, transposed_conv_hidden_dim=24,
+                                                                 transposed_conv_kernel_size=4, transposed_conv_scales=[2, 2])),
     "author_toy_gate": _with_wn(waveflow_author_config(n_flows=2, n_group=10, n_channels=128, n_layers=2, kernel=5,
                                                        n_mel_channels=12, hop_length=40, win_length=160, speaker_embed=8,
                                                        cond_layers=2, cond_hidden=32, wn_cond_hidden=24),
@@ -254,6 +281,16 @@ WAVEGLOW_AX_CONFIGS = {
                                                    hop_length=40, win_length=160, speaker_embed=8, cond_hidden=48,
                                                    cond_output=48, t_hidden=48, t_kernels=(4, 9), t_scales=(2, 3), t_output=32),
                           group_conv_output_dim=24, group_conv_groupped=True),
+    # the WN's own TransposedUpsampleNet behind its cond stack: factor 6 != hop / n_group = 5 (interpolated), and
+    # factor 4 == hop / n_group (centre-cropped: the mel carries one frame more than the latent)
+    "toy_wn_tconv": waveglow_ax_config(n_flows=2, n_group=8, n_layers=2, n_mel_channels=16, hop_length=40, win_length=160,
+                                       WN=dict(cond_layers=2, cond_hidden_channels=32, cond_activation_func='lrelu',
+                                               negative_slope=0.3, transposed_conv_hidden_dim=32,
+                                               transposed_conv_kernel_size=[4, 9], transposed_conv_scales=[2, 3])),
+    "toy_wn_tconv_crop": waveglow_ax_config(n_flows=2, n_group=8, n_layers=2, n_mel_channels=16, hop_length=32,
+                                            win_length=128,
+                                            WN=dict(cond_layers=1, transposed_conv_hidden_dim=24,
+                                                    transposed_conv_kernel_size=4, transposed_conv_scales=[2, 2])),
     "toy_groupconv_dense": waveglow_ax_config(n_flows=4, n_group=8, n_mel_channels=20, group_conv_output_dim=12,
                                               group_conv_groupped=False, WN=dict(speaker_embed_dim=4)),
     # the untts notebook's vocoder: model-level transposed-conv upsampling, 1x1-conv cond residual; toy and full size
@@ -329,9 +366,13 @@ def waveglow_ax_state_dict(cfg, seed=1234, end_std=None):
         if sdim:
             sd[p + ".speaker_embed.weight"] = rng.standard_normal((512, sdim), dtype=np.float32)
         ck = 2 * wn.get("cond_kernel_size", 1) - 1
-        dims = [c_wn + sdim] + [wn["cond_hidden_channels"]] * (wn["cond_layers"] - 1) + [2 * C * n_layers]
+        cond_out = wn.get("transposed_conv_hidden_dim", 256) if _wn_tconv(wn) else 2 * C * n_layers
+        dims = [c_wn + sdim] + [wn["cond_hidden_channels"]] * (wn["cond_layers"] - 1) + [cond_out]
         for l in range(wn["cond_layers"]):
             _wn_conv(rng, sd, f"{p}.cond_layers.{l}", dims[l + 1], dims[l], ck, gain=0.5)
+        if _wn_tconv(wn):
+            _tconv_params(rng, sd, p + ".upsample_net", cond_out, 2 * C * n_layers, cond_out,
+                          wn.get("transposed_conv_kernel_size", 4), wn["transposed_conv_scales"])
         for i in range(n_layers):
             _wn_conv(rng, sd, f"{p}.in_layers.{i}", 2 * C, C, ks)
             _wn_conv(rng, sd, f"{p}.res_skip_layers.{i}", 2 * C if (i < n_layers - 1 and not wn.get("merge_res_skip")) else C, C, 1)
@@ -395,7 +436,11 @@ def waveflow_state_dict(cfg, seed=1234, end_std=None):
         if sdim:
             sd[p + ".speaker_embed.weight"] = rng.standard_normal((512, sdim), dtype=np.float32)
         ck = 2 * wn.get("cond_kernel_size", 1) - 1
-        dims = [c_wn + sdim] + [wn["cond_hidden_channels"]] * (wn["cond_layers"] - 1) + [2 * C * n_layers]
+        cond_out = wn.get("transposed_conv_hidden_dim", 256) if _wn_tconv(wn) else 2 * C * n_layers
+        if _wn_tconv(wn):
+            _tconv_params(rng, sd, p + ".upsample_net", cond_out, 2 * C * n_layers, cond_out,
+                          wn.get("transposed_conv_kernel_size", 4), wn["transposed_conv_scales"])
+        dims = [c_wn + sdim] + [wn["cond_hidden_channels"]] * (wn["cond_layers"] - 1) + [cond_out]
         for l in range(wn["cond_layers"]):
             # (the single-layer recipe keeps its historical fan so the committed config-4 goldens stay valid)
             fan = dims[l] * 4 if wn["cond_layers"] == 1 else dims[l] * ck

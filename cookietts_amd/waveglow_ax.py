@@ -73,7 +73,15 @@ class _WN2d(nn.Module):
         if sdim:
             self.speaker_embed = nn.Embedding(512, sdim)                        # glow_ax.py:459-461
         k = 2 * wn.get('cond_kernel_size', 1) - 1                               # glow_ax.py:474
-        dims = [cond_in + sdim] + [wn['cond_hidden_channels']] * (wn['cond_layers'] - 1) + [2 * C_ * n_layers]
+        cond_out = 2 * C_ * n_layers
+        if wn.get('transposed_conv_scales') and wn.get('transposed_conv_hidden_dim', 256) and wn.get('transposed_conv_kernel_size', 4):
+            # the WN's own TransposedUpsampleNet behind its cond stack (upsample_first is False): the stack ends at the
+            # net's hidden width, the net ends at 2C*n_layers (glow_ax.py:286-295 / 462-470)
+            hid = wn.get('transposed_conv_hidden_dim', 256)
+            self.upsample_net = _TransposedUpsampleNet(hid, cond_out, hid, wn.get('transposed_conv_kernel_size', 4),
+                                                       wn['transposed_conv_scales'], False, False, False, False)
+            cond_out = hid
+        dims = [cond_in + sdim] + [wn['cond_hidden_channels']] * (wn['cond_layers'] - 1) + [cond_out]
         self.cond_layers = nn.ModuleList([_WNConv((dims[l + 1], dims[l], k)) for l in range(wn['cond_layers'])])
         if wn.get('seperable_conv', False) and not (kh == 1 and kw == 1):       # glow_ax.py:521-531
             self.in_layers = nn.ModuleList([nn.ModuleList([_WNConv((C_, 1, kh, kw)), _WNConv((2 * C_, C_, 1, 1))])
@@ -102,7 +110,15 @@ class _WN1d(nn.Module):
         if sdim:
             self.speaker_embed = nn.Embedding(512, sdim)                        # glow_ax.py:283-285
         k = 2 * wn.get('cond_kernel_size', 1) - 1                               # glow_ax.py:299
-        dims = [cond_in + sdim] + [wn['cond_hidden_channels']] * (wn['cond_layers'] - 1) + [2 * C_ * n_layers]
+        cond_out = 2 * C_ * n_layers
+        if wn.get('transposed_conv_scales') and wn.get('transposed_conv_hidden_dim', 256) and wn.get('transposed_conv_kernel_size', 4):
+            # the WN's own TransposedUpsampleNet behind its cond stack (upsample_first is False): the stack ends at the
+            # net's hidden width, the net ends at 2C*n_layers (glow_ax.py:286-295 / 462-470)
+            hid = wn.get('transposed_conv_hidden_dim', 256)
+            self.upsample_net = _TransposedUpsampleNet(hid, cond_out, hid, wn.get('transposed_conv_kernel_size', 4),
+                                                       wn['transposed_conv_scales'], False, False, False, False)
+            cond_out = hid
+        dims = [cond_in + sdim] + [wn['cond_hidden_channels']] * (wn['cond_layers'] - 1) + [cond_out]
         self.cond_layers = nn.ModuleList([_WNConv((dims[l + 1], dims[l], k)) for l in range(wn['cond_layers'])])
         self.in_layers = nn.ModuleList([_WNConv((2 * C_, C_, ks)) for _ in range(n_layers)])
         merge = bool(wn.get('merge_res_skip', False))                            # glow_ax.py:352-355
@@ -285,16 +301,18 @@ class WaveGlow(nn.Module):
             need(n_group <= 32, "waveflow=False with n_group > 32")
         need(cond_residual in (False, True, 0, 1, '1x1conv'), f"cond_residual={cond_residual!r}")
         use_tconv = bool(transposed_conv_scales) and bool(transposed_conv_hidden_dim) and bool(transposed_conv_kernel_size)
-        need(upsample_first in (False, None, True), f"upsample_first={upsample_first!r}")
+        need(upsample_first is False or upsample_first is True or upsample_first is None or upsample_first == 0,
+             f"upsample_first={upsample_first!r}")
         if upsample_first is True:                                # ax:121-126, 174-186: cond upsampled at model level
             need(not waveflow, "upsample_first=True with waveflow=True")
             need(use_tconv, "upsample_first=True without a TransposedUpsampleNet")
-            need(int(np.prod(transposed_conv_scales)) != hop_length // n_group,
-                 "transposed_conv_scales whose product equals hop_length // n_group (the reference crops to an empty "
-                 "tensor there, ax:180-184)")
         else:
             need(not use_tconv, "TransposedUpsampleNet with upsample_first != True")
-        need(not wn.get('transposed_conv_scales'), "WN-level TransposedUpsampleNet")
+        wn_tconv = bool(wn.get('transposed_conv_scales')) and bool(wn.get('transposed_conv_hidden_dim', 256)) \
+            and bool(wn.get('transposed_conv_kernel_size', 4))
+        need(not (wn_tconv and upsample_first is True), "WN-level TransposedUpsampleNet together with upsample_first=True")
+        need(not wn_tconv or wn.get('cond_layers', 1) >= 1, "WN-level TransposedUpsampleNet without WN cond layers")
+        self._wn_tconv_factor = int(np.prod(wn['transposed_conv_scales'])) if wn_tconv else 0
         need(cond_padding_mode in ('zeros', 'replicate') and wn.get('cond_padding_mode', 'zeros') in ('zeros', 'replicate'),
              "cond_padding_mode other than 'zeros' / 'replicate'")
         need(not preceived_vol_scaling, "preceived_vol_scaling")
@@ -390,7 +408,7 @@ class WaveGlow(nn.Module):
             self.z_split_sizes.append(n_rem)
         # one k=1 linear WN cond layer on the bare mel commutes with the interpolation: folded into the in-layer GEMM
         self._folded = (bool(waveflow) and not cond_layers and not speaker_embed and not wn.get('speaker_embed_dim', 0)
-                        and not group_conv_output_dim
+                        and not group_conv_output_dim and not wn_tconv
                         and wn.get('cond_layers', 1) == 1 and wn.get('cond_kernel_size', 1) == 1
                         and self._act_wn[0] == 0)
         self._packed = None
@@ -542,6 +560,10 @@ class WaveGlow(nn.Module):
                        'res_conv': (_CondConv(self.res_conv.weight.detach().float(), self.res_conv.bias, 0, 0.0, device, stream)
                                     if hasattr(self, 'res_conv') else None),            # ax:303-304
                        'group': self._group_conv_ops(device, stream),                  # ax:131-134, 320-321
+                       'wn_tconv': ([[_TransposedConv(m.weight.detach().float(), m.bias, sc, 1 if act else 0, 0.4, device, stream)
+                                      for m, sc, act in zip(c.WN.upsample_net.convs(), c.WN.upsample_net.scales,
+                                                            c.WN.upsample_net.acts)] for c in self.WN]
+                                    if self._wn_tconv_factor else None),                # glow_ax.py:362-373 / 545-554
                        'tconv': ([_TransposedConv(m.weight.detach().float(), m.bias, sc, 1 if act else 0, 0.4, device, stream)
                                   for m, sc, act in zip(self.upsample_net.convs(), self.upsample_net.scales,
                                                         self.upsample_net.acts)]
@@ -551,6 +573,28 @@ class WaveGlow(nn.Module):
             torch.cuda.current_stream(device).synchronize()
         self._packed = (device, blob, ops, key)
         return blob, ops
+
+    def _to_latent_length(self, h, B, rows_n, hT, hld, T, ld, dst, interpolate, stream):
+        """``_upsample_mels`` after the transposed convs (ax:177-185, glow_ax.py:365-372 / 548-553): linear interpolation
+        (align_corners=True) to the latent's length when the net's factor is not hop // n_group, else a centre crop -
+        the 1-D rule ``[pad_l : -pad_r]`` or the 2-D WN's ``[pad : -(pad + pad % 2)]``."""
+        lib = _lib.lib()
+        if interpolate:
+            for b in range(B):
+                _lib.check(lib.ctts_resample_rows_f32(_lib.ptr(h[b]), _lib.ptr(dst[b]), 1, rows_n, hT, hld, PAD, T, ld, PAD, 0,
+                                                      0.0, stream), "ctts_resample_rows_f32")
+            return
+        if self.waveflow:
+            pad = (hT - T) // 2
+            lo, hi = pad, pad + pad % 2
+        else:
+            lo, hi = (hT - T) // 2, -((T - hT) // 2)
+        if hT - lo - hi != T or lo < 0:
+            raise RuntimeError(f"upsampled conditioning of length {hT} cannot be cropped to the latent's {T} columns "
+                               f"(the reference fails on the same shapes)")
+        for b in range(B):      # shifted copy: 'nearest' at scale 1 from the source advanced by `lo` columns
+            _lib.check(lib.ctts_resample_rows_f32(h[b].data_ptr() + 4 * lo, _lib.ptr(dst[b]), 1, rows_n, hT - lo, hld, PAD, T,
+                                                  ld, PAD, 2, 1.0, stream), "ctts_resample_rows_f32")
 
     def _group_conv_ops(self, device, stream):
         """One dense 1x1 operator per flow out of ``n_flow_group_conv``: flow k owns output rows [k*out, (k+1)*out) and,
@@ -643,12 +687,12 @@ class WaveGlow(nn.Module):
             T = out_steps
             ld = _ld_for(T)
             xw = rows(c_wn_in + (0 if grp else sdim) + (16 if grp else 0))
-            for b in range(B):
-                _lib.check(lib.ctts_resample_rows_f32(_lib.ptr(h[b]), _lib.ptr(xw[b]), 1, c_wn_in, hT, hld, PAD,
-                                                      T, ld, PAD, 0, 0.0, stream), "ctts_resample_rows_f32")
+            self._to_latent_length(h, B, c_wn_in, hT, hld, T, ld, xw, factor != self.hop_length // self.n_group, stream)
         # per flow: WN speaker embedding, conv stack -> 2C*n_layers rows
         C2L = 2 * self.WN_config['n_channels'] * self.WN_config['n_layers']
-        frames = torch.zeros(self.n_flows, B, C2L, ld, dtype=torch.float32, device=dev)
+        wn_up = ops.get('wn_tconv')                 # per-flow TransposedUpsampleNet behind the WN cond stack
+        T_out, ld_out = (out_steps, _ld_for(out_steps)) if wn_up else (T, ld)
+        frames = torch.zeros(self.n_flows, B, C2L, ld_out, dtype=torch.float32, device=dev)
         xk = rows(self.wn_cond_channels + sdim) if grp else xw
         for k in range(self.n_flows):
             if grp:                                                              # this flow's chunk of the group conv
@@ -660,10 +704,16 @@ class WaveGlow(nn.Module):
                                                    B, xk.shape[1], T, ld, PAD, stream), "ctts_embed_rows_f32")
             h = xk
             for l, op in enumerate(ops['wn'][k]):
-                y = frames[k] if l == len(ops['wn'][k]) - 1 else rows(op.c_out)
+                y = frames[k] if (l == len(ops['wn'][k]) - 1 and not wn_up) else rows(op.c_out)
                 op(h, y, B, T, ld, stream, self.WN_config.get('cond_padding_mode', 'zeros'))
                 h = y
-        return frames, ld, T
+            if wn_up:                                                            # glow_ax.py:389-390 -> :362-373
+                hT, hld = T, ld
+                for tc in wn_up[k]:
+                    h, hT, hld = tc(h, B, hT, hld, stream)
+                self._to_latent_length(h, B, C2L, hT, hld, T_out, ld_out, frames[k],
+                                       self._wn_tconv_factor != self.hop_length // self.n_group, stream)
+        return frames, ld_out, T_out
 
     # --------------------------------------------------------------------- the path ----
     def inverse(self, z, cond, speaker_ids=None, return_CPU=True):
@@ -694,9 +744,9 @@ class WaveGlow(nn.Module):
                                                         _lib.ptr(audio), B, T, mel.shape[2], _lib.ptr(ws),
                                                         ws.numel() * 4, stream), "ctts_waveflow_inverse_f32")
             else:
-                frames, ld, _ = self._cond_frames(ops, mel, speaker_ids, stream)
+                frames, ld, n_cond = self._cond_frames(ops, mel, speaker_ids, stream, out_steps=T // self.n_group)
                 _lib.check(lib.ctts_waveflow_inverse_cond_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(zz), _lib.ptr(frames),
-                                                             ld, PAD, _lib.ptr(audio), B, T, mel.shape[2], _lib.ptr(ws),
+                                                             ld, PAD, _lib.ptr(audio), B, T, n_cond, _lib.ptr(ws),
                                                              ws.numel() * 4, stream), "ctts_waveflow_inverse_cond_f32")
             if self.preempthasis:      # ax:351-355 (scipy lfilter on the host there; here on the device, in place)
                 _lib.check(lib.ctts_deemphasis_f32(_lib.ptr(audio), _lib.ptr(audio), B, T, float(self.preempthasis),

@@ -147,6 +147,35 @@ def model_cond(sd, cfg, mel, speaker_ids=None):
     return (cond + res).astype(F32)
 
 
+def to_latent_length(cond, L, interpolation_required, two_d):
+    """The tail of ``_upsample_mels`` (ax:177-185 = glow_ax.py:365-372 for the 1-D WN; :548-553 for WN_2d): linear
+    interpolation with align_corners=True when the transposed convs' factor is not hop // n_group and the lengths
+    differ, else a centre crop - ``[pad_l : -pad_r]`` (1-D) or ``[pad : -(pad + pad % 2)]`` (2-D)."""
+    n = cond.shape[2]
+    if interpolation_required and n != L:
+        return lerp_align_corners(cond, L)
+    if two_d:
+        pad = (n - L) // 2
+        out = cond[:, :, pad:n - (pad + pad % 2)]
+    else:
+        pad_l, pad_r = (n - L) // 2, -((L - n) // 2)
+        out = cond[:, :, pad_l:n - pad_r]
+    assert out.shape[2] == L, f"crop of {n} columns to {L} fails in the reference as well"
+    return np.ascontiguousarray(out)
+
+
+def wn_upsample(sd, p, wn, spect, L, upsample_factor, two_d):
+    """``if self.upsample_first is False: spect = self._upsample_mels(spect, audio.shape)`` (glow_ax.py:389-390 / 576-577):
+    the WN's own TransposedUpsampleNet when it has one, then interpolation or crop to the latent's length."""
+    required = True
+    if f"{p}.upsample_net.t_convs.0.weight" in sd:
+        scales = wn["transposed_conv_scales"]
+        spect = transposed_upsample_net(sd, p + ".upsample_net", spect, scales, wn.get("transposed_conv_kernel_size", 4),
+                                        False, False, False)
+        required = int(np.prod(scales)) != upsample_factor
+    return to_latent_length(spect, L, required, two_d)
+
+
 def flow_conds(sd, cfg, cond):
     """efficient_model_ax.py:131-134, 320-321: the optional per-flow 1x1 (grouped) conv of the conditioning,
     ``n_flow_group_conv(cond).chunk(n_flows, dim=1)`` -> list of per-flow tensors; without it every flow gets `cond`."""
@@ -265,7 +294,7 @@ def waveflow_inverse(sd, cfg, z, mel, speaker_ids=None):
                                 wn.get("cond_padding_mode", 'zeros'))
             if wn_act is not None and (wn.get("cond_out_activation_func", True) or l != wn["cond_layers"] - 1):
                 spect = wn_act(spect).astype(F32)
-        cond = lerp_align_corners(spect, L)
+        cond = wn_upsample(sd, p, wn, spect, L, cfg["hop_length"] // G, True)
         ws = _w(sd, p + ".start").reshape(C)
         bs = sd[p + ".start.bias"]
         if sep:

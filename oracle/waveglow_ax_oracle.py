@@ -25,7 +25,7 @@ from __future__ import annotations
 import numpy as np
 
 from .waveflow_oracle import (F32, _shift, _w, activation, conv1d_same, deemphasis, flow_conds, gated_unit, lerp_align_corners,
-                              model_cond, permutation, transposed_upsample_net)
+                              model_cond, permutation, to_latent_length, transposed_upsample_net, wn_upsample)
 
 
 def flow_channels(cfg):
@@ -44,7 +44,7 @@ def mixing_kind(cfg):
     return '1x1conv' if name in "1x1convinvertibleconv1x1invconv" else 'permuteheight'
 
 
-def wn1d(sd, p, wn, a0, frames, speaker_ids, L):
+def wn1d(sd, p, wn, a0, frames, speaker_ids, L, upsample_factor=None):
     """One 1-D WN: a0 [B, h, L], frames [B, c, F] (frame rate) -> (log_s, t), each [B, h, L]."""
     C, n_layers = wn["n_channels"], wn["n_layers"]
     ks = wn.get("kernel_size_w") or wn.get("kernel_size")
@@ -59,7 +59,9 @@ def wn1d(sd, p, wn, a0, frames, speaker_ids, L):
                             wn.get("cond_padding_mode", 'zeros'))
         if act is not None and (wn.get("cond_out_activation_func", True) or l != wn["cond_layers"] - 1):
             spect = act(spect).astype(F32)
-    cond = lerp_align_corners(spect, L)
+    # upsample_first is False: the WN brings its conditioning to the latent's rate itself (glow_ax.py:389-390);
+    # upsample_factor None = it arrives at that rate already (upsample_first=True)
+    cond = spect if upsample_factor is None else wn_upsample(sd, p, wn, spect, L, upsample_factor, False)
     out = None
     for i in range(n_layers):
         d = 2 ** i
@@ -105,8 +107,7 @@ def waveglow_ax_inverse(sd, cfg, z, mel, speaker_ids=None, flow_trace=None):
         frames = transposed_upsample_net(sd, "upsample_net", frames, cfg["transposed_conv_scales"],
                                          cfg["transposed_conv_kernel_size"], True, cfg.get("transposed_conv_residual", False),
                                          cfg.get("transposed_conv_residual_linear", False))
-        assert frames.shape[2] != L, "the reference crops to an empty tensor when no interpolation is required"
-        frames = lerp_align_corners(frames, L)
+        frames = to_latent_length(frames, L, int(np.prod(cfg["transposed_conv_scales"])) != cfg["hop_length"] // G, False)
     frames_k = flow_conds(sd, cfg, frames)
 
     def unmix(k, v):
@@ -120,7 +121,8 @@ def waveglow_ax_inverse(sd, cfg, z, mel, speaker_ids=None, flow_trace=None):
         if not mix_first:
             zz = unmix(k, zz)
         h = zz.shape[1] // 2
-        log_s, t = wn1d(sd, f"WN.{k}.WN", wn, zz[:, :h], frames_k[k], speaker_ids, L)
+        log_s, t = wn1d(sd, f"WN.{k}.WN", wn, zz[:, :h], frames_k[k], speaker_ids, L,
+                        None if cfg.get("upsample_first") is True else cfg["hop_length"] // G)
         with np.errstate(over="ignore", invalid="ignore"):
             a1 = ((zz[:, h:] - t) / np.exp(log_s)).astype(F32)
         zz = np.concatenate([zz[:, :h], a1], axis=1)

@@ -237,7 +237,8 @@ def make_waveflow(full_length=False):
              ("untts_toy", "untts_toy", 2, 7, 0.8, 8),
              # merge_res_skip + GLU on the dense 2-D core; merge_res_skip + GSIRRU on the separable C = 128 core
              ("toy_merge", "toy_merge", 2, 5, 0.7, 9), ("author_toy_gate", "author_toy_gate", 1, 5, 0.7, 10),
-             ("toy_groupconv", "toy_groupconv", 2, 5, 0.7, 11)]
+             ("toy_groupconv", "toy_groupconv", 2, 5, 0.7, 11),
+             ("toy_wn_tconv", "toy_wn_tconv", 2, 6, 0.7, 12), ("toy_wn_tconv_crop", "toy_wn_tconv_crop", 2, 7, 0.7, 13)]
     only = [a for a in sys.argv[2:]]
     if full_length:
         # BASELINE config 4 at the metric's utterance length: one 80x900 mel (~10 s of CPU here)
@@ -290,7 +291,9 @@ def make_waveglow_ax(full_length=False, untts=False, gates=False):
         cases = [(k, 1, 4, 0.8, 40 + i) for i, k in enumerate(sorted(
             k for k in synthetic.WAVEGLOW_AX_CONFIGS if k.startswith("toy_gate_") or k == "toy_merge"))]
         # ... and the per-flow (grouped / dense) 1x1 conv of the conditioning
-        cases += [("toy_groupconv", 2, 5, 0.8, 60), ("toy_groupconv_dense", 2, 6, 0.8, 61)]
+        cases += [("toy_groupconv", 2, 5, 0.8, 60), ("toy_groupconv_dense", 2, 6, 0.8, 61),
+                  # the WN's own TransposedUpsampleNet, interpolated and cropped
+                  ("toy_wn_tconv", 2, 6, 0.8, 62), ("toy_wn_tconv_crop", 2, 7, 0.8, 63)]
         only = sys.argv[2:]
         if only:
             cases = [c for c in cases if c[0] in only]

@@ -14,7 +14,7 @@ from oracle import waveglow_ax_oracle as ao
 WAVE_TOL = 1e-3           # BASELINE.json: waveform RMS relative error
 ORACLE_TOL = 5e-6
 SMALL = ["toy_conv", "toy_conv_mixlast", "toy_permute", "toy_permute_mixfirst", "notebook_toy", "untts_toy", "toy_merge",
-         "toy_groupconv", "toy_groupconv_dense"]
+         "toy_groupconv", "toy_groupconv_dense", "toy_wn_tconv", "toy_wn_tconv_crop"]
 GATES = sorted(k for k in synthetic.WAVEGLOW_AX_CONFIGS if k.startswith("toy_gate_"))       # the 13 non-GTU units
 
 
@@ -74,8 +74,7 @@ def test_host_state_dict_keys_match_reference_format():
     assert float(m.WN[0].WN.end.weight.abs().max()) == 0.0                  # zero-init end (glow_ax.py:278-281)
     with pytest.raises(NotImplementedError):
         WaveGlow(**dict(synthetic.WAVEGLOW_AX_CONFIGS["toy_conv"], upsample_first=True))       # no TransposedUpsampleNet
-    with pytest.raises(NotImplementedError):                                                    # 2*3 == 48 // 8: the
-        WaveGlow(**dict(synthetic.WAVEGLOW_AX_CONFIGS["untts_toy"], hop_length=48))             # reference crops to nothing
+    WaveGlow(**dict(synthetic.WAVEGLOW_AX_CONFIGS["untts_toy"], hop_length=48))   # 2*3 == 48 // 8: cropped, not interpolated
     with pytest.raises(Exception, match="gated_unit is invalid"):                                 # glow_ax.py:198
         WaveGlow(**synthetic.waveglow_ax_config(WN=dict(gated_unit="GXU")))
     mg = WaveGlow(**synthetic.WAVEGLOW_AX_CONFIGS["toy_merge"])
