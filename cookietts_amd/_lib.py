@@ -49,13 +49,14 @@ class WaveFlowConfig(C.Structure):
     """``ctts_waveflow_config``."""
     _fields_ = [(n, C.c_int32) for n in ("n_mel_channels", "n_flows", "n_group", "n_layers", "n_channels",
                                          "kernel_size_w", "kernel_size_h", "dilation_h", "seperable_conv",
-                                         "cond_precomputed", "gated_unit", "merge_res_skip")]
+                                         "cond_precomputed", "gated_unit", "merge_res_skip", "n_early_every", "n_early_size",
+                                         "mixing", "mix_first")]
 
 
 class WaveFlowFlowWeights(C.Structure):
     _fields_ = [("start_w", _FP), ("start_b", _FP), ("cond_w", _FP), ("cond_b", _FP),
                 ("in_w", C.POINTER(_FP)), ("in_b", C.POINTER(_FP)), ("rs_w", C.POINTER(_FP)), ("rs_b", C.POINTER(_FP)),
-                ("end_w", _FP), ("end_b", _FP), ("dw_w", C.POINTER(_FP)), ("dw_b", C.POINTER(_FP))]
+                ("end_w", _FP), ("end_b", _FP), ("dw_w", C.POINTER(_FP)), ("dw_b", C.POINTER(_FP)), ("w_inverse", _FP)]
 
 
 class WgaxConfig(C.Structure):

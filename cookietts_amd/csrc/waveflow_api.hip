@@ -30,8 +30,9 @@ struct WfPlan {
     int C, kmel, nch_in, nch_c;      // nch_c = chunks per (tap) segment
     bool sep, precond;               // separable in-layers; conditioning handed over per flow at frame rate
     int taps;                        // GEMM taps: kh*kw, or 1 behind the depthwise stage
+    std::vector<int> n_rem;          // active latent rows per flow (early outputs, ax:170-189)
     struct Flow {
-        size_t start_w, start_b, end_w, end_b;
+        size_t start_w, start_b, end_w, end_b, winv;
         std::vector<size_t> in_A, in_b, rs_A, rs_b, rs_T, rs_Tb, dw_w, dw_b, sA1, sb1, sA2, sb2;
     };
     std::vector<Flow> fl;
@@ -59,6 +60,19 @@ int make_wf_plan(const ctts_waveflow_config* cfg, WfPlan& p) {
     CTTS_CHECK_ARG(c.dilation_h == 1, "dilation_h=%d (only 1 built)", c.dilation_h);
     CTTS_CHECK_ARG(c.gated_unit >= 0 && c.gated_unit < GATE_KINDS && (c.merge_res_skip == 0 || c.merge_res_skip == 1),
                    "gated_unit=%d merge_res_skip=%d", c.gated_unit, c.merge_res_skip);
+    CTTS_CHECK_ARG((c.mixing == CTTS_MIX_PERMUTE || c.mixing == CTTS_MIX_CONV1X1) && (c.mix_first == 0 || c.mix_first == 1) &&
+                   c.n_early_every >= 0 && c.n_early_size >= 0, "mixing=%d mix_first=%d early %d/%d", c.mixing, c.mix_first,
+                   c.n_early_every, c.n_early_size);
+    CTTS_CHECK_ARG(c.mixing != CTTS_MIX_PERMUTE || c.n_flows % 2 == 0 || c.n_flows == 1, "PermuteHeight requires even n_flows");
+    {
+        int n_rem = c.n_group;
+        p.n_rem.clear();
+        for (int k = 0; k < c.n_flows; ++k) {
+            if (c.n_early_every > 0 && k % c.n_early_every == 0 && k > 0) n_rem -= c.n_early_size;
+            CTTS_CHECK_ARG(n_rem >= 2, "flow %d has %d remaining rows (increase n_group or decrease n_early_every/n_early_size)", k, n_rem);
+            p.n_rem.push_back(n_rem);
+        }
+    }
     p.sep = c.seperable_conv != 0 && !(c.kernel_size_h == 1 && c.kernel_size_w == 1);   // glow_ax.py:521
     p.precond = c.cond_precomputed != 0;
     p.taps = p.sep ? 1 : c.kernel_size_h * c.kernel_size_w;
@@ -77,6 +91,7 @@ int make_wf_plan(const ctts_waveflow_config* cfg, WfPlan& p) {
         auto& f = p.fl[k];
         f.start_w = take(p.C); f.start_b = take(p.C);
         f.end_w = take(2 * p.C); f.end_b = take(2);
+        f.winv = take(c.mixing == CTTS_MIX_CONV1X1 ? (size_t)p.n_rem[k] * p.n_rem[k] : 0);
         for (int i = 0; i < c.n_layers; ++i) {
             f.in_A.push_back(take((size_t)p.in_mb() * p.nch_in * GEMM_KC * WF_BM));
             f.in_b.push_back(take((size_t)p.in_mb() * WF_BM));
@@ -463,6 +478,28 @@ void launch_depthwise_vec(dim3 grid, hipStream_t s, const WfSlots& xs, const flo
     else hipLaunchKernelGGL((wf_depthwise_vec_kernel<KW, 0>), grid, dim3(256), 0, s, xs, w, b, y, C, kh, dw, a_min, L, ld, pad);
 }
 
+// InvertibleConv1x1.inverse over the latent rows (efficient_modules.py:269-286): new[i] = sum_j Winv[i][j] old[j] for
+// the n active logical rows, in place (a thread owns its columns), rows addressed through the logical -> physical map
+__global__ __launch_bounds__(256) void wf_mix_kernel(float* __restrict__ rows, const float* __restrict__ Winv, RowMap map,
+                                                     int n, int G, int Lr) {
+    __shared__ float sW[64 * 64];
+    for (int i = threadIdx.x; i < n * n; i += 256) sW[i] = Winv[i];
+    __syncthreads();
+    const int l = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (l >= Lr) return;
+    float v[64];
+    float* base = rows + (size_t)b * G * Lr + l;
+#pragma unroll 1
+    for (int j = 0; j < n; ++j) v[j] = base[(size_t)map.phys[j] * Lr];
+#pragma unroll 1
+    for (int i = 0; i < n; ++i) {
+        float acc = 0.f;
+#pragma unroll 1
+        for (int j = 0; j < n; ++j) acc = fmaf(sW[i * n + j], v[j], acc);
+        base[(size_t)map.phys[i] * Lr] = acc;
+    }
+}
+
 void wf_permutation(int k, int G, int* perm) {
     for (int g = 0; g < G; ++g) perm[g] = G - 1 - g;                       // reverse (k % 4 in {0,1})
     if (k % 4 == 2 || k % 4 == 3) {                                        // reverse each half separately
@@ -508,25 +545,40 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
         CTTS_CHECK_LAUNCH("wf_interp");
     }
 
-    // logical row g of the current flow lives in physical row phys[g] of w.rows
+    // Logical row g of the current flow lives in physical row phys[g] of w.rows.  With early outputs only the LAST
+    // n_rem rows of the squeezed latent are active at first (the last split, ax:311-313); the earlier chunks re-join in
+    // front, one per n_early_every flows (ax:340-341).
     int phys[64], perm[64], tmp[64];
-    for (int i = 0; i < G; ++i) phys[i] = i;
+    int Ga = p.n_rem[p.c.n_flows - 1];
+    for (int i = 0; i < Ga; ++i) phys[i] = G - Ga + i;
     auto X = [&](int layer, int slot) { return w.X + ((size_t)layer * kh + slot) * w.xslot; };
     const bool fuse = p.fused() && !getenv("CTTS_WF_NO_FUSE");
     const bool sep_fuse = p.sep_fused() && !getenv("CTTS_WF_NO_FUSE");
+    // un-mix of flow k on the active rows: PermuteHeight composes into the map, the 1x1 conv is a pass over the rows
+    auto unmix = [&](int k) -> int {
+        if (p.c.mixing == CTTS_MIX_PERMUTE) {
+            wf_permutation(k, Ga, perm);
+            for (int i = 0; i < Ga; ++i) tmp[i] = phys[perm[i]];
+            for (int i = 0; i < Ga; ++i) phys[i] = tmp[i];
+            return CTTS_OK;
+        }
+        RowMap m;
+        for (int i = 0; i < 64; ++i) m.phys[i] = i < Ga ? phys[i] : 0;
+        hipLaunchKernelGGL(wf_mix_kernel, lgrid, dim3(256), 0, s, w.rows, blob + p.fl[k].winv, m, Ga, G, g.Lr);
+        CTTS_CHECK_LAUNCH("wf_mix");
+        return CTTS_OK;
+    };
 
     for (int k = p.c.n_flows - 1; k >= 0; --k) {
         const auto& f = p.fl[k];
-        wf_permutation(k, G, perm);
-        for (int i = 0; i < G; ++i) tmp[i] = phys[perm[i]];
-        for (int i = 0; i < G; ++i) phys[i] = tmp[i];
+        if (!p.c.mix_first && (rc = unmix(k))) return rc;                      // ax:324-325
         if (p.precond) {   // this flow's conditioning, upsampled once for all rows and layers
             const float* fr = cond + (size_t)k * batch * 2 * C * p.c.n_layers * cond_ld;
             hipLaunchKernelGGL(wf_interp_cond_kernel, dim3((L + 255) / 256, 2 * C * p.c.n_layers, batch), dim3(256), 0, s,
                                fr, w.cond_up, 2 * C, p.c.n_layers, frames, cond_ld, cond_pad, L, g.ld, g.pad, w.cond_slot);
             CTTS_CHECK_LAUNCH("wf_interp_cond");
         }
-        for (int r = 0; r < G - 1; ++r) {
+        for (int r = 0; r < Ga - 1; ++r) {
             const int slot = r % kh;
             hipLaunchKernelGGL(wf_start_kernel, dim3(((L + 3) / 4 + 255) / 256, (C + 15) / 16, batch), dim3(256), 0, s,
                                w.rows, blob + f.start_w, blob + f.start_b, X(0, slot), C, G, phys[r], L, g.Lr, g.ld, g.pad);
@@ -627,6 +679,13 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
         const size_t n4 = (size_t)batch * G * g.Lr / 4;
         hipLaunchKernelGGL(wf_nan_to_zero_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, w.rows, n4);
         CTTS_CHECK_LAUNCH("wf_nan_to_zero");
+        if (p.c.mix_first && (rc = unmix(k))) return rc;                       // ax:337-338
+        if (k > 0 && p.n_rem[k - 1] > Ga) {                                    // ax:340-341: the early chunk re-joins in front
+            const int grow = p.n_rem[k - 1] - Ga;
+            for (int i = Ga - 1; i >= 0; --i) phys[i + grow] = phys[i];
+            for (int i = 0; i < grow; ++i) phys[i] = G - Ga - grow + i;
+            Ga += grow;
+        }
     }
     RowMap map;
     for (int i = 0; i < 64; ++i) map.phys[i] = i < G ? phys[i] : 0;
@@ -663,6 +722,11 @@ int ctts_waveflow_pack_flow(const ctts_waveflow_config* cfg, int32_t k, const ct
     CTTS_CHECK_HIP(hipMemcpyAsync(blob + f.start_b, w->start_b, C * sizeof(float), hipMemcpyDeviceToDevice, s));
     CTTS_CHECK_HIP(hipMemcpyAsync(blob + f.end_w, w->end_w, 2 * C * sizeof(float), hipMemcpyDeviceToDevice, s));
     CTTS_CHECK_HIP(hipMemcpyAsync(blob + f.end_b, w->end_b, 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (p.c.mixing == CTTS_MIX_CONV1X1) {
+        CTTS_CHECK_ARG(w->w_inverse != nullptr, "waveflow pack_flow: 1x1-conv mixing needs w_inverse (flow %d)", k);
+        CTTS_CHECK_HIP(hipMemcpyAsync(blob + f.winv, w->w_inverse, (size_t)p.n_rem[k] * p.n_rem[k] * sizeof(float),
+                                      hipMemcpyDeviceToDevice, s));
+    }
     for (int i = 0; i < p.c.n_layers; ++i) {
         CTTS_CHECK_ARG(w->in_w[i] && w->in_b[i] && w->rs_w[i] && w->rs_b[i], "waveflow pack_flow: NULL layer %d", i);
         CTTS_CHECK_HIP(hipMemsetAsync(blob + f.in_A[i], 0, (size_t)p.in_mb() * p.nch_in * GEMM_KC * WF_BM * sizeof(float), s));

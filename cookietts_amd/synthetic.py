@@ -170,6 +170,15 @@ WAVEFLOW_CONFIGS = {
     "toy_merge": waveflow_config(n_flows=4, n_group=8, n_channels=64, n_layers=3, WN=dict(merge_res_skip=True, gated_unit='GLU')),
     "toy_groupconv": waveflow_config(n_flows=4, n_group=8, n_channels=64, n_layers=2, group_conv_output_dim=16,
                                      group_conv_groupped=True),
+    # InvertibleConv1x1 mixing before the coupling with early outputs; PermuteHeight before the coupling with early
+    # outputs; 1x1 conv after the coupling (the three orders / kinds config 4 does not use)
+    "toy_conv_early": waveflow_config(n_flows=5, n_group=8, n_channels=64, n_layers=2, channel_mixing='1x1conv',
+                                      mix_first=True, n_early_every=2, n_early_size=2),
+    "toy_permute_mixfirst_early": waveflow_config(n_flows=4, n_group=12, n_channels=64, n_layers=2, hop_length=240,
+                                                  win_length=960, channel_mixing='permute', mix_first=True, n_early_every=3,
+                                                  n_early_size=4),
+    "toy_conv_mixlast": waveflow_config(n_flows=4, n_group=8, n_channels=64, n_layers=2, channel_mixing='1x1conv',
+                                        mix_first=False),
     # the 2-D WN's own TransposedUpsampleNet: interpolated (factor 6 vs hop / n_group = 5) and cropped (factor 4 == 32 / 8)
     "toy_wn_tconv": waveflow_config(n_flows=2, n_group=8, n_channels=64, n_layers=2, n_mel_channels=16, hop_length=40,
                                     win_length=160, WN=dict(cond_layers=2, cond_hidden_channels=32,
@@ -453,6 +462,12 @@ def waveflow_state_dict(cfg, seed=1234, end_std=None):
                 wn_conv(f"{p}.in_layers.{i}", (2 * C, C, kh, kw), C * kh * kw)
             rs = 2 * C if (i < n_layers - 1 and not wn.get("merge_res_skip")) else C
             wn_conv(f"{p}.res_skip_layers.{i}", (rs, C, 1, 1), C)
+    if cfg.get("channel_mixing", '1x1conv').lower() in "1x1convinvertibleconv1x1invconv":      # ax:24-25, 148-149
+        for k, n_rem in enumerate(waveglow_ax_flow_channels(cfg)):
+            a = rng.standard_normal((n_rem, n_rem)).astype(np.float64)
+            q, _ = np.linalg.qr(a)
+            q = q + 0.05 * rng.standard_normal((n_rem, n_rem))
+            sd[f"convinv.{k}.weight"] = q.astype(np.float32)[:, :, None]
     return sd
 
 

@@ -291,10 +291,8 @@ class WaveGlow(nn.Module):
                                                          "waveflowpermuteheightpermutechannelpermute")), \
             "channel_mixing option is invalid. Options are '1x1conv' or 'permuteheight'"          # ax:24
         mixing = '1x1conv' if channel_mixing.lower() in "1x1convinvertibleconv1x1invconv" else 'permuteheight'   # ax:25
-        if waveflow:       # the WaveFlow kernels fold the row permutation into addressing: these stay unbuilt there
-            need(mixing == 'permuteheight', "waveflow=True with channel_mixing='1x1conv'")
-            need(not mix_first, "waveflow=True with mix_first=True")
-            need(n_early_every > n_flows, "waveflow=True with early outputs (n_early_every <= n_flows)")
+        if waveflow:
+            need(n_group <= 64, "waveflow=True with n_group > 64")
         else:
             need(not wn.get('seperable_conv', False), "waveflow=False with seperable_conv")
             need(wn['n_channels'] % 128 == 0, "waveflow=False with n_channels not a multiple of 128")
@@ -387,11 +385,20 @@ class WaveGlow(nn.Module):
             self.group_conv_in = wn_cond
             wn_cond = group_conv_output_dim
         self.wn_cond_channels = wn_cond
-        if waveflow:
-            self.WN = nn.ModuleList([_Coupling(_WN2d(wn_cond, wn)) for _ in range(n_flows)])
-            self.convinv = []                                                    # PermuteHeight: no parameters (ax:144)
-            self.z_split_sizes = [n_group]
-        else:                                                                    # ax:166-189
+        if waveflow:                                                             # ax:166-189 (the 2-D WN does not
+            self.WN = nn.ModuleList([_Coupling(_WN2d(wn_cond, wn)) for _ in range(n_flows)])   # depend on the row count)
+            self.convinv = nn.ModuleList() if mixing == '1x1conv' else []        # PermuteHeight: no parameters (ax:144)
+            n_rem = n_group
+            self.z_split_sizes = []
+            for k in range(n_flows):
+                if k % n_early_every == 0 and k > 0:
+                    n_rem -= n_early_size
+                    self.z_split_sizes.append(n_early_size)
+                assert n_rem > 0, "n_remaining_channels is 0. (increase n_group or decrease n_early_every/n_early_size)"
+                if mixing == '1x1conv':
+                    self.convinv.append(InvertibleConv1x1(n_rem))
+            self.z_split_sizes.append(n_rem)
+        else:
             self.WN = nn.ModuleList()
             self.convinv = nn.ModuleList() if mixing == '1x1conv' else []
             n_rem = n_group
@@ -424,6 +431,9 @@ class WaveGlow(nn.Module):
                                    seperable_conv=1 if wn.get('seperable_conv', False) else 0,
                                    gated_unit=_lib.GATED_UNITS[str(wn.get('gated_unit', 'GTU')).upper()],
                                    merge_res_skip=1 if wn.get('merge_res_skip', False) else 0,
+                                   n_early_every=self.n_early_every, n_early_size=self.n_early_size,
+                                   mixing=_lib.MIX_CONV1X1 if self.channel_mixing == '1x1conv' else _lib.MIX_PERMUTE,
+                                   mix_first=1 if self.mix_first else 0,
                                    cond_precomputed=0 if self._folded else 1)
 
     def c_config_1d(self):
@@ -546,6 +556,12 @@ class WaveGlow(nn.Module):
                 fw.rs_b = arr(lambda i: dev(wn.res_skip_layers[i].bias))
                 fw.end_w = dev(wn.end.weight)
                 fw.end_b = dev(wn.end.bias)
+                if self.channel_mixing == '1x1conv':                            # efficient_modules.py:271-276
+                    W = self.convinv[k].weight.detach().squeeze(-1)
+                    W_inverse = W.float().cpu().inverse().to(device).contiguous()
+                    self.convinv[k].W_inverse = W_inverse[..., None]
+                    keep.append(W_inverse)
+                    fw.w_inverse = W_inverse.data_ptr()
                 _lib.check(lib.ctts_waveflow_pack_flow(C.byref(cfg), k, C.byref(fw), _lib.ptr(blob), stream),
                            f"ctts_waveflow_pack_flow({k})")
             ops = None

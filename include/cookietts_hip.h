@@ -198,6 +198,9 @@ int ctts_flow_tail_f32(const ctts_waveglow_config* cfg, const void* packed, int3
  * in-layer GEMM (BASELINE config 4), or an arbitrary per-flow stack evaluated by the caller at frame rate and
  * handed over (cond_precomputed; SURVEY 8f.4: speaker embeddings, model-level and WN-level conv stacks with
  * activations - composed from ctts_conv1d_f32 / ctts_embed_rows_f32 / ctts_scale_add_rows_f32). */
+/* channel mixing between flows (efficient_model_ax.py:139-165) */
+#define CTTS_MIX_PERMUTE 0
+#define CTTS_MIX_CONV1X1 1
 /* WN_config['gated_unit'] names in the order of get_gate_func (glow_ax.py:168-198) */
 #define CTTS_GATE_GTU 0
 #define CTTS_GATE_GTRU 1
@@ -227,6 +230,10 @@ typedef struct ctts_waveflow_config {
     int32_t gated_unit;      /* CTTS_GATE_*: WN_config['gated_unit'] (glow_ax.py:168-198); 0 = 'GTU' */
     int32_t merge_res_skip;  /* 0 | 1: WN_config['merge_res_skip'] (glow_ax.py:612-626: every res_skip layer has C rows,
                                 all of them skip; the layer input stays the `start` output) */
+    int32_t n_early_every;   /* early outputs (ax:170-176, 340-341); 0 or > n_flows: none */
+    int32_t n_early_size;    /* rows leaving the latent at every n_early_every-th flow */
+    int32_t mixing;          /* CTTS_MIX_PERMUTE (PermuteHeight, folded into row addressing) | CTTS_MIX_CONV1X1 */
+    int32_t mix_first;       /* 0 | 1: un-mix after / before the coupling inverse (ax:324-325, 337-338) */
 } ctts_waveflow_config;
 
 /* Dense, weight-norm-folded fp32 weights of one flow in checkpoint layouts
@@ -244,6 +251,7 @@ typedef struct ctts_waveflow_flow_weights {
     const float* end_b;        /* [2] */
     const float* const* dw_w;  /* separable only: n_layers x [C][kh][kw]  depthwise (in_layers.i.0), else NULL */
     const float* const* dw_b;  /* n_layers x [C] */
+    const float* w_inverse;    /* [n_rem_k][n_rem_k] fp32 inverse of convinv.k.weight (CTTS_MIX_CONV1X1), else NULL */
 } ctts_waveflow_flow_weights;
 
 size_t ctts_waveflow_packed_bytes(const ctts_waveflow_config* cfg);
@@ -311,8 +319,6 @@ int ctts_deemphasis_f32(const float* x, float* y, int32_t batch, int32_t T, doub
  * rate (upsample_first=False; `frames` columns, interpolated to the latent's rate inside the gate epilogue) or already
  * at the latent's rate (upsample_first=True, efficient_model_ax.py:116-126, 174-186: model-level TransposedUpsampleNet
  * via ctts_interleave_phases_f32 + ctts_resample_rows_f32; `frames` == samples / n_group, read as it is). */
-#define CTTS_MIX_PERMUTE 0
-#define CTTS_MIX_CONV1X1 1
 typedef struct ctts_wgax_config {
     int32_t n_flows;         /* 48 in the reference's timed notebook config */
     int32_t n_group;         /* 24 (even, <= 32) */

@@ -282,9 +282,26 @@ def waveflow_inverse(sd, cfg, z, mel, speaker_ids=None):
     frames_k = flow_conds(sd, cfg, model_cond(sd, cfg, mel, speaker_ids))
     wn_act = activation(wn.get("cond_activation_func", 'none'), wn.get("negative_slope"))
     sep = bool(wn.get("seperable_conv")) and not (kh == 1 and kw == 1)
+    # early outputs (ax:311-313): the LAST split is the initial latent, earlier chunks re-join in front (ax:340-341)
+    every, esize = cfg.get("n_early_every", 10 ** 9) or 10 ** 9, cfg.get("n_early_size", 0)
+    n_early = sum(1 for k in range(1, n_flows) if k % every == 0)
+    remained = [a[:, i * esize:(i + 1) * esize] for i in range(n_early)]
+    a = a[:, n_early * esize:]
+    name = cfg.get("channel_mixing", '1x1conv').lower()
+    conv_mix = name in "1x1convinvertibleconv1x1invconv"                       # ax:25
+    mix_first = cfg.get("mix_first", True)
+
+    def unmix(k, v):                                                           # PermuteHeight / InvertibleConv1x1 inverse
+        if not conv_mix:
+            return v[:, permutation(k, v.shape[1]), :]
+        w_inv = np.linalg.inv(sd[f"convinv.{k}.weight"][:, :, 0].astype(F32)).astype(F32)
+        return np.matmul(w_inv, v).astype(F32)
+
     for k in reversed(range(n_flows)):
         p = f"WN.{k}.WN"
-        a = a[:, permutation(k, G), :]
+        G = a.shape[1]                                                         # active rows of this flow
+        if not mix_first:
+            a = unmix(k, a)                                                    # ax:324-325
         spect = frames_k[k]
         if wn.get("speaker_embed_dim", 0):
             emb = sd[p + ".speaker_embed.weight"][np.asarray(speaker_ids)]
@@ -294,7 +311,7 @@ def waveflow_inverse(sd, cfg, z, mel, speaker_ids=None):
                                 wn.get("cond_padding_mode", 'zeros'))
             if wn_act is not None and (wn.get("cond_out_activation_func", True) or l != wn["cond_layers"] - 1):
                 spect = wn_act(spect).astype(F32)
-        cond = wn_upsample(sd, p, wn, spect, L, cfg["hop_length"] // G, True)
+        cond = wn_upsample(sd, p, wn, spect, L, cfg["hop_length"] // cfg["n_group"], True)
         ws = _w(sd, p + ".start").reshape(C)
         bs = sd[p + ".start.bias"]
         if sep:
@@ -343,6 +360,11 @@ def waveflow_inverse(sd, cfg, z, mel, speaker_ids=None):
                 y.append(((a[:, r + 1, :] - t) / np.exp(log_s)).astype(F32))
         a = np.stack(y, axis=1)
         a = np.where(np.isnan(a), F32(0), a).astype(F32)
+        if mix_first:
+            a = unmix(k, a)                                                    # ax:337-338
+        if k % every == 0 and k:
+            a = np.concatenate([remained.pop(), a], axis=1)
+    assert not remained
     audio = np.ascontiguousarray(a.transpose(0, 2, 1)).reshape(B, T)
     if cfg.get("preempthasis"):
         audio = deemphasis(audio, cfg["preempthasis"])

@@ -238,7 +238,11 @@ def make_waveflow(full_length=False):
              # merge_res_skip + GLU on the dense 2-D core; merge_res_skip + GSIRRU on the separable C = 128 core
              ("toy_merge", "toy_merge", 2, 5, 0.7, 9), ("author_toy_gate", "author_toy_gate", 1, 5, 0.7, 10),
              ("toy_groupconv", "toy_groupconv", 2, 5, 0.7, 11),
-             ("toy_wn_tconv", "toy_wn_tconv", 2, 6, 0.7, 12), ("toy_wn_tconv_crop", "toy_wn_tconv_crop", 2, 7, 0.7, 13)]
+             ("toy_wn_tconv", "toy_wn_tconv", 2, 6, 0.7, 12), ("toy_wn_tconv_crop", "toy_wn_tconv_crop", 2, 7, 0.7, 13),
+             # InvertibleConv1x1 / PermuteHeight mixing in both orders with early outputs on the 2-D core
+             ("toy_conv_early", "toy_conv_early", 2, 6, 0.7, 14),
+             ("toy_permute_mixfirst_early", "toy_permute_mixfirst_early", 1, 5, 0.8, 15),
+             ("toy_conv_mixlast", "toy_conv_mixlast", 2, 5, 0.7, 16)]
     only = [a for a in sys.argv[2:]]
     if full_length:
         # BASELINE config 4 at the metric's utterance length: one 80x900 mel (~10 s of CPU here)

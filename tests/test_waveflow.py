@@ -20,7 +20,8 @@ def _load(name):
 
 
 ALL = ["toy", "toy_odd", "full_short", "author_toy", "author_short", "untts_toy", "toy_merge", "author_toy_gate",
-       "toy_groupconv", "toy_wn_tconv", "toy_wn_tconv_crop"]   # author_*: SURVEY 8f.4 option set;
+       "toy_groupconv", "toy_wn_tconv", "toy_wn_tconv_crop", "toy_conv_early", "toy_permute_mixfirst_early",
+       "toy_conv_mixlast"]   # author_*: SURVEY 8f.4 option set;
 # untts_toy: the same family with shift_spect / scale_spect (scripts/"UnTTS Inference.ipynb"); toy_merge / author_toy_gate:
 # merge_res_skip with the GLU / GSIRRU gated units on the dense and the separable 2-D core
 
@@ -74,8 +75,8 @@ def test_host_state_dict_keys_match_reference_format():
         own = m.state_dict()
         assert sorted(own) == sorted(sd)
         assert all(tuple(own[k].shape) == sd[k].shape for k in sd)
-    with pytest.raises(NotImplementedError):
-        WaveGlow(**dict(synthetic.WAVEFLOW_CONFIGS["toy"], channel_mixing='1x1conv'))
+    mc = WaveGlow(**synthetic.WAVEFLOW_CONFIGS["toy_conv_early"])
+    assert mc.z_split_sizes == [2, 2, 4] and [tuple(c.weight.shape) for c in mc.convinv] == [(8, 8, 1)] * 2 + [(6, 6, 1)] * 2 + [(4, 4, 1)]
     with pytest.raises(NotImplementedError):
         WaveGlow(**dict(synthetic.WAVEFLOW_CONFIGS["toy"], waveflow=False))
 

@@ -83,8 +83,6 @@ def test_host_state_dict_keys_match_reference_format():
     u = WaveGlow(**synthetic.WAVEGLOW_AX_CONFIGS["untts_toy"])
     assert [type(t).__name__ for t in u.upsample_net.t_convs] == ["ConvTranspose1d", "LeakyReLU"] * 2
     assert tuple(u.res_conv.weight.shape) == (48, 24, 1) and u.upsample_net.res_weight is not None
-    with pytest.raises(NotImplementedError):
-        WaveGlow(**dict(synthetic.WAVEFLOW_CONFIGS["toy"], channel_mixing='1x1conv'))    # waveflow=True + 1x1conv
     with pytest.raises(AssertionError):
         WaveGlow(**dict(synthetic.WAVEGLOW_AX_CONFIGS["toy_conv"], channel_mixing='shuffle'))
 
