@@ -192,8 +192,8 @@ int ctts_flow_tail_f32(const ctts_waveglow_config* cfg, const void* packed, int3
 /* ---- WaveFlow ("ax" core, waveflow=True): _4_mtw/waveglow/efficient_model_ax.py --------- */
 
 /* Constructor arguments that shape the path (efficient_model_ax.py:19-169, glow_ax.py:427-543).
- * Built: channel_mixing='permuteheight', mix_first=False, all fourteen gated units, res_skip=True, merge_res_skip,
- * n_early_every > n_flows, linear upsampling; in-layers dense (kh*kw <= 11 taps) or separable (depthwise kh x kw
+ * Built: PermuteHeight (folded into row addressing) or InvertibleConv1x1 mixing in both orders (mix_first), early
+ * outputs, all fourteen gated units, res_skip=True, merge_res_skip, linear upsampling; in-layers dense (kh*kw <= 11 taps) or separable (depthwise kh x kw
  * + pointwise, glow_ax.py:525-531); conditioning either ONE k=1 linear WN cond layer on the mel, folded into the
  * in-layer GEMM (BASELINE config 4), or an arbitrary per-flow stack evaluated by the caller at frame rate and
  * handed over (cond_precomputed; SURVEY 8f.4: speaker embeddings, model-level and WN-level conv stacks with
