@@ -208,6 +208,7 @@ SIGNATURES = {
     "ctts_taco_stop_rule_f32": (C.c_int, [_FP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _FP, _FP]),
     "ctts_affine_rows_f32": (C.c_int, [_FP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                        C.c_float, _FP]),
+    "ctts_vol_unscale_f32": (C.c_int, [_FP, C.c_int64, _FP]),
     "ctts_resample_rows_f32": (C.c_int, [_FP, _FP] + [C.c_int32] * 9 + [C.c_float, _FP]),
     "ctts_interleave_phases_f32": (C.c_int, [_FP, _FP] + [C.c_int32] * 10 + [_FP]),
     "ctts_set_f32_gemm_mode": (C.c_int, [C.c_int32]),

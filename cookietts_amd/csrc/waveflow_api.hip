@@ -396,6 +396,15 @@ __global__ __launch_bounds__(256) void interleave_phases_kernel(const float* __r
     y[((size_t)b * C + c) * ld_out + pad_out + n] = v;
 }
 
+// inverse of the "perceived volume" companding (efficient_model_ax.py:342-344): z > 0 -> 10^log2(z), z < 0 -> -(10^log2(-z))
+__global__ __launch_bounds__(256) void vol_unscale_kernel(float* __restrict__ x, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    if (v > 0.f) x[i] = powf(10.0f, log2f(v));
+    else if (v < 0.f) x[i] = -powf(10.0f, log2f(-v));
+}
+
 // y[n] = x[n] + p * y[n-1], one workgroup per utterance, fp64 state (scipy.signal.lfilter([1],[1,-p]) runs in
 // float64 on the reference's CPU path, ax:351-355).  Thread t owns one contiguous span: pass 1 runs the recurrence
 // from a zero state to get the span's own contribution, thread 0 chains the 256 span ends
@@ -838,6 +847,13 @@ int ctts_interleave_phases_f32(const float* phases, float* y, int32_t batch, int
     hipLaunchKernelGGL(interleave_phases_kernel, dim3((T_out + 255) / 256, C, batch), dim3(256), 0, as_stream(stream), phases,
                        y, C, stride, padding, T_in, ld_in, pad_in, T_out, ld_out, pad_out, (size_t)batch * C * ld_in);
     CTTS_CHECK_LAUNCH("interleave_phases");
+    return CTTS_OK;
+}
+
+int ctts_vol_unscale_f32(float* x, int64_t n, void* stream) {
+    CTTS_CHECK_ARG(x && n >= 1, "vol_unscale: bad argument");
+    hipLaunchKernelGGL(vol_unscale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, (size_t)n);
+    CTTS_CHECK_LAUNCH("vol_unscale");
     return CTTS_OK;
 }
 

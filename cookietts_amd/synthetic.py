@@ -179,6 +179,12 @@ WAVEFLOW_CONFIGS = {
                                                   n_early_size=4),
     "toy_conv_mixlast": waveflow_config(n_flows=4, n_group=8, n_channels=64, n_layers=2, channel_mixing='1x1conv',
                                         mix_first=False),
+    # model-level TransposedUpsampleNet (upsample_first=True) in front of the 2-D core
+    "toy_upsample_first": waveflow_config(n_flows=2, n_group=8, n_channels=64, n_layers=2, n_mel_channels=16, hop_length=40,
+                                          win_length=160, upsample_first=True, transposed_conv_hidden_dim=24,
+                                          transposed_conv_kernel_size=[4, 9], transposed_conv_scales=[2, 3],
+                                          transposed_conv_output_dim=20, transposed_conv_residual=True,
+                                          transposed_conv_residual_linear=True, transposed_conv_res_rezero=False),
     # the 2-D WN's own TransposedUpsampleNet: interpolated (factor 6 vs hop / n_group = 5) and cropped (factor 4 == 32 / 8)
     "toy_wn_tconv": waveflow_config(n_flows=2, n_group=8, n_channels=64, n_layers=2, n_mel_channels=16, hop_length=40,
                                     win_length=160, WN=dict(cond_layers=2, cond_hidden_channels=32,
@@ -290,6 +296,11 @@ WAVEGLOW_AX_CONFIGS = {
                                                    hop_length=40, win_length=160, speaker_embed=8, cond_hidden=48,
                                                    cond_output=48, t_hidden=48, t_kernels=(4, 9), t_scales=(2, 3), t_output=32),
                           group_conv_output_dim=24, group_conv_groupped=True),
+    # sigmoid conditioning activations at model and WN level + the "perceived volume" companding of the output
+    "toy_sigmoid_vol": waveglow_ax_config(n_flows=2, n_group=8, n_layers=2, n_mel_channels=16, cond_layers=2,
+                                          cond_activation_func='sigmoid', cond_hidden_channels=24, cond_output_channels=20,
+                                          preceived_vol_scaling=True,
+                                          WN=dict(cond_layers=2, cond_hidden_channels=24, cond_activation_func='sigmoid')),
     # the WN's own TransposedUpsampleNet behind its cond stack: factor 6 != hop / n_group = 5 (interpolated), and
     # factor 4 == hop / n_group (centre-cropped: the mel carries one frame more than the latent)
     "toy_wn_tconv": waveglow_ax_config(n_flows=2, n_group=8, n_layers=2, n_mel_channels=16, hop_length=40, win_length=160,
@@ -435,6 +446,21 @@ def waveflow_state_dict(cfg, seed=1234, end_std=None):
         dims = [c_in] + [cfg["cond_hidden_channels"]] * (cfg["cond_layers"] - 1) + [c_wn]
         for l in range(cfg["cond_layers"]):
             wn_conv(f"cond_layers.{l}", (dims[l + 1], dims[l], k), dims[l] * k)
+    if cfg.get("upsample_first") is True:                                        # ax:116-126
+        t_out = cfg.get("transposed_conv_output_dim") or c_wn
+        if cfg.get("transposed_conv_res_rezero"):
+            sd["upsample_net.res_weight"] = np.array([0.4], np.float32)
+        hid, ksz, scales = cfg["transposed_conv_hidden_dim"], cfg["transposed_conv_kernel_size"], cfg["transposed_conv_scales"]
+        idx = 0
+        for i, sc in enumerate(scales):
+            last = i + 1 == len(scales)
+            ind, outd = (c_wn if i == 0 else hid), (t_out if last else hid)
+            kk = ksz[i] if isinstance(ksz, (list, tuple)) else ksz
+            bound = 1.0 / np.sqrt(ind * kk / sc)
+            sd[f"upsample_net.t_convs.{idx}.weight"] = _uniform(rng, (ind, outd, kk), bound)
+            sd[f"upsample_net.t_convs.{idx}.bias"] = _uniform(rng, (outd,), bound)
+            idx += 2
+        c_wn = t_out
     c_wn = _group_conv_params(rng, sd, cfg, c_wn)
     sdim = wn.get("speaker_embed_dim", 0)
     for k in range(cfg["n_flows"]):

@@ -160,7 +160,9 @@ def _act_code(name, negative_slope):
         return 1, float(negative_slope)
     if name == 'tanh':
         return 2, 0.0
-    raise NotImplementedError(f"cond_activation_func={name!r} is not built on the HIP path")
+    if name == 'sigmoid':
+        return 3, 0.0          # composed in _CondConv: sigmoid(x) = (tanh(x / 2) + 1) / 2
+    raise NotImplementedError(name)                                            # ax:111
 
 
 class _CondConv:
@@ -171,9 +173,12 @@ class _CondConv:
         lib = _lib.lib()
         out_c, in_c, k = w.shape
         self.c_in, self.c_out = -(-in_c // 16) * 16, out_c
+        self.sigmoid = act == 3
         wp = torch.zeros(out_c, self.c_in, k, dtype=torch.float32, device=device)
         wp[:, :in_c] = w
         b = b.detach().float().contiguous()
+        if self.sigmoid:       # tanh epilogue on the halved pre-activation, then (t + 1) / 2 with ctts_affine_rows_f32
+            wp, b, act = wp * 0.5, b * 0.5, 2
         self.desc = _lib.Conv1dDesc(c_in=self.c_in, c_out=out_c, kernel_size=k, act=act, slope=slope)
         nbytes = lib.ctts_conv1d_packed_bytes(C.byref(self.desc))
         if nbytes == 0:
@@ -193,6 +198,9 @@ class _CondConv:
         for b in range(B):
             _lib.check(_lib.lib().ctts_conv1d_f32(C.byref(self.desc), _lib.ptr(self.blob), _lib.ptr(x[b]), _lib.ptr(y[b]),
                                                  0, 1, T, ld, PAD, stream), "ctts_conv1d_f32")
+            if self.sigmoid:
+                _lib.check(_lib.lib().ctts_affine_rows_f32(_lib.ptr(y[b]), 1, y.shape[1], self.c_out, T, ld, PAD, 1.0, 0.5,
+                                                           stream), "ctts_affine_rows_f32")
 
 
 def _r16(n):
@@ -302,8 +310,10 @@ class WaveGlow(nn.Module):
         need(upsample_first is False or upsample_first is True or upsample_first is None or upsample_first == 0,
              f"upsample_first={upsample_first!r}")
         if upsample_first is True:                                # ax:121-126, 174-186: cond upsampled at model level
-            need(not waveflow, "upsample_first=True with waveflow=True")
             need(use_tconv, "upsample_first=True without a TransposedUpsampleNet")
+            need(transposed_conv_residual_linear or not transposed_conv_residual,
+                 "transposed_conv_residual with 'nearest' interpolation (F.interpolate rejects align_corners there: the "
+                 "reference raises ValueError, glow_ax.py:231)")
         else:
             need(not use_tconv, "TransposedUpsampleNet with upsample_first != True")
         wn_tconv = bool(wn.get('transposed_conv_scales')) and bool(wn.get('transposed_conv_hidden_dim', 256)) \
@@ -313,7 +323,6 @@ class WaveGlow(nn.Module):
         self._wn_tconv_factor = int(np.prod(wn['transposed_conv_scales'])) if wn_tconv else 0
         need(cond_padding_mode in ('zeros', 'replicate') and wn.get('cond_padding_mode', 'zeros') in ('zeros', 'replicate'),
              "cond_padding_mode other than 'zeros' / 'replicate'")
-        need(not preceived_vol_scaling, "preceived_vol_scaling")
         need(not load_hidden_from_disk, "hidden cond from disk")
         need(not unsupported.get('iso226_empthasis', False), "iso226 emphasis")
         need(wn.get('cond_layers', 1) >= 1, "WN without cond layers")
@@ -348,6 +357,7 @@ class WaveGlow(nn.Module):
         self.multispeaker = speaker_embed > 0 or wn.get('speaker_embed_dim', 0) > 0
         self.cond_residual, self.cond_res_rezero = cond_residual, cond_res_rezero
         self.shift_spect, self.scale_spect = float(shift_spect), float(scale_spect)
+        self.vol_scaling = bool(preceived_vol_scaling)
         self.upsample_early = upsample_first is True
         self.WN_config = wn
         # activation tables (validated now so that an unsupported name fails at construction)
@@ -415,7 +425,8 @@ class WaveGlow(nn.Module):
             self.z_split_sizes.append(n_rem)
         # one k=1 linear WN cond layer on the bare mel commutes with the interpolation: folded into the in-layer GEMM
         self._folded = (bool(waveflow) and not cond_layers and not speaker_embed and not wn.get('speaker_embed_dim', 0)
-                        and not group_conv_output_dim and not wn_tconv
+                        and not group_conv_output_dim and not wn_tconv and not self.upsample_early
+                        and self.shift_spect == 0. and self.scale_spect == 1.
                         and wn.get('cond_layers', 1) == 1 and wn.get('cond_kernel_size', 1) == 1
                         and self._act_wn[0] == 0)
         self._packed = None
@@ -764,6 +775,8 @@ class WaveGlow(nn.Module):
                 _lib.check(lib.ctts_waveflow_inverse_cond_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(zz), _lib.ptr(frames),
                                                              ld, PAD, _lib.ptr(audio), B, T, n_cond, _lib.ptr(ws),
                                                              ws.numel() * 4, stream), "ctts_waveflow_inverse_cond_f32")
+            if self.vol_scaling:       # ax:342-344
+                _lib.check(lib.ctts_vol_unscale_f32(_lib.ptr(audio), audio.numel(), stream), "ctts_vol_unscale_f32")
             if self.preempthasis:      # ax:351-355 (scipy lfilter on the host there; here on the device, in place)
                 _lib.check(lib.ctts_deemphasis_f32(_lib.ptr(audio), _lib.ptr(audio), B, T, float(self.preempthasis),
                                                   stream), "ctts_deemphasis_f32")
@@ -797,6 +810,8 @@ class WaveGlow(nn.Module):
             _lib.check(lib.ctts_wgax_inverse_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(zz), _lib.ptr(frames), ld, PAD,
                                                  n_cond, _lib.ptr(audio), B, T, _lib.ptr(ws), ws.numel() * 4,
                                                  stream), "ctts_wgax_inverse_f32")
+            if self.vol_scaling:
+                _lib.check(lib.ctts_vol_unscale_f32(_lib.ptr(audio), audio.numel(), stream), "ctts_vol_unscale_f32")
             if self.preempthasis:
                 _lib.check(lib.ctts_deemphasis_f32(_lib.ptr(audio), _lib.ptr(audio), B, T, float(self.preempthasis),
                                                   stream), "ctts_deemphasis_f32")

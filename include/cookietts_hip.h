@@ -282,6 +282,7 @@ int ctts_waveflow_inverse_cond_f32(const ctts_waveflow_config* cfg, const void* 
  *   scale_add_rows: y = alpha * x + r   (r may be NULL; alpha read from the device: the rezero parameter, ax:299-307)
  *   deemphasis:     y[n] = x[n] + p * y[n-1] per utterance, fp64 recurrence like scipy.signal.lfilter (ax:351-355);
  *                   in place (y == x) allowed
+ *   vol_unscale:    x > 0 -> 10^log2(x), x < 0 -> -(10^log2(-x)) in place over n floats (preceived_vol_scaling, ax:342-344)
  *   affine_rows:    x = (x + shift) * scale on rows [0, rows), valid columns only (shift_spect / scale_spect, ax:206-209)
  *   resample_rows:  F.interpolate along time, padded rows in and out: mode 0 'linear' align_corners=True to T_out
  *                   (ax:174, glow_ax.py:365), mode 1 'linear' align_corners=False and mode 2 'nearest' with the given
@@ -290,6 +291,7 @@ int ctts_waveflow_inverse_cond_f32(const ctts_waveflow_config* cfg, const void* 
  *                   input positions, one per output residue r = (n + padding) mod stride, each run with
  *                   ctts_conv1d_f32 into phases[r] ([stride][B][C][ld_in]); this call writes
  *                   y[n] = phases[(n + padding) % stride][(n + padding) / stride] for n in [0, T_out) */
+int ctts_vol_unscale_f32(float* x, int64_t n, void* stream);
 int ctts_affine_rows_f32(float* x, int32_t batch, int32_t C, int32_t rows, int32_t T, int32_t ld, int32_t pad, float shift,
                          float scale, void* stream);
 int ctts_resample_rows_f32(const float* x, float* y, int32_t batch, int32_t C, int32_t T_in, int32_t ld_in, int32_t pad_in,

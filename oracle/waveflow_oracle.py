@@ -279,7 +279,13 @@ def waveflow_inverse(sd, cfg, z, mel, speaker_ids=None):
     B, T = z.shape
     L = T // G
     a = np.ascontiguousarray(z.reshape(B, L, G).transpose(0, 2, 1))        # a[b, g, l] = z[b, G*l + g]
-    frames_k = flow_conds(sd, cfg, model_cond(sd, cfg, mel, speaker_ids))
+    frames = model_cond(sd, cfg, mel, speaker_ids)
+    if cfg.get("upsample_first") is True:                                  # ax:318-319 -> _upsample_mels :174-186
+        frames = transposed_upsample_net(sd, "upsample_net", frames, cfg["transposed_conv_scales"],
+                                         cfg["transposed_conv_kernel_size"], True, cfg.get("transposed_conv_residual", False),
+                                         cfg.get("transposed_conv_residual_linear", False))
+        frames = to_latent_length(frames, L, int(np.prod(cfg["transposed_conv_scales"])) != cfg["hop_length"] // G, False)
+    frames_k = flow_conds(sd, cfg, frames)
     wn_act = activation(wn.get("cond_activation_func", 'none'), wn.get("negative_slope"))
     sep = bool(wn.get("seperable_conv")) and not (kh == 1 and kw == 1)
     # early outputs (ax:311-313): the LAST split is the initial latent, earlier chunks re-join in front (ax:340-341)
@@ -311,7 +317,8 @@ def waveflow_inverse(sd, cfg, z, mel, speaker_ids=None):
                                 wn.get("cond_padding_mode", 'zeros'))
             if wn_act is not None and (wn.get("cond_out_activation_func", True) or l != wn["cond_layers"] - 1):
                 spect = wn_act(spect).astype(F32)
-        cond = wn_upsample(sd, p, wn, spect, L, cfg["hop_length"] // cfg["n_group"], True)
+        # `if not self.upsample_first:` (glow_ax.py:576-577): the WN upsamples unless the model already did
+        cond = spect if cfg.get("upsample_first") else wn_upsample(sd, p, wn, spect, L, cfg["hop_length"] // cfg["n_group"], True)
         ws = _w(sd, p + ".start").reshape(C)
         bs = sd[p + ".start.bias"]
         if sep:
@@ -366,6 +373,11 @@ def waveflow_inverse(sd, cfg, z, mel, speaker_ids=None):
             a = np.concatenate([remained.pop(), a], axis=1)
     assert not remained
     audio = np.ascontiguousarray(a.transpose(0, 2, 1)).reshape(B, T)
+    if cfg.get("preceived_vol_scaling"):                                   # ax:342-344
+        with np.errstate(divide="ignore", invalid="ignore"):
+            pos = np.power(F32(10.0), np.log2(np.where(audio > 0, audio, F32(1)))).astype(F32)
+            neg = -np.power(F32(10.0), np.log2(np.where(audio < 0, -audio, F32(1)))).astype(F32)
+        audio = np.where(audio > 0, pos, np.where(audio < 0, neg, audio)).astype(F32)
     if cfg.get("preempthasis"):
         audio = deemphasis(audio, cfg["preempthasis"])
     return audio

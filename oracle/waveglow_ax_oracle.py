@@ -135,6 +135,11 @@ def waveglow_ax_inverse(sd, cfg, z, mel, speaker_ids=None, flow_trace=None):
             flow_trace.append(zz.copy())
     assert not remained
     audio = np.ascontiguousarray(zz.transpose(0, 2, 1)).reshape(B, T)
+    if cfg.get("preceived_vol_scaling"):                                   # ax:342-344
+        with np.errstate(divide="ignore", invalid="ignore"):
+            pos = np.power(F32(10.0), np.log2(np.where(audio > 0, audio, F32(1)))).astype(F32)
+            neg = -np.power(F32(10.0), np.log2(np.where(audio < 0, -audio, F32(1)))).astype(F32)
+        audio = np.where(audio > 0, pos, np.where(audio < 0, neg, audio)).astype(F32)
     if cfg.get("preempthasis"):
         audio = deemphasis(audio, cfg["preempthasis"])
     return audio

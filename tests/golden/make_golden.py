@@ -242,7 +242,8 @@ def make_waveflow(full_length=False):
              # InvertibleConv1x1 / PermuteHeight mixing in both orders with early outputs on the 2-D core
              ("toy_conv_early", "toy_conv_early", 2, 6, 0.7, 14),
              ("toy_permute_mixfirst_early", "toy_permute_mixfirst_early", 1, 5, 0.8, 15),
-             ("toy_conv_mixlast", "toy_conv_mixlast", 2, 5, 0.7, 16)]
+             ("toy_conv_mixlast", "toy_conv_mixlast", 2, 5, 0.7, 16),
+             ("toy_upsample_first", "toy_upsample_first", 2, 6, 0.7, 17)]
     only = [a for a in sys.argv[2:]]
     if full_length:
         # BASELINE config 4 at the metric's utterance length: one 80x900 mel (~10 s of CPU here)
@@ -297,7 +298,9 @@ def make_waveglow_ax(full_length=False, untts=False, gates=False):
         # ... and the per-flow (grouped / dense) 1x1 conv of the conditioning
         cases += [("toy_groupconv", 2, 5, 0.8, 60), ("toy_groupconv_dense", 2, 6, 0.8, 61),
                   # the WN's own TransposedUpsampleNet, interpolated and cropped
-                  ("toy_wn_tconv", 2, 6, 0.8, 62), ("toy_wn_tconv_crop", 2, 7, 0.8, 63)]
+                  ("toy_wn_tconv", 2, 6, 0.8, 62), ("toy_wn_tconv_crop", 2, 7, 0.8, 63),
+                  # sigmoid conditioning activations + preceived_vol_scaling
+                  ("toy_sigmoid_vol", 2, 5, 0.5, 64)]
         only = sys.argv[2:]
         if only:
             cases = [c for c in cases if c[0] in only]

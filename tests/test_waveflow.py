@@ -21,7 +21,7 @@ def _load(name):
 
 ALL = ["toy", "toy_odd", "full_short", "author_toy", "author_short", "untts_toy", "toy_merge", "author_toy_gate",
        "toy_groupconv", "toy_wn_tconv", "toy_wn_tconv_crop", "toy_conv_early", "toy_permute_mixfirst_early",
-       "toy_conv_mixlast"]   # author_*: SURVEY 8f.4 option set;
+       "toy_conv_mixlast", "toy_upsample_first"]   # author_*: SURVEY 8f.4 option set;
 # untts_toy: the same family with shift_spect / scale_spect (scripts/"UnTTS Inference.ipynb"); toy_merge / author_toy_gate:
 # merge_res_skip with the GLU / GSIRRU gated units on the dense and the separable 2-D core
 
@@ -88,6 +88,26 @@ def _model(key, seed):
     m = WaveGlow(**cfg)
     m.load_state_dict(synthetic.to_torch(sd))
     return m.cuda().eval(), cfg, sd
+
+
+@pytest.mark.gpu
+def test_hip_shift_scale_disable_the_folded_cond_layer(hip_lib_path):
+    """config-4-style model (one linear WN cond layer, normally folded into the in-layer GEMM on the raw mel) with
+    shift_spect / scale_spect: the mel must be shifted and scaled first (ax:281-284), so the fold is off."""
+    from cookietts_amd.waveglow_ax import WaveGlow
+    cfg = dict(synthetic.WAVEFLOW_CONFIGS["toy"], shift_spect=2.0, scale_spect=0.5)
+    sd = synthetic.waveflow_state_dict(cfg, seed=21)
+    m = WaveGlow(**cfg)
+    m.load_state_dict(synthetic.to_torch(sd))
+    m = m.cuda().eval()
+    assert not m._folded and WaveGlow(**synthetic.WAVEFLOW_CONFIGS["toy"])._folded
+    mel = synthetic.synthetic_mel(2, 5, seed=21)
+    melp = np.pad(mel, ((0, 0), (0, 0), (0, 1)))
+    z = np.random.default_rng(21).standard_normal((2, 5 * cfg["hop_length"])).astype(np.float32) * np.float32(0.7)
+    ref = wf.waveflow_inverse(sd, cfg, z, melp)
+    got, _ = m.inverse(torch.from_numpy(z).cuda(), torch.from_numpy(melp).cuda())
+    assert rms_rel_err(got.numpy(), ref) < WAVE_TOL
+    assert rms_rel_err(got.numpy(), wf.waveflow_inverse(sd, synthetic.WAVEFLOW_CONFIGS["toy"], z, melp)) > 1e-2   # it matters
 
 
 @pytest.mark.gpu
