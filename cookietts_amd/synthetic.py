@@ -179,6 +179,8 @@ WAVEFLOW_CONFIGS = {
                                                   n_early_size=4),
     "toy_conv_mixlast": waveflow_config(n_flows=4, n_group=8, n_channels=64, n_layers=2, channel_mixing='1x1conv',
                                         mix_first=False),
+    "toy_no_res_skip": waveflow_config(n_flows=2, n_group=8, n_channels=64, n_layers=3,
+                                       WN=dict(res_skip=False, merge_res_skip=True)),
     # model-level TransposedUpsampleNet (upsample_first=True) in front of the 2-D core
     "toy_upsample_first": waveflow_config(n_flows=2, n_group=8, n_channels=64, n_layers=2, n_mel_channels=16, hop_length=40,
                                           win_length=160, upsample_first=True, transposed_conv_hidden_dim=24,
@@ -296,6 +298,9 @@ WAVEGLOW_AX_CONFIGS = {
                                                    hop_length=40, win_length=160, speaker_embed=8, cond_hidden=48,
                                                    cond_output=48, t_hidden=48, t_kernels=(4, 9), t_scales=(2, 3), t_output=32),
                           group_conv_output_dim=24, group_conv_groupped=True),
+    # res_skip=False: the gated activations are the skip (with merge_res_skip; and the single-layer case without it)
+    "toy_no_res_skip": waveglow_ax_config(n_flows=2, n_group=8, n_layers=3, WN=dict(res_skip=False, merge_res_skip=True)),
+    "toy_no_res_skip_1layer": waveglow_ax_config(n_flows=2, n_group=8, n_layers=1, WN=dict(res_skip=False)),
     # sigmoid conditioning activations at model and WN level + the "perceived volume" companding of the output
     "toy_sigmoid_vol": waveglow_ax_config(n_flows=2, n_group=8, n_layers=2, n_mel_channels=16, cond_layers=2,
                                           cond_activation_func='sigmoid', cond_hidden_channels=24, cond_output_channels=20,
@@ -395,7 +400,8 @@ def waveglow_ax_state_dict(cfg, seed=1234, end_std=None):
                           wn.get("transposed_conv_kernel_size", 4), wn["transposed_conv_scales"])
         for i in range(n_layers):
             _wn_conv(rng, sd, f"{p}.in_layers.{i}", 2 * C, C, ks)
-            _wn_conv(rng, sd, f"{p}.res_skip_layers.{i}", 2 * C if (i < n_layers - 1 and not wn.get("merge_res_skip")) else C, C, 1)
+            if wn.get("res_skip", True):
+                _wn_conv(rng, sd, f"{p}.res_skip_layers.{i}", 2 * C if (i < n_layers - 1 and not wn.get("merge_res_skip")) else C, C, 1)
         if conv_mix:
             a = rng.standard_normal((n_rem, n_rem)).astype(np.float64)
             q, _ = np.linalg.qr(a)
@@ -487,7 +493,8 @@ def waveflow_state_dict(cfg, seed=1234, end_std=None):
             else:
                 wn_conv(f"{p}.in_layers.{i}", (2 * C, C, kh, kw), C * kh * kw)
             rs = 2 * C if (i < n_layers - 1 and not wn.get("merge_res_skip")) else C
-            wn_conv(f"{p}.res_skip_layers.{i}", (rs, C, 1, 1), C)
+            if wn.get("res_skip", True):
+                wn_conv(f"{p}.res_skip_layers.{i}", (rs, C, 1, 1), C)
     if cfg.get("channel_mixing", '1x1conv').lower() in "1x1convinvertibleconv1x1invconv":      # ax:24-25, 148-149
         for k, n_rem in enumerate(waveglow_ax_flow_channels(cfg)):
             a = rng.standard_normal((n_rem, n_rem)).astype(np.float64)

@@ -90,7 +90,8 @@ class _WN2d(nn.Module):
             self.in_layers = nn.ModuleList([_WNConv((2 * C_, C_, kh, kw)) for _ in range(n_layers)])
         merge = bool(wn.get('merge_res_skip', False))                            # glow_ax.py:535-538
         self.res_skip_layers = nn.ModuleList([
-            _WNConv((2 * C_ if (i < n_layers - 1 and not merge) else C_, C_, 1, 1)) for i in range(n_layers)])
+            _WNConv((2 * C_ if (i < n_layers - 1 and not merge) else C_, C_, 1, 1)) for i in range(n_layers)]
+            if wn.get('res_skip', True) else [])                                 # res_skip=False: acts are the skip (:609)
 
 
 class _WN1d(nn.Module):
@@ -123,7 +124,8 @@ class _WN1d(nn.Module):
         self.in_layers = nn.ModuleList([_WNConv((2 * C_, C_, ks)) for _ in range(n_layers)])
         merge = bool(wn.get('merge_res_skip', False))                            # glow_ax.py:352-355
         self.res_skip_layers = nn.ModuleList([
-            _WNConv((2 * C_ if (i < n_layers - 1 and not merge) else C_, C_, 1)) for i in range(n_layers)])
+            _WNConv((2 * C_ if (i < n_layers - 1 and not merge) else C_, C_, 1)) for i in range(n_layers)]
+            if wn.get('res_skip', True) else [])                                 # res_skip=False: acts are the skip (:401)
 
 
 class InvertibleConv1x1(nn.Module):
@@ -327,7 +329,12 @@ class WaveGlow(nn.Module):
         need(not unsupported.get('iso226_empthasis', False), "iso226 emphasis")
         need(wn.get('cond_layers', 1) >= 1, "WN without cond layers")
         need(wn.get('upsample_mode', 'linear') == 'linear', "WN upsample_mode != 'linear'")
-        need(wn.get('res_skip', True), "res_skip=False")
+        if waveflow:                                                            # glow_ax.py:259 / :433
+            assert wn.get('res_skip', True) or wn.get('merge_res_skip', False), \
+                "Cannot remove res_skip without using merge_res_skip"
+        else:
+            assert (wn.get('res_skip', True) or wn.get('merge_res_skip', False)) or wn['n_layers'] == 1, \
+                "Cannot remove res_skip without using merge_res_skip"
         if str(wn.get('gated_unit', 'GTU')).upper() not in _lib.GATED_UNITS:
             raise Exception("gated_unit is invalid\nOptions are ('GTU','GTRU','GLU').")     # glow_ax.py:198
         assert not wn.get('rezero', False), "WN ReZero is depreciated"                         # glow_ax.py:272, 450
@@ -441,7 +448,7 @@ class WaveGlow(nn.Module):
                                    kernel_size_w=wn['kernel_size_w'], kernel_size_h=wn['kernel_size_h'], dilation_h=1,
                                    seperable_conv=1 if wn.get('seperable_conv', False) else 0,
                                    gated_unit=_lib.GATED_UNITS[str(wn.get('gated_unit', 'GTU')).upper()],
-                                   merge_res_skip=1 if wn.get('merge_res_skip', False) else 0,
+                                   merge_res_skip=1 if (wn.get('merge_res_skip', False) or not wn.get('res_skip', True)) else 0,
                                    n_early_every=self.n_early_every, n_early_size=self.n_early_size,
                                    mixing=_lib.MIX_CONV1X1 if self.channel_mixing == '1x1conv' else _lib.MIX_PERMUTE,
                                    mix_first=1 if self.mix_first else 0,
@@ -455,7 +462,7 @@ class WaveGlow(nn.Module):
                                mixing=_lib.MIX_CONV1X1 if self.channel_mixing == '1x1conv' else _lib.MIX_PERMUTE,
                                mix_first=1 if self.mix_first else 0, ignore_nan=1 if self.ignore_nan else 0,
                                gated_unit=_lib.GATED_UNITS[str(wn.get('gated_unit', 'GTU')).upper()],
-                               merge_res_skip=1 if wn.get('merge_res_skip', False) else 0)
+                               merge_res_skip=1 if (wn.get('merge_res_skip', False) or not wn.get('res_skip', True)) else 0)
 
     def _invalidate(self):
         self._packed, self._ws = None, {}
@@ -529,6 +536,12 @@ class WaveGlow(nn.Module):
                 for i in range(n_layers):
                     a[i] = fn(i)
                 return a
+            # res_skip=False (glow_ax.py:401 / :609: `res_skip_acts = acts`): the same launch with an identity weight
+            no_rs = not wn_cfg.get('res_skip', True)
+            if no_rs:
+                eye = torch.eye(wn_cfg['n_channels'], dtype=torch.float32, device=device).contiguous()
+                zero_b = torch.zeros(wn_cfg['n_channels'], dtype=torch.float32, device=device)
+                keep += [eye, zero_b]
             for k in range(self.n_flows):
                 wn = self.WN[k].WN
                 if not self.waveflow:
@@ -537,8 +550,8 @@ class WaveGlow(nn.Module):
                     fw.start_b = dev(wn.start.bias)
                     fw.in_w = arr(lambda i: self._dense(wn.in_layers[i], stream, keep).data_ptr())
                     fw.in_b = arr(lambda i: dev(wn.in_layers[i].bias))
-                    fw.rs_w = arr(lambda i: self._dense(wn.res_skip_layers[i], stream, keep).data_ptr())
-                    fw.rs_b = arr(lambda i: dev(wn.res_skip_layers[i].bias))
+                    fw.rs_w = arr(lambda i: eye.data_ptr() if no_rs else self._dense(wn.res_skip_layers[i], stream, keep).data_ptr())
+                    fw.rs_b = arr(lambda i: zero_b.data_ptr() if no_rs else dev(wn.res_skip_layers[i].bias))
                     fw.end_w = dev(wn.end.weight)
                     fw.end_b = dev(wn.end.bias)
                     if self.channel_mixing == '1x1conv':
@@ -563,8 +576,8 @@ class WaveGlow(nn.Module):
                 if sep:
                     fw.dw_w = arr(lambda i: self._dense(wn.in_layers[i][0], stream, keep).data_ptr())
                     fw.dw_b = arr(lambda i: dev(wn.in_layers[i][0].bias))
-                fw.rs_w = arr(lambda i: self._dense(wn.res_skip_layers[i], stream, keep).data_ptr())
-                fw.rs_b = arr(lambda i: dev(wn.res_skip_layers[i].bias))
+                fw.rs_w = arr(lambda i: eye.data_ptr() if no_rs else self._dense(wn.res_skip_layers[i], stream, keep).data_ptr())
+                fw.rs_b = arr(lambda i: zero_b.data_ptr() if no_rs else dev(wn.res_skip_layers[i].bias))
                 fw.end_w = dev(wn.end.weight)
                 fw.end_b = dev(wn.end.bias)
                 if self.channel_mixing == '1x1conv':                            # efficient_modules.py:271-276

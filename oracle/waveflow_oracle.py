@@ -326,7 +326,8 @@ def waveflow_inverse(sd, cfg, z, mel, speaker_ids=None):
             wpw = [_w(sd, f"{p}.in_layers.{i}.1")[:, :, 0, 0] for i in range(n_layers)]      # [2C, C]
         else:
             win = [_w(sd, f"{p}.in_layers.{i}") for i in range(n_layers)]      # [2C, C, kh, kw]
-        wrs = [_w(sd, f"{p}.res_skip_layers.{i}")[:, :, 0, 0] for i in range(n_layers)]
+        has_rs = wn.get("res_skip", True)
+        wrs = [_w(sd, f"{p}.res_skip_layers.{i}")[:, :, 0, 0] for i in range(n_layers)] if has_rs else None
         wend = sd[p + ".end.weight"][:, :, 0, 0]
         bend = sd[p + ".end.bias"]
         y = [a[:, 0, :]]
@@ -355,8 +356,8 @@ def waveflow_inverse(sd, cfg, z, mel, speaker_ids=None):
                             u = u + np.matmul(np.ascontiguousarray(win[i][:, :, ah, j]), _shift(row, j * dw - pad))
                 u = u.astype(F32)
                 act = gated_unit(wn.get("gated_unit", 'GTU'), u, C)
-                rs = np.matmul(wrs[i], act) + sd[f"{p}.res_skip_layers.{i}.bias"][None, :, None]
-                if i < n_layers - 1 and not wn.get("merge_res_skip", False):     # glow_ax.py:612-626
+                rs = (np.matmul(wrs[i], act) + sd[f"{p}.res_skip_layers.{i}.bias"][None, :, None]) if has_rs else act   # :609
+                if i < n_layers - 1 and not wn.get("merge_res_skip", False) and has_rs:     # glow_ax.py:612-626
                     x = x + rs[:, :C]
                     out = rs[:, C:] if out is None else out + rs[:, C:]
                 else:

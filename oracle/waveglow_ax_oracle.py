@@ -71,9 +71,12 @@ def wn1d(sd, p, wn, a0, frames, speaker_ids, L, upsample_factor=None):
             u = u + np.matmul(np.ascontiguousarray(w[:, :, t]), _shift(x, (t - ks // 2) * d))
         u = (u.astype(F32) + cond[:, 2 * C * i:2 * C * (i + 1)]).astype(F32)   # GTU: in_act + spect, then gate
         g = gated_unit(wn.get("gated_unit", 'GTU'), u, C)
-        rs = (np.matmul(_w(sd, f"{p}.res_skip_layers.{i}")[:, :, 0], g)
-              + sd[f"{p}.res_skip_layers.{i}.bias"][None, :, None]).astype(F32)
-        if i < n_layers - 1 and not wn.get("merge_res_skip", False):               # glow_ax.py:401-416
+        if wn.get("res_skip", True):
+            rs = (np.matmul(_w(sd, f"{p}.res_skip_layers.{i}")[:, :, 0], g)
+                  + sd[f"{p}.res_skip_layers.{i}.bias"][None, :, None]).astype(F32)
+        else:
+            rs = g                                                              # glow_ax.py:401: res_skip_acts = acts
+        if i < n_layers - 1 and not wn.get("merge_res_skip", False) and wn.get("res_skip", True):   # glow_ax.py:401-416
             x = (x + rs[:, :C]).astype(F32)
             out = rs[:, C:] if out is None else (out + rs[:, C:]).astype(F32)
         else:
