@@ -50,7 +50,7 @@ class WaveFlowConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_mel_channels", "n_flows", "n_group", "n_layers", "n_channels",
                                          "kernel_size_w", "kernel_size_h", "dilation_h", "seperable_conv",
                                          "cond_precomputed", "gated_unit", "merge_res_skip", "n_early_every", "n_early_size",
-                                         "mixing", "mix_first")]
+                                         "mixing", "mix_first")] + [("dilation_w", C.c_int32 * 12)]
 
 
 class WaveFlowFlowWeights(C.Structure):
@@ -63,7 +63,18 @@ class WgaxConfig(C.Structure):
     """``ctts_wgax_config`` (ax core, waveflow=False)."""
     _fields_ = [(n, C.c_int32) for n in ("n_flows", "n_group", "n_early_every", "n_early_size", "n_layers",
                                          "n_channels", "kernel_size", "mixing", "mix_first", "ignore_nan", "gated_unit",
-                                         "merge_res_skip")]
+                                         "merge_res_skip")] + [("dilation_w", C.c_int32 * 12)]
+
+
+def dilation_array(spec, n_layers):
+    """WN_config['n_layers_dilations_w'] (None | int | list, glow_ax.py:328-333) -> the config structs' int32[12]
+    (0 = the default 2^i)."""
+    arr = (C.c_int32 * 12)()
+    if spec is not None:
+        vals = [spec] * n_layers if isinstance(spec, int) else list(spec)
+        for i in range(n_layers):
+            arr[i] = int(vals[i])
+    return arr
 
 
 # WN_config['gated_unit'] -> CTTS_GATE_* (get_gate_func, glow_ax.py:168-198; the reference upper-cases the name)

@@ -12,6 +12,7 @@
 // extra K of every in-layer GEMM (the [B, 2*C*n_layers, L] tensor is never materialised).
 // PermuteHeight (efficient_modules.py:360-403) is folded into a logical->physical row map.
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 
 #include "gemm_f32.h"
@@ -131,7 +132,9 @@ int make_wf_geom(const WfPlan& p, int samples, WfGeom& g) {
                    samples, p.c.n_group);
     g.L = samples / p.c.n_group;
     g.Lr = round_up(g.L, 4);
-    const int maxshift = (p.c.kernel_size_w / 2) << (p.c.n_layers - 1);
+    int maxshift = 0;
+    for (int i = 0; i < p.c.n_layers; ++i)
+        maxshift = std::max(maxshift, (p.c.kernel_size_w / 2) * (p.c.dilation_w[i] > 0 ? p.c.dilation_w[i] : 1 << i));
     g.pad = round_up(maxshift > 128 ? maxshift : 128, 32);
     const int bn = gemm_bn(WF_BM);
     g.ntiles = (g.L + bn - 1) / bn;
@@ -594,7 +597,7 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
             CTTS_CHECK_LAUNCH("wf_start");
             const int a_min = (kh - 1 - r) > 0 ? (kh - 1 - r) : 0;   // earlier rows do not exist: skip those taps
             for (int i = 0; i < p.c.n_layers; ++i) {
-                const int dw = 1 << i;
+                const int dw = p.c.dilation_w[i] > 0 ? p.c.dilation_w[i] : 1 << i;
                 // merge_res_skip (glow_ax.py:612-626): no residual into `audio`, so every layer's queue holds the
                 // `start` outputs - layer i reads the ring of layer 0 and nothing is written to ring i+1
                 const bool merge = p.c.merge_res_skip != 0;

@@ -17,6 +17,7 @@
 //   coupling inverse, NaN -> 0, [un-mix if mix_first]          ax_couple_kernel (em:100-104, ax:333-337)
 // `output` starts from the first layer's skip (glow_ax.py:405-410): 0 + r == r exactly, so the SPLIT epilogue's
 // "store on layer 0, accumulate afterwards" is bit-identical.
+#include <algorithm>
 #include <vector>
 
 #include "gemm_f32.h"
@@ -100,7 +101,8 @@ int make_ax_geom(const AxPlan& p, long long samples, AxGeom& g) {
     CTTS_CHECK_ARG(samples >= p.c.n_group && samples % p.c.n_group == 0 && samples / p.c.n_group < (1 << 30),
                    "wgax: samples=%lld not a positive multiple of n_group=%d", samples, p.c.n_group);
     g.L = (int)(samples / p.c.n_group);
-    const int reach = (p.c.kernel_size / 2) << (p.c.n_layers - 1);
+    int reach = 0;
+    for (int i = 0; i < p.c.n_layers; ++i) reach = std::max(reach, (p.c.kernel_size / 2) * (p.c.dilation_w[i] > 0 ? p.c.dilation_w[i] : 1 << i));
     g.pad = round_up(reach > 128 ? reach : 128, 32);
     g.ntiles = (g.L + GEMM_BN - 1) / GEMM_BN;
     g.ld = round_up(g.L, 256) + 2 * g.pad;
@@ -387,7 +389,7 @@ int ctts_wgax_inverse_f32(const ctts_wgax_config* cfg, const void* packed, const
         CTTS_CHECK_LAUNCH("ax_start");
         const float* fr = cond + (size_t)k * batch * 2 * C * nl * cond_ld;
         for (int i = 0; i < nl; ++i) {
-            const int dil = 1 << i;
+            const int dil = p.c.dilation_w[i] > 0 ? p.c.dilation_w[i] : 1 << i;
             {
                 GemmArgs a = base_args();
                 a.A = blob + f.in_A[i]; a.bias = blob + f.in_b[i];

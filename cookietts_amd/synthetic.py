@@ -181,6 +181,7 @@ WAVEFLOW_CONFIGS = {
                                         mix_first=False),
     "toy_no_res_skip": waveflow_config(n_flows=2, n_group=8, n_channels=64, n_layers=3,
                                        WN=dict(res_skip=False, merge_res_skip=True)),
+    "toy_dilations": waveflow_config(n_flows=2, n_group=8, n_channels=64, n_layers=3, WN=dict(n_layers_dilations_w=[2, 5, 1])),
     # model-level TransposedUpsampleNet (upsample_first=True) in front of the 2-D core
     "toy_upsample_first": waveflow_config(n_flows=2, n_group=8, n_channels=64, n_layers=2, n_mel_channels=16, hop_length=40,
                                           win_length=160, upsample_first=True, transposed_conv_hidden_dim=24,
@@ -298,6 +299,9 @@ WAVEGLOW_AX_CONFIGS = {
                                                    hop_length=40, win_length=160, speaker_embed=8, cond_hidden=48,
                                                    cond_output=48, t_hidden=48, t_kernels=(4, 9), t_scales=(2, 3), t_output=32),
                           group_conv_output_dim=24, group_conv_groupped=True),
+    # per-layer width dilations instead of 2^i (a list, and the constant-int form)
+    "toy_dilations": waveglow_ax_config(n_flows=2, n_group=8, n_layers=3, kernel_size_w=5, WN=dict(n_layers_dilations_w=[3, 1, 7])),
+    "toy_dilations_const": waveglow_ax_config(n_flows=2, n_group=8, n_layers=2, WN=dict(n_layers_dilations_w=2)),
     # res_skip=False: the gated activations are the skip (with merge_res_skip; and the single-layer case without it)
     "toy_no_res_skip": waveglow_ax_config(n_flows=2, n_group=8, n_layers=3, WN=dict(res_skip=False, merge_res_skip=True)),
     "toy_no_res_skip_1layer": waveglow_ax_config(n_flows=2, n_group=8, n_layers=1, WN=dict(res_skip=False)),

@@ -338,7 +338,7 @@ class WaveGlow(nn.Module):
         if str(wn.get('gated_unit', 'GTU')).upper() not in _lib.GATED_UNITS:
             raise Exception("gated_unit is invalid\nOptions are ('GTU','GTRU','GLU').")     # glow_ax.py:198
         assert not wn.get('rezero', False), "WN ReZero is depreciated"                         # glow_ax.py:272, 450
-        need(wn.get('n_layers_dilations_w') is None, "custom width dilations")
+        need(wn['n_layers'] <= 12, "more than 12 WN layers")
         if waveflow:
             dh = wn.get('n_layers_dilations_h', 1)
             dh = [dh] * wn['n_layers'] if isinstance(dh, int) else list(dh)
@@ -452,6 +452,7 @@ class WaveGlow(nn.Module):
                                    n_early_every=self.n_early_every, n_early_size=self.n_early_size,
                                    mixing=_lib.MIX_CONV1X1 if self.channel_mixing == '1x1conv' else _lib.MIX_PERMUTE,
                                    mix_first=1 if self.mix_first else 0,
+                                   dilation_w=_lib.dilation_array(wn.get('n_layers_dilations_w'), wn['n_layers']),
                                    cond_precomputed=0 if self._folded else 1)
 
     def c_config_1d(self):
@@ -462,7 +463,8 @@ class WaveGlow(nn.Module):
                                mixing=_lib.MIX_CONV1X1 if self.channel_mixing == '1x1conv' else _lib.MIX_PERMUTE,
                                mix_first=1 if self.mix_first else 0, ignore_nan=1 if self.ignore_nan else 0,
                                gated_unit=_lib.GATED_UNITS[str(wn.get('gated_unit', 'GTU')).upper()],
-                               merge_res_skip=1 if (wn.get('merge_res_skip', False) or not wn.get('res_skip', True)) else 0)
+                               merge_res_skip=1 if (wn.get('merge_res_skip', False) or not wn.get('res_skip', True)) else 0,
+                               dilation_w=_lib.dilation_array(wn.get('n_layers_dilations_w'), wn['n_layers']))
 
     def _invalidate(self):
         self._packed, self._ws = None, {}

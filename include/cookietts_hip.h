@@ -234,6 +234,7 @@ typedef struct ctts_waveflow_config {
     int32_t n_early_size;    /* rows leaving the latent at every n_early_every-th flow */
     int32_t mixing;          /* CTTS_MIX_PERMUTE (PermuteHeight, folded into row addressing) | CTTS_MIX_CONV1X1 */
     int32_t mix_first;       /* 0 | 1: un-mix after / before the coupling inverse (ax:324-325, 337-338) */
+    int32_t dilation_w[12];  /* WN_config['n_layers_dilations_w'] per layer (glow_ax.py:507-509); 0 = the default 2^i */
 } ctts_waveflow_config;
 
 /* Dense, weight-norm-folded fp32 weights of one flow in checkpoint layouts
@@ -334,6 +335,7 @@ typedef struct ctts_wgax_config {
     int32_t ignore_nan;      /* 1: NaN -> 0 on the latent after every coupling (the reference's default) */
     int32_t gated_unit;      /* CTTS_GATE_* (0 = 'GTU') */
     int32_t merge_res_skip;  /* 0 | 1 (glow_ax.py:401-416) */
+    int32_t dilation_w[12];  /* WN_config['n_layers_dilations_w'] per layer (glow_ax.py:331-333); 0 = the default 2^i */
 } ctts_wgax_config;
 
 /* Dense, weight-norm-folded fp32 device weights of one flow in checkpoint layouts (keys WN.k.WN.*, convinv.k.weight) */

@@ -336,7 +336,8 @@ def waveflow_inverse(sd, cfg, z, mel, speaker_ids=None):
             x = ws[None, :, None] * y[r][:, None, :] + bs[None, :, None]       # [B, C, L]
             out = None
             for i in range(n_layers):
-                dw, dh = 2 ** i, dhs[i]
+                dlw = wn.get("n_layers_dilations_w")                          # glow_ax.py:507-509
+                dw, dh = (2 ** i if dlw is None else (dlw if isinstance(dlw, int) else dlw[i])), dhs[i]
                 pad = ((kw - 1) * dw) // 2
                 Q = np.concatenate([queues[i], x[:, :, None, :]], axis=2)      # [B, C, (kh-1)dh+1, L]
                 queues[i] = Q[:, :, 1:, :] if (kh - 1) * dh > 0 else queues[i]

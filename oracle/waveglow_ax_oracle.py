@@ -64,7 +64,8 @@ def wn1d(sd, p, wn, a0, frames, speaker_ids, L, upsample_factor=None):
     cond = spect if upsample_factor is None else wn_upsample(sd, p, wn, spect, L, upsample_factor, False)
     out = None
     for i in range(n_layers):
-        d = 2 ** i
+        dl = wn.get("n_layers_dilations_w")                                    # glow_ax.py:328-333
+        d = 2 ** i if dl is None else (dl if isinstance(dl, int) else dl[i])
         w = _w(sd, f"{p}.in_layers.{i}")                                   # [2C, C, ks]
         u = sd[f"{p}.in_layers.{i}.bias"][None, :, None] + np.zeros((x.shape[0], 2 * C, L), F32)
         for t in range(ks):

@@ -243,7 +243,8 @@ def make_waveflow(full_length=False):
              ("toy_conv_early", "toy_conv_early", 2, 6, 0.7, 14),
              ("toy_permute_mixfirst_early", "toy_permute_mixfirst_early", 1, 5, 0.8, 15),
              ("toy_conv_mixlast", "toy_conv_mixlast", 2, 5, 0.7, 16),
-             ("toy_upsample_first", "toy_upsample_first", 2, 6, 0.7, 17), ("toy_no_res_skip", "toy_no_res_skip", 2, 5, 0.7, 18)]
+             ("toy_upsample_first", "toy_upsample_first", 2, 6, 0.7, 17), ("toy_no_res_skip", "toy_no_res_skip", 2, 5, 0.7, 18),
+             ("toy_dilations", "toy_dilations", 2, 5, 0.7, 19)]
     only = [a for a in sys.argv[2:]]
     if full_length:
         # BASELINE config 4 at the metric's utterance length: one 80x900 mel (~10 s of CPU here)
@@ -302,7 +303,9 @@ def make_waveglow_ax(full_length=False, untts=False, gates=False):
                   # sigmoid conditioning activations + preceived_vol_scaling
                   ("toy_sigmoid_vol", 2, 5, 0.5, 64),
                   # res_skip=False
-                  ("toy_no_res_skip", 2, 5, 0.8, 65), ("toy_no_res_skip_1layer", 1, 6, 0.8, 66)]
+                  ("toy_no_res_skip", 2, 5, 0.8, 65), ("toy_no_res_skip_1layer", 1, 6, 0.8, 66),
+                  # per-layer width dilations
+                  ("toy_dilations", 2, 5, 0.8, 67), ("toy_dilations_const", 1, 6, 0.8, 68)]
         only = sys.argv[2:]
         if only:
             cases = [c for c in cases if c[0] in only]
