@@ -50,7 +50,8 @@ class WaveFlowConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_mel_channels", "n_flows", "n_group", "n_layers", "n_channels",
                                          "kernel_size_w", "kernel_size_h", "dilation_h", "seperable_conv",
                                          "cond_precomputed", "gated_unit", "merge_res_skip", "n_early_every", "n_early_size",
-                                         "mixing", "mix_first")] + [("dilation_w", C.c_int32 * 12)]
+                                         "mixing", "mix_first")] + [("dilation_w", C.c_int32 * 12),
+                                                                     ("dilation_h_l", C.c_int32 * 12)]
 
 
 class WaveFlowFlowWeights(C.Structure):

@@ -38,6 +38,8 @@ struct WfPlan {
     };
     std::vector<Flow> fl;
     size_t total;
+    int ring;                        // ring slots per layer: (kh - 1) * max height dilation + 1 rows of history
+    int dh(int i) const { return c.dilation_h_l[i] > 0 ? c.dilation_h_l[i] : c.dilation_h; }
     int rs_rows(int i) const { return (i < c.n_layers - 1 && !c.merge_res_skip) ? 2 * C : C; }
     int rs_mb(int i) const { return (rs_rows(i) + WF_BM - 1) / WF_BM; }
     int in_mb() const { return (C + 63) / 64; }
@@ -58,7 +60,12 @@ int make_wf_plan(const ctts_waveflow_config* cfg, WfPlan& p) {
     CTTS_CHECK_ARG(c.n_channels >= 64 && c.n_channels % 64 == 0, "n_channels=%d (multiple of 64)", c.n_channels);
     CTTS_CHECK_ARG(c.kernel_size_w % 2 == 1 && c.kernel_size_w >= 1 && c.kernel_size_h >= 1, "kernel %dx%d",
                    c.kernel_size_h, c.kernel_size_w);
-    CTTS_CHECK_ARG(c.dilation_h == 1, "dilation_h=%d (only 1 built)", c.dilation_h);
+    CTTS_CHECK_ARG(c.dilation_h >= 1, "dilation_h=%d", c.dilation_h);
+    p.ring = 1;
+    for (int i = 0; i < c.n_layers; ++i) {
+        CTTS_CHECK_ARG(c.dilation_h_l[i] >= 0 && c.dilation_w[i] >= 0, "negative dilation (layer %d)", i);
+        p.ring = std::max(p.ring, (c.kernel_size_h - 1) * p.dh(i) + 1);
+    }
     CTTS_CHECK_ARG(c.gated_unit >= 0 && c.gated_unit < GATE_KINDS && (c.merge_res_skip == 0 || c.merge_res_skip == 1),
                    "gated_unit=%d merge_res_skip=%d", c.gated_unit, c.merge_res_skip);
     CTTS_CHECK_ARG((c.mixing == CTTS_MIX_PERMUTE || c.mixing == CTTS_MIX_CONV1X1) && (c.mix_first == 0 || c.mix_first == 1) &&
@@ -154,7 +161,7 @@ void wf_carve(const WfPlan& p, const WfGeom& g, int batch, float* base, WfWs& w)
     w.cond_up = take(p.precond ? w.cond_slot * p.c.n_layers : 0);
     w.dwout = take(p.sep ? B * p.C * g.ld : 0);
     w.xslot = align_up(B * p.C * g.ld);
-    w.X = take(w.xslot * p.c.n_layers * p.c.kernel_size_h);
+    w.X = take(w.xslot * p.c.n_layers * p.ring);
     w.act = take(B * p.C * g.ld);
     w.out = take(B * p.C * g.ld);
     w.total = o;
@@ -563,7 +570,8 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
     int phys[64], perm[64], tmp[64];
     int Ga = p.n_rem[p.c.n_flows - 1];
     for (int i = 0; i < Ga; ++i) phys[i] = G - Ga + i;
-    auto X = [&](int layer, int slot) { return w.X + ((size_t)layer * kh + slot) * w.xslot; };
+    const int NS = p.ring;
+    auto X = [&](int layer, int slot) { return w.X + ((size_t)layer * NS + slot) * w.xslot; };
     const bool fuse = p.fused() && !getenv("CTTS_WF_NO_FUSE");
     const bool sep_fuse = p.sep_fused() && !getenv("CTTS_WF_NO_FUSE");
     // un-mix of flow k on the active rows: PermuteHeight composes into the map, the 1x1 conv is a pass over the rows
@@ -591,17 +599,18 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
             CTTS_CHECK_LAUNCH("wf_interp_cond");
         }
         for (int r = 0; r < Ga - 1; ++r) {
-            const int slot = r % kh;
+            const int slot = r % NS;
             hipLaunchKernelGGL(wf_start_kernel, dim3(((L + 3) / 4 + 255) / 256, (C + 15) / 16, batch), dim3(256), 0, s,
                                w.rows, blob + f.start_w, blob + f.start_b, X(0, slot), C, G, phys[r], L, g.Lr, g.ld, g.pad);
             CTTS_CHECK_LAUNCH("wf_start");
-            const int a_min = (kh - 1 - r) > 0 ? (kh - 1 - r) : 0;   // earlier rows do not exist: skip those taps
             for (int i = 0; i < p.c.n_layers; ++i) {
                 const int dw = p.c.dilation_w[i] > 0 ? p.c.dilation_w[i] : 1 << i;
                 // merge_res_skip (glow_ax.py:612-626): no residual into `audio`, so every layer's queue holds the
                 // `start` outputs - layer i reads the ring of layer 0 and nothing is written to ring i+1
                 const bool merge = p.c.merge_res_skip != 0;
                 const int si = merge ? 0 : i;
+                const int dh = p.dh(i);                                   // height tap ah reads row r - (kh-1-ah)*dh
+                const int a_min = std::max(0, kh - 1 - r / dh);           // earlier rows do not exist: skip those taps
                 GemmArgs a{};
                 a.gate = p.c.gated_unit;
                 a.bm = WF_BM;
@@ -613,7 +622,7 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
                 int ns = 0;
                 if (p.sep) {
                     WfSlots xs{};
-                    for (int ah = a_min; ah < kh; ++ah) xs.p[ah] = X(si, (r - (kh - 1 - ah)) % kh);
+                    for (int ah = a_min; ah < kh; ++ah) xs.p[ah] = X(si, (r - (kh - 1 - ah) * dh) % NS);
                     const dim3 vgrid(((L + 3) / 4 + 255) / 256, C, batch);
                     const bool vec = g.pad % 4 == 0 && g.ld % 4 == 0 && (dw <= 2 || dw % 4 == 0);
                     if (vec && kw == 7) launch_depthwise_vec<7>(vgrid, s, xs, blob + f.dw_w[i], blob + f.dw_b[i], w.dwout, C, kh, dw, a_min, L, g.ld, g.pad);
@@ -642,9 +651,9 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
                 } else {
                     a.a_ch_off = a_min * kw * p.nch_c;
                     for (int ah = a_min; ah < gkh; ++ah) {
-                        const int src_row = r - (kh - 1 - ah);
+                        const int src_row = r - (kh - 1 - ah) * dh;
                         for (int j = 0; j < gkw; ++j)
-                            a.seg[ns++] = {X(si, src_row % kh), cstride, p.nch_c, (j - kw / 2) * dw, 0, 0};
+                            a.seg[ns++] = {X(si, src_row % NS), cstride, p.nch_c, (j - kw / 2) * dw, 0, 0};
                     }
                     a.nch_total = (kh - a_min) * kw * p.nch_c;
                 }

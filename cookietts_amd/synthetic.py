@@ -182,6 +182,13 @@ WAVEFLOW_CONFIGS = {
     "toy_no_res_skip": waveflow_config(n_flows=2, n_group=8, n_channels=64, n_layers=3,
                                        WN=dict(res_skip=False, merge_res_skip=True)),
     "toy_dilations": waveflow_config(n_flows=2, n_group=8, n_channels=64, n_layers=3, WN=dict(n_layers_dilations_w=[2, 5, 1])),
+    # per-layer height dilations (deeper row queues, glow_ax.py:510-512, 597-602): dense C = 64 and separable C = 128
+    "toy_dilations_h": waveflow_config(n_flows=2, n_group=10, n_channels=64, n_layers=3, hop_length=40, win_length=160,
+                                       n_mel_channels=16, WN=dict(n_layers_dilations_h=[1, 2, 3])),
+    "author_toy_dilations_h": _with_wn(waveflow_author_config(n_flows=2, n_group=10, n_channels=128, n_layers=2, kernel=3,
+                                                              n_mel_channels=12, hop_length=40, win_length=160, speaker_embed=8,
+                                                              cond_layers=2, cond_hidden=32, wn_cond_hidden=24),
+                                       n_layers_dilations_h=2),
     # model-level TransposedUpsampleNet (upsample_first=True) in front of the 2-D core
     "toy_upsample_first": waveflow_config(n_flows=2, n_group=8, n_channels=64, n_layers=2, n_mel_channels=16, hop_length=40,
                                           win_length=160, upsample_first=True, transposed_conv_hidden_dim=24,

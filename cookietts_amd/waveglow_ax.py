@@ -342,7 +342,7 @@ class WaveGlow(nn.Module):
         if waveflow:
             dh = wn.get('n_layers_dilations_h', 1)
             dh = [dh] * wn['n_layers'] if isinstance(dh, int) else list(dh)
-            need(all(d == 1 for d in dh), "height dilation != 1")
+            need(all(d >= 1 for d in dh), "height dilation < 1")
             need(wn.get('seperable_conv', False) or wn['kernel_size_h'] * wn['kernel_size_w'] <= 11,
                  "dense in-layer kernels with more than 11 taps (use seperable_conv)")
         else:
@@ -453,6 +453,7 @@ class WaveGlow(nn.Module):
                                    mixing=_lib.MIX_CONV1X1 if self.channel_mixing == '1x1conv' else _lib.MIX_PERMUTE,
                                    mix_first=1 if self.mix_first else 0,
                                    dilation_w=_lib.dilation_array(wn.get('n_layers_dilations_w'), wn['n_layers']),
+                                   dilation_h_l=_lib.dilation_array(wn.get('n_layers_dilations_h', 1), wn['n_layers']),
                                    cond_precomputed=0 if self._folded else 1)
 
     def c_config_1d(self):

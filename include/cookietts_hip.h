@@ -224,7 +224,7 @@ typedef struct ctts_waveflow_config {
     int32_t n_channels;      /* 64 (multiple of 64) */
     int32_t kernel_size_w;   /* 3 (odd) */
     int32_t kernel_size_h;   /* 3 */
-    int32_t dilation_h;      /* 1 (all layers) */
+    int32_t dilation_h;      /* height dilation of every layer unless dilation_h_l overrides it (>= 1; config 4: 1) */
     int32_t seperable_conv;  /* 0 | 1  (WN_config['seperable_conv'], the reference's spelling) */
     int32_t cond_precomputed;/* 0: mel + folded cond layer;  1: ctts_waveflow_inverse_cond_f32 */
     int32_t gated_unit;      /* CTTS_GATE_*: WN_config['gated_unit'] (glow_ax.py:168-198); 0 = 'GTU' */
@@ -235,6 +235,7 @@ typedef struct ctts_waveflow_config {
     int32_t mixing;          /* CTTS_MIX_PERMUTE (PermuteHeight, folded into row addressing) | CTTS_MIX_CONV1X1 */
     int32_t mix_first;       /* 0 | 1: un-mix after / before the coupling inverse (ax:324-325, 337-338) */
     int32_t dilation_w[12];  /* WN_config['n_layers_dilations_w'] per layer (glow_ax.py:507-509); 0 = the default 2^i */
+    int32_t dilation_h_l[12];/* WN_config['n_layers_dilations_h'] per layer (glow_ax.py:510-512); 0 = `dilation_h` */
 } ctts_waveflow_config;
 
 /* Dense, weight-norm-folded fp32 weights of one flow in checkpoint layouts

@@ -244,7 +244,8 @@ def make_waveflow(full_length=False):
              ("toy_permute_mixfirst_early", "toy_permute_mixfirst_early", 1, 5, 0.8, 15),
              ("toy_conv_mixlast", "toy_conv_mixlast", 2, 5, 0.7, 16),
              ("toy_upsample_first", "toy_upsample_first", 2, 6, 0.7, 17), ("toy_no_res_skip", "toy_no_res_skip", 2, 5, 0.7, 18),
-             ("toy_dilations", "toy_dilations", 2, 5, 0.7, 19)]
+             ("toy_dilations", "toy_dilations", 2, 5, 0.7, 19),
+             ("toy_dilations_h", "toy_dilations_h", 2, 6, 0.7, 20), ("author_toy_dilations_h", "author_toy_dilations_h", 1, 5, 0.7, 21)]
     only = [a for a in sys.argv[2:]]
     if full_length:
         # BASELINE config 4 at the metric's utterance length: one 80x900 mel (~10 s of CPU here)
