@@ -325,7 +325,6 @@ class WaveGlow(nn.Module):
         self._wn_tconv_factor = int(np.prod(wn['transposed_conv_scales'])) if wn_tconv else 0
         need(cond_padding_mode in ('zeros', 'replicate') and wn.get('cond_padding_mode', 'zeros') in ('zeros', 'replicate'),
              "cond_padding_mode other than 'zeros' / 'replicate'")
-        need(not load_hidden_from_disk, "hidden cond from disk")
         need(not unsupported.get('iso226_empthasis', False), "iso226 emphasis")
         need(wn.get('cond_layers', 1) >= 1, "WN without cond layers")
         need(wn.get('upsample_mode', 'linear') == 'linear', "WN upsample_mode != 'linear'")
@@ -365,6 +364,7 @@ class WaveGlow(nn.Module):
         self.cond_residual, self.cond_res_rezero = cond_residual, cond_res_rezero
         self.shift_spect, self.scale_spect = float(shift_spect), float(scale_spect)
         self.vol_scaling = bool(preceived_vol_scaling)
+        self.use_hidden_cond = load_hidden_from_disk                              # ax:36: a data-loader hint, not used by the model
         self.upsample_early = upsample_first is True
         self.WN_config = wn
         # activation tables (validated now so that an unsupported name fails at construction)
