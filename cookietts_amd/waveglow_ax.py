@@ -1,22 +1,27 @@
-"""WaveFlow / "ax" WaveGlow core on the MI355X HIP path (BASELINE config 4, and the ``waveflow=False`` WaveGlow the
-reference's own timing notebook runs).
+"""WaveFlow / "ax" WaveGlow core on the MI355X HIP path (BASELINE config 4, the ``waveflow=False`` WaveGlow the
+reference's own timing notebook runs, and every other config the reference tree prints).
 
 Host-side mirror of ``/root/reference/CookieTTS/_4_mtw/waveglow/efficient_model_ax.py``
-``WaveGlow`` (:18-169 constructor, :279-357 ``inverse``, :359-388 ``infer``) for ``waveflow=True``
-(``WaveFlowCoupling`` + ``WN_2d``, efficient_modules.py:19-65, glow_ax.py:421-635),
-``channel_mixing='permuteheight'``, ``mix_first=False``, linear-interpolated conditioning: BASELINE config 4,
-and the option set of the author's own checkpoints: speaker embeddings at model and WN level,
-model-level residual + rezero conv conditioning stack, multi-layer WN conditioning stacks with activations,
-separable (depthwise + pointwise) in-layers, log-variance mel channels, de-emphasis.  Same constructor kwargs, same
-``state_dict`` keys (``WN.k.WN.{start,cond_layers.0,in_layers.i,res_skip_layers.i}.{weight_g,weight_v,
-bias}``, ``WN.k.WN.end.{weight,bias}``), same ``infer`` / ``inverse`` contracts (output length
-``(F-1)*hop`` with the default ``artifact_trimming=1``; ``return_CPU=True`` moves the result to
-the host like the reference).  Everything else the constructor accepts raises NotImplementedError.
-``waveflow=False`` selects ``AffineCouplingBlock`` + the 1-D ``WN`` (efficient_modules.py:68-105, glow_ax.py:245-418)
-with ``InvertibleConv1x1`` (efficient_modules.py:235-286) or ``PermuteHeight`` channel mixing in either ``mix_first``
-order and early outputs (``ctts_wgax_inverse_f32``).
-All arithmetic runs in the C-ABI HIP library (``ctts_waveflow_inverse_f32`` / ``ctts_wgax_inverse_f32``); no CPU
-fallback.
+``WaveGlow`` (:18-169 constructor, :279-357 ``inverse``, :359-388 ``infer``):
+
+* ``waveflow=True``: ``WaveFlowCoupling`` + ``WN_2d`` (efficient_modules.py:19-65, glow_ax.py:421-635) ->
+  ``ctts_waveflow_inverse_f32`` / ``ctts_waveflow_inverse_cond_f32``;
+* ``waveflow=False``: ``AffineCouplingBlock`` + the 1-D ``WN`` (efficient_modules.py:68-105, glow_ax.py:245-418) ->
+  ``ctts_wgax_inverse_f32``;
+* on both: ``PermuteHeight`` or ``InvertibleConv1x1`` mixing in either ``mix_first`` order, early outputs, all
+  fourteen gated units, ``merge_res_skip`` / ``res_skip=False``, per-layer dilations, speaker embeddings at model and
+  WN level, the model-level conditioning stack (plain / residual / 1x1-conv residual, rezero), multi-layer WN
+  conditioning stacks with activations, the grouped per-flow cond conv, model- and WN-level
+  ``TransposedUpsampleNet``, spect shift / scale, log-variance mel channels, perceived-volume companding,
+  de-emphasis; separable (depthwise + pointwise) in-layers on the 2-D core.
+
+Same constructor kwargs, same ``state_dict`` keys (``WN.k.WN.{start,cond_layers.l,in_layers.i,res_skip_layers.i}.
+{weight_g,weight_v,bias}``, ``WN.k.WN.end.{weight,bias}``, ``convinv.k.weight``, ``upsample_net.*``, ...), same
+``infer`` / ``inverse`` contracts (output length ``(F-1)*hop`` with the default ``artifact_trimming=1``;
+``return_CPU=True`` moves the result to the host like the reference).  The few options left raise
+NotImplementedError.  The conditioning stacks are composed on the host from operator-level C entry points
+(``ctts_conv1d_f32``, ``ctts_embed_rows_f32``, ``ctts_scale_add_rows_f32``, ``ctts_resample_rows_f32``,
+``ctts_interleave_phases_f32``, ...); all arithmetic runs in the C-ABI HIP library; no CPU fallback.
 """
 from __future__ import annotations
 
