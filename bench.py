@@ -49,7 +49,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
 # HBM bytes per in-layer launch from committed PMC passes (2 x FETCH_SIZE (gfx950 half-count correction,
 # calibrated on flow_tail) + WRITE_SIZE), config 2 shapes only; not re-measured inside a bench run.
-TRAFFIC_FILES = ["r2_pmc_traffic.json", "r1_17_pmc_traffic.json"]
+TRAFFIC_FILES = ["r3_pmc_traffic.json", "r1_17_pmc_traffic.json"]
 
 
 def load_traffic():
@@ -226,8 +226,8 @@ def worker(args):
             sd = synthetic.waveglow_state_dict(cfg, seed=seed)
             model.load_state_dict(synthetic.to_torch(sd))
         model = model.to(device).eval()
-        import cookietts_amd
-        cookietts_amd.set_f32_gemm_mode(args.gemm_mode)          # explicit: never inherited from the environment
+        model.set_f32_gemm_mode(args.gemm_mode)                  # in the model's config struct (ABI 4): explicit, never
+                                                                 # inherited from the environment or a process default
         if args.dtype == "bf16":
             model.set_compute_dtype(torch.bfloat16)
         elif args.dtype == "bf16x3":

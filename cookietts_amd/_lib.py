@@ -19,7 +19,8 @@ class WaveGlowConfig(C.Structure):
     """``ctts_waveglow_config`` (include/cookietts_hip.h)."""
     _fields_ = [(n, C.c_int32) for n in (
         "n_mel_channels", "n_group", "n_flows", "n_early_every", "n_early_size",
-        "win_length", "hop_length", "n_layers", "n_channels", "kernel_size", "cond_hidden", "speaker_embed_dim")]
+        "win_length", "hop_length", "n_layers", "n_channels", "kernel_size", "cond_hidden", "speaker_embed_dim",
+        "f32_gemm_mode")]
 
 
 class StftConfig(C.Structure):
@@ -51,7 +52,8 @@ class WaveFlowConfig(C.Structure):
                                          "kernel_size_w", "kernel_size_h", "dilation_h", "seperable_conv",
                                          "cond_precomputed", "gated_unit", "merge_res_skip", "n_early_every", "n_early_size",
                                          "mixing", "mix_first")] + [("dilation_w", C.c_int32 * 12),
-                                                                     ("dilation_h_l", C.c_int32 * 12)]
+                                                                     ("dilation_h_l", C.c_int32 * 12),
+                                                                     ("f32_gemm_mode", C.c_int32)]
 
 
 class WaveFlowFlowWeights(C.Structure):
@@ -64,7 +66,7 @@ class WgaxConfig(C.Structure):
     """``ctts_wgax_config`` (ax core, waveflow=False)."""
     _fields_ = [(n, C.c_int32) for n in ("n_flows", "n_group", "n_early_every", "n_early_size", "n_layers",
                                          "n_channels", "kernel_size", "mixing", "mix_first", "ignore_nan", "gated_unit",
-                                         "merge_res_skip")] + [("dilation_w", C.c_int32 * 12)]
+                                         "merge_res_skip")] + [("dilation_w", C.c_int32 * 12), ("f32_gemm_mode", C.c_int32)]
 
 
 def dilation_array(spec, n_layers):
@@ -114,7 +116,7 @@ class TacoDecoderWeights(C.Structure):
 class Conv1dDesc(C.Structure):
     """``ctts_conv1d_desc``."""
     _fields_ = [("c_in", C.c_int32), ("c_out", C.c_int32), ("kernel_size", C.c_int32), ("act", C.c_int32),
-                ("slope", C.c_float)]
+                ("slope", C.c_float), ("f32_gemm_mode", C.c_int32)]
 
 
 class TacoMemoryWeights(C.Structure):
@@ -225,20 +227,38 @@ SIGNATURES = {
     "ctts_interleave_phases_f32": (C.c_int, [_FP, _FP] + [C.c_int32] * 10 + [_FP]),
     "ctts_set_f32_gemm_mode": (C.c_int, [C.c_int32]),
     "ctts_get_f32_gemm_mode": (C.c_int, []),
+    "ctts_tuning_reload": (C.c_int, []),
     "ctts_profile_enable": (C.c_int, [C.c_int32]),
     "ctts_profile_collect": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }
 
-GEMM_MODES = {"f32": 0, "bf16x3": 1}
+GEMM_MODES = {"f32": 0, "bf16x3": 1}                      # ctts_set_f32_gemm_mode: the library DEFAULT
+# f32_gemm_mode field of the config structs (CTTS_GEMM_*): the mode a MODEL asks for
+MODEL_GEMM_MODES = {None: 0, "default": 0, "f32": 1, "bf16x3": 2}
+
+
+def model_gemm_mode(mode):
+    """``None`` / ``"default"`` (the library default), ``"f32"`` or ``"bf16x3"`` -> CTTS_GEMM_*."""
+    try:
+        return MODEL_GEMM_MODES[mode]
+    except KeyError:
+        raise ValueError(f"f32 GEMM mode {mode!r}: expected one of 'default', 'f32', 'bf16x3'") from None
 
 
 def set_f32_gemm_mode(mode):
-    """Main loop of the fp32 conv-GEMM for the whole process: ``"f32"`` (default, fp32 MFMA) or ``"bf16x3"`` (each
-    operand split in registers into hi + lo bf16, three bf16 MFMA products per pair, fp32 accumulation; tensors and
-    weights stay fp32).  Returns the previous mode name."""
+    """Library DEFAULT main loop of the fp32 conv-GEMM, used by models that did not choose one themselves
+    (``model.set_f32_gemm_mode(...)`` puts the choice into the model's own config struct, so two models in one process
+    can differ): ``"f32"`` (initial value, fp32 MFMA) or ``"bf16x3"`` (each operand split in registers into hi + lo
+    bf16, three bf16 MFMA products per pair, fp32 accumulation; tensors and weights stay fp32).  Returns the previous
+    default's name."""
     prev = {v: k for k, v in GEMM_MODES.items()}[lib().ctts_get_f32_gemm_mode()]
     check(lib().ctts_set_f32_gemm_mode(GEMM_MODES[mode]), "ctts_set_f32_gemm_mode")
     return prev
+
+
+def tuning_reload():
+    """Re-read the CTTS_* launch-shape knobs from the environment (the library reads them once, at the first launch)."""
+    check(lib().ctts_tuning_reload(), "ctts_tuning_reload")
 
 
 PROF_WN_IN = 0
@@ -278,7 +298,7 @@ def lib():
                 raise HipLibraryError(f"{path} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
-        if handle.ctts_abi_version() != 3:
+        if handle.ctts_abi_version() != 4:
             raise HipLibraryError(f"ABI version mismatch: library reports {handle.ctts_abi_version()}")
         env_mode = os.environ.get("CTTS_F32_GEMM_MODE")          # "f32" (default) or "bf16x3": see set_f32_gemm_mode
         if env_mode:

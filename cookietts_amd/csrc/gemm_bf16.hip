@@ -7,6 +7,7 @@
 #include <cstdlib>
 
 #include "gemm_bf16.h"
+#include "tuning.h"
 
 namespace ctts {
 
@@ -768,9 +769,11 @@ int launch_pack_a_bf16(bf16_t* dst, const float* src, int MB, int nch_total, int
     return CTTS_OK;
 }
 
+#ifdef CTTS_W4_TIMING_EXPERIMENTS
 extern "C" int ctts_debug_w4_stamps(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w4_stamps), sizeof(g_w4_stamps)) == hipSuccess ? 0 : -1;
 }
+#endif
 
 int launch_gemm_bf16(int epi, const BGemmArgs& a, hipStream_t stream) {
     CTTS_CHECK_ARG(a.nseg >= 1 && a.nseg <= BGEMM_MAX_SEG, "gemm_bf16: nseg=%d", a.nseg);
@@ -787,15 +790,16 @@ int launch_gemm_bf16(int epi, const BGemmArgs& a, hipStream_t stream) {
         for (int s = 1; s < a.interleave; ++s)
             CTTS_CHECK_ARG(a.seg[s].nch == a.seg[0].nch, "gemm_bf16: interleaved segments must have equal length");
     }
-    // block-shape overrides for A/B tests (read per launch so a test can flip them in-process)
-    const bool use_glds = getenv("CTTS_BF16_NO_GLDS") == nullptr;
-    const bool no_wide = getenv("CTTS_BF16_NO_WIDE") != nullptr;
-    const bool no_pp = getenv("CTTS_BF16_NO_PP") != nullptr;
-    const int pp_stages = getenv("CTTS_BF16_PP_STAGES") ? atoi(getenv("CTTS_BF16_PP_STAGES")) : 3;
+    // block-shape overrides for A/B tests (tuning.h: the environment is read once; ctts_tuning_reload re-reads it)
+    const Tuning tune = tuning();
+    const bool use_glds = !tune.bf16_no_glds;
+    const bool no_wide = tune.bf16_no_wide;
+    const bool no_pp = tune.bf16_no_pp;
+    const int pp_stages = tune.bf16_pp_stages;
     // four-wave 128 x 128 wave tiles: opt-in.  Measured equal to the skewed 8-wave kernel on the in-layer GEMM (both
     // are held by the clock the chip sustains under bf16 MFMA + LDS traffic) and slower on the short-K
     // res GEMM, where its one-wave-per-SIMD epilogue is exposed.
-    const bool w4 = getenv("CTTS_BF16_W4") != nullptr;
+    const bool w4 = tune.bf16_w4;
     // wide (256 x 256, 512 threads) tiles when the problem has enough of them to fill the chip
     const int ntiles_w = (a.L + 255) / 256;
     const bool pp = !no_pp && a.nch_total + 3 <= BGEMM_PP_MAX_CHUNKS;
@@ -810,17 +814,19 @@ int launch_gemm_bf16(int epi, const BGemmArgs& a, hipStream_t stream) {
                    "gemm_bf16: M=%d pairC=%d MB=%d split=%d", b.M, b.pairC, b.MB, b.split);
     long long blocks = (long long)b.MB * b.ntiles * b.batch;
     b.map_mode = 0;
-    if (b.MB == 4 && !getenv("CTTS_GEMM_NO_XCD_PAIR")) {
+    if (b.MB == 4 && !tune.no_xcd_pair) {
         b.map_mode = 1;
         blocks = 16ll * (((long long)b.ntiles * b.batch + 3) / 4);
     }
     CTTS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "gemm_bf16: grid %lld", blocks);
     const dim3 grid((unsigned)blocks);
     if (epi == BGEMM_EPI_GATE) {
-        const int dbg = getenv("CTTS_BF16_W4_DEBUG") ? atoi(getenv("CTTS_BF16_W4_DEBUG")) : 0;
+#ifdef CTTS_W4_TIMING_EXPERIMENTS     /* stage-removal variants of the four-wave kernel (scripts/w4_stamps.py); not in the product build */
+        const int dbg = tune.w4_debug;
 #define CTTS_W4_DBG(D) if (wide && pp && w4 && dbg == D) hipLaunchKernelGGL((conv_gemm_bf16_w4_kernel<BGEMM_EPI_GATE, D>), grid, dim3(256), 0, stream, b); else
         CTTS_W4_DBG(1) CTTS_W4_DBG(2) CTTS_W4_DBG(4) CTTS_W4_DBG(5) CTTS_W4_DBG(6)
 #undef CTTS_W4_DBG
+#endif
         if (wide && pp && w4) hipLaunchKernelGGL((conv_gemm_bf16_w4_kernel<BGEMM_EPI_GATE>), grid, dim3(256), 0, stream, b);
         else if (wide && pp && pp_stages == 4) hipLaunchKernelGGL((conv_gemm_bf16_pp_kernel<BGEMM_EPI_GATE, 4>), grid, dim3(512), 0, stream, b);
         else if (wide && pp) hipLaunchKernelGGL((conv_gemm_bf16_pp_kernel<BGEMM_EPI_GATE, 3>), grid, dim3(512), 0, stream, b);

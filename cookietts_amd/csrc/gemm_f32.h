@@ -132,8 +132,10 @@ struct GemmArgs {
     int addend_frames;
     int map_mode;         // block id -> (m-block, tile, batch) mapping, chosen by the launcher (see gemm_f32.hip)
     int gate;             // GateKind of a GATE launch (0 = GTU); != 0 is routed to GEMM_EPI_GATEX by the launcher
-    int exact_f32;        // 1 = always the fp32 MFMA main loop, whatever set_gemm_f32_mode says (STFT: its sums cancel,
-                          // so the split-bf16 loop's 2^-17 operand error exceeds the 1e-4 log-mel bound)
+    int gemm_mode;        // CTTS_GEMM_DEFAULT (0: the library default, ctts_set_f32_gemm_mode) | CTTS_GEMM_F32 | CTTS_GEMM_BF16X3:
+                          // the caller's config struct carries it (ABI 4), so two models of one process can differ.  The
+                          // STFT always asks for CTTS_GEMM_F32: its sums cancel, the split loop's 2^-17 operand error
+                          // would exceed the 1e-4 log-mel bound
     const float* rs_wT;   // GEMM_EPI_GATE_RS: res/skip weight transposed and row-padded: [64][128]
     const float* rs_bias; // [128] (rows >= rs_rows zero)
     int rs_rows;          // 128 (res + skip) or 64 (last layer: skip only)
@@ -156,9 +158,13 @@ __host__ __device__ inline int gemm_dense_row(int epi, int bm, int mb, int r, in
 
 int launch_gemm_f32(int epi, const GemmArgs& a, hipStream_t stream);
 
-// Process-wide main-loop selection of launch_gemm_f32: 0 = fp32 MFMA (default), 1 = split bf16 (three bf16 MFMA products
-// per fp32 operand pair, see conv_gemm_f32_kernel<..., X3>).  Set through ctts_set_f32_gemm_mode.
+// Library DEFAULT of the main-loop selection (what CTTS_GEMM_DEFAULT resolves to): 0 = fp32 MFMA (initially), 1 = split
+// bf16 (three bf16 MFMA products per fp32 operand pair, see conv_gemm_f32_kernel<..., X3>).  ctts_set_f32_gemm_mode.
 int set_gemm_f32_mode(int mode);
 int get_gemm_f32_mode();
+// true when a launch with this GemmArgs.gemm_mode / config f32_gemm_mode runs the split-bf16 main loop
+bool gemm_mode_is_split(int gemm_mode);
+// validates a config struct's f32_gemm_mode field
+inline bool gemm_mode_valid(int m) { return m == CTTS_GEMM_DEFAULT || m == CTTS_GEMM_F32 || m == CTTS_GEMM_BF16X3; }
 
 }  // namespace ctts

@@ -16,8 +16,10 @@
 //   2-stage variant that stages global->LDS through registers one chunk ahead.
 #include <atomic>
 #include <cstdlib>
+#include <mutex>
 
 #include "gemm_f32.h"
+#include "tuning.h"
 #include "gemm_bf16.h"   // pack_bf16x2 (split-bf16 main loop)
 
 namespace ctts {
@@ -657,8 +659,8 @@ void launch_shape_g(int bm, dim3 grid, hipStream_t stream, const GemmArgs& a) {
 
 template <int EPI>
 void launch_shape(int bm, dim3 grid, hipStream_t stream, const GemmArgs& a) {
-    if (getenv("CTTS_F32_NO_GLDS") || a.nch_total > GEMM_GLDS_MAX_CHUNKS) launch_shape_g<EPI, false>(bm, grid, stream, a);
-    else if (gemm_f32_mode() == 1 && !a.exact_f32) launch_shape_x3<EPI>(bm, grid, stream, a);
+    if (tuning().f32_no_glds || a.nch_total > GEMM_GLDS_MAX_CHUNKS) launch_shape_g<EPI, false>(bm, grid, stream, a);
+    else if (gemm_mode_is_split(a.gemm_mode)) launch_shape_x3<EPI>(bm, grid, stream, a);
     else launch_shape_g<EPI, true>(bm, grid, stream, a);
 }
 
@@ -670,11 +672,44 @@ int set_gemm_f32_mode(int mode) {
     return 0;
 }
 int get_gemm_f32_mode() { return gemm_f32_mode(); }
+bool gemm_mode_is_split(int m) { return m == CTTS_GEMM_BF16X3 || (m == CTTS_GEMM_DEFAULT && gemm_f32_mode() == 1); }
+
+namespace {
+std::mutex g_tune_mu;
+Tuning g_tune{};
+bool g_tune_loaded = false;
+void load_tuning_locked() {
+    auto on = [](const char* n) { return getenv(n) != nullptr; };
+    auto num = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
+    g_tune.f32_no_glds = on("CTTS_F32_NO_GLDS");
+    g_tune.no_xcd_pair = on("CTTS_GEMM_NO_XCD_PAIR");
+    g_tune.bf16_no_glds = on("CTTS_BF16_NO_GLDS");
+    g_tune.bf16_no_wide = on("CTTS_BF16_NO_WIDE");
+    g_tune.bf16_no_pp = on("CTTS_BF16_NO_PP");
+    g_tune.bf16_w4 = on("CTTS_BF16_W4");
+    g_tune.bf16_pp_stages = num("CTTS_BF16_PP_STAGES", 3);
+    g_tune.wf_no_fuse = on("CTTS_WF_NO_FUSE");
+    g_tune.taco_no_fuse = on("CTTS_TACO_NO_FUSE");
+    g_tune.w4_debug = num("CTTS_BF16_W4_DEBUG", 0);
+    g_tune_loaded = true;
+}
+}  // namespace
+
+Tuning tuning() {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    if (!g_tune_loaded) load_tuning_locked();
+    return g_tune;
+}
+void reload_tuning() {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    load_tuning_locked();
+}
 
 int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
     GemmArgs a = a_in;
     if (a.bm == 0) a.bm = 256;
     CTTS_CHECK_ARG(a.bm == 256 || a.bm == 128, "gemm: bm=%d", a.bm);
+    CTTS_CHECK_ARG(gemm_mode_valid(a.gemm_mode), "gemm: f32_gemm_mode %d (0 default, 1 fp32 MFMA, 2 split bf16)", a.gemm_mode);
     const int bn = gemm_bn(a.bm);
     CTTS_CHECK_ARG(a.nseg >= 1 && a.nseg <= GEMM_MAX_SEG, "gemm: nseg=%d", a.nseg);
     int nch = 0;
@@ -705,7 +740,7 @@ int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
     long long blocks = (long long)a.MB * a.ntiles * a.batch;
     a.map_mode = 0;
     // measured on config 2 (PMC FETCH_SIZE per in-layer launch): 4.2 GB -> 2.5 GB at unchanged speed
-    if (a.MB == 4 && epi != GEMM_EPI_GATE_RS && !getenv("CTTS_GEMM_NO_XCD_PAIR")) {
+    if (a.MB == 4 && epi != GEMM_EPI_GATE_RS && !tuning().no_xcd_pair) {
         a.map_mode = 1;
         blocks = 16ll * (((long long)a.ntiles * a.batch + 3) / 4);
     }
@@ -720,10 +755,10 @@ int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
         case GEMM_EPI_GATE_RS:
             CTTS_CHECK_ARG(a.bm == 128 && a.pairC <= 64 && a.MB == 1 && a.rs_wT && a.rs_bias && (a.rs_rows == 64 || a.rs_rows == 128),
                            "gemm: fused res/skip needs bm=128, <= 64 channels");
-            if (getenv("CTTS_F32_NO_GLDS") || a.nch_total > GEMM_GLDS_MAX_CHUNKS) {
+            if (tuning().f32_no_glds || a.nch_total > GEMM_GLDS_MAX_CHUNKS) {
                 if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, 4, false>), grid, dim3(256), 0, stream, a);
                 else hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, GEMM_MAX_SEG, false>), grid, dim3(256), 0, stream, a);
-            } else if (gemm_f32_mode() == 1 && !a.exact_f32) {
+            } else if (gemm_mode_is_split(a.gemm_mode)) {
                 if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, 4, true, true>), grid, dim3(256), 0, stream, a);
                 else hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, GEMM_MAX_SEG, true, true>), grid, dim3(256), 0, stream, a);
             } else {

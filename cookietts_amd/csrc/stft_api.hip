@@ -210,7 +210,7 @@ int ctts_stft_mel_f32(const ctts_stft_config* cfg, const void* packed, const flo
     CTTS_CHECK_LAUNCH("stft_frames");
 
     GemmArgs a{};
-    a.exact_f32 = 1;            // Fourier sums cancel: keep exact fp32 products under any process-wide GEMM mode
+    a.gemm_mode = CTTS_GEMM_F32;   // Fourier sums cancel: exact fp32 products, whatever the library default is
     a.ld = g.ld; a.pad = 0; a.L = g.frames; a.ntiles = g.ntiles; a.batch = batch;
     a.A = blob + p.basis_A; a.bias = blob + p.zero_bias;
     a.nseg = 1; a.nch_total = p.N / GEMM_KC; a.MB = p.mb_mag;
@@ -227,7 +227,7 @@ int ctts_stft_mel_f32(const ctts_stft_config* cfg, const void* packed, const flo
     }
     if (mel) {
         GemmArgs m{};
-        m.exact_f32 = 1;
+        m.gemm_mode = CTTS_GEMM_F32;
         m.ld = g.ld; m.pad = 0; m.L = g.frames; m.ntiles = g.ntiles; m.batch = batch;
         m.A = blob + p.mel_A; m.bias = blob + p.zero_bias;
         m.nseg = 1; m.nch_total = p.kmel / GEMM_KC; m.MB = p.mb_mel;
@@ -258,7 +258,7 @@ int ctts_stft_transform_f32(const ctts_stft_config* cfg, const void* packed, con
                        p.N, p.c.hop_length, g.frames, g.ld);
     CTTS_CHECK_LAUNCH("stft_frames");
     GemmArgs a{};
-    a.exact_f32 = 1;            // Fourier sums cancel: keep exact fp32 products under any process-wide GEMM mode
+    a.gemm_mode = CTTS_GEMM_F32;   // Fourier sums cancel: exact fp32 products, whatever the library default is
     a.ld = g.ld; a.pad = 0; a.L = g.frames; a.ntiles = g.ntiles; a.batch = batch; a.dst_ld = g.ld; a.dst_pad = 0;
     a.A = blob + p.lin_A; a.bias = blob + p.zero_bias;
     a.nseg = 1; a.nch_total = p.N / GEMM_KC; a.MB = p.mb_lin; a.M = 2 * p.cutoff;
@@ -300,7 +300,7 @@ int ctts_stft_inverse_bias_f32(const ctts_stft_config* cfg, const void* packed, 
                        bias_spec, bias_bstride, strength, R, p.cutoff, p.kinv, frames, g.ld);
     CTTS_CHECK_LAUNCH("stft_recombine");
     GemmArgs a{};
-    a.exact_f32 = 1;            // Fourier sums cancel: keep exact fp32 products under any process-wide GEMM mode
+    a.gemm_mode = CTTS_GEMM_F32;   // Fourier sums cancel: exact fp32 products, whatever the library default is
     a.ld = g.ld; a.pad = 0; a.L = frames; a.ntiles = g.ntiles; a.batch = batch; a.dst_ld = g.ld; a.dst_pad = 0;
     a.A = blob + p.inv_A; a.bias = blob + p.zero_bias;
     a.nseg = 1; a.nch_total = p.kinv / GEMM_KC; a.MB = p.mb_inv; a.M = p.N;

@@ -21,6 +21,7 @@ int make_conv_plan(const ctts_conv1d_desc* d, ConvPlan& p) {
     CTTS_CHECK_ARG(d->kernel_size % 2 == 1 && d->kernel_size >= 1 && d->kernel_size <= GEMM_MAX_SEG - 1,
                    "conv1d: kernel_size=%d (odd, <= %d)", d->kernel_size, GEMM_MAX_SEG - 1);
     CTTS_CHECK_ARG(d->act >= 0 && d->act <= 2, "conv1d: act=%d", d->act);
+    CTTS_CHECK_ARG(gemm_mode_valid(d->f32_gemm_mode), "conv1d: f32_gemm_mode=%d (CTTS_GEMM_*)", d->f32_gemm_mode);
     p.mb = (d->c_out + GEMM_BM - 1) / GEMM_BM;
     p.nch = d->kernel_size * d->c_in / GEMM_KC;
     size_t o = 0;
@@ -187,6 +188,7 @@ int ctts_conv1d_f32(const ctts_conv1d_desc* d, const void* packed, const float* 
     GemmArgs a{};
     a.ld = ld; a.pad = pad; a.L = T; a.ntiles = ntiles; a.batch = batch;
     a.dst_ld = ld; a.dst_pad = pad;
+    a.gemm_mode = d->f32_gemm_mode;
     a.A = blob + p.A; a.bias = blob + p.bias;
     a.nseg = d->kernel_size; a.interleave = d->kernel_size; a.nch_total = p.nch; a.MB = p.mb; a.M = d->c_out;
     for (int t = 0; t < d->kernel_size; ++t)

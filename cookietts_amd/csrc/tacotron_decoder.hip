@@ -13,6 +13,7 @@
 //   energies are finite, so location conv, energies, softmax (wave-level reductions), context and the
 //   expected position are computed for the window only; weights outside it are exact zeros.
 #include "tacotron_plan.h"
+#include "tuning.h"
 
 namespace ctts {
 namespace {
@@ -884,7 +885,7 @@ int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void*
     const bool fuse = fast && n_steps > 0 && Rd % R_DEC == 0 && Rd2 % R_D2 == 0 && Ra % R_ATT == 0 &&
                       NB * (p.I_dec + Rd) + 4 * R_DEC * NB <= ATTN_SMEM_FLOATS &&
                       NB * (p.I_d2 + Rd2) + 4 * R_D2 * NB <= ATTN_SMEM_FLOATS &&
-                      NB * (p.I_att + Ra) + 4 * R_ATT * NB <= PROJ_FUSED_SMEM_FLOATS && !getenv("CTTS_TACO_NO_FUSE");
+                      NB * (p.I_att + Ra) + 4 * R_ATT * NB <= PROJ_FUSED_SMEM_FLOATS && !tuning().taco_no_fuse;
     const LstmPart att_early{nullptr, w.gp_att, Pn, p.I_att, 1}, att_fresh{w.gp_att, nullptr, 0, Pn, 0};
     const LstmPart dec_early{nullptr, w.gp_dec, 0, Ra, 1}, dec_fresh{w.gp_dec, nullptr, Ra, p.I_dec, 0};
     const LstmPart d2_early{nullptr, w.gp_d2, 0, 0, 1}, d2_fresh{w.gp_d2, nullptr, 0, p.I_d2, 0};

@@ -753,7 +753,8 @@ void xchg_layout(int A, Xchg& x) {
     x.dech = take(2 * PD_NB * PD_RD);
     x.d2h = take(2 * PD_NB * PD_RD);
     x.h1 = take(2 * PD_NB * PD_P);
-    x.ctl = take(8);          // control words LAST: sticky across launches (zeroed by the owner of the buffer, once)
+    x.ctl = o;                // control words = exactly the LAST 8 words (64 bytes) of the buffer, as the header says:
+    o += 8;                   // sticky across launches (zeroed by the owner of the buffer, once)
     x.total = o;
 }
 
@@ -775,6 +776,15 @@ extern "C" {
 size_t ctts_taco_decoder_persistent_bytes(const ctts_taco_decoder_config* cfg, int32_t batch, int32_t text_len) {
     DecPlan p;
     if (make_dec_plan(cfg, p) || !pd_supported(p, batch, text_len)) return 0;
+    // a current device with fewer than 256 CUs (a CPX / DPX partition) cannot keep the grid co-resident: per-launch form.
+    // Without any device (a host-only size query) the answer is the shape's.
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus < PD_WG) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    (void)hipGetLastError();
     Xchg x;
     xchg_layout(p.c.attention_dim, x);
     return x.total * sizeof(u64);

@@ -1,0 +1,24 @@
+// Launch-shape overrides for A/B measurements (never arithmetic: every alternative is bit-identical or tested equal).
+// The environment is read ONCE, at the first launch that asks; ctts_tuning_reload() re-reads it (tests, profiling
+// scripts).  Arithmetic choices (fp32 MFMA vs split-bf16 main loop) are NOT here: they travel in the config structs.
+#pragma once
+
+namespace ctts {
+
+struct Tuning {
+    bool f32_no_glds;      // CTTS_F32_NO_GLDS: fp32 conv-GEMM without the LDS-DMA staging
+    bool no_xcd_pair;      // CTTS_GEMM_NO_XCD_PAIR: plain block id -> tile mapping
+    bool bf16_no_glds;     // CTTS_BF16_NO_GLDS
+    bool bf16_no_wide;     // CTTS_BF16_NO_WIDE: never the 256 x 256 block
+    bool bf16_no_pp;       // CTTS_BF16_NO_PP: never the ping-pong kernel
+    bool bf16_w4;          // CTTS_BF16_W4: four-wave 128 x 128 wave tiles (opt-in)
+    int bf16_pp_stages;    // CTTS_BF16_PP_STAGES: 3 (default) or 4
+    bool wf_no_fuse;       // CTTS_WF_NO_FUSE: WaveFlow layer as separate GATE + res/skip launches
+    bool taco_no_fuse;     // CTTS_TACO_NO_FUSE: per-launch decoder without the fused projection kernel
+    int w4_debug;          // CTTS_BF16_W4_DEBUG (only in builds with -DCTTS_W4_TIMING_EXPERIMENTS)
+};
+
+Tuning tuning();           // snapshot (by value)
+void reload_tuning();      // ctts_tuning_reload
+
+}  // namespace ctts

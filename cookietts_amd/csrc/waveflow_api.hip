@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "gemm_f32.h"
+#include "tuning.h"
 #include "waveglow_kernels.h"
 #include "waveflow_sep.h"
 
@@ -56,6 +57,7 @@ int make_wf_plan(const ctts_waveflow_config* cfg, WfPlan& p) {
     p.c = *cfg;
     const auto& c = p.c;
     CTTS_CHECK_ARG(c.n_flows >= 1 && c.n_layers >= 1 && c.n_layers <= 12, "n_flows=%d n_layers=%d", c.n_flows, c.n_layers);
+    CTTS_CHECK_ARG(gemm_mode_valid(c.f32_gemm_mode), "f32_gemm_mode=%d (CTTS_GEMM_DEFAULT / _F32 / _BF16X3)", c.f32_gemm_mode);
     CTTS_CHECK_ARG(c.n_group >= 2 && c.n_group <= 64, "n_group=%d", c.n_group);
     CTTS_CHECK_ARG(c.n_channels >= 64 && c.n_channels % 64 == 0, "n_channels=%d (multiple of 64)", c.n_channels);
     CTTS_CHECK_ARG(c.kernel_size_w % 2 == 1 && c.kernel_size_w >= 1 && c.kernel_size_h >= 1, "kernel %dx%d",
@@ -338,7 +340,8 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int e = blockIdx.y, b = blockIdx.z;
     if (t >= T) return;
-    x[((size_t)b * C + row0 + e) * ld + pad + t] = table[(size_t)ids[b] * E + e];
+    const long long id = ids[b];          // an id outside the table poisons the utterance (NaN) instead of reading out of bounds
+    x[((size_t)b * C + row0 + e) * ld + pad + t] = (id >= 0 && id < CTTS_N_SPEAKERS) ? table[(size_t)id * E + e] : __builtin_nanf("");
 }
 
 // y = alpha * x + r on the valid columns (rezero + residual of the model-level cond stack, ax:299-307)
@@ -572,8 +575,9 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
     for (int i = 0; i < Ga; ++i) phys[i] = G - Ga + i;
     const int NS = p.ring;
     auto X = [&](int layer, int slot) { return w.X + ((size_t)layer * NS + slot) * w.xslot; };
-    const bool fuse = p.fused() && !getenv("CTTS_WF_NO_FUSE");
-    const bool sep_fuse = p.sep_fused() && !getenv("CTTS_WF_NO_FUSE");
+    const bool no_fuse = tuning().wf_no_fuse;
+    const bool fuse = p.fused() && !no_fuse;
+    const bool sep_fuse = p.sep_fused() && !no_fuse;
     // un-mix of flow k on the active rows: PermuteHeight composes into the map, the 1x1 conv is a pass over the rows
     auto unmix = [&](int k) -> int {
         if (p.c.mixing == CTTS_MIX_PERMUTE) {
@@ -613,6 +617,7 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
                 const int a_min = std::max(0, kh - 1 - r / dh);           // earlier rows do not exist: skip those taps
                 GemmArgs a{};
                 a.gate = p.c.gated_unit;
+                a.gemm_mode = p.c.f32_gemm_mode;
                 a.bm = WF_BM;
                 a.ld = g.ld; a.pad = g.pad; a.L = L; a.ntiles = g.ntiles; a.batch = batch;
                 a.dst_ld = g.ld; a.dst_pad = g.pad;
@@ -640,6 +645,7 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
                         q.xin = X(si, slot);
                         q.xout = (i == p.c.n_layers - 1 || merge) ? nullptr : X(i + 1, slot);
                         q.gate = p.c.gated_unit;
+                        q.split_bf16 = gemm_mode_is_split(p.c.f32_gemm_mode) ? 1 : 0;
                         q.out = w.out; q.acc_out = i > 0 ? 1 : 0; q.rs_rows = p.rs_rows(i);
                         q.L = L; q.ld = g.ld; q.pad = g.pad; q.ntiles = (L + 63) / 64;
                         if ((rc = launch_wf_sep_layer(q, batch, s))) return rc;
@@ -680,6 +686,7 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
                 if ((rc = launch_gemm_f32(GEMM_EPI_GATE, a, s))) return rc;
 
                 GemmArgs q{};
+                q.gemm_mode = p.c.f32_gemm_mode;
                 q.bm = WF_BM;
                 q.ld = g.ld; q.pad = g.pad; q.L = L; q.ntiles = g.ntiles; q.batch = batch;
                 q.dst_ld = g.ld; q.dst_pad = g.pad;

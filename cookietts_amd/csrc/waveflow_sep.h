@@ -20,6 +20,7 @@ struct WfSepArgs {
     int acc_out;                        // out += (layers > 0) or out = (layer 0)
     int rs_rows;                        // 256, or 128 on the last layer / with merge_res_skip (skip only)
     int gate;                           // GateKind (gemm_f32.h), 0 = GTU
+    int split_bf16;                     // 1: split-bf16 main loop (the model's f32_gemm_mode resolved by the caller)
     int L, ld, pad, ntiles;             // ntiles = ceil(L / 64)
 };
 

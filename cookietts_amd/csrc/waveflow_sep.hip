@@ -18,7 +18,7 @@
 // LDS stage with a register prefetch; B is the LDS tile.  50 KiB of LDS -> three workgroups per CU.
 #include "waveflow_sep.h"
 #include "gemm_bf16.h"   // pack_bf16x2
-#include "gemm_f32.h"    // get_gemm_f32_mode
+#include "gemm_f32.h"
 
 namespace ctts {
 namespace {
@@ -273,7 +273,7 @@ int launch_wf_sep_pack(const float* pw_w, const float* pw_b, const float* rs_w, 
 int launch_wf_sep_layer(const WfSepArgs& a, int batch, hipStream_t s) {
     CTTS_CHECK_ARG(a.L <= a.ntiles * SN && a.ntiles * SN + a.pad <= a.ld && a.pad % 4 == 0 && a.ld % 4 == 0 && a.dwout &&
                    a.cond && a.xin && a.out, "wf_sep_layer: geometry L=%d ld=%d pad=%d", a.L, a.ld, a.pad);
-    if (get_gemm_f32_mode() == 1) hipLaunchKernelGGL(wf_sep_layer_kernel<true>, dim3((unsigned)(a.ntiles * batch)), dim3(256), 0, s, a);
+    if (a.split_bf16) hipLaunchKernelGGL(wf_sep_layer_kernel<true>, dim3((unsigned)(a.ntiles * batch)), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(wf_sep_layer_kernel<false>, dim3((unsigned)(a.ntiles * batch)), dim3(256), 0, s, a);
     CTTS_CHECK_LAUNCH("wf_sep_layer");
     return CTTS_OK;

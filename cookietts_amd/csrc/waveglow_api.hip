@@ -5,6 +5,7 @@
 
 #include "gemm_bf16.h"
 #include "gemm_f32.h"
+#include "tuning.h"
 #include "waveglow_kernels.h"
 
 namespace ctts {
@@ -51,6 +52,7 @@ int make_plan(const ctts_waveglow_config* cfg, Plan& p) {
     p.c = *cfg;
     const auto& c = p.c;
     CTTS_CHECK_ARG(c.n_flows >= 1 && c.n_layers >= 1 && c.n_layers <= 12, "n_flows=%d n_layers=%d", c.n_flows, c.n_layers);
+    CTTS_CHECK_ARG(gemm_mode_valid(c.f32_gemm_mode), "f32_gemm_mode=%d (CTTS_GEMM_DEFAULT / _F32 / _BF16X3)", c.f32_gemm_mode);
     CTTS_CHECK_ARG(c.n_group >= 2 && c.n_group % 2 == 0 && c.n_group <= 8, "n_group=%d (even, <= 8)", c.n_group);
     CTTS_CHECK_ARG(c.kernel_size == 3, "kernel_size=%d (only 3 built)", c.kernel_size);
     CTTS_CHECK_ARG(c.n_channels >= 128 && c.n_channels % 128 == 0, "n_channels=%d (multiple of 128)", c.n_channels);
@@ -165,8 +167,9 @@ struct ProfScope {
 };
 
 // ---- stage launchers ---------------------------------------------------------------
-GemmArgs base_args(const Geom& g, int batch) {
+GemmArgs base_args(const Plan& p, const Geom& g, int batch) {
     GemmArgs a{};
+    a.gemm_mode = p.c.f32_gemm_mode;
     a.ld = g.ld; a.pad = g.pad; a.L = g.L; a.ntiles = g.ntiles; a.batch = batch;
     a.dst_ld = g.ld; a.dst_pad = g.pad;
     return a;
@@ -181,7 +184,10 @@ __global__ __launch_bounds__(256) void speaker_rows_kernel(const float* __restri
     const int e = blockIdx.y, b = blockIdx.z;
     if (n >= ld) return;
     float v = 0.f;
-    if (e < sdim && n >= pad && n < pad + L) v = table[(size_t)ids[b] * sdim + e];
+    if (e < sdim && n >= pad && n < pad + L) {
+        const long long id = ids[b];      // an id outside the table poisons the utterance (NaN) instead of reading out of bounds
+        v = (id >= 0 && id < CTTS_N_SPEAKERS) ? table[(size_t)id * sdim + e] : __builtin_nanf("");
+    }
     spk[((size_t)b * n_flows * S + (size_t)k * S + e) * ld + n] = v;
 }
 
@@ -200,7 +206,7 @@ int fill_speaker_rows(const Plan& p, const Geom& g, const float* blob, const int
 int run_cond(const Plan& p, const Geom& g, const float* blob, const float* spect, const float* spk, float* h_tmp,
              float* h_all, int batch, hipStream_t s) {
     const long long hstride = (long long)p.c.n_flows * p.H * g.ld;
-    GemmArgs a = base_args(g, batch);
+    GemmArgs a = base_args(p, g, batch);
     a.A = blob + p.cond0_A; a.bias = blob + p.cond0_b;
     a.nseg = 1; a.nch_total = p.nch0; a.MB = p.c.n_flows;
     a.seg[0] = {spect, (long long)p.K0 * g.ld, p.K0 / GEMM_KC, 0, 0, 0};
@@ -235,7 +241,7 @@ int run_wn_stack(const Plan& p, const Geom& g, const float* blob, int k, const f
     for (int i = 0; i < p.c.n_layers; ++i) {
         const int dil = 1 << i;
         {
-            GemmArgs a = base_args(g, batch);
+            GemmArgs a = base_args(p, g, batch);
             a.A = blob + f.in_A[i]; a.bias = blob + f.in_b[i];
             a.nseg = 4; a.interleave = 3; a.nch_total = p.nch_in; a.MB = p.mb_in;
             a.seg[0] = {x, cstride, ncx, -dil, 0, 0};
@@ -250,7 +256,7 @@ int run_wn_stack(const Plan& p, const Geom& g, const float* blob, int k, const f
         }
         {
             const bool last = i == p.c.n_layers - 1;
-            GemmArgs a = base_args(g, batch);
+            GemmArgs a = base_args(p, g, batch);
             a.A = blob + f.rs_A[i]; a.bias = blob + f.rs_b[i];
             a.nseg = 1; a.nch_total = p.nch_rs; a.MB = p.rs_mb(i);
             a.seg[0] = {act, cstride, p.nch_rs, 0, 0, 0};
@@ -753,6 +759,7 @@ int ctts_set_f32_gemm_mode(int32_t mode) {
     return CTTS_OK;
 }
 int ctts_get_f32_gemm_mode(void) { return get_gemm_f32_mode(); }
+int ctts_tuning_reload(void) { reload_tuning(); return CTTS_OK; }
 
 int ctts_profile_enable(int32_t on) {
     std::lock_guard<std::mutex> lk(g_prof.mu);

@@ -26,6 +26,7 @@ call counter (untts/model.py:326,333-336) is not reproduced (plain eval-mode bat
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -37,6 +38,12 @@ from . import _cache, _lib
 __all__ = ["Tacotron2", "Decoder", "load_model", "stop_step"]
 
 STOP_CHECK_EVERY = 32
+PINNED_SLOTS = 4            # pinned verdict slots per inference() call (two blocks are in flight at most)
+PERSIST_CTL_WORDS = 8       # the LAST 8 uint64 words (64 bytes) of a persistent-decoder exchange buffer are its control words
+# environment knobs, read once at import: CTTS_TACO_NO_PERSIST=1 keeps the six-launches-per-step decoder,
+# CTTS_TACO_CHUNK=n overrides the steps per launch block (profiling)
+_PERSIST_ON = not os.environ.get("CTTS_TACO_NO_PERSIST")
+_CHUNK = int(os.environ.get("CTTS_TACO_CHUNK", 0))
 drop_rate = 0.5
 
 
@@ -171,6 +178,8 @@ class Decoder(nn.Module):
         self._memory_in_dim = hp.encoder_LSTM_dim + hp.speaker_embedding_dim + hp.torchMoji_crushedDim + 1
         self._packed = None
         self._ws = {}
+        self._xchg = {}
+        self.use_persistent = _PERSIST_ON      # False: the six-launches-per-step decoder (CTTS_TACO_NO_PERSIST=1 at import)
         _cache.hook_invalidate(self)
 
     # ------------------------------------------------------------------ plumbing ----
@@ -183,7 +192,7 @@ class Decoder(nn.Module):
             location_kernel_size=K, window_range=self.windowed_attention_range)
 
     def _invalidate(self):
-        self._packed, self._ws = None, {}
+        self._packed, self._ws, self._xchg = None, {}, {}
 
     def _apply(self, fn, *a, **kw):
         self._invalidate()
@@ -277,21 +286,31 @@ class Decoder(nn.Module):
             self._ws = {key: wss}
         masks = [keep_masks if len(groups) == 1 else keep_masks[:, :, g0:g1].contiguous() for g0, g1 in groups]
         # persistent form (one launch per block of steps, weight-stationary fresh columns, granule all-gathers) where the
-        # library builds it for this shape; CTTS_TACO_NO_PERSIST=1 keeps the six-launches-per-step form
-        import os
-        xchg = []
-        for g0, g1 in groups:
-            off = os.environ.get("CTTS_TACO_NO_PERSIST") or Decoder._persistent_disabled
-            nb = 0 if off else lib.ctts_taco_decoder_persistent_bytes(C.byref(cfg), g1 - g0, T)
-            xchg.append(torch.zeros(nb // 8, dtype=torch.int64, device=device) if nb else None)
+        # library builds it for this shape and device (0 bytes otherwise: the six-launches-per-step form).  The exchange
+        # buffers are zero-filled once and kept with the workspaces; their last 64 bytes are the sticky control words.
+        persist = bool(self.use_persistent) and not Decoder._persistent_disabled
+        xchg = self._xchg.get(key) if persist else [None] * len(groups)
+        if xchg is None:
+            xchg = []
+            for g0, g1 in groups:
+                nb = lib.ctts_taco_decoder_persistent_bytes(C.byref(cfg), g1 - g0, T)
+                xchg.append(torch.zeros(nb // 8, dtype=torch.int64, device=device) if nb else None)
+            self._xchg = {key: xchg}
+        xchg = list(xchg)
+
+        def ctl_words(xb):
+            return xb[-PERSIST_CTL_WORDS:].view(torch.int32)[:4]
+
+        def raise_if_aborted(words):
+            if int(words[0]) != 0:
+                self._xchg = {}       # the control words are sticky: drop the buffers so a retry starts clean
+                raise _lib.HipLibraryError(f"persistent decoder gave up waiting (workgroup {int(words[1])}, "
+                                           f"phase {int(words[2])}, step {int(words[3])})")
 
         def check_persistent():
-            for (g0, g1), xb in zip(groups, xchg):
+            for xb in xchg:
                 if xb is not None:
-                    ctl = xb[-8:-6].view(torch.int32).cpu()
-                    if int(ctl[0]) != 0:
-                        raise _lib.HipLibraryError(
-                            f"persistent decoder gave up waiting (workgroup {int(ctl[1])}, phase {int(ctl[2])}, step {int(ctl[3])})")
+                    raise_if_aborted(ctl_words(xb).cpu())
         mel = torch.zeros(B, self.n_mel_channels, max_steps, dtype=torch.float32, device=device)
         gate = torch.zeros(B, max_steps, dtype=torch.float32, device=device)
         align = torch.zeros(B, max_steps, T, dtype=torch.float32, device=device)
@@ -307,15 +326,20 @@ class Decoder(nn.Module):
             # host looks at block k-1's verdict only after block k is enqueued, so the GPU never waits for the host;
             # steps run past the stop are trimmed below (at most 2 * STOP_CHECK_EVERY of them).
             done, n_total = 0, None
+            chunk = _CHUNK or (STOP_CHECK_EVERY if fixed_steps is None else max_steps)
             if fixed_steps is None:
                 state = torch.empty(lib.ctts_taco_stop_state_bytes(B) // 4, dtype=torch.float32, device=device)
                 _lib.check(lib.ctts_taco_stop_reset(_lib.ptr(state), B, max_steps, stream), "ctts_taco_stop_reset")
                 verdict_dev = state[B + 1:B + 2].view(torch.int32)
-                pending = []                                   # (pinned int32[1], event) per enqueued block
+                # per enqueued block one pinned slot [verdict, ctl word 0 of every group] and one event; two blocks are in
+                # flight at most, so a ring of PINNED_SLOTS slots allocated once per call is never overwritten while pending
+                pinned = torch.zeros(PINNED_SLOTS, 1 + len(groups), dtype=torch.int32).pin_memory()
+                events = [torch.cuda.Event() for _ in range(PINNED_SLOTS)]
+                pending, n_blocks = [], 0                      # slots of enqueued, not yet examined blocks
             while done < max_steps and n_total is None:
-                chunk = int(os.environ.get("CTTS_TACO_CHUNK", 0)) or (STOP_CHECK_EVERY if fixed_steps is None else max_steps)
                 n = min(chunk, max_steps - done)
-                for gi, ((g0, g1), ws, km, xb) in enumerate(zip(groups, wss, masks, xchg)):
+                for gi, ((g0, g1), ws, km) in enumerate(zip(groups, wss, masks)):
+                    xb = xchg[gi]
                     if xb is not None:
                         _lib.check(lib.ctts_taco_decoder_steps_persistent_f32(
                             C.byref(cfg), _lib.ptr(blob), _lib.ptr(km), _lib.ptr(mel[g0:g1]), _lib.ptr(gate[g0:g1]),
@@ -327,12 +351,14 @@ class Decoder(nn.Module):
                             # fall back to the per-launch form for good and redo this block with it
                             stream_obj.synchronize()
                             Decoder._persistent_probed = True
-                            if int(xb[-8:-6].view(torch.int32)[0].item()) != 0:
+                            if int(ctl_words(xb)[0].item()) != 0:
                                 import warnings
                                 warnings.warn("persistent decoder kernel could not run (workgroups not co-resident?); "
                                               "using the per-launch decoder")
                                 Decoder._persistent_disabled = True
-                                xchg[gi] = xb = None
+                                xchg = [None] * len(groups)      # every remaining group of this call too
+                                self._xchg = {}
+                                xb = None
                     if xb is None:
                         _lib.check(lib.ctts_taco_decoder_steps_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(km), _lib.ptr(mel[g0:g1]),
                                                                   _lib.ptr(gate[g0:g1]), _lib.ptr(align[g0:g1]), g1 - g0, T, done,
@@ -342,18 +368,23 @@ class Decoder(nn.Module):
                     _lib.check(lib.ctts_taco_stop_rule_f32(_lib.ptr(gate), B, max_steps, done - n, n,
                                                            float(self.gate_threshold), int(self.gate_delay), _lib.ptr(state),
                                                            stream), "ctts_taco_stop_rule_f32")
-                    host = torch.empty(1, dtype=torch.int32, pin_memory=True)
-                    host.copy_(verdict_dev, non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record(stream_obj)
-                    pending.append((host, ev))
+                    slot = n_blocks % PINNED_SLOTS
+                    n_blocks += 1
+                    pinned[slot, 0:1].copy_(verdict_dev, non_blocking=True)
+                    for gi, xb in enumerate(xchg):              # a kernel abort ends the loop at the next block
+                        if xb is not None:
+                            pinned[slot, 1 + gi:2 + gi].copy_(ctl_words(xb)[0:1], non_blocking=True)
+                        else:
+                            pinned[slot, 1 + gi] = 0
+                    events[slot].record(stream_obj)
+                    pending.append(slot)
                     while len(pending) > (1 if done < max_steps else 0) and n_total is None:
-                        host0, ev0 = pending.pop(0)
-                        ev0.synchronize()
-                        if int(host0[0]) >= 0:
-                            n_total = int(host0[0])
-                    if any(x is not None for x in xchg) and len(pending) == 0:
-                        check_persistent()
+                        slot0 = pending.pop(0)
+                        events[slot0].synchronize()
+                        if bool((pinned[slot0, 1:] != 0).any()):
+                            check_persistent()                  # raises with the recorded (workgroup, phase, step)
+                        if int(pinned[slot0, 0]) >= 0:
+                            n_total = int(pinned[slot0, 0])
             if any(x is not None for x in xchg):
                 stream_obj.synchronize()
                 check_persistent()

@@ -157,6 +157,7 @@ class WaveGlow(nn.Module):
         self._packed = None          # (device, fp32 blob, bf16 blob or None, param key)
         _cache.hook_invalidate(self)
         self._compute_dtype = torch.float32
+        self._f32_gemm_mode = None   # None: the library default; see set_f32_gemm_mode
         self._workspaces = {}        # (device, B, F) -> zero-initialised workspace tensor
 
     # ------------------------------------------------------------------ plumbing ----
@@ -167,7 +168,15 @@ class WaveGlow(nn.Module):
             n_early_every=self.n_early_every, n_early_size=self.n_early_size,
             win_length=self.win_length, hop_length=self.hop_length, n_layers=wn['n_layers'],
             n_channels=wn['n_channels'], kernel_size=wn['kernel_size'], cond_hidden=256,
-            speaker_embed_dim=wn.get('speaker_embed_dim', 0))
+            speaker_embed_dim=wn.get('speaker_embed_dim', 0), f32_gemm_mode=_lib.model_gemm_mode(self._f32_gemm_mode))
+
+    def set_f32_gemm_mode(self, mode):
+        """Main loop of THIS model's fp32 GEMMs: ``"f32"`` (fp32 MFMA), ``"bf16x3"`` (split bf16: fp32 tensors, three
+        bf16 MFMA products per operand pair) or ``None`` / ``"default"`` (whatever ``cookietts_amd.set_f32_gemm_mode``
+        set for the process; fp32 MFMA initially).  Travels in the config struct: other models are not affected."""
+        _lib.model_gemm_mode(mode)
+        self._f32_gemm_mode = mode
+        return self
 
     def _invalidate(self):
         self._packed = None
@@ -375,10 +384,13 @@ class WaveGlow(nn.Module):
         if self.multispeaker:
             if speaker_id is None:      # the reference would feed cond_layers[0] too few channels and crash (glow.py:193-198)
                 raise RuntimeError("this WaveGlow is multispeaker (speaker_embed_dim > 0): pass speaker_id")
+            # range check like nn.Embedding's, where it costs no device sync (host ids); ids already on the device are
+            # checked by the kernel, which turns an out-of-range id into a NaN utterance instead of an out-of-bounds read
+            if not speaker_id.is_cuda and speaker_id.numel() and \
+                    (int(speaker_id.min()) < 0 or int(speaker_id.max()) >= _lib.N_SPEAKERS):
+                raise IndexError("speaker id out of range of the embedding table")
             ids = speaker_id.detach().to(device=device, dtype=torch.int64).reshape(-1).contiguous()
             assert ids.shape[0] == B, (tuple(ids.shape), B)
-            if int(ids.min()) < 0 or int(ids.max()) >= _lib.N_SPEAKERS:
-                raise IndexError("speaker id out of range of the embedding table")
         mode = self._use_bf16()
         ws = self._workspace(device, B, F, bf16=mode)
         wave = torch.empty(B, L * self.n_group, dtype=torch.float32, device=device)

@@ -176,7 +176,7 @@ class _CondConv:
     """One ``ctts_conv1d`` operator of a conditioning stack: dense [out, in, k] weight, input channels zero-padded
     to the primitive's multiple of 16."""
 
-    def __init__(self, w, b, act, slope, device, stream):
+    def __init__(self, w, b, act, slope, device, stream, gemm_mode=0):
         lib = _lib.lib()
         out_c, in_c, k = w.shape
         self.c_in, self.c_out = -(-in_c // 16) * 16, out_c
@@ -186,7 +186,8 @@ class _CondConv:
         b = b.detach().float().contiguous()
         if self.sigmoid:       # tanh epilogue on the halved pre-activation, then (t + 1) / 2 with ctts_affine_rows_f32
             wp, b, act = wp * 0.5, b * 0.5, 2
-        self.desc = _lib.Conv1dDesc(c_in=self.c_in, c_out=out_c, kernel_size=k, act=act, slope=slope)
+        self.desc = _lib.Conv1dDesc(c_in=self.c_in, c_out=out_c, kernel_size=k, act=act, slope=slope,
+                                    f32_gemm_mode=gemm_mode)
         nbytes = lib.ctts_conv1d_packed_bytes(C.byref(self.desc))
         if nbytes == 0:
             raise _lib.HipLibraryError("unsupported cond conv: " + lib.ctts_last_error().decode())
@@ -226,7 +227,7 @@ class _TransposedConv:
     out[n] = sum_q W[:, :, r + q s]^T x[(n + p) // s - q], run by ``ctts_conv1d_f32`` over the input positions and
     interleaved by ``ctts_interleave_phases_f32``."""
 
-    def __init__(self, w, b, s, act, slope, device, stream):
+    def __init__(self, w, b, s, act, slope, device, stream, gemm_mode=0):
         in_c, out_c, k = w.shape                                   # ConvTranspose1d weight layout
         if (k - s) % 2 or k < s:
             raise NotImplementedError(f"transposed conv with kernel {k}, stride {s}: output length is not stride * T")
@@ -236,7 +237,7 @@ class _TransposedConv:
             for q in range(Q):
                 if r + q * s < k:
                     wr[r, :, :, Q - 1 - q] = w[:, :, r + q * s].t()   # tap offset -q of a 'same' conv with 2Q-1 taps
-        self.ops = [_CondConv(wr[r], b, act, slope, device, stream) for r in range(s)]
+        self.ops = [_CondConv(wr[r], b, act, slope, device, stream, gemm_mode) for r in range(s)]
         self.s, self.p, self.out_c = s, (k - s) // 2, out_c
         self.extra = (k - self.p - 1) // s                          # phase positions needed past the input length
 
@@ -293,7 +294,7 @@ class WaveGlow(nn.Module):
                  preempthasis=None, use_logvar_channels=False, load_hidden_from_disk=False,
                  transposed_conv_hidden_dim=256, transposed_conv_kernel_size=4, transposed_conv_scales=None,
                  transposed_conv_output_dim=256, transposed_conv_residual=False, transposed_conv_residual_linear=False,
-                 transposed_conv_res_rezero=False, group_conv_output_dim=None, group_conv_groupped=True, **unsupported):
+                 transposed_conv_res_rezero=False, group_conv_output_dim=None, group_conv_groupped=True, iso226_empthasis=False):
         super().__init__()
         assert n_group % 2 == 0
         assert hop_length % n_group == 0, "hop_length is not int divisible by n_group"
@@ -330,7 +331,7 @@ class WaveGlow(nn.Module):
         self._wn_tconv_factor = int(np.prod(wn['transposed_conv_scales'])) if wn_tconv else 0
         need(cond_padding_mode in ('zeros', 'replicate') and wn.get('cond_padding_mode', 'zeros') in ('zeros', 'replicate'),
              "cond_padding_mode other than 'zeros' / 'replicate'")
-        need(not unsupported.get('iso226_empthasis', False), "iso226 emphasis")
+        need(not iso226_empthasis, "iso226 emphasis")
         need(wn.get('cond_layers', 1) >= 1, "WN without cond layers")
         need(wn.get('upsample_mode', 'linear') == 'linear', "WN upsample_mode != 'linear'")
         if waveflow:                                                            # glow_ax.py:259 / :433
@@ -443,6 +444,7 @@ class WaveGlow(nn.Module):
                         and self._act_wn[0] == 0)
         self._packed = None
         self._ws = {}
+        self._f32_gemm_mode = None
         _cache.hook_invalidate(self)
 
     # ------------------------------------------------------------------ plumbing ----
@@ -459,7 +461,16 @@ class WaveGlow(nn.Module):
                                    mix_first=1 if self.mix_first else 0,
                                    dilation_w=_lib.dilation_array(wn.get('n_layers_dilations_w'), wn['n_layers']),
                                    dilation_h_l=_lib.dilation_array(wn.get('n_layers_dilations_h', 1), wn['n_layers']),
-                                   cond_precomputed=0 if self._folded else 1)
+                                   cond_precomputed=0 if self._folded else 1,
+                                   f32_gemm_mode=_lib.model_gemm_mode(self._f32_gemm_mode))
+
+    def set_f32_gemm_mode(self, mode):
+        """Main loop of THIS model's GEMMs (both cores, and the conditioning operators in front of them): ``"f32"``,
+        ``"bf16x3"`` or ``None`` / ``"default"`` (the library default).  See ``waveglow.WaveGlow.set_f32_gemm_mode``."""
+        _lib.model_gemm_mode(mode)
+        self._f32_gemm_mode = mode
+        self._invalidate()            # the conditioning operators carry the mode in their packed descriptors
+        return self
 
     def c_config_1d(self):
         wn = self.WN_config
@@ -470,7 +481,8 @@ class WaveGlow(nn.Module):
                                mix_first=1 if self.mix_first else 0, ignore_nan=1 if self.ignore_nan else 0,
                                gated_unit=_lib.GATED_UNITS[str(wn.get('gated_unit', 'GTU')).upper()],
                                merge_res_skip=1 if (wn.get('merge_res_skip', False) or not wn.get('res_skip', True)) else 0,
-                               dilation_w=_lib.dilation_array(wn.get('n_layers_dilations_w'), wn['n_layers']))
+                               dilation_w=_lib.dilation_array(wn.get('n_layers_dilations_w'), wn['n_layers']),
+                               f32_gemm_mode=_lib.model_gemm_mode(self._f32_gemm_mode))
 
     def _invalidate(self):
         self._packed, self._ws = None, {}
@@ -597,22 +609,23 @@ class WaveGlow(nn.Module):
                 _lib.check(lib.ctts_waveflow_pack_flow(C.byref(cfg), k, C.byref(fw), _lib.ptr(blob), stream),
                            f"ctts_waveflow_pack_flow({k})")
             ops = None
+            gm = _lib.model_gemm_mode(self._f32_gemm_mode)
             if not self._folded:
                 def stack(layers, act, act_last):
                     out = []
                     for l, layer in enumerate(layers):
                         a = act if (act_last or l != len(layers) - 1) else (0, 0.0)
-                        out.append(_CondConv(self._dense(layer, stream, keep), layer.bias, a[0], a[1], device, stream))
+                        out.append(_CondConv(self._dense(layer, stream, keep), layer.bias, a[0], a[1], device, stream, gm))
                     return out
                 ops = {'model': stack(self.cond_layers, self._act_model, True),          # ax:293-297: every layer
-                       'res_conv': (_CondConv(self.res_conv.weight.detach().float(), self.res_conv.bias, 0, 0.0, device, stream)
+                       'res_conv': (_CondConv(self.res_conv.weight.detach().float(), self.res_conv.bias, 0, 0.0, device, stream, gm)
                                     if hasattr(self, 'res_conv') else None),            # ax:303-304
                        'group': self._group_conv_ops(device, stream),                  # ax:131-134, 320-321
-                       'wn_tconv': ([[_TransposedConv(m.weight.detach().float(), m.bias, sc, 1 if act else 0, 0.4, device, stream)
+                       'wn_tconv': ([[_TransposedConv(m.weight.detach().float(), m.bias, sc, 1 if act else 0, 0.4, device, stream, gm)
                                       for m, sc, act in zip(c.WN.upsample_net.convs(), c.WN.upsample_net.scales,
                                                             c.WN.upsample_net.acts)] for c in self.WN]
                                     if self._wn_tconv_factor else None),                # glow_ax.py:362-373 / 545-554
-                       'tconv': ([_TransposedConv(m.weight.detach().float(), m.bias, sc, 1 if act else 0, 0.4, device, stream)
+                       'tconv': ([_TransposedConv(m.weight.detach().float(), m.bias, sc, 1 if act else 0, 0.4, device, stream, gm)
                                   for m, sc, act in zip(self.upsample_net.convs(), self.upsample_net.scales,
                                                         self.upsample_net.acts)]
                                  if self.upsample_early else None),                     # glow_ax.py:214-226
@@ -657,7 +670,7 @@ class WaveGlow(nn.Module):
         for k in range(self.n_flows):
             row0 = k * cin_g if conv.groups > 1 else 0
             ops.append((_CondConv(w[k * out:(k + 1) * out].contiguous(), b[k * out:(k + 1) * out].contiguous(), 0, 0.0,
-                                  device, stream), row0))
+                                  device, stream, _lib.model_gemm_mode(self._f32_gemm_mode)), row0))
         return ops
 
     def _cond_frames(self, ops, cond, speaker_ids, stream, out_steps=None):

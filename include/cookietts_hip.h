@@ -38,7 +38,16 @@ extern "C" {
 #define CTTS_E_LAUNCH (-2)    /* HIP launch or runtime error */
 #define CTTS_E_WORKSPACE (-3) /* workspace too small */
 
-#define CTTS_ABI_VERSION 3   /* 2: ctts_waveglow_config.speaker_embed_dim, ctts_waveglow_flow_weights.speaker_embed */
+#define CTTS_ABI_VERSION 4   /* 2: ctts_waveglow_config.speaker_embed_dim, ctts_waveglow_flow_weights.speaker_embed
+                              * 3: gated_unit / merge_res_skip in ctts_waveflow_config and ctts_wgax_config
+                              * 4: f32_gemm_mode in ctts_waveglow_config, ctts_waveflow_config, ctts_wgax_config and
+                              *    ctts_conv1d_desc (the arithmetic mode belongs to the model, not to the process);
+                              *    ctts_tuning_reload; the persistent decoder's control words are exactly the last 64 bytes */
+
+/* Main loop of the fp32 conv-GEMM a model's launches use (field f32_gemm_mode of the config structs). */
+#define CTTS_GEMM_DEFAULT 0  /* the library default: fp32 MFMA unless ctts_set_f32_gemm_mode changed it */
+#define CTTS_GEMM_F32 1      /* v_mfma_f32_32x32x2_f32: exact fp32 products */
+#define CTTS_GEMM_BF16X3 2   /* split bf16: hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulation */
 #define CTTS_N_SPEAKERS 512  /* rows of every speaker-embedding table (glow.py:129, efficient_model_ax.py:60) */
 
 int ctts_abi_version(void);
@@ -59,6 +68,7 @@ typedef struct ctts_waveglow_config {
     int32_t kernel_size;    /* 3 */
     int32_t cond_hidden;    /* 256, hard-coded at glow.py:153 */
     int32_t speaker_embed_dim; /* WN_config['speaker_embed_dim'] (glow.py:116,129-133): 0 = single speaker */
+    int32_t f32_gemm_mode;  /* CTTS_GEMM_*: main loop of this model's fp32 GEMMs (fp32 entry points only) */
 } ctts_waveglow_config;
 
 typedef struct ctts_waveglow_geometry {
@@ -236,6 +246,7 @@ typedef struct ctts_waveflow_config {
     int32_t mix_first;       /* 0 | 1: un-mix after / before the coupling inverse (ax:324-325, 337-338) */
     int32_t dilation_w[12];  /* WN_config['n_layers_dilations_w'] per layer (glow_ax.py:507-509); 0 = the default 2^i */
     int32_t dilation_h_l[12];/* WN_config['n_layers_dilations_h'] per layer (glow_ax.py:510-512); 0 = `dilation_h` */
+    int32_t f32_gemm_mode;   /* CTTS_GEMM_*: main loop of this model's GEMMs (dense and fused separable layers) */
 } ctts_waveflow_config;
 
 /* Dense, weight-norm-folded fp32 weights of one flow in checkpoint layouts
@@ -337,6 +348,7 @@ typedef struct ctts_wgax_config {
     int32_t gated_unit;      /* CTTS_GATE_* (0 = 'GTU') */
     int32_t merge_res_skip;  /* 0 | 1 (glow_ax.py:401-416) */
     int32_t dilation_w[12];  /* WN_config['n_layers_dilations_w'] per layer (glow_ax.py:331-333); 0 = the default 2^i */
+    int32_t f32_gemm_mode;   /* CTTS_GEMM_*: main loop of this model's GEMMs */
 } ctts_wgax_config;
 
 /* Dense, weight-norm-folded fp32 device weights of one flow in checkpoint layouts (keys WN.k.WN.*, convinv.k.weight) */
@@ -442,9 +454,10 @@ int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void*
  * launches).  Same state (workspace), same outputs, same keep_masks contract as ctts_taco_decoder_steps_f32, so the
  * two can be mixed call by call.  Built for the repo-default decoder shape (attention RNN 1280, decoder RNNs 768,
  * prenet 256, memory 512, window 16), batch <= 4, text_len <= 1024 on a device with >= 256 CUs:
- * ctts_taco_decoder_persistent_bytes returns 0 otherwise (use the per-launch form).
+ * ctts_taco_decoder_persistent_bytes returns 0 otherwise, also when the CURRENT device has fewer CUs (use the per-launch
+ * form); with no device at all it answers for the shape alone.
  *   exchange: ctts_taco_decoder_persistent_bytes(...) device bytes, zero-filled ONCE by the caller; the call clears the
- *   granule tags itself before every launch.  The LAST 64 bytes are control words (uint32): word 0 stays 0 on success;
+ *   granule tags itself before every launch.  The LAST 64 bytes (bytes - 64 .. bytes) are control words (uint32): word 0 stays 0 on success;
  *   non-zero = a bounded wait gave up (words 1..3: workgroup, phase, step), the outputs of that call are invalid and
  *   every later launch on the same buffer returns immediately (sticky) until the caller zeroes the words. */
 size_t ctts_taco_decoder_persistent_bytes(const ctts_taco_decoder_config* cfg, int32_t batch, int32_t text_len);
@@ -471,6 +484,7 @@ typedef struct ctts_conv1d_desc {
     int32_t kernel_size;  /* odd, <= 11 */
     int32_t act;          /* 0 none, 1 LeakyReLU(slope), 2 tanh */
     float slope;
+    int32_t f32_gemm_mode; /* CTTS_GEMM_*: main loop of this operator's GEMM */
 } ctts_conv1d_desc;
 size_t ctts_conv1d_packed_bytes(const ctts_conv1d_desc* d);
 /* w [c_out][c_in][k], b [c_out]; bn_* [c_out] or all NULL (eval BatchNorm1d folded: w*s, (b-mean)*s+beta). */
@@ -602,9 +616,19 @@ int ctts_taco_stop_rule_f32(const float* gate_logits, int32_t batch, int32_t gat
  * the same kernel, tensors, packed weights and epilogues, but each operand value is split in registers into
  * hi = bf16(v), lo = bf16(v - hi) and each product is computed as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16
  * with fp32 accumulation: operands carry 16 mantissa bits (relative product error ~2^-16), the matrix pipe does
- * 3/16 of the cycles.  Process-wide; returns 0, or -1 for an unknown mode.  ctts_get_f32_gemm_mode returns the mode. */
+ * 3/16 of the cycles.
+ * The mode is part of each model's config struct (f32_gemm_mode = CTTS_GEMM_F32 | CTTS_GEMM_BF16X3), so two models in one
+ * process can differ and nothing races with in-flight calls.  ctts_set_f32_gemm_mode only sets what CTTS_GEMM_DEFAULT (0)
+ * resolves to (0 = fp32 MFMA, the initial value; 1 = split bf16) for callers that leave the field at 0, and for the two
+ * entry points without a config struct (ctts_lstm_seq_f32's input projection, ctts_taco_decoder_init_f32's processed
+ * memory); returns 0, or -1 for an unknown mode.  The STFT entry points always compute in fp32 MFMA (their sums cancel). */
 int ctts_set_f32_gemm_mode(int32_t mode);
 int ctts_get_f32_gemm_mode(void);
+
+/* Launch-shape overrides for A/B measurements (CTTS_F32_NO_GLDS, CTTS_GEMM_NO_XCD_PAIR, CTTS_BF16_NO_GLDS / _NO_WIDE /
+ * _NO_PP / _W4 / _PP_STAGES, CTTS_WF_NO_FUSE, CTTS_TACO_NO_FUSE) never change results.  The environment is read once,
+ * at the first launch; this re-reads it (tests and profiling scripts that flip a knob in-process). */
+int ctts_tuning_reload(void);
 
 /* ---- in-library kernel timing (bench.py roofline leg) --------------------------------- */
 /* When enabled, ctts_waveglow_infer_f32 brackets every launch of the dominant kernel

@@ -70,3 +70,39 @@ def test_stft_stays_exact_in_split_mode(split_mode):
     finally:
         cookietts_amd.set_f32_gemm_mode(prev)
     assert torch.equal(mel_split, mel_f32)
+
+
+def test_two_models_two_modes_interleaved_on_two_streams(hip_lib_path):
+    """The arithmetic mode travels in each model's config struct (ABI 4): an fp32-MFMA model and a split-bf16 model of one
+    process, called alternately on two streams, each reproduce bit for bit what they give when run alone, and the
+    library default (left at fp32) is untouched."""
+    from cookietts_amd import WaveGlow, _lib, synthetic
+    g = np.load(os.path.join(GOLDEN, "waveglow_toy_early.npz"))
+    cfg = synthetic.WAVEGLOW_CONFIGS[str(g["config_key"])]
+    sd = synthetic.to_torch(synthetic.waveglow_state_dict(cfg, seed=int(g["seed"])))
+    models = {}
+    for mode in ("f32", "bf16x3"):
+        m = WaveGlow(**cfg)
+        m.load_state_dict(sd)
+        models[mode] = m.cuda().eval().set_f32_gemm_mode(mode)
+    assert models["f32"].c_config().f32_gemm_mode == 1 and models["bf16x3"].c_config().f32_gemm_mode == 2
+    mel, z = torch.from_numpy(g["mel"]).cuda(), torch.from_numpy(g["z_scaled"]).cuda()
+    alone = {k: m.infer_from_noise(mel, z).clone() for k, m in models.items()}
+    torch.cuda.synchronize()
+    assert not torch.equal(alone["f32"], alone["bf16x3"])                   # the two loops really differ in the last bits
+    streams = {k: torch.cuda.Stream() for k in models}
+    outs = {k: [] for k in models}
+    for _ in range(3):
+        for k, m in models.items():
+            with torch.cuda.stream(streams[k]):
+                outs[k].append(m.infer_from_noise(mel, z).clone())
+    torch.cuda.synchronize()
+    for k in models:
+        for o in outs[k]:
+            assert torch.equal(o, alone[k]), k
+        err = rms_rel_err(alone[k].cpu().numpy(), g["wave"])
+        print(f"{k}: rms rel err vs reference = {err:.3e}")
+        assert err < (1e-5 if k == "f32" else 1e-4)
+    assert _lib.lib().ctts_get_f32_gemm_mode() == 0
+    with pytest.raises(ValueError):
+        models["f32"].set_f32_gemm_mode("tf32")

@@ -291,14 +291,66 @@ def test_persistent_decoder_equals_per_launch_decoder(hip_lib_path, monkeypatch)
         lens[0] = T
         masks = synthetic.prenet_dropout_masks(n, B, seed=B)
         m.decoder.gate_threshold, m.decoder.max_decoder_steps = 2.0, n           # runs all n steps, in blocks of 32
-        monkeypatch.delenv("CTTS_TACO_NO_PERSIST", raising=False)
+        m.decoder.use_persistent = True
         a = m.decoder.inference(mem, lens, keep_masks=masks)
-        monkeypatch.setenv("CTTS_TACO_NO_PERSIST", "1")
+        m.decoder.use_persistent = False
         b = m.decoder.inference(mem, lens, keep_masks=masks)
-        monkeypatch.delenv("CTTS_TACO_NO_PERSIST")
+        m.decoder.use_persistent = True
         assert a[0].shape == b[0].shape == (B, 80, n)
         print(f"B={B} T={T}: mel {float((a[0] - b[0]).abs().max()):.2e} align {float((a[2] - b[2]).abs().max()):.2e}")
         assert (a[0] - b[0]).abs().max() < MEL_TOL and (a[1] - b[1]).abs().max() < MEL_TOL
         assert (a[2] - b[2]).abs().max() < MEL_TOL
     from cookietts_amd.tacotron2 import Decoder
     assert Decoder._persistent_probed and not Decoder._persistent_disabled       # the persistent path really ran
+
+
+@pytest.mark.gpu
+def test_persistent_decoder_abort_is_detected_and_falls_back(hip_lib_path):
+    """The control words are the LAST 64 bytes of the exchange buffer on both sides of the ABI: a non-zero word 0 there
+    (what a bounded wait that gave up leaves behind; the kernel then returns at entry without touching anything) must
+    surface as HipLibraryError with the recorded (workgroup, phase, step) - not as a zero-filled mel - and, on the first
+    persistent launch of a process, as a warning plus the per-launch decoder's result."""
+    import ctypes as C
+    import warnings
+    from cookietts_amd import _lib
+    from cookietts_amd.tacotron2 import Decoder, PERSIST_CTL_WORDS
+    m, g, hp, sd = _model()
+    dec = m.decoder
+    rng = np.random.default_rng(5)
+    B, T, n = 2, 48, 40
+    mem = torch.from_numpy((rng.standard_normal((B, T, synthetic.tacotron_memory_in_dim(hp))) * 0.5).astype(np.float32)).cuda()
+    lens = torch.tensor([T, T - 9]).cuda()
+    masks = synthetic.prenet_dropout_masks(n, B, seed=3)
+    dec.gate_threshold, dec.max_decoder_steps = 2.0, n
+    dec.use_persistent = False
+    want = dec.inference(mem, lens, keep_masks=masks)
+    dec.use_persistent = True
+    good = dec.inference(mem, lens, keep_masks=masks)
+    assert Decoder._persistent_probed and not Decoder._persistent_disabled
+    assert (good[0] - want[0]).abs().max() < MEL_TOL
+    (key, bufs), = dec._xchg.items()
+    nb = _lib.lib().ctts_taco_decoder_persistent_bytes(C.byref(dec.c_config()), B, T)
+    assert bufs[0].numel() * 8 == nb and nb % 64 == 0
+
+    def poison(xb):
+        ctl = xb[-PERSIST_CTL_WORDS:].view(torch.int32)
+        ctl[0], ctl[1], ctl[2], ctl[3] = 1, 7, 3, 5
+    poison(bufs[0])
+    with pytest.raises(_lib.HipLibraryError, match="workgroup 7, phase 3, step 5"):
+        dec.inference(mem, lens, keep_masks=masks)
+    assert dec._xchg == {}                                   # sticky words dropped with the buffer: the next call is clean
+    again = dec.inference(mem, lens, keep_masks=masks)
+    assert torch.equal(again[0], good[0])
+    # first-launch probe: same poison on a fresh process-wide state -> warning, per-launch result, persistent form off
+    try:
+        Decoder._persistent_probed = False
+        (key, bufs), = dec._xchg.items()
+        poison(bufs[0])
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            fb = dec.inference(mem, lens, keep_masks=masks)
+        assert any("per-launch decoder" in str(x.message) for x in w)
+        assert Decoder._persistent_disabled and dec._xchg == {}
+        assert torch.equal(fb[0], want[0]) and torch.equal(fb[2], want[2])
+    finally:
+        Decoder._persistent_probed, Decoder._persistent_disabled = True, False
