@@ -636,13 +636,19 @@ def tacotron_memory_in_dim(hp):
     return hp.encoder_LSTM_dim + hp.speaker_embedding_dim + hp.torchMoji_crushedDim + 1
 
 
-def tacotron_state_dict(hp, seed=1234, shapes=None):
+def tacotron_state_dict(hp, seed=1234, shapes=None, attention_drive=None):
     """Random-init state dict for the reference's ``Tacotron2`` (keys/shapes of its own
     ``state_dict()``; ``shapes`` = {key: shape} from a constructed module, or None to derive them
     from ``cookietts_amd.tacotron2.Tacotron2(hp)``).  Deterministic numpy recipe:
     weights ~ U(+-1/sqrt(fan_in)), BatchNorm running stats non-trivial, the two zero-initialised
     learnable scalars (decoder.exp_smoothing_factor, attention windowed_att_pos_offset) non-zero,
-    and the sylps head forced positive so log(pred_sylps) is finite."""
+    and the sylps head forced positive so log(pred_sylps) is finite.
+
+    ``attention_drive=(a, c, gain)`` turns the near-uniform attention of the plain recipe (energies ~ +-0.3) into a peaked,
+    monotonically advancing one, the regime a trained model runs in: the energy vector ``v`` is scaled by ``gain``,
+    location filter 0 reads the previous weights one and two tokens to the left (taps 13, 14 of channel 0 = ``a``),
+    and attention dims 0..3 carry that feature (location_dense rows 0..3 = e_0, v[0..3] = c / 4), so each step the
+    peak moves right until the window reaches its right clamp (model.py:131-146)."""
     if shapes is None:
         from .tacotron2 import Tacotron2
         shapes = {k: tuple(v.shape) for k, v in Tacotron2(hp).state_dict().items()}
@@ -675,6 +681,18 @@ def tacotron_state_dict(hp, seed=1234, shapes=None):
             sd[key] = _uniform(rng, shape, 1.0 / np.sqrt(fan_in))
         else:
             sd[key] = _uniform(rng, shape, 0.05)
+    if attention_drive is not None:
+        a, c, gain = (np.float32(x) for x in attention_drive)
+        att = "decoder.attention_layer."
+        v = sd[att + "v.linear_layer.weight"] * gain
+        v[0, :4] = c / np.float32(4)
+        sd[att + "v.linear_layer.weight"] = v.astype(np.float32)
+        w = sd[att + "location_layer.location_conv.conv.weight"]
+        w[0] = 0
+        w[0, 0, 13:15] = a
+        d = sd[att + "location_layer.location_dense.linear_layer.weight"]
+        d[:4] = 0
+        d[:4, 0] = 1
     return sd
 
 

@@ -343,7 +343,7 @@ def make_waveglow_ax(full_length=False, untts=False, gates=False):
               f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
-def _ref_tacotron(hp, seed):
+def _ref_tacotron(hp, seed, attention_drive=None):
     """Reference Tacotron2 with the recipe weights.  Shims: no-op RNNCellBase input checks
     (removed in torch 2.x, called at utils/model/layers.py:375-379)."""
     import json
@@ -357,7 +357,7 @@ def _ref_tacotron(hp, seed):
     shapes = {k: list(v.shape) for k, v in m.state_dict().items()}
     with open(os.path.join(HERE, "tacotron_state_shapes.json"), "w") as f:
         json.dump(shapes, f, indent=0, sort_keys=True)
-    sd = synthetic.tacotron_state_dict(hp, seed=seed, shapes=shapes)
+    sd = synthetic.tacotron_state_dict(hp, seed=seed, shapes=shapes, attention_drive=attention_drive)
     res = m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
     assert not res.missing_keys and not res.unexpected_keys
     return m.eval(), ref_model, sd
@@ -436,6 +436,76 @@ def make_tacotron():
           f"-> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+TACOTRON_LONG = {"long": None, "long_peaked": (2.0, 8.0, 1.0), "long_sharp": (4.0, 12.0, 10.0)}   # name -> synthetic attention_drive
+
+
+def make_tacotron_long():
+    """Config 5 at full size over a long horizon (BASELINE.json config 5; model.py:1044-1080, :851-916, :131-146):
+    Tacotron2.inference on B=4, 200 symbols, lengths [200,195,150,100], 256 forced steps, prenet masks injected.
+    Three weight recipes: the plain one (near-uniform attention; the window drifts to the right clamp of every item),
+    a peaked one (weights 0.5-0.7 advancing ~1.5 tokens per step, diffuse once the window sits at the right clamp) and a
+    sharp one (weights up to 0.99, jittering at the clamp: a trajectory on which the reference's own fp32 rounding is
+    amplified to 3e-2 in the weights by step 256 - kept to pin the growth law, tests/test_tacotron_long.py).
+    Captured besides the outputs: the decoder's mel before the postnet, the attention position the decoder carries
+    into each step (the ``current_pos`` argument of Attention.forward) and the window start the reference derives
+    from it (same three lines as model.py:131-139, applied to the captured position)."""
+    torch.set_num_threads(8)
+    hp = synthetic.tacotron_hparams()
+    seed, n_steps, B, T_txt = 1234, 256, 4, 200
+    lengths = np.array([200, 195, 150, 100], dtype=np.int64)
+    rng = np.random.default_rng(2026)
+    text = rng.integers(1, hp.n_symbols, size=(B, T_txt)).astype(np.int64)
+    for b in range(B):
+        text[b, lengths[b]:] = 0
+    speakers = np.array([0, 1, 2, 3], dtype=np.int64)
+    tm = rng.standard_normal((B, hp.torchMoji_attDim)).astype(np.float32)
+    mask_seed = seed + 2
+    masks = synthetic.prenet_dropout_masks(n_steps, B, hp.prenet_dim, seed=mask_seed)
+    for name, drive in TACOTRON_LONG.items():
+        model, ref_model, sd = _ref_tacotron(hp, seed, attention_drive=drive)
+        pos, dec_mel = [], []
+        h1 = model.decoder.attention_layer.register_forward_pre_hook(lambda m, a: pos.append(a[7].detach().clone()))
+        h2 = model.postnet.register_forward_pre_hook(lambda m, a: dec_mel.append(a[0].detach().clone()))
+        saved = ref_model.F.dropout
+        ref_model.F.dropout = _MaskedDropout(masks)
+        try:
+            model.decoder.max_decoder_steps = n_steps
+            model.decoder.gate_threshold = 2.0
+            with torch.no_grad():
+                enc_out, _, sylps = model.encoder(model.embedding(torch.from_numpy(text)).transpose(1, 2),
+                                                  torch.from_numpy(lengths), speaker_ids=torch.from_numpy(speakers))
+                out = model.inference(torch.from_numpy(text), torch.from_numpy(lengths), torch.from_numpy(speakers),
+                                      torch.from_numpy(tm))
+        finally:
+            ref_model.F.dropout = saved
+            h1.remove()
+            h2.remove()
+        pos = torch.stack(pos)                                         # [steps, B]: position carried INTO each step
+        att = model.decoder.attention_layer
+        R = att.windowed_attention_range
+        cur = pos + att.windowed_att_pos_offset.detach()
+        cur = torch.min(cur.clamp(min=R), (torch.from_numpy(lengths) - 1 - R).to(cur))
+        start = (cur - R).clamp(min=0).round().to(torch.int64).numpy()  # [steps, B]
+        align = out["alignments"].numpy().astype(np.float32)
+        for b in range(B):                                             # the captured start IS the support of the weights
+            for i in range(n_steps):
+                nz = np.nonzero(align[b, i])[0]
+                assert nz.min() >= start[i, b] and nz.max() <= min(start[i, b] + 2 * R, lengths[b] - 1)
+        extra = {"encoder_outputs": enc_out.numpy().astype(np.float32)} if drive is None else {}
+        path = os.path.join(HERE, f"tacotron_{name}.npz")
+        np.savez_compressed(path, seed=seed, mask_seed=mask_seed, n_steps=n_steps,
+                            attention_drive=np.array(drive if drive else [], dtype=np.float32),
+                            text=text, lengths=lengths, speakers=speakers, torchmoji=tm,
+                            pred_sylps=sylps.numpy().astype(np.float32),
+                            decoder_mel=dec_mel[0].numpy().astype(np.float32),
+                            pred_mel_postnet=out["pred_mel_postnet"].numpy().astype(np.float32),
+                            pred_gate=out["pred_gate"].numpy().astype(np.float32), alignments=align,
+                            attention_position=pos.numpy().astype(np.float32), window_start=start.astype(np.int32), **extra)
+        print(f"[golden] tacotron_{name}: postnet mel {tuple(out['pred_mel_postnet'].shape)}, window start at steps "
+              f"0/64/128/255 {start[0].tolist()} {start[64].tolist()} {start[128].tolist()} {start[255].tolist()}, "
+              f"max weight {align.max(-1).mean():.3f} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def make_alignment():
     """utils/model/utils.py:47-120 run here on seeded attention maps (data only)."""
     from CookieTTS.utils.model.utils import alignment_metric, get_first_over_thresh
@@ -482,6 +552,8 @@ if __name__ == "__main__":
         make_alignment()
     if "tacotron" in which:
         make_tacotron()
+    if "tacotron_long" in which:
+        make_tacotron_long()
     if "waveflow" in which:
         make_waveflow()
     if "waveglow" in which:
