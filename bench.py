@@ -48,7 +48,8 @@ METRIC = "audio samples/sec (22.05kHz) WaveGlow infer, 80×900 mel, 1/2/4/8 GPU;
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
 # HBM bytes per in-layer launch from committed PMC passes (2 x FETCH_SIZE (gfx950 half-count correction,
-# calibrated on flow_tail) + WRITE_SIZE), config 2 shapes only; not re-measured inside a bench run.
+# calibrated on flow_tail) + WRITE_SIZE) of the exact launch shapes named in the file; not re-measured inside a bench run
+# (PMC collection needs its own rocprofv3 passes: scripts/pmc3.sh).
 TRAFFIC_FILES = ["r3_pmc_traffic.json", "r1_17_pmc_traffic.json"]
 
 
@@ -56,10 +57,19 @@ def load_traffic():
     for name in TRAFFIC_FILES:
         try:
             with open(os.path.join(REPO, "profiles", name)) as f:
-                return {k: v.get("hbm_bytes_per_launch") for k, v in json.load(f).items()}, "profiles/" + name
+                return {k: v for k, v in json.load(f).items() if isinstance(v, dict)}, "profiles/" + name
         except Exception:
             continue
     return {}, None
+
+
+def traffic_bytes(traffic, args, B, F):
+    """HBM bytes per in-layer launch from the committed PMC passes, only for the exact launch shape they were taken on."""
+    key = "f32_bf16x3" if (args.dtype == "f32" and args.gemm_mode == "bf16x3") else args.dtype
+    e = traffic.get(key)
+    if not e or args.config != "full" or F != 900 or B != e.get("batch", 8):
+        return None
+    return e.get("hbm_bytes_per_launch")
 
 
 def parse_args(argv=None):
@@ -321,7 +331,7 @@ def worker(args):
             roofline = {"kernel": kname + " (WN in-layer: dilated conv + cond + tanh*sigmoid)",
                         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                        "traffic": traffic.get(args.dtype) if (B, F, args.config) == (8, 900, "full") else None,
+                        "traffic": traffic_bytes(traffic, args, B, F),
                         "traffic_source": (f"{traffic_src}: committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this "
                                            f"launch shape, not re-measured in this run") if traffic_src else None,
                         "launches": int(n.value), "mean_launch_ms": round(mean_s * 1e3, 4),

@@ -33,13 +33,36 @@ def short(name):
     return "".join(out).replace("ctts::", "")
 
 
+def derive(e):
+    """GRBM_GUI_ACTIVE is summed over the 8 XCDs (18.9e9 / s on the headline kernel = 8 x 2.36 GHz); SQ_VALU_MFMA_BUSY_CYCLES
+    is summed over the 1024 SIMDs and equals 64 x the number of v_mfma_f32_32x32x2_f32 issued (checked on the headline:
+    845.57 GFLOP / 4096 flop x 64 = 13 212 057 600 exactly).  Busy fraction of a SIMD's matrix pipe =
+    busy / (1024 x GUI_ACTIVE / 8); shader clock under the kernel = GUI_ACTIVE / 8 / duration."""
+    if e.get("GRBM_GUI_ACTIVE"):
+        e["shader_clock_ghz_under_pmc"] = e["GRBM_GUI_ACTIVE"] / 8.0 / (e["mean_us_under_pmc"] * 1e3)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in e:
+            e["mfma_busy_frac_per_simd"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["GRBM_GUI_ACTIVE"] * 128.0)
+    if e.get("SQ_WAVE_CYCLES"):
+        for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"):
+            if n in e:
+                e[n + "_frac_of_wave_cycles"] = e[n] / e["SQ_WAVE_CYCLES"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dirs", nargs="+")
     ap.add_argument("--label", default="")
     ap.add_argument("--min-us", type=float, default=20.0, help="drop kernels whose mean duration is below this")
     ap.add_argument("--match", default="", help="regex a kernel name must match")
+    ap.add_argument("--rederive", action="store_true", help="the arguments are summary .json files: recompute the derived fields in place")
     a = ap.parse_args()
+    if a.rederive:
+        for path in a.dirs:
+            d = json.load(open(path))
+            for e in d["kernels"].values():
+                derive(e)
+            json.dump(d, open(path, "w"), indent=1)
+        return
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
     dur = collections.defaultdict(lambda: [0.0, 0])
     meta = {}
@@ -69,13 +92,7 @@ def main():
         e = {"dispatches_per_pass": max(c[1] for c in counters.values()), "mean_us_under_pmc": round(mean_us, 2), **meta[k]}
         for n, c in sorted(counters.items()):
             e[n] = c[0] / c[1]
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in e and "GRBM_GUI_ACTIVE" in e and e["GRBM_GUI_ACTIVE"]:
-            # busy cycles are summed over the SIMDs' matrix pipes that report: per-CU-cycle fraction = busy / (active * 256 CUs * 4)
-            e["mfma_busy_frac_per_simd"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["GRBM_GUI_ACTIVE"] * 256 * 4)
-        if "SQ_WAVE_CYCLES" in e and e["SQ_WAVE_CYCLES"]:
-            for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"):
-                if n in e:
-                    e[n + "_frac_of_wave_cycles"] = e[n] / e["SQ_WAVE_CYCLES"]
+        derive(e)
         out[k] = e
     json.dump({"label": a.label, "source_dirs": a.dirs, "kernels": dict(sorted(out.items(), key=lambda kv: -kv[1]["mean_us_under_pmc"] * kv[1]["dispatches_per_pass"]))},
               sys.stdout, indent=1)

@@ -290,8 +290,14 @@ def test_waveglow_options_match_reference_golden(hip_lib_path, name):
         assert m.multispeaker
         with pytest.raises(RuntimeError):
             m.infer_from_noise(mel, z)                                      # ids are required (glow.py:193-198)
-        with pytest.raises(IndexError):
-            m.infer_from_noise(mel, z, speaker_id=torch.tensor([0, 1, 512]).cuda())
+        with pytest.raises(IndexError):                                     # host ids: checked like nn.Embedding, no sync
+            m.infer_from_noise(mel, z, speaker_id=torch.tensor([0, 1, 512]))
+        # device ids are not read back (no host sync per call): the kernel poisons THAT utterance instead of reading
+        # outside the table; the other utterances are untouched
+        bad_ids = ids.clone()
+        bad_ids[2] = 512
+        bad = m.infer_from_noise(mel, z, speaker_id=bad_ids).cpu().numpy()
+        assert np.isnan(bad[2]).all() and np.array_equal(bad[:2], wave[:2])
         other = m.infer_from_noise(mel, z, speaker_id=ids.flip(0)).cpu().numpy()
         assert rms_rel_err(other, g["wave"]) > 5e-3                          # the embedding really conditions the flows
         assert rms_rel_err(other[1], g["wave"][1]) < WAVE_TOL                # ... per utterance: the middle id is unchanged
