@@ -83,6 +83,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-frames", type=int, default=900,
                     help="mel frames of the CPU-baseline utterance (0 = skip; default = the metric's 900)")
     ap.add_argument("--cpu-budget", type=float, default=40.0, help="wall-time budget (s) of the CPU-baseline repeats")
+    ap.add_argument("--no-cpu-aggregate", action="store_true",
+                    help="skip the concurrent-instances leg of the CPU baseline (single-instance figure only)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-exchange", action="store_true", help="skip the scatter/gather timing for N > 1")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "bf16x3"],
@@ -168,18 +170,37 @@ def launch_ranks(n, argv):
 
 
 # ------------------------------------------------------------------------------- worker ----
-def cpu_baseline(cfg, sd, frames, seed, budget_s):
+def cpu_baseline(cfg, sd, frames, seed, budget_s, config_key=None, aggregate=True):
+    """Single-instance figure (best thread count of a probe) and, beside it, the aggregate of as many concurrent
+    single-utterance instances as fill the host (the metric's batch is 8 utterances): `value` is the better of the two
+    - the best this box's CPU does on the workload - and `cores` the threads that figure used."""
     from oracle import waveglow_torch_cpu as wt
     r = wt.timed_baseline(sd, cfg, frames, seed, budget_s=budget_s)
-    return {"value": r["value"], "unit": "samples/s", "cores": r["cores"], "kind": "port",
-            "sample": f"oracle/waveglow_torch_cpu.py (torch CPU conv ops, reference-free restatement pinned to the "
-                      f"reference goldens), same 12x512 model, 1 utterance x {frames} mel frames ({r['samples']} samples), "
-                      f"torch.set_num_threads({r['threads_set']}) (fastest of a probe over {r['probe']} s per "
-                      f"thread count on a short utterance; {r['physical']} physical cores), warm-up + best of {r['runs']} "
-                      f"= {r['best_s']:.2f} s"}
+    out = {"value": r["value"], "unit": "samples/s", "cores": r["cores"], "kind": "port",
+           "sample": f"oracle/waveglow_torch_cpu.py (torch CPU conv ops, reference-free restatement pinned to the "
+                     f"reference goldens), same 12x512 model, 1 utterance x {frames} mel frames ({r['samples']} samples), "
+                     f"torch.set_num_threads({r['threads_set']}) (fastest of a probe over {r['probe']} s per "
+                     f"thread count on a short utterance; {r['physical']} physical cores), warm-up + best of {r['runs']} "
+                     f"= {r['best_s']:.2f} s -> {r['value']:.0f} samples/s single instance",
+           "single_instance": {"value": r["value"], "threads": r["cores"], "best_s": r["best_s"], "runs": r["runs"]}}
+    if aggregate and config_key is not None:
+        inst = max(1, min(16, r["physical"] // max(r["cores"], 1)))
+        if inst > 1:
+            try:
+                g = wt.timed_aggregate(config_key, frames, seed, r["cores"], inst)
+                out["aggregate"] = g
+                out["sample"] += (f"; aggregate: {inst} concurrent fresh processes x {r['cores']} threads, one {frames}-frame "
+                                  f"utterance each, started together: {g['samples']} samples in {g['span_s']:.2f} s = "
+                                  f"{g['value']:.0f} samples/s ({inst * r['cores']} threads)")
+                if g["value"] > out["value"]:
+                    out["value"], out["cores"] = g["value"], inst * r["cores"]
+            except Exception as e:       # the single-instance figure stands; say why the aggregate is missing
+                out["sample"] += f"; aggregate run failed: {e!r}"[:300]
+    return out
 
 
-def worker(args):
+def worker(args, pre=None):
+    """``pre`` = {"sd": ..., "cpu": ...} computed by main() BEFORE this process touched the GPU (N = 1 only)."""
     import ctypes
     import numpy as np
     import torch
@@ -233,7 +254,7 @@ def worker(args):
         lib = _lib.lib()
         model = WaveGlow(**cfg)
         if rank == 0:                                      # rank 0 owns the checkpoint ...
-            sd = synthetic.waveglow_state_dict(cfg, seed=seed)
+            sd = pre["sd"] if pre else synthetic.waveglow_state_dict(cfg, seed=seed)
             model.load_state_dict(synthetic.to_torch(sd))
         model = model.to(device).eval()
         model.set_f32_gemm_mode(args.gemm_mode)                  # in the model's config struct (ABI 4): explicit, never
@@ -362,9 +383,7 @@ def worker(args):
                 roofline["step_hbm_algorithmic"] = {"bytes_per_step": step_bytes, "achieved": round(step_bytes * args.steps / elapsed / 1e9, 1),
                                                     "peak": 8000.0, "unit": "GB/s",
                                                     "frac": round(step_bytes * args.steps / elapsed / 8e12, 4)}
-        cpu = None
-        if world == 1 and args.cpu_frames > 0 and not selftest:
-            cpu = cpu_baseline(cfg, sd, args.cpu_frames, seed, args.cpu_budget)
+        cpu = pre["cpu"] if pre else None      # timed by main() before the GPU was touched (its aggregate leg starts children)
         line = {
             "metric": METRIC, "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -390,7 +409,18 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # launcher role: nothing below this line in THIS process imports torch or touches HIP
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
-    worker(args)
+    pre = None
+    if args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.selftest_launcher and args.dtype != "cpu":
+        # The CPU baseline runs FIRST, while this process has made no HIP call: its aggregate leg starts child
+        # processes, and nothing GPU-initialised may ever be forked / exec'd on this pool.  (Profiler runs pass
+        # --cpu-frames 0: rocprofv3's preloaded library initialises the GPU before Python starts.)
+        from cookietts_amd import synthetic
+        cfg = synthetic.WAVEGLOW_CONFIGS[args.config]
+        pre = {"sd": synthetic.waveglow_state_dict(cfg, seed=1234), "cpu": None}
+        if args.cpu_frames > 0:
+            pre["cpu"] = cpu_baseline(cfg, pre["sd"], args.cpu_frames, 1234, args.cpu_budget, config_key=args.config,
+                                      aggregate=not args.no_cpu_aggregate)
+    worker(args, pre)
 
 
 if __name__ == "__main__":

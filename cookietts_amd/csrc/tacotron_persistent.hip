@@ -112,24 +112,44 @@ __device__ __forceinline__ bool gather(const u64* g, int count, float* dst, unsi
     }
 }
 
-__device__ __forceinline__ float wave_total(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+// 64-lane reductions on the DPP network (v_add_f32_dpp: quad_perm x2, row_half_mirror, row_mirror, row_bcast15,
+// row_bcast31; the total lands in lanes 48..63 and is read back with v_readlane, so the result is wave-uniform): ~12
+// issue slots per value instead of six ds_bpermute round trips through the LDS crossbar, which every phase of the step
+// used to pay in sequence (360 ds_bpermute in the round-2 ISA).  N independent values interleave level by level.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
 }
-
-// N independent 64-lane sums, level by level: the N butterflies of a level are independent, so their cross-lane
-// operations pipeline instead of paying the exchange latency N x 6 times in sequence.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max(float v) {     // disabled rows / lanes see their own value
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false)));
+}
 template <int N>
 __device__ __forceinline__ void wave_totals(float (&v)[N]) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        float o[N];
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0xB1, 0xf>(v[i]);      // quad_perm [1,0,3,2]
 #pragma unroll
-        for (int i = 0; i < N; ++i) o[i] = __shfl_xor(v[i], off);
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x4E, 0xf>(v[i]);      // quad_perm [2,3,0,1]
 #pragma unroll
-        for (int i = 0; i < N; ++i) v[i] += o[i];
-    }
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x141, 0xf>(v[i]);     // row_half_mirror
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x140, 0xf>(v[i]);     // row_mirror: every lane holds its row's sum
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x142, 0xa>(v[i]);     // row_bcast15 into rows 1, 3
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x143, 0xc>(v[i]);     // row_bcast31 into rows 2, 3: row 3 = total
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[i]), 63));
+}
+__device__ __forceinline__ float wave_total(float v) {
+    float a[1] = {v};
+    wave_totals<1>(a);
+    return a[0];
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = dpp_max<0xB1, 0xf>(v); v = dpp_max<0x4E, 0xf>(v); v = dpp_max<0x141, 0xf>(v); v = dpp_max<0x140, 0xf>(v);
+    v = dpp_max<0x142, 0xa>(v); v = dpp_max<0x143, 0xc>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // Units of a cell with hidden size H on LSTM workgroup wg: 252 workgroups, the first H - 252 * (H / 252) take one more.
@@ -140,15 +160,18 @@ __device__ __forceinline__ int unit_first(int H, int wg) { return wg * (H / PD_L
 // the wave has fewer rows); the values are consumed by fma_rows, so the L2 / Infinity-Cache latency of the whole
 // chunk is paid once.
 template <int NR, int NJ>
-__device__ __forceinline__ void issue_rows(const float* __restrict__ W, int ldw, int col0, const int (&rows)[NR], int lane,
-                                           float4 (&w)[NR][NJ]) {
+__device__ __forceinline__ void issue_rows(const float* __restrict__ blob, unsigned mat, int ldw, int col0, const int (&rows)[NR],
+                                           int lane, float4 (&w)[NR][NJ]) {
+    // rows are wave-uniform: the row base is scalar arithmetic and every load shares one per-lane offset
+    const unsigned lane_off = 4u * (unsigned)lane;
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-        const bool valid = rows[i] >= 0;                                  // wave-uniform
-        const float* rp = W + (size_t)(valid ? rows[i] : 0) * ldw + col0 + 4 * lane;
+        const int row = __builtin_amdgcn_readfirstlane(rows[i]);
+        const bool valid = row >= 0;                                      // wave-uniform
+        const float* rp = blob + mat + (size_t)(valid ? row : 0) * ldw + col0;    // scalar
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-            w[i][j] = valid ? *reinterpret_cast<const float4*>(rp + 256 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            w[i][j] = valid ? *reinterpret_cast<const float4*>(rp + 256 * j + lane_off) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -171,10 +194,10 @@ __device__ __forceinline__ void fma_rows(const float4 (&w)[NR][NJ], const float*
 }
 
 template <int NR, int NJ>
-__device__ __forceinline__ void early_rows(const float* __restrict__ W, int ldw, int col0, const int (&rows)[NR],
+__device__ __forceinline__ void early_rows(const float* __restrict__ blob, unsigned mat, int ldw, int col0, const int (&rows)[NR],
                                            const float* xs, int n, int xoff, int lane, float (&acc)[NR][PD_NB]) {
     float4 w[NR][NJ];
-    issue_rows<NR, NJ>(W, ldw, col0, rows, lane, w);
+    issue_rows<NR, NJ>(blob, mat, ldw, col0, rows, lane, w);
     fma_rows<NR, NJ>(w, xs, n, xoff, lane, acc);
 }
 
@@ -245,10 +268,10 @@ struct AttnLds {
     float q[PD_AMAX];
     float en[64], wts[64];
     float w[PD_TMAX], cum[PD_TMAX];
-    float cpart[4][PD_DM];                        // context partial sums of the four position groups
     float ctx[PD_DM];
     float pos;
 };
+static_assert(PD_T == PD_DM, "the context pass maps one thread to one memory dimension");
 static_assert(sizeof(AttnLds) <= LSTM_FLOATS * sizeof(float), "the attention scratch shares the LSTM workgroups' LDS");
 
 #define PD_STAMP(k)                                                                                         \
@@ -274,6 +297,8 @@ struct AttnRegs {
 // Part 1, BEFORE the query of this step is known (it depends only on the previous step's weights and position, so it
 // runs while the LSTM workgroups are still in their attention-RNN phase): window start, the bursts for the 33-row
 // windows of the processed memory and of the memory, the location conv.  Returns the window start.
+constexpr int PD_WH = (PD_W + 1) / 2;     // window positions per energies wave
+
 __device__ __forceinline__ int pd_attention_pre(const PdArgs& a, AttnLds& s, const AttnRegs& r, int b) {
     const int t = threadIdx.x;
     const int W = 2 * a.R + 1, padk = (a.K - 1) / 2;
@@ -321,10 +346,31 @@ __device__ __forceinline__ int pd_attention_pre(const PdArgs& a, AttnLds& s, con
             s.loc[tt][f] = (acc0 + acc2) + (acc1 + acc3);
         }
     }
-    return s0;      // (the caller's q gather ends with a workgroup barrier: loc / pmw / memw are visible after it)
+    __syncthreads();
+    // everything of the pre-activation that does not need the query: location-dense row of this lane's attention dim on
+    // the location features (33 x 32 x A contraction, features read as 16-byte LDS broadcasts), added IN PLACE to the
+    // staged processed-memory window (each (position, dim) element belongs to exactly one thread).  It used to run
+    // after the query arrived (5.4 us of the step's critical path, LDS-broadcast bound); here it hides in the ~40 us
+    // this workgroup waits for the query anyway.
+    if (r.pg >= 0 && r.ad < a.A) {
+        const int t0 = r.pg == 0 ? 0 : (W + 1) / 2, t1 = r.pg == 0 ? (W + 1) / 2 : W;
+#pragma unroll 1
+        for (int tt = t0; tt < t1; ++tt) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int f4 = 0; f4 < PD_FMAX / 4; ++f4) {
+                const float4 l = *reinterpret_cast<const float4*>(&s.loc[tt][4 * f4]);     // wave-uniform address: broadcast
+                a0 = fmaf(r.wd[4 * f4 + 0], l.x, a0); a1 = fmaf(r.wd[4 * f4 + 1], l.y, a1);
+                a2 = fmaf(r.wd[4 * f4 + 2], l.z, a2); a3 = fmaf(r.wd[4 * f4 + 3], l.w, a3);
+            }
+            s.pmw[tt * a.A + r.ad] += (a0 + a2) + (a1 + a3);
+        }
+    }
+    return s0;      // (the caller's q gather ends with a workgroup barrier: pmw / memw are visible after it)
 }
 
-// Part 2, on the critical path between the query and the context: energies, softmax, context, publish.
+// Part 2, on the critical path between the query and the context: tanh + v-weighted sum over the attention dims,
+// softmax, context, publish.
 __device__ __forceinline__ void pd_attention_post(const PdArgs& a, AttnLds& s, const AttnRegs& r, int b, int s0, unsigned epoch,
                                                   int step, u64* g_ctx) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -335,25 +381,13 @@ __device__ __forceinline__ void pd_attention_post(const PdArgs& a, AttnLds& s, c
         const int t0 = r.pg == 0 ? 0 : (W + 1) / 2, t1 = r.pg == 0 ? (W + 1) / 2 : W;
         const bool live = r.ad < a.A;
         const float qa = live ? s.q[r.ad] : 0.f;
-        float ev[(PD_W + 1) / 2];
+        float ev[PD_WH];
 #pragma unroll
-        for (int i = 0; i < (PD_W + 1) / 2; ++i) {
-            const int tt = min(t0 + i, W - 1);
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;         // four chains: the 32-term dot is latency-bound otherwise
+        for (int i = 0; i < PD_WH; ++i)     // pmw = processed memory + location term (pd_attention_pre)
+            ev[i] = live ? r.va * fast_tanh(s.pmw[min(t0 + i, W - 1) * a.A + r.ad] + qa) : 0.f;
+        wave_totals<PD_WH>(ev);
 #pragma unroll
-            for (int f4 = 0; f4 < PD_FMAX / 4; ++f4) {
-                const float4 l = *reinterpret_cast<const float4*>(&s.loc[tt][4 * f4]);     // wave-uniform address: broadcast
-                a0 = fmaf(r.wd[4 * f4 + 0], l.x, a0); a1 = fmaf(r.wd[4 * f4 + 1], l.y, a1);
-                a2 = fmaf(r.wd[4 * f4 + 2], l.z, a2); a3 = fmaf(r.wd[4 * f4 + 3], l.w, a3);
-            }
-            float acc = (a0 + a2) + (a1 + a3);
-            acc += qa;
-            acc += live ? s.pmw[tt * a.A + r.ad] : 0.f;
-            ev[i] = live ? r.va * fast_tanh(acc) : 0.f;
-        }
-        wave_totals<(PD_W + 1) / 2>(ev);
-#pragma unroll
-        for (int i = 0; i < (PD_W + 1) / 2; ++i)
+        for (int i = 0; i < PD_WH; ++i)
             if (lane == 0 && t0 + i < t1) s.epart[wv % 3][t0 + i] = ev[i];
     }
     __syncthreads();
@@ -362,43 +396,34 @@ __device__ __forceinline__ void pd_attention_post(const PdArgs& a, AttnLds& s, c
         const int pos_l = s0 + lane;
         float e = -INFINITY;
         if (lane < W && pos_l < len && pos_l < a.T) e = (s.epart[0][lane] + s.epart[1][lane]) + s.epart[2][lane];
-        float m = e;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        const float pexp = lane < W ? expf(e - m) : 0.f;
-        const float sum = wave_total(pexp);
-        const float wgt = pexp / sum;
-        if (lane < W) s.wts[lane] = wgt;
-        const float np = wave_total(lane < W ? wgt * (float)(s0 + lane) : 0.f);
+        const float m = wave_max(e);
+        // exp(e - m) on the hardware exp2 (abs error ~1e-7 of a value <= 1); masked lanes: exp2(-inf) = 0
+        const float pexp = lane < W ? __builtin_amdgcn_exp2f((e - m) * 1.4426950408889634f) : 0.f;
+        float sums[2] = {pexp, pexp * (float)(s0 + lane)};     // normaliser and expected position in one pass
+        wave_totals<2>(sums);
+        const float inv = 1.0f / sums[0];
+        if (lane < W) s.wts[lane] = pexp * inv;
         if (lane == 0) {
             const float sf = pd_sigmoid((a.blob + a.scalars)[1]);
-            s.pos = s.pos * sf + np * (1.0f - sf);
+            s.pos = s.pos * sf + (sums[1] * inv) * (1.0f - sf);
         }
     }
     __syncthreads();
     PD_STAMP(4);
-    {   // context = sum_t w[t] * memory[t] out of the staged window: thread = (four dims, one of four position groups)
-        const int d4 = t & 127, grp = t >> 7;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    {   // context = sum_t w[t] * memory[t] out of the staged window: one thread per dimension, two chains, no second pass
+        const int d = t;      // PD_T == PD_DM
+        float c0 = 0.f, c1 = 0.f;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const int tt = grp + 4 * k;
-            if (tt < W) {
-                const float wgt = s0 + tt < a.T ? s.wts[tt] : 0.f;
-                const float4 m = *reinterpret_cast<const float4*>(s.memw + tt * PD_DM + 4 * d4);
-                acc.x = fmaf(wgt, m.x, acc.x); acc.y = fmaf(wgt, m.y, acc.y);
-                acc.z = fmaf(wgt, m.z, acc.z); acc.w = fmaf(wgt, m.w, acc.w);
-            }
+        for (int tt = 0; tt + 1 < PD_W; tt += 2) {
+            c0 = fmaf(tt < W ? s.wts[tt] : 0.f, s.memw[tt * PD_DM + d], c0);
+            c1 = fmaf(tt + 1 < W ? s.wts[tt + 1] : 0.f, s.memw[(tt + 1) * PD_DM + d], c1);
         }
-        *reinterpret_cast<float4*>(&s.cpart[grp][4 * d4]) = acc;
-    }
-    __syncthreads();
-    PD_STAMP(5);
-    for (int d = t; d < PD_DM; d += PD_T) {
-        const float c = (s.cpart[0][d] + s.cpart[1][d]) + (s.cpart[2][d] + s.cpart[3][d]);
+        c0 = fmaf(PD_W - 1 < W ? s.wts[PD_W - 1] : 0.f, s.memw[(PD_W - 1) * PD_DM + d], c0);
+        const float c = c0 + c1;
         s.ctx[d] = c;
         publish(g_ctx, b * PD_DM + d, epoch, c);
     }
+    PD_STAMP(5);
     for (int p = t; p < a.T; p += PD_T) {
         const float wgt = (p >= s0 && p < s0 + W) ? s.wts[p - s0] : 0.f;
         s.w[p] = wgt;
@@ -564,12 +589,12 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
     // phase): one generation of each is live at a time.  Early parts of step0, in the order the loop accumulates them:
     float eA[3][PD_NB], eD[2][PD_NB], e2[2][PD_NB];
     zero_rows<3>(eA); zero_rows<2>(eD); zero_rows<2>(e2);
-    early_rows<3, 2>((a.blob + a.att_wih), I_att, PD_P, rowA, X + XCTX, PD_DM, 0, lane, eA);
-    early_rows<3, 3>((a.blob + a.att_wih), I_att, PD_P + PD_DM, rowA, X + XDEC, PD_RD, 0, lane, eA);
-    early_rows<3, 3>((a.blob + a.att_whh), PD_RA, 0, rowA, X + XATT, PD_RA, 0, lane, eA);
-    early_rows<3, 2>((a.blob + a.att_whh), PD_RA, 768, rowA, X + XATT, PD_RA, 768, lane, eA);
-    early_rows<2, 3>((a.blob + a.dec_whh), PD_RD, 0, rowD, X + XDEC, PD_RD, 0, lane, eD);
-    early_rows<2, 3>((a.blob + a.d2_whh), PD_RD, 0, rowD, X + XD2, PD_RD, 0, lane, e2);
+    early_rows<3, 2>(a.blob, a.att_wih, I_att, PD_P, rowA, X + XCTX, PD_DM, 0, lane, eA);
+    early_rows<3, 3>(a.blob, a.att_wih, I_att, PD_P + PD_DM, rowA, X + XDEC, PD_RD, 0, lane, eA);
+    early_rows<3, 3>(a.blob, a.att_whh, PD_RA, 0, rowA, X + XATT, PD_RA, 0, lane, eA);
+    early_rows<3, 2>(a.blob, a.att_whh, PD_RA, 768, rowA, X + XATT, PD_RA, 768, lane, eA);
+    early_rows<2, 3>(a.blob, a.dec_whh, PD_RD, 0, rowD, X + XDEC, PD_RD, 0, lane, eD);
+    early_rows<2, 3>(a.blob, a.d2_whh, PD_RD, 0, rowD, X + XD2, PD_RD, 0, lane, e2);
     __syncthreads();
 
     bool fail = false;
@@ -597,7 +622,7 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
         // (weight loads whose vector operand is the one being gathered are issued BEFORE the gather: their L2 / Infinity
         // Cache latency runs out during the wait, the FMAs follow the barrier)
         float4 pfB[2][3];
-        issue_rows<2, 3>((a.blob + a.dec_wih), I_dec, 0, rowD, lane, pfB);
+        issue_rows<2, 3>(a.blob, a.dec_wih, I_dec, 0, rowD, lane, pfB);
         PD_GATHER(10, (a.xb + a.g_atth), PD_NB * PD_RA, X + XATT, 1u);
         PD_STAMP(2);
         if (fail) break;
@@ -606,17 +631,16 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
         if (wave == 0 && q_row >= 0) {
             float q[PD_NB] = {0.f, 0.f, 0.f, 0.f};
             row_dots<5>(L + WQ, X + XATT, PD_RA, lane, q);
-#pragma unroll
-            for (int b = 0; b < PD_NB; ++b) q[b] = wave_total(q[b]);
+            wave_totals<PD_NB>(q);
             if (lane < PD_NB)
                 publish((a.xb + a.g_q) + (size_t)par * PD_NB * a.A, lane * a.A + q_row, epoch,
                         lane == 0 ? q[0] : lane == 1 ? q[1] : lane == 2 ? q[2] : q[3]);
         }
         fma_rows<2, 3>(pfB, X + XATT, PD_RA, 0, lane, eD);
-        early_rows<2, 2>((a.blob + a.dec_wih), I_dec, 768, rowD, X + XATT, PD_RA, 768, lane, eD);
+        early_rows<2, 2>(a.blob, a.dec_wih, I_dec, 768, rowD, X + XATT, PD_RA, 768, lane, eD);
         PD_STAMP(3);
         float4 pfC[3][2];
-        issue_rows<3, 2>((a.blob + a.att_wih), I_att, PD_P, rowA, lane, pfC);
+        issue_rows<3, 2>(a.blob, a.att_wih, I_att, PD_P, rowA, lane, pfC);
         PD_GATHER(4, (a.xb + a.g_ctx), PD_NB * PD_DM, X + XCTX, 3u);
         PD_STAMP(4);
         if (fail) break;
@@ -636,8 +660,8 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
         fma_rows<3, 2>(pfC, X + XCTX, PD_DM, 0, lane, eA);
         PD_STAMP(5);
         float4 pfD[3][3], wf2[2][3];      // the second decoder RNN's fresh columns (its whole W_ih, L2-resident): same trick
-        issue_rows<2, 3>((a.blob + a.d2_wih), PD_RD, 0, rowD, lane, wf2);
-        issue_rows<3, 3>((a.blob + a.att_wih), I_att, PD_P + PD_DM, rowA, lane, pfD);
+        issue_rows<2, 3>(a.blob, a.d2_wih, PD_RD, 0, rowD, lane, wf2);
+        issue_rows<3, 3>(a.blob, a.att_wih, I_att, PD_P + PD_DM, rowA, lane, pfD);
         PD_GATHER(6, (a.xb + a.g_dech), PD_NB * PD_RD, X + XDEC, 4u);
         PD_STAMP(6);
         if (fail) break;
@@ -649,7 +673,7 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
         fma_rows<3, 3>(pfD, X + XDEC, PD_RD, 0, lane, eA);
         PD_STAMP(7);
         float4 pfE[2][3];
-        issue_rows<2, 3>((a.blob + a.d2_whh), PD_RD, 0, rowD, lane, pfE);
+        issue_rows<2, 3>(a.blob, a.d2_whh, PD_RD, 0, rowD, lane, pfE);
         PD_GATHER(6, (a.xb + a.g_d2h), PD_NB * PD_RD, X + XD2, 5u);
         PD_STAMP(8);
         if (fail) break;
@@ -663,7 +687,10 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
             row_dots<3>(wrow, X + XD2, PD_RD, lane, o2);                  // W[:, :768] . d2_h   (the residual sum, model.py:755)
             row_dots<2>(wrow + 3 * 64 * 4, X + XCTX, PD_DM, lane, o);     // W[:, 768:] . ctx
 #pragma unroll
-            for (int b = 0; b < PD_NB; ++b) o[b] = wave_total(o[b] + o2[b]) + bpr;
+            for (int b = 0; b < PD_NB; ++b) o[b] += o2[b];
+            wave_totals<PD_NB>(o);
+#pragma unroll
+            for (int b = 0; b < PD_NB; ++b) o[b] += bpr;
             if (lane < PD_NB) {
                 const int b = lane;
                 const float val = lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3];
@@ -681,8 +708,8 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
         fma_rows<2, 3>(pfE, X + XD2, PD_RD, 0, lane, e2);
         if (have_next) {
             // the two prenet exchanges below are pure latency: the recurrent columns of step + 1 fill them
-            early_rows<3, 3>((a.blob + a.att_whh), PD_RA, 0, rowA, X + XATT, PD_RA, 0, lane, eA);
-            early_rows<3, 2>((a.blob + a.att_whh), PD_RA, 768, rowA, X + XATT, PD_RA, 768, lane, eA);
+            early_rows<3, 3>(a.blob, a.att_whh, PD_RA, 0, rowA, X + XATT, PD_RA, 0, lane, eA);
+            early_rows<3, 2>(a.blob, a.att_whh, PD_RA, 768, rowA, X + XATT, PD_RA, 768, lane, eA);
             PD_STAMP(9);
             PD_GATHER(2, (a.xb + a.g_h1), PD_NB * PD_P, X + XH1, 6u);
             PD_STAMP(10);
@@ -693,8 +720,7 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
                 const int row = k == 0 ? w2_row0 : w2_row1;
                 float o[PD_NB] = {0.f, 0.f, 0.f, 0.f};
                 row_dots<1>(L + WW2 + k * 64 * 4, X + XH1, PD_P, lane, o);
-#pragma unroll
-                for (int b = 0; b < PD_NB; ++b) o[b] = wave_total(o[b]);
+                wave_totals<PD_NB>(o);
                 if (lane < PD_NB) {
                     const int b = lane;
                     const float val = lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3];
@@ -704,7 +730,7 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
                     publish((a.xb + a.g_p) + (size_t)par * PD_NB * PD_P, b * PD_P + row, epoch, pv);
                 }
             }
-            early_rows<2, 3>((a.blob + a.dec_whh), PD_RD, 0, rowD, X + XDEC, PD_RD, 0, lane, eD);
+            early_rows<2, 3>(a.blob, a.dec_whh, PD_RD, 0, rowD, X + XDEC, PD_RD, 0, lane, eD);
             PD_STAMP(11);
             PD_GATHER(2, (a.xb + a.g_p), PD_NB * PD_P, X + XP, 7u);
             PD_STAMP(12);

@@ -115,7 +115,7 @@ def timed_baseline(sd, cfg, frames, seed, budget_s=40.0, max_runs=5, probe_frame
     best-of-N full utterances at the best count.
 
     oneDNN's batch-1 conv1d does not scale to every core of a large host: the probe times ``probe_frames`` frames at
-    {physical cores, /2, /4, /8} threads and keeps the fastest, so the baseline is the best this CPU can do, not a
+    {physical cores, /2, /4, /8, 8, 4} threads and keeps the fastest, so the baseline is the best this CPU can do, not a
     thread-oversubscribed figure.  N is bounded by ``budget_s`` of wall time (at least one timed run always happens).
     Returns dict(value samples/s, cores = threads used, runs, best_s, samples, probe).
     """
@@ -134,7 +134,7 @@ def timed_baseline(sd, cfg, frames, seed, budget_s=40.0, max_runs=5, probe_frame
     torch.set_num_threads(phys)
     waveglow_infer(w, cfg, *inputs(min(8, frames)))            # first-touch warm-up, untimed
     probe = {}
-    for n in sorted({phys, max(phys // 2, 1), max(phys // 4, 1), max(phys // 8, 1)}, reverse=True):
+    for n in sorted({phys, max(phys // 2, 1), max(phys // 4, 1), max(phys // 8, 1), min(8, phys), min(4, phys)}, reverse=True):
         torch.set_num_threads(n)
         t0 = time.perf_counter()
         waveglow_infer(w, cfg, pm, pz)
@@ -152,3 +152,92 @@ def timed_baseline(sd, cfg, frames, seed, budget_s=40.0, max_runs=5, probe_frame
     return {"value": wave.size / best, "cores": cores, "threads_set": torch.get_num_threads(), "physical": phys,
             "runs": runs, "best_s": best, "samples": int(wave.size), "frames": frames,
             "probe": {str(k): round(v, 3) for k, v in probe.items()}}
+
+
+# ---- aggregate figure: several single-utterance instances side by side -------------------------------------------
+# One utterance on `threads` cores leaves the rest of a large host idle while the GPU row runs a batch of 8.  The
+# aggregate figure runs `instances` fresh child processes at once (each: its own weights, warm-up, then ONE timed
+# utterance, all started together on a file barrier) and counts all their samples over the span from the first start
+# to the last end.  The children never touch a GPU (HIP_VISIBLE_DEVICES is emptied, nothing of the HIP library loads).
+def _child_main(argv):
+    import argparse
+    import json
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", required=True)
+    ap.add_argument("--frames", type=int, required=True)
+    ap.add_argument("--threads", type=int, required=True)
+    ap.add_argument("--seed", type=int, required=True)
+    ap.add_argument("--sync-dir", required=True)
+    ap.add_argument("--index", type=int, required=True)
+    a = ap.parse_args(argv)
+    from cookietts_amd import synthetic
+    cfg = synthetic.WAVEGLOW_CONFIGS[a.config]
+    torch.set_num_threads(a.threads)
+    w = fold(synthetic.waveglow_state_dict(cfg, seed=a.seed))
+    G, hop = cfg["n_group"], cfg["hop_length"]
+
+    def inputs(fr, sd_):
+        return (synthetic.synthetic_mel(1, fr, seed=sd_),
+                synthetic.synthetic_noise(1, G, fr * hop // G, seed=sd_) * np.float32(0.6))
+    waveglow_infer(w, cfg, *inputs(min(8, a.frames), a.seed))                 # warm-up, untimed
+    mel, z = inputs(a.frames, a.seed + a.index)
+    open(os.path.join(a.sync_dir, f"ready_{a.index}"), "w").close()
+    go = os.path.join(a.sync_dir, "go")
+    t_wait = time.time()
+    while not os.path.exists(go):
+        if time.time() - t_wait > 600:
+            raise SystemExit("no go file")
+        time.sleep(0.01)
+    t0 = time.time()
+    wave = waveglow_infer(w, cfg, mel, z)
+    t1 = time.time()
+    print(json.dumps({"index": a.index, "start": t0, "end": t1, "samples": int(wave.size), "finite": bool(np.isfinite(wave).all())}),
+          flush=True)
+
+
+def timed_aggregate(config_key, frames, seed, threads, instances, timeout_s=900.0):
+    """`instances` concurrent child processes x `threads` threads, one `frames`-frame utterance each.
+    Returns dict(value = all samples / (last end - first start), instances, threads, span_s, per_instance_s)."""
+    import json
+    import subprocess
+    import sys
+    import tempfile
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="",
+               OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+    env["PYTHONPATH"] = repo + os.pathsep + env.get("PYTHONPATH", "")
+    with tempfile.TemporaryDirectory(prefix="ctts_cpu_") as d:
+        procs = [subprocess.Popen([sys.executable, "-m", "oracle.waveglow_torch_cpu", "--config", config_key, "--frames", str(frames),
+                                   "--threads", str(threads), "--seed", str(seed), "--sync-dir", d, "--index", str(i)],
+                                  cwd=repo, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                 for i in range(instances)]
+        try:
+            t0 = time.time()
+            while not all(os.path.exists(os.path.join(d, f"ready_{i}")) for i in range(instances)):
+                for p in procs:
+                    if p.poll() is not None:
+                        raise RuntimeError(f"CPU-baseline child exited early ({p.returncode}): {p.stderr.read()[-2000:]}")
+                if time.time() - t0 > timeout_s:
+                    raise RuntimeError("CPU-baseline children did not get ready in time")
+                time.sleep(0.05)
+            open(os.path.join(d, "go"), "w").close()
+            outs = []
+            for p in procs:
+                out, err = p.communicate(timeout=timeout_s)
+                if p.returncode != 0:
+                    raise RuntimeError(f"CPU-baseline child failed ({p.returncode}): {err[-2000:]}")
+                outs.append(json.loads(out.strip().splitlines()[-1]))
+        finally:
+            for p in procs:           # exact children only
+                if p.poll() is None:
+                    p.kill()
+    assert all(o["finite"] for o in outs)
+    span = max(o["end"] for o in outs) - min(o["start"] for o in outs)
+    total = sum(o["samples"] for o in outs)
+    return {"value": total / span, "instances": instances, "threads": threads, "span_s": span, "samples": total,
+            "per_instance_s": [round(o["end"] - o["start"], 2) for o in sorted(outs, key=lambda o: o["index"])]}
+
+
+if __name__ == "__main__":
+    import sys
+    _child_main(sys.argv[1:])

@@ -14,6 +14,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cookietts_amd import synthetic  # noqa: E402
 
 
+def _batches(args, default):
+    return tuple(int(x) for x in args.batches.split(",")) if getattr(args, "batches", "") else default
+
+
 def timed(fn, warmup, steps):
     for _ in range(warmup):
         fn()
@@ -79,7 +83,7 @@ def row_waveglow_ax_notebook(args):
     m.load_state_dict(synthetic.to_torch(synthetic.waveglow_ax_state_dict(cfg, seed=1234)))
     m = m.cuda().eval()
     rows = []
-    for B in (1, 8):
+    for B in _batches(args, (1, 8)):
         F = 468                                                   # -> (F - 1) * 600 = 280 200 samples = 5.8375 s
         mel = torch.from_numpy(synthetic.synthetic_mel(B, F, cfg["n_mel_channels"])).cuda()
         ids = torch.zeros(B, dtype=torch.int64).cuda()
@@ -158,7 +162,7 @@ def row_waveglow_ax_untts(args):
     m.load_state_dict(synthetic.to_torch(synthetic.waveglow_ax_state_dict(cfg, seed=1234)))
     m = m.cuda().eval()
     rows = []
-    for B in (1, 4):
+    for B in _batches(args, (1, 4)):
         F = 468
         mel = torch.from_numpy(synthetic.synthetic_mel(B, F, cfg["n_mel_channels"])).cuda()
         ids = torch.zeros(B, dtype=torch.int64).cuda()
@@ -176,6 +180,7 @@ if __name__ == "__main__":
     ap.add_argument("--rows", default="waveflow,tacotron,stft")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batches", default="", help="comma list: restrict the multi-batch rows (waveglow_ax, waveglow_ax_untts) to these batch sizes (PMC passes)")
     args = ap.parse_args()
     fns = {"waveflow": row_waveflow, "waveflow_author": row_waveflow_author, "tacotron": row_tacotron, "stft": row_stft,
            "waveglow_ax": row_waveglow_ax_notebook, "waveglow_ax_untts": row_waveglow_ax_untts}
