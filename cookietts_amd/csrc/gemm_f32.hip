@@ -72,13 +72,23 @@ __device__ __forceinline__ void split_epilogue(const GemmArgs& a, f32x16 (&acc)[
         // the wave pays one memory latency per tile, not one per element (the compiler must
         // otherwise order every load behind the previous, possibly aliasing, store).
         float old[2][16];
-        if (accum) {   // uniform; columns >= L of a padded row are readable, so no per-lane guard
+        if (accum && rbase + 32 <= M) {   // uniform; columns >= L of a padded row are readable, so no per-lane guard
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
                     old[nt][r] = src[(size_t)(rdst + row) * a.dst_ld + a.dst_pad + ncol0 + nt * 32 + l31];
+                }
+        } else if (accum) {               // last row tile of a ragged M (the postnet's 80 mel rows): rows >= M do not
+                                          // exist in the destination tensor - reading them ran past the end of the last
+                                          // batch item's allocation (a memory fault when it ends at a mapping boundary)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    old[nt][r] = rbase + row < M ? src[(size_t)(rdst + row) * a.dst_ld + a.dst_pad + ncol0 + nt * 32 + l31] : 0.0f;
                 }
         } else {
 #pragma unroll
