@@ -83,6 +83,10 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-frames", type=int, default=900,
                     help="mel frames of the CPU-baseline utterance (0 = skip; default = the metric's 900)")
     ap.add_argument("--cpu-budget", type=float, default=40.0, help="wall-time budget (s) of the CPU-baseline repeats")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="launcher role (--gpus N > 1): wall-clock seconds after which the rank processes are terminated (exit 124)")
+    ap.add_argument("--no-exchange-dry-run", action="store_true",
+                    help="N = 1: skip the world-size-1 RCCL pass over the broadcast / scatter / gather code (outside the timed steps)")
     ap.add_argument("--no-cpu-aggregate", action="store_true",
                     help="skip the concurrent-instances leg of the CPU baseline (single-instance figure only)")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -109,22 +113,48 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, timeout_s=1500.0, log_dir=None):
     """Start ``n`` fresh rank processes of this script.  The parent has not imported torch and makes
-    no HIP call, so nothing GPU-initialised is ever forked or exec'd.  Returns the exit code."""
+    no HIP call, so nothing GPU-initialised is ever forked or exec'd.  Every rank's stderr goes to
+    ``<log_dir>/rank<r>.err`` (the tail of a failing rank's file is echoed); a wall-clock ``timeout_s``
+    ends exactly the children this function started and returns 124.  Returns the exit code."""
     port = _free_port()
-    procs = []
+    log_dir = log_dir or os.environ.get("CTTS_BENCH_LOG_DIR") or os.path.join(REPO, "gpurun_out", "bench_logs")
+    os.makedirs(log_dir, exist_ok=True)
+    procs, errs = [], []
     for r in range(n):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        errs.append(open(os.path.join(log_dir, f"rank{r}.err"), "w"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
-                                      stderr=None, text=True))
+                                      stderr=errs[-1], text=True))
+
+    def end_children(which):
+        for r in which:                       # exactly these PIDs
+            if procs[r].poll() is None:
+                procs[r].terminate()
+        for r in which:
+            try:
+                procs[r].wait(20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+
+    def echo_tail(r, lines=30):
+        errs[r].flush()
+        try:
+            with open(os.path.join(log_dir, f"rank{r}.err")) as f:
+                tail = f.read().splitlines()[-lines:]
+        except OSError:
+            tail = []
+        sys.stderr.write(f"[bench launcher] ---- tail of {log_dir}/rank{r}.err ----\n" + "\n".join(tail) + "\n")
+
     failed = None
     out0 = None
     pending = set(range(n))
+    t_start = time.monotonic()
     while pending and failed is None:
         for r in sorted(pending):
             if r == 0 and out0 is None and procs[0].poll() is not None:
@@ -137,33 +167,42 @@ def launch_ranks(n, argv):
                 failed = (r, rc)
                 break
         if pending and failed is None:
+            if time.monotonic() - t_start > timeout_s:
+                sys.stderr.write(f"[bench launcher] wall-clock limit of {timeout_s:.0f} s reached with ranks {sorted(pending)} "
+                                 f"still running: terminating them\n")
+                end_children(sorted(pending))
+                for r in sorted(pending):
+                    echo_tail(r, 10)
+                for f in errs:
+                    f.close()
+                return 124
             time.sleep(0.2)
             if out0 is None and procs[0].poll() is not None:
                 out0 = procs[0].stdout.read()
     if failed is not None:
-        for r in pending:                     # the others would hang in a collective: end exactly these PIDs
-            procs[r].terminate()
-        for r in pending:
-            try:
-                procs[r].wait(20)
-            except subprocess.TimeoutExpired:
-                procs[r].kill()
+        end_children(sorted(pending))         # the others would hang in a collective
         sys.stderr.write(f"[bench launcher] rank {failed[0]} exited with code {failed[1]}\n")
+        echo_tail(failed[0])
         if out0 is None and procs[0].stdout is not None:
             try:
                 out0 = procs[0].stdout.read()
             except Exception:
                 out0 = ""
         sys.stdout.write(out0 or "")
+        for f in errs:
+            f.close()
         return failed[1] if failed[1] > 0 else 1
     if out0 is None:
         out0 = procs[0].stdout.read()
+    for f in errs:
+        f.close()
     lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
     for ln in out0.splitlines():
         if not ln.startswith("{"):
             sys.stderr.write(ln + "\n")
     if not lines:
         sys.stderr.write("[bench launcher] rank 0 printed no JSON line\n")
+        echo_tail(0)
         return 1
     print(lines[-1])
     return 0
@@ -245,7 +284,10 @@ def worker(args, pre=None):
         lib = None
         model = torch.nn.Linear(8, 8)                      # something to broadcast
         if os.environ.get("CTTS_BENCH_SELFTEST_FAIL_RANK") == str(rank):
+            sys.stderr.write("selftest: this rank fails on purpose\n")
             raise SystemExit(7)                            # lets the test see a rank failure propagate
+        if os.environ.get("CTTS_BENCH_SELFTEST_HANG_RANK") == str(rank):
+            time.sleep(3600)                               # lets the test see the wall-clock limit end the ranks
 
         def step_on(m):                                   # stand-in with the vocoder's shape contract
             return m.mean(dim=1, keepdim=True).repeat_interleave(cfg["hop_length"], dim=2).reshape(m.shape[0], -1)
@@ -323,6 +365,39 @@ def worker(args, pre=None):
                         scatter_bytes=int(world * B * n_mel * F * 4), gather_bytes=int(world * B * T * 4),
                         note="steady state (second pass; the first opens the RCCL point-to-point channels); "
                              "barrier + synchronize on both sides of each leg, so each figure includes one barrier")
+
+    # N = 1: the same exchange code on a world-size-1 RCCL group, outside the timed steps, so that broadcast / scatter /
+    # gather have run on RCCL on this box before the first multi-GPU lease.  A failure here is
+    # recorded, it never takes the headline line down.
+    if world == 1 and not selftest and not args.no_exchange and not args.no_exchange_dry_run:
+        try:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+            sync()
+            t0 = time.perf_counter()
+            nbytes = sharding.broadcast_state_dict(model, src=0)
+            sync()
+            t1 = time.perf_counter()
+            n_mel = cfg["n_mel_channels"]
+            local, counts = sharding.scatter_mels(mel, n_mel, device, src=0)
+            sync()
+            t2 = time.perf_counter()
+            wave = step_on(local)
+            sync()
+            t3 = time.perf_counter()
+            waves = sharding.gather_waves(wave, counts, dst=0)
+            sync()
+            t4 = time.perf_counter()
+            assert waves.shape == (B, T) and bool(torch.isfinite(waves).all())
+            exchange = {"dry_run_world_1": True, "backend": "nccl (RCCL)", "broadcast_ms": (t1 - t0) * 1e3,
+                        "broadcast_bytes": int(nbytes), "scatter_ms": (t2 - t1) * 1e3, "infer_ms": (t3 - t2) * 1e3,
+                        "gather_ms": (t4 - t3) * 1e3, "scatter_bytes": int(B * n_mel * F * 4), "gather_bytes": int(B * T * 4),
+                        "note": "world size 1: the code path of the multi-GPU exchange on RCCL, not an xGMI measurement"}
+            dist.destroy_process_group()
+        except Exception as e:
+            exchange = {"dry_run_world_1": True, "error": repr(e)[:300]}
 
     if rank == 0:
         samples = world * B * T * args.steps
@@ -408,7 +483,7 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # launcher role: nothing below this line in THIS process imports torch or touches HIP
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], timeout_s=args.launch_timeout))
     pre = None
     if args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.selftest_launcher and args.dtype != "cpu":
         # The CPU baseline runs FIRST, while this process has made no HIP call: its aggregate leg starts child

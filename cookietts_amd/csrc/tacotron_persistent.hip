@@ -264,7 +264,6 @@ struct AttnLds {
     float memw[PD_W * PD_DM];                     // the memory window (context operand), staged before the query arrives
     float loc[PD_W][PD_FMAX + 4];                 // rows 16-byte aligned: read as float4 broadcasts
     float wcat[2][PD_W + PD_KMAX - 1 + 1];
-    float epart[3][64];                           // energies of the three 64-wide attention-dim blocks
     float q[PD_AMAX];
     float en[64], wts[64];
     float w[PD_TMAX], cum[PD_TMAX];
@@ -290,8 +289,8 @@ static_assert(sizeof(AttnLds) <= LSTM_FLOATS * sizeof(float), "the attention scr
 struct AttnRegs {
     float wl[2 * PD_KMAX];      // location conv taps [c][j] of filter t % 32
     float wd[PD_FMAX];          // location-dense weight column [f] of attention dim `ad`
-    float va;                   // v[ad]
-    int ad, pg;                 // energies: attention dim, position group (-1: this wave sits the energies out)
+    float va3[3];               // v[lane], v[lane + 64], v[lane + 128]: the energies pass
+    int ad, pg;                 // location-dense pass: attention dim, position group (-1: this wave sits it out)
 };
 
 // Part 1, BEFORE the query of this step is known (it depends only on the previous step's weights and position, so it
@@ -377,25 +376,32 @@ __device__ __forceinline__ void pd_attention_post(const PdArgs& a, AttnLds& s, c
     const int wg = blockIdx.x;
     const int W = 2 * a.R + 1;
     const int len = reinterpret_cast<const int*>(a.ws + a.lengths)[b];
-    if (r.pg >= 0) {   // energies (model.py:107-112): wave = (64 attention dims, half of the window positions)
-        const int t0 = r.pg == 0 ? 0 : (W + 1) / 2, t1 = r.pg == 0 ? (W + 1) / 2 : W;
-        const bool live = r.ad < a.A;
-        const float qa = live ? s.q[r.ad] : 0.f;
-        float ev[PD_WH];
+    {   // energies (model.py:107-112): wave wv takes window positions wv, wv + 8, ...; a lane sums its three attention
+        // dims (lane, lane + 64, lane + 128) first, so a position costs ONE 64-lane reduction, not three (round 2 / the
+        // first round-3 cut: 17 reductions per wave; now at most 5)
+        float qv[3], ev[5];
 #pragma unroll
-        for (int i = 0; i < PD_WH; ++i)     // pmw = processed memory + location term (pd_attention_pre)
-            ev[i] = live ? r.va * fast_tanh(s.pmw[min(t0 + i, W - 1) * a.A + r.ad] + qa) : 0.f;
-        wave_totals<PD_WH>(ev);
+        for (int j = 0; j < 3; ++j) qv[j] = lane + 64 * j < a.A ? s.q[lane + 64 * j] : 0.f;
 #pragma unroll
-        for (int i = 0; i < PD_WH; ++i)
-            if (lane == 0 && t0 + i < t1) s.epart[wv % 3][t0 + i] = ev[i];
+        for (int i = 0; i < 5; ++i) {
+            const int tt = min(wv + 8 * i, W - 1);
+            float e = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)     // pmw = processed memory + location term (pd_attention_pre)
+                e += lane + 64 * j < a.A ? r.va3[j] * fast_tanh(s.pmw[tt * a.A + lane + 64 * j] + qv[j]) : 0.f;
+            ev[i] = e;
+        }
+        wave_totals<5>(ev);
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            if (lane == 0 && wv + 8 * i < W) s.en[wv + 8 * i] = ev[i];
     }
     __syncthreads();
     PD_STAMP(3);
     if (wv == 0) {
         const int pos_l = s0 + lane;
         float e = -INFINITY;
-        if (lane < W && pos_l < len && pos_l < a.T) e = (s.epart[0][lane] + s.epart[1][lane]) + s.epart[2][lane];
+        if (lane < W && pos_l < len && pos_l < a.T) e = s.en[lane];
         const float m = wave_max(e);
         // exp(e - m) on the hardware exp2 (abs error ~1e-7 of a value <= 1); masked lanes: exp2(-inf) = 0
         const float pexp = lane < W ? __builtin_amdgcn_exp2f((e - m) * 1.4426950408889634f) : 0.f;
@@ -456,7 +462,8 @@ __device__ __forceinline__ void attention_workgroup(const PdArgs& a, AttnLds& at
         const bool live = r.pg >= 0 && r.ad < a.A;
 #pragma unroll
         for (int ff = 0; ff < PD_FMAX; ++ff) r.wd[ff] = (live && ff < a.F) ? (a.blob + a.Wd)[(size_t)ff * a.A + r.ad] : 0.f;
-        r.va = live ? (a.blob + a.v)[r.ad] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) r.va3[j] = lane + 64 * j < a.A ? (a.blob + a.v)[lane + 64 * j] : 0.f;
     }
     for (int i = t; i < PD_W * (PD_FMAX + 4); i += PD_T) (&att.loc[0][0])[i] = 0.f;     // filters >= F stay zero
     for (int d = t; d < PD_DM; d += PD_T) att.ctx[d] = 0.f;

@@ -51,7 +51,7 @@ def test_parent_does_not_import_torch_before_spawning():
         "import sys; sys.argv = ['bench.py', '--gpus', '2']\n"
         "import bench\n"
         "seen = {}\n"
-        "def fake(n, argv):\n"
+        "def fake(n, argv, **kw):\n"
         "    seen['n'] = n; seen['torch'] = 'torch' in sys.modules; return 0\n"
         "bench.launch_ranks = fake\n"
         "try:\n"
@@ -61,3 +61,29 @@ def test_parent_does_not_import_torch_before_spawning():
         "assert seen == {'n': 2, 'torch': False}, seen\n")
     r = subprocess.run([sys.executable, "-c", code], env=_env(), cwd=REPO, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_launcher_keeps_per_rank_stderr_and_echoes_the_failing_rank(tmp_path):
+    env = _env()
+    env["CTTS_BENCH_SELFTEST_FAIL_RANK"] = "1"
+    env["CTTS_BENCH_LOG_DIR"] = str(tmp_path)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2",
+                        "--frames", "4", "--selftest-launcher"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 7
+    assert (tmp_path / "rank0.err").exists() and "fails on purpose" in (tmp_path / "rank1.err").read_text()
+    assert "tail of" in r.stderr and "fails on purpose" in r.stderr
+
+
+def test_launcher_wall_clock_limit_ends_its_children(tmp_path):
+    # rank 1 never reaches the first collective and never exits: the launcher's own limit must end both ranks
+    import time
+    env = _env()
+    env["CTTS_BENCH_SELFTEST_HANG_RANK"] = "1"
+    env["CTTS_BENCH_LOG_DIR"] = str(tmp_path)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2",
+                        "--frames", "4", "--selftest-launcher", "--launch-timeout", "20"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 124 and time.time() - t0 < 120
+    assert "wall-clock limit" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
