@@ -596,10 +596,10 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
     // phase): one generation of each is live at a time.  Early parts of step0, in the order the loop accumulates them:
     float eA[3][PD_NB], eD[2][PD_NB], e2[2][PD_NB];
     zero_rows<3>(eA); zero_rows<2>(eD); zero_rows<2>(e2);
-    early_rows<3, 2>(a.blob, a.att_wih, I_att, PD_P, rowA, X + XCTX, PD_DM, 0, lane, eA);
-    early_rows<3, 3>(a.blob, a.att_wih, I_att, PD_P + PD_DM, rowA, X + XDEC, PD_RD, 0, lane, eA);
     early_rows<3, 3>(a.blob, a.att_whh, PD_RA, 0, rowA, X + XATT, PD_RA, 0, lane, eA);
     early_rows<3, 2>(a.blob, a.att_whh, PD_RA, 768, rowA, X + XATT, PD_RA, 768, lane, eA);
+    early_rows<3, 2>(a.blob, a.att_wih, I_att, PD_P, rowA, X + XCTX, PD_DM, 0, lane, eA);
+    early_rows<3, 3>(a.blob, a.att_wih, I_att, PD_P + PD_DM, rowA, X + XDEC, PD_RD, 0, lane, eA);
     early_rows<2, 3>(a.blob, a.dec_whh, PD_RD, 0, rowD, X + XDEC, PD_RD, 0, lane, eD);
     early_rows<2, 3>(a.blob, a.d2_whh, PD_RD, 0, rowD, X + XD2, PD_RD, 0, lane, e2);
     __syncthreads();
@@ -615,6 +615,20 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
         const unsigned epoch = (unsigned)step + 1u;
         const int par = step & 1;
         PD_STAMP(0);
+        // the prenet's dropout keep-bytes of step + 1 for this wave's row (waves 1, 2: first layer, rows of the folded
+        // projection; waves 3, 4: second layer), lane = batch item.  Loaded HERE, a whole step ahead of their use: they
+        // are first-touch HBM bytes, and the load used to sit between the row's dot product and its publish - ~1.5 us
+        // on the critical path of both prenet exchanges.
+        const bool have_next = step + 1 < a.max_steps;
+        unsigned char keep_next = 0;
+        if (have_next && lane < a.batch) {
+            if (wave == 1 || (wave == 2 && pr_row1 >= 0)) {
+                const int j = (wave == 1 ? pr_row0 : pr_row1) - a.n_mel - 1;
+                if (j >= 0) keep_next = a.keep[(((size_t)(step + 1) * 2 + 0) * a.batch + lane) * PD_P + j];
+            } else if (wave == 3 || (wave == 4 && w2_row1 >= 0)) {
+                keep_next = a.keep[(((size_t)(step + 1) * 2 + 1) * a.batch + lane) * PD_P + (wave == 3 ? w2_row0 : w2_row1)];
+            }
+        }
         // ---- A: attention RNN on the fresh prenet columns (model.py:707-717)
         {
             float4 wf[3][1];
@@ -628,8 +642,9 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
         PD_STAMP(1);
         // (weight loads whose vector operand is the one being gathered are issued BEFORE the gather: their L2 / Infinity
         // Cache latency runs out during the wait, the FMAs follow the barrier)
-        float4 pfB[2][3];
+        float4 pfB[2][3], pfB2[2][2];
         issue_rows<2, 3>(a.blob, a.dec_wih, I_dec, 0, rowD, lane, pfB);
+        issue_rows<2, 2>(a.blob, a.dec_wih, I_dec, 768, rowD, lane, pfB2);
         PD_GATHER(10, (a.xb + a.g_atth), PD_NB * PD_RA, X + XATT, 1u);
         PD_STAMP(2);
         if (fail) break;
@@ -644,7 +659,15 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
                         lane == 0 ? q[0] : lane == 1 ? q[1] : lane == 2 ? q[2] : q[3]);
         }
         fma_rows<2, 3>(pfB, X + XATT, PD_RA, 0, lane, eD);
-        early_rows<2, 2>(a.blob, a.dec_wih, I_dec, 768, rowD, X + XATT, PD_RA, 768, lane, eD);
+        fma_rows<2, 2>(pfB2, X + XATT, PD_RA, 768, lane, eD);
+        // the attention RNN's recurrent columns of step + 1 (W_hh . att_h(step)): streamed HERE, in front of the longest
+        // wait of the step (query exchange + attention + context exchange), not between the projection's publish and
+        // the prenet gather where they delayed a 1.5 us exchange by 3 us (scripts/micro/allgather_floor.hip: the
+        // prenet-sized all-gather alone costs 1.5 us, the att_h-sized one 3.7)
+        if (have_next) {
+            early_rows<3, 3>(a.blob, a.att_whh, PD_RA, 0, rowA, X + XATT, PD_RA, 0, lane, eA);
+            early_rows<3, 2>(a.blob, a.att_whh, PD_RA, 768, rowA, X + XATT, PD_RA, 768, lane, eA);
+        }
         PD_STAMP(3);
         float4 pfC[3][2];
         issue_rows<3, 2>(a.blob, a.att_wih, I_att, PD_P, rowA, lane, pfC);
@@ -679,13 +702,13 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
         cell_update(gates, c2, h2, (a.xb + a.g_d2h) + (size_t)par * PD_NB * PD_RD, epoch, PD_RD, UD, FD, t);
         fma_rows<3, 3>(pfD, X + XDEC, PD_RD, 0, lane, eA);
         PD_STAMP(7);
-        float4 pfE[2][3];
+        float4 pfE[2][3], pfE2[2][3];      // recurrent columns of both decoder RNNs for step + 1
         issue_rows<2, 3>(a.blob, a.d2_whh, PD_RD, 0, rowD, lane, pfE);
+        issue_rows<2, 3>(a.blob, a.dec_whh, PD_RD, 0, rowD, lane, pfE2);
         PD_GATHER(6, (a.xb + a.g_d2h), PD_NB * PD_RD, X + XD2, 5u);
         PD_STAMP(8);
         if (fail) break;
         // ---- E: projection row set on [dec_h + d2_h | ctx] (model.py:757-765; rows: mel, gate, folded prenet layer 1)
-        const bool have_next = step + 1 < a.max_steps;
         if (wave == 1 || (wave == 2 && pr_row1 >= 0)) {
             const int row = wave == 1 ? pr_row0 : pr_row1;
             const float* wrow = L + WPR + (wave == 1 ? 0 : 5 * 64 * 4);
@@ -707,16 +730,15 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
                     if (b < a.batch) a.gate_out[(size_t)b * a.max_steps + step] = val;
                 } else if (have_next) {     // first prenet layer of step + 1: relu, always-on dropout (model.py:187-190)
                     const int j = row - a.n_mel - 1;
-                    const bool kp = b < a.batch && a.keep[(((size_t)(step + 1) * 2 + 0) * a.batch + b) * PD_P + j] != 0;
+                    const bool kp = keep_next != 0;        // (lanes >= batch loaded nothing: 0)
                     publish((a.xb + a.g_h1) + (size_t)par * PD_NB * PD_P, b * PD_P + j, epoch, kp ? fmaxf(val, 0.f) * 2.0f : 0.0f);
                 }
             }
         }
         fma_rows<2, 3>(pfE, X + XD2, PD_RD, 0, lane, e2);
+        fma_rows<2, 3>(pfE2, X + XDEC, PD_RD, 0, lane, eD);
         if (have_next) {
-            // the two prenet exchanges below are pure latency: the recurrent columns of step + 1 fill them
-            early_rows<3, 3>(a.blob, a.att_whh, PD_RA, 0, rowA, X + XATT, PD_RA, 0, lane, eA);
-            early_rows<3, 2>(a.blob, a.att_whh, PD_RA, 768, rowA, X + XATT, PD_RA, 768, lane, eA);
+            // the two prenet exchanges below are the shortest of the step (1.5 us alone): nothing is streamed in them
             PD_STAMP(9);
             PD_GATHER(2, (a.xb + a.g_h1), PD_NB * PD_P, X + XH1, 6u);
             PD_STAMP(10);
@@ -731,13 +753,12 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
                 if (lane < PD_NB) {
                     const int b = lane;
                     const float val = lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3];
-                    const bool kp = b < a.batch && a.keep[(((size_t)(step + 1) * 2 + 1) * a.batch + b) * PD_P + row] != 0;
+                    const bool kp = keep_next != 0;
                     const float pv = kp ? fmaxf(val, 0.f) * 2.0f : 0.0f;
                     pown[k][b] = pv;
                     publish((a.xb + a.g_p) + (size_t)par * PD_NB * PD_P, b * PD_P + row, epoch, pv);
                 }
             }
-            early_rows<2, 3>(a.blob, a.dec_whh, PD_RD, 0, rowD, X + XDEC, PD_RD, 0, lane, eD);
             PD_STAMP(11);
             PD_GATHER(2, (a.xb + a.g_p), PD_NB * PD_P, X + XP, 7u);
             PD_STAMP(12);

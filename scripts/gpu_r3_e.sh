@@ -1,5 +1,5 @@
 #!/bin/bash
-# all-gather floor microbenchmark; Tacotron tests + timeline + row on the energies re-layout
+# all-gather floor microbenchmark; Tacotron tests + timeline + row
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
