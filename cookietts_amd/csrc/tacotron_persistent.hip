@@ -45,6 +45,7 @@ constexpr int WQ = WFD + 4 * PD_UD * 2 * 64 * 4;               // query row     
 constexpr int WPR = WQ + 5 * 64 * 4;                           // two projection rows              [2][5][64] float4
 constexpr int WW2 = WPR + 2 * 5 * 64 * 4;                      // two second-prenet rows           [2][1][64] float4
 constexpr int LSTM_FLOATS = WW2 + 2 * 64 * 4;
+constexpr int PD_DBG_SLOTS = 24;             // ctts_taco_decoder_persistent_debug: [PD_WG][64 steps][PD_DBG_SLOTS] stamps
 constexpr unsigned PD_SPIN_LIMIT = 400000;   // polls per gather before giving up (~0.5 s)
 
 typedef unsigned long long u64;
@@ -64,7 +65,7 @@ struct PdArgs {
     unsigned memory, pm, lengths, att_h_in, dec_h_in, d2_h_in, att_h_out, dec_h_out, d2_h_out, att_c, dec_c, d2_c, ctx,
         prenet, w, cum, pos;                                                              // ws offsets
     unsigned g_p, g_atth, g_q, g_ctx, g_dech, g_d2h, g_h1, ctl;                           // xb offsets (u64 words)
-    u64* dbg;                   // optional [PD_WG][64 steps][16] stamps of s_memrealtime (100 MHz), NULL = off
+    u64* dbg;                   // optional [PD_WG][64 steps][PD_DBG_SLOTS] stamps of s_memrealtime (100 MHz), NULL = off
     int A, F, K, R, n_mel, T, batch, nbc, step0, n_steps, max_steps, pd_rows;   // nbc: batch rows the workspace holds
 };
 
@@ -275,8 +276,14 @@ static_assert(sizeof(AttnLds) <= LSTM_FLOATS * sizeof(float), "the attention scr
 
 #define PD_STAMP(k)                                                                                         \
     do {                                                                                                    \
-        if (a.dbg && t == 0 && step - a.step0 < 64)                                                         \
-            a.dbg[((size_t)wg * 64 + (step - a.step0)) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();      \
+        if constexpr (DBG) if (a.dbg && t == 0 && step - a.step0 < 64)                                      \
+            a.dbg[((size_t)wg * 64 + (step - a.step0)) * PD_DBG_SLOTS + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+// publish-time stamps of the waves that are not wave 0 (lane 0 of the publishing wave)
+#define PD_STAMP_LANE0(k)                                                                                   \
+    do {                                                                                                    \
+        if constexpr (DBG) if (a.dbg && lane == 0 && step - a.step0 < 64)                                   \
+            a.dbg[((size_t)wg * 64 + (step - a.step0)) * PD_DBG_SLOTS + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 
 // Windowed location-sensitive attention of utterance b (model.py:93-161, 49-65) on a dedicated 512-thread workgroup.
@@ -370,6 +377,7 @@ __device__ __forceinline__ int pd_attention_pre(const PdArgs& a, AttnLds& s, con
 
 // Part 2, on the critical path between the query and the context: tanh + v-weighted sum over the attention dims,
 // softmax, context, publish.
+template <bool DBG>
 __device__ __forceinline__ void pd_attention_post(const PdArgs& a, AttnLds& s, const AttnRegs& r, int b, int s0, unsigned epoch,
                                                   int step, u64* g_ctx) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -440,6 +448,7 @@ __device__ __forceinline__ void pd_attention_post(const PdArgs& a, AttnLds& s, c
 }
 
 // ---- the four attention workgroups --------------------------------------------------------------------------------
+template <bool DBG>
 __device__ __forceinline__ void attention_workgroup(const PdArgs& a, AttnLds& att, int wg) {
     const int t = threadIdx.x;
     const int b = wg - PD_LWG;
@@ -480,7 +489,7 @@ __device__ __forceinline__ void attention_workgroup(const PdArgs& a, AttnLds& at
         if (__syncthreads_or(ok_ ? 0 : 1)) return;
         PD_STAMP(2);
         if (real) {
-            pd_attention_post(a, att, r, b, s0, epoch, step, (a.xb + a.g_ctx) + (size_t)par * PD_NB * PD_DM);
+            pd_attention_post<DBG>(a, att, r, b, s0, epoch, step, (a.xb + a.g_ctx) + (size_t)par * PD_NB * PD_DM);
         } else {
             for (int d = t; d < PD_DM; d += PD_T) publish((a.xb + a.g_ctx) + (size_t)par * PD_NB * PD_DM, b * PD_DM + d, epoch, 0.f);
         }
@@ -493,6 +502,10 @@ __device__ __forceinline__ void attention_workgroup(const PdArgs& a, AttnLds& at
     }
 }
 
+// DBG = true: the same kernel with the s_memrealtime stamps of ctts_taco_decoder_persistent_debug compiled in.  They are
+// NOT in the product instantiation: a dozen conditional stores were enough to push the register allocator from 54 to
+// ~160 spilled VGPRs (40.5 -> 45.7 us per step, measured), so a profiled run is ~10 % slower than the product.
+template <bool DBG>
 __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a) {
     __shared__ __attribute__((aligned(16))) float L[LSTM_FLOATS];
     __shared__ float gates[4 * PD_UA][PD_NB];
@@ -507,7 +520,7 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
     if (__hip_atomic_load((gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
         return;                                  // an earlier launch on this exchange buffer gave up: stay down
     if (wg >= PD_LWG) {
-        attention_workgroup(a, *reinterpret_cast<AttnLds*>(L), wg);
+        attention_workgroup<DBG>(a, *reinterpret_cast<AttnLds*>(L), wg);
         return;
     }
     float* X = L;
@@ -657,6 +670,7 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
             if (lane < PD_NB)
                 publish((a.xb + a.g_q) + (size_t)par * PD_NB * a.A, lane * a.A + q_row, epoch,
                         lane == 0 ? q[0] : lane == 1 ? q[1] : lane == 2 ? q[2] : q[3]);
+            PD_STAMP_LANE0(17);
         }
         fma_rows<2, 3>(pfB, X + XATT, PD_RA, 0, lane, eD);
         fma_rows<2, 2>(pfB2, X + XATT, PD_RA, 768, lane, eD);
@@ -687,11 +701,11 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
         zero_rows<2>(eD);
         __syncthreads();
         cell_update(gates, cD, hD, (a.xb + a.g_dech) + (size_t)par * PD_NB * PD_RD, epoch, PD_RD, UD, FD, t);
+        PD_STAMP(13);
         fma_rows<3, 2>(pfC, X + XCTX, PD_DM, 0, lane, eA);
         PD_STAMP(5);
-        float4 pfD[3][3], wf2[2][3];      // the second decoder RNN's fresh columns (its whole W_ih, L2-resident): same trick
+        float4 wf2[2][3];      // the second decoder RNN's fresh columns (its whole W_ih, L2-resident): same trick
         issue_rows<2, 3>(a.blob, a.d2_wih, PD_RD, 0, rowD, lane, wf2);
-        issue_rows<3, 3>(a.blob, a.att_wih, I_att, PD_P + PD_DM, rowA, lane, pfD);
         PD_GATHER(6, (a.xb + a.g_dech), PD_NB * PD_RD, X + XDEC, 4u);
         PD_STAMP(6);
         if (fail) break;
@@ -700,7 +714,10 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
         zero_rows<2>(e2);
         __syncthreads();
         cell_update(gates, c2, h2, (a.xb + a.g_d2h) + (size_t)par * PD_NB * PD_RD, epoch, PD_RD, UD, FD, t);
-        fma_rows<3, 3>(pfD, X + XDEC, PD_RD, 0, lane, eA);
+        PD_STAMP(14);
+        // the attention RNN's decoder-hidden columns of step + 1: streamed after the publish, inside the d2_h exchange (a
+        // 3072-granule all-gather, ~2.5 us alone), instead of being held in 36 registers across the dec_h gather
+        early_rows<3, 3>(a.blob, a.att_wih, I_att, PD_P + PD_DM, rowA, X + XDEC, PD_RD, 0, lane, eA);
         PD_STAMP(7);
         float4 pfE[2][3], pfE2[2][3];      // recurrent columns of both decoder RNNs for step + 1
         issue_rows<2, 3>(a.blob, a.d2_whh, PD_RD, 0, rowD, lane, pfE);
@@ -734,6 +751,7 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
                     publish((a.xb + a.g_h1) + (size_t)par * PD_NB * PD_P, b * PD_P + j, epoch, kp ? fmaxf(val, 0.f) * 2.0f : 0.0f);
                 }
             }
+            if (wave == 1) PD_STAMP_LANE0(15);
         }
         fma_rows<2, 3>(pfE, X + XD2, PD_RD, 0, lane, e2);
         fma_rows<2, 3>(pfE2, X + XDEC, PD_RD, 0, lane, eD);
@@ -758,6 +776,7 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
                     pown[k][b] = pv;
                     publish((a.xb + a.g_p) + (size_t)par * PD_NB * PD_P, b * PD_P + row, epoch, pv);
                 }
+                if (wave == 3) PD_STAMP_LANE0(16);
             }
             PD_STAMP(11);
             PD_GATHER(2, (a.xb + a.g_p), PD_NB * PD_P, X + XP, 7u);
@@ -792,6 +811,7 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
     }
 }
 #undef PD_STAMP
+#undef PD_STAMP_LANE0
 
 void* g_pd_debug = nullptr;      // ctts_taco_decoder_persistent_debug: stamp buffer, not part of the product path
 
@@ -895,7 +915,8 @@ int ctts_taco_decoder_steps_persistent_f32(const ctts_taco_decoder_config* cfg, 
     a.n_mel = c.n_mel_channels; a.T = text_len; a.batch = batch; a.nbc = pad_batch(batch); a.step0 = step0; a.n_steps = n_steps;
     a.max_steps = max_steps; a.pd_rows = p.pd_rows;
     a.dbg = reinterpret_cast<u64*>(g_pd_debug);
-    hipLaunchKernelGGL(taco_persistent_kernel, dim3(PD_WG), dim3(PD_T), 0, s, a);
+    if (a.dbg) hipLaunchKernelGGL(taco_persistent_kernel<true>, dim3(PD_WG), dim3(PD_T), 0, s, a);
+    else hipLaunchKernelGGL(taco_persistent_kernel<false>, dim3(PD_WG), dim3(PD_T), 0, s, a);
     CTTS_CHECK_LAUNCH("taco_persistent");
     return CTTS_OK;
 }

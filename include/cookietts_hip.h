@@ -467,8 +467,9 @@ int ctts_taco_decoder_steps_persistent_f32(const ctts_taco_decoder_config* cfg, 
                                            int32_t n_steps, int32_t max_steps, void* workspace, void* exchange,
                                            size_t exchange_bytes, void* stream);
 
-/* Profiling aid for the persistent decoder: `stamps` = device buffer of 256 x 64 x 16 uint64 receiving s_memrealtime
- * (100 MHz) at the phase boundaries of the first 64 steps of every later launch; NULL switches it off. */
+/* Profiling aid for the persistent decoder: `stamps` = device buffer of 256 x 64 x 24 uint64 receiving s_memrealtime
+ * (100 MHz) at the phase boundaries (slots 0..12) and at the publish instants (13..17) of the first 64 steps of every
+ * later launch; NULL switches it off (scripts/profile_persistent.py). */
 int ctts_taco_decoder_persistent_debug(void* stamps);
 
 /* ---- Tacotron2-TM one-shot stages: operator-level primitives ------------------------------- */

@@ -12,12 +12,13 @@ rng = np.random.default_rng(1)
 mem = torch.from_numpy((rng.standard_normal((B, T, 1313)) * 0.5).astype(np.float32)).cuda()
 lens = torch.tensor([200, 195, 150, 100]).cuda()
 m.decoder.inference(mem, lens, fixed_steps=steps)            # warm
-stamps = torch.zeros(256 * 64 * 16, dtype=torch.int64, device="cuda")
+SLOTS = 24
+stamps = torch.zeros(256 * 64 * SLOTS, dtype=torch.int64, device="cuda")
 _lib.lib().ctts_taco_decoder_persistent_debug(_lib.ptr(stamps))
 m.decoder.inference(mem, lens, fixed_steps=steps)
 torch.cuda.synchronize()
 _lib.lib().ctts_taco_decoder_persistent_debug(None)
-s = stamps.cpu().numpy().reshape(256, 64, 16).astype(np.float64) / 100.0      # us
+s = stamps.cpu().numpy().reshape(256, 64, SLOTS).astype(np.float64) / 100.0      # us
 names = ["A:fresh att+publish", "wait att_h", "B:q+early dec(att)", "wait ctx", "C:fresh dec+early", "wait dec_h",
          "D:fresh d2+early", "wait d2_h", "E:proj+early d2hh", "wait h1", "F:W2+early att hh", "wait p"]
 for wg in (0, 19, 100, 251):
@@ -28,3 +29,23 @@ for wg in (252, 255):
     d = np.diff(s[wg, 8:56, :7], axis=1).mean(axis=0)
     print(f"attention wg {wg}: " + " | ".join(f"{n} {v:.1f}" for n, v in zip(
         ["pre (bursts + loc conv)", "wait q", "energies", "softmax", "ctx", "publish + w/cum"], d)))
+
+# Cross-workgroup view of every exchange (s_memrealtime is one chip-wide 100 MHz counter): when did the LAST publisher
+# publish, how far apart were the publishers, and how long after the last publish had the FIRST / LAST consumer its copy.
+# (publish stamps: 1 att_h, 17 q, attention 5 ctx, 13 dec_h, 14 d2_h, 15 h1, 16 p; gather-done stamps: 2, attn 2, 4, 6, 8, 10, 12)
+L, Aw = slice(0, 252), slice(252, 256)
+steps_ss = slice(8, 56)
+def col(wgs, k):
+    x = s[wgs, steps_ss, k]
+    return np.where(x > 0, x, np.nan)
+rows = [("att_h (5120 granules)", col(L, 1), col(L, 2)), ("q (768, to the 4 attention wgs)", col(slice(0, 192), 17), col(Aw, 2)),
+        ("ctx (2048)", col(Aw, 5), col(L, 4)), ("dec_h (3072)", col(L, 13), col(L, 6)), ("d2_h (3072)", col(L, 14), col(L, 8)),
+        ("h1 (1024)", col(L, 15), col(L, 10)), ("p (1024)", col(L, 16), col(L, 12))]
+print("exchange: publisher spread (last - first publish) | first consumer done after last publish | last consumer done after last publish  [us, mean over steps]")
+for name, pub, done in rows:
+    last_pub, first_pub = np.nanmax(pub, axis=0), np.nanmin(pub, axis=0)
+    print(f"  {name:34s} {np.nanmean(last_pub - first_pub):5.2f} | {np.nanmean(np.nanmin(done, axis=0) - last_pub):5.2f} | {np.nanmean(np.nanmax(done, axis=0) - last_pub):5.2f}")
+print("compute between a gather and the next publish (mean over workgroups and steps): "
+      f"A {np.nanmean(col(L, 1) - col(L, 0)):.2f} | q {np.nanmean(col(slice(0, 192), 17) - col(slice(0, 192), 2)):.2f} | "
+      f"attention post {np.nanmean(col(Aw, 5) - col(Aw, 2)):.2f} | C {np.nanmean(col(L, 13) - col(L, 4)):.2f} | "
+      f"D {np.nanmean(col(L, 14) - col(L, 6)):.2f} | h1 {np.nanmean(col(L, 15) - col(L, 8)):.2f} | p {np.nanmean(col(L, 16) - col(L, 10)):.2f}")
