@@ -108,6 +108,15 @@ def test_config2_waveglow_full_length_matches_reference_golden(hip_lib_path):
     err3 = rms_rel_err(m.infer_from_noise(mel, torch.from_numpy(g["z_scaled"]).cuda()).cpu().numpy(), g["wave"])
     print(f"config 2 full length, bf16x3: rms rel err vs reference = {err3:.3e}")
     assert err3 < 1e-4
+    # config 3's arithmetic (bf16 MFMA, single product) on the same utterance against the fp32 REFERENCE: outside the
+    # north-star's 1e-3 by construction (tests/test_bf16_error_budget.py: the 8-bit mantissa of the single product is
+    # the limiter, 1.9e-3 even with an fp32 residual stream), so gated at what it measures, with margin for the
+    # hardware exp / summation order: BF16_VS_REFERENCE_LIMIT
+    from test_waveglow_gpu import BF16_VS_REFERENCE_LIMIT
+    m.set_compute_dtype(torch.bfloat16)
+    err16 = rms_rel_err(m.infer_from_noise(mel, torch.from_numpy(g["z_scaled"]).cuda()).cpu().numpy(), g["wave"])
+    print(f"config 3 arithmetic (bf16) at full length, 80 x 900: rms rel err vs the fp32 reference = {err16:.3e}")
+    assert err16 < BF16_VS_REFERENCE_LIMIT["full_len"]
 
 
 def test_config4_waveflow_full_length_matches_reference_golden(hip_lib_path):

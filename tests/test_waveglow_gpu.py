@@ -120,7 +120,11 @@ def test_no_cpu_fallback(hip_lib_path):
 # fp32 summation order and the hardware exp/rcp in the gate, which flips an occasional bf16 rounding
 # (1 ulp = 2^-8 relative) that then propagates through 8 layers x n flows; bound found empirically.
 BF16_VS_BF16_ORACLE_TOL = 5e-3
-# Reported, not gated: error of the bf16 path against the fp32 reference golden.
+# Against the fp32 REFERENCE goldens the bf16 path is gated at what a single bf16 product can deliver (measured on the
+# MI355X: toy_early 5e-4, small 1.5e-3, full_short 2.1e-3; tests/test_bf16_error_budget.py pins on the CPU why: operand
+# rounding alone gives 1.4e-3 / 1.9e-3 on small / full_short even with every tensor stored in fp32).  Limits = measured
+# x ~1.5.  The north-star bound of 1e-3 is met by the fp32 path and by bf16x3, not by config 3's arithmetic.
+BF16_VS_REFERENCE_LIMIT = {"toy_early": 1.0e-3, "small": 2.5e-3, "full_short": 3.2e-3, "full_len": 4.0e-3}
 
 
 @pytest.mark.parametrize("name", ["toy_early", "small", "full_short"])
@@ -136,7 +140,7 @@ def test_waveglow_bf16_matches_bf16_rounded_oracle(hip_lib_path, name):
     e32 = rms_rel_err(wave, g["wave"])
     print(f"bf16 {name}: rms rel err vs bf16-rounded oracle = {e16:.3e}; vs fp32 reference (reported) = {e32:.3e}")
     assert e16 < BF16_VS_BF16_ORACLE_TOL
-    assert e32 < 2e-2                      # sanity only: same waveform, bf16-level noise
+    assert e32 < BF16_VS_REFERENCE_LIMIT[name]
     # switching back restores the exact fp32 path
     m.set_compute_dtype(torch.float32)
     w32 = m.infer_from_noise(torch.from_numpy(g["mel"]).cuda(), torch.from_numpy(g["z_scaled"]).cuda()).cpu().numpy()
