@@ -121,10 +121,10 @@ def test_no_cpu_fallback(hip_lib_path):
 # (1 ulp = 2^-8 relative) that then propagates through 8 layers x n flows; bound found empirically.
 BF16_VS_BF16_ORACLE_TOL = 5e-3
 # Against the fp32 REFERENCE goldens the bf16 path is gated at what a single bf16 product can deliver (measured on the
-# MI355X: toy_early 5e-4, small 1.5e-3, full_short 2.1e-3; tests/test_bf16_error_budget.py pins on the CPU why: operand
+# MI355X: toy_early 5e-4, small 1.5e-3, full_short 2.1e-3, full_len (80 x 900) 2.4e-3; tests/test_bf16_error_budget.py pins on the CPU why: operand
 # rounding alone gives 1.4e-3 / 1.9e-3 on small / full_short even with every tensor stored in fp32).  Limits = measured
 # x ~1.5.  The north-star bound of 1e-3 is met by the fp32 path and by bf16x3, not by config 3's arithmetic.
-BF16_VS_REFERENCE_LIMIT = {"toy_early": 1.0e-3, "small": 2.5e-3, "full_short": 3.2e-3, "full_len": 4.0e-3}
+BF16_VS_REFERENCE_LIMIT = {"toy_early": 1.0e-3, "small": 2.5e-3, "full_short": 3.2e-3, "full_len": 3.6e-3}
 
 
 @pytest.mark.parametrize("name", ["toy_early", "small", "full_short"])
