@@ -6,6 +6,9 @@
 //   mode 0: serial polling (issue my NPT loads, wait, check, s_sleep 2, again)         = the product's gather
 //   mode 1: two poll rounds in flight (the second issued half a round-trip after the first)
 //   mode 2: 16-byte granules {tag, v0, v1, v2} (one third of the requests)
+//   mode 3: 8-byte granules, all NPT polling loads of a round ISSUED BACK TO BACK before the first check (the product's
+//           loop checks each load before issuing the next: hipcc keeps every relaxed atomic load inside its own
+//           predicated block, so a round of NPT loads costs NPT dependent round trips)
 // Also prints the time of the same loop with the publish but WITHOUT the gather (compute skeleton only).
 //   hipcc --offload-arch=gfx950 -O3 allgather_floor.hip -o allgather_floor && ./allgather_floor
 #include <hip/hip_runtime.h>
@@ -26,7 +29,24 @@ __device__ __forceinline__ bool gather(const u64* g, int count, float* dst, unsi
     unsigned done = 0;
     for (unsigned spins = 0; spins < 2000000u; ++spins) {
         bool ok = true;
-        if (MODE == 1) {
+        if (MODE == 3) {
+            u64 x[NPT];
+#pragma unroll
+            for (int k = 0; k < NPT; ++k) {
+                const int i = min(t + T * k, count - 1);
+                asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=&v"(x[k]) : "v"(g + i) : "memory");
+            }
+#pragma unroll
+            for (int k = 0; k < NPT; ++k) asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[k])::"memory");
+#pragma unroll
+            for (int k = 0; k < NPT; ++k) {
+                const int i = t + T * k;
+                if (i < count && !((done >> k) & 1u)) {
+                    if ((unsigned)(x[k] >> 32) == epoch) { dst[i] = __uint_as_float((unsigned)x[k]); done |= 1u << k; }
+                    else ok = false;
+                }
+            }
+        } else if (MODE == 1) {
             u64 xa[NPT], xb[NPT];
 #pragma unroll
             for (int k = 0; k < NPT; ++k) {
@@ -152,6 +172,11 @@ int main() {
     run<10, 1>("two rounds in flight, 8-byte granules", 5120, xb, stamps, sink);
     run<4, 1>("two rounds in flight, 8-byte granules", 2048, xb, stamps, sink);
     run<2, 1>("two rounds in flight, 8-byte granules", 1024, xb, stamps, sink);
+    run<10, 3>("round issued back to back, 8-byte granules", 5120, xb, stamps, sink);
+    run<6, 3>("round issued back to back, 8-byte granules", 3072, xb, stamps, sink);
+    run<4, 3>("round issued back to back, 8-byte granules", 2048, xb, stamps, sink);
+    run<2, 3>("round issued back to back, 8-byte granules", 1024, xb, stamps, sink);
+    run<6, 0>("serial polling, 8-byte granules", 3072, xb, stamps, sink);
     run<10, 2>("serial polling, 16-byte granules", 5120, xb, stamps, sink);
     run<4, 2>("serial polling, 16-byte granules", 2048, xb, stamps, sink);
     return 0;
