@@ -228,6 +228,7 @@ SIGNATURES = {
     "ctts_set_f32_gemm_mode": (C.c_int, [C.c_int32]),
     "ctts_get_f32_gemm_mode": (C.c_int, []),
     "ctts_tuning_reload": (C.c_int, []),
+    "ctts_tuning_flags": (C.c_int, []),
     "ctts_profile_enable": (C.c_int, [C.c_int32]),
     "ctts_profile_collect": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }
@@ -256,9 +257,19 @@ def set_f32_gemm_mode(mode):
     return prev
 
 
+TUNING_BITS = {"CTTS_F32_NO_GLDS": 0, "CTTS_GEMM_NO_XCD_PAIR": 1, "CTTS_BF16_NO_GLDS": 2, "CTTS_BF16_NO_WIDE": 3,
+               "CTTS_BF16_NO_PP": 4, "CTTS_BF16_W4": 5, "CTTS_BF16_PP_STAGES": 6, "CTTS_WF_NO_FUSE": 7, "CTTS_TACO_NO_FUSE": 8,
+               "CTTS_F32_NO_SMALL": 9, "CTTS_F32_FORCE_SMALL": 10}
+
+
 def tuning_reload():
     """Re-read the CTTS_* launch-shape knobs from the environment (the library reads them once, at the first launch)."""
     check(lib().ctts_tuning_reload(), "ctts_tuning_reload")
+
+
+def tuning_active(name):
+    """True when the library currently runs with knob ``name`` set (``ctts_tuning_flags``)."""
+    return bool(lib().ctts_tuning_flags() >> TUNING_BITS[name] & 1)
 
 
 PROF_WN_IN = 0

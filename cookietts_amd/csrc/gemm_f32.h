@@ -157,6 +157,10 @@ __host__ __device__ inline int gemm_dense_row(int epi, int bm, int mb, int r, in
 }
 
 int launch_gemm_f32(int epi, const GemmArgs& a, hipStream_t stream);
+// Small-problem shape (gemm_f32_small.hip): 128 x 64 blocks / 64 x 32 wave tiles on the SAME packed operands, bit-identical
+// results; chosen by launch_gemm_f32 when the 256 x 128 shape would start fewer than two blocks per CU.
+bool gemm_f32_small_applies(int epi, const GemmArgs& a);
+int launch_gemm_f32_small(int epi, const GemmArgs& a, hipStream_t stream);
 
 // Library DEFAULT of the main-loop selection (what CTTS_GEMM_DEFAULT resolves to): 0 = fp32 MFMA (initially), 1 = split
 // bf16 (three bf16 MFMA products per fp32 operand pair, see conv_gemm_f32_kernel<..., X3>).  ctts_set_f32_gemm_mode.

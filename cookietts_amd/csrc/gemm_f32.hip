@@ -692,6 +692,8 @@ void load_tuning_locked() {
     auto on = [](const char* n) { return getenv(n) != nullptr; };
     auto num = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
     g_tune.f32_no_glds = on("CTTS_F32_NO_GLDS");
+    g_tune.f32_no_small = on("CTTS_F32_NO_SMALL");
+    g_tune.f32_force_small = on("CTTS_F32_FORCE_SMALL");
     g_tune.no_xcd_pair = on("CTTS_GEMM_NO_XCD_PAIR");
     g_tune.bf16_no_glds = on("CTTS_BF16_NO_GLDS");
     g_tune.bf16_no_wide = on("CTTS_BF16_NO_WIDE");
@@ -759,6 +761,7 @@ int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
     CTTS_CHECK_ARG(a.gate >= 0 && a.gate < GATE_KINDS && (a.gate == 0 || epi == GEMM_EPI_GATE), "gemm: gate=%d with epilogue %d",
                    a.gate, epi);
     if (epi == GEMM_EPI_GATE && a.gate != GATE_GTU) epi = GEMM_EPI_GATEX;
+    if (gemm_f32_small_applies(epi, a)) return launch_gemm_f32_small(epi, a, stream);
     switch (epi) {
         case GEMM_EPI_GATEX: launch_shape<GEMM_EPI_GATEX>(a.bm, grid, stream, a); break;
         case GEMM_EPI_GATE: launch_shape<GEMM_EPI_GATE>(a.bm, grid, stream, a); break;

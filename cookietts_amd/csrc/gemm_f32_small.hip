@@ -1,0 +1,328 @@
+// Small-problem shape of the fp32 MFMA conv-GEMM (same contract, same packed operands, same bits as gemm_f32.hip).
+//
+// Why: the 256 x 128 block of gemm_f32.hip gives every wave a 128 x 64 tile.  A launch with fewer than 1024 such wave
+// tiles leaves SIMDs idle however its blocks are shaped, and a wave alone on its SIMD keeps the matrix pipe only ~68 %
+// busy (nobody covers its LDS waits and chunk barriers).  Measured on the ax WaveGlow of the author's notebook at B = 1
+// (profiles/r3_02_pmc_ax_notebook_b1.json): in-layer GEMM 184 blocks = 736 wave tiles, matrix pipe busy 0.49; res/skip
+// GEMM 92 blocks, 0.29.  The Tacotron encoder / postnet convolutions, the conditioning stacks at frame rate and the
+// STFT are smaller still.
+//
+// Here a block is 128 x 64 and a wave tile 64 x 32 (2 x 1 tiles of v_mfma_f32_32x32x2_f32): four times as many wave tiles,
+// 39 KB of LDS and ~64 VGPRs per block, so four blocks share a CU and 3-4 waves a SIMD.
+//   * Operands are NOT repacked: a block reads one 128-row half (wave-row `half` of M-block `mb`) of the 256-row packing.
+//     For the pair epilogues that half holds [64 first-half channels | the 64 matching second-half channels]; wave wm
+//     takes rows 32 wm .. +32 (first) and 64 + 32 wm .. +32 (second), so the pairing still happens in registers.
+//   * Every output element sums the same chunks and k-steps in the same order with the same instruction as the large
+//     shape: results are bit-identical (tests/test_conv1d_primitive.py, test_waveglow_ax.py).
+//   * Staging: global -> LDS DMA (16 B per lane, per-lane source addresses: the A half is 16 runs of 512 B), three
+//     stages, two chunks ahead, three DMA pieces per chunk per wave, counted vmcnt + s_barrier.
+#include "gemm_f32.h"
+#include "tuning.h"
+
+namespace ctts {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int S_BM = 128, S_BN = 64;
+constexpr int S_ASTAGE = GEMM_KC * S_BM;                 // 2048 floats
+constexpr int S_STAGE = GEMM_KC * (S_BM + S_BN);         // 3072 floats = 12 KiB
+constexpr int S_MAX_CHUNKS = 256;                        // chunk -> B address table entries (same bound as gemm_f32.hip)
+constexpr int S_NST = 3;
+constexpr int S_SEGTAB = S_NST * S_STAGE;
+constexpr int S_CHTAB = S_SEGTAB + GEMM_MAX_SEG * 4;
+constexpr int S_LDS_FLOATS = S_CHTAB + 2 * S_MAX_CHUNKS;
+
+__device__ __forceinline__ float s_fast_sigmoid(float u) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f));
+}
+__device__ __forceinline__ float s_fast_tanh(float u) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * 2.8853900817779268f));
+}
+
+typedef const __attribute__((address_space(1))) float* gfloat_ptr;
+typedef __attribute__((address_space(3))) float* lds_fptr;
+
+template <int EPI, int SEGS>
+__global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmArgs a, const int ntiles_s) {
+    __shared__ __attribute__((aligned(16))) float lds[S_LDS_FLOATS];
+    constexpr bool PAIR = EPI == GEMM_EPI_GATE || EPI == GEMM_EPI_GATEX || EPI == GEMM_EPI_MAG;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    int id = blockIdx.x;
+    const int mbs = id % (2 * a.MB);
+    id /= 2 * a.MB;
+    const int tile = id % ntiles_s;
+    const int b = id / ntiles_s;
+    const int mb = mbs >> 1, half = mbs & 1;
+    const int n0 = tile * S_BN;
+
+    // segment table -> LDS (a dynamically indexed kernarg struct would be copied to scratch), then chunk -> B address
+#pragma unroll
+    for (int sidx = 0; sidx < GEMM_MAX_SEG; ++sidx) {
+        if (sidx < SEGS && t == sidx) {
+            const GemmSeg& g = a.seg[sidx];
+            unsigned int* e = reinterpret_cast<unsigned int*>(lds + S_SEGTAB + sidx * 4);
+            if (sidx < a.nseg) {
+                const float* base = g.base + (size_t)b * g.bstride + (size_t)(mb * g.mb_rows) * a.ld + (a.pad + n0 + g.shift);
+                const unsigned long long u = reinterpret_cast<unsigned long long>(base);
+                e[0] = (unsigned int)u; e[1] = (unsigned int)(u >> 32); e[2] = (unsigned int)g.nch;
+            } else {
+                e[0] = 0; e[1] = 0; e[2] = 0x7fffffffu;
+            }
+            e[3] = 0;
+        }
+    }
+    __syncthreads();
+    {
+        unsigned long long* tab = reinterpret_cast<unsigned long long*>(lds + S_CHTAB);
+        const int ilv0 = a.interleave > 1 ? a.interleave : 0;
+        const int n_il = ilv0 * a.seg[0].nch;
+        for (int c0 = t; c0 < a.nch_total; c0 += 256) {
+            int c = c0, sg, loc;
+            if (c < n_il) {
+                sg = c % ilv0;
+                loc = c / ilv0;
+            } else {
+                c -= n_il;
+                sg = ilv0;
+                for (int k = 0; k < SEGS - 1; ++k) {                 // sequential walk over the non-interleaved segments
+                    const int nck = (int)reinterpret_cast<const unsigned int*>(lds + S_SEGTAB + k * 4)[2];
+                    if (sg == k && k < a.nseg - 1 && c >= nck) { c -= nck; sg = k + 1; }
+                }
+                loc = c;
+            }
+            const unsigned int* e = reinterpret_cast<const unsigned int*>(lds + S_SEGTAB + sg * 4);
+            const unsigned long long base = ((unsigned long long)e[1] << 32) | e[0];
+            tab[c0] = base + (unsigned long long)loc * GEMM_KC * a.ld * sizeof(float);
+        }
+    }
+    __syncthreads();
+
+    const int nalloc = a.a_nch_alloc ? a.a_nch_alloc : a.nch_total;
+    // A: chunk c of M-block mb in the 256-row packing, rows [128 half, +128).  Piece p of this wave fills LDS floats
+    // [wave * 256 + p * 1024, +256) of the [16][128] stage: k-row 2 wave + 8 p + (lane >> 5), columns 4 (lane & 31).
+    const gfloat_ptr a_base = (gfloat_ptr)(a.A + ((size_t)mb * nalloc + a.a_ch_off) * (GEMM_KC * 256) + 128 * half +
+                                           (2 * wave + (lane >> 5)) * 256 + (lane & 31) * 4);
+    // B: [16][64] stage, this wave's piece = k-rows 4 wave .. +4: k-row 4 wave + (lane >> 4), columns 4 (lane & 15)
+    const size_t b_off = (size_t)(4 * wave + (lane >> 4)) * a.ld + (lane & 15) * 4;
+    const unsigned long long* ctab = reinterpret_cast<const unsigned long long*>(lds + S_CHTAB);
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+#define S_ISSUE_A(buf, c, p)                                                                                     \
+    __builtin_amdgcn_global_load_lds(a_base + (size_t)(c) * (GEMM_KC * 256) + (p) * (8 * 256),                   \
+                                     (lds_fptr)(lds + (buf) * S_STAGE + wave * 256 + (p) * 1024), 16, 0, 0)
+#define S_ISSUE_B(buf, c)                                                                                        \
+    do {                                                                                                         \
+        const unsigned long long ub_ = ctab[c];                                                                  \
+        const unsigned long long us_ =                                                                           \
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |             \
+            (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                                  \
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off,                               \
+                                         (lds_fptr)(lds + (buf) * S_STAGE + S_ASTAGE + wave * 256), 16, 0, 0);   \
+    } while (0)
+
+    const int nch = a.nch_total;
+    S_ISSUE_A(0, 0, 0); S_ISSUE_A(0, 0, 1); S_ISSUE_B(0, 0);
+    {
+        const int c1 = nch > 1 ? 1 : 0;
+        S_ISSUE_A(1, c1, 0); S_ISSUE_A(1, c1, 1); S_ISSUE_B(1, c1);
+    }
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // fragment rows of this wave inside the 128-row half
+    const int arow0 = PAIR ? 32 * wm : 64 * wm;
+    const int arow1 = PAIR ? 64 + 32 * wm : 64 * wm + 32;
+    int cur = 0;
+    for (int ch = 0; ch < nch; ++ch) {
+        const float* As = lds + cur * S_STAGE + l31;
+        const float* Bs = lds + cur * S_STAGE + S_ASTAGE + wn * 32 + l31;
+        const int nb = cur >= 1 ? cur - 1 : 2;              // (cur + 2) % 3: the stage chunk ch - 1 occupied
+        const int cn = ch + 2 < nch ? ch + 2 : nch - 1;     // the last two iterations re-issue the final chunk
+        float av0[GEMM_KC / 2], av1[GEMM_KC / 2], bv[GEMM_KC / 2];
+#define S_READ(ks)                                                                                               \
+        av0[ks] = As[(2 * (ks) + lhi) * S_BM + arow0]; av1[ks] = As[(2 * (ks) + lhi) * S_BM + arow1];            \
+        bv[ks] = Bs[(2 * (ks) + lhi) * S_BN];
+#define S_MFMA(ks)                                                                                               \
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[ks], bv[ks], acc[0], 0, 0, 0);                         \
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[ks], bv[ks], acc[1], 0, 0, 0);
+        S_READ(0) S_READ(1)
+        __builtin_amdgcn_sched_barrier(0);
+        S_READ(2) S_MFMA(0) S_ISSUE_A(nb, cn, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        S_READ(3) S_MFMA(1) S_ISSUE_A(nb, cn, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        S_READ(4) S_MFMA(2) S_ISSUE_B(nb, cn);
+        __builtin_amdgcn_sched_barrier(0);
+        S_READ(5) S_MFMA(3)
+        __builtin_amdgcn_sched_barrier(0);
+        S_READ(6) S_MFMA(4)
+        __builtin_amdgcn_sched_barrier(0);
+        S_READ(7) S_MFMA(5)
+        __builtin_amdgcn_sched_barrier(0);
+        S_MFMA(6) S_MFMA(7)
+#undef S_READ
+#undef S_MFMA
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");    // chunk ch + 1 landed, the newest still in flight
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+#undef S_ISSUE_A
+#undef S_ISSUE_B
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the re-issued tail DMAs still target LDS
+    __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if (t < S_BM) lds[t] = a.bias[mb * 256 + 128 * half + t];
+    __syncthreads();
+    const int n = n0 + wn * 32 + l31;
+    if constexpr (PAIR) {
+        float* dst = a.dst0 + (size_t)b * a.dst0_bstride;
+        const int cbase = (mb * 2 + half) * 64 + 32 * wm;
+        if (cbase < a.pairC && n < a.L) {
+            float add0[16], add1[16];
+            if ((EPI == GEMM_EPI_GATE || EPI == GEMM_EPI_GATEX) && a.addend && a.addend_frames > 0) {   // interpolated addend
+                const int F = a.addend_frames;
+                const float scale = a.L > 1 ? (float)(F - 1) / (float)(a.L - 1) : 0.f;
+                const float real = scale * (float)n;
+                const int i0 = (int)real;
+                const int i1 = i0 + 1 < F ? i0 + 1 : F - 1;
+                const float l1 = real - (float)i0;
+                const float l0 = 1.0f - l1;
+                const float* ad = a.addend + (size_t)b * a.addend_bstride + a.addend_pad;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = min(cbase + (r & 3) + 8 * (r >> 2) + 4 * lhi, a.pairC - 1);
+                    const float* r0 = ad + (size_t)c * a.addend_ld;
+                    const float* r1 = ad + (size_t)(a.pairC + c) * a.addend_ld;
+                    add0[r] = l0 * r0[i0] + l1 * r0[i1];
+                    add1[r] = l0 * r1[i0] + l1 * r1[i1];
+                }
+            } else if ((EPI == GEMM_EPI_GATE || EPI == GEMM_EPI_GATEX) && a.addend) {
+                const float* ad = a.addend + (size_t)b * a.addend_bstride + a.addend_pad + n;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = min(cbase + (r & 3) + 8 * (r >> 2) + 4 * lhi, a.pairC - 1);
+                    add0[r] = ad[(size_t)c * a.addend_ld];
+                    add1[r] = ad[(size_t)(a.pairC + c) * a.addend_ld];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) add0[r] = add1[r] = 0.0f;
+            }
+            if constexpr (EPI == GEMM_EPI_GATEX) {
+#define S_GATEX_LOOP(K)                                                                                           \
+                case K:                                                                                           \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                              \
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;                                         \
+                        const float u0 = acc[0][r] + lds[32 * wm + row] + add0[r];                                \
+                        const float u1 = acc[1][r] + lds[64 + 32 * wm + row] + add1[r];                           \
+                        if (cbase + row < a.pairC) dst[(size_t)(cbase + row) * a.dst_ld + a.dst_pad + n] = gate_eval<K>(u0, u1); \
+                    }                                                                                             \
+                    break;
+                switch (a.gate) {
+                    S_GATEX_LOOP(1) S_GATEX_LOOP(2) S_GATEX_LOOP(3) S_GATEX_LOOP(4) S_GATEX_LOOP(5) S_GATEX_LOOP(6) S_GATEX_LOOP(7)
+                    S_GATEX_LOOP(8) S_GATEX_LOOP(9) S_GATEX_LOOP(10) S_GATEX_LOOP(11) S_GATEX_LOOP(12) S_GATEX_LOOP(13)
+                    default:
+                    S_GATEX_LOOP(0)
+                }
+#undef S_GATEX_LOOP
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const float u0 = acc[0][r] + lds[32 * wm + row] + add0[r];
+                    const float u1 = acc[1][r] + lds[64 + 32 * wm + row] + add1[r];
+                    float v;
+                    if constexpr (EPI == GEMM_EPI_GATE) v = s_fast_tanh(u0) * s_fast_sigmoid(u1);
+                    else v = sqrtf(u0 * u0 + u1 * u1);
+                    if (cbase + row < a.pairC) dst[(size_t)(cbase + row) * a.dst_ld + a.dst_pad + n] = v;
+                }
+            }
+        }
+    } else {
+        // rows < split -> dst0 (= src0 + v when acc0), rows >= split -> dst1[row - split] (+= when acc1)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int rbase = mb * 256 + 128 * half + 64 * wm + 32 * mt;     // uniform per tile
+            if (rbase >= a.M) continue;
+            const bool second = rbase >= a.split;
+            float* dst = second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride;
+            const float* src = second ? dst : (a.src0 ? a.src0 + (size_t)b * a.src0_bstride : dst);
+            const int accum = second ? a.acc1 : a.acc0;
+            const int rdst = second ? rbase - a.split : rbase;
+            if (n < a.L) {
+                float old[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    old[r] = (accum && rbase + row < a.M) ? src[(size_t)(rdst + row) * a.dst_ld + a.dst_pad + n] : 0.0f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    float v = acc[mt][r] + lds[64 * wm + 32 * mt + row] + old[r];
+                    if constexpr (EPI == GEMM_EPI_LOG) v = logf(fmaxf(v, a.clip));
+                    if constexpr (EPI == GEMM_EPI_LRELU) v = v > 0.f ? v : a.clip * v;
+                    if constexpr (EPI == GEMM_EPI_TANH) v = tanhf(v);
+                    if (rbase + row < a.M) dst[(size_t)(rdst + row) * a.dst_ld + a.dst_pad + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int EPI>
+void launch_small(dim3 grid, hipStream_t stream, const GemmArgs& a, int ntiles_s) {
+    if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_small_kernel<EPI, 4>), grid, dim3(256), 0, stream, a, ntiles_s);
+    else hipLaunchKernelGGL((conv_gemm_f32_small_kernel<EPI, GEMM_MAX_SEG>), grid, dim3(256), 0, stream, a, ntiles_s);
+}
+
+}  // namespace
+
+bool gemm_f32_small_applies(int epi, const GemmArgs& a) {
+    if (a.bm != 256 || a.nch_total > S_MAX_CHUNKS || gemm_mode_is_split(a.gemm_mode)) return false;
+    const Tuning tune = tuning();
+    if (tune.f32_no_glds || tune.f32_no_small) return false;
+    if (!(epi == GEMM_EPI_SPLIT || epi == GEMM_EPI_GATE || epi == GEMM_EPI_GATEX || epi == GEMM_EPI_MAG || epi == GEMM_EPI_LOG ||
+          epi == GEMM_EPI_LRELU || epi == GEMM_EPI_TANH))
+        return false;
+    // fewer 256 x 128 blocks than two per CU: the large shape cannot fill the chip
+    return (long long)a.MB * a.ntiles * a.batch < 2ll * 256 || tune.f32_force_small;
+}
+
+int launch_gemm_f32_small(int epi, const GemmArgs& a, hipStream_t stream) {
+    const int ntiles_s = (a.L + S_BN - 1) / S_BN;
+    const long long blocks = 2ll * a.MB * ntiles_s * a.batch;
+    CTTS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "gemm (small shape): grid %lld", blocks);
+    const dim3 grid((unsigned)blocks);
+    switch (epi) {
+        case GEMM_EPI_GATEX: launch_small<GEMM_EPI_GATEX>(grid, stream, a, ntiles_s); break;
+        case GEMM_EPI_GATE: launch_small<GEMM_EPI_GATE>(grid, stream, a, ntiles_s); break;
+        case GEMM_EPI_MAG: launch_small<GEMM_EPI_MAG>(grid, stream, a, ntiles_s); break;
+        case GEMM_EPI_LOG: launch_small<GEMM_EPI_LOG>(grid, stream, a, ntiles_s); break;
+        case GEMM_EPI_LRELU: launch_small<GEMM_EPI_LRELU>(grid, stream, a, ntiles_s); break;
+        case GEMM_EPI_TANH: launch_small<GEMM_EPI_TANH>(grid, stream, a, ntiles_s); break;
+        case GEMM_EPI_SPLIT: launch_small<GEMM_EPI_SPLIT>(grid, stream, a, ntiles_s); break;
+        default: set_error("gemm (small shape): epilogue %d", epi); return CTTS_E_ARG;
+    }
+    CTTS_CHECK_LAUNCH("conv_gemm_f32_small");
+    return CTTS_OK;
+}
+
+}  // namespace ctts

@@ -626,10 +626,14 @@ int ctts_taco_stop_rule_f32(const float* gate_logits, int32_t batch, int32_t gat
 int ctts_set_f32_gemm_mode(int32_t mode);
 int ctts_get_f32_gemm_mode(void);
 
-/* Launch-shape overrides for A/B measurements (CTTS_F32_NO_GLDS, CTTS_GEMM_NO_XCD_PAIR, CTTS_BF16_NO_GLDS / _NO_WIDE /
+/* Launch-shape overrides for A/B measurements (CTTS_F32_NO_GLDS, CTTS_F32_NO_SMALL, CTTS_F32_FORCE_SMALL, CTTS_GEMM_NO_XCD_PAIR, CTTS_BF16_NO_GLDS / _NO_WIDE /
  * _NO_PP / _W4 / _PP_STAGES, CTTS_WF_NO_FUSE, CTTS_TACO_NO_FUSE) never change results.  The environment is read once,
  * at the first launch; this re-reads it (tests and profiling scripts that flip a knob in-process). */
 int ctts_tuning_reload(void);
+/* The knobs as the library currently sees them: bit 0 CTTS_F32_NO_GLDS, 1 CTTS_GEMM_NO_XCD_PAIR, 2 CTTS_BF16_NO_GLDS,
+ * 3 CTTS_BF16_NO_WIDE, 4 CTTS_BF16_NO_PP, 5 CTTS_BF16_W4, 6 CTTS_BF16_PP_STAGES=4, 7 CTTS_WF_NO_FUSE, 8 CTTS_TACO_NO_FUSE,
+ * 9 CTTS_F32_NO_SMALL, 10 CTTS_F32_FORCE_SMALL (tests assert that a knob they set is the one in effect). */
+int ctts_tuning_flags(void);
 
 /* ---- in-library kernel timing (bench.py roofline leg) --------------------------------- */
 /* When enabled, ctts_waveglow_infer_f32 brackets every launch of the dominant kernel

@@ -21,6 +21,28 @@ def hip_lib_path():
     return build.build(verbose=False)
 
 
+@pytest.fixture
+def tuning(monkeypatch):
+    """Flip a CTTS_* launch-shape knob for the rest of the test: the library reads its environment ONCE, so setting the
+    variable alone does nothing - this sets it, makes the library re-read (ctts_tuning_reload) and checks that the knob
+    is the one in effect (ctts_tuning_flags).  Everything is undone after the test."""
+    from cookietts_amd import _lib
+
+    class Knobs:
+        def set(self, name, value="1"):
+            monkeypatch.setenv(name, value)
+            _lib.tuning_reload()
+            assert _lib.tuning_active(name), name
+
+        def clear(self, name):
+            monkeypatch.delenv(name, raising=False)
+            _lib.tuning_reload()
+            assert not _lib.tuning_active(name), name
+    yield Knobs()
+    monkeypatch.undo()
+    _lib.tuning_reload()
+
+
 def rms_rel_err(a, b):
     import numpy as np
     a = np.asarray(a, dtype=np.float64)

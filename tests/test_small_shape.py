@@ -1,0 +1,105 @@
+"""The small-problem shape of the fp32 conv-GEMM (csrc/gemm_f32_small.hip: 128 x 64 blocks, 64 x 32 wave tiles on the SAME
+packed operands) against the 256 x 128 shape: every output element sums the same chunks and k-steps in the same order, so
+the two must agree BIT FOR BIT on every epilogue; and the goldens still hold when the large shape is forced at toy size
+(the toy goldens otherwise all run through the small shape now).  Knobs: CTTS_F32_NO_SMALL / CTTS_F32_FORCE_SMALL."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rms_rel_err
+from cookietts_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("c_in,c_out,k,act,slope,T,acc", [
+    (32, 24, 1, 0, 0.0, 7, False),        # SPLIT, ragged rows and columns, one chunk
+    (48, 80, 5, 0, 0.0, 200, True),       # SPLIT with accumulate into a ragged M (the postnet's residual convs)
+    (512, 512, 5, 2, 0.0, 131, False),    # TANH, 160 chunks, five interleaved segments
+    (416, 512, 9, 1, 0.25, 90, False),    # LRELU, nine segments (segment table path), 234 chunks
+])
+def test_conv1d_small_shape_is_bit_identical(hip_lib_path, tuning, c_in, c_out, k, act, slope, T, acc):
+    from cookietts_amd.waveglow_ax import PAD, _CondConv
+    from cookietts_amd import _lib
+    rng = np.random.default_rng(c_in * 7 + k)
+    w = (rng.standard_normal((c_out, c_in, k)) / np.sqrt(c_in * k)).astype(np.float32)
+    b = rng.standard_normal(c_out).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    op = _CondConv(torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev), act, slope, dev, stream)
+    B = 2
+    ld = -(-T // 128) * 128 + 2 * PAD
+    xin = torch.zeros(B, op.c_in, ld, device=dev)
+    xin[:, :c_in, PAD:PAD + T] = torch.from_numpy(rng.standard_normal((B, c_in, T)).astype(np.float32)).to(dev)
+    y0 = torch.zeros(B, -(-c_out // 16) * 16, ld, device=dev)
+    if acc:
+        y0[:, :c_out, PAD:PAD + T] = torch.from_numpy(rng.standard_normal((B, c_out, T)).astype(np.float32)).to(dev)
+
+    def run():
+        y = y0.clone()
+        if acc:
+            _lib.check(_lib.lib().ctts_conv1d_f32(C.byref(op.desc), _lib.ptr(op.blob), _lib.ptr(xin), _lib.ptr(y), 1, B, T, ld, PAD,
+                                                  stream), "ctts_conv1d_f32")
+        else:
+            op(xin, y, B, T, ld, stream)
+        torch.cuda.synchronize()
+        return y
+    small = run()                           # a handful of 256 x 128 blocks: the small shape is chosen
+    tuning.set("CTTS_F32_NO_SMALL")
+    big = run()
+    assert torch.equal(small, big)
+    assert float(small[:, :c_out, PAD:PAD + T].abs().max()) > 0
+
+
+@pytest.mark.parametrize("name", ["waveglow_ax_notebook_toy", "waveglow_ax_toy_gate_glu", "waveglow_ax_toy_merge"])
+def test_ax_core_small_shape_is_bit_identical_and_large_shape_still_meets_the_golden(hip_lib_path, tuning, name):
+    """GATE with the interpolated conditioning addend, GATEX (GLU), merged res/skip: small shape (default at this size) ==
+    large shape (forced), both against the reference golden."""
+    from cookietts_amd.waveglow_ax import WaveGlow
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    cfg = synthetic.WAVEGLOW_AX_CONFIGS[str(g["config_key"])]
+    m = WaveGlow(**cfg)
+    m.load_state_dict(synthetic.to_torch(synthetic.waveglow_ax_state_dict(cfg, seed=int(g["seed"]))))
+    m = m.cuda().eval()
+    z, mel = torch.from_numpy(g["z"]).cuda(), torch.from_numpy(np.pad(g["mel"], ((0, 0), (0, 0), (0, 1)))).cuda()
+    kw = {"speaker_ids": torch.from_numpy(g["speaker_ids"]).cuda()} if "speaker_ids" in g.files else {}
+    small, _ = m.inverse(z, mel, return_CPU=False, **kw)
+    tuning.set("CTTS_F32_NO_SMALL")
+    big, _ = m.inverse(z, mel, return_CPU=False, **kw)
+    assert torch.equal(small, big)
+    err = rms_rel_err(big.cpu().numpy(), g["inverse_full"])
+    print(f"{name}: large shape forced, rms rel err vs reference = {err:.3e}")
+    assert err < 1e-3
+
+
+def test_waveglow_and_stft_small_shape_is_bit_identical(hip_lib_path, tuning):
+    """glow.py core (GATE with a plain addend-free K, SPLIT read-modify-write) on a 12 x 512 model at a width where the
+    large shape is the default, against the small shape forced; and the STFT's MAG / LOG epilogues."""
+    from cookietts_amd import TacotronSTFT, WaveGlow
+    cfg = synthetic.WAVEGLOW_CONFIGS["full"]
+    m = WaveGlow(**cfg)
+    m.load_state_dict(synthetic.to_torch(synthetic.waveglow_state_dict(cfg, seed=5)))
+    m = m.cuda().eval()
+    B, F = 3, 101                                           # 4 x 26 x 3 = 312 blocks... still below two per CU: the
+    mel = torch.from_numpy(synthetic.synthetic_mel(B, F, seed=6)).cuda()     # default IS the small shape here
+    zz = torch.from_numpy(synthetic.synthetic_noise(B, 8, F * 32, seed=6) * np.float32(0.6)).cuda()
+    small = m.infer_from_noise(mel, zz)
+    tuning.set("CTTS_F32_NO_SMALL")
+    big = m.infer_from_noise(mel, zz)
+    assert torch.isfinite(big).all() and torch.equal(small, big)
+    tuning.clear("CTTS_F32_NO_SMALL")
+    B, F = 8, 70                                            # 4 x 18 x 8 = 576 blocks: the large shape by default
+    mel = torch.from_numpy(synthetic.synthetic_mel(B, F, seed=7)).cuda()
+    zz = torch.from_numpy(synthetic.synthetic_noise(B, 8, F * 32, seed=7) * np.float32(0.6)).cuda()
+    big = m.infer_from_noise(mel, zz)
+    tuning.set("CTTS_F32_FORCE_SMALL")
+    assert torch.equal(big, m.infer_from_noise(mel, zz))
+    tuning.clear("CTTS_F32_FORCE_SMALL")
+    stft = TacotronSTFT(1024, 256, 1024, 80, 22050, 0.0, 8000.0).cuda()
+    audio = torch.from_numpy(np.random.default_rng(3).uniform(-0.7, 0.7, (2, 20000)).astype(np.float32)).cuda()
+    mel_small = stft.mel_spectrogram(audio)
+    tuning.set("CTTS_F32_NO_SMALL")
+    assert torch.equal(mel_small, stft.mel_spectrogram(audio))

@@ -146,21 +146,21 @@ def test_hip_infer_contract_and_ragged_vs_oracle(hip_lib_path):
 
 
 @pytest.mark.gpu
-def test_fused_res_skip_epilogue_matches_two_kernel_path(hip_lib_path, monkeypatch):
+def test_fused_res_skip_epilogue_matches_two_kernel_path(hip_lib_path, tuning):
     """C = 64 runs the res/skip GEMM inside the in-layer kernel; CTTS_WF_NO_FUSE keeps the two-launch path."""
     g, cfg, _ = _load("toy")
     m, _, _ = _model(str(g["config_key"]), int(g["seed"]))
     melp = torch.from_numpy(np.pad(g["mel"], ((0, 0), (0, 0), (0, 1)))).cuda()
     z = torch.from_numpy(g["z"]).cuda()
     fused, _ = m.inverse(z, melp)
-    monkeypatch.setenv("CTTS_WF_NO_FUSE", "1")
+    tuning.set("CTTS_WF_NO_FUSE")
     plain, _ = m.inverse(z, melp)
     assert rms_rel_err(plain.numpy(), g["inverse_full"]) < WAVE_TOL
     assert rms_rel_err(fused.numpy(), plain.numpy()) < 1e-5
 
 
 @pytest.mark.gpu
-def test_author_options_ragged_vs_oracle_and_speaker_requirement(hip_lib_path):
+def test_author_options_ragged_vs_oracle_and_speaker_requirement(hip_lib_path, tuning):
     """8f.4 option set at a width that is not a multiple of 4 or of the 256-column tile, batch 3, both fused
     (C = 64) and two-kernel res/skip paths; a multispeaker model refuses to run without speaker ids (ax:288)."""
     m, cfg, sd = _model("author_toy", 12)
@@ -172,11 +172,9 @@ def test_author_options_ragged_vs_oracle_and_speaker_requirement(hip_lib_path):
     ref = wf.waveflow_inverse(sd, cfg, z, mel, ids)
     got, _ = m.inverse(torch.from_numpy(z).cuda(), torch.from_numpy(mel).cuda(), speaker_ids=torch.from_numpy(ids).cuda())
     assert rms_rel_err(got.numpy(), ref) < WAVE_TOL
-    os.environ["CTTS_WF_NO_FUSE"] = "1"
-    try:
-        plain, _ = m.inverse(torch.from_numpy(z).cuda(), torch.from_numpy(mel).cuda(), speaker_ids=torch.from_numpy(ids).cuda())
-    finally:
-        del os.environ["CTTS_WF_NO_FUSE"]
+    tuning.set("CTTS_WF_NO_FUSE")
+    plain, _ = m.inverse(torch.from_numpy(z).cuda(), torch.from_numpy(mel).cuda(), speaker_ids=torch.from_numpy(ids).cuda())
+    tuning.clear("CTTS_WF_NO_FUSE")
     assert rms_rel_err(plain.numpy(), ref) < WAVE_TOL
     with pytest.raises(Exception, match="requires speaker ids"):
         m.inverse(torch.from_numpy(z).cuda(), torch.from_numpy(mel).cuda())
@@ -185,7 +183,7 @@ def test_author_options_ragged_vs_oracle_and_speaker_requirement(hip_lib_path):
 
 
 @pytest.mark.gpu
-def test_author_full_width_fused_1x1_stages_vs_oracle(hip_lib_path):
+def test_author_full_width_fused_1x1_stages_vs_oracle(hip_lib_path, tuning):
     """The author's full option set (C = 128: depthwise launch + fused pointwise/gate/res-skip kernel), two utterances,
     L = 150 (three 64-column tiles, ragged, not a multiple of 4), against the oracle and against the unfused launches."""
     m, cfg, sd = _model("author", 31)
@@ -197,10 +195,8 @@ def test_author_full_width_fused_1x1_stages_vs_oracle(hip_lib_path):
     args = (torch.from_numpy(z).cuda(), torch.from_numpy(mel).cuda())
     got, _ = m.inverse(*args, speaker_ids=torch.from_numpy(ids).cuda())
     assert rms_rel_err(got.numpy(), ref) < WAVE_TOL
-    os.environ["CTTS_WF_NO_FUSE"] = "1"
-    try:
-        plain, _ = m.inverse(*args, speaker_ids=torch.from_numpy(ids).cuda())
-    finally:
-        del os.environ["CTTS_WF_NO_FUSE"]
+    tuning.set("CTTS_WF_NO_FUSE")
+    plain, _ = m.inverse(*args, speaker_ids=torch.from_numpy(ids).cuda())
+    tuning.clear("CTTS_WF_NO_FUSE")
     assert rms_rel_err(plain.numpy(), ref) < WAVE_TOL
     assert rms_rel_err(got.numpy(), plain.numpy()) < 1e-5

@@ -164,7 +164,7 @@ def test_waveglow_bf16x3_matches_reference_golden(hip_lib_path, name):
     assert err < 1e-4            # and an order of magnitude inside it: this is not the bf16 path
 
 
-def test_waveglow_bf16x3_speaker_options_and_block_shapes(hip_lib_path, monkeypatch):
+def test_waveglow_bf16x3_speaker_options_and_block_shapes(hip_lib_path, tuning):
     """Speaker rows + ReZero through the split path (ragged 20-wide embedding), and the narrow / wide block shapes of
     the split GEMMs agree bit for bit (same K order)."""
     g = np.load(os.path.join(GOLDEN, "waveglow_toy_spk_rezero.npz"))
@@ -181,10 +181,10 @@ def test_waveglow_bf16x3_speaker_options_and_block_shapes(hip_lib_path, monkeypa
     mel = torch.from_numpy(synthetic.synthetic_mel(B, F, seed=6)).cuda()
     z = torch.from_numpy(synthetic.synthetic_noise(B, 8, F * 32, seed=6) * np.float32(0.6)).cuda()
     default = m.infer_from_noise(mel, z)
-    monkeypatch.setenv("CTTS_BF16_NO_WIDE", "1")
+    tuning.set("CTTS_BF16_NO_WIDE")
     assert torch.equal(default, m.infer_from_noise(mel, z))
-    monkeypatch.delenv("CTTS_BF16_NO_WIDE")
-    monkeypatch.setenv("CTTS_BF16_NO_GLDS", "1")
+    tuning.clear("CTTS_BF16_NO_WIDE")
+    tuning.set("CTTS_BF16_NO_GLDS")
     assert torch.equal(default, m.infer_from_noise(mel, z))
 
 
@@ -201,7 +201,7 @@ def test_waveglow_bf16_ragged_and_batch_independent(hip_lib_path):
 
 @pytest.mark.parametrize("knob", ["CTTS_BF16_W4", "CTTS_BF16_NO_WIDE", "CTTS_BF16_NO_PP", "CTTS_BF16_NO_GLDS",
                                   "CTTS_GEMM_NO_XCD_PAIR"])
-def test_waveglow_bf16_block_shapes_agree(hip_lib_path, monkeypatch, knob):
+def test_waveglow_bf16_block_shapes_agree(hip_lib_path, tuning, knob):
     """Full model at a size that selects the 256x256 skewed 8-wave kernel (>= 512 workgroups, ragged last tile; W4
     selects the four-wave 128x128-wave-tile kernel of the same block):
     every block shape / staging variant accumulates K in the same order, so the waveforms must be identical."""
@@ -212,13 +212,13 @@ def test_waveglow_bf16_block_shapes_agree(hip_lib_path, monkeypatch, knob):
     z = torch.from_numpy(synthetic.synthetic_noise(B, 8, F * 32, seed=6) * np.float32(0.6)).cuda()
     default = m.infer_from_noise(mel, z)
     assert torch.isfinite(default).all()
-    monkeypatch.setenv(knob, "1")
+    tuning.set(knob)
     other = m.infer_from_noise(mel, z)
     assert torch.equal(default, other)
 
 
 @pytest.mark.parametrize("knob", ["CTTS_F32_NO_GLDS", "CTTS_GEMM_NO_XCD_PAIR"])
-def test_waveglow_fp32_staging_variants_agree(hip_lib_path, monkeypatch, knob):
+def test_waveglow_fp32_staging_variants_agree(hip_lib_path, tuning, knob):
     """fp32 conv-GEMM: DMA-staged 3-stage kernel (default) vs the register-staged one, and both block mappings:
     same K order, so the waveforms are identical (full model, ragged width, enough tiles for every path)."""
     m, cfg, sd = _model("full", 5)
@@ -227,7 +227,7 @@ def test_waveglow_fp32_staging_variants_agree(hip_lib_path, monkeypatch, knob):
     z = torch.from_numpy(synthetic.synthetic_noise(B, 8, F * 32, seed=6) * np.float32(0.6)).cuda()
     default = m.infer_from_noise(mel, z)
     assert torch.isfinite(default).all()
-    monkeypatch.setenv(knob, "1")
+    tuning.set(knob)
     assert torch.equal(default, m.infer_from_noise(mel, z))
 
 
