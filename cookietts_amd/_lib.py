@@ -180,6 +180,9 @@ SIGNATURES = {
     "ctts_lstm_seq_f32": (C.c_int, [_FP, _FP, _FP, C.c_int32, _FP, C.c_int64, C.c_int32, C.c_int32, _FP, C.c_int32,
                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP,
                                     C.c_size_t, _FP]),
+    "ctts_lstm_biseq_f32": (C.c_int, [_FP, _FP, _FP, _FP, _FP, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _FP, C.c_int32,
+                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                      _FP, _FP, C.c_size_t, _FP]),
     "ctts_taco_embed_f32": (C.c_int, [_FP, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_int32, _FP]),
     "ctts_taco_memory_f32": (C.c_int, [C.POINTER(TacoMemoryWeights), _FP, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32,

@@ -325,6 +325,15 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmCall q) {
     lstm_body<NB, R>(q, lstm_smem, blockIdx.x);
 }
 
+// Both directions of a bidirectional layer advance in ONE launch per time step (blockIdx.y = direction): the encoder's
+// BiLSTM is 2 x T dependent launches of ~6.7 us otherwise, i.e. launch-bound.
+template <int NB, int R>
+__global__ __launch_bounds__(256) void lstm_step2_kernel(const LstmCall q0, const LstmCall q1) {
+    extern __shared__ __attribute__((aligned(16))) float lstm_smem[];
+    if (blockIdx.y == 0) lstm_body<NB, R>(q0, lstm_smem, blockIdx.x);
+    else lstm_body<NB, R>(q1, lstm_smem, blockIdx.x);
+}
+
 // ---- attention step --------------------------------------------------------------------
 struct AttnArgs {
     const float *Wq, *v, *Wloc, *Wd, *scalars;
@@ -727,6 +736,24 @@ int launch_lstm(const float* wih, const float* whh, const float* bih, const floa
     return CTTS_E_ARG;
 }
 
+template <int NB>
+int launch_lstm2(const LstmCall& q0, const LstmCall& q1, hipStream_t s) {
+    const int I = q0.I, H = q0.H;
+    const size_t smem_base = (size_t)NB * (I + H) * sizeof(float);
+#define CTTS_LSTM2_CASE(RR)                                                                                        \
+    if (H % RR == 0 && H / RR <= 256) {                                                                           \
+        const size_t smem = smem_base + 4 * RR * NB * sizeof(float);                                              \
+        hipLaunchKernelGGL((lstm_step2_kernel<NB, RR>), dim3(H / RR, 2), dim3(256), smem, s, q0, q1);             \
+        CTTS_CHECK_LAUNCH("lstm_step2");                                                                           \
+        return CTTS_OK;                                                                                            \
+    }
+    CTTS_LSTM2_CASE(1) CTTS_LSTM2_CASE(2) CTTS_LSTM2_CASE(3) CTTS_LSTM2_CASE(4) CTTS_LSTM2_CASE(5) CTTS_LSTM2_CASE(6)
+    CTTS_LSTM2_CASE(8)
+#undef CTTS_LSTM2_CASE
+    set_error("lstm_step2: no tiling for hidden size %d", H);
+    return CTTS_E_ARG;
+}
+
 int launch_lstm_raw(int NB, const float* wih, const float* whh, const float* bih, const float* bhh, const float* in0,
                     int n0, const float* in1, int n1, const float* in2, int n2, const float* h_old, float* h_new, float* c,
                     int I, int H, int batch, const LstmSeq& sq, hipStream_t s, const LstmPart* part = nullptr) {
@@ -1009,10 +1036,16 @@ size_t ctts_lstm_seq_workspace_bytes(int32_t hidden_size, int32_t batch, int32_t
     return (align_up((size_t)batch * 4 * hidden_size * ld) + 3 * align_up(NB * hidden_size)) * sizeof(float);
 }
 
-int ctts_lstm_seq_f32(const void* packed, const float* x, const int32_t* lengths, int32_t reverse, float* out,
-                      int64_t out_bstride, int32_t out_tstride, int32_t out_col, float* hn, int32_t hn_stride,
-                      int32_t hn_col, int32_t batch, int32_t T, int32_t input_size, int32_t hidden_size, int32_t ld,
-                      int32_t pad, void* workspace, size_t workspace_bytes, void* stream) {
+namespace {
+// One direction of a packed-sequence LSTM, ready to step: workspace carved and zeroed, input projection launched.
+struct SeqDir {
+    const float* whh; float *h0, *h1, *c; LstmSeq sq; int H, NB;
+};
+
+int seq_prepare(const void* packed, const float* x, const int32_t* lengths, int32_t reverse, float* out, int64_t out_bstride,
+                int32_t out_tstride, int32_t out_col, float* hn, int32_t hn_stride, int32_t hn_col, int32_t batch, int32_t T,
+                int32_t input_size, int32_t hidden_size, int32_t ld, int32_t pad, void* workspace, size_t workspace_bytes,
+                hipStream_t s, SeqDir& d) {
     SeqPlan p;
     int rc = make_seq_plan(input_size, hidden_size, p); if (rc) return rc;
     CTTS_CHECK_ARG(packed && x && lengths && out && hn && workspace, "lstm_seq: NULL pointer");
@@ -1021,14 +1054,14 @@ int ctts_lstm_seq_f32(const void* packed, const float* x, const int32_t* lengths
     CTTS_CHECK_ARG(ld % 4 == 0 && ntiles * 128 + 2 * pad <= ld, "lstm_seq: geometry T=%d ld=%d pad=%d", T, ld, pad);
     const size_t need = ctts_lstm_seq_workspace_bytes(hidden_size, batch, ld);
     if (need > workspace_bytes) { set_error("lstm_seq: workspace %zu bytes < required %zu", workspace_bytes, need); return CTTS_E_WORKSPACE; }
-    hipStream_t s = as_stream(stream);
     const float* blob = static_cast<const float*>(packed);
     const int H = p.H, NB = pad_batch(batch);
     float* xp = static_cast<float*>(workspace);
-    float* h0 = xp + align_up((size_t)batch * 4 * H * ld);
-    float* h1 = h0 + align_up((size_t)NB * H);
-    float* c = h1 + align_up((size_t)NB * H);
-    CTTS_CHECK_HIP(hipMemsetAsync(h0, 0, 3 * align_up((size_t)NB * H) * sizeof(float), s));
+    d.h0 = xp + align_up((size_t)batch * 4 * H * ld);
+    d.h1 = d.h0 + align_up((size_t)NB * H);
+    d.c = d.h1 + align_up((size_t)NB * H);
+    d.whh = blob + p.whh; d.H = H; d.NB = NB;
+    CTTS_CHECK_HIP(hipMemsetAsync(d.h0, 0, 3 * align_up((size_t)NB * H) * sizeof(float), s));
     // input projection for every time step: Xp[b][4H][t] = W_ih x_t + b_ih + b_hh
     GemmArgs a{};
     a.ld = ld; a.pad = pad; a.L = T; a.ntiles = ntiles; a.batch = batch; a.dst_ld = ld; a.dst_pad = pad;
@@ -1039,17 +1072,64 @@ int ctts_lstm_seq_f32(const void* packed, const float* x, const int32_t* lengths
     a.split = p.mb * 256;
     rc = launch_gemm_f32(GEMM_EPI_SPLIT, a, s);
     if (rc) return rc;
-    LstmSeq sq{};
-    sq.gadd = xp; sq.ga_bstride = (long long)4 * H * ld; sq.ga_ld = ld; sq.ga_pad = pad;
-    sq.lengths = lengths; sq.reverse = reverse;
-    sq.out = out; sq.out_bstride = out_bstride; sq.out_tstride = out_tstride; sq.out_col = out_col;
-    sq.hn = hn; sq.hn_stride = hn_stride; sq.hn_col = hn_col;
+    d.sq = LstmSeq{};
+    d.sq.gadd = xp; d.sq.ga_bstride = (long long)4 * H * ld; d.sq.ga_ld = ld; d.sq.ga_pad = pad;
+    d.sq.lengths = lengths; d.sq.reverse = reverse;
+    d.sq.out = out; d.sq.out_bstride = out_bstride; d.sq.out_tstride = out_tstride; d.sq.out_col = out_col;
+    d.sq.hn = hn; d.sq.hn_stride = hn_stride; d.sq.hn_col = hn_col;
+    return CTTS_OK;
+}
+}  // namespace
+
+int ctts_lstm_seq_f32(const void* packed, const float* x, const int32_t* lengths, int32_t reverse, float* out,
+                      int64_t out_bstride, int32_t out_tstride, int32_t out_col, float* hn, int32_t hn_stride,
+                      int32_t hn_col, int32_t batch, int32_t T, int32_t input_size, int32_t hidden_size, int32_t ld,
+                      int32_t pad, void* workspace, size_t workspace_bytes, void* stream) {
+    hipStream_t s = as_stream(stream);
+    SeqDir d;
+    int rc = seq_prepare(packed, x, lengths, reverse, out, out_bstride, out_tstride, out_col, hn, hn_stride, hn_col, batch, T,
+                         input_size, hidden_size, ld, pad, workspace, workspace_bytes, s, d);
+    if (rc) return rc;
     for (int step = 0; step < T; ++step) {
-        sq.step = step;
-        float* hold = (step & 1) ? h1 : h0;
-        float* hnew = (step & 1) ? h0 : h1;
-        rc = launch_lstm_raw(NB, nullptr, blob + p.whh, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, hold, hnew, c,
-                             0, H, batch, sq, s);
+        d.sq.step = step;
+        float* hold = (step & 1) ? d.h1 : d.h0;
+        float* hnew = (step & 1) ? d.h0 : d.h1;
+        rc = launch_lstm_raw(d.NB, nullptr, d.whh, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, hold, hnew, d.c,
+                             0, d.H, batch, d.sq, s);
+        if (rc) return rc;
+    }
+    return CTTS_OK;
+}
+
+int ctts_lstm_biseq_f32(const void* packed_fwd, const void* packed_bwd, const float* x, const int32_t* lengths, float* out,
+                        int64_t out_bstride, int32_t out_tstride, int32_t out_col_fwd, int32_t out_col_bwd, float* hn,
+                        int32_t hn_stride, int32_t hn_col_fwd, int32_t hn_col_bwd, int32_t batch, int32_t T, int32_t input_size,
+                        int32_t hidden_size, int32_t ld, int32_t pad, void* workspace_fwd, void* workspace_bwd,
+                        size_t workspace_bytes, void* stream) {
+    hipStream_t s = as_stream(stream);
+    CTTS_CHECK_ARG(workspace_fwd != workspace_bwd, "lstm_biseq: the two directions need their own workspaces");
+    SeqDir d[2];
+    int rc = seq_prepare(packed_fwd, x, lengths, 0, out, out_bstride, out_tstride, out_col_fwd, hn, hn_stride, hn_col_fwd, batch,
+                         T, input_size, hidden_size, ld, pad, workspace_fwd, workspace_bytes, s, d[0]);
+    if (rc) return rc;
+    rc = seq_prepare(packed_bwd, x, lengths, 1, out, out_bstride, out_tstride, out_col_bwd, hn, hn_stride, hn_col_bwd, batch, T,
+                     input_size, hidden_size, ld, pad, workspace_bwd, workspace_bytes, s, d[1]);
+    if (rc) return rc;
+    const LstmPart whole{nullptr, nullptr, 0, 0, 1};
+    for (int step = 0; step < T; ++step) {
+        LstmCall q[2];
+        for (int k = 0; k < 2; ++k) {
+            d[k].sq.step = step;
+            float* hold = (step & 1) ? d[k].h1 : d[k].h0;
+            float* hnew = (step & 1) ? d[k].h0 : d[k].h1;
+            q[k] = LstmCall{nullptr, d[k].whh, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, hold, hnew, d[k].c,
+                            d[k].sq, whole, 0, d[k].H, batch};
+        }
+        switch (d[0].NB) {
+            case 1: rc = launch_lstm2<1>(q[0], q[1], s); break;
+            case 2: rc = launch_lstm2<2>(q[0], q[1], s); break;
+            default: rc = launch_lstm2<4>(q[0], q[1], s); break;
+        }
         if (rc) return rc;
     }
     return CTTS_OK;

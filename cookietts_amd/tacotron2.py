@@ -592,12 +592,12 @@ class Encoder(nn.Module):
                 nbytes = lib.ctts_lstm_seq_workspace_bytes(H, g1 - g0, ld)
                 if nbytes == 0:
                     raise _lib.HipLibraryError("lstm_seq workspace query failed: " + lib.ctts_last_error().decode())
-                ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
-                for d, blob in enumerate(packs):
-                    _lib.check(lib.ctts_lstm_seq_f32(_lib.ptr(blob), _lib.ptr(x[g0:g1]), _lib.ptr(lens[g0:g1]), d,
-                                                    _lib.ptr(memory_in[g0:g1]), T * row, row, d * H, _lib.ptr(hn[g0:g1]), 2 * H,
-                                                    d * H, g1 - g0, T, I, H, ld, PAD, _lib.ptr(ws), ws.numel() * 4, st),
-                               "ctts_lstm_seq_f32")
+                # both directions in lockstep: one launch per time step instead of two (the layer is launch-bound)
+                ws = torch.empty(2, nbytes // 4, dtype=torch.float32, device=device)
+                _lib.check(lib.ctts_lstm_biseq_f32(_lib.ptr(packs[0]), _lib.ptr(packs[1]), _lib.ptr(x[g0:g1]),
+                                                   _lib.ptr(lens[g0:g1]), _lib.ptr(memory_in[g0:g1]), T * row, row, 0, H,
+                                                   _lib.ptr(hn[g0:g1]), 2 * H, 0, H, g1 - g0, T, I, H, ld, PAD,
+                                                   _lib.ptr(ws[0]), _lib.ptr(ws[1]), nbytes, st), "ctts_lstm_biseq_f32")
 
 
 class SylpsNet(nn.Module):

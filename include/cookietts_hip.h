@@ -508,6 +508,15 @@ int ctts_lstm_seq_f32(const void* packed, const float* x, const int32_t* lengths
                       int64_t out_bstride, int32_t out_tstride, int32_t out_col, float* hn, int32_t hn_stride,
                       int32_t hn_col, int32_t batch, int32_t T, int32_t input_size, int32_t hidden_size, int32_t ld,
                       int32_t pad, void* workspace, size_t workspace_bytes, void* stream);
+/* Both directions of a bidirectional layer (nn.LSTM(bidirectional=True), model.py:299-309) in lockstep: ONE launch per time
+ * step covers the forward step t and the reverse step of every item, so the layer costs T dependent launches, not 2 T.
+ * Same arithmetic and outputs as two ctts_lstm_seq_f32 calls (reverse = 0 into out_col_fwd / hn_col_fwd, reverse = 1 into
+ * out_col_bwd / hn_col_bwd); each direction needs its own workspace of ctts_lstm_seq_workspace_bytes. */
+int ctts_lstm_biseq_f32(const void* packed_fwd, const void* packed_bwd, const float* x, const int32_t* lengths, float* out,
+                        int64_t out_bstride, int32_t out_tstride, int32_t out_col_fwd, int32_t out_col_bwd, float* hn,
+                        int32_t hn_stride, int32_t hn_col_fwd, int32_t hn_col_bwd, int32_t batch, int32_t T, int32_t input_size,
+                        int32_t hidden_size, int32_t ld, int32_t pad, void* workspace_fwd, void* workspace_bwd,
+                        size_t workspace_bytes, void* stream);
 
 /* x0[b][c][pad+t] = c < E ? embedding[text[b][t]][c] : spk_table[speaker[b]][c - E]   (model.py:1049, 284-288) */
 int ctts_taco_embed_f32(const float* embedding, const float* spk_table, const int64_t* text,

@@ -354,3 +354,48 @@ def test_persistent_decoder_abort_is_detected_and_falls_back(hip_lib_path):
         assert torch.equal(fb[0], want[0]) and torch.equal(fb[2], want[2])
     finally:
         Decoder._persistent_probed, Decoder._persistent_disabled = True, False
+
+
+@pytest.mark.gpu
+def test_bidirectional_lstm_launch_equals_two_one_direction_runs(hip_lib_path):
+    """ctts_lstm_biseq_f32 (both directions of the encoder BiLSTM in one launch per time step) against two
+    ctts_lstm_seq_f32 runs: the same kernels' arithmetic, so bit-equal outputs and final states, ragged lengths."""
+    import ctypes as C
+    from cookietts_amd import _lib
+    from cookietts_amd.tacotron2 import PAD, _ld_for
+    m, g, hp, sd = _model()
+    enc = m.encoder
+    dev = torch.device("cuda", 0)
+    lib = _lib.lib()
+    convs, packs = enc._ops(dev)
+    I, H = enc.lstm.input_size, enc.lstm.hidden_size
+    B, T = 3, 77
+    ld = _ld_for(T)
+    rng = np.random.default_rng(77)
+    x = torch.zeros(B, I, ld, device=dev)
+    x[:, :, PAD:PAD + T] = torch.from_numpy(rng.standard_normal((B, I, T)).astype(np.float32)).to(dev)
+    lens = torch.tensor([77, 40, 1], dtype=torch.int32, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    nbytes = lib.ctts_lstm_seq_workspace_bytes(H, B, ld)
+    row = 2 * H + 5
+    outs = []
+    for both in (False, True):
+        out = torch.zeros(B, T, row, device=dev)
+        hn = torch.zeros(B, 2 * H, device=dev)
+        ws = torch.empty(2, nbytes // 4, device=dev)
+        if both:
+            _lib.check(lib.ctts_lstm_biseq_f32(_lib.ptr(packs[0]), _lib.ptr(packs[1]), _lib.ptr(x), _lib.ptr(lens), _lib.ptr(out),
+                                               T * row, row, 0, H, _lib.ptr(hn), 2 * H, 0, H, B, T, I, H, ld, PAD, _lib.ptr(ws[0]),
+                                               _lib.ptr(ws[1]), nbytes, st), "ctts_lstm_biseq_f32")
+        else:
+            for d in range(2):
+                _lib.check(lib.ctts_lstm_seq_f32(_lib.ptr(packs[d]), _lib.ptr(x), _lib.ptr(lens), d, _lib.ptr(out), T * row, row,
+                                                 d * H, _lib.ptr(hn), 2 * H, d * H, B, T, I, H, ld, PAD, _lib.ptr(ws[d]), nbytes,
+                                                 st), "ctts_lstm_seq_f32")
+        torch.cuda.synchronize()
+        outs.append((out, hn))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][0][0, :, :2 * H].abs().max()) > 0 and float(outs[0][0][1, 40:].abs().max()) == 0.0
+    assert lib.ctts_lstm_biseq_f32(_lib.ptr(packs[0]), _lib.ptr(packs[1]), _lib.ptr(x), _lib.ptr(lens), _lib.ptr(outs[0][0]),
+                                   T * row, row, 0, H, _lib.ptr(outs[0][1]), 2 * H, 0, H, B, T, I, H, ld, PAD, _lib.ptr(ws[0]),
+                                   _lib.ptr(ws[0]), nbytes, st) != 0             # one workspace for both directions: refused
