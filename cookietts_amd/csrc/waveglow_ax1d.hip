@@ -56,7 +56,9 @@ int make_ax_plan(const ctts_wgax_config* cfg, AxPlan& p) {
     CTTS_CHECK_ARG(c.n_group >= 2 && c.n_group % 2 == 0 && c.n_group <= AX_MAX_GROUP, "wgax: n_group=%d (even, <= 32)", c.n_group);
     CTTS_CHECK_ARG(c.kernel_size % 2 == 1 && c.kernel_size >= 1 && c.kernel_size <= GEMM_MAX_SEG - 1,
                    "wgax: kernel_size=%d (odd, <= 11)", c.kernel_size);
-    CTTS_CHECK_ARG(c.n_channels >= 128 && c.n_channels % 128 == 0, "wgax: n_channels=%d (multiple of 128)", c.n_channels);
+    // 32: the res / skip split row of the SPLIT epilogue is a multiple of 32; a ragged last M-block (channels that are
+    // not a multiple of 128) is zero-padded in the packed weights and masked in the epilogues
+    CTTS_CHECK_ARG(c.n_channels >= 32 && c.n_channels % 32 == 0, "wgax: n_channels=%d (multiple of 32)", c.n_channels);
     CTTS_CHECK_ARG(c.n_early_every >= 1 && c.n_early_size >= 0 && c.n_early_size % 2 == 0, "wgax: early outputs");
     CTTS_CHECK_ARG(c.mixing == CTTS_MIX_PERMUTE || c.mixing == CTTS_MIX_CONV1X1, "wgax: mixing=%d", c.mixing);
     CTTS_CHECK_ARG(c.mixing != CTTS_MIX_PERMUTE || c.n_flows % 2 == 0, "wgax: PermuteHeight requires even n_flows");
@@ -65,7 +67,7 @@ int make_ax_plan(const ctts_wgax_config* cfg, AxPlan& p) {
     p.C = c.n_channels;
     p.nch_c = p.C / GEMM_KC;
     p.nch_in = c.kernel_size * p.nch_c;
-    p.mb_in = 2 * p.C / GEMM_BM;
+    p.mb_in = (2 * p.C + GEMM_BM - 1) / GEMM_BM;
     p.mb_end = 1;
     int n_rem = c.n_group;
     p.fd.resize(c.n_flows);

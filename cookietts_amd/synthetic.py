@@ -306,6 +306,11 @@ WAVEGLOW_AX_CONFIGS = {
                                                    hop_length=40, win_length=160, speaker_embed=8, cond_hidden=48,
                                                    cond_output=48, t_hidden=48, t_kernels=(4, 9), t_scales=(2, 3), t_output=32),
                           group_conv_output_dim=24, group_conv_groupped=True),
+    # channel counts that are not a multiple of the GEMM's 128-channel M-block (ragged last block, split row 96 / 160)
+    "toy_c96": waveglow_ax_config(n_flows=4, n_group=8, n_channels=96, n_layers=3, channel_mixing='permute', mix_first=False,
+                                  n_early_every=2),
+    "toy_c160": waveglow_ax_config(n_flows=2, n_group=12, n_channels=160, n_layers=2, kernel_size_w=5, hop_length=240,
+                                   win_length=960, WN=dict(gated_unit='GTLRU')),
     # per-layer width dilations instead of 2^i (a list, and the constant-int form)
     "toy_dilations": waveglow_ax_config(n_flows=2, n_group=8, n_layers=3, kernel_size_w=5, WN=dict(n_layers_dilations_w=[3, 1, 7])),
     "toy_dilations_const": waveglow_ax_config(n_flows=2, n_group=8, n_layers=2, WN=dict(n_layers_dilations_w=2)),

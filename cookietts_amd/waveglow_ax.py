@@ -311,7 +311,7 @@ class WaveGlow(nn.Module):
             need(n_group <= 64, "waveflow=True with n_group > 64")
         else:
             need(not wn.get('seperable_conv', False), "waveflow=False with seperable_conv")
-            need(wn['n_channels'] % 128 == 0, "waveflow=False with n_channels not a multiple of 128")
+            need(wn['n_channels'] % 32 == 0, "waveflow=False with n_channels not a multiple of 32")
             need(n_group <= 32, "waveflow=False with n_group > 32")
         need(cond_residual in (False, True, 0, 1, '1x1conv'), f"cond_residual={cond_residual!r}")
         use_tconv = bool(transposed_conv_scales) and bool(transposed_conv_hidden_dim) and bool(transposed_conv_kernel_size)

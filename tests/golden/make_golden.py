@@ -306,7 +306,9 @@ def make_waveglow_ax(full_length=False, untts=False, gates=False):
                   # res_skip=False
                   ("toy_no_res_skip", 2, 5, 0.8, 65), ("toy_no_res_skip_1layer", 1, 6, 0.8, 66),
                   # per-layer width dilations
-                  ("toy_dilations", 2, 5, 0.8, 67), ("toy_dilations_const", 1, 6, 0.8, 68)]
+                  ("toy_dilations", 2, 5, 0.8, 67), ("toy_dilations_const", 1, 6, 0.8, 68),
+                  # n_channels not a multiple of 128
+                  ("toy_c96", 2, 5, 0.8, 69), ("toy_c160", 1, 6, 0.8, 70)]
         only = sys.argv[2:]
         if only:
             cases = [c for c in cases if c[0] in only]

@@ -54,7 +54,8 @@ def test_conv1d_small_shape_is_bit_identical(hip_lib_path, tuning, c_in, c_out, 
     assert float(small[:, :c_out, PAD:PAD + T].abs().max()) > 0
 
 
-@pytest.mark.parametrize("name", ["waveglow_ax_notebook_toy", "waveglow_ax_toy_gate_glu", "waveglow_ax_toy_merge"])
+@pytest.mark.parametrize("name", ["waveglow_ax_notebook_toy", "waveglow_ax_toy_gate_glu", "waveglow_ax_toy_merge",
+                                  "waveglow_ax_toy_c96", "waveglow_ax_toy_c160"])
 def test_ax_core_small_shape_is_bit_identical_and_large_shape_still_meets_the_golden(hip_lib_path, tuning, name):
     """GATE with the interpolated conditioning addend, GATEX (GLU), merged res/skip: small shape (default at this size) ==
     large shape (forced), both against the reference golden."""

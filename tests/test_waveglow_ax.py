@@ -16,7 +16,7 @@ ORACLE_TOL = 5e-6
 SMALL = ["toy_conv", "toy_conv_mixlast", "toy_permute", "toy_permute_mixfirst", "notebook_toy", "untts_toy", "toy_merge",
          "toy_groupconv", "toy_groupconv_dense", "toy_wn_tconv", "toy_wn_tconv_crop",
          "toy_sigmoid_vol", "toy_no_res_skip", "toy_no_res_skip_1layer",
-         "toy_dilations", "toy_dilations_const"]
+         "toy_dilations", "toy_dilations_const", "toy_c96", "toy_c160"]
 GATES = sorted(k for k in synthetic.WAVEGLOW_AX_CONFIGS if k.startswith("toy_gate_"))       # the 13 non-GTU units
 
 
@@ -102,7 +102,7 @@ def test_c_abi_size_queries_and_argument_validation(hip_lib_path):
     assert lib.ctts_wgax_workspace_bytes(C.byref(cfg), 1, 24 * 11675) > 0
     assert lib.ctts_wgax_workspace_bytes(C.byref(cfg), 1, 24 * 11675 + 1) == 0          # not a multiple of n_group
     assert b"multiple of n_group" in lib.ctts_last_error()
-    for field, bad in (("n_group", 34), ("n_channels", 192), ("kernel_size", 4), ("mixing", 2), ("n_early_size", 3)):
+    for field, bad in (("n_group", 34), ("n_channels", 144), ("kernel_size", 4), ("mixing", 2), ("n_early_size", 3)):
         c2 = _lib.WgaxConfig.from_buffer_copy(cfg)
         setattr(c2, field, bad)
         assert lib.ctts_wgax_packed_bytes(C.byref(c2)) == 0, field
