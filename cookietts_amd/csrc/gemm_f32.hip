@@ -768,6 +768,7 @@ int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
         case GEMM_EPI_GATE_RS:
             CTTS_CHECK_ARG(a.bm == 128 && a.pairC <= 64 && a.MB == 1 && a.rs_wT && a.rs_bias && (a.rs_rows == 64 || a.rs_rows == 128),
                            "gemm: fused res/skip needs bm=128, <= 64 channels");
+            if (gemm_f32_small_applies(epi, a)) return launch_gemm_f32_small(epi, a, stream);
             if (tuning().f32_no_glds || a.nch_total > GEMM_GLDS_MAX_CHUNKS) {
                 if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, 4, false>), grid, dim3(256), 0, stream, a);
                 else hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, GEMM_MAX_SEG, false>), grid, dim3(256), 0, stream, a);

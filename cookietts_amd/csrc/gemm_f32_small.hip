@@ -30,6 +30,8 @@ constexpr int S_ASTAGE = GEMM_KC * S_BM;                 // 2048 floats
 constexpr int S_STAGE = GEMM_KC * (S_BM + S_BN);         // 3072 floats = 12 KiB
 constexpr int S_MAX_CHUNKS = 256;                        // chunk -> B address table entries (same bound as gemm_f32.hip)
 constexpr int S_NST = 3;
+// the fused WaveFlow layer takes the small shape below this many 128 x 256 blocks (set from the B = 1 / 2 / 8 measurements)
+constexpr long long GATE_RS_SMALL_BELOW_BLOCKS = 256;
 constexpr int S_SEGTAB = S_NST * S_STAGE;
 constexpr int S_CHTAB = S_SEGTAB + GEMM_MAX_SEG * 4;
 constexpr int S_LDS_FLOATS = S_CHTAB + 2 * S_MAX_CHUNKS;
@@ -287,6 +289,221 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
     }
 }
 
+
+// ---- fused WaveFlow layer (GEMM_EPI_GATE_RS), small-problem shape --------------------------------------------------
+// Block 128 rows (the <= 64 channels' first- and second-half rows: the bm = 128 packing as it is) x 128 columns, waves
+// 1 x 4, wave tile 128 x 32 (4 x 1 MFMA tiles): half the columns per wave of gemm_f32.hip's 128 x 256 block, so a
+// launch has twice as many waves of half the length.  WaveFlow's row recurrence makes a call ~960 DEPENDENT launches; at
+// batch 1 a launch is 57 large blocks and its duration is one wave's serial time (113 us; B = 1 and B = 2 cost the same
+// 109 ms per call, profiles/r3_11).  Same packed operands, same chunk / k-step order per element: bit-identical.
+constexpr int R_BN = 128;
+constexpr int R_STAGE = GEMM_KC * (S_BM + R_BN);         // 4096 floats = 16 KiB
+constexpr int R_SEGTAB = S_NST * R_STAGE;
+constexpr int R_CHTAB = R_SEGTAB + GEMM_MAX_SEG * 4;
+constexpr int R_LDS_FLOATS = R_CHTAB + 2 * S_MAX_CHUNKS;
+static_assert(64 * 128 + 128 <= S_NST * R_STAGE, "the res/skip weights are staged over the main loop's stages");
+
+template <int SEGS>
+__global__ __launch_bounds__(256, 3) void conv_gemm_f32_gate_rs_small_kernel(const GemmArgs a, const int ntiles_s) {
+    __shared__ __attribute__((aligned(16))) float lds[R_LDS_FLOATS];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wn = wave;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int tile = blockIdx.x % ntiles_s;
+    const int b = blockIdx.x / ntiles_s;
+    const int n0 = tile * R_BN;
+
+#pragma unroll
+    for (int sidx = 0; sidx < GEMM_MAX_SEG; ++sidx) {
+        if (sidx < SEGS && t == sidx) {
+            const GemmSeg& g = a.seg[sidx];
+            unsigned int* e = reinterpret_cast<unsigned int*>(lds + R_SEGTAB + sidx * 4);
+            if (sidx < a.nseg) {
+                const float* base = g.base + (size_t)b * g.bstride + (a.pad + n0 + g.shift);
+                const unsigned long long u = reinterpret_cast<unsigned long long>(base);
+                e[0] = (unsigned int)u; e[1] = (unsigned int)(u >> 32); e[2] = (unsigned int)g.nch;
+            } else {
+                e[0] = 0; e[1] = 0; e[2] = 0x7fffffffu;
+            }
+            e[3] = 0;
+        }
+    }
+    __syncthreads();
+    {
+        unsigned long long* tab = reinterpret_cast<unsigned long long*>(lds + R_CHTAB);
+        const int ilv0 = a.interleave > 1 ? a.interleave : 0;
+        const int n_il = ilv0 * a.seg[0].nch;
+        for (int c0 = t; c0 < a.nch_total; c0 += 256) {
+            int c = c0, sg, loc;
+            if (c < n_il) {
+                sg = c % ilv0;
+                loc = c / ilv0;
+            } else {
+                c -= n_il;
+                sg = ilv0;
+                for (int k = 0; k < SEGS - 1; ++k) {
+                    const int nck = (int)reinterpret_cast<const unsigned int*>(lds + R_SEGTAB + k * 4)[2];
+                    if (sg == k && k < a.nseg - 1 && c >= nck) { c -= nck; sg = k + 1; }
+                }
+                loc = c;
+            }
+            const unsigned int* e = reinterpret_cast<const unsigned int*>(lds + R_SEGTAB + sg * 4);
+            const unsigned long long base = ((unsigned long long)e[1] << 32) | e[0];
+            tab[c0] = base + (unsigned long long)loc * GEMM_KC * a.ld * sizeof(float);
+        }
+    }
+    __syncthreads();
+
+    const int nalloc = a.a_nch_alloc ? a.a_nch_alloc : a.nch_total;
+    // A: the [16][128] chunk of the bm = 128 packing, copied linearly: piece p of this wave = floats [wave * 256 + p * 1024, +256)
+    const gfloat_ptr a_base = (gfloat_ptr)(a.A + (size_t)a.a_ch_off * S_ASTAGE + wave * 256 + lane * 4);
+    (void)nalloc;
+    // B: [16][128] stage, piece p of this wave = k-row 2 wave + 8 p + (lane >> 5), columns 4 (lane & 31)
+    const size_t b_off = (size_t)(2 * wave + (lane >> 5)) * a.ld + (lane & 31) * 4;
+    const size_t b_piece = (size_t)8 * a.ld;
+    const unsigned long long* ctab = reinterpret_cast<const unsigned long long*>(lds + R_CHTAB);
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+#define R_ISSUE_A(buf, c, p)                                                                                     \
+    __builtin_amdgcn_global_load_lds(a_base + (size_t)(c) * S_ASTAGE + (p) * 1024,                                \
+                                     (lds_fptr)(lds + (buf) * R_STAGE + wave * 256 + (p) * 1024), 16, 0, 0)
+#define R_ISSUE_B(buf, c, p)                                                                                     \
+    do {                                                                                                         \
+        const unsigned long long ub_ = ctab[c];                                                                  \
+        const unsigned long long us_ =                                                                           \
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |             \
+            (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                                  \
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off + (p) * b_piece,              \
+                                         (lds_fptr)(lds + (buf) * R_STAGE + S_ASTAGE + wave * 256 + (p) * 1024), 16, 0, 0); \
+    } while (0)
+
+    const int nch = a.nch_total;
+    R_ISSUE_A(0, 0, 0); R_ISSUE_A(0, 0, 1); R_ISSUE_B(0, 0, 0); R_ISSUE_B(0, 0, 1);
+    {
+        const int c1 = nch > 1 ? 1 : 0;
+        R_ISSUE_A(1, c1, 0); R_ISSUE_A(1, c1, 1); R_ISSUE_B(1, c1, 0); R_ISSUE_B(1, c1, 1);
+    }
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    int cur = 0;
+    for (int ch = 0; ch < nch; ++ch) {
+        const float* As = lds + cur * R_STAGE + l31;
+        const float* Bs = lds + cur * R_STAGE + S_ASTAGE + wn * 32 + l31;
+        const int nb = cur >= 1 ? cur - 1 : 2;
+        const int cn = ch + 2 < nch ? ch + 2 : nch - 1;
+        float av[GEMM_KC / 2][4], bv[GEMM_KC / 2];
+#define R_READ(ks)                                                                                               \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) av[ks][mt] = As[(2 * (ks) + lhi) * S_BM + mt * 32];      \
+        bv[ks] = Bs[(2 * (ks) + lhi) * R_BN];
+#define R_MFMA(ks)                                                                                               \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                         \
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks][mt], bv[ks], acc[mt], 0, 0, 0);
+        R_READ(0)
+        __builtin_amdgcn_sched_barrier(0);
+        R_READ(1) R_MFMA(0) R_ISSUE_A(nb, cn, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        R_READ(2) R_MFMA(1) R_ISSUE_A(nb, cn, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        R_READ(3) R_MFMA(2) R_ISSUE_B(nb, cn, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        R_READ(4) R_MFMA(3) R_ISSUE_B(nb, cn, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        R_READ(5) R_MFMA(4)
+        __builtin_amdgcn_sched_barrier(0);
+        R_READ(6) R_MFMA(5)
+        __builtin_amdgcn_sched_barrier(0);
+        R_READ(7) R_MFMA(6)
+        __builtin_amdgcn_sched_barrier(0);
+        R_MFMA(7)
+#undef R_READ
+#undef R_MFMA
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+#undef R_ISSUE_A
+#undef R_ISSUE_B
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue: gate in registers, res/skip 1x1 GEMM on the gated tile, read-modify-write (gemm_f32.hip GATE_RS)
+    if (t < S_BM) lds[t] = a.bias[t];
+    __syncthreads();
+    const int n = n0 + wn * 32 + l31;
+    float actv[2][16];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const bool ok = mt * 32 + row < a.pairC;
+            float u0 = acc[mt][r] + lds[mt * 32 + row];
+            float u1 = acc[mt + 2][r] + lds[64 + mt * 32 + row];
+            if (a.addend) {                                // uniform; columns >= L of a padded row are readable
+                const float* ad = a.addend + (size_t)b * a.addend_bstride + a.addend_pad + n;
+                const int c = min(mt * 32 + row, a.pairC - 1);
+                u0 += ad[(size_t)c * a.addend_ld];
+                u1 += ad[(size_t)(a.pairC + c) * a.addend_ld];
+            }
+            actv[mt][r] = ok ? s_fast_tanh(u0) * s_fast_sigmoid(u1) : 0.0f;
+        }
+    __syncthreads();                                       // everyone is done with the bias copy in LDS
+    for (int i = t * 4; i < 64 * 128; i += 1024)
+        *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(a.rs_wT + i);
+    if (t < 128) lds[64 * 128 + t] = a.rs_bias[t];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        const int r = s & 15;
+        const int ch = (s >> 4) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        float a2[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a2[mt] = lds[ch * 128 + mt * 32 + l31];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[mt], actv[s >> 4][r], acc[mt], 0, 0, 0);
+    }
+    const float* rbias = lds + 64 * 128;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int rbase = mt * 32;
+        if (rbase >= a.rs_rows) continue;
+        const bool second = rbase >= a.split;
+        float* dst = second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride;
+        const float* src = second ? dst : (a.src0 ? a.src0 + (size_t)b * a.src0_bstride : dst);
+        const int accum = second ? a.acc1 : a.acc0;
+        const int rdst = second ? rbase - a.split : rbase;
+        if (n < a.L) {
+            float old[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                old[r] = (accum && rbase + row < a.rs_rows) ? src[(size_t)(rdst + row) * a.dst_ld + a.dst_pad + n] : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const float v = acc[mt][r] + rbias[rbase + row] + old[r];
+                if (rbase + row < a.rs_rows) dst[(size_t)(rdst + row) * a.dst_ld + a.dst_pad + n] = v;
+            }
+        }
+    }
+}
+
 template <int EPI>
 void launch_small(dim3 grid, hipStream_t stream, const GemmArgs& a, int ntiles_s) {
     if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_small_kernel<EPI, 4>), grid, dim3(256), 0, stream, a, ntiles_s);
@@ -296,9 +513,13 @@ void launch_small(dim3 grid, hipStream_t stream, const GemmArgs& a, int ntiles_s
 }  // namespace
 
 bool gemm_f32_small_applies(int epi, const GemmArgs& a) {
-    if (a.bm != 256 || a.nch_total > S_MAX_CHUNKS || gemm_mode_is_split(a.gemm_mode)) return false;
+    if (a.nch_total > S_MAX_CHUNKS || gemm_mode_is_split(a.gemm_mode)) return false;
     const Tuning tune = tuning();
     if (tune.f32_no_glds || tune.f32_no_small) return false;
+    if (epi == GEMM_EPI_GATE_RS)       // fused WaveFlow layer (bm = 128, one M-block): 128 x 128 blocks of 128 x 32 wave tiles
+        return a.bm == 128 && a.MB == 1 && a.gate == GATE_GTU &&
+               ((long long)a.ntiles * a.batch < GATE_RS_SMALL_BELOW_BLOCKS || tune.f32_force_small);
+    if (a.bm != 256) return false;
     if (!(epi == GEMM_EPI_SPLIT || epi == GEMM_EPI_GATE || epi == GEMM_EPI_GATEX || epi == GEMM_EPI_MAG || epi == GEMM_EPI_LOG ||
           epi == GEMM_EPI_LRELU || epi == GEMM_EPI_TANH))
         return false;
@@ -307,6 +528,15 @@ bool gemm_f32_small_applies(int epi, const GemmArgs& a) {
 }
 
 int launch_gemm_f32_small(int epi, const GemmArgs& a, hipStream_t stream) {
+    if (epi == GEMM_EPI_GATE_RS) {
+        const int nt = (a.L + R_BN - 1) / R_BN;
+        const long long nblk = (long long)nt * a.batch;
+        CTTS_CHECK_ARG(nblk > 0 && nblk < (1ll << 31), "gemm (small fused shape): grid %lld", nblk);
+        if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_gate_rs_small_kernel<4>), dim3((unsigned)nblk), dim3(256), 0, stream, a, nt);
+        else hipLaunchKernelGGL((conv_gemm_f32_gate_rs_small_kernel<GEMM_MAX_SEG>), dim3((unsigned)nblk), dim3(256), 0, stream, a, nt);
+        CTTS_CHECK_LAUNCH("conv_gemm_f32_gate_rs_small");
+        return CTTS_OK;
+    }
     const int ntiles_s = (a.L + S_BN - 1) / S_BN;
     const long long blocks = 2ll * a.MB * ntiles_s * a.batch;
     CTTS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "gemm (small shape): grid %lld", blocks);

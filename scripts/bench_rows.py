@@ -35,21 +35,25 @@ def row_waveflow(args):
     m = WaveGlow(**cfg)
     m.load_state_dict(synthetic.to_torch(synthetic.waveflow_state_dict(cfg, seed=1234)))
     m = m.cuda().eval()
-    B, F = 8, 900
-    mel = torch.from_numpy(synthetic.synthetic_mel(B, F)).cuda()
-    dt = timed(lambda: m.infer(mel, sigma=0.6, return_CPU=False), args.warmup, args.steps)
-    samples = B * (F - 1) * 256
-    wn = cfg["WN_config"]
-    C, G = wn["n_channels"], cfg["n_group"]
-    launches = cfg["n_flows"] * (G - 1) * wn["n_layers"]
-    mac = 0.6515e6 * (G - 1) * cfg["n_flows"] / G          # per output sample
-    return {"row": "B/config4", "metric": "audio samples/sec (22.05kHz) WaveFlow infer (8 flows, 64 ch, h=16), 80x900 mel",
-            "value": samples / dt, "unit": "samples/s", "rtf": samples / dt / 22050, "ms_per_call": dt * 1e3,
-            "dtype": "f32", "batch": B, "frames": F, "kernel_launches_per_utterance_batch": launches + 2 * cfg["n_flows"] * (G - 1),
-            "achieved_tflops_algorithmic": 2 * mac * samples / dt / 1e12,
-            # 138 KB of per-layer-kernel traffic per output sample (2304 B per row, step, layer)
-            "achieved_GBps_vs_138KB_per_sample": 138e3 * samples / dt / 1e9,
-            "hbm_frac_vs_138KB_per_sample": 138e3 * samples / dt / 8e12}
+    rows = []
+    for B in _batches(args, (1, 8)):     # B = 1 too: the reference's own WaveFlow timing table is batch 1
+        F = 900
+        mel = torch.from_numpy(synthetic.synthetic_mel(B, F)).cuda()
+        dt = timed(lambda: m.infer(mel, sigma=0.6, return_CPU=False), args.warmup, args.steps)
+        samples = B * (F - 1) * 256
+        wn = cfg["WN_config"]
+        C, G = wn["n_channels"], cfg["n_group"]
+        launches = cfg["n_flows"] * (G - 1) * wn["n_layers"]
+        mac = 0.6515e6 * (G - 1) * cfg["n_flows"] / G          # per output sample
+        rows.append({"row": "B/config4", "metric": "audio samples/sec (22.05kHz) WaveFlow infer (8 flows, 64 ch, h=16), 80x900 mel",
+                     "value": samples / dt, "unit": "samples/s", "rtf": samples / dt / 22050, "ms_per_call": dt * 1e3,
+                     "dtype": "f32", "batch": B, "frames": F,
+                     "kernel_launches_per_utterance_batch": launches + 2 * cfg["n_flows"] * (G - 1),
+                     "achieved_tflops_algorithmic": 2 * mac * samples / dt / 1e12,
+                     # 138 KB of per-layer-kernel traffic per output sample (2304 B per row, step, layer)
+                     "achieved_GBps_vs_138KB_per_sample": 138e3 * samples / dt / 1e9,
+                     "hbm_frac_vs_138KB_per_sample": 138e3 * samples / dt / 8e12})
+    return rows
 
 
 def row_waveflow_author(args):

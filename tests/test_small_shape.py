@@ -104,3 +104,24 @@ def test_waveglow_and_stft_small_shape_is_bit_identical(hip_lib_path, tuning):
     mel_small = stft.mel_spectrogram(audio)
     tuning.set("CTTS_F32_NO_SMALL")
     assert torch.equal(mel_small, stft.mel_spectrogram(audio))
+
+
+@pytest.mark.parametrize("name", ["toy", "full_short", "toy_dilations_h"])
+def test_waveflow_fused_layer_small_shape_is_bit_identical(hip_lib_path, tuning, name):
+    """The fused WaveFlow layer (GATE_RS: dilated 2-D conv GEMM + gate + res/skip GEMM in one launch) in its small shape
+    (128 x 128 blocks, 128 x 32 wave tiles; the default below 256 large blocks) against the 128 x 256 shape, and the
+    large shape against the reference golden."""
+    from cookietts_amd import WaveFlow
+    g = np.load(os.path.join(GOLDEN, f"waveflow_{name}.npz"))
+    cfg = synthetic.WAVEFLOW_CONFIGS[str(g["config_key"])]
+    m = WaveFlow(**cfg)
+    m.load_state_dict(synthetic.to_torch(synthetic.waveflow_state_dict(cfg, seed=int(g["seed"]))))
+    m = m.cuda().eval()
+    z, mel = torch.from_numpy(g["z"]).cuda(), torch.from_numpy(np.pad(g["mel"], ((0, 0), (0, 0), (0, 1)))).cuda()
+    small, _ = m.inverse(z, mel, return_CPU=False)
+    tuning.set("CTTS_F32_NO_SMALL")
+    big, _ = m.inverse(z, mel, return_CPU=False)
+    assert torch.equal(small, big)
+    err = rms_rel_err(big.cpu().numpy(), g["inverse_full"])
+    print(f"waveflow {name}: large shape forced, rms rel err vs reference = {err:.3e}")
+    assert err < 1e-3
