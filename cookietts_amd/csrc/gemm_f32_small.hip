@@ -18,6 +18,7 @@
 //     stages, two chunks ahead, three DMA pieces per chunk per wave, counted vmcnt + s_barrier.
 #include "gemm_f32.h"
 #include "tuning.h"
+#include "gemm_bf16.h"   // pack_bf16x2 (split-bf16 main loop)
 
 namespace ctts {
 
@@ -46,7 +47,21 @@ __device__ __forceinline__ float s_fast_tanh(float u) {
 typedef const __attribute__((address_space(1))) float* gfloat_ptr;
 typedef __attribute__((address_space(3))) float* lds_fptr;
 
-template <int EPI, int SEGS>
+// split-bf16 main loop (X3), exactly as in conv_gemm_f32_kernel<..., X3>: the 8 k-values a lane reads per fragment and chunk
+// become one bf16x8 operand pair hi = bf16(v), lo = bf16(v - hi); a 32x32 tile of the chunk is lo*hi + hi*lo + hi*hi on
+// v_mfma_f32_32x32x16_bf16, in that order - so this shape stays bit-identical to the large one in split mode too
+typedef __bf16 s_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int s_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void s_split8(const float (&v)[8], s_u32x4& hi, s_u32x4& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned int h = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+        hi[j] = h;
+        lo[j] = pack_bf16x2(v[2 * j] - __builtin_bit_cast(float, h << 16), v[2 * j + 1] - __builtin_bit_cast(float, h & 0xffff0000u));
+    }
+}
+
+template <int EPI, int SEGS, bool X3 = false>
 __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmArgs a, const int ntiles_s) {
     __shared__ __attribute__((aligned(16))) float lds[S_LDS_FLOATS];
     constexpr bool PAIR = EPI == GEMM_EPI_GATE || EPI == GEMM_EPI_GATEX || EPI == GEMM_EPI_MAG;
@@ -154,6 +169,30 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
         const float* Bs = lds + cur * S_STAGE + S_ASTAGE + wn * 32 + l31;
         const int nb = cur >= 1 ? cur - 1 : 2;              // (cur + 2) % 3: the stage chunk ch - 1 occupied
         const int cn = ch + 2 < nch ? ch + 2 : nch - 1;     // the last two iterations re-issue the final chunk
+        if constexpr (X3) {
+            s_u32x4 ah[2], al[2], bh, bl;
+            {
+                float v[8];
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) v[ks] = Bs[(2 * ks + lhi) * S_BN];
+                s_split8(v, bh, bl);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                float v[8];
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) v[ks] = As[(2 * ks + lhi) * S_BM + (mt == 0 ? arow0 : arow1)];
+                s_split8(v, ah[mt], al[mt]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            S_ISSUE_A(nb, cn, 0); S_ISSUE_A(nb, cn, 1); S_ISSUE_B(nb, cn);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s_bf16x8, al[mt]), __builtin_bit_cast(s_bf16x8, bh), acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s_bf16x8, ah[mt]), __builtin_bit_cast(s_bf16x8, bl), acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s_bf16x8, ah[mt]), __builtin_bit_cast(s_bf16x8, bh), acc[mt], 0, 0, 0);
+            }
+        } else {
         float av0[GEMM_KC / 2], av1[GEMM_KC / 2], bv[GEMM_KC / 2];
 #define S_READ(ks)                                                                                               \
         av0[ks] = As[(2 * (ks) + lhi) * S_BM + arow0]; av1[ks] = As[(2 * (ks) + lhi) * S_BM + arow1];            \
@@ -178,6 +217,7 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
         S_MFMA(6) S_MFMA(7)
 #undef S_READ
 #undef S_MFMA
+        }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(3)" ::: "memory");    // chunk ch + 1 landed, the newest still in flight
         __builtin_amdgcn_s_barrier();
@@ -506,6 +546,11 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_f32_gate_rs_small_kernel(con
 
 template <int EPI>
 void launch_small(dim3 grid, hipStream_t stream, const GemmArgs& a, int ntiles_s) {
+    if (gemm_mode_is_split(a.gemm_mode)) {
+        if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_small_kernel<EPI, 4, true>), grid, dim3(256), 0, stream, a, ntiles_s);
+        else hipLaunchKernelGGL((conv_gemm_f32_small_kernel<EPI, GEMM_MAX_SEG, true>), grid, dim3(256), 0, stream, a, ntiles_s);
+        return;
+    }
     if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_small_kernel<EPI, 4>), grid, dim3(256), 0, stream, a, ntiles_s);
     else hipLaunchKernelGGL((conv_gemm_f32_small_kernel<EPI, GEMM_MAX_SEG>), grid, dim3(256), 0, stream, a, ntiles_s);
 }
@@ -513,11 +558,11 @@ void launch_small(dim3 grid, hipStream_t stream, const GemmArgs& a, int ntiles_s
 }  // namespace
 
 bool gemm_f32_small_applies(int epi, const GemmArgs& a) {
-    if (a.nch_total > S_MAX_CHUNKS || gemm_mode_is_split(a.gemm_mode)) return false;
+    if (a.nch_total > S_MAX_CHUNKS) return false;
     const Tuning tune = tuning();
     if (tune.f32_no_glds || tune.f32_no_small) return false;
     if (epi == GEMM_EPI_GATE_RS)       // fused WaveFlow layer (bm = 128, one M-block): 128 x 128 blocks of 128 x 32 wave tiles
-        return a.bm == 128 && a.MB == 1 && a.gate == GATE_GTU &&
+        return a.bm == 128 && a.MB == 1 && a.gate == GATE_GTU && !gemm_mode_is_split(a.gemm_mode) &&
                ((long long)a.ntiles * a.batch < GATE_RS_SMALL_BELOW_BLOCKS || tune.f32_force_small);
     if (a.bm != 256) return false;
     if (!(epi == GEMM_EPI_SPLIT || epi == GEMM_EPI_GATE || epi == GEMM_EPI_GATEX || epi == GEMM_EPI_MAG || epi == GEMM_EPI_LOG ||

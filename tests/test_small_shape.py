@@ -125,3 +125,27 @@ def test_waveflow_fused_layer_small_shape_is_bit_identical(hip_lib_path, tuning,
     err = rms_rel_err(big.cpu().numpy(), g["inverse_full"])
     print(f"waveflow {name}: large shape forced, rms rel err vs reference = {err:.3e}")
     assert err < 1e-3
+
+
+def test_small_shape_in_split_bf16_mode_is_bit_identical(hip_lib_path, tuning):
+    """The split-bf16 main loop (model.set_f32_gemm_mode('bf16x3')) in the small shape: same three products in the same
+    order per chunk as the large shape, so bit-identical there too; and inside 1e-4 of the reference golden."""
+    from cookietts_amd.waveglow_ax import WaveGlow
+    g = np.load(os.path.join(GOLDEN, "waveglow_ax_notebook_toy.npz"))
+    cfg = synthetic.WAVEGLOW_AX_CONFIGS[str(g["config_key"])]
+    m = WaveGlow(**cfg)
+    m.load_state_dict(synthetic.to_torch(synthetic.waveglow_ax_state_dict(cfg, seed=int(g["seed"]))))
+    m = m.cuda().eval().set_f32_gemm_mode("bf16x3")
+    z, mel = torch.from_numpy(g["z"]).cuda(), torch.from_numpy(np.pad(g["mel"], ((0, 0), (0, 0), (0, 1)))).cuda()
+    ids = torch.from_numpy(g["speaker_ids"]).cuda()
+    small, _ = m.inverse(z, mel, speaker_ids=ids, return_CPU=False)
+    tuning.set("CTTS_F32_NO_SMALL")
+    big, _ = m.inverse(z, mel, speaker_ids=ids, return_CPU=False)
+    assert torch.equal(small, big)
+    err = rms_rel_err(small.cpu().numpy(), g["inverse_full"])
+    print(f"waveglow_ax notebook_toy, split-bf16 loop, small shape: rms rel err vs reference = {err:.3e}")
+    assert err < 1e-4
+    m.set_f32_gemm_mode("f32")
+    tuning.clear("CTTS_F32_NO_SMALL")
+    exact, _ = m.inverse(z, mel, speaker_ids=ids, return_CPU=False)
+    assert not torch.equal(exact, small)                    # the split loop really ran
