@@ -61,6 +61,34 @@ __device__ __forceinline__ void s_split8(const float (&v)[8], s_u32x4& hi, s_u32
     }
 }
 
+// scripts/micro/small_gemm_timeline.hip compiles this file with CTTS_SMALL_GEMM_STAMPS to get a per-block timeline
+// (s_memrealtime at entry / tables built / first chunk landed / main loop done / epilogue operands landed / stores
+// acknowledged); the library build never defines it
+#ifdef CTTS_SMALL_GEMM_STAMPS
+__device__ unsigned long long* g_small_stamps;
+#define S_STAMP(k)                                                                                               \
+    do {                                                                                                         \
+        if (threadIdx.x == 0) g_small_stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime();   \
+    } while (0)
+#define S_STAMP_DRAIN(k)                                                                                         \
+    do {                                                                                                         \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
+        S_STAMP(k);                                                                                              \
+    } while (0)
+// slot 6: HW_ID (cu_id [11:8], sh_id [12], se_id [15:13]) | XCC_ID << 32: which CU the block landed on
+#define S_STAMP_WHERE()                                                                                          \
+    do {                                                                                                         \
+        if (threadIdx.x == 0)                                                                                    \
+            g_small_stamps[(size_t)blockIdx.x * 8 + 6] =                                                         \
+                (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |                                  \
+                ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);                          \
+    } while (0)
+#else
+#define S_STAMP_WHERE()
+#define S_STAMP(k)
+#define S_STAMP_DRAIN(k)
+#endif
+
 template <int EPI, int SEGS, bool X3 = false>
 __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmArgs a, const int ntiles_s) {
     __shared__ __attribute__((aligned(16))) float lds[S_LDS_FLOATS];
@@ -72,6 +100,8 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
 
+    S_STAMP(0);
+    S_STAMP_WHERE();
     int id = blockIdx.x;
     const int mbs = id % (2 * a.MB);
     id /= 2 * a.MB;
@@ -79,6 +109,36 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
     const int b = id / ntiles_s;
     const int mb = mbs >> 1, half = mbs & 1;
     const int n0 = tile * S_BN;
+
+    // SPLIT-family epilogues add the destination's previous contents (x += res, skip += ...).  Nothing in this launch
+    // writes this block's tile before its own epilogue, so those 2 x 16 values per lane are requested FIRST: they travel
+    // while the tables are built and the first chunks stream in (loads return in order, so the first counted vmcnt wait
+    // of the main loop covers them) instead of as an exposed round trip of every block at the end of the launch - all
+    // blocks of a short launch reach their epilogues together (scripts/micro/small_gemm_timeline.hip: 6.9 us of 41)
+    float old[PAIR ? 1 : 2][16];
+    if constexpr (!PAIR) {
+        const int n = n0 + wn * 32 + l31;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int rbase = mb * 256 + 128 * half + 32 * wm + 64 * mt;
+            const bool second = rbase >= a.split;
+            const float* dstc = second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride;
+            const float* src = second ? dstc : (a.src0 ? a.src0 + (size_t)b * a.src0_bstride : dstc);
+            const int accum = second ? a.acc1 : a.acc0;
+            const int rdst = second ? rbase - a.split : rbase;
+            // one unconditional form (two differently guarded forms would meet in register copies, which wait for the
+            // loads): lanes past the last column / rows past M re-read the last valid one and are never stored
+            if (accum && rbase < a.M) {
+                const float* sp = src + (size_t)rdst * a.dst_ld + a.dst_pad + min(n, a.L - 1);
+                const int rlast = a.M - 1 - rbase;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) old[mt][r] = sp[(size_t)min((r & 3) + 8 * (r >> 2) + 4 * lhi, rlast) * a.dst_ld];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) old[mt][r] = 0.0f;
+            }
+        }
+    }
 
     // segment table -> LDS (a dynamically indexed kernarg struct would be copied to scratch), then chunk -> B address
 #pragma unroll
@@ -150,7 +210,18 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
                                          (lds_fptr)(lds + (buf) * S_STAGE + S_ASTAGE + wave * 256), 16, 0, 0);   \
     } while (0)
 
+#define S_ISSUE_B_AT(buf, ub)                                                                                    \
+    do {                                                                                                         \
+        const unsigned long long ub_ = (ub);                                                                     \
+        const unsigned long long us_ =                                                                           \
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |             \
+            (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                                  \
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off,                               \
+                                         (lds_fptr)(lds + (buf) * S_STAGE + S_ASTAGE + wave * 256), 16, 0, 0);   \
+    } while (0)
+
     const int nch = a.nch_total;
+    S_STAMP(1);
     S_ISSUE_A(0, 0, 0); S_ISSUE_A(0, 0, 1); S_ISSUE_B(0, 0);
     {
         const int c1 = nch > 1 ? 1 : 0;
@@ -159,17 +230,20 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
     asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    S_STAMP(2);
 
     // fragment rows of this wave inside the 128-row half
-    const int arow0 = PAIR ? 32 * wm : 64 * wm;
-    const int arow1 = PAIR ? 64 + 32 * wm : 64 * wm + 32;
+    // (tile mt of wave wm = rows 32 wm + 64 mt for every epilogue: the pair epilogues need that pairing, and a fixed
+    // 64-row distance lets one ds_read2st64_b32 fetch both A fragments of a k-step)
+    const int arow0 = 32 * wm;
+    const int arow1 = 64 + 32 * wm;
     int cur = 0;
-    for (int ch = 0; ch < nch; ++ch) {
-        const float* As = lds + cur * S_STAGE + l31;
-        const float* Bs = lds + cur * S_STAGE + S_ASTAGE + wn * 32 + l31;
-        const int nb = cur >= 1 ? cur - 1 : 2;              // (cur + 2) % 3: the stage chunk ch - 1 occupied
-        const int cn = ch + 2 < nch ? ch + 2 : nch - 1;     // the last two iterations re-issue the final chunk
-        if constexpr (X3) {
+    if constexpr (X3) {
+        for (int ch = 0; ch < nch; ++ch) {
+            const float* As = lds + cur * S_STAGE + l31;
+            const float* Bs = lds + cur * S_STAGE + S_ASTAGE + wn * 32 + l31;
+            const int nb = cur >= 1 ? cur - 1 : 2;              // (cur + 2) % 3: the stage chunk ch - 1 occupied
+            const int cn = ch + 2 < nch ? ch + 2 : nch - 1;     // the last two iterations re-issue the final chunk
             s_u32x4 ah[2], al[2], bh, bl;
             {
                 float v[8];
@@ -192,42 +266,82 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s_bf16x8, ah[mt]), __builtin_bit_cast(s_bf16x8, bl), acc[mt], 0, 0, 0);
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s_bf16x8, ah[mt]), __builtin_bit_cast(s_bf16x8, bh), acc[mt], 0, 0, 0);
             }
-        } else {
-        float av0[GEMM_KC / 2], av1[GEMM_KC / 2], bv[GEMM_KC / 2];
-#define S_READ(ks)                                                                                               \
-        av0[ks] = As[(2 * (ks) + lhi) * S_BM + arow0]; av1[ks] = As[(2 * (ks) + lhi) * S_BM + arow1];            \
-        bv[ks] = Bs[(2 * (ks) + lhi) * S_BN];
-#define S_MFMA(ks)                                                                                               \
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[ks], bv[ks], acc[0], 0, 0, 0);                         \
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[ks], bv[ks], acc[1], 0, 0, 0);
-        S_READ(0) S_READ(1)
-        __builtin_amdgcn_sched_barrier(0);
-        S_READ(2) S_MFMA(0) S_ISSUE_A(nb, cn, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        S_READ(3) S_MFMA(1) S_ISSUE_A(nb, cn, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        S_READ(4) S_MFMA(2) S_ISSUE_B(nb, cn);
-        __builtin_amdgcn_sched_barrier(0);
-        S_READ(5) S_MFMA(3)
-        __builtin_amdgcn_sched_barrier(0);
-        S_READ(6) S_MFMA(4)
-        __builtin_amdgcn_sched_barrier(0);
-        S_READ(7) S_MFMA(5)
-        __builtin_amdgcn_sched_barrier(0);
-        S_MFMA(6) S_MFMA(7)
-#undef S_READ
-#undef S_MFMA
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");    // chunk ch + 1 landed, the newest still in flight
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            cur = cur == 2 ? 0 : cur + 1;
         }
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");    // chunk ch + 1 landed, the newest still in flight
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        cur = cur == 2 ? 0 : cur + 1;
+    } else {
+        // The MFMA stream runs THROUGH the chunk boundary: the wait-for-landing + barrier of chunk ch + 1 sits in front of
+        // the last two k-steps of chunk ch, and the first two fragment reads of chunk ch + 1 are issued right behind
+        // it, so a wave reaches the barrier with its k-step-5 MFMAs executing and starts the next chunk with operands that
+        // were requested two MFMA pairs earlier.  Slot safety: at the barrier every wave has ISSUED all its reads of
+        // chunk ch; the first DMA into that slot is issued a chunk later and its data arrive later still.
+        //
+        // The fragment reads and their waits are written by hand: with LDS-DMA in a loop hipcc turns every wait for an
+        // LDS result into s_waitcnt lgkmcnt(0), i.e. each MFMA pair first drains the reads issued just in front of it
+        // (scripts/micro/small_gemm_timeline.hip: main loop 79 us -> 60 us with reads, DMA issue and barrier removed).
+        // LDS returns in order, so "k-step ks has arrived" is lgkmcnt(number of LDS instructions issued after it).
+        // A k-step is two instructions: ds_read2st64_b32 (rows arow0 and arow0 + 64 of k-row 2 ks + lhi) and ds_read_b32.
+        typedef float s_f32x2 __attribute__((ext_vector_type(2)));
+        s_f32x2 av[GEMM_KC / 2];
+        float bv[GEMM_KC / 2];
+        const unsigned lds0 = (unsigned)(size_t)(lds_fptr)lds;
+        const unsigned a_lane = lds0 + (unsigned)((lhi * S_BM + arow0 + l31) * 4);
+        const unsigned b_lane = lds0 + (unsigned)((S_ASTAGE + lhi * S_BN + wn * 32 + l31) * 4);
+#define S_READ_AT(ks, aaddr, baddr)                                                                              \
+        asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(av[ks]) : "v"(aaddr), "n"(4 * (ks)), "n"(4 * (ks) + 1)); \
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bv[ks]) : "v"(baddr), "n"(2 * (ks) * S_BN * 4));
+#define S_WAIT(n, ks) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(av[ks]), "+v"(bv[ks]));
+#define S_MFMA(ks)                                                                                               \
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks][0], bv[ks], acc[0], 0, 0, 0);                       \
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks][1], bv[ks], acc[1], 0, 0, 0);
+        S_READ_AT(0, a_lane, b_lane) S_READ_AT(1, a_lane, b_lane)
+        for (int ch = 0; ch < nch; ++ch) {
+            const int nxt = cur == 2 ? 0 : cur + 1;
+            const unsigned aa = a_lane + (unsigned)(cur * S_STAGE * 4), ba = b_lane + (unsigned)(cur * S_STAGE * 4);
+            const unsigned an = a_lane + (unsigned)(nxt * S_STAGE * 4), bn = b_lane + (unsigned)(nxt * S_STAGE * 4);
+            const int nb = cur >= 1 ? cur - 1 : 2;              // (cur + 2) % 3: the stage chunk ch - 1 occupied
+            const int cn = ch + 2 < nch ? ch + 2 : nch - 1;     // the last two iterations re-issue the final chunk
+            unsigned long long ub_next;                         // B address of chunk cn: one more in-order LDS read
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(ub_next) : "v"((unsigned)(lds0 + cn * 8)), "n"(S_CHTAB * 4));
+            // outstanding here: k-steps 0, 1 of this chunk (2 + 2) and the table entry (1)
+            S_READ_AT(2, aa, ba) S_WAIT(5, 0) S_MFMA(0) S_ISSUE_A(nb, cn, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            S_READ_AT(3, aa, ba) S_WAIT(5, 1) S_MFMA(1) S_ISSUE_A(nb, cn, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            S_READ_AT(4, aa, ba) S_WAIT(4, 2)                   // (covers the older table entry)
+            asm volatile("" : "+v"(ub_next));
+            S_MFMA(2) S_ISSUE_B_AT(nb, ub_next);
+            __builtin_amdgcn_sched_barrier(0);
+            S_READ_AT(5, aa, ba) S_WAIT(4, 3) S_MFMA(3)
+            __builtin_amdgcn_sched_barrier(0);
+            S_READ_AT(6, aa, ba) S_WAIT(4, 4) S_MFMA(4)
+            __builtin_amdgcn_sched_barrier(0);
+            S_READ_AT(7, aa, ba) S_WAIT(4, 5) S_MFMA(5)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");    // chunk ch + 1 landed, the newest still in flight
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            S_READ_AT(0, an, bn) S_READ_AT(1, an, bn)           // (past the last chunk: a re-issued copy, never used)
+            S_WAIT(6, 6) S_MFMA(6)
+            __builtin_amdgcn_sched_barrier(0);
+            S_WAIT(4, 7) S_MFMA(7)
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[0]), "+v"(bv[0]), "+v"(av[1]), "+v"(bv[1]));   // the two reads past the end
+#undef S_READ_AT
+#undef S_WAIT
+#undef S_MFMA
     }
 #undef S_ISSUE_A
 #undef S_ISSUE_B
+#undef S_ISSUE_B_AT
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the re-issued tail DMAs still target LDS
     __builtin_amdgcn_s_barrier();
+    S_STAMP(3);
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     if (t < S_BM) lds[t] = a.bias[mb * 256 + 128 * half + t];
@@ -267,6 +381,7 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
 #pragma unroll
                 for (int r = 0; r < 16; ++r) add0[r] = add1[r] = 0.0f;
             }
+            S_STAMP_DRAIN(4);
             if constexpr (EPI == GEMM_EPI_GATEX) {
 #define S_GATEX_LOOP(K)                                                                                           \
                 case K:                                                                                           \
@@ -301,24 +416,17 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
         // rows < split -> dst0 (= src0 + v when acc0), rows >= split -> dst1[row - split] (+= when acc1)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            const int rbase = mb * 256 + 128 * half + 64 * wm + 32 * mt;     // uniform per tile
+            const int rbase = mb * 256 + 128 * half + 32 * wm + 64 * mt;     // uniform per tile
             if (rbase >= a.M) continue;
             const bool second = rbase >= a.split;
             float* dst = second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride;
-            const float* src = second ? dst : (a.src0 ? a.src0 + (size_t)b * a.src0_bstride : dst);
-            const int accum = second ? a.acc1 : a.acc0;
             const int rdst = second ? rbase - a.split : rbase;
             if (n < a.L) {
-                float old[16];
+                if (mt == 1) { S_STAMP_DRAIN(4); }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    old[r] = (accum && rbase + row < a.M) ? src[(size_t)(rdst + row) * a.dst_ld + a.dst_pad + n] : 0.0f;
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    float v = acc[mt][r] + lds[64 * wm + 32 * mt + row] + old[r];
+                    float v = acc[mt][r] + lds[32 * wm + 64 * mt + row] + old[mt][r];
                     if constexpr (EPI == GEMM_EPI_LOG) v = logf(fmaxf(v, a.clip));
                     if constexpr (EPI == GEMM_EPI_LRELU) v = v > 0.f ? v : a.clip * v;
                     if constexpr (EPI == GEMM_EPI_TANH) v = tanhf(v);
@@ -327,6 +435,7 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
             }
         }
     }
+    S_STAMP_DRAIN(5);
 }
 
 

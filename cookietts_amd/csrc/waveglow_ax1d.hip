@@ -8,13 +8,16 @@
 // the reference concatenates them back (ax:310-316, 340-341), so "cat" is a change of ch_off.
 //
 // Per flow, in the reference's inverse order:
-//   [un-mix]      (mix_first=False: ax:324-325)              ax_mix_kernel, in place on the latent rows
-//   start 1x1                                                  ax_start_kernel
+//   [un-mix]      (mix_first=False: ax:324-325)              \
+//   start 1x1     (glow_ax.py:376)                             } second half of ax_boundary_kernel
 //   conditioning  frame-rate rows, linearly interpolated       inside the GATE epilogue (glow_ax.py:362-373, 389-390)
 //   n_layers x (dilated conv + cond + gate | res/skip 1x1)    conv_gemm_f32<GATE> with the conditioning as
 //                                                             interpolated epilogue addend, conv_gemm_f32<SPLIT>
-//   end 1x1                                                    conv_gemm_f32<SPLIT>, M = 2*n_half
-//   coupling inverse, NaN -> 0, [un-mix if mix_first]          ax_couple_kernel (em:100-104, ax:333-337)
+//   end 1x1       (2*n_half <= 32 rows: not a GEMM-shaped job) \
+//   coupling inverse, NaN -> 0, [un-mix if mix_first]          } first half of ax_boundary_kernel (em:100-104, ax:333-337)
+// Everything between the last res/skip GEMM of flow k and the first in-layer GEMM of flow k - 1 works on the <= 32
+// latent rows of one time step, so it is ONE launch per flow boundary (was: a 256-row GEMM block for <= 32 `end` rows +
+// three elementwise launches = 58 us of the 1.1 ms a notebook-config flow takes at batch 1).
 // `output` starts from the first layer's skip (glow_ax.py:405-410): 0 + r == r exactly, so the SPLIT epilogue's
 // "store on layer 0, accumulate afterwards" is bit-identical.
 #include <algorithm>
@@ -35,10 +38,10 @@ struct AxFlowDims { int n_rem, n_half, ch_off; };
 
 struct AxPlan {
     ctts_wgax_config c;
-    int C, nch_in, nch_c, mb_in, mb_end;
+    int C, nch_in, nch_c, mb_in;
     std::vector<AxFlowDims> fd;
     struct Flow {
-        size_t start_w, start_b, end_A, end_b, winv;
+        size_t start_w, start_b, end_w, end_b, winv;
         std::vector<size_t> in_A, in_b, rs_A, rs_b;
     };
     std::vector<Flow> fl;
@@ -68,7 +71,6 @@ int make_ax_plan(const ctts_wgax_config* cfg, AxPlan& p) {
     p.nch_c = p.C / GEMM_KC;
     p.nch_in = c.kernel_size * p.nch_c;
     p.mb_in = (2 * p.C + GEMM_BM - 1) / GEMM_BM;
-    p.mb_end = 1;
     int n_rem = c.n_group;
     p.fd.resize(c.n_flows);
     for (int k = 0; k < c.n_flows; ++k) {                       // ax:170-189
@@ -84,8 +86,8 @@ int make_ax_plan(const ctts_wgax_config* cfg, AxPlan& p) {
         const auto& d = p.fd[k];
         f.start_w = take((size_t)p.C * d.n_half);
         f.start_b = take(p.C);
-        f.end_A = take((size_t)p.mb_end * p.nch_c * A_TILE);
-        f.end_b = take((size_t)p.mb_end * GEMM_BM);
+        f.end_w = take((size_t)2 * d.n_half * p.C);             // dense [2h][C], read by ax_boundary_kernel
+        f.end_b = take((size_t)2 * d.n_half);
         f.winv = take((size_t)d.n_rem * d.n_rem);
         for (int i = 0; i < c.n_layers; ++i) {
             f.in_A.push_back(take((size_t)p.mb_in * p.nch_in * A_TILE));
@@ -112,18 +114,16 @@ int make_ax_geom(const AxPlan& p, long long samples, AxGeom& g) {
     return CTTS_OK;
 }
 
-struct AxWs { float *audio, *x, *act, *out, *e; size_t total; int e_rows; };
+struct AxWs { float *audio, *x, *act, *out; size_t total; };
 
 void ax_carve(const AxPlan& p, const AxGeom& g, int batch, float* base, AxWs& w) {
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o = align_up(o + n); return base ? base + r : nullptr; };
     const size_t B = batch;
-    w.e_rows = p.c.n_group;                                   // 2*n_half <= n_group
     w.audio = take(B * p.c.n_group * g.ld);
     w.x = take(B * p.C * g.ld);
     w.act = take(B * p.C * g.ld);
     w.out = take(B * p.C * g.ld);
-    w.e = take(B * w.e_rows * g.ld);
     w.total = o;
 }
 
@@ -138,8 +138,6 @@ void ax_permutation(int k, int n, int* perm) {
         for (int i = 0; i < n; ++i) perm[i] = n - 1 - i;
     }
 }
-
-struct AxPerm { int src[AX_MAX_GROUP]; };
 
 // audio rows [b][g][pad + l] = z[b][G*l + g]   (ax:310); halo and tail columns are left untouched (zero)
 __global__ __launch_bounds__(256) void ax_squeeze_kernel(const float* __restrict__ z, float* __restrict__ audio, int G, int L,
@@ -163,106 +161,203 @@ __global__ __launch_bounds__(256) void ax_unsqueeze_kernel(const float* __restri
     for (int g = 0; g < G; ++g) wb[g] = ab[(size_t)g * ld];
 }
 
-// One thread owns one time step of the n latent rows (n <= 64), held in LDS column `tid` (conflict-free).
-//   PERMUTE: out[i] = in[src[i]]                                     (efficient_modules.py:360-373)
-//   CONV1X1: out[i] = sum_j Winv[i][j] * in[j], j ascending with fma  (em:283: F.conv1d with W^-1)
-__device__ inline void ax_mix_column(const float* col, int n, int mixing, const int* sP, const float* sW, float* dst,
-                                     size_t dst_stride) {
-    if (mixing == CTTS_MIX_PERMUTE) {
-        for (int i = 0; i < n; ++i) dst[(size_t)i * dst_stride] = col[sP[i] * 256];
-    } else {
-        for (int i = 0; i < n; ++i) {
-            float s = 0.f;
-            for (int j = 0; j < n; ++j) s = fmaf(sW[i * n + j], col[j * 256], s);
-            dst[(size_t)i * dst_stride] = s;
+// ---- the flow boundary: end 1x1 + coupling inverse (+ un-mix) of flow k, (un-mix +) start 1x1 of flow k - 1 -----------
+// A workgroup owns 64 time steps and keeps their G <= 32 latent rows in LDS from the first load to the last store; 8
+// waves.  At batch 1 a launch is ~180 workgroups, one per CU: what matters is the number of DEPENDENT memory round trips,
+// so both small contractions are laid out for "issue every load, wait once":
+//   end      e[r] = be[r] + sum_c We[r][c] * out[c]     (<= 32 rows x C) as v_mfma_f32_32x32x2_f32 over (32 rows) x (2 x
+//            32 time steps): the waves split C in chunks of 32 channels, fragments straight from global memory (16 + 32
+//            independent loads per chunk), partial tiles meet in LDS
+//   couple   (log_s, t) = (e[:h], e[h:]);  a1 = (a1 - t) / exp(log_s)   (efficient_modules.py:100-103; note the order,
+//            glow.py has (b, log_s));  NaN -> 0 on the flow's latent rows (ax:13-16, 333-334)
+//   mix      PERMUTE: out[i] = in[src[i]] (em:360-373);  CONV1X1: out[i] = sum_j Winv[i][j] * in[j], j ascending with
+//            fma (em:283: F.conv1d with W^-1) - after the coupling when mix_first, before `start` otherwise
+//   start    x[c] = bs[c] + sum_{j < h'} Ws[c][j] * a[ch_off' + j]   (glow_ax.py:376): C rows x (K = h' <= 16) on the same
+//            MFMA, a wave per 32 channels, B fragments from the LDS rows, accumulators initialised with the bias
+struct AxPerm { int src[AX_MAX_GROUP]; };
+
+struct AxBoundary {
+    float* audio;               // [B][G][ld]
+    int G, C, L, ld, pad, mixing, ignore_nan;
+    // flow k just finished its layers (do_couple)
+    int do_couple, ch_off, h, mix_after;
+    const float* out;           // [B][C][ld] skip sum
+    const float *end_w, *end_b; // [2h][C], [2h]
+    const float* winv;          // [2h][2h] (CONV1X1 and mix_after)
+    AxPerm perm;
+    // flow k - 1 starts (do_start)
+    int do_start, s_ch_off, s_h, mix_before;
+    const float* s_winv;
+    AxPerm s_perm;
+    const float *start_w, *start_b;   // [C][h'], [C]
+    float* x;                   // [B][C][ld]
+};
+
+typedef float axb_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int AXB_COLS = 64;
+constexpr int AXB_ROWS = AX_MAX_GROUP;
+constexpr int AXB_WAVES = 8;
+constexpr int AXB_THREADS = 64 * AXB_WAVES;
+// LDS floats: latent rows | 4 partial e tiles | e rows | mix scratch | one mixing matrix | one permutation
+constexpr int AXB_TILE = AXB_ROWS * AXB_COLS;
+constexpr int AXB_LDS_FLOATS = AXB_TILE + 4 * AXB_TILE + AXB_TILE + AXB_TILE + AXB_ROWS * AXB_ROWS + AXB_ROWS;
+static_assert(AXB_LDS_FLOATS * sizeof(float) <= 64 * 1024, "ax_boundary_kernel: static LDS");
+
+// rows [off, off + n) of sa <- mix(rows [off, off + n) of sa), through sb; every thread calls it
+__device__ __forceinline__ void axb_mix(float* sa, float* sb, float* sW, int* sP, const float* __restrict__ Winv,
+                                        const AxPerm& perm, int mixing, int off, int n, int lane, int wave) {
+    const int t = wave * 64 + lane;
+    __syncthreads();                                        // previous users of sW / sP / sb are done, sa is complete
+    if (mixing == CTTS_MIX_CONV1X1) {
+        for (int i = t; i < n * n; i += AXB_THREADS) sW[i] = Winv[i];
+    } else if (t < AX_MAX_GROUP) {
+        int v = 0;
+#pragma unroll
+        for (int q = 0; q < AX_MAX_GROUP; ++q) v = (t == q) ? perm.src[q] : v;   // a kernarg array indexed at run time would go to scratch
+        sP[t] = v;
+    }
+    __syncthreads();
+    for (int i = wave; i < n; i += AXB_WAVES) {
+        float v;
+        if (mixing == CTTS_MIX_PERMUTE) {
+            v = sa[(off + sP[i]) * AXB_COLS + lane];
+        } else {
+            v = 0.f;
+            for (int j = 0; j < n; ++j) v = fmaf(sW[i * n + j], sa[(off + j) * AXB_COLS + lane], v);
         }
-    }
-}
-
-__global__ __launch_bounds__(256) void ax_mix_kernel(float* __restrict__ audio, const float* __restrict__ Winv, AxPerm perm,
-                                                     int mixing, int G, int ch_off, int n, int L, int ld, int pad) {
-    extern __shared__ float smem[];
-    float* sW = smem;                       // [n*n] (CONV1X1)
-    float* sa = smem + n * n;               // [n][256]
-    int* sP = reinterpret_cast<int*>(sa + n * 256);   // [n]  (a kernarg array indexed at run time would go to scratch)
-    if (mixing == CTTS_MIX_CONV1X1)
-        for (int i = threadIdx.x; i < n * n; i += 256) sW[i] = Winv[i];
-    if (threadIdx.x < AX_MAX_GROUP) {
-        int v = 0;
-#pragma unroll
-        for (int q = 0; q < AX_MAX_GROUP; ++q) v = (threadIdx.x == q) ? perm.src[q] : v;
-        if ((int)threadIdx.x < n) sP[threadIdx.x] = v;
+        sb[i * AXB_COLS + lane] = v;
     }
     __syncthreads();
-    const int l = blockIdx.x * 256 + threadIdx.x;
+    for (int i = wave; i < n; i += AXB_WAVES) sa[(off + i) * AXB_COLS + lane] = sb[i * AXB_COLS + lane];
+}
+
+__global__ __launch_bounds__(AXB_THREADS) void ax_boundary_kernel(const AxBoundary p) {
+    __shared__ float smem[AXB_LDS_FLOATS];
+    float* sa = smem;                                   // [G][64]  latent rows of this tile
+    float* red = sa + AXB_TILE;                         // [4][32][64] partial e tiles (waves w and w + 4 share slot w)
+    float* se = red + 4 * AXB_TILE;                     // [32][64] e rows
+    float* sb = se + AXB_TILE;                          // [32][64] mix scratch
+    float* sW = sb + AXB_TILE;                          // [32 * 32]
+    int* sP = reinterpret_cast<int*>(sW + AXB_ROWS * AXB_ROWS);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int l0 = blockIdx.x * AXB_COLS;
     const int b = blockIdx.y;
-    if (l >= L) return;
-    float* ab = audio + ((size_t)b * G + ch_off) * ld + pad + l;
-    float* col = sa + threadIdx.x;
-    for (int j = 0; j < n; ++j) col[j * 256] = ab[(size_t)j * ld];
-    ax_mix_column(col, n, mixing, sP, sW, ab, (size_t)ld);
-}
+    const int G = p.G, C = p.C;
+    const int l = l0 + lane;
+    const bool valid = l < p.L;
+    float* ab = p.audio + (size_t)b * G * p.ld + p.pad;
+    int first_dirty = G;                                 // rows >= first_dirty go back to HBM
 
-// x[b][c][pad + l] = bs[c] + sum_{j < h} Ws[c][j] * audio[b][ch_off + j][pad + l]   (glow_ax.py:376 `start`)
-// grid (L/256, C/8, B): a thread keeps 8 channels of one time step; the h input rows are re-read per channel group
-// (h*4 bytes per step, L2-resident) - the stage is bound by the C*4 bytes per step it writes.
-__global__ __launch_bounds__(256) void ax_start_kernel(const float* __restrict__ audio, const float* __restrict__ Ws,
-                                                       const float* __restrict__ bs, float* __restrict__ x, int C, int G,
-                                                       int ch_off, int h, int L, int ld, int pad) {
-    const int l = blockIdx.x * 256 + threadIdx.x;
-    const int c0 = blockIdx.y * 8, b = blockIdx.z;
-    if (l >= L) return;
-    float acc[8];
+    // loads of a ragged last tile re-read the last valid time step
+    for (int g = wave; g < G; g += AXB_WAVES) sa[g * AXB_COLS + lane] = ab[(size_t)g * p.ld + min(l, p.L - 1)];
+
+    if (p.do_couple) {
+        const int h = p.h, n = 2 * h;
+        axb_f32x16 acc[2];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = bs[c0 + q];
-    const float* ab = audio + ((size_t)b * G + ch_off) * ld + pad + l;
-    for (int j = 0; j < h; ++j) {
-        const float a = ab[(size_t)j * ld];
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] = fmaf(Ws[(c0 + q) * h + j], a, acc[q]);
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        const float* ob = p.out + (size_t)b * C * p.ld + p.pad;
+        const int col0 = min(l0 + l31, p.L - 1), col1 = min(l0 + 32 + l31, p.L - 1);
+        const float* wrow = p.end_w + (size_t)min(l31, n - 1) * C + lhi;
+        const float wmask = l31 < n ? 1.f : 0.f;         // rows >= n of the 32-row tile: zero weights
+        for (int q = wave; q < C / 32; q += AXB_WAVES) {
+            float av[16], b0[16], b1[16];
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                av[ks] = wrow[q * 32 + 2 * ks];
+                const float* orow = ob + (size_t)(q * 32 + 2 * ks + lhi) * p.ld;
+                b0[ks] = orow[col0];
+                b1[ks] = orow[col1];
+            }
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks] * wmask, b0[ks], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks] * wmask, b1[ks], acc[1], 0, 0, 0);
+            }
+        }
+        // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+        float* slot = red + (wave & 3) * AXB_TILE;
+        if (wave < 4) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    slot[((r & 3) + 8 * (r >> 2) + 4 * lhi) * AXB_COLS + nt * 32 + l31] = acc[nt][r];
+        }
+        __syncthreads();
+        if (wave >= 4) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    slot[((r & 3) + 8 * (r >> 2) + 4 * lhi) * AXB_COLS + nt * 32 + l31] += acc[nt][r];
+        }
+        __syncthreads();
+        for (int r = wave; r < n; r += AXB_WAVES) {
+            const float* q = red + r * AXB_COLS + lane;
+            se[r * AXB_COLS + lane] = p.end_b[r] + ((q[0] + q[AXB_TILE]) + (q[2 * AXB_TILE] + q[3 * AXB_TILE]));
+        }
+        __syncthreads();
+        for (int j = wave; j < h; j += AXB_WAVES) {
+            float a0 = sa[(p.ch_off + j) * AXB_COLS + lane];
+            float a1 = (sa[(p.ch_off + h + j) * AXB_COLS + lane] - se[(h + j) * AXB_COLS + lane]) / expf(se[j * AXB_COLS + lane]);
+            if (p.ignore_nan) { a0 = (a0 != a0) ? 0.f : a0; a1 = (a1 != a1) ? 0.f : a1; }
+            sa[(p.ch_off + j) * AXB_COLS + lane] = a0;
+            sa[(p.ch_off + h + j) * AXB_COLS + lane] = a1;
+        }
+        if (p.mix_after) axb_mix(sa, sb, sW, sP, p.winv, p.perm, p.mixing, p.ch_off, n, lane, wave);
+        first_dirty = p.ch_off;
     }
-    float* xb = x + ((size_t)b * C + c0) * ld + pad + l;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) xb[(size_t)q * ld] = acc[q];
-}
-
-// (log_s, t) = (e[:h], e[h:]);  a1 = (a1 - t) / exp(log_s)   (efficient_modules.py:100-103; note the order,
-// glow.py has (b, log_s));  NaN -> 0 on the whole latent (ax:13-16, 333-334);  then, for mix_first, the un-mix.
-__global__ __launch_bounds__(256) void ax_couple_kernel(float* __restrict__ audio, const float* __restrict__ e,
-                                                        const float* __restrict__ Winv, AxPerm perm, int mixing,
-                                                        int mix_here, int ignore_nan, int G, int e_rows, int ch_off, int h,
-                                                        int L, int ld, int pad) {
-    extern __shared__ float smem[];
-    const int n = 2 * h;
-    float* sW = smem;
-    float* sa = smem + n * n;
-    int* sP = reinterpret_cast<int*>(sa + n * 256);
-    if (mix_here && mixing == CTTS_MIX_CONV1X1)
-        for (int i = threadIdx.x; i < n * n; i += 256) sW[i] = Winv[i];
-    if (threadIdx.x < AX_MAX_GROUP) {
-        int v = 0;
-#pragma unroll
-        for (int q = 0; q < AX_MAX_GROUP; ++q) v = (threadIdx.x == q) ? perm.src[q] : v;
-        if ((int)threadIdx.x < n) sP[threadIdx.x] = v;
+    if (p.do_start && p.mix_before) {
+        axb_mix(sa, sb, sW, sP, p.s_winv, p.s_perm, p.mixing, p.s_ch_off, 2 * p.s_h, lane, wave);
+        first_dirty = min(first_dirty, p.s_ch_off);
     }
     __syncthreads();
-    const int l = blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y;
-    if (l >= L) return;
-    float* ab = audio + ((size_t)b * G + ch_off) * ld + pad + l;
-    const float* eb = e + (size_t)b * e_rows * ld + pad + l;
-    float* col = sa + threadIdx.x;
-    for (int j = 0; j < h; ++j) {
-        float a0 = ab[(size_t)j * ld];
-        float a1 = (ab[(size_t)(h + j) * ld] - eb[(size_t)(h + j) * ld]) / expf(eb[(size_t)j * ld]);
-        if (ignore_nan) { a0 = (a0 != a0) ? 0.f : a0; a1 = (a1 != a1) ? 0.f : a1; }
-        col[j * 256] = a0;
-        col[(h + j) * 256] = a1;
-    }
-    if (mix_here) {
-        ax_mix_column(col, n, mixing, sP, sW, ab, (size_t)ld);
-    } else {
-        for (int j = 0; j < n; ++j) ab[(size_t)j * ld] = col[j * 256];
+    if (valid)
+        for (int g = first_dirty + wave; g < G; g += AXB_WAVES) ab[(size_t)g * p.ld + l] = sa[g * AXB_COLS + lane];
+    if (p.do_start) {
+        const int hs = p.s_h;
+        float* xb = p.x + (size_t)b * C * p.ld + p.pad;
+        // B fragments of the K = 16 (h' zero-padded) contraction: the same for every 32-channel tile of this wave
+        float b0[8], b1[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int j = 2 * ks + lhi;
+            const float* arow = sa + (p.s_ch_off + min(j, hs - 1)) * AXB_COLS;
+            b0[ks] = j < hs ? arow[l31] : 0.f;
+            b1[ks] = j < hs ? arow[32 + l31] : 0.f;
+        }
+        for (int m = wave; m < C / 32; m += AXB_WAVES) {
+            const int c0 = 32 * m;
+            float av[8];
+            const float* wrow = p.start_w + (size_t)(c0 + l31) * hs;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int j = 2 * ks + lhi;
+                av[ks] = j < hs ? wrow[j] : 0.f;
+            }
+            axb_f32x16 acc[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = p.start_b[c0 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], b0[ks], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], b1[ks], acc[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int col = l0 + nt * 32 + l31;
+                if (col < p.L) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        xb[(size_t)(c0 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * p.ld + col] = acc[nt][r];
+                }
+            }
+        }
     }
 }
 
@@ -272,8 +367,6 @@ __global__ __launch_bounds__(64) void replicate_halo_kernel(float* __restrict__ 
     const int i = threadIdx.x;
     if (i < halo) { row[-1 - i] = row[0]; row[T + i] = row[T - 1]; }
 }
-
-size_t mix_smem(int n) { return ((size_t)n * n + (size_t)n * 256 + (size_t)n) * sizeof(float); }
 
 }  // namespace
 }  // namespace ctts
@@ -309,11 +402,8 @@ int ctts_wgax_pack_flow(const ctts_wgax_config* cfg, int32_t k, const ctts_wgax_
         if ((rc = d2d(f.winv, w->w_inverse, (size_t)d.n_rem * d.n_rem))) return rc;
     }
     CTTS_CHECK_ARG(w->end_w && w->end_b && w->in_w && w->in_b && w->rs_w && w->rs_b, "wgax pack_flow: NULL weights");
-    // end: dense [2h][C] -> one 256-row M-block, rows >= 2h zero
-    if ((rc = launch_pack_a(blob + f.end_A, w->end_w, GEMM_BM, p.mb_end, p.nch_c, 0, C, GEMM_EPI_SPLIT, C, 2 * d.n_half, 0,
-                            C, 1, s))) return rc;
-    if ((rc = launch_pack_bias(blob + f.end_b, GEMM_BM, p.mb_end, w->end_b, 0, nullptr, 0, GEMM_EPI_SPLIT, C,
-                               2 * d.n_half, s))) return rc;
+    if ((rc = d2d(f.end_w, w->end_w, (size_t)2 * d.n_half * C))) return rc;      // dense [2h][C] as it is
+    if ((rc = d2d(f.end_b, w->end_b, (size_t)2 * d.n_half))) return rc;
     for (int i = 0; i < p.c.n_layers; ++i) {
         CTTS_CHECK_ARG(w->in_w[i] && w->in_b[i] && w->rs_w[i] && w->rs_b[i], "wgax pack_flow: NULL layer %d weights", i);
         // K = [per 16-channel slab: tap 0 .. tap ks-1];  in_w[i] is [2C][C][ks]
@@ -378,19 +468,32 @@ int ctts_wgax_inverse_f32(const ctts_wgax_config* cfg, const void* packed, const
         a.gemm_mode = p.c.f32_gemm_mode;
         return a;
     };
+    // one launch per flow boundary: end + coupling (+ un-mix) of flow `done`, (un-mix +) start of flow `next`; -1 = none
+    auto boundary = [&](int done, int next) -> int {
+        AxBoundary q{};
+        q.audio = w.audio; q.G = G; q.C = C; q.L = L; q.ld = g.ld; q.pad = g.pad;
+        q.mixing = p.c.mixing; q.ignore_nan = p.c.ignore_nan ? 1 : 0;
+        if (done >= 0) {
+            const auto& f = p.fl[done];
+            const auto& d = p.fd[done];
+            q.do_couple = 1; q.ch_off = d.ch_off; q.h = d.n_half; q.mix_after = p.c.mix_first ? 1 : 0;
+            q.out = w.out; q.end_w = blob + f.end_w; q.end_b = blob + f.end_b; q.winv = blob + f.winv;
+            if (p.c.mixing == CTTS_MIX_PERMUTE) ax_permutation(done, d.n_rem, q.perm.src);
+        }
+        if (next >= 0) {
+            const auto& f = p.fl[next];
+            const auto& d = p.fd[next];
+            q.do_start = 1; q.s_ch_off = d.ch_off; q.s_h = d.n_half; q.mix_before = p.c.mix_first ? 0 : 1;   // ax:324-325
+            q.s_winv = blob + f.winv; q.start_w = blob + f.start_w; q.start_b = blob + f.start_b; q.x = w.x;
+            if (p.c.mixing == CTTS_MIX_PERMUTE) ax_permutation(next, d.n_rem, q.s_perm.src);
+        }
+        hipLaunchKernelGGL(ax_boundary_kernel, dim3((L + AXB_COLS - 1) / AXB_COLS, batch), dim3(AXB_THREADS), 0, s, q);
+        CTTS_CHECK_LAUNCH("ax_boundary");
+        return CTTS_OK;
+    };
+    if ((rc = boundary(-1, p.c.n_flows - 1))) return rc;
     for (int k = p.c.n_flows - 1; k >= 0; --k) {
         const auto& f = p.fl[k];
-        const auto& d = p.fd[k];
-        AxPerm perm{};
-        if (p.c.mixing == CTTS_MIX_PERMUTE) ax_permutation(k, d.n_rem, perm.src);
-        if (!p.c.mix_first) {                                                   // ax:324-325
-            hipLaunchKernelGGL(ax_mix_kernel, lgrid, dim3(256), mix_smem(d.n_rem), s, w.audio, blob + f.winv, perm,
-                               p.c.mixing, G, d.ch_off, d.n_rem, L, g.ld, g.pad);
-            CTTS_CHECK_LAUNCH("ax_mix");
-        }
-        hipLaunchKernelGGL(ax_start_kernel, dim3((L + 255) / 256, C / 8, batch), dim3(256), 0, s, w.audio, blob + f.start_w,
-                           blob + f.start_b, w.x, C, G, d.ch_off, d.n_half, L, g.ld, g.pad);
-        CTTS_CHECK_LAUNCH("ax_start");
         const float* fr = cond + (size_t)k * batch * 2 * C * nl * cond_ld;
         for (int i = 0; i < nl; ++i) {
             const int dil = p.c.dilation_w[i] > 0 ? p.c.dilation_w[i] : 1 << i;
@@ -424,21 +527,7 @@ int ctts_wgax_inverse_f32(const ctts_wgax_config* cfg, const void* packed, const
                 if ((rc = launch_gemm_f32(GEMM_EPI_SPLIT, a, s))) return rc;
             }
         }
-        {   // end 1x1: out [C] -> e [2h] (rows >= 2h of the M-block are padding, never stored)
-            GemmArgs a = base_args();
-            a.A = blob + f.end_A; a.bias = blob + f.end_b;
-            a.nseg = 1; a.nch_total = p.nch_c; a.MB = p.mb_end;
-            a.seg[0] = {w.out, cstride, p.nch_c, 0, 0, 0};
-            a.M = 2 * d.n_half;
-            a.dst0 = w.e; a.dst0_bstride = (long long)w.e_rows * g.ld;
-            a.dst1 = w.e; a.dst1_bstride = (long long)w.e_rows * g.ld;
-            a.split = 0;
-            if ((rc = launch_gemm_f32(GEMM_EPI_SPLIT, a, s))) return rc;
-        }
-        hipLaunchKernelGGL(ax_couple_kernel, lgrid, dim3(256), mix_smem(d.n_rem), s, w.audio, w.e, blob + f.winv, perm,
-                           p.c.mixing, p.c.mix_first ? 1 : 0, p.c.ignore_nan ? 1 : 0, G, w.e_rows, d.ch_off, d.n_half, L,
-                           g.ld, g.pad);
-        CTTS_CHECK_LAUNCH("ax_couple");
+        if ((rc = boundary(k, k - 1))) return rc;
     }
     hipLaunchKernelGGL(ax_unsqueeze_kernel, lgrid, dim3(256), 0, s, w.audio, audio, G, L, g.ld, g.pad);
     CTTS_CHECK_LAUNCH("ax_unsqueeze");
