@@ -2,8 +2,8 @@
 // GATE epilogue), the product kernel of cookietts_amd/csrc/gemm_f32.hip compiled into this file, timed with HIP events
 // over 24 launches on rotating weights - the product loop, without the rest of the model around it.  Round 3 used it with
 // temporary patches of the main loop to bound what each ingredient costs (profiles/r3_15_headline_gemm_experiments.txt):
-// per-launch 6.20 ms as shipped; LDS-DMA issue removed 5.86; fragment reads removed 6.19; barrier removed 6.16; all
-// three removed 5.78 ms (0.93 of the fp32 MFMA peak).  A DMA instruction costs the same with 4-byte lanes, with one M0
+// per launch 6.20 ms as shipped (6.28 with the hand-scheduled variant the other figures build on); LDS-DMA issue removed
+// 5.86; fragment reads removed 6.26; barrier removed 6.33; all three removed 5.78 ms (0.93 of the fp32 MFMA peak).  A DMA instruction costs the same with 4-byte lanes, with one M0
 // value for all pieces, as buffer_load ... lds, and without the vmcnt wait: it is the ISSUE of the six LDS-DMA
 // instructions per wave and chunk (~55 matrix-pipe cycles each) that the loop pays, not their data path.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I cookietts_amd/csrc scripts/micro/headline_gemm.hip -o /tmp/headline_gemm
