@@ -543,44 +543,74 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_f32_gate_rs_small_kernel(con
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
+    // Same hand-scheduled loop as conv_gemm_f32_small_kernel (counted LDS waits, MFMA stream through the chunk boundary);
+    // here a k-step is three LDS instructions (row tiles 0|2 and 1|3 by ds_read2st64_b32, one B value) and four MFMAs, and
+    // a launch at batch 1 has ONE wave per SIMD, so nothing else hides an exposed LDS round trip.
+    typedef float r_f32x2 __attribute__((ext_vector_type(2)));
+    r_f32x2 a02[2], a13[2];
+    float bq[2];
+    const unsigned lds0 = (unsigned)(size_t)(lds_fptr)lds;
+    const unsigned a_lane = lds0 + (unsigned)((lhi * S_BM + l31) * 4);
+    const unsigned b_lane = lds0 + (unsigned)((S_ASTAGE + lhi * R_BN + wn * 32 + l31) * 4);
+#define R_READ_AT(ks, aaddr, baddr)                                                                              \
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(a02[(ks) & 1]) : "v"(aaddr), "n"(4 * (ks)), "n"(4 * (ks) + 1)); \
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(a13[(ks) & 1]) : "v"((aaddr) + 128u), "n"(4 * (ks)), "n"(4 * (ks) + 1)); \
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bq[(ks) & 1]) : "v"(baddr), "n"(2 * (ks) * R_BN * 4));
+#define R_WAIT(n, ks) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a02[(ks) & 1]), "+v"(a13[(ks) & 1]), "+v"(bq[(ks) & 1]));
+#define R_MFMA(ks)                                                                                               \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a02[(ks) & 1][0], bq[(ks) & 1], acc[0], 0, 0, 0);               \
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a13[(ks) & 1][0], bq[(ks) & 1], acc[1], 0, 0, 0);               \
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a02[(ks) & 1][1], bq[(ks) & 1], acc[2], 0, 0, 0);               \
+    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a13[(ks) & 1][1], bq[(ks) & 1], acc[3], 0, 0, 0);
+#define R_ISSUE_B_AT(buf, ub, p)                                                                                 \
+    do {                                                                                                         \
+        const unsigned long long ub_ = (ub);                                                                     \
+        const unsigned long long us_ =                                                                           \
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |             \
+            (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                                  \
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off + (p) * b_piece,              \
+                                         (lds_fptr)(lds + (buf) * R_STAGE + S_ASTAGE + wave * 256 + (p) * 1024), 16, 0, 0); \
+    } while (0)
+    R_READ_AT(0, a_lane, b_lane)
     int cur = 0;
     for (int ch = 0; ch < nch; ++ch) {
-        const float* As = lds + cur * R_STAGE + l31;
-        const float* Bs = lds + cur * R_STAGE + S_ASTAGE + wn * 32 + l31;
+        const int nxt = cur == 2 ? 0 : cur + 1;
+        const unsigned aa = a_lane + (unsigned)(cur * R_STAGE * 4), ba = b_lane + (unsigned)(cur * R_STAGE * 4);
+        const unsigned an = a_lane + (unsigned)(nxt * R_STAGE * 4), bn = b_lane + (unsigned)(nxt * R_STAGE * 4);
         const int nb = cur >= 1 ? cur - 1 : 2;
         const int cn = ch + 2 < nch ? ch + 2 : nch - 1;
-        float av[GEMM_KC / 2][4], bv[GEMM_KC / 2];
-#define R_READ(ks)                                                                                               \
-        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) av[ks][mt] = As[(2 * (ks) + lhi) * S_BM + mt * 32];      \
-        bv[ks] = Bs[(2 * (ks) + lhi) * R_BN];
-#define R_MFMA(ks)                                                                                               \
-        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                         \
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks][mt], bv[ks], acc[mt], 0, 0, 0);
-        R_READ(0)
+        unsigned long long ub_next;
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(ub_next) : "v"((unsigned)(lds0 + cn * 8)), "n"(R_CHTAB * 4));
+        // outstanding: k-step 0 (3 instructions) and the table entry (1)
+        R_READ_AT(1, aa, ba) R_WAIT(4, 0) R_MFMA(0) R_ISSUE_A(nb, cn, 0);
         __builtin_amdgcn_sched_barrier(0);
-        R_READ(1) R_MFMA(0) R_ISSUE_A(nb, cn, 0);
+        R_READ_AT(2, aa, ba) R_WAIT(3, 1)                   // (covers the older table entry)
+        asm volatile("" : "+v"(ub_next));
+        R_MFMA(1) R_ISSUE_A(nb, cn, 1);
         __builtin_amdgcn_sched_barrier(0);
-        R_READ(2) R_MFMA(1) R_ISSUE_A(nb, cn, 1);
+        R_READ_AT(3, aa, ba) R_WAIT(3, 2) R_MFMA(2) R_ISSUE_B_AT(nb, ub_next, 0);
         __builtin_amdgcn_sched_barrier(0);
-        R_READ(3) R_MFMA(2) R_ISSUE_B(nb, cn, 0);
+        R_READ_AT(4, aa, ba) R_WAIT(3, 3) R_MFMA(3) R_ISSUE_B_AT(nb, ub_next, 1);
         __builtin_amdgcn_sched_barrier(0);
-        R_READ(4) R_MFMA(3) R_ISSUE_B(nb, cn, 1);
+        R_READ_AT(5, aa, ba) R_WAIT(3, 4) R_MFMA(4)
         __builtin_amdgcn_sched_barrier(0);
-        R_READ(5) R_MFMA(4)
+        R_READ_AT(6, aa, ba) R_WAIT(3, 5) R_MFMA(5)
         __builtin_amdgcn_sched_barrier(0);
-        R_READ(6) R_MFMA(5)
+        R_READ_AT(7, aa, ba) R_WAIT(3, 6) R_MFMA(6)
         __builtin_amdgcn_sched_barrier(0);
-        R_READ(7) R_MFMA(6)
-        __builtin_amdgcn_sched_barrier(0);
-        R_MFMA(7)
-#undef R_READ
-#undef R_MFMA
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // chunk ch + 1 landed, the newest still in flight
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        cur = cur == 2 ? 0 : cur + 1;
+        R_READ_AT(0, an, bn)                                // (past the last chunk: a re-issued copy, never used)
+        R_WAIT(3, 7) R_MFMA(7)
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a02[0]), "+v"(a13[0]), "+v"(bq[0]));
+#undef R_READ_AT
+#undef R_WAIT
+#undef R_MFMA
+#undef R_ISSUE_B_AT
 #undef R_ISSUE_A
 #undef R_ISSUE_B
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
