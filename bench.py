@@ -65,7 +65,7 @@ def load_traffic():
 
 def traffic_bytes(traffic, args, B, F):
     """HBM bytes per in-layer launch from the committed PMC passes, only for the exact launch shape they were taken on."""
-    key = "f32_bf16x3" if (args.dtype == "f32" and args.gemm_mode == "bf16x3") else args.dtype
+    key = ("f32_" + args.gemm_mode) if (args.dtype == "f32" and args.gemm_mode != "f32") else args.dtype
     e = traffic.get(key)
     if not e or args.config != "full" or F != 900 or B != e.get("batch", 8):
         return None
@@ -95,10 +95,11 @@ def parse_args(argv=None):
                     help="f32 = BASELINE config 2 (default, the headline); bf16 = config 3 (use --batch 32); bf16x3 = "
                          "split-bf16 (hi + lo operands, three bf16 MFMA products per contraction, fp32 accumulate): an "
                          "extra row, never the headline")
-    ap.add_argument("--gemm-mode", default="f32", choices=["f32", "bf16x3"],
+    ap.add_argument("--gemm-mode", default="f32", choices=["f32", "bf16x3", "bf16x6"],
                     help="main loop of the fp32 conv-GEMM (--dtype f32 only): f32 = fp32 MFMA products (default, the "
                          "headline); bf16x3 = operands split in registers into hi + lo bf16, three bf16 MFMA products, "
-                         "fp32 accumulate - an extra row, labelled in the line's dtype.  Set explicitly here; the "
+                         "fp32 accumulate; bf16x6 = hi + mid + lo (24 mantissa bits), the six products >= 2^-16 - "
+                         "extra rows, labelled in the line's dtype.  Set explicitly here; the "
                          "CTTS_F32_GEMM_MODE environment variable is ignored by bench.py")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="test hook for tests/test_bench_launcher.py: gloo on CPU with a stand-in step function; "
@@ -416,14 +417,14 @@ def worker(args, pre=None):
             # C*2C*3 plus this layer's slice of the conditioning projection 256*2C
             mac = 3 * C * 2 * C + 256 * 2 * C
             # bf16x3 executes three bf16 products per algorithmic MAC; the roofline counts the EXECUTED bf16 flops
-            split = args.dtype == "bf16x3" or (args.dtype == "f32" and args.gemm_mode == "bf16x3")
-            flop_per_launch = 2.0 * mac * B * L * (3 if split else 1)
+            products = 3 if args.dtype == "bf16x3" else {"f32": 1, "bf16x3": 3, "bf16x6": 6}[args.gemm_mode] if args.dtype == "f32" else 1
+            flop_per_launch = 2.0 * mac * B * L * products
             mean_s = ms.value / max(n.value, 1) * 1e-3
             achieved = flop_per_launch / mean_s / 1e12
             peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
             kname = "conv_gemm_f32_kernel<GATE>" if args.dtype == "f32" else "conv_gemm_bf16_pp_kernel<GATE>"
-            if args.dtype == "f32" and args.gemm_mode == "bf16x3":
-                kname, peak = "conv_gemm_f32_kernel<GATE, X3>", BF16_MFMA_PEAK_TFLOPS
+            if args.dtype == "f32" and args.gemm_mode != "f32":
+                kname, peak = f"conv_gemm_f32_kernel<GATE, X{products}>", BF16_MFMA_PEAK_TFLOPS
             roofline = {"kernel": kname + " (WN in-layer: dilated conv + cond + tanh*sigmoid)",
                         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
@@ -432,9 +433,9 @@ def worker(args, pre=None):
                                            f"launch shape, not re-measured in this run") if traffic_src else None,
                         "launches": int(n.value), "mean_launch_ms": round(mean_s * 1e3, 4),
                         "flop_per_launch": flop_per_launch}
-            if split:
-                roofline["note"] = ("flop_per_launch counts the three executed bf16 products per algorithmic MAC; "
-                                    "algorithmic flops are a third of it")
+            if products > 1:
+                roofline["note"] = (f"flop_per_launch counts the {products} executed bf16 products per algorithmic MAC; "
+                                    f"algorithmic flops are 1/{products} of it")
             if args.dtype == "bf16":
                 # In bf16 the in-layer GEMM stays MFMA-bound (1430 FLOP/B vs a ridge of ~312); the memory-bound WN
                 # kernels are the res GEMM (K = C, per layer: act read + x read-modify-write = 3*C*2 B per time step)
@@ -463,7 +464,7 @@ def worker(args, pre=None):
             "metric": METRIC, "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype if (args.gemm_mode == "f32" or args.dtype != "f32") else "f32 tensors, split-bf16 GEMM products (bf16x3)",
+            "dtype": args.dtype if (args.gemm_mode == "f32" or args.dtype != "f32") else f"f32 tensors, split-bf16 GEMM products ({args.gemm_mode})",
             "data": "synthetic" if not selftest else "LAUNCHER SELF-TEST (gloo/CPU stand-in step; not a measurement)",
             "rtf": value / 22050.0,
             "config": {"workload": f"WaveGlow {args.config} ({cfg['n_flows']} flows, {C} WN ch, "

@@ -236,25 +236,25 @@ SIGNATURES = {
     "ctts_profile_collect": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }
 
-GEMM_MODES = {"f32": 0, "bf16x3": 1}                      # ctts_set_f32_gemm_mode: the library DEFAULT
+GEMM_MODES = {"f32": 0, "bf16x3": 1, "bf16x6": 2}                      # ctts_set_f32_gemm_mode: the library DEFAULT
 # f32_gemm_mode field of the config structs (CTTS_GEMM_*): the mode a MODEL asks for
-MODEL_GEMM_MODES = {None: 0, "default": 0, "f32": 1, "bf16x3": 2}
+MODEL_GEMM_MODES = {None: 0, "default": 0, "f32": 1, "bf16x3": 2, "bf16x6": 3}
 
 
 def model_gemm_mode(mode):
-    """``None`` / ``"default"`` (the library default), ``"f32"`` or ``"bf16x3"`` -> CTTS_GEMM_*."""
+    """``None`` / ``"default"`` (the library default), ``"f32"``, ``"bf16x3"`` or ``"bf16x6"`` -> CTTS_GEMM_*."""
     try:
         return MODEL_GEMM_MODES[mode]
     except KeyError:
-        raise ValueError(f"f32 GEMM mode {mode!r}: expected one of 'default', 'f32', 'bf16x3'") from None
+        raise ValueError(f"f32 GEMM mode {mode!r}: expected one of 'default', 'f32', 'bf16x3', 'bf16x6'") from None
 
 
 def set_f32_gemm_mode(mode):
     """Library DEFAULT main loop of the fp32 conv-GEMM, used by models that did not choose one themselves
     (``model.set_f32_gemm_mode(...)`` puts the choice into the model's own config struct, so two models in one process
-    can differ): ``"f32"`` (initial value, fp32 MFMA) or ``"bf16x3"`` (each operand split in registers into hi + lo
-    bf16, three bf16 MFMA products per pair, fp32 accumulation; tensors and weights stay fp32).  Returns the previous
-    default's name."""
+    can differ): ``"f32"`` (initial value, fp32 MFMA), ``"bf16x3"`` (each operand split in registers into hi + lo
+    bf16, three bf16 MFMA products per pair, fp32 accumulation; tensors and weights stay fp32) or ``"bf16x6"`` (hi + mid +
+    lo, six products: fp32-grade).  Returns the previous default's name."""
     prev = {v: k for k, v in GEMM_MODES.items()}[lib().ctts_get_f32_gemm_mode()]
     check(lib().ctts_set_f32_gemm_mode(GEMM_MODES[mode]), "ctts_set_f32_gemm_mode")
     return prev

@@ -169,6 +169,8 @@ int get_gemm_f32_mode();
 // true when a launch with this GemmArgs.gemm_mode / config f32_gemm_mode runs the split-bf16 main loop
 bool gemm_mode_is_split(int gemm_mode);
 // validates a config struct's f32_gemm_mode field
-inline bool gemm_mode_valid(int m) { return m == CTTS_GEMM_DEFAULT || m == CTTS_GEMM_F32 || m == CTTS_GEMM_BF16X3; }
+inline bool gemm_mode_valid(int m) { return m == CTTS_GEMM_DEFAULT || m == CTTS_GEMM_F32 || m == CTTS_GEMM_BF16X3 || m == CTTS_GEMM_BF16X6; }
+// 0: fp32 MFMA; 3 / 6: bf16 products per operand pair of the split loops (the library default resolved)
+int gemm_split_level(int gemm_mode);
 
 }  // namespace ctts

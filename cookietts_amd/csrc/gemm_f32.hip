@@ -127,6 +127,9 @@ __device__ __forceinline__ void split_epilogue(const GemmArgs& a, f32x16 (&acc)[
 // operand: hi = bf16(v), lo = bf16(v - hi), and a 32x32 tile of the chunk is three bf16 MFMAs hi*hi + hi*lo + lo*hi
 // (96 matrix-pipe cycles) instead of eight fp32 MFMAs (512).  Operands carry 16 mantissa bits, accumulation is fp32;
 // tensors, packed weights and epilogues are untouched, so every fp32 path of the library can run on it.
+// X6 (XS = 6): a three-way split hi + mid + lo (3 x 8 = 24 mantissa bits = all of an fp32 operand) and the six products
+// whose weight is >= 2^-16 of the leading one: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi, accumulated in that order
+// (smallest first); the three dropped products are <= 2^-24 relative.  192 matrix-pipe cycles per tile and chunk.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split8(const float (&v)[8], u32x4_t& hi, u32x4_t& lo) {
@@ -138,8 +141,23 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4_t& hi, u32x4_t
     }
 }
 
-template <int EPI, int WM, int SEGS, bool GLDS, bool X3 = false>
+__device__ __forceinline__ void split8x3(const float (&v)[8], u32x4_t& hi, u32x4_t& mid, u32x4_t& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned int h = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+        const float r0 = v[2 * j] - __builtin_bit_cast(float, h << 16), r1 = v[2 * j + 1] - __builtin_bit_cast(float, h & 0xffff0000u);
+        const unsigned int m = pack_bf16x2(r0, r1);
+        hi[j] = h;
+        mid[j] = m;
+        lo[j] = pack_bf16x2(r0 - __builtin_bit_cast(float, m << 16), r1 - __builtin_bit_cast(float, m & 0xffff0000u));
+    }
+}
+
+template <int EPI, int WM, int SEGS, bool GLDS, int XS = 0>
 __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a) {
+    constexpr bool X3 = XS != 0;                           // any split-bf16 main loop (XS = 3 or 6 products)
+    constexpr bool X6 = XS == 6;
+    static_assert(XS == 0 || XS == 3 || XS == 6, "main loop: fp32 MFMA, 3 or 6 bf16 products");
     static_assert(!X3 || GLDS, "the split-bf16 loop is built on the DMA-staged pipeline");
     constexpr int NST = GLDS ? 3 : 2;
     constexpr int SEGTAB = NST * STAGE;
@@ -374,24 +392,34 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
             // B fragments first, then per row tile: [read + split A(mt + 1) | 6 MFMAs of mt | DMA pieces]: the VALU work
             // of the next row tile sits in the shadow of this row tile's 192 matrix-pipe cycles
             u32x4_t ah[2], al[2], bh[2], bl[2];
+            [[maybe_unused]] u32x4_t am[2], bm[2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 float v[8];
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) v[ks] = Bs[(2 * ks + lhi) * BN + nt * 32];
-                split8(v, bh[nt], bl[nt]);
+                if constexpr (X6) split8x3(v, bh[nt], bm[nt], bl[nt]);
+                else split8(v, bh[nt], bl[nt]);
             }
 #define CTTS_X3_A(mt, slot)                                                                     \
             {                                                                                   \
                 float v[8];                                                                     \
                 _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) v[ks] = As[(2 * ks + lhi) * BM + (mt) * 32]; \
-                split8(v, ah[slot], al[slot]);                                                  \
+                if constexpr (X6) split8x3(v, ah[slot], am[slot], al[slot]);                    \
+                else split8(v, ah[slot], al[slot]);                                             \
             }
+#define CTTS_X3_P(A_, B_, mt, nt)                                                               \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, A_), __builtin_bit_cast(bf16x8_t, B_), acc[mt][nt], 0, 0, 0);
 #define CTTS_X3_MFMA6(mt, slot)                                                                 \
             _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                  \
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, al[slot]), __builtin_bit_cast(bf16x8_t, bh[nt]), acc[mt][nt], 0, 0, 0); \
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah[slot]), __builtin_bit_cast(bf16x8_t, bl[nt]), acc[mt][nt], 0, 0, 0); \
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah[slot]), __builtin_bit_cast(bf16x8_t, bh[nt]), acc[mt][nt], 0, 0, 0); \
+                CTTS_X3_P(al[slot], bh[nt], mt, nt)                                             \
+                CTTS_X3_P(ah[slot], bl[nt], mt, nt)                                             \
+                if constexpr (X6) {                                                             \
+                    CTTS_X3_P(am[slot], bm[nt], mt, nt)                                         \
+                    CTTS_X3_P(am[slot], bh[nt], mt, nt)                                         \
+                    CTTS_X3_P(ah[slot], bm[nt], mt, nt)                                         \
+                }                                                                               \
+                CTTS_X3_P(ah[slot], bh[nt], mt, nt)                                             \
             }
             CTTS_X3_A(0, 0)
             __builtin_amdgcn_sched_barrier(0);
@@ -409,6 +437,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
             __builtin_amdgcn_sched_barrier(0);
             CTTS_X3_MFMA6(3, 1)
 #undef CTTS_X3_A
+#undef CTTS_X3_P
 #undef CTTS_X3_MFMA6
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                // chunk ch+1 landed, the newest in flight
             __builtin_amdgcn_s_barrier();
@@ -643,15 +672,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
 std::atomic<int> g_gemm_mode{0};
 inline int gemm_f32_mode() { return g_gemm_mode.load(std::memory_order_relaxed); }
 
-template <int EPI>
-void launch_shape_x3(int bm, dim3 grid, hipStream_t stream, const GemmArgs& a) {
+template <int EPI, int XS>
+void launch_shape_xs(int bm, dim3 grid, hipStream_t stream, const GemmArgs& a) {
     const bool few = a.nseg <= 4;
     if (bm == 128) {
-        if (few) hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 1, 4, true, true>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 1, GEMM_MAX_SEG, true, true>), grid, dim3(256), 0, stream, a);
+        if (few) hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 1, 4, true, XS>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 1, GEMM_MAX_SEG, true, XS>), grid, dim3(256), 0, stream, a);
     } else {
-        if (few) hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 2, 4, true, true>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 2, GEMM_MAX_SEG, true, true>), grid, dim3(256), 0, stream, a);
+        if (few) hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 2, 4, true, XS>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((conv_gemm_f32_kernel<EPI, 2, GEMM_MAX_SEG, true, XS>), grid, dim3(256), 0, stream, a);
     }
 }
 
@@ -670,19 +699,26 @@ void launch_shape_g(int bm, dim3 grid, hipStream_t stream, const GemmArgs& a) {
 template <int EPI>
 void launch_shape(int bm, dim3 grid, hipStream_t stream, const GemmArgs& a) {
     if (tuning().f32_no_glds || a.nch_total > GEMM_GLDS_MAX_CHUNKS) launch_shape_g<EPI, false>(bm, grid, stream, a);
-    else if (gemm_mode_is_split(a.gemm_mode)) launch_shape_x3<EPI>(bm, grid, stream, a);
+    else if (gemm_split_level(a.gemm_mode) == 6) launch_shape_xs<EPI, 6>(bm, grid, stream, a);
+    else if (gemm_split_level(a.gemm_mode) == 3) launch_shape_xs<EPI, 3>(bm, grid, stream, a);
     else launch_shape_g<EPI, true>(bm, grid, stream, a);
 }
 
 }  // namespace
 
 int set_gemm_f32_mode(int mode) {
-    if (mode != 0 && mode != 1) return -1;
+    if (mode != 0 && mode != 1 && mode != 2) return -1;      // 0 fp32 MFMA, 1 split bf16 x3, 2 split bf16 x6
     g_gemm_mode.store(mode, std::memory_order_relaxed);
     return 0;
 }
 int get_gemm_f32_mode() { return gemm_f32_mode(); }
-bool gemm_mode_is_split(int m) { return m == CTTS_GEMM_BF16X3 || (m == CTTS_GEMM_DEFAULT && gemm_f32_mode() == 1); }
+int gemm_split_level(int m) {
+    if (m == CTTS_GEMM_BF16X3) return 3;
+    if (m == CTTS_GEMM_BF16X6) return 6;
+    if (m == CTTS_GEMM_DEFAULT) return gemm_f32_mode() == 1 ? 3 : gemm_f32_mode() == 2 ? 6 : 0;
+    return 0;
+}
+bool gemm_mode_is_split(int m) { return gemm_split_level(m) != 0; }
 
 namespace {
 std::mutex g_tune_mu;
@@ -772,9 +808,12 @@ int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
             if (tuning().f32_no_glds || a.nch_total > GEMM_GLDS_MAX_CHUNKS) {
                 if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, 4, false>), grid, dim3(256), 0, stream, a);
                 else hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, GEMM_MAX_SEG, false>), grid, dim3(256), 0, stream, a);
-            } else if (gemm_mode_is_split(a.gemm_mode)) {
-                if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, 4, true, true>), grid, dim3(256), 0, stream, a);
-                else hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, GEMM_MAX_SEG, true, true>), grid, dim3(256), 0, stream, a);
+            } else if (gemm_split_level(a.gemm_mode) == 6) {
+                if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, 4, true, 6>), grid, dim3(256), 0, stream, a);
+                else hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, GEMM_MAX_SEG, true, 6>), grid, dim3(256), 0, stream, a);
+            } else if (gemm_split_level(a.gemm_mode) == 3) {
+                if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, 4, true, 3>), grid, dim3(256), 0, stream, a);
+                else hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, GEMM_MAX_SEG, true, 3>), grid, dim3(256), 0, stream, a);
             } else {
                 if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, 4, true>), grid, dim3(256), 0, stream, a);
                 else hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, GEMM_MAX_SEG, true>), grid, dim3(256), 0, stream, a);

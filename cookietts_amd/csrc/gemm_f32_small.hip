@@ -89,8 +89,22 @@ __device__ unsigned long long* g_small_stamps;
 #define S_STAMP_DRAIN(k)
 #endif
 
-template <int EPI, int SEGS, bool X3 = false>
+__device__ __forceinline__ void s_split8x3(const float (&v)[8], s_u32x4& hi, s_u32x4& mid, s_u32x4& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned int h = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+        const float r0 = v[2 * j] - __builtin_bit_cast(float, h << 16), r1 = v[2 * j + 1] - __builtin_bit_cast(float, h & 0xffff0000u);
+        const unsigned int m = pack_bf16x2(r0, r1);
+        hi[j] = h;
+        mid[j] = m;
+        lo[j] = pack_bf16x2(r0 - __builtin_bit_cast(float, m << 16), r1 - __builtin_bit_cast(float, m & 0xffff0000u));
+    }
+}
+
+// XS: 0 = fp32 MFMA, 3 / 6 = split-bf16 products per operand pair (gemm_f32.hip, X3 / X6)
+template <int EPI, int SEGS, int XS = 0>
 __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmArgs a, const int ntiles_s) {
+    constexpr bool X3 = XS != 0, X6 = XS == 6;
     __shared__ __attribute__((aligned(16))) float lds[S_LDS_FLOATS];
     constexpr bool PAIR = EPI == GEMM_EPI_GATE || EPI == GEMM_EPI_GATEX || EPI == GEMM_EPI_MAG;
 
@@ -245,27 +259,32 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
             const int nb = cur >= 1 ? cur - 1 : 2;              // (cur + 2) % 3: the stage chunk ch - 1 occupied
             const int cn = ch + 2 < nch ? ch + 2 : nch - 1;     // the last two iterations re-issue the final chunk
             s_u32x4 ah[2], al[2], bh, bl;
+            [[maybe_unused]] s_u32x4 am[2], bm;
             {
                 float v[8];
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) v[ks] = Bs[(2 * ks + lhi) * S_BN];
-                s_split8(v, bh, bl);
+                if constexpr (X6) s_split8x3(v, bh, bm, bl);
+                else s_split8(v, bh, bl);
             }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 float v[8];
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) v[ks] = As[(2 * ks + lhi) * S_BM + (mt == 0 ? arow0 : arow1)];
-                s_split8(v, ah[mt], al[mt]);
+                if constexpr (X6) s_split8x3(v, ah[mt], am[mt], al[mt]);
+                else s_split8(v, ah[mt], al[mt]);
             }
             __builtin_amdgcn_sched_barrier(0);
             S_ISSUE_A(nb, cn, 0); S_ISSUE_A(nb, cn, 1); S_ISSUE_B(nb, cn);
+#define S_X3_P(A_, B_) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s_bf16x8, A_), __builtin_bit_cast(s_bf16x8, B_), acc[mt], 0, 0, 0);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s_bf16x8, al[mt]), __builtin_bit_cast(s_bf16x8, bh), acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s_bf16x8, ah[mt]), __builtin_bit_cast(s_bf16x8, bl), acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s_bf16x8, ah[mt]), __builtin_bit_cast(s_bf16x8, bh), acc[mt], 0, 0, 0);
+                S_X3_P(al[mt], bh) S_X3_P(ah[mt], bl)
+                if constexpr (X6) { S_X3_P(am[mt], bm) S_X3_P(am[mt], bh) S_X3_P(ah[mt], bm) }
+                S_X3_P(ah[mt], bh)
             }
+#undef S_X3_P
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(3)" ::: "memory");    // chunk ch + 1 landed, the newest still in flight
             __builtin_amdgcn_s_barrier();
@@ -683,15 +702,19 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_f32_gate_rs_small_kernel(con
     }
 }
 
+template <int EPI, int XS>
+void launch_small_xs(dim3 grid, hipStream_t stream, const GemmArgs& a, int ntiles_s) {
+    if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_small_kernel<EPI, 4, XS>), grid, dim3(256), 0, stream, a, ntiles_s);
+    else hipLaunchKernelGGL((conv_gemm_f32_small_kernel<EPI, GEMM_MAX_SEG, XS>), grid, dim3(256), 0, stream, a, ntiles_s);
+}
+
 template <int EPI>
 void launch_small(dim3 grid, hipStream_t stream, const GemmArgs& a, int ntiles_s) {
-    if (gemm_mode_is_split(a.gemm_mode)) {
-        if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_small_kernel<EPI, 4, true>), grid, dim3(256), 0, stream, a, ntiles_s);
-        else hipLaunchKernelGGL((conv_gemm_f32_small_kernel<EPI, GEMM_MAX_SEG, true>), grid, dim3(256), 0, stream, a, ntiles_s);
-        return;
+    switch (gemm_split_level(a.gemm_mode)) {
+        case 6: launch_small_xs<EPI, 6>(grid, stream, a, ntiles_s); break;
+        case 3: launch_small_xs<EPI, 3>(grid, stream, a, ntiles_s); break;
+        default: launch_small_xs<EPI, 0>(grid, stream, a, ntiles_s); break;
     }
-    if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_small_kernel<EPI, 4>), grid, dim3(256), 0, stream, a, ntiles_s);
-    else hipLaunchKernelGGL((conv_gemm_f32_small_kernel<EPI, GEMM_MAX_SEG>), grid, dim3(256), 0, stream, a, ntiles_s);
 }
 
 }  // namespace

@@ -57,7 +57,7 @@ int make_wf_plan(const ctts_waveflow_config* cfg, WfPlan& p) {
     p.c = *cfg;
     const auto& c = p.c;
     CTTS_CHECK_ARG(c.n_flows >= 1 && c.n_layers >= 1 && c.n_layers <= 12, "n_flows=%d n_layers=%d", c.n_flows, c.n_layers);
-    CTTS_CHECK_ARG(gemm_mode_valid(c.f32_gemm_mode), "f32_gemm_mode=%d (CTTS_GEMM_DEFAULT / _F32 / _BF16X3)", c.f32_gemm_mode);
+    CTTS_CHECK_ARG(gemm_mode_valid(c.f32_gemm_mode), "f32_gemm_mode=%d (CTTS_GEMM_DEFAULT / _F32 / _BF16X3 / _BF16X6)", c.f32_gemm_mode);
     CTTS_CHECK_ARG(c.n_group >= 2 && c.n_group <= 64, "n_group=%d", c.n_group);
     CTTS_CHECK_ARG(c.n_channels >= 64 && c.n_channels % 64 == 0, "n_channels=%d (multiple of 64)", c.n_channels);
     CTTS_CHECK_ARG(c.kernel_size_w % 2 == 1 && c.kernel_size_w >= 1 && c.kernel_size_h >= 1, "kernel %dx%d",
@@ -645,7 +645,7 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
                         q.xin = X(si, slot);
                         q.xout = (i == p.c.n_layers - 1 || merge) ? nullptr : X(i + 1, slot);
                         q.gate = p.c.gated_unit;
-                        q.split_bf16 = gemm_mode_is_split(p.c.f32_gemm_mode) ? 1 : 0;
+                        q.split_bf16 = gemm_split_level(p.c.f32_gemm_mode) == 3 ? 1 : 0;   // (x6: the fused separable layer stays on fp32 MFMA)
                         q.out = w.out; q.acc_out = i > 0 ? 1 : 0; q.rs_rows = p.rs_rows(i);
                         q.L = L; q.ld = g.ld; q.pad = g.pad; q.ntiles = (L + 63) / 64;
                         if ((rc = launch_wf_sep_layer(q, batch, s))) return rc;

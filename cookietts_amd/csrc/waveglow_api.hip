@@ -52,7 +52,7 @@ int make_plan(const ctts_waveglow_config* cfg, Plan& p) {
     p.c = *cfg;
     const auto& c = p.c;
     CTTS_CHECK_ARG(c.n_flows >= 1 && c.n_layers >= 1 && c.n_layers <= 12, "n_flows=%d n_layers=%d", c.n_flows, c.n_layers);
-    CTTS_CHECK_ARG(gemm_mode_valid(c.f32_gemm_mode), "f32_gemm_mode=%d (CTTS_GEMM_DEFAULT / _F32 / _BF16X3)", c.f32_gemm_mode);
+    CTTS_CHECK_ARG(gemm_mode_valid(c.f32_gemm_mode), "f32_gemm_mode=%d (CTTS_GEMM_DEFAULT / _F32 / _BF16X3 / _BF16X6)", c.f32_gemm_mode);
     CTTS_CHECK_ARG(c.n_group >= 2 && c.n_group % 2 == 0 && c.n_group <= 8, "n_group=%d (even, <= 8)", c.n_group);
     CTTS_CHECK_ARG(c.kernel_size == 3, "kernel_size=%d (only 3 built)", c.kernel_size);
     CTTS_CHECK_ARG(c.n_channels >= 128 && c.n_channels % 128 == 0, "n_channels=%d (multiple of 128)", c.n_channels);
@@ -755,7 +755,7 @@ int ctts_waveglow_infer_spk_f32(const ctts_waveglow_config* cfg, const void* pac
 }
 
 int ctts_set_f32_gemm_mode(int32_t mode) {
-    if (set_gemm_f32_mode(mode)) { set_error("set_f32_gemm_mode: unknown mode %d (0 = fp32 MFMA, 1 = split bf16)", mode); return CTTS_E_ARG; }
+    if (set_gemm_f32_mode(mode)) { set_error("set_f32_gemm_mode: unknown mode %d (0 = fp32 MFMA, 1 = split bf16 x3, 2 = split bf16 x6)", mode); return CTTS_E_ARG; }
     return CTTS_OK;
 }
 int ctts_get_f32_gemm_mode(void) { return get_gemm_f32_mode(); }

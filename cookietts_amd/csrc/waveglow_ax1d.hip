@@ -55,7 +55,7 @@ int make_ax_plan(const ctts_wgax_config* cfg, AxPlan& p) {
     p.c = *cfg;
     const auto& c = p.c;
     CTTS_CHECK_ARG(c.n_flows >= 1 && c.n_layers >= 1 && c.n_layers <= 12, "wgax: n_flows=%d n_layers=%d", c.n_flows, c.n_layers);
-    CTTS_CHECK_ARG(gemm_mode_valid(c.f32_gemm_mode), "f32_gemm_mode=%d (CTTS_GEMM_DEFAULT / _F32 / _BF16X3)", c.f32_gemm_mode);
+    CTTS_CHECK_ARG(gemm_mode_valid(c.f32_gemm_mode), "f32_gemm_mode=%d (CTTS_GEMM_DEFAULT / _F32 / _BF16X3 / _BF16X6)", c.f32_gemm_mode);
     CTTS_CHECK_ARG(c.n_group >= 2 && c.n_group % 2 == 0 && c.n_group <= AX_MAX_GROUP, "wgax: n_group=%d (even, <= 32)", c.n_group);
     CTTS_CHECK_ARG(c.kernel_size % 2 == 1 && c.kernel_size >= 1 && c.kernel_size <= GEMM_MAX_SEG - 1,
                    "wgax: kernel_size=%d (odd, <= 11)", c.kernel_size);

@@ -466,7 +466,7 @@ class WaveGlow(nn.Module):
 
     def set_f32_gemm_mode(self, mode):
         """Main loop of THIS model's GEMMs (both cores, and the conditioning operators in front of them): ``"f32"``,
-        ``"bf16x3"`` or ``None`` / ``"default"`` (the library default).  See ``waveglow.WaveGlow.set_f32_gemm_mode``."""
+        ``"bf16x3"``, ``"bf16x6"`` or ``None`` / ``"default"`` (the library default).  See ``waveglow.WaveGlow.set_f32_gemm_mode``."""
         _lib.model_gemm_mode(mode)
         self._f32_gemm_mode = mode
         self._invalidate()            # the conditioning operators carry the mode in their packed descriptors

@@ -48,6 +48,7 @@ extern "C" {
 #define CTTS_GEMM_DEFAULT 0  /* the library default: fp32 MFMA unless ctts_set_f32_gemm_mode changed it */
 #define CTTS_GEMM_F32 1      /* v_mfma_f32_32x32x2_f32: exact fp32 products */
 #define CTTS_GEMM_BF16X3 2   /* split bf16: hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulation */
+#define CTTS_GEMM_BF16X6 3   /* 3-way split (24 mantissa bits): the six products >= 2^-16 (hh, hm, mh, hl, lh, mm); fp32-grade */
 #define CTTS_N_SPEAKERS 512  /* rows of every speaker-embedding table (glow.py:129, efficient_model_ax.py:60) */
 
 int ctts_abi_version(void);
@@ -626,10 +627,13 @@ int ctts_taco_stop_rule_f32(const float* gate_logits, int32_t batch, int32_t gat
  * the same kernel, tensors, packed weights and epilogues, but each operand value is split in registers into
  * hi = bf16(v), lo = bf16(v - hi) and each product is computed as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16
  * with fp32 accumulation: operands carry 16 mantissa bits (relative product error ~2^-16), the matrix pipe does
- * 3/16 of the cycles.
- * The mode is part of each model's config struct (f32_gemm_mode = CTTS_GEMM_F32 | CTTS_GEMM_BF16X3), so two models in one
+ * 3/16 of the cycles.  mode 2 ("split bf16 x6"): hi + mid + lo (24 mantissa bits = the whole fp32 operand) and the six
+ * products of weight >= 2^-16 (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi, accumulated smallest first; the three dropped
+ * ones are <= 2^-24 relative): fp32-grade results at 6/16 of the fp32 matrix-pipe cycles (tests/test_gemm_mode.py holds
+ * its error against the reference goldens within 2x of the fp32 MFMA path's).
+ * The mode is part of each model's config struct (f32_gemm_mode = CTTS_GEMM_F32 | CTTS_GEMM_BF16X3 | CTTS_GEMM_BF16X6), so two models in one
  * process can differ and nothing races with in-flight calls.  ctts_set_f32_gemm_mode only sets what CTTS_GEMM_DEFAULT (0)
- * resolves to (0 = fp32 MFMA, the initial value; 1 = split bf16) for callers that leave the field at 0, and for the two
+ * resolves to (0 = fp32 MFMA, the initial value; 1 = split bf16 x3; 2 = split bf16 x6) for callers that leave the field at 0, and for the two
  * entry points without a config struct (ctts_lstm_seq_f32's input projection, ctts_taco_decoder_init_f32's processed
  * memory); returns 0, or -1 for an unknown mode.  The STFT entry points always compute in fp32 MFMA (their sums cancel). */
 int ctts_set_f32_gemm_mode(int32_t mode);

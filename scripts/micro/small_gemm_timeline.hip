@@ -23,6 +23,7 @@ void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(s
 Tuning tuning() { return Tuning{}; }
 void reload_tuning() {}
 bool gemm_mode_is_split(int) { return false; }
+int gemm_split_level(int) { return 0; }
 }  // namespace ctts
 
 using namespace ctts;

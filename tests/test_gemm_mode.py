@@ -106,3 +106,62 @@ def test_two_models_two_modes_interleaved_on_two_streams(hip_lib_path):
     assert _lib.lib().ctts_get_f32_gemm_mode() == 0
     with pytest.raises(ValueError):
         models["f32"].set_f32_gemm_mode("tf32")
+
+
+# ---- "bf16x6": three-way split, the six products >= 2^-16: an fp32-GRADE fast path ----------------------------------
+# (honest if its error against the goldens is within 2x of the fp32 MFMA path's)
+X6_VS_F32_ERROR_RATIO = 2.0
+
+
+@pytest.mark.parametrize("name", ["toy_early", "small", "full_short"])
+def test_waveglow_bf16x6_is_fp32_grade(hip_lib_path, name):
+    """glow.py path under the six-product loop (large shape at full_short, small shape at toy size): the error against
+    the reference golden stays within 2x of what exact fp32 products give, and far below the three-product loop's."""
+    from cookietts_amd import WaveGlow, synthetic
+    g = np.load(os.path.join(GOLDEN, f"waveglow_{name}.npz"))
+    cfg = synthetic.WAVEGLOW_CONFIGS[str(g["config_key"])]
+    m = WaveGlow(**cfg)
+    m.load_state_dict(synthetic.to_torch(synthetic.waveglow_state_dict(cfg, seed=int(g["seed"]))))
+    m = m.cuda().eval()
+    mel, z = torch.from_numpy(g["mel"]).cuda(), torch.from_numpy(g["z_scaled"]).cuda()
+    err = {}
+    for mode in ("f32", "bf16x3", "bf16x6"):
+        m.set_f32_gemm_mode(mode)
+        err[mode] = rms_rel_err(m.infer_from_noise(mel, z).cpu().numpy(), g["wave"])
+    print(f"waveglow {name}: rms rel err vs reference: fp32 MFMA {err['f32']:.3e}, bf16x6 {err['bf16x6']:.3e}, bf16x3 {err['bf16x3']:.3e}")
+    assert m.c_config().f32_gemm_mode == 3
+    assert err["bf16x6"] <= X6_VS_F32_ERROR_RATIO * err["f32"]
+    assert err["bf16x6"] < err["bf16x3"]
+
+
+def test_ax_core_and_waveflow_bf16x6_are_fp32_grade(hip_lib_path):
+    """The ax 1-D core (small shape, interpolated conditioning addend) and WaveFlow config 4 (fused layer: its main loop
+    takes the six products, the in-register second GEMM stays fp32) under the six-product loop."""
+    from cookietts_amd import WaveFlow, synthetic
+    from cookietts_amd.waveglow_ax import WaveGlow as AxWaveGlow
+    g = np.load(os.path.join(GOLDEN, "waveglow_ax_notebook_toy.npz"))
+    cfg = synthetic.WAVEGLOW_AX_CONFIGS[str(g["config_key"])]
+    m = AxWaveGlow(**cfg)
+    m.load_state_dict(synthetic.to_torch(synthetic.waveglow_ax_state_dict(cfg, seed=int(g["seed"]))))
+    m = m.cuda().eval()
+    z, mel = torch.from_numpy(g["z"]).cuda(), torch.from_numpy(np.pad(g["mel"], ((0, 0), (0, 0), (0, 1)))).cuda()
+    ids = torch.from_numpy(g["speaker_ids"]).cuda()
+    err = {}
+    for mode in ("f32", "bf16x6"):
+        m.set_f32_gemm_mode(mode)
+        err[mode] = rms_rel_err(m.inverse(z, mel, speaker_ids=ids, return_CPU=False)[0].cpu().numpy(), g["inverse_full"])
+    print(f"waveglow_ax notebook_toy: fp32 MFMA {err['f32']:.3e}, bf16x6 {err['bf16x6']:.3e}")
+    assert err["bf16x6"] <= X6_VS_F32_ERROR_RATIO * err["f32"]
+
+    g = np.load(os.path.join(GOLDEN, "waveflow_full_short.npz"))
+    cfg = synthetic.WAVEFLOW_CONFIGS[str(g["config_key"])]
+    w = WaveFlow(**cfg)
+    w.load_state_dict(synthetic.to_torch(synthetic.waveflow_state_dict(cfg, seed=int(g["seed"]))))
+    w = w.cuda().eval()
+    melp = torch.from_numpy(np.pad(g["mel"], ((0, 0), (0, 0), (0, 1)))).cuda()
+    zz = torch.from_numpy(g["z"]).cuda()
+    for mode in ("f32", "bf16x6"):
+        w.set_f32_gemm_mode(mode)
+        err[mode] = rms_rel_err(w.inverse(zz, melp)[0].numpy(), g["inverse_full"])
+    print(f"waveflow full_short: fp32 MFMA {err['f32']:.3e}, bf16x6 {err['bf16x6']:.3e}")
+    assert err["bf16x6"] <= X6_VS_F32_ERROR_RATIO * err["f32"]
