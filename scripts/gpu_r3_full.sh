@@ -11,7 +11,8 @@ timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -2 | tee gpurun_out/r3
 python bench.py > gpurun_out/r3_${tag}_bench_f32.json 2> gpurun_out/r3_${tag}_bench_f32.err
 python bench.py --steps 5 --warmup 2 --dtype bf16 --batch 32 --cpu-frames 0 > gpurun_out/r3_${tag}_bench_bf16_b32.json 2>/dev/null
 python bench.py --steps 5 --warmup 2 --gemm-mode bf16x3 --cpu-frames 0 > gpurun_out/r3_${tag}_bench_f32_split_bf16x3.json 2>/dev/null
-for f in bench_f32 bench_bf16_b32 bench_f32_split_bf16x3; do python - "$f" "$tag" <<'PY'
+python bench.py --steps 5 --warmup 2 --gemm-mode bf16x6 --cpu-frames 0 > gpurun_out/r3_${tag}_bench_f32_split_bf16x6.json 2>/dev/null
+for f in bench_f32 bench_bf16_b32 bench_f32_split_bf16x3 bench_f32_split_bf16x6; do python - "$f" "$tag" <<'PY'
 import json, sys
 d = json.loads([l for l in open(f"gpurun_out/r3_{sys.argv[2]}_{sys.argv[1]}.json") if l.startswith("{")][-1])
 print(sys.argv[1], d["value"], d["ms_per_step"], d["dtype"], d["roofline"]["frac"], (d.get("cpu_baseline") or {}).get("value"))
