@@ -69,6 +69,10 @@ enum GateKind : int {
 };
 
 #if defined(__HIPCC__)
+// linear interpolation of the GATE epilogues' frame-rate addend, spelled out so that every kernel shape rounds alike
+// (left to the compiler, l0 * a + l1 * b contracts to either fma(l0, a, l1 * b) or fma(l1, b, l0 * a))
+__device__ __forceinline__ float gemm_lerp(float l0, float a, float l1, float b) { return __builtin_fmaf(l0, a, l1 * b); }
+
 // compile-time unit; callers switch on the run-time kind OUTSIDE their element loops
 template <int KIND>
 __device__ __forceinline__ float gate_eval(float u0, float u1) {

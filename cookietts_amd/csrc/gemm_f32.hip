@@ -559,8 +559,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
                             }
 #pragma unroll
                             for (int q = 0; q < 8; ++q) {
-                                add0[hf * 8 + q] = l0 * s00[q] + l1 * s01[q];
-                                add1[hf * 8 + q] = l0 * s10[q] + l1 * s11[q];
+                                add0[hf * 8 + q] = gemm_lerp(l0, s00[q], l1, s01[q]);
+                                add1[hf * 8 + q] = gemm_lerp(l0, s10[q], l1, s11[q]);
                             }
                         }
                     } else if ((EPI == GEMM_EPI_GATE || EPI == GEMM_EPI_GATEX) && a.addend) {   // uniform

@@ -154,6 +154,42 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
         }
     }
 
+    // GATE-family epilogues add a conditioning term (the ax core: frame-rate rows, linearly interpolated - glow_ax.py:362-373).
+    // In the fp32 loop its operands are requested here for the same reason as `old` above (the split loops have no
+    // registers to spare: they request them in the epilogue); the arithmetic stays in the epilogue either way.
+    constexpr bool HAS_ADDEND = EPI == GEMM_EPI_GATE || EPI == GEMM_EPI_GATEX;
+    constexpr bool HOIST_ADDEND = HAS_ADDEND && XS == 0;
+    [[maybe_unused]] float adv[HAS_ADDEND ? 4 : 1][16];
+    [[maybe_unused]] float ad_l0 = 1.0f, ad_l1 = 0.0f;
+#define S_LOAD_ADDEND()                                                                                          \
+    do {                                                                                                         \
+        const int n_ = n0 + wn * 32 + l31;                                                                       \
+        const int cb_ = (mb * 2 + half) * 64 + 32 * wm;                                                          \
+        if (a.addend && cb_ < a.pairC) {                                                                         \
+            const int nc_ = min(n_, a.L - 1);               /* lanes past the last column re-read it (never stored) */ \
+            int i0_ = nc_, i1_ = nc_;                                                                            \
+            if (a.addend_frames > 0) {                                                                           \
+                const int F_ = a.addend_frames;                                                                  \
+                const float scale_ = a.L > 1 ? (float)(F_ - 1) / (float)(a.L - 1) : 0.f;                         \
+                const float real_ = scale_ * (float)n_;                                                          \
+                i0_ = min((int)real_, F_ - 1);                                                                   \
+                i1_ = i0_ + 1 < F_ ? i0_ + 1 : F_ - 1;                                                           \
+                ad_l1 = real_ - (float)(int)real_;                                                               \
+                ad_l0 = 1.0f - ad_l1;                                                                            \
+            }                                                                                                    \
+            const float* ad_ = a.addend + (size_t)b * a.addend_bstride + a.addend_pad;                           \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                     \
+                const int c_ = min(cb_ + (r & 3) + 8 * (r >> 2) + 4 * lhi, a.pairC - 1);                         \
+                const float* r0_ = ad_ + (size_t)c_ * a.addend_ld;                                               \
+                const float* r1_ = ad_ + (size_t)(a.pairC + c_) * a.addend_ld;                                   \
+                adv[0][r] = r0_[i0_]; adv[1][r] = r0_[i1_]; adv[2][r] = r1_[i0_]; adv[3][r] = r1_[i1_];          \
+            }                                                                                                    \
+        } else {                                                                                                 \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) adv[0][r] = adv[1][r] = adv[2][r] = adv[3][r] = 0.0f; \
+        }                                                                                                        \
+    } while (0)
+    if constexpr (HOIST_ADDEND) S_LOAD_ADDEND();
+
     // segment table -> LDS (a dynamically indexed kernarg struct would be copied to scratch), then chunk -> B address
 #pragma unroll
     for (int sidx = 0; sidx < GEMM_MAX_SEG; ++sidx) {
@@ -371,30 +407,13 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
         const int cbase = (mb * 2 + half) * 64 + 32 * wm;
         if (cbase < a.pairC && n < a.L) {
             float add0[16], add1[16];
-            if ((EPI == GEMM_EPI_GATE || EPI == GEMM_EPI_GATEX) && a.addend && a.addend_frames > 0) {   // interpolated addend
-                const int F = a.addend_frames;
-                const float scale = a.L > 1 ? (float)(F - 1) / (float)(a.L - 1) : 0.f;
-                const float real = scale * (float)n;
-                const int i0 = (int)real;
-                const int i1 = i0 + 1 < F ? i0 + 1 : F - 1;
-                const float l1 = real - (float)i0;
-                const float l0 = 1.0f - l1;
-                const float* ad = a.addend + (size_t)b * a.addend_bstride + a.addend_pad;
+            if constexpr (HAS_ADDEND && !HOIST_ADDEND) S_LOAD_ADDEND();
+            if constexpr (HAS_ADDEND) {
+                const bool interp = a.addend_frames > 0;    // (same arithmetic as the large shape, on operands requested at entry)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int c = min(cbase + (r & 3) + 8 * (r >> 2) + 4 * lhi, a.pairC - 1);
-                    const float* r0 = ad + (size_t)c * a.addend_ld;
-                    const float* r1 = ad + (size_t)(a.pairC + c) * a.addend_ld;
-                    add0[r] = l0 * r0[i0] + l1 * r0[i1];
-                    add1[r] = l0 * r1[i0] + l1 * r1[i1];
-                }
-            } else if ((EPI == GEMM_EPI_GATE || EPI == GEMM_EPI_GATEX) && a.addend) {
-                const float* ad = a.addend + (size_t)b * a.addend_bstride + a.addend_pad + n;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int c = min(cbase + (r & 3) + 8 * (r >> 2) + 4 * lhi, a.pairC - 1);
-                    add0[r] = ad[(size_t)c * a.addend_ld];
-                    add1[r] = ad[(size_t)(a.pairC + c) * a.addend_ld];
+                    add0[r] = interp ? gemm_lerp(ad_l0, adv[0][r], ad_l1, adv[1][r]) : adv[0][r];
+                    add1[r] = interp ? gemm_lerp(ad_l0, adv[2][r], ad_l1, adv[3][r]) : adv[2][r];
                 }
             } else {
 #pragma unroll
@@ -455,6 +474,7 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
         }
     }
     S_STAMP_DRAIN(5);
+#undef S_LOAD_ADDEND
 }
 
 
