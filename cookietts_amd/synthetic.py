@@ -311,6 +311,11 @@ WAVEGLOW_AX_CONFIGS = {
                                   n_early_every=2),
     "toy_c160": waveglow_ax_config(n_flows=2, n_group=12, n_channels=160, n_layers=2, kernel_size_w=5, hop_length=240,
                                    win_length=960, WN=dict(gated_unit='GTLRU')),
+    # the widest latent the 1-D core takes (n_group = 32 rows in the flow-boundary kernel), with early outputs changing the
+    # row count between flows; 32 channels = one 32-channel chunk (seven of the boundary kernel's eight waves idle in `end`)
+    "toy_g32": waveglow_ax_config(n_flows=4, n_group=32, n_channels=32, n_layers=2, n_early_every=2, n_early_size=4),
+    "toy_g32_permute": waveglow_ax_config(n_flows=4, n_group=32, n_channels=64, n_layers=2, channel_mixing='permute',
+                                          mix_first=False, n_early_every=2, n_early_size=2),
     # per-layer width dilations instead of 2^i (a list, and the constant-int form)
     "toy_dilations": waveglow_ax_config(n_flows=2, n_group=8, n_layers=3, kernel_size_w=5, WN=dict(n_layers_dilations_w=[3, 1, 7])),
     "toy_dilations_const": waveglow_ax_config(n_flows=2, n_group=8, n_layers=2, WN=dict(n_layers_dilations_w=2)),

@@ -308,7 +308,9 @@ def make_waveglow_ax(full_length=False, untts=False, gates=False):
                   # per-layer width dilations
                   ("toy_dilations", 2, 5, 0.8, 67), ("toy_dilations_const", 1, 6, 0.8, 68),
                   # n_channels not a multiple of 128
-                  ("toy_c96", 2, 5, 0.8, 69), ("toy_c160", 1, 6, 0.8, 70)]
+                  ("toy_c96", 2, 5, 0.8, 69), ("toy_c160", 1, 6, 0.8, 70),
+                  # n_group = 32 (the widest latent), 1x1-conv mixing before / permutation after the coupling
+                  ("toy_g32", 2, 5, 0.8, 71), ("toy_g32_permute", 2, 6, 0.8, 72)]
         only = sys.argv[2:]
         if only:
             cases = [c for c in cases if c[0] in only]

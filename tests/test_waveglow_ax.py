@@ -16,7 +16,7 @@ ORACLE_TOL = 5e-6
 SMALL = ["toy_conv", "toy_conv_mixlast", "toy_permute", "toy_permute_mixfirst", "notebook_toy", "untts_toy", "toy_merge",
          "toy_groupconv", "toy_groupconv_dense", "toy_wn_tconv", "toy_wn_tconv_crop",
          "toy_sigmoid_vol", "toy_no_res_skip", "toy_no_res_skip_1layer",
-         "toy_dilations", "toy_dilations_const", "toy_c96", "toy_c160"]
+         "toy_dilations", "toy_dilations_const", "toy_c96", "toy_c160", "toy_g32", "toy_g32_permute"]
 GATES = sorted(k for k in synthetic.WAVEGLOW_AX_CONFIGS if k.startswith("toy_gate_"))       # the 13 non-GTU units
 
 
