@@ -492,7 +492,7 @@ constexpr int R_LDS_FLOATS = R_CHTAB + 2 * S_MAX_CHUNKS;
 static_assert(64 * 128 + 128 <= S_NST * R_STAGE, "the res/skip weights are staged over the main loop's stages");
 
 template <int SEGS>
-__global__ __launch_bounds__(256, 3) void conv_gemm_f32_gate_rs_small_kernel(const GemmArgs a, const int ntiles_s) {
+__global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_small_kernel(const GemmArgs a, const int ntiles_s) {
     __shared__ __attribute__((aligned(16))) float lds[R_LDS_FLOATS];
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -502,6 +502,39 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_f32_gate_rs_small_kernel(con
     const int tile = blockIdx.x % ntiles_s;
     const int b = blockIdx.x / ntiles_s;
     const int n0 = tile * R_BN;
+
+    // Everything the epilogue needs from memory is requested at kernel ENTRY (a batch-1 launch is one wave per SIMD: each
+    // dependent round trip at the end is exposed in full): the destination's old values (x += res, skip += ...), the
+    // res/skip weights on their way to LDS, both bias vectors.  Nothing in this launch writes this block's tile before its
+    // own epilogue.  The launch shape is only taken below two blocks per CU, so the registers are there.
+    typedef float r_f32x4 __attribute__((ext_vector_type(4)));
+    float old[4][16];
+    r_f32x4 rsw[8];
+    {
+        const int n_ = n0 + wn * 32 + l31;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int rbase = mt * 32;
+            const bool second = rbase >= a.split;
+            const float* dstc = second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride;
+            const float* src = second ? dstc : (a.src0 ? a.src0 + (size_t)b * a.src0_bstride : dstc);
+            const int accum = second ? a.acc1 : a.acc0;
+            const int rdst = second ? rbase - a.split : rbase;
+            if (accum && rbase < a.rs_rows) {       // one unconditional form; rows / columns past the end re-read the last one
+                const float* sp = src + (size_t)rdst * a.dst_ld + a.dst_pad + min(n_, a.L - 1);
+                const int rlast = a.rs_rows - 1 - rbase;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) old[mt][r] = sp[(size_t)min((r & 3) + 8 * (r >> 2) + 4 * lhi, rlast) * a.dst_ld];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) old[mt][r] = 0.0f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) rsw[k] = *reinterpret_cast<const r_f32x4*>(a.rs_wT + t * 4 + k * 1024);
+    }
+    const float bias_pre = t < S_BM ? a.bias[t] : 0.0f;
+    const float rsb_pre = t < 128 ? a.rs_bias[t] : 0.0f;
 
 #pragma unroll
     for (int sidx = 0; sidx < GEMM_MAX_SEG; ++sidx) {
@@ -656,7 +689,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_f32_gate_rs_small_kernel(con
     __builtin_amdgcn_s_barrier();
 
     // ---- epilogue: gate in registers, res/skip 1x1 GEMM on the gated tile, read-modify-write (gemm_f32.hip GATE_RS)
-    if (t < S_BM) lds[t] = a.bias[t];
+    if (t < S_BM) lds[t] = bias_pre;
     __syncthreads();
     const int n = n0 + wn * 32 + l31;
     float actv[2][16];
@@ -677,9 +710,9 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_f32_gate_rs_small_kernel(con
             actv[mt][r] = ok ? s_fast_tanh(u0) * s_fast_sigmoid(u1) : 0.0f;
         }
     __syncthreads();                                       // everyone is done with the bias copy in LDS
-    for (int i = t * 4; i < 64 * 128; i += 1024)
-        *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(a.rs_wT + i);
-    if (t < 128) lds[64 * 128 + t] = a.rs_bias[t];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) *reinterpret_cast<r_f32x4*>(lds + t * 4 + k * 1024) = rsw[k];
+    if (t < 128) lds[64 * 128 + t] = rsb_pre;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -702,20 +735,12 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_f32_gate_rs_small_kernel(con
         if (rbase >= a.rs_rows) continue;
         const bool second = rbase >= a.split;
         float* dst = second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride;
-        const float* src = second ? dst : (a.src0 ? a.src0 + (size_t)b * a.src0_bstride : dst);
-        const int accum = second ? a.acc1 : a.acc0;
         const int rdst = second ? rbase - a.split : rbase;
         if (n < a.L) {
-            float old[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                old[r] = (accum && rbase + row < a.rs_rows) ? src[(size_t)(rdst + row) * a.dst_ld + a.dst_pad + n] : 0.0f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                const float v = acc[mt][r] + rbias[rbase + row] + old[r];
+                const float v = acc[mt][r] + rbias[rbase + row] + old[mt][r];
                 if (rbase + row < a.rs_rows) dst[(size_t)(rdst + row) * a.dst_ld + a.dst_pad + n] = v;
             }
         }
