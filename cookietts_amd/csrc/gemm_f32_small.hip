@@ -190,6 +190,58 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
     } while (0)
     if constexpr (HOIST_ADDEND) S_LOAD_ADDEND();
 
+    const int nalloc = a.a_nch_alloc ? a.a_nch_alloc : a.nch_total;
+    // A: chunk c of M-block mb in the 256-row packing, rows [128 half, +128).  Piece p of this wave fills LDS floats
+    // [wave * 256 + p * 1024, +256) of the [16][128] stage: k-row 2 wave + 8 p + (lane >> 5), columns 4 (lane & 31).
+    const gfloat_ptr a_base = (gfloat_ptr)(a.A + ((size_t)mb * nalloc + a.a_ch_off) * (GEMM_KC * 256) + 128 * half +
+                                           (2 * wave + (lane >> 5)) * 256 + (lane & 31) * 4);
+    // B: [16][64] stage, this wave's piece = k-rows 4 wave .. +4: k-row 4 wave + (lane >> 4), columns 4 (lane & 15)
+    const size_t b_off = (size_t)(4 * wave + (lane >> 4)) * a.ld + (lane & 15) * 4;
+    const unsigned long long* ctab = reinterpret_cast<const unsigned long long*>(lds + S_CHTAB);
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+#define S_ISSUE_A(buf, c, p)                                                                                     \
+    __builtin_amdgcn_global_load_lds(a_base + (size_t)(c) * (GEMM_KC * 256) + (p) * (8 * 256),                   \
+                                     (lds_fptr)(lds + (buf) * S_STAGE + wave * 256 + (p) * 1024), 16, 0, 0)
+#define S_ISSUE_B(buf, c)                                                                                        \
+    do {                                                                                                         \
+        const unsigned long long ub_ = ctab[c];                                                                  \
+        const unsigned long long us_ =                                                                           \
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |             \
+            (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                                  \
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off,                               \
+                                         (lds_fptr)(lds + (buf) * S_STAGE + S_ASTAGE + wave * 256), 16, 0, 0);   \
+    } while (0)
+
+#define S_ISSUE_B_AT(buf, ub)                                                                                    \
+    do {                                                                                                         \
+        const unsigned long long ub_ = (ub);                                                                     \
+        const unsigned long long us_ =                                                                           \
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |             \
+            (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                                  \
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off,                               \
+                                         (lds_fptr)(lds + (buf) * S_STAGE + S_ASTAGE + wave * 256), 16, 0, 0);   \
+    } while (0)
+
+    // Chunks 0 and 1 are requested BEFORE the tables are built (their B addresses follow from the first two segments by
+    // the same rule as the table's): the first DMA round trip and the table build overlap instead of adding up.
+    const int nch = a.nch_total;
+    {
+        const GemmSeg& g0 = a.seg[0];
+        const GemmSeg& g1 = a.seg[1];
+        const float* sb0 = g0.base + (size_t)b * g0.bstride + (size_t)(mb * g0.mb_rows) * a.ld + (a.pad + n0 + g0.shift);
+        const float* sb1 = g1.base + (size_t)b * g1.bstride + (size_t)(mb * g1.mb_rows) * a.ld + (a.pad + n0 + g1.shift);
+        const float* c1p = nch <= 1 ? sb0 : a.interleave > 1 ? sb1 : g0.nch > 1 ? sb0 + (size_t)GEMM_KC * a.ld : sb1;
+        const int c1 = nch > 1 ? 1 : 0;
+        S_ISSUE_A(0, 0, 0); S_ISSUE_A(0, 0, 1); S_ISSUE_B_AT(0, reinterpret_cast<unsigned long long>(sb0));
+        S_ISSUE_A(1, c1, 0); S_ISSUE_A(1, c1, 1); S_ISSUE_B_AT(1, reinterpret_cast<unsigned long long>(c1p));
+    }
+
     // segment table -> LDS (a dynamically indexed kernarg struct would be copied to scratch), then chunk -> B address
 #pragma unroll
     for (int sidx = 0; sidx < GEMM_MAX_SEG; ++sidx) {
@@ -232,51 +284,7 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
     }
     __syncthreads();
 
-    const int nalloc = a.a_nch_alloc ? a.a_nch_alloc : a.nch_total;
-    // A: chunk c of M-block mb in the 256-row packing, rows [128 half, +128).  Piece p of this wave fills LDS floats
-    // [wave * 256 + p * 1024, +256) of the [16][128] stage: k-row 2 wave + 8 p + (lane >> 5), columns 4 (lane & 31).
-    const gfloat_ptr a_base = (gfloat_ptr)(a.A + ((size_t)mb * nalloc + a.a_ch_off) * (GEMM_KC * 256) + 128 * half +
-                                           (2 * wave + (lane >> 5)) * 256 + (lane & 31) * 4);
-    // B: [16][64] stage, this wave's piece = k-rows 4 wave .. +4: k-row 4 wave + (lane >> 4), columns 4 (lane & 15)
-    const size_t b_off = (size_t)(4 * wave + (lane >> 4)) * a.ld + (lane & 15) * 4;
-    const unsigned long long* ctab = reinterpret_cast<const unsigned long long*>(lds + S_CHTAB);
-
-    f32x16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-
-#define S_ISSUE_A(buf, c, p)                                                                                     \
-    __builtin_amdgcn_global_load_lds(a_base + (size_t)(c) * (GEMM_KC * 256) + (p) * (8 * 256),                   \
-                                     (lds_fptr)(lds + (buf) * S_STAGE + wave * 256 + (p) * 1024), 16, 0, 0)
-#define S_ISSUE_B(buf, c)                                                                                        \
-    do {                                                                                                         \
-        const unsigned long long ub_ = ctab[c];                                                                  \
-        const unsigned long long us_ =                                                                           \
-            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |             \
-            (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                                  \
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off,                               \
-                                         (lds_fptr)(lds + (buf) * S_STAGE + S_ASTAGE + wave * 256), 16, 0, 0);   \
-    } while (0)
-
-#define S_ISSUE_B_AT(buf, ub)                                                                                    \
-    do {                                                                                                         \
-        const unsigned long long ub_ = (ub);                                                                     \
-        const unsigned long long us_ =                                                                           \
-            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |             \
-            (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                                  \
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off,                               \
-                                         (lds_fptr)(lds + (buf) * S_STAGE + S_ASTAGE + wave * 256), 16, 0, 0);   \
-    } while (0)
-
-    const int nch = a.nch_total;
     S_STAMP(1);
-    S_ISSUE_A(0, 0, 0); S_ISSUE_A(0, 0, 1); S_ISSUE_B(0, 0);
-    {
-        const int c1 = nch > 1 ? 1 : 0;
-        S_ISSUE_A(1, c1, 0); S_ISSUE_A(1, c1, 1); S_ISSUE_B(1, c1);
-    }
     asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -536,6 +544,57 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_small_kernel(con
     const float bias_pre = t < S_BM ? a.bias[t] : 0.0f;
     const float rsb_pre = t < 128 ? a.rs_bias[t] : 0.0f;
 
+    const int nalloc = a.a_nch_alloc ? a.a_nch_alloc : a.nch_total;
+    // A: the [16][128] chunk of the bm = 128 packing, copied linearly: piece p of this wave = floats [wave * 256 + p * 1024, +256)
+    const gfloat_ptr a_base = (gfloat_ptr)(a.A + (size_t)a.a_ch_off * S_ASTAGE + wave * 256 + lane * 4);
+    (void)nalloc;
+    // B: [16][128] stage, piece p of this wave = k-row 2 wave + 8 p + (lane >> 5), columns 4 (lane & 31)
+    const size_t b_off = (size_t)(2 * wave + (lane >> 5)) * a.ld + (lane & 31) * 4;
+    const size_t b_piece = (size_t)8 * a.ld;
+    const unsigned long long* ctab = reinterpret_cast<const unsigned long long*>(lds + R_CHTAB);
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+#define R_ISSUE_A(buf, c, p)                                                                                     \
+    __builtin_amdgcn_global_load_lds(a_base + (size_t)(c) * S_ASTAGE + (p) * 1024,                                \
+                                     (lds_fptr)(lds + (buf) * R_STAGE + wave * 256 + (p) * 1024), 16, 0, 0)
+#define R_ISSUE_B(buf, c, p)                                                                                     \
+    do {                                                                                                         \
+        const unsigned long long ub_ = ctab[c];                                                                  \
+        const unsigned long long us_ =                                                                           \
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |             \
+            (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                                  \
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off + (p) * b_piece,              \
+                                         (lds_fptr)(lds + (buf) * R_STAGE + S_ASTAGE + wave * 256 + (p) * 1024), 16, 0, 0); \
+    } while (0)
+
+#define R_ISSUE_B_AT(buf, ub, p)                                                                                 \
+    do {                                                                                                         \
+        const unsigned long long ub_ = (ub);                                                                     \
+        const unsigned long long us_ =                                                                           \
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |             \
+            (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                                  \
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off + (p) * b_piece,              \
+                                         (lds_fptr)(lds + (buf) * R_STAGE + S_ASTAGE + wave * 256 + (p) * 1024), 16, 0, 0); \
+    } while (0)
+    // chunks 0 and 1 before the tables are built (as in conv_gemm_f32_small_kernel)
+    const int nch = a.nch_total;
+    {
+        const GemmSeg& g0 = a.seg[0];
+        const GemmSeg& g1 = a.seg[1];
+        const float* sb0 = g0.base + (size_t)b * g0.bstride + (a.pad + n0 + g0.shift);
+        const float* sb1 = g1.base + (size_t)b * g1.bstride + (a.pad + n0 + g1.shift);
+        const float* c1p = nch <= 1 ? sb0 : a.interleave > 1 ? sb1 : g0.nch > 1 ? sb0 + (size_t)GEMM_KC * a.ld : sb1;
+        const int c1 = nch > 1 ? 1 : 0;
+        const unsigned long long u0 = reinterpret_cast<unsigned long long>(sb0), u1 = reinterpret_cast<unsigned long long>(c1p);
+        R_ISSUE_A(0, 0, 0); R_ISSUE_A(0, 0, 1); R_ISSUE_B_AT(0, u0, 0); R_ISSUE_B_AT(0, u0, 1);
+        R_ISSUE_A(1, c1, 0); R_ISSUE_A(1, c1, 1); R_ISSUE_B_AT(1, u1, 0); R_ISSUE_B_AT(1, u1, 1);
+    }
+
 #pragma unroll
     for (int sidx = 0; sidx < GEMM_MAX_SEG; ++sidx) {
         if (sidx < SEGS && t == sidx) {
@@ -577,40 +636,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_small_kernel(con
     }
     __syncthreads();
 
-    const int nalloc = a.a_nch_alloc ? a.a_nch_alloc : a.nch_total;
-    // A: the [16][128] chunk of the bm = 128 packing, copied linearly: piece p of this wave = floats [wave * 256 + p * 1024, +256)
-    const gfloat_ptr a_base = (gfloat_ptr)(a.A + (size_t)a.a_ch_off * S_ASTAGE + wave * 256 + lane * 4);
-    (void)nalloc;
-    // B: [16][128] stage, piece p of this wave = k-row 2 wave + 8 p + (lane >> 5), columns 4 (lane & 31)
-    const size_t b_off = (size_t)(2 * wave + (lane >> 5)) * a.ld + (lane & 31) * 4;
-    const size_t b_piece = (size_t)8 * a.ld;
-    const unsigned long long* ctab = reinterpret_cast<const unsigned long long*>(lds + R_CHTAB);
-
-    f32x16 acc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-
-#define R_ISSUE_A(buf, c, p)                                                                                     \
-    __builtin_amdgcn_global_load_lds(a_base + (size_t)(c) * S_ASTAGE + (p) * 1024,                                \
-                                     (lds_fptr)(lds + (buf) * R_STAGE + wave * 256 + (p) * 1024), 16, 0, 0)
-#define R_ISSUE_B(buf, c, p)                                                                                     \
-    do {                                                                                                         \
-        const unsigned long long ub_ = ctab[c];                                                                  \
-        const unsigned long long us_ =                                                                           \
-            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |             \
-            (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                                  \
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off + (p) * b_piece,              \
-                                         (lds_fptr)(lds + (buf) * R_STAGE + S_ASTAGE + wave * 256 + (p) * 1024), 16, 0, 0); \
-    } while (0)
-
-    const int nch = a.nch_total;
-    R_ISSUE_A(0, 0, 0); R_ISSUE_A(0, 0, 1); R_ISSUE_B(0, 0, 0); R_ISSUE_B(0, 0, 1);
-    {
-        const int c1 = nch > 1 ? 1 : 0;
-        R_ISSUE_A(1, c1, 0); R_ISSUE_A(1, c1, 1); R_ISSUE_B(1, c1, 0); R_ISSUE_B(1, c1, 1);
-    }
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -634,15 +659,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_small_kernel(con
     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a13[(ks) & 1][0], bq[(ks) & 1], acc[1], 0, 0, 0);               \
     acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a02[(ks) & 1][1], bq[(ks) & 1], acc[2], 0, 0, 0);               \
     acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a13[(ks) & 1][1], bq[(ks) & 1], acc[3], 0, 0, 0);
-#define R_ISSUE_B_AT(buf, ub, p)                                                                                 \
-    do {                                                                                                         \
-        const unsigned long long ub_ = (ub);                                                                     \
-        const unsigned long long us_ =                                                                           \
-            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |             \
-            (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                                  \
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off + (p) * b_piece,              \
-                                         (lds_fptr)(lds + (buf) * R_STAGE + S_ASTAGE + wave * 256 + (p) * 1024), 16, 0, 0); \
-    } while (0)
     R_READ_AT(0, a_lane, b_lane)
     int cur = 0;
     for (int ch = 0; ch < nch; ++ch) {
