@@ -730,6 +730,7 @@ void load_tuning_locked() {
     g_tune.f32_no_glds = on("CTTS_F32_NO_GLDS");
     g_tune.f32_no_small = on("CTTS_F32_NO_SMALL");
     g_tune.f32_force_small = on("CTTS_F32_FORCE_SMALL");
+    g_tune.f32_no_splitk = on("CTTS_F32_NO_SPLITK");
     g_tune.no_xcd_pair = on("CTTS_GEMM_NO_XCD_PAIR");
     g_tune.bf16_no_glds = on("CTTS_BF16_NO_GLDS");
     g_tune.bf16_no_wide = on("CTTS_BF16_NO_WIDE");

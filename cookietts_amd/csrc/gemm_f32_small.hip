@@ -33,6 +33,8 @@ constexpr int S_MAX_CHUNKS = 256;                        // chunk -> B address t
 constexpr int S_NST = 3;
 // the fused WaveFlow layer takes the small shape below this many 128 x 256 blocks (set from the B = 1 / 2 / 8 measurements)
 constexpr long long GATE_RS_SMALL_BELOW_BLOCKS = 256;
+// ... and the split-K shape (128 x 64 blocks, K halves on wave pairs) up to this many 128 x 256 blocks (batch 1-2 of config 4)
+constexpr long long GATE_RS_SPLITK_MAX_BLOCKS = 128;
 constexpr int S_SEGTAB = S_NST * S_STAGE;
 constexpr int S_CHTAB = S_SEGTAB + GEMM_MAX_SEG * 4;
 constexpr int S_LDS_FLOATS = S_CHTAB + 2 * S_MAX_CHUNKS;
@@ -763,6 +765,290 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_small_kernel(con
     }
 }
 
+
+// ---- fused WaveFlow layer (GEMM_EPI_GATE_RS), split-K shape for batch 1-2 -----------------------------------------------
+// At batch 1 the 128 x 128 shape above is 113 workgroups with one wave per SIMD: fewer than half of the CUs work, and a
+// launch lasts one wave's serial chain of 36 chunks x 32 MFMAs.  A wave must own all <= 64 channels (128 rows) of its 32
+// columns for the gate -> res/skip GEMM fusion, so the rows cannot be split; the K axis can.  Here a workgroup is 128 rows
+// x 64 columns, waves (wn = column tile, kh = K half): chunks are staged in PAIRS, the kh = 0 waves take the even chunk of
+// a pair and the kh = 1 waves the odd one.  226 workgroups at batch 1 (88 % of the CUs), each wave half the chain.  After
+// the loop the kh = 1 accumulators meet the kh = 0 ones through LDS, the kh = 0 waves gate, the gated tile goes through
+// LDS to both halves, and the second GEMM is split by rows: kh = 0 the res rows, kh = 1 the skip rows.
+// The sum over K is (even chunks) + (odd chunks): NOT the chunk order of the other shapes - equal to them within fp32
+// summation noise, not bit for bit (tests/test_small_shape.py).
+constexpr int K_BN = 64;
+constexpr int K_CHUNK = GEMM_KC * (S_BM + K_BN);         // 3072 floats: A [16][128] | B [16][64]
+constexpr int K_STAGE = 2 * K_CHUNK;                     // a pair of chunks
+constexpr int K_NST = 3;
+constexpr int K_SEGTAB = K_NST * K_STAGE;
+constexpr int K_CHTAB = K_SEGTAB + GEMM_MAX_SEG * 4;
+constexpr int K_LDS_FLOATS = K_CHTAB + 2 * S_MAX_CHUNKS; // 75 968 B: dynamic LDS, two workgroups per CU
+constexpr int K_RED = 0;                                 // epilogue: [2 wn][64][64] partial accumulators, then the res/skip weights
+constexpr int K_ACT = 8192;                              //           [2 wn][32][64] gated tile
+constexpr int K_BIAS = 12288;                            //           128 in-layer + 128 res/skip biases
+static_assert(K_BIAS + 256 <= K_NST * K_STAGE, "the epilogue lives in the stage area");
+
+template <int SEGS>
+__global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_splitk_kernel(const GemmArgs a, const int ntiles_s) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wn = wave & 1, kh = wave >> 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int tile = blockIdx.x % ntiles_s;
+    const int b = blockIdx.x / ntiles_s;
+    const int n0 = tile * K_BN;
+    const int n = n0 + wn * 32 + l31;
+
+    // epilogue operands requested at entry (see conv_gemm_f32_gate_rs_small_kernel): this wave stores row tiles 2 kh, 2 kh + 1
+    typedef float k_f32x4 __attribute__((ext_vector_type(4)));
+    float old[2][16];
+    k_f32x4 rsw[8];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rbase = (2 * kh + j) * 32;
+        const bool second = rbase >= a.split;
+        const float* dstc = second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride;
+        const float* src = second ? dstc : (a.src0 ? a.src0 + (size_t)b * a.src0_bstride : dstc);
+        const int accum = second ? a.acc1 : a.acc0;
+        const int rdst = second ? rbase - a.split : rbase;
+        if (accum && rbase < a.rs_rows) {
+            const float* sp = src + (size_t)rdst * a.dst_ld + a.dst_pad + min(n, a.L - 1);
+            const int rlast = a.rs_rows - 1 - rbase;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) old[j][r] = sp[(size_t)min((r & 3) + 8 * (r >> 2) + 4 * lhi, rlast) * a.dst_ld];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) old[j][r] = 0.0f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rsw[k] = *reinterpret_cast<const k_f32x4*>(a.rs_wT + t * 4 + k * 1024);
+    const float bias_pre = t < S_BM ? a.bias[t] : 0.0f;
+    const float rsb_pre = t < 128 ? a.rs_bias[t] : 0.0f;
+
+    // segment table, then chunk -> B address (as in the other shapes)
+#pragma unroll
+    for (int sidx = 0; sidx < GEMM_MAX_SEG; ++sidx) {
+        if (sidx < SEGS && t == sidx) {
+            const GemmSeg& g = a.seg[sidx];
+            unsigned int* e = reinterpret_cast<unsigned int*>(lds + K_SEGTAB + sidx * 4);
+            if (sidx < a.nseg) {
+                const float* base = g.base + (size_t)b * g.bstride + (a.pad + n0 + g.shift);
+                const unsigned long long u = reinterpret_cast<unsigned long long>(base);
+                e[0] = (unsigned int)u; e[1] = (unsigned int)(u >> 32); e[2] = (unsigned int)g.nch;
+            } else {
+                e[0] = 0; e[1] = 0; e[2] = 0x7fffffffu;
+            }
+            e[3] = 0;
+        }
+    }
+    __syncthreads();
+    {
+        unsigned long long* tab = reinterpret_cast<unsigned long long*>(lds + K_CHTAB);
+        const int ilv0 = a.interleave > 1 ? a.interleave : 0;
+        const int n_il = ilv0 * a.seg[0].nch;
+        for (int c0 = t; c0 < a.nch_total; c0 += 256) {
+            int c = c0, sg, loc;
+            if (c < n_il) {
+                sg = c % ilv0;
+                loc = c / ilv0;
+            } else {
+                c -= n_il;
+                sg = ilv0;
+                for (int k = 0; k < SEGS - 1; ++k) {
+                    const int nck = (int)reinterpret_cast<const unsigned int*>(lds + K_SEGTAB + k * 4)[2];
+                    if (sg == k && k < a.nseg - 1 && c >= nck) { c -= nck; sg = k + 1; }
+                }
+                loc = c;
+            }
+            const unsigned int* e = reinterpret_cast<const unsigned int*>(lds + K_SEGTAB + sg * 4);
+            const unsigned long long base = ((unsigned long long)e[1] << 32) | e[0];
+            tab[c0] = base + (unsigned long long)loc * GEMM_KC * a.ld * sizeof(float);
+        }
+    }
+    __syncthreads();
+
+    // DMA pieces of a chunk: A [16][128] = 8 pieces of 1 KiB (this wave: pieces wave, wave + 4), B [16][64] = 4 pieces (piece
+    // wave = k-rows 4 wave .. +4: k-row 4 wave + (lane >> 4), columns 4 (lane & 15)).  Slot cs = 2 stage + chunk parity.
+    const gfloat_ptr a_base = (gfloat_ptr)(a.A + (size_t)a.a_ch_off * S_ASTAGE + wave * 256 + lane * 4);
+    const size_t b_off = (size_t)(4 * wave + (lane >> 4)) * a.ld + (lane & 15) * 4;
+    const unsigned lds0 = (unsigned)(size_t)(lds_fptr)lds;
+#define K_ISSUE_A(cs, c, p)                                                                                      \
+    __builtin_amdgcn_global_load_lds(a_base + (size_t)(c) * S_ASTAGE + (p) * 1024,                                \
+                                     (lds_fptr)(lds + (cs) * K_CHUNK + wave * 256 + (p) * 1024), 16, 0, 0)
+#define K_ISSUE_B_AT(cs, ub)                                                                                     \
+    do {                                                                                                         \
+        const unsigned long long ub_ = (ub);                                                                     \
+        const unsigned long long us_ =                                                                           \
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |             \
+            (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                                  \
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off,                               \
+                                         (lds_fptr)(lds + (cs) * K_CHUNK + S_ASTAGE + wave * 256), 16, 0, 0);    \
+    } while (0)
+    const unsigned long long* ctab = reinterpret_cast<const unsigned long long*>(lds + K_CHTAB);
+    const int nch = a.nch_total;
+    const int npairs = (nch + 1) / 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {                            // pairs 0 and 1 (chunks past the end: a copy of the last one)
+        const int ce = min(2 * j, nch - 1), co = min(2 * j + 1, nch - 1);
+        K_ISSUE_A(2 * j, ce, 0); K_ISSUE_A(2 * j, ce, 1); K_ISSUE_B_AT(2 * j, ctab[ce]);
+        K_ISSUE_A(2 * j + 1, co, 0); K_ISSUE_A(2 * j + 1, co, 1); K_ISSUE_B_AT(2 * j + 1, ctab[co]);
+    }
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    // hand-scheduled loop over PAIRS (gemm_f32_small.hip above: counted LDS waits, MFMA stream through the pair boundary);
+    // this wave reads the chunk of parity kh; six DMA pieces per wave and pair
+    typedef float k_f32x2 __attribute__((ext_vector_type(2)));
+    k_f32x2 a02[2], a13[2];
+    float bq[2];
+    const unsigned a_lane = lds0 + (unsigned)((kh * K_CHUNK + lhi * S_BM + l31) * 4);
+    const unsigned b_lane = lds0 + (unsigned)((kh * K_CHUNK + S_ASTAGE + lhi * K_BN + wn * 32 + l31) * 4);
+#define K_READ_AT(ks, aaddr, baddr)                                                                              \
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(a02[(ks) & 1]) : "v"(aaddr), "n"(4 * (ks)), "n"(4 * (ks) + 1)); \
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(a13[(ks) & 1]) : "v"((aaddr) + 128u), "n"(4 * (ks)), "n"(4 * (ks) + 1)); \
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bq[(ks) & 1]) : "v"(baddr), "n"(2 * (ks) * K_BN * 4));
+#define K_WAIT(n_, ks) asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(a02[(ks) & 1]), "+v"(a13[(ks) & 1]), "+v"(bq[(ks) & 1]));
+#define K_MFMA(ks)                                                                                               \
+    if (active) {                                                                                                \
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a02[(ks) & 1][0], bq[(ks) & 1], acc[0], 0, 0, 0);           \
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a13[(ks) & 1][0], bq[(ks) & 1], acc[1], 0, 0, 0);           \
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a02[(ks) & 1][1], bq[(ks) & 1], acc[2], 0, 0, 0);           \
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a13[(ks) & 1][1], bq[(ks) & 1], acc[3], 0, 0, 0);           \
+    }
+    K_READ_AT(0, a_lane, b_lane)
+    int cur = 0;
+    for (int i = 0; i < npairs; ++i) {
+        const bool active = 2 * i + kh < nch;               // an odd chunk count leaves the last pair's odd half empty
+        const int nxt = cur == 2 ? 0 : cur + 1;
+        const unsigned aa = a_lane + (unsigned)(cur * K_STAGE * 4), ba = b_lane + (unsigned)(cur * K_STAGE * 4);
+        const unsigned an = a_lane + (unsigned)(nxt * K_STAGE * 4), bn = b_lane + (unsigned)(nxt * K_STAGE * 4);
+        const int nb = cur >= 1 ? cur - 1 : 2;              // (cur + 2) % 3: the stage pair i - 1 occupied
+        const int ne = min(2 * (i + 2), nch - 1), no = min(2 * (i + 2) + 1, nch - 1);
+        unsigned long long ub_e, ub_o;
+        asm volatile("ds_read_b64 %0, %1" : "=v"(ub_e) : "v"((unsigned)(lds0 + K_CHTAB * 4 + ne * 8)));
+        asm volatile("ds_read_b64 %0, %1" : "=v"(ub_o) : "v"((unsigned)(lds0 + K_CHTAB * 4 + no * 8)));
+        // outstanding: k-step 0 (3 instructions) and the two table entries
+        K_READ_AT(1, aa, ba) K_WAIT(5, 0) K_MFMA(0) K_ISSUE_A(2 * nb, ne, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        K_READ_AT(2, aa, ba) K_WAIT(3, 1)                   // (covers the older table entries)
+        asm volatile("" : "+v"(ub_e), "+v"(ub_o));
+        K_MFMA(1) K_ISSUE_A(2 * nb, ne, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        K_READ_AT(3, aa, ba) K_WAIT(3, 2) K_MFMA(2) K_ISSUE_B_AT(2 * nb, ub_e);
+        __builtin_amdgcn_sched_barrier(0);
+        K_READ_AT(4, aa, ba) K_WAIT(3, 3) K_MFMA(3) K_ISSUE_A(2 * nb + 1, no, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        K_READ_AT(5, aa, ba) K_WAIT(3, 4) K_MFMA(4) K_ISSUE_A(2 * nb + 1, no, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        K_READ_AT(6, aa, ba) K_WAIT(3, 5) K_MFMA(5) K_ISSUE_B_AT(2 * nb + 1, ub_o);
+        __builtin_amdgcn_sched_barrier(0);
+        K_READ_AT(7, aa, ba) K_WAIT(3, 6) K_MFMA(6)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // pair i + 1 landed, the newest still in flight
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        K_READ_AT(0, an, bn)
+        K_WAIT(3, 7) K_MFMA(7)
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a02[0]), "+v"(a13[0]), "+v"(bq[0]));
+#undef K_READ_AT
+#undef K_WAIT
+#undef K_MFMA
+#undef K_ISSUE_A
+#undef K_ISSUE_B_AT
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if (kh == 1) {
+        float* red = lds + K_RED + wn * 4096 + lane;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(mt * 16 + r) * 64] = acc[mt][r];
+    }
+    if (t < S_BM) { lds[K_BIAS + t] = bias_pre; lds[K_BIAS + 128 + t] = rsb_pre; }
+    __syncthreads();
+    float actv[2][16];
+    if (kh == 0) {
+        const float* red = lds + K_RED + wn * 4096 + lane;
+        float* act = lds + K_ACT + wn * 2048 + lane;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const bool ok = mt * 32 + row < a.pairC;
+                float u0 = (acc[mt][r] + red[(mt * 16 + r) * 64]) + lds[K_BIAS + mt * 32 + row];
+                float u1 = (acc[mt + 2][r] + red[((mt + 2) * 16 + r) * 64]) + lds[K_BIAS + 64 + mt * 32 + row];
+                if (a.addend) {                            // uniform; columns >= L of a padded row are readable
+                    const float* ad = a.addend + (size_t)b * a.addend_bstride + a.addend_pad + n;
+                    const int c = min(mt * 32 + row, a.pairC - 1);
+                    u0 += ad[(size_t)c * a.addend_ld];
+                    u1 += ad[(size_t)(a.pairC + c) * a.addend_ld];
+                }
+                actv[mt][r] = ok ? s_fast_tanh(u0) * s_fast_sigmoid(u1) : 0.0f;
+                act[(mt * 16 + r) * 64] = actv[mt][r];
+            }
+    }
+    __syncthreads();                                       // partial accumulators consumed, gated tile published
+#pragma unroll
+    for (int k = 0; k < 8; ++k) *reinterpret_cast<k_f32x4*>(lds + K_RED + t * 4 + k * 1024) = rsw[k];
+    if (kh == 1) {
+        const float* act = lds + K_ACT + wn * 2048 + lane;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) actv[mt][r] = act[(mt * 16 + r) * 64];
+    }
+    __syncthreads();
+    // res/skip GEMM on the gated tile, rows split between the K halves: row tiles 2 kh and 2 kh + 1
+    f32x16 acc2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[j][r] = 0.0f;
+#pragma unroll
+    for (int s2 = 0; s2 < 32; ++s2) {
+        const int r = s2 & 15;
+        const int ch = (s2 >> 4) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        float w2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) w2[j] = lds[K_RED + ch * 128 + (2 * kh + j) * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[j], actv[s2 >> 4][r], acc2[j], 0, 0, 0);
+    }
+    const float* rbias = lds + K_BIAS + 128;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rbase = (2 * kh + j) * 32;
+        if (rbase >= a.rs_rows) continue;
+        const bool second = rbase >= a.split;
+        float* dst = second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride;
+        const int rdst = second ? rbase - a.split : rbase;
+        if (n < a.L) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const float v = acc2[j][r] + rbias[rbase + row] + old[j][r];
+                if (rbase + row < a.rs_rows) dst[(size_t)(rdst + row) * a.dst_ld + a.dst_pad + n] = v;
+            }
+        }
+    }
+}
+
 template <int EPI, int XS>
 void launch_small_xs(dim3 grid, hipStream_t stream, const GemmArgs& a, int ntiles_s) {
     if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_small_kernel<EPI, 4, XS>), grid, dim3(256), 0, stream, a, ntiles_s);
@@ -796,6 +1082,24 @@ bool gemm_f32_small_applies(int epi, const GemmArgs& a) {
 }
 
 int launch_gemm_f32_small(int epi, const GemmArgs& a, hipStream_t stream) {
+    if (epi == GEMM_EPI_GATE_RS && !tuning().f32_no_splitk && (long long)a.ntiles * a.batch <= GATE_RS_SPLITK_MAX_BLOCKS) {
+        const int nt = (a.L + K_BN - 1) / K_BN;
+        const long long nblk = (long long)nt * a.batch;
+        CTTS_CHECK_ARG(nblk > 0 && nblk < (1ll << 31), "gemm (split-K fused shape): grid %lld", nblk);
+        constexpr size_t LDS = K_LDS_FLOATS * sizeof(float);         // above the 64 KiB default: opt in once per kernel
+        static bool attr_set[2] = {false, false};
+        const int vi = a.nseg <= 4 ? 0 : 1;
+        if (!attr_set[vi]) {
+            const void* fn = vi == 0 ? reinterpret_cast<const void*>(conv_gemm_f32_gate_rs_splitk_kernel<4>)
+                                     : reinterpret_cast<const void*>(conv_gemm_f32_gate_rs_splitk_kernel<GEMM_MAX_SEG>);
+            CTTS_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+            attr_set[vi] = true;
+        }
+        if (vi == 0) hipLaunchKernelGGL((conv_gemm_f32_gate_rs_splitk_kernel<4>), dim3((unsigned)nblk), dim3(256), LDS, stream, a, nt);
+        else hipLaunchKernelGGL((conv_gemm_f32_gate_rs_splitk_kernel<GEMM_MAX_SEG>), dim3((unsigned)nblk), dim3(256), LDS, stream, a, nt);
+        CTTS_CHECK_LAUNCH("conv_gemm_f32_gate_rs_splitk");
+        return CTTS_OK;
+    }
     if (epi == GEMM_EPI_GATE_RS) {
         const int nt = (a.L + R_BN - 1) / R_BN;
         const long long nblk = (long long)nt * a.batch;

@@ -32,8 +32,10 @@ def test_config2_waveglow_full_size_properties(hip_lib_path):
     assert rms_rel_err(cut[:, :n].cpu().numpy(), full[:2, :n].cpu().numpy()) < 1e-5
 
 
-def test_config4_waveflow_full_size_properties(hip_lib_path):
-    """Config 4: 8 flows x 64 channels, n_group 16, B = 8 x (80 x 900) mel."""
+def test_config4_waveflow_full_size_properties(hip_lib_path, tuning):
+    """Config 4: 8 flows x 64 channels, n_group 16, B = 8 x (80 x 900) mel.  One utterance alone equals its row in the
+    batch BIT FOR BIT as long as both run a shape with the same K order (the 128 x 256 / 128 x 128 shapes); the batch-1
+    default is the split-K shape, which sums (even chunks) + (odd chunks): equal to fp32 summation noise."""
     from cookietts_amd import WaveFlow
     cfg = synthetic.WAVEFLOW_CONFIGS["full"]
     m = WaveFlow(**cfg)
@@ -47,6 +49,12 @@ def test_config4_waveflow_full_size_properties(hip_lib_path):
     assert full.shape == (B, (F - 1) * 256) and torch.isfinite(full).all()
     again, _ = m.inverse(z, mel, return_CPU=False)
     assert torch.equal(full, again)
+    for b in (0, 7):
+        one, _ = m.inverse(z[b:b + 1], mel[b:b + 1], return_CPU=False)
+        d = rms_rel_err(one[0].cpu().numpy(), full[b].cpu().numpy())
+        print(f"config 4, utterance {b} alone (split-K shape) vs in the batch of 8: rms rel diff {d:.3e}")
+        assert d < 5e-6
+    tuning.set("CTTS_F32_NO_SPLITK")
     for b in (0, 7):
         one, _ = m.inverse(z[b:b + 1], mel[b:b + 1], return_CPU=False)
         assert torch.equal(one[0], full[b])

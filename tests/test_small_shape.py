@@ -107,10 +107,11 @@ def test_waveglow_and_stft_small_shape_is_bit_identical(hip_lib_path, tuning):
 
 
 @pytest.mark.parametrize("name", ["toy", "full_short", "toy_dilations_h"])
-def test_waveflow_fused_layer_small_shape_is_bit_identical(hip_lib_path, tuning, name):
-    """The fused WaveFlow layer (GATE_RS: dilated 2-D conv GEMM + gate + res/skip GEMM in one launch) in its small shape
-    (128 x 128 blocks, 128 x 32 wave tiles; the default below 256 large blocks) against the 128 x 256 shape, and the
-    large shape against the reference golden."""
+def test_waveflow_fused_layer_small_shapes(hip_lib_path, tuning, name):
+    """The fused WaveFlow layer (GATE_RS: dilated 2-D conv GEMM + gate + res/skip GEMM in one launch) in its three shapes:
+    the 128 x 128 shape (128 x 32 wave tiles) is BIT-IDENTICAL to the 128 x 256 one; the split-K shape (128 x 64 blocks,
+    the K halves on wave pairs: the default at this size) sums (even chunks) + (odd chunks) and agrees to fp32 summation
+    noise; every shape meets the reference golden."""
     from cookietts_amd import WaveFlow
     g = np.load(os.path.join(GOLDEN, f"waveflow_{name}.npz"))
     cfg = synthetic.WAVEFLOW_CONFIGS[str(g["config_key"])]
@@ -118,13 +119,17 @@ def test_waveflow_fused_layer_small_shape_is_bit_identical(hip_lib_path, tuning,
     m.load_state_dict(synthetic.to_torch(synthetic.waveflow_state_dict(cfg, seed=int(g["seed"]))))
     m = m.cuda().eval()
     z, mel = torch.from_numpy(g["z"]).cuda(), torch.from_numpy(np.pad(g["mel"], ((0, 0), (0, 0), (0, 1)))).cuda()
+    splitk, _ = m.inverse(z, mel, return_CPU=False)
+    tuning.set("CTTS_F32_NO_SPLITK")
     small, _ = m.inverse(z, mel, return_CPU=False)
     tuning.set("CTTS_F32_NO_SMALL")
     big, _ = m.inverse(z, mel, return_CPU=False)
     assert torch.equal(small, big)
-    err = rms_rel_err(big.cpu().numpy(), g["inverse_full"])
-    print(f"waveflow {name}: large shape forced, rms rel err vs reference = {err:.3e}")
-    assert err < 1e-3
+    assert not torch.equal(splitk, big)                      # the split-K shape really ran
+    d = rms_rel_err(splitk.cpu().numpy(), big.cpu().numpy())
+    err, err_sk = rms_rel_err(big.cpu().numpy(), g["inverse_full"]), rms_rel_err(splitk.cpu().numpy(), g["inverse_full"])
+    print(f"waveflow {name}: rms rel err vs reference: large shape {err:.3e}, split-K shape {err_sk:.3e}; split-K vs large {d:.3e}")
+    assert err < 1e-3 and err_sk < 1e-3 and d < 5e-6
 
 
 def test_small_shape_in_split_bf16_mode_is_bit_identical(hip_lib_path, tuning):
