@@ -30,7 +30,7 @@ namespace {
 
 constexpr int STAGE = GEMM_KC * (256 + 128);            // 6144 floats = 24 KiB for both shapes
 // (the segment table, GEMM_MAX_SEG x 4 dwords, sits behind the last stage)
-constexpr int GEMM_GLDS_MAX_CHUNKS = 256;               // DMA-staged kernels: chunk address table entries
+constexpr int GEMM_GLDS_MAX_CHUNKS = 384;               // DMA-staged kernels: chunk address table entries
 
 // Gate math on the hardware transcendental unit: exp via v_exp_f32 (2^x), reciprocal via
 // v_rcp_f32 (1 ulp).  Absolute error of tanh/sigmoid <= ~3e-7, far inside the parity budget.

@@ -29,7 +29,9 @@ namespace {
 constexpr int S_BM = 128, S_BN = 64;
 constexpr int S_ASTAGE = GEMM_KC * S_BM;                 // 2048 floats
 constexpr int S_STAGE = GEMM_KC * (S_BM + S_BN);         // 3072 floats = 12 KiB
-constexpr int S_MAX_CHUNKS = 256;                        // chunk -> B address table entries (same bound as gemm_f32.hip)
+constexpr int S_MAX_CHUNKS = 384;                        // chunk -> B address table entries (same bound as gemm_f32.hip): 40 128 B of
+                                                         // LDS per block still lets four blocks share a CU; the k = 5 cond convs
+                                                         // of the author's WaveFlow stack are 290 chunks
 constexpr int S_NST = 3;
 // the fused WaveFlow layer takes the small shape below this many 128 x 256 blocks (set from the B = 1 / 2 / 8 measurements)
 constexpr long long GATE_RS_SMALL_BELOW_BLOCKS = 256;
@@ -782,7 +784,7 @@ constexpr int K_STAGE = 2 * K_CHUNK;                     // a pair of chunks
 constexpr int K_NST = 3;
 constexpr int K_SEGTAB = K_NST * K_STAGE;
 constexpr int K_CHTAB = K_SEGTAB + GEMM_MAX_SEG * 4;
-constexpr int K_LDS_FLOATS = K_CHTAB + 2 * S_MAX_CHUNKS; // 75 968 B: dynamic LDS, two workgroups per CU
+constexpr int K_LDS_FLOATS = K_CHTAB + 2 * S_MAX_CHUNKS; // 77 KB: dynamic LDS, two workgroups per CU
 constexpr int K_RED = 0;                                 // epilogue: [2 wn][64][64] partial accumulators, then the res/skip weights
 constexpr int K_ACT = 8192;                              //           [2 wn][32][64] gated tile
 constexpr int K_BIAS = 12288;                            //           128 in-layer + 128 res/skip biases

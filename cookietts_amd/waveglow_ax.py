@@ -203,6 +203,13 @@ class _CondConv:
         if padding_mode == 'replicate' and k > 1:      # edge values into the halo the taps reach (nn.Conv1d padding_mode)
             _lib.check(_lib.lib().ctts_replicate_halo_f32(_lib.ptr(x), B, x.shape[1], T, ld, PAD, k // 2, stream),
                        "ctts_replicate_halo_f32")
+        if (not self.sigmoid and x.shape[1] == self.c_in and y.shape[1] == self.c_out
+                and tuple(x.stride()) == (self.c_in * ld, ld, 1) and tuple(y.stride()) == (self.c_out * ld, ld, 1)):
+            # both buffers have exactly the operator's row counts: the dense [batch][c][ld] strides of the primitive hold
+            # for the whole batch, one launch (B x the workgroups) instead of B
+            _lib.check(_lib.lib().ctts_conv1d_f32(C.byref(self.desc), _lib.ptr(self.blob), _lib.ptr(x), _lib.ptr(y),
+                                                 0, B, T, ld, PAD, stream), "ctts_conv1d_f32")
+            return
         for b in range(B):
             _lib.check(_lib.lib().ctts_conv1d_f32(C.byref(self.desc), _lib.ptr(self.blob), _lib.ptr(x[b]), _lib.ptr(y[b]),
                                                  0, 1, T, ld, PAD, stream), "ctts_conv1d_f32")
