@@ -31,6 +31,7 @@ constexpr int SM = 256;            // GEMM rows (2C)
 constexpr int SKC = 16;            // K rows per A stage
 constexpr int TILE_F = SC * SN;    // 8192 floats: depthwise tile, later the gated tile
 constexpr int ASTG_F = SKC * SM;   // 4096 floats
+constexpr size_t SEP_LDS_BYTES = (size_t)(TILE_F + 2 * ASTG_F + 2 * SM) * sizeof(float);   // 67 584 B: two workgroups per CU
 
 __device__ __forceinline__ float sep_sigmoid(float u) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f));
@@ -122,11 +123,98 @@ __device__ __forceinline__ void tile_gemm(f32x16 (&acc)[2][2], const float* __re
     }
 }
 
+
+// ---- fp32 main loop, DMA-staged and hand-scheduled (second half of round 3) ------------------------------------------
+// Same contraction as tile_gemm<false>, but: A chunks go global -> LDS by DMA into TWO stages (no register round trip, no
+// ds_write), one barrier per chunk, fragment reads and their waits written by hand (hipcc waits for every LDS result with
+// lgkmcnt(0) once LDS-DMA is in the loop; LDS returns in order, so "k-step ks is here" = lgkmcnt(4), the four reads issued
+// behind it), and the MFMA stream runs through the chunk boundary: wait-for-landing + barrier of chunk ch + 1 sit in front of
+// the last k-step of chunk ch, the DMA of chunk ch + 2 (into the stage just released) and the first fragments of chunk
+// ch + 1 are issued right behind them.  Split in two so that the caller can put its own loads between the first DMAs and
+// the loop (in-order return: anything issued BEFORE the DMAs would be waited for by the first vmcnt).
+typedef const __attribute__((address_space(1))) float* sep_gptr;
+typedef __attribute__((address_space(3))) float* sep_lptr;
+struct SepFrag { float a0[2], a1[2], b0[2], b1[2]; };
+
+#define SEP_ISSUE(ch_, st_)                                                                                      \
+    _Pragma("unroll") for (int p_ = 0; p_ < 4; ++p_)                                                             \
+        __builtin_amdgcn_global_load_lds((sep_gptr)(Ag + (size_t)(ch_) * ASTG_F + (w + 4 * p_) * 256 + lane * 4), \
+                                         (sep_lptr)(As + (st_) * ASTG_F + (w + 4 * p_) * 256), 16, 0, 0);
+#define SEP_READ(ks, aaddr, baddr)                                                                               \
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.a0[(ks) & 1]) : "v"(aaddr), "n"((ks) * 2 * SM * 4));   \
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.a1[(ks) & 1]) : "v"(aaddr), "n"((ks) * 2 * SM * 4 + 128)); \
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.b0[(ks) & 1]) : "v"(baddr), "n"((ks) * 2 * SN * 4));   \
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.b1[(ks) & 1]) : "v"(baddr), "n"((ks) * 2 * SN * 4 + 128));
+#define SEP_WAIT(n_, ks)                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(f.a0[(ks) & 1]), "+v"(f.a1[(ks) & 1]), "+v"(f.b0[(ks) & 1]), "+v"(f.b1[(ks) & 1]));
+#define SEP_MFMA(ks)                                                                                             \
+    if (active) {                                                                                                \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[(ks) & 1], f.b0[(ks) & 1], acc[0][0], 0, 0, 0);     \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[(ks) & 1], f.b1[(ks) & 1], acc[0][1], 0, 0, 0);     \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[(ks) & 1], f.b0[(ks) & 1], acc[1][0], 0, 0, 0);     \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[(ks) & 1], f.b1[(ks) & 1], acc[1][1], 0, 0, 0);     \
+    }
+
+// chunks 0 and 1 on their way (8 DMA instructions per wave outstanding when this returns)
+__device__ __forceinline__ void sep_gemm_issue(const float* __restrict__ Ag, float* As, int w, int lane) {
+    SEP_ISSUE(0, 0)
+    SEP_ISSUE(1, 1)
+}
+
+// EXTRA_VM = vector-memory instructions the caller issued AFTER sep_gemm_issue (they return behind chunk 1)
+template <int EXTRA_VM>
+__device__ __forceinline__ void sep_gemm_run(f32x16 (&acc)[2][2], const float* __restrict__ Ag, float* As, const float* Bs,
+                                             int w, int lane, int l31, int lhi, bool active) {
+    SepFrag f;
+    const unsigned a_lane = (unsigned)(size_t)(sep_lptr)As + (unsigned)((lhi * SM + 64 * w + l31) * 4);
+    const unsigned b_lane = (unsigned)(size_t)(sep_lptr)const_cast<float*>(Bs) + (unsigned)((lhi * SN + l31) * 4);
+    if constexpr (EXTRA_VM + 4 <= 63) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EXTRA_VM + 4) : "memory");   // chunk 0 landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    SEP_READ(0, a_lane, b_lane)
+#pragma unroll 1
+    for (int ch = 0; ch < SC / SKC; ++ch) {
+        const int st = ch & 1;
+        const unsigned aa = a_lane + (unsigned)(st * ASTG_F * 4), ba = b_lane + (unsigned)(ch * SKC * SN * 4);
+        const unsigned an = a_lane + (unsigned)((st ^ 1) * ASTG_F * 4), bn = b_lane + (unsigned)((ch + 1) * SKC * SN * 4);
+        SEP_READ(1, aa, ba) SEP_WAIT(4, 0) SEP_MFMA(0)
+        __builtin_amdgcn_sched_barrier(0);
+        SEP_READ(2, aa, ba) SEP_WAIT(4, 1) SEP_MFMA(1)
+        __builtin_amdgcn_sched_barrier(0);
+        SEP_READ(3, aa, ba) SEP_WAIT(4, 2) SEP_MFMA(2)
+        __builtin_amdgcn_sched_barrier(0);
+        SEP_READ(4, aa, ba) SEP_WAIT(4, 3) SEP_MFMA(3)
+        __builtin_amdgcn_sched_barrier(0);
+        SEP_READ(5, aa, ba) SEP_WAIT(4, 4) SEP_MFMA(4)
+        __builtin_amdgcn_sched_barrier(0);
+        SEP_READ(6, aa, ba) SEP_WAIT(4, 5) SEP_MFMA(5)
+        __builtin_amdgcn_sched_barrier(0);
+        SEP_READ(7, aa, ba) SEP_WAIT(4, 6) SEP_MFMA(6)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // chunk ch + 1 landed (and whatever the caller slipped in)
+        __builtin_amdgcn_s_barrier();                       // ... for everyone; all reads of this stage have been issued
+        __builtin_amdgcn_sched_barrier(0);
+        if (ch + 2 < SC / SKC) { SEP_ISSUE(ch + 2, st) }
+        SEP_READ(0, an, bn)                                 // (past the last chunk: valid LDS, never used)
+        SEP_WAIT(4, 7) SEP_MFMA(7)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.a0[0]), "+v"(f.a1[0]), "+v"(f.b0[0]), "+v"(f.b1[0]));
+    __syncthreads();                                        // nobody reads Bs or the A stages any more
+}
+#undef SEP_ISSUE
+#undef SEP_READ
+#undef SEP_WAIT
+#undef SEP_MFMA
+
 template <bool X3>
 __global__ __launch_bounds__(256, 2) void wf_sep_layer_kernel(const WfSepArgs a) {
-    __shared__ __attribute__((aligned(16))) float tile[TILE_F];
-    __shared__ __attribute__((aligned(16))) float As[ASTG_F];
-    __shared__ float bias1[SM], bias2[SM];
+    extern __shared__ __attribute__((aligned(16))) float sep_lds[];     // SEP_LDS_BYTES: tile | two A stages | biases
+    float* tile = sep_lds;
+    float* As = tile + TILE_F;
+    float* bias1 = As + 2 * ASTG_F;
+    float* bias2 = bias1 + SM;
 
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -173,7 +261,12 @@ __global__ __launch_bounds__(256, 2) void wf_sep_layer_kernel(const WfSepArgs a)
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    tile_gemm<X3>(acc, a.A1, As, tile, t, w, l31, lhi, true);
+    if constexpr (X3) {
+        tile_gemm<X3>(acc, a.A1, As, tile, t, w, l31, lhi, true);
+    } else {
+        sep_gemm_issue(a.A1, As, w, lane);
+        sep_gemm_run<0>(acc, a.A1, As, tile, w, lane, l31, lhi, true);
+    }
     // (tile_gemm ends with a barrier: nobody reads the depthwise tile any more)
 #define CTTS_SEP_GATE(EXPR)                                                                                  \
     _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                        \
@@ -205,28 +298,46 @@ __global__ __launch_bounds__(256, 2) void wf_sep_layer_kernel(const WfSepArgs a)
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    tile_gemm<X3>(acc, a.A2, As, tile, t, w, l31, lhi, active);
-    if (!active) return;
-
-    // ---- phase 5: rows < split -> x_{i+1} = x_i + res, rows >= split -> out (+)= skip.  All loads of a row tile
-    // before its first store (one memory latency per tile, and the two destinations may alias nothing here).
+    // rows < split -> x_{i+1} = x_i + res, rows >= split -> out (+)= skip: the old values of this wave's two row tiles
+    // (64 registers, the ones the conditioning addend occupied until the gate) are requested together with the first A
+    // chunks of the second GEMM instead of behind it
     const int split = a.rs_rows == SM ? SC : 0;
+    float old[2][2][16];
+    auto load_old = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int rbase = 64 * w + 32 * mt;
+            const bool second = rbase >= split;
+            const float* src = (second ? a.out : a.xin) + bofs;
+            const bool accum = second ? a.acc_out != 0 : true;
+            const int rdst = second ? rbase - split : rbase;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    old[mt][nt][r] = (accum && active) ? src[(size_t)(rdst + rr) * a.ld + a.pad + n0 + 32 * nt + l31] : 0.0f;
+                }
+        }
+    };
+    if constexpr (X3) {
+        tile_gemm<X3>(acc, a.A2, As, tile, t, w, l31, lhi, active);
+        if (!active) return;
+        load_old();
+    } else {
+        load_old();                                         // in flight together with the first A chunks (loads return in
+        sep_gemm_issue(a.A2, As, w, lane);                  // order: issued behind the DMAs they would need a wait count of
+        sep_gemm_run<0>(acc, a.A2, As, tile, w, lane, l31, lhi, active);   // 68, two more than the counter has)
+        if (!active) return;
+    }
+
+    // ---- phase 5: stores
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int rbase = 64 * w + 32 * mt;
         const bool second = rbase >= split;
         float* dst = (second ? a.out : a.xout) + bofs;
-        const float* src = (second ? a.out : a.xin) + bofs;
-        const bool accum = second ? a.acc_out != 0 : true;
         const int rdst = second ? rbase - split : rbase;
-        float old[2][16];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                old[nt][r] = accum ? src[(size_t)(rdst + rr) * a.ld + a.pad + n0 + 32 * nt + l31] : 0.0f;
-            }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int n = n0 + 32 * nt + l31;
@@ -234,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void wf_sep_layer_kernel(const WfSepArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rr = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    dst[(size_t)(rdst + rr) * a.ld + a.pad + n] = acc[mt][nt][r] + bias2[rbase + rr] + old[nt][r];
+                    dst[(size_t)(rdst + rr) * a.ld + a.pad + n] = acc[mt][nt][r] + bias2[rbase + rr] + old[mt][nt][r];
                 }
             }
         }
@@ -273,8 +384,14 @@ int launch_wf_sep_pack(const float* pw_w, const float* pw_b, const float* rs_w, 
 int launch_wf_sep_layer(const WfSepArgs& a, int batch, hipStream_t s) {
     CTTS_CHECK_ARG(a.L <= a.ntiles * SN && a.ntiles * SN + a.pad <= a.ld && a.pad % 4 == 0 && a.ld % 4 == 0 && a.dwout &&
                    a.cond && a.xin && a.out, "wf_sep_layer: geometry L=%d ld=%d pad=%d", a.L, a.ld, a.pad);
-    if (a.split_bf16) hipLaunchKernelGGL(wf_sep_layer_kernel<true>, dim3((unsigned)(a.ntiles * batch)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(wf_sep_layer_kernel<false>, dim3((unsigned)(a.ntiles * batch)), dim3(256), 0, s, a);
+    static bool attr_set = false;                           // 67 584 B of dynamic LDS: above the 64 KiB default, opt in once
+    if (!attr_set) {
+        CTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_sep_layer_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEP_LDS_BYTES));
+        CTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_sep_layer_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEP_LDS_BYTES));
+        attr_set = true;
+    }
+    if (a.split_bf16) hipLaunchKernelGGL(wf_sep_layer_kernel<true>, dim3((unsigned)(a.ntiles * batch)), dim3(256), SEP_LDS_BYTES, s, a);
+    else hipLaunchKernelGGL(wf_sep_layer_kernel<false>, dim3((unsigned)(a.ntiles * batch)), dim3(256), SEP_LDS_BYTES, s, a);
     CTTS_CHECK_LAUNCH("wf_sep_layer");
     return CTTS_OK;
 }
