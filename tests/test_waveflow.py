@@ -204,3 +204,23 @@ def test_author_full_width_fused_1x1_stages_vs_oracle(hip_lib_path, tuning):
     tuning.clear("CTTS_WF_NO_FUSE")
     assert rms_rel_err(plain.numpy(), ref) < WAVE_TOL
     assert rms_rel_err(got.numpy(), plain.numpy()) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["author_toy", "author_toy_gate"])
+def test_author_options_under_the_split_gemm_modes(hip_lib_path, name):
+    """The author's option set (separable in-layers: the fused pointwise + res/skip kernel of waveflow_sep.hip, conditioning
+    stacks, speaker embeddings) under the split-bf16 GEMM loops: three products stay far inside the waveform bound, six
+    products (the fused separable layer keeps fp32 MFMA there, the conv-GEMMs around it take the six-product loop) stay
+    within 2x of the fp32 MFMA path's error."""
+    g, cfg, _ = _load(name)
+    m, _, _ = _model(str(g["config_key"]), int(g["seed"]))
+    melp = torch.from_numpy(np.pad(g["mel"], ((0, 0), (0, 0), (0, 1)))).cuda()
+    ids = None if _ids(g) is None else torch.from_numpy(_ids(g)).cuda()
+    z = torch.from_numpy(g["z"]).cuda()
+    err = {}
+    for mode in ("f32", "bf16x3", "bf16x6"):
+        m.set_f32_gemm_mode(mode)
+        err[mode] = rms_rel_err(m.inverse(z, melp, speaker_ids=ids)[0].numpy(), g["inverse_full"])
+    print(f"waveflow {name}: rms rel err vs reference: fp32 MFMA {err['f32']:.3e}, bf16x3 {err['bf16x3']:.3e}, bf16x6 {err['bf16x6']:.3e}")
+    assert err["f32"] < WAVE_TOL and err["bf16x3"] < 1e-4 and err["bf16x6"] <= 2.0 * err["f32"]
