@@ -8,7 +8,7 @@
 // STFT are smaller still.
 //
 // Here a block is 128 x 64 and a wave tile 64 x 32 (2 x 1 tiles of v_mfma_f32_32x32x2_f32): four times as many wave tiles,
-// 39 KB of LDS and ~64 VGPRs per block, so four blocks share a CU and 3-4 waves a SIMD.
+// 40 KB of LDS per block, so four blocks share a CU and 3-4 waves a SIMD.
 //   * Operands are NOT repacked: a block reads one 128-row half (wave-row `half` of M-block `mb`) of the 256-row packing.
 //     For the pair epilogues that half holds [64 first-half channels | the 64 matching second-half channels]; wave wm
 //     takes rows 32 wm .. +32 (first) and 64 + 32 wm .. +32 (second), so the pairing still happens in registers.
