@@ -314,6 +314,43 @@ __global__ __launch_bounds__(256) void wf_interp_cond_kernel(const float* __rest
 }
 
 
+// Four time steps per thread, one 16-byte store (pad and ld multiples of 4): the scalar form writes its 0.8 GB per flow of the
+// author's model with 4-byte stores at 1.6 TB/s.  Same arithmetic per element.
+__global__ __launch_bounds__(256) void wf_interp_cond_vec_kernel(const float* __restrict__ frames, float* __restrict__ up,
+                                                                 int rows2c, int n_layers, int F, int f_ld, int f_pad,
+                                                                 int L, int ld, int pad, size_t slot) {
+    const int l4 = 4 * (blockIdx.x * 256 + threadIdx.x);
+    const int ch = blockIdx.y, b = blockIdx.z;
+    if (l4 >= L) return;
+    const float* src = frames + ((size_t)b * rows2c * n_layers + ch) * f_ld + f_pad;
+    const float scale = L > 1 ? (float)(F - 1) / (float)(L - 1) : 0.f;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int l = min(l4 + j, L - 1);
+        if (F == L) {
+            v[j] = src[l];
+        } else {
+            const float real = scale * (float)l;
+            const int i0 = (int)real;
+            const int i1 = i0 + 1 < F ? i0 + 1 : F - 1;
+            const float l1 = real - (float)i0;
+            const float l0 = 1.0f - l1;
+            v[j] = l0 * src[i0] + l1 * src[i1];
+        }
+    }
+    const int layer = ch / rows2c, r = ch % rows2c;
+    float* dst = up + (size_t)layer * slot + ((size_t)b * rows2c + r) * ld + pad + l4;
+    if (l4 + 3 < L) {
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (l4 + j < L) dst[j] = v[j];
+    }
+}
+
+
 // Depthwise stage of a separable in-layer (glow_ax.py:525-527: Conv2d(C, C, (kh, kw), groups=C), width dilation dw,
 // causal in height): y[b][c][l] = bias[c] + sum_{a >= a_min} sum_j w[c][a][j] * x_a[b][c][l + (j - kw/2) * dw], where
 // x_a is the ring slot of height tap a (taps a < a_min reach above the first row: zeros, skipped).
@@ -598,8 +635,12 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
         if (!p.c.mix_first && (rc = unmix(k))) return rc;                      // ax:324-325
         if (p.precond) {   // this flow's conditioning, upsampled once for all rows and layers
             const float* fr = cond + (size_t)k * batch * 2 * C * p.c.n_layers * cond_ld;
-            hipLaunchKernelGGL(wf_interp_cond_kernel, dim3((L + 255) / 256, 2 * C * p.c.n_layers, batch), dim3(256), 0, s,
-                               fr, w.cond_up, 2 * C, p.c.n_layers, frames, cond_ld, cond_pad, L, g.ld, g.pad, w.cond_slot);
+            if (g.pad % 4 == 0 && g.ld % 4 == 0 && w.cond_slot % 4 == 0)
+                hipLaunchKernelGGL(wf_interp_cond_vec_kernel, dim3(((L + 3) / 4 + 255) / 256, 2 * C * p.c.n_layers, batch), dim3(256), 0, s,
+                                   fr, w.cond_up, 2 * C, p.c.n_layers, frames, cond_ld, cond_pad, L, g.ld, g.pad, w.cond_slot);
+            else
+                hipLaunchKernelGGL(wf_interp_cond_kernel, dim3((L + 255) / 256, 2 * C * p.c.n_layers, batch), dim3(256), 0, s,
+                                   fr, w.cond_up, 2 * C, p.c.n_layers, frames, cond_ld, cond_pad, L, g.ld, g.pad, w.cond_slot);
             CTTS_CHECK_LAUNCH("wf_interp_cond");
         }
         for (int r = 0; r < Ga - 1; ++r) {
