@@ -1072,9 +1072,15 @@ bool gemm_f32_small_applies(int epi, const GemmArgs& a) {
     if (a.nch_total > S_MAX_CHUNKS) return false;
     const Tuning tune = tuning();
     if (tune.f32_no_glds || tune.f32_no_small) return false;
-    if (epi == GEMM_EPI_GATE_RS)       // fused WaveFlow layer (bm = 128, one M-block): 128 x 128 blocks of 128 x 32 wave tiles
-        return a.bm == 128 && a.MB == 1 && a.gate == GATE_GTU && !gemm_mode_is_split(a.gemm_mode) &&
-               ((long long)a.ntiles * a.batch < GATE_RS_SMALL_BELOW_BLOCKS || tune.f32_force_small);
+    if (epi == GEMM_EPI_GATE_RS) {     // fused WaveFlow layer (bm = 128, one M-block): 128 x 128 blocks of 128 x 32 wave tiles
+        if (!(a.bm == 128 && a.MB == 1 && a.gate == GATE_GTU)) return false;
+        // under the split-bf16 loops only the split-K range: there the launch is latency-bound and the fp32 split-K shape
+        // (exact products: never less accurate than what was asked for) beats the split loop of the 128 x 256 shape
+        // (config 4 at batch 1: 38.8 ms against 67 / 83 ms)
+        if (gemm_mode_is_split(a.gemm_mode))
+            return !tune.f32_no_splitk && (long long)a.ntiles * a.batch <= GATE_RS_SPLITK_MAX_BLOCKS;
+        return (long long)a.ntiles * a.batch < GATE_RS_SMALL_BELOW_BLOCKS || tune.f32_force_small;
+    }
     if (a.bm != 256) return false;
     if (!(epi == GEMM_EPI_SPLIT || epi == GEMM_EPI_GATE || epi == GEMM_EPI_GATEX || epi == GEMM_EPI_MAG || epi == GEMM_EPI_LOG ||
           epi == GEMM_EPI_LRELU || epi == GEMM_EPI_TANH))
