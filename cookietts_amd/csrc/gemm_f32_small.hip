@@ -34,6 +34,7 @@ constexpr int S_MAX_CHUNKS = 384;                        // chunk -> B address t
                                                          // of the author's WaveFlow stack are 290 chunks
 constexpr int S_NST = 3;
 // the fused WaveFlow layer takes the small shape below this many 128 x 256 blocks (set from the B = 1 / 2 / 8 measurements)
+constexpr long long SMALL_BELOW_LARGE_BLOCKS = 2048;      // generic shape: taken below this many 256 x 128 blocks
 constexpr long long GATE_RS_SMALL_BELOW_BLOCKS = 256;
 // ... and the split-K shape (128 x 64 blocks, K halves on wave pairs) up to this many 128 x 256 blocks (batch 1-2 of config 4)
 constexpr long long GATE_RS_SPLITK_MAX_BLOCKS = 128;
@@ -1085,8 +1086,11 @@ bool gemm_f32_small_applies(int epi, const GemmArgs& a) {
     if (!(epi == GEMM_EPI_SPLIT || epi == GEMM_EPI_GATE || epi == GEMM_EPI_GATEX || epi == GEMM_EPI_MAG || epi == GEMM_EPI_LOG ||
           epi == GEMM_EPI_LRELU || epi == GEMM_EPI_TANH))
         return false;
-    // fewer 256 x 128 blocks than two per CU: the large shape cannot fill the chip
-    return (long long)a.MB * a.ntiles * a.batch < 2ll * 256 || tune.f32_force_small;
+    // Below four rounds of 256 x 128 blocks (two per CU) the small shape wins since its main loop was written by hand:
+    // measured on the final tree (profiles/r3_30_shape_crossover.txt) - ax notebook B=8 (1472 large blocks) 332.9 -> 317.9 ms,
+    // untts B=4 (1104) 254.8 -> 239.9, WaveGlow 12 x 512 at B=2 (1800) 219.7 -> 209.3 and B=1 113.2 -> 109.9; from B=3 (2700
+    // blocks) on the large shape is ahead (303.5 vs 308.4 ms; headline B=8: 0.857 vs 0.783 of the MFMA peak)
+    return (long long)a.MB * a.ntiles * a.batch < SMALL_BELOW_LARGE_BLOCKS || tune.f32_force_small;
 }
 
 int launch_gemm_f32_small(int epi, const GemmArgs& a, hipStream_t stream) {

@@ -84,15 +84,15 @@ def test_waveglow_and_stft_small_shape_is_bit_identical(hip_lib_path, tuning):
     m = WaveGlow(**cfg)
     m.load_state_dict(synthetic.to_torch(synthetic.waveglow_state_dict(cfg, seed=5)))
     m = m.cuda().eval()
-    B, F = 3, 101                                           # 4 x 26 x 3 = 312 blocks... still below two per CU: the
-    mel = torch.from_numpy(synthetic.synthetic_mel(B, F, seed=6)).cuda()     # default IS the small shape here
+    B, F = 3, 101                                           # 4 x 26 x 3 = 312 blocks: the default IS the small shape here
+    mel = torch.from_numpy(synthetic.synthetic_mel(B, F, seed=6)).cuda()
     zz = torch.from_numpy(synthetic.synthetic_noise(B, 8, F * 32, seed=6) * np.float32(0.6)).cuda()
     small = m.infer_from_noise(mel, zz)
     tuning.set("CTTS_F32_NO_SMALL")
     big = m.infer_from_noise(mel, zz)
     assert torch.isfinite(big).all() and torch.equal(small, big)
     tuning.clear("CTTS_F32_NO_SMALL")
-    B, F = 8, 70                                            # 4 x 18 x 8 = 576 blocks: the large shape by default
+    B, F = 8, 300                                           # 4 x 75 x 8 = 2400 blocks: the large shape by default
     mel = torch.from_numpy(synthetic.synthetic_mel(B, F, seed=7)).cuda()
     zz = torch.from_numpy(synthetic.synthetic_noise(B, 8, F * 32, seed=7) * np.float32(0.6)).cuda()
     big = m.infer_from_noise(mel, zz)
