@@ -176,6 +176,8 @@ class _CondConv:
     """One ``ctts_conv1d`` operator of a conditioning stack: dense [out, in, k] weight, input channels zero-padded
     to the primitive's multiple of 16."""
 
+    batched = True      # one launch for the whole batch when the buffers allow it (tests turn it off to compare)
+
     def __init__(self, w, b, act, slope, device, stream, gemm_mode=0):
         lib = _lib.lib()
         out_c, in_c, k = w.shape
@@ -203,7 +205,7 @@ class _CondConv:
         if padding_mode == 'replicate' and k > 1:      # edge values into the halo the taps reach (nn.Conv1d padding_mode)
             _lib.check(_lib.lib().ctts_replicate_halo_f32(_lib.ptr(x), B, x.shape[1], T, ld, PAD, k // 2, stream),
                        "ctts_replicate_halo_f32")
-        if (not self.sigmoid and x.shape[1] == self.c_in and y.shape[1] == self.c_out
+        if (self.batched and not self.sigmoid and x.shape[1] == self.c_in and y.shape[1] == self.c_out
                 and tuple(x.stride()) == (self.c_in * ld, ld, 1) and tuple(y.stride()) == (self.c_out * ld, ld, 1)):
             # both buffers have exactly the operator's row counts: the dense [batch][c][ld] strides of the primitive hold
             # for the whole batch, one launch (B x the workgroups) instead of B

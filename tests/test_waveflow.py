@@ -224,3 +224,23 @@ def test_author_options_under_the_split_gemm_modes(hip_lib_path, name):
         err[mode] = rms_rel_err(m.inverse(z, melp, speaker_ids=ids)[0].numpy(), g["inverse_full"])
     print(f"waveflow {name}: rms rel err vs reference: fp32 MFMA {err['f32']:.3e}, bf16x3 {err['bf16x3']:.3e}, bf16x6 {err['bf16x6']:.3e}")
     assert err["f32"] < WAVE_TOL and err["bf16x3"] < 1e-4 and err["bf16x6"] <= 2.0 * err["f32"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["author_toy", "untts_toy"])
+def test_batched_conditioning_convs_equal_the_per_utterance_launches(hip_lib_path, name):
+    """The conditioning stacks run each conv as ONE launch for the batch when the buffers have the operator's exact row
+    counts; same kernel, same K order: bit-identical to one launch per utterance."""
+    from cookietts_amd.waveglow_ax import _CondConv
+    g, cfg, _ = _load(name)
+    m, _, _ = _model(str(g["config_key"]), int(g["seed"]))
+    melp = torch.from_numpy(np.pad(g["mel"], ((0, 0), (0, 0), (0, 1)))).cuda()
+    ids = None if _ids(g) is None else torch.from_numpy(_ids(g)).cuda()
+    z = torch.from_numpy(g["z"]).cuda()
+    batched, _ = m.inverse(z, melp, speaker_ids=ids)
+    try:
+        _CondConv.batched = False
+        looped, _ = m.inverse(z, melp, speaker_ids=ids)
+    finally:
+        _CondConv.batched = True
+    assert torch.equal(batched, looped)
