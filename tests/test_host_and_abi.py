@@ -151,3 +151,24 @@ def test_host_side_queries_of_the_other_families(hip_lib_path):
     assert lib.ctts_taco_decoder_packed_bytes(ctypes.byref(dc)) > 0
     assert lib.ctts_taco_decoder_workspace_bytes(ctypes.byref(dc), 4, 200) > 0
     assert lib.ctts_taco_decoder_workspace_bytes(ctypes.byref(dc), 5, 200) == 0
+
+
+def test_gemm_mode_names_and_tuning_bits(hip_lib_path):
+    """The arithmetic mode names map onto the header's CTTS_GEMM_* values (ABI 4 + the six-product loop), unknown names are
+    refused on the host, the library refuses unknown defaults, and every launch-shape knob has its bit in ctts_tuning_flags."""
+    import re
+    from cookietts_amd import WaveGlow, _lib
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "cookietts_hip.h")).read()
+    consts = {k: int(v) for k, v in re.findall(r"#define (CTTS_GEMM_\w+) (\d+)", hdr)}
+    assert consts == {"CTTS_GEMM_DEFAULT": 0, "CTTS_GEMM_F32": 1, "CTTS_GEMM_BF16X3": 2, "CTTS_GEMM_BF16X6": 3}
+    assert [_lib.model_gemm_mode(m) for m in (None, "default", "f32", "bf16x3", "bf16x6")] == [0, 0, 1, 2, 3]
+    with pytest.raises(ValueError):
+        _lib.model_gemm_mode("bf16x9")
+    m = WaveGlow(**synthetic.WAVEGLOW_CONFIGS["toy"])
+    assert m.set_f32_gemm_mode("bf16x6") is m and m.c_config().f32_gemm_mode == 3
+    assert _lib.GEMM_MODES == {"f32": 0, "bf16x3": 1, "bf16x6": 2}
+    lib = _lib.lib()
+    assert lib.ctts_set_f32_gemm_mode(3) != 0 and lib.ctts_get_f32_gemm_mode() == 0     # unknown default refused, fp32 MFMA stays
+    for name, bit in _lib.TUNING_BITS.items():
+        assert f"{bit} {name}" in hdr or name in hdr, name
+    assert _lib.TUNING_BITS["CTTS_F32_NO_SPLITK"] == 11
