@@ -16,6 +16,8 @@
 //     shape: results are bit-identical (tests/test_conv1d_primitive.py, test_waveglow_ax.py).
 //   * Staging: global -> LDS DMA (16 B per lane, per-lane source addresses: the A half is 16 runs of 512 B), three
 //     stages, two chunks ahead, three DMA pieces per chunk per wave, counted vmcnt + s_barrier.
+#include <mutex>
+
 #include "gemm_f32.h"
 #include "tuning.h"
 #include "gemm_bf16.h"   // pack_bf16x2 (split-bf16 main loop)
@@ -1099,13 +1101,17 @@ int launch_gemm_f32_small(int epi, const GemmArgs& a, hipStream_t stream) {
         const long long nblk = (long long)nt * a.batch;
         CTTS_CHECK_ARG(nblk > 0 && nblk < (1ll << 31), "gemm (split-K fused shape): grid %lld", nblk);
         constexpr size_t LDS = K_LDS_FLOATS * sizeof(float);         // above the 64 KiB default: opt in once per kernel
-        static bool attr_set[2] = {false, false};
         const int vi = a.nseg <= 4 ? 0 : 1;
-        if (!attr_set[vi]) {
-            const void* fn = vi == 0 ? reinterpret_cast<const void*>(conv_gemm_f32_gate_rs_splitk_kernel<4>)
-                                     : reinterpret_cast<const void*>(conv_gemm_f32_gate_rs_splitk_kernel<GEMM_MAX_SEG>);
-            CTTS_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-            attr_set[vi] = true;
+        {   // once per process and kernel (one process per GPU); a failure is reported by every call that meets it
+            static std::mutex mu;
+            static bool attr_set[2] = {false, false};
+            std::lock_guard<std::mutex> lk(mu);
+            if (!attr_set[vi]) {
+                const void* fn = vi == 0 ? reinterpret_cast<const void*>(conv_gemm_f32_gate_rs_splitk_kernel<4>)
+                                         : reinterpret_cast<const void*>(conv_gemm_f32_gate_rs_splitk_kernel<GEMM_MAX_SEG>);
+                CTTS_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+                attr_set[vi] = true;
+            }
         }
         if (vi == 0) hipLaunchKernelGGL((conv_gemm_f32_gate_rs_splitk_kernel<4>), dim3((unsigned)nblk), dim3(256), LDS, stream, a, nt);
         else hipLaunchKernelGGL((conv_gemm_f32_gate_rs_splitk_kernel<GEMM_MAX_SEG>), dim3((unsigned)nblk), dim3(256), LDS, stream, a, nt);

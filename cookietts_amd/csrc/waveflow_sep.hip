@@ -16,6 +16,8 @@
 // accumulator VGPRs).  GEMM 1 rows are packed so that a wave holds 32 channels' tanh rows (tile row 0) and the SAME
 // channels' sigmoid rows (tile row 1): the gate is lane-local.  A is streamed in 16-row K chunks (16 KiB) through one
 // LDS stage with a register prefetch; B is the LDS tile.  50 KiB of LDS -> three workgroups per CU.
+#include <mutex>
+
 #include "waveflow_sep.h"
 #include "gemm_bf16.h"   // pack_bf16x2
 #include "gemm_f32.h"
@@ -384,11 +386,15 @@ int launch_wf_sep_pack(const float* pw_w, const float* pw_b, const float* rs_w, 
 int launch_wf_sep_layer(const WfSepArgs& a, int batch, hipStream_t s) {
     CTTS_CHECK_ARG(a.L <= a.ntiles * SN && a.ntiles * SN + a.pad <= a.ld && a.pad % 4 == 0 && a.ld % 4 == 0 && a.dwout &&
                    a.cond && a.xin && a.out, "wf_sep_layer: geometry L=%d ld=%d pad=%d", a.L, a.ld, a.pad);
-    static bool attr_set = false;                           // 67 584 B of dynamic LDS: above the 64 KiB default, opt in once
-    if (!attr_set) {
-        CTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_sep_layer_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEP_LDS_BYTES));
-        CTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_sep_layer_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEP_LDS_BYTES));
-        attr_set = true;
+    {   // 67 584 B of dynamic LDS: above the 64 KiB default, opt in once per process (one process per GPU)
+        static std::mutex mu;
+        static bool attr_set = false;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!attr_set) {
+            CTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_sep_layer_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEP_LDS_BYTES));
+            CTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_sep_layer_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEP_LDS_BYTES));
+            attr_set = true;
+        }
     }
     if (a.split_bf16) hipLaunchKernelGGL(wf_sep_layer_kernel<true>, dim3((unsigned)(a.ntiles * batch)), dim3(256), SEP_LDS_BYTES, s, a);
     else hipLaunchKernelGGL(wf_sep_layer_kernel<false>, dim3((unsigned)(a.ntiles * batch)), dim3(256), SEP_LDS_BYTES, s, a);
