@@ -63,15 +63,6 @@ def load_traffic():
     return {}, None
 
 
-def traffic_bytes(traffic, args, B, F):
-    """HBM bytes per in-layer launch from the committed PMC passes, only for the exact launch shape they were taken on."""
-    key = ("f32_" + args.gemm_mode) if (args.dtype == "f32" and args.gemm_mode != "f32") else args.dtype
-    e = traffic.get(key)
-    if not e or args.config != "full" or F != 900 or B != e.get("batch", 8):
-        return None
-    return e.get("hbm_bytes_per_launch")
-
-
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,7 +73,16 @@ def parse_args(argv=None):
     ap.add_argument("--config", default="full", help="key of cookietts_amd.synthetic.WAVEGLOW_CONFIGS")
     ap.add_argument("--cpu-frames", type=int, default=900,
                     help="mel frames of the CPU-baseline utterance (0 = skip; default = the metric's 900)")
-    ap.add_argument("--cpu-budget", type=float, default=40.0, help="wall-time budget (s) of the CPU-baseline repeats")
+    ap.add_argument("--cpu-budget", type=float, default=25.0, help="wall-time budget (s) of the CPU-baseline repeats")
+    ap.add_argument("--cpu-aggregate-frames", type=int, default=300,
+                    help="mel frames per utterance of the concurrent-instances leg of the CPU baseline (the single-instance leg "
+                         "runs --cpu-frames; the shorter utterance keeps the whole CPU part near 90 s; samples/s is what is "
+                         "compared, and the WN convolutions are linear in the utterance length)")
+    ap.add_argument("--rows", default="config3,bf16x6,config4,config5",
+                    help="N = 1 only: short secondary rows run AFTER the headline's timed region and attached to the JSON "
+                         "line as \"rows\" (config3 = bf16 B=32, bf16x6 = six-product loop at the headline batch, config4 = "
+                         "WaveFlow B=8 and B=1, config5 = Tacotron2 900 forced steps B=4 + chained vocoder); empty = none")
+    ap.add_argument("--no-rows", action="store_true", help="same as --rows ''")
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
                     help="launcher role (--gpus N > 1): wall-clock seconds after which the rank processes are terminated (exit 124)")
     ap.add_argument("--no-exchange-dry-run", action="store_true",
@@ -210,7 +210,7 @@ def launch_ranks(n, argv, timeout_s=1500.0, log_dir=None):
 
 
 # ------------------------------------------------------------------------------- worker ----
-def cpu_baseline(cfg, sd, frames, seed, budget_s, config_key=None, aggregate=True):
+def cpu_baseline(cfg, sd, frames, seed, budget_s, config_key=None, aggregate=True, aggregate_frames=None):
     """Single-instance figure (best thread count of a probe) and, beside it, the aggregate of as many concurrent
     single-utterance instances as fill the host (the metric's batch is 8 utterances): `value` is the better of the two
     - the best this box's CPU does on the workload - and `cores` the threads that figure used."""
@@ -227,9 +227,11 @@ def cpu_baseline(cfg, sd, frames, seed, budget_s, config_key=None, aggregate=Tru
         inst = max(1, min(16, r["physical"] // max(r["cores"], 1)))
         if inst > 1:
             try:
-                g = wt.timed_aggregate(config_key, frames, seed, r["cores"], inst)
+                af = min(frames, aggregate_frames or frames)
+                g = wt.timed_aggregate(config_key, af, seed, r["cores"], inst)
+                g["frames"] = af
                 out["aggregate"] = g
-                out["sample"] += (f"; aggregate: {inst} concurrent fresh processes x {r['cores']} threads, one {frames}-frame "
+                out["sample"] += (f"; aggregate: {inst} concurrent fresh processes x {r['cores']} threads, one {af}-frame "
                                   f"utterance each, started together: {g['samples']} samples in {g['span_s']:.2f} s = "
                                   f"{g['value']:.0f} samples/s ({inst * r['cores']} threads)")
                 if g["value"] > out["value"]:
@@ -237,6 +239,171 @@ def cpu_baseline(cfg, sd, frames, seed, budget_s, config_key=None, aggregate=Tru
             except Exception as e:       # the single-instance figure stands; say why the aggregate is missing
                 out["sample"] += f"; aggregate run failed: {e!r}"[:300]
     return out
+
+
+def wn_roofline(lib, cfg, dtype, gemm_mode, B, F, steps, elapsed, config_key="full"):
+    """Roofline object of the WN kernels from the library's own HIP-event timing of the steps just run (profile slots
+    collected and cleared here): the in-layer conv-GEMM against the MFMA peak of the arithmetic it executes; in bf16 also
+    the res and deferred-skip GEMMs and the whole step against HBM."""
+    import ctypes
+    from cookietts_amd import _lib
+    wn = cfg["WN_config"]
+    C, n_layers = wn["n_channels"], wn["n_layers"]
+    L = F * cfg["hop_length"] // cfg["n_group"]
+    traffic, traffic_src = load_traffic()
+    n = ctypes.c_int64()
+    ms = ctypes.c_double()
+    _lib.check(lib.ctts_profile_collect(_lib.PROF_WN_IN, ctypes.byref(n), ctypes.byref(ms)), "profile")
+    # algorithmic MACs per time step of ONE in-layer launch (SURVEY.md 8d): dilated conv
+    # C*2C*3 plus this layer's slice of the conditioning projection 256*2C
+    mac = 3 * C * 2 * C + 256 * 2 * C
+    # bf16x3 executes three bf16 products per algorithmic MAC; the roofline counts the EXECUTED bf16 flops
+    products = 3 if dtype == "bf16x3" else {"f32": 1, "bf16x3": 3, "bf16x6": 6}[gemm_mode] if dtype == "f32" else 1
+    flop_per_launch = 2.0 * mac * B * L * products
+    mean_s = ms.value / max(n.value, 1) * 1e-3
+    achieved = flop_per_launch / mean_s / 1e12
+    peak = FP32_MFMA_PEAK_TFLOPS if dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
+    kname = "conv_gemm_f32_kernel<GATE>" if dtype == "f32" else "conv_gemm_bf16_pp_kernel<GATE>"
+    if dtype == "f32" and gemm_mode != "f32":
+        kname, peak = f"conv_gemm_f32_kernel<GATE, X{products}>", BF16_MFMA_PEAK_TFLOPS
+    key = ("f32_" + gemm_mode) if (dtype == "f32" and gemm_mode != "f32") else dtype
+    e = traffic.get(key)
+    tbytes = e.get("hbm_bytes_per_launch") if (e and config_key == "full" and F == 900 and B == e.get("batch", 8)) else None
+    roofline = {"kernel": kname + " (WN in-layer: dilated conv + cond + tanh*sigmoid)",
+                "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "traffic": tbytes,
+                "traffic_source": (f"{traffic_src}: committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this "
+                                   f"launch shape, not re-measured in this run") if traffic_src else None,
+                "launches": int(n.value), "mean_launch_ms": round(mean_s * 1e3, 4),
+                "flop_per_launch": flop_per_launch}
+    if products > 1:
+        roofline["note"] = (f"flop_per_launch counts the {products} executed bf16 products per algorithmic MAC; "
+                            f"algorithmic flops are 1/{products} of it")
+    # the other WN launches of the step (fp32: res/skip + next layer's cond rows in one SPLIT GEMM, K = C; bf16: the res
+    # GEMM and the deferred skip GEMM, both memory-bound there)
+    for key2, which, kname2, bpt in (
+            ("res_hbm", _lib.PROF_WN_RS, "conv_gemm_bf16_pp_kernel<SPLIT> (WN res 1x1: x += W_res act)", 3.0),
+            ("skip_hbm", _lib.PROF_WN_SKIP, "conv_gemm_bf16_pp_kernel<SPLIT> (WN skip sum over 4 layers' act)", 5.5)):
+        n2 = ctypes.c_int64()
+        ms2 = ctypes.c_double()
+        _lib.check(lib.ctts_profile_collect(which, ctypes.byref(n2), ctypes.byref(ms2)), "profile")
+        if n2.value == 0:
+            continue
+        mean2 = ms2.value / n2.value * 1e-3
+        if dtype == "bf16":
+            # In bf16 the in-layer GEMM stays MFMA-bound (1430 FLOP/B vs a ridge of ~312); the memory-bound WN kernels are
+            # the res GEMM (K = C, per layer: act read + x read-modify-write = 3*C*2 B per time step) and the deferred skip
+            # GEMM (K = 4*C per launch: 4 act reads + the skip sum written, and re-read by the second launch = 5.5*C*2 B per
+            # time step on average).  Report both against HBM.
+            bytes2 = float(bpt * C * 2) * B * L
+            roofline[key2] = {"kernel": kname2, "bound": "hbm", "achieved": round(bytes2 / mean2 / 1e9, 1), "peak": 8000.0,
+                              "unit": "GB/s", "frac": round(bytes2 / mean2 / 8e12, 4), "launches": int(n2.value),
+                              "mean_launch_ms": round(mean2 * 1e3, 4), "bytes_per_launch": bytes2}
+        elif which == _lib.PROF_WN_RS:
+            # fp32: one SPLIT launch per layer = res/skip rows (2C, or C for the last layer) + the next layer's share of the
+            # conditioning is NOT here (it is folded into the in-layer K axis); K = C
+            flop2 = 2.0 * (2 * C * C * (n_layers - 1) + C * C) / n_layers * B * L * products
+            roofline["res_skip_mfma"] = {"kernel": "conv_gemm_f32_kernel<SPLIT> (WN res/skip 1x1, read-modify-write epilogue)",
+                                         "bound": "mfma", "achieved": round(flop2 / mean2 / 1e12, 2), "peak": peak,
+                                         "unit": "TFLOP/s", "frac": round(flop2 / mean2 / 1e12 / peak, 4),
+                                         "launches": int(n2.value), "mean_launch_ms": round(mean2 * 1e3, 4),
+                                         "flop_per_launch_mean": flop2}
+    if dtype == "bf16":
+        # whole step against HBM with SURVEY 8d's per-layer-kernel byte count (7*C*2 B per step per layer; the deferred-skip form moves ~5.4*C*2)
+        step_bytes = 7.0 * C * 2 * n_layers * cfg["n_flows"] * B * L
+        roofline["step_hbm_algorithmic"] = {"bytes_per_step": step_bytes, "achieved": round(step_bytes * steps / elapsed / 1e9, 1),
+                                            "peak": 8000.0, "unit": "GB/s", "frac": round(step_bytes * steps / elapsed / 8e12, 4)}
+    flop_step = 2.0 * 18.85e6 * B * L * cfg["n_flows"] if (C == 512 and n_layers == 8) else None     # SURVEY 8d: 18.85 M MAC / step / flow
+    if flop_step and dtype == "f32" and gemm_mode == "f32":
+        roofline["step_mfma_algorithmic"] = {"flop_per_step": flop_step, "achieved": round(flop_step * steps / elapsed / 1e12, 2),
+                                             "peak": peak, "unit": "TFLOP/s", "frac": round(flop_step * steps / elapsed / 1e12 / peak, 4)}
+    return roofline
+
+
+def under_profiler():
+    """rocprofv3's preloaded library initialises the GPU before Python starts: nothing may be forked from such a process."""
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "HSA_TOOLS_LIB")):
+        return True
+    return any(k.startswith(("ROCPROF", "ROCPROFILER", "ROCP_")) for k in os.environ)
+
+
+def run_rows(which, model, cfg, lib, args, device):
+    """Short secondary rows after the headline's timed region (N = 1 only).  Each row is guarded: a failure is recorded
+    in the row and never takes the headline line down.  ``model`` is the headline's WaveGlow (config 2 weights)."""
+    import time as _t
+    import types
+    import torch
+    sys.path.insert(0, os.path.join(REPO, "scripts"))
+    import bench_rows
+    from cookietts_amd import synthetic
+    rows = []
+    t_all = _t.perf_counter()
+
+    def guard(name, fn):
+        t0 = _t.perf_counter()
+        try:
+            out = fn()
+            for r in (out if isinstance(out, list) else [out]):
+                r["row_wall_s"] = round(_t.perf_counter() - t0, 1)
+                rows.append(r)
+        except Exception as e:                                    # noqa: BLE001 - recorded, never fatal
+            rows.append({"row": name, "error": repr(e)[:400]})
+
+    def timed_infer(mel, steps, warmup):
+        for _ in range(warmup):
+            model.infer(mel, sigma=0.6)
+        torch.cuda.synchronize(device)
+        lib.ctts_profile_enable(1)
+        t0 = _t.perf_counter()
+        for _ in range(steps):
+            out = model.infer(mel, sigma=0.6)
+        torch.cuda.synchronize(device)
+        dt = _t.perf_counter() - t0
+        lib.ctts_profile_enable(0)
+        assert bool(torch.isfinite(out).all())
+        return dt, out
+
+    F = 900
+    T = F * cfg["hop_length"]
+
+    def config3():
+        B3 = 32
+        mel = torch.from_numpy(synthetic.synthetic_mel(B3, F, seed=4321)).to(device)
+        model.set_compute_dtype(torch.bfloat16)
+        try:
+            dt, out = timed_infer(mel, 3, 1)
+            roof = wn_roofline(lib, cfg, "bf16", "f32", B3, F, 3, dt, args.config)
+        finally:
+            model.set_compute_dtype(torch.float32)
+        return {"row": "A/config3 (1-GPU shard)", "metric": METRIC, "value": B3 * T * 3 / dt, "unit": "samples/s",
+                "rtf": B3 * T * 3 / dt / 22050.0, "ms_per_step": dt / 3 * 1e3, "steps": 3, "warmup": 1, "dtype": "bf16",
+                "batch": B3, "frames": F, "roofline": roof,
+                "note": "BASELINE config 3's per-GPU shard (256 utterances / 8 GPUs = 32): bf16 MFMA WN stacks, fp32 tails"}
+
+    def bf16x6():
+        mel = torch.from_numpy(synthetic.synthetic_mel(args.batch, F, seed=4322)).to(device)
+        model.set_f32_gemm_mode("bf16x6")
+        try:
+            dt, out = timed_infer(mel, 2, 1)
+            roof = wn_roofline(lib, cfg, "f32", "bf16x6", args.batch, F, 2, dt, args.config)
+        finally:
+            model.set_f32_gemm_mode(args.gemm_mode)
+        return {"row": "A/config2 under --gemm-mode bf16x6", "metric": METRIC, "value": args.batch * T * 2 / dt, "unit": "samples/s",
+                "ms_per_step": dt / 2 * 1e3, "steps": 2, "warmup": 1, "batch": args.batch, "frames": F,
+                "dtype": "f32 tensors, split-bf16 GEMM products (bf16x6)", "roofline": roof}
+
+    ns = types.SimpleNamespace(steps=3, warmup=1, batches="")
+    for name in which:
+        if name == "config3" and args.dtype == "f32":
+            guard("A/config3", config3)
+        elif name == "bf16x6" and args.dtype == "f32" and args.gemm_mode == "f32":
+            guard("A/bf16x6", bf16x6)
+        elif name == "config4":
+            guard("B/config4", lambda: bench_rows.row_waveflow(ns))
+        elif name == "config5":
+            guard("C/config5", lambda: bench_rows.row_tacotron(types.SimpleNamespace(steps=2, warmup=1, batches=""), vocoder=model))
+    return rows, round(_t.perf_counter() - t_all, 1)
 
 
 def worker(args, pre=None):
@@ -328,13 +495,21 @@ def worker(args, pre=None):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step_on(mel)
+    sync()
+    elapsed_own = time.perf_counter() - t0             # this rank's K steps, before waiting for the others
     fence()
     elapsed = time.perf_counter() - t0
     if lib is not None:
         lib.ctts_profile_enable(0)
     assert out.shape == (B, T) and bool(torch.isfinite(out).all())
 
+    rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
+        # every rank's own time for the same K steps (the barrier-to-barrier span is the max): stragglers show up here
+        mine = torch.tensor([elapsed_own], dtype=torch.float64, device=device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -343,16 +518,18 @@ def worker(args, pre=None):
     # slices, every rank vocodes its slice, waves are gathered point-to-point into rank 0
     if world > 1 and not args.no_exchange:
         n_mel = cfg["n_mel_channels"]
+        # config 3 ships bf16 mels (32 x 80 x 900 bf16 = 4.6 MB per rank); the fp32 path ships fp32
+        xdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
         all_mels = None
         if rank == 0:
             all_mels = torch.cat([torch.from_numpy(synthetic.synthetic_mel(B, F, seed=seed + r)) for r in range(world)]).to(device)
         for it in range(2):                                # pass 0 opens the point-to-point connections
             fence()
             t0 = time.perf_counter()
-            local, counts = sharding.scatter_mels(all_mels, n_mel, device, src=0)
+            local, counts = sharding.scatter_mels(all_mels, n_mel, device, src=0, dtype=xdtype)
             fence()
             t1 = time.perf_counter()
-            wave = step_on(local)
+            wave = step_on(local.float())
             fence()
             t2 = time.perf_counter()
             waves = sharding.gather_waves(wave, counts, dst=0)
@@ -363,7 +540,8 @@ def worker(args, pre=None):
             if selftest:
                 assert torch.equal(waves, step_on(all_mels))
         exchange.update(scatter_ms=(t1 - t0) * 1e3, infer_ms=(t2 - t1) * 1e3, gather_ms=(t3 - t2) * 1e3,
-                        scatter_bytes=int(world * B * n_mel * F * 4), gather_bytes=int(world * B * T * 4),
+                        scatter_bytes=int(world * B * n_mel * F * (2 if xdtype == torch.bfloat16 else 4)),
+                        scatter_dtype=str(xdtype).replace("torch.", ""), gather_bytes=int(world * B * T * 4),
                         note="steady state (second pass; the first opens the RCCL point-to-point channels); "
                              "barrier + synchronize on both sides of each leg, so each figure includes one barrier")
 
@@ -405,64 +583,17 @@ def worker(args, pre=None):
         value = samples / elapsed
         wn = cfg["WN_config"]
         C, n_layers = wn["n_channels"], wn["n_layers"]
-        L = T // cfg["n_group"]
-        roofline = None
-        if timing:
-            from cookietts_amd import _lib
-            traffic, traffic_src = load_traffic()
-            n = ctypes.c_int64()
-            ms = ctypes.c_double()
-            _lib.check(lib.ctts_profile_collect(_lib.PROF_WN_IN, ctypes.byref(n), ctypes.byref(ms)), "profile")
-            # algorithmic MACs per time step of ONE in-layer launch: dilated conv
-            # C*2C*3 plus this layer's slice of the conditioning projection 256*2C
-            mac = 3 * C * 2 * C + 256 * 2 * C
-            # bf16x3 executes three bf16 products per algorithmic MAC; the roofline counts the EXECUTED bf16 flops
-            products = 3 if args.dtype == "bf16x3" else {"f32": 1, "bf16x3": 3, "bf16x6": 6}[args.gemm_mode] if args.dtype == "f32" else 1
-            flop_per_launch = 2.0 * mac * B * L * products
-            mean_s = ms.value / max(n.value, 1) * 1e-3
-            achieved = flop_per_launch / mean_s / 1e12
-            peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
-            kname = "conv_gemm_f32_kernel<GATE>" if args.dtype == "f32" else "conv_gemm_bf16_pp_kernel<GATE>"
-            if args.dtype == "f32" and args.gemm_mode != "f32":
-                kname, peak = f"conv_gemm_f32_kernel<GATE, X{products}>", BF16_MFMA_PEAK_TFLOPS
-            roofline = {"kernel": kname + " (WN in-layer: dilated conv + cond + tanh*sigmoid)",
-                        "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
-                        "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                        "traffic": traffic_bytes(traffic, args, B, F),
-                        "traffic_source": (f"{traffic_src}: committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this "
-                                           f"launch shape, not re-measured in this run") if traffic_src else None,
-                        "launches": int(n.value), "mean_launch_ms": round(mean_s * 1e3, 4),
-                        "flop_per_launch": flop_per_launch}
-            if products > 1:
-                roofline["note"] = (f"flop_per_launch counts the {products} executed bf16 products per algorithmic MAC; "
-                                    f"algorithmic flops are 1/{products} of it")
-            if args.dtype == "bf16":
-                # In bf16 the in-layer GEMM stays MFMA-bound (1430 FLOP/B vs a ridge of ~312); the memory-bound WN
-                # kernels are the res GEMM (K = C, per layer: act read + x read-modify-write = 3*C*2 B per time step)
-                # and the deferred skip GEMM (K = 4*C per launch: 4 act reads + the skip sum written, and re-read by
-                # the second launch = 5.5*C*2 B per time step on average).  Report both against HBM.
-                for key, which, kname2, bpt in (
-                        ("res_hbm", _lib.PROF_WN_RS, "conv_gemm_bf16_pp_kernel<SPLIT> (WN res 1x1: x += W_res act)", 3.0),
-                        ("skip_hbm", _lib.PROF_WN_SKIP, "conv_gemm_bf16_pp_kernel<SPLIT> (WN skip sum over 4 layers' act)", 5.5)):
-                    n2 = ctypes.c_int64()
-                    ms2 = ctypes.c_double()
-                    _lib.check(lib.ctts_profile_collect(which, ctypes.byref(n2), ctypes.byref(ms2)), "profile")
-                    if n2.value > 0:
-                        mean2 = ms2.value / n2.value * 1e-3
-                        bytes2 = float(bpt * C * 2) * B * L
-                        roofline[key] = {
-                            "kernel": kname2, "bound": "hbm", "achieved": round(bytes2 / mean2 / 1e9, 1), "peak": 8000.0,
-                            "unit": "GB/s", "frac": round(bytes2 / mean2 / 8e12, 4), "launches": int(n2.value),
-                            "mean_launch_ms": round(mean2 * 1e3, 4), "bytes_per_launch": bytes2}
-                # whole step against HBM with SURVEY 8d's per-layer-kernel byte count (7*C*2 B per step per layer; the deferred-skip form moves ~5.4*C*2)
-                step_bytes = 7.0 * C * 2 * n_layers * cfg["n_flows"] * B * L
-                roofline["step_hbm_algorithmic"] = {"bytes_per_step": step_bytes, "achieved": round(step_bytes * args.steps / elapsed / 1e9, 1),
-                                                    "peak": 8000.0, "unit": "GB/s",
-                                                    "frac": round(step_bytes * args.steps / elapsed / 8e12, 4)}
+        roofline = wn_roofline(lib, cfg, args.dtype, args.gemm_mode, B, F, args.steps, elapsed, args.config) if timing else None
         cpu = pre["cpu"] if pre else None      # timed by main() before the GPU was touched (its aggregate leg starts children)
+        rows, rows_s = None, None
+        which_rows = [] if (args.no_rows or world > 1 or selftest) else [r for r in args.rows.split(",") if r]
+        if which_rows:
+            rows, rows_s = run_rows(which_rows, model, cfg, lib, args, device)
         line = {
             "metric": METRIC, "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_ranks": {"min": min(rank_ms), "max": max(rank_ms), "all": [round(x, 3) for x in rank_ms]},
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype if (args.gemm_mode == "f32" or args.dtype != "f32") else f"f32 tensors, split-bf16 GEMM products ({args.gemm_mode})",
             "data": "synthetic" if not selftest else "LAUNCHER SELF-TEST (gloo/CPU stand-in step; not a measurement)",
@@ -474,6 +605,9 @@ def worker(args, pre=None):
                        "parallelism": f"utterance-batch shard x{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "exchange": exchange,
         }
+        if rows is not None:
+            line["rows"] = rows
+            line["rows_wall_s"] = rows_s
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
@@ -493,9 +627,15 @@ def main():
         from cookietts_amd import synthetic
         cfg = synthetic.WAVEGLOW_CONFIGS[args.config]
         pre = {"sd": synthetic.waveglow_state_dict(cfg, seed=1234), "cpu": None}
-        if args.cpu_frames > 0:
+        if args.cpu_frames > 0 and under_profiler():
+            # rocprofv3's preloaded library has initialised the GPU already: no child processes, and the CPU legs would
+            # only be profiled idle time
+            pre["cpu"] = {"value": None, "unit": "samples/s", "cores": 0, "kind": "port",
+                          "sample": "skipped: running under rocprofv3 (its library initialises the GPU before Python starts, "
+                                    "so the aggregate leg's child processes may not be started)"}
+        elif args.cpu_frames > 0:
             pre["cpu"] = cpu_baseline(cfg, pre["sd"], args.cpu_frames, 1234, args.cpu_budget, config_key=args.config,
-                                      aggregate=not args.no_cpu_aggregate)
+                                      aggregate=not args.no_cpu_aggregate, aggregate_frames=args.cpu_aggregate_frames)
     worker(args, pre)
 
 

@@ -230,15 +230,17 @@ SIGNATURES = {
     "ctts_interleave_phases_f32": (C.c_int, [_FP, _FP] + [C.c_int32] * 10 + [_FP]),
     "ctts_set_f32_gemm_mode": (C.c_int, [C.c_int32]),
     "ctts_get_f32_gemm_mode": (C.c_int, []),
+    "ctts_last_gemm_loop": (C.c_int, []),
     "ctts_tuning_reload": (C.c_int, []),
     "ctts_tuning_flags": (C.c_int, []),
     "ctts_profile_enable": (C.c_int, [C.c_int32]),
     "ctts_profile_collect": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }
 
-GEMM_MODES = {"f32": 0, "bf16x3": 1, "bf16x6": 2}                      # ctts_set_f32_gemm_mode: the library DEFAULT
-# f32_gemm_mode field of the config structs (CTTS_GEMM_*): the mode a MODEL asks for
+# CTTS_GEMM_*: ONE encoding for the f32_gemm_mode field of the config structs (the mode a MODEL asks for) and for the
+# deprecated process-wide default (ctts_set_f32_gemm_mode / ctts_get_f32_gemm_mode, ABI 5)
 MODEL_GEMM_MODES = {None: 0, "default": 0, "f32": 1, "bf16x3": 2, "bf16x6": 3}
+GEMM_MODES = {"f32": 1, "bf16x3": 2, "bf16x6": 3}
 
 
 def model_gemm_mode(mode):
@@ -262,7 +264,7 @@ def set_f32_gemm_mode(mode):
 
 TUNING_BITS = {"CTTS_F32_NO_GLDS": 0, "CTTS_GEMM_NO_XCD_PAIR": 1, "CTTS_BF16_NO_GLDS": 2, "CTTS_BF16_NO_WIDE": 3,
                "CTTS_BF16_NO_PP": 4, "CTTS_BF16_W4": 5, "CTTS_BF16_PP_STAGES": 6, "CTTS_WF_NO_FUSE": 7, "CTTS_TACO_NO_FUSE": 8,
-               "CTTS_F32_NO_SMALL": 9, "CTTS_F32_FORCE_SMALL": 10, "CTTS_F32_NO_SPLITK": 11}
+               "CTTS_F32_NO_SMALL": 9, "CTTS_F32_FORCE_SMALL": 10, "CTTS_F32_NO_SPLITK": 11, "CTTS_WF_NO_VEC_INTERP": 12}
 
 
 def tuning_reload():
@@ -312,7 +314,7 @@ def lib():
                 raise HipLibraryError(f"{path} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
-        if handle.ctts_abi_version() != 4:
+        if handle.ctts_abi_version() != 5:
             raise HipLibraryError(f"ABI version mismatch: library reports {handle.ctts_abi_version()}")
         env_mode = os.environ.get("CTTS_F32_GEMM_MODE")          # "f32" (default) or "bf16x3": see set_f32_gemm_mode
         if env_mode:

@@ -166,10 +166,14 @@ int launch_gemm_f32(int epi, const GemmArgs& a, hipStream_t stream);
 bool gemm_f32_small_applies(int epi, const GemmArgs& a);
 int launch_gemm_f32_small(int epi, const GemmArgs& a, hipStream_t stream);
 
-// Library DEFAULT of the main-loop selection (what CTTS_GEMM_DEFAULT resolves to): 0 = fp32 MFMA (initially), 1 = split
-// bf16 (three bf16 MFMA products per fp32 operand pair, see conv_gemm_f32_kernel<..., X3>).  ctts_set_f32_gemm_mode.
+// Library DEFAULT of the main-loop selection (what CTTS_GEMM_DEFAULT resolves to), in the config structs' own encoding:
+// CTTS_GEMM_F32 (initially), CTTS_GEMM_BF16X3 (three bf16 MFMA products per fp32 operand pair, see
+// conv_gemm_f32_kernel<..., X3>) or CTTS_GEMM_BF16X6.  ctts_set_f32_gemm_mode (deprecated: prefer the per-model field).
 int set_gemm_f32_mode(int mode);
 int get_gemm_f32_mode();
+// what the calling thread's most recent conv-GEMM launch ran (ctts_last_gemm_loop): bits 0-3 split level, 16 small shape, 32 split-K
+void note_gemm_loop(int code);
+int last_gemm_loop();
 // true when a launch with this GemmArgs.gemm_mode / config f32_gemm_mode runs the split-bf16 main loop
 bool gemm_mode_is_split(int gemm_mode);
 // validates a config struct's f32_gemm_mode field

@@ -669,7 +669,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
     }
 }
 
-std::atomic<int> g_gemm_mode{0};
+std::atomic<int> g_gemm_mode{CTTS_GEMM_F32};
 inline int gemm_f32_mode() { return g_gemm_mode.load(std::memory_order_relaxed); }
 
 template <int EPI, int XS>
@@ -706,16 +706,21 @@ void launch_shape(int bm, dim3 grid, hipStream_t stream, const GemmArgs& a) {
 
 }  // namespace
 
+// the library default is stored in the SAME encoding as the config structs' field (CTTS_GEMM_F32 / _BF16X3 / _BF16X6)
 int set_gemm_f32_mode(int mode) {
-    if (mode != 0 && mode != 1 && mode != 2) return -1;      // 0 fp32 MFMA, 1 split bf16 x3, 2 split bf16 x6
+    if (mode == CTTS_GEMM_DEFAULT) mode = CTTS_GEMM_F32;     // "reset": the initial value
+    if (mode != CTTS_GEMM_F32 && mode != CTTS_GEMM_BF16X3 && mode != CTTS_GEMM_BF16X6) return -1;
     g_gemm_mode.store(mode, std::memory_order_relaxed);
     return 0;
 }
 int get_gemm_f32_mode() { return gemm_f32_mode(); }
+namespace { thread_local int t_last_loop = 0; }
+void note_gemm_loop(int code) { t_last_loop = code; }
+int last_gemm_loop() { return t_last_loop; }
 int gemm_split_level(int m) {
+    if (m == CTTS_GEMM_DEFAULT) m = gemm_f32_mode();
     if (m == CTTS_GEMM_BF16X3) return 3;
     if (m == CTTS_GEMM_BF16X6) return 6;
-    if (m == CTTS_GEMM_DEFAULT) return gemm_f32_mode() == 1 ? 3 : gemm_f32_mode() == 2 ? 6 : 0;
     return 0;
 }
 bool gemm_mode_is_split(int m) { return gemm_split_level(m) != 0; }
@@ -739,6 +744,7 @@ void load_tuning_locked() {
     g_tune.bf16_pp_stages = num("CTTS_BF16_PP_STAGES", 3);
     g_tune.wf_no_fuse = on("CTTS_WF_NO_FUSE");
     g_tune.taco_no_fuse = on("CTTS_TACO_NO_FUSE");
+    g_tune.wf_no_vec_interp = on("CTTS_WF_NO_VEC_INTERP");
     g_tune.w4_debug = num("CTTS_BF16_W4_DEBUG", 0);
     g_tune_loaded = true;
 }
@@ -798,14 +804,16 @@ int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
     CTTS_CHECK_ARG(a.gate >= 0 && a.gate < GATE_KINDS && (a.gate == 0 || epi == GEMM_EPI_GATE), "gemm: gate=%d with epilogue %d",
                    a.gate, epi);
     if (epi == GEMM_EPI_GATE && a.gate != GATE_GTU) epi = GEMM_EPI_GATEX;
+    // the fused res/skip epilogue is validated BEFORE any shape is chosen: the small and split-K shapes take the same arguments
+    CTTS_CHECK_ARG(epi != GEMM_EPI_GATE_RS ||
+                       (a.bm == 128 && a.pairC <= 64 && a.MB == 1 && a.rs_wT && a.rs_bias && (a.rs_rows == 64 || a.rs_rows == 128)),
+                   "gemm: fused res/skip needs bm=128, <= 64 channels, rs_wT / rs_bias and 64 or 128 res/skip rows");
     if (gemm_f32_small_applies(epi, a)) return launch_gemm_f32_small(epi, a, stream);
+    note_gemm_loop((tuning().f32_no_glds || a.nch_total > GEMM_GLDS_MAX_CHUNKS) ? 0 : gemm_split_level(a.gemm_mode));
     switch (epi) {
         case GEMM_EPI_GATEX: launch_shape<GEMM_EPI_GATEX>(a.bm, grid, stream, a); break;
         case GEMM_EPI_GATE: launch_shape<GEMM_EPI_GATE>(a.bm, grid, stream, a); break;
         case GEMM_EPI_GATE_RS:
-            CTTS_CHECK_ARG(a.bm == 128 && a.pairC <= 64 && a.MB == 1 && a.rs_wT && a.rs_bias && (a.rs_rows == 64 || a.rs_rows == 128),
-                           "gemm: fused res/skip needs bm=128, <= 64 channels");
-            if (gemm_f32_small_applies(epi, a)) return launch_gemm_f32_small(epi, a, stream);
             if (tuning().f32_no_glds || a.nch_total > GEMM_GLDS_MAX_CHUNKS) {
                 if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, 4, false>), grid, dim3(256), 0, stream, a);
                 else hipLaunchKernelGGL((conv_gemm_f32_kernel<GEMM_EPI_GATE_RS, 1, GEMM_MAX_SEG, false>), grid, dim3(256), 0, stream, a);

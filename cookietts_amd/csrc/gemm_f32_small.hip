@@ -1115,6 +1115,7 @@ int launch_gemm_f32_small(int epi, const GemmArgs& a, hipStream_t stream) {
         }
         if (vi == 0) hipLaunchKernelGGL((conv_gemm_f32_gate_rs_splitk_kernel<4>), dim3((unsigned)nblk), dim3(256), LDS, stream, a, nt);
         else hipLaunchKernelGGL((conv_gemm_f32_gate_rs_splitk_kernel<GEMM_MAX_SEG>), dim3((unsigned)nblk), dim3(256), LDS, stream, a, nt);
+        note_gemm_loop(16 | 32);                                     // fp32 MFMA whatever the mode (see cookietts_hip.h)
         CTTS_CHECK_LAUNCH("conv_gemm_f32_gate_rs_splitk");
         return CTTS_OK;
     }
@@ -1124,6 +1125,7 @@ int launch_gemm_f32_small(int epi, const GemmArgs& a, hipStream_t stream) {
         CTTS_CHECK_ARG(nblk > 0 && nblk < (1ll << 31), "gemm (small fused shape): grid %lld", nblk);
         if (a.nseg <= 4) hipLaunchKernelGGL((conv_gemm_f32_gate_rs_small_kernel<4>), dim3((unsigned)nblk), dim3(256), 0, stream, a, nt);
         else hipLaunchKernelGGL((conv_gemm_f32_gate_rs_small_kernel<GEMM_MAX_SEG>), dim3((unsigned)nblk), dim3(256), 0, stream, a, nt);
+        note_gemm_loop(16);
         CTTS_CHECK_LAUNCH("conv_gemm_f32_gate_rs_small");
         return CTTS_OK;
     }
@@ -1141,6 +1143,7 @@ int launch_gemm_f32_small(int epi, const GemmArgs& a, hipStream_t stream) {
         case GEMM_EPI_SPLIT: launch_small<GEMM_EPI_SPLIT>(grid, stream, a, ntiles_s); break;
         default: set_error("gemm (small shape): epilogue %d", epi); return CTTS_E_ARG;
     }
+    note_gemm_loop(16 | gemm_split_level(a.gemm_mode));
     CTTS_CHECK_LAUNCH("conv_gemm_f32_small");
     return CTTS_OK;
 }

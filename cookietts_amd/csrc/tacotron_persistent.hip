@@ -1,25 +1,32 @@
-// Persistent Tacotron2-TM decoder loop for gfx950: ONE launch runs a whole block of decoder steps
-// (model.py:668-767 per step) on all 256 CUs, instead of six dependent launches per step.
+// Persistent, WEIGHT-RESIDENT Tacotron2-TM decoder loop for gfx950: ONE launch runs a whole block of decoder steps
+// (model.py:668-767 per step) on all 256 CUs, and every LSTM weight stays ON its compute unit for the whole launch.
 //
-// Why: a decoder step is a chain of small dependent mat-vecs (27 M fp32 weights, batch <= 4).  As six launches per
-// step it costs 85 us/step: every launch pays a dependent boundary + a cold ramp of its weight stream, and the two
-// one-workgroup-per-utterance stages serialise the rest.  Here every workgroup (one per CU) owns a fixed slice of the
-// work for the whole block of steps:
-//   * workgroups 0..251 ("LSTM workgroups"): 5-6 attention-RNN units, 3-4 decoder-RNN units and 3-4 second-decoder-RNN
-//     units each (4 gate rows per unit); plus one row of the query projection (workgroups < attention_dim), one or two
-//     rows of the projection row set [mel | gate | first prenet layer folded through the mel projection] and one or
-//     two rows of the second prenet layer;
+// Why: a decoder step is a chain of small dependent mat-vecs (27 M fp32 weights = 108 MB, batch <= 4).  As six launches
+// per step it costs 85 us/step.  The first persistent form (round 2-3) kept 21 % of the weights on the CU and streamed
+// the other 85 MB from L2 / Infinity Cache every step: 39.6 us/step, with the all-gathers of the step queueing behind
+// the workgroup's own weight stream in the CU's memory pipeline.  But the chip holds 256 x (512 KB registers + 160 KB
+// LDS) = 168 MB on-CU - more than the weights.  This form puts them there:
+//   * workgroups 0..251 ("LSTM workgroups", 256 threads = one wave per SIMD, so each wave owns the SIMD's whole
+//     512-entry register file): every wave owns two or three whole LSTM units (all four gate rows, ALL columns) of the
+//     workgroup's 5-6 attention-RNN units, 3-4 decoder-RNN units and 3-4 second-decoder-RNN units: 304-384 weights per
+//     lane in VGPRs + AGPRs, the rest (up to 28 tiles of 1 KB per wave) in LDS; the products run on the matrix pipe
+//     (v_mfma_f32_4x4x1_16b_f32: gate rows x batch items, 16 column blocks per instruction), the gate sums of a unit end
+//     up in the lanes that update its cell - no barrier between product and cell.  Four workgroup classes (6/3/3,
+//     5/4/3, 5/3/4, 5/3/3 units) spread the 1280 + 768 + 768 units over 252 workgroups.
+//     Plus, as before: one row of the query projection (workgroups < attention_dim), one or two rows of the projection
+//     row set [mel | gate | first prenet layer folded through the mel projection] and one or two rows of the second
+//     prenet layer, LDS-resident.
 //   * workgroups 252..255: the windowed location-sensitive attention of utterance b = workgroup - 252, nothing else.
-// The columns of every mat-vec whose input is produced in the SAME step ("fresh": prenet -> attention RNN, context ->
-// decoder RNN, decoder hidden -> second decoder RNN, and the small rows) are weight-stationary on the CU for the whole
-// launch (LDS, the second decoder RNN's in registers); the columns whose input was produced earlier (recurrent states,
-// previous context: 79 % of the weights) are streamed from L2 / Infinity Cache after the workgroup has published its
-// result and before it polls for the next vector, into per-lane partial sums - off the critical path.
+// Per step NOTHING is streamed but the 33-row attention windows and the prenet's dropout bytes: the weight bytes are
+// read once per launch (108 MB at entry).  The per-lane partial sums of every product are accumulated as soon as the
+// product's input vector has arrived ("early" products of the next cell evaluation run right after a publish, inside
+// the next exchange's latency) and reduced over the wave (DPP) only in the fresh phase.
 // Exchanges: a vector produced by many workgroups and needed by all (att_h, q, ctx, dec_h, d2_h, h1, prenet) is
 // all-gathered through 8-byte {tag = step + 1, value} granules written with ONE agent-scope (write-through) store each
 // and polled with agent-scope loads: the data is the flag, no fences, no grid barrier (MI355X_MICROARCH.md
-// "handoff" / "allgather" rows; cdna_hip_programming.md Guideline 16 R2).  Every poll loop is bounded; on a timeout
-// the workgroup records (code, workgroup, phase, step) in the control words and the whole grid drains.
+// "handoff" / "allgather" rows; cdna_hip_programming.md Guideline 16 R2).  With no weight stream in the CU's memory
+// pipeline the polls are the only traffic ("parked" column of the price list).  Every poll loop is bounded; on a
+// timeout the workgroup records (code, workgroup, phase, step) in the control words and the whole grid drains.
 // Granule tags are zeroed by the host wrapper before EVERY launch; the control words are sticky.
 #include "tacotron_plan.h"
 
@@ -30,21 +37,24 @@ using namespace taco;
 
 constexpr int PD_WG = 256;          // workgroups == CUs of an MI355X
 constexpr int PD_LWG = 252;         // LSTM workgroups; the last PD_NB are the attention workgroups
-constexpr int PD_T = 512;           // threads per workgroup (8 waves, 2 per SIMD)
+constexpr int PD_T = 256;           // threads per workgroup: 4 waves, ONE per SIMD (512 registers per lane)
+constexpr int PD_NW = PD_T / 64;
 constexpr int PD_NB = 4;            // batch, padded
 constexpr int PD_RA = 1280, PD_RD = 768, PD_P = 256, PD_DM = 512;
-constexpr int PD_UA = 6, PD_UD = 4; // max LSTM units per workgroup: ceil(1280 / 252), ceil(768 / 252)
 constexpr int PD_AMAX = 192, PD_TMAX = 1024, PD_W = 33, PD_FMAX = 32, PD_KMAX = 31;
-// LDS vector store X of an LSTM workgroup: [b][n] per vector
-constexpr int XP = 0, XCTX = XP + PD_NB * PD_P, XDEC = XCTX + PD_NB * PD_DM, XATT = XDEC + PD_NB * PD_RD,
-              XD2 = XATT + PD_NB * PD_RA, XH1 = XD2 + PD_NB * PD_RD, X_FLOATS = XH1 + PD_NB * PD_P;
-// weight-stationary LDS images, one float4 per lane: [row][j][lane]
-constexpr int WFA = X_FLOATS;                                  // attention RNN, prenet columns: [24][1][64] float4
-constexpr int WFD = WFA + 4 * PD_UA * 1 * 64 * 4;              // decoder RNN, context columns:   [16][2][64] float4
-constexpr int WQ = WFD + 4 * PD_UD * 2 * 64 * 4;               // query row                        [5][64] float4
-constexpr int WPR = WQ + 5 * 64 * 4;                           // two projection rows              [2][5][64] float4
-constexpr int WW2 = WPR + 2 * 5 * 64 * 4;                      // two second-prenet rows           [2][1][64] float4
-constexpr int LSTM_FLOATS = WW2 + 2 * 64 * 4;
+// workgroup classes: units of (attention RNN, decoder RNN, second decoder RNN) per workgroup
+//   class 0: wg   0..19  (6, 3, 3)     class 1: wg 20..31  (5, 4, 3)     class 2: wg 32..43  (5, 3, 4)     class 3: wg 44..251 (5, 3, 3)
+// 20 * 6 + 232 * 5 = 1280;  12 * 4 + 240 * 3 = 768 (twice)
+constexpr int PD_C0 = 20, PD_C1 = 32, PD_C2 = 44;
+// LDS vector store X of an LSTM workgroup: [item][n + 16] per vector (padded rows, see pd_xs)
+constexpr int XP = 0, XCTX = XP + PD_NB * (PD_P + 16), XDEC = XCTX + PD_NB * (PD_DM + 16), XATT = XDEC + PD_NB * (PD_RD + 16),
+              XD2 = XATT + PD_NB * (PD_RA + 16), XH1 = XD2 + PD_NB * (PD_RD + 16), X_FLOATS = XH1 + PD_NB * (PD_P + 16);
+// LDS-resident single rows (plain row layout)
+constexpr int WQ = X_FLOATS;                                   // query row                        [1280]
+constexpr int WPR = WQ + PD_RA;                                // two projection rows              [2][1280]
+constexpr int WW2 = WPR + 2 * (PD_RD + PD_DM);                 // two second-prenet rows           [2][256]
+constexpr int WLT = WW2 + 2 * PD_P;                            // LSTM weight tiles kept in LDS: [tile][lane] float4, 76 tiles
+constexpr int LSTM_FLOATS = WLT + 76 * 64 * 4;
 constexpr int PD_DBG_SLOTS = 24;             // ctts_taco_decoder_persistent_debug: [PD_WG][64 steps][PD_DBG_SLOTS] stamps
 constexpr unsigned PD_SPIN_LIMIT = 400000;   // polls per gather before giving up (~0.5 s)
 
@@ -83,7 +93,7 @@ __device__ __forceinline__ void publish(u64* g, int idx, unsigned epoch, float v
                        __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// All-gather receive: thread t owns granules t, t + 512, ...; a granule is accepted when its tag equals `epoch`.
+// All-gather receive: thread t owns granules t, t + 256, ...; a granule is accepted when its tag equals `epoch`.
 // Returns false on timeout / abort (after recording it).  The caller follows with a workgroup barrier.
 template <int NPT>
 __device__ __forceinline__ bool gather(const u64* g, int count, float* dst, unsigned epoch, unsigned* ctl, int t,
@@ -153,100 +163,6 @@ __device__ __forceinline__ float wave_max(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// Units of a cell with hidden size H on LSTM workgroup wg: 252 workgroups, the first H - 252 * (H / 252) take one more.
-__device__ __forceinline__ int unit_count(int H, int wg) { return H / PD_LWG + (wg < H % PD_LWG ? 1 : 0); }
-__device__ __forceinline__ int unit_first(int H, int wg) { return wg * (H / PD_LWG) + min(wg, H % PD_LWG); }
-
-// Issue this wave's NR x NJ sixteen-byte weight loads of columns [col0, col0 + 256 NJ) of weight rows `rows` (< 0:
-// the wave has fewer rows); the values are consumed by fma_rows, so the L2 / Infinity-Cache latency of the whole
-// chunk is paid once.
-template <int NR, int NJ>
-__device__ __forceinline__ void issue_rows(const float* __restrict__ blob, unsigned mat, int ldw, int col0, const int (&rows)[NR],
-                                           int lane, float4 (&w)[NR][NJ]) {
-    // rows are wave-uniform: the row base is scalar arithmetic and every load shares one per-lane offset
-    const unsigned lane_off = 4u * (unsigned)lane;
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const int row = __builtin_amdgcn_readfirstlane(rows[i]);
-        const bool valid = row >= 0;                                      // wave-uniform
-        const float* rp = blob + mat + (size_t)(valid ? row : 0) * ldw + col0;    // scalar
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            w[i][j] = valid ? *reinterpret_cast<const float4*>(rp + 256 * j + lane_off) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-}
-
-// acc[i][b] += sum over this lane's columns of w[i][j] . x[b][xoff + c]   (per-lane partial sums, no reduction)
-template <int NR, int NJ>
-__device__ __forceinline__ void fma_rows(const float4 (&w)[NR][NJ], const float* xs, int n, int xoff, int lane,
-                                         float (&acc)[NR][PD_NB]) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        float4 x[PD_NB];
-#pragma unroll
-        for (int b = 0; b < PD_NB; ++b) x[b] = *reinterpret_cast<const float4*>(xs + b * n + xoff + 4 * (lane + 64 * j));
-#pragma unroll
-        for (int i = 0; i < NR; ++i)
-#pragma unroll
-            for (int b = 0; b < PD_NB; ++b)     // explicit fma chain: the same arithmetic in every inlined copy, so a block of
-                                                // steps split over several launches reproduces one long launch bit for bit
-                acc[i][b] = fmaf(w[i][j].w, x[b].w, fmaf(w[i][j].z, x[b].z, fmaf(w[i][j].y, x[b].y, fmaf(w[i][j].x, x[b].x, acc[i][b]))));
-    }
-}
-
-template <int NR, int NJ>
-__device__ __forceinline__ void early_rows(const float* __restrict__ blob, unsigned mat, int ldw, int col0, const int (&rows)[NR],
-                                           const float* xs, int n, int xoff, int lane, float (&acc)[NR][PD_NB]) {
-    float4 w[NR][NJ];
-    issue_rows<NR, NJ>(blob, mat, ldw, col0, rows, lane, w);
-    fma_rows<NR, NJ>(w, xs, n, xoff, lane, acc);
-}
-
-// gates[local row][b] = reduce over the wave (early partial sums + fresh columns) + bias
-template <int NR, int NJ>
-__device__ __forceinline__ void fresh_gates(const float4 (&wf)[NR][NJ], const float (&bias)[NR], const float* xs, int n,
-                                            const float (&early)[NR][PD_NB], float (*gates)[PD_NB], int nrows, int wave,
-                                            int lane) {
-    float tot[NR][PD_NB];
-#pragma unroll
-    for (int i = 0; i < NR; ++i)
-#pragma unroll
-        for (int b = 0; b < PD_NB; ++b) tot[i][b] = early[i][b];
-    fma_rows<NR, NJ>(wf, xs, n, 0, lane, tot);
-    wave_totals<NR * PD_NB>(reinterpret_cast<float (&)[NR * PD_NB]>(tot));
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const int r = wave + 8 * i;
-        if (r < nrows && lane < PD_NB)
-            gates[r][lane] = (lane == 0 ? tot[i][0] : lane == 1 ? tot[i][1] : lane == 2 ? tot[i][2] : tot[i][3]) + bias[i];
-    }
-}
-
-template <int NR>
-__device__ __forceinline__ void zero_rows(float (&acc)[NR][PD_NB]) {
-#pragma unroll
-    for (int i = 0; i < NR; ++i)
-#pragma unroll
-        for (int b = 0; b < PD_NB; ++b) acc[i][b] = 0.f;
-}
-
-// LSTM cell update of the workgroup's U units (layers.py:308-372, gate order i, f, g, o; local row = gate * U + unit);
-// publishes h' at [b][first + unit].
-__device__ __forceinline__ void cell_update(const float (*gates)[PD_NB], float (*cst)[PD_NB], float (*hown)[PD_NB], u64* g,
-                                            unsigned epoch, int H, int U, int first, int t) {
-    if (t < U * PD_NB) {
-        const int u = t / PD_NB, b = t % PD_NB;
-        const float gi = fast_sigmoid(gates[0 * U + u][b]), gf = fast_sigmoid(gates[1 * U + u][b]);
-        const float gg = fast_tanh(gates[2 * U + u][b]), go = fast_sigmoid(gates[3 * U + u][b]);
-        const float c = gf * cst[u][b] + gi * gg;
-        const float h = go * fast_tanh(c);
-        cst[u][b] = c;
-        hown[u][b] = h;
-        publish(g, b * H + first + u, epoch, h);
-    }
-}
-
-// one row (NJ float4 per lane, LDS-resident) against NB staged vectors -> per-lane partial dot products
 template <int NJ>
 __device__ __forceinline__ void row_dots(const float* wrow, const float* xs, int n, int lane, float (&acc)[PD_NB]) {
 #pragma unroll
@@ -271,7 +187,7 @@ struct AttnLds {
     float ctx[PD_DM];
     float pos;
 };
-static_assert(PD_T == PD_DM, "the context pass maps one thread to one memory dimension");
+static_assert(PD_DM == 2 * PD_T, "the context pass maps one thread to two memory dimensions");
 static_assert(sizeof(AttnLds) <= LSTM_FLOATS * sizeof(float), "the attention scratch shares the LSTM workgroups' LDS");
 
 #define PD_STAMP(k)                                                                                         \
@@ -303,8 +219,6 @@ struct AttnRegs {
 // Part 1, BEFORE the query of this step is known (it depends only on the previous step's weights and position, so it
 // runs while the LSTM workgroups are still in their attention-RNN phase): window start, the bursts for the 33-row
 // windows of the processed memory and of the memory, the location conv.  Returns the window start.
-constexpr int PD_WH = (PD_W + 1) / 2;     // window positions per energies wave
-
 __device__ __forceinline__ int pd_attention_pre(const PdArgs& a, AttnLds& s, const AttnRegs& r, int b) {
     const int t = threadIdx.x;
     const int W = 2 * a.R + 1, padk = (a.K - 1) / 2;
@@ -316,17 +230,26 @@ __device__ __forceinline__ int pd_attention_pre(const PdArgs& a, AttnLds& s, con
     const int s0 = (int)rintf(fmaxf(cur - (float)a.R, 0.f));
     {
         const int a4 = a.A / 4;
-        for (int i = t; i < W * a4; i += PD_T) {
-            const int tt = i / a4, c4 = i % a4;
-            const int pos = min(s0 + tt, a.T - 1);
-            *reinterpret_cast<float4*>(s.pmw + tt * a.A + c4 * 4) =
-                *reinterpret_cast<const float4*>((a.ws + a.pm) + ((size_t)b * a.T + pos) * a.A + c4 * 4);
-        }
-        for (int i = t; i < W * (PD_DM / 4); i += PD_T) {      // rows clamped: a masked row has weight exactly 0
-            const int tt = i / (PD_DM / 4), d4 = i % (PD_DM / 4);
-            const int pos = min(s0 + tt, a.T - 1);
-            *reinterpret_cast<float4*>(s.memw + tt * PD_DM + d4 * 4) =
-                *reinterpret_cast<const float4*>((a.ws + a.memory) + ((size_t)b * a.T + pos) * PD_DM + d4 * 4);
+        if (s0 + W <= a.T) {
+            // the 33 rows of a window are consecutive rows of the [T][A] / [T][512] arrays: two linear copies, no index math
+            const float4* pmsrc = reinterpret_cast<const float4*>((a.ws + a.pm) + ((size_t)b * a.T + s0) * a.A);
+            const float4* msrc = reinterpret_cast<const float4*>((a.ws + a.memory) + ((size_t)b * a.T + s0) * PD_DM);
+            for (int i = t; i < W * a4; i += PD_T) reinterpret_cast<float4*>(s.pmw)[i] = pmsrc[i];
+#pragma unroll 6
+            for (int i = t; i < W * (PD_DM / 4); i += PD_T) reinterpret_cast<float4*>(s.memw)[i] = msrc[i];
+        } else {
+            for (int i = t; i < W * a4; i += PD_T) {
+                const int tt = i / a4, c4 = i % a4;
+                const int pos = min(s0 + tt, a.T - 1);
+                *reinterpret_cast<float4*>(s.pmw + tt * a.A + c4 * 4) =
+                    *reinterpret_cast<const float4*>((a.ws + a.pm) + ((size_t)b * a.T + pos) * a.A + c4 * 4);
+            }
+            for (int i = t; i < W * (PD_DM / 4); i += PD_T) {      // rows clamped: a masked row has weight exactly 0
+                const int tt = i / (PD_DM / 4), d4 = i % (PD_DM / 4);
+                const int pos = min(s0 + tt, a.T - 1);
+                *reinterpret_cast<float4*>(s.memw + tt * PD_DM + d4 * 4) =
+                    *reinterpret_cast<const float4*>((a.ws + a.memory) + ((size_t)b * a.T + pos) * PD_DM + d4 * 4);
+            }
         }
         for (int i = t; i < 2 * (W + a.K - 1); i += PD_T) {
             const int c = i / (W + a.K - 1), j = i % (W + a.K - 1);
@@ -336,9 +259,9 @@ __device__ __forceinline__ int pd_attention_pre(const PdArgs& a, AttnLds& s, con
         }
     }
     __syncthreads();
-    {   // location conv (model.py:56-60): thread = (filter f, position group g of 16); taps out of registers
+    {   // location conv (model.py:56-60): thread = (filter f, position group g of 8); taps out of registers
         const int f = t & 31, g = t >> 5;
-        for (int tt = g; tt < W; tt += 16) {
+        for (int tt = g; tt < W; tt += PD_T / 32) {
             float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
 #pragma unroll
             for (int j = 0; j + 1 < PD_KMAX; j += 2) {
@@ -359,17 +282,27 @@ __device__ __forceinline__ int pd_attention_pre(const PdArgs& a, AttnLds& s, con
     // after the query arrived (5.4 us of the step's critical path, LDS-broadcast bound); here it hides in the ~40 us
     // this workgroup waits for the query anyway.
     if (r.pg >= 0 && r.ad < a.A) {
-        const int t0 = r.pg == 0 ? 0 : (W + 1) / 2, t1 = r.pg == 0 ? (W + 1) / 2 : W;
+        // three positions per pass with independent chains (one position per pass was bound by the LDS round trips: read
+        // the features, 32 dependent-by-four FMAs, read-modify-write the pre-activation)
 #pragma unroll 1
-        for (int tt = t0; tt < t1; ++tt) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int tt0 = 0; tt0 < W; tt0 += 3) {
+            float acc[3][4];
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[u][k] = 0.f;
 #pragma unroll
             for (int f4 = 0; f4 < PD_FMAX / 4; ++f4) {
-                const float4 l = *reinterpret_cast<const float4*>(&s.loc[tt][4 * f4]);     // wave-uniform address: broadcast
-                a0 = fmaf(r.wd[4 * f4 + 0], l.x, a0); a1 = fmaf(r.wd[4 * f4 + 1], l.y, a1);
-                a2 = fmaf(r.wd[4 * f4 + 2], l.z, a2); a3 = fmaf(r.wd[4 * f4 + 3], l.w, a3);
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const float4 l = *reinterpret_cast<const float4*>(&s.loc[min(tt0 + u, W - 1)][4 * f4]);   // wave-uniform address: broadcast
+                    acc[u][0] = fmaf(r.wd[4 * f4 + 0], l.x, acc[u][0]); acc[u][1] = fmaf(r.wd[4 * f4 + 1], l.y, acc[u][1]);
+                    acc[u][2] = fmaf(r.wd[4 * f4 + 2], l.z, acc[u][2]); acc[u][3] = fmaf(r.wd[4 * f4 + 3], l.w, acc[u][3]);
+                }
             }
-            s.pmw[tt * a.A + r.ad] += (a0 + a2) + (a1 + a3);
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (tt0 + u < W) s.pmw[(tt0 + u) * a.A + r.ad] += (acc[u][0] + acc[u][2]) + (acc[u][1] + acc[u][3]);
         }
     }
     return s0;      // (the caller's q gather ends with a workgroup barrier: pmw / memw are visible after it)
@@ -384,25 +317,25 @@ __device__ __forceinline__ void pd_attention_post(const PdArgs& a, AttnLds& s, c
     const int wg = blockIdx.x;
     const int W = 2 * a.R + 1;
     const int len = reinterpret_cast<const int*>(a.ws + a.lengths)[b];
-    {   // energies (model.py:107-112): wave wv takes window positions wv, wv + 8, ...; a lane sums its three attention
-        // dims (lane, lane + 64, lane + 128) first, so a position costs ONE 64-lane reduction, not three (round 2 / the
-        // first round-3 cut: 17 reductions per wave; now at most 5)
-        float qv[3], ev[5];
+    {   // energies (model.py:107-112): wave wv takes window positions wv, wv + 4, ...; a lane sums its three attention
+        // dims (lane, lane + 64, lane + 128) first, so a position costs ONE 64-lane reduction, not three
+        constexpr int NE = (PD_W + PD_NW - 1) / PD_NW;
+        float qv[3], ev[NE];
 #pragma unroll
         for (int j = 0; j < 3; ++j) qv[j] = lane + 64 * j < a.A ? s.q[lane + 64 * j] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int tt = min(wv + 8 * i, W - 1);
+        for (int i = 0; i < NE; ++i) {
+            const int tt = min(wv + PD_NW * i, W - 1);
             float e = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; ++j)     // pmw = processed memory + location term (pd_attention_pre)
                 e += lane + 64 * j < a.A ? r.va3[j] * fast_tanh(s.pmw[tt * a.A + lane + 64 * j] + qv[j]) : 0.f;
             ev[i] = e;
         }
-        wave_totals<5>(ev);
+        wave_totals<NE>(ev);
 #pragma unroll
-        for (int i = 0; i < 5; ++i)
-            if (lane == 0 && wv + 8 * i < W) s.en[wv + 8 * i] = ev[i];
+        for (int i = 0; i < NE; ++i)
+            if (lane == 0 && wv + PD_NW * i < W) s.en[wv + PD_NW * i] = ev[i];
     }
     __syncthreads();
     PD_STAMP(3);
@@ -424,18 +357,26 @@ __device__ __forceinline__ void pd_attention_post(const PdArgs& a, AttnLds& s, c
     }
     __syncthreads();
     PD_STAMP(4);
-    {   // context = sum_t w[t] * memory[t] out of the staged window: one thread per dimension, two chains, no second pass
-        const int d = t;      // PD_T == PD_DM
-        float c0 = 0.f, c1 = 0.f;
+    {   // context = sum_t w[t] * memory[t] out of the staged window: dimensions t and t + 256 per thread, two chains each
+        // (the same two-chain order per dimension as the one-dimension-per-thread form)
+        float c0[2] = {0.f, 0.f}, c1[2] = {0.f, 0.f};
 #pragma unroll
         for (int tt = 0; tt + 1 < PD_W; tt += 2) {
-            c0 = fmaf(tt < W ? s.wts[tt] : 0.f, s.memw[tt * PD_DM + d], c0);
-            c1 = fmaf(tt + 1 < W ? s.wts[tt + 1] : 0.f, s.memw[(tt + 1) * PD_DM + d], c1);
+            const float w0 = tt < W ? s.wts[tt] : 0.f, w1 = tt + 1 < W ? s.wts[tt + 1] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                c0[k] = fmaf(w0, s.memw[tt * PD_DM + t + PD_T * k], c0[k]);
+                c1[k] = fmaf(w1, s.memw[(tt + 1) * PD_DM + t + PD_T * k], c1[k]);
+            }
         }
-        c0 = fmaf(PD_W - 1 < W ? s.wts[PD_W - 1] : 0.f, s.memw[(PD_W - 1) * PD_DM + d], c0);
-        const float c = c0 + c1;
-        s.ctx[d] = c;
-        publish(g_ctx, b * PD_DM + d, epoch, c);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int d = t + PD_T * k;
+            c0[k] = fmaf(PD_W - 1 < W ? s.wts[PD_W - 1] : 0.f, s.memw[(PD_W - 1) * PD_DM + d], c0[k]);
+            const float c = c0[k] + c1[k];
+            s.ctx[d] = c;
+            publish(g_ctx, b * PD_DM + d, epoch, c);
+        }
     }
     PD_STAMP(5);
     for (int p = t; p < a.T; p += PD_T) {
@@ -466,7 +407,7 @@ __device__ __forceinline__ void attention_workgroup(const PdArgs& a, AttnLds& at
             r.wl[j] = (f < a.F && j < a.K) ? (a.blob + a.Wloc)[(f * 2 + 0) * a.K + j] : 0.f;
             r.wl[PD_KMAX + j] = (f < a.F && j < a.K) ? (a.blob + a.Wloc)[(f * 2 + 1) * a.K + j] : 0.f;
         }
-        r.pg = wv < 6 ? wv / 3 : -1;
+        r.pg = wv < 3 ? 0 : -1;          // waves 0..2: attention dims 0..191, every window position
         r.ad = (wv % 3) * 64 + lane;
         const bool live = r.pg >= 0 && r.ad < a.A;
 #pragma unroll
@@ -502,125 +443,359 @@ __device__ __forceinline__ void attention_workgroup(const PdArgs& a, AttnLds& at
     }
 }
 
-// DBG = true: the same kernel with the s_memrealtime stamps of ctts_taco_decoder_persistent_debug compiled in.  They are
-// NOT in the product instantiation: a dozen conditional stores were enough to push the register allocator from 54 to
-// ~160 spilled VGPRs (40.5 -> 45.7 us per step, measured), so a profiled run is ~10 % slower than the product.
-template <bool DBG>
-__global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a) {
-    __shared__ __attribute__((aligned(16))) float L[LSTM_FLOATS];
-    __shared__ float gates[4 * PD_UA][PD_NB];
-    __shared__ float cA[PD_UA][PD_NB], cD[PD_UD][PD_NB], c2[PD_UD][PD_NB];
-    __shared__ float hA[PD_UA][PD_NB], hD[PD_UD][PD_NB], h2[PD_UD][PD_NB];
-    __shared__ float pown[2][PD_NB];
 
+// ---- the weight-resident LSTM wave -----------------------------------------------------------------------------------
+// A wave owns whole LSTM units ("slots": all four gate rows i, f, g~, o of one unit of one cell) and evaluates them on the
+// matrix pipe with v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4x1 blocks; lane l = 4 blk + sub; measured operand layout,
+// scripts/micro/mfma_4x4x1_layout.hip: A[blk][row = sub], B[blk][col = sub], D[vgpr = row][lane = 4 blk + col]):
+//     A[blk][i] = W[gate i of the unit][column k],   B[blk][j] = x[item j][column k],   k = 64 tile + 4 blk + e  (e = 0..3)
+// so one "tile" = one float4 of weights per lane (64 columns of the unit's four rows) + one 16-byte LDS read of x per lane
+// feeds four MFMAs, and D[i] in lane (blk, j) accumulates gate i / item j over the columns of block blk.  After the last
+// product the 16 blocks are summed across lanes; every lane with sub = j then holds the four pre-activations of item j:
+// the cell update runs right there - no LDS round trip, no workgroup barrier between the gate sums and the cell.
+// The weights are ordinary values that only MFMAs consume: the register allocator spreads them over VGPRs AND AGPRs (512
+// per lane at one wave per SIMD; AGPR-held ones are copied by v_accvgpr_read on the otherwise idle VALU).
+typedef float pd_f4 __attribute__((ext_vector_type(4)));
+
+
+template <int I> struct IC { static constexpr int value = I; };
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) { f(IC<B>{}); static_for<B + 1, E>(f); }
+}
+
+// Units of workgroup wg (class table above) and its first unit per cell
+__device__ __forceinline__ int pd_first_att(int wg) { return wg < PD_C0 ? 6 * wg : 6 * PD_C0 + 5 * (wg - PD_C0); }
+__device__ __forceinline__ int pd_first_dec(int wg) {
+    return wg < PD_C0 ? 3 * wg : wg < PD_C1 ? 3 * PD_C0 + 4 * (wg - PD_C0) : 3 * PD_C0 + 4 * (PD_C1 - PD_C0) + 3 * (wg - PD_C1);
+}
+__device__ __forceinline__ int pd_first_d2(int wg) {
+    return wg < PD_C1 ? 3 * wg : wg < PD_C2 ? 3 * PD_C1 + 4 * (wg - PD_C1) : 3 * PD_C1 + 4 * (PD_C2 - PD_C1) + 3 * (wg - PD_C2);
+}
+
+// cell types of a slot.  Tiles of a slot, fresh segment first:
+//   ATT (44): prenet 4 [fresh] | context 8 | decoder hidden 12 | own hidden (W_hh) 20
+//   DEC (40): context 8 [fresh] | attention hidden 20 | own hidden 12
+//   D2  (24): decoder hidden 12 [fresh] | own hidden 12
+constexpr int CELL_NONE = 0, CELL_ATT = 1, CELL_DEC = 2, CELL_D2 = 3;
+__host__ __device__ constexpr int pd_cell_tiles(int c) { return c == CELL_ATT ? 44 : c == CELL_DEC ? 40 : c == CELL_D2 ? 24 : 0; }
+
+// A wave signature: up to three slots (cell types) and the number of its trailing tiles that live in LDS instead of
+// registers.  The trailing tiles are always "early" (off the critical path) tiles of the last slot.
+template <int C0, int C1, int C2, int NL>
+struct PdSig {
+    static constexpr int cell[3] = {C0, C1, C2};
+    static constexpr int off[4] = {0, pd_cell_tiles(C0), pd_cell_tiles(C0) + pd_cell_tiles(C1),
+                                   pd_cell_tiles(C0) + pd_cell_tiles(C1) + pd_cell_tiles(C2)};
+    static constexpr int NT = off[3], NLDS = NL, NREG = NT - NL;
+    static_assert(NREG <= 96, "more than 384 weight registers per lane");
+};
+using SigSAA = PdSig<CELL_D2, CELL_ATT, CELL_ATT, 16>;     // 92 tiles, 76 in registers
+using SigSDA = PdSig<CELL_D2, CELL_DEC, CELL_ATT, 16>;     // 108 - 16 = 92
+using SigDD = PdSig<CELL_DEC, CELL_DEC, CELL_NONE, 0>;     // 80
+using SigDDD = PdSig<CELL_DEC, CELL_DEC, CELL_DEC, 28>;    // 120 - 28 = 92
+using SigSDD = PdSig<CELL_D2, CELL_DEC, CELL_DEC, 16>;     // 104 - 16 = 88
+constexpr int PD_LT_WAVE = 28;                             // most LDS tiles of one wave; LDS tile slots per workgroup:
+constexpr int PD_LT = 76;                                  // 16+16+16+28 (class 0), 16+16+12+28, 16+16+12+16, 16+16+12+0
+
+// padded X rows: item j of a vector of n floats starts at j (n + 16): the 16-byte reads of the four items of a block fall
+// into different banks
+__host__ __device__ constexpr int pd_xs(int n) { return n + 16; }
+
+struct PdSlotRt {          // runtime side of a slot
+    int unit;              // unit index inside its cell (row of gate i: i * H + unit)
+    pd_f4 acc;             // D accumulators: gate i of item (lane & 3), block (lane >> 2).  ONE chain per slot: a second
+                           // interleaved chain was measured (A 1.06 -> 0.98 us) and cost more in spilled weights than it won
+    float bias[4];
+    float c, h;            // cell state / hidden value of item (lane & 3)
+};
+
+// all-gather receive into a padded X vector (item stride n + 16).  Two granules per 16-byte agent-scope load (each half is
+// written by ONE 8-byte store and carries its own tag; 8-byte loads swept the same vector 1.8x slower).  Every sweep of a
+// vector by all 256 CUs is 256 x 8 N bytes of fabric traffic (10 MB for att_h) that the publishers' stores and every
+// other CU's sweep queue behind, so the wait is split: a LIGHT phase polls one pair per thread (512 of the 4 N granules)
+// until those are there - the publishers of a vector finish within ~0.8 us of each other - and only then the FULL sweep
+// reads everything, PB pairs of a thread in flight at a time, and re-reads what was still missing.
+// The loads are raw buffer loads with the sc1 bit (what an agent-scope atomic load lowers to), so that the compiler
+// tracks them itself (inline-asm loads cost ~125 spilled weight registers around every gather).
+typedef unsigned pd_u4 __attribute__((ext_vector_type(4)));
+constexpr int PD_AUX_SC1 = 16;
+template <int N>
+__device__ __forceinline__ bool gather_x(const u64* g, float* dst, unsigned epoch, unsigned* ctl, int t, unsigned phase, unsigned step) {
+    constexpr int PAIRS = 2 * N, PPT = (PAIRS + PD_T - 1) / PD_T;
+    // pairs of a thread in flight during a full sweep: everything at once up to 6 (24 data registers), else rounds of 5
+    // (att_h: 10 pairs per thread; all 10 at once spilt 70 weight registers)
+    constexpr int PB = PPT <= 6 ? PPT : 5;
+    static_assert(PAIRS >= PD_T && N % 2 == 0, "every thread owns at least one pair");
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64*>(g), 0, PD_NB * N * 8, 0x00020000);
+    auto timed_out = [&](unsigned spins) -> bool {
+        if ((spins & 255u) != 255u) return false;
+        if (__hip_atomic_load((gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
+        if (spins > PD_SPIN_LIMIT) {
+            if ((t & 63) == 0 && atomicCAS(ctl, 0u, 1u) == 0u) { ctl[1] = blockIdx.x; ctl[2] = phase; ctl[3] = step; }
+            return true;
+        }
+        return false;
+    };
+    if constexpr (PPT > 4) {
+        // light phase (large vectors only): thread t watches pair t - one contiguous 4 KB read per workgroup.  (A sample
+        // strided over all units of item 0, i.e. over all publishing workgroups, was measured slower: att_h 4.3 -> 5.2 us.)
+        const int pl = t;
+        for (unsigned spins = 0;; ++spins) {
+            const pd_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * pl, 0, PD_AUX_SC1);
+            if (__all(v[1] == epoch && v[3] == epoch)) break;
+            if (timed_out(spins)) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+#pragma unroll 1
+    for (int k0 = 0; k0 < PPT; k0 += PB) {          // full sweep
+        unsigned done = 0;
+        for (unsigned spins = 0;; ++spins) {
+            pd_u4 v[PB];
+#pragma unroll
+            for (int k = 0; k < PB; ++k)
+                if (k0 + k < PPT && t + PD_T * (k0 + k) < PAIRS && !((done >> k) & 1u))
+                    v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * (t + PD_T * (k0 + k)), 0, PD_AUX_SC1);
+                else v[k] = pd_u4{0u, 0u, 0u, 0u};
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < PB; ++k) {
+                const int i = 2 * (t + PD_T * (k0 + k));
+                if (k0 + k < PPT && t + PD_T * (k0 + k) < PAIRS && !((done >> k) & 1u)) {
+                    if (v[k][1] == epoch && v[k][3] == epoch) {
+                        float* d = dst + i + 16 * (i / N);
+                        d[0] = __uint_as_float(v[k][0]); d[1] = __uint_as_float(v[k][2]);
+                        done |= 1u << k;
+                    } else {
+                        ok = false;
+                    }
+                }
+            }
+            if (__all(ok)) break;
+            if (timed_out(spins)) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    return true;
+}
+
+// sum of the 16 blocks: every lane ends with the total of its item (lane & 3).  Within a row of 16 lanes on the DPP
+// network (row_ror:4, row_ror:8), across the four rows through the LDS crossbar (xor 16, xor 32).
+__device__ __forceinline__ float pd_block_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));     // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));     // row_ror:8
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+#define PD_MFMA(acc, wv, xv) (acc) = __builtin_amdgcn_mfma_f32_4x4x1f32((wv), (xv), (acc), 0, 0, 0)
+
+template <class SIG>
+struct PdWaveW {
+    // register tiles 0 .. NREG-1 as single floats (VGPRs and AGPRs, the allocator's choice; 128-bit tuples instead made it
+    // spill 40 tiles per wave to scratch: an aligned AGPR quadruple per tile is much harder to place than four singles)
+    float r[SIG::NREG > 0 ? 4 * SIG::NREG : 4];
+};
+
+// tile T of this wave
+template <class SIG, int T>
+__device__ __forceinline__ pd_f4 pd_tile(const PdWaveW<SIG>& w, const float* lt, int lane) {
+    if constexpr (T < SIG::NREG) return pd_f4{w.r[4 * T], w.r[4 * T + 1], w.r[4 * T + 2], w.r[4 * T + 3]};
+    else return *reinterpret_cast<const pd_f4*>(lt + ((T - SIG::NREG) * 64 + lane) * 4);
+}
+
+// One segment [T0, T0 + NTILE) of slot tiles against NTILE consecutive 64-column chunks of an X vector starting at chunk X0:
+// for every slot s of the signature whose cell is CELL and whose segment starts at tile SEG inside the slot.  Slots of
+// the same cell share the x read and interleave their MFMAs (independent accumulators).
+template <class SIG, int CELL, int SEG, int NTILE>
+__device__ __forceinline__ void pd_segment(const PdWaveW<SIG>& w, const float* lt, const float* xlane, int lane, PdSlotRt (&sl)[3]) {
+    static_for<0, NTILE>([&](auto tt) {
+        constexpr int tau = decltype(tt)::value;
+        const pd_f4 x = *reinterpret_cast<const pd_f4*>(xlane + 64 * tau);
+        static_for<0, 3>([&](auto ss) {
+            constexpr int s = decltype(ss)::value;
+            if constexpr (SIG::cell[s] == CELL) {
+                const pd_f4 wv = pd_tile<SIG, SIG::off[s] + SEG + tau>(w, lt, lane);
+                PD_MFMA(sl[s].acc, wv[0], x[0]); PD_MFMA(sl[s].acc, wv[1], x[1]);
+                PD_MFMA(sl[s].acc, wv[2], x[2]); PD_MFMA(sl[s].acc, wv[3], x[3]);
+            }
+        });
+        // a fence for the instruction scheduler every second tile: without it the x reads (and the AGPR copies) of a whole
+        // segment are hoisted in front of its first MFMA and the weights end up in scratch
+        if constexpr (tau % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// LSTM cell update of every slot of cell CELL (layers.py:308-372, gate order i, f, g, o): block sums, activations,
+// publish h' of item (lane & 3) at [item][first + unit] from the lanes of block 0.
+template <class SIG, int CELL>
+__device__ __forceinline__ void pd_cells(PdSlotRt (&sl)[3], u64* g, unsigned epoch, int H, int first, int lane) {
+    static_for<0, 3>([&](auto ss) {
+        constexpr int s = decltype(ss)::value;
+        if constexpr (SIG::cell[s] == CELL) {
+            float pre[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pre[i] = pd_block_sum(sl[s].acc[i]) + sl[s].bias[i];
+            const float gi = fast_sigmoid(pre[0]), gf = fast_sigmoid(pre[1]);
+            const float gg = fast_tanh(pre[2]), go = fast_sigmoid(pre[3]);
+            sl[s].c = gf * sl[s].c + gi * gg;
+            sl[s].h = go * fast_tanh(sl[s].c);
+            if (lane < PD_NB) publish(g, lane * H + first + sl[s].unit, epoch, sl[s].h);
+            sl[s].acc = pd_f4{0.f, 0.f, 0.f, 0.f};
+        }
+    });
+}
+
+// one LDS-resident single row (query / projection / second prenet layer) on the matrix pipe: A = the row in sub-lane 0,
+// zero in the three other rows of the block.  wrow: [64 m4 + 4 blk + e], xlane as above.  Accumulates into acc[0].
+template <int NTILE>
+__device__ __forceinline__ void pd_row(const float* wrow, const float* xlane, int lane, pd_f4& acc) {
+    const bool row0 = (lane & 3) == 0;
+    pd_f4 c1 = {0.f, 0.f, 0.f, 0.f};                              // two interleaved chains: a single row IS the critical path
+#pragma unroll
+    for (int tau = 0; tau < NTILE; ++tau) {
+        pd_f4 wv = *reinterpret_cast<const pd_f4*>(wrow + 64 * tau + 4 * (lane >> 2));
+        const pd_f4 x = *reinterpret_cast<const pd_f4*>(xlane + 64 * tau);
+        if (!row0) wv = pd_f4{0.f, 0.f, 0.f, 0.f};
+        PD_MFMA(acc, wv[0], x[0]); PD_MFMA(c1, wv[1], x[1]); PD_MFMA(acc, wv[2], x[2]); PD_MFMA(c1, wv[3], x[3]);
+    }
+    acc[0] += c1[0];
+}
+
+struct LstmLds {
+    float pown[2][PD_NB];                         // this workgroup's one or two prenet outputs (state for the next launch)
+};
+
+// runtime description of a wave's slots: unit index inside its cell (or -1)
+struct PdSlots { int unit[3]; };
+
+template <class SIG, bool DBG>
+__device__ __forceinline__ void lstm_wave(const PdArgs& a, float* L, LstmLds& S, int wg, const PdSlots& su, int lt_tile0) {
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wg = blockIdx.x;
-    unsigned* ctl = reinterpret_cast<unsigned*>(a.xb + a.ctl);
-    if (__hip_atomic_load((gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
-        return;                                  // an earlier launch on this exchange buffer gave up: stay down
-    if (wg >= PD_LWG) {
-        attention_workgroup<DBG>(a, *reinterpret_cast<AttnLds*>(L), wg);
-        return;
-    }
+    const int blk = lane >> 2, sub = lane & 3;
     float* X = L;
-    const int I_att = PD_P + PD_DM + PD_RD, I_dec = PD_RA + PD_DM, Dp = PD_RD + PD_DM;
-    const int UA = unit_count(PD_RA, wg), FA = unit_first(PD_RA, wg);
-    const int UD = unit_count(PD_RD, wg), FD = unit_first(PD_RD, wg);
+    const float* lt = L + WLT + lt_tile0 * 64 * 4;                      // this wave's LDS tiles
+    constexpr int I_att = PD_P + PD_DM + PD_RD, I_dec = PD_RA + PD_DM, Dp = PD_RD + PD_DM;
+    const int FA = pd_first_att(wg), FD = pd_first_dec(wg), F2 = pd_first_d2(wg);
+    unsigned* ctl = reinterpret_cast<unsigned*>(a.xb + a.ctl);
+    // this lane's read position in every X vector: item sub, columns 4 blk ..
+    const float* xP = X + XP + sub * pd_xs(PD_P) + 4 * blk;
+    const float* xC = X + XCTX + sub * pd_xs(PD_DM) + 4 * blk;
+    const float* xD = X + XDEC + sub * pd_xs(PD_RD) + 4 * blk;
+    const float* xA = X + XATT + sub * pd_xs(PD_RA) + 4 * blk;
+    const float* x2 = X + XD2 + sub * pd_xs(PD_RD) + 4 * blk;
+    const float* xH = X + XH1 + sub * pd_xs(PD_P) + 4 * blk;
 
-    // this wave's weight rows (row-per-wave: local rows wave, wave + 8, wave + 16; local row r = gate r / U of unit r % U)
-    int rowA[3], rowD[2];
+    // ---- entry: every weight of this wave's units, once per launch.  Tile tau of a slot = float4 at
+    // blob[mat + (gate * H + first + unit) * ld + col(tau) + 4 blk], gate = sub.
+    PdWaveW<SIG> w;
+    PdSlotRt sl[3];
+    const int nbc = a.nbc;
+    static_for<0, 3>([&](auto ss) {
+        constexpr int s = decltype(ss)::value;
+        constexpr int cell = SIG::cell[s];
+        sl[s].unit = su.unit[s];
+        sl[s].acc = pd_f4{0.f, 0.f, 0.f, 0.f};
+        sl[s].c = 0.f; sl[s].h = 0.f;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { const int r = wave + 8 * i; rowA[i] = r < 4 * UA ? (r / UA) * PD_RA + FA + r % UA : -1; }
+        for (int i = 0; i < 4; ++i) sl[s].bias[i] = 0.f;
+        if constexpr (cell != CELL_NONE) {
+            constexpr int H = cell == CELL_ATT ? PD_RA : PD_RD;
+            const int first = cell == CELL_ATT ? FA : cell == CELL_DEC ? FD : F2;
+            const int urow = first + su.unit[s];
+            const unsigned wih = cell == CELL_ATT ? a.att_wih : cell == CELL_DEC ? a.dec_wih : a.d2_wih;
+            const unsigned whh = cell == CELL_ATT ? a.att_whh : cell == CELL_DEC ? a.dec_whh : a.d2_whh;
+            const unsigned bih = cell == CELL_ATT ? a.att_bih : cell == CELL_DEC ? a.dec_bih : a.d2_bih;
+            const unsigned bhh = cell == CELL_ATT ? a.att_bhh : cell == CELL_DEC ? a.dec_bhh : a.d2_bhh;
+            constexpr int ldi = cell == CELL_ATT ? I_att : cell == CELL_DEC ? I_dec : PD_RD;
+            const float* rih = a.blob + wih + (size_t)(sub * H + urow) * ldi + 4 * blk;
+            const float* rhh = a.blob + whh + (size_t)(sub * H + urow) * H + 4 * blk;
+            // column base of tile tau in [W_ih | W_hh] per cell (see the table above)
+            static_for<0, pd_cell_tiles(cell)>([&](auto tt) {
+                constexpr int tau = decltype(tt)::value;
+                constexpr int T = SIG::off[s] + tau;
+                const float* src;
+                if constexpr (cell == CELL_ATT) {
+                    if constexpr (tau < 4) src = rih + 64 * tau;                                   // prenet columns
+                    else if constexpr (tau < 12) src = rih + PD_P + 64 * (tau - 4);                // context
+                    else if constexpr (tau < 24) src = rih + PD_P + PD_DM + 64 * (tau - 12);       // decoder hidden
+                    else src = rhh + 64 * (tau - 24);
+                } else if constexpr (cell == CELL_DEC) {
+                    if constexpr (tau < 8) src = rih + PD_RA + 64 * tau;                           // context
+                    else if constexpr (tau < 28) src = rih + 64 * (tau - 8);                       // attention hidden
+                    else src = rhh + 64 * (tau - 28);
+                } else {
+                    if constexpr (tau < 12) src = rih + 64 * tau;                                  // decoder hidden
+                    else src = rhh + 64 * (tau - 12);
+                }
+                if constexpr (T < SIG::NREG) {
+                    // four SCALAR loads (volatile: the vectoriser must not merge them): a value that is born as a quarter
+                    // of a 128-bit load stays a sub-register of the tuple and the allocator then spills whole tuples; a
+                    // value pinned by inline asm ("=a" / "=v") cannot move between the register files.  Plain scalar
+                    // values that only MFMAs consume are spread over VGPRs and AGPRs by the allocator itself.
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { const int r = wave + 8 * i; rowD[i] = r < 4 * UD ? (r / UD) * PD_RD + FD + r % UD : -1; }
-
-    // ---- weight-stationary part.  LDS: fresh columns of the attention / decoder RNN and the small rows; registers: the
-    // second decoder RNN's fresh columns (its whole W_ih) and the biases.
-    for (int i = t; i < 4 * UA * 64; i += PD_T) {
-        const int r = i >> 6, l = i & 63;
-        const int row = (r / UA) * PD_RA + FA + r % UA;
-        *reinterpret_cast<float4*>(L + WFA + i * 4) = *reinterpret_cast<const float4*>((a.blob + a.att_wih) + (size_t)row * I_att + 4 * l);
-    }
-    for (int i = t; i < 4 * UD * 2 * 64; i += PD_T) {
-        const int r = i >> 7, j = (i >> 6) & 1, l = i & 63;
-        const int row = (r / UD) * PD_RD + FD + r % UD;
-        *reinterpret_cast<float4*>(L + WFD + i * 4) =
-            *reinterpret_cast<const float4*>((a.blob + a.dec_wih) + (size_t)row * I_dec + PD_RA + 4 * (l + 64 * j));
-    }
+                    for (int e = 0; e < 4; ++e) w.r[4 * T + e] = *reinterpret_cast<const volatile float*>(src + e);
+                } else {
+                    *reinterpret_cast<pd_f4*>(L + WLT + ((lt_tile0 + T - SIG::NREG) * 64 + lane) * 4) = *reinterpret_cast<const pd_f4*>(src);
+                }
+                if constexpr (tau % 8 == 7) __builtin_amdgcn_sched_barrier(0);      // loads in batches of eight
+            });
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                sl[s].bias[i] = __int_as_float(__builtin_amdgcn_readfirstlane(
+                    __float_as_int((a.blob + bih)[i * H + urow] + (a.blob + bhh)[i * H + urow])));
+            // state of step0: cell state and own hidden value of item sub
+            const unsigned cst = cell == CELL_ATT ? a.att_c : cell == CELL_DEC ? a.dec_c : a.d2_c;
+            const unsigned hin = cell == CELL_ATT ? a.att_h_in : cell == CELL_DEC ? a.dec_h_in : a.d2_h_in;
+            if (sub < nbc) { sl[s].c = (a.ws + cst)[sub * H + urow]; sl[s].h = (a.ws + hin)[sub * H + urow]; }
+        }
+    });
+    // the LDS-resident single rows (plain row layout)
     const int q_row = wg < a.A ? wg : -1;
     const int pr_row0 = wg, pr_row1 = wg + PD_LWG < a.pd_rows ? wg + PD_LWG : -1;
     const int w2_row0 = wg, w2_row1 = wg + PD_LWG < PD_P ? wg + PD_LWG : -1;
-    for (int i = t; i < 5 * 64; i += PD_T) {
-        const int j = i >> 6, l = i & 63;
-        if (q_row >= 0)
-            *reinterpret_cast<float4*>(L + WQ + i * 4) = *reinterpret_cast<const float4*>((a.blob + a.Wq) + (size_t)q_row * PD_RA + 4 * (l + 64 * j));
-        *reinterpret_cast<float4*>(L + WPR + i * 4) = *reinterpret_cast<const float4*>((a.blob + a.Wproj) + (size_t)pr_row0 * Dp + 4 * (l + 64 * j));
+    for (int i = t; i < PD_RA / 4; i += PD_T) {
+        if (q_row >= 0) reinterpret_cast<float4*>(L + WQ)[i] = reinterpret_cast<const float4*>((a.blob + a.Wq) + (size_t)q_row * PD_RA)[i];
+        reinterpret_cast<float4*>(L + WPR)[i] = reinterpret_cast<const float4*>((a.blob + a.Wproj) + (size_t)pr_row0 * Dp)[i];
         if (pr_row1 >= 0)
-            *reinterpret_cast<float4*>(L + WPR + 5 * 64 * 4 + i * 4) =
-                *reinterpret_cast<const float4*>((a.blob + a.Wproj) + (size_t)pr_row1 * Dp + 4 * (l + 64 * j));
+            reinterpret_cast<float4*>(L + WPR + Dp)[i] = reinterpret_cast<const float4*>((a.blob + a.Wproj) + (size_t)pr_row1 * Dp)[i];
     }
-    if (t < 64) {
-        *reinterpret_cast<float4*>(L + WW2 + t * 4) = *reinterpret_cast<const float4*>((a.blob + a.W2) + (size_t)w2_row0 * PD_P + 4 * t);
-        if (w2_row1 >= 0)
-            *reinterpret_cast<float4*>(L + WW2 + 64 * 4 + t * 4) = *reinterpret_cast<const float4*>((a.blob + a.W2) + (size_t)w2_row1 * PD_P + 4 * t);
-    }
-    float bA[3], bD[2], b2[2];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) bA[i] = rowA[i] >= 0 ? (a.blob + a.att_bih)[rowA[i]] + (a.blob + a.att_bhh)[rowA[i]] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const bool valid = rowD[i] >= 0;
-        const int row = valid ? rowD[i] : 0;
-        bD[i] = valid ? (a.blob + a.dec_bih)[row] + (a.blob + a.dec_bhh)[row] : 0.f;
-        b2[i] = valid ? (a.blob + a.d2_bih)[row] + (a.blob + a.d2_bhh)[row] : 0.f;
+    if (t < PD_P / 4) {
+        reinterpret_cast<float4*>(L + WW2)[t] = reinterpret_cast<const float4*>((a.blob + a.W2) + (size_t)w2_row0 * PD_P)[t];
+        if (w2_row1 >= 0) reinterpret_cast<float4*>(L + WW2 + PD_P)[t] = reinterpret_cast<const float4*>((a.blob + a.W2) + (size_t)w2_row1 * PD_P)[t];
     }
     const float bpr = wave == 1 ? (a.blob + a.bproj)[pr_row0] : (wave == 2 && pr_row1 >= 0) ? (a.blob + a.bproj)[pr_row1] : 0.f;
 
-    // ---- entry: state of step0 from the workspace (written by the init / the previous launch).  The workspace holds
-    // nbc <= 4 batch rows per state array; the rows above stay zero here and are never written back.
-    const int nbc = a.nbc;
-    for (int i = t; i < PD_NB * PD_P; i += PD_T) X[XP + i] = i / PD_P < nbc ? (a.ws + a.prenet)[i] : 0.f;
-    for (int i = t; i < PD_NB * PD_DM; i += PD_T) X[XCTX + i] = i / PD_DM < nbc ? (a.ws + a.ctx)[i] : 0.f;
-    for (int i = t; i < PD_NB * PD_RD; i += PD_T) {
-        X[XDEC + i] = i / PD_RD < nbc ? (a.ws + a.dec_h_in)[i] : 0.f;
-        X[XD2 + i] = i / PD_RD < nbc ? (a.ws + a.d2_h_in)[i] : 0.f;
-    }
-    for (int i = t; i < PD_NB * PD_RA; i += PD_T) X[XATT + i] = i / PD_RA < nbc ? (a.ws + a.att_h_in)[i] : 0.f;
-    if (t < UA * PD_NB) {
-        const int u = t / PD_NB, b = t % PD_NB;
-        cA[u][b] = b < nbc ? (a.ws + a.att_c)[b * PD_RA + FA + u] : 0.f;
-        hA[u][b] = b < nbc ? (a.ws + a.att_h_in)[b * PD_RA + FA + u] : 0.f;
-    }
-    if (t < UD * PD_NB) {
-        const int u = t / PD_NB, b = t % PD_NB;
-        cD[u][b] = b < nbc ? (a.ws + a.dec_c)[b * PD_RD + FD + u] : 0.f;
-        hD[u][b] = b < nbc ? (a.ws + a.dec_h_in)[b * PD_RD + FD + u] : 0.f;
-        c2[u][b] = b < nbc ? (a.ws + a.d2_c)[b * PD_RD + FD + u] : 0.f;
-        h2[u][b] = b < nbc ? (a.ws + a.d2_h_in)[b * PD_RD + FD + u] : 0.f;
-    }
+    // ---- entry: the vectors of step0 from the workspace (written by the init / the previous launch).  The workspace
+    // holds nbc <= 4 batch rows per state array; the rows above stay zero here and are never written back.
+    auto load_x = [&](int xo, int n, unsigned src) {
+        for (int i = t; i < PD_NB * n; i += PD_T) X[xo + i + 16 * (i / n)] = i / n < nbc ? (a.ws + src)[i] : 0.f;
+    };
+    load_x(XP, PD_P, a.prenet); load_x(XCTX, PD_DM, a.ctx); load_x(XDEC, PD_RD, a.dec_h_in); load_x(XD2, PD_RD, a.d2_h_in);
+    load_x(XATT, PD_RA, a.att_h_in);
     if (t < 2 * PD_NB) {
         const int k = t / PD_NB, b = t % PD_NB;
         const int row = k == 0 ? w2_row0 : w2_row1;
-        pown[k][b] = (row >= 0 && b < nbc) ? (a.ws + a.prenet)[b * PD_P + row] : 0.f;
+        S.pown[k][b] = (row >= 0 && b < nbc) ? (a.ws + a.prenet)[b * PD_P + row] : 0.f;
     }
     __syncthreads();
-    // per-lane partial sums of the early columns of the next cell evaluations (reduced over the wave only in the fresh
-    // phase): one generation of each is live at a time.  Early parts of step0, in the order the loop accumulates them:
-    float eA[3][PD_NB], eD[2][PD_NB], e2[2][PD_NB];
-    zero_rows<3>(eA); zero_rows<2>(eD); zero_rows<2>(e2);
-    early_rows<3, 3>(a.blob, a.att_whh, PD_RA, 0, rowA, X + XATT, PD_RA, 0, lane, eA);
-    early_rows<3, 2>(a.blob, a.att_whh, PD_RA, 768, rowA, X + XATT, PD_RA, 768, lane, eA);
-    early_rows<3, 2>(a.blob, a.att_wih, I_att, PD_P, rowA, X + XCTX, PD_DM, 0, lane, eA);
-    early_rows<3, 3>(a.blob, a.att_wih, I_att, PD_P + PD_DM, rowA, X + XDEC, PD_RD, 0, lane, eA);
-    early_rows<2, 3>(a.blob, a.dec_whh, PD_RD, 0, rowD, X + XDEC, PD_RD, 0, lane, eD);
-    early_rows<2, 3>(a.blob, a.d2_whh, PD_RD, 0, rowD, X + XD2, PD_RD, 0, lane, e2);
+    // the early products of step0, in the order the loop accumulates them
+    pd_segment<SIG, CELL_ATT, 24, 20>(w, lt, xA, lane, sl);
+    pd_segment<SIG, CELL_ATT, 4, 8>(w, lt, xC, lane, sl);
+    pd_segment<SIG, CELL_ATT, 12, 12>(w, lt, xD, lane, sl);
+    pd_segment<SIG, CELL_DEC, 28, 12>(w, lt, xD, lane, sl);
+    pd_segment<SIG, CELL_D2, 12, 12>(w, lt, x2, lane, sl);
+    // early part of the projection rows: W[:, :768] . dec_h + W[:, 768:] . ctx (the d2_h part waits for the d2_h exchange)
+    pd_f4 accP = {0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
     bool fail = false;
-#define PD_GATHER(NPT, buf, count, dst, phase)                                                                       \
+#define PD_GATHER(NPT, N, buf, dst, phase)                                                                          \
     do {                                                                                                               \
-        const bool ok_ = gather<NPT>((buf) + (size_t)par * (count), (count), (dst), epoch, ctl, t, (phase), (unsigned)step); \
+        const bool ok_ = gather_x<N>((buf) + (size_t)par * (PD_NB * (N)), (dst), epoch, ctl, t, (phase), (unsigned)step); \
         if (__syncthreads_or(ok_ ? 0 : 1)) { fail = true; }                                                            \
     } while (0)
 
@@ -629,118 +804,75 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
         const int par = step & 1;
         PD_STAMP(0);
         // the prenet's dropout keep-bytes of step + 1 for this wave's row (waves 1, 2: first layer, rows of the folded
-        // projection; waves 3, 4: second layer), lane = batch item.  Loaded HERE, a whole step ahead of their use: they
-        // are first-touch HBM bytes, and the load used to sit between the row's dot product and its publish - ~1.5 us
-        // on the critical path of both prenet exchanges.
+        // projection; waves 3, 0: second layer), lane = batch item.  Loaded HERE, a whole step ahead of their use: they
+        // are first-touch HBM bytes.
         const bool have_next = step + 1 < a.max_steps;
         unsigned char keep_next = 0;
         if (have_next && lane < a.batch) {
             if (wave == 1 || (wave == 2 && pr_row1 >= 0)) {
                 const int j = (wave == 1 ? pr_row0 : pr_row1) - a.n_mel - 1;
                 if (j >= 0) keep_next = a.keep[(((size_t)(step + 1) * 2 + 0) * a.batch + lane) * PD_P + j];
-            } else if (wave == 3 || (wave == 4 && w2_row1 >= 0)) {
+            } else if (wave == 3 || (wave == 0 && w2_row1 >= 0)) {
                 keep_next = a.keep[(((size_t)(step + 1) * 2 + 1) * a.batch + lane) * PD_P + (wave == 3 ? w2_row0 : w2_row1)];
             }
         }
         // ---- A: attention RNN on the fresh prenet columns (model.py:707-717)
-        {
-            float4 wf[3][1];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) wf[i][0] = *reinterpret_cast<const float4*>(L + WFA + (((wave + 8 * i) % (4 * PD_UA)) * 64 + lane) * 4);
-            fresh_gates<3, 1>(wf, bA, X + XP, PD_P, eA, gates, 4 * UA, wave, lane);
-        }
-        zero_rows<3>(eA);
-        __syncthreads();
-        cell_update(gates, cA, hA, (a.xb + a.g_atth) + (size_t)par * PD_NB * PD_RA, epoch, PD_RA, UA, FA, t);
+        pd_segment<SIG, CELL_ATT, 0, 4>(w, lt, xP, lane, sl);
+        pd_cells<SIG, CELL_ATT>(sl, (a.xb + a.g_atth) + (size_t)par * PD_NB * PD_RA, epoch, PD_RA, FA, lane);
         PD_STAMP(1);
-        // (weight loads whose vector operand is the one being gathered are issued BEFORE the gather: their L2 / Infinity
-        // Cache latency runs out during the wait, the FMAs follow the barrier)
-        float4 pfB[2][3], pfB2[2][2];
-        issue_rows<2, 3>(a.blob, a.dec_wih, I_dec, 0, rowD, lane, pfB);
-        issue_rows<2, 2>(a.blob, a.dec_wih, I_dec, 768, rowD, lane, pfB2);
-        PD_GATHER(10, (a.xb + a.g_atth), PD_NB * PD_RA, X + XATT, 1u);
+        PD_GATHER(20, PD_RA, (a.xb + a.g_atth), X + XATT, 1u);
         PD_STAMP(2);
         if (fail) break;
-        // ---- B: query row (model.py:126 query_layer); then, while the attention workgroups work, the columns that
-        // multiply att_h(step): the decoder RNN's (needed in C) and the attention RNN's recurrent ones (step + 1)
+        // ---- B: query row (model.py:126 query_layer); then, while the attention workgroups work, the products on
+        // att_h(step): the decoder RNN's (needed in C) and the attention RNN's recurrent ones (step + 1)
         if (wave == 0 && q_row >= 0) {
-            float q[PD_NB] = {0.f, 0.f, 0.f, 0.f};
-            row_dots<5>(L + WQ, X + XATT, PD_RA, lane, q);
-            wave_totals<PD_NB>(q);
-            if (lane < PD_NB)
-                publish((a.xb + a.g_q) + (size_t)par * PD_NB * a.A, lane * a.A + q_row, epoch,
-                        lane == 0 ? q[0] : lane == 1 ? q[1] : lane == 2 ? q[2] : q[3]);
+            pd_f4 q = {0.f, 0.f, 0.f, 0.f};
+            pd_row<20>(L + WQ, xA, lane, q);
+            const float qv = pd_block_sum(q[0]);
+            if (lane < PD_NB) publish((a.xb + a.g_q) + (size_t)par * PD_NB * a.A, lane * a.A + q_row, epoch, qv);
             PD_STAMP_LANE0(17);
         }
-        fma_rows<2, 3>(pfB, X + XATT, PD_RA, 0, lane, eD);
-        fma_rows<2, 2>(pfB2, X + XATT, PD_RA, 768, lane, eD);
-        // the attention RNN's recurrent columns of step + 1 (W_hh . att_h(step)): streamed HERE, in front of the longest
-        // wait of the step (query exchange + attention + context exchange), not between the projection's publish and
-        // the prenet gather where they delayed a 1.5 us exchange by 3 us (scripts/micro/allgather_floor.hip: the
-        // prenet-sized all-gather alone costs 1.5 us, the att_h-sized one 3.7)
-        if (have_next) {
-            early_rows<3, 3>(a.blob, a.att_whh, PD_RA, 0, rowA, X + XATT, PD_RA, 0, lane, eA);
-            early_rows<3, 2>(a.blob, a.att_whh, PD_RA, 768, rowA, X + XATT, PD_RA, 768, lane, eA);
-        }
+        pd_segment<SIG, CELL_DEC, 8, 20>(w, lt, xA, lane, sl);
+        pd_segment<SIG, CELL_ATT, 24, 20>(w, lt, xA, lane, sl);
         PD_STAMP(3);
-        float4 pfC[3][2];
-        issue_rows<3, 2>(a.blob, a.att_wih, I_att, PD_P, rowA, lane, pfC);
-        PD_GATHER(4, (a.xb + a.g_ctx), PD_NB * PD_DM, X + XCTX, 3u);
+        PD_GATHER(8, PD_DM, (a.xb + a.g_ctx), X + XCTX, 3u);
         PD_STAMP(4);
         if (fail) break;
         // ---- C: decoder RNN on the fresh context columns (model.py:741-747)
-        {
-            float4 wf[2][2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    wf[i][j] = *reinterpret_cast<const float4*>(L + WFD + ((((wave + 8 * i) % (4 * PD_UD)) * 2 + j) * 64 + lane) * 4);
-            fresh_gates<2, 2>(wf, bD, X + XCTX, PD_DM, eD, gates, 4 * UD, wave, lane);
-        }
-        zero_rows<2>(eD);
-        __syncthreads();
-        cell_update(gates, cD, hD, (a.xb + a.g_dech) + (size_t)par * PD_NB * PD_RD, epoch, PD_RD, UD, FD, t);
+        pd_segment<SIG, CELL_DEC, 0, 8>(w, lt, xC, lane, sl);
+        pd_cells<SIG, CELL_DEC>(sl, (a.xb + a.g_dech) + (size_t)par * PD_NB * PD_RD, epoch, PD_RD, FD, lane);
         PD_STAMP(13);
-        fma_rows<3, 2>(pfC, X + XCTX, PD_DM, 0, lane, eA);
+        pd_segment<SIG, CELL_ATT, 4, 8>(w, lt, xC, lane, sl);                   // attention RNN of step + 1 on ctx(step)
         PD_STAMP(5);
-        float4 wf2[2][3];      // the second decoder RNN's fresh columns (its whole W_ih, L2-resident): same trick
-        issue_rows<2, 3>(a.blob, a.d2_wih, PD_RD, 0, rowD, lane, wf2);
-        PD_GATHER(6, (a.xb + a.g_dech), PD_NB * PD_RD, X + XDEC, 4u);
+        PD_GATHER(12, PD_RD, (a.xb + a.g_dech), X + XDEC, 4u);
         PD_STAMP(6);
         if (fail) break;
         // ---- D: second decoder RNN on the fresh decoder-hidden columns (model.py:749-755)
-        fresh_gates<2, 3>(wf2, b2, X + XDEC, PD_RD, e2, gates, 4 * UD, wave, lane);
-        zero_rows<2>(e2);
-        __syncthreads();
-        cell_update(gates, c2, h2, (a.xb + a.g_d2h) + (size_t)par * PD_NB * PD_RD, epoch, PD_RD, UD, FD, t);
+        pd_segment<SIG, CELL_D2, 0, 12>(w, lt, xD, lane, sl);
+        pd_cells<SIG, CELL_D2>(sl, (a.xb + a.g_d2h) + (size_t)par * PD_NB * PD_RD, epoch, PD_RD, F2, lane);
         PD_STAMP(14);
-        // the attention RNN's decoder-hidden columns of step + 1: streamed after the publish, inside the d2_h exchange (a
-        // 3072-granule all-gather, ~2.5 us alone), instead of being held in 36 registers across the dec_h gather
-        early_rows<3, 3>(a.blob, a.att_wih, I_att, PD_P + PD_DM, rowA, X + XDEC, PD_RD, 0, lane, eA);
+        // products of step + 1 on dec_h(step): the attention RNN's decoder-hidden columns, the decoder RNN's recurrent
+        // ones; and the part of the projection rows that does not need d2_h
+        pd_segment<SIG, CELL_ATT, 12, 12>(w, lt, xD, lane, sl);
+        pd_segment<SIG, CELL_DEC, 28, 12>(w, lt, xD, lane, sl);
+        if (wave == 1 || (wave == 2 && pr_row1 >= 0)) {
+            const float* wrow = L + WPR + (wave == 1 ? 0 : Dp);
+            pd_row<12>(wrow, xD, lane, accP);                                    // W[:, :768] . dec_h
+            pd_row<8>(wrow + PD_RD, xC, lane, accP);                             // W[:, 768:] . ctx
+        }
         PD_STAMP(7);
-        float4 pfE[2][3], pfE2[2][3];      // recurrent columns of both decoder RNNs for step + 1
-        issue_rows<2, 3>(a.blob, a.d2_whh, PD_RD, 0, rowD, lane, pfE);
-        issue_rows<2, 3>(a.blob, a.dec_whh, PD_RD, 0, rowD, lane, pfE2);
-        PD_GATHER(6, (a.xb + a.g_d2h), PD_NB * PD_RD, X + XD2, 5u);
+        PD_GATHER(12, PD_RD, (a.xb + a.g_d2h), X + XD2, 5u);
         PD_STAMP(8);
         if (fail) break;
         // ---- E: projection row set on [dec_h + d2_h | ctx] (model.py:757-765; rows: mel, gate, folded prenet layer 1)
         if (wave == 1 || (wave == 2 && pr_row1 >= 0)) {
             const int row = wave == 1 ? pr_row0 : pr_row1;
-            const float* wrow = L + WPR + (wave == 1 ? 0 : 5 * 64 * 4);
-            float o[PD_NB] = {0.f, 0.f, 0.f, 0.f}, o2[PD_NB] = {0.f, 0.f, 0.f, 0.f};
-            row_dots<3>(wrow, X + XDEC, PD_RD, lane, o);                  // W[:, :768] . dec_h
-            row_dots<3>(wrow, X + XD2, PD_RD, lane, o2);                  // W[:, :768] . d2_h   (the residual sum, model.py:755)
-            row_dots<2>(wrow + 3 * 64 * 4, X + XCTX, PD_DM, lane, o);     // W[:, 768:] . ctx
-#pragma unroll
-            for (int b = 0; b < PD_NB; ++b) o[b] += o2[b];
-            wave_totals<PD_NB>(o);
-#pragma unroll
-            for (int b = 0; b < PD_NB; ++b) o[b] += bpr;
+            const float* wrow = L + WPR + (wave == 1 ? 0 : Dp);
+            pd_row<12>(wrow, x2, lane, accP);                                    // W[:, :768] . d2_h   (the residual sum, model.py:755)
+            const float val = pd_block_sum(accP[0]) + bpr;
+            accP = pd_f4{0.f, 0.f, 0.f, 0.f};
             if (lane < PD_NB) {
                 const int b = lane;
-                const float val = lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3];
                 if (row < a.n_mel) {
                     if (b < a.batch) a.mel_out[((size_t)b * a.n_mel + row) * a.max_steps + step] = val;
                 } else if (row == a.n_mel) {
@@ -753,62 +885,96 @@ __global__ __launch_bounds__(PD_T, 2) void taco_persistent_kernel(const PdArgs a
             }
             if (wave == 1) PD_STAMP_LANE0(15);
         }
-        fma_rows<2, 3>(pfE, X + XD2, PD_RD, 0, lane, e2);
-        fma_rows<2, 3>(pfE2, X + XDEC, PD_RD, 0, lane, eD);
+        pd_segment<SIG, CELL_D2, 12, 12>(w, lt, x2, lane, sl);                  // second decoder RNN of step + 1 on d2_h(step)
         if (have_next) {
-            // the two prenet exchanges below are the shortest of the step (1.5 us alone): nothing is streamed in them
             PD_STAMP(9);
-            PD_GATHER(2, (a.xb + a.g_h1), PD_NB * PD_P, X + XH1, 6u);
+            PD_GATHER(4, PD_P, (a.xb + a.g_h1), X + XH1, 6u);
             PD_STAMP(10);
             if (fail) break;
             // ---- F: second prenet layer rows
-            if (wave == 3 || (wave == 4 && w2_row1 >= 0)) {
-                const int k = wave - 3;
+            if (wave == 3 || (wave == 0 && w2_row1 >= 0)) {
+                const int k = wave == 3 ? 0 : 1;
                 const int row = k == 0 ? w2_row0 : w2_row1;
-                float o[PD_NB] = {0.f, 0.f, 0.f, 0.f};
-                row_dots<1>(L + WW2 + k * 64 * 4, X + XH1, PD_P, lane, o);
-                wave_totals<PD_NB>(o);
+                pd_f4 o = {0.f, 0.f, 0.f, 0.f};
+                pd_row<4>(L + WW2 + k * PD_P, xH, lane, o);
+                const float val = pd_block_sum(o[0]);
                 if (lane < PD_NB) {
                     const int b = lane;
-                    const float val = lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3];
                     const bool kp = keep_next != 0;
                     const float pv = kp ? fmaxf(val, 0.f) * 2.0f : 0.0f;
-                    pown[k][b] = pv;
+                    S.pown[k][b] = pv;
                     publish((a.xb + a.g_p) + (size_t)par * PD_NB * PD_P, b * PD_P + row, epoch, pv);
                 }
                 if (wave == 3) PD_STAMP_LANE0(16);
             }
             PD_STAMP(11);
-            PD_GATHER(2, (a.xb + a.g_p), PD_NB * PD_P, X + XP, 7u);
+            PD_GATHER(4, PD_P, (a.xb + a.g_p), X + XP, 7u);
             PD_STAMP(12);
             if (fail) break;
         }
     }
 #undef PD_GATHER
     if (fail) return;
-    // ---- exit: this workgroup's slices of the state for the next launch
+    // ---- exit: this wave's slices of the state for the next launch
     __syncthreads();
-    if (t < UA * PD_NB) {
-        const int u = t / PD_NB, b = t % PD_NB;
-        if (b < nbc) {
-            (a.ws + a.att_h_out)[b * PD_RA + FA + u] = hA[u][b];
-            (a.ws + a.att_c)[b * PD_RA + FA + u] = cA[u][b];
+    static_for<0, 3>([&](auto ss) {
+        constexpr int s = decltype(ss)::value;
+        constexpr int cell = SIG::cell[s];
+        if constexpr (cell != CELL_NONE) {
+            constexpr int H = cell == CELL_ATT ? PD_RA : PD_RD;
+            const int urow = (cell == CELL_ATT ? FA : cell == CELL_DEC ? FD : F2) + sl[s].unit;
+            const unsigned cst = cell == CELL_ATT ? a.att_c : cell == CELL_DEC ? a.dec_c : a.d2_c;
+            const unsigned hout = cell == CELL_ATT ? a.att_h_out : cell == CELL_DEC ? a.dec_h_out : a.d2_h_out;
+            if (lane < nbc) { (a.ws + hout)[lane * H + urow] = sl[s].h; (a.ws + cst)[lane * H + urow] = sl[s].c; }
         }
-    }
-    if (t < UD * PD_NB) {
-        const int u = t / PD_NB, b = t % PD_NB;
-        if (b < nbc) {
-            (a.ws + a.dec_h_out)[b * PD_RD + FD + u] = hD[u][b];
-            (a.ws + a.dec_c)[b * PD_RD + FD + u] = cD[u][b];
-            (a.ws + a.d2_h_out)[b * PD_RD + FD + u] = h2[u][b];
-            (a.ws + a.d2_c)[b * PD_RD + FD + u] = c2[u][b];
-        }
-    }
+    });
     if (t < 2 * PD_NB) {
         const int k = t / PD_NB, b = t % PD_NB;
         const int row = k == 0 ? w2_row0 : w2_row1;
-        if (row >= 0 && b < nbc) (a.ws + a.prenet)[b * PD_P + row] = pown[k][b];
+        if (row >= 0 && b < nbc) (a.ws + a.prenet)[b * PD_P + row] = S.pown[k][b];
     }
+}
+
+// The four waves of an LSTM workgroup of each class (slot = unit index inside the workgroup's units of that cell):
+//   class 0 (6,3,3): (S0 A0 A1) (S1 A2 A3) (S2 A4 A5) (D0 D1 D2)      class 1 (5,4,3): (S0 A0 A1) (S1 A2 A3) (S2 D0 A4) (D1 D2 D3)
+//   class 2 (5,3,4): (S0 A0 A1) (S1 A2 A3) (S2 D0 A4) (S3 D1 D2)      class 3 (5,3,3): (S0 A0 A1) (S1 A2 A3) (S2 D0 A4) (D1 D2)
+// LDS tiles of the waves start at 0, 16, 32, 48 (class 0) / 0, 16, 32, 44 (classes 1-3).
+template <bool DBG>
+__device__ __forceinline__ void lstm_workgroup(const PdArgs& a, float* L, LstmLds& S, int wg) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cls = wg < PD_C0 ? 0 : wg < PD_C1 ? 1 : wg < PD_C2 ? 2 : 3;
+    // ONE call (= one inlined copy of the step loop) per signature; slots and the first LDS tile are runtime values
+    PdSlots su;
+    int lt0;
+    if (wave < 2 || (wave == 2 && cls == 0)) {
+        su.unit[0] = wave; su.unit[1] = 2 * wave; su.unit[2] = 2 * wave + 1; lt0 = 16 * wave;
+        lstm_wave<SigSAA, DBG>(a, L, S, wg, su, lt0);
+    } else if (wave == 2) {
+        su.unit[0] = 2; su.unit[1] = 0; su.unit[2] = 4; lt0 = 32;
+        lstm_wave<SigSDA, DBG>(a, L, S, wg, su, lt0);
+    } else if (cls <= 1) {
+        su.unit[0] = cls; su.unit[1] = cls + 1; su.unit[2] = cls + 2; lt0 = 48;
+        lstm_wave<SigDDD, DBG>(a, L, S, wg, su, lt0);
+    } else if (cls == 2) {
+        su.unit[0] = 3; su.unit[1] = 1; su.unit[2] = 2; lt0 = 48;
+        lstm_wave<SigSDD, DBG>(a, L, S, wg, su, lt0);
+    } else {
+        su.unit[0] = 1; su.unit[1] = 2; su.unit[2] = -1; lt0 = 48;
+        lstm_wave<SigDD, DBG>(a, L, S, wg, su, lt0);
+    }
+}
+
+// DBG = true: the same kernel with the s_memrealtime stamps of ctts_taco_decoder_persistent_debug compiled in.
+template <bool DBG>
+__global__ __launch_bounds__(PD_T, 1) void taco_persistent_kernel(const PdArgs a) {
+    __shared__ __attribute__((aligned(16))) float L[LSTM_FLOATS];
+    __shared__ LstmLds S;
+    const int wg = blockIdx.x;
+    unsigned* ctl = reinterpret_cast<unsigned*>(a.xb + a.ctl);
+    if (__hip_atomic_load((gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+        return;                                  // an earlier launch on this exchange buffer gave up: stay down
+    if (wg >= PD_LWG) attention_workgroup<DBG>(a, *reinterpret_cast<AttnLds*>(L), wg);
+    else lstm_workgroup<DBG>(a, L, S, wg);
 }
 #undef PD_STAMP
 #undef PD_STAMP_LANE0

@@ -1,4 +1,7 @@
-// Launch-shape overrides for A/B measurements (never arithmetic: every alternative is bit-identical or tested equal).
+// Launch-shape overrides for A/B measurements.  The shapes of one GEMM are tested equal within the parity tolerance, not
+// all bit-identical: the split-K shape of the fused WaveFlow layer (CTTS_F32_NO_SPLITK turns it off) sums K in a different
+// order AND always computes in fp32 MFMA, also under the split-bf16 modes (include/cookietts_hip.h, "Which loop a launch
+// really runs"; ctts_last_gemm_loop reports it).
 // The environment is read ONCE, at the first launch that asks; ctts_tuning_reload() re-reads it (tests, profiling
 // scripts).  Arithmetic choices (fp32 MFMA vs split-bf16 main loop) are NOT here: they travel in the config structs.
 #pragma once
@@ -18,6 +21,7 @@ struct Tuning {
     int bf16_pp_stages;    // CTTS_BF16_PP_STAGES: 3 (default) or 4
     bool wf_no_fuse;       // CTTS_WF_NO_FUSE: WaveFlow layer as separate GATE + res/skip launches
     bool taco_no_fuse;     // CTTS_TACO_NO_FUSE: per-launch decoder without the fused projection kernel
+    bool wf_no_vec_interp; // CTTS_WF_NO_VEC_INTERP: the scalar form of the WaveFlow conditioning interpolation (bit-identical)
     int w4_debug;          // CTTS_BF16_W4_DEBUG (only in builds with -DCTTS_W4_TIMING_EXPERIMENTS)
 };
 

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void wf_interp_kernel(const float* __restrict_
         const int i1 = i0 + 1 < F ? i0 + 1 : F - 1;
         const float l1 = real - (float)i0;
         const float l0 = 1.0f - l1;
-        v = l0 * src[i0] + l1 * src[i1];
+        v = gemm_lerp(l0, src[i0], l1, src[i1]);   // explicit contraction: every interpolation in the library rounds the same way
     }
     up[((size_t)b * kmel + m) * ld + pad + l] = v;
 }
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void wf_interp_cond_kernel(const float* __rest
         const int i1 = i0 + 1 < F ? i0 + 1 : F - 1;
         const float l1 = real - (float)i0;
         const float l0 = 1.0f - l1;
-        v = l0 * src[i0] + l1 * src[i1];
+        v = gemm_lerp(l0, src[i0], l1, src[i1]);   // explicit contraction: every interpolation in the library rounds the same way
     }
     const int layer = ch / rows2c, r = ch % rows2c;
     up[(size_t)layer * slot + ((size_t)b * rows2c + r) * ld + pad + l] = v;
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void wf_interp_cond_vec_kernel(const float* __
             const int i1 = i0 + 1 < F ? i0 + 1 : F - 1;
             const float l1 = real - (float)i0;
             const float l0 = 1.0f - l1;
-            v[j] = l0 * src[i0] + l1 * src[i1];
+            v[j] = gemm_lerp(l0, src[i0], l1, src[i1]);
         }
     }
     const int layer = ch / rows2c, r = ch % rows2c;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void resample_rows_kernel(const float* __restr
         const int i1 = i0 + 1 < Tin ? i0 + 1 : Tin - 1;
         const float l1 = real - (float)i0;
         const float l0 = 1.0f - l1;
-        v = l0 * src[i0] + l1 * src[i1];
+        v = gemm_lerp(l0, src[i0], l1, src[i1]);   // explicit contraction: every interpolation in the library rounds the same way
     }
     y[((size_t)b * C + c) * ld_out + pad_out + n] = v;
 }
@@ -635,7 +635,7 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
         if (!p.c.mix_first && (rc = unmix(k))) return rc;                      // ax:324-325
         if (p.precond) {   // this flow's conditioning, upsampled once for all rows and layers
             const float* fr = cond + (size_t)k * batch * 2 * C * p.c.n_layers * cond_ld;
-            if (g.pad % 4 == 0 && g.ld % 4 == 0 && w.cond_slot % 4 == 0)
+            if (g.pad % 4 == 0 && g.ld % 4 == 0 && w.cond_slot % 4 == 0 && !tuning().wf_no_vec_interp)
                 hipLaunchKernelGGL(wf_interp_cond_vec_kernel, dim3(((L + 3) / 4 + 255) / 256, 2 * C * p.c.n_layers, batch), dim3(256), 0, s,
                                    fr, w.cond_up, 2 * C, p.c.n_layers, frames, cond_ld, cond_pad, L, g.ld, g.pad, w.cond_slot);
             else
@@ -690,6 +690,7 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
                         q.out = w.out; q.acc_out = i > 0 ? 1 : 0; q.rs_rows = p.rs_rows(i);
                         q.L = L; q.ld = g.ld; q.pad = g.pad; q.ntiles = (L + 63) / 64;
                         if ((rc = launch_wf_sep_layer(q, batch, s))) return rc;
+                        note_gemm_loop(q.split_bf16 ? 3 : 0);
                         continue;
                     }
                     a.a_ch_off = 0;

@@ -755,16 +755,21 @@ int ctts_waveglow_infer_spk_f32(const ctts_waveglow_config* cfg, const void* pac
 }
 
 int ctts_set_f32_gemm_mode(int32_t mode) {
-    if (set_gemm_f32_mode(mode)) { set_error("set_f32_gemm_mode: unknown mode %d (0 = fp32 MFMA, 1 = split bf16 x3, 2 = split bf16 x6)", mode); return CTTS_E_ARG; }
+    if (set_gemm_f32_mode(mode)) {
+        set_error("set_f32_gemm_mode: unknown mode %d (CTTS_GEMM_F32 = 1, CTTS_GEMM_BF16X3 = 2, CTTS_GEMM_BF16X6 = 3; 0 resets to fp32)", mode);
+        return CTTS_E_ARG;
+    }
     return CTTS_OK;
 }
 int ctts_get_f32_gemm_mode(void) { return get_gemm_f32_mode(); }
+int ctts_last_gemm_loop(void) { return last_gemm_loop(); }
 int ctts_tuning_reload(void) { reload_tuning(); return CTTS_OK; }
 int ctts_tuning_flags(void) {
     const Tuning t = tuning();
     return (t.f32_no_glds ? 1 : 0) | (t.no_xcd_pair ? 2 : 0) | (t.bf16_no_glds ? 4 : 0) | (t.bf16_no_wide ? 8 : 0) |
            (t.bf16_no_pp ? 16 : 0) | (t.bf16_w4 ? 32 : 0) | (t.bf16_pp_stages == 4 ? 64 : 0) | (t.wf_no_fuse ? 128 : 0) |
-           (t.taco_no_fuse ? 256 : 0) | (t.f32_no_small ? 512 : 0) | (t.f32_force_small ? 1024 : 0) | (t.f32_no_splitk ? 2048 : 0);
+           (t.taco_no_fuse ? 256 : 0) | (t.f32_no_small ? 512 : 0) | (t.f32_force_small ? 1024 : 0) | (t.f32_no_splitk ? 2048 : 0) |
+           (t.wf_no_vec_interp ? 4096 : 0);
 }
 
 int ctts_profile_enable(int32_t on) {

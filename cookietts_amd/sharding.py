@@ -70,11 +70,13 @@ def broadcast_state_dict(module: torch.nn.Module, src: int = 0, group=None, buck
     return total
 
 
-def scatter_mels(mels: Optional[torch.Tensor], n_mel: int, device, src: int = 0, group=None):
-    """rank ``src`` holds ``mels`` [N, n_mel, F]; returns this rank's slice [n_r, n_mel, F].
+def scatter_mels(mels: Optional[torch.Tensor], n_mel: int, device, src: int = 0, group=None, dtype=torch.float32):
+    """rank ``src`` holds ``mels`` [N, n_mel, F]; returns this rank's slice [n_r, n_mel, F] in ``dtype``.
 
     Slices are padded to the largest shard so the collective is regular; the pad is cut
-    off again before returning.
+    off again before returning.  ``dtype=torch.bfloat16`` is the wire format SURVEY.md 8e names for config 3
+    (32 x 80 x 900 bf16 = 4.6 MB per rank, half the fp32 scatter): the bf16 WN path rounds the mel to bf16 at its first
+    GEMM anyway, so rounding it before the wire changes nothing downstream.  Every rank must pass the same ``dtype``.
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -86,13 +88,13 @@ def scatter_mels(mels: Optional[torch.Tensor], n_mel: int, device, src: int = 0,
     n_items, frames = int(meta[0]), int(meta[1])
     counts = shard_counts(n_items, world)
     cmax = max(max(counts), 1)
-    recv = torch.empty(cmax, n_mel, frames, dtype=torch.float32, device=device)
+    recv = torch.empty(cmax, n_mel, frames, dtype=dtype, device=device)
     chunks = None
     if rank == src:
         chunks, start = [], 0
         for c in counts:
-            buf = torch.zeros(cmax, n_mel, frames, dtype=torch.float32, device=device)
-            buf[:c] = mels[start:start + c].to(device=device, dtype=torch.float32)
+            buf = torch.zeros(cmax, n_mel, frames, dtype=dtype, device=device)
+            buf[:c] = mels[start:start + c].to(device=device, dtype=dtype)
             chunks.append(buf)
             start += c
     dist.scatter(recv, chunks, src=src, group=group)
@@ -115,13 +117,14 @@ def gather_waves(wave: torch.Tensor, counts: Sequence[int], dst: int = 0, group=
 
 
 def sharded_infer(infer_fn: Callable[[torch.Tensor], torch.Tensor], mels: Optional[torch.Tensor],
-                  n_mel: int, device, root: int = 0, group=None):
-    """scatter -> local ``infer_fn(mel_slice) -> [n_r, T]`` -> gather.  Returns waves on ``root``."""
-    local, counts = scatter_mels(mels, n_mel, device, src=root, group=group)
+                  n_mel: int, device, root: int = 0, group=None, wire_dtype=torch.float32):
+    """scatter -> local ``infer_fn(mel_slice) -> [n_r, T]`` -> gather.  Returns waves on ``root``.
+    ``wire_dtype=torch.bfloat16`` ships the mels as bf16 (config 3); ``infer_fn`` receives that dtype."""
+    local, counts = scatter_mels(mels, n_mel, device, src=root, group=group, dtype=wire_dtype)
     if local.shape[0] > 0:
         wave = infer_fn(local)
     else:   # this rank got no utterance: contribute an empty slab of the right width
         frames = local.shape[2]
-        probe = infer_fn(torch.zeros(1, n_mel, frames, device=device))
+        probe = infer_fn(torch.zeros(1, n_mel, frames, device=device, dtype=wire_dtype))
         wave = probe[:0]
     return gather_waves(wave, counts, dst=root, group=group)

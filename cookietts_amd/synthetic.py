@@ -646,7 +646,7 @@ def tacotron_memory_in_dim(hp):
     return hp.encoder_LSTM_dim + hp.speaker_embedding_dim + hp.torchMoji_crushedDim + 1
 
 
-def tacotron_state_dict(hp, seed=1234, shapes=None, attention_drive=None):
+def tacotron_state_dict(hp, seed=1234, shapes=None, attention_drive=None, stop_drive=None):
     """Random-init state dict for the reference's ``Tacotron2`` (keys/shapes of its own
     ``state_dict()``; ``shapes`` = {key: shape} from a constructed module, or None to derive them
     from ``cookietts_amd.tacotron2.Tacotron2(hp)``).  Deterministic numpy recipe:
@@ -658,7 +658,14 @@ def tacotron_state_dict(hp, seed=1234, shapes=None, attention_drive=None):
     monotonically advancing one, the regime a trained model runs in: the energy vector ``v`` is scaled by ``gain``,
     location filter 0 reads the previous weights one and two tokens to the left (taps 13, 14 of channel 0 = ``a``),
     and attention dims 0..3 carry that feature (location_dense rows 0..3 = e_0, v[0..3] = c / 4), so each step the
-    peak moves right until the window reaches its right clamp (model.py:131-146)."""
+    peak moves right until the window reaches its right clamp (model.py:131-146).
+
+    ``stop_drive=(rate, sharp, [t_1, ..., t_k])`` builds a step clock into the second decoder LSTM so that a gate layer can be
+    given logits that cross the stop threshold at designed steps (tests/golden/make_golden.py tacotron_stop): unit 0 counts
+    (forget / input / output gates pinned open by +-12 biases, cell input tanh^-1-free constant ``rate``: h_0(t) =
+    tanh((t+1) rate)), unit j = 1..k is a sharp step of that clock (forget gate shut, cell input ``sharp`` x (h_0 - theta_j) read
+    through weight_hh, theta_j = tanh((t_j - 1/2) rate)): h_j(t) ~ +-tanh(1) from decoder step t_j on.  All other weights of
+    those 1 + k units, and the same units of the first decoder LSTM, are zero, so d_j = dec_h_j + dec2_h_j = h_j exactly."""
     if shapes is None:
         from .tacotron2 import Tacotron2
         shapes = {k: tuple(v.shape) for k, v in Tacotron2(hp).state_dict().items()}
@@ -703,6 +710,23 @@ def tacotron_state_dict(hp, seed=1234, shapes=None, attention_drive=None):
         d = sd[att + "location_layer.location_dense.linear_layer.weight"]
         d[:4] = 0
         d[:4, 0] = 1
+    if stop_drive is not None:
+        rate, sharp, times = stop_drive
+        H = hp.second_decoder_rnn_dim
+        units = list(range(1 + len(times)))
+        for cell in ("decoder.decoder_rnn", "decoder.second_decoder_rnn"):
+            for name in (".weight_ih", ".weight_hh", ".bias_ih", ".bias_hh"):
+                for g in range(4):
+                    sd[cell + name][[g * H + j for j in units]] = 0
+        whh, bih = sd["decoder.second_decoder_rnn.weight_hh"], sd["decoder.second_decoder_rnn.bias_ih"]
+        big = np.float32(12.0)
+        bih[0 * H + 0], bih[1 * H + 0], bih[3 * H + 0] = big, big, big       # clock: i, f, o open (gate order i, f, g, o)
+        bih[2 * H + 0] = np.float32(np.arctanh(rate))                          # cell input tanh(.) = rate per step
+        for j, t in enumerate(times, start=1):
+            theta = np.tanh((t - 0.5) * rate)
+            bih[0 * H + j], bih[1 * H + j], bih[3 * H + j] = big, -big, big    # i open, f shut, o open
+            whh[2 * H + j, 0] = np.float32(sharp)
+            bih[2 * H + j] = np.float32(-sharp * theta)
     return sd
 
 

@@ -128,10 +128,10 @@ def stop_step(gate_logits, gate_threshold, gate_delay, max_decoder_steps, state=
     return None, (sig_max, break_point, i0 + n)
 
 
-class Decoder(nn.Module):
-    _persistent_probed = False        # process-wide: the first persistent launch is checked synchronously
-    _persistent_disabled = False
+PERSIST_REPROBE_AFTER = 16     # inference() calls a decoder spends on the per-launch form before it tries the persistent form again
 
+
+class Decoder(nn.Module):
     def __init__(self, hparams):
         super().__init__()
         hp = hparams
@@ -180,7 +180,23 @@ class Decoder(nn.Module):
         self._ws = {}
         self._xchg = {}
         self.use_persistent = _PERSIST_ON      # False: the six-launches-per-step decoder (CTTS_TACO_NO_PERSIST=1 at import)
+        # per-decoder state of the persistent form: "unprobed" (its next launch is checked synchronously), "ok", or
+        # "disabled" (a probe found the 256 workgroups not co-resident; re-probed after PERSIST_REPROBE_AFTER calls)
+        self._persist = "unprobed"
+        self._persist_fallback_calls = 0
         _cache.hook_invalidate(self)
+
+    @property
+    def persistent_state(self):
+        """Which form of the decoder loop the next ``inference`` call of THIS decoder takes: "off" (``use_persistent``
+        False), "unprobed" / "ok" (persistent kernel), or "disabled" (per-launch form after a failed probe)."""
+        return self._persist if self.use_persistent else "off"
+
+    def reprobe_persistent(self):
+        """Forget a failed probe now (it is forgotten by itself after PERSIST_REPROBE_AFTER calls): the next call launches
+        the persistent kernel again and checks it synchronously."""
+        self._persist, self._persist_fallback_calls = "unprobed", 0
+        self._xchg = {}
 
     # ------------------------------------------------------------------ plumbing ----
     def c_config(self):
@@ -288,7 +304,11 @@ class Decoder(nn.Module):
         # persistent form (one launch per block of steps, weight-stationary fresh columns, granule all-gathers) where the
         # library builds it for this shape and device (0 bytes otherwise: the six-launches-per-step form).  The exchange
         # buffers are zero-filled once and kept with the workspaces; their last 64 bytes are the sticky control words.
-        persist = bool(self.use_persistent) and not Decoder._persistent_disabled
+        if self._persist == "disabled" and self.use_persistent:
+            self._persist_fallback_calls += 1
+            if self._persist_fallback_calls > PERSIST_REPROBE_AFTER:
+                self.reprobe_persistent()
+        persist = bool(self.use_persistent) and self._persist != "disabled"
         xchg = self._xchg.get(key) if persist else [None] * len(groups)
         if xchg is None:
             xchg = []
@@ -345,17 +365,20 @@ class Decoder(nn.Module):
                             C.byref(cfg), _lib.ptr(blob), _lib.ptr(km), _lib.ptr(mel[g0:g1]), _lib.ptr(gate[g0:g1]),
                             _lib.ptr(align[g0:g1]), g1 - g0, T, done, n, max_steps, _lib.ptr(ws), _lib.ptr(xb),
                             xb.numel() * 8, stream), "ctts_taco_decoder_steps_persistent_f32")
-                        if not Decoder._persistent_probed:
-                            # first persistent launch of this process: make sure all 256 workgroups really were resident
-                            # together (a bounded wait gives up otherwise and leaves the decoder state untouched), else
-                            # fall back to the per-launch form for good and redo this block with it
+                        if self._persist == "unprobed":
+                            # first persistent launch of this decoder (or the first after a re-probe): make sure all 256
+                            # workgroups really were resident together (a bounded wait gives up otherwise and leaves the
+                            # decoder state untouched), else fall back to the per-launch form for the next
+                            # PERSIST_REPROBE_AFTER calls of THIS decoder and redo this block with it
                             stream_obj.synchronize()
-                            Decoder._persistent_probed = True
-                            if int(ctl_words(xb)[0].item()) != 0:
+                            self._persist = "ok"
+                            words = ctl_words(xb).cpu()
+                            if int(words[0]) != 0:
                                 import warnings
-                                warnings.warn("persistent decoder kernel could not run (workgroups not co-resident?); "
-                                              "using the per-launch decoder")
-                                Decoder._persistent_disabled = True
+                                warnings.warn(f"persistent decoder kernel could not run (workgroup {int(words[1])} gave up in "
+                                              f"phase {int(words[2])} of step {int(words[3])}: workgroups not co-resident?); this "
+                                              f"decoder uses the per-launch form for its next {PERSIST_REPROBE_AFTER} calls")
+                                self._persist, self._persist_fallback_calls = "disabled", 0
                                 xchg = [None] * len(groups)      # every remaining group of this call too
                                 self._xchg = {}
                                 xb = None

@@ -38,14 +38,16 @@ extern "C" {
 #define CTTS_E_LAUNCH (-2)    /* HIP launch or runtime error */
 #define CTTS_E_WORKSPACE (-3) /* workspace too small */
 
-#define CTTS_ABI_VERSION 4   /* 2: ctts_waveglow_config.speaker_embed_dim, ctts_waveglow_flow_weights.speaker_embed
+#define CTTS_ABI_VERSION 5   /* 2: ctts_waveglow_config.speaker_embed_dim, ctts_waveglow_flow_weights.speaker_embed
                               * 3: gated_unit / merge_res_skip in ctts_waveflow_config and ctts_wgax_config
                               * 4: f32_gemm_mode in ctts_waveglow_config, ctts_waveflow_config, ctts_wgax_config and
                               *    ctts_conv1d_desc (the arithmetic mode belongs to the model, not to the process);
-                              *    ctts_tuning_reload; the persistent decoder's control words are exactly the last 64 bytes */
+                              *    ctts_tuning_reload; the persistent decoder's control words are exactly the last 64 bytes
+                              * 5: ctts_set_f32_gemm_mode / ctts_get_f32_gemm_mode speak CTTS_GEMM_* (one encoding for the
+                              *    process default and the config structs' field) and are deprecated; ctts_last_gemm_loop */
 
 /* Main loop of the fp32 conv-GEMM a model's launches use (field f32_gemm_mode of the config structs). */
-#define CTTS_GEMM_DEFAULT 0  /* the library default: fp32 MFMA unless ctts_set_f32_gemm_mode changed it */
+#define CTTS_GEMM_DEFAULT 0  /* the library default: fp32 MFMA unless the deprecated ctts_set_f32_gemm_mode changed it */
 #define CTTS_GEMM_F32 1      /* v_mfma_f32_32x32x2_f32: exact fp32 products */
 #define CTTS_GEMM_BF16X3 2   /* split bf16: hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulation */
 #define CTTS_GEMM_BF16X6 3   /* 3-way split (24 mantissa bits): the six products >= 2^-16 (hh, hm, mh, hl, lh, mm); fp32-grade */
@@ -632,20 +634,35 @@ int ctts_taco_stop_rule_f32(const float* gate_logits, int32_t batch, int32_t gat
  * ones are <= 2^-24 relative): fp32-grade results at 6/16 of the fp32 matrix-pipe cycles (tests/test_gemm_mode.py holds
  * its error against the reference goldens within 2x of the fp32 MFMA path's).
  * The mode is part of each model's config struct (f32_gemm_mode = CTTS_GEMM_F32 | CTTS_GEMM_BF16X3 | CTTS_GEMM_BF16X6), so two models in one
- * process can differ and nothing races with in-flight calls.  ctts_set_f32_gemm_mode only sets what CTTS_GEMM_DEFAULT (0)
- * resolves to (0 = fp32 MFMA, the initial value; 1 = split bf16 x3; 2 = split bf16 x6) for callers that leave the field at 0, and for the two
- * entry points without a config struct (ctts_lstm_seq_f32's input projection, ctts_taco_decoder_init_f32's processed
- * memory); returns 0, or -1 for an unknown mode.  The STFT entry points always compute in fp32 MFMA (their sums cancel). */
+ * process can differ and nothing races with in-flight calls.  The STFT entry points always compute in fp32 MFMA (their
+ * sums cancel).
+ *
+ * Which loop a launch really runs also depends on its SHAPE (all of it deterministic in the arguments, none of it in the
+ * environment): the fused WaveFlow layer (C = 64) runs the fp32-MFMA split-K shape whenever ntiles * batch <= 128
+ * (B <= 2 at 900 frames) under EVERY mode, and the fused separable layer (C = 128) runs fp32 MFMA under CTTS_GEMM_BF16X6;
+ * the split-K shape sums in a different order than the other shapes, so the same utterance is bit-identical across
+ * batch sizes only within one shape.  ctts_last_gemm_loop() reports what the most recent conv-GEMM launch of the calling
+ * thread ran, so that a benchmark row can label itself: bits 0-3 = split level (0 fp32 MFMA, 3, 6), bit 4 = small shape,
+ * bit 5 = split-K shape.
+ *
+ * DEPRECATED - ctts_set_f32_gemm_mode / ctts_get_f32_gemm_mode: a process-wide default (what CTTS_GEMM_DEFAULT (0) in a
+ * config struct resolves to, and the mode of the two entry points without a config struct: ctts_lstm_seq_f32's input
+ * projection, ctts_taco_decoder_init_f32's processed memory).  Superseded by the per-model field; kept for callers that
+ * flip one switch for a whole process.  Since ABI 5 both speak CTTS_GEMM_*: set takes CTTS_GEMM_F32 / _BF16X3 / _BF16X6
+ * (CTTS_GEMM_DEFAULT resets to fp32 MFMA) and returns 0, or -1 for anything else; get returns one of the three. */
+int ctts_last_gemm_loop(void);
 int ctts_set_f32_gemm_mode(int32_t mode);
 int ctts_get_f32_gemm_mode(void);
 
 /* Launch-shape overrides for A/B measurements (CTTS_F32_NO_GLDS, CTTS_F32_NO_SMALL, CTTS_F32_FORCE_SMALL, CTTS_GEMM_NO_XCD_PAIR, CTTS_BF16_NO_GLDS / _NO_WIDE /
- * _NO_PP / _W4 / _PP_STAGES, CTTS_WF_NO_FUSE, CTTS_TACO_NO_FUSE) never change results.  The environment is read once,
+ * _NO_PP / _W4 / _PP_STAGES, CTTS_WF_NO_FUSE, CTTS_WF_NO_VEC_INTERP, CTTS_TACO_NO_FUSE) never change results beyond the parity
+ * tolerance (CTTS_F32_NO_SPLITK changes the summation order of the fused WaveFlow layer at batch <= 2, see above).  The environment is read once,
  * at the first launch; this re-reads it (tests and profiling scripts that flip a knob in-process). */
 int ctts_tuning_reload(void);
 /* The knobs as the library currently sees them: bit 0 CTTS_F32_NO_GLDS, 1 CTTS_GEMM_NO_XCD_PAIR, 2 CTTS_BF16_NO_GLDS,
  * 3 CTTS_BF16_NO_WIDE, 4 CTTS_BF16_NO_PP, 5 CTTS_BF16_W4, 6 CTTS_BF16_PP_STAGES=4, 7 CTTS_WF_NO_FUSE, 8 CTTS_TACO_NO_FUSE,
- * 9 CTTS_F32_NO_SMALL, 10 CTTS_F32_FORCE_SMALL, 11 CTTS_F32_NO_SPLITK (tests assert that a knob they set is the one in effect). */
+ * 9 CTTS_F32_NO_SMALL, 10 CTTS_F32_FORCE_SMALL, 11 CTTS_F32_NO_SPLITK, 12 CTTS_WF_NO_VEC_INTERP (tests assert that a knob they set is the
+ * one in effect). */
 int ctts_tuning_flags(void);
 
 /* ---- in-library kernel timing (bench.py roofline leg) --------------------------------- */

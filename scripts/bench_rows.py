@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Secondary measurements for SURVEY.md 8 rows B (WaveFlow, config 4), C (Tacotron2 decoder, config 5)
-and D (STFT/mel).  bench.py stays the headline (config 2); this prints one JSON line per row."""
+and D (STFT/mel).  bench.py stays the headline (config 2): it imports the row functions of this file and attaches
+short runs of configs 3 / 4 / 5 to its JSON line as ``rows`` (after, never inside, the headline's timed region);
+run as a script this prints one JSON line per row."""
 import argparse
 import json
 import os
@@ -29,6 +31,19 @@ def timed(fn, warmup, steps):
     return (time.perf_counter() - t0) / steps
 
 
+FP32_MFMA_PEAK_TFLOPS = 157.3
+
+
+def gemm_loop_label():
+    """What the calling thread's last conv-GEMM launch really ran (ctts_last_gemm_loop): the fused WaveFlow layer runs
+    fp32 MFMA in its split-K shape (batch <= 2) whatever mode the model asked for."""
+    from cookietts_amd import _lib
+    code = _lib.lib().ctts_last_gemm_loop()
+    loop = {0: "fp32 MFMA", 3: "split-bf16 x3", 6: "split-bf16 x6"}.get(code & 15, f"level {code & 15}")
+    shape = "split-K shape" if code & 32 else "small shape" if code & 16 else "large shape"
+    return f"{loop}, {shape}"
+
+
 def row_waveflow(args):
     from cookietts_amd.waveglow_ax import WaveGlow
     cfg = synthetic.WAVEFLOW_CONFIGS["full"]
@@ -40,6 +55,7 @@ def row_waveflow(args):
         F = 900
         mel = torch.from_numpy(synthetic.synthetic_mel(B, F)).cuda()
         dt = timed(lambda: m.infer(mel, sigma=0.6, return_CPU=False), args.warmup, args.steps)
+        loop = gemm_loop_label()
         samples = B * (F - 1) * 256
         wn = cfg["WN_config"]
         C, G = wn["n_channels"], cfg["n_group"]
@@ -50,6 +66,8 @@ def row_waveflow(args):
                      "dtype": "f32", "batch": B, "frames": F,
                      "kernel_launches_per_utterance_batch": launches + 2 * cfg["n_flows"] * (G - 1),
                      "achieved_tflops_algorithmic": 2 * mac * samples / dt / 1e12,
+                     "mfma_frac_algorithmic": 2 * mac * samples / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                     "last_gemm_loop": loop,
                      # 138 KB of per-layer-kernel traffic per output sample (2304 B per row, step, layer)
                      "achieved_GBps_vs_138KB_per_sample": 138e3 * samples / dt / 1e9,
                      "hbm_frac_vs_138KB_per_sample": 138e3 * samples / dt / 8e12})
@@ -107,7 +125,8 @@ def row_waveglow_ax_notebook(args):
     return rows
 
 
-def row_tacotron(args):
+def row_tacotron(args, vocoder=None):
+    """``vocoder``: a WaveGlow (config 2 weights) already on the GPU, or None to build one."""
     from cookietts_amd.tacotron2 import Tacotron2
     hp = synthetic.tacotron_hparams()
     m = Tacotron2(hp)
@@ -125,18 +144,21 @@ def row_tacotron(args):
     weights_mb = sum(p.numel() for n, p in m.decoder.named_parameters()
                      if "rnn" in n or "projection" in n or "gate" in n or "query" in n or "prenet" in n) * 4 / 1e6
     # chained vocoder: WaveGlow config 2 weights on the B=4 x 900-frame mel the model just produced
-    from cookietts_amd import WaveGlow
-    wcfg = synthetic.WAVEGLOW_CONFIGS["full"]
-    wg = WaveGlow(**wcfg)
-    wg.load_state_dict(synthetic.to_torch(synthetic.waveglow_state_dict(wcfg, seed=1234)))
-    wg = wg.cuda().eval()
+    wg = vocoder
+    if wg is None:
+        from cookietts_amd import WaveGlow
+        wcfg = synthetic.WAVEGLOW_CONFIGS["full"]
+        wg = WaveGlow(**wcfg)
+        wg.load_state_dict(synthetic.to_torch(synthetic.waveglow_state_dict(wcfg, seed=1234)))
+        wg = wg.cuda().eval()
     mel = m.inference(text, lens, spk, tm, fixed_steps=steps)["pred_mel_postnet"].clamp(-11.52, 2.0)
     dv = timed(lambda: wg.infer(mel, sigma=0.6), 1, max(1, args.steps - 1))
     samples = B * steps * 256
     return {"row": "C/config5", "metric": "Tacotron2-TM decoder step time, B=4, 200 symbols, 900 forced steps",
             "value": dd / steps * 1e6, "unit": "us/step", "higher_is_better": False,
             "mel_frames_per_s_batch": B * steps / dd, "end_to_end_ms_incl_encoder_postnet": dt * 1e3,
-            "dtype": "f32", "weights_streamed_per_step_MB": weights_mb,
+            "dtype": "f32", "weights_streamed_per_step_MB": weights_mb, "decoder_form": m.decoder.persistent_state,
+            "floor_us_per_step_at_8TBps": weights_mb / 1e3 / 8000.0 * 1e6,
             "achieved_weight_stream_GBps": weights_mb / 1e3 / (dd / steps),
             "hbm_frac_weight_stream": weights_mb / 1e3 / (dd / steps) / 8000.0,
             "chained_vocoder_samples_per_s": samples / dv, "chained_vocoder_ms": dv * 1e3,
@@ -193,5 +215,5 @@ if __name__ == "__main__":
         from cookietts_amd import _lib
         mode = {v: k for k, v in _lib.GEMM_MODES.items()}[_lib.lib().ctts_get_f32_gemm_mode()]
         for line in (out if isinstance(out, list) else [out]):
-            line["f32_gemm_mode"] = mode          # "f32" (fp32 MFMA products) or "bf16x3" (CTTS_F32_GEMM_MODE=bf16x3)
+            line["f32_gemm_mode"] = mode          # the process default the models inherited: "f32" unless CTTS_F32_GEMM_MODE set it
             print(json.dumps(line), flush=True)

@@ -347,7 +347,7 @@ def make_waveglow_ax(full_length=False, untts=False, gates=False):
               f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
-def _ref_tacotron(hp, seed, attention_drive=None):
+def _ref_tacotron(hp, seed, attention_drive=None, stop_drive=None):
     """Reference Tacotron2 with the recipe weights.  Shims: no-op RNNCellBase input checks
     (removed in torch 2.x, called at utils/model/layers.py:375-379)."""
     import json
@@ -361,7 +361,7 @@ def _ref_tacotron(hp, seed, attention_drive=None):
     shapes = {k: list(v.shape) for k, v in m.state_dict().items()}
     with open(os.path.join(HERE, "tacotron_state_shapes.json"), "w") as f:
         json.dump(shapes, f, indent=0, sort_keys=True)
-    sd = synthetic.tacotron_state_dict(hp, seed=seed, shapes=shapes, attention_drive=attention_drive)
+    sd = synthetic.tacotron_state_dict(hp, seed=seed, shapes=shapes, attention_drive=attention_drive, stop_drive=stop_drive)
     res = m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
     assert not res.missing_keys and not res.unexpected_keys
     return m.eval(), ref_model, sd
@@ -510,6 +510,132 @@ def make_tacotron_long():
               f"max weight {align.max(-1).mean():.3f} -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+# name -> (gate_threshold, gate_delay, max_decoder_steps) set on the decoder the way the server does (text2speech.py:410-412,457)
+TACOTRON_STOP_CASES = {
+    "delay0": (0.5, 0, 200), "delay2": (0.5, 2, 200), "delay3": (0.5, 3, 200), "delay4": (0.5, 4, 200),
+    "delay10": (0.5, 10, 200), "thr_hi": (0.75, 2, 90), "cap_before": (0.5, 0, 50), "cap_in_delay": (0.5, 4, 64),
+    "never": (0.97, 0, 80),
+}
+# the step clock built into the second decoder LSTM (synthetic.tacotron_state_dict stop_drive): (rate, sharpness, step times)
+TACOTRON_STOP_DRIVE = (0.01, 800.0, [1, 4, 23, 25, 40, 52, 61])
+# what the gate layer adds per step unit: f(t) = -1 + sum_j amp_j [t >= t_j]  ->  f = +1 on steps 1-3 and 23-24, -1 between,
+# 3 from step 40, 5 from 52, 7 from 61; item b's logit is f(t) - level_b
+TACOTRON_STOP_AMPS = [2.0, -2.0, 2.0, -2.0, 4.0, 2.0, 2.0]
+TACOTRON_STOP_LEVELS = [0.0, 2.0, 6.0, 4.0]
+# => first step >= 5 at which sigmoid(gate) > 0.5 per item.  Item 0 also spikes on steps 1-3 (ignored by the rule, model.py:893:
+# ``if i > 4``) and is over the threshold on steps 23, 24 only until step 40 (the rule keeps the running max, :894)
+TACOTRON_STOP_CROSS = [23, 40, 61, 52]
+TACOTRON_STOP_PROBE = 72
+
+
+def make_tacotron_stop():
+    """Goldens in which the reference's OWN stop rule ends Decoder.inference (model.py:879-904): full-size model (config 5
+    hparams), B=4, 72 symbols, lengths [72,64,48,56], peaked attention recipe, and the step clock of
+    ``synthetic.tacotron_state_dict(stop_drive=...)`` in the second decoder LSTM.  The gate layer (weight and bias stored in
+    the fixture: part of the weight recipe) reads the clock's step units with the amplitudes above, and tells the items apart
+    through the attention context, whose speaker part is constant per item: a forced probe run of the reference captures the
+    context per step and the context half of the gate weight is the ridge solution that maps it to -level_b (the gate output
+    does not feed back into the recurrence, model.py:668-767, so the probe's trajectory is the cases' trajectory).
+    Each case then runs ``Tacotron2.inference`` with the reference's rule live and ``gate_threshold`` / ``gate_delay`` /
+    ``max_decoder_steps`` set on the decoder as the server sets them."""
+    torch.set_num_threads(8)
+    hp = synthetic.tacotron_hparams()
+    seed, B, T_txt = 1234, 4, 72
+    lengths = np.array([72, 64, 48, 56], dtype=np.int64)
+    rng = np.random.default_rng(4242)
+    text = rng.integers(1, hp.n_symbols, size=(B, T_txt)).astype(np.int64)
+    for b in range(B):
+        text[b, lengths[b]:] = 0
+    speakers = np.array([3, 2, 1, 0], dtype=np.int64)
+    tm = rng.standard_normal((B, hp.torchMoji_attDim)).astype(np.float32)
+    mask_seed = seed + 3
+    max_cap = max(c[2] for c in TACOTRON_STOP_CASES.values())
+    masks = synthetic.prenet_dropout_masks(max_cap, B, hp.prenet_dim, seed=mask_seed)
+    drive = TACOTRON_LONG["long_peaked"]
+    model, ref_model, sd = _ref_tacotron(hp, seed, attention_drive=drive, stop_drive=TACOTRON_STOP_DRIVE)
+    args = (torch.from_numpy(text), torch.from_numpy(lengths), torch.from_numpy(speakers), torch.from_numpy(tm))
+    saved = ref_model.F.dropout
+
+    def run(thr, delay, cap, hook=None):
+        ref_model.F.dropout = _MaskedDropout(masks)
+        h = model.decoder.gate_layer.register_forward_pre_hook(hook) if hook else None
+        dec_mel = []
+        h2 = model.postnet.register_forward_pre_hook(lambda m, a: dec_mel.append(a[0].detach().clone()))
+        try:
+            model.decoder.gate_delay = int(delay)                 # text2speech.py:410
+            model.decoder.max_decoder_steps = int(cap)            # :411
+            model.decoder.gate_threshold = float(thr)             # :412
+            with torch.no_grad():
+                out = model.inference(*args)
+        finally:
+            ref_model.F.dropout = saved
+            h2.remove()
+            if h:
+                h.remove()
+        return {k: v.numpy().astype(np.float32) for k, v in out.items()}, dec_mel[0].numpy().astype(np.float32)
+
+    # ---- probe: forced run, capture the gate layer's input [d ; ctx] per step
+    feats = []
+    run(2.0, 0, TACOTRON_STOP_PROBE, hook=lambda m, a: feats.append(a[0].detach().clone().numpy().astype(np.float64)))
+    X = np.stack(feats)                                            # [steps, B, 1280]
+    n, H = X.shape[0], hp.second_decoder_rnn_dim
+    k = len(TACOTRON_STOP_AMPS)
+    hi = np.tanh(1.0)                                              # a step unit's two output levels are -+tanh(1) (sharp limit)
+    units = X[:, :, 1:1 + k]
+    on = np.arange(n)[:, None, None] >= np.array(TACOTRON_STOP_DRIVE[2])[None, None, :]
+    assert ((units > 0) == on).all() and np.abs(np.abs(units) - hi).max() < 0.02, np.abs(np.abs(units) - hi).max()
+    ctx = X[:, :, H:].reshape(n * B, -1)
+    A = np.concatenate([ctx, np.ones((n * B, 1))], axis=1)
+    target = np.tile(-np.array(TACOTRON_STOP_LEVELS), n)
+    sol = np.linalg.solve(A @ A.T + 1e-2 * np.eye(n * B), target)
+    wb = A.T @ sol
+    gate_w = np.zeros((1, X.shape[2]), dtype=np.float32)
+    gate_w[0, H:] = wb[:-1]
+    gate_w[0, 1:1 + k] = np.array(TACOTRON_STOP_AMPS) / (2 * hi)
+    gate_b = np.array([wb[-1] - 1.0 + sum(TACOTRON_STOP_AMPS) / 2], dtype=np.float32)
+    fit = (A @ wb).reshape(n, B)
+    print(f"[golden] tacotron_stop: context half of the gate weight |w|_2 = {np.linalg.norm(wb[:-1]):.2f}, item-level fit "
+          f"residual {np.abs(fit + np.array(TACOTRON_STOP_LEVELS)).max():.4f}")
+    assert np.abs(fit + np.array(TACOTRON_STOP_LEVELS)).max() < 0.05
+    with torch.no_grad():
+        model.decoder.gate_layer.linear_layer.weight.copy_(torch.from_numpy(gate_w))
+        model.decoder.gate_layer.linear_layer.bias.copy_(torch.from_numpy(gate_b))
+
+    # ---- the cases: the reference's rule ends the loop
+    store = dict(seed=seed, mask_seed=mask_seed, attention_drive=np.array(drive, dtype=np.float32),
+                 stop_rate=np.float64(TACOTRON_STOP_DRIVE[0]), stop_sharp=np.float64(TACOTRON_STOP_DRIVE[1]),
+                 stop_times=np.array(TACOTRON_STOP_DRIVE[2], dtype=np.int64), text=text, lengths=lengths,
+                 speakers=speakers, torchmoji=tm, gate_w=gate_w, gate_b=gate_b, case_names=np.array(list(TACOTRON_STOP_CASES)),
+                 case_params=np.array(list(TACOTRON_STOP_CASES.values()), dtype=np.float64))
+    t_mel, outs = [], {}
+    for name, (thr, delay, cap) in TACOTRON_STOP_CASES.items():
+        out, dec_mel = run(thr, delay, cap)
+        T = out["pred_mel_postnet"].shape[2]
+        assert out["pred_gate"].shape == (B, T) and out["alignments"].shape == (B, T, T_txt) and dec_mel.shape == (B, 80, T)
+        t_mel.append(T)
+        outs[name] = (out, dec_mel)
+        store[f"{name}_pred_mel_postnet"] = out["pred_mel_postnet"]  # the postnet sees T frames: differs near the end per case
+        print(f"[golden] tacotron_stop {name}: thr {thr} delay {delay} cap {cap} -> T_mel {T}")
+    longest = max(outs, key=lambda c: outs[c][1].shape[2])
+    out, dec_mel = outs[longest]
+    for name, T in zip(TACOTRON_STOP_CASES, t_mel):                  # the rule does not feed back: every case is a prefix
+        o, dm = outs[name]
+        assert np.array_equal(dm, dec_mel[:, :, :T]) and np.array_equal(o["alignments"], out["alignments"][:, :T])
+        assert np.abs(o["pred_gate"] - out["pred_gate"][:, :T]).max() < 1e-7       # torch.sigmoid over a different length: 1 ulp
+    store.update(T_mel=np.array(t_mel, dtype=np.int64), decoder_mel=dec_mel, pred_gate=out["pred_gate"],
+                 alignments=out["alignments"])
+    sg = out["pred_gate"]
+    first = [int(np.argmax(sg[b, 5:] > 0.5) + 5) for b in range(B)]
+    assert first == TACOTRON_STOP_CROSS, first
+    assert (sg[0, 1:4] > 0.5).all() and (sg[1:, :5] < 0.5).all() and (sg[0, 25:40] < 0.5).all() and (sg[0, 4:23] < 0.5).all()
+    assert t_mel == [62, 64, 65, 66, 72, 90, 50, 64, 80], t_mel
+    print(f"[golden] tacotron_stop: first crossings {first}, min |sigmoid(gate) - 0.5| = {np.abs(sg - 0.5).min():.3f}, "
+          f"max sigmoid {sg.max():.3f}")
+    path = os.path.join(HERE, "tacotron_stop.npz")
+    np.savez_compressed(path, **store)
+    print(f"[golden] tacotron_stop -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def make_alignment():
     """utils/model/utils.py:47-120 run here on seeded attention maps (data only)."""
     from CookieTTS.utils.model.utils import alignment_metric, get_first_over_thresh
@@ -558,6 +684,8 @@ if __name__ == "__main__":
         make_tacotron()
     if "tacotron_long" in which:
         make_tacotron_long()
+    if "tacotron_stop" in which:
+        make_tacotron_stop()
     if "waveflow" in which:
         make_waveflow()
     if "waveglow" in which:

@@ -34,6 +34,23 @@ def test_launcher_spawns_ranks_and_reports_exchange():
     assert "SELF-TEST" in line["data"]                     # can never be mistaken for a measurement
 
 
+def test_launcher_eight_ranks_reports_every_ranks_step_time():
+    """The node's shape (8 ranks): one line, per-rank step times (min / max / all) so that stragglers are visible, and the
+    scatter / gather legs of the exchange over 8 uneven-free shards."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--frames", "4", "--selftest-launcher"], env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["config"]["samples_per_step"] == 8 * 2 * 4 * 256
+    ranks = line["ms_per_step_ranks"]
+    assert len(ranks["all"]) == 8 and ranks["min"] <= ranks["max"] <= line["ms_per_step"] * 1.0001
+    ex = line["exchange"]
+    assert ex["gather_bytes"] == 8 * 2 * 4 * 256 * 4 and ex["scatter_dtype"] == "float32" and ex["gather_ms"] >= 0
+    assert "rows" not in line                                      # secondary rows are an N = 1 matter
+
+
 def test_launcher_propagates_rank_failure():
     # rank 1 dies before the first collective; rank 0 would wait for it forever: the launcher must end it and fail
     env = _env()

@@ -23,7 +23,7 @@ def test_mode_switch_roundtrip(hip_lib_path):
     import cookietts_amd
     from cookietts_amd import _lib
     prev = cookietts_amd.set_f32_gemm_mode("bf16x3")
-    assert _lib.lib().ctts_get_f32_gemm_mode() == 1
+    assert _lib.lib().ctts_get_f32_gemm_mode() == 2 == _lib.MODEL_GEMM_MODES["bf16x3"]      # CTTS_GEMM_BF16X3
     assert cookietts_amd.set_f32_gemm_mode(prev) == "bf16x3"
     assert _lib.lib().ctts_set_f32_gemm_mode(7) != 0                      # unknown mode: refused, mode unchanged
     assert _lib.lib().ctts_get_f32_gemm_mode() == _lib.GEMM_MODES[prev]
@@ -103,7 +103,7 @@ def test_two_models_two_modes_interleaved_on_two_streams(hip_lib_path):
         err = rms_rel_err(alone[k].cpu().numpy(), g["wave"])
         print(f"{k}: rms rel err vs reference = {err:.3e}")
         assert err < (1e-5 if k == "f32" else 1e-4)
-    assert _lib.lib().ctts_get_f32_gemm_mode() == 0
+    assert _lib.lib().ctts_get_f32_gemm_mode() == 1                              # CTTS_GEMM_F32: the process default untouched
     with pytest.raises(ValueError):
         models["f32"].set_f32_gemm_mode("tf32")
 

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(hip_lib_path):
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in include/cookietts_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == declared, "ctypes signature table out of sync with the header"
-    assert handle.ctts_abi_version() == 4
+    assert handle.ctts_abi_version() == 5
 
 
 def test_host_side_queries_run_without_gpu(hip_lib_path):
@@ -166,9 +166,15 @@ def test_gemm_mode_names_and_tuning_bits(hip_lib_path):
         _lib.model_gemm_mode("bf16x9")
     m = WaveGlow(**synthetic.WAVEGLOW_CONFIGS["toy"])
     assert m.set_f32_gemm_mode("bf16x6") is m and m.c_config().f32_gemm_mode == 3
-    assert _lib.GEMM_MODES == {"f32": 0, "bf16x3": 1, "bf16x6": 2}
+    # one encoding (CTTS_GEMM_*) for the per-model field and the deprecated process default (ABI 5)
+    assert _lib.GEMM_MODES == {"f32": 1, "bf16x3": 2, "bf16x6": 3}
+    assert all(_lib.MODEL_GEMM_MODES[k] == v for k, v in _lib.GEMM_MODES.items())
     lib = _lib.lib()
-    assert lib.ctts_set_f32_gemm_mode(3) != 0 and lib.ctts_get_f32_gemm_mode() == 0     # unknown default refused, fp32 MFMA stays
+    assert lib.ctts_get_f32_gemm_mode() == 1                                             # CTTS_GEMM_F32 initially
+    assert lib.ctts_set_f32_gemm_mode(4) != 0 and lib.ctts_set_f32_gemm_mode(-1) != 0 and lib.ctts_get_f32_gemm_mode() == 1
+    assert lib.ctts_set_f32_gemm_mode(3) == 0 and lib.ctts_get_f32_gemm_mode() == 3      # the per-model constant means the same here
+    assert lib.ctts_set_f32_gemm_mode(0) == 0 and lib.ctts_get_f32_gemm_mode() == 1      # CTTS_GEMM_DEFAULT resets to fp32 MFMA
+    assert "DEPRECATED - ctts_set_f32_gemm_mode" in hdr and lib.ctts_last_gemm_loop() == 0
     for name, bit in _lib.TUNING_BITS.items():
         assert f"{bit} {name}" in hdr or name in hdr, name
     assert _lib.TUNING_BITS["CTTS_F32_NO_SPLITK"] == 11

@@ -20,7 +20,7 @@ def _fake_vocoder(mel):                       # [n, 80, F] -> [n, F*4]; item-wis
     return (mel.mean(dim=1, keepdim=True) * torch.arange(1, 5).view(1, 4, 1)).transpose(1, 2).reshape(mel.shape[0], -1)
 
 
-def _worker(rank, world, port, n_items, q):
+def _worker(rank, world, port, n_items, q, wire=torch.float32):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -40,26 +40,43 @@ def _worker(rank, world, port, n_items, q):
         ws = [torch.empty_like(w) for _ in range(world)]
         dist.all_gather(ws, w)
         same = all(torch.equal(ws[0], x) for x in ws)
-        out = sharding.sharded_infer(_fake_vocoder, mels, 80, torch.device("cpu"), root=0)
+        out = sharding.sharded_infer(lambda m: _fake_vocoder(m.float()), mels, 80, torch.device("cpu"), root=0, wire_dtype=wire)
         if rank == 0:
-            q.put((same, torch.equal(out, _fake_vocoder(mels)), tuple(out.shape)))
+            want = _fake_vocoder(mels.to(wire).float())          # the wire rounds the mel once (bf16: config 3), nothing else
+            q.put((same, torch.equal(out, want), tuple(out.shape)))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_items", [5, 1, 4])
-def test_sharded_infer_matches_single_process(n_items):
+def _run_world(world, n_items, wire=torch.float32):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_items, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, q, wire)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(180)
         assert p.exitcode == 0
     same, equal, shape = q.get(timeout=10)
     assert same and equal and shape == (n_items, 24)
+
+
+@pytest.mark.parametrize("n_items", [5, 1, 4])
+def test_sharded_infer_matches_single_process(n_items):
+    _run_world(2, n_items)
+
+
+def test_sharded_infer_with_bf16_mels_on_the_wire():
+    """config 3 scatters bf16 mels (half the bytes); the result is the vocoder of the bf16-rounded mel."""
+    _run_world(2, 5, wire=torch.bfloat16)
+
+
+@pytest.mark.parametrize("n_items", [250, 3])
+def test_sharded_infer_on_eight_ranks_with_uneven_shards(n_items):
+    """The node's shape: 8 ranks; 250 utterances -> shards of 32 x 2 + 31 x 6, 3 utterances -> five ranks get none."""
+    assert sharding.shard_counts(250, 8) == [32, 32, 31, 31, 31, 31, 31, 31]
+    _run_world(8, n_items)
 
 
 def test_shard_counts():

@@ -300,8 +300,7 @@ def test_persistent_decoder_equals_per_launch_decoder(hip_lib_path, monkeypatch)
         print(f"B={B} T={T}: mel {float((a[0] - b[0]).abs().max()):.2e} align {float((a[2] - b[2]).abs().max()):.2e}")
         assert (a[0] - b[0]).abs().max() < MEL_TOL and (a[1] - b[1]).abs().max() < MEL_TOL
         assert (a[2] - b[2]).abs().max() < MEL_TOL
-    from cookietts_amd.tacotron2 import Decoder
-    assert Decoder._persistent_probed and not Decoder._persistent_disabled       # the persistent path really ran
+    assert m.decoder.persistent_state == "ok"                                      # the persistent path really ran
 
 
 @pytest.mark.gpu
@@ -313,7 +312,7 @@ def test_persistent_decoder_abort_is_detected_and_falls_back(hip_lib_path):
     import ctypes as C
     import warnings
     from cookietts_amd import _lib
-    from cookietts_amd.tacotron2 import Decoder, PERSIST_CTL_WORDS
+    from cookietts_amd.tacotron2 import PERSIST_CTL_WORDS
     m, g, hp, sd = _model()
     dec = m.decoder
     rng = np.random.default_rng(5)
@@ -326,7 +325,7 @@ def test_persistent_decoder_abort_is_detected_and_falls_back(hip_lib_path):
     want = dec.inference(mem, lens, keep_masks=masks)
     dec.use_persistent = True
     good = dec.inference(mem, lens, keep_masks=masks)
-    assert Decoder._persistent_probed and not Decoder._persistent_disabled
+    assert dec.persistent_state == "ok"
     assert (good[0] - want[0]).abs().max() < MEL_TOL
     (key, bufs), = dec._xchg.items()
     nb = _lib.lib().ctts_taco_decoder_persistent_bytes(C.byref(dec.c_config()), B, T)
@@ -341,19 +340,33 @@ def test_persistent_decoder_abort_is_detected_and_falls_back(hip_lib_path):
     assert dec._xchg == {}                                   # sticky words dropped with the buffer: the next call is clean
     again = dec.inference(mem, lens, keep_masks=masks)
     assert torch.equal(again[0], good[0])
-    # first-launch probe: same poison on a fresh process-wide state -> warning, per-launch result, persistent form off
-    try:
-        Decoder._persistent_probed = False
-        (key, bufs), = dec._xchg.items()
-        poison(bufs[0])
-        with warnings.catch_warnings(record=True) as w:
-            warnings.simplefilter("always")
-            fb = dec.inference(mem, lens, keep_masks=masks)
-        assert any("per-launch decoder" in str(x.message) for x in w)
-        assert Decoder._persistent_disabled and dec._xchg == {}
-        assert torch.equal(fb[0], want[0]) and torch.equal(fb[2], want[2])
-    finally:
-        Decoder._persistent_probed, Decoder._persistent_disabled = True, False
+    # first-launch probe of THIS decoder: same poison -> warning, per-launch result, this decoder's persistent form off for
+    # its next PERSIST_REPROBE_AFTER calls - and a second model in the same process is not touched by it
+    from cookietts_amd import tacotron2
+    other, _, _, _ = _model()
+    dec.reprobe_persistent()
+    assert dec.persistent_state == "unprobed" and dec._xchg == {}
+    dec.inference(mem, lens, keep_masks=masks)                       # allocates the exchange buffer, probes fine
+    dec._persist = "unprobed"
+    (key, bufs), = dec._xchg.items()
+    poison(bufs[0])
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        fb = dec.inference(mem, lens, keep_masks=masks)
+    assert any("per-launch form" in str(x.message) and "workgroup 7" in str(x.message) for x in w)
+    assert dec.persistent_state == "disabled" and dec._xchg == {}
+    assert torch.equal(fb[0], want[0]) and torch.equal(fb[2], want[2])
+    assert other.decoder.persistent_state == "unprobed"
+    other.decoder.gate_threshold, other.decoder.max_decoder_steps = 2.0, n
+    og = other.decoder.inference(mem, lens, keep_masks=masks)
+    assert other.decoder.persistent_state == "ok" and other.decoder._xchg and torch.equal(og[0], good[0])
+    for _ in range(tacotron2.PERSIST_REPROBE_AFTER):                  # the per-launch form, quietly
+        fb = dec.inference(mem, lens, keep_masks=masks)
+        assert dec.persistent_state == "disabled" and torch.equal(fb[0], want[0])
+    back = dec.inference(mem, lens, keep_masks=masks)                # re-probed by itself
+    assert dec.persistent_state == "ok" and dec._xchg and torch.equal(back[0], good[0])
+    dec.use_persistent = False
+    assert dec.persistent_state == "off"
 
 
 @pytest.mark.gpu

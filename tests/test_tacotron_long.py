@@ -6,12 +6,15 @@ of the HIP decoder on the GPU - plus the chained Tacotron2.inference -> WaveGlow
 Three weight recipes (synthetic.tacotron_state_dict attention_drive):
   long         near-uniform attention; every item's window drifts from 0 to its right clamp (167/162/117/67)
   long_peaked  weights 0.5-0.7 advancing ~1.5 tokens per step, diffuse at the clamp
-  long_sharp   weights up to 0.99 jittering at the right clamp.  This trajectory amplifies rounding: the numpy fp32
-               restatement (oracle: the same equations, BLAS summation order instead of MKL-DNN's) is itself 1e-4 / 2e-4 /
-               1.2e-2 / 3.0e-2 away from the reference's weights in the four 64-step bands (growth ~ e^(0.05 n) from
-               1e-7), so no fp32 implementation can be pinned to 1e-4 there.  Growth-law gate: per band,
-               HIP-vs-reference <= max(1e-4, GROWTH_SLACK x the oracle's own distance) - a third fp32 evaluation order
-               may sit as far from the reference as the second one does, times a constant, and not further.
+  long_sharp   weights up to 0.99 jittering at the right clamp.  This trajectory amplifies rounding (~e^(0.05 n)): two
+               correct fp32 evaluations end up 1e-2 apart in the weights after 256 steps, so "HIP vs reference <= 1e-4"
+               cannot be asked there.  The arbiter is the EXACT trajectory: tests/golden/tacotron_long_sharp_arbiter.npz
+               (make_arbiter.py) holds the fp64 run of the oracle's equations and, per 64-step band, the distance to it
+               of an ensemble of 24 equally valid fp32 evaluations (the fp32 oracle started from a decoder input moved by
+               <= 1 ulp per entry).  Measured there: the ensemble's band-4 distance spans 6.5e-3 .. 3.8e-2 in the weights
+               and the reference's own run sits at 1.3e-3 (a lucky member: 1-ulp changes of the input move a run across
+               that whole range), so "within 2x of the reference's distance" would be a coin toss; the gate is
+               |HIP - fp64| <= ARBITER_SLACK x the ensemble's maximum, per band and quantity.
 """
 import json
 import os
@@ -26,11 +29,7 @@ from oracle import tacotron_oracle as to
 
 MEL_TOL = 1e-4            # BASELINE.json: mel L_inf <= 1e-4
 BAND = 64
-GROWTH_SLACK = 8.0
-# |numpy fp32 oracle - reference| per 64-step band on long_sharp, measured by test_oracle_matches_long_goldens (which
-# asserts the oracle stays below them): the trajectory's own sensitivity to fp32 rounding
-SHARP_ORACLE_ALIGN = [1.5e-4, 3.5e-4, 2.0e-2, 5.0e-2]
-SHARP_ORACLE_MEL = [1e-6, 2e-6, 4e-5, 1e-4]
+ARBITER_SLACK = 2.0       # |x - fp64| <= ARBITER_SLACK x max over the fp32 ensemble of |member - fp64|, per band
 WINDOW_END = {"long": [167, 162, 117, 67], "long_peaked": [167, 162, 117, 67], "long_sharp": [167, 162, 117, 67]}
 
 
@@ -85,12 +84,45 @@ def test_oracle_matches_long_goldens(name):
     ba, bm = _bands(o["alignments"], g["alignments"], 1), _bands(o["pred_mel_postnet"], g["pred_mel_postnet"], 2)
     bd = _bands(o["pred_mel"], g["decoder_mel"], 2)
     print(f"oracle vs reference, {name}: align bands {ba}  postnet mel bands {bm}  decoder mel bands {bd}")
+    sig = 1 / (1 + np.exp(-o["gate_logits"]))
     if name == "long_sharp":
-        assert all(x <= lim for x, lim in zip(ba, SHARP_ORACLE_ALIGN)) and all(x <= lim for x, lim in zip(bm, SHARP_ORACLE_MEL))
+        _assert_within_ensemble(dict(alignments=o["alignments"], pred_mel=o["pred_mel"], pred_mel_postnet=o["pred_mel_postnet"],
+                                     gate=sig), "fp32 oracle")
     else:
         assert max(ba) < (1e-6 if name == "long" else 5e-5) and max(bm) < 1e-5 and max(bd) < 1e-5
-    sig = 1 / (1 + np.exp(-o["gate_logits"]))
-    assert np.abs(sig - g["pred_gate"]).max() < (1e-4 if name == "long_sharp" else 1e-5)
+        assert np.abs(sig - g["pred_gate"]).max() < 1e-5
+
+
+def _arbiter():
+    return np.load(os.path.join(GOLDEN, "tacotron_long_sharp_arbiter.npz"))
+
+
+def _assert_within_ensemble(out, who):
+    """out: alignments [B,T,txt], pred_mel / pred_mel_postnet [B,80,T], gate (sigmoid) [B,T] of a long_sharp run."""
+    a = _arbiter()
+    axes = {"alignments": 1, "pred_mel": 2, "pred_mel_postnet": 2, "gate": 1}
+    for q, name in enumerate(str(x) for x in a["quantities"]):
+        d = _bands(out[name], a[name].astype(np.float64), axes[name])
+        lim = ARBITER_SLACK * a["ensemble"][:, q].max(axis=0)
+        ref = a["reference"][q]
+        print(f"{who} vs the fp64 trajectory, {name}: {['%.2e' % x for x in d]}  (ensemble max {['%.2e' % x for x in lim / ARBITER_SLACK]}, "
+              f"reference {['%.2e' % x for x in ref]})")
+        assert all(x <= l for x, l in zip(d, lim)), (who, name, d, lim.tolist())
+
+
+def test_arbiter_fixture_is_what_the_docstring_says():
+    a = _arbiter()
+    g = np.load(os.path.join(GOLDEN, "tacotron_long_sharp.npz"))
+    ens, ref = a["ensemble"], a["reference"]
+    assert ens.shape == (24, 4, 4) and ref.shape == (4, 4) and [str(x) for x in a["quantities"]][0] == "alignments"
+    assert a["alignments"].shape == g["alignments"].shape and a["pred_mel"].shape == g["decoder_mel"].shape
+    # the stored reference distances are the reference golden against the stored fp64 trajectory
+    assert np.allclose(_bands(g["alignments"], a["alignments"].astype(np.float64), 1), ref[0], rtol=1e-6)
+    # amplification: the weights' distance grows > 30x from band 1 to band 4 for every member, and the ensemble itself
+    # spreads > 4x in band 4: luck, not implementation quality, decides where an fp32 run ends up
+    assert (ens[:, 0, 3] > 30 * ens[:, 0, 0]).all() and ens[:, 0, 3].max() > 4 * ens[:, 0, 3].min()
+    # the reference's own run is inside the gate (it is closer to the exact trajectory than every member)
+    assert (ref <= ARBITER_SLACK * ens.max(axis=0)).all()
 
 
 def _model(sd, hp):
@@ -106,7 +138,6 @@ def _model(sd, hp):
 def test_hip_tacotron_matches_long_goldens(hip_lib_path, name, form):
     """Both forms of the decoder, the encoder at 200 ragged tokens, the memory assembly and the postnet against the
     reference over 256 steps; the measured L_inf per 64-step band is printed and gated."""
-    from cookietts_amd.tacotron2 import Decoder
     g, hp, sd, masks, n = _load(name)
     m = _model(sd, hp)
     m.decoder.use_persistent = form == "persistent"
@@ -114,7 +145,7 @@ def test_hip_tacotron_matches_long_goldens(hip_lib_path, name, form):
                       torch.from_numpy(g["speakers"]).cuda(), torch.from_numpy(g["torchmoji"]).cuda(),
                       keep_masks=masks, fixed_steps=n)
     if form == "persistent":
-        assert Decoder._persistent_probed and not Decoder._persistent_disabled and m.decoder._xchg   # it really ran
+        assert m.decoder.persistent_state == "ok" and m.decoder._xchg                              # it really ran
     else:
         assert not m.decoder._xchg
     o = {k: v.cpu().numpy() for k, v in out.items()}
@@ -131,11 +162,8 @@ def test_hip_tacotron_matches_long_goldens(hip_lib_path, name, form):
     print(f"{name} / {form} vs reference, L_inf per {BAND}-step band:\n  alignments  {ba}\n  decoder mel {bd}\n"
           f"  postnet mel {bm}\n  gate        {bg}")
     if name == "long_sharp":
-        lim_a = [max(MEL_TOL, GROWTH_SLACK * x) for x in SHARP_ORACLE_ALIGN]
-        lim_m = [max(MEL_TOL, GROWTH_SLACK * x) for x in SHARP_ORACLE_MEL]
-        assert all(x <= l for x, l in zip(ba, lim_a)), (ba, lim_a)
-        assert all(x <= l for x, l in zip(bm, lim_m)) and all(x <= l for x, l in zip(bd, lim_m)), (bm, bd, lim_m)
-        assert all(x <= l for x, l in zip(bg, lim_m))
+        _assert_within_ensemble(dict(alignments=o["alignments"], pred_mel=o["pred_mel"], pred_mel_postnet=o["pred_mel_postnet"],
+                                     gate=o["pred_gate"]), f"HIP {form}")
     else:
         assert max(ba) < MEL_TOL and max(bd) < MEL_TOL and max(bm) < MEL_TOL and max(bg) < MEL_TOL
         # same window at every one of the 4 x 256 steps: the support of the weights sits inside the reference's window

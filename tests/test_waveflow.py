@@ -187,6 +187,22 @@ def test_author_options_ragged_vs_oracle_and_speaker_requirement(hip_lib_path, t
 
 
 @pytest.mark.gpu
+def test_conditioning_interpolation_kernels_are_bit_identical(hip_lib_path, tuning):
+    """The 16-byte-store and the scalar form of the WaveFlow conditioning interpolation (glow_ax.py:545-554) share one
+    explicitly contracted lerp: the waveform must not depend on which one the geometry selects."""
+    m, cfg, sd = _model("author_toy", 12)
+    B, Fr = 2, 23
+    mel = torch.from_numpy(synthetic.synthetic_mel(B, Fr, cfg["n_mel_channels"] * 2, seed=3)).cuda()
+    ids = torch.from_numpy(np.array([5, 77], np.int64)).cuda()
+    z = torch.from_numpy((np.random.default_rng(4).standard_normal((B, (Fr - 1) * cfg["hop_length"])) * 0.8).astype(np.float32)).cuda()
+    vec, _ = m.inverse(z, mel, speaker_ids=ids)
+    tuning.set("CTTS_WF_NO_VEC_INTERP")
+    scalar, _ = m.inverse(z, mel, speaker_ids=ids)
+    tuning.clear("CTTS_WF_NO_VEC_INTERP")
+    assert torch.equal(vec, scalar)
+
+
+@pytest.mark.gpu
 def test_author_full_width_fused_1x1_stages_vs_oracle(hip_lib_path, tuning):
     """The author's full option set (C = 128: depthwise launch + fused pointwise/gate/res-skip kernel), two utterances,
     L = 150 (three 64-column tiles, ragged, not a multiple of 4), against the oracle and against the unfused launches."""
