@@ -88,6 +88,27 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.8853900817779268f));
 }
 
+// ~2-ulp forms for the cell updates, a third of libm's instructions: e^y on the hardware exp2 with the product y log2(e)
+// carried in two parts (the plain product's rounding error grows with |y|), tanh as an odd polynomial below 0.625 (own
+// least-squares fit of (tanh x - x) / x^3 in x^2, 1.3 ulp) and 1 - 2 / (1 + e^(2|x|)) above.  Measured on the
+// rounding-amplifying trajectory (tests/test_tacotron_long.py): distance to the exact run in band 1 1.6e-4 with the
+// fast forms, 1.1e-4 with libm or these; step time 32.2 / 34.1 (libm) us.
+__device__ __forceinline__ float acc_exp(float y) {
+    const float p = y * 1.4426950408889634f;
+    const float r = fmaf(y, 1.4426950408889634f, -p) + y * 1.925963033500011e-08f;     // log2(e) = hi + lo
+    const float e = __builtin_amdgcn_exp2f(p);
+    return fmaf(e, r * 0.6931471805599453f, e);
+}
+__device__ __forceinline__ float acc_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + acc_exp(-x)); }
+__device__ __forceinline__ float acc_tanh(float x) {
+    const float ax = fabsf(x), u = x * x;
+    float pl = fmaf(u, -0.005704042501747608f, 0.020637862384319305f);
+    pl = fmaf(u, pl, -0.05373915657401085f); pl = fmaf(u, pl, 0.133314311504364f); pl = fmaf(u, pl, -0.3333328068256378f);
+    const float small = fmaf(ax * u, pl, ax);
+    const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + acc_exp(2.0f * ax));
+    return copysignf(ax < 0.625f ? small : big, x);
+}
+
 __device__ __forceinline__ void publish(u64* g, int idx, unsigned epoch, float v) {
     __hip_atomic_store((gu64*)g + idx, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
@@ -329,6 +350,7 @@ __device__ __forceinline__ void pd_attention_post(const PdArgs& a, AttnLds& s, c
             float e = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; ++j)     // pmw = processed memory + location term (pd_attention_pre)
+                // (tanhf here: arbiter distance of band 1 1.6e-4 -> 1.1e-4, step 32 -> 36 us with libm in the cells as well: not taken)
                 e += lane + 64 * j < a.A ? r.va3[j] * fast_tanh(s.pmw[tt * a.A + lane + 64 * j] + qv[j]) : 0.f;
             ev[i] = e;
         }
@@ -344,8 +366,7 @@ __device__ __forceinline__ void pd_attention_post(const PdArgs& a, AttnLds& s, c
         float e = -INFINITY;
         if (lane < W && pos_l < len && pos_l < a.T) e = s.en[lane];
         const float m = wave_max(e);
-        // exp(e - m) on the hardware exp2 (abs error ~1e-7 of a value <= 1); masked lanes: exp2(-inf) = 0
-        const float pexp = lane < W ? __builtin_amdgcn_exp2f((e - m) * 1.4426950408889634f) : 0.f;
+        const float pexp = lane < W ? expf(e - m) : 0.f;          // masked lanes: exp(-inf) = 0
         float sums[2] = {pexp, pexp * (float)(s0 + lane)};     // normaliser and expected position in one pass
         wave_totals<2>(sums);
         const float inv = 1.0f / sums[0];
@@ -638,10 +659,12 @@ __device__ __forceinline__ void pd_cells(PdSlotRt (&sl)[3], u64* g, unsigned epo
             float pre[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) pre[i] = pd_block_sum(sl[s].acc[i]) + sl[s].bias[i];
-            const float gi = fast_sigmoid(pre[0]), gf = fast_sigmoid(pre[1]);
-            const float gg = fast_tanh(pre[2]), go = fast_sigmoid(pre[3]);
+            // ~2-ulp forms (acc_*): the 1e-7 ABSOLUTE error of the plain exp2 / rcp forms is what the sharp-attention
+            // trajectory amplifies most (tests/test_tacotron_long.py, arbiter)
+            const float gi = acc_sigmoid(pre[0]), gf = acc_sigmoid(pre[1]);
+            const float gg = acc_tanh(pre[2]), go = acc_sigmoid(pre[3]);
             sl[s].c = gf * sl[s].c + gi * gg;
-            sl[s].h = go * fast_tanh(sl[s].c);
+            sl[s].h = go * acc_tanh(sl[s].c);
             if (lane < PD_NB) publish(g, lane * H + first + sl[s].unit, epoch, sl[s].h);
             sl[s].acc = pd_f4{0.f, 0.f, 0.f, 0.f};
         }
