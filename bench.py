@@ -280,35 +280,45 @@ def wn_roofline(lib, cfg, dtype, gemm_mode, B, F, steps, elapsed, config_key="fu
     if products > 1:
         roofline["note"] = (f"flop_per_launch counts the {products} executed bf16 products per algorithmic MAC; "
                             f"algorithmic flops are 1/{products} of it")
-    # the other WN launches of the step (fp32: res/skip + next layer's cond rows in one SPLIT GEMM, K = C; bf16: the res
-    # GEMM and the deferred skip GEMM, both memory-bound there)
-    for key2, which, kname2, bpt in (
-            ("res_hbm", _lib.PROF_WN_RS, "conv_gemm_bf16_pp_kernel<SPLIT> (WN res 1x1: x += W_res act)", 3.0),
-            ("skip_hbm", _lib.PROF_WN_SKIP, "conv_gemm_bf16_pp_kernel<SPLIT> (WN skip sum over 4 layers' act)", 5.5)):
+    # the other WN launches of the step: the res GEMM per layer (K = C) and the deferred skip GEMM per four layers (K = 4 C);
+    # MFMA-bound in fp32, memory-bound in bf16.  (CTTS_F32_NO_DEFER_SKIP: one res/skip GEMM per layer, no skip slot.)
+    slots = {}
+    for which in (_lib.PROF_WN_RS, _lib.PROF_WN_SKIP):
         n2 = ctypes.c_int64()
         ms2 = ctypes.c_double()
         _lib.check(lib.ctts_profile_collect(which, ctypes.byref(n2), ctypes.byref(ms2)), "profile")
-        if n2.value == 0:
-            continue
-        mean2 = ms2.value / n2.value * 1e-3
-        if dtype == "bf16":
-            # In bf16 the in-layer GEMM stays MFMA-bound (1430 FLOP/B vs a ridge of ~312); the memory-bound WN kernels are
-            # the res GEMM (K = C, per layer: act read + x read-modify-write = 3*C*2 B per time step) and the deferred skip
-            # GEMM (K = 4*C per launch: 4 act reads + the skip sum written, and re-read by the second launch = 5.5*C*2 B per
-            # time step on average).  Report both against HBM.
-            bytes2 = float(bpt * C * 2) * B * L
-            roofline[key2] = {"kernel": kname2, "bound": "hbm", "achieved": round(bytes2 / mean2 / 1e9, 1), "peak": 8000.0,
-                              "unit": "GB/s", "frac": round(bytes2 / mean2 / 8e12, 4), "launches": int(n2.value),
-                              "mean_launch_ms": round(mean2 * 1e3, 4), "bytes_per_launch": bytes2}
-        elif which == _lib.PROF_WN_RS:
-            # fp32: one SPLIT launch per layer = res/skip rows (2C, or C for the last layer) + the next layer's share of the
-            # conditioning is NOT here (it is folded into the in-layer K axis); K = C
-            flop2 = 2.0 * (2 * C * C * (n_layers - 1) + C * C) / n_layers * B * L * products
-            roofline["res_skip_mfma"] = {"kernel": "conv_gemm_f32_kernel<SPLIT> (WN res/skip 1x1, read-modify-write epilogue)",
-                                         "bound": "mfma", "achieved": round(flop2 / mean2 / 1e12, 2), "peak": peak,
-                                         "unit": "TFLOP/s", "frac": round(flop2 / mean2 / 1e12 / peak, 4),
-                                         "launches": int(n2.value), "mean_launch_ms": round(mean2 * 1e3, 4),
-                                         "flop_per_launch_mean": flop2}
+        if n2.value > 0:
+            slots[which] = (int(n2.value), ms2.value / n2.value * 1e-3)
+    if dtype == "bf16":
+        # In bf16 the in-layer GEMM stays MFMA-bound (1430 FLOP/B vs a ridge of ~312); the memory-bound WN kernels are the
+        # res GEMM (per layer: act read + x read-modify-write = 3*C*2 B per time step) and the deferred skip GEMM (4 act
+        # reads + the skip sum written, and re-read by the second launch = 5.5*C*2 B per time step on average).
+        for key2, which, kname2, bpt in (
+                ("res_hbm", _lib.PROF_WN_RS, "conv_gemm_bf16_pp_kernel<SPLIT> (WN res 1x1: x += W_res act)", 3.0),
+                ("skip_hbm", _lib.PROF_WN_SKIP, "conv_gemm_bf16_pp_kernel<SPLIT> (WN skip sum over 4 layers' act)", 5.5)):
+            if which in slots:
+                n2, mean2 = slots[which]
+                bytes2 = float(bpt * C * 2) * B * L
+                roofline[key2] = {"kernel": kname2, "bound": "hbm", "achieved": round(bytes2 / mean2 / 1e9, 1), "peak": 8000.0,
+                                  "unit": "GB/s", "frac": round(bytes2 / mean2 / 8e12, 4), "launches": n2,
+                                  "mean_launch_ms": round(mean2 * 1e3, 4), "bytes_per_launch": bytes2}
+    else:
+        deferred = _lib.PROF_WN_SKIP in slots
+        if _lib.PROF_WN_RS in slots:
+            n2, mean2 = slots[_lib.PROF_WN_RS]
+            flop2 = (2.0 * C * C if deferred else 2.0 * (2 * C * C * (n_layers - 1) + C * C) / n_layers) * B * L * products
+            roofline["res_skip_mfma"] = {
+                "kernel": "conv_gemm_f32_kernel<SPLIT> (" + ("WN res 1x1: x += W_res act" if deferred else "WN res/skip 1x1") +
+                          ", read-modify-write epilogue)", "bound": "mfma", "achieved": round(flop2 / mean2 / 1e12, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(flop2 / mean2 / 1e12 / peak, 4), "launches": n2,
+                "mean_launch_ms": round(mean2 * 1e3, 4), "flop_per_launch_mean": flop2}
+        if deferred:
+            n2, mean2 = slots[_lib.PROF_WN_SKIP]
+            flop2 = 2.0 * C * 4 * C * B * L * products
+            roofline["skip_mfma"] = {"kernel": "conv_gemm_f32_kernel<SPLIT> (deferred skip GEMM over four layers' act, K = 4 C)",
+                                     "bound": "mfma", "achieved": round(flop2 / mean2 / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                                     "frac": round(flop2 / mean2 / 1e12 / peak, 4), "launches": n2,
+                                     "mean_launch_ms": round(mean2 * 1e3, 4), "flop_per_launch": flop2}
     if dtype == "bf16":
         # whole step against HBM with SURVEY 8d's per-layer-kernel byte count (7*C*2 B per step per layer; the deferred-skip form moves ~5.4*C*2)
         step_bytes = 7.0 * C * 2 * n_layers * cfg["n_flows"] * B * L

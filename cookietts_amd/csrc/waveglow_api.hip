@@ -39,10 +39,17 @@ struct Plan {
     struct Flow {
         size_t start_w, start_b, end_w, end_b, winv, spk_tab;
         std::vector<size_t> in_A, in_b, rs_A, rs_b;
+        // deferred-skip form (round 4, profiles/r4_07_res_skip_experiments.txt): res rows per layer, skip rows of a group of
+        // up to F32_SKIP_GROUP layers side by side along K
+        std::vector<size_t> res_A, res_b, skip_A, skip_b;
     };
     std::vector<Flow> fl;
     size_t total;
 
+    static constexpr int F32_SKIP_GROUP = 4;
+    int mb_c() const { return (C + GEMM_BM - 1) / GEMM_BM; }
+    int n_groups() const { return (c.n_layers + F32_SKIP_GROUP - 1) / F32_SKIP_GROUP; }
+    int group_layers(int g) const { return g + 1 < n_groups() ? F32_SKIP_GROUP : c.n_layers - g * F32_SKIP_GROUP; }
     int rs_rows(int layer) const { return layer < c.n_layers - 1 ? 2 * C : C; }
     int rs_mb(int layer) const { return (rs_rows(layer) + GEMM_BM - 1) / GEMM_BM; }
 };
@@ -103,6 +110,12 @@ int make_plan(const ctts_waveglow_config* cfg, Plan& p) {
             f.in_b.push_back(take((size_t)p.mb_in * GEMM_BM));
             f.rs_A.push_back(take((size_t)p.rs_mb(i) * p.nch_rs * A_TILE));
             f.rs_b.push_back(take((size_t)p.rs_mb(i) * GEMM_BM));
+            f.res_A.push_back(i + 1 < c.n_layers ? take((size_t)p.mb_c() * p.nch_rs * A_TILE) : 0);
+            f.res_b.push_back(i + 1 < c.n_layers ? take((size_t)p.mb_c() * GEMM_BM) : 0);
+        }
+        for (int gi = 0; gi < p.n_groups(); ++gi) {
+            f.skip_A.push_back(take((size_t)p.mb_c() * p.group_layers(gi) * p.nch_rs * A_TILE));
+            f.skip_b.push_back(take((size_t)p.mb_c() * GEMM_BM));
         }
     }
     p.total = o;
@@ -124,6 +137,7 @@ int make_geom(const Plan& p, int frames, Geom& g) {
 
 struct Workspace {
     float *audio, *spect, *spk, *h_tmp, *h_all, *x, *act, *out;
+    float* act_all;     // deferred-skip form: the gated activations of every layer of a flow ([n_layers] x act)
     size_t total;  // floats
 };
 
@@ -139,6 +153,7 @@ void carve(const Plan& p, const Geom& g, int batch, float* base, Workspace& w) {
     w.x = take(B * p.C * g.ld);
     w.act = take(B * p.C * g.ld);
     w.out = take(B * p.C * g.ld);
+    w.act_all = take((size_t)p.c.n_layers * B * p.C * g.ld);
     w.total = o;
 }
 
@@ -229,7 +244,7 @@ int run_cond(const Plan& p, const Geom& g, const float* blob, const float* spect
 }
 
 int run_wn_stack(const Plan& p, const Geom& g, const float* blob, int k, const float* audio, const float* h_all,
-                 float* x, float* act, float* out, int batch, hipStream_t s) {
+                 float* x, float* act, float* out, int batch, hipStream_t s, float* act_all = nullptr) {
     const auto& f = p.fl[k];
     const auto& d = p.fd[k];
     const long long cstride = (long long)p.C * g.ld;
@@ -238,8 +253,14 @@ int run_wn_stack(const Plan& p, const Geom& g, const float* blob, int k, const f
                              d.n_half, g.L, g.ld, g.pad, s);
     if (rc) return rc;
     const int ncx = p.C / GEMM_KC;
+    // Deferred-skip form (default since round 4; CTTS_F32_NO_DEFER_SKIP = the per-layer form; the fp32 analogue of the bf16 path's): every layer's gated activation is
+    // kept, the per-layer launch computes the res rows only (x += W_res act), and the skip rows of up to four layers are
+    // ONE contraction with K = 4 C at the end of the group.  Same products, different summation order of the skip sum.
+    const bool defer = act_all != nullptr && !tuning().f32_no_defer_skip;
+    const size_t act_stride = (size_t)batch * p.C * g.ld;
     for (int i = 0; i < p.c.n_layers; ++i) {
         const int dil = 1 << i;
+        if (defer) act = act_all + (size_t)i * act_stride;
         {
             GemmArgs a = base_args(p, g, batch);
             a.A = blob + f.in_A[i]; a.bias = blob + f.in_b[i];
@@ -254,7 +275,36 @@ int run_wn_stack(const Plan& p, const Geom& g, const float* blob, int k, const f
             rc = launch_gemm_f32(GEMM_EPI_GATE, a, s);
             if (rc) return rc;
         }
-        {
+        if (defer) {
+            const bool last = i == p.c.n_layers - 1;
+            if (!last) {
+                GemmArgs a = base_args(p, g, batch);
+                a.A = blob + f.res_A[i]; a.bias = blob + f.res_b[i];
+                a.nseg = 1; a.nch_total = p.nch_rs; a.MB = p.mb_c();
+                a.seg[0] = {act, cstride, p.nch_rs, 0, 0, 0};
+                a.M = p.C; a.split = p.C;
+                a.dst0 = x; a.dst0_bstride = cstride; a.acc0 = 1;
+                a.dst1 = out; a.dst1_bstride = cstride; a.acc1 = 0;
+                ProfScope ps(CTTS_PROF_WN_RS, s);
+                rc = launch_gemm_f32(GEMM_EPI_SPLIT, a, s);
+                if (rc) return rc;
+            }
+            const int gi = i / Plan::F32_SKIP_GROUP;
+            if (last || (i + 1) % Plan::F32_SKIP_GROUP == 0) {
+                const int nl = p.group_layers(gi);
+                GemmArgs a = base_args(p, g, batch);
+                a.A = blob + f.skip_A[gi]; a.bias = blob + f.skip_b[gi];
+                a.nseg = nl; a.nch_total = nl * p.nch_rs; a.MB = p.mb_c();
+                for (int j = 0; j < nl; ++j)
+                    a.seg[j] = {act_all + (size_t)(gi * Plan::F32_SKIP_GROUP + j) * act_stride, cstride, p.nch_rs, 0, 0, 0};
+                a.M = p.C; a.split = 0;
+                a.dst0 = x; a.dst0_bstride = cstride; a.acc0 = 1;
+                a.dst1 = out; a.dst1_bstride = cstride; a.acc1 = gi > 0 ? 1 : 0;
+                ProfScope ps(CTTS_PROF_WN_SKIP, s);
+                rc = launch_gemm_f32(GEMM_EPI_SPLIT, a, s);
+                if (rc) return rc;
+            }
+        } else {
             const bool last = i == p.c.n_layers - 1;
             GemmArgs a = base_args(p, g, batch);
             a.A = blob + f.rs_A[i]; a.bias = blob + f.rs_b[i];
@@ -662,6 +712,21 @@ int ctts_waveglow_pack_flow(const ctts_waveglow_config* cfg, int32_t k, const ct
                                 0, C, 1, s))) return rc;
         if ((rc = launch_pack_bias(blob + f.rs_b[i], GEMM_BM, p.rs_mb(i), w->rs_b[i], 0, nullptr, 0, GEMM_EPI_SPLIT, C, rows,
                                    s))) return rc;
+        // deferred-skip form: res rows [0, C) alone; skip rows ([C, 2C), or [0, C) of the last layer) at K offset
+        // (member of the group) * C of the group's matrix, skip biases summed per group
+        const bool last = i == p.c.n_layers - 1;
+        const int gi = i / Plan::F32_SKIP_GROUP, gj = i % Plan::F32_SKIP_GROUP;
+        if (!last) {
+            if ((rc = launch_pack_a(blob + f.res_A[i], w->rs_w[i], GEMM_BM, p.mb_c(), p.nch_rs, 0, C, GEMM_EPI_SPLIT, C, C,
+                                    0, C, 1, s))) return rc;
+            if ((rc = launch_pack_bias(blob + f.res_b[i], GEMM_BM, p.mb_c(), w->rs_b[i], 0, nullptr, 0, GEMM_EPI_SPLIT, C, C,
+                                       s))) return rc;
+        }
+        if ((rc = launch_pack_a(blob + f.skip_A[gi], w->rs_w[i], GEMM_BM, p.mb_c(), p.group_layers(gi) * p.nch_rs, gj * C, C,
+                                GEMM_EPI_SPLIT, C, C, last ? 0 : C, C, 1, s))) return rc;
+        hipLaunchKernelGGL(skip_bias_kernel, dim3((p.mb_c() * GEMM_BM + 255) / 256), dim3(256), 0, s, blob + f.skip_b[gi],
+                           w->rs_b[i] + (last ? 0 : C), C, p.mb_c() * GEMM_BM, gj == 0 ? 1 : 0);
+        CTTS_CHECK_LAUNCH("skip_bias_f32");
     }
     return CTTS_OK;
 }
@@ -746,7 +811,7 @@ int ctts_waveglow_infer_spk_f32(const ctts_waveglow_config* cfg, const void* pac
     rc = run_cond(p, g, blob, w.spect, w.spk, w.h_tmp, w.h_all, batch, s);
     if (rc) return rc;
     for (int k = p.c.n_flows - 1; k >= 0; --k) {
-        rc = run_wn_stack(p, g, blob, k, w.audio, w.h_all, w.x, w.act, w.out, batch, s);
+        rc = run_wn_stack(p, g, blob, k, w.audio, w.h_all, w.x, w.act, w.out, batch, s, w.act_all);
         if (rc) return rc;
         rc = run_flow_tail(p, g, blob, k, w.out, w.audio, k == 0 ? wave : nullptr, batch, s);
         if (rc) return rc;
@@ -769,7 +834,7 @@ int ctts_tuning_flags(void) {
     return (t.f32_no_glds ? 1 : 0) | (t.no_xcd_pair ? 2 : 0) | (t.bf16_no_glds ? 4 : 0) | (t.bf16_no_wide ? 8 : 0) |
            (t.bf16_no_pp ? 16 : 0) | (t.bf16_w4 ? 32 : 0) | (t.bf16_pp_stages == 4 ? 64 : 0) | (t.wf_no_fuse ? 128 : 0) |
            (t.taco_no_fuse ? 256 : 0) | (t.f32_no_small ? 512 : 0) | (t.f32_force_small ? 1024 : 0) | (t.f32_no_splitk ? 2048 : 0) |
-           (t.wf_no_vec_interp ? 4096 : 0);
+           (t.wf_no_vec_interp ? 4096 : 0) | (t.f32_no_defer_skip ? 8192 : 0);
 }
 
 int ctts_profile_enable(int32_t on) {

@@ -231,6 +231,22 @@ def test_waveglow_fp32_staging_variants_agree(hip_lib_path, tuning, knob):
     assert torch.equal(default, m.infer_from_noise(mel, z))
 
 
+@pytest.mark.parametrize("name", ["toy_early", "full_short"])
+def test_waveglow_per_layer_res_skip_form_matches_golden_and_the_default(hip_lib_path, tuning, name):
+    """The default WN stack keeps every layer's gated activation and sums the skip rows of four layers in one K = 4C GEMM
+    (glow.py:211-220 restated); CTTS_F32_NO_DEFER_SKIP is the one-res/skip-GEMM-per-layer form of rounds 1-3.  Same products,
+    another order of the skip sum: both match the reference golden, and each other far inside the bound."""
+    g = np.load(os.path.join(GOLDEN, f"waveglow_{name}.npz"))
+    m, cfg, _ = _model(str(g["config_key"]), int(g["seed"]))
+    args = (torch.from_numpy(g["mel"]).cuda(), torch.from_numpy(g["z_scaled"]).cuda())
+    deferred = m.infer_from_noise(*args).cpu().numpy()
+    tuning.set("CTTS_F32_NO_DEFER_SKIP")
+    per_layer = m.infer_from_noise(*args).cpu().numpy()
+    e = (rms_rel_err(deferred, g["wave"]), rms_rel_err(per_layer, g["wave"]), rms_rel_err(deferred, per_layer))
+    print(f"{name}: deferred vs reference {e[0]:.3e}, per-layer vs reference {e[1]:.3e}, deferred vs per-layer {e[2]:.3e}")
+    assert e[0] < WAVE_TOL and e[1] < WAVE_TOL and e[2] < 1e-5
+
+
 def test_5_infer_vocoder_slot(hip_lib_path, tmp_path):
     """The two call sites of _5_infer/t2s_server/text2speech.py (:175-179, :658-665) against a reference-format
     checkpoint (train.py:128-145)."""
