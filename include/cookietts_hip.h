@@ -451,10 +451,10 @@ int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void*
                                 float* align_out, int32_t batch, int32_t text_len, int32_t step0,
                                 int32_t n_steps, int32_t max_steps, void* workspace, void* stream);
 
-/* Persistent form of ctts_taco_decoder_steps_f32: ONE launch of 256 resident workgroups runs all n_steps steps; the
- * columns of every mat-vec that depend on the current step are weight-stationary in registers, the rest is streamed in
- * the exchange gaps, and vectors move between workgroups as 8-byte {tag, value} granules (no grid barrier, no per-step
- * launches).  Same state (workspace), same outputs, same keep_masks contract as ctts_taco_decoder_steps_f32, so the
+/* Persistent form of ctts_taco_decoder_steps_f32: ONE launch of 256 resident workgroups (256 threads each, one wave per
+ * SIMD) runs all n_steps steps with EVERY LSTM weight resident on the compute units for the whole launch (registers + LDS;
+ * the 108 MB of weights are read once, at entry: ask for blocks of >= 32 steps), products on v_mfma_f32_4x4x1, and vectors
+ * move between workgroups as 8-byte {tag, value} granules (no grid barrier, no per-step launches).  Same state (workspace), same outputs, same keep_masks contract as ctts_taco_decoder_steps_f32, so the
  * two can be mixed call by call.  Built for the repo-default decoder shape (attention RNN 1280, decoder RNNs 768,
  * prenet 256, memory 512, window 16), batch <= 4, text_len <= 1024 on a device with >= 256 CUs:
  * ctts_taco_decoder_persistent_bytes returns 0 otherwise, also when the CURRENT device has fewer CUs (use the per-launch
