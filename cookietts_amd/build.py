@@ -16,7 +16,7 @@ INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 LIB_PATH = os.path.join(PKG_DIR, "libcookietts_hip.so")
 OBJ_DIR = os.path.join(PKG_DIR, "build")
 ARCH = "gfx950"
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("CTTS_HIPCC_EXTRA", "").split()
 # per-file additions.  tacotron_persistent.hip: the SLP vectoriser packs its scalar fp32 FMAs into v_pk_fma_f32, whose
 # register-pair operands cost hundreds of moves and spills in a kernel that keeps ~100 weights resident per lane
 EXTRA_FLAGS = {"tacotron_persistent.hip": ["-fno-slp-vectorize"]}

@@ -9,10 +9,10 @@
 //   * workgroups 0..251 ("LSTM workgroups", 256 threads = one wave per SIMD, so each wave owns the SIMD's whole
 //     512-entry register file): every wave owns two or three whole LSTM units (all four gate rows, ALL columns) of the
 //     workgroup's 5-6 attention-RNN units, 3-4 decoder-RNN units and 3-4 second-decoder-RNN units: 304-384 weights per
-//     lane in VGPRs + AGPRs, the rest (up to 28 tiles of 1 KB per wave) in LDS; the products run on the matrix pipe
+//     lane in VGPRs + AGPRs, the rest (up to 36 tiles of 1 KB per wave) in LDS; the products run on the matrix pipe
 //     (v_mfma_f32_4x4x1_16b_f32: gate rows x batch items, 16 column blocks per instruction), the gate sums of a unit end
-//     up in the lanes that update its cell - no barrier between product and cell.  Four workgroup classes (6/3/3,
-//     5/4/3, 5/3/4, 5/3/3 units) spread the 1280 + 768 + 768 units over 252 workgroups.
+//     up in the lanes that update its cell - no barrier between product and cell.  Four workgroup classes (6/2/3,
+//     5/4/2, 5/3/4, 5/3/3 units) spread the 1280 + 768 + 768 units over 252 workgroups, one decoder-RNN unit per wave at most.
 //     Plus, as before: one row of the query projection (workgroups < attention_dim), one or two rows of the projection
 //     row set [mel | gate | first prenet layer folded through the mel projection] and one or two rows of the second
 //     prenet layer, LDS-resident.
@@ -43,9 +43,12 @@ constexpr int PD_NB = 4;            // batch, padded
 constexpr int PD_RA = 1280, PD_RD = 768, PD_P = 256, PD_DM = 512;
 constexpr int PD_AMAX = 192, PD_TMAX = 1024, PD_W = 33, PD_FMAX = 32, PD_KMAX = 31;
 // workgroup classes: units of (attention RNN, decoder RNN, second decoder RNN) per workgroup
-//   class 0: wg   0..19  (6, 3, 3)     class 1: wg 20..31  (5, 4, 3)     class 2: wg 32..43  (5, 3, 4)     class 3: wg 44..251 (5, 3, 3)
-// 20 * 6 + 232 * 5 = 1280;  12 * 4 + 240 * 3 = 768 (twice)
-constexpr int PD_C0 = 20, PD_C1 = 32, PD_C2 = 44;
+//   class 0: wg   0..19  (6, 2, 3)     class 1: wg 20..51  (5, 4, 2)     class 2: wg 52..95  (5, 3, 4)     class 3: wg 96..251 (5, 3, 3)
+// 20 * 6 + 232 * 5 = 1280;  20 * 2 + 32 * 4 + 200 * 3 = 768;  20 * 3 + 32 * 2 + 44 * 4 + 156 * 3 = 768.  Chosen so that NO
+// wave holds more than one decoder-RNN unit or more than one second-decoder unit (the fresh phases C and D are then one
+// cell per wave; three decoder cells on one wave delayed the dec_h exchange of the whole chip by ~1.5 us) and at most
+// two attention-RNN units, and every class fits 92 register tiles per wave + 76 LDS tiles per workgroup.
+constexpr int PD_C0 = 20, PD_C1 = 52, PD_C2 = 96;
 // LDS vector store X of an LSTM workgroup: [item][n + 16] per vector (padded rows, see pd_xs)
 constexpr int XP = 0, XCTX = XP + PD_NB * (PD_P + 16), XDEC = XCTX + PD_NB * (PD_DM + 16), XATT = XDEC + PD_NB * (PD_RD + 16),
               XD2 = XATT + PD_NB * (PD_RA + 16), XH1 = XD2 + PD_NB * (PD_RD + 16), X_FLOATS = XH1 + PD_NB * (PD_P + 16);
@@ -94,6 +97,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // rounding-amplifying trajectory (tests/test_tacotron_long.py): distance to the exact run in band 1 1.6e-4 with the
 // fast forms, 1.1e-4 with libm or these; step time 32.2 / 34.1 (libm) us.
 __device__ __forceinline__ float acc_exp(float y) {
+    y = fminf(y, 88.0f);                                  // e^88 is finite: inf * (correction) would be NaN, and 1 / (1 + e^88) is 0 anyway
     const float p = y * 1.4426950408889634f;
     const float r = fmaf(y, 1.4426950408889634f, -p) + y * 1.925963033500011e-08f;     // log2(e) = hi + lo
     const float e = __builtin_amdgcn_exp2f(p);
@@ -488,10 +492,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 // Units of workgroup wg (class table above) and its first unit per cell
 __device__ __forceinline__ int pd_first_att(int wg) { return wg < PD_C0 ? 6 * wg : 6 * PD_C0 + 5 * (wg - PD_C0); }
 __device__ __forceinline__ int pd_first_dec(int wg) {
-    return wg < PD_C0 ? 3 * wg : wg < PD_C1 ? 3 * PD_C0 + 4 * (wg - PD_C0) : 3 * PD_C0 + 4 * (PD_C1 - PD_C0) + 3 * (wg - PD_C1);
+    return wg < PD_C0 ? 2 * wg : wg < PD_C1 ? 2 * PD_C0 + 4 * (wg - PD_C0) : 2 * PD_C0 + 4 * (PD_C1 - PD_C0) + 3 * (wg - PD_C1);
 }
 __device__ __forceinline__ int pd_first_d2(int wg) {
-    return wg < PD_C1 ? 3 * wg : wg < PD_C2 ? 3 * PD_C1 + 4 * (wg - PD_C1) : 3 * PD_C1 + 4 * (PD_C2 - PD_C1) + 3 * (wg - PD_C2);
+    return wg < PD_C0   ? 3 * wg
+           : wg < PD_C1 ? 3 * PD_C0 + 2 * (wg - PD_C0)
+           : wg < PD_C2 ? 3 * PD_C0 + 2 * (PD_C1 - PD_C0) + 4 * (wg - PD_C1)
+                        : 3 * PD_C0 + 2 * (PD_C1 - PD_C0) + 4 * (PD_C2 - PD_C1) + 3 * (wg - PD_C2);
 }
 
 // cell types of a slot.  Tiles of a slot, fresh segment first:
@@ -511,12 +518,12 @@ struct PdSig {
     static constexpr int NT = off[3], NLDS = NL, NREG = NT - NL;
     static_assert(NREG <= 96, "more than 384 weight registers per lane");
 };
-using SigSAA = PdSig<CELL_D2, CELL_ATT, CELL_ATT, 16>;     // 92 tiles, 76 in registers
-using SigSDA = PdSig<CELL_D2, CELL_DEC, CELL_ATT, 16>;     // 108 - 16 = 92
-using SigDD = PdSig<CELL_DEC, CELL_DEC, CELL_NONE, 0>;     // 80
-using SigDDD = PdSig<CELL_DEC, CELL_DEC, CELL_DEC, 28>;    // 120 - 28 = 92
-using SigSDD = PdSig<CELL_D2, CELL_DEC, CELL_DEC, 16>;     // 104 - 16 = 88
-constexpr int PD_LT_WAVE = 28;                             // most LDS tiles of one wave; LDS tile slots per workgroup:
+using SigSDA = PdSig<CELL_D2, CELL_DEC, CELL_ATT, 16>;     // 108 tiles, 92 in registers (the common wave: 3 of 4 in every class)
+using SigSAA = PdSig<CELL_D2, CELL_ATT, CELL_ATT, 20>;     // 112 - 20 = 92
+using SigDAA = PdSig<CELL_DEC, CELL_ATT, CELL_ATT, 36>;    // 128 - 36 = 92
+using SigDA = PdSig<CELL_DEC, CELL_ATT, CELL_NONE, 0>;     // 84
+using SigAA = PdSig<CELL_ATT, CELL_ATT, CELL_NONE, 0>;     // 88
+constexpr int PD_LT_WAVE = 36;                             // most LDS tiles of one wave; LDS tile slots per workgroup:
 constexpr int PD_LT = 76;                                  // 16+16+16+28 (class 0), 16+16+12+28, 16+16+12+16, 16+16+12+0
 
 // padded X rows: item j of a vector of n floats starts at j (n + 16): the 16-byte reads of the four items of a block fall
@@ -959,31 +966,32 @@ __device__ __forceinline__ void lstm_wave(const PdArgs& a, float* L, LstmLds& S,
 }
 
 // The four waves of an LSTM workgroup of each class (slot = unit index inside the workgroup's units of that cell):
-//   class 0 (6,3,3): (S0 A0 A1) (S1 A2 A3) (S2 A4 A5) (D0 D1 D2)      class 1 (5,4,3): (S0 A0 A1) (S1 A2 A3) (S2 D0 A4) (D1 D2 D3)
-//   class 2 (5,3,4): (S0 A0 A1) (S1 A2 A3) (S2 D0 A4) (S3 D1 D2)      class 3 (5,3,3): (S0 A0 A1) (S1 A2 A3) (S2 D0 A4) (D1 D2)
-// LDS tiles of the waves start at 0, 16, 32, 48 (class 0) / 0, 16, 32, 44 (classes 1-3).
+//   class 0 (6,2,3): (S0 D0 A0) (S1 D1 A1) (S2 A2 A3) (A4 A5)         class 1 (5,4,2): (S0 D0 A0) (S1 D1 A1) (D2 A2) (D3 A3 A4)
+//   class 2 (5,3,4): (S0 D0 A0) (S1 D1 A1) (S2 D2 A2) (S3 A3 A4)      class 3 (5,3,3): (S0 D0 A0) (S1 D1 A1) (S2 D2 A2) (A3 A4)
+// LDS tiles: an S-D-A wave 16 at 16 * wave; the S-A-A wave 20 at 32 (class 0) / 48 (class 2); the D-A-A wave 36 at 32.
 template <bool DBG>
 __device__ __forceinline__ void lstm_workgroup(const PdArgs& a, float* L, LstmLds& S, int wg) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cls = wg < PD_C0 ? 0 : wg < PD_C1 ? 1 : wg < PD_C2 ? 2 : 3;
-    // ONE call (= one inlined copy of the step loop) per signature; slots and the first LDS tile are runtime values
+    // ONE call (= one inlined copy of the step loop) per signature; slots and the first LDS tile are runtime values.  (Two
+    // inlined copies of one signature with different constants mis-computed one slot: profiles/HISTORY.md, round 4.)
     PdSlots su;
-    int lt0;
-    if (wave < 2 || (wave == 2 && cls == 0)) {
-        su.unit[0] = wave; su.unit[1] = 2 * wave; su.unit[2] = 2 * wave + 1; lt0 = 16 * wave;
-        lstm_wave<SigSAA, DBG>(a, L, S, wg, su, lt0);
-    } else if (wave == 2) {
-        su.unit[0] = 2; su.unit[1] = 0; su.unit[2] = 4; lt0 = 32;
+    int lt0 = 16 * wave;
+    if (wave < 2 || (wave == 2 && cls >= 2)) {
+        su.unit[0] = wave; su.unit[1] = wave; su.unit[2] = wave;
         lstm_wave<SigSDA, DBG>(a, L, S, wg, su, lt0);
-    } else if (cls <= 1) {
-        su.unit[0] = cls; su.unit[1] = cls + 1; su.unit[2] = cls + 2; lt0 = 48;
-        lstm_wave<SigDDD, DBG>(a, L, S, wg, su, lt0);
-    } else if (cls == 2) {
-        su.unit[0] = 3; su.unit[1] = 1; su.unit[2] = 2; lt0 = 48;
-        lstm_wave<SigSDD, DBG>(a, L, S, wg, su, lt0);
-    } else {
-        su.unit[0] = 1; su.unit[1] = 2; su.unit[2] = -1; lt0 = 48;
-        lstm_wave<SigDD, DBG>(a, L, S, wg, su, lt0);
+    } else if ((wave == 2 && cls == 0) || (wave == 3 && cls == 2)) {
+        su.unit[0] = wave; su.unit[1] = wave == 2 ? 2 : 3; su.unit[2] = wave == 2 ? 3 : 4;
+        lstm_wave<SigSAA, DBG>(a, L, S, wg, su, lt0);
+    } else if (wave == 3 && cls == 1) {
+        su.unit[0] = 3; su.unit[1] = 3; su.unit[2] = 4; lt0 = 32;
+        lstm_wave<SigDAA, DBG>(a, L, S, wg, su, lt0);
+    } else if (wave == 2 && cls == 1) {
+        su.unit[0] = 2; su.unit[1] = 2; su.unit[2] = -1;
+        lstm_wave<SigDA, DBG>(a, L, S, wg, su, lt0);
+    } else {        // wave 3 of classes 0 and 3
+        su.unit[0] = cls == 0 ? 4 : 3; su.unit[1] = cls == 0 ? 5 : 4; su.unit[2] = -1;
+        lstm_wave<SigAA, DBG>(a, L, S, wg, su, lt0);
     }
 }
 
