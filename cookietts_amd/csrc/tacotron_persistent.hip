@@ -565,16 +565,20 @@ __device__ __forceinline__ bool gather_x(const u64* g, float* dst, unsigned epoc
         }
         return false;
     };
-    if constexpr (PPT > 4) {
-        // light phase (large vectors only): thread t watches pair t - one contiguous 4 KB read per workgroup.  (A sample
-        // strided over all units of item 0, i.e. over all publishing workgroups, was measured slower: att_h 4.3 -> 5.2 us.)
-        const int pl = t;
-        for (unsigned spins = 0;; ++spins) {
-            const pd_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * pl, 0, PD_AUX_SC1);
-            if (__all(v[1] == epoch && v[3] == epoch)) break;
-            if (timed_out(spins)) return false;
-            __builtin_amdgcn_s_sleep(1);
+    {
+        // light phase: ONE wave watches 64 pairs spread over all units of item 0 (= over all publishing workgroups) while the
+        // other three wait at the barrier: a quarter of the polling traffic of a 256-thread watch, and none of the
+        // full-sweep traffic before the vector is (nearly) complete
+        if (t < 64) {
+            const int pl = t * (N / 2 / 64);
+            for (unsigned spins = 0;; ++spins) {
+                const pd_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * pl, 0, PD_AUX_SC1);
+                if (__all(v[1] == epoch && v[3] == epoch)) break;
+                if (timed_out(spins)) break;          // recorded in the control words: the sweep below gives up on them
+                __builtin_amdgcn_s_sleep(1);
+            }
         }
+        __syncthreads();
     }
 #pragma unroll 1
     for (int k0 = 0; k0 < PPT; k0 += PB) {          // full sweep
