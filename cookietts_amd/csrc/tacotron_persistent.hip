@@ -59,6 +59,9 @@ constexpr int WW2 = WPR + 2 * (PD_RD + PD_DM);                 // two second-pre
 constexpr int WLT = WW2 + 2 * PD_P;                            // LSTM weight tiles kept in LDS: [tile][lane] float4, 76 tiles
 constexpr int LSTM_FLOATS = WLT + 76 * 64 * 4;
 constexpr int PD_DBG_SLOTS = 24;             // ctts_taco_decoder_persistent_debug: [PD_WG][64 steps][PD_DBG_SLOTS] stamps
+#ifndef PD_PB_MAX
+#define PD_PB_MAX 6
+#endif
 constexpr unsigned PD_SPIN_LIMIT = 400000;   // polls per gather before giving up (~0.5 s)
 
 typedef unsigned long long u64;
@@ -348,17 +351,34 @@ __device__ __forceinline__ void pd_attention_post(const PdArgs& a, AttnLds& s, c
         float qv[3], ev[NE];
 #pragma unroll
         for (int j = 0; j < 3; ++j) qv[j] = lane + 64 * j < a.A ? s.q[lane + 64 * j] : 0.f;
+        // staged by hand: all 27 loads, then all exp2, then all rcp, then the sums.  Written as one loop per position the
+        // wave executed 27 dependent exp2 -> add -> rcp -> fma chains back to back (2.1 us: a wave issues in order and the
+        // transcendental pipe has ~40 cycles of latency); the order of every sum is unchanged
+        // (tanhf here: arbiter distance of band 1 1.6e-4 -> 1.1e-4, step 32 -> 36 us with libm in the cells as well: not taken)
+        float x[NE][3];
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const int tt = min(wv + PD_NW * i, W - 1);
-            float e = 0.f;
+        for (int i = 0; i < NE; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j)     // pmw = processed memory + location term (pd_attention_pre)
-                // (tanhf here: arbiter distance of band 1 1.6e-4 -> 1.1e-4, step 32 -> 36 us with libm in the cells as well: not taken)
-                e += lane + 64 * j < a.A ? r.va3[j] * fast_tanh(s.pmw[tt * a.A + lane + 64 * j] + qv[j]) : 0.f;
+                x[i][j] = lane + 64 * j < a.A ? s.pmw[min(wv + PD_NW * i, W - 1) * a.A + lane + 64 * j] + qv[j] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) x[i][j] = __builtin_amdgcn_exp2f(x[i][j] * 2.8853900817779268f);
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) x[i][j] = __builtin_amdgcn_rcpf(1.0f + x[i][j]);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            float e = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) e += lane + 64 * j < a.A ? r.va3[j] * (1.0f - 2.0f * x[i][j]) : 0.f;
             ev[i] = e;
         }
+        PD_STAMP(18);
         wave_totals<NE>(ev);
+        PD_STAMP(19);
 #pragma unroll
         for (int i = 0; i < NE; ++i)
             if (lane == 0 && wv + PD_NW * i < W) s.en[wv + PD_NW * i] = ev[i];
@@ -553,7 +573,7 @@ __device__ __forceinline__ bool gather_x(const u64* g, float* dst, unsigned epoc
     constexpr int PAIRS = 2 * N, PPT = (PAIRS + PD_T - 1) / PD_T;
     // pairs of a thread in flight during a full sweep: everything at once up to 6 (24 data registers), else rounds of 5
     // (att_h: 10 pairs per thread; all 10 at once spilt 70 weight registers)
-    constexpr int PB = PPT <= 6 ? PPT : 5;
+    constexpr int PB = PPT <= PD_PB_MAX ? PPT : 5;
     static_assert(PAIRS >= PD_T && N % 2 == 0, "every thread owns at least one pair");
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64*>(g), 0, PD_NB * N * 8, 0x00020000);
     auto timed_out = [&](unsigned spins) -> bool {

@@ -30,6 +30,11 @@ for wg in (252, 255):
     print(f"attention wg {wg}: " + " | ".join(f"{n} {v:.1f}" for n, v in zip(
         ["pre (bursts + loc conv)", "wait q", "energies", "softmax", "ctx", "publish + w/cum"], d)))
 
+for wg in (252,):
+    e = s[wg, 8:56, :]
+    print(f"attention wg {wg} energies split: q gathered -> tanh loop done {np.mean(e[:, 18] - e[:, 2]):.2f} | wave reductions "
+          f"{np.mean(e[:, 19] - e[:, 18]):.2f} | store + barrier {np.mean(e[:, 3] - e[:, 19]):.2f} us")
+
 # Cross-workgroup view of every exchange (s_memrealtime is one chip-wide 100 MHz counter): when did the LAST publisher
 # publish, how far apart were the publishers, and how long after the last publish had the FIRST / LAST consumer its copy.
 # (publish stamps: 1 att_h, 17 q, attention 5 ctx, 13 dec_h, 14 d2_h, 15 h1, 16 p; gather-done stamps: 2, attn 2, 4, 6, 8, 10, 12)
