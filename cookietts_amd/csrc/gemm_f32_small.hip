@@ -1071,6 +1071,8 @@ void launch_small(dim3 grid, hipStream_t stream, const GemmArgs& a, int ntiles_s
 
 }  // namespace
 
+static inline long long gate_rs_blocks(const GemmArgs& a) { return a.shape_blocks > 0 ? a.shape_blocks : (long long)a.ntiles * a.batch; }
+
 bool gemm_f32_small_applies(int epi, const GemmArgs& a) {
     if (a.nch_total > S_MAX_CHUNKS) return false;
     const Tuning tune = tuning();
@@ -1081,8 +1083,8 @@ bool gemm_f32_small_applies(int epi, const GemmArgs& a) {
         // (exact products: never less accurate than what was asked for) beats the split loop of the 128 x 256 shape
         // (config 4 at batch 1: 38.8 ms against 67 / 83 ms)
         if (gemm_mode_is_split(a.gemm_mode))
-            return !tune.f32_no_splitk && (long long)a.ntiles * a.batch <= GATE_RS_SPLITK_MAX_BLOCKS;
-        return (long long)a.ntiles * a.batch < GATE_RS_SMALL_BELOW_BLOCKS || tune.f32_force_small;
+            return !tune.f32_no_splitk && gate_rs_blocks(a) <= GATE_RS_SPLITK_MAX_BLOCKS;
+        return gate_rs_blocks(a) < GATE_RS_SMALL_BELOW_BLOCKS || tune.f32_force_small;
     }
     if (a.bm != 256) return false;
     if (!(epi == GEMM_EPI_SPLIT || epi == GEMM_EPI_GATE || epi == GEMM_EPI_GATEX || epi == GEMM_EPI_MAG || epi == GEMM_EPI_LOG ||
@@ -1096,7 +1098,7 @@ bool gemm_f32_small_applies(int epi, const GemmArgs& a) {
 }
 
 int launch_gemm_f32_small(int epi, const GemmArgs& a, hipStream_t stream) {
-    if (epi == GEMM_EPI_GATE_RS && !tuning().f32_no_splitk && (long long)a.ntiles * a.batch <= GATE_RS_SPLITK_MAX_BLOCKS) {
+    if (epi == GEMM_EPI_GATE_RS && !tuning().f32_no_splitk && gate_rs_blocks(a) <= GATE_RS_SPLITK_MAX_BLOCKS) {
         const int nt = (a.L + K_BN - 1) / K_BN;
         const long long nblk = (long long)nt * a.batch;
         CTTS_CHECK_ARG(nblk > 0 && nblk < (1ll << 31), "gemm (split-K fused shape): grid %lld", nblk);

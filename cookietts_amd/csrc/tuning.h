@@ -22,6 +22,7 @@ struct Tuning {
     bool wf_no_fuse;       // CTTS_WF_NO_FUSE: WaveFlow layer as separate GATE + res/skip launches
     bool taco_no_fuse;     // CTTS_TACO_NO_FUSE: per-launch decoder without the fused projection kernel
     bool f32_no_defer_skip;  // CTTS_F32_NO_DEFER_SKIP: WaveGlow fp32 WN stack with one res/skip GEMM per layer (the form before round 4)
+    bool wf_no_region_split; // CTTS_WF_NO_REGION_SPLIT: the fused WaveFlow layer as ONE launch per layer (no A | M | B regions on three streams)
     bool wf_no_vec_interp; // CTTS_WF_NO_VEC_INTERP: the scalar form of the WaveFlow conditioning interpolation (bit-identical)
     int w4_debug;          // CTTS_BF16_W4_DEBUG (only in builds with -DCTTS_W4_TIMING_EXPERIMENTS)
 };

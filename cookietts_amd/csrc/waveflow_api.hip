@@ -577,6 +577,86 @@ namespace {
 
 // Shared body of the two entry points.  cond = mel [B][n_mel][frames] (dense) when the single linear cond layer is
 // folded into the GEMM, or the per-flow frame-rate conditioning [n_flows][B][2C*n_layers][cond_ld] (padded rows).
+// ---- region split of a fused-layer launch (see the runner) ----------------------------------------------------------
+constexpr int WF_TILE = 256;          // columns per region unit: every launch shape's tile width divides it
+#ifndef WF_NBIG
+#define WF_NBIG 2                     // big regions per layer (2: A | M | B on three streams)
+#endif
+constexpr int WF_NREG = 2 * WF_NBIG - 1;     // regions incl. the one-tile separators: big 0, sep 0, big 1, sep 1, ...
+struct WfRegionStreams {              // per host thread: one helper stream per region but the first + double-buffered events
+    hipStream_t st[WF_NREG] = {};
+    hipEvent_t fork = nullptr, ev[WF_NREG][2] = {};
+    bool ready = false;
+    int init() {
+        if (ready) return CTTS_OK;
+        for (int k = 1; k < WF_NREG; ++k) CTTS_CHECK_HIP(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
+        CTTS_CHECK_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        for (int k = 0; k < WF_NREG; ++k)
+            for (int q = 0; q < 2; ++q) CTTS_CHECK_HIP(hipEventCreateWithFlags(&ev[k][q], hipEventDisableTiming));
+        ready = true;
+        return CTTS_OK;
+    }
+};
+thread_local WfRegionStreams t_wf_streams;
+
+struct WfRegionSplit {
+    bool on = false;
+    int ntiles = 0, L = 0;
+    int tile0[WF_NREG + 1] = {};
+    void plan() {       // big regions of (ntiles - separators) / WF_NBIG tiles, one-tile separators between them
+        const int big = (ntiles - (WF_NBIG - 1)) / WF_NBIG;
+        int t = 0;
+        for (int k = 0; k < WF_NREG; ++k) { tile0[k] = t; t += (k & 1) ? 1 : big; }
+        tile0[WF_NREG] = ntiles;          // the last big region takes the remainder
+    }
+    static GemmArgs shifted(const GemmArgs& a, int tile0, int nt, int L) {
+        GemmArgs r = a;
+        const long long co = (long long)tile0 * WF_TILE;
+        for (int j = 0; j < r.nseg; ++j) r.seg[j].base += co;
+        if (r.dst0) r.dst0 += co;
+        if (r.dst1) r.dst1 += co;
+        if (r.src0) r.src0 += co;
+        if (r.addend) r.addend += co;
+        const int cols = L - tile0 * WF_TILE;
+        r.L = cols < nt * WF_TILE ? cols : nt * WF_TILE;
+        r.ntiles = nt;
+        r.shape_blocks = 255;       // every region on the 128 x 128 shape (same K order as the 128 x 256 one; never the split-K shape)
+        return r;
+    }
+    int begin_row(hipStream_t s) {
+        auto& t = t_wf_streams;
+        int rc = t.init(); if (rc) return rc;
+        plan();
+        CTTS_CHECK_HIP(hipEventRecord(t.fork, s));                      // the row's start kernel has written every column
+        for (int k = 1; k < WF_NREG; ++k) CTTS_CHECK_HIP(hipStreamWaitEvent(t.st[k], t.fork, 0));
+        return CTTS_OK;
+    }
+    // region k of layer i waits for its neighbours' layer i - 1 (its own layer i - 1 precedes it on its stream)
+    int layer(const GemmArgs& a, int i, hipStream_t s) {
+        auto& t = t_wf_streams;
+        const int par = i & 1, prev = par ^ 1;
+        for (int k = 0; k < WF_NREG; ++k) {
+            hipStream_t st = k == 0 ? s : t.st[k];
+            if (i > 0) {
+                if (k > 0) CTTS_CHECK_HIP(hipStreamWaitEvent(st, t.ev[k - 1][prev], 0));
+                if (k + 1 < WF_NREG) CTTS_CHECK_HIP(hipStreamWaitEvent(st, t.ev[k + 1][prev], 0));
+            }
+            const int rc = launch_gemm_f32(GEMM_EPI_GATE_RS, shifted(a, tile0[k], tile0[k + 1] - tile0[k], L), st);
+            if (rc) return rc;
+            CTTS_CHECK_HIP(hipEventRecord(t.ev[k][par], st));
+        }
+        last_par = par;
+        return CTTS_OK;
+    }
+    int end_row(hipStream_t s) {                                        // the row's tail kernel reads every column
+        auto& t = t_wf_streams;
+        for (int k = 1; k < WF_NREG; ++k) CTTS_CHECK_HIP(hipStreamWaitEvent(s, t.ev[k][last_par], 0));
+        return CTTS_OK;
+    }
+    int last_par = 0;
+};
+
+
 int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float* z, const float* cond, int cond_ld,
                int cond_pad, float* audio, int batch, int samples, int frames, void* workspace, size_t workspace_bytes,
                void* stream) {
@@ -614,6 +694,16 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
     auto X = [&](int layer, int slot) { return w.X + ((size_t)layer * NS + slot) * w.xslot; };
     const bool no_fuse = tuning().wf_no_fuse;
     const bool fuse = p.fused() && !no_fuse;
+    // Region split of the fused layer (round 4): every layer launch used to wait for the slowest of the previous layer's 456
+    // workgroups although tile t of layer i + 1 needs only tiles t - 1, t, t + 1 of layer i (dilation <= 128 < one 256-column
+    // tile).  The columns are cut into three regions A | M (one tile) | B launched on three streams: A(i+1) and B(i+1) wait
+    // for M(i) only, M(i+1) waits for A(i) and B(i), so the two halves drift by up to a layer and each half's tail overlaps
+    // the other's next layer.  Same kernel, same tiles: bit-identical to the single launch (CTTS_WF_NO_REGION_SPLIT).
+    WfRegionSplit rsplit;
+    // (only where the launch is the 128 x 256 shape: below 256 blocks - batch <= 4 at 900 frames - a layer lasts ~35-100 us and
+    // three launches + six event operations per layer make the call host-bound: measured 38.7 -> 78 ms at batch 1)
+    rsplit.on = fuse && !tuning().wf_no_region_split && g.ntiles >= 8 && (long long)g.ntiles * batch >= 256 && !tuning().f32_force_small;
+    rsplit.ntiles = g.ntiles; rsplit.L = L;
     const bool sep_fuse = p.sep_fused() && !no_fuse;
     // un-mix of flow k on the active rows: PermuteHeight composes into the map, the 1x1 conv is a pass over the rows
     auto unmix = [&](int k) -> int {
@@ -648,6 +738,7 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
             hipLaunchKernelGGL(wf_start_kernel, dim3(((L + 3) / 4 + 255) / 256, (C + 15) / 16, batch), dim3(256), 0, s,
                                w.rows, blob + f.start_w, blob + f.start_b, X(0, slot), C, G, phys[r], L, g.Lr, g.ld, g.pad);
             CTTS_CHECK_LAUNCH("wf_start");
+            if (rsplit.on && (rc = rsplit.begin_row(s))) return rc;
             for (int i = 0; i < p.c.n_layers; ++i) {
                 const int dw = p.c.dilation_w[i] > 0 ? p.c.dilation_w[i] : 1 << i;
                 // merge_res_skip (glow_ax.py:612-626): no residual into `audio`, so every layer's queue holds the
@@ -721,6 +812,10 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
                     a.src0 = X(si, slot); a.src0_bstride = cstride;
                     a.dst1 = w.out; a.dst1_bstride = cstride; a.acc1 = i > 0 ? 1 : 0;
                     a.split = last ? 0 : C;
+                    if (rsplit.on) {
+                        if ((rc = rsplit.layer(a, i, s))) return rc;
+                        continue;
+                    }
                     if ((rc = launch_gemm_f32(GEMM_EPI_GATE_RS, a, s))) return rc;
                     continue;
                 }
@@ -742,6 +837,7 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
                 q.split = last ? 0 : C;
                 if ((rc = launch_gemm_f32(GEMM_EPI_SPLIT, q, s))) return rc;
             }
+            if (rsplit.on && (rc = rsplit.end_row(s))) return rc;
             hipLaunchKernelGGL(wf_tail_kernel, dim3((g.Lr + 255) / 256, batch), dim3(256), 0, s, w.out, w.rows,
                                blob + f.end_w, blob + f.end_b, C, G, phys[r + 1], L, g.Lr, g.ld, g.pad);
             CTTS_CHECK_LAUNCH("wf_tail");
