@@ -26,7 +26,13 @@ Beside the timed weak-scaling steps the per-request exchange of §8e is timed on
 Extra objects on the line:
   roofline     - the dominant kernel (WN in-layer conv-GEMM: dilated conv + cond + gate),
                  algorithmic FLOPs per launch / mean launch time measured with HIP events
-                 inside the library on the launch stream, vs the MFMA peak of the dtype.
+                 inside the library on the launch stream, vs the MFMA peak of the dtype; beside it the
+                 res GEMM, the deferred skip GEMM and the whole step against the same peak.
+  rows         - N = 1 only, AFTER the timed region: short runs of config 3 (bf16, B=32, with its own
+                 roofline), the bf16x6 GEMM mode, config 4 (WaveFlow, B=1 and B=8) and config 5 (Tacotron2
+                 decoder, 900 forced steps, chained into the headline's vocoder), ~7 s; a failing row is
+                 recorded in place and never takes the headline down (--no-rows / --rows '' to skip).
+  ms_per_step_ranks - every rank's own time for the K steps (min / max / all): stragglers at N > 1.
   cpu_baseline - oracle/waveglow_torch_cpu.py (a reference-free torch-CPU restatement pinned to the
                  reference's goldens; test infrastructure) timed on this box's physical cores on ONE
                  full 80x900 utterance of the same model: 1 warm-up + best-of-N (rank 0, N=1 only).

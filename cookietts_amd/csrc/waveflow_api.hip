@@ -579,6 +579,9 @@ namespace {
 // folded into the GEMM, or the per-flow frame-rate conditioning [n_flows][B][2C*n_layers][cond_ld] (padded rows).
 // ---- region split of a fused-layer launch (see the runner) ----------------------------------------------------------
 constexpr int WF_TILE = 256;          // columns per region unit: every launch shape's tile width divides it
+#ifndef WF_SPLIT_MIN_BLOCKS
+#define WF_SPLIT_MIN_BLOCKS 256
+#endif
 #ifndef WF_NBIG
 #define WF_NBIG 2                     // big regions per layer (2: A | M | B on three streams)
 #endif
@@ -702,7 +705,7 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
     WfRegionSplit rsplit;
     // (only where the launch is the 128 x 256 shape: below 256 blocks - batch <= 4 at 900 frames - a layer lasts ~35-100 us and
     // three launches + six event operations per layer make the call host-bound: measured 38.7 -> 78 ms at batch 1)
-    rsplit.on = fuse && !tuning().wf_no_region_split && g.ntiles >= 8 && (long long)g.ntiles * batch >= 256 && !tuning().f32_force_small;
+    rsplit.on = fuse && !tuning().wf_no_region_split && g.ntiles >= 8 && (long long)g.ntiles * batch >= WF_SPLIT_MIN_BLOCKS && !tuning().f32_force_small;
     rsplit.ntiles = g.ntiles; rsplit.L = L;
     const bool sep_fuse = p.sep_fused() && !no_fuse;
     // un-mix of flow k on the active rows: PermuteHeight composes into the map, the 1x1 conv is a pass over the rows

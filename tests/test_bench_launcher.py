@@ -104,3 +104,24 @@ def test_launcher_wall_clock_limit_ends_its_children(tmp_path):
     assert r.returncode == 124 and time.time() - t0 < 120
     assert "wall-clock limit" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_defaults_and_profiler_guard(monkeypatch):
+    """Defaults the driver relies on: N = 1, the secondary rows on, the CPU aggregate on 300-frame utterances; and the guard that
+    keeps a profiled run (rocprofv3's library initialises the GPU before Python starts) from starting child processes."""
+    sys.path.insert(0, REPO)
+    import bench
+    a = bench.parse_args([])
+    assert a.gpus == 1 and a.rows == "config3,bf16x6,config4,config5" and not a.no_rows
+    assert a.cpu_frames == 900 and a.cpu_aggregate_frames == 300 and a.cpu_budget <= 30
+    for k in list(os.environ):
+        if k.startswith(("ROCPROF", "ROCP_")):
+            monkeypatch.delenv(k)
+    monkeypatch.delenv("LD_PRELOAD", raising=False)
+    monkeypatch.delenv("HSA_TOOLS_LIB", raising=False)
+    assert not bench.under_profiler()
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    assert bench.under_profiler()
+    monkeypatch.delenv("LD_PRELOAD")
+    monkeypatch.setenv("ROCPROFILER_SOMETHING", "1")
+    assert bench.under_profiler()
