@@ -59,6 +59,9 @@ constexpr int WW2 = WPR + 2 * (PD_RD + PD_DM);                 // two second-pre
 constexpr int WLT = WW2 + 2 * PD_P;                            // LSTM weight tiles kept in LDS: [tile][lane] float4, 76 tiles
 constexpr int LSTM_FLOATS = WLT + 76 * 64 * 4;
 constexpr int PD_DBG_SLOTS = 24;             // ctts_taco_decoder_persistent_debug: [PD_WG][64 steps][PD_DBG_SLOTS] stamps
+#ifndef PD_LIGHT_SAMPLES_BIG
+#define PD_LIGHT_SAMPLES_BIG 1
+#endif
 #ifndef PD_PB_MAX
 #define PD_PB_MAX 6
 #endif
@@ -590,10 +593,16 @@ __device__ __forceinline__ bool gather_x(const u64* g, float* dst, unsigned epoc
         // other three wait at the barrier: a quarter of the polling traffic of a 256-thread watch, and none of the
         // full-sweep traffic before the vector is (nearly) complete
         if (t < 64) {
-            const int pl = t * (N / 2 / 64);
+            constexpr int NS = PPT > 6 ? PD_LIGHT_SAMPLES_BIG : 1;      // samples per lane
             for (unsigned spins = 0;; ++spins) {
-                const pd_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * pl, 0, PD_AUX_SC1);
-                if (__all(v[1] == epoch && v[3] == epoch)) break;
+                bool ok = true;
+#pragma unroll
+                for (int q = 0; q < NS; ++q) {
+                    const int pl = (t * NS + q) * (N / 2 / (64 * NS));
+                    const pd_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * pl, 0, PD_AUX_SC1);
+                    ok = ok && v[1] == epoch && v[3] == epoch;
+                }
+                if (__all(ok)) break;
                 if (timed_out(spins)) break;          // recorded in the control words: the sweep below gives up on them
                 __builtin_amdgcn_s_sleep(1);
             }
