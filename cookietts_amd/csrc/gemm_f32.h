@@ -102,7 +102,7 @@ struct GemmSeg {
     int nch;              // K chunks (of GEMM_KC rows) this segment contributes
     int shift;            // column shift (time steps)
     int mb_rows;          // extra row offset per M-block (block-diagonal batched GEMMs)
-    int reserved;
+    int fresh;            // wf_row_persistent_kernel only: rows written by other workgroups of the SAME launch (read at agent scope)
 };
 
 struct GemmArgs {
@@ -168,12 +168,21 @@ int launch_gemm_f32(int epi, const GemmArgs& a, hipStream_t stream);
 bool gemm_f32_small_applies(int epi, const GemmArgs& a);
 int launch_gemm_f32_small(int epi, const GemmArgs& a, hipStream_t stream);
 
+// WaveFlow row step as ONE launch (gemm_f32_small.hip, wf_row_persistent_kernel): the GEMM_EPI_GATE_RS layers of a row as items of
+// a work queue, tile (layer i + 1, t) waiting for tiles t - 1, t, t + 1 of layer i only.  `layers_dev`: the row's GemmArgs in
+// device memory, exactly what launch_gemm_f32(GEMM_EPI_GATE_RS, ...) would have been given layer by layer, with GemmSeg.fresh
+// set on the segments the previous layer of the same row writes.  Needs |shift| <= 128 on fresh segments.
+bool wf_row_persistent_supported(const GemmArgs& a);
+int wf_row_tiles(int L);                      // 128-column tiles per batch item (the flag array's inner extent)
+int launch_wf_row_persistent(const GemmArgs* layers_dev, int nlayers, int max_nseg, int L, int batch, unsigned int* counter,
+                             unsigned int* flags, unsigned int* abort_word, unsigned int epoch, hipStream_t stream);
+
 // Library DEFAULT of the main-loop selection (what CTTS_GEMM_DEFAULT resolves to), in the config structs' own encoding:
 // CTTS_GEMM_F32 (initially), CTTS_GEMM_BF16X3 (three bf16 MFMA products per fp32 operand pair, see
 // conv_gemm_f32_kernel<..., X3>) or CTTS_GEMM_BF16X6.  ctts_set_f32_gemm_mode (deprecated: prefer the per-model field).
 int set_gemm_f32_mode(int mode);
 int get_gemm_f32_mode();
-// what the calling thread's most recent conv-GEMM launch ran (ctts_last_gemm_loop): bits 0-3 split level, 16 small shape, 32 split-K
+// what the calling thread's most recent conv-GEMM launch ran (ctts_last_gemm_loop): bits 0-3 split level, 16 small shape, 32 split-K, 64 row-persistent queue
 void note_gemm_loop(int code);
 int last_gemm_loop();
 // true when a launch with this GemmArgs.gemm_mode / config f32_gemm_mode runs the split-bf16 main loop

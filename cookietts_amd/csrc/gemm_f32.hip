@@ -746,6 +746,10 @@ void load_tuning_locked() {
     g_tune.taco_no_fuse = on("CTTS_TACO_NO_FUSE");
     g_tune.wf_no_vec_interp = on("CTTS_WF_NO_VEC_INTERP");
     g_tune.wf_no_region_split = on("CTTS_WF_NO_REGION_SPLIT");
+    g_tune.wf_no_row_queue = on("CTTS_WF_NO_ROW_QUEUE");
+    g_tune.wf_row_queue_min = num("CTTS_WF_ROW_QUEUE_MIN", -1);
+    g_tune.wf_inject_abort = num("CTTS_WF_INJECT_ABORT", 0);
+    g_tune.wf_queue_debug = num("CTTS_WF_QUEUE_DEBUG", 0);
     g_tune.f32_no_defer_skip = on("CTTS_F32_NO_DEFER_SKIP");
     g_tune.w4_debug = num("CTTS_BF16_W4_DEBUG", 0);
     g_tune_loaded = true;

@@ -16,6 +16,7 @@
 //     shape: results are bit-identical (tests/test_conv1d_primitive.py, test_waveglow_ax.py).
 //   * Staging: global -> LDS DMA (16 B per lane, per-lane source addresses: the A half is 16 runs of 512 B), three
 //     stages, two chunks ahead, three DMA pieces per chunk per wave, counted vmcnt + s_barrier.
+#include <algorithm>
 #include <mutex>
 
 #include "gemm_f32.h"
@@ -504,18 +505,33 @@ constexpr int R_STAGE = GEMM_KC * (S_BM + R_BN);         // 4096 floats = 16 KiB
 constexpr int R_SEGTAB = S_NST * R_STAGE;
 constexpr int R_CHTAB = R_SEGTAB + GEMM_MAX_SEG * 4;
 constexpr int R_LDS_FLOATS = R_CHTAB + 2 * S_MAX_CHUNKS;
+constexpr int R_AUX_SC1 = 16;                            // cache-policy immediate of the DMA builtin: sc1 (agent scope)
 static_assert(64 * 128 + 128 <= S_NST * R_STAGE, "the res/skip weights are staged over the main loop's stages");
 
-template <int SEGS>
-__global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_small_kernel(const GemmArgs a, const int ntiles_s) {
+// One 128 x 128 tile (column tile `tile` of batch item `b`).  FRESH = false: the body of the per-layer launch.  FRESH = true: the
+// tile is an item of wf_row_persistent_kernel below, where OTHER workgroups of the SAME launch - possibly on another XCD, whose
+// L2 is not coherent with this one - produced part of what it reads and will read what it writes:
+//   * segments marked GemmSeg.fresh, the residual source and the skip accumulator are read at agent scope (sc1: served by the
+//     memory side, never by a line this XCD's L2 or this CU's L1 kept from an earlier layer),
+//   * the results are stored at agent scope (write-through); the caller's release fence + flag make them visible.
+// Everything else (weights, the ring slots of earlier rows, the conditioning) was written by earlier launches and is read as before.
+// (ARGS: `const GemmArgs` in the kernel-argument segment, or the same struct in the constant address space when the descriptor is
+// read from memory - then every field is a scalar load; pointers that come out of memory are generic to the compiler, so each
+// one that is dereferenced is cast to the global address space: a flat load would also count on lgkmcnt and break the
+// counted LDS waits of the main loop)
+typedef __attribute__((address_space(1))) float* r_gptr;
+typedef const __attribute__((address_space(1))) float* r_cgptr;
+__device__ __forceinline__ float r_load_old(r_cgptr p, bool fresh) {
+    return fresh ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <int SEGS, bool FRESH, class ARGS>
+__device__ __forceinline__ void gate_rs_small_tile(ARGS& a, const int tile, const int b) {
     __shared__ __attribute__((aligned(16))) float lds[R_LDS_FLOATS];
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wn = wave;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int tile = blockIdx.x % ntiles_s;
-    const int b = blockIdx.x / ntiles_s;
     const int n0 = tile * R_BN;
 
     // Everything the epilogue needs from memory is requested at kernel ENTRY (a batch-1 launch is one wave per SIMD: each
@@ -531,25 +547,25 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_small_kernel(con
         for (int mt = 0; mt < 4; ++mt) {
             const int rbase = mt * 32;
             const bool second = rbase >= a.split;
-            const float* dstc = second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride;
-            const float* src = second ? dstc : (a.src0 ? a.src0 + (size_t)b * a.src0_bstride : dstc);
+            const r_cgptr dstc = (r_cgptr)(second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride);
+            const r_cgptr src = second ? dstc : (a.src0 ? (r_cgptr)(a.src0 + (size_t)b * a.src0_bstride) : dstc);
             const int accum = second ? a.acc1 : a.acc0;
             const int rdst = second ? rbase - a.split : rbase;
             if (accum && rbase < a.rs_rows) {       // one unconditional form; rows / columns past the end re-read the last one
-                const float* sp = src + (size_t)rdst * a.dst_ld + a.dst_pad + min(n_, a.L - 1);
+                const r_cgptr sp = src + (size_t)rdst * a.dst_ld + a.dst_pad + min(n_, a.L - 1);
                 const int rlast = a.rs_rows - 1 - rbase;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) old[mt][r] = sp[(size_t)min((r & 3) + 8 * (r >> 2) + 4 * lhi, rlast) * a.dst_ld];
+                for (int r = 0; r < 16; ++r) old[mt][r] = r_load_old(sp + (size_t)min((r & 3) + 8 * (r >> 2) + 4 * lhi, rlast) * a.dst_ld, FRESH);
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) old[mt][r] = 0.0f;
             }
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) rsw[k] = *reinterpret_cast<const r_f32x4*>(a.rs_wT + t * 4 + k * 1024);
+        for (int k = 0; k < 8; ++k) rsw[k] = *reinterpret_cast<const __attribute__((address_space(1))) r_f32x4*>((r_cgptr)a.rs_wT + t * 4 + k * 1024);
     }
-    const float bias_pre = t < S_BM ? a.bias[t] : 0.0f;
-    const float rsb_pre = t < 128 ? a.rs_bias[t] : 0.0f;
+    const float bias_pre = t < S_BM ? ((r_cgptr)a.bias)[t] : 0.0f;
+    const float rsb_pre = t < 128 ? ((r_cgptr)a.rs_bias)[t] : 0.0f;
 
     const int nalloc = a.a_nch_alloc ? a.a_nch_alloc : a.nch_total;
     // A: the [16][128] chunk of the bm = 128 packing, copied linearly: piece p of this wave = floats [wave * 256 + p * 1024, +256)
@@ -558,7 +574,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_small_kernel(con
     // B: [16][128] stage, piece p of this wave = k-row 2 wave + 8 p + (lane >> 5), columns 4 (lane & 31)
     const size_t b_off = (size_t)(2 * wave + (lane >> 5)) * a.ld + (lane & 31) * 4;
     const size_t b_piece = (size_t)8 * a.ld;
-    const unsigned long long* ctab = reinterpret_cast<const unsigned long long*>(lds + R_CHTAB);
 
     f32x16 acc[4];
 #pragma unroll
@@ -569,35 +584,34 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_small_kernel(con
 #define R_ISSUE_A(buf, c, p)                                                                                     \
     __builtin_amdgcn_global_load_lds(a_base + (size_t)(c) * S_ASTAGE + (p) * 1024,                                \
                                      (lds_fptr)(lds + (buf) * R_STAGE + wave * 256 + (p) * 1024), 16, 0, 0)
-#define R_ISSUE_B(buf, c, p)                                                                                     \
-    do {                                                                                                         \
-        const unsigned long long ub_ = ctab[c];                                                                  \
-        const unsigned long long us_ =                                                                           \
-            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |             \
-            (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                                  \
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off + (p) * b_piece,              \
-                                         (lds_fptr)(lds + (buf) * R_STAGE + S_ASTAGE + wave * 256 + (p) * 1024), 16, 0, 0); \
-    } while (0)
-
+    // a table entry = address of the chunk's B rows | (FRESH: bit 0 = the segment is marked fresh -> sc1 DMA); addresses are
+    // 4-byte aligned, so the bit is free
 #define R_ISSUE_B_AT(buf, ub, p)                                                                                 \
     do {                                                                                                         \
         const unsigned long long ub_ = (ub);                                                                     \
+        const unsigned lo_ = (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                 \
         const unsigned long long us_ =                                                                           \
             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |             \
-            (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                                  \
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off + (p) * b_piece,              \
-                                         (lds_fptr)(lds + (buf) * R_STAGE + S_ASTAGE + wave * 256 + (p) * 1024), 16, 0, 0); \
+            (FRESH ? (lo_ & ~1u) : lo_);                                                                         \
+        if (FRESH && (lo_ & 1u))                                                                                 \
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off + (p) * b_piece,          \
+                                             (lds_fptr)(lds + (buf) * R_STAGE + S_ASTAGE + wave * 256 + (p) * 1024), 16, 0, R_AUX_SC1); \
+        else                                                                                                     \
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off + (p) * b_piece,          \
+                                             (lds_fptr)(lds + (buf) * R_STAGE + S_ASTAGE + wave * 256 + (p) * 1024), 16, 0, 0); \
     } while (0)
     // chunks 0 and 1 before the tables are built (as in conv_gemm_f32_small_kernel)
     const int nch = a.nch_total;
     {
-        const GemmSeg& g0 = a.seg[0];
-        const GemmSeg& g1 = a.seg[1];
+        const auto& g0 = a.seg[0];
+        const auto& g1 = a.seg[1];
         const float* sb0 = g0.base + (size_t)b * g0.bstride + (a.pad + n0 + g0.shift);
         const float* sb1 = g1.base + (size_t)b * g1.bstride + (a.pad + n0 + g1.shift);
         const float* c1p = nch <= 1 ? sb0 : a.interleave > 1 ? sb1 : g0.nch > 1 ? sb0 + (size_t)GEMM_KC * a.ld : sb1;
         const int c1 = nch > 1 ? 1 : 0;
-        const unsigned long long u0 = reinterpret_cast<unsigned long long>(sb0), u1 = reinterpret_cast<unsigned long long>(c1p);
+        const bool c1_is_seg1 = nch > 1 && (a.interleave > 1 || g0.nch <= 1);
+        const unsigned long long u0 = reinterpret_cast<unsigned long long>(sb0) | (FRESH && g0.fresh ? 1u : 0u),
+                                 u1 = reinterpret_cast<unsigned long long>(c1p) | (FRESH && (c1_is_seg1 ? g1.fresh : g0.fresh) ? 1u : 0u);
         R_ISSUE_A(0, 0, 0); R_ISSUE_A(0, 0, 1); R_ISSUE_B_AT(0, u0, 0); R_ISSUE_B_AT(0, u0, 1);
         R_ISSUE_A(1, c1, 0); R_ISSUE_A(1, c1, 1); R_ISSUE_B_AT(1, u1, 0); R_ISSUE_B_AT(1, u1, 1);
     }
@@ -605,16 +619,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_small_kernel(con
 #pragma unroll
     for (int sidx = 0; sidx < GEMM_MAX_SEG; ++sidx) {
         if (sidx < SEGS && t == sidx) {
-            const GemmSeg& g = a.seg[sidx];
+            const auto& g = a.seg[sidx];
             unsigned int* e = reinterpret_cast<unsigned int*>(lds + R_SEGTAB + sidx * 4);
             if (sidx < a.nseg) {
                 const float* base = g.base + (size_t)b * g.bstride + (a.pad + n0 + g.shift);
                 const unsigned long long u = reinterpret_cast<unsigned long long>(base);
                 e[0] = (unsigned int)u; e[1] = (unsigned int)(u >> 32); e[2] = (unsigned int)g.nch;
+                e[3] = FRESH && g.fresh ? 1u : 0u;
             } else {
-                e[0] = 0; e[1] = 0; e[2] = 0x7fffffffu;
+                e[0] = 0; e[1] = 0; e[2] = 0x7fffffffu; e[3] = 0;
             }
-            e[3] = 0;
         }
     }
     __syncthreads();
@@ -638,7 +652,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_small_kernel(con
             }
             const unsigned int* e = reinterpret_cast<const unsigned int*>(lds + R_SEGTAB + sg * 4);
             const unsigned long long base = ((unsigned long long)e[1] << 32) | e[0];
-            tab[c0] = base + (unsigned long long)loc * GEMM_KC * a.ld * sizeof(float);
+            tab[c0] = (base + (unsigned long long)loc * GEMM_KC * a.ld * sizeof(float)) | e[3];
         }
     }
     __syncthreads();
@@ -725,7 +739,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_small_kernel(con
             float u0 = acc[mt][r] + lds[mt * 32 + row];
             float u1 = acc[mt + 2][r] + lds[64 + mt * 32 + row];
             if (a.addend) {                                // uniform; columns >= L of a padded row are readable
-                const float* ad = a.addend + (size_t)b * a.addend_bstride + a.addend_pad + n;
+                const r_cgptr ad = (r_cgptr)a.addend + (size_t)b * a.addend_bstride + a.addend_pad + n;
                 const int c = min(mt * 32 + row, a.pairC - 1);
                 u0 += ad[(size_t)c * a.addend_ld];
                 u1 += ad[(size_t)(a.pairC + c) * a.addend_ld];
@@ -757,19 +771,108 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_small_kernel(con
         const int rbase = mt * 32;
         if (rbase >= a.rs_rows) continue;
         const bool second = rbase >= a.split;
-        float* dst = second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride;
+        const r_gptr dst = (r_gptr)(second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride);
         const int rdst = second ? rbase - a.split : rbase;
         if (n < a.L) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 const float v = acc[mt][r] + rbias[rbase + row] + old[mt][r];
-                if (rbase + row < a.rs_rows) dst[(size_t)(rdst + row) * a.dst_ld + a.dst_pad + n] = v;
+                if (rbase + row < a.rs_rows) {
+                    const r_gptr dp = dst + (size_t)(rdst + row) * a.dst_ld + a.dst_pad + n;
+                    if constexpr (FRESH) __hip_atomic_store(dp, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else *dp = v;
+                }
             }
         }
     }
 }
 
+template <int SEGS>
+__global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_small_kernel(const GemmArgs a, const int ntiles_s) {
+    gate_rs_small_tile<SEGS, false, const GemmArgs>(a, blockIdx.x % ntiles_s, blockIdx.x / ntiles_s);
+}
+
+// ---- WaveFlow row step as ONE launch: the fused layers of a row free-run through a work queue ---------------------------
+//   A row of the WaveFlow recurrence is n_layers dependent fused layers; launched one by one, every layer
+// waits for the slowest workgroup of the one before it, although tile t of layer i + 1 only needs tiles t - 1, t, t + 1 of
+// layer i (|column shift| <= 128 = one tile).  Here the row is ONE launch of resident workgroups that take ITEMS (layer, batch
+// item, tile) from an atomic counter in layer-major order and run gate_rs_small_tile on each:
+//   * an item waits for the <= 3 flags of its neighbours in the previous layer ({epoch} words, written at agent scope after a
+//     release fence), computes, stores at agent scope, releases its own flag;
+//   * items are CLAIMED IN ORDER and every dependency of an item precedes it in that order, so the oldest unfinished item can
+//     always run: no co-residency requirement, no deadlock by construction.  The wait is bounded all the same (s_memrealtime):
+//     on expiry the abort word is set, every workgroup leaves, the host API reports it (and poisons the output);
+//   * with 2 workgroups per CU and ~900 items per layer the dependencies of a freshly claimed item are one whole layer of items
+//     behind the running window: nobody waits, the CUs never drain between layers, and a CU that is faster simply takes more
+//     items (the per-layer launch quantises 456 blocks on 512 slots).
+// Same tile body, same chunk order: bit-identical to the per-layer launches (tests/test_waveflow.py, test_full_size.py).
+struct WfRowArgs {
+    const GemmArgs* layers;            // [nlayers] in device memory
+    int nlayers, ntiles_s, batch;
+    unsigned int* counter;             // this launch's item counter (zeroed by the host at the start of the call)
+    unsigned int* flags;               // [nlayers][batch][ntiles_s], value = epoch of the launch that last finished the item
+    unsigned int* abort_word;          // != 0: a bounded wait expired somewhere in this call
+    unsigned int epoch;                // > 0, unique per launch within a call
+    unsigned int timeout_ticks;        // of s_memrealtime (100 MHz)
+    int debug;                         // CTTS_WF_QUEUE_DEBUG (diagnosis only): 1 no dependency waits, 2 no tile body
+};
+
+template <int SEGS>
+__global__ __launch_bounds__(256, 2) void wf_row_persistent_kernel(const WfRowArgs w) {
+    __shared__ int s_item, s_abort;
+    const int t = threadIdx.x;
+    const int per_layer = w.ntiles_s * w.batch, total = w.nlayers * per_layer;
+    // ONE `t == 0` region per iteration, between two barriers, and every branch that contains a barrier on a readfirstlane'd
+    // (provably uniform) value: with the claim at the top of the loop and the flag store at its bottom the compiler threaded
+    // the two `t == 0` regions together across the back edge and lane 0 left the loop's barriers to the other 63 lanes of its
+    // wave - the launch never ended (first version of this kernel, profiles/HISTORY.md round 4)
+    auto claim = [&]() -> int {
+        return __hip_atomic_load(w.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0
+                   ? total
+                   : (int)__hip_atomic_fetch_add(w.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (t == 0) { s_abort = 0; s_item = claim(); }
+    __syncthreads();
+    for (;;) {
+        const int q = __builtin_amdgcn_readfirstlane(s_item);
+        if (q >= total) break;
+        const int layer = q / per_layer, rem = q - layer * per_layer;
+        const int b = rem / w.ntiles_s, tile = rem - b * w.ntiles_s;
+        if (layer > 0 && t < 3 && !(w.debug & 1)) {
+            const int tt = tile + t - 1;
+            if (tt >= 0 && tt < w.ntiles_s) {
+                const unsigned int* f = w.flags + (size_t)(layer - 1) * per_layer + b * w.ntiles_s + tt;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                for (unsigned spins = 0; __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != w.epoch; ++spins) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if ((spins & 63u) == 63u) {
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > w.timeout_ticks) {
+                            __hip_atomic_store(w.abort_word, 1u + (unsigned)layer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            s_abort = 1;
+                            break;
+                        }
+                        if (__hip_atomic_load(w.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { s_abort = 1; break; }
+                    }
+                }
+            }
+        }
+        __syncthreads();                                   // dependencies met
+        if (__builtin_amdgcn_readfirstlane(s_abort)) break;
+        if (!(w.debug & 2)) {
+            typedef const __attribute__((address_space(4))) GemmArgs const_args;     // scalar loads of the descriptor
+            gate_rs_small_tile<SEGS, true, const_args>(*((const_args*)w.layers + layer), tile, b);
+        }
+        if (w.debug & 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");    // this thread's stores are visible to the agent ...
+        __syncthreads();                                   // ... for every thread of the item; the LDS is free; s_item has been read
+        if (t == 0) {
+            __hip_atomic_store(w.flags + (size_t)layer * per_layer + rem, w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_item = claim();
+        }
+        __syncthreads();
+    }
+}
 
 // ---- fused WaveFlow layer (GEMM_EPI_GATE_RS), split-K shape for batch 1-2 -----------------------------------------------
 // At batch 1 the 128 x 128 shape above is 113 workgroups with one wave per SIMD: fewer than half of the CUs work, and a
@@ -1147,6 +1250,45 @@ int launch_gemm_f32_small(int epi, const GemmArgs& a, hipStream_t stream) {
     }
     note_gemm_loop(16 | gemm_split_level(a.gemm_mode));
     CTTS_CHECK_LAUNCH("conv_gemm_f32_small");
+    return CTTS_OK;
+}
+
+// ---- WaveFlow row step as one launch (wf_row_persistent_kernel) -------------------------------------------------------------
+bool wf_row_persistent_supported(const GemmArgs& a) {
+    if (!(a.bm == 128 && a.MB == 1 && a.gate == GATE_GTU && a.pairC <= 64 && a.rs_wT && a.rs_bias)) return false;
+    if (a.nch_total > S_MAX_CHUNKS || gemm_mode_is_split(a.gemm_mode)) return false;
+    const Tuning tune = tuning();
+    return !(tune.f32_no_glds || tune.f32_no_small);
+}
+
+int wf_row_tiles(int L) { return (L + R_BN - 1) / R_BN; }
+
+int launch_wf_row_persistent(const GemmArgs* layers_dev, int nlayers, int max_nseg, int L, int batch, unsigned int* counter,
+                             unsigned int* flags, unsigned int* abort_word, unsigned int epoch, hipStream_t stream) {
+    WfRowArgs w{};
+    w.layers = layers_dev; w.nlayers = nlayers; w.ntiles_s = wf_row_tiles(L); w.batch = batch;
+    w.counter = counter; w.flags = flags; w.abort_word = abort_word; w.epoch = epoch;
+    w.timeout_ticks = 50u * 1000u * 1000u;                              // 0.5 s: a whole call is ~0.2 s
+    w.debug = tuning().wf_queue_debug;
+    CTTS_CHECK_ARG(layers_dev && counter && flags && abort_word && epoch > 0 && nlayers >= 1 && batch >= 1 && w.ntiles_s >= 1,
+                   "waveflow row launch: bad argument");
+    // two resident workgroups per CU; fewer items than that: one workgroup per item of a layer would still leave most of them
+    // waiting, so never more workgroups than items of TWO layers
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        CTTS_CHECK_HIP(hipGetDevice(&dev));
+        CTTS_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const long long items = (long long)nlayers * w.ntiles_s * batch;
+    const long long want = std::min<long long>(2ll * n_cu, std::min<long long>(items, 2ll * w.ntiles_s * batch));
+    const dim3 grid((unsigned)std::max<long long>(want, 1));
+    if (max_nseg <= 4) hipLaunchKernelGGL((wf_row_persistent_kernel<4>), grid, dim3(256), 0, stream, w);
+    else hipLaunchKernelGGL((wf_row_persistent_kernel<GEMM_MAX_SEG>), grid, dim3(256), 0, stream, w);
+    note_gemm_loop(16 | 64);
+    CTTS_CHECK_LAUNCH("wf_row_persistent");
     return CTTS_OK;
 }
 

@@ -151,7 +151,13 @@ int make_wf_geom(const WfPlan& p, int samples, WfGeom& g) {
     return CTTS_OK;
 }
 
-struct WfWs { float *rows, *mel_up, *cond_up, *dwout, *X, *act, *out; size_t total, xslot, cond_slot; };
+// Row queue (wf_row_persistent_kernel): control words + the layer descriptors of one flow, inside the caller's workspace
+struct WfQueueWs {
+    unsigned int *abort_word, *counters, *flags;     // [1] | [n_flows * n_group] | [n_layers][batch][tiles of 128 columns]
+    GemmArgs* layers;                                // [n_group][n_layers] of the flow being run
+    size_t control_bytes;                            // abort word .. end of the flags: zeroed at the start of every call
+};
+struct WfWs { float *rows, *mel_up, *cond_up, *dwout, *X, *act, *out; size_t total, xslot, cond_slot; WfQueueWs q; };
 
 void wf_carve(const WfPlan& p, const WfGeom& g, int batch, float* base, WfWs& w) {
     size_t o = 0;
@@ -166,6 +172,16 @@ void wf_carve(const WfPlan& p, const WfGeom& g, int batch, float* base, WfWs& w)
     w.X = take(w.xslot * p.c.n_layers * p.ring);
     w.act = take(B * p.C * g.ld);
     w.out = take(B * p.C * g.ld);
+    {
+        const size_t n_count = (size_t)p.c.n_flows * p.c.n_group, n_flags = (size_t)p.c.n_layers * B * wf_row_tiles(g.L);
+        const size_t control = align_up(ALIGN_F + n_count + n_flags);                       // in 4-byte words
+        float* c = take(control);
+        w.q.abort_word = reinterpret_cast<unsigned int*>(c);
+        w.q.counters = c ? w.q.abort_word + ALIGN_F : nullptr;
+        w.q.flags = c ? w.q.counters + n_count : nullptr;
+        w.q.control_bytes = control * sizeof(float);
+        w.q.layers = reinterpret_cast<GemmArgs*>(take(((size_t)p.c.n_group * p.c.n_layers * sizeof(GemmArgs) + 3) / 4));
+    }
     w.total = o;
 }
 
@@ -586,6 +602,17 @@ constexpr int WF_TILE = 256;          // columns per region unit: every launch s
 #define WF_NBIG 2                     // big regions per layer (2: A | M | B on three streams)
 #endif
 constexpr int WF_NREG = 2 * WF_NBIG - 1;     // regions incl. the one-tile separators: big 0, sep 0, big 1, sep 1, ...
+// the row queue is taken from this many 128-column items per layer on (below: the split-K / small per-layer shapes)
+#ifndef WF_ROW_QUEUE_MIN_ITEMS
+#define WF_ROW_QUEUE_MIN_ITEMS 300
+#endif
+// audio[b][:] = NaN when the row queue's abort word is set
+__global__ void wf_abort_poison_kernel(const unsigned int* __restrict__ abort_word, float* __restrict__ audio, long long n) {
+    if (*abort_word == 0) return;
+    float* a = audio + (size_t)blockIdx.x * n;
+    for (long long i = threadIdx.x; i < n; i += 256) a[i] = __builtin_nanf("");
+}
+
 struct WfRegionStreams {              // per host thread: one helper stream per region but the first + double-buffered events
     hipStream_t st[WF_NREG] = {};
     hipEvent_t fork = nullptr, ev[WF_NREG][2] = {};
@@ -707,6 +734,24 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
     // three launches + six event operations per layer make the call host-bound: measured 38.7 -> 78 ms at batch 1)
     rsplit.on = fuse && !tuning().wf_no_region_split && g.ntiles >= 8 && (long long)g.ntiles * batch >= WF_SPLIT_MIN_BLOCKS && !tuning().f32_force_small;
     rsplit.ntiles = g.ntiles; rsplit.L = L;
+    // Row queue (round 4, gemm_f32_small.hip wf_row_persistent_kernel): the fused layers of a row as ONE launch whose workgroups take
+    // (layer, tile) items in order and wait for the three neighbouring tiles of the previous layer only.  Same tile body as the
+    // per-layer 128 x 128 shape: bit-identical to it (and to the 128 x 256 shape).  Descriptors: the GemmArgs of a whole flow are
+    // built on the host, copied once per flow, and a row's launch points at its slice.
+    const int q_items = wf_row_tiles(L) * batch;
+    const int q_min = tuning().wf_row_queue_min >= 0 ? tuning().wf_row_queue_min : WF_ROW_QUEUE_MIN_ITEMS;
+    bool queue_on = fuse && !p.sep && !tuning().wf_no_row_queue && q_items >= q_min;
+    for (int i = 0; i < p.c.n_layers && queue_on; ++i)      // a fresh segment may reach one 128-column tile to either side
+        queue_on = (kw / 2) * (p.c.dilation_w[i] > 0 ? p.c.dilation_w[i] : 1 << i) <= 128;
+    std::vector<GemmArgs> q_layers;
+    unsigned int q_launch = 0;
+    if (queue_on) {
+        CTTS_CHECK_HIP(hipMemsetAsync(w.q.abort_word, 0, w.q.control_bytes, s));
+        if (tuning().wf_inject_abort) {
+            const unsigned int one = 1;
+            CTTS_CHECK_HIP(hipMemcpyAsync(w.q.abort_word, &one, sizeof(one), hipMemcpyHostToDevice, s));
+        }
+    }
     const bool sep_fuse = p.sep_fused() && !no_fuse;
     // un-mix of flow k on the active rows: PermuteHeight composes into the map, the 1x1 conv is a pass over the rows
     auto unmix = [&](int k) -> int {
@@ -723,9 +768,67 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
         return CTTS_OK;
     };
 
+    // the fused dense layer (no depthwise stage) of flow f, row r, layer i - the ONE place its launch arguments are made, for the
+    // per-layer launches, the region split and the row queue alike
+    auto fused_args = [&](const WfPlan::Flow& f, int r, int i, bool mark_fresh) {
+        const int dw = p.c.dilation_w[i] > 0 ? p.c.dilation_w[i] : 1 << i;
+        const bool merge = p.c.merge_res_skip != 0;
+        const int si = merge ? 0 : i, slot = r % NS;
+        const int dh = p.dh(i);
+        const int a_min = std::max(0, kh - 1 - r / dh);
+        GemmArgs a{};
+        a.gate = p.c.gated_unit;
+        a.gemm_mode = p.c.f32_gemm_mode;
+        a.bm = WF_BM;
+        a.ld = g.ld; a.pad = g.pad; a.L = L; a.ntiles = g.ntiles; a.batch = batch;
+        a.dst_ld = g.ld; a.dst_pad = g.pad;
+        a.A = blob + f.in_A[i]; a.bias = blob + f.in_b[i];
+        a.a_nch_alloc = p.nch_in;
+        a.MB = p.in_mb(); a.M = 2 * C; a.pairC = C;
+        int ns = 0;
+        a.a_ch_off = a_min * kw * p.nch_c;
+        for (int ah = a_min; ah < gkh; ++ah) {
+            const int src_row = r - (kh - 1 - ah) * dh;
+            // the current row's slot of layer i > 0 is what layer i - 1 of this very row wrote
+            const int fresh = mark_fresh && src_row == r && si > 0 ? 1 : 0;
+            for (int j = 0; j < gkw; ++j)
+                a.seg[ns++] = {X(si, src_row % NS), cstride, p.nch_c, (j - kw / 2) * dw, 0, fresh};
+        }
+        a.nch_total = (kh - a_min) * kw * p.nch_c;
+        if (p.precond) {
+            a.addend = w.cond_up + (size_t)i * w.cond_slot;
+            a.addend_bstride = (long long)2 * C * g.ld;
+        } else {
+            a.seg[ns++] = {w.mel_up, (long long)p.kmel * g.ld, p.kmel / GEMM_KC, 0, 0, 0};
+            a.nch_total += p.kmel / GEMM_KC;
+        }
+        a.nseg = ns;
+        const bool last = i == p.c.n_layers - 1 || merge;       // all rows of the res/skip GEMM are skip rows
+        // x_{i+1}[row r] = x_i[row r] + res -> layer i+1's ring slot;  skip rows (+)= into w.out
+        a.rs_wT = blob + f.rs_T[i]; a.rs_bias = blob + f.rs_Tb[i]; a.rs_rows = p.rs_rows(i);
+        a.dst0 = last ? w.out : X(i + 1, slot); a.dst0_bstride = cstride; a.acc0 = 1;
+        a.src0 = X(si, slot); a.src0_bstride = cstride;
+        a.dst1 = w.out; a.dst1_bstride = cstride; a.acc1 = i > 0 ? 1 : 0;
+        a.split = last ? 0 : C;
+        return a;
+    };
+
     for (int k = p.c.n_flows - 1; k >= 0; --k) {
         const auto& f = p.fl[k];
         if (!p.c.mix_first && (rc = unmix(k))) return rc;                      // ax:324-325
+        int q_max_nseg = 0;
+        if (queue_on) {                                                        // this flow's descriptors, one copy
+            q_layers.clear();
+            for (int r = 0; r < Ga - 1; ++r)
+                for (int i = 0; i < p.c.n_layers; ++i) {
+                    q_layers.push_back(fused_args(f, r, i, !(tuning().wf_queue_debug & 4)));
+                    const GemmArgs& a = q_layers.back();
+                    q_max_nseg = std::max(q_max_nseg, a.nseg);
+                    CTTS_CHECK_ARG(wf_row_persistent_supported(a), "waveflow row queue: layer %d not supported by the tile body", i);
+                }
+            // (pageable source: the copy is staged before the call returns, so the vector can be reused for the next flow)
+            CTTS_CHECK_HIP(hipMemcpyAsync(w.q.layers, q_layers.data(), q_layers.size() * sizeof(GemmArgs), hipMemcpyHostToDevice, s));
+        }
         if (p.precond) {   // this flow's conditioning, upsampled once for all rows and layers
             const float* fr = cond + (size_t)k * batch * 2 * C * p.c.n_layers * cond_ld;
             if (g.pad % 4 == 0 && g.ld % 4 == 0 && w.cond_slot % 4 == 0 && !tuning().wf_no_vec_interp)
@@ -741,6 +844,12 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
             hipLaunchKernelGGL(wf_start_kernel, dim3(((L + 3) / 4 + 255) / 256, (C + 15) / 16, batch), dim3(256), 0, s,
                                w.rows, blob + f.start_w, blob + f.start_b, X(0, slot), C, G, phys[r], L, g.Lr, g.ld, g.pad);
             CTTS_CHECK_LAUNCH("wf_start");
+            if (queue_on) {
+                const unsigned int li = q_launch++;
+                if ((rc = launch_wf_row_persistent(w.q.layers + (size_t)r * p.c.n_layers, p.c.n_layers, q_max_nseg, L, batch,
+                                                   w.q.counters + li, w.q.flags, w.q.abort_word, li + 1, s)))
+                    return rc;
+            } else {
             if (rsplit.on && (rc = rsplit.begin_row(s))) return rc;
             for (int i = 0; i < p.c.n_layers; ++i) {
                 const int dw = p.c.dilation_w[i] > 0 ? p.c.dilation_w[i] : 1 << i;
@@ -809,12 +918,15 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
                 a.nseg = ns;
                 const bool last = i == p.c.n_layers - 1 || merge;       // all rows of the res/skip GEMM are skip rows
                 if (fuse) {
-                    // x_{i+1}[row r] = x_i[row r] + res -> layer i+1's ring slot;  skip rows (+)= into w.out
-                    a.rs_wT = blob + f.rs_T[i]; a.rs_bias = blob + f.rs_Tb[i]; a.rs_rows = p.rs_rows(i);
-                    a.dst0 = last ? w.out : X(i + 1, slot); a.dst0_bstride = cstride; a.acc0 = 1;
-                    a.src0 = X(si, slot); a.src0_bstride = cstride;
-                    a.dst1 = w.out; a.dst1_bstride = cstride; a.acc1 = i > 0 ? 1 : 0;
-                    a.split = last ? 0 : C;
+                    if (!p.sep) a = fused_args(f, r, i, false);
+                    else {
+                        // x_{i+1}[row r] = x_i[row r] + res -> layer i+1's ring slot;  skip rows (+)= into w.out
+                        a.rs_wT = blob + f.rs_T[i]; a.rs_bias = blob + f.rs_Tb[i]; a.rs_rows = p.rs_rows(i);
+                        a.dst0 = last ? w.out : X(i + 1, slot); a.dst0_bstride = cstride; a.acc0 = 1;
+                        a.src0 = X(si, slot); a.src0_bstride = cstride;
+                        a.dst1 = w.out; a.dst1_bstride = cstride; a.acc1 = i > 0 ? 1 : 0;
+                        a.split = last ? 0 : C;
+                    }
                     if (rsplit.on) {
                         if ((rc = rsplit.layer(a, i, s))) return rc;
                         continue;
@@ -841,6 +953,7 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
                 if ((rc = launch_gemm_f32(GEMM_EPI_SPLIT, q, s))) return rc;
             }
             if (rsplit.on && (rc = rsplit.end_row(s))) return rc;
+            }
             hipLaunchKernelGGL(wf_tail_kernel, dim3((g.Lr + 255) / 256, batch), dim3(256), 0, s, w.out, w.rows,
                                blob + f.end_w, blob + f.end_b, C, G, phys[r + 1], L, g.Lr, g.ld, g.pad);
             CTTS_CHECK_LAUNCH("wf_tail");
@@ -860,6 +973,10 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
     for (int i = 0; i < 64; ++i) map.phys[i] = i < G ? phys[i] : 0;
     hipLaunchKernelGGL(wf_unsqueeze_kernel, dim3((L + 255) / 256, batch), dim3(256), 0, s, w.rows, audio, G, L, g.Lr, map);
     CTTS_CHECK_LAUNCH("wf_unsqueeze");
+    if (queue_on) {      // a bounded wait of the row queue expired (never, by construction): the audio is NaN, not plausible noise
+        hipLaunchKernelGGL(wf_abort_poison_kernel, dim3(batch), dim3(256), 0, s, w.q.abort_word, audio, (long long)G * L);
+        CTTS_CHECK_LAUNCH("wf_abort_poison");
+    }
     return CTTS_OK;
 }
 

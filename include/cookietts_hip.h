@@ -643,7 +643,7 @@ int ctts_taco_stop_rule_f32(const float* gate_logits, int32_t batch, int32_t gat
  * the split-K shape sums in a different order than the other shapes, so the same utterance is bit-identical across
  * batch sizes only within one shape.  ctts_last_gemm_loop() reports what the most recent conv-GEMM launch of the calling
  * thread ran, so that a benchmark row can label itself: bits 0-3 = split level (0 fp32 MFMA, 3, 6), bit 4 = small shape,
- * bit 5 = split-K shape.
+ * bit 5 = split-K shape, bit 6 = the WaveFlow row queue (one launch per row, see ctts_waveflow_inverse_f32).
  *
  * DEPRECATED - ctts_set_f32_gemm_mode / ctts_get_f32_gemm_mode: a process-wide default (what CTTS_GEMM_DEFAULT (0) in a
  * config struct resolves to, and the mode of the two entry points without a config struct: ctts_lstm_seq_f32's input
@@ -661,7 +661,8 @@ int ctts_get_f32_gemm_mode(void);
 int ctts_tuning_reload(void);
 /* The knobs as the library currently sees them: bit 0 CTTS_F32_NO_GLDS, 1 CTTS_GEMM_NO_XCD_PAIR, 2 CTTS_BF16_NO_GLDS,
  * 3 CTTS_BF16_NO_WIDE, 4 CTTS_BF16_NO_PP, 5 CTTS_BF16_W4, 6 CTTS_BF16_PP_STAGES=4, 7 CTTS_WF_NO_FUSE, 8 CTTS_TACO_NO_FUSE,
- * 9 CTTS_F32_NO_SMALL, 10 CTTS_F32_FORCE_SMALL, 11 CTTS_F32_NO_SPLITK, 12 CTTS_WF_NO_VEC_INTERP, 13 CTTS_F32_NO_DEFER_SKIP, 14 CTTS_WF_NO_REGION_SPLIT (tests assert that a knob they set is the
+ * 9 CTTS_F32_NO_SMALL, 10 CTTS_F32_FORCE_SMALL, 11 CTTS_F32_NO_SPLITK, 12 CTTS_WF_NO_VEC_INTERP, 13 CTTS_F32_NO_DEFER_SKIP, 14 CTTS_WF_NO_REGION_SPLIT,
+ * 15 CTTS_WF_NO_ROW_QUEUE, 16 CTTS_WF_ROW_QUEUE_MIN set, 17 CTTS_WF_INJECT_ABORT (tests assert that a knob they set is the
  * one in effect). */
 int ctts_tuning_flags(void);
 

@@ -40,7 +40,7 @@ def gemm_loop_label():
     from cookietts_amd import _lib
     code = _lib.lib().ctts_last_gemm_loop()
     loop = {0: "fp32 MFMA", 3: "split-bf16 x3", 6: "split-bf16 x6"}.get(code & 15, f"level {code & 15}")
-    shape = "split-K shape" if code & 32 else "small shape" if code & 16 else "large shape"
+    shape = "row queue (one launch per row), 128 x 128 tiles" if code & 64 else "split-K shape" if code & 32 else "small shape" if code & 16 else "large shape"
     return f"{loop}, {shape}"
 
 

@@ -1,0 +1,75 @@
+"""The WaveFlow row queue (gemm_f32_small.hip ``wf_row_persistent_kernel``): the fused layers of a row as ONE launch whose
+workgroups take (layer, tile) items in order and wait for three neighbouring tiles of the previous layer.  It runs the same
+tile body as the per-layer 128 x 128 shape, so every form must agree BIT FOR BIT; its bounded wait must fail loudly."""
+import numpy as np
+import pytest
+import torch
+
+from cookietts_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _model():
+    from cookietts_amd import WaveFlow
+    cfg = synthetic.WAVEFLOW_CONFIGS["full"]
+    m = WaveFlow(**cfg)
+    m.load_state_dict(synthetic.to_torch(synthetic.waveflow_state_dict(cfg, seed=78)))
+    return m.cuda().eval()
+
+
+def _inputs(B, F, seed):
+    mel = torch.from_numpy(synthetic.synthetic_mel(B, F + 1, seed=seed)).cuda()
+    g = torch.Generator().manual_seed(seed)
+    z = (torch.randn(B, F * 256, generator=g) * 0.6).cuda()
+    return z, mel
+
+
+@pytest.mark.parametrize("B,F", [(1, 120), (3, 333), (8, 240)])
+def test_row_queue_equals_per_layer_launches(hip_lib_path, tuning, B, F):
+    """Queue forced on at every size (ragged last tile at F = 333) vs one launch per layer on the 128 x 128 shape."""
+    from cookietts_amd import _lib
+    m = _model()
+    z, mel = _inputs(B, F, seed=11 + B)
+    tuning.set("CTTS_F32_NO_SPLITK")                       # the split-K shape sums K in another order
+    tuning.set("CTTS_WF_NO_ROW_QUEUE")
+    tuning.set("CTTS_WF_NO_REGION_SPLIT")
+    ref, _ = m.inverse(z, mel, return_CPU=False)
+    assert not _lib.lib().ctts_last_gemm_loop() & 64
+    tuning.clear("CTTS_WF_NO_ROW_QUEUE")
+    tuning.set("CTTS_WF_ROW_QUEUE_MIN", "1")
+    for _ in range(3):                                     # epochs, counters and flags are re-armed per call
+        got, _ = m.inverse(z, mel, return_CPU=False)
+        assert _lib.lib().ctts_last_gemm_loop() & 64, "the row queue did not run"
+        assert torch.isfinite(got).all() and torch.equal(got, ref)
+
+
+def test_row_queue_full_size_default_and_forms(hip_lib_path, tuning):
+    """Config 4 at B = 8 x 900 frames takes the queue by default; region split and single launches give the same bits."""
+    from cookietts_amd import _lib
+    m = _model()
+    z, mel = _inputs(8, 900, seed=5)
+    got, _ = m.inverse(z, mel, return_CPU=False)
+    assert _lib.lib().ctts_last_gemm_loop() & 64
+    tuning.set("CTTS_WF_NO_ROW_QUEUE")
+    split, _ = m.inverse(z, mel, return_CPU=False)
+    assert not _lib.lib().ctts_last_gemm_loop() & 64
+    assert torch.equal(got, split)
+    tuning.set("CTTS_WF_NO_REGION_SPLIT")
+    single, _ = m.inverse(z, mel, return_CPU=False)
+    assert torch.equal(got, single)
+
+
+def test_row_queue_abort_is_loud(hip_lib_path, tuning):
+    """With the abort word set (what an expired wait does) every workgroup leaves and the audio is NaN, not noise; the next
+    call without the injection is clean again."""
+    m = _model()
+    z, mel = _inputs(2, 100, seed=3)
+    tuning.set("CTTS_WF_ROW_QUEUE_MIN", "1")
+    good, _ = m.inverse(z, mel, return_CPU=False)
+    tuning.set("CTTS_WF_INJECT_ABORT")
+    bad, _ = m.inverse(z, mel, return_CPU=False)
+    assert torch.isnan(bad).all()
+    tuning.clear("CTTS_WF_INJECT_ABORT")
+    again, _ = m.inverse(z, mel, return_CPU=False)
+    assert torch.equal(again, good)
