@@ -173,8 +173,11 @@ int launch_gemm_f32_small(int epi, const GemmArgs& a, hipStream_t stream);
 // device memory, exactly what launch_gemm_f32(GEMM_EPI_GATE_RS, ...) would have been given layer by layer, with GemmSeg.fresh
 // set on the segments the previous layer of the same row writes.  Needs |shift| <= 128 on fresh segments.
 bool wf_row_persistent_supported(const GemmArgs& a);
-int wf_row_tiles(int L);                      // 128-column tiles per batch item (the flag array's inner extent)
-int launch_wf_row_persistent(const GemmArgs* layers_dev, int nlayers, int max_nseg, int L, int batch, unsigned int* counter,
+// body 0: items = 128 x 128 tiles (same bits as the 128 x 128 / 128 x 256 per-layer shapes); body 1: 128 x 64 tiles of the split-K
+// shape (same bits as THAT per-layer shape)
+int wf_row_cus();                             // CUs of the current device
+int wf_row_tiles(int L, int body);            // tiles per batch item (the flag array's inner extent)
+int launch_wf_row_persistent(const GemmArgs* layers_dev, int nlayers, int max_nseg, int L, int batch, int body, unsigned int* counter,
                              unsigned int* flags, unsigned int* abort_word, unsigned int epoch, hipStream_t stream);
 
 // Library DEFAULT of the main-loop selection (what CTTS_GEMM_DEFAULT resolves to), in the config structs' own encoding:

@@ -17,6 +17,7 @@
 //   * Staging: global -> LDS DMA (16 B per lane, per-lane source addresses: the A half is 16 runs of 512 B), three
 //     stages, two chunks ahead, three DMA pieces per chunk per wave, counted vmcnt + s_barrier.
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 
 #include "gemm_f32.h"
@@ -793,87 +794,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_small_kernel(con
     gate_rs_small_tile<SEGS, false, const GemmArgs>(a, blockIdx.x % ntiles_s, blockIdx.x / ntiles_s);
 }
 
-// ---- WaveFlow row step as ONE launch: the fused layers of a row free-run through a work queue ---------------------------
-// (VERDICT r3 item 5.)  A row of the WaveFlow recurrence is n_layers dependent fused layers; launched one by one, every layer
-// waits for the slowest workgroup of the one before it, although tile t of layer i + 1 only needs tiles t - 1, t, t + 1 of
-// layer i (|column shift| <= 128 = one tile).  Here the row is ONE launch of resident workgroups that take ITEMS (layer, batch
-// item, tile) from an atomic counter in layer-major order and run gate_rs_small_tile on each:
-//   * an item waits for the <= 3 flags of its neighbours in the previous layer ({epoch} words, written at agent scope after a
-//     release fence), computes, stores at agent scope, releases its own flag;
-//   * items are CLAIMED IN ORDER and every dependency of an item precedes it in that order, so the oldest unfinished item can
-//     always run: no co-residency requirement, no deadlock by construction.  The wait is bounded all the same (s_memrealtime):
-//     on expiry the abort word is set, every workgroup leaves, the host API reports it (and poisons the output);
-//   * with 2 workgroups per CU and ~900 items per layer the dependencies of a freshly claimed item are one whole layer of items
-//     behind the running window: nobody waits, the CUs never drain between layers, and a CU that is faster simply takes more
-//     items (the per-layer launch quantises 456 blocks on 512 slots).
-// Same tile body, same chunk order: bit-identical to the per-layer launches (tests/test_waveflow.py, test_full_size.py).
-struct WfRowArgs {
-    const GemmArgs* layers;            // [nlayers] in device memory
-    int nlayers, ntiles_s, batch;
-    unsigned int* counter;             // this launch's item counter (zeroed by the host at the start of the call)
-    unsigned int* flags;               // [nlayers][batch][ntiles_s], value = epoch of the launch that last finished the item
-    unsigned int* abort_word;          // != 0: a bounded wait expired somewhere in this call
-    unsigned int epoch;                // > 0, unique per launch within a call
-    unsigned int timeout_ticks;        // of s_memrealtime (100 MHz)
-    int debug;                         // CTTS_WF_QUEUE_DEBUG (diagnosis only): 1 no dependency waits, 2 no tile body
-};
-
-template <int SEGS>
-__global__ __launch_bounds__(256, 2) void wf_row_persistent_kernel(const WfRowArgs w) {
-    __shared__ int s_item, s_abort;
-    const int t = threadIdx.x;
-    const int per_layer = w.ntiles_s * w.batch, total = w.nlayers * per_layer;
-    // ONE `t == 0` region per iteration, between two barriers, and every branch that contains a barrier on a readfirstlane'd
-    // (provably uniform) value: with the claim at the top of the loop and the flag store at its bottom the compiler threaded
-    // the two `t == 0` regions together across the back edge and lane 0 left the loop's barriers to the other 63 lanes of its
-    // wave - the launch never ended (first version of this kernel, profiles/HISTORY.md round 4)
-    auto claim = [&]() -> int {
-        return __hip_atomic_load(w.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0
-                   ? total
-                   : (int)__hip_atomic_fetch_add(w.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    if (t == 0) { s_abort = 0; s_item = claim(); }
-    __syncthreads();
-    for (;;) {
-        const int q = __builtin_amdgcn_readfirstlane(s_item);
-        if (q >= total) break;
-        const int layer = q / per_layer, rem = q - layer * per_layer;
-        const int b = rem / w.ntiles_s, tile = rem - b * w.ntiles_s;
-        if (layer > 0 && t < 3 && !(w.debug & 1)) {
-            const int tt = tile + t - 1;
-            if (tt >= 0 && tt < w.ntiles_s) {
-                const unsigned int* f = w.flags + (size_t)(layer - 1) * per_layer + b * w.ntiles_s + tt;
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                for (unsigned spins = 0; __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != w.epoch; ++spins) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if ((spins & 63u) == 63u) {
-                        if (__builtin_amdgcn_s_memrealtime() - t0 > w.timeout_ticks) {
-                            __hip_atomic_store(w.abort_word, 1u + (unsigned)layer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            s_abort = 1;
-                            break;
-                        }
-                        if (__hip_atomic_load(w.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { s_abort = 1; break; }
-                    }
-                }
-            }
-        }
-        __syncthreads();                                   // dependencies met
-        if (__builtin_amdgcn_readfirstlane(s_abort)) break;
-        if (!(w.debug & 2)) {
-            typedef const __attribute__((address_space(4))) GemmArgs const_args;     // scalar loads of the descriptor
-            gate_rs_small_tile<SEGS, true, const_args>(*((const_args*)w.layers + layer), tile, b);
-        }
-        if (w.debug & 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");    // this thread's stores are visible to the agent ...
-        __syncthreads();                                   // ... for every thread of the item; the LDS is free; s_item has been read
-        if (t == 0) {
-            __hip_atomic_store(w.flags + (size_t)layer * per_layer + rem, w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_item = claim();
-        }
-        __syncthreads();
-    }
-}
-
 // ---- fused WaveFlow layer (GEMM_EPI_GATE_RS), split-K shape for batch 1-2 -----------------------------------------------
 // At batch 1 the 128 x 128 shape above is 113 workgroups with one wave per SIMD: fewer than half of the CUs work, and a
 // launch lasts one wave's serial chain of 36 chunks x 32 MFMAs.  A wave must own all <= 64 channels (128 rows) of its 32
@@ -896,16 +816,16 @@ constexpr int K_ACT = 8192;                              //           [2 wn][32]
 constexpr int K_BIAS = 12288;                            //           128 in-layer + 128 res/skip biases
 static_assert(K_BIAS + 256 <= K_NST * K_STAGE, "the epilogue lives in the stage area");
 
-template <int SEGS>
-__global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_splitk_kernel(const GemmArgs a, const int ntiles_s) {
+// (FRESH / ARGS: as gate_rs_small_tile - the tile is an item of the row queue and reads / writes what other workgroups of the same
+// launch write / read)
+template <int SEGS, bool FRESH, class ARGS>
+__device__ __forceinline__ void gate_rs_splitk_tile(ARGS& a, const int tile, const int b) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wn = wave & 1, kh = wave >> 1;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int tile = blockIdx.x % ntiles_s;
-    const int b = blockIdx.x / ntiles_s;
     const int n0 = tile * K_BN;
     const int n = n0 + wn * 32 + l31;
 
@@ -917,39 +837,39 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_splitk_kernel(co
     for (int j = 0; j < 2; ++j) {
         const int rbase = (2 * kh + j) * 32;
         const bool second = rbase >= a.split;
-        const float* dstc = second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride;
-        const float* src = second ? dstc : (a.src0 ? a.src0 + (size_t)b * a.src0_bstride : dstc);
+        const r_cgptr dstc = (r_cgptr)(second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride);
+        const r_cgptr src = second ? dstc : (a.src0 ? (r_cgptr)(a.src0 + (size_t)b * a.src0_bstride) : dstc);
         const int accum = second ? a.acc1 : a.acc0;
         const int rdst = second ? rbase - a.split : rbase;
         if (accum && rbase < a.rs_rows) {
-            const float* sp = src + (size_t)rdst * a.dst_ld + a.dst_pad + min(n, a.L - 1);
+            const r_cgptr sp = src + (size_t)rdst * a.dst_ld + a.dst_pad + min(n, a.L - 1);
             const int rlast = a.rs_rows - 1 - rbase;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) old[j][r] = sp[(size_t)min((r & 3) + 8 * (r >> 2) + 4 * lhi, rlast) * a.dst_ld];
+            for (int r = 0; r < 16; ++r) old[j][r] = r_load_old(sp + (size_t)min((r & 3) + 8 * (r >> 2) + 4 * lhi, rlast) * a.dst_ld, FRESH);
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) old[j][r] = 0.0f;
         }
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) rsw[k] = *reinterpret_cast<const k_f32x4*>(a.rs_wT + t * 4 + k * 1024);
-    const float bias_pre = t < S_BM ? a.bias[t] : 0.0f;
-    const float rsb_pre = t < 128 ? a.rs_bias[t] : 0.0f;
+    for (int k = 0; k < 8; ++k) rsw[k] = *reinterpret_cast<const __attribute__((address_space(1))) k_f32x4*>((r_cgptr)a.rs_wT + t * 4 + k * 1024);
+    const float bias_pre = t < S_BM ? ((r_cgptr)a.bias)[t] : 0.0f;
+    const float rsb_pre = t < 128 ? ((r_cgptr)a.rs_bias)[t] : 0.0f;
 
     // segment table, then chunk -> B address (as in the other shapes)
 #pragma unroll
     for (int sidx = 0; sidx < GEMM_MAX_SEG; ++sidx) {
         if (sidx < SEGS && t == sidx) {
-            const GemmSeg& g = a.seg[sidx];
+            const auto& g = a.seg[sidx];
             unsigned int* e = reinterpret_cast<unsigned int*>(lds + K_SEGTAB + sidx * 4);
             if (sidx < a.nseg) {
                 const float* base = g.base + (size_t)b * g.bstride + (a.pad + n0 + g.shift);
                 const unsigned long long u = reinterpret_cast<unsigned long long>(base);
                 e[0] = (unsigned int)u; e[1] = (unsigned int)(u >> 32); e[2] = (unsigned int)g.nch;
+                e[3] = FRESH && g.fresh ? 1u : 0u;
             } else {
-                e[0] = 0; e[1] = 0; e[2] = 0x7fffffffu;
+                e[0] = 0; e[1] = 0; e[2] = 0x7fffffffu; e[3] = 0;
             }
-            e[3] = 0;
         }
     }
     __syncthreads();
@@ -973,7 +893,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_splitk_kernel(co
             }
             const unsigned int* e = reinterpret_cast<const unsigned int*>(lds + K_SEGTAB + sg * 4);
             const unsigned long long base = ((unsigned long long)e[1] << 32) | e[0];
-            tab[c0] = base + (unsigned long long)loc * GEMM_KC * a.ld * sizeof(float);
+            tab[c0] = (base + (unsigned long long)loc * GEMM_KC * a.ld * sizeof(float)) | e[3];      // bit 0: fresh (sc1 DMA)
         }
     }
     __syncthreads();
@@ -989,11 +909,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_splitk_kernel(co
 #define K_ISSUE_B_AT(cs, ub)                                                                                     \
     do {                                                                                                         \
         const unsigned long long ub_ = (ub);                                                                     \
+        const unsigned lo_ = (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                 \
         const unsigned long long us_ =                                                                           \
             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |             \
-            (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                                  \
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off,                               \
-                                         (lds_fptr)(lds + (cs) * K_CHUNK + S_ASTAGE + wave * 256), 16, 0, 0);    \
+            (FRESH ? (lo_ & ~1u) : lo_);                                                                         \
+        if (FRESH && (lo_ & 1u))                                                                                 \
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off,                           \
+                                             (lds_fptr)(lds + (cs) * K_CHUNK + S_ASTAGE + wave * 256), 16, 0, R_AUX_SC1); \
+        else                                                                                                     \
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off,                           \
+                                             (lds_fptr)(lds + (cs) * K_CHUNK + S_ASTAGE + wave * 256), 16, 0, 0); \
     } while (0)
     const unsigned long long* ctab = reinterpret_cast<const unsigned long long*>(lds + K_CHTAB);
     const int nch = a.nch_total;
@@ -1102,7 +1027,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_splitk_kernel(co
                 float u0 = (acc[mt][r] + red[(mt * 16 + r) * 64]) + lds[K_BIAS + mt * 32 + row];
                 float u1 = (acc[mt + 2][r] + red[((mt + 2) * 16 + r) * 64]) + lds[K_BIAS + 64 + mt * 32 + row];
                 if (a.addend) {                            // uniform; columns >= L of a padded row are readable
-                    const float* ad = a.addend + (size_t)b * a.addend_bstride + a.addend_pad + n;
+                    const r_cgptr ad = (r_cgptr)a.addend + (size_t)b * a.addend_bstride + a.addend_pad + n;
                     const int c = min(mt * 32 + row, a.pairC - 1);
                     u0 += ad[(size_t)c * a.addend_ld];
                     u1 += ad[(size_t)(a.pairC + c) * a.addend_ld];
@@ -1144,16 +1069,119 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_splitk_kernel(co
         const int rbase = (2 * kh + j) * 32;
         if (rbase >= a.rs_rows) continue;
         const bool second = rbase >= a.split;
-        float* dst = second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride;
+        const r_gptr dst = (r_gptr)(second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride);
         const int rdst = second ? rbase - a.split : rbase;
         if (n < a.L) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 const float v = acc2[j][r] + rbias[rbase + row] + old[j][r];
-                if (rbase + row < a.rs_rows) dst[(size_t)(rdst + row) * a.dst_ld + a.dst_pad + n] = v;
+                if (rbase + row < a.rs_rows) {
+                    const r_gptr dp = dst + (size_t)(rdst + row) * a.dst_ld + a.dst_pad + n;
+                    if constexpr (FRESH) __hip_atomic_store(dp, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else *dp = v;
+                }
             }
         }
+    }
+}
+
+template <int SEGS>
+__global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_splitk_kernel(const GemmArgs a, const int ntiles_s) {
+    gate_rs_splitk_tile<SEGS, false, const GemmArgs>(a, blockIdx.x % ntiles_s, blockIdx.x / ntiles_s);
+}
+
+// ---- WaveFlow row step as ONE launch: the fused layers of a row free-run through a work queue ---------------------------
+// (VERDICT r3 item 5.)  A row of the WaveFlow recurrence is n_layers dependent fused layers; launched one by one, every layer
+// waits for the slowest workgroup of the one before it, although tile t of layer i + 1 only needs tiles t - 1, t, t + 1 of
+// layer i (|column shift| <= 128 = one tile).  Here the row is ONE launch of resident workgroups that take ITEMS (layer, batch
+// item, tile) from an atomic counter in layer-major order and run gate_rs_small_tile on each:
+//   * an item waits for the <= 3 flags of its neighbours in the previous layer ({epoch} words, written at agent scope after a
+//     release fence), computes, stores at agent scope, releases its own flag;
+//   * items are CLAIMED IN ORDER and every dependency of an item precedes it in that order, so the oldest unfinished item can
+//     always run: no co-residency requirement, no deadlock by construction.  The wait is bounded all the same (s_memrealtime):
+//     on expiry the abort word is set, every workgroup leaves, the host API reports it (and poisons the output);
+//   * with 2 workgroups per CU and ~900 items per layer the dependencies of a freshly claimed item are one whole layer of items
+//     behind the running window: nobody waits, the CUs never drain between layers, and a CU that is faster simply takes more
+//     items (the per-layer launch quantises 456 blocks on 512 slots).
+// Same tile body, same chunk order: bit-identical to the per-layer launches (tests/test_waveflow.py, test_full_size.py).
+struct WfRowArgs {
+    const GemmArgs* layers;            // [nlayers] in device memory
+    int nlayers, ntiles_s, batch;
+    unsigned int* counter;             // this launch's item counter (zeroed by the host at the start of the call)
+    unsigned int* flags;               // [nlayers][batch][ntiles_s], value = epoch of the launch that last finished the item
+    unsigned int* abort_word;          // != 0: a bounded wait expired somewhere in this call
+    unsigned int epoch;                // > 0, unique per launch within a call
+    unsigned int timeout_ticks;        // of s_memrealtime (100 MHz)
+    int ntiles_k;                      // 64-column tiles per batch item (the split-K body's items)
+    int debug;                         // CTTS_WF_QUEUE_DEBUG (diagnosis only): 1 no dependency waits, 2 no tile body, 8 release fence (L2 write-back), 64 two workgroups per CU at every size
+};
+
+// BODY 0: items are 128 x 128 tiles (gate_rs_small_tile, neighbours t - 1 .. t + 1); BODY 1: 128 x 64 tiles of the split-K body
+// (gate_rs_splitk_tile: half the serial chain per item, twice the items - the sizes at which a layer has fewer items than
+// the chip has workgroup slots; a 128-column shift reaches tiles t - 2 .. t + 2)
+// (Two workgroups per CU.  Three - the 128 x 128 body with every epilogue operand loaded late, 168 registers - gave 168.2 ms at
+// batch 8 against 166.3, and 136 against 100 at batch 4 where a layer has fewer items than slots: profiles/r4_12.)
+template <int SEGS, int BODY>
+__global__ __launch_bounds__(256, 2) void wf_row_persistent_kernel(const WfRowArgs w) {
+    __shared__ int s_item, s_abort;
+    constexpr int HALO = BODY == 1 ? 2 : 1;
+    const int t = threadIdx.x;
+    const int ntiles = BODY == 1 ? w.ntiles_k : w.ntiles_s;
+    const int per_layer = ntiles * w.batch, total = w.nlayers * per_layer;
+    // ONE `t == 0` region per iteration, between two barriers, and every branch that contains a barrier on a readfirstlane'd
+    // (provably uniform) value: with the claim at the top of the loop and the flag store at its bottom the compiler threaded
+    // the two `t == 0` regions together across the back edge and lane 0 left the loop's barriers to the other 63 lanes of its
+    // wave - the launch never ended (first version of this kernel, profiles/HISTORY.md round 4)
+    auto claim = [&]() -> int {
+        return __hip_atomic_load(w.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0
+                   ? total
+                   : (int)__hip_atomic_fetch_add(w.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (t == 0) { s_abort = 0; s_item = claim(); }
+    __syncthreads();
+    for (;;) {
+        const int q = __builtin_amdgcn_readfirstlane(s_item);
+        if (q >= total) break;
+        const int layer = q / per_layer, rem = q - layer * per_layer;
+        const int b = rem / ntiles, tile = rem - b * ntiles;
+        if (layer > 0 && t < 2 * HALO + 1 && !(w.debug & 1)) {
+            const int tt = tile + t - HALO;
+            if (tt >= 0 && tt < ntiles) {
+                const unsigned int* f = w.flags + (size_t)(layer - 1) * per_layer + b * ntiles + tt;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                for (unsigned spins = 0; __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != w.epoch; ++spins) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if ((spins & 63u) == 63u) {
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > w.timeout_ticks) {
+                            __hip_atomic_store(w.abort_word, 1u + (unsigned)layer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            s_abort = 1;
+                            break;
+                        }
+                        if (__hip_atomic_load(w.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { s_abort = 1; break; }
+                    }
+                }
+            }
+        }
+        __syncthreads();                                   // dependencies met
+        if (__builtin_amdgcn_readfirstlane(s_abort)) break;
+        if (!(w.debug & 2)) {
+            typedef const __attribute__((address_space(4))) GemmArgs const_args;     // scalar loads of the descriptor
+            if constexpr (BODY == 1) gate_rs_splitk_tile<SEGS, true, const_args>(*((const_args*)w.layers + layer), tile, b);
+            else gate_rs_small_tile<SEGS, true, const_args>(*((const_args*)w.layers + layer), tile, b);
+        }
+        // Release.  Every result was stored at agent scope (sc1: written THROUGH this XCD's L2), so a store is visible to the
+        // agent once it is acknowledged: vmcnt(0) of every thread, then the barrier, then the flag.  The formal release fence
+        // adds `buffer_wbl2 sc1`, a walk of the whole L2 for dirty lines that are not there: measured 226.9 ms per call with it
+        // against 166.0 without (config 4, B = 8; CTTS_WF_QUEUE_DEBUG=8 brings it back for A/B).
+        if (w.debug & 8) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // ... for every thread of the item; the LDS is free; s_item has been read
+        if (t == 0) {
+            __hip_atomic_store(w.flags + (size_t)layer * per_layer + rem, w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_item = claim();
+        }
+        __syncthreads();
     }
 }
 
@@ -1261,33 +1289,60 @@ bool wf_row_persistent_supported(const GemmArgs& a) {
     return !(tune.f32_no_glds || tune.f32_no_small);
 }
 
-int wf_row_tiles(int L) { return (L + R_BN - 1) / R_BN; }
+int wf_row_cus() {                                  // CUs of the current device (one process per GPU: asked once)
+    static std::atomic<int> n_cu{0};
+    int n = n_cu.load(std::memory_order_relaxed);
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                ? prop.multiProcessorCount : 256;
+        n_cu.store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
 
-int launch_wf_row_persistent(const GemmArgs* layers_dev, int nlayers, int max_nseg, int L, int batch, unsigned int* counter,
+int wf_row_tiles(int L, int body) { return body == 1 ? (L + K_BN - 1) / K_BN : (L + R_BN - 1) / R_BN; }
+
+int launch_wf_row_persistent(const GemmArgs* layers_dev, int nlayers, int max_nseg, int L, int batch, int body, unsigned int* counter,
                              unsigned int* flags, unsigned int* abort_word, unsigned int epoch, hipStream_t stream) {
     WfRowArgs w{};
-    w.layers = layers_dev; w.nlayers = nlayers; w.ntiles_s = wf_row_tiles(L); w.batch = batch;
+    w.layers = layers_dev; w.nlayers = nlayers; w.ntiles_s = wf_row_tiles(L, 0); w.ntiles_k = wf_row_tiles(L, 1); w.batch = batch;
     w.counter = counter; w.flags = flags; w.abort_word = abort_word; w.epoch = epoch;
     w.timeout_ticks = 50u * 1000u * 1000u;                              // 0.5 s: a whole call is ~0.2 s
     w.debug = tuning().wf_queue_debug;
-    CTTS_CHECK_ARG(layers_dev && counter && flags && abort_word && epoch > 0 && nlayers >= 1 && batch >= 1 && w.ntiles_s >= 1,
-                   "waveflow row launch: bad argument");
-    // two resident workgroups per CU; fewer items than that: one workgroup per item of a layer would still leave most of them
-    // waiting, so never more workgroups than items of TWO layers
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        CTTS_CHECK_HIP(hipGetDevice(&dev));
-        CTTS_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    const long long items = (long long)nlayers * w.ntiles_s * batch;
-    const long long want = std::min<long long>(2ll * n_cu, std::min<long long>(items, 2ll * w.ntiles_s * batch));
+    CTTS_CHECK_ARG(layers_dev && counter && flags && abort_word && epoch > 0 && nlayers >= 1 && batch >= 1 && w.ntiles_s >= 1 &&
+                       (body == 0 || body == 1), "waveflow row launch: bad argument");
+    const int n_cu = wf_row_cus();
+    // Two resident workgroups per CU, never more than the items of two layers (the rest could only wait).  A layer of no more
+    // items than CUs gets ONE workgroup per item: a second workgroup on a CU would run the next layer's item next to the
+    // straggler it waits for and halve that one's matrix pipe (config 4, batch 1: 55 ms per call with 2 per CU)
+    const long long per_layer = (long long)(body == 1 ? w.ntiles_k : w.ntiles_s) * batch;
+    long long want = std::min<long long>(2ll * n_cu, std::min<long long>(nlayers * per_layer, 2 * per_layer));
+    if (per_layer <= n_cu && !(w.debug & 64)) want = per_layer;
     const dim3 grid((unsigned)std::max<long long>(want, 1));
-    if (max_nseg <= 4) hipLaunchKernelGGL((wf_row_persistent_kernel<4>), grid, dim3(256), 0, stream, w);
-    else hipLaunchKernelGGL((wf_row_persistent_kernel<GEMM_MAX_SEG>), grid, dim3(256), 0, stream, w);
-    note_gemm_loop(16 | 64);
+    const int vi = max_nseg <= 4 ? 0 : 1;
+    if (body == 1) {
+        constexpr size_t LDS = K_LDS_FLOATS * sizeof(float);            // above the 64 KiB default: opt in once per kernel
+        {
+            static std::mutex mu;
+            static bool attr_set[2] = {false, false};
+            std::lock_guard<std::mutex> lk(mu);
+            if (!attr_set[vi]) {
+                const void* fn = vi == 0 ? reinterpret_cast<const void*>(wf_row_persistent_kernel<4, 1>)
+                                         : reinterpret_cast<const void*>(wf_row_persistent_kernel<GEMM_MAX_SEG, 1>);
+                CTTS_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+                attr_set[vi] = true;
+            }
+        }
+        if (vi == 0) hipLaunchKernelGGL((wf_row_persistent_kernel<4, 1>), grid, dim3(256), LDS, stream, w);
+        else hipLaunchKernelGGL((wf_row_persistent_kernel<GEMM_MAX_SEG, 1>), grid, dim3(256), LDS, stream, w);
+        note_gemm_loop(16 | 32 | 64);
+    } else {
+        if (vi == 0) hipLaunchKernelGGL((wf_row_persistent_kernel<4, 0>), grid, dim3(256), 0, stream, w);
+        else hipLaunchKernelGGL((wf_row_persistent_kernel<GEMM_MAX_SEG, 0>), grid, dim3(256), 0, stream, w);
+        note_gemm_loop(16 | 64);
+    }
     CTTS_CHECK_LAUNCH("wf_row_persistent");
     return CTTS_OK;
 }

@@ -173,7 +173,7 @@ void wf_carve(const WfPlan& p, const WfGeom& g, int batch, float* base, WfWs& w)
     w.act = take(B * p.C * g.ld);
     w.out = take(B * p.C * g.ld);
     {
-        const size_t n_count = (size_t)p.c.n_flows * p.c.n_group, n_flags = (size_t)p.c.n_layers * B * wf_row_tiles(g.L);
+        const size_t n_count = (size_t)p.c.n_flows * p.c.n_group, n_flags = (size_t)p.c.n_layers * B * wf_row_tiles(g.L, 1);
         const size_t control = align_up(ALIGN_F + n_count + n_flags);                       // in 4-byte words
         float* c = take(control);
         w.q.abort_word = reinterpret_cast<unsigned int*>(c);
@@ -602,9 +602,16 @@ constexpr int WF_TILE = 256;          // columns per region unit: every launch s
 #define WF_NBIG 2                     // big regions per layer (2: A | M | B on three streams)
 #endif
 constexpr int WF_NREG = 2 * WF_NBIG - 1;     // regions incl. the one-tile separators: big 0, sep 0, big 1, sep 1, ...
-// the row queue is taken from this many 128-column items per layer on (below: the split-K / small per-layer shapes)
+// The row queue is taken from this many 128-column items per layer on: more than one per CU.  Up to there a layer is one wave's
+// serial chain however it is launched (config 4, batch 1 and 2: 38 / 58 ms per call either way) and the per-layer launches stay.
 #ifndef WF_ROW_QUEUE_MIN_ITEMS
-#define WF_ROW_QUEUE_MIN_ITEMS 300
+#define WF_ROW_QUEUE_MIN_ITEMS 257
+#endif
+#ifndef WF_ROW_QUEUE_MAX_ITEMS
+#define WF_ROW_QUEUE_MAX_ITEMS 1400
+#endif
+#ifndef WF_ROW_QUEUE_SPLITK_BELOW
+#define WF_ROW_QUEUE_SPLITK_BELOW 400
 #endif
 // audio[b][:] = NaN when the row queue's abort word is set
 __global__ void wf_abort_poison_kernel(const unsigned int* __restrict__ abort_word, float* __restrict__ audio, long long n) {
@@ -738,9 +745,18 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
     // (layer, tile) items in order and wait for the three neighbouring tiles of the previous layer only.  Same tile body as the
     // per-layer 128 x 128 shape: bit-identical to it (and to the 128 x 256 shape).  Descriptors: the GemmArgs of a whole flow are
     // built on the host, copied once per flow, and a row's launch points at its slice.
-    const int q_items = wf_row_tiles(L) * batch;
+    const int q_items = wf_row_tiles(L, 0) * batch;
     const int q_min = tuning().wf_row_queue_min >= 0 ? tuning().wf_row_queue_min : WF_ROW_QUEUE_MIN_ITEMS;
-    bool queue_on = fuse && !p.sep && !tuning().wf_no_row_queue && q_items >= q_min;
+    // (upper bound: from ~1400 items per layer on - batch 16 at 900 frames: 326 ms against 319 - the per-layer launches on the
+    // 128 x 256 shape with the region split are ahead again: more work per workgroup, and a layer's tail is small against it)
+    bool queue_on = fuse && !p.sep && !tuning().wf_no_row_queue && q_items >= q_min &&
+                    (q_items < WF_ROW_QUEUE_MAX_ITEMS || tuning().wf_row_queue_min >= 0);
+    // Which tile body (measured, profiles/r4_12): below 400 items of 128 columns per layer the split-K body (items of 128 x 64, half
+    // the serial chain each: 97 -> 77 ms at batch 3 x 900 frames, 95 -> 66 at 8 x 300); the 128 x 128 body from there on
+    int q_body = 0;
+    if (!tuning().f32_no_splitk) q_body = q_items < WF_ROW_QUEUE_SPLITK_BELOW ? 1 : 0;
+    if (tuning().wf_queue_debug & 16) q_body = 0;
+    if (tuning().wf_queue_debug & 32) q_body = 1;
     for (int i = 0; i < p.c.n_layers && queue_on; ++i)      // a fresh segment may reach one 128-column tile to either side
         queue_on = (kw / 2) * (p.c.dilation_w[i] > 0 ? p.c.dilation_w[i] : 1 << i) <= 128;
     std::vector<GemmArgs> q_layers;
@@ -846,7 +862,7 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
             CTTS_CHECK_LAUNCH("wf_start");
             if (queue_on) {
                 const unsigned int li = q_launch++;
-                if ((rc = launch_wf_row_persistent(w.q.layers + (size_t)r * p.c.n_layers, p.c.n_layers, q_max_nseg, L, batch,
+                if ((rc = launch_wf_row_persistent(w.q.layers + (size_t)r * p.c.n_layers, p.c.n_layers, q_max_nseg, L, batch, q_body,
                                                    w.q.counters + li, w.q.flags, w.q.abort_word, li + 1, s)))
                     return rc;
             } else {

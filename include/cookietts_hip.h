@@ -278,7 +278,17 @@ size_t ctts_waveflow_workspace_bytes(const ctts_waveflow_config* cfg, int32_t ba
 /* WaveGlow.inverse(z, cond) of the ax core (efficient_model_ax.py:279-357) for waveflow=True:
  *   z    [B][T] fp32, sigma applied (T multiple of n_group)      mel [B][n_mel][frames] (as passed
  *   to inverse(), i.e. already padded by infer())                audio [B][T]
- * Includes the per-flow NaN -> 0 (ax:333-334).  Workspace zero-filled once before first use. */
+ * Includes the per-flow NaN -> 0 (ax:333-334).  Workspace zero-filled once before first use.
+ *
+ * How a row of the recurrence is launched (C = 64 models; results of the forms agree bit for bit within one tile shape, see
+ * "Which loop a launch really runs" below): one launch per fused layer (small sizes: a layer is one wave's serial chain),
+ * or - from 257 column tiles of 128 per layer on (batch 3 at 900 frames) up to 1400 - the ROW QUEUE: the row's n_layers fused
+ * layers as ONE launch whose workgroups take (layer, tile) items from an atomic counter in order and wait, per item, for the
+ * flags of the neighbouring tiles of the previous layer only.  Items are claimed in order, so the oldest unfinished item can
+ * always run: the launch cannot deadlock and needs no co-residency.  Its wait is bounded all the same (0.5 s); if it ever expires
+ * every workgroup leaves and the call fills `audio` with NaN instead of returning plausible noise (stream-ordered, so the
+ * status code cannot report it).  CTTS_WF_NO_ROW_QUEUE = always one launch per layer.  The queue's control words and layer
+ * descriptors live in the caller's workspace (included in ctts_waveflow_workspace_bytes). */
 int ctts_waveflow_inverse_f32(const ctts_waveflow_config* cfg, const void* packed, const float* z,
                               const float* mel, float* audio, int32_t batch, int32_t samples,
                               int32_t frames, void* workspace, size_t workspace_bytes,
@@ -639,9 +649,10 @@ int ctts_taco_stop_rule_f32(const float* gate_logits, int32_t batch, int32_t gat
  *
  * Which loop a launch really runs also depends on its SHAPE (all of it deterministic in the arguments, none of it in the
  * environment): the fused WaveFlow layer (C = 64) runs the fp32-MFMA split-K shape whenever ntiles * batch <= 128
- * (B <= 2 at 900 frames) under EVERY mode, and the fused separable layer (C = 128) runs fp32 MFMA under CTTS_GEMM_BF16X6;
+ * (B <= 2 at 900 frames) under EVERY mode - and, under fp32 MFMA, as the item body of the row queue while a layer has 257-399
+ * column tiles of 128 (B = 3 at 900 frames) - and the fused separable layer (C = 128) runs fp32 MFMA under CTTS_GEMM_BF16X6;
  * the split-K shape sums in a different order than the other shapes, so the same utterance is bit-identical across
- * batch sizes only within one shape.  ctts_last_gemm_loop() reports what the most recent conv-GEMM launch of the calling
+ * batch sizes only within one shape (CTTS_F32_NO_SPLITK: one K order at every size).  ctts_last_gemm_loop() reports what the most recent conv-GEMM launch of the calling
  * thread ran, so that a benchmark row can label itself: bits 0-3 = split level (0 fp32 MFMA, 3, 6), bit 4 = small shape,
  * bit 5 = split-K shape, bit 6 = the WaveFlow row queue (one launch per row, see ctts_waveflow_inverse_f32).
  *
@@ -655,7 +666,7 @@ int ctts_set_f32_gemm_mode(int32_t mode);
 int ctts_get_f32_gemm_mode(void);
 
 /* Launch-shape overrides for A/B measurements (CTTS_F32_NO_GLDS, CTTS_F32_NO_SMALL, CTTS_F32_FORCE_SMALL, CTTS_GEMM_NO_XCD_PAIR, CTTS_BF16_NO_GLDS / _NO_WIDE /
- * _NO_PP / _W4 / _PP_STAGES, CTTS_WF_NO_FUSE, CTTS_WF_NO_VEC_INTERP, CTTS_TACO_NO_FUSE) never change results beyond the parity
+ * _NO_PP / _W4 / _PP_STAGES, CTTS_WF_NO_FUSE, CTTS_WF_NO_VEC_INTERP, CTTS_WF_NO_REGION_SPLIT, CTTS_WF_NO_ROW_QUEUE, CTTS_TACO_NO_FUSE) never change results beyond the parity
  * tolerance (CTTS_F32_NO_SPLITK changes the summation order of the fused WaveFlow layer at batch <= 2, see above).  The environment is read once,
  * at the first launch; this re-reads it (tests and profiling scripts that flip a knob in-process). */
 int ctts_tuning_reload(void);

@@ -40,7 +40,10 @@ def gemm_loop_label():
     from cookietts_amd import _lib
     code = _lib.lib().ctts_last_gemm_loop()
     loop = {0: "fp32 MFMA", 3: "split-bf16 x3", 6: "split-bf16 x6"}.get(code & 15, f"level {code & 15}")
-    shape = "row queue (one launch per row), 128 x 128 tiles" if code & 64 else "split-K shape" if code & 32 else "small shape" if code & 16 else "large shape"
+    if code & 64:
+        shape = "row queue (one launch per row), " + ("split-K items of 128 x 64" if code & 32 else "items of 128 x 128")
+    else:
+        shape = "split-K shape" if code & 32 else "small shape" if code & 16 else "large shape"
     return f"{loop}, {shape}"
 
 
@@ -59,12 +62,12 @@ def row_waveflow(args):
         samples = B * (F - 1) * 256
         wn = cfg["WN_config"]
         C, G = wn["n_channels"], cfg["n_group"]
-        launches = cfg["n_flows"] * (G - 1) * wn["n_layers"]
         mac = 0.6515e6 * (G - 1) * cfg["n_flows"] / G          # per output sample
         rows.append({"row": "B/config4", "metric": "audio samples/sec (22.05kHz) WaveFlow infer (8 flows, 64 ch, h=16), 80x900 mel",
                      "value": samples / dt, "unit": "samples/s", "rtf": samples / dt / 22050, "ms_per_call": dt * 1e3,
                      "dtype": "f32", "batch": B, "frames": F,
-                     "kernel_launches_per_utterance_batch": launches + 2 * cfg["n_flows"] * (G - 1),
+                     # per row of the recurrence: start + tail + (row queue: ONE launch for the n_layers fused layers | one per layer)
+                     "kernel_launches_per_utterance_batch": (1 if "row queue" in loop else wn["n_layers"]) * cfg["n_flows"] * (G - 1) + 2 * cfg["n_flows"] * (G - 1),
                      "achieved_tflops_algorithmic": 2 * mac * samples / dt / 1e12,
                      "mfma_frac_algorithmic": 2 * mac * samples / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                      "last_gemm_loop": loop,

@@ -21,10 +21,15 @@ print("ms", " ".join("%.1f" % t for t in ts), "loop", _lib.lib().ctts_last_gemm_
 '''
 cases = [tuple(int(x) for x in c.split(":")) for c in sys.argv[1].split(",")]
 for B, F, dbg in cases:
-    env = dict(os.environ, CTTS_WF_QUEUE_DEBUG=str(dbg))
+    # debug >= 0: queue forced, CTTS_WF_QUEUE_DEBUG = debug (+ 1024: CTTS_F32_NO_SPLITK, i.e. the 128 x 128 body at every size);
+    # -1: queue off; -2: library default
+    env = dict(os.environ)
     if dbg >= 0:
         env["CTTS_WF_ROW_QUEUE_MIN"] = "1"
-    else:
+        env["CTTS_WF_QUEUE_DEBUG"] = str(dbg & 1023)
+        if dbg & 1024:
+            env["CTTS_F32_NO_SPLITK"] = "1"
+    elif dbg == -1:
         env["CTTS_WF_NO_ROW_QUEUE"] = "1"
     try:
         p = subprocess.run([sys.executable, "-c", CHILD, str(B), str(F)], env=env, capture_output=True, text=True, timeout=100)

@@ -25,22 +25,26 @@ def _inputs(B, F, seed):
     return z, mel
 
 
-@pytest.mark.parametrize("B,F", [(1, 120), (3, 333), (8, 240)])
-def test_row_queue_equals_per_layer_launches(hip_lib_path, tuning, B, F):
-    """Queue forced on at every size (ragged last tile at F = 333) vs one launch per layer on the 128 x 128 shape."""
+@pytest.mark.parametrize("B,F,splitk", [(1, 120, False), (3, 333, False), (8, 240, False), (1, 120, True), (2, 333, True)])
+def test_row_queue_equals_per_layer_launches(hip_lib_path, tuning, B, F, splitk):
+    """Queue forced on at every size (ragged last tile at F = 333) vs one launch per layer: items of 128 x 128 tiles against the
+    128 x 128 shape, items of the split-K body (what the queue takes below 600 items per layer) against the split-K shape."""
     from cookietts_amd import _lib
     m = _model()
     z, mel = _inputs(B, F, seed=11 + B)
-    tuning.set("CTTS_F32_NO_SPLITK")                       # the split-K shape sums K in another order
+    if not splitk:
+        tuning.set("CTTS_F32_NO_SPLITK")                   # the split-K shape sums K in another order
     tuning.set("CTTS_WF_NO_ROW_QUEUE")
     tuning.set("CTTS_WF_NO_REGION_SPLIT")
     ref, _ = m.inverse(z, mel, return_CPU=False)
-    assert not _lib.lib().ctts_last_gemm_loop() & 64
+    code = _lib.lib().ctts_last_gemm_loop()
+    assert not code & 64 and bool(code & 32) == splitk
     tuning.clear("CTTS_WF_NO_ROW_QUEUE")
     tuning.set("CTTS_WF_ROW_QUEUE_MIN", "1")
     for _ in range(3):                                     # epochs, counters and flags are re-armed per call
         got, _ = m.inverse(z, mel, return_CPU=False)
-        assert _lib.lib().ctts_last_gemm_loop() & 64, "the row queue did not run"
+        code = _lib.lib().ctts_last_gemm_loop()
+        assert code & 64 and bool(code & 32) == splitk, "the row queue did not run (or not with the expected body)"
         assert torch.isfinite(got).all() and torch.equal(got, ref)
 
 
