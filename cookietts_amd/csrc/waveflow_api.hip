@@ -620,6 +620,36 @@ __global__ void wf_abort_poison_kernel(const unsigned int* __restrict__ abort_wo
     for (long long i = threadIdx.x; i < n; i += 256) a[i] = __builtin_nanf("");
 }
 
+// Host side of the row queue's descriptors: a PINNED buffer per host thread, so that the per-flow copies are ordinary stream-ordered
+// DMA whatever the runtime does with pageable sources; the buffer is rewritten by the thread's next call only after the event
+// recorded behind this call's last copy (normally long past: the wait is a formality).  Never freed (as the helper streams below).
+struct WfDescHost {
+    GemmArgs* host = nullptr;
+    size_t cap = 0;
+    hipEvent_t done = nullptr;
+    bool pending = false, in_call = false;
+    int begin(size_t n) {
+        if (in_call) CTTS_CHECK_HIP(hipDeviceSynchronize());     // the previous call failed half-way: its copies may still be queued
+        in_call = true;
+        if (pending) { CTTS_CHECK_HIP(hipEventSynchronize(done)); pending = false; }
+        if (!done) CTTS_CHECK_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        if (n > cap) {
+            if (host) CTTS_CHECK_HIP(hipHostFree(host));
+            host = nullptr; cap = 0;
+            CTTS_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&host), n * sizeof(GemmArgs), hipHostMallocDefault));
+            cap = n;
+        }
+        return CTTS_OK;
+    }
+    int end(hipStream_t s) {
+        CTTS_CHECK_HIP(hipEventRecord(done, s));
+        pending = true;
+        in_call = false;
+        return CTTS_OK;
+    }
+};
+thread_local WfDescHost t_wf_desc;
+
 struct WfRegionStreams {              // per host thread: one helper stream per region but the first + double-buffered events
     hipStream_t st[WF_NREG] = {};
     hipEvent_t fork = nullptr, ev[WF_NREG][2] = {};
@@ -759,14 +789,12 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
     if (tuning().wf_queue_debug & 32) q_body = 1;
     for (int i = 0; i < p.c.n_layers && queue_on; ++i)      // a fresh segment may reach one 128-column tile to either side
         queue_on = (kw / 2) * (p.c.dilation_w[i] > 0 ? p.c.dilation_w[i] : 1 << i) <= 128;
-    std::vector<GemmArgs> q_layers;
+    size_t q_host_off = 0;                                 // descriptors of the flows already queued (in the pinned host buffer)
     unsigned int q_launch = 0;
     if (queue_on) {
+        if ((rc = t_wf_desc.begin((size_t)p.c.n_flows * G * p.c.n_layers))) return rc;
         CTTS_CHECK_HIP(hipMemsetAsync(w.q.abort_word, 0, w.q.control_bytes, s));
-        if (tuning().wf_inject_abort) {
-            const unsigned int one = 1;
-            CTTS_CHECK_HIP(hipMemcpyAsync(w.q.abort_word, &one, sizeof(one), hipMemcpyHostToDevice, s));
-        }
+        if (tuning().wf_inject_abort) CTTS_CHECK_HIP(hipMemsetAsync(w.q.abort_word, 1, sizeof(unsigned int), s));   // (tests)
     }
     const bool sep_fuse = p.sep_fused() && !no_fuse;
     // un-mix of flow k on the active rows: PermuteHeight composes into the map, the 1x1 conv is a pass over the rows
@@ -834,16 +862,16 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
         if (!p.c.mix_first && (rc = unmix(k))) return rc;                      // ax:324-325
         int q_max_nseg = 0;
         if (queue_on) {                                                        // this flow's descriptors, one copy
-            q_layers.clear();
+            GemmArgs* host = t_wf_desc.host + q_host_off;
+            size_t n = 0;
             for (int r = 0; r < Ga - 1; ++r)
                 for (int i = 0; i < p.c.n_layers; ++i) {
-                    q_layers.push_back(fused_args(f, r, i, !(tuning().wf_queue_debug & 4)));
-                    const GemmArgs& a = q_layers.back();
+                    const GemmArgs& a = host[n++] = fused_args(f, r, i, !(tuning().wf_queue_debug & 4));
                     q_max_nseg = std::max(q_max_nseg, a.nseg);
                     CTTS_CHECK_ARG(wf_row_persistent_supported(a), "waveflow row queue: layer %d not supported by the tile body", i);
                 }
-            // (pageable source: the copy is staged before the call returns, so the vector can be reused for the next flow)
-            CTTS_CHECK_HIP(hipMemcpyAsync(w.q.layers, q_layers.data(), q_layers.size() * sizeof(GemmArgs), hipMemcpyHostToDevice, s));
+            CTTS_CHECK_HIP(hipMemcpyAsync(w.q.layers, host, n * sizeof(GemmArgs), hipMemcpyHostToDevice, s));
+            q_host_off += n;
         }
         if (p.precond) {   // this flow's conditioning, upsampled once for all rows and layers
             const float* fr = cond + (size_t)k * batch * 2 * C * p.c.n_layers * cond_ld;
@@ -989,6 +1017,7 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
     for (int i = 0; i < 64; ++i) map.phys[i] = i < G ? phys[i] : 0;
     hipLaunchKernelGGL(wf_unsqueeze_kernel, dim3((L + 255) / 256, batch), dim3(256), 0, s, w.rows, audio, G, L, g.Lr, map);
     CTTS_CHECK_LAUNCH("wf_unsqueeze");
+    if (queue_on && (rc = t_wf_desc.end(s))) return rc;
     if (queue_on) {      // a bounded wait of the row queue expired (never, by construction): the audio is NaN, not plausible noise
         hipLaunchKernelGGL(wf_abort_poison_kernel, dim3(batch), dim3(256), 0, s, w.q.abort_word, audio, (long long)G * L);
         CTTS_CHECK_LAUNCH("wf_abort_poison");
