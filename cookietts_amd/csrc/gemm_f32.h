@@ -162,6 +162,12 @@ __host__ __device__ inline int gemm_dense_row(int epi, int bm, int mb, int r, in
     return row < M ? row : -1;
 }
 
+// defaults launch_gemm_f32 fills in before a kernel sees the arguments (anything that launches a tile body itself does the same)
+inline void gemm_apply_defaults(GemmArgs& a) {
+    if (a.bm == 0) a.bm = 256;
+    if (a.addend_ld == 0) { a.addend_ld = a.ld; a.addend_pad = a.pad; }
+}
+int gemm_check_args(int epi, const GemmArgs& a);      // the shape-independent argument checks of launch_gemm_f32 (defaults applied)
 int launch_gemm_f32(int epi, const GemmArgs& a, hipStream_t stream);
 // Small-problem shape (gemm_f32_small.hip): 128 x 64 blocks / 64 x 32 wave tiles on the SAME packed operands, bit-identical
 // results; chosen by launch_gemm_f32 when the 256 x 128 shape would start fewer than two blocks per CU.

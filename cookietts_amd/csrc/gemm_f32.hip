@@ -766,9 +766,8 @@ void reload_tuning() {
     load_tuning_locked();
 }
 
-int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
-    GemmArgs a = a_in;
-    if (a.bm == 0) a.bm = 256;
+// every argument check that does not depend on the launch shape (a: defaults applied)
+int gemm_check_args(int epi, const GemmArgs& a) {
     CTTS_CHECK_ARG(a.bm == 256 || a.bm == 128, "gemm: bm=%d", a.bm);
     CTTS_CHECK_ARG(gemm_mode_valid(a.gemm_mode), "gemm: f32_gemm_mode %d (0 default, 1 fp32 MFMA, 2 split bf16)", a.gemm_mode);
     const int bn = gemm_bn(a.bm);
@@ -795,9 +794,22 @@ int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
                                          : (a.M > (a.MB - 1) * a.bm && a.M <= a.MB * a.bm),
                    "gemm: M=%d pairC=%d MB=%d bm=%d", a.M, a.pairC, a.MB, a.bm);
     CTTS_CHECK_ARG(a.dst_ld > 0 && a.dst0, "gemm: destination not set");
-    if (a.addend_ld == 0) { a.addend_ld = a.ld; a.addend_pad = a.pad; }
     CTTS_CHECK_ARG(a.addend_frames == 0 || ((epi == GEMM_EPI_GATE || epi == GEMM_EPI_GATEX) && a.addend && a.addend_frames <= a.addend_ld - a.addend_pad),
                    "gemm: interpolated addend needs the GATE epilogue (frames=%d)", a.addend_frames);
+    CTTS_CHECK_ARG(a.gate >= 0 && a.gate < GATE_KINDS && (a.gate == 0 || epi == GEMM_EPI_GATE), "gemm: gate=%d with epilogue %d",
+                   a.gate, epi);
+    // the fused res/skip epilogue is validated BEFORE any shape is chosen: the small and split-K shapes (and the row queue's tile
+    // bodies) take the same arguments
+    CTTS_CHECK_ARG(epi != GEMM_EPI_GATE_RS ||
+                       (a.bm == 128 && a.pairC <= 64 && a.MB == 1 && a.rs_wT && a.rs_bias && (a.rs_rows == 64 || a.rs_rows == 128)),
+                   "gemm: fused res/skip needs bm=128, <= 64 channels, rs_wT / rs_bias and 64 or 128 res/skip rows");
+    return CTTS_OK;
+}
+
+int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
+    GemmArgs a = a_in;
+    gemm_apply_defaults(a);
+    if (int rc = gemm_check_args(epi, a)) return rc;
     long long blocks = (long long)a.MB * a.ntiles * a.batch;
     a.map_mode = 0;
     // measured on config 2 (PMC FETCH_SIZE per in-layer launch): 4.2 GB -> 2.5 GB at unchanged speed
@@ -807,13 +819,7 @@ int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
     }
     CTTS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "gemm: grid %lld", blocks);
     dim3 grid((unsigned)blocks);
-    CTTS_CHECK_ARG(a.gate >= 0 && a.gate < GATE_KINDS && (a.gate == 0 || epi == GEMM_EPI_GATE), "gemm: gate=%d with epilogue %d",
-                   a.gate, epi);
     if (epi == GEMM_EPI_GATE && a.gate != GATE_GTU) epi = GEMM_EPI_GATEX;
-    // the fused res/skip epilogue is validated BEFORE any shape is chosen: the small and split-K shapes take the same arguments
-    CTTS_CHECK_ARG(epi != GEMM_EPI_GATE_RS ||
-                       (a.bm == 128 && a.pairC <= 64 && a.MB == 1 && a.rs_wT && a.rs_bias && (a.rs_rows == 64 || a.rs_rows == 128)),
-                   "gemm: fused res/skip needs bm=128, <= 64 channels, rs_wT / rs_bias and 64 or 128 res/skip rows");
     if (gemm_f32_small_applies(epi, a)) return launch_gemm_f32_small(epi, a, stream);
     note_gemm_loop((tuning().f32_no_glds || a.nch_total > GEMM_GLDS_MAX_CHUNKS) ? 0 : gemm_split_level(a.gemm_mode));
     switch (epi) {

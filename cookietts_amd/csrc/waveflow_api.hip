@@ -866,7 +866,9 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
             size_t n = 0;
             for (int r = 0; r < Ga - 1; ++r)
                 for (int i = 0; i < p.c.n_layers; ++i) {
-                    const GemmArgs& a = host[n++] = fused_args(f, r, i, !(tuning().wf_queue_debug & 4));
+                    GemmArgs& a = host[n++] = fused_args(f, r, i, !(tuning().wf_queue_debug & 4));
+                    gemm_apply_defaults(a);                     // (the tile body is launched without launch_gemm_f32:
+                    if ((rc = gemm_check_args(GEMM_EPI_GATE_RS, a))) return rc;   //  its defaults and checks are applied here)
                     q_max_nseg = std::max(q_max_nseg, a.nseg);
                     CTTS_CHECK_ARG(wf_row_persistent_supported(a), "waveflow row queue: layer %d not supported by the tile body", i);
                 }

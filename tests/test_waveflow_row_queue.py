@@ -77,3 +77,30 @@ def test_row_queue_abort_is_loud(hip_lib_path, tuning):
     tuning.clear("CTTS_WF_INJECT_ABORT")
     again, _ = m.inverse(z, mel, return_CPU=False)
     assert torch.equal(again, good)
+
+
+@pytest.mark.parametrize("key", ["toy", "toy_dilations", "toy_conv_early"])
+@pytest.mark.parametrize("precond", [False, True])
+def test_row_queue_on_the_goldens_configs(hip_lib_path, tuning, key, precond):
+    """Queue forced on small golden configurations, with the conditioning folded into the in-layer GEMM (a K segment) and handed
+    over precomputed (shift_spect / scale_spect turn the fold off: the per-element addend, whose row stride and pad are defaults
+    that launch_gemm_f32 fills in - the queue launches the tile body without it and once forgot them)."""
+    from cookietts_amd import _lib
+    from cookietts_amd.waveglow_ax import WaveGlow
+    cfg = dict(synthetic.WAVEFLOW_CONFIGS[key])
+    if precond:
+        cfg.update(shift_spect=2.0, scale_spect=0.5)
+    m = WaveGlow(**cfg)
+    m.load_state_dict(synthetic.to_torch(synthetic.waveflow_state_dict(cfg, seed=31)))
+    m = m.cuda().eval()
+    assert m._folded != precond
+    F = 9
+    mel = torch.from_numpy(np.pad(synthetic.synthetic_mel(2, F, seed=31)[:, :cfg["n_mel_channels"]], ((0, 0), (0, 0), (0, 1)))).cuda()
+    z = (torch.randn(2, F * cfg["hop_length"], generator=torch.Generator().manual_seed(31)) * 0.7).cuda()
+    tuning.set("CTTS_WF_NO_ROW_QUEUE")
+    ref, _ = m.inverse(z, mel, return_CPU=False)
+    tuning.clear("CTTS_WF_NO_ROW_QUEUE")
+    tuning.set("CTTS_WF_ROW_QUEUE_MIN", "1")
+    got, _ = m.inverse(z, mel, return_CPU=False)
+    assert _lib.lib().ctts_last_gemm_loop() & 64, "the row queue did not run"
+    assert torch.equal(got, ref)
