@@ -1096,11 +1096,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_splitk_kernel(co
 // waits for the slowest workgroup of the one before it, although tile t of layer i + 1 only needs tiles t - 1, t, t + 1 of
 // layer i (|column shift| <= 128 = one tile).  Here the row is ONE launch of resident workgroups that take ITEMS (layer, batch
 // item, tile) from an atomic counter in layer-major order and run gate_rs_small_tile on each:
-//   * an item waits for the <= 3 flags of its neighbours in the previous layer ({epoch} words, written at agent scope after a
-//     release fence), computes, stores at agent scope, releases its own flag;
-//   * items are CLAIMED IN ORDER and every dependency of an item precedes it in that order, so the oldest unfinished item can
-//     always run: no co-residency requirement, no deadlock by construction.  The wait is bounded all the same (s_memrealtime):
-//     on expiry the abort word is set, every workgroup leaves, the host API reports it (and poisons the output);
+//   * an item waits for the <= 3 flags of its neighbours in the previous layer ({epoch} words), computes, stores at agent scope,
+//     waits for the stores' acknowledgements, sets its own flag;
+//   * items are CLAIMED IN ORDER, one at a time, and every dependency of an item precedes it in that order: the oldest
+//     unfinished item is always being worked on with every dependency finished - no co-residency requirement, no deadlock
+//     by construction.  The wait is bounded all the same (s_memrealtime): on expiry the abort word is set, every workgroup leaves,
+//     and the call fills its output with NaN;
 //   * with 2 workgroups per CU and ~900 items per layer the dependencies of a freshly claimed item are one whole layer of items
 //     behind the running window: nobody waits, the CUs never drain between layers, and a CU that is faster simply takes more
 //     items (the per-layer launch quantises 456 blocks on 512 slots).
@@ -1179,6 +1180,8 @@ __global__ __launch_bounds__(256, 2) void wf_row_persistent_kernel(const WfRowAr
         __syncthreads();                                   // ... for every thread of the item; the LDS is free; s_item has been read
         if (t == 0) {
             __hip_atomic_store(w.flags + (size_t)layer * per_layer + rem, w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (claimed only now: a workgroup that claimed its next item early - to hide the atomic's round trip - kept it from
+            //  the workgroups that were idle in the meantime: 106 -> 117 ms at batch 5, 38.5 -> 47 at batch 1)
             s_item = claim();
         }
         __syncthreads();
