@@ -105,3 +105,27 @@ def test_row_queue_on_the_goldens_configs(hip_lib_path, tuning, key, precond):
     got, _ = m.inverse(z, mel, return_CPU=False)
     assert _lib.lib().ctts_last_gemm_loop() & 64, "the row queue did not run"
     assert torch.equal(got, ref)
+
+
+def test_row_queue_two_streams_share_the_chip(hip_lib_path, tuning):
+    """Two models' calls on two streams, queued back to back from one host thread, so that row launches of both are resident at
+    the same time and neither gets the chip to itself: the queue needs no co-residency (items are claimed in order), each call
+    has its own counters / flags in its own workspace, and the results equal the calls run alone."""
+    ma, mb = _model(), _model()
+    za, mela = _inputs(3, 150, seed=41)
+    zb, melb = _inputs(2, 210, seed=42)
+    tuning.set("CTTS_WF_ROW_QUEUE_MIN", "1")
+    ref_a, _ = ma.inverse(za, mela, return_CPU=False)
+    ref_b, _ = mb.inverse(zb, melb, return_CPU=False)
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for _ in range(3):
+        with torch.cuda.stream(sa):
+            got_a, _ = ma.inverse(za, mela, return_CPU=False)
+        with torch.cuda.stream(sb):
+            got_b, _ = mb.inverse(zb, melb, return_CPU=False)
+        outs.append((got_a, got_b))
+    torch.cuda.synchronize()
+    for got_a, got_b in outs:
+        assert torch.equal(got_a, ref_a) and torch.equal(got_b, ref_b)
