@@ -288,7 +288,10 @@ size_t ctts_waveflow_workspace_bytes(const ctts_waveflow_config* cfg, int32_t ba
  * always run: the launch cannot deadlock and needs no co-residency.  Its wait is bounded all the same (0.5 s); if it ever expires
  * every workgroup leaves and the call fills `audio` with NaN instead of returning plausible noise (stream-ordered, so the
  * status code cannot report it).  CTTS_WF_NO_ROW_QUEUE = always one launch per layer.  The queue's control words and layer
- * descriptors live in the caller's workspace (included in ctts_waveflow_workspace_bytes). */
+ * descriptors live in the caller's workspace (included in ctts_waveflow_workspace_bytes); the descriptors reach it through a
+ * pinned staging buffer of the calling host thread, which the thread's NEXT call rewrites only after an event behind this
+ * call's last copy - so a call with the row queue may wait on the host for the thread's previous call and must not be recorded
+ * into a HIP graph (use CTTS_WF_NO_ROW_QUEUE there). */
 int ctts_waveflow_inverse_f32(const ctts_waveflow_config* cfg, const void* packed, const float* z,
                               const float* mel, float* audio, int32_t batch, int32_t samples,
                               int32_t frames, void* workspace, size_t workspace_bytes,
