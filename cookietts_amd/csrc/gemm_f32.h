@@ -183,15 +183,19 @@ bool wf_row_persistent_supported(const GemmArgs& a);
 // shape (same bits as THAT per-layer shape)
 int wf_row_cus();                             // CUs of the current device
 int wf_row_tiles(int L, int body);            // tiles per batch item (the flag array's inner extent)
-int launch_wf_row_persistent(const GemmArgs* layers_dev, int nlayers, int max_nseg, int L, int batch, int body, unsigned int* counter,
-                             unsigned int* flags, unsigned int* abort_word, unsigned int epoch, hipStream_t stream);
+// tails_dev != NULL: the whole-flow form - `nrows` rows chained in one launch, layers_dev = [nrows][nlayers], a tail stage (end conv,
+// affine update, next row's start conv: waveflow_tail.h) behind every row; the flag array then holds nrows * (nlayers + 1) stages
+struct WfTailDesc;
+int launch_wf_row_persistent(const GemmArgs* layers_dev, const WfTailDesc* tails_dev, int nrows, int nlayers, int max_nseg, int L,
+                             int batch, int body, unsigned int* counter, unsigned int* flags, unsigned int* abort_word,
+                             unsigned int epoch, hipStream_t stream);
 
 // Library DEFAULT of the main-loop selection (what CTTS_GEMM_DEFAULT resolves to), in the config structs' own encoding:
 // CTTS_GEMM_F32 (initially), CTTS_GEMM_BF16X3 (three bf16 MFMA products per fp32 operand pair, see
 // conv_gemm_f32_kernel<..., X3>) or CTTS_GEMM_BF16X6.  ctts_set_f32_gemm_mode (deprecated: prefer the per-model field).
 int set_gemm_f32_mode(int mode);
 int get_gemm_f32_mode();
-// what the calling thread's most recent conv-GEMM launch ran (ctts_last_gemm_loop): bits 0-3 split level, 16 small shape, 32 split-K, 64 row-persistent queue
+// what the calling thread's most recent conv-GEMM launch ran (ctts_last_gemm_loop): bits 0-3 split level, 16 small shape, 32 split-K, 64 row queue, 128 its whole-flow form
 void note_gemm_loop(int code);
 int last_gemm_loop();
 // true when a launch with this GemmArgs.gemm_mode / config f32_gemm_mode runs the split-bf16 main loop

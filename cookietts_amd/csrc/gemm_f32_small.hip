@@ -22,6 +22,7 @@
 
 #include "gemm_f32.h"
 #include "tuning.h"
+#include "waveflow_tail.h"
 #include "gemm_bf16.h"   // pack_bf16x2 (split-bf16 main loop)
 
 namespace ctts {
@@ -1106,8 +1107,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_splitk_kernel(co
 //     behind the running window: nobody waits, the CUs never drain between layers, and a CU that is faster simply takes more
 //     items (the per-layer launch quantises 456 blocks on 512 slots).
 // Same tile body, same chunk order: bit-identical to the per-layer launches (tests/test_waveflow.py, test_full_size.py).
+// Whole-FLOW form (tails != NULL): the rows of a flow are chained in the same launch.  A row's stages are its n_layers fused
+// layers and then a TAIL stage per tile (end conv -> affine update of the next latent row -> the next row's start conv, all
+// per column: waveflow_tail.h), which depends on the last layer of its own tile only; the first layer of the next row depends
+// on the tail stage of the neighbouring tiles.  No launch boundary is left inside a flow, so EVERYTHING written inside the
+// launch is read at agent scope: the host marks every X segment fresh, the tail reads the skip sum at agent scope.
 struct WfRowArgs {
-    const GemmArgs* layers;            // [nlayers] in device memory
+    const GemmArgs* layers;            // [nrows][nlayers] in device memory
+    const WfTailDesc* tails;           // [nrows], or NULL: one row per launch, no tail stage
+    int nrows;
     int nlayers, ntiles_s, batch;
     unsigned int* counter;             // this launch's item counter (zeroed by the host at the start of the call)
     unsigned int* flags;               // [nlayers][batch][ntiles_s], value = epoch of the launch that last finished the item
@@ -1123,13 +1131,77 @@ struct WfRowArgs {
 // the chip has workgroup slots; a 128-column shift reaches tiles t - 2 .. t + 2)
 // (Two workgroups per CU.  Three - the 128 x 128 body with every epilogue operand loaded late, 168 registers - gave 168.2 ms at
 // batch 8 against 166.3, and 136 against 100 at batch 4 where a layer has fewer items than slots: profiles/r4_12.)
+// tail stage of one tile of NCOL columns (256 threads: wave wv = channel quarter, lane = column (+ 64))
+template <int NCOL, class DESC>
+__device__ __forceinline__ void wf_tail_start_tile(DESC& d, const int tile, const int b, float* part /* [3][2][NCOL] + [NCOL] */) {
+    constexpr int CPL = NCOL / 64;                       // columns per lane
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int n0 = tile * NCOL;
+    const int C = d.C, cq = C / 4, cbeg = wv * cq;
+    float e0[CPL], e1[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) e0[k] = e1[k] = 0.f;
+    const r_cgptr ob = (r_cgptr)d.out + (size_t)b * d.out_bstride + d.pad + n0 + lane;
+    const r_cgptr we = (r_cgptr)d.Wend;
+    for (int c = cbeg; c < cbeg + cq; ++c) {
+        const float w0 = we[c], w1 = we[C + c];
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {                  // (columns >= L of a padded row are readable)
+            const float v = __hip_atomic_load(ob + (size_t)c * d.ld + 64 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            e0[k] = wf_end_fma(w0, v, e0[k]);
+            e1[k] = wf_end_fma(w1, v, e1[k]);
+        }
+    }
+    if (wv > 0) {
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            part[((wv - 1) * 2 + 0) * NCOL + lane + 64 * k] = e0[k];
+            part[((wv - 1) * 2 + 1) * NCOL + lane + 64 * k] = e1[k];
+        }
+    }
+    __syncthreads();
+    float* anew = part + 6 * NCOL;
+    if (wv == 0) {
+        const float b0 = ((r_cgptr)d.bend)[0], b1 = ((r_cgptr)d.bend)[1];
+        const r_gptr rp = (r_gptr)d.rows + ((size_t)b * d.G + d.row) * d.Lr;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const int col = lane + 64 * k, n = n0 + col;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                e0[k] += part[(q * 2 + 0) * NCOL + col];
+                e1[k] += part[(q * 2 + 1) * NCOL + col];
+            }
+            float a = 0.f;
+            if (n < d.L) a = wf_row_update(rp[n], e0[k], e1[k], b0, b1);
+            if (n < d.Lr) __hip_atomic_store(rp + n, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (row tail stays zero)
+            anew[col] = a;
+        }
+    }
+    __syncthreads();
+    if (d.x0) {                                          // the next row's start conv; columns >= L are halo: zero
+        const int col = t % NCOL, n = n0 + col;
+        const int L4 = (d.L + 3) & ~3;                   // (what wf_start_kernel writes: whole float4s that begin below L)
+        if (n < L4) {
+            const float a = anew[col];
+            const r_gptr xb = (r_gptr)d.x0 + (size_t)b * d.x0_bstride + d.pad + n;
+            const r_cgptr ws = (r_cgptr)d.ws, bs = (r_cgptr)d.bs;
+            for (int c = t / NCOL; c < C; c += 256 / NCOL)
+                __hip_atomic_store(xb + (size_t)c * d.ld, n < d.L ? wf_start_value(ws[c], a, bs[c]) : 0.f, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 template <int SEGS, int BODY>
 __global__ __launch_bounds__(256, 2) void wf_row_persistent_kernel(const WfRowArgs w) {
     __shared__ int s_item, s_abort;
+    __shared__ float s_tail[7 * 128];
     constexpr int HALO = BODY == 1 ? 2 : 1;
     const int t = threadIdx.x;
     const int ntiles = BODY == 1 ? w.ntiles_k : w.ntiles_s;
-    const int per_layer = ntiles * w.batch, total = w.nlayers * per_layer;
+    const int spr = w.nlayers + (w.tails ? 1 : 0);       // stages per row
+    const int per_layer = ntiles * w.batch, total = w.nrows * spr * per_layer;
     // ONE `t == 0` region per iteration, between two barriers, and every branch that contains a barrier on a readfirstlane'd
     // (provably uniform) value: with the claim at the top of the loop and the flag store at its bottom the compiler threaded
     // the two `t == 0` regions together across the back edge and lane 0 left the loop's barriers to the other 63 lanes of its
@@ -1144,18 +1216,20 @@ __global__ __launch_bounds__(256, 2) void wf_row_persistent_kernel(const WfRowAr
     for (;;) {
         const int q = __builtin_amdgcn_readfirstlane(s_item);
         if (q >= total) break;
-        const int layer = q / per_layer, rem = q - layer * per_layer;
+        const int gs = q / per_layer, rem = q - gs * per_layer;              // global stage (row-major), item within it
+        const int row = gs / spr, layer = gs - row * spr;                    // layer == nlayers: the row's tail stage
         const int b = rem / ntiles, tile = rem - b * ntiles;
-        if (layer > 0 && t < 2 * HALO + 1 && !(w.debug & 1)) {
+        const int halo = layer == w.nlayers ? 0 : HALO;                      // a tail item needs its own tile only
+        if (gs > 0 && t < 2 * HALO + 1 && !(w.debug & 1)) {
             const int tt = tile + t - HALO;
-            if (tt >= 0 && tt < ntiles) {
-                const unsigned int* f = w.flags + (size_t)(layer - 1) * per_layer + b * ntiles + tt;
+            if (tt >= tile - halo && tt <= tile + halo && tt >= 0 && tt < ntiles) {
+                const unsigned int* f = w.flags + (size_t)(gs - 1) * per_layer + b * ntiles + tt;
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 for (unsigned spins = 0; __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != w.epoch; ++spins) {
                     __builtin_amdgcn_s_sleep(8);
                     if ((spins & 63u) == 63u) {
                         if (__builtin_amdgcn_s_memrealtime() - t0 > w.timeout_ticks) {
-                            __hip_atomic_store(w.abort_word, 1u + (unsigned)layer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(w.abort_word, 1u + (unsigned)gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             s_abort = 1;
                             break;
                         }
@@ -1166,10 +1240,14 @@ __global__ __launch_bounds__(256, 2) void wf_row_persistent_kernel(const WfRowAr
         }
         __syncthreads();                                   // dependencies met
         if (__builtin_amdgcn_readfirstlane(s_abort)) break;
-        if (!(w.debug & 2)) {
+        if (layer == w.nlayers) {
+            typedef const __attribute__((address_space(4))) WfTailDesc const_tail;
+            wf_tail_start_tile<BODY == 1 ? 64 : 128, const_tail>(*((const_tail*)w.tails + row), tile, b, s_tail);
+        } else if (!(w.debug & 2)) {
             typedef const __attribute__((address_space(4))) GemmArgs const_args;     // scalar loads of the descriptor
-            if constexpr (BODY == 1) gate_rs_splitk_tile<SEGS, true, const_args>(*((const_args*)w.layers + layer), tile, b);
-            else gate_rs_small_tile<SEGS, true, const_args>(*((const_args*)w.layers + layer), tile, b);
+            const_args& a = *((const_args*)w.layers + (size_t)row * w.nlayers + layer);
+            if constexpr (BODY == 1) gate_rs_splitk_tile<SEGS, true, const_args>(a, tile, b);
+            else gate_rs_small_tile<SEGS, true, const_args>(a, tile, b);
         }
         // Release.  Every result was stored at agent scope (sc1: written THROUGH this XCD's L2), so a store is visible to the
         // agent once it is acknowledged: vmcnt(0) of every thread, then the barrier, then the flag.  The formal release fence
@@ -1179,7 +1257,7 @@ __global__ __launch_bounds__(256, 2) void wf_row_persistent_kernel(const WfRowAr
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                   // ... for every thread of the item; the LDS is free; s_item has been read
         if (t == 0) {
-            __hip_atomic_store(w.flags + (size_t)layer * per_layer + rem, w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(w.flags + (size_t)gs * per_layer + rem, w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // (claimed only now: a workgroup that claimed its next item early - to hide the atomic's round trip - kept it from
             //  the workgroups that were idle in the meantime: 106 -> 117 ms at batch 5, 38.5 -> 47 at batch 1)
             s_item = claim();
@@ -1307,21 +1385,22 @@ int wf_row_cus() {                                  // CUs of the current device
 
 int wf_row_tiles(int L, int body) { return body == 1 ? (L + K_BN - 1) / K_BN : (L + R_BN - 1) / R_BN; }
 
-int launch_wf_row_persistent(const GemmArgs* layers_dev, int nlayers, int max_nseg, int L, int batch, int body, unsigned int* counter,
-                             unsigned int* flags, unsigned int* abort_word, unsigned int epoch, hipStream_t stream) {
+int launch_wf_row_persistent(const GemmArgs* layers_dev, const WfTailDesc* tails_dev, int nrows, int nlayers, int max_nseg, int L,
+                             int batch, int body, unsigned int* counter, unsigned int* flags, unsigned int* abort_word,
+                             unsigned int epoch, hipStream_t stream) {
     WfRowArgs w{};
-    w.layers = layers_dev; w.nlayers = nlayers; w.ntiles_s = wf_row_tiles(L, 0); w.ntiles_k = wf_row_tiles(L, 1); w.batch = batch;
+    w.layers = layers_dev; w.tails = tails_dev; w.nrows = nrows; w.nlayers = nlayers; w.ntiles_s = wf_row_tiles(L, 0); w.ntiles_k = wf_row_tiles(L, 1); w.batch = batch;
     w.counter = counter; w.flags = flags; w.abort_word = abort_word; w.epoch = epoch;
     w.timeout_ticks = 50u * 1000u * 1000u;                              // 0.5 s: a whole call is ~0.2 s
     w.debug = tuning().wf_queue_debug;
-    CTTS_CHECK_ARG(layers_dev && counter && flags && abort_word && epoch > 0 && nlayers >= 1 && batch >= 1 && w.ntiles_s >= 1 &&
-                       (body == 0 || body == 1), "waveflow row launch: bad argument");
+    CTTS_CHECK_ARG(layers_dev && counter && flags && abort_word && epoch > 0 && nlayers >= 1 && nrows >= 1 && batch >= 1 &&
+                       w.ntiles_s >= 1 && (body == 0 || body == 1), "waveflow row launch: bad argument");
     const int n_cu = wf_row_cus();
     // Two resident workgroups per CU, never more than the items of two layers (the rest could only wait).  A layer of no more
     // items than CUs gets ONE workgroup per item: a second workgroup on a CU would run the next layer's item next to the
     // straggler it waits for and halve that one's matrix pipe (config 4, batch 1: 55 ms per call with 2 per CU)
     const long long per_layer = (long long)(body == 1 ? w.ntiles_k : w.ntiles_s) * batch;
-    long long want = std::min<long long>(2ll * n_cu, std::min<long long>(nlayers * per_layer, 2 * per_layer));
+    long long want = std::min<long long>(2ll * n_cu, std::min<long long>((long long)nrows * nlayers * per_layer, 2 * per_layer));
     if (per_layer <= n_cu && !(w.debug & 64)) want = per_layer;
     const dim3 grid((unsigned)std::max<long long>(want, 1));
     const int vi = max_nseg <= 4 ? 0 : 1;
@@ -1340,11 +1419,11 @@ int launch_wf_row_persistent(const GemmArgs* layers_dev, int nlayers, int max_ns
         }
         if (vi == 0) hipLaunchKernelGGL((wf_row_persistent_kernel<4, 1>), grid, dim3(256), LDS, stream, w);
         else hipLaunchKernelGGL((wf_row_persistent_kernel<GEMM_MAX_SEG, 1>), grid, dim3(256), LDS, stream, w);
-        note_gemm_loop(16 | 32 | 64);
+        note_gemm_loop(16 | 32 | 64 | (tails_dev ? 128 : 0));
     } else {
         if (vi == 0) hipLaunchKernelGGL((wf_row_persistent_kernel<4, 0>), grid, dim3(256), 0, stream, w);
         else hipLaunchKernelGGL((wf_row_persistent_kernel<GEMM_MAX_SEG, 0>), grid, dim3(256), 0, stream, w);
-        note_gemm_loop(16 | 64);
+        note_gemm_loop(16 | 64 | (tails_dev ? 128 : 0));
     }
     CTTS_CHECK_LAUNCH("wf_row_persistent");
     return CTTS_OK;

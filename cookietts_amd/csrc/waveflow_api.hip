@@ -19,6 +19,7 @@
 #include "tuning.h"
 #include "waveglow_kernels.h"
 #include "waveflow_sep.h"
+#include "waveflow_tail.h"
 
 namespace ctts {
 namespace {
@@ -153,8 +154,9 @@ int make_wf_geom(const WfPlan& p, int samples, WfGeom& g) {
 
 // Row queue (wf_row_persistent_kernel): control words + the layer descriptors of one flow, inside the caller's workspace
 struct WfQueueWs {
-    unsigned int *abort_word, *counters, *flags;     // [1] | [n_flows * n_group] | [n_layers][batch][tiles of 128 columns]
+    unsigned int *abort_word, *counters, *flags;     // [1] | [n_flows * n_group] | [n_group * (n_layers + 1) stages][batch][tiles of 64 columns]
     GemmArgs* layers;                                // [n_group][n_layers] of the flow being run
+    WfTailDesc* tails;                               // [n_group]
     size_t control_bytes;                            // abort word .. end of the flags: zeroed at the start of every call
 };
 struct WfWs { float *rows, *mel_up, *cond_up, *dwout, *X, *act, *out; size_t total, xslot, cond_slot; WfQueueWs q; };
@@ -173,7 +175,7 @@ void wf_carve(const WfPlan& p, const WfGeom& g, int batch, float* base, WfWs& w)
     w.act = take(B * p.C * g.ld);
     w.out = take(B * p.C * g.ld);
     {
-        const size_t n_count = (size_t)p.c.n_flows * p.c.n_group, n_flags = (size_t)p.c.n_layers * B * wf_row_tiles(g.L, 1);
+        const size_t n_count = (size_t)p.c.n_flows * p.c.n_group, n_flags = (size_t)p.c.n_group * (p.c.n_layers + 1) * B * wf_row_tiles(g.L, 1);
         const size_t control = align_up(ALIGN_F + n_count + n_flags);                       // in 4-byte words
         float* c = take(control);
         w.q.abort_word = reinterpret_cast<unsigned int*>(c);
@@ -181,6 +183,7 @@ void wf_carve(const WfPlan& p, const WfGeom& g, int batch, float* base, WfWs& w)
         w.q.flags = c ? w.q.counters + n_count : nullptr;
         w.q.control_bytes = control * sizeof(float);
         w.q.layers = reinterpret_cast<GemmArgs*>(take(((size_t)p.c.n_group * p.c.n_layers * sizeof(GemmArgs) + 3) / 4));
+        w.q.tails = reinterpret_cast<WfTailDesc*>(take(((size_t)p.c.n_group * sizeof(WfTailDesc) + 3) / 4));
     }
     w.total = o;
 }
@@ -256,8 +259,8 @@ __global__ __launch_bounds__(256) void wf_start_kernel(const float* __restrict__
     for (int c = c0; c < c0 + 16 && c < C; ++c) {
         const float w = ws[c], bias = bs[c];
         float4 v;
-        v.x = w * a.x + bias;
-        v.y = k1 ? w * a.y + bias : 0.f; v.z = k2 ? w * a.z + bias : 0.f; v.w = k3 ? w * a.w + bias : 0.f;
+        v.x = wf_start_value(w, a.x, bias);
+        v.y = k1 ? wf_start_value(w, a.y, bias) : 0.f; v.z = k2 ? wf_start_value(w, a.z, bias) : 0.f; v.w = k3 ? wf_start_value(w, a.w, bias) : 0.f;
         *reinterpret_cast<float4*>(xb + (size_t)c * ld) = v;
     }
 }
@@ -278,8 +281,8 @@ __global__ __launch_bounds__(256) void wf_tail_kernel(const float* __restrict__ 
     for (int c = cbeg; c < cbeg + cq; ++c) {
         const float4 v = *reinterpret_cast<const float4*>(ob + (size_t)c * ld);
         const float w0 = Wend[c], w1 = Wend[C + c];
-        e0.x = fmaf(w0, v.x, e0.x); e0.y = fmaf(w0, v.y, e0.y); e0.z = fmaf(w0, v.z, e0.z); e0.w = fmaf(w0, v.w, e0.w);
-        e1.x = fmaf(w1, v.x, e1.x); e1.y = fmaf(w1, v.y, e1.y); e1.z = fmaf(w1, v.z, e1.z); e1.w = fmaf(w1, v.w, e1.w);
+        e0.x = wf_end_fma(w0, v.x, e0.x); e0.y = wf_end_fma(w0, v.y, e0.y); e0.z = wf_end_fma(w0, v.z, e0.z); e0.w = wf_end_fma(w0, v.w, e0.w);
+        e1.x = wf_end_fma(w1, v.x, e1.x); e1.y = wf_end_fma(w1, v.y, e1.y); e1.z = wf_end_fma(w1, v.z, e1.z); e1.w = wf_end_fma(w1, v.w, e1.w);
     }
     if (wv > 0) {
         *reinterpret_cast<float4*>(&part[wv - 1][0][lane * 4]) = e0;
@@ -297,10 +300,10 @@ __global__ __launch_bounds__(256) void wf_tail_kernel(const float* __restrict__ 
     const float b0 = bend[0], b1 = bend[1];
     float* rp = rows + ((size_t)b * G + row) * Lr + n;
     float4 a = *reinterpret_cast<const float4*>(rp);
-    a.x = (a.x - (e1.x + b1)) / expf(e0.x + b0);
-    a.y = n + 1 < L ? (a.y - (e1.y + b1)) / expf(e0.y + b0) : 0.f;       // row tail stays zero
-    a.z = n + 2 < L ? (a.z - (e1.z + b1)) / expf(e0.z + b0) : 0.f;
-    a.w = n + 3 < L ? (a.w - (e1.w + b1)) / expf(e0.w + b0) : 0.f;
+    a.x = wf_row_update(a.x, e0.x, e1.x, b0, b1);
+    a.y = n + 1 < L ? wf_row_update(a.y, e0.y, e1.y, b0, b1) : 0.f;       // row tail stays zero
+    a.z = n + 2 < L ? wf_row_update(a.z, e0.z, e1.z, b0, b1) : 0.f;
+    a.w = n + 3 < L ? wf_row_update(a.w, e0.w, e1.w, b0, b1) : 0.f;
     *reinterpret_cast<float4*>(rp) = a;
 }
 
@@ -624,7 +627,7 @@ __global__ void wf_abort_poison_kernel(const unsigned int* __restrict__ abort_wo
 // DMA whatever the runtime does with pageable sources; the buffer is rewritten by the thread's next call only after the event
 // recorded behind this call's last copy (normally long past: the wait is a formality).  Never freed (as the helper streams below).
 struct WfDescHost {
-    GemmArgs* host = nullptr;
+    char* host = nullptr;                                  // bytes
     size_t cap = 0;
     hipEvent_t done = nullptr;
     bool pending = false, in_call = false;
@@ -636,7 +639,7 @@ struct WfDescHost {
         if (n > cap) {
             if (host) CTTS_CHECK_HIP(hipHostFree(host));
             host = nullptr; cap = 0;
-            CTTS_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&host), n * sizeof(GemmArgs), hipHostMallocDefault));
+            CTTS_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&host), n, hipHostMallocDefault));
             cap = n;
         }
         return CTTS_OK;
@@ -789,10 +792,12 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
     if (tuning().wf_queue_debug & 32) q_body = 1;
     for (int i = 0; i < p.c.n_layers && queue_on; ++i)      // a fresh segment may reach one 128-column tile to either side
         queue_on = (kw / 2) * (p.c.dilation_w[i] > 0 ? p.c.dilation_w[i] : 1 << i) <= 128;
-    size_t q_host_off = 0;                                 // descriptors of the flows already queued (in the pinned host buffer)
+    size_t q_host_off = 0;                                 // bytes of the pinned host buffer the flows queued so far occupy
+    // whole-flow form: every row of a flow in ONE launch (tail stages between the rows); CTTS_WF_QUEUE_DEBUG=128: one launch per row
+    const bool q_flow = queue_on && !(tuning().wf_queue_debug & 128);
     unsigned int q_launch = 0;
     if (queue_on) {
-        if ((rc = t_wf_desc.begin((size_t)p.c.n_flows * G * p.c.n_layers))) return rc;
+        if ((rc = t_wf_desc.begin((size_t)p.c.n_flows * G * (p.c.n_layers * sizeof(GemmArgs) + sizeof(WfTailDesc))))) return rc;
         CTTS_CHECK_HIP(hipMemsetAsync(w.q.abort_word, 0, w.q.control_bytes, s));
         if (tuning().wf_inject_abort) CTTS_CHECK_HIP(hipMemsetAsync(w.q.abort_word, 1, sizeof(unsigned int), s));   // (tests)
     }
@@ -814,7 +819,9 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
 
     // the fused dense layer (no depthwise stage) of flow f, row r, layer i - the ONE place its launch arguments are made, for the
     // per-layer launches, the region split and the row queue alike
-    auto fused_args = [&](const WfPlan::Flow& f, int r, int i, bool mark_fresh) {
+    // mark_fresh: 0 no marks (per-layer launches), 1 what the previous layer of the SAME row wrote (row queue, one launch per
+    // row), 2 every X segment (whole-flow queue: earlier rows were written inside the same launch too)
+    auto fused_args = [&](const WfPlan::Flow& f, int r, int i, int mark_fresh) {
         const int dw = p.c.dilation_w[i] > 0 ? p.c.dilation_w[i] : 1 << i;
         const bool merge = p.c.merge_res_skip != 0;
         const int si = merge ? 0 : i, slot = r % NS;
@@ -834,7 +841,7 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
         for (int ah = a_min; ah < gkh; ++ah) {
             const int src_row = r - (kh - 1 - ah) * dh;
             // the current row's slot of layer i > 0 is what layer i - 1 of this very row wrote
-            const int fresh = mark_fresh && src_row == r && si > 0 ? 1 : 0;
+            const int fresh = mark_fresh == 2 || (mark_fresh == 1 && src_row == r && si > 0) ? 1 : 0;
             for (int j = 0; j < gkw; ++j)
                 a.seg[ns++] = {X(si, src_row % NS), cstride, p.nch_c, (j - kw / 2) * dw, 0, fresh};
         }
@@ -862,18 +869,32 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
         if (!p.c.mix_first && (rc = unmix(k))) return rc;                      // ax:324-325
         int q_max_nseg = 0;
         if (queue_on) {                                                        // this flow's descriptors, one copy
-            GemmArgs* host = t_wf_desc.host + q_host_off;
+            GemmArgs* host = reinterpret_cast<GemmArgs*>(t_wf_desc.host + q_host_off);
             size_t n = 0;
             for (int r = 0; r < Ga - 1; ++r)
                 for (int i = 0; i < p.c.n_layers; ++i) {
-                    GemmArgs& a = host[n++] = fused_args(f, r, i, !(tuning().wf_queue_debug & 4));
+                    GemmArgs& a = host[n++] = fused_args(f, r, i, (tuning().wf_queue_debug & 4) ? 0 : q_flow ? 2 : 1);
                     gemm_apply_defaults(a);                     // (the tile body is launched without launch_gemm_f32:
                     if ((rc = gemm_check_args(GEMM_EPI_GATE_RS, a))) return rc;   //  its defaults and checks are applied here)
                     q_max_nseg = std::max(q_max_nseg, a.nseg);
                     CTTS_CHECK_ARG(wf_row_persistent_supported(a), "waveflow row queue: layer %d not supported by the tile body", i);
                 }
             CTTS_CHECK_HIP(hipMemcpyAsync(w.q.layers, host, n * sizeof(GemmArgs), hipMemcpyHostToDevice, s));
-            q_host_off += n;
+            q_host_off += n * sizeof(GemmArgs);
+            if (q_flow) {                                                      // the tail stage behind every row
+                WfTailDesc* th = reinterpret_cast<WfTailDesc*>(t_wf_desc.host + q_host_off);
+                for (int r = 0; r < Ga - 1; ++r) {
+                    WfTailDesc d{};
+                    d.out = w.out; d.out_bstride = cstride;
+                    d.rows = w.rows; d.Wend = blob + f.end_w; d.bend = blob + f.end_b;
+                    d.ws = blob + f.start_w; d.bs = blob + f.start_b;
+                    d.x0 = r + 1 < Ga - 1 ? X(0, (r + 1) % NS) : nullptr; d.x0_bstride = cstride;
+                    d.C = C; d.G = G; d.row = phys[r + 1]; d.L = L; d.Lr = g.Lr; d.ld = g.ld; d.pad = g.pad;
+                    th[r] = d;
+                }
+                CTTS_CHECK_HIP(hipMemcpyAsync(w.q.tails, th, (size_t)(Ga - 1) * sizeof(WfTailDesc), hipMemcpyHostToDevice, s));
+                q_host_off += (size_t)(Ga - 1) * sizeof(WfTailDesc);
+            }
         }
         if (p.precond) {   // this flow's conditioning, upsampled once for all rows and layers
             const float* fr = cond + (size_t)k * batch * 2 * C * p.c.n_layers * cond_ld;
@@ -885,14 +906,23 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
                                    fr, w.cond_up, 2 * C, p.c.n_layers, frames, cond_ld, cond_pad, L, g.ld, g.pad, w.cond_slot);
             CTTS_CHECK_LAUNCH("wf_interp_cond");
         }
-        for (int r = 0; r < Ga - 1; ++r) {
+        if (q_flow) {                                       // start of row 0, then every row and tail of the flow in one launch
+            hipLaunchKernelGGL(wf_start_kernel, dim3(((L + 3) / 4 + 255) / 256, (C + 15) / 16, batch), dim3(256), 0, s,
+                               w.rows, blob + f.start_w, blob + f.start_b, X(0, 0), C, G, phys[0], L, g.Lr, g.ld, g.pad);
+            CTTS_CHECK_LAUNCH("wf_start");
+            const unsigned int li = q_launch++;
+            if ((rc = launch_wf_row_persistent(w.q.layers, w.q.tails, Ga - 1, p.c.n_layers, q_max_nseg, L, batch, q_body,
+                                               w.q.counters + li, w.q.flags, w.q.abort_word, li + 1, s)))
+                return rc;
+        }
+        for (int r = 0; r < Ga - 1 && !q_flow; ++r) {
             const int slot = r % NS;
             hipLaunchKernelGGL(wf_start_kernel, dim3(((L + 3) / 4 + 255) / 256, (C + 15) / 16, batch), dim3(256), 0, s,
                                w.rows, blob + f.start_w, blob + f.start_b, X(0, slot), C, G, phys[r], L, g.Lr, g.ld, g.pad);
             CTTS_CHECK_LAUNCH("wf_start");
             if (queue_on) {
                 const unsigned int li = q_launch++;
-                if ((rc = launch_wf_row_persistent(w.q.layers + (size_t)r * p.c.n_layers, p.c.n_layers, q_max_nseg, L, batch, q_body,
+                if ((rc = launch_wf_row_persistent(w.q.layers + (size_t)r * p.c.n_layers, nullptr, 1, p.c.n_layers, q_max_nseg, L, batch, q_body,
                                                    w.q.counters + li, w.q.flags, w.q.abort_word, li + 1, s)))
                     return rc;
             } else {
@@ -964,7 +994,7 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
                 a.nseg = ns;
                 const bool last = i == p.c.n_layers - 1 || merge;       // all rows of the res/skip GEMM are skip rows
                 if (fuse) {
-                    if (!p.sep) a = fused_args(f, r, i, false);
+                    if (!p.sep) a = fused_args(f, r, i, 0);
                     else {
                         // x_{i+1}[row r] = x_i[row r] + res -> layer i+1's ring slot;  skip rows (+)= into w.out
                         a.rs_wT = blob + f.rs_T[i]; a.rs_bias = blob + f.rs_Tb[i]; a.rs_rows = p.rs_rows(i);

@@ -282,9 +282,10 @@ size_t ctts_waveflow_workspace_bytes(const ctts_waveflow_config* cfg, int32_t ba
  *
  * How a row of the recurrence is launched (C = 64 models; results of the forms agree bit for bit within one tile shape, see
  * "Which loop a launch really runs" below): one launch per fused layer (small sizes: a layer is one wave's serial chain),
- * or - from 257 column tiles of 128 per layer on (batch 3 at 900 frames) up to 1400 - the ROW QUEUE: the row's n_layers fused
- * layers as ONE launch whose workgroups take (layer, tile) items from an atomic counter in order and wait, per item, for the
- * flags of the neighbouring tiles of the previous layer only.  Items are claimed in order, so the oldest unfinished item can
+ * or - from 257 column tiles of 128 per layer on (batch 3 at 900 frames) up to 1400 - the ROW QUEUE: ALL rows of a flow (each
+ * row = its n_layers fused layers + a tail stage: end conv, affine update of the next latent row, the next row's start conv) as
+ * ONE launch whose workgroups take (row, stage, tile) items from an atomic counter in order and wait, per item, for the flags
+ * of the neighbouring tiles of the previous stage only.  Items are claimed in order, so the oldest unfinished item can
  * always run: the launch cannot deadlock and needs no co-residency.  Its wait is bounded all the same (0.5 s); if it ever expires
  * every workgroup leaves and the call fills `audio` with NaN instead of returning plausible noise (stream-ordered, so the
  * status code cannot report it).  CTTS_WF_NO_ROW_QUEUE = always one launch per layer.  The queue's control words and layer
@@ -657,7 +658,7 @@ int ctts_taco_stop_rule_f32(const float* gate_logits, int32_t batch, int32_t gat
  * the split-K shape sums in a different order than the other shapes, so the same utterance is bit-identical across
  * batch sizes only within one shape (CTTS_F32_NO_SPLITK: one K order at every size).  ctts_last_gemm_loop() reports what the most recent conv-GEMM launch of the calling
  * thread ran, so that a benchmark row can label itself: bits 0-3 = split level (0 fp32 MFMA, 3, 6), bit 4 = small shape,
- * bit 5 = split-K shape, bit 6 = the WaveFlow row queue (one launch per row, see ctts_waveflow_inverse_f32).
+ * bit 5 = split-K shape, bit 6 = the WaveFlow row queue, bit 7 = its whole-flow form (one launch per flow, see ctts_waveflow_inverse_f32).
  *
  * DEPRECATED - ctts_set_f32_gemm_mode / ctts_get_f32_gemm_mode: a process-wide default (what CTTS_GEMM_DEFAULT (0) in a
  * config struct resolves to, and the mode of the two entry points without a config struct: ctts_lstm_seq_f32's input
@@ -676,7 +677,7 @@ int ctts_tuning_reload(void);
 /* The knobs as the library currently sees them: bit 0 CTTS_F32_NO_GLDS, 1 CTTS_GEMM_NO_XCD_PAIR, 2 CTTS_BF16_NO_GLDS,
  * 3 CTTS_BF16_NO_WIDE, 4 CTTS_BF16_NO_PP, 5 CTTS_BF16_W4, 6 CTTS_BF16_PP_STAGES=4, 7 CTTS_WF_NO_FUSE, 8 CTTS_TACO_NO_FUSE,
  * 9 CTTS_F32_NO_SMALL, 10 CTTS_F32_FORCE_SMALL, 11 CTTS_F32_NO_SPLITK, 12 CTTS_WF_NO_VEC_INTERP, 13 CTTS_F32_NO_DEFER_SKIP, 14 CTTS_WF_NO_REGION_SPLIT,
- * 15 CTTS_WF_NO_ROW_QUEUE, 16 CTTS_WF_ROW_QUEUE_MIN set, 17 CTTS_WF_INJECT_ABORT (tests assert that a knob they set is the
+ * 15 CTTS_WF_NO_ROW_QUEUE, 16 CTTS_WF_ROW_QUEUE_MIN set, 17 CTTS_WF_INJECT_ABORT, 18 CTTS_WF_QUEUE_DEBUG != 0 (tests assert that a knob they set is the
  * one in effect). */
 int ctts_tuning_flags(void);
 

@@ -41,7 +41,8 @@ def gemm_loop_label():
     code = _lib.lib().ctts_last_gemm_loop()
     loop = {0: "fp32 MFMA", 3: "split-bf16 x3", 6: "split-bf16 x6"}.get(code & 15, f"level {code & 15}")
     if code & 64:
-        shape = "row queue (one launch per row), " + ("split-K items of 128 x 64" if code & 32 else "items of 128 x 128")
+        shape = ("row queue (one launch per flow), " if code & 128 else "row queue (one launch per row), ") + \
+            ("split-K items of 128 x 64" if code & 32 else "items of 128 x 128")
     else:
         shape = "split-K shape" if code & 32 else "small shape" if code & 16 else "large shape"
     return f"{loop}, {shape}"
@@ -67,7 +68,8 @@ def row_waveflow(args):
                      "value": samples / dt, "unit": "samples/s", "rtf": samples / dt / 22050, "ms_per_call": dt * 1e3,
                      "dtype": "f32", "batch": B, "frames": F,
                      # per row of the recurrence: start + tail + (row queue: ONE launch for the n_layers fused layers | one per layer)
-                     "kernel_launches_per_utterance_batch": (1 if "row queue" in loop else wn["n_layers"]) * cfg["n_flows"] * (G - 1) + 2 * cfg["n_flows"] * (G - 1),
+                     "kernel_launches_per_utterance_batch": (2 * cfg["n_flows"] if "per flow" in loop else
+                                                             ((1 if "row queue" in loop else wn["n_layers"]) + 2) * cfg["n_flows"] * (G - 1)),
                      "achieved_tflops_algorithmic": 2 * mac * samples / dt / 1e12,
                      "mfma_frac_algorithmic": 2 * mac * samples / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                      "last_gemm_loop": loop,

@@ -1,6 +1,7 @@
-"""The WaveFlow row queue (gemm_f32_small.hip ``wf_row_persistent_kernel``): the fused layers of a row as ONE launch whose
-workgroups take (layer, tile) items in order and wait for three neighbouring tiles of the previous layer.  It runs the same
-tile body as the per-layer 128 x 128 shape, so every form must agree BIT FOR BIT; its bounded wait must fail loudly."""
+"""The WaveFlow row queue (gemm_f32_small.hip ``wf_row_persistent_kernel``): the rows of a flow - each row its fused layers and a
+tail stage (end conv, affine update, next row's start conv) - as ONE launch whose workgroups take (row, stage, tile) items in
+order and wait for the neighbouring tiles of the previous stage.  It runs the same tile bodies and the same per-column tail
+arithmetic as the per-layer launches, so every form must agree BIT FOR BIT; its bounded wait must fail loudly."""
 import numpy as np
 import pytest
 import torch
@@ -44,8 +45,11 @@ def test_row_queue_equals_per_layer_launches(hip_lib_path, tuning, B, F, splitk)
     for _ in range(3):                                     # epochs, counters and flags are re-armed per call
         got, _ = m.inverse(z, mel, return_CPU=False)
         code = _lib.lib().ctts_last_gemm_loop()
-        assert code & 64 and bool(code & 32) == splitk, "the row queue did not run (or not with the expected body)"
+        assert (code & 192) == 192 and bool(code & 32) == splitk, "the whole-flow queue did not run (or not with the expected body)"
         assert torch.isfinite(got).all() and torch.equal(got, ref)
+    tuning.set("CTTS_WF_QUEUE_DEBUG", "128")               # one launch per ROW (start / tail kernels between) instead of per flow
+    got, _ = m.inverse(z, mel, return_CPU=False)
+    assert (_lib.lib().ctts_last_gemm_loop() & 192) == 64 and torch.equal(got, ref)
 
 
 def test_row_queue_full_size_default_and_forms(hip_lib_path, tuning):
