@@ -829,6 +829,7 @@ __device__ __forceinline__ void gate_rs_splitk_tile(ARGS& a, const int tile, con
     const int l31 = lane & 31, lhi = lane >> 5;
     const int n0 = tile * K_BN;
     const int n = n0 + wn * 32 + l31;
+    if constexpr (!FRESH) { S_STAMP(0); S_STAMP_WHERE(); }
 
     // epilogue operands requested at entry (see conv_gemm_f32_gate_rs_small_kernel): this wave stores row tiles 2 kh, 2 kh + 1
     typedef float k_f32x4 __attribute__((ext_vector_type(4)));
@@ -930,9 +931,11 @@ __device__ __forceinline__ void gate_rs_splitk_tile(ARGS& a, const int tile, con
         K_ISSUE_A(2 * j, ce, 0); K_ISSUE_A(2 * j, ce, 1); K_ISSUE_B_AT(2 * j, ctab[ce]);
         K_ISSUE_A(2 * j + 1, co, 0); K_ISSUE_A(2 * j + 1, co, 1); K_ISSUE_B_AT(2 * j + 1, ctab[co]);
     }
+    if constexpr (!FRESH) S_STAMP(1);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!FRESH) S_STAMP(2);
 
     f32x16 acc[4];
 #pragma unroll
@@ -1004,6 +1007,7 @@ __device__ __forceinline__ void gate_rs_splitk_tile(ARGS& a, const int tile, con
 #undef K_ISSUE_B_AT
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if constexpr (!FRESH) S_STAMP(3);
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     if (kh == 1) {
@@ -1038,6 +1042,7 @@ __device__ __forceinline__ void gate_rs_splitk_tile(ARGS& a, const int tile, con
             }
     }
     __syncthreads();                                       // partial accumulators consumed, gated tile published
+    if constexpr (!FRESH) S_STAMP(4);
 #pragma unroll
     for (int k = 0; k < 8; ++k) *reinterpret_cast<k_f32x4*>(lds + K_RED + t * 4 + k * 1024) = rsw[k];
     if (kh == 1) {
@@ -1064,6 +1069,7 @@ __device__ __forceinline__ void gate_rs_splitk_tile(ARGS& a, const int tile, con
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[j], actv[s2 >> 4][r], acc2[j], 0, 0, 0);
     }
+    if constexpr (!FRESH) S_STAMP(5);
     const float* rbias = lds + K_BIAS + 128;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -1085,6 +1091,7 @@ __device__ __forceinline__ void gate_rs_splitk_tile(ARGS& a, const int tile, con
             }
         }
     }
+    if constexpr (!FRESH) S_STAMP_DRAIN(7);
 }
 
 template <int SEGS>
