@@ -955,8 +955,19 @@ __device__ __forceinline__ void gate_rs_splitk_tile(ARGS& a, const int tile, con
     asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(a13[(ks) & 1]) : "v"((aaddr) + 128u), "n"(4 * (ks)), "n"(4 * (ks) + 1)); \
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bq[(ks) & 1]) : "v"(baddr), "n"(2 * (ks) * K_BN * 4));
 #define K_WAIT(n_, ks) asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(a02[(ks) & 1]), "+v"(a13[(ks) & 1]), "+v"(bq[(ks) & 1]));
+#ifdef CTTS_EXP_NO_LDSREAD    /* scripts/micro/wf_splitk_timeline.hip only: the loop's matrix work on stale registers */
+#undef K_READ_AT
+#undef K_WAIT
+#define K_READ_AT(ks, aaddr, baddr)
+#define K_WAIT(n_, ks) asm volatile("" : "+v"(a02[(ks) & 1]), "+v"(a13[(ks) & 1]), "+v"(bq[(ks) & 1]));
+#endif
+#ifdef CTTS_EXP_NO_MFMA       /* scripts/micro/wf_splitk_timeline.hip only: the loop without its matrix work */
+#define K_MFMA_ON false
+#else
+#define K_MFMA_ON true
+#endif
 #define K_MFMA(ks)                                                                                               \
-    if (active) {                                                                                                \
+    if (K_MFMA_ON && active) {                                                                                                \
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a02[(ks) & 1][0], bq[(ks) & 1], acc[0], 0, 0, 0);           \
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a13[(ks) & 1][0], bq[(ks) & 1], acc[1], 0, 0, 0);           \
         acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a02[(ks) & 1][1], bq[(ks) & 1], acc[2], 0, 0, 0);           \
@@ -975,19 +986,26 @@ __device__ __forceinline__ void gate_rs_splitk_tile(ARGS& a, const int tile, con
         asm volatile("ds_read_b64 %0, %1" : "=v"(ub_e) : "v"((unsigned)(lds0 + K_CHTAB * 4 + ne * 8)));
         asm volatile("ds_read_b64 %0, %1" : "=v"(ub_o) : "v"((unsigned)(lds0 + K_CHTAB * 4 + no * 8)));
         // outstanding: k-step 0 (3 instructions) and the two table entries
-        K_READ_AT(1, aa, ba) K_WAIT(5, 0) K_MFMA(0) K_ISSUE_A(2 * nb, ne, 0);
+#ifdef CTTS_EXP_NO_DMA        /* ... only: the loop without re-filling its stages (stale operands) */
+#define K_LOOP_ISSUE_A(cs, c, p)
+#define K_LOOP_ISSUE_B(cs, ub)
+#else
+#define K_LOOP_ISSUE_A(cs, c, p) K_ISSUE_A(cs, c, p)
+#define K_LOOP_ISSUE_B(cs, ub) K_ISSUE_B_AT(cs, ub)
+#endif
+        K_READ_AT(1, aa, ba) K_WAIT(5, 0) K_MFMA(0) K_LOOP_ISSUE_A(2 * nb, ne, 0);
         __builtin_amdgcn_sched_barrier(0);
         K_READ_AT(2, aa, ba) K_WAIT(3, 1)                   // (covers the older table entries)
         asm volatile("" : "+v"(ub_e), "+v"(ub_o));
-        K_MFMA(1) K_ISSUE_A(2 * nb, ne, 1);
+        K_MFMA(1) K_LOOP_ISSUE_A(2 * nb, ne, 1);
         __builtin_amdgcn_sched_barrier(0);
-        K_READ_AT(3, aa, ba) K_WAIT(3, 2) K_MFMA(2) K_ISSUE_B_AT(2 * nb, ub_e);
+        K_READ_AT(3, aa, ba) K_WAIT(3, 2) K_MFMA(2) K_LOOP_ISSUE_B(2 * nb, ub_e);
         __builtin_amdgcn_sched_barrier(0);
-        K_READ_AT(4, aa, ba) K_WAIT(3, 3) K_MFMA(3) K_ISSUE_A(2 * nb + 1, no, 0);
+        K_READ_AT(4, aa, ba) K_WAIT(3, 3) K_MFMA(3) K_LOOP_ISSUE_A(2 * nb + 1, no, 0);
         __builtin_amdgcn_sched_barrier(0);
-        K_READ_AT(5, aa, ba) K_WAIT(3, 4) K_MFMA(4) K_ISSUE_A(2 * nb + 1, no, 1);
+        K_READ_AT(5, aa, ba) K_WAIT(3, 4) K_MFMA(4) K_LOOP_ISSUE_A(2 * nb + 1, no, 1);
         __builtin_amdgcn_sched_barrier(0);
-        K_READ_AT(6, aa, ba) K_WAIT(3, 5) K_MFMA(5) K_ISSUE_B_AT(2 * nb + 1, ub_o);
+        K_READ_AT(6, aa, ba) K_WAIT(3, 5) K_MFMA(5) K_LOOP_ISSUE_B(2 * nb + 1, ub_o);
         __builtin_amdgcn_sched_barrier(0);
         K_READ_AT(7, aa, ba) K_WAIT(3, 6) K_MFMA(6)
         __builtin_amdgcn_sched_barrier(0);
@@ -1005,6 +1023,9 @@ __device__ __forceinline__ void gate_rs_splitk_tile(ARGS& a, const int tile, con
 #undef K_MFMA
 #undef K_ISSUE_A
 #undef K_ISSUE_B_AT
+#undef K_LOOP_ISSUE_A
+#undef K_LOOP_ISSUE_B
+#undef K_MFMA_ON
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if constexpr (!FRESH) S_STAMP(3);

@@ -6,6 +6,8 @@
 //   published | 5 second GEMM done | 7 stores acknowledged
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DCTTS_SMALL_GEMM_STAMPS -I include -I cookietts_amd/csrc \
 //       scripts/micro/wf_splitk_timeline.hip -o /tmp/wf_splitk_timeline && /tmp/wf_splitk_timeline
+// Variants of the main loop (timing only, results garbage): -DCTTS_EXP_NO_MFMA (no matrix work), -DCTTS_EXP_NO_DMA (stages
+// never re-filled), -DCTTS_EXP_NO_LDSREAD (operands stay in registers).  profiles/r4_19_wf_splitk_timeline.txt.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
