@@ -605,10 +605,11 @@ constexpr int WF_TILE = 256;          // columns per region unit: every launch s
 #define WF_NBIG 2                     // big regions per layer (2: A | M | B on three streams)
 #endif
 constexpr int WF_NREG = 2 * WF_NBIG - 1;     // regions incl. the one-tile separators: big 0, sep 0, big 1, sep 1, ...
-// The row queue is taken from this many 128-column items per layer on: more than one per CU.  Up to there a layer is one wave's
-// serial chain however it is launched (config 4, batch 1 and 2: 38 / 58 ms per call either way) and the per-layer launches stay.
+// The row queue is taken from this many 128-column items per layer on.  Below, a layer is one wave's serial chain however it is
+// launched (config 4, batch 1 = 113 items: 37.2 ms per call per layer, 38.3 queued); at batch 2 (226 items) the whole-flow queue
+// is 2 % ahead (56.9 against 58.3 ms).
 #ifndef WF_ROW_QUEUE_MIN_ITEMS
-#define WF_ROW_QUEUE_MIN_ITEMS 257
+#define WF_ROW_QUEUE_MIN_ITEMS 200
 #endif
 #ifndef WF_ROW_QUEUE_MAX_ITEMS
 #define WF_ROW_QUEUE_MAX_ITEMS 1400

@@ -282,7 +282,7 @@ size_t ctts_waveflow_workspace_bytes(const ctts_waveflow_config* cfg, int32_t ba
  *
  * How a row of the recurrence is launched (C = 64 models; results of the forms agree bit for bit within one tile shape, see
  * "Which loop a launch really runs" below): one launch per fused layer (small sizes: a layer is one wave's serial chain),
- * or - from 257 column tiles of 128 per layer on (batch 3 at 900 frames) up to 1400 - the ROW QUEUE: ALL rows of a flow (each
+ * or - from 200 column tiles of 128 per layer on (batch 2 at 900 frames) up to 1400 - the ROW QUEUE: ALL rows of a flow (each
  * row = its n_layers fused layers + a tail stage: end conv, affine update of the next latent row, the next row's start conv) as
  * ONE launch whose workgroups take (row, stage, tile) items from an atomic counter in order and wait, per item, for the flags
  * of the neighbouring tiles of the previous stage only.  Items are claimed in order, so the oldest unfinished item can
@@ -653,8 +653,8 @@ int ctts_taco_stop_rule_f32(const float* gate_logits, int32_t batch, int32_t gat
  *
  * Which loop a launch really runs also depends on its SHAPE (all of it deterministic in the arguments, none of it in the
  * environment): the fused WaveFlow layer (C = 64) runs the fp32-MFMA split-K shape whenever ntiles * batch <= 128
- * (B <= 2 at 900 frames) under EVERY mode - and, under fp32 MFMA, as the item body of the row queue while a layer has 257-399
- * column tiles of 128 (B = 3 at 900 frames) - and the fused separable layer (C = 128) runs fp32 MFMA under CTTS_GEMM_BF16X6;
+ * (B <= 2 at 900 frames) under EVERY mode - and, under fp32 MFMA, as the item body of the row queue while a layer has 200-399
+ * column tiles of 128 (B = 2-3 at 900 frames) - and the fused separable layer (C = 128) runs fp32 MFMA under CTTS_GEMM_BF16X6;
  * the split-K shape sums in a different order than the other shapes, so the same utterance is bit-identical across
  * batch sizes only within one shape (CTTS_F32_NO_SPLITK: one K order at every size).  ctts_last_gemm_loop() reports what the most recent conv-GEMM launch of the calling
  * thread ran, so that a benchmark row can label itself: bits 0-3 = split level (0 fp32 MFMA, 3, 6), bit 4 = small shape,
