@@ -783,8 +783,11 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
     const int q_min = tuning().wf_row_queue_min >= 0 ? tuning().wf_row_queue_min : WF_ROW_QUEUE_MIN_ITEMS;
     // (upper bound: from ~1400 items per layer on - batch 16 at 900 frames: 326 ms against 319 - the per-layer launches on the
     // 128 x 256 shape with the region split are ahead again: more work per workgroup, and a layer's tail is small against it)
+    // (the queue's tile bodies are the fp32-MFMA DMA-staged ones: under the split-bf16 modes, CTTS_F32_NO_GLDS or CTTS_F32_NO_SMALL
+    // the layers are launched one by one as before)
     bool queue_on = fuse && !p.sep && !tuning().wf_no_row_queue && q_items >= q_min &&
-                    (q_items < WF_ROW_QUEUE_MAX_ITEMS || tuning().wf_row_queue_min >= 0);
+                    (q_items < WF_ROW_QUEUE_MAX_ITEMS || tuning().wf_row_queue_min >= 0) &&
+                    !gemm_mode_is_split(p.c.f32_gemm_mode) && !tuning().f32_no_glds && !tuning().f32_no_small;
     // Which tile body (measured, profiles/r4_12): below 400 items of 128 columns per layer the split-K body (items of 128 x 64, half
     // the serial chain each: 97 -> 77 ms at batch 3 x 900 frames, 95 -> 66 at 8 x 300); the 128 x 128 body from there on
     int q_body = 0;

@@ -133,3 +133,23 @@ def test_row_queue_two_streams_share_the_chip(hip_lib_path, tuning):
     torch.cuda.synchronize()
     for got_a, got_b in outs:
         assert torch.equal(got_a, ref_a) and torch.equal(got_b, ref_b)
+
+
+def test_split_bf16_modes_keep_the_per_layer_launches(hip_lib_path, tuning):
+    """The queue's tile bodies are fp32-MFMA only: a model that asks for the split-bf16 loops at a queue-eligible size runs
+    its layers one launch at a time (and still agrees with the fp32 result to the mode's accuracy) instead of failing."""
+    from conftest import rms_rel_err
+    from cookietts_amd import _lib
+    m = _model()
+    z, mel = _inputs(5, 600, seed=9)                       # 5 x 600 frames: 375 tiles of 128 columns per layer (> 1 per CU)
+    ref, _ = m.inverse(z, mel, return_CPU=False)
+    assert _lib.lib().ctts_last_gemm_loop() & 64
+    for mode, tol in (("bf16x3", 1e-4), ("bf16x6", 5e-6)):
+        m.set_f32_gemm_mode(mode)
+        got, _ = m.inverse(z, mel, return_CPU=False)
+        code = _lib.lib().ctts_last_gemm_loop()
+        assert not code & 64 and (code & 15) == (3 if mode == "bf16x3" else 6)
+        d = rms_rel_err(got.cpu().numpy(), ref.cpu().numpy())
+        print(f"config 4, 5 x 600 frames under {mode}: rms rel diff vs fp32 MFMA {d:.2e}")
+        assert d < tol
+    m.set_f32_gemm_mode("f32")
