@@ -83,7 +83,7 @@ def test_row_queue_abort_is_loud(hip_lib_path, tuning):
     assert torch.equal(again, good)
 
 
-@pytest.mark.parametrize("key", ["toy", "toy_dilations", "toy_conv_early", "kh1"])
+@pytest.mark.parametrize("key", ["toy", "toy_dilations", "toy_conv_early", "kh1", "merge"])
 @pytest.mark.parametrize("precond", [False, True])
 def test_row_queue_on_the_goldens_configs(hip_lib_path, tuning, key, precond):
     """Queue forced on small golden configurations, with the conditioning folded into the in-layer GEMM (a K segment) and handed
@@ -92,7 +92,13 @@ def test_row_queue_on_the_goldens_configs(hip_lib_path, tuning, key, precond):
     from cookietts_amd import _lib
     from cookietts_amd.waveglow_ax import WaveGlow
     # "kh1": a 1 x 3 kernel = at most four K segments per layer: the kernels' four-segment instantiation
-    cfg = dict(synthetic.WAVEFLOW_CONFIGS[key]) if key != "kh1" else synthetic.waveflow_config(n_flows=2, n_group=8, n_layers=3, kernel_size_h=1)
+    # "merge": merge_res_skip with the tanh-sigmoid unit (every layer reads the start outputs, all rows are skip rows)
+    if key == "kh1":
+        cfg = synthetic.waveflow_config(n_flows=2, n_group=8, n_layers=3, kernel_size_h=1)
+    elif key == "merge":
+        cfg = synthetic.waveflow_config(n_flows=2, n_group=8, n_layers=3, WN=dict(merge_res_skip=True))
+    else:
+        cfg = dict(synthetic.WAVEFLOW_CONFIGS[key])
     if precond:
         cfg.update(shift_spect=2.0, scale_spect=0.5)
     m = WaveGlow(**cfg)
