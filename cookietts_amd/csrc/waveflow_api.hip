@@ -612,7 +612,7 @@ constexpr int WF_NREG = 2 * WF_NBIG - 1;     // regions incl. the one-tile separ
 #define WF_ROW_QUEUE_MIN_ITEMS 200
 #endif
 #ifndef WF_ROW_QUEUE_MAX_ITEMS
-#define WF_ROW_QUEUE_MAX_ITEMS 1400
+#define WF_ROW_QUEUE_MAX_ITEMS 1250
 #endif
 #ifndef WF_ROW_QUEUE_SPLITK_BELOW
 #define WF_ROW_QUEUE_SPLITK_BELOW 400
@@ -781,8 +781,9 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
     // built on the host, copied once per flow, and a row's launch points at its slice.
     const int q_items = wf_row_tiles(L, 0) * batch;
     const int q_min = tuning().wf_row_queue_min >= 0 ? tuning().wf_row_queue_min : WF_ROW_QUEUE_MIN_ITEMS;
-    // (upper bound: from ~1400 items per layer on - batch 16 at 900 frames: 326 ms against 319 - the per-layer launches on the
-    // 128 x 256 shape with the region split are ahead again: more work per workgroup, and a layer's tail is small against it)
+    // (upper bound: from ~1250 items per layer on - batch 10 at 900 frames: 204.0 ms queued against 207.6, batch 12: 245.1 against
+    // 243.4, batch 16: 327 against 319 - the per-layer launches on the 128 x 256 shape with the region split are ahead again: more
+    // work per workgroup, and a layer's tail is small against it)
     // (the queue's tile bodies are the fp32-MFMA DMA-staged ones: under the split-bf16 modes, CTTS_F32_NO_GLDS or CTTS_F32_NO_SMALL
     // the layers are launched one by one as before)
     bool queue_on = fuse && !p.sep && !tuning().wf_no_row_queue && q_items >= q_min &&

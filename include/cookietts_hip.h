@@ -282,7 +282,7 @@ size_t ctts_waveflow_workspace_bytes(const ctts_waveflow_config* cfg, int32_t ba
  *
  * How a row of the recurrence is launched (C = 64 models; results of the forms agree bit for bit within one tile shape, see
  * "Which loop a launch really runs" below): one launch per fused layer (small sizes: a layer is one wave's serial chain),
- * or - from 200 column tiles of 128 per layer on (batch 2 at 900 frames) up to 1400 - the ROW QUEUE: ALL rows of a flow (each
+ * or - from 200 column tiles of 128 per layer on (batch 2 at 900 frames) up to 1250 - the ROW QUEUE: ALL rows of a flow (each
  * row = its n_layers fused layers + a tail stage: end conv, affine update of the next latent row, the next row's start conv) as
  * ONE launch whose workgroups take (row, stage, tile) items from an atomic counter in order and wait, per item, for the flags
  * of the neighbouring tiles of the previous stage only.  Items are claimed in order, so the oldest unfinished item can
