@@ -869,6 +869,115 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
         return a;
     };
 
+    // one row of the recurrence as one launch per layer (per-layer GEMM shapes, region split, separable / unfused forms)
+    auto per_layer_row = [&](const WfPlan::Flow& f, int r, int slot) -> int {
+        int rc = CTTS_OK;
+        if (rsplit.on && (rc = rsplit.begin_row(s))) return rc;
+        for (int i = 0; i < p.c.n_layers; ++i) {
+            const int dw = p.c.dilation_w[i] > 0 ? p.c.dilation_w[i] : 1 << i;
+            // merge_res_skip (glow_ax.py:612-626): no residual into `audio`, so every layer's queue holds the
+            // `start` outputs - layer i reads the ring of layer 0 and nothing is written to ring i+1
+            const bool merge = p.c.merge_res_skip != 0;
+            const int si = merge ? 0 : i;
+            const int dh = p.dh(i);                                   // height tap ah reads row r - (kh-1-ah)*dh
+            const int a_min = std::max(0, kh - 1 - r / dh);           // earlier rows do not exist: skip those taps
+            GemmArgs a{};
+            a.gate = p.c.gated_unit;
+            a.gemm_mode = p.c.f32_gemm_mode;
+            a.bm = WF_BM;
+            a.ld = g.ld; a.pad = g.pad; a.L = L; a.ntiles = g.ntiles; a.batch = batch;
+            a.dst_ld = g.ld; a.dst_pad = g.pad;
+            a.A = blob + f.in_A[i]; a.bias = blob + f.in_b[i];
+            a.a_nch_alloc = p.nch_in;
+            a.MB = p.in_mb(); a.M = 2 * C; a.pairC = C;
+            int ns = 0;
+            if (p.sep) {
+                WfSlots xs{};
+                for (int ah = a_min; ah < kh; ++ah) xs.p[ah] = X(si, (r - (kh - 1 - ah) * dh) % NS);
+                const dim3 vgrid(((L + 3) / 4 + 255) / 256, C, batch);
+                const bool vec = g.pad % 4 == 0 && g.ld % 4 == 0 && (dw <= 2 || dw % 4 == 0);
+                if (vec && kw == 7) launch_depthwise_vec<7>(vgrid, s, xs, blob + f.dw_w[i], blob + f.dw_b[i], w.dwout, C, kh, dw, a_min, L, g.ld, g.pad);
+                else if (vec && kw == 5) launch_depthwise_vec<5>(vgrid, s, xs, blob + f.dw_w[i], blob + f.dw_b[i], w.dwout, C, kh, dw, a_min, L, g.ld, g.pad);
+                else if (vec && kw == 3) launch_depthwise_vec<3>(vgrid, s, xs, blob + f.dw_w[i], blob + f.dw_b[i], w.dwout, C, kh, dw, a_min, L, g.ld, g.pad);
+                else
+                    hipLaunchKernelGGL(wf_depthwise_kernel, dim3((L + 255) / 256, C, batch), dim3(256), 0, s, xs,
+                                       blob + f.dw_w[i], blob + f.dw_b[i], w.dwout, C, kh, kw, dw, a_min, L, g.ld, g.pad);
+                CTTS_CHECK_LAUNCH("wf_depthwise");
+                if (sep_fuse) {
+                    WfSepArgs q{};
+                    q.dwout = w.dwout;
+                    q.A1 = blob + f.sA1[i]; q.b1 = blob + f.sb1[i]; q.A2 = blob + f.sA2[i]; q.b2 = blob + f.sb2[i];
+                    q.cond = w.cond_up + (size_t)i * w.cond_slot;
+                    q.xin = X(si, slot);
+                    q.xout = (i == p.c.n_layers - 1 || merge) ? nullptr : X(i + 1, slot);
+                    q.gate = p.c.gated_unit;
+                    q.split_bf16 = gemm_split_level(p.c.f32_gemm_mode) == 3 ? 1 : 0;   // (x6: the fused separable layer stays on fp32 MFMA)
+                    q.out = w.out; q.acc_out = i > 0 ? 1 : 0; q.rs_rows = p.rs_rows(i);
+                    q.L = L; q.ld = g.ld; q.pad = g.pad; q.ntiles = (L + 63) / 64;
+                    if ((rc = launch_wf_sep_layer(q, batch, s))) return rc;
+                    note_gemm_loop(q.split_bf16 ? 3 : 0);
+                    continue;
+                }
+                a.a_ch_off = 0;
+                a.seg[ns++] = {w.dwout, cstride, p.nch_c, 0, 0, 0};
+                a.nch_total = p.nch_c;
+            } else {
+                a.a_ch_off = a_min * kw * p.nch_c;
+                for (int ah = a_min; ah < gkh; ++ah) {
+                    const int src_row = r - (kh - 1 - ah) * dh;
+                    for (int j = 0; j < gkw; ++j)
+                        a.seg[ns++] = {X(si, src_row % NS), cstride, p.nch_c, (j - kw / 2) * dw, 0, 0};
+                }
+                a.nch_total = (kh - a_min) * kw * p.nch_c;
+            }
+            if (p.precond) {
+                a.addend = w.cond_up + (size_t)i * w.cond_slot;
+                a.addend_bstride = (long long)2 * C * g.ld;
+            } else {
+                a.seg[ns++] = {w.mel_up, (long long)p.kmel * g.ld, p.kmel / GEMM_KC, 0, 0, 0};
+                a.nch_total += p.kmel / GEMM_KC;
+            }
+            a.nseg = ns;
+            const bool last = i == p.c.n_layers - 1 || merge;       // all rows of the res/skip GEMM are skip rows
+            if (fuse) {
+                if (!p.sep) a = fused_args(f, r, i, 0);
+                else {
+                    // x_{i+1}[row r] = x_i[row r] + res -> layer i+1's ring slot;  skip rows (+)= into w.out
+                    a.rs_wT = blob + f.rs_T[i]; a.rs_bias = blob + f.rs_Tb[i]; a.rs_rows = p.rs_rows(i);
+                    a.dst0 = last ? w.out : X(i + 1, slot); a.dst0_bstride = cstride; a.acc0 = 1;
+                    a.src0 = X(si, slot); a.src0_bstride = cstride;
+                    a.dst1 = w.out; a.dst1_bstride = cstride; a.acc1 = i > 0 ? 1 : 0;
+                    a.split = last ? 0 : C;
+                }
+                if (rsplit.on) {
+                    if ((rc = rsplit.layer(a, i, s))) return rc;
+                    continue;
+                }
+                if ((rc = launch_gemm_f32(GEMM_EPI_GATE_RS, a, s))) return rc;
+                continue;
+            }
+            a.dst0 = w.act; a.dst0_bstride = cstride;
+            if ((rc = launch_gemm_f32(GEMM_EPI_GATE, a, s))) return rc;
+
+            GemmArgs q{};
+            q.gemm_mode = p.c.f32_gemm_mode;
+            q.bm = WF_BM;
+            q.ld = g.ld; q.pad = g.pad; q.L = L; q.ntiles = g.ntiles; q.batch = batch;
+            q.dst_ld = g.ld; q.dst_pad = g.pad;
+            q.A = blob + f.rs_A[i]; q.bias = blob + f.rs_b[i];
+            q.nseg = 1; q.nch_total = p.nch_c; q.MB = p.rs_mb(i); q.M = p.rs_rows(i);
+            q.seg[0] = {w.act, cstride, p.nch_c, 0, 0, 0};
+            // x_{i+1}[row r] = x_i[row r] + res : written into layer i+1's ring slot (its queue entry)
+            q.dst0 = last ? w.out : X(i + 1, slot); q.dst0_bstride = cstride; q.acc0 = 1;
+            q.src0 = X(si, slot); q.src0_bstride = cstride;
+            q.dst1 = w.out; q.dst1_bstride = cstride; q.acc1 = i > 0 ? 1 : 0;
+            q.split = last ? 0 : C;
+            if ((rc = launch_gemm_f32(GEMM_EPI_SPLIT, q, s))) return rc;
+        }
+        if (rsplit.on && (rc = rsplit.end_row(s))) return rc;
+        return CTTS_OK;
+    };
+
     for (int k = p.c.n_flows - 1; k >= 0; --k) {
         const auto& f = p.fl[k];
         if (!p.c.mix_first && (rc = unmix(k))) return rc;                      // ax:324-325
@@ -930,110 +1039,8 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
                 if ((rc = launch_wf_row_persistent(w.q.layers + (size_t)r * p.c.n_layers, nullptr, 1, p.c.n_layers, q_max_nseg, L, batch, q_body,
                                                    w.q.counters + li, w.q.flags, w.q.abort_word, li + 1, s)))
                     return rc;
-            } else {
-            if (rsplit.on && (rc = rsplit.begin_row(s))) return rc;
-            for (int i = 0; i < p.c.n_layers; ++i) {
-                const int dw = p.c.dilation_w[i] > 0 ? p.c.dilation_w[i] : 1 << i;
-                // merge_res_skip (glow_ax.py:612-626): no residual into `audio`, so every layer's queue holds the
-                // `start` outputs - layer i reads the ring of layer 0 and nothing is written to ring i+1
-                const bool merge = p.c.merge_res_skip != 0;
-                const int si = merge ? 0 : i;
-                const int dh = p.dh(i);                                   // height tap ah reads row r - (kh-1-ah)*dh
-                const int a_min = std::max(0, kh - 1 - r / dh);           // earlier rows do not exist: skip those taps
-                GemmArgs a{};
-                a.gate = p.c.gated_unit;
-                a.gemm_mode = p.c.f32_gemm_mode;
-                a.bm = WF_BM;
-                a.ld = g.ld; a.pad = g.pad; a.L = L; a.ntiles = g.ntiles; a.batch = batch;
-                a.dst_ld = g.ld; a.dst_pad = g.pad;
-                a.A = blob + f.in_A[i]; a.bias = blob + f.in_b[i];
-                a.a_nch_alloc = p.nch_in;
-                a.MB = p.in_mb(); a.M = 2 * C; a.pairC = C;
-                int ns = 0;
-                if (p.sep) {
-                    WfSlots xs{};
-                    for (int ah = a_min; ah < kh; ++ah) xs.p[ah] = X(si, (r - (kh - 1 - ah) * dh) % NS);
-                    const dim3 vgrid(((L + 3) / 4 + 255) / 256, C, batch);
-                    const bool vec = g.pad % 4 == 0 && g.ld % 4 == 0 && (dw <= 2 || dw % 4 == 0);
-                    if (vec && kw == 7) launch_depthwise_vec<7>(vgrid, s, xs, blob + f.dw_w[i], blob + f.dw_b[i], w.dwout, C, kh, dw, a_min, L, g.ld, g.pad);
-                    else if (vec && kw == 5) launch_depthwise_vec<5>(vgrid, s, xs, blob + f.dw_w[i], blob + f.dw_b[i], w.dwout, C, kh, dw, a_min, L, g.ld, g.pad);
-                    else if (vec && kw == 3) launch_depthwise_vec<3>(vgrid, s, xs, blob + f.dw_w[i], blob + f.dw_b[i], w.dwout, C, kh, dw, a_min, L, g.ld, g.pad);
-                    else
-                        hipLaunchKernelGGL(wf_depthwise_kernel, dim3((L + 255) / 256, C, batch), dim3(256), 0, s, xs,
-                                           blob + f.dw_w[i], blob + f.dw_b[i], w.dwout, C, kh, kw, dw, a_min, L, g.ld, g.pad);
-                    CTTS_CHECK_LAUNCH("wf_depthwise");
-                    if (sep_fuse) {
-                        WfSepArgs q{};
-                        q.dwout = w.dwout;
-                        q.A1 = blob + f.sA1[i]; q.b1 = blob + f.sb1[i]; q.A2 = blob + f.sA2[i]; q.b2 = blob + f.sb2[i];
-                        q.cond = w.cond_up + (size_t)i * w.cond_slot;
-                        q.xin = X(si, slot);
-                        q.xout = (i == p.c.n_layers - 1 || merge) ? nullptr : X(i + 1, slot);
-                        q.gate = p.c.gated_unit;
-                        q.split_bf16 = gemm_split_level(p.c.f32_gemm_mode) == 3 ? 1 : 0;   // (x6: the fused separable layer stays on fp32 MFMA)
-                        q.out = w.out; q.acc_out = i > 0 ? 1 : 0; q.rs_rows = p.rs_rows(i);
-                        q.L = L; q.ld = g.ld; q.pad = g.pad; q.ntiles = (L + 63) / 64;
-                        if ((rc = launch_wf_sep_layer(q, batch, s))) return rc;
-                        note_gemm_loop(q.split_bf16 ? 3 : 0);
-                        continue;
-                    }
-                    a.a_ch_off = 0;
-                    a.seg[ns++] = {w.dwout, cstride, p.nch_c, 0, 0, 0};
-                    a.nch_total = p.nch_c;
-                } else {
-                    a.a_ch_off = a_min * kw * p.nch_c;
-                    for (int ah = a_min; ah < gkh; ++ah) {
-                        const int src_row = r - (kh - 1 - ah) * dh;
-                        for (int j = 0; j < gkw; ++j)
-                            a.seg[ns++] = {X(si, src_row % NS), cstride, p.nch_c, (j - kw / 2) * dw, 0, 0};
-                    }
-                    a.nch_total = (kh - a_min) * kw * p.nch_c;
-                }
-                if (p.precond) {
-                    a.addend = w.cond_up + (size_t)i * w.cond_slot;
-                    a.addend_bstride = (long long)2 * C * g.ld;
-                } else {
-                    a.seg[ns++] = {w.mel_up, (long long)p.kmel * g.ld, p.kmel / GEMM_KC, 0, 0, 0};
-                    a.nch_total += p.kmel / GEMM_KC;
-                }
-                a.nseg = ns;
-                const bool last = i == p.c.n_layers - 1 || merge;       // all rows of the res/skip GEMM are skip rows
-                if (fuse) {
-                    if (!p.sep) a = fused_args(f, r, i, 0);
-                    else {
-                        // x_{i+1}[row r] = x_i[row r] + res -> layer i+1's ring slot;  skip rows (+)= into w.out
-                        a.rs_wT = blob + f.rs_T[i]; a.rs_bias = blob + f.rs_Tb[i]; a.rs_rows = p.rs_rows(i);
-                        a.dst0 = last ? w.out : X(i + 1, slot); a.dst0_bstride = cstride; a.acc0 = 1;
-                        a.src0 = X(si, slot); a.src0_bstride = cstride;
-                        a.dst1 = w.out; a.dst1_bstride = cstride; a.acc1 = i > 0 ? 1 : 0;
-                        a.split = last ? 0 : C;
-                    }
-                    if (rsplit.on) {
-                        if ((rc = rsplit.layer(a, i, s))) return rc;
-                        continue;
-                    }
-                    if ((rc = launch_gemm_f32(GEMM_EPI_GATE_RS, a, s))) return rc;
-                    continue;
-                }
-                a.dst0 = w.act; a.dst0_bstride = cstride;
-                if ((rc = launch_gemm_f32(GEMM_EPI_GATE, a, s))) return rc;
-
-                GemmArgs q{};
-                q.gemm_mode = p.c.f32_gemm_mode;
-                q.bm = WF_BM;
-                q.ld = g.ld; q.pad = g.pad; q.L = L; q.ntiles = g.ntiles; q.batch = batch;
-                q.dst_ld = g.ld; q.dst_pad = g.pad;
-                q.A = blob + f.rs_A[i]; q.bias = blob + f.rs_b[i];
-                q.nseg = 1; q.nch_total = p.nch_c; q.MB = p.rs_mb(i); q.M = p.rs_rows(i);
-                q.seg[0] = {w.act, cstride, p.nch_c, 0, 0, 0};
-                // x_{i+1}[row r] = x_i[row r] + res : written into layer i+1's ring slot (its queue entry)
-                q.dst0 = last ? w.out : X(i + 1, slot); q.dst0_bstride = cstride; q.acc0 = 1;
-                q.src0 = X(si, slot); q.src0_bstride = cstride;
-                q.dst1 = w.out; q.dst1_bstride = cstride; q.acc1 = i > 0 ? 1 : 0;
-                q.split = last ? 0 : C;
-                if ((rc = launch_gemm_f32(GEMM_EPI_SPLIT, q, s))) return rc;
-            }
-            if (rsplit.on && (rc = rsplit.end_row(s))) return rc;
+            } else if ((rc = per_layer_row(f, r, slot))) {
+                return rc;
             }
             hipLaunchKernelGGL(wf_tail_kernel, dim3((g.Lr + 255) / 256, batch), dim3(256), 0, s, w.out, w.rows,
                                blob + f.end_w, blob + f.end_b, C, G, phys[r + 1], L, g.Lr, g.ld, g.pad);
