@@ -143,6 +143,8 @@ struct GemmArgs {
     const float* rs_wT;   // GEMM_EPI_GATE_RS: res/skip weight transposed and row-padded: [64][128]
     const float* rs_bias; // [128] (rows >= rs_rows zero)
     int rs_rows;          // 128 (res + skip) or 64 (last layer: skip only)
+    int gt_limit;         // set by the launcher: column tiles (tile + ntiles * batch item) this launch covers, counted from 0 (the
+                          // tiles behind it went to a separate small-shape launch: launch_gemm_f32, "round-aligned")
     long long shape_blocks;   // > 0: the launch is a PART of a larger one (a column region): choose the block shape as if the
                           // grid had this many large blocks, so that every part sums K in the order of the whole launch
 };

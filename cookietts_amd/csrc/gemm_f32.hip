@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
         const int x = id & 7, j = id >> 3;
         mb = 2 * (x & 1) + (j & 1);
         const int gt = (j >> 1) * 4 + (x >> 1);
-        if (gt >= a.ntiles * a.batch) return;            // whole workgroup: grid is rounded up to 4 tiles
+        if (gt >= a.gt_limit) return;                    // whole workgroup: grid is rounded up to 4 tiles
         tile = gt % a.ntiles;
         b = gt / a.ntiles;
     } else {
@@ -736,6 +736,7 @@ void load_tuning_locked() {
     g_tune.f32_no_small = on("CTTS_F32_NO_SMALL");
     g_tune.f32_force_small = on("CTTS_F32_FORCE_SMALL");
     g_tune.f32_no_splitk = on("CTTS_F32_NO_SPLITK");
+    g_tune.f32_no_round_split = on("CTTS_F32_NO_ROUND_SPLIT");
     g_tune.no_xcd_pair = on("CTTS_GEMM_NO_XCD_PAIR");
     g_tune.bf16_no_glds = on("CTTS_BF16_NO_GLDS");
     g_tune.bf16_no_wide = on("CTTS_BF16_NO_WIDE");
@@ -810,17 +811,47 @@ int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
     GemmArgs a = a_in;
     gemm_apply_defaults(a);
     if (int rc = gemm_check_args(epi, a)) return rc;
-    long long blocks = (long long)a.MB * a.ntiles * a.batch;
+    if (epi == GEMM_EPI_GATE && a.gate != GATE_GTU) epi = GEMM_EPI_GATEX;
+    if (gemm_f32_small_applies(epi, a)) return launch_gemm_f32_small(epi, a, stream);
+    long long tiles = (long long)a.ntiles * a.batch;         // column tiles of the launch, tile + ntiles * batch item
+    // Round-aligned launch.  Two workgroups share a CU, so a launch runs in rounds of 2 x CUs workgroups; one whose count is a
+    // little above a whole number of rounds ends with a round that a few CUs run alone.  Measured on the headline's in-layer
+    // launch (scripts/micro/headline_gemm.hip): 7168 workgroups = 14 rounds 5.99 ms, 7200 = 14.06 rounds 6.20 ms - 0.21 ms for
+    // 0.45 % more work.  The tiles beyond the last whole round (they lie at the end of the last batch item) go to a launch of
+    // the small-problem shape FIRST - a quarter of the tile per workgroup, so they spread over every CU; same packed operands,
+    // same K order: bit-identical - and this launch covers the rest.  CTTS_F32_NO_ROUND_SPLIT = one launch.
+    if (a.bm == 256 && epi != GEMM_EPI_GATE_RS && a.addend_frames == 0 && a.shape_blocks == 0 && !tuning().f32_no_round_split &&
+        !tuning().f32_no_glds && !tuning().f32_no_small && a.nch_total <= GEMM_GLDS_MAX_CHUNKS) {
+        const long long slots = 2ll * wf_row_cus();
+        const long long rounds = a.MB * tiles / slots;
+        const long long rem_tiles = (a.MB * tiles - rounds * slots + a.MB - 1) / a.MB;
+        if (rounds >= 2 && rem_tiles > 0 && rem_tiles * a.MB <= slots * 3 / 10 && rem_tiles < a.ntiles) {
+            GemmArgs r = a;                                    // the last rem_tiles column tiles of the last batch item
+            const int bn = gemm_bn(a.bm);
+            const long long co = (long long)(a.ntiles - rem_tiles) * bn;
+            const long long bo = a.batch - 1;
+            for (int j = 0; j < r.nseg; ++j) r.seg[j].base += bo * r.seg[j].bstride + co;
+            if (r.dst0) r.dst0 += bo * r.dst0_bstride + co;
+            if (r.dst1) r.dst1 += bo * r.dst1_bstride + co;
+            if (r.src0) r.src0 += bo * r.src0_bstride + co;
+            if (r.addend) r.addend += bo * r.addend_bstride + co;
+            r.L = a.L - (int)co;
+            r.ntiles = (int)rem_tiles;
+            r.batch = 1;
+            if (int rc = launch_gemm_f32_small(epi, r, stream)) return rc;
+            tiles -= rem_tiles;
+        }
+    }
+    a.gt_limit = (int)tiles;
+    long long blocks = (long long)a.MB * tiles;
     a.map_mode = 0;
     // measured on config 2 (PMC FETCH_SIZE per in-layer launch): 4.2 GB -> 2.5 GB at unchanged speed
     if (a.MB == 4 && epi != GEMM_EPI_GATE_RS && !tuning().no_xcd_pair) {
         a.map_mode = 1;
-        blocks = 16ll * (((long long)a.ntiles * a.batch + 3) / 4);
+        blocks = 16ll * ((tiles + 3) / 4);
     }
     CTTS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "gemm: grid %lld", blocks);
     dim3 grid((unsigned)blocks);
-    if (epi == GEMM_EPI_GATE && a.gate != GATE_GTU) epi = GEMM_EPI_GATEX;
-    if (gemm_f32_small_applies(epi, a)) return launch_gemm_f32_small(epi, a, stream);
     note_gemm_loop((tuning().f32_no_glds || a.nch_total > GEMM_GLDS_MAX_CHUNKS) ? 0 : gemm_split_level(a.gemm_mode));
     switch (epi) {
         case GEMM_EPI_GATEX: launch_shape<GEMM_EPI_GATEX>(a.bm, grid, stream, a); break;

@@ -677,7 +677,7 @@ int ctts_tuning_reload(void);
 /* The knobs as the library currently sees them: bit 0 CTTS_F32_NO_GLDS, 1 CTTS_GEMM_NO_XCD_PAIR, 2 CTTS_BF16_NO_GLDS,
  * 3 CTTS_BF16_NO_WIDE, 4 CTTS_BF16_NO_PP, 5 CTTS_BF16_W4, 6 CTTS_BF16_PP_STAGES=4, 7 CTTS_WF_NO_FUSE, 8 CTTS_TACO_NO_FUSE,
  * 9 CTTS_F32_NO_SMALL, 10 CTTS_F32_FORCE_SMALL, 11 CTTS_F32_NO_SPLITK, 12 CTTS_WF_NO_VEC_INTERP, 13 CTTS_F32_NO_DEFER_SKIP, 14 CTTS_WF_NO_REGION_SPLIT,
- * 15 CTTS_WF_NO_ROW_QUEUE, 16 CTTS_WF_ROW_QUEUE_MIN set, 17 CTTS_WF_INJECT_ABORT, 18 CTTS_WF_QUEUE_DEBUG != 0 (tests assert that a knob they set is the
+ * 15 CTTS_WF_NO_ROW_QUEUE, 16 CTTS_WF_ROW_QUEUE_MIN set, 17 CTTS_WF_INJECT_ABORT, 18 CTTS_WF_QUEUE_DEBUG != 0, 19 CTTS_F32_NO_ROUND_SPLIT (tests assert that a knob they set is the
  * one in effect). */
 int ctts_tuning_flags(void);
 

@@ -20,13 +20,16 @@ namespace ctts {
 void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 bool gemm_f32_small_applies(int, const GemmArgs&) { return false; }
 int launch_gemm_f32_small(int, const GemmArgs&, hipStream_t) { return CTTS_E_ARG; }
+int wf_row_cus() { return 256; }
 }  // namespace ctts
 using namespace ctts;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 int main(int argc, char** argv) {
     const char* label = argc > 1 ? argv[1] : "product";
-    const int C = 512, CC = 256, B = 8, L = 28800, PADC = 128, layers = 8;
+    setenv("CTTS_F32_NO_ROUND_SPLIT", "1", 1);           // this file times ONE large-shape launch (the small shape is not linked in)
+    const int C = 512, CC = 256, B = 8, PADC = 128, layers = 8;
+    const int L = getenv("HG_L") ? atoi(getenv("HG_L")) : 28800;      // (multiples of 128; 28 672 = exactly 14 rounds of 512 workgroups)
     const int ld = L + 2 * PADC;
     const int nch = 3 * C / GEMM_KC + CC / GEMM_KC;      // 112
     const size_t a_tile = (size_t)GEMM_KC * 256;
@@ -67,6 +70,7 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(st));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double flop = 2.0 * 1024 * (double)(nch * GEMM_KC) * (double)B * L;
+    printf("L = %d: %d workgroups = %.3f rounds of 512;  ", L, 4 * (L / 128) * B, 4.0 * (L / 128) * B / 512.0);
     printf("%-34s %.4f ms per launch  %.1f TFLOP/s  %.4f of 157.3\n", label, ms / reps, flop / (ms / reps * 1e-3) / 1e12, flop / (ms / reps * 1e-3) / 157.3e12);
     return 0;
 }
