@@ -283,6 +283,11 @@ def wn_roofline(lib, cfg, dtype, gemm_mode, B, F, steps, elapsed, config_key="fu
                                    f"launch shape, not re-measured in this run") if traffic_src else None,
                 "launches": int(n.value), "mean_launch_ms": round(mean_s * 1e3, 4),
                 "flop_per_launch": flop_per_launch}
+    if dtype == "f32" and not _lib.tuning_active("CTTS_F32_NO_ROUND_SPLIT"):
+        # round-aligned launches (gemm_f32.hip launch_gemm_f32): the timed span of a launch covers BOTH kernels it may consist of
+        roofline["launch_parts"] = ("a launch = conv_gemm_f32_kernel on the column tiles of its whole rounds of 2 x CUs workgroups "
+                                    "+, first, conv_gemm_f32_small_kernel on the few tiles beyond them (config 2: 1792 + 8 of 1800 "
+                                    "tiles); mean_launch_ms spans both, flop_per_launch is the whole launch's")
     if products > 1:
         roofline["note"] = (f"flop_per_launch counts the {products} executed bf16 products per algorithmic MAC; "
                             f"algorithmic flops are 1/{products} of it")
