@@ -56,7 +56,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
 # HBM bytes per in-layer launch from committed PMC passes (2 x FETCH_SIZE (gfx950 half-count correction,
 # calibrated on flow_tail) + WRITE_SIZE) of the exact launch shapes named in the file; not re-measured inside a bench run
 # (PMC collection needs its own rocprofv3 passes: scripts/pmc3.sh).
-TRAFFIC_FILES = ["r3_pmc_traffic.json", "r1_17_pmc_traffic.json"]
+TRAFFIC_FILES = ["r4_pmc_traffic.json", "r3_pmc_traffic.json", "r1_17_pmc_traffic.json"]
 
 
 def load_traffic():
