@@ -23,11 +23,6 @@ def test_config2_waveglow_full_size_properties(hip_lib_path, tuning):
     full = m.infer_from_noise(mel, z)
     assert full.shape == (B, F * 256) and torch.isfinite(full).all()
     assert torch.equal(full, m.infer_from_noise(mel, z))                      # deterministic, workspace reused
-    # round-aligned launches (the tiles beyond the last whole round of workgroups run on the small shape: 8 of 1800 tiles per
-    # WN launch here) against one large-shape launch each: the same bits
-    tuning.set("CTTS_F32_NO_ROUND_SPLIT")
-    assert torch.equal(full, m.infer_from_noise(mel, z))
-    tuning.clear("CTTS_F32_NO_ROUND_SPLIT")
     for b in (0, 7):                                                           # utterances do not interact
         assert torch.equal(m.infer_from_noise(mel[b:b + 1], z[b:b + 1])[0], full[b])
     # locality: a WN sees +-255 steps, 12 flows -> 3060 steps = 96 frames; frames 0..299 of a 600-frame cut must
@@ -173,11 +168,6 @@ def test_config3_bf16_full_size_properties(hip_lib_path):
     full = m.infer_from_noise(mel, z)
     assert full.shape == (B, F * 256) and torch.isfinite(full).all()
     assert torch.equal(full, m.infer_from_noise(mel, z))                      # deterministic, workspace reused
-    # round-aligned launches (the tiles beyond the last whole round of workgroups run on the small shape: 8 of 1800 tiles per
-    # WN launch here) against one large-shape launch each: the same bits
-    tuning.set("CTTS_F32_NO_ROUND_SPLIT")
-    assert torch.equal(full, m.infer_from_noise(mel, z))
-    tuning.clear("CTTS_F32_NO_ROUND_SPLIT")
     for b in (0, 17, 31):                                                      # utterances do not interact
         assert torch.equal(m.infer_from_noise(mel[b:b + 1].contiguous(), z[b:b + 1].contiguous())[0], full[b])
     # locality (receptive field 96 frames): the first 300 frames of a 600-frame cut reproduce the full run
