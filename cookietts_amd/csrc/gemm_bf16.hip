@@ -88,6 +88,39 @@ __device__ __forceinline__ void build_chunk_table(const BGemmArgs& a, unsigned l
              16ull * ((size_t)(mb * (mbr / 8) + 4 * local) * a.ld + a.pad + n0 + shift);
 }
 
+// Block id -> (m-block, column tile, batch item).  Workgroup ids go round-robin over the 8 XCDs (id % 8), each with a
+// private L2, and all m-blocks of a column tile read the same B tile:
+//   map_mode 1 (MB == 4): XCD x owns the m-block pair {2(x&1), 2(x&1)+1} of the column tiles 4q + (x>>1), the two
+//     m-blocks of a tile on ids 8 apart: the B tile goes through 2 private L2s instead of 4 (and each L2 holds half of A);
+//   map_mode 2 (MB == 2): XCD x owns BOTH m-blocks of the column tiles 8q + x, on ids 8 apart: the B tile of the
+//     memory-bound res / skip GEMMs is fetched from HBM once instead of twice (round 5: FETCH_SIZE of these launches was
+//     the B bytes twice plus the read-modify-write destination, profiles/r3_01_pmc_config3_bf16_b32.json);
+//   map_mode 3 (MB == 4, experiment CTTS_BF16_MAP=2): all four m-blocks of a tile on one XCD.
+// Returns false for the ids beyond the last tile (the grid is rounded up to whole groups).
+__device__ __forceinline__ bool block_map(const BGemmArgs& a, int id, int& mb, int& tile, int& b) {
+    int gt;
+    if (a.map_mode == 1) {
+        const int x = id & 7, j = id >> 3;
+        mb = 2 * (x & 1) + (j & 1);
+        gt = (j >> 1) * 4 + (x >> 1);
+    } else if (a.map_mode == 2) {
+        const int x = id & 7, j = id >> 3;
+        mb = j & 1;
+        gt = (j >> 1) * 8 + x;
+    } else if (a.map_mode == 3) {
+        const int x = id & 7, j = id >> 3;
+        mb = j & 3;
+        gt = (j >> 2) * 8 + x;
+    } else {
+        mb = id % a.MB;
+        gt = id / a.MB;
+    }
+    if (gt >= a.ntiles * a.batch) return false;
+    tile = gt % a.ntiles;
+    b = gt / a.ntiles;
+    return true;
+}
+
 // Epilogue shared by the block shapes.  32x32 C/D layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5):
 // for a fixed register group q = r>>2 the lane holds 4 consecutive channels (8q + 4*lhi + 0..3) of one column,
 // i.e. half of a 16-byte K8 unit, lanes l and l+32 complete the unit.  The natural 8-byte accesses are
@@ -223,23 +256,8 @@ __global__ __launch_bounds__(128 * NW, 2) void conv_gemm_bf16_kernel(const BGemm
     const int wm = wave / NW, wn = wave % NW;
     const int l31 = lane & 31, lhi = lane >> 5;
 
-    int id = blockIdx.x;
     int mb, tile, b;
-    if (a.map_mode == 1) {
-        // MB == 4: XCD x (= id % 8) owns the m-block pair {2(x&1), 2(x&1)+1} of the column tiles t = 4q + (x>>1), the
-        // two m-blocks of a tile on consecutive ids: the B tile goes through 2 private L2s instead of 4
-        const int x = id & 7, j = id >> 3;
-        mb = 2 * (x & 1) + (j & 1);
-        const int gt = (j >> 1) * 4 + (x >> 1);
-        if (gt >= a.ntiles * a.batch) return;            // whole workgroup: the grid is rounded up to 4 tiles
-        tile = gt % a.ntiles;
-        b = gt / a.ntiles;
-    } else {
-        mb = id % a.MB;
-        id /= a.MB;
-        tile = id % a.ntiles;
-        b = id / a.ntiles;
-    }
+    if (!block_map(a, blockIdx.x, mb, tile, b)) return;     // whole workgroup
     const int n0 = tile * BN;
 
     // per-thread B staging: units (g, n) with g = t / BN (+2), n = t % BN, relative to the chunk's table entry
@@ -395,23 +413,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_bf16_pp_kernel(const BGemmAr
     const int wm = wave >> 2, wn = wave & 3;                // wm = which half (leading 0 / lagging 1)
     const int l31 = lane & 31, lhi = lane >> 5;
 
-    int id = blockIdx.x;
     int mb, tile, b;
-    if (a.map_mode == 1) {
-        // MB == 4: XCD x (= id % 8) owns the m-block pair {2(x&1), 2(x&1)+1} of the column tiles t = 4q + (x>>1), the
-        // two m-blocks of a tile on consecutive ids: the B tile goes through 2 private L2s instead of 4
-        const int x = id & 7, j = id >> 3;
-        mb = 2 * (x & 1) + (j & 1);
-        const int gt = (j >> 1) * 4 + (x >> 1);
-        if (gt >= a.ntiles * a.batch) return;            // whole workgroup: the grid is rounded up to 4 tiles
-        tile = gt % a.ntiles;
-        b = gt / a.ntiles;
-    } else {
-        mb = id % a.MB;
-        id /= a.MB;
-        tile = id % a.ntiles;
-        b = id / a.ntiles;
-    }
+    if (!block_map(a, blockIdx.x, mb, tile, b)) return;     // whole workgroup
     const int n0 = tile * BN;
     const int nch = a.nch_total;
 
@@ -571,21 +574,8 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_w4_kernel(const BGemmArgs 
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
 
-    int id = blockIdx.x;
     int mb, tile, b;
-    if (a.map_mode == 1) {                                  // see conv_gemm_bf16_pp_kernel
-        const int x = id & 7, j = id >> 3;
-        mb = 2 * (x & 1) + (j & 1);
-        const int gt = (j >> 1) * 4 + (x >> 1);
-        if (gt >= a.ntiles * a.batch) return;
-        tile = gt % a.ntiles;
-        b = gt / a.ntiles;
-    } else {
-        mb = id % a.MB;
-        id /= a.MB;
-        tile = id % a.ntiles;
-        b = id / a.ntiles;
-    }
+    if (!block_map(a, blockIdx.x, mb, tile, b)) return;
     const int n0 = tile * BN;
     const int nch = a.nch_total;
 
@@ -814,9 +804,16 @@ int launch_gemm_bf16(int epi, const BGemmArgs& a, hipStream_t stream) {
                    "gemm_bf16: M=%d pairC=%d MB=%d split=%d", b.M, b.pairC, b.MB, b.split);
     long long blocks = (long long)b.MB * b.ntiles * b.batch;
     b.map_mode = 0;
-    if (b.MB == 4 && !tune.no_xcd_pair) {
+    const long long tiles = (long long)b.ntiles * b.batch;
+    if (b.MB == 4 && !tune.no_xcd_pair && tune.bf16_map == 2) {
+        b.map_mode = 3;
+        blocks = 32ll * ((tiles + 7) / 8);
+    } else if (b.MB == 4 && !tune.no_xcd_pair) {
         b.map_mode = 1;
-        blocks = 16ll * (((long long)b.ntiles * b.batch + 3) / 4);
+        blocks = 16ll * ((tiles + 3) / 4);
+    } else if (b.MB == 2 && !tune.no_xcd_pair && tune.bf16_map != 1) {
+        b.map_mode = 2;
+        blocks = 16ll * ((tiles + 7) / 8);
     }
     CTTS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "gemm_bf16: grid %lld", blocks);
     const dim3 grid((unsigned)blocks);

@@ -1,0 +1,240 @@
+// What the bf16 in-layer conv-GEMM's per-chunk instruction mix sustains on MI355X, stage by stage.
+//
+// The product kernel (cookietts_amd/csrc/gemm_bf16.hip conv_gemm_bf16_pp_kernel) runs, per K chunk of 32 and per wave,
+// 16 v_mfma_f32_32x32x16_bf16 + 12 ds_read_b128 + 4 global_load_lds_dwordx4 + one s_barrier, 8 waves per workgroup (two per
+// SIMD, the halves skewed by one phase), one workgroup per CU.  This file issues exactly that mix with the stages switched on
+// one at a time, on ZERO and on RANDOM operands, and prints TFLOP/s, the shader clock the chip sustained (s_memtime over
+// s_memrealtime) and cycles per MFMA per SIMD (32 = the matrix pipe never idles):
+//   mode 0  registers only: the 16 MFMAs of a chunk on 8 + 4 resident fragments
+//   mode 1  + the 12 fragment reads per chunk from a 3-stage LDS ring, skewed halves, one barrier per chunk
+//   mode 2  + the LDS-DMA staging of the next-but-one chunk (A from a 3.7 MB L2-resident image, B streamed from a 0.95 GB
+//           tensor through the same chunk -> address table), counted vmcnt: the product kernel's main loop without its epilogue,
+//           on the product grid (4 m-blocks x 113 column tiles x 32 utterances, 56 chunks)
+// hipcc --offload-arch=gfx950 -O3 -o bf16_mix_ceiling bf16_mix_ceiling.hip && ./bf16_mix_ceiling
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) u32x4* gunit_ptr;
+typedef __attribute__((address_space(3))) u32x4* lds_ptr;
+typedef unsigned long long u64;
+
+constexpr int NT = 512, BM = 256, BN = 256, A_UNITS = 4 * BM, B_UNITS = 4 * BN, STAGE_UNITS = A_UNITS + B_UNITS, NS = 3;
+constexpr int MAX_CHUNKS = 64;
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void mix_kernel(const u32x4* __restrict__ A, const u32x4* __restrict__ Bm,
+                                                     const long long* __restrict__ tab_g, long long bstride_units, int ld,
+                                                     int ntiles, int nch, float* __restrict__ out, u64* __restrict__ clk) {
+    __shared__ __attribute__((aligned(16))) u32x4 lds[NS * STAGE_UNITS + MAX_CHUNKS / 2];
+    u64* tab = reinterpret_cast<u64*>(lds + NS * STAGE_UNITS);
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, lhi = lane >> 5;
+
+    int mb = 0, tile = 0, b = 0;
+    if (MODE == 2) {                                        // the product kernel's XCD-paired block map (MB == 4)
+        const int id = blockIdx.x, x = id & 7, j = id >> 3;
+        mb = 2 * (x & 1) + (j & 1);
+        const int gt = (j >> 1) * 4 + (x >> 1);
+        tile = gt % ntiles;
+        b = gt / ntiles;
+        if (t < nch) tab[t] = (u64)(Bm + b * bstride_units + tile * BN + tab_g[t]);
+    } else {
+        // fill the ring once from the A image (random or zero): the fragments read below are real data
+        for (int u = t; u < NS * STAGE_UNITS; u += NT) lds[u] = A[u];
+    }
+    const unsigned boff0 = (unsigned)(((t >> 8) * ld + (t & 255)) * 16), boff1 = boff0 + (unsigned)(2 * ld * 16);
+    const unsigned aoff0 = (unsigned)(t * 16), aoff1 = aoff0 + NT * 16;
+    typedef const __attribute__((address_space(1))) char* gbyte_ptr;
+    const gbyte_ptr abase = (gbyte_ptr)A + (size_t)mb * nch * (A_UNITS * 16);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+#define PP_DMA(buf, c, ub)                                                                      \
+    do {                                                                                        \
+        lds_ptr la_ = (lds_ptr)(lds + (buf) * STAGE_UNITS + wave * 64);                         \
+        const gbyte_ptr ac_ = abase + (size_t)(c) * (A_UNITS * 16);                             \
+        __builtin_amdgcn_global_load_lds((gunit_ptr)(ac_ + aoff0), la_, 16, 0, 0);              \
+        __builtin_amdgcn_global_load_lds((gunit_ptr)(ac_ + aoff1), la_ + NT, 16, 0, 0);         \
+        const gbyte_ptr bc_ = (gbyte_ptr)(ub);                                                  \
+        __builtin_amdgcn_global_load_lds((gunit_ptr)(bc_ + boff0), la_ + A_UNITS, 16, 0, 0);    \
+        __builtin_amdgcn_global_load_lds((gunit_ptr)(bc_ + boff1), la_ + A_UNITS + NT, 16, 0, 0); \
+    } while (0)
+#define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define UNIFORM64(v) \
+    (((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)((v) >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(v)))
+
+    __syncthreads();
+    u64 ub = 0;
+    if (MODE == 2) {
+#pragma unroll
+        for (int c = 0; c < NS - 1; ++c) { ub = UNIFORM64(tab[c]); PP_DMA(c, c, ub); }
+        WAIT_VM(4 * (NS - 2));
+        ub = UNIFORM64(tab[NS - 1]);
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wm) __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_sched_barrier(0);
+
+    u32x4 av[2][4], bv[2][2];
+#define LOAD_FRAGS()                                                                            \
+    do {                                                                                        \
+        const u32x4* As = lds + cur * STAGE_UNITS + wm * 128 + l31;                             \
+        const u32x4* Bs = lds + cur * STAGE_UNITS + A_UNITS + wn * 64 + l31;                    \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                      \
+            const int grp = 2 * ks + lhi;                                                       \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) av[ks][mt] = As[grp * BM + mt * 32]; \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) bv[ks][nt] = Bs[grp * BN + nt * 32]; \
+        }                                                                                       \
+    } while (0)
+#define MFMA16()                                                                                \
+    do {                                                                                        \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                    \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                \
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                      \
+                        *reinterpret_cast<const bf16x8*>(&av[ks][mt]),                          \
+                        *reinterpret_cast<const bf16x8*>(&bv[ks][nt]), acc[mt][nt], 0, 0, 0);   \
+    } while (0)
+
+    int cur = 0;
+    const u64 c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    if (MODE == 0) {
+        LOAD_FRAGS();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int ch = 0; ch < nch; ++ch) {
+            MFMA16();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if (!wm) {
+        for (int ch = 0; ch < nch; ++ch) {                  // leading half: [LOAD ch | COMPUTE ch]
+            LOAD_FRAGS();
+            u64 tnext = 0;
+            if (MODE == 2) {
+                tnext = tab[ch + NS < MAX_CHUNKS ? ch + NS : 0];
+                if (ch + NS - 1 < nch) { const int nb = cur >= 1 ? cur - 1 : NS - 1; PP_DMA(nb, ch + NS - 1, ub); }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            MFMA16();
+            if (MODE == 2) ub = UNIFORM64(tnext);
+            __builtin_amdgcn_sched_barrier(0);
+            if (MODE == 2) { if (ch + NS - 1 < nch) WAIT_VM(4 * (NS - 2)); else WAIT_VM(0); }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            cur = cur == NS - 1 ? 0 : cur + 1;
+        }
+    } else {
+        for (int ch = 0; ch < nch; ++ch) {                  // lagging half: [COMPUTE ch-1 | LOAD ch]
+            if (ch > 0) MFMA16();
+            __builtin_amdgcn_sched_barrier(0);
+            LOAD_FRAGS();
+            u64 tnext = 0;
+            if (MODE == 2) {
+                tnext = tab[ch + NS < MAX_CHUNKS ? ch + NS : 0];
+                if (ch + NS - 1 < nch) { const int nb = cur >= 1 ? cur - 1 : NS - 1; PP_DMA(nb, ch + NS - 1, ub); }
+                if (ch + NS - 1 < nch) WAIT_VM(4 * (NS - 2)); else WAIT_VM(0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (MODE == 2) ub = UNIFORM64(tnext);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            cur = cur == NS - 1 ? 0 : cur + 1;
+        }
+        MFMA16();
+    }
+    const u64 c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (wm) __builtin_amdgcn_s_setprio(0);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    if (s == 12345.678f) out[blockIdx.x * NT + t] = s;       // keep the accumulators alive, store (almost) never
+    if (t == 0 && blockIdx.x == (MODE == 2 ? 4001 : 17)) { clk[0] = c1 - c0; clk[1] = r1 - r0; }
+}
+
+static unsigned short bf16_bits(float f) {
+    unsigned int u;
+    memcpy(&u, &f, 4);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+int main() {
+    // product shapes of config 3's in-layer launch: M = 1024 (4 m-blocks), K = 1792 (56 chunks: 3 taps x 16 slabs interleaved,
+    // then 8 slabs of the conditioning hidden), B = 32 utterances x 28 800 columns (113 tiles of 256), ld = 28 928 + 2 x 128
+    const int nch = 56, ntiles = 113, batch = 32, ld = 113 * 256 + 256, pad = 128, C8 = 64 + 32;
+    const size_t a_units = (size_t)4 * nch * A_UNITS;                         // 3.67 MB
+    const long long bstride = (long long)C8 * ld;                             // units per utterance (x: 64 groups, h: 32)
+    const size_t b_units = (size_t)batch * bstride;                           // 1.4 GB
+    std::vector<long long> tab(nch);
+    for (int c = 0; c < nch; ++c) {
+        if (c < 48) { const int tap = c % 3, slab = c / 3; tab[c] = (long long)(4 * slab) * ld + pad + (tap - 1) * 4; }
+        else tab[c] = (long long)(64 + 4 * (c - 48)) * ld + pad;
+    }
+    u32x4 *A, *Bm; long long* tab_d; float* out; u64* clk;
+    CHECK(hipMalloc(&A, a_units * 16)); CHECK(hipMalloc(&Bm, b_units * 16)); CHECK(hipMalloc(&tab_d, nch * 8));
+    CHECK(hipMalloc(&out, (size_t)16384 * NT * 4)); CHECK(hipMalloc(&clk, 16));
+    CHECK(hipMemcpy(tab_d, tab.data(), nch * 8, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+
+    printf("%-44s %-7s %9s %9s %10s %8s\n", "mode", "data", "ms", "TFLOP/s", "clock MHz", "cyc/MFMA");
+    for (int data = 0; data < 2; ++data) {
+        if (data == 0) { CHECK(hipMemset(A, 0, a_units * 16)); CHECK(hipMemset(Bm, 0, b_units * 16)); }
+        else {
+            // weights ~ N(0, 0.05), activations ~ N(0, 1): what a WN layer sees
+            std::vector<unsigned short> h(a_units * 8);
+            unsigned long long st = 88172645463325252ull;
+            auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (double)(st >> 11) / 9007199254740992.0; };
+            auto gauss = [&]() { double s = 0; for (int i = 0; i < 12; ++i) s += rnd(); return (float)(s - 6.0); };
+            for (auto& v : h) v = bf16_bits(0.05f * gauss());
+            CHECK(hipMemcpy(A, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+            std::vector<unsigned short> hb((size_t)1 << 24);                  // 32 MB of random activations, tiled over B
+            for (auto& v : hb) v = bf16_bits(gauss());
+            for (size_t off = 0; off < b_units * 16; off += hb.size() * 2) {
+                const size_t n = std::min(hb.size() * 2, b_units * 16 - off);
+                CHECK(hipMemcpy((char*)Bm + off, hb.data(), n, hipMemcpyHostToDevice));
+            }
+        }
+        for (int mode = 0; mode < 3; ++mode) {
+            const int wgs = mode == 2 ? 16 * ((ntiles * batch + 3) / 4) : 256;
+            const int chunks = mode == 2 ? nch : 20000;
+            float best = 1e30f; u64 h[2] = {0, 0};
+            for (int rep = 0; rep < (mode == 2 ? 6 : 3); ++rep) {
+                CHECK(hipEventRecord(e0));
+                if (mode == 0) hipLaunchKernelGGL(mix_kernel<0>, dim3(wgs), dim3(NT), 0, 0, A, Bm, tab_d, bstride, ld, ntiles, chunks, out, clk);
+                if (mode == 1) hipLaunchKernelGGL(mix_kernel<1>, dim3(wgs), dim3(NT), 0, 0, A, Bm, tab_d, bstride, ld, ntiles, chunks, out, clk);
+                if (mode == 2) hipLaunchKernelGGL(mix_kernel<2>, dim3(wgs), dim3(NT), 0, 0, A, Bm, tab_d, bstride, ld, ntiles, chunks, out, clk);
+                CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+                float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best) { best = ms; CHECK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost)); }
+            }
+            const double flops = 2.0 * 32 * 32 * 16 * 16.0 * 8 * chunks * (mode == 2 ? (double)4 * ntiles * batch : wgs);
+            const char* names[3] = {"0 registers only (16 MFMA / chunk / wave)", "1 + 12 ds_read_b128 / chunk, barrier, skew",
+                                    "2 + 4 LDS-DMA / chunk (product main loop)"};
+            // two waves per SIMD share the pipe: cycles per MFMA per SIMD = loop cycles / (chunks x 16 x 2)
+            printf("%-44s %-7s %9.3f %9.1f %10.0f %8.2f\n", names[mode], data ? "random" : "zeros", best, flops / best / 1e9,
+                   (double)h[0] / ((double)h[1] / 100.0), (double)h[0] / (chunks * 32.0));
+        }
+    }
+    return 0;
+}
