@@ -39,6 +39,30 @@ def _deps():
     return hdrs
 
 
+_INC = None
+
+
+def _includes(path, seen=None):
+    """Transitive ``#include "..."`` closure of one source (headers of csrc/ and include/): a header edit rebuilds only
+    the objects that see it."""
+    import re
+    global _INC
+    _INC = _INC or re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+    seen = set() if seen is None else seen
+    try:
+        text = open(path).read()
+    except OSError:
+        return seen
+    for inc in _INC.findall(text):
+        cand = os.path.normpath(os.path.join(os.path.dirname(path), inc))
+        if not os.path.exists(cand):
+            cand = os.path.join(INCLUDE, os.path.basename(inc))
+        if os.path.exists(cand) and cand not in seen:
+            seen.add(cand)
+            _includes(cand, seen)
+    return seen
+
+
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
@@ -52,14 +76,14 @@ def build(force=False, verbose=True):
         return LIB_PATH
     hipcc = _hipcc()
     os.makedirs(OBJ_DIR, exist_ok=True)
-    newest_hdr = max(os.path.getmtime(f) for f in _deps())
     objs = []
     procs = []
     for src in sources():
         obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if (not force and os.path.exists(obj)
-                and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_hdr)):
+        newest = max([os.path.getmtime(src), os.path.getmtime(os.path.abspath(__file__))] +
+                     [os.path.getmtime(h) for h in _includes(src)])
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > newest:
             continue
         cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-I", INCLUDE, "-c", src, "-o", obj]
         if verbose:

@@ -75,8 +75,10 @@ def scatter_mels(mels: Optional[torch.Tensor], n_mel: int, device, src: int = 0,
 
     Slices are padded to the largest shard so the collective is regular; the pad is cut
     off again before returning.  ``dtype=torch.bfloat16`` is the wire format SURVEY.md 8e names for config 3
-    (32 x 80 x 900 bf16 = 4.6 MB per rank, half the fp32 scatter): the bf16 WN path rounds the mel to bf16 at its first
-    GEMM anyway, so rounding it before the wire changes nothing downstream.  Every rank must pass the same ``dtype``.
+    (32 x 80 x 900 bf16 = 4.6 MB per rank, half the fp32 scatter).  The bf16 WN path rounds the mel to bf16 before its first
+    conditioning GEMM, which is the only consumer of the mel in ``glow.py`` WaveGlow, so for THAT model the wire rounding is
+    the rounding the model applies itself; a model that feeds the mel to an fp32 stage first (the ax core's upsampling
+    stack) would see a different input - keep fp32 on the wire there.  Every rank must pass the same ``dtype``.
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -101,14 +103,27 @@ def scatter_mels(mels: Optional[torch.Tensor], n_mel: int, device, src: int = 0,
     return recv[:counts[rank]], counts
 
 
-def gather_waves(wave: torch.Tensor, counts: Sequence[int], dst: int = 0, group=None):
-    """Every rank contributes ``wave`` [n_r, T]; rank ``dst`` gets [sum n_r, T], others None."""
+_WAVE_DTYPES = (torch.float32, torch.bfloat16, torch.float16, torch.int16)
+
+
+def gather_waves(wave: Optional[torch.Tensor], counts: Sequence[int], dst: int = 0, group=None, device=None):
+    """Every rank contributes ``wave`` [n_r, T]; rank ``dst`` gets [sum n_r, T], others None.
+
+    A rank whose share is empty (``counts[rank] == 0``) may pass ``None``: the slab width and dtype are agreed with one
+    16-byte MAX all-reduce, so such a rank never has to run an inference just to learn the output shape."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     cmax = max(max(counts), 1)
-    T = wave.shape[1]
-    send = torch.zeros(cmax, T, dtype=wave.dtype, device=wave.device)
-    send[:wave.shape[0]] = wave
+    if wave is not None:
+        device = wave.device
+    meta = torch.zeros(2, dtype=torch.int64, device=device)
+    if wave is not None and wave.shape[0] > 0:
+        meta[0], meta[1] = wave.shape[1], _WAVE_DTYPES.index(wave.dtype)
+    dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=group)
+    T, dtype = int(meta[0]), _WAVE_DTYPES[int(meta[1])]
+    send = torch.zeros(cmax, T, dtype=dtype, device=device)
+    if wave is not None and wave.shape[0] > 0:
+        send[:wave.shape[0]] = wave
     bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
     dist.gather(send, bufs, dst=dst, group=group)
     if rank != dst:
@@ -119,12 +134,8 @@ def gather_waves(wave: torch.Tensor, counts: Sequence[int], dst: int = 0, group=
 def sharded_infer(infer_fn: Callable[[torch.Tensor], torch.Tensor], mels: Optional[torch.Tensor],
                   n_mel: int, device, root: int = 0, group=None, wire_dtype=torch.float32):
     """scatter -> local ``infer_fn(mel_slice) -> [n_r, T]`` -> gather.  Returns waves on ``root``.
-    ``wire_dtype=torch.bfloat16`` ships the mels as bf16 (config 3); ``infer_fn`` receives that dtype."""
+    ``wire_dtype=torch.bfloat16`` ships the mels as bf16 (config 3); ``infer_fn`` receives that dtype.
+    A rank that received no utterance (fewer utterances than ranks) does not call ``infer_fn`` at all."""
     local, counts = scatter_mels(mels, n_mel, device, src=root, group=group, dtype=wire_dtype)
-    if local.shape[0] > 0:
-        wave = infer_fn(local)
-    else:   # this rank got no utterance: contribute an empty slab of the right width
-        frames = local.shape[2]
-        probe = infer_fn(torch.zeros(1, n_mel, frames, device=device, dtype=wire_dtype))
-        wave = probe[:0]
-    return gather_waves(wave, counts, dst=root, group=group)
+    wave = infer_fn(local) if local.shape[0] > 0 else None
+    return gather_waves(wave, counts, dst=root, group=group, device=device)

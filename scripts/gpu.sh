@@ -45,6 +45,6 @@ case "$task" in
     done ;;
   micro)
     tag=$1; shift
-    timeout 900 scripts/micro/bin/"$1" "${@:2}" > gpurun_out/${tag}.txt 2>&1; echo "rc=$?"; cat gpurun_out/${tag}.txt ;;
+    timeout ${MICRO_TIMEOUT:-300} scripts/micro/bin/"$1" "${@:2}" > gpurun_out/${tag}.txt 2>&1; echo "rc=$?"; cat gpurun_out/${tag}.txt ;;
   *) echo "unknown task $task"; exit 2 ;;
 esac

@@ -31,7 +31,12 @@ constexpr int MAX_CHUNKS = 64;
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <int MODE>
+// VAR (mode 2 only; experiments on where the staging's cycles go): bit 0 = no A DMA, bit 1 = no B DMA, bit 2 = never wait for
+// the DMA (vmcnt), bit 3 = every workgroup streams the SAME B tile (L2-resident: latency / bandwidth out of the picture)
+// FL (mode 2): how the LDS-DMA is addressed: 0 = global_load_lds as the compiler emits it (64-bit VGPR address), 1 = global_load_lds
+// with an SGPR base + one 32-bit VGPR offset, 2 = buffer_load ... lds with a 32-bit VGPR offset (offen), 3 = buffer_load ... lds with
+// NO VGPR: the resource adds lane * 16 B itself (ADD_TID_ENABLE, stride 16), every operand of the instruction is scalar
+template <int MODE, int VAR = 0, int FL = 0>
 __global__ __launch_bounds__(512, 2) void mix_kernel(const u32x4* __restrict__ A, const u32x4* __restrict__ Bm,
                                                      const long long* __restrict__ tab_g, long long bstride_units, int ld,
                                                      int ntiles, int nch, float* __restrict__ out, u64* __restrict__ clk) {
@@ -48,6 +53,7 @@ __global__ __launch_bounds__(512, 2) void mix_kernel(const u32x4* __restrict__ A
         const int gt = (j >> 1) * 4 + (x >> 1);
         tile = gt % ntiles;
         b = gt / ntiles;
+        if (VAR & 8) { tile = 0; b = 0; }
         if (t < nch) tab[t] = (u64)(Bm + b * bstride_units + tile * BN + tab_g[t]);
     } else {
         // fill the ring once from the A image (random or zero): the fragments read below are real data
@@ -66,17 +72,50 @@ __global__ __launch_bounds__(512, 2) void mix_kernel(const u32x4* __restrict__ A
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    // wave-uniform pieces of the same addresses (FL 3): A units wave * 64 (+512), B row group wave / 4 (+2), columns (wave & 3) * 64
+    const unsigned sa0 = (unsigned)(wave * 1024), sa1 = sa0 + NT * 16;
+    const unsigned sb0 = (unsigned)((((wave >> 2) * ld) + (wave & 3) * 64) * 16), sb1 = sb0 + (unsigned)(2 * ld * 16);
+    // with ADD_TID_ENABLE (bit 23 of word 3) the DATA_FORMAT bits are stride[17:14] on gfx9: leave them clear
+    const unsigned flags = FL == 3 ? (1u << 23) : 0x00020000u;
 #define PP_DMA(buf, c, ub)                                                                      \
     do {                                                                                        \
         lds_ptr la_ = (lds_ptr)(lds + (buf) * STAGE_UNITS + wave * 64);                         \
         const gbyte_ptr ac_ = abase + (size_t)(c) * (A_UNITS * 16);                             \
-        __builtin_amdgcn_global_load_lds((gunit_ptr)(ac_ + aoff0), la_, 16, 0, 0);              \
-        __builtin_amdgcn_global_load_lds((gunit_ptr)(ac_ + aoff1), la_ + NT, 16, 0, 0);         \
         const gbyte_ptr bc_ = (gbyte_ptr)(ub);                                                  \
-        __builtin_amdgcn_global_load_lds((gunit_ptr)(bc_ + boff0), la_ + A_UNITS, 16, 0, 0);    \
-        __builtin_amdgcn_global_load_lds((gunit_ptr)(bc_ + boff1), la_ + A_UNITS + NT, 16, 0, 0); \
+        if (FL == 0) {                                                                          \
+            if (!(VAR & 1)) {                                                                   \
+                __builtin_amdgcn_global_load_lds((gunit_ptr)(ac_ + aoff0), la_, 16, 0, 0);      \
+                __builtin_amdgcn_global_load_lds((gunit_ptr)(ac_ + aoff1), la_ + NT, 16, 0, 0); \
+            }                                                                                   \
+            if (!(VAR & 2)) {                                                                   \
+                __builtin_amdgcn_global_load_lds((gunit_ptr)(bc_ + boff0), la_ + A_UNITS, 16, 0, 0); \
+                __builtin_amdgcn_global_load_lds((gunit_ptr)(bc_ + boff1), la_ + A_UNITS + NT, 16, 0, 0); \
+            }                                                                                   \
+        } else if (FL == 1) {                                                                   \
+            unsigned a0_ = aoff0, a1_ = aoff1, b0_ = boff0, b1_ = boff1;                        \
+            asm volatile("" : "+v"(a0_), "+v"(a1_), "+v"(b0_), "+v"(b1_));                     \
+            __builtin_amdgcn_global_load_lds((gunit_ptr)(ac_ + a0_), la_, 16, 0, 0);            \
+            __builtin_amdgcn_global_load_lds((gunit_ptr)(ac_ + a1_), la_ + NT, 16, 0, 0);       \
+            __builtin_amdgcn_global_load_lds((gunit_ptr)(bc_ + b0_), la_ + A_UNITS, 16, 0, 0);  \
+            __builtin_amdgcn_global_load_lds((gunit_ptr)(bc_ + b1_), la_ + A_UNITS + NT, 16, 0, 0); \
+        } else {                                                                                \
+            const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)ac_, FL == 3 ? 16 : 0, 0x7fffffff, flags); \
+            const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)bc_, FL == 3 ? 16 : 0, 0x7fffffff, flags); \
+            if (FL == 2) {                                                                      \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, la_, 16, aoff0, 0, 0, 0);         \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, la_ + NT, 16, aoff1, 0, 0, 0);    \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, la_ + A_UNITS, 16, boff0, 0, 0, 0); \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, la_ + A_UNITS + NT, 16, boff1, 0, 0, 0); \
+            } else {                                                                            \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, la_, 16, 0, sa0, 0, 0);           \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, la_ + NT, 16, 0, sa1, 0, 0);      \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, la_ + A_UNITS, 16, 0, sb0, 0, 0); \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, la_ + A_UNITS + NT, 16, 0, sb1, 0, 0); \
+            }                                                                                   \
+        }                                                                                       \
     } while (0)
-#define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+    constexpr int PER = ((VAR & 1) ? 0 : 2) + ((VAR & 2) ? 0 : 2);   // DMAs per thread per chunk
+#define WAIT_VM(n) do { if (!(VAR & 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory"); } while (0)
 #define UNIFORM64(v) \
     (((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)((v) >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(v)))
 
@@ -85,7 +124,7 @@ __global__ __launch_bounds__(512, 2) void mix_kernel(const u32x4* __restrict__ A
     if (MODE == 2) {
 #pragma unroll
         for (int c = 0; c < NS - 1; ++c) { ub = UNIFORM64(tab[c]); PP_DMA(c, c, ub); }
-        WAIT_VM(4 * (NS - 2));
+        WAIT_VM(PER * (NS - 2));
         ub = UNIFORM64(tab[NS - 1]);
     }
     __builtin_amdgcn_s_barrier();
@@ -135,7 +174,7 @@ __global__ __launch_bounds__(512, 2) void mix_kernel(const u32x4* __restrict__ A
             MFMA16();
             if (MODE == 2) ub = UNIFORM64(tnext);
             __builtin_amdgcn_sched_barrier(0);
-            if (MODE == 2) { if (ch + NS - 1 < nch) WAIT_VM(4 * (NS - 2)); else WAIT_VM(0); }
+            if (MODE == 2) { if (ch + NS - 1 < nch) WAIT_VM(PER * (NS - 2)); else WAIT_VM(0); }
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             cur = cur == NS - 1 ? 0 : cur + 1;
@@ -149,7 +188,7 @@ __global__ __launch_bounds__(512, 2) void mix_kernel(const u32x4* __restrict__ A
             if (MODE == 2) {
                 tnext = tab[ch + NS < MAX_CHUNKS ? ch + NS : 0];
                 if (ch + NS - 1 < nch) { const int nb = cur >= 1 ? cur - 1 : NS - 1; PP_DMA(nb, ch + NS - 1, ub); }
-                if (ch + NS - 1 < nch) WAIT_VM(4 * (NS - 2)); else WAIT_VM(0);
+                if (ch + NS - 1 < nch) WAIT_VM(PER * (NS - 2)); else WAIT_VM(0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (MODE == 2) ub = UNIFORM64(tnext);
@@ -170,6 +209,7 @@ __global__ __launch_bounds__(512, 2) void mix_kernel(const u32x4* __restrict__ A
 #pragma unroll
             for (int r = 0; r < 16; ++r) s += acc[i][j][r];
     if (s == 12345.678f) out[blockIdx.x * NT + t] = s;       // keep the accumulators alive, store (almost) never
+    if ((VAR & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (t == 0 && blockIdx.x == (MODE == 2 ? 4001 : 17)) { clk[0] = c1 - c0; clk[1] = r1 - r0; }
 }
 
@@ -215,25 +255,38 @@ int main() {
                 CHECK(hipMemcpy((char*)Bm + off, hb.data(), n, hipMemcpyHostToDevice));
             }
         }
-        for (int mode = 0; mode < 3; ++mode) {
+        struct Row { int mode, var; const char* name; int fl = 0; };
+        const Row rows[] = {{0, 0, "0 registers only (16 MFMA / chunk / wave)"},
+                            {1, 0, "1 + 12 ds_read_b128 / chunk, barrier, skew"},
+                            {2, 0, "2 + 4 LDS-DMA / chunk (product main loop)"},
+                            {2, 4, "2 never waiting for the DMA (issue cost)"},
+                            {2, 8, "2 B tile L2-resident (no HBM latency)"},
+                            {2, 1, "2 B DMA only (2 / chunk)"},
+                            {2, 2, "2 A DMA only (2 / chunk)"},
+                            {2, 3, "2 no DMA issued (stale LDS)"},
+                            {2, 0, "2 DMA = global, SGPR base + 32-bit voffset", 1},
+                            {2, 0, "2 DMA = buffer_load offen lds", 2},
+                            {2, 0, "2 DMA = buffer_load lds, add-tid, no VGPR", 3}};
+        for (const Row& rw : rows) {
+            const int mode = rw.mode;
             const int wgs = mode == 2 ? 16 * ((ntiles * batch + 3) / 4) : 256;
             const int chunks = mode == 2 ? nch : 20000;
             float best = 1e30f; u64 h[2] = {0, 0};
-            for (int rep = 0; rep < (mode == 2 ? 6 : 3); ++rep) {
+            for (int rep = 0; rep < (mode == 2 ? 5 : 2); ++rep) {
                 CHECK(hipEventRecord(e0));
-                if (mode == 0) hipLaunchKernelGGL(mix_kernel<0>, dim3(wgs), dim3(NT), 0, 0, A, Bm, tab_d, bstride, ld, ntiles, chunks, out, clk);
-                if (mode == 1) hipLaunchKernelGGL(mix_kernel<1>, dim3(wgs), dim3(NT), 0, 0, A, Bm, tab_d, bstride, ld, ntiles, chunks, out, clk);
-                if (mode == 2) hipLaunchKernelGGL(mix_kernel<2>, dim3(wgs), dim3(NT), 0, 0, A, Bm, tab_d, bstride, ld, ntiles, chunks, out, clk);
+#define LAUNCH(M, V, F) if (mode == M && rw.var == V && rw.fl == F) hipLaunchKernelGGL((mix_kernel<M, V, F>), dim3(wgs), dim3(NT), 0, 0, A, Bm, tab_d, bstride, ld, ntiles, chunks, out, clk)
+                LAUNCH(0, 0, 0); LAUNCH(1, 0, 0); LAUNCH(2, 0, 0); LAUNCH(2, 4, 0); LAUNCH(2, 8, 0); LAUNCH(2, 1, 0); LAUNCH(2, 2, 0); LAUNCH(2, 3, 0);
+                LAUNCH(2, 0, 1); LAUNCH(2, 0, 2); LAUNCH(2, 0, 3);
+#undef LAUNCH
                 CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
                 float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
                 if (ms < best) { best = ms; CHECK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost)); }
             }
             const double flops = 2.0 * 32 * 32 * 16 * 16.0 * 8 * chunks * (mode == 2 ? (double)4 * ntiles * batch : wgs);
-            const char* names[3] = {"0 registers only (16 MFMA / chunk / wave)", "1 + 12 ds_read_b128 / chunk, barrier, skew",
-                                    "2 + 4 LDS-DMA / chunk (product main loop)"};
             // two waves per SIMD share the pipe: cycles per MFMA per SIMD = loop cycles / (chunks x 16 x 2)
-            printf("%-44s %-7s %9.3f %9.1f %10.0f %8.2f\n", names[mode], data ? "random" : "zeros", best, flops / best / 1e9,
+            printf("%-44s %-7s %9.3f %9.1f %10.0f %8.2f\n", rw.name, data ? "random" : "zeros", best, flops / best / 1e9,
                    (double)h[0] / ((double)h[1] / 100.0), (double)h[0] / (chunks * 32.0));
+            fflush(stdout);
         }
     }
     return 0;
