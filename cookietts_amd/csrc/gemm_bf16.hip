@@ -69,9 +69,10 @@ int launch_gemm_bf16(int epi, const BGemmArgs& a, hipStream_t stream) {
     long long blocks = (long long)b.MB * b.ntiles * b.batch;
     b.map_mode = 0;
     const long long tiles = (long long)b.ntiles * b.batch;
-    // persistent-stream kernel: one workgroup per CU walks its tile sequence (gemm_bf16_kernels.h); K of more than NS chunks
+    // persistent kernel: one workgroup per CU walks its tile sequence (gemm_bf16_kernels.h); K of more than NS chunks.
+    // Opt-in (CTTS_BF16_PS=1) while it measures equal to the per-tile kernel on random operands (profiles/r5_10).
     const int ps_stages = tune.bf16_ps_stages;
-    const bool ps = wide && pp && !w4 && !tune.bf16_no_ps && b.nch_total > ps_stages && tune.bf16_map != 2;
+    const bool ps = wide && pp && !w4 && tune.bf16_ps && b.nch_total > ps_stages && tune.bf16_map != 2;
     const int cus = ps ? wf_row_cus() : 0;
     int ps_grid = 0;
     if (b.MB == 4 && !tune.no_xcd_pair && tune.bf16_map == 2) {

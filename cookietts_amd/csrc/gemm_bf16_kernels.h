@@ -561,26 +561,27 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_bf16_pp_kernel(const BGemmAr
     bf16_epilogue<EPI>(a, acc, lds, t, mb, wm, wn, b, n0, l31, lhi);
 }
 
-// Persistent-stream form of the 256 x 256 block (round 5).  What the timelines of the skewed kernel above said
-// (scripts/micro/bf16_mix_ceiling.hip, profiles/r5_03): its LOAD phase (12 fragment reads + 4 LDS-DMA issues of ~60 stall
-// cycles each + the barrier) is longer than the 512 matrix-pipe cycles of the partner's COMPUTE phase, so the pipe idles
-// ~150 cycles per phase (41.6 cycles per MFMA and SIMD against 32), and every workgroup pays its own prologue (first DMA
-// latency, ~4 k cycles) and epilogue with nothing else resident on the CU (one workgroup of 100 KiB LDS per CU).  Here:
-//   * every wave is a self-contained software-pipelined stream (the four-wave kernel's schedule on 128 x 64 wave tiles):
-//     fragments double-buffered per k-step, every ds_read / DMA issued in the shadow of one MFMA, ONE barrier per chunk
-//     between the k-steps.  A wave stalled in a DMA issue is covered by its partner on the same SIMD (both always have
-//     MFMAs ready in registers) instead of lengthening a phase that the partner waits for;
-//   * ONE workgroup per CU walks a sequence of column tiles of one m-block (XCD-aware: the m-blocks of a column tile run
-//     on one XCD pair / one XCD at the same time) and the DMA cursor runs NS chunks ahead of the MFMAs ACROSS tile
-//     boundaries: the next tile's first chunks land while this tile's epilogue runs, the pipeline never drains;
+// Persistent form of the skewed 256 x 256 block (round 5).  The per-tile kernel above pays, per workgroup and with nothing
+// else resident on the CU (one workgroup of 100 KiB LDS per CU): the first DMA latency (~4 k cycles), the drain of the last
+// chunks and an epilogue, ~18 k of its ~84 k cycles per tile on config 3's in-layer launch (profiles/r5_08).  Here ONE
+// workgroup per CU walks a sequence of column tiles of one m-block (XCD-aware: the m-blocks of a column tile run on one XCD
+// pair / one XCD at the same time) and the chunk stream never stops at a tile boundary:
+//   * intervals are those of the skewed kernel, numbered over the whole stream: leading half [LOAD v | COMPUTE v], lagging
+//     half [COMPUTE v-1 | LOAD v], one barrier; the DMA of chunk v + NS - 1 is issued in interval v whichever tile it
+//     belongs to, so the next tile's first chunks land while this tile's epilogue runs;
+//   * a half runs its epilogue inside the interval that follows its last COMPUTE of the tile, after issuing that
+//     interval's DMA: the two halves' epilogues overlap each other and the lagging half's last COMPUTE;
 //   * bias staged once per workgroup (the m-block is fixed), chunk -> address tables double-buffered by tile parity and
-//     built one tile ahead by the threads that are otherwise idle.
-// Arithmetic and summation order are those of the skewed kernel: bit-identical results.
-// vmcnt: a thread issues 4 DMAs per chunk in stream order; "all but the newest 4(NS-2)" = chunk v+1 has landed.  The
-// epilogue's stores only ADD to the outstanding count (loads return in order), so the counted waits stay safe.
-__device__ unsigned long long g_ps_stamps[32];   // DBG: [wave half][{loop cycles, epilogue cycles, 100 MHz ticks of the loop, tile count}]
+//     built one tile ahead (when the DMA cursor enters tile k, the table of tile k + 1 is written over that of k - 1).
+// Arithmetic and summation order are those of the per-tile kernel: bit-identical results.
+// (An earlier form with every wave a self-contained software-pipelined stream - fragments double-buffered per k-step, DMA
+// issued between MFMAs - measured 39-41 cycles per MFMA and SIMD against this structure's 36.5: a DMA issued inside an
+// MFMA stream costs ~19 matrix-pipe cycles, in a LOAD phase ~2; profiles/r5_08_bf16_harness_stream_form.txt.)
+// vmcnt: a thread issues 4 DMAs per interval in stream order; "all but the newest 4 (NS - 2)" = chunk v + 1 has landed.
+// The epilogue's stores are younger than the interval's DMA and only ADD to the outstanding count: the waits stay safe.
+__device__ unsigned long long g_ps_stamps[32];   // DBG: [wave half][{tile cycles, epilogue cycles, 100 MHz ticks of the tile, tiles}]
 
-template <int EPI, int NS, int DBG = 0>   // DBG (harness only; 2 and 4 compute garbage): 1 = s_memtime stamps of workgroup 100, third tile, 2 = no DMA after the prologue, 4 = no barrier in the chunk
+template <int EPI, int NS, int DBG = 0>   // DBG (harness only): 1 = s_memtime stamps of workgroup 100, third tile
 __global__ __launch_bounds__(512) void conv_gemm_bf16_ps_kernel(const BGemmArgs a) {
     constexpr int NT = 512, BN = 256, MAXC = BGEMM_PP_MAX_CHUNKS;
     constexpr int B_UNITS = 4 * BN;
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16_ps_kernel(const BGemmArgs 
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave >> 2, wn = wave & 3;                // wm = which half (leading 0 / lagging 1)
     const int l31 = lane & 31, lhi = lane >> 5;
     const int nch = a.nch_total;
 
@@ -643,141 +644,181 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16_ps_kernel(const BGemmArgs 
     const gbyte_ptr abase = (gbyte_ptr)a.A + (size_t)mb * nch * (A_UNITS * 16);
 
     f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+#define CTTS_PS_ZERO()                                                                              \
+    do {                                                                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                            \
+            _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                        \
+                _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) acc[i_][j_][r_] = 0.0f;           \
+    } while (0)
+    CTTS_PS_ZERO();
 
     typedef __attribute__((address_space(3))) u32x4* lds_ptr;
-    // piece j of chunk c (A image: units t, t + 512; B rows: groups t / 256 and + 2) -> LDS stage buf
     // The address is a wave-uniform 64-bit base (SGPR pair) + a 32-bit per-lane offset: global_load_lds_dwordx4 v, s[a:b].
     // The offsets are laundered through an empty asm so that the compiler cannot fold them into loop-carried 64-bit VGPR
     // addresses (global_load_lds v[a:b], off): that form costs ~4 more matrix-pipe cycles per MFMA in this loop
     // (profiles/r5_07_bf16_mix_ceiling_dma_forms.txt: 41.0 -> 36.6 cycles per MFMA and SIMD).
-#define CTTS_PS_DMA1(buf, c, ub, j)                                                                 \
+    // chunk c (of the cursor's tile, B rows at ub) -> LDS stage buf
+#define CTTS_PS_DMA(buf, c, ub)                                                                     \
     do {                                                                                            \
         lds_ptr la_ = (lds_ptr)(lds + (buf) * SU + wave * 64);                                      \
-        unsigned o_ = (j) == 0 ? aoff0 : (j) == 1 ? aoff1 : (j) == 2 ? boff0 : boff1;               \
-        asm volatile("" : "+v"(o_));                                                                \
-        if ((j) == 0) __builtin_amdgcn_global_load_lds((gunit_ptr)(abase + (size_t)(c) * (A_UNITS * 16) + o_), la_, 16, 0, 0); \
-        else if ((j) == 1) __builtin_amdgcn_global_load_lds((gunit_ptr)(abase + (size_t)(c) * (A_UNITS * 16) + o_), la_ + NT, 16, 0, 0); \
-        else if ((j) == 2) __builtin_amdgcn_global_load_lds((gunit_ptr)((gbyte_ptr)(ub) + o_), la_ + A_UNITS, 16, 0, 0); \
-        else __builtin_amdgcn_global_load_lds((gunit_ptr)((gbyte_ptr)(ub) + o_), la_ + A_UNITS + NT, 16, 0, 0); \
+        const gbyte_ptr ac_ = abase + (size_t)(c) * (A_UNITS * 16);                                 \
+        unsigned a0_ = aoff0, a1_ = aoff1, b0_ = boff0, b1_ = boff1;                                \
+        asm volatile("" : "+v"(a0_), "+v"(a1_), "+v"(b0_), "+v"(b1_));                             \
+        __builtin_amdgcn_global_load_lds((gunit_ptr)(ac_ + a0_), la_, 16, 0, 0);                    \
+        __builtin_amdgcn_global_load_lds((gunit_ptr)(ac_ + a1_), la_ + NT, 16, 0, 0);               \
+        const gbyte_ptr bc_ = (gbyte_ptr)(ub);                                                      \
+        __builtin_amdgcn_global_load_lds((gunit_ptr)(bc_ + b0_), la_ + A_UNITS, 16, 0, 0);          \
+        __builtin_amdgcn_global_load_lds((gunit_ptr)(bc_ + b1_), la_ + A_UNITS + NT, 16, 0, 0);     \
     } while (0)
 #define CTTS_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define CTTS_UNIFORM64(v) \
     (((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)((v) >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(v)))
-#define CTTS_SB() __builtin_amdgcn_sched_barrier(0)
 
     __syncthreads();                                        // tables, bias visible (no DMA in flight yet)
-    // prologue: chunks 0 .. NS-1 of the first tile (the launcher guarantees nch > NS)
+    // prologue: chunks 0 .. NS-2 of the first tile in flight (the launcher guarantees nch > NS), chunk 0 landed
 #pragma unroll
-    for (int c = 0; c < NS; ++c) {
-        const u64 ub = CTTS_UNIFORM64(tabs[c]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) CTTS_PS_DMA1(c, c, ub, j);
+    for (int c = 0; c < NS - 1; ++c) {
+        const u64 ub0 = CTTS_UNIFORM64(tabs[c]);
+        CTTS_PS_DMA(c, c, ub0);
     }
-    int dk = 0, dch = NS;                                   // DMA cursor: next chunk to issue = chunk dch of tile dk
-    CTTS_WAIT_VM(4 * (NS - 1));                             // chunk 0 landed (own DMAs)
-    __builtin_amdgcn_s_barrier();
-    CTTS_SB();
+    int dk = 0, dch = NS - 1;                               // DMA cursor: next chunk to issue = chunk dch of tile dk ...
+    u64 ub = CTTS_UNIFORM64(tabs[NS - 1]);                  // ... whose B rows start at ub
+    CTTS_WAIT_VM(4 * (NS - 2));
+    __builtin_amdgcn_s_barrier();                           // chunk 0 is in LDS
+    if (wm) __builtin_amdgcn_s_setprio(1);                  // the later-dispatched half loses every arbitration otherwise
+    __builtin_amdgcn_sched_barrier(0);
 
-    u32x4 fa[2][4], fb[2][2];                               // [k-step][tile] fragments
-#define CTTS_PS_FRAG1(ks, i, buf)                                                                   \
+    u32x4 av[2][4], bv[2][2];
+#define CTTS_LOAD_FRAGS()                                                                           \
     do {                                                                                            \
-        if ((i) < 4) fa[ks][(i)] = lds[(buf) * SU + (2 * (ks) + lhi) * BGEMM_BM + wm * 128 + l31 + (i) * 32]; \
-        else fb[ks][(i) - 4] = lds[(buf) * SU + A_UNITS + (2 * (ks) + lhi) * BN + wn * 64 + l31 + ((i) - 4) * 32]; \
+        const u32x4* As = lds + cur * SU + wm * 128 + l31;                                          \
+        const u32x4* Bs = lds + cur * SU + A_UNITS + wn * 64 + l31;                                 \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                          \
+            const int grp = 2 * ks + lhi;                                                           \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) av[ks][mt] = As[grp * BGEMM_BM + mt * 32]; \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) bv[ks][nt] = Bs[grp * BN + nt * 32];   \
+        }                                                                                           \
     } while (0)
-#define CTTS_PS_MFMA1(ks, mt, nt)                                                                   \
-    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&fa[ks][mt]), \
-                                                          *reinterpret_cast<const bf16x8*>(&fb[ks][nt]), acc[mt][nt], 0, 0, 0)
-#pragma unroll
-    for (int i = 0; i < 6; ++i) CTTS_PS_FRAG1(0, i, 0);
-
-    int cur = 0, v = 0;                                     // LDS stage and stream index of the chunk being multiplied
-    int gt = first;                                         // its tile
-    // One chunk of the stream.  STEADY: chunk v + NS exists (DMA issued, constant vmcnt); otherwise the stream's tail.
-#define CTTS_PS_CHUNK(STEADY)                                                                       \
+    // The 16 MFMAs of a chunk.  FETCH: the address of the DMA cursor's chunk is read from the table behind MFMA 1 and made
+    // wave-uniform behind MFMA 11, in the shadow of the matrix pipe: nothing of it is left in a LOAD phase, which is the
+    // phase the interval waits for (12 fragment reads + 4 DMA issues against the partner's 512 matrix-pipe cycles).
+#define CTTS_MFMA16(FETCH)                                                                          \
     do {                                                                                            \
-        const int nxt = cur == NS - 1 ? 0 : cur + 1;                                                \
-        u64 tnext = 0;                                                                              \
-        /* k-step 0 (MFMA m row-major over the 4 x 2 tiles); k-step-1 fragment m is read behind MFMA m */ \
-        _Pragma("unroll") for (int m = 0; m < 8; ++m) {                                             \
-            CTTS_PS_MFMA1(0, m >> 1, m & 1);                                                        \
-            CTTS_SB();                                                                              \
-            if (m < 6) CTTS_PS_FRAG1(1, m, cur);                                                    \
-            if (STEADY && m == 6) tnext = tabs[(dk & 1) * MAXC + dch];                              \
-            CTTS_SB();                                                                              \
-        }                                                                                           \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  /* k-step-1 fragments, table entry */   \
-        if (STEADY) CTTS_WAIT_VM(4 * (NS - 2));            /* own DMAs of chunk v+1 landed */       \
-        else {                                                                                      \
-            const int ahead = total - 1 - v;               /* chunks issued beyond v (< NS - 1 here or no DMA left) */ \
-            if (ahead >= 3) CTTS_WAIT_VM(8);                                                        \
-            else if (ahead == 2) CTTS_WAIT_VM(4);                                                   \
-            else CTTS_WAIT_VM(0);                                                                   \
-        }                                                                                           \
-        if (!(DBG & 4)) __builtin_amdgcn_s_barrier();      /* chunk v+1 visible; stage `cur` is free */ \
-        CTTS_SB();                                                                                  \
-        const bool more = STEADY || v + 1 < total;                                                  \
-        const u64 ub = STEADY ? CTTS_UNIFORM64(tnext) : 0;                                          \
-        /* k-step 1: the next chunk's k-step-0 fragments behind MFMAs 0..5, the DMA of chunk v+NS behind 1, 3, 5, 7 */ \
-        _Pragma("unroll") for (int m = 0; m < 8; ++m) {                                             \
-            CTTS_PS_MFMA1(1, m >> 1, m & 1);                                                        \
-            CTTS_SB();                                                                              \
-            if (m < 6 && more) CTTS_PS_FRAG1(0, m, nxt);                                            \
-            if (STEADY && (m & 1) && !(DBG & 2)) CTTS_PS_DMA1(cur, dch, ub, m >> 1);                \
-            CTTS_SB();                                                                              \
-        }                                                                                           \
-        if (STEADY) {                                                                               \
-            if (++dch == nch) {                            /* the cursor enters tile dk + 1: build the table of tile dk + 2 */ \
-                dch = 0;                                                                            \
-                ++dk;                                                                               \
-                if (dk + 1 < my_tiles && t < nch) {                                                 \
-                    const int g2 = first + (dk + 1) * step;                                         \
-                    tabs[((dk + 1) & 1) * MAXC + t] = rel[t] + (u64)(g2 / a.ntiles) * bsb[t] + 16ull * (u64)((g2 % a.ntiles) * BN); \
+        u64 tnext_ = 0;                                                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                            \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                        \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                  \
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                          \
+                        *reinterpret_cast<const bf16x8*>(&av[ks][mt]),                              \
+                        *reinterpret_cast<const bf16x8*>(&bv[ks][nt]), acc[mt][nt], 0, 0, 0);       \
+                    if (FETCH && ks * 8 + mt * 2 + nt == 1) {                                       \
+                        __builtin_amdgcn_sched_barrier(0);                                          \
+                        tnext_ = tabs[(dk & 1) * MAXC + dch];                                       \
+                        __builtin_amdgcn_sched_barrier(0);                                          \
+                    }                                                                               \
+                    if (FETCH && ks * 8 + mt * 2 + nt == 11) {                                      \
+                        __builtin_amdgcn_sched_barrier(0);                                          \
+                        ub = CTTS_UNIFORM64(tnext_);                                                \
+                        __builtin_amdgcn_sched_barrier(0);                                          \
+                    }                                                                               \
                 }                                                                                   \
+    } while (0)
+    // interval v's DMA (chunk v + NS - 1 of the stream) into the stage of chunk v - 1; then the cursor moves on, the table
+    // of the tile after the one it enters is built, and the next chunk's address is fetched (tnext -> ub after the MFMAs)
+#define CTTS_PS_ISSUE()                                                                             \
+    do {                                                                                            \
+        const int nb = cur >= 1 ? cur - 1 : NS - 1;        /* (cur + NS - 1) % NS */                \
+        CTTS_PS_DMA(nb, dch, ub);                                                                   \
+        if (++dch == nch) {                                                                         \
+            dch = 0;                                                                                \
+            ++dk;                                                                                   \
+            if (dk + 1 < my_tiles && t < nch) {                                                     \
+                const int g2 = first + (dk + 1) * step;                                             \
+                tabs[((dk + 1) & 1) * MAXC + t] = rel[t] + (u64)(g2 / a.ntiles) * bsb[t] + 16ull * (u64)((g2 % a.ntiles) * BN); \
             }                                                                                       \
         }                                                                                           \
-        cur = nxt;                                                                                  \
-        ++v;                                                                                        \
+    } while (0)
+    // own DMAs of chunk v + 1 landed: everything but the chunks issued after it
+#define CTTS_PS_WAIT_NEXT()                                                                         \
+    do {                                                                                            \
+        const int after = total - 2 - v;                   /* chunks of the stream beyond v + 1 */   \
+        if (after >= NS - 2) CTTS_WAIT_VM(4 * (NS - 2));                                            \
+        else if (NS > 3 && after == 1) CTTS_WAIT_VM(4);                                             \
+        else CTTS_WAIT_VM(0);                                                                       \
+    } while (0)
+#define CTTS_PS_EPILOGUE()                                                                          \
+    do {                                                                                            \
+        const unsigned long long e0_ = (DBG & 1) ? __builtin_readcyclecounter() : 0;                \
+        /* lane ids laundered: keeps the epilogue's address arithmetic out of the chunk loop's live registers (LICM) */ \
+        int l31_ = l31, lhi_ = lhi;                                                                 \
+        asm volatile("" : "+v"(l31_), "+v"(lhi_));                                                  \
+        bf16_epilogue<EPI, true>(a, acc, bias_lds, t, mb, wm, wn, gt_done / a.ntiles, (gt_done % a.ntiles) * BN, l31_, lhi_); \
+        CTTS_PS_ZERO();                                                                             \
+        if ((DBG & 1) && blockIdx.x == 100 && tiles_done == 2 && lane == 0 && wn == 0) {            \
+            unsigned long long* o_ = g_ps_stamps + 4 * wm;                                          \
+            const unsigned long long now_ = __builtin_readcyclecounter();                           \
+            o_[0] = now_ - st_tile; o_[1] = now_ - e0_; o_[2] = __builtin_amdgcn_s_memrealtime() - rt_tile; o_[3] = my_tiles; \
+        }                                                                                           \
+        if (DBG & 1) { st_tile = __builtin_readcyclecounter(); rt_tile = __builtin_amdgcn_s_memrealtime(); } \
+        ++tiles_done;                                                                               \
     } while (0)
 
-    static_assert(NS == 4 || NS == 3, "tail waits below assume NS - 2 <= 2 chunks in flight");
-    int tile_seq = 0;
-    for (;;) {
-        int ch = 0;
-        const unsigned long long st0 = DBG ? __builtin_readcyclecounter() : 0, rt0 = DBG ? __builtin_amdgcn_s_memrealtime() : 0;
-        {
-            const int left = total - NS - v;               // steady chunks ahead in the stream
-            const int n_steady = left < nch ? (left > 0 ? left : 0) : nch;
-            for (; ch < n_steady; ++ch) CTTS_PS_CHUNK(true);
+    static_assert(NS == 3 || NS == 4, "tail waits above");
+    int cur = 0, ch = 0, gt = first, gt_done = first, tiles_done = 0;
+    unsigned long long st_tile = 0, rt_tile = 0;
+    if (!wm) {
+        // leading half: [LOAD v | COMPUTE v]; the epilogue of a tile opens the interval after its last chunk
+        for (int v = 0;; ++v) {
+            const bool issue = v + NS - 1 < total;
+            const bool boundary = v > 0 && ch == 0;
+            if (boundary) {
+                if (issue) CTTS_PS_ISSUE();
+                CTTS_PS_EPILOGUE();
+                if (v == total) break;
+            }
+            CTTS_LOAD_FRAGS();
+            if (issue && !boundary) CTTS_PS_ISSUE();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            CTTS_MFMA16(true);                              // + the next interval's DMA address
+            __builtin_amdgcn_sched_barrier(0);
+            CTTS_PS_WAIT_NEXT();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            cur = cur == NS - 1 ? 0 : cur + 1;
+            if (++ch == nch) { ch = 0; gt_done = gt; gt += step; }
         }
-        for (; ch < nch; ++ch) CTTS_PS_CHUNK(false);
-        const int tile = gt % a.ntiles, b = gt / a.ntiles;
-        const unsigned long long st1 = DBG ? __builtin_readcyclecounter() : 0, rt1 = DBG ? __builtin_amdgcn_s_memrealtime() : 0;
-        bf16_epilogue<EPI, true>(a, acc, bias_lds, t, mb, wm, wn, b, tile * BN, l31, lhi);
-        if ((DBG & 1) && blockIdx.x == 100 && tile_seq == 2 && lane == 0 && (wave & 3) == 0) {
-            unsigned long long* o = g_ps_stamps + 4 * wm;
-            o[0] = st1 - st0; o[1] = __builtin_readcyclecounter() - st1; o[2] = rt1 - rt0; o[3] = my_tiles;
+    } else {
+        // lagging half: [COMPUTE v-1 | LOAD v]; its epilogue follows its last COMPUTE of the tile
+        for (int v = 0;; ++v) {
+            if (v > 0) CTTS_MFMA16(true);                   // + this interval's DMA address (the cursor moved in interval v - 1)
+            __builtin_amdgcn_sched_barrier(0);
+            const bool issue = v + NS - 1 < total;
+            const bool boundary = v > 0 && ch == 0;
+            if (boundary) {
+                if (issue) CTTS_PS_ISSUE();
+                CTTS_PS_EPILOGUE();
+                if (v == total) break;
+            }
+            CTTS_LOAD_FRAGS();
+            if (issue && !boundary) CTTS_PS_ISSUE();
+            CTTS_PS_WAIT_NEXT();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this half's reads of the stage are complete
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            cur = cur == NS - 1 ? 0 : cur + 1;
+            if (++ch == nch) { ch = 0; gt_done = gt; gt += step; }
         }
-        ++tile_seq;
-        gt += step;
-        if (gt >= T) break;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     }
-#undef CTTS_PS_CHUNK
-#undef CTTS_PS_FRAG1
-#undef CTTS_PS_MFMA1
-#undef CTTS_PS_DMA1
-#undef CTTS_SB
+    if (wm) __builtin_amdgcn_s_setprio(0);
+#undef CTTS_PS_EPILOGUE
+#undef CTTS_PS_WAIT_NEXT
+#undef CTTS_PS_ISSUE
+#undef CTTS_MFMA16
+#undef CTTS_LOAD_FRAGS
+#undef CTTS_PS_DMA
+#undef CTTS_PS_ZERO
 #undef CTTS_UNIFORM64
 #undef CTTS_WAIT_VM
 }

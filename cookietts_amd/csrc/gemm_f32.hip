@@ -338,23 +338,35 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
     } while (0)
 
     typedef __attribute__((address_space(3))) float* lds_fptr;
-    const gfloat_ptr apg = (gfloat_ptr)ap;
+    typedef const __attribute__((address_space(1))) char* gbyte_ptr;
+    // wave-uniform A base of this m-block and the 32-bit per-lane byte offsets of the two operands
+    const gbyte_ptr apu = (gbyte_ptr)(a.A + ((size_t)mb * nalloc + a.a_ch_off) * A_STAGE);
+    unsigned piece_lane[6];
+#pragma unroll
+    for (int p_ = 0; p_ < 6; ++p_)
+        piece_lane[p_] = p_ < NA ? (unsigned)(t * 16 + 4096 * p_) : (unsigned)(thread_off * 4 + (size_t)(p_ - NA) * (piece_stride * 4));
     const unsigned long long* ctab = reinterpret_cast<const unsigned long long*>(lds + CHTAB);
-    // DMA piece p (0..5) of chunk c into stage buf: pieces [0, NA) = A, [NA, 6) = B; `bp_` = this thread's B address
+    // DMA piece p (0..5) of chunk c into stage buf: pieces [0, NA) = A, [NA, 6) = B.  Every address is a wave-uniform
+    // 64-bit base (ac_ / bp_, SGPR pair) + a 32-bit lane offset, laundered through an empty asm so that the compiler keeps
+    // that form (global_load_lds_dwordx4 v, s[a:b]) instead of folding it into a loop-carried 64-bit VGPR address
+    // (v[a:b], off): with the 64-bit form every DMA blocks the matrix pipe for ~20 cycles (round 5,
+    // profiles/r5_07_bf16_mix_ceiling_dma_forms.txt).
 #define CTTS_GLDS_PIECE(p, la_, ac_, bp_)                                                                   \
     do {                                                                                                    \
-        if constexpr ((p) < NA) __builtin_amdgcn_global_load_lds((ac_) + 1024 * (p), (la_) + 1024 * (p), 16, 0, 0); \
-        else __builtin_amdgcn_global_load_lds((bp_) + ((p) - NA) * piece_stride, (la_) + A_STAGE + 1024 * ((p) - NA), 16, 0, 0); \
+        unsigned o_ = piece_lane[(p)];                     /* lane offset incl. the piece's own offset: nothing to reassociate */ \
+        asm volatile("" : "+v"(o_));                                                                        \
+        if constexpr ((p) < NA) __builtin_amdgcn_global_load_lds((gfloat_ptr)((ac_) + o_), (la_) + 1024 * (p), 16, 0, 0); \
+        else __builtin_amdgcn_global_load_lds((gfloat_ptr)((bp_) + o_), (la_) + A_STAGE + 1024 * ((p) - NA), 16, 0, 0); \
     } while (0)
 #define CTTS_GLDS_ADDR_A(buf, c)                                                                            \
     lds_fptr la_ = (lds_fptr)(lds + (buf) * STAGE + wave * 256);                                            \
-    const gfloat_ptr ac_ = apg + (size_t)(c) * A_STAGE;                                                     \
+    const gbyte_ptr ac_ = apu + (size_t)(c) * (A_STAGE * 4);                                                \
     const unsigned long long ub_ = ctab[c];
 #define CTTS_GLDS_ADDR_B()                                                                                  \
     const unsigned long long us_ =                                                                          \
         ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |            \
         (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                                 \
-    const gfloat_ptr bp_ = reinterpret_cast<gfloat_ptr>(us_) + thread_off;
+    const gbyte_ptr bp_ = reinterpret_cast<gbyte_ptr>(us_);
 #define CTTS_GLDS_ADDR(buf, c) CTTS_GLDS_ADDR_A(buf, c) CTTS_GLDS_ADDR_B()
 #define CTTS_ISSUE_GLDS(buf, c)                                                                             \
     do {                                                                                                    \
@@ -744,7 +756,7 @@ void load_tuning_locked() {
     g_tune.bf16_w4 = on("CTTS_BF16_W4");
     g_tune.bf16_pp_stages = num("CTTS_BF16_PP_STAGES", 3);
     g_tune.bf16_map = num("CTTS_BF16_MAP", 0);
-    g_tune.bf16_no_ps = on("CTTS_BF16_NO_PS");
+    g_tune.bf16_ps = on("CTTS_BF16_PS");
     g_tune.bf16_ps_stages = num("CTTS_BF16_PS_STAGES", 4) == 3 ? 3 : 4;
     g_tune.wf_no_fuse = on("CTTS_WF_NO_FUSE");
     g_tune.taco_no_fuse = on("CTTS_TACO_NO_FUSE");

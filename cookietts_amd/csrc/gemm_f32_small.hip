@@ -56,6 +56,18 @@ __device__ __forceinline__ float s_fast_tanh(float u) {
 
 typedef const __attribute__((address_space(1))) float* gfloat_ptr;
 typedef __attribute__((address_space(3))) float* lds_fptr;
+typedef const __attribute__((address_space(1))) char* gbyte_ptr;
+
+// One 16-byte-per-lane global -> LDS DMA whose address is a wave-uniform 64-bit base (SGPR pair) + a 32-bit lane byte
+// offset: global_load_lds_dwordx4 v, s[a:b].  The lane offset is laundered through an empty asm so that the compiler
+// cannot fold it into a 64-bit VGPR address (global_load_lds_dwordx4 v[a:b], off): with that form every DMA keeps the
+// matrix pipe from issuing for ~20 cycles (round 5, profiles/r5_07_bf16_mix_ceiling_dma_forms.txt).
+#define CTTS_GLDS_U(ubase, lane_off, ldsdst, aux)                                                                \
+    do {                                                                                                         \
+        unsigned o_ = (lane_off);                                                                                \
+        asm volatile("" : "+v"(o_));                                                                             \
+        __builtin_amdgcn_global_load_lds((gfloat_ptr)((ubase) + o_), (ldsdst), 16, 0, (aux));                    \
+    } while (0)
 
 // split-bf16 main loop (X3), exactly as in conv_gemm_f32_kernel<..., X3>: the 8 k-values a lane reads per fragment and chunk
 // become one bf16x8 operand pair hi = bf16(v), lo = bf16(v - hi); a 32x32 tile of the chunk is lo*hi + hi*lo + hi*hi on
@@ -203,10 +215,12 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
     const int nalloc = a.a_nch_alloc ? a.a_nch_alloc : a.nch_total;
     // A: chunk c of M-block mb in the 256-row packing, rows [128 half, +128).  Piece p of this wave fills LDS floats
     // [wave * 256 + p * 1024, +256) of the [16][128] stage: k-row 2 wave + 8 p + (lane >> 5), columns 4 (lane & 31).
-    const gfloat_ptr a_base = (gfloat_ptr)(a.A + ((size_t)mb * nalloc + a.a_ch_off) * (GEMM_KC * 256) + 128 * half +
-                                           (2 * wave + (lane >> 5)) * 256 + (lane & 31) * 4);
+    // Every DMA address below is a wave-uniform 64-bit base + a 32-bit lane byte offset (CTTS_GLDS_U): the form
+    // global_load_lds_dwordx4 v, s[a:b], which does not block the matrix pipe the way the 64-bit VGPR address form does.
+    const gbyte_ptr a_base = (gbyte_ptr)(a.A + ((size_t)mb * nalloc + a.a_ch_off) * (GEMM_KC * 256) + 128 * half + 2 * wave * 256);
+    const unsigned dma_a_lane = (unsigned)(((lane >> 5) * 256 + (lane & 31) * 4) * 4), dma_a_lane1 = dma_a_lane + 8 * 256 * 4;   // piece 0 / 1
     // B: [16][64] stage, this wave's piece = k-rows 4 wave .. +4: k-row 4 wave + (lane >> 4), columns 4 (lane & 15)
-    const size_t b_off = (size_t)(4 * wave + (lane >> 4)) * a.ld + (lane & 15) * 4;
+    const unsigned dma_b_lane = (unsigned)(((size_t)(4 * wave + (lane >> 4)) * a.ld + (lane & 15) * 4) * 4);
     const unsigned long long* ctab = reinterpret_cast<const unsigned long long*>(lds + S_CHTAB);
 
     f32x16 acc[2];
@@ -216,16 +230,16 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
 #define S_ISSUE_A(buf, c, p)                                                                                     \
-    __builtin_amdgcn_global_load_lds(a_base + (size_t)(c) * (GEMM_KC * 256) + (p) * (8 * 256),                   \
-                                     (lds_fptr)(lds + (buf) * S_STAGE + wave * 256 + (p) * 1024), 16, 0, 0)
+    CTTS_GLDS_U(a_base + (size_t)(c) * (GEMM_KC * 256 * 4), (p) ? dma_a_lane1 : dma_a_lane,                       \
+                (lds_fptr)(lds + (buf) * S_STAGE + wave * 256 + (p) * 1024), 0)
 #define S_ISSUE_B(buf, c)                                                                                        \
     do {                                                                                                         \
         const unsigned long long ub_ = ctab[c];                                                                  \
         const unsigned long long us_ =                                                                           \
             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |             \
             (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                                  \
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off,                               \
-                                         (lds_fptr)(lds + (buf) * S_STAGE + S_ASTAGE + wave * 256), 16, 0, 0);   \
+        CTTS_GLDS_U(reinterpret_cast<gbyte_ptr>(us_), dma_b_lane,                                                    \
+                    (lds_fptr)(lds + (buf) * S_STAGE + S_ASTAGE + wave * 256), 0);                               \
     } while (0)
 
 #define S_ISSUE_B_AT(buf, ub)                                                                                    \
@@ -234,8 +248,8 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
         const unsigned long long us_ =                                                                           \
             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |             \
             (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                                  \
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off,                               \
-                                         (lds_fptr)(lds + (buf) * S_STAGE + S_ASTAGE + wave * 256), 16, 0, 0);   \
+        CTTS_GLDS_U(reinterpret_cast<gbyte_ptr>(us_), dma_b_lane,                                                    \
+                    (lds_fptr)(lds + (buf) * S_STAGE + S_ASTAGE + wave * 256), 0);                               \
     } while (0)
 
     // Chunks 0 and 1 are requested BEFORE the tables are built (their B addresses follow from the first two segments by
@@ -571,11 +585,12 @@ __device__ __forceinline__ void gate_rs_small_tile(ARGS& a, const int tile, cons
 
     const int nalloc = a.a_nch_alloc ? a.a_nch_alloc : a.nch_total;
     // A: the [16][128] chunk of the bm = 128 packing, copied linearly: piece p of this wave = floats [wave * 256 + p * 1024, +256)
-    const gfloat_ptr a_base = (gfloat_ptr)(a.A + (size_t)a.a_ch_off * S_ASTAGE + wave * 256 + lane * 4);
+    const gbyte_ptr a_base = (gbyte_ptr)(a.A + (size_t)a.a_ch_off * S_ASTAGE + wave * 256);
+    const unsigned dma_a_lane = (unsigned)(lane * 16), dma_a_lane1 = dma_a_lane + 4096;   // piece 0 / 1
     (void)nalloc;
     // B: [16][128] stage, piece p of this wave = k-row 2 wave + 8 p + (lane >> 5), columns 4 (lane & 31)
-    const size_t b_off = (size_t)(2 * wave + (lane >> 5)) * a.ld + (lane & 31) * 4;
-    const size_t b_piece = (size_t)8 * a.ld;
+    const unsigned dma_b_lane = (unsigned)(((size_t)(2 * wave + (lane >> 5)) * a.ld + (lane & 31) * 4) * 4);
+    const unsigned dma_b_lane1 = dma_b_lane + (unsigned)(8 * a.ld * 4);   // piece 1: eight k-rows on
 
     f32x16 acc[4];
 #pragma unroll
@@ -584,8 +599,8 @@ __device__ __forceinline__ void gate_rs_small_tile(ARGS& a, const int tile, cons
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
 #define R_ISSUE_A(buf, c, p)                                                                                     \
-    __builtin_amdgcn_global_load_lds(a_base + (size_t)(c) * S_ASTAGE + (p) * 1024,                                \
-                                     (lds_fptr)(lds + (buf) * R_STAGE + wave * 256 + (p) * 1024), 16, 0, 0)
+    CTTS_GLDS_U(a_base + (size_t)(c) * (S_ASTAGE * 4), (p) ? dma_a_lane1 : dma_a_lane,                           \
+                (lds_fptr)(lds + (buf) * R_STAGE + wave * 256 + (p) * 1024), 0)
     // a table entry = address of the chunk's B rows | (FRESH: bit 0 = the segment is marked fresh -> sc1 DMA); addresses are
     // 4-byte aligned, so the bit is free
 #define R_ISSUE_B_AT(buf, ub, p)                                                                                 \
@@ -596,11 +611,11 @@ __device__ __forceinline__ void gate_rs_small_tile(ARGS& a, const int tile, cons
             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |             \
             (FRESH ? (lo_ & ~1u) : lo_);                                                                         \
         if (FRESH && (lo_ & 1u))                                                                                 \
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off + (p) * b_piece,          \
-                                             (lds_fptr)(lds + (buf) * R_STAGE + S_ASTAGE + wave * 256 + (p) * 1024), 16, 0, R_AUX_SC1); \
+            CTTS_GLDS_U(reinterpret_cast<gbyte_ptr>(us_), (p) ? dma_b_lane1 : dma_b_lane,                                \
+                        (lds_fptr)(lds + (buf) * R_STAGE + S_ASTAGE + wave * 256 + (p) * 1024), R_AUX_SC1);      \
         else                                                                                                     \
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off + (p) * b_piece,          \
-                                             (lds_fptr)(lds + (buf) * R_STAGE + S_ASTAGE + wave * 256 + (p) * 1024), 16, 0, 0); \
+            CTTS_GLDS_U(reinterpret_cast<gbyte_ptr>(us_), (p) ? dma_b_lane1 : dma_b_lane,                                \
+                        (lds_fptr)(lds + (buf) * R_STAGE + S_ASTAGE + wave * 256 + (p) * 1024), 0);              \
     } while (0)
     // chunks 0 and 1 before the tables are built (as in conv_gemm_f32_small_kernel)
     const int nch = a.nch_total;
@@ -902,12 +917,13 @@ __device__ __forceinline__ void gate_rs_splitk_tile(ARGS& a, const int tile, con
 
     // DMA pieces of a chunk: A [16][128] = 8 pieces of 1 KiB (this wave: pieces wave, wave + 4), B [16][64] = 4 pieces (piece
     // wave = k-rows 4 wave .. +4: k-row 4 wave + (lane >> 4), columns 4 (lane & 15)).  Slot cs = 2 stage + chunk parity.
-    const gfloat_ptr a_base = (gfloat_ptr)(a.A + (size_t)a.a_ch_off * S_ASTAGE + wave * 256 + lane * 4);
-    const size_t b_off = (size_t)(4 * wave + (lane >> 4)) * a.ld + (lane & 15) * 4;
+    const gbyte_ptr a_base = (gbyte_ptr)(a.A + (size_t)a.a_ch_off * S_ASTAGE + wave * 256);
+    const unsigned dma_a_lane = (unsigned)(lane * 16), dma_a_lane1 = dma_a_lane + 4096;   // piece 0 / 1
+    const unsigned dma_b_lane = (unsigned)(((size_t)(4 * wave + (lane >> 4)) * a.ld + (lane & 15) * 4) * 4);
     const unsigned lds0 = (unsigned)(size_t)(lds_fptr)lds;
 #define K_ISSUE_A(cs, c, p)                                                                                      \
-    __builtin_amdgcn_global_load_lds(a_base + (size_t)(c) * S_ASTAGE + (p) * 1024,                                \
-                                     (lds_fptr)(lds + (cs) * K_CHUNK + wave * 256 + (p) * 1024), 16, 0, 0)
+    CTTS_GLDS_U(a_base + (size_t)(c) * (S_ASTAGE * 4), (p) ? dma_a_lane1 : dma_a_lane,                           \
+                (lds_fptr)(lds + (cs) * K_CHUNK + wave * 256 + (p) * 1024), 0)
 #define K_ISSUE_B_AT(cs, ub)                                                                                     \
     do {                                                                                                         \
         const unsigned long long ub_ = (ub);                                                                     \
@@ -916,11 +932,11 @@ __device__ __forceinline__ void gate_rs_splitk_tile(ARGS& a, const int tile, con
             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |             \
             (FRESH ? (lo_ & ~1u) : lo_);                                                                         \
         if (FRESH && (lo_ & 1u))                                                                                 \
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off,                           \
-                                             (lds_fptr)(lds + (cs) * K_CHUNK + S_ASTAGE + wave * 256), 16, 0, R_AUX_SC1); \
+            CTTS_GLDS_U(reinterpret_cast<gbyte_ptr>(us_), dma_b_lane,                                                \
+                        (lds_fptr)(lds + (cs) * K_CHUNK + S_ASTAGE + wave * 256), R_AUX_SC1);                    \
         else                                                                                                     \
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<gfloat_ptr>(us_) + b_off,                           \
-                                             (lds_fptr)(lds + (cs) * K_CHUNK + S_ASTAGE + wave * 256), 16, 0, 0); \
+            CTTS_GLDS_U(reinterpret_cast<gbyte_ptr>(us_), dma_b_lane,                                                \
+                        (lds_fptr)(lds + (cs) * K_CHUNK + S_ASTAGE + wave * 256), 0);                            \
     } while (0)
     const unsigned long long* ctab = reinterpret_cast<const unsigned long long*>(lds + K_CHTAB);
     const int nch = a.nch_total;
