@@ -70,9 +70,12 @@ int launch_gemm_bf16(int epi, const BGemmArgs& a, hipStream_t stream) {
     b.map_mode = 0;
     const long long tiles = (long long)b.ntiles * b.batch;
     // persistent kernel: one workgroup per CU walks its tile sequence (gemm_bf16_kernels.h); K of more than NS chunks.
-    // Opt-in (CTTS_BF16_PS=1) while it measures equal to the per-tile kernel on random operands (profiles/r5_10).
+    // Default for short K (<= 32 chunks: config 3's res GEMM, K = 512, where a tile's prologue is a large share of its
+    // time: 0.729 -> 0.675 ms); on the long-K launches it measures equal (in-layer) or behind (skip) the per-tile kernel
+    // (profiles/r5_14_bf16_ps_ab.txt).  CTTS_BF16_PS=1: everywhere it applies; CTTS_BF16_NO_PS: nowhere.
     const int ps_stages = tune.bf16_ps_stages;
-    const bool ps = wide && pp && !w4 && tune.bf16_ps && b.nch_total > ps_stages && tune.bf16_map != 2;
+    const bool ps = wide && pp && !w4 && !tune.bf16_no_ps && (tune.bf16_ps || b.nch_total <= 32) && b.nch_total > ps_stages &&
+                    tune.bf16_map != 2;
     const int cus = ps ? wf_row_cus() : 0;
     int ps_grid = 0;
     if (b.MB == 4 && !tune.no_xcd_pair && tune.bf16_map == 2) {

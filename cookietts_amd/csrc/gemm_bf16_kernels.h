@@ -924,15 +924,19 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_w4_kernel(const BGemmArgs 
             *reinterpret_cast<const bf16x8*>(&fa[ks][mt]),                                          \
             *reinterpret_cast<const bf16x8*>(&fb[ks][nt]), acc[(nt) >> 1][mt][(nt) & 1], 0, 0, 0);  \
     } while (0)
+    // SGPR base + 32-bit lane offset per piece (see the skewed kernel's DMA)
+    unsigned w4_lane[8];
+#pragma unroll
+    for (int j_ = 0; j_ < 8; ++j_) w4_lane[j_] = j_ < 4 ? aoff + (unsigned)(j_ * (NT * 16)) : boff + (unsigned)(j_ - 4) * bstep;
 #define CTTS_W4_DMA1(buf, c, ub, j)                                                                 \
     do {                                                                                            \
         lds_ptr la_ = (lds_ptr)(lds + (buf) * STAGE_UNITS + wave * 64);                             \
+        unsigned o_ = w4_lane[(j)];                                                                 \
+        asm volatile("" : "+v"(o_));                                                                \
         if ((j) < 4)                                                                                \
-            __builtin_amdgcn_global_load_lds((gunit_ptr)(abase + (size_t)(c) * (A_UNITS * 16) + aoff + (j) * (NT * 16)), \
-                                             la_ + (j) * NT, 16, 0, 0);                             \
+            __builtin_amdgcn_global_load_lds((gunit_ptr)(abase + (size_t)(c) * (A_UNITS * 16) + o_), la_ + (j) * NT, 16, 0, 0); \
         else                                                                                        \
-            __builtin_amdgcn_global_load_lds((gunit_ptr)((gbyte_ptr)(ub) + boff + ((j) - 4) * bstep), \
-                                             la_ + A_UNITS + ((j) - 4) * NT, 16, 0, 0);             \
+            __builtin_amdgcn_global_load_lds((gunit_ptr)((gbyte_ptr)(ub) + o_), la_ + A_UNITS + ((j) - 4) * NT, 16, 0, 0); \
     } while (0)
 #define CTTS_SB() __builtin_amdgcn_sched_barrier(0)
 

@@ -757,6 +757,7 @@ void load_tuning_locked() {
     g_tune.bf16_pp_stages = num("CTTS_BF16_PP_STAGES", 3);
     g_tune.bf16_map = num("CTTS_BF16_MAP", 0);
     g_tune.bf16_ps = on("CTTS_BF16_PS");
+    g_tune.bf16_no_ps = on("CTTS_BF16_NO_PS");
     g_tune.bf16_ps_stages = num("CTTS_BF16_PS_STAGES", 4) == 3 ? 3 : 4;
     g_tune.wf_no_fuse = on("CTTS_WF_NO_FUSE");
     g_tune.taco_no_fuse = on("CTTS_TACO_NO_FUSE");

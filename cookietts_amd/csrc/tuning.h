@@ -20,7 +20,8 @@ struct Tuning {
     bool bf16_no_pp;       // CTTS_BF16_NO_PP: never the ping-pong kernel
     bool bf16_w4;          // CTTS_BF16_W4: four-wave 128 x 128 wave tiles (opt-in)
     int bf16_pp_stages;    // CTTS_BF16_PP_STAGES: 3 (default) or 4
-    bool bf16_ps;          // CTTS_BF16_PS: the persistent form of the skewed 8-wave kernel (one workgroup per CU walks a tile sequence); opt-in
+    bool bf16_ps;          // CTTS_BF16_PS: the persistent form of the skewed 8-wave kernel (one workgroup per CU walks a tile sequence) on every wide launch, not only the short-K ones
+    bool bf16_no_ps;       // CTTS_BF16_NO_PS: never the persistent form
     int bf16_ps_stages;    // CTTS_BF16_PS_STAGES: LDS stages of the persistent-stream kernel, 4 (default) or 3
     int bf16_map;          // CTTS_BF16_MAP: (A/B) 1 = MB == 2 launches keep the plain id -> tile map, 2 = MB == 4 launches put all four m-blocks of a tile on one XCD
     bool wf_no_fuse;       // CTTS_WF_NO_FUSE: WaveFlow layer as separate GATE + res/skip launches

@@ -200,10 +200,11 @@ def test_waveglow_bf16_ragged_and_batch_independent(hip_lib_path):
 
 
 @pytest.mark.parametrize("knob", ["CTTS_BF16_W4", "CTTS_BF16_NO_WIDE", "CTTS_BF16_NO_PP", "CTTS_BF16_NO_GLDS",
-                                  "CTTS_GEMM_NO_XCD_PAIR"])
+                                  "CTTS_GEMM_NO_XCD_PAIR", "CTTS_BF16_PS", "CTTS_BF16_NO_PS"])
 def test_waveglow_bf16_block_shapes_agree(hip_lib_path, tuning, knob):
     """Full model at a size that selects the 256x256 skewed 8-wave kernel (>= 512 workgroups, ragged last tile; W4
-    selects the four-wave 128x128-wave-tile kernel of the same block):
+    selects the four-wave 128x128-wave-tile kernel of the same block; PS the persistent form, in which a workgroup walks
+    two or three tiles here and the DMA runs across the tile boundaries):
     every block shape / staging variant accumulates K in the same order, so the waveforms must be identical."""
     m, cfg, sd = _model("full", 5)
     m.set_compute_dtype(torch.bfloat16)
