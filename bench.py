@@ -46,6 +46,7 @@ import socket
 import subprocess
 import sys
 import time
+import types
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
@@ -105,8 +106,8 @@ def parse_args(argv=None):
                     help="main loop of the fp32 conv-GEMM (--dtype f32 only): f32 = fp32 MFMA products (default, the "
                          "headline); bf16x3 = operands split in registers into hi + lo bf16, three bf16 MFMA products, "
                          "fp32 accumulate; bf16x6 = hi + mid + lo (24 mantissa bits), the six products >= 2^-16 - "
-                         "extra rows, labelled in the line's dtype.  Set explicitly here; the "
-                         "CTTS_F32_GEMM_MODE environment variable is ignored by bench.py")
+                         "extra rows, labelled in the line's dtype.  Travels in the model's config "
+                         "struct; there is no process-wide default")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="test hook for tests/test_bench_launcher.py: gloo on CPU with a stand-in step function; "
                          "exercises the launcher, the rank plumbing and sharding.py only - measures nothing")
@@ -247,9 +248,9 @@ def cpu_baseline(cfg, sd, frames, seed, budget_s, config_key=None, aggregate=Tru
     return out
 
 
-def wn_roofline(lib, cfg, dtype, gemm_mode, B, F, steps, elapsed, config_key="full"):
-    """Roofline object of the WN kernels from the library's own HIP-event timing of the steps just run (profile slots
-    collected and cleared here): the in-layer conv-GEMM against the MFMA peak of the arithmetic it executes; in bf16 also
+def wn_roofline(prof, cfg, dtype, gemm_mode, B, F, steps, elapsed, config_key="full"):
+    """Roofline object of the WN kernels from the library's own HIP-event timing of the steps just run (``prof``: the
+    caller-owned ``_lib.Profile`` that was bound while they ran; its slots are collected and cleared here): the in-layer conv-GEMM against the MFMA peak of the arithmetic it executes; in bf16 also
     the res and deferred-skip GEMMs and the whole step against HBM."""
     import ctypes
     from cookietts_amd import _lib
@@ -257,9 +258,8 @@ def wn_roofline(lib, cfg, dtype, gemm_mode, B, F, steps, elapsed, config_key="fu
     C, n_layers = wn["n_channels"], wn["n_layers"]
     L = F * cfg["hop_length"] // cfg["n_group"]
     traffic, traffic_src = load_traffic()
-    n = ctypes.c_int64()
-    ms = ctypes.c_double()
-    _lib.check(lib.ctts_profile_collect(_lib.PROF_WN_IN, ctypes.byref(n), ctypes.byref(ms)), "profile")
+    n_in, ms_in = prof.collect(_lib.PROF_WN_IN)
+    n, ms = types.SimpleNamespace(value=n_in), types.SimpleNamespace(value=ms_in)
     # algorithmic MACs per time step of ONE in-layer launch: dilated conv
     # C*2C*3 plus this layer's slice of the conditioning projection 256*2C
     mac = 3 * C * 2 * C + 256 * 2 * C
@@ -295,11 +295,9 @@ def wn_roofline(lib, cfg, dtype, gemm_mode, B, F, steps, elapsed, config_key="fu
     # MFMA-bound in fp32, memory-bound in bf16.  (CTTS_F32_NO_DEFER_SKIP: one res/skip GEMM per layer, no skip slot.)
     slots = {}
     for which in (_lib.PROF_WN_RS, _lib.PROF_WN_SKIP):
-        n2 = ctypes.c_int64()
-        ms2 = ctypes.c_double()
-        _lib.check(lib.ctts_profile_collect(which, ctypes.byref(n2), ctypes.byref(ms2)), "profile")
-        if n2.value > 0:
-            slots[which] = (int(n2.value), ms2.value / n2.value * 1e-3)
+        n2, ms2 = prof.collect(which)
+        if n2 > 0:
+            slots[which] = (n2, ms2 / n2 * 1e-3)
     if dtype == "bf16":
         # In bf16 the in-layer GEMM stays MFMA-bound (1430 FLOP/B vs a ridge of ~312); the memory-bound WN kernels are the
         # res GEMM (per layer: act read + x read-modify-write = 3*C*2 B per time step) and the deferred skip GEMM (4 act
@@ -357,9 +355,10 @@ def run_rows(which, model, cfg, lib, args, device):
     import torch
     sys.path.insert(0, os.path.join(REPO, "scripts"))
     import bench_rows
-    from cookietts_amd import synthetic
+    from cookietts_amd import _lib, synthetic
     rows = []
     t_all = _t.perf_counter()
+    prof = _lib.Profile()                                  # the rows' own timing slots (caller-owned handle, ABI 6)
 
     def guard(name, fn):
         t0 = _t.perf_counter()
@@ -375,13 +374,12 @@ def run_rows(which, model, cfg, lib, args, device):
         for _ in range(warmup):
             model.infer(mel, sigma=0.6)
         torch.cuda.synchronize(device)
-        lib.ctts_profile_enable(1)
-        t0 = _t.perf_counter()
-        for _ in range(steps):
-            out = model.infer(mel, sigma=0.6)
-        torch.cuda.synchronize(device)
-        dt = _t.perf_counter() - t0
-        lib.ctts_profile_enable(0)
+        with prof:
+            t0 = _t.perf_counter()
+            for _ in range(steps):
+                out = model.infer(mel, sigma=0.6)
+            torch.cuda.synchronize(device)
+            dt = _t.perf_counter() - t0
         assert bool(torch.isfinite(out).all())
         return dt, out
 
@@ -394,7 +392,7 @@ def run_rows(which, model, cfg, lib, args, device):
         model.set_compute_dtype(torch.bfloat16)
         try:
             dt, out = timed_infer(mel, 3, 1)
-            roof = wn_roofline(lib, cfg, "bf16", "f32", B3, F, 3, dt, args.config)
+            roof = wn_roofline(prof, cfg, "bf16", "f32", B3, F, 3, dt, args.config)
         finally:
             model.set_compute_dtype(torch.float32)
         return {"row": "A/config3 (1-GPU shard)", "metric": METRIC, "value": B3 * T * 3 / dt, "unit": "samples/s",
@@ -407,7 +405,7 @@ def run_rows(which, model, cfg, lib, args, device):
         model.set_f32_gemm_mode("bf16x6")
         try:
             dt, out = timed_infer(mel, 2, 1)
-            roof = wn_roofline(lib, cfg, "f32", "bf16x6", args.batch, F, 2, dt, args.config)
+            roof = wn_roofline(prof, cfg, "f32", "bf16x6", args.batch, F, 2, dt, args.config)
         finally:
             model.set_f32_gemm_mode(args.gemm_mode)
         return {"row": "A/config2 under --gemm-mode bf16x6", "metric": METRIC, "value": args.batch * T * 2 / dt, "unit": "samples/s",
@@ -511,8 +509,9 @@ def worker(args, pre=None):
         out = step_on(mel)
     fence()
     timing = not args.no_kernel_timing and lib is not None
+    prof = _lib.Profile() if timing else None
     if timing:
-        lib.ctts_profile_enable(1)
+        prof.bind()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step_on(mel)
@@ -520,8 +519,8 @@ def worker(args, pre=None):
     elapsed_own = time.perf_counter() - t0             # this rank's K steps, before waiting for the others
     fence()
     elapsed = time.perf_counter() - t0
-    if lib is not None:
-        lib.ctts_profile_enable(0)
+    if timing:
+        prof.unbind()
     assert out.shape == (B, T) and bool(torch.isfinite(out).all())
 
     rank_ms = [elapsed / args.steps * 1e3]
@@ -604,7 +603,7 @@ def worker(args, pre=None):
         value = samples / elapsed
         wn = cfg["WN_config"]
         C, n_layers = wn["n_channels"], wn["n_layers"]
-        roofline = wn_roofline(lib, cfg, args.dtype, args.gemm_mode, B, F, args.steps, elapsed, args.config) if timing else None
+        roofline = wn_roofline(prof, cfg, args.dtype, args.gemm_mode, B, F, args.steps, elapsed, args.config) if timing else None
         cpu = pre["cpu"] if pre else None      # timed by main() before the GPU was touched (its aggregate leg starts children)
         rows, rows_s = None, None
         which_rows = [] if (args.no_rows or world > 1 or selftest) else [r for r in args.rows.split(",") if r]

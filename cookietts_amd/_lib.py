@@ -205,6 +205,7 @@ SIGNATURES = {
                                              C.c_int32, C.c_int32, _FP, C.c_size_t, _FP]),
     "ctts_waveflow_inverse_cond_f32": (C.c_int, [C.POINTER(WaveFlowConfig), _FP, _FP, _FP, C.c_int32, C.c_int32, _FP,
                                                  C.c_int32, C.c_int32, C.c_int32, _FP, C.c_size_t, _FP]),
+    "ctts_waveflow_abort_status": (C.c_int, [C.POINTER(WaveFlowConfig), C.c_int32, C.c_int32, _FP, C.c_size_t, _FP]),
     "ctts_wgax_packed_bytes": (C.c_size_t, [C.POINTER(WgaxConfig)]),
     "ctts_wgax_pack_flow": (C.c_int, [C.POINTER(WgaxConfig), C.c_int32, C.POINTER(WgaxFlowWeights), _FP, _FP]),
     "ctts_wgax_workspace_bytes": (C.c_size_t, [C.POINTER(WgaxConfig), C.c_int32, C.c_int64]),
@@ -233,18 +234,20 @@ SIGNATURES = {
     "ctts_last_gemm_loop": (C.c_int, []),
     "ctts_tuning_reload": (C.c_int, []),
     "ctts_tuning_flags": (C.c_int, []),
-    "ctts_profile_enable": (C.c_int, [C.c_int32]),
-    "ctts_profile_collect": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "ctts_profile_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "ctts_profile_bind": (C.c_int, [C.c_void_p]),
+    "ctts_profile_collect": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "ctts_profile_destroy": (C.c_int, [C.c_void_p]),
 }
 
-# CTTS_GEMM_*: ONE encoding for the f32_gemm_mode field of the config structs (the mode a MODEL asks for) and for the
-# deprecated process-wide default (ctts_set_f32_gemm_mode / ctts_get_f32_gemm_mode, ABI 5)
+# CTTS_GEMM_*: the f32_gemm_mode field of the config structs (the mode a MODEL asks for).  There is no process-wide default
+# any more (ABI 6): "default" / None = fp32 MFMA.
 MODEL_GEMM_MODES = {None: 0, "default": 0, "f32": 1, "bf16x3": 2, "bf16x6": 3}
 GEMM_MODES = {"f32": 1, "bf16x3": 2, "bf16x6": 3}
 
 
 def model_gemm_mode(mode):
-    """``None`` / ``"default"`` (the library default), ``"f32"``, ``"bf16x3"`` or ``"bf16x6"`` -> CTTS_GEMM_*."""
+    """``None`` / ``"default"`` (fp32 MFMA), ``"f32"``, ``"bf16x3"`` or ``"bf16x6"`` -> CTTS_GEMM_*."""
     try:
         return MODEL_GEMM_MODES[mode]
     except KeyError:
@@ -252,14 +255,52 @@ def model_gemm_mode(mode):
 
 
 def set_f32_gemm_mode(mode):
-    """Library DEFAULT main loop of the fp32 conv-GEMM, used by models that did not choose one themselves
-    (``model.set_f32_gemm_mode(...)`` puts the choice into the model's own config struct, so two models in one process
-    can differ): ``"f32"`` (initial value, fp32 MFMA), ``"bf16x3"`` (each operand split in registers into hi + lo
-    bf16, three bf16 MFMA products per pair, fp32 accumulation; tensors and weights stay fp32) or ``"bf16x6"`` (hi + mid +
-    lo, six products: fp32-grade).  Returns the previous default's name."""
-    prev = {v: k for k, v in GEMM_MODES.items()}[lib().ctts_get_f32_gemm_mode()]
-    check(lib().ctts_set_f32_gemm_mode(GEMM_MODES[mode]), "ctts_set_f32_gemm_mode")
-    return prev
+    """Removed with ABI 6: the process-wide default main loop was hidden state shared by every model and thread.  Choose
+    per model: ``model.set_f32_gemm_mode("bf16x6")`` (it travels in the model's config struct)."""
+    if mode in (None, "default", "f32"):
+        return "f32"
+    raise RuntimeError(f"cookietts_amd.set_f32_gemm_mode({mode!r}): the process-wide default was removed; "
+                       f"call model.set_f32_gemm_mode({mode!r}) on each model instead")
+
+
+class Profile:
+    """A caller-owned set of kernel-timing slots (``ctts_profile_create``).  Inside ``with profile:`` the calling THREAD's
+    WaveGlow launches are bracketed with HIP events on their stream and filed here; ``collect(which)`` -> (launches, total
+    ms) and empties the slot.  Two threads with two profiles never see each other's launches."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        check(lib().ctts_profile_create(C.byref(h)), "ctts_profile_create")
+        self._h = h
+
+    def __enter__(self):
+        check(lib().ctts_profile_bind(self._h), "ctts_profile_bind")
+        return self
+
+    def __exit__(self, *exc):
+        check(lib().ctts_profile_bind(None), "ctts_profile_bind")
+        return False
+
+    bind = __enter__
+
+    def unbind(self):
+        self.__exit__()
+
+    def collect(self, which):
+        n, ms = C.c_int64(), C.c_double()
+        check(lib().ctts_profile_collect(self._h, which, C.byref(n), C.byref(ms)), "ctts_profile_collect")
+        return int(n.value), float(ms.value)
+
+    def close(self):
+        if self._h is not None and _LIB is not None:
+            _LIB.ctts_profile_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 TUNING_BITS = {"CTTS_F32_NO_GLDS": 0, "CTTS_GEMM_NO_XCD_PAIR": 1, "CTTS_BF16_NO_GLDS": 2, "CTTS_BF16_NO_WIDE": 3,
@@ -315,13 +356,8 @@ def lib():
                 raise HipLibraryError(f"{path} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
-        if handle.ctts_abi_version() != 5:
+        if handle.ctts_abi_version() != 6:
             raise HipLibraryError(f"ABI version mismatch: library reports {handle.ctts_abi_version()}")
-        env_mode = os.environ.get("CTTS_F32_GEMM_MODE")          # "f32" (default) or "bf16x3": see set_f32_gemm_mode
-        if env_mode:
-            if env_mode not in GEMM_MODES:
-                raise HipLibraryError(f"CTTS_F32_GEMM_MODE={env_mode!r}: expected one of {sorted(GEMM_MODES)}")
-            handle.ctts_set_f32_gemm_mode(GEMM_MODES[env_mode])
         _LIB = handle
     return _LIB
 

@@ -195,7 +195,6 @@ int launch_wf_row_persistent(const GemmArgs* layers_dev, const WfTailDesc* tails
 // Library DEFAULT of the main-loop selection (what CTTS_GEMM_DEFAULT resolves to), in the config structs' own encoding:
 // CTTS_GEMM_F32 (initially), CTTS_GEMM_BF16X3 (three bf16 MFMA products per fp32 operand pair, see
 // conv_gemm_f32_kernel<..., X3>) or CTTS_GEMM_BF16X6.  ctts_set_f32_gemm_mode (deprecated: prefer the per-model field).
-int set_gemm_f32_mode(int mode);
 int get_gemm_f32_mode();
 // what the calling thread's most recent conv-GEMM launch ran (ctts_last_gemm_loop): bits 0-3 split level, 16 small shape, 32 split-K, 64 row queue, 128 its whole-flow form
 void note_gemm_loop(int code);

@@ -681,8 +681,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
     }
 }
 
-std::atomic<int> g_gemm_mode{CTTS_GEMM_F32};
-inline int gemm_f32_mode() { return g_gemm_mode.load(std::memory_order_relaxed); }
+// CTTS_GEMM_DEFAULT in a config struct = fp32 MFMA.  (Until ABI 5 a process-wide default could be set; it is gone: the
+// mode travels in the config structs only.)
+inline int gemm_f32_mode() { return CTTS_GEMM_F32; }
 
 template <int EPI, int XS>
 void launch_shape_xs(int bm, dim3 grid, hipStream_t stream, const GemmArgs& a) {
@@ -718,13 +719,6 @@ void launch_shape(int bm, dim3 grid, hipStream_t stream, const GemmArgs& a) {
 
 }  // namespace
 
-// the library default is stored in the SAME encoding as the config structs' field (CTTS_GEMM_F32 / _BF16X3 / _BF16X6)
-int set_gemm_f32_mode(int mode) {
-    if (mode == CTTS_GEMM_DEFAULT) mode = CTTS_GEMM_F32;     // "reset": the initial value
-    if (mode != CTTS_GEMM_F32 && mode != CTTS_GEMM_BF16X3 && mode != CTTS_GEMM_BF16X6) return -1;
-    g_gemm_mode.store(mode, std::memory_order_relaxed);
-    return 0;
-}
 int get_gemm_f32_mode() { return gemm_f32_mode(); }
 namespace { thread_local int t_last_loop = 0; }
 void note_gemm_loop(int code) { t_last_loop = code; }
@@ -841,7 +835,9 @@ int launch_gemm_f32(int epi, const GemmArgs& a_in, hipStream_t stream) {
         const long long slots = 2ll * wf_row_cus();
         const long long rounds = a.MB * tiles / slots;
         const long long rem_tiles = (a.MB * tiles - rounds * slots + a.MB - 1) / a.MB;
-        if (rounds >= 2 && rem_tiles > 0 && rem_tiles * a.MB <= slots * 3 / 10 && rem_tiles < a.ntiles) {
+        // (the peeled tiles must hold valid columns: a caller may over-provision ntiles, L <= (ntiles - rem_tiles) * bn)
+        if (rounds >= 2 && rem_tiles > 0 && rem_tiles * a.MB <= slots * 3 / 10 && rem_tiles < a.ntiles &&
+            (long long)(a.ntiles - rem_tiles) * gemm_bn(a.bm) < a.L) {
             GemmArgs r = a;                                    // the last rem_tiles column tiles of the last batch item
             const int bn = gemm_bn(a.bm);
             const long long co = (long long)(a.ntiles - rem_tiles) * bn;

@@ -1268,14 +1268,27 @@ __global__ __launch_bounds__(256, 2) void wf_row_persistent_kernel(const WfRowAr
             const int tt = tile + t - HALO;
             if (tt >= tile - halo && tt <= tile + halo && tt >= 0 && tt < ntiles) {
                 const unsigned int* f = w.flags + (size_t)(gs - 1) * per_layer + b * ntiles + tt;
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                // The bound is on time WITHOUT PROGRESS, not on wall time: s_memrealtime keeps running while the process is
+                // preempted or shares the GPU, so an expired period only aborts if the launch's item counter has not moved since
+                // the period began - and the first expiry merely opens a second period (everybody was frozen together; the
+                // others need a moment to be seen moving again).
+                unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                unsigned int seen = __hip_atomic_load(w.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int expired = 0;
                 for (unsigned spins = 0; __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != w.epoch; ++spins) {
                     __builtin_amdgcn_s_sleep(8);
                     if ((spins & 63u) == 63u) {
-                        if (__builtin_amdgcn_s_memrealtime() - t0 > w.timeout_ticks) {
-                            __hip_atomic_store(w.abort_word, 1u + (unsigned)gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            s_abort = 1;
-                            break;
+                        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                        if (now - t0 > w.timeout_ticks) {
+                            const unsigned int c = __hip_atomic_load(w.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (c != seen) expired = 0;                    // items were claimed meanwhile: the launch is alive
+                            else if (++expired >= 2) {
+                                __hip_atomic_store(w.abort_word, 1u + (unsigned)gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                s_abort = 1;
+                                break;
+                            }
+                            seen = c;
+                            t0 = now;
                         }
                         if (__hip_atomic_load(w.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { s_abort = 1; break; }
                     }
@@ -1284,6 +1297,11 @@ __global__ __launch_bounds__(256, 2) void wf_row_persistent_kernel(const WfRowAr
         }
         __syncthreads();                                   // dependencies met
         if (__builtin_amdgcn_readfirstlane(s_abort)) break;
+        // Acquire.  Everything another workgroup wrote inside this launch is read with sc1 loads / sc1 DMA (GemmSeg.fresh, the
+        // tail's atomic loads), which is what makes the relaxed flag protocol correct today; the invalidate (buffer_inv sc1)
+        // makes it correct for a plain load of such data too, should one ever be added.  CTTS_WF_QUEUE_DEBUG=256
+        // leaves it out (A/B: profiles/r5_17_wf_queue_acquire_ab.txt).
+        if (!(w.debug & 256)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (layer == w.nlayers) {
             typedef const __attribute__((address_space(4))) WfTailDesc const_tail;
             wf_tail_start_tile<BODY == 1 ? 64 : 128, const_tail>(*((const_tail*)w.tails + row), tile, b, s_tail);
@@ -1435,7 +1453,7 @@ int launch_wf_row_persistent(const GemmArgs* layers_dev, const WfTailDesc* tails
     WfRowArgs w{};
     w.layers = layers_dev; w.tails = tails_dev; w.nrows = nrows; w.nlayers = nlayers; w.ntiles_s = wf_row_tiles(L, 0); w.ntiles_k = wf_row_tiles(L, 1); w.batch = batch;
     w.counter = counter; w.flags = flags; w.abort_word = abort_word; w.epoch = epoch;
-    w.timeout_ticks = 50u * 1000u * 1000u;                              // 0.5 s: a whole call is ~0.2 s
+    w.timeout_ticks = 100u * 1000u * 1000u;                             // 1 s without a single item being claimed, twice in a row (a whole call is ~0.2 s)
     w.debug = tuning().wf_queue_debug;
     CTTS_CHECK_ARG(layers_dev && counter && flags && abort_word && epoch > 0 && nlayers >= 1 && nrows >= 1 && batch >= 1 &&
                        w.ntiles_s >= 1 && (body == 0 || body == 1), "waveflow row launch: bad argument");

@@ -155,6 +155,7 @@ int make_wf_geom(const WfPlan& p, int samples, WfGeom& g) {
 // Row queue (wf_row_persistent_kernel): control words + the layer descriptors of one flow, inside the caller's workspace
 struct WfQueueWs {
     unsigned int *abort_word, *counters, *flags;     // [1] | [n_flows * n_group] | [n_group * (n_layers + 1) stages][batch][tiles of 64 columns]
+    unsigned int* status;                            // sticky: WF_ABORT_MAGIC once a call on this workspace aborted, until it is reported
     GemmArgs* layers;                                // [n_group][n_layers] of the flow being run
     WfTailDesc* tails;                               // [n_group]
     size_t control_bytes;                            // abort word .. end of the flags: zeroed at the start of every call
@@ -184,6 +185,7 @@ void wf_carve(const WfPlan& p, const WfGeom& g, int batch, float* base, WfWs& w)
         w.q.control_bytes = control * sizeof(float);
         w.q.layers = reinterpret_cast<GemmArgs*>(take(((size_t)p.c.n_group * p.c.n_layers * sizeof(GemmArgs) + 3) / 4));
         w.q.tails = reinterpret_cast<WfTailDesc*>(take(((size_t)p.c.n_group * sizeof(WfTailDesc) + 3) / 4));
+        w.q.status = reinterpret_cast<unsigned int*>(take(ALIGN_F));   // outside the per-call memset
     }
     w.total = o;
 }
@@ -617,9 +619,13 @@ constexpr int WF_NREG = 2 * WF_NBIG - 1;     // regions incl. the one-tile separ
 #ifndef WF_ROW_QUEUE_SPLITK_BELOW
 #define WF_ROW_QUEUE_SPLITK_BELOW 400
 #endif
-// audio[b][:] = NaN when the row queue's abort word is set
-__global__ void wf_abort_poison_kernel(const unsigned int* __restrict__ abort_word, float* __restrict__ audio, long long n) {
+// audio[b][:] = NaN when the row queue's abort word is set, and the workspace's sticky status word says so until a later
+// call reports it (CTTS_E_ABORT): the NaN is the in-stream marker, the status the one a caller can act on
+constexpr unsigned int WF_ABORT_MAGIC = 0xAB0F7001u;       // a value, not a flag: the workspace may start out as anything
+__global__ void wf_abort_poison_kernel(const unsigned int* __restrict__ abort_word, float* __restrict__ audio, long long n,
+                                       unsigned int* __restrict__ status) {
     if (*abort_word == 0) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *status = WF_ABORT_MAGIC;
     float* a = audio + (size_t)blockIdx.x * n;
     for (long long i = threadIdx.x; i < n; i += 256) a[i] = __builtin_nanf("");
 }
@@ -728,6 +734,22 @@ struct WfRegionSplit {
 };
 
 
+thread_local const void* t_wf_queued_ws = nullptr;          // workspace of this thread's last row-queue call, not yet checked
+
+// Synchronises `s`, reads the workspace's sticky status word and clears it: CTTS_E_ABORT (+ ctts_last_error) if a row-queue
+// call on this workspace gave up its bounded wait since the last report.
+int wf_report_abort(unsigned int* status, hipStream_t s) {
+    unsigned int host = 0;
+    CTTS_CHECK_HIP(hipMemcpyAsync(&host, status, sizeof host, hipMemcpyDeviceToHost, s));
+    CTTS_CHECK_HIP(hipStreamSynchronize(s));
+    if (host != WF_ABORT_MAGIC) return CTTS_OK;
+    CTTS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof host, s));
+    set_error("waveflow: the row queue of an earlier call on this workspace aborted (a bounded wait between workgroups "
+              "expired); that call's audio is NaN.  Repeat it - with CTTS_WF_NO_ROW_QUEUE=1 (one launch per layer) if it "
+              "happens again");
+    return CTTS_E_ABORT;
+}
+
 int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float* z, const float* cond, int cond_ld,
                int cond_pad, float* audio, int batch, int samples, int frames, void* workspace, size_t workspace_bytes,
                void* stream) {
@@ -741,6 +763,12 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
         return CTTS_E_WORKSPACE;
     }
     hipStream_t s = as_stream(stream);
+    // the previous call of this thread on this workspace used the row queue: if it aborted, say so now instead of computing
+    // on top of it (one stream synchronisation + 4 bytes; the caller sees CTTS_E_ABORT once, the call after that runs)
+    if (t_wf_queued_ws == workspace) {
+        t_wf_queued_ws = nullptr;
+        if ((rc = wf_report_abort(w.q.status, s))) return rc;
+    }
     const float* blob = static_cast<const float*>(packed);
     const int G = p.c.n_group, C = p.C, L = g.L, kh = p.c.kernel_size_h, kw = p.c.kernel_size_w;
     const int gkh = p.sep ? 1 : kh, gkw = p.sep ? 1 : kw;
@@ -1063,8 +1091,10 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
     CTTS_CHECK_LAUNCH("wf_unsqueeze");
     if (queue_on && (rc = t_wf_desc.end(s))) return rc;
     if (queue_on) {      // a bounded wait of the row queue expired (never, by construction): the audio is NaN, not plausible noise
-        hipLaunchKernelGGL(wf_abort_poison_kernel, dim3(batch), dim3(256), 0, s, w.q.abort_word, audio, (long long)G * L);
+        hipLaunchKernelGGL(wf_abort_poison_kernel, dim3(batch), dim3(256), 0, s, w.q.abort_word, audio, (long long)G * L,
+                           w.q.status);
         CTTS_CHECK_LAUNCH("wf_abort_poison");
+        t_wf_queued_ws = workspace;                        // the thread's next call on this workspace looks at the status first
     }
     return CTTS_OK;
 }
@@ -1152,6 +1182,21 @@ int ctts_waveflow_inverse_f32(const ctts_waveflow_config* cfg, const void* packe
     CTTS_CHECK_ARG(cfg && !cfg->cond_precomputed, "waveflow inverse: this model takes per-flow conditioning "
                                                   "(ctts_waveflow_inverse_cond_f32)");
     return wf_inverse(cfg, packed, z, mel, 0, 0, audio, batch, samples, frames, workspace, workspace_bytes, stream);
+}
+
+int ctts_waveflow_abort_status(const ctts_waveflow_config* cfg, int32_t batch, int32_t samples, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    WfPlan p; WfGeom g; WfWs w;
+    int rc = make_wf_plan(cfg, p); if (rc) return rc;
+    rc = make_wf_geom(p, samples, g); if (rc) return rc;
+    CTTS_CHECK_ARG(workspace && batch >= 1, "waveflow abort_status: bad argument");
+    wf_carve(p, g, batch, static_cast<float*>(workspace), w);
+    if (w.total * sizeof(float) > workspace_bytes) {
+        set_error("waveflow abort_status: workspace %zu bytes < required %zu", workspace_bytes, w.total * sizeof(float));
+        return CTTS_E_WORKSPACE;
+    }
+    if (t_wf_queued_ws == workspace) t_wf_queued_ws = nullptr;
+    return wf_report_abort(w.q.status, as_stream(stream));
 }
 
 int ctts_waveflow_inverse_cond_f32(const ctts_waveflow_config* cfg, const void* packed, const float* z,

@@ -153,29 +153,33 @@ void carve(const Plan& p, const Geom& g, int batch, float* base, Workspace& w) {
     w.x = take(B * p.C * g.ld);
     w.act = take(B * p.C * g.ld);
     w.out = take(B * p.C * g.ld);
-    w.act_all = take((size_t)p.c.n_layers * B * p.C * g.ld);
+    // gated activations of ONE skip group (its skip GEMM runs at the end of the group; the next group reuses the slots)
+    w.act_all = take((size_t)std::min(p.c.n_layers, (int)Plan::F32_SKIP_GROUP) * B * p.C * g.ld);
     w.total = o;
 }
 
 // ---- profiling hooks ---------------------------------------------------------------
+// A profile is a caller-owned handle (ctts_profile_create); a thread records into the handle it bound
+// (ctts_profile_bind), so two threads timing two models at once keep disjoint slots.  No process-wide switch.
 struct Prof {
     std::mutex mu;
-    bool on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[CTTS_PROF_N];
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
-} g_prof;
+};
+thread_local Prof* t_prof = nullptr;
 
 struct ProfScope {
     int which; hipStream_t s; hipEvent_t stop = nullptr; bool active = false;
     ProfScope(int which_, hipStream_t s_) : which(which_), s(s_) {
-        std::lock_guard<std::mutex> lk(g_prof.mu);
-        if (!g_prof.on) return;
+        Prof* pr = t_prof;
+        if (!pr) return;
+        std::lock_guard<std::mutex> lk(pr->mu);
         std::pair<hipEvent_t, hipEvent_t> e;
-        if (!g_prof.pool.empty()) { e = g_prof.pool.back(); g_prof.pool.pop_back(); }
+        if (!pr->pool.empty()) { e = pr->pool.back(); pr->pool.pop_back(); }
         else { if (hipEventCreate(&e.first) != hipSuccess || hipEventCreate(&e.second) != hipSuccess) return; }
         (void)hipEventRecord(e.first, s);
         stop = e.second;
-        g_prof.ev[which].push_back(e);
+        pr->ev[which].push_back(e);
         active = true;
     }
     ~ProfScope() { if (active) (void)hipEventRecord(stop, s); }
@@ -260,7 +264,7 @@ int run_wn_stack(const Plan& p, const Geom& g, const float* blob, int k, const f
     const size_t act_stride = (size_t)batch * p.C * g.ld;
     for (int i = 0; i < p.c.n_layers; ++i) {
         const int dil = 1 << i;
-        if (defer) act = act_all + (size_t)i * act_stride;
+        if (defer) act = act_all + (size_t)(i % Plan::F32_SKIP_GROUP) * act_stride;
         {
             GemmArgs a = base_args(p, g, batch);
             a.A = blob + f.in_A[i]; a.bias = blob + f.in_b[i];
@@ -296,7 +300,7 @@ int run_wn_stack(const Plan& p, const Geom& g, const float* blob, int k, const f
                 a.A = blob + f.skip_A[gi]; a.bias = blob + f.skip_b[gi];
                 a.nseg = nl; a.nch_total = nl * p.nch_rs; a.MB = p.mb_c();
                 for (int j = 0; j < nl; ++j)
-                    a.seg[j] = {act_all + (size_t)(gi * Plan::F32_SKIP_GROUP + j) * act_stride, cstride, p.nch_rs, 0, 0, 0};
+                    a.seg[j] = {act_all + (size_t)j * act_stride, cstride, p.nch_rs, 0, 0, 0};
                 a.M = p.C; a.split = 0;
                 a.dst0 = x; a.dst0_bstride = cstride; a.acc0 = 1;
                 a.dst1 = out; a.dst1_bstride = cstride; a.acc1 = gi > 0 ? 1 : 0;
@@ -399,14 +403,14 @@ void carve_bf(const Plan& p, const Geom& g, int batch, char* base, BfWs& w, int 
     w.h_tmp_bf = (bf16_t*)take(planes * B * p.c.n_flows * p.H * g.ld * 2);
     w.h_bf = (bf16_t*)take(planes * B * p.c.n_flows * p.H * g.ld * 2);
     w.x = (bf16_t*)take(planes * B * p.C * g.ld * 2);
-    w.act = (bf16_t*)take(planes * B * p.C * g.ld * 2 * p.c.n_layers);   // one buffer per layer (deferred skip GEMM)
+    w.act = (bf16_t*)take(planes * B * p.C * g.ld * 2 * std::min(p.c.n_layers, BF_SKIP_GROUP));   // one buffer per layer of a skip group
     w.out = (bf16_t*)take(planes * B * p.C * g.ld * 2);
     const long long on = P == 3 ? 1 : 0;
     w.spect_lo = on * (long long)(B * p.K0 * g.ld);
     w.spk_lo = on * (long long)(B * p.c.n_flows * p.S * g.ld);
     w.h_lo = on * (long long)(B * p.c.n_flows * p.H * g.ld);
     w.x_lo = on * (long long)(B * p.C * g.ld);
-    w.act_lo = on * (long long)(B * p.C * g.ld) * p.c.n_layers;
+    w.act_lo = on * (long long)(B * p.C * g.ld) * std::min(p.c.n_layers, BF_SKIP_GROUP);
     w.total_bytes = o;
 }
 
@@ -560,9 +564,29 @@ int run_wn_stack_bf16(const Plan& p, const BfPlan& q, const Geom& g, const float
     const int ncx = p.C / BGEMM_KC, P = q.P, ks = p.c.kernel_size;
     const size_t act_layer = (size_t)batch * cstride;
     int rc;
+    const float* skip_b = reinterpret_cast<const float*>(bblob + q.skip_b[k]);
+    // skip sum = sum_i W_skip_i act_i + sum_i b_skip_i: K = n_layers * C, fp32 accumulation inside a launch (one launch at the
+    // end of each group of BF_SKIP_GROUP layers, over the group's kept activations - the next group reuses their slots), one
+    // rounding of the running sum per group of BF_SKIP_GROUP layers
+    auto skip_group = [&](int gi) -> int {
+        const int nl = q.group_layers(gi, p.c.n_layers);
+        BGemmArgs a{};
+        a.ld = g.ld; a.pad = g.pad; a.L = g.L; a.ntiles = g.ntiles; a.batch = batch;
+        a.A = bblob + q.skip_A[k][gi]; a.bias = skip_b + (gi == 0 ? 0 : q.mb_c * BGEMM_BM);
+        int ns = 0;
+        for (int j = 0; j < nl; ++j)
+            ns = push_segs(a, ns, P, w.act + (size_t)j * act_layer, w.act_lo, cstride, ncx, 0, 0);
+        a.nseg = ns; a.nch_total = nl * q.nch_rs; a.MB = q.mb_c;
+        a.M = p.C; a.split = p.C;
+        a.dst0 = w.out; a.dst0_bstride = cstride; a.acc0 = gi > 0 ? 1 : 0;
+        a.dst1 = w.out; a.dst1_bstride = cstride; a.acc1 = a.acc0;
+        a.lo_off = w.x_lo;
+        ProfScope ps(CTTS_PROF_WN_SKIP, s);
+        return launch_gemm_bf16(BGEMM_EPI_SPLIT, a, s);
+    };
     for (int i = 0; i < p.c.n_layers; ++i) {
         const int dil = 1 << i;
-        bf16_t* act = w.act + (size_t)i * act_layer;
+        bf16_t* act = w.act + (size_t)(i % BF_SKIP_GROUP) * act_layer;
         {
             BGemmArgs a{};
             a.ld = g.ld; a.pad = g.pad; a.L = g.L; a.ntiles = g.ntiles; a.batch = batch;
@@ -590,25 +614,9 @@ int run_wn_stack_bf16(const Plan& p, const BfPlan& q, const Geom& g, const float
             ProfScope ps(CTTS_PROF_WN_RS, s);
             if ((rc = launch_gemm_bf16(BGEMM_EPI_SPLIT, a, s))) return rc;
         }
-    }
-    // skip sum = sum_i W_skip_i act_i + sum_i b_skip_i: K = n_layers * C, fp32 accumulation inside a launch, one
-    // rounding of the running sum per group of BF_SKIP_GROUP layers
-    const float* skip_b = reinterpret_cast<const float*>(bblob + q.skip_b[k]);
-    for (int gi = 0; gi < q.n_groups; ++gi) {
-        const int nl = q.group_layers(gi, p.c.n_layers);
-        BGemmArgs a{};
-        a.ld = g.ld; a.pad = g.pad; a.L = g.L; a.ntiles = g.ntiles; a.batch = batch;
-        a.A = bblob + q.skip_A[k][gi]; a.bias = skip_b + (gi == 0 ? 0 : q.mb_c * BGEMM_BM);
-        int ns = 0;
-        for (int j = 0; j < nl; ++j)
-            ns = push_segs(a, ns, P, w.act + (size_t)(gi * BF_SKIP_GROUP + j) * act_layer, w.act_lo, cstride, ncx, 0, 0);
-        a.nseg = ns; a.nch_total = nl * q.nch_rs; a.MB = q.mb_c;
-        a.M = p.C; a.split = p.C;
-        a.dst0 = w.out; a.dst0_bstride = cstride; a.acc0 = gi > 0 ? 1 : 0;
-        a.dst1 = w.out; a.dst1_bstride = cstride; a.acc1 = a.acc0;
-        a.lo_off = w.x_lo;
-        ProfScope ps(CTTS_PROF_WN_SKIP, s);
-        if ((rc = launch_gemm_bf16(BGEMM_EPI_SPLIT, a, s))) return rc;
+        if (i == p.c.n_layers - 1 || (i + 1) % BF_SKIP_GROUP == 0) {
+            if ((rc = skip_group(i / BF_SKIP_GROUP))) return rc;
+        }
     }
     return CTTS_OK;
 }
@@ -820,11 +828,14 @@ int ctts_waveglow_infer_spk_f32(const ctts_waveglow_config* cfg, const void* pac
 }
 
 int ctts_set_f32_gemm_mode(int32_t mode) {
-    if (set_gemm_f32_mode(mode)) {
-        set_error("set_f32_gemm_mode: unknown mode %d (CTTS_GEMM_F32 = 1, CTTS_GEMM_BF16X3 = 2, CTTS_GEMM_BF16X6 = 3; 0 resets to fp32)", mode);
-        return CTTS_E_ARG;
-    }
-    return CTTS_OK;
+    // ABI 6: there is no process-wide default any more (hidden state shared by every model and thread of the process)
+    if (mode == CTTS_GEMM_DEFAULT || mode == CTTS_GEMM_F32) return CTTS_OK;
+    if (mode == CTTS_GEMM_BF16X3 || mode == CTTS_GEMM_BF16X6)
+        set_error("set_f32_gemm_mode: the process-wide default was removed in ABI 6; put CTTS_GEMM_* %d into the f32_gemm_mode "
+                  "field of the model's config struct", mode);
+    else
+        set_error("set_f32_gemm_mode: unknown mode %d (CTTS_GEMM_F32 = 1, CTTS_GEMM_BF16X3 = 2, CTTS_GEMM_BF16X6 = 3)", mode);
+    return CTTS_E_ARG;
 }
 int ctts_get_f32_gemm_mode(void) { return get_gemm_f32_mode(); }
 int ctts_last_gemm_loop(void) { return last_gemm_loop(); }
@@ -840,26 +851,46 @@ int ctts_tuning_flags(void) {
            (t.bf16_no_ps ? (1 << 21) : 0);
 }
 
-int ctts_profile_enable(int32_t on) {
-    std::lock_guard<std::mutex> lk(g_prof.mu);
-    g_prof.on = on != 0;
+int ctts_profile_create(void** handle) {
+    CTTS_CHECK_ARG(handle, "profile_create: NULL");
+    *handle = new Prof();
     return CTTS_OK;
 }
 
-int ctts_profile_collect(int32_t which, int64_t* launches, double* total_ms) {
-    CTTS_CHECK_ARG(which >= 0 && which < CTTS_PROF_N && launches && total_ms, "profile_collect: bad argument");
-    std::lock_guard<std::mutex> lk(g_prof.mu);
+int ctts_profile_bind(void* handle) {
+    t_prof = static_cast<Prof*>(handle);
+    return CTTS_OK;
+}
+
+int ctts_profile_collect(void* handle, int32_t which, int64_t* launches, double* total_ms) {
+    Prof* pr = static_cast<Prof*>(handle);
+    CTTS_CHECK_ARG(pr && which >= 0 && which < CTTS_PROF_N && launches && total_ms, "profile_collect: bad argument");
+    std::lock_guard<std::mutex> lk(pr->mu);
     double tot = 0.0;
     int64_t n = 0;
-    for (auto& e : g_prof.ev[which]) {
+    for (auto& e : pr->ev[which]) {
         float ms = 0.f;
         CTTS_CHECK_HIP(hipEventSynchronize(e.second));
         CTTS_CHECK_HIP(hipEventElapsedTime(&ms, e.first, e.second));
         tot += ms; ++n;
-        g_prof.pool.push_back(e);
+        pr->pool.push_back(e);
     }
-    g_prof.ev[which].clear();
+    pr->ev[which].clear();
     *launches = n; *total_ms = tot;
+    return CTTS_OK;
+}
+
+int ctts_profile_destroy(void* handle) {
+    Prof* pr = static_cast<Prof*>(handle);
+    if (!pr) return CTTS_OK;
+    if (t_prof == pr) t_prof = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(pr->mu);
+        for (int w = 0; w < CTTS_PROF_N; ++w)
+            for (auto& e : pr->ev[w]) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        for (auto& e : pr->pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    }
+    delete pr;
     return CTTS_OK;
 }
 

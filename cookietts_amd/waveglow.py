@@ -174,8 +174,8 @@ class WaveGlow(nn.Module):
         """Main loop of THIS model's fp32 GEMMs: ``"f32"`` (fp32 MFMA), ``"bf16x3"`` (split bf16: fp32 tensors, three
         bf16 MFMA products per operand pair, 16 mantissa bits per operand), ``"bf16x6"`` (three-way split = all 24
         mantissa bits, the six products >= 2^-16: fp32-grade error at 6/16 of the fp32 matrix-pipe cost) or ``None`` /
-        ``"default"`` (whatever ``cookietts_amd.set_f32_gemm_mode`` set for the process; fp32 MFMA initially).  Travels
-        in the config struct: other models are not affected."""
+        ``"default"`` (fp32 MFMA).  Travels in the config struct: other models are not affected; there is no process-wide
+        default (removed with ABI 6)."""
         _lib.model_gemm_mode(mode)
         self._f32_gemm_mode = mode
         return self

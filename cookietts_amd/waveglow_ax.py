@@ -18,7 +18,7 @@ Host-side mirror of ``/root/reference/CookieTTS/_4_mtw/waveglow/efficient_model_
 Same constructor kwargs, same ``state_dict`` keys (``WN.k.WN.{start,cond_layers.l,in_layers.i,res_skip_layers.i}.
 {weight_g,weight_v,bias}``, ``WN.k.WN.end.{weight,bias}``, ``convinv.k.weight``, ``upsample_net.*``, ...), same
 ``infer`` / ``inverse`` contracts (output length ``(F-1)*hop`` with the default ``artifact_trimming=1``;
-``return_CPU=True`` moves the result to the host like the reference).  The few options left (DESIGN.md section 6) raise
+``return_CPU=True`` moves the result to the host like the reference).  The few options left (DESIGN.md section 4) raise
 NotImplementedError.  The conditioning stacks are composed on the host from operator-level C entry points
 (``ctts_conv1d_f32``, ``ctts_embed_rows_f32``, ``ctts_scale_add_rows_f32``, ``ctts_resample_rows_f32``,
 ``ctts_interleave_phases_f32``, ...); all arithmetic runs in the C-ABI HIP library; no CPU fallback.
@@ -825,6 +825,11 @@ class WaveGlow(nn.Module):
                                                   stream), "ctts_deemphasis_f32")
         if return_CPU:
             audio = audio.cpu()
+            # the copy synchronised the stream: a row-queue abort of THIS call is known now - raise instead of handing out
+            # its NaN audio (a call that stays on the device reports it through the next call on this workspace: CTTS_E_ABORT)
+            with torch.cuda.device(device):
+                _lib.check(lib.ctts_waveflow_abort_status(C.byref(cfg), B, T, _lib.ptr(ws), ws.numel() * 4, stream),
+                           "WaveFlow.inverse")
         return audio, None
 
     def _inverse_1d(self, z, cond, speaker_ids, return_CPU):

@@ -37,17 +37,23 @@ extern "C" {
 #define CTTS_E_ARG (-1)       /* bad argument / unsupported shape */
 #define CTTS_E_LAUNCH (-2)    /* HIP launch or runtime error */
 #define CTTS_E_WORKSPACE (-3) /* workspace too small */
+#define CTTS_E_ABORT (-4)     /* an earlier call on this workspace gave up a bounded device-side wait (ABI 6; ctts_waveflow_abort_status) */
 
-#define CTTS_ABI_VERSION 5   /* 2: ctts_waveglow_config.speaker_embed_dim, ctts_waveglow_flow_weights.speaker_embed
+#define CTTS_ABI_VERSION 6   /* 2: ctts_waveglow_config.speaker_embed_dim, ctts_waveglow_flow_weights.speaker_embed
                               * 3: gated_unit / merge_res_skip in ctts_waveflow_config and ctts_wgax_config
                               * 4: f32_gemm_mode in ctts_waveglow_config, ctts_waveflow_config, ctts_wgax_config and
                               *    ctts_conv1d_desc (the arithmetic mode belongs to the model, not to the process);
                               *    ctts_tuning_reload; the persistent decoder's control words are exactly the last 64 bytes
                               * 5: ctts_set_f32_gemm_mode / ctts_get_f32_gemm_mode speak CTTS_GEMM_* (one encoding for the
-                              *    process default and the config structs' field) and are deprecated; ctts_last_gemm_loop */
+                              *    process default and the config structs' field) and are deprecated; ctts_last_gemm_loop
+                              * 6: no process-global state behind the ABI: the process-wide GEMM mode is gone (set fails for
+                              *    the split modes), profiles are caller-owned handles (ctts_profile_create / _bind /
+                              *    _collect(handle, ...) / _destroy replace ctts_profile_enable / _collect(which, ...)), a
+                              *    row-queue abort is a status (CTTS_E_ABORT from the next ctts_waveflow_inverse_* on that
+                              *    workspace, ctts_waveflow_abort_status) besides the NaN audio */
 
 /* Main loop of the fp32 conv-GEMM a model's launches use (field f32_gemm_mode of the config structs). */
-#define CTTS_GEMM_DEFAULT 0  /* the library default: fp32 MFMA unless the deprecated ctts_set_f32_gemm_mode changed it */
+#define CTTS_GEMM_DEFAULT 0  /* the library default: fp32 MFMA */
 #define CTTS_GEMM_F32 1      /* v_mfma_f32_32x32x2_f32: exact fp32 products */
 #define CTTS_GEMM_BF16X3 2   /* split bf16: hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulation */
 #define CTTS_GEMM_BF16X6 3   /* 3-way split (24 mantissa bits): the six products >= 2^-16 (hh, hm, mh, hl, lh, mm); fp32-grade */
@@ -286,9 +292,14 @@ size_t ctts_waveflow_workspace_bytes(const ctts_waveflow_config* cfg, int32_t ba
  * row = its n_layers fused layers + a tail stage: end conv, affine update of the next latent row, the next row's start conv) as
  * ONE launch whose workgroups take (row, stage, tile) items from an atomic counter in order and wait, per item, for the flags
  * of the neighbouring tiles of the previous stage only.  Items are claimed in order, so the oldest unfinished item can
- * always run: the launch cannot deadlock and needs no co-residency.  Its wait is bounded all the same (0.5 s); if it ever expires
- * every workgroup leaves and the call fills `audio` with NaN instead of returning plausible noise (stream-ordered, so the
- * status code cannot report it).  CTTS_WF_NO_ROW_QUEUE = always one launch per layer.  The queue's control words and layer
+ * always run: the launch cannot deadlock and needs no co-residency.  Its wait is bounded all the same (two periods of 1 s in a
+ * row during which no workgroup of the launch claimed an item - time without progress, not wall time); if it ever expires
+ * every workgroup leaves, the call fills `audio` with NaN instead of returning plausible noise (stream-ordered, so THIS
+ * call's status code cannot report it) and a sticky status word in the workspace is set: the calling thread's NEXT
+ * ctts_waveflow_inverse_* on that workspace synchronises the stream first, returns CTTS_E_ABORT with ctts_last_error() text
+ * and clears the word (the call after that runs normally); ctts_waveflow_abort_status asks at once.  NaN is also a legal
+ * output of this path (ignore_nan, ax:333-334) - the status, not the NaN, is what says "aborted".
+ * CTTS_WF_NO_ROW_QUEUE = always one launch per layer.  The queue's control words and layer
  * descriptors live in the caller's workspace (included in ctts_waveflow_workspace_bytes); the descriptors reach it through a
  * pinned staging buffer of the calling host thread, which the thread's NEXT call rewrites only after an event behind this
  * call's last copy - so a call with the row queue may wait on the host for the thread's previous call and must not be recorded
@@ -297,6 +308,12 @@ int ctts_waveflow_inverse_f32(const ctts_waveflow_config* cfg, const void* packe
                               const float* mel, float* audio, int32_t batch, int32_t samples,
                               int32_t frames, void* workspace, size_t workspace_bytes,
                               void* stream);
+
+/* Synchronises `stream` and reports (and clears) the workspace's row-queue status: CTTS_OK, or CTTS_E_ABORT if a
+ * ctts_waveflow_inverse_* call on this workspace (same cfg / batch / samples, which fix its layout) aborted since the last
+ * report.  The Python WaveFlow.inverse / infer call it whenever they synchronise anyway and raise. */
+int ctts_waveflow_abort_status(const ctts_waveflow_config* cfg, int32_t batch, int32_t samples, void* workspace,
+                               size_t workspace_bytes, void* stream);
 
 /* Same, for cond_precomputed models: cond [n_flows][B][2*C*n_layers][cond_ld] fp32 = the output of each flow's
  * WN conditioning stack at FRAME rate (glow_ax.py:566-577), valid frames at columns [cond_pad, cond_pad+frames);
@@ -660,37 +677,42 @@ int ctts_taco_stop_rule_f32(const float* gate_logits, int32_t batch, int32_t gat
  * thread ran, so that a benchmark row can label itself: bits 0-3 = split level (0 fp32 MFMA, 3, 6), bit 4 = small shape,
  * bit 5 = split-K shape, bit 6 = the WaveFlow row queue, bit 7 = its whole-flow form (one launch per flow, see ctts_waveflow_inverse_f32).
  *
- * DEPRECATED - ctts_set_f32_gemm_mode / ctts_get_f32_gemm_mode: a process-wide default (what CTTS_GEMM_DEFAULT (0) in a
- * config struct resolves to, and the mode of the two entry points without a config struct: ctts_lstm_seq_f32's input
- * projection, ctts_taco_decoder_init_f32's processed memory).  Superseded by the per-model field; kept for callers that
- * flip one switch for a whole process.  Since ABI 5 both speak CTTS_GEMM_*: set takes CTTS_GEMM_F32 / _BF16X3 / _BF16X6
- * (CTTS_GEMM_DEFAULT resets to fp32 MFMA) and returns 0, or -1 for anything else; get returns one of the three. */
+ * REMOVED in ABI 6 - the process-wide default of ABI <= 5 (ctts_set_f32_gemm_mode): hidden state shared by every model and
+ * thread of a process.  CTTS_GEMM_DEFAULT (0) in a config struct now always means fp32 MFMA, and so do the two entry points
+ * without a config struct (ctts_lstm_seq_f32's input projection, ctts_taco_decoder_init_f32's processed memory).  The symbols
+ * stay for old callers: set accepts CTTS_GEMM_DEFAULT / CTTS_GEMM_F32 (no-op) and fails with CTTS_E_ARG for the split modes,
+ * get returns CTTS_GEMM_F32. */
 int ctts_last_gemm_loop(void);
 int ctts_set_f32_gemm_mode(int32_t mode);
 int ctts_get_f32_gemm_mode(void);
 
 /* Launch-shape overrides for A/B measurements (CTTS_F32_NO_GLDS, CTTS_F32_NO_SMALL, CTTS_F32_FORCE_SMALL, CTTS_GEMM_NO_XCD_PAIR, CTTS_BF16_NO_GLDS / _NO_WIDE /
- * _NO_PP / _W4 / _PP_STAGES, CTTS_WF_NO_FUSE, CTTS_WF_NO_VEC_INTERP, CTTS_WF_NO_REGION_SPLIT, CTTS_WF_NO_ROW_QUEUE, CTTS_F32_NO_ROUND_SPLIT, CTTS_TACO_NO_FUSE) never change results beyond the parity
+ * _NO_PP / _W4 / _PP_STAGES / _PS / _NO_PS / _PS_STAGES / _MAP, CTTS_WF_NO_FUSE, CTTS_WF_NO_VEC_INTERP, CTTS_WF_NO_REGION_SPLIT, CTTS_WF_NO_ROW_QUEUE, CTTS_F32_NO_ROUND_SPLIT, CTTS_TACO_NO_FUSE) never change results beyond the parity
  * tolerance (CTTS_F32_NO_SPLITK changes the summation order of the fused WaveFlow layer at batch <= 2, see above).  The environment is read once,
  * at the first launch; this re-reads it (tests and profiling scripts that flip a knob in-process). */
 int ctts_tuning_reload(void);
 /* The knobs as the library currently sees them: bit 0 CTTS_F32_NO_GLDS, 1 CTTS_GEMM_NO_XCD_PAIR, 2 CTTS_BF16_NO_GLDS,
  * 3 CTTS_BF16_NO_WIDE, 4 CTTS_BF16_NO_PP, 5 CTTS_BF16_W4, 6 CTTS_BF16_PP_STAGES=4, 7 CTTS_WF_NO_FUSE, 8 CTTS_TACO_NO_FUSE,
  * 9 CTTS_F32_NO_SMALL, 10 CTTS_F32_FORCE_SMALL, 11 CTTS_F32_NO_SPLITK, 12 CTTS_WF_NO_VEC_INTERP, 13 CTTS_F32_NO_DEFER_SKIP, 14 CTTS_WF_NO_REGION_SPLIT,
- * 15 CTTS_WF_NO_ROW_QUEUE, 16 CTTS_WF_ROW_QUEUE_MIN set, 17 CTTS_WF_INJECT_ABORT, 18 CTTS_WF_QUEUE_DEBUG != 0, 19 CTTS_F32_NO_ROUND_SPLIT (tests assert that a knob they set is the
- * one in effect). */
+ * 15 CTTS_WF_NO_ROW_QUEUE, 16 CTTS_WF_ROW_QUEUE_MIN set, 17 CTTS_WF_INJECT_ABORT, 18 CTTS_WF_QUEUE_DEBUG != 0, 19 CTTS_F32_NO_ROUND_SPLIT,
+ * 20 CTTS_BF16_PS (persistent form of the skewed bf16 kernel on every wide launch), 21 CTTS_BF16_NO_PS (tests assert that a knob they
+ * set is the one in effect). */
 int ctts_tuning_flags(void);
 
-/* ---- in-library kernel timing (bench.py roofline leg) --------------------------------- */
-/* When enabled, ctts_waveglow_infer_f32 brackets every launch of the dominant kernel
- * (WN in-layer GEMM: dilated conv + cond + gate) with hipEvents on `stream`. */
+/* ---- in-library kernel timing (bench.py roofline leg) ---------------------------------
+ * A profile is an opaque caller-owned handle (ABI 6; until ABI 5 one set of process-global slots).  A thread that has
+ * BOUND a handle brackets every launch of the WN GEMMs it issues (ctts_waveglow_infer_* on that thread) with hipEvents on
+ * the launch's stream and files them in the handle; ctts_profile_bind(NULL) stops recording on the calling thread.  Two
+ * threads with two handles never see each other's launches.  collect synchronises the recorded events of one slot,
+ * returns launches + summed milliseconds and empties the slot.  destroy: no thread may still be bound to the handle. */
 #define CTTS_PROF_WN_IN 0
 #define CTTS_PROF_WN_RS 1   /* fp32: res/skip GEMM; bf16: res GEMM (x += W_res act) */
-#define CTTS_PROF_WN_SKIP 2 /* bf16 only: deferred skip GEMM over K = n_layers * C */
+#define CTTS_PROF_WN_SKIP 2 /* deferred skip GEMM over K = (layers of the group) * C */
 #define CTTS_PROF_N 3
-int ctts_profile_enable(int32_t on);
-/* Synchronises the recorded events and returns launches + summed milliseconds; resets. */
-int ctts_profile_collect(int32_t which, int64_t* launches, double* total_ms);
+int ctts_profile_create(void** handle);
+int ctts_profile_bind(void* handle);
+int ctts_profile_collect(void* handle, int32_t which, int64_t* launches, double* total_ms);
+int ctts_profile_destroy(void* handle);
 
 #ifdef __cplusplus
 }

@@ -48,12 +48,21 @@ def gemm_loop_label():
     return f"{loop}, {shape}"
 
 
+def _mode(m, args):
+    """The rows' GEMM main loop travels in each model's config (``--gemm-mode``; there is no process-wide default)."""
+    mode = getattr(args, "gemm_mode", "f32")
+    if mode != "f32" and hasattr(m, "set_f32_gemm_mode"):
+        m.set_f32_gemm_mode(mode)
+    return m
+
+
 def row_waveflow(args):
     from cookietts_amd.waveglow_ax import WaveGlow
     cfg = synthetic.WAVEFLOW_CONFIGS["full"]
     m = WaveGlow(**cfg)
     m.load_state_dict(synthetic.to_torch(synthetic.waveflow_state_dict(cfg, seed=1234)))
     m = m.cuda().eval()
+    _mode(m, args)
     rows = []
     for B in _batches(args, (1, 8)):     # B = 1 too: the reference's own WaveFlow timing table is batch 1 (BASELINE.md 3)
         F = 900
@@ -87,6 +96,7 @@ def row_waveflow_author(args):
     m = WaveGlow(**cfg)
     m.load_state_dict(synthetic.to_torch(synthetic.waveflow_state_dict(cfg, seed=1234)))
     m = m.cuda().eval()
+    _mode(m, args)
     B, F = 8, 400
     mel = torch.from_numpy(synthetic.synthetic_mel(B, F, cfg["n_mel_channels"] * 2)).cuda()
     ids = torch.arange(B).cuda()
@@ -109,6 +119,7 @@ def row_waveglow_ax_notebook(args):
     m = WaveGlow(**cfg)
     m.load_state_dict(synthetic.to_torch(synthetic.waveglow_ax_state_dict(cfg, seed=1234)))
     m = m.cuda().eval()
+    _mode(m, args)
     rows = []
     for B in _batches(args, (1, 8)):
         F = 468                                                   # -> (F - 1) * 600 = 280 200 samples = 5.8375 s
@@ -197,6 +208,7 @@ def row_waveglow_ax_untts(args):
     m = WaveGlow(**cfg)
     m.load_state_dict(synthetic.to_torch(synthetic.waveglow_ax_state_dict(cfg, seed=1234)))
     m = m.cuda().eval()
+    _mode(m, args)
     rows = []
     for B in _batches(args, (1, 4)):
         F = 468
@@ -216,14 +228,14 @@ if __name__ == "__main__":
     ap.add_argument("--rows", default="waveflow,tacotron,stft")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--gemm-mode", default="f32", choices=["f32", "bf16x3", "bf16x6"],
+                    help="main loop of the rows' fp32 conv-GEMMs, set on each model (model.set_f32_gemm_mode)")
     ap.add_argument("--batches", default="", help="comma list: restrict the multi-batch rows (waveglow_ax, waveglow_ax_untts) to these batch sizes (PMC passes)")
     args = ap.parse_args()
     fns = {"waveflow": row_waveflow, "waveflow_author": row_waveflow_author, "tacotron": row_tacotron, "stft": row_stft,
            "waveglow_ax": row_waveglow_ax_notebook, "waveglow_ax_untts": row_waveglow_ax_untts}
     for r in args.rows.split(","):
         out = fns[r](args)
-        from cookietts_amd import _lib
-        mode = {v: k for k, v in _lib.GEMM_MODES.items()}[_lib.lib().ctts_get_f32_gemm_mode()]
         for line in (out if isinstance(out, list) else [out]):
-            line["f32_gemm_mode"] = mode          # the process default the models inherited: "f32" unless CTTS_F32_GEMM_MODE set it
+            line["f32_gemm_mode"] = args.gemm_mode    # set on every model of the row (model.set_f32_gemm_mode)
             print(json.dumps(line), flush=True)

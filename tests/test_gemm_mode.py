@@ -1,4 +1,4 @@
-"""The split-bf16 main loop of the fp32 conv-GEMM (``set_f32_gemm_mode("bf16x3")``): every vocoder path under it stays
+"""The split-bf16 main loop of the fp32 conv-GEMM (``model.set_f32_gemm_mode("bf16x3")``): every vocoder path under it stays
 inside the north-star waveform bound against the REFERENCE goldens; the STFT keeps exact fp32 products."""
 import os
 
@@ -11,45 +11,42 @@ from conftest import GOLDEN, rms_rel_err
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture
-def split_mode(hip_lib_path):
-    import cookietts_amd
-    prev = cookietts_amd.set_f32_gemm_mode("bf16x3")
-    yield
-    cookietts_amd.set_f32_gemm_mode(prev)
-
-
-def test_mode_switch_roundtrip(hip_lib_path):
+def test_there_is_no_process_wide_mode(hip_lib_path):
+    """ABI 6: the mode travels in each model's config struct only.  The old process-wide switch is
+    read-only: the C symbol refuses the split modes with an error text, the Python function raises."""
     import cookietts_amd
     from cookietts_amd import _lib
-    prev = cookietts_amd.set_f32_gemm_mode("bf16x3")
-    assert _lib.lib().ctts_get_f32_gemm_mode() == 2 == _lib.MODEL_GEMM_MODES["bf16x3"]      # CTTS_GEMM_BF16X3
-    assert cookietts_amd.set_f32_gemm_mode(prev) == "bf16x3"
-    assert _lib.lib().ctts_set_f32_gemm_mode(7) != 0                      # unknown mode: refused, mode unchanged
-    assert _lib.lib().ctts_get_f32_gemm_mode() == _lib.GEMM_MODES[prev]
+    lib = _lib.lib()
+    assert lib.ctts_get_f32_gemm_mode() == 1 == _lib.MODEL_GEMM_MODES["f32"]
+    assert lib.ctts_set_f32_gemm_mode(2) != 0 and b"removed in ABI 6" in lib.ctts_last_error()
+    assert lib.ctts_set_f32_gemm_mode(7) != 0 and b"unknown mode" in lib.ctts_last_error()
+    assert lib.ctts_set_f32_gemm_mode(0) == 0 and lib.ctts_set_f32_gemm_mode(1) == 0 and lib.ctts_get_f32_gemm_mode() == 1
+    assert cookietts_amd.set_f32_gemm_mode("f32") == "f32"
+    with pytest.raises(RuntimeError, match="model.set_f32_gemm_mode"):
+        cookietts_amd.set_f32_gemm_mode("bf16x3")
 
 
 @pytest.mark.parametrize("name", ["toy_early", "full_short"])
-def test_waveglow_fp32_layout_split_mode(split_mode, name):
+def test_waveglow_fp32_layout_split_mode(hip_lib_path, name):
     from cookietts_amd import WaveGlow, synthetic
     g = np.load(os.path.join(GOLDEN, f"waveglow_{name}.npz"))
     cfg = synthetic.WAVEGLOW_CONFIGS[str(g["config_key"])]
     m = WaveGlow(**cfg)
     m.load_state_dict(synthetic.to_torch(synthetic.waveglow_state_dict(cfg, seed=int(g["seed"]))))
-    m = m.cuda().eval()
+    m = m.cuda().eval().set_f32_gemm_mode("bf16x3")
     wave = m.infer_from_noise(torch.from_numpy(g["mel"]).cuda(), torch.from_numpy(g["z_scaled"]).cuda()).cpu().numpy()
     err = rms_rel_err(wave, g["wave"])
     print(f"split-bf16 GEMM loop, waveglow {name}: rms rel err vs reference = {err:.3e}")
     assert err < 1e-4                                                       # bound 1e-3; an order inside it
 
 
-def test_waveflow_split_mode(split_mode):
+def test_waveflow_split_mode(hip_lib_path):
     from cookietts_amd import WaveFlow, synthetic
     g = np.load(os.path.join(GOLDEN, "waveflow_full_short.npz"))
     cfg = synthetic.WAVEFLOW_CONFIGS[str(g["config_key"])]
     m = WaveFlow(**cfg)
     m.load_state_dict(synthetic.to_torch(synthetic.waveflow_state_dict(cfg, seed=int(g["seed"]))))
-    m = m.cuda().eval()
+    m = m.cuda().eval().set_f32_gemm_mode("bf16x3")
     melp = torch.from_numpy(np.pad(g["mel"], ((0, 0), (0, 0), (0, 1)))).cuda()
     audio, _ = m.inverse(torch.from_numpy(g["z"]).cuda(), melp)
     err = rms_rel_err(audio.numpy(), g["inverse_full"])
@@ -57,19 +54,21 @@ def test_waveflow_split_mode(split_mode):
     assert err < 1e-4
 
 
-def test_stft_stays_exact_in_split_mode(split_mode):
-    """Same bits as in fp32 mode: the STFT GEMMs opt out (their sums cancel; the log-mel bound is 1e-4 absolute)."""
-    import cookietts_amd
-    from cookietts_amd import TacotronSTFT
+def test_stft_has_no_mode_and_keeps_exact_fp32_products(hip_lib_path):
+    """The STFT GEMMs always run exact fp32 products (their sums cancel; the log-mel bound is 1e-4 absolute): there is no
+    mode to set on them, and a split-bf16 model living in the same process does not change their bits."""
+    from cookietts_amd import TacotronSTFT, WaveGlow, synthetic
     stft = TacotronSTFT(1024, 256, 1024, 80, 22050, 0.0, 8000.0).cuda()
+    assert not hasattr(stft, "set_f32_gemm_mode")
     audio = torch.from_numpy(np.random.default_rng(3).uniform(-0.7, 0.7, (2, 20000)).astype(np.float32)).cuda()
-    mel_split = stft.mel_spectrogram(audio)
-    prev = cookietts_amd.set_f32_gemm_mode("f32")
-    try:
-        mel_f32 = stft.mel_spectrogram(audio)
-    finally:
-        cookietts_amd.set_f32_gemm_mode(prev)
-    assert torch.equal(mel_split, mel_f32)
+    mel_before = stft.mel_spectrogram(audio)
+    cfg = synthetic.WAVEGLOW_CONFIGS["toy"]
+    m = WaveGlow(**cfg)
+    m.load_state_dict(synthetic.to_torch(synthetic.waveglow_state_dict(cfg, seed=1)))
+    m = m.cuda().eval().set_f32_gemm_mode("bf16x3")
+    m.infer_from_noise(torch.from_numpy(synthetic.synthetic_mel(1, 8, seed=2)).cuda(),
+                       torch.from_numpy(synthetic.synthetic_noise(1, 8, 256, seed=2)).cuda())
+    assert torch.equal(stft.mel_spectrogram(audio), mel_before)
 
 
 def test_two_models_two_modes_interleaved_on_two_streams(hip_lib_path):

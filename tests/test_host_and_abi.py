@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(hip_lib_path):
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in include/cookietts_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == declared, "ctypes signature table out of sync with the header"
-    assert handle.ctts_abi_version() == 5
+    assert handle.ctts_abi_version() == 6
 
 
 def test_host_side_queries_run_without_gpu(hip_lib_path):
@@ -166,15 +166,26 @@ def test_gemm_mode_names_and_tuning_bits(hip_lib_path):
         _lib.model_gemm_mode("bf16x9")
     m = WaveGlow(**synthetic.WAVEGLOW_CONFIGS["toy"])
     assert m.set_f32_gemm_mode("bf16x6") is m and m.c_config().f32_gemm_mode == 3
-    # one encoding (CTTS_GEMM_*) for the per-model field and the deprecated process default (ABI 5)
+    # one encoding (CTTS_GEMM_*); no process-wide default since ABI 6: the old setter is read-only
     assert _lib.GEMM_MODES == {"f32": 1, "bf16x3": 2, "bf16x6": 3}
     assert all(_lib.MODEL_GEMM_MODES[k] == v for k, v in _lib.GEMM_MODES.items())
     lib = _lib.lib()
-    assert lib.ctts_get_f32_gemm_mode() == 1                                             # CTTS_GEMM_F32 initially
+    assert lib.ctts_abi_version() == 6
+    assert lib.ctts_get_f32_gemm_mode() == 1                                             # CTTS_GEMM_F32, always
     assert lib.ctts_set_f32_gemm_mode(4) != 0 and lib.ctts_set_f32_gemm_mode(-1) != 0 and lib.ctts_get_f32_gemm_mode() == 1
-    assert lib.ctts_set_f32_gemm_mode(3) == 0 and lib.ctts_get_f32_gemm_mode() == 3      # the per-model constant means the same here
-    assert lib.ctts_set_f32_gemm_mode(0) == 0 and lib.ctts_get_f32_gemm_mode() == 1      # CTTS_GEMM_DEFAULT resets to fp32 MFMA
-    assert "DEPRECATED - ctts_set_f32_gemm_mode" in hdr and lib.ctts_last_gemm_loop() == 0
+    assert lib.ctts_set_f32_gemm_mode(3) != 0 and b"removed in ABI 6" in lib.ctts_last_error() and lib.ctts_get_f32_gemm_mode() == 1
+    assert lib.ctts_set_f32_gemm_mode(0) == 0 and lib.ctts_set_f32_gemm_mode(1) == 0
+    assert "REMOVED in ABI 6" in hdr and lib.ctts_last_gemm_loop() == 0
+    # profiles are caller-owned handles (no GPU needed to create, bind, collect an empty slot and destroy one)
+    import ctypes as C
+    h = C.c_void_p()
+    assert lib.ctts_profile_create(C.byref(h)) == 0 and h.value
+    n, ms = C.c_int64(-1), C.c_double(-1.0)
+    assert lib.ctts_profile_bind(h) == 0 and lib.ctts_profile_collect(h, 0, C.byref(n), C.byref(ms)) == 0
+    assert n.value == 0 and ms.value == 0.0
+    assert lib.ctts_profile_collect(h, 9, C.byref(n), C.byref(ms)) != 0 and lib.ctts_profile_collect(None, 0, C.byref(n), C.byref(ms)) != 0
+    assert lib.ctts_profile_bind(None) == 0 and lib.ctts_profile_destroy(h) == 0
+    assert "int ctts_profile_enable" not in hdr
     for name, bit in _lib.TUNING_BITS.items():
         assert f"{bit} {name}" in hdr or name in hdr, name
     assert _lib.TUNING_BITS["CTTS_F32_NO_SPLITK"] == 11

@@ -69,18 +69,67 @@ def test_row_queue_full_size_default_and_forms(hip_lib_path, tuning):
 
 
 def test_row_queue_abort_is_loud(hip_lib_path, tuning):
-    """With the abort word set (what an expired wait does) every workgroup leaves and the audio is NaN, not noise; the next
-    call without the injection is clean again."""
+    """With the abort word set (what an expired wait does) every workgroup leaves; the audio is NaN, not noise - and the
+    abort is a STATUS (ABI 6): a call that returns to the host raises at once, a call that stays on the
+    device is reported by the next call on that workspace (CTTS_E_ABORT, once), after which the workspace is clean again."""
+    from cookietts_amd import _lib
     m = _model()
     z, mel = _inputs(2, 100, seed=3)
     tuning.set("CTTS_WF_ROW_QUEUE_MIN", "1")
     good, _ = m.inverse(z, mel, return_CPU=False)
     tuning.set("CTTS_WF_INJECT_ABORT")
-    bad, _ = m.inverse(z, mel, return_CPU=False)
+    with pytest.raises(_lib.HipLibraryError, match="row queue .* aborted"):       # synchronising call: raises itself
+        m.inverse(z, mel, return_CPU=True)
+    bad, _ = m.inverse(z, mel, return_CPU=False)                                  # device-side call: NaN now ...
     assert torch.isnan(bad).all()
     tuning.clear("CTTS_WF_INJECT_ABORT")
-    again, _ = m.inverse(z, mel, return_CPU=False)
+    with pytest.raises(_lib.HipLibraryError, match="rc=-4"):                      # ... CTTS_E_ABORT from the next call
+        m.inverse(z, mel, return_CPU=False)
+    again, _ = m.inverse(z, mel, return_CPU=False)                                # reported once; clean afterwards
     assert torch.equal(again, good)
+    cpu, _ = m.inverse(z, mel, return_CPU=True)
+    assert torch.equal(cpu, good.cpu())
+
+
+def test_two_threads_time_two_models_into_disjoint_profiles(hip_lib_path):
+    """Kernel-timing slots are caller-owned handles bound per thread (ABI 6): two threads running two WaveGlow models
+    concurrently each collect exactly their own launches."""
+    import threading
+    from cookietts_amd import WaveGlow, _lib
+    cfg = synthetic.WAVEGLOW_CONFIGS["toy_early"]
+    n_layers, n_flows = cfg["WN_config"]["n_layers"], cfg["n_flows"]
+    results, errors = {}, []
+
+    def run(tag, calls):
+        try:
+            torch.cuda.set_device(0)
+            m = WaveGlow(**cfg)
+            m.load_state_dict(synthetic.to_torch(synthetic.waveglow_state_dict(cfg, seed=7 + calls)))
+            m = m.cuda().eval()
+            mel = torch.from_numpy(synthetic.synthetic_mel(1, 12, seed=calls)).cuda()
+            zz = torch.from_numpy(synthetic.synthetic_noise(1, cfg["n_group"], 12 * 32, seed=calls)).cuda()
+            stream = torch.cuda.Stream()
+            prof = _lib.Profile()
+            with torch.cuda.stream(stream):
+                m.infer_from_noise(mel, zz)                      # not bound yet: must not be recorded anywhere
+                with prof:
+                    for _ in range(calls):
+                        m.infer_from_noise(mel, zz)
+                m.infer_from_noise(mel, zz)                      # unbound again
+            stream.synchronize()
+            results[tag] = prof.collect(_lib.PROF_WN_IN)
+            prof.close()
+        except Exception as e:                                   # noqa: BLE001 - reported by the main thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=run, args=("a", 2)), threading.Thread(target=run, args=("b", 5))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert results["a"][0] == 2 * n_flows * n_layers and results["b"][0] == 5 * n_flows * n_layers
+    assert results["a"][1] > 0.0 and results["b"][1] > 0.0
 
 
 @pytest.mark.parametrize("key", ["toy", "toy_dilations", "toy_conv_early", "kh1", "merge"])
