@@ -1269,25 +1269,25 @@ __global__ __launch_bounds__(256, 2) void wf_row_persistent_kernel(const WfRowAr
             if (tt >= tile - halo && tt <= tile + halo && tt >= 0 && tt < ntiles) {
                 const unsigned int* f = w.flags + (size_t)(gs - 1) * per_layer + b * ntiles + tt;
                 // The bound is on time WITHOUT PROGRESS, not on wall time: s_memrealtime keeps running while the process is
-                // preempted or shares the GPU, so an expired period only aborts if the launch's item counter has not moved since
-                // the period began - and the first expiry merely opens a second period (everybody was frozen together; the
-                // others need a moment to be seen moving again).
+                // preempted or shares the GPU, so the first expiry only takes a snapshot of the launch's item counter and opens a
+                // second period (everybody was frozen together; the others need a moment to be seen moving again); the wait
+                // aborts when a whole further period passes in which no workgroup claimed an item.
                 unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                unsigned int seen = __hip_atomic_load(w.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                int expired = 0;
+                unsigned int seen = 0;
+                bool have_seen = false;                                    // (the counter is only looked at once a period has expired)
                 for (unsigned spins = 0; __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != w.epoch; ++spins) {
                     __builtin_amdgcn_s_sleep(8);
                     if ((spins & 63u) == 63u) {
                         const unsigned long long now = __builtin_amdgcn_s_memrealtime();
                         if (now - t0 > w.timeout_ticks) {
                             const unsigned int c = __hip_atomic_load(w.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (c != seen) expired = 0;                    // items were claimed meanwhile: the launch is alive
-                            else if (++expired >= 2) {
+                            if (have_seen && c == seen) {                  // a whole period in which nobody claimed an item
                                 __hip_atomic_store(w.abort_word, 1u + (unsigned)gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 s_abort = 1;
                                 break;
                             }
                             seen = c;
+                            have_seen = true;
                             t0 = now;
                         }
                         if (__hip_atomic_load(w.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { s_abort = 1; break; }
