@@ -209,6 +209,15 @@ WAVEFLOW_CONFIGS = {
                                 gated_unit='GSIRRU', merge_res_skip=True),
     # the WaveFlow printed by scripts/"UnTTS Inference.ipynb" (cell output at line 64): the same option family with
     # 12 flows, a 3-layer k=3 cond stack and the mel shifted / scaled on entry (shift_spect 11.52, scale_spect 0.25)
+    # The reference's only published numbers for this path ("WaveFlow Inference Times.png") sweep n_group
+    # 8 / 12 / 20 / 50 (hop % n_group == 0, efficient_model_ax.py:23), 64 ... 512 channels, dense and separable in-layers:
+    # the corners of that sweep at toy depth
+    "table_g50_c128": waveflow_config(n_flows=2, n_group=50, n_channels=128, n_layers=3, hop_length=300, win_length=1200),
+    "table_g50_c256_sep": waveflow_config(n_flows=2, n_group=50, n_channels=256, n_layers=2, hop_length=300, win_length=1200,
+                                          WN=dict(seperable_conv=True)),
+    "table_g20_c512": waveflow_config(n_flows=2, n_group=20, n_channels=512, n_layers=2, hop_length=300, win_length=1200),
+    "table_g12_c256_sep": waveflow_config(n_flows=2, n_group=12, n_channels=256, n_layers=2, hop_length=300, win_length=1200,
+                                          WN=dict(seperable_conv=True)),
     "untts_toy": dict(waveflow_author_config(n_flows=4, n_group=10, n_channels=64, n_layers=3, kernel=5, n_mel_channels=12,
                                              hop_length=40, win_length=160, speaker_embed=8, cond_layers=3, cond_hidden=32,
                                              wn_cond_hidden=24),

@@ -88,6 +88,49 @@ def row_waveflow(args):
     return rows
 
 
+# "WaveFlow Inference Times.png" (CookieTTS/_4_mtw/): the reference's only published numbers for this path.
+# Columns: n_group, n_flows, n_channels, separable, published 22 kHz real-time factor (batch 1, 8 layers, hardware not named).
+PUBLISHED_WAVEFLOW_TABLE = [
+    (8, 6, 64, 0, 17.002), (8, 6, 64, 1, 16.432), (8, 8, 64, 0, 12.448), (8, 8, 64, 1, 12.251), (8, 8, 128, 1, 9.316),
+    (20, 4, 128, 1, 8.807), (20, 6, 64, 0, 6.200), (20, 6, 64, 1, 6.011), (20, 6, 128, 1, 6.003), (8, 8, 128, 0, 5.376),
+    (20, 6, 256, 1, 4.956), (20, 8, 64, 0, 4.911), (20, 8, 64, 1, 4.612), (8, 8, 256, 1, 4.488), (20, 8, 128, 1, 4.450),
+    (12, 8, 256, 1, 4.218), (20, 8, 128, 0, 4.070), (20, 8, 256, 1, 3.778), (20, 10, 128, 1, 3.674), (20, 12, 128, 1, 3.076),
+    (20, 6, 256, 0, 1.953), (50, 8, 128, 0, 1.929), (50, 8, 256, 1, 1.747), (20, 8, 512, 1, 1.630), (20, 8, 256, 0, 1.459),
+    (50, 8, 256, 0, 1.131), (20, 8, 512, 0, 0.375), (50, 8, 512, 0, 0.336)]
+
+
+def row_waveflow_table(args):
+    """Every architecture of the reference's published WaveFlow sweep at batch 1 (the only batch it published), ~10 s of audio:
+    3x3 kernels, 8 layers, permuteheight mixing (config 4's family), hop 256 for n_group 8 and 300 otherwise
+    (hop % n_group == 0, efficient_model_ax.py:23); random-init weights.  The published factor is printed beside ours for
+    context only: its hardware is not named."""
+    import gc
+    from cookietts_amd.waveglow_ax import WaveGlow
+    rows = []
+    for G, n_flows, C, sep, published in PUBLISHED_WAVEFLOW_TABLE:
+        hop = 256 if G == 8 else 300
+        cfg = synthetic.waveflow_config(n_flows=n_flows, n_group=G, n_channels=C, hop_length=hop, win_length=4 * hop,
+                                        WN=dict(seperable_conv=bool(sep)))
+        m = WaveGlow(**cfg)
+        m.load_state_dict(synthetic.to_torch(synthetic.waveflow_state_dict(cfg, seed=1234)))
+        m = m.cuda().eval()
+        _mode(m, args)
+        F = 220500 // hop
+        mel = torch.from_numpy(synthetic.synthetic_mel(1, F)).cuda()
+        dt = timed(lambda: m.infer(mel, sigma=0.6, return_CPU=False), args.warmup, args.steps)
+        samples = (F - 1) * hop
+        rows.append({"row": "B/waveflow_table", "metric": "real-time factor at 22.05 kHz, WaveFlow infer, batch 1",
+                     "n_group": G, "n_flows": n_flows, "n_layers": 8, "n_channels": C, "seperable_conv": sep, "hop_length": hop,
+                     "frames": F, "value": samples / dt / 22050, "unit": "x real time", "ms_per_call": dt * 1e3,
+                     "published_rtf_22khz": published, "vs_published": samples / dt / 22050 / published,
+                     "published_source": "CookieTTS/_4_mtw/WaveFlow Inference Times.png (hardware not named)",
+                     "last_gemm_loop": gemm_loop_label(), "dtype": "f32"})
+        del m
+        gc.collect()
+        torch.cuda.empty_cache()
+    return rows
+
+
 def row_waveflow_author(args):
     """the option set / sizes of the author's own WaveFlow checkpoints (48 kHz, hop 600, n_group 20,
     128 channels, separable 7x7 in-layers, speaker embeddings, 5 + 3 layer conditioning stacks, de-emphasis)."""
@@ -232,7 +275,7 @@ if __name__ == "__main__":
                     help="main loop of the rows' fp32 conv-GEMMs, set on each model (model.set_f32_gemm_mode)")
     ap.add_argument("--batches", default="", help="comma list: restrict the multi-batch rows (waveglow_ax, waveglow_ax_untts) to these batch sizes (PMC passes)")
     args = ap.parse_args()
-    fns = {"waveflow": row_waveflow, "waveflow_author": row_waveflow_author, "tacotron": row_tacotron, "stft": row_stft,
+    fns = {"waveflow": row_waveflow, "waveflow_table": row_waveflow_table, "waveflow_author": row_waveflow_author, "tacotron": row_tacotron, "stft": row_stft,
            "waveglow_ax": row_waveglow_ax_notebook, "waveglow_ax_untts": row_waveglow_ax_untts}
     for r in args.rows.split(","):
         out = fns[r](args)

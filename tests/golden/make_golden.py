@@ -245,7 +245,10 @@ def make_waveflow(full_length=False):
              ("toy_conv_mixlast", "toy_conv_mixlast", 2, 5, 0.7, 16),
              ("toy_upsample_first", "toy_upsample_first", 2, 6, 0.7, 17), ("toy_no_res_skip", "toy_no_res_skip", 2, 5, 0.7, 18),
              ("toy_dilations", "toy_dilations", 2, 5, 0.7, 19),
-             ("toy_dilations_h", "toy_dilations_h", 2, 6, 0.7, 20), ("author_toy_dilations_h", "author_toy_dilations_h", 1, 5, 0.7, 21)]
+             ("toy_dilations_h", "toy_dilations_h", 2, 6, 0.7, 20), ("author_toy_dilations_h", "author_toy_dilations_h", 1, 5, 0.7, 21),
+             # corners of the reference's published sweep ("WaveFlow Inference Times.png"): n_group 50 / 20 / 12, 128 ... 512 channels
+             ("table_g50_c128", "table_g50_c128", 2, 5, 0.7, 22), ("table_g50_c256_sep", "table_g50_c256_sep", 1, 5, 0.7, 23),
+             ("table_g20_c512", "table_g20_c512", 1, 5, 0.7, 24), ("table_g12_c256_sep", "table_g12_c256_sep", 2, 4, 0.7, 25)]
     only = [a for a in sys.argv[2:]]
     if full_length:
         # BASELINE config 4 at the metric's utterance length: one 80x900 mel (~10 s of CPU here)

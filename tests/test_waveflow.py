@@ -22,7 +22,9 @@ def _load(name):
 ALL = ["toy", "toy_odd", "full_short", "author_toy", "author_short", "untts_toy", "toy_merge", "author_toy_gate",
        "toy_groupconv", "toy_wn_tconv", "toy_wn_tconv_crop", "toy_conv_early", "toy_permute_mixfirst_early",
        "toy_conv_mixlast", "toy_upsample_first", "toy_no_res_skip",
-       "toy_dilations", "toy_dilations_h", "author_toy_dilations_h"]   # author_*: SURVEY 8f.4 option set;
+       "toy_dilations", "toy_dilations_h", "author_toy_dilations_h",
+       "table_g50_c128", "table_g50_c256_sep", "table_g20_c512", "table_g12_c256_sep"]   # author_*: SURVEY 8f.4 option set;
+# table_*: corners of the reference's published sweep (n_group 50 / 20 / 12, 128 ... 512 channels, dense / separable);
 # untts_toy: the same family with shift_spect / scale_spect (scripts/"UnTTS Inference.ipynb"); toy_merge / author_toy_gate:
 # merge_res_skip with the GLU / GSIRRU gated units on the dense and the separable 2-D core
 
