@@ -655,6 +655,16 @@ def tacotron_memory_in_dim(hp):
     return hp.encoder_LSTM_dim + hp.speaker_embedding_dim + hp.torchMoji_crushedDim + 1
 
 
+# A checkpoint's own hparams shape the model (the server builds it from checkpoint['hparams'], text2speech.py:299-316):
+# every width away from the repo defaults, roughly halved.  Runs on the per-launch decoder (the
+# persistent form is built for the default widths only).
+TACOTRON_SMALL_OVERRIDES = dict(
+    symbols_embedding_dim=256, encoder_speaker_embed_dim=32, encoder_conv_hidden_dim=256, encoder_LSTM_dim=512,
+    torchMoji_crushedDim=16, speaker_embedding_dim=128, memory_bottleneck_dim=256, prenet_dim=128, attention_rnn_dim=640,
+    decoder_rnn_dim=384, second_decoder_rnn_dim=384, attention_dim=96, windowed_attention_range=8,
+    attention_location_n_filters=16, attention_location_kernel_size=15, postnet_embedding_dim=256)
+
+
 def tacotron_state_dict(hp, seed=1234, shapes=None, attention_drive=None, stop_drive=None):
     """Random-init state dict for the reference's ``Tacotron2`` (keys/shapes of its own
     ``state_dict()``; ``shapes`` = {key: shape} from a constructed module, or None to derive them

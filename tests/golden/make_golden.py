@@ -350,7 +350,7 @@ def make_waveglow_ax(full_length=False, untts=False, gates=False):
               f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
-def _ref_tacotron(hp, seed, attention_drive=None, stop_drive=None):
+def _ref_tacotron(hp, seed, attention_drive=None, stop_drive=None, shapes_file="tacotron_state_shapes.json"):
     """Reference Tacotron2 with the recipe weights.  Shims: no-op RNNCellBase input checks
     (removed in torch 2.x, called at utils/model/layers.py:375-379)."""
     import json
@@ -362,7 +362,7 @@ def _ref_tacotron(hp, seed, attention_drive=None, stop_drive=None):
     torch.manual_seed(0)
     m = ref_model.Tacotron2(hp)
     shapes = {k: list(v.shape) for k, v in m.state_dict().items()}
-    with open(os.path.join(HERE, "tacotron_state_shapes.json"), "w") as f:
+    with open(os.path.join(HERE, shapes_file), "w") as f:
         json.dump(shapes, f, indent=0, sort_keys=True)
     sd = synthetic.tacotron_state_dict(hp, seed=seed, shapes=shapes, attention_drive=attention_drive, stop_drive=stop_drive)
     res = m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
@@ -440,6 +440,44 @@ def make_tacotron():
                         pred_gate=out["pred_gate"].numpy().astype(np.float32),
                         alignments=out["alignments"].numpy().astype(np.float32))
     print(f"[golden] tacotron_full: postnet mel {tuple(out['pred_mel_postnet'].shape)} enc {tuple(enc_out.shape)} "
+          f"-> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def make_tacotron_small():
+    """Tacotron2.inference of a model whose hparams are NOT the repo defaults (every width roughly halved,
+    synthetic.TACOTRON_SMALL_OVERRIDES): what loading somebody's checkpoint amounts to (text2speech.py:299-316)."""
+    torch.set_num_threads(8)
+    hp = synthetic.tacotron_hparams(**synthetic.TACOTRON_SMALL_OVERRIDES)
+    seed = 4321
+    model, ref_model, sd = _ref_tacotron(hp, seed, shapes_file="tacotron_small_state_shapes.json")
+    rng = np.random.default_rng(123)
+    B, T_txt, n_steps = 3, 40, 24
+    text = rng.integers(1, hp.n_symbols, size=(B, T_txt)).astype(np.int64)
+    lengths = np.array([40, 29, 12], dtype=np.int64)
+    for b in range(B):
+        text[b, lengths[b]:] = 0
+    speakers = np.array([2, 9, 300], dtype=np.int64)
+    tm = rng.standard_normal((B, hp.torchMoji_attDim)).astype(np.float32)
+    masks = synthetic.prenet_dropout_masks(n_steps, B, hp.prenet_dim, seed=seed + 1)
+    saved = ref_model.F.dropout
+    ref_model.F.dropout = _MaskedDropout(masks)
+    try:
+        model.decoder.max_decoder_steps = n_steps
+        model.decoder.gate_threshold = 2.0
+        with torch.no_grad():
+            enc_out, _, sylps = model.encoder(model.embedding(torch.from_numpy(text)).transpose(1, 2),
+                                              torch.from_numpy(lengths), speaker_ids=torch.from_numpy(speakers))
+            out = model.inference(torch.from_numpy(text), torch.from_numpy(lengths), torch.from_numpy(speakers),
+                                  torch.from_numpy(tm))
+    finally:
+        ref_model.F.dropout = saved
+    path = os.path.join(HERE, "tacotron_small.npz")
+    np.savez_compressed(path, seed=seed, text=text, lengths=lengths, speakers=speakers, torchmoji=tm, masks=masks,
+                        encoder_outputs=enc_out.numpy().astype(np.float32), pred_sylps=sylps.numpy().astype(np.float32),
+                        pred_mel_postnet=out["pred_mel_postnet"].numpy().astype(np.float32),
+                        pred_gate=out["pred_gate"].numpy().astype(np.float32),
+                        alignments=out["alignments"].numpy().astype(np.float32))
+    print(f"[golden] tacotron_small: postnet mel {tuple(out['pred_mel_postnet'].shape)} enc {tuple(enc_out.shape)} "
           f"-> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
@@ -685,6 +723,8 @@ if __name__ == "__main__":
         make_alignment()
     if "tacotron" in which:
         make_tacotron()
+    if "tacotron_small" in which:      # on request only
+        make_tacotron_small()
     if "tacotron_long" in which:
         make_tacotron_long()
     if "tacotron_stop" in which:

@@ -412,3 +412,52 @@ def test_bidirectional_lstm_launch_equals_two_one_direction_runs(hip_lib_path):
     assert lib.ctts_lstm_biseq_f32(_lib.ptr(packs[0]), _lib.ptr(packs[1]), _lib.ptr(x), _lib.ptr(lens), _lib.ptr(outs[0][0]),
                                    T * row, row, 0, H, _lib.ptr(outs[0][1]), 2 * H, 0, H, B, T, I, H, ld, PAD, _lib.ptr(ws[0]),
                                    _lib.ptr(ws[0]), nbytes, st) != 0             # one workspace for both directions: refused
+
+
+# ---- a model whose hparams are not the repo defaults ---------------------------------------------
+# The server builds the model from checkpoint['hparams'] (text2speech.py:299-316): every width roughly halved here
+# (synthetic.TACOTRON_SMALL_OVERRIDES); golden = the reference's own Tacotron2.inference of that model.
+def _small():
+    g = np.load(os.path.join(GOLDEN, "tacotron_small.npz"))
+    hp = synthetic.tacotron_hparams(**synthetic.TACOTRON_SMALL_OVERRIDES)
+    shapes = json.load(open(os.path.join(GOLDEN, "tacotron_small_state_shapes.json")))
+    return g, hp, synthetic.tacotron_state_dict(hp, seed=int(g["seed"]), shapes=shapes), shapes
+
+
+def test_non_default_hparams_build_the_reference_module_tree_and_match_the_oracle():
+    from cookietts_amd.tacotron2 import Tacotron2
+    g, hp, sd, shapes = _small()
+    m = Tacotron2(hp)
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == shapes   # keys / shapes of the REFERENCE's module for this hp
+    m.load_state_dict(synthetic.to_torch(sd))
+    assert m.decoder.c_config().attention_rnn_dim == 640 and m.decoder.c_config().prenet_dim == 128
+    o = to.tacotron_inference_steps(sd, hp, g["text"], g["lengths"], g["speakers"], g["torchmoji"], g["masks"],
+                                    g["masks"].shape[0])
+    assert np.abs(o["encoder_outputs"] - g["encoder_outputs"]).max() < 1e-6
+    assert np.abs(o["pred_mel_postnet"] - g["pred_mel_postnet"]).max() < 1e-5
+    assert np.abs(o["alignments"] - g["alignments"]).max() < 1e-6
+    assert ((g["alignments"] > 0).sum(axis=2) <= 17).all()                 # +-8 window here
+
+
+@pytest.mark.gpu
+def test_hip_non_default_hparams_match_reference_golden(hip_lib_path):
+    """Loads from a reference-format state dict and runs on the per-launch decoder (the persistent form is built for the
+    default widths only and reports 0 bytes for this shape)."""
+    from cookietts_amd import _lib
+    from cookietts_amd.tacotron2 import Tacotron2
+    import ctypes as C
+    g, hp, sd, _ = _small()
+    m = Tacotron2(hp)
+    m.load_state_dict(synthetic.to_torch(sd))
+    m = m.cuda().eval()
+    cfg = m.decoder.c_config()
+    assert _lib.lib().ctts_taco_decoder_persistent_bytes(C.byref(cfg), 3, 40) == 0
+    n = g["masks"].shape[0]
+    out = m.inference(torch.from_numpy(g["text"]).cuda(), torch.from_numpy(g["lengths"]).cuda(),
+                      torch.from_numpy(g["speakers"]).cuda(), torch.from_numpy(g["torchmoji"]).cuda(),
+                      keep_masks=g["masks"], fixed_steps=n)
+    enc = out["encoder_outputs"].cpu().numpy()
+    errs = {k: float(np.abs(out[k].cpu().numpy() - g[k]).max()) for k in ("pred_sylps", "pred_mel_postnet", "pred_gate", "alignments")}
+    print("non-default hparams: encoder Linf", np.abs(enc - g["encoder_outputs"]).max(), errs)
+    assert np.abs(enc - g["encoder_outputs"]).max() < MEL_TOL
+    assert all(e < MEL_TOL for e in errs.values()), errs
