@@ -57,7 +57,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
 # HBM bytes per in-layer launch from committed PMC passes (2 x FETCH_SIZE (gfx950 half-count correction,
 # calibrated on flow_tail) + WRITE_SIZE) of the exact launch shapes named in the file; not re-measured inside a bench run
 # (PMC collection needs its own rocprofv3 passes: scripts/pmc3.sh).
-TRAFFIC_FILES = ["r4_pmc_traffic.json", "r3_pmc_traffic.json", "r1_17_pmc_traffic.json"]
+TRAFFIC_FILES = ["r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r1_17_pmc_traffic.json"]
 
 
 def load_traffic():
@@ -303,14 +303,16 @@ def wn_roofline(prof, cfg, dtype, gemm_mode, B, F, steps, elapsed, config_key="f
         # res GEMM (per layer: act read + x read-modify-write = 3*C*2 B per time step) and the deferred skip GEMM (4 act
         # reads + the skip sum written, and re-read by the second launch = 5.5*C*2 B per time step on average).
         for key2, which, kname2, bpt in (
-                ("res_hbm", _lib.PROF_WN_RS, "conv_gemm_bf16_pp_kernel<SPLIT> (WN res 1x1: x += W_res act)", 3.0),
+                ("res_hbm", _lib.PROF_WN_RS, "conv_gemm_bf16_ps_kernel<SPLIT> (WN res 1x1: x += W_res act; persistent form)", 3.0),
                 ("skip_hbm", _lib.PROF_WN_SKIP, "conv_gemm_bf16_pp_kernel<SPLIT> (WN skip sum over 4 layers' act)", 5.5)):
             if which in slots:
                 n2, mean2 = slots[which]
                 bytes2 = float(bpt * C * 2) * B * L
+                e2 = traffic.get("bf16_res" if key2 == "res_hbm" else "bf16_skip")
+                t2 = e2.get("hbm_bytes_per_launch") if (e2 and config_key == "full" and F == 900 and B == e2.get("batch")) else None
                 roofline[key2] = {"kernel": kname2, "bound": "hbm", "achieved": round(bytes2 / mean2 / 1e9, 1), "peak": 8000.0,
                                   "unit": "GB/s", "frac": round(bytes2 / mean2 / 8e12, 4), "launches": n2,
-                                  "mean_launch_ms": round(mean2 * 1e3, 4), "bytes_per_launch": bytes2}
+                                  "mean_launch_ms": round(mean2 * 1e3, 4), "bytes_per_launch": bytes2, "traffic": t2}
     else:
         deferred = _lib.PROF_WN_SKIP in slots
         if _lib.PROF_WN_RS in slots:
