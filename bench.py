@@ -85,7 +85,7 @@ def parse_args(argv=None):
                     help="mel frames per utterance of the concurrent-instances leg of the CPU baseline (the single-instance leg "
                          "runs --cpu-frames; the shorter utterance keeps the whole CPU part near 90 s; samples/s is what is "
                          "compared, and the WN convolutions are linear in the utterance length)")
-    ap.add_argument("--rows", default="config3,bf16x6,config4,config5",
+    ap.add_argument("--rows", default="config3,config3f16,bf16x6,config4,config5",
                     help="N = 1 only: short secondary rows run AFTER the headline's timed region and attached to the JSON "
                          "line as \"rows\" (config3 = bf16 B=32, bf16x6 = six-product loop at the headline batch, config4 = "
                          "WaveFlow B=8 and B=1, config5 = Tacotron2 900 forced steps B=4 + chained vocoder); empty = none")
@@ -98,8 +98,9 @@ def parse_args(argv=None):
                     help="skip the concurrent-instances leg of the CPU baseline (single-instance figure only)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-exchange", action="store_true", help="skip the scatter/gather timing for N > 1")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "bf16x3"],
-                    help="f32 = BASELINE config 2 (default, the headline); bf16 = config 3 (use --batch 32); bf16x3 = "
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16", "bf16x3"],
+                    help="f32 = BASELINE config 2 (default, the headline); bf16 = config 3 (use --batch 32); f16 = config 3's "
+                         "kernels on IEEE-half storage / v_mfma_f32_32x32x16_f16 (the reference's own half mode; extra row); bf16x3 = "
                          "split-bf16 (hi + lo operands, three bf16 MFMA products per contraction, fp32 accumulate): an "
                          "extra row, never the headline")
     ap.add_argument("--gemm-mode", default="f32", choices=["f32", "bf16x3", "bf16x6"],
@@ -269,10 +270,11 @@ def wn_roofline(prof, cfg, dtype, gemm_mode, B, F, steps, elapsed, config_key="f
     mean_s = ms.value / max(n.value, 1) * 1e-3
     achieved = flop_per_launch / mean_s / 1e12
     peak = FP32_MFMA_PEAK_TFLOPS if dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
-    kname = "conv_gemm_f32_kernel<GATE>" if dtype == "f32" else "conv_gemm_bf16_pp_kernel<GATE>"
+    half = dtype in ("bf16", "f16")
+    kname = "conv_gemm_f32_kernel<GATE>" if dtype == "f32" else ("conv_gemm_bf16_pp_kernel<GATE, F16>" if dtype == "f16" else "conv_gemm_bf16_pp_kernel<GATE>")
     if dtype == "f32" and gemm_mode != "f32":
         kname, peak = f"conv_gemm_f32_kernel<GATE, X{products}>", BF16_MFMA_PEAK_TFLOPS
-    key = ("f32_" + gemm_mode) if (dtype == "f32" and gemm_mode != "f32") else dtype
+    key = ("f32_" + gemm_mode) if (dtype == "f32" and gemm_mode != "f32") else ("bf16" if half else dtype)
     e = traffic.get(key)
     tbytes = e.get("hbm_bytes_per_launch") if (e and config_key == "full" and F == 900 and B == e.get("batch", 8)) else None
     roofline = {"kernel": kname + " (WN in-layer: dilated conv + cond + tanh*sigmoid)",
@@ -298,7 +300,7 @@ def wn_roofline(prof, cfg, dtype, gemm_mode, B, F, steps, elapsed, config_key="f
         n2, ms2 = prof.collect(which)
         if n2 > 0:
             slots[which] = (n2, ms2 / n2 * 1e-3)
-    if dtype == "bf16":
+    if half:
         # In bf16 the in-layer GEMM stays MFMA-bound (1430 FLOP/B vs a ridge of ~312); the memory-bound WN kernels are the
         # res GEMM (per layer: act read + x read-modify-write = 3*C*2 B per time step) and the deferred skip GEMM (4 act
         # reads + the skip sum written, and re-read by the second launch = 5.5*C*2 B per time step on average).
@@ -330,7 +332,7 @@ def wn_roofline(prof, cfg, dtype, gemm_mode, B, F, steps, elapsed, config_key="f
                                      "bound": "mfma", "achieved": round(flop2 / mean2 / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
                                      "frac": round(flop2 / mean2 / 1e12 / peak, 4), "launches": n2,
                                      "mean_launch_ms": round(mean2 * 1e3, 4), "flop_per_launch": flop2}
-    if dtype == "bf16":
+    if half:
         # whole step against HBM with SURVEY 8d's per-layer-kernel byte count (7*C*2 B per step per layer; the deferred-skip form moves ~5.4*C*2)
         step_bytes = 7.0 * C * 2 * n_layers * cfg["n_flows"] * B * L
         roofline["step_hbm_algorithmic"] = {"bytes_per_step": step_bytes, "achieved": round(step_bytes * steps / elapsed / 1e9, 1),
@@ -388,19 +390,22 @@ def run_rows(which, model, cfg, lib, args, device):
     F = 900
     T = F * cfg["hop_length"]
 
-    def config3():
+    def config3(fmt="bf16"):
         B3 = 32
         mel = torch.from_numpy(synthetic.synthetic_mel(B3, F, seed=4321)).to(device)
-        model.set_compute_dtype(torch.bfloat16)
+        model.set_compute_dtype(torch.bfloat16 if fmt == "bf16" else torch.float16)
         try:
             dt, out = timed_infer(mel, 3, 1)
-            roof = wn_roofline(prof, cfg, "bf16", "f32", B3, F, 3, dt, args.config)
+            roof = wn_roofline(prof, cfg, fmt, "f32", B3, F, 3, dt, args.config)
         finally:
             model.set_compute_dtype(torch.float32)
-        return {"row": "A/config3 (1-GPU shard)", "metric": METRIC, "value": B3 * T * 3 / dt, "unit": "samples/s",
-                "rtf": B3 * T * 3 / dt / 22050.0, "ms_per_step": dt / 3 * 1e3, "steps": 3, "warmup": 1, "dtype": "bf16",
+        return {"row": "A/config3 (1-GPU shard)" + ("" if fmt == "bf16" else ", IEEE-half storage"), "metric": METRIC,
+                "value": B3 * T * 3 / dt, "unit": "samples/s",
+                "rtf": B3 * T * 3 / dt / 22050.0, "ms_per_step": dt / 3 * 1e3, "steps": 3, "warmup": 1, "dtype": fmt,
                 "batch": B3, "frames": F, "roofline": roof,
-                "note": "BASELINE config 3's per-GPU shard (256 utterances / 8 GPUs = 32): bf16 MFMA WN stacks, fp32 tails"}
+                "note": ("BASELINE config 3's per-GPU shard (256 utterances / 8 GPUs = 32): bf16 MFMA WN stacks, fp32 tails" if fmt == "bf16" else
+                         "config 3's shard on the same kernels with IEEE-half storage and v_mfma_f32_32x32x16_f16 (the reference's own "
+                         "reduced-precision mode, glow.py:343): 8x closer to the fp32 reference than bf16, inside the 1e-3 bound")}
 
     def bf16x6():
         mel = torch.from_numpy(synthetic.synthetic_mel(args.batch, F, seed=4322)).to(device)
@@ -418,6 +423,8 @@ def run_rows(which, model, cfg, lib, args, device):
     for name in which:
         if name == "config3" and args.dtype == "f32":
             guard("A/config3", config3)
+        elif name == "config3f16" and args.dtype == "f32":
+            guard("A/config3f16", lambda: config3("f16"))
         elif name == "bf16x6" and args.dtype == "f32" and args.gemm_mode == "f32":
             guard("A/bf16x6", bf16x6)
         elif name == "config4":
@@ -492,6 +499,8 @@ def worker(args, pre=None):
                                                                  # inherited from the environment or a process default
         if args.dtype == "bf16":
             model.set_compute_dtype(torch.bfloat16)
+        elif args.dtype == "f16":
+            model.set_compute_dtype(torch.float16)
         elif args.dtype == "bf16x3":
             model.set_compute_dtype("bf16x3")
 
@@ -621,7 +630,7 @@ def worker(args, pre=None):
             "data": "synthetic" if not selftest else "LAUNCHER SELF-TEST (gloo/CPU stand-in step; not a measurement)",
             "rtf": value / 22050.0,
             "config": {"workload": f"WaveGlow {args.config} ({cfg['n_flows']} flows, {C} WN ch, "
-                                   f"{cfg['n_group']} groups, {n_layers} layers) { {'f32': 'fp32', 'bf16': 'bf16-MFMA', 'bf16x3': 'split-bf16 (3 bf16 MFMA products, fp32 accumulate)'}[args.dtype] } infer, batch {B} x (80x{F}) "
+                                   f"{cfg['n_group']} groups, {n_layers} layers) { {'f32': 'fp32', 'bf16': 'bf16-MFMA', 'f16': 'fp16-MFMA (IEEE-half storage)', 'bf16x3': 'split-bf16 (3 bf16 MFMA products, fp32 accumulate)'}[args.dtype] } infer, batch {B} x (80x{F}) "
                                    f"mel per GPU, sigma 0.6, random-init weights",
                        "batch_per_gpu": B, "frames": F, "samples_per_step": world * B * T,
                        "parallelism": f"utterance-batch shard x{world}"},

@@ -142,6 +142,9 @@ SIGNATURES = {
                                               _FP]),
     "ctts_waveglow_infer_spk_bf16x3": (C.c_int, [_CFG, _FP, _FP, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP, C.c_size_t,
                                                _FP]),
+    "ctts_waveglow_infer_spk_f16": (C.c_int, [_CFG, _FP, _FP, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32, _FP, C.c_size_t,
+                                             _FP]),
+    "ctts_waveglow_pack_flow_f16": (C.c_int, [_CFG, C.c_int32, C.POINTER(WaveGlowFlowWeights), _FP, _FP]),
     "ctts_waveglow_packed_bf16x3_bytes": (C.c_size_t, [_CFG]),
     "ctts_waveglow_pack_flow_bf16x3": (C.c_int, [_CFG, C.c_int32, C.POINTER(WaveGlowFlowWeights), _FP, _FP]),
     "ctts_waveglow_workspace_bf16x3_bytes": (C.c_size_t, [_CFG, C.c_int32, C.c_int32]),

@@ -43,6 +43,10 @@ struct BGemmArgs {
     int split;            // SPLIT: rows < split -> dst0, else dst1[row - split] (multiple of 32)
     int pairC;            // GATE: channels (dense rows c and pairC + c)
     int map_mode;         // block id -> (m-block, tile, batch) mapping, chosen by the launcher
+    // Element format of A, of every K segment and of the destinations: 0 = bf16 (config 3), 1 = IEEE half ("f16": the
+    // reference's own reduced-precision mode, glow.py:343; 11-bit significands - inside the 1e-3 waveform bound where one
+    // bf16 product per MAC is not).  Same layouts, same kernels; v_mfma_f32_32x32x16_f16 instead of ..._bf16, fp32 accumulate.
+    int f16;
     // Split-bf16 ("bf16x3") destinations: lo_off != 0 -> every destination tensor is a PAIR of planes, hi at dst and lo
     // at dst + lo_off (elements): the epilogue stores hi = bf16(v), lo = bf16(v - hi) and read-modify-write
     // destinations are read as hi + lo.  The K side of the split is expressed with segments (x_hi*W_hi + x_lo*W_hi +
@@ -69,7 +73,7 @@ int launch_gemm_bf16(int epi, const BGemmArgs& a, hipStream_t stream);
 // part: 0 = bf16(w) (round to nearest even), 1 = bf16(w - bf16(w)) (the low half of the split-bf16 form)
 int launch_pack_a_bf16(bf16_t* dst, const float* src, int MB, int nch_total, int k_off, int ksrc, int epi, int C,
                        int M, long long src_row_off, long long src_row_stride, int src_k_stride, hipStream_t s,
-                       int k_group = 1, int k_member = 0, int part = 0);
+                       int k_group = 1, int k_member = 0, int part = 0, int f16 = 0);
 
 __host__ __device__ inline bf16_t f32_to_bf16_rne(float f) {
     union { float f; unsigned int u; } v;
@@ -83,6 +87,10 @@ __host__ __device__ inline float bf16_to_f32(bf16_t h) {
     return v.f;
 }
 
+// IEEE half (round to nearest even; overflow -> inf, subnormals kept): raw bits in the same 16-bit storage type.  Device only.
+__device__ __forceinline__ bf16_t f32_to_f16_rne(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+__device__ __forceinline__ float f16_to_f32(bf16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+
 // two fp32 -> packed bf16 (round to nearest even): one v_cvt_pk_bf16_f32 on the device
 __host__ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -94,6 +102,24 @@ __host__ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi)
 #else
     return (unsigned int)f32_to_bf16_rne(lo) | ((unsigned int)f32_to_bf16_rne(hi) << 16);
 #endif
+}
+
+// two fp32 -> packed IEEE half (round to nearest even)
+__device__ __forceinline__ unsigned int pack_f16x2(float lo, float hi) {
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2h_t __attribute__((ext_vector_type(2)));
+    const f32x2h_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, f16x2_t));
+}
+// format-generic forms (F16: a compile-time choice of the kernel instantiation)
+template <bool F16> __device__ __forceinline__ unsigned int pack_h2(float lo, float hi) {
+    if constexpr (F16) return pack_f16x2(lo, hi); else return pack_bf16x2(lo, hi);
+}
+template <bool F16> __device__ __forceinline__ float h_to_f32(bf16_t h) {
+    if constexpr (F16) return f16_to_f32(h); else return bf16_to_f32(h);
+}
+template <bool F16> __device__ __forceinline__ bf16_t f32_to_h(float f) {
+    if constexpr (F16) return f32_to_f16_rne(f); else return f32_to_bf16_rne(f);
 }
 
 }  // namespace ctts

@@ -9,7 +9,7 @@ namespace ctts {
 
 int launch_pack_a_bf16(bf16_t* dst, const float* src, int MB, int nch_total, int k_off, int ksrc, int epi, int C,
                        int M, long long src_row_off, long long src_row_stride, int src_k_stride, hipStream_t s,
-                       int k_group, int k_member, int part) {
+                       int k_group, int k_member, int part, int f16) {
     // a ragged ksrc (e.g. a 20-wide speaker embedding) is zero-filled up to its 32-wide slab boundary
     const int kfill = (ksrc + BGEMM_KC - 1) / BGEMM_KC * BGEMM_KC;
     CTTS_CHECK_ARG(k_off % 8 == 0 && ksrc > 0, "pack_a_bf16: k offset must be 8-aligned");
@@ -18,7 +18,7 @@ int launch_pack_a_bf16(bf16_t* dst, const float* src, int MB, int nch_total, int
     CTTS_CHECK_ARG(k_off + kspan * (k_group > 1 ? k_group : 1) <= nch_total * BGEMM_KC, "pack_a_bf16: k range");
     CTTS_CHECK_ARG(k_group <= 1 || (ksrc % BGEMM_KC == 0 && k_off % BGEMM_KC == 0), "pack_a_bf16: k group");
     hipLaunchKernelGGL(pack_a_bf16_kernel, dim3(kspan / 8, MB), dim3(256), 0, s, dst, src, nch_total, k_off, ksrc, epi, C,
-                       M, src_row_off, src_row_stride, src_k_stride, k_group, k_member, part);
+                       M, src_row_off, src_row_stride, src_k_stride, k_group, k_member, part, f16);
     CTTS_CHECK_LAUNCH("pack_a_bf16");
     return CTTS_OK;
 }
@@ -94,7 +94,22 @@ int launch_gemm_bf16(int epi, const BGemmArgs& a, hipStream_t stream) {
     }
     CTTS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "gemm_bf16: grid %lld", blocks);
     const dim3 grid((unsigned)blocks);
-    if (ps && ps_grid >= 16) {
+    if (b.f16) {
+        // IEEE-half operands: the default shapes only (the A/B knobs of the bf16 kernels other than PS / NO_PS / NO_WIDE do not apply)
+        CTTS_CHECK_ARG(b.lo_off == 0, "gemm_bf16: the split (hi + lo) form exists for bf16 only");
+        const dim3 pg((unsigned)(ps_grid > 0 ? ps_grid : 1));
+        if (epi == BGEMM_EPI_GATE) {
+            if (ps && ps_grid >= 16 && b.nch_total > 4) hipLaunchKernelGGL((conv_gemm_bf16_ps_kernel<BGEMM_EPI_GATE, 4, 0, true>), pg, dim3(512), 0, stream, b);
+            else if (wide && pp) hipLaunchKernelGGL((conv_gemm_bf16_pp_kernel<BGEMM_EPI_GATE, 3, true>), grid, dim3(512), 0, stream, b);
+            else if (wide) hipLaunchKernelGGL((conv_gemm_bf16_kernel<BGEMM_EPI_GATE, true, 4, true>), grid, dim3(512), 0, stream, b);
+            else hipLaunchKernelGGL((conv_gemm_bf16_kernel<BGEMM_EPI_GATE, true, 2, true>), grid, dim3(256), 0, stream, b);
+        } else {
+            if (ps && ps_grid >= 16 && b.nch_total > 4) hipLaunchKernelGGL((conv_gemm_bf16_ps_kernel<BGEMM_EPI_SPLIT, 4, 0, true>), pg, dim3(512), 0, stream, b);
+            else if (wide && pp) hipLaunchKernelGGL((conv_gemm_bf16_pp_kernel<BGEMM_EPI_SPLIT, 3, true>), grid, dim3(512), 0, stream, b);
+            else if (wide) hipLaunchKernelGGL((conv_gemm_bf16_kernel<BGEMM_EPI_SPLIT, true, 4, true>), grid, dim3(512), 0, stream, b);
+            else hipLaunchKernelGGL((conv_gemm_bf16_kernel<BGEMM_EPI_SPLIT, true, 2, true>), grid, dim3(256), 0, stream, b);
+        }
+    } else if (ps && ps_grid >= 16) {
         const dim3 pg((unsigned)ps_grid);
         if (epi == BGEMM_EPI_GATE) {
             if (ps_stages == 3) hipLaunchKernelGGL((conv_gemm_bf16_ps_kernel<BGEMM_EPI_GATE, 3>), pg, dim3(512), 0, stream, b);

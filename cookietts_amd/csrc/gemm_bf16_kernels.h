@@ -31,7 +31,15 @@ __device__ __forceinline__ float fast_sigmoid(float u) {
 __device__ __forceinline__ float fast_tanh(float u) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * 2.8853900817779268f));
 }
-__device__ __forceinline__ unsigned int pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// one v_mfma_f32_32x32x16 on two 16-byte K8 units: bf16 or IEEE-half operands, fp32 accumulate
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_k16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <bool F16 = false>
+__device__ __forceinline__ unsigned int pack2(float lo, float hi) { return pack_h2<F16>(lo, hi); }
 // tanh(u0) * sigmoid(u1) = (e^{2 u0} - 1) / ((e^{2 u0} + 1)(1 + e^{-u1})): three transcendentals instead of four.
 // u0 is clamped to +-10 (tanh is 1 to fp32 precision there) so the numerator stays finite; a huge e^{-u1} drives
 // the reciprocal to 0, which is the limit.
@@ -43,7 +51,7 @@ __device__ __forceinline__ float fast_gate(float u0, float u1) {
 
 // split-bf16: low halves of two values whose high halves are the packed pair `hi` (lo = bf16(v - float(hi)))
 __device__ __forceinline__ unsigned int pack2_residual(float v0, float v1, unsigned int hi) {
-    return pack2(v0 - __builtin_bit_cast(float, hi << 16), v1 - __builtin_bit_cast(float, hi & 0xffff0000u));
+    return pack2<false>(v0 - __builtin_bit_cast(float, hi << 16), v1 - __builtin_bit_cast(float, hi & 0xffff0000u));
 }
 
 // Half-wave exchange (v_permlane32_swap): lanes 32..63 of x swap with lanes 0..31 of y.
@@ -138,7 +146,7 @@ __device__ __forceinline__ bool block_map(const BGemmArgs& a, int id, int& mb, i
 // global access is one 16-byte unit per lane (consecutive lanes -> consecutive units).
 // STAGED: `lds` already holds this m-block's 256 bias values (the persistent kernel stages them once per workgroup and
 // must not pass a barrier here: its LDS-DMA of the next tile is in flight).
-template <int EPI, bool STAGED = false>
+template <int EPI, bool STAGED = false, bool F16 = false>
 __device__ __forceinline__ void bf16_epilogue(const BGemmArgs& a, f32x16 (&acc)[4][2], u32x4* lds, int t, int mb, int wm,
                                               int wn, int b, int n0, int l31, int lhi) {
     float* bias_s = reinterpret_cast<float*>(lds);
@@ -170,8 +178,8 @@ __device__ __forceinline__ void bf16_epilogue(const BGemmArgs& a, f32x16 (&acc)[
                             const float u1 = acc[mt + 2][nt][4 * q + j] + bias[64 + mt * 32 + row];
                             v[j] = fast_gate(u0, u1);
                         }
-                        pk[h][0] = pack2(v[0], v[1]);
-                        pk[h][1] = pack2(v[2], v[3]);
+                        pk[h][0] = pack2<F16>(v[0], v[1]);
+                        pk[h][1] = pack2<F16>(v[2], v[3]);
                         if (a.lo_off) {                      // uniform
                             pl[h][0] = pack2_residual(v[0], v[1], pk[h][0]);
                             pl[h][1] = pack2_residual(v[2], v[3], pk[h][1]);
@@ -233,10 +241,10 @@ __device__ __forceinline__ void bf16_epilogue(const BGemmArgs& a, f32x16 (&acc)[
                     for (int d = 0; d < 4; ++d) {
                         // even / odd channel of the dword; the old value of a split destination is hi + lo
                         const float ev = v[d >> 1][2 * (d & 1)] +
-                                         (bf16_to_f32((bf16_t)(o[d] & 0xffff)) + bf16_to_f32((bf16_t)(ol[d] & 0xffff)));
+                                         (h_to_f32<F16>((bf16_t)(o[d] & 0xffff)) + bf16_to_f32((bf16_t)(ol[d] & 0xffff)));
                         const float od = v[d >> 1][2 * (d & 1) + 1] +
-                                         (bf16_to_f32((bf16_t)(o[d] >> 16)) + bf16_to_f32((bf16_t)(ol[d] >> 16)));
-                        pk[d] = pack2(ev, od);
+                                         (h_to_f32<F16>((bf16_t)(o[d] >> 16)) + bf16_to_f32((bf16_t)(ol[d] >> 16)));
+                        pk[d] = pack2<F16>(ev, od);
                         pl[d] = a.lo_off ? pack2_residual(ev, od, pk[d]) : 0u;
                     }
                     bf16_t* du = dst + ((size_t)(cg0 + 2 * qp + lhi) * a.ld + a.pad + n) * 8;
@@ -251,7 +259,7 @@ __device__ __forceinline__ void bf16_epilogue(const BGemmArgs& a, f32x16 (&acc)[
 // NW = waves along N: 2 -> 256 threads, block tile 256 x 128; 4 -> 512 threads, block tile 256 x 256 (one
 // workgroup per CU).  The wide tile stages 1/3 fewer bytes per FLOP: at bf16 MFMA rates the CU's vector-memory
 // path (64 B/clk) is the co-bottleneck of the narrow tile (PMC: MFMA busy 44 %, issue-stalled 48 %).
-template <int EPI, bool GLDS, int NW>
+template <int EPI, bool GLDS, int NW, bool F16 = false>
 __global__ __launch_bounds__(128 * NW, 2) void conv_gemm_bf16_kernel(const BGemmArgs a) {
     constexpr int NT = 128 * NW;                            // threads
     constexpr int BN = 64 * NW;
@@ -373,9 +381,7 @@ __global__ __launch_bounds__(128 * NW, 2) void conv_gemm_bf16_kernel(const BGemm
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        *reinterpret_cast<const bf16x8*>(&av[ks][mt]), *reinterpret_cast<const bf16x8*>(&bv[ks][nt]),
-                        acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = mfma_k16<F16>(av[ks][mt], bv[ks][nt], acc[mt][nt]);
         // pin the LDS->MFMA pipeline: fragments of k-step 1 are read while k-step 0 runs on the matrix pipe
         __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(128 * NW, 2) void conv_gemm_bf16_kernel(const BGemm
 #undef CTTS_STORE_LDS
 #undef CTTS_ISSUE_GLDS
 
-    bf16_epilogue<EPI>(a, acc, lds, t, mb, wm, wn, b, n0, l31, lhi);
+    bf16_epilogue<EPI, false, F16>(a, acc, lds, t, mb, wm, wn, b, n0, l31, lhi);
 }
 
 // Skewed ("ping-pong") form of the 256 x 256 block (512 threads = 8 waves, one workgroup per CU, two waves per
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(128 * NW, 2) void conv_gemm_bf16_kernel(const BGemm
 // LDS: NS stages x 32 KiB (NS - 1 chunks of DMA in flight).  Both halves read chunk k inside interval k; the DMA
 // issued in interval k (chunk k+NS-1) rewrites the buffer of chunk k-1, read by both before the closing barrier of
 // interval k-1; a thread passes that barrier only after its own DMAs of chunk k have landed (counted vmcnt).
-template <int EPI, int NS>
+template <int EPI, int NS, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void conv_gemm_bf16_pp_kernel(const BGemmArgs a) {
     constexpr int NT = 512, BN = 256;
     constexpr int B_UNITS = 4 * BN;
@@ -496,9 +502,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_bf16_pp_kernel(const BGemmAr
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
             _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                    \
                 _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                \
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                      \
-                        *reinterpret_cast<const bf16x8*>(&av[ks][mt]),                          \
-                        *reinterpret_cast<const bf16x8*>(&bv[ks][nt]), acc[mt][nt], 0, 0, 0);   \
+                    acc[mt][nt] = mfma_k16<F16>(av[ks][mt], bv[ks][nt], acc[mt][nt]);          \
     } while (0)
     // DMA of chunk ch+NS-1 into the buffer of chunk ch-1, then: own DMAs of chunk ch+1 landed
 #define CTTS_DMA_AND_WAIT()                                                                     \
@@ -558,7 +562,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_bf16_pp_kernel(const BGemmAr
 #undef CTTS_UNIFORM64
 #undef CTTS_WAIT_VM
     if (wm) __builtin_amdgcn_s_setprio(0);
-    bf16_epilogue<EPI>(a, acc, lds, t, mb, wm, wn, b, n0, l31, lhi);
+    bf16_epilogue<EPI, false, F16>(a, acc, lds, t, mb, wm, wn, b, n0, l31, lhi);
 }
 
 // Persistent form of the skewed 256 x 256 block (round 5).  The per-tile kernel above pays, per workgroup and with nothing
@@ -581,7 +585,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_bf16_pp_kernel(const BGemmAr
 // The epilogue's stores are younger than the interval's DMA and only ADD to the outstanding count: the waits stay safe.
 __device__ unsigned long long g_ps_stamps[32];   // DBG: [wave half][{tile cycles, epilogue cycles, 100 MHz ticks of the tile, tiles}]
 
-template <int EPI, int NS, int DBG = 0>   // DBG (harness only): 1 = s_memtime stamps of workgroup 100, third tile
+template <int EPI, int NS, int DBG = 0, bool F16 = false>   // DBG (harness only): 1 = s_memtime stamps of workgroup 100, third tile
 __global__ __launch_bounds__(512) void conv_gemm_bf16_ps_kernel(const BGemmArgs a) {
     constexpr int NT = 512, BN = 256, MAXC = BGEMM_PP_MAX_CHUNKS;
     constexpr int B_UNITS = 4 * BN;
@@ -708,9 +712,7 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16_ps_kernel(const BGemmArgs 
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                            \
             _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                        \
                 _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                  \
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                          \
-                        *reinterpret_cast<const bf16x8*>(&av[ks][mt]),                              \
-                        *reinterpret_cast<const bf16x8*>(&bv[ks][nt]), acc[mt][nt], 0, 0, 0);       \
+                    acc[mt][nt] = mfma_k16<F16>(av[ks][mt], bv[ks][nt], acc[mt][nt]);              \
                     if (FETCH && ks * 8 + mt * 2 + nt == 1) {                                       \
                         __builtin_amdgcn_sched_barrier(0);                                          \
                         tnext_ = tabs[(dk & 1) * MAXC + dch];                                       \
@@ -752,7 +754,7 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16_ps_kernel(const BGemmArgs 
         /* lane ids laundered: keeps the epilogue's address arithmetic out of the chunk loop's live registers (LICM) */ \
         int l31_ = l31, lhi_ = lhi;                                                                 \
         asm volatile("" : "+v"(l31_), "+v"(lhi_));                                                  \
-        bf16_epilogue<EPI, true>(a, acc, bias_lds, t, mb, wm, wn, gt_done / a.ntiles, (gt_done % a.ntiles) * BN, l31_, lhi_); \
+        bf16_epilogue<EPI, true, F16>(a, acc, bias_lds, t, mb, wm, wn, gt_done / a.ntiles, (gt_done % a.ntiles) * BN, l31_, lhi_); \
         CTTS_PS_ZERO();                                                                             \
         if ((DBG & 1) && blockIdx.x == 100 && tiles_done == 2 && lane == 0 && wn == 0) {            \
             unsigned long long* o_ = g_ps_stamps + 4 * wm;                                          \
@@ -1004,7 +1006,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_w4_kernel(const BGemmArgs 
 __global__ __launch_bounds__(256) void pack_a_bf16_kernel(bf16_t* __restrict__ dst, const float* __restrict__ src,
                                                          int nch_total, int k_off, int ksrc, int epi, int C, int M,
                                                          long long src_row_off, long long src_row_stride,
-                                                         int src_k_stride, int k_group, int k_member, int part) {
+                                                         int src_k_stride, int k_group, int k_member, int part, int f16) {
     const int mb = blockIdx.y;
     const int ug = blockIdx.x;                // 8-wide k group index within [0, ksrc/8)
     const int r = threadIdx.x;
@@ -1017,8 +1019,8 @@ __global__ __launch_bounds__(256) void pack_a_bf16_kernel(bf16_t* __restrict__ d
     for (int j = 0; j < 8; ++j) {
         const int k = k0 + j;
         const float v = (drow >= 0 && k < ksrc) ? src[(src_row_off + drow) * src_row_stride + (long long)k * src_k_stride] : 0.f;
-        const bf16_t hi = f32_to_bf16_rne(v);
-        d[j] = part == 0 ? hi : f32_to_bf16_rne(v - bf16_to_f32(hi));
+        const bf16_t hi = f16 ? f32_to_f16_rne(v) : f32_to_bf16_rne(v);
+        d[j] = part == 0 ? hi : f32_to_bf16_rne(v - bf16_to_f32(hi));          // (part 1: the split-bf16 form only)
     }
 }
 

@@ -352,13 +352,15 @@ struct BfPlan {
     int nch_in, nch_rs, nch_c0, nch_c1;
     int mb_c, n_groups;                            // M-blocks of a C-row GEMM; skip launches per flow
     int P;                                         // K products per operand pair: 1 = bf16, 3 = split bf16 (hi*hi + lo*hi + hi*lo)
+    int f16;                                       // 1: IEEE-half storage and MFMA operands instead of bf16 (P == 1 only)
     int group_layers(int g, int n_layers) const { return std::min(BF_SKIP_GROUP, n_layers - g * BF_SKIP_GROUP); }
 };
 
-void make_bf_plan(const Plan& p, BfPlan& q, int P) {
+void make_bf_plan(const Plan& p, BfPlan& q, int P, int f16 = 0) {
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o = (o + n + 127) / 128 * 128; return r; };
     q.P = P;
+    q.f16 = f16;
     q.nch_in = P * (p.c.kernel_size * p.C + p.H) / BGEMM_KC;
     q.nch_rs = P * p.C / BGEMM_KC;
     q.nch_c0 = P * (p.K0 + p.S) / BGEMM_KC;
@@ -427,7 +429,7 @@ __device__ __forceinline__ unsigned int pack_bf16x2_residual(float v0, float v1,
 }
 
 __global__ __launch_bounds__(256) void cvt_f32_to_k8_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
-                                                            int rows, int ld, long long lo_off) {
+                                                            int rows, int ld, long long lo_off, int f16) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int grp = blockIdx.y, b = blockIdx.z;
     if (n >= ld) return;
@@ -436,8 +438,8 @@ __global__ __launch_bounds__(256) void cvt_f32_to_k8_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float v0 = s[(size_t)(2 * j) * ld], v1 = s[(size_t)(2 * j + 1) * ld];
-        pk[j] = pack_bf16x2(v0, v1);
-        pl[j] = pack_bf16x2_residual(v0, v1, pk[j]);
+        pk[j] = f16 ? pack_f16x2(v0, v1) : pack_bf16x2(v0, v1);
+        pl[j] = pack_bf16x2_residual(v0, v1, pk[j]);        // (only stored in the split-bf16 form: lo_off != 0)
     }
     bf16_t* d = dst + (((size_t)b * (rows / 8) + grp) * ld + n) * 8;
     *reinterpret_cast<uint4*>(d) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(256) void cvt_f32_to_k8_kernel(const float* __restr
 template <int H>
 __global__ __launch_bounds__(256) void wn_start_bf16_kernel(const float* __restrict__ audio, const float* __restrict__ Ws,
                                                             const float* __restrict__ bs, bf16_t* __restrict__ x, int C,
-                                                            int G, int ch_off, int L, int ld, int pad, long long lo_off) {
+                                                            int G, int ch_off, int L, int ld, int pad, long long lo_off, int f16) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int grp = blockIdx.y, b = blockIdx.z;
     if (n >= L) return;
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(256) void wn_start_bf16_kernel(const float* __restr
             for (int j = 0; j < H; ++j) acc = fmaf(Ws[c * H + j], a[j], acc);
             v[e] = acc;
         }
-        pk[q] = pack_bf16x2(v[0], v[1]);
+        pk[q] = f16 ? pack_f16x2(v[0], v[1]) : pack_bf16x2(v[0], v[1]);
         pl[q] = pack_bf16x2_residual(v[0], v[1], pk[q]);
     }
     bf16_t* d = x + (((size_t)b * (C / 8) + grp) * ld + pad + n) * 8;
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(256) void flow_tail_bf16_kernel(const bf16_t* __res
                                                              float* __restrict__ wave, const float* __restrict__ Wend,
                                                              const float* __restrict__ bend, const float* __restrict__ Winv,
                                                              int C, int G, int ch_off, int L, int ld, int pad,
-                                                             long long lo_off) {
+                                                             long long lo_off, int f16) {
     constexpr int E = 2 * H;
     __shared__ float sW[E * 512 + E * E + E];
     const int b = blockIdx.y;
@@ -503,8 +505,8 @@ __global__ __launch_bounds__(256) void flow_tail_bf16_kernel(const bf16_t* __res
         const unsigned int w4[4] = {u.x, u.y, u.z, u.w}, l4[4] = {ul.x, ul.y, ul.z, ul.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float v0 = bf16_to_f32((bf16_t)(w4[q] & 0xffff)) + bf16_to_f32((bf16_t)(l4[q] & 0xffff));
-            const float v1 = bf16_to_f32((bf16_t)(w4[q] >> 16)) + bf16_to_f32((bf16_t)(l4[q] >> 16));
+            const float v0 = (f16 ? f16_to_f32((bf16_t)(w4[q] & 0xffff)) : bf16_to_f32((bf16_t)(w4[q] & 0xffff))) + bf16_to_f32((bf16_t)(l4[q] & 0xffff));
+            const float v1 = (f16 ? f16_to_f32((bf16_t)(w4[q] >> 16)) : bf16_to_f32((bf16_t)(w4[q] >> 16))) + bf16_to_f32((bf16_t)(l4[q] >> 16));
             const int c = grp * 8 + 2 * q;
 #pragma unroll
             for (int j = 0; j < E; ++j) e[j] = fmaf(sW[j * C + c + 1], v1, fmaf(sW[j * C + c], v0, e[j]));
@@ -553,7 +555,7 @@ int run_wn_stack_bf16(const Plan& p, const BfPlan& q, const Geom& g, const float
 #define CTTS_BSTART(HH)                                                                                       \
     case HH:                                                                                                  \
         hipLaunchKernelGGL(wn_start_bf16_kernel<HH>, sgrid, dim3(256), 0, s, w.audio, blob + f.start_w,       \
-                           blob + f.start_b, w.x, p.C, p.c.n_group, d.ch_off, g.L, g.ld, g.pad, w.x_lo);      \
+                           blob + f.start_b, w.x, p.C, p.c.n_group, d.ch_off, g.L, g.ld, g.pad, w.x_lo, q.f16); \
         break;
     switch (d.n_half) {
         CTTS_BSTART(1) CTTS_BSTART(2) CTTS_BSTART(3) CTTS_BSTART(4)
@@ -571,6 +573,7 @@ int run_wn_stack_bf16(const Plan& p, const BfPlan& q, const Geom& g, const float
     auto skip_group = [&](int gi) -> int {
         const int nl = q.group_layers(gi, p.c.n_layers);
         BGemmArgs a{};
+        a.f16 = q.f16;
         a.ld = g.ld; a.pad = g.pad; a.L = g.L; a.ntiles = g.ntiles; a.batch = batch;
         a.A = bblob + q.skip_A[k][gi]; a.bias = skip_b + (gi == 0 ? 0 : q.mb_c * BGEMM_BM);
         int ns = 0;
@@ -589,6 +592,7 @@ int run_wn_stack_bf16(const Plan& p, const BfPlan& q, const Geom& g, const float
         bf16_t* act = w.act + (size_t)(i % BF_SKIP_GROUP) * act_layer;
         {
             BGemmArgs a{};
+            a.f16 = q.f16;
             a.ld = g.ld; a.pad = g.pad; a.L = g.L; a.ntiles = g.ntiles; a.batch = batch;
             a.A = bblob + q.in_A[k][i]; a.bias = blob + f.in_b[i];
             int ns = 0;
@@ -604,6 +608,7 @@ int run_wn_stack_bf16(const Plan& p, const BfPlan& q, const Geom& g, const float
         if (i < p.c.n_layers - 1) {
             // x += W_res act + b_res   (glow.py:213-217; the skip rows wait for the end of the stack)
             BGemmArgs a{};
+            a.f16 = q.f16;
             a.ld = g.ld; a.pad = g.pad; a.L = g.L; a.ntiles = g.ntiles; a.batch = batch;
             a.A = bblob + q.rs_A[k][i]; a.bias = blob + f.rs_b[i];
             a.nseg = push_segs(a, 0, P, act, w.act_lo, cstride, ncx, 0, 0); a.nch_total = q.nch_rs; a.MB = q.mb_c;
@@ -897,7 +902,7 @@ int ctts_profile_destroy(void* handle) {
 // ---- bf16 MFMA variants: P = 1 (bf16 storage, config 3) and P = 3 (split bf16: every operand is a hi + lo pair of
 // bf16 planes, every contraction three bf16 MFMA products hi*hi + lo*hi + hi*lo with fp32 accumulation - inputs carry
 // 16 mantissa bits instead of 8, at a third of the bf16 rate) ------------------------------------------------------
-static size_t packed_bf16_bytes_impl(const ctts_waveglow_config* cfg, int P) {
+static size_t packed_bf16_bytes_impl(const ctts_waveglow_config* cfg, int P) {   // (the same for f16)
     Plan p; BfPlan q;
     if (make_plan(cfg, p)) return 0;
     if (p.C % BGEMM_KC != 0 || p.H % BGEMM_KC != 0) { set_error("bf16: channels must be multiples of 32"); return 0; }
@@ -906,12 +911,13 @@ static size_t packed_bf16_bytes_impl(const ctts_waveglow_config* cfg, int P) {
 }
 
 static int pack_flow_bf16_impl(const ctts_waveglow_config* cfg, int32_t k, const ctts_waveglow_flow_weights* w,
-                               void* packed_bf16, void* stream, int P) {
+                               void* packed_bf16, void* stream, int P, int f16 = 0) {
     Plan p; BfPlan q;
     int rc = make_plan(cfg, p); if (rc) return rc;
     CTTS_CHECK_ARG(k >= 0 && k < p.c.n_flows && w && packed_bf16, "pack_flow_bf16: bad argument");
     CTTS_CHECK_ARG(p.C % BGEMM_KC == 0 && p.H % BGEMM_KC == 0, "pack_flow_bf16: channels must be multiples of 32");
-    make_bf_plan(p, q, P);
+    CTTS_CHECK_ARG(!f16 || P == 1, "pack_flow: the split form exists for bf16 only");
+    make_bf_plan(p, q, P, f16);
     CTTS_CHECK_ARG(q.nch_in <= BGEMM_MAX_CHUNKS && BF_SKIP_GROUP * q.nch_rs <= BGEMM_MAX_CHUNKS,
                    "pack_flow_bf16: K of %d chunks exceeds the chunk table", q.nch_in);
     hipStream_t s = as_stream(stream);
@@ -925,11 +931,11 @@ static int pack_flow_bf16_impl(const ctts_waveglow_config* cfg, int32_t k, const
     for (int pi = 0; pi < P; ++pi) {
         const int part = pi == 2;
         if ((rc = launch_pack_a_bf16(c0, w->cond_w[0], 1, q.nch_c0, pi * p.K0, p.K0, BGEMM_EPI_SPLIT, C, H, 0, p.K0 + sdim, 1,
-                                     s, 1, 0, part))) return rc;
+                                     s, 1, 0, part, q.f16))) return rc;
         if (sdim && (rc = launch_pack_a_bf16(c0, w->cond_w[0] + p.K0, 1, q.nch_c0, P * p.K0 + pi * p.S, sdim, BGEMM_EPI_SPLIT,
-                                             C, H, 0, p.K0 + sdim, 1, s, 1, 0, part))) return rc;
+                                             C, H, 0, p.K0 + sdim, 1, s, 1, 0, part, q.f16))) return rc;
         if ((rc = launch_pack_a_bf16(c1, w->cond_w[1], 1, q.nch_c1, pi * H, H, BGEMM_EPI_SPLIT, C, H, 0, H, 1, s, 1, 0,
-                                     part))) return rc;
+                                     part, q.f16))) return rc;
     }
     for (int i = 0; i < p.c.n_layers; ++i) {
         CTTS_CHECK_ARG(w->in_w[i] && w->rs_w[i] && w->cond_w[2] && w->rs_b[i], "pack_flow_bf16: NULL layer %d weights", i);
@@ -941,14 +947,14 @@ static int pack_flow_bf16_impl(const ctts_waveglow_config* cfg, int32_t k, const
             // in-layer K = [per 32-channel slab: (tap, product) round-robin] then [cond products]
             for (int t = 0; t < ks; ++t)
                 if ((rc = launch_pack_a_bf16(bb + q.in_A[k][i], w->in_w[i] + t, p.mb_in, q.nch_in, 0, C, BGEMM_EPI_GATE, C,
-                                             2 * C, 0, (long long)C * ks, ks, s, ks * P, t * P + pi, part))) return rc;
+                                             2 * C, 0, (long long)C * ks, ks, s, ks * P, t * P + pi, part, q.f16))) return rc;
             if ((rc = launch_pack_a_bf16(bb + q.in_A[k][i], w->cond_w[2], p.mb_in, q.nch_in, ks * P * C + pi * H, H,
-                                         BGEMM_EPI_GATE, C, 2 * C, (long long)2 * C * i, H, 1, s, 1, 0, part))) return rc;
+                                         BGEMM_EPI_GATE, C, 2 * C, (long long)2 * C * i, H, 1, s, 1, 0, part, q.f16))) return rc;
             if (!last && (rc = launch_pack_a_bf16(bb + q.rs_A[k][i], w->rs_w[i], q.mb_c, q.nch_rs, pi * C, C, BGEMM_EPI_SPLIT,
-                                                  C, C, 0, C, 1, s, 1, 0, part))) return rc;
+                                                  C, C, 0, C, 1, s, 1, 0, part, q.f16))) return rc;
             if ((rc = launch_pack_a_bf16(bb + q.skip_A[k][gi], w->rs_w[i], q.mb_c, q.group_layers(gi, p.c.n_layers) * q.nch_rs,
                                          (j * P + pi) * C, C, BGEMM_EPI_SPLIT, C, C, last ? 0 : C, C, 1, s, 1, 0,
-                                         part))) return rc;
+                                         part, q.f16))) return rc;
         }
         hipLaunchKernelGGL(skip_bias_kernel, dim3((2 * q.mb_c * BGEMM_BM + 255) / 256), dim3(256), 0, s,
                            reinterpret_cast<float*>(bb + q.skip_b[k]), w->rs_b[i] + (last ? 0 : C), C,
@@ -967,13 +973,13 @@ static size_t workspace_bf16_bytes_impl(const ctts_waveglow_config* cfg, int32_t
 
 static int infer_bf16_impl(const ctts_waveglow_config* cfg, const void* packed, const void* packed_bf16, const float* mel,
                            const float* z_scaled, const int64_t* speaker_ids, float* wave, int32_t batch, int32_t frames,
-                           void* workspace, size_t workspace_bytes, void* stream, int P) {
+                           void* workspace, size_t workspace_bytes, void* stream, int P, int f16 = 0) {
     Plan p; Geom g; BfWs w; BfPlan q;
     int rc = make_plan(cfg, p); if (rc) return rc;
     rc = make_geom(p, frames, g); if (rc) return rc;
     CTTS_CHECK_ARG(packed && packed_bf16 && mel && z_scaled && wave && workspace && batch >= 1, "infer_bf16: bad argument");
     CTTS_CHECK_ARG(p.C % BGEMM_KC == 0 && p.C <= 512, "infer_bf16: n_channels=%d (multiple of 32, <= 512)", p.C);
-    make_bf_plan(p, q, P);
+    make_bf_plan(p, q, P, f16);
     carve_bf(p, g, batch, static_cast<char*>(workspace), w, P);
     if (w.total_bytes > workspace_bytes) {
         set_error("infer_bf16: workspace %zu bytes < required %zu", workspace_bytes, w.total_bytes);
@@ -990,17 +996,18 @@ static int infer_bf16_impl(const ctts_waveglow_config* cfg, const void* packed, 
     // cond layers 0 / 1 for all flows on bf16 MFMA: spect -> bf16 K8, then two flow-batched GEMMs whose
     // epilogues write the conditioning hidden directly in bf16 K8
     hipLaunchKernelGGL(cvt_f32_to_k8_kernel, dim3((g.ld + 255) / 256, p.K0 / 8, batch), dim3(256), 0, s, w.spect,
-                       w.spect_bf, p.K0, g.ld, w.spect_lo);
+                       w.spect_bf, p.K0, g.ld, w.spect_lo, q.f16);
     CTTS_CHECK_LAUNCH("cvt_f32_to_k8");
     if (p.S) {
         if ((rc = fill_speaker_rows(p, g, blob, speaker_ids, w.spk, batch, s))) return rc;
         hipLaunchKernelGGL(cvt_f32_to_k8_kernel, dim3((g.ld + 255) / 256, p.c.n_flows * p.S / 8, batch), dim3(256), 0, s,
-                           w.spk, w.spk_bf, p.c.n_flows * p.S, g.ld, w.spk_lo);
+                           w.spk, w.spk_bf, p.c.n_flows * p.S, g.ld, w.spk_lo, q.f16);
         CTTS_CHECK_LAUNCH("cvt_f32_to_k8(speaker rows)");
     }
     {
         const long long hstride = (long long)p.c.n_flows * p.H * g.ld;
         BGemmArgs a{};
+        a.f16 = q.f16;
         a.ld = g.ld; a.pad = g.pad; a.L = g.L; a.ntiles = g.ntiles; a.batch = batch;
         a.A = bblob + q.cond0_A; a.bias = blob + p.cond0_b;
         a.nch_total = q.nch_c0; a.MB = p.c.n_flows; a.M = p.c.n_flows * BGEMM_BM;
@@ -1027,7 +1034,7 @@ static int infer_bf16_impl(const ctts_waveglow_config* cfg, const void* packed, 
 #define CTTS_BTAIL(HH)                                                                                            \
     case HH:                                                                                                      \
         hipLaunchKernelGGL(flow_tail_bf16_kernel<HH>, tgrid, dim3(256), 0, s, w.out, w.audio, wv, blob + f.end_w, \
-                           blob + f.end_b, blob + f.winv, p.C, p.c.n_group, d.ch_off, g.L, g.ld, g.pad, w.x_lo);  \
+                           blob + f.end_b, blob + f.winv, p.C, p.c.n_group, d.ch_off, g.L, g.ld, g.pad, w.x_lo, q.f16); \
         break;
         switch (d.n_half) {
             CTTS_BTAIL(1) CTTS_BTAIL(2) CTTS_BTAIL(3) CTTS_BTAIL(4)
@@ -1058,6 +1065,18 @@ int ctts_waveglow_infer_spk_bf16(const ctts_waveglow_config* cfg, const void* pa
                                  int32_t batch, int32_t frames, void* workspace, size_t workspace_bytes, void* stream) {
     return infer_bf16_impl(cfg, packed, packed_bf16, mel, z_scaled, speaker_ids, wave, batch, frames, workspace,
                            workspace_bytes, stream, 1);
+}
+
+// IEEE-half variant: the layouts, sizes and kernels of the bf16 variant with half storage and v_mfma_f32_32x32x16_f16
+int ctts_waveglow_pack_flow_f16(const ctts_waveglow_config* cfg, int32_t k, const ctts_waveglow_flow_weights* w,
+                                void* packed_f16, void* stream) {
+    return pack_flow_bf16_impl(cfg, k, w, packed_f16, stream, 1, 1);
+}
+int ctts_waveglow_infer_spk_f16(const ctts_waveglow_config* cfg, const void* packed, const void* packed_f16,
+                                const float* mel, const float* z_scaled, const int64_t* speaker_ids, float* wave,
+                                int32_t batch, int32_t frames, void* workspace, size_t workspace_bytes, void* stream) {
+    return infer_bf16_impl(cfg, packed, packed_f16, mel, z_scaled, speaker_ids, wave, batch, frames, workspace,
+                           workspace_bytes, stream, 1, 1);
 }
 
 size_t ctts_waveglow_packed_bf16x3_bytes(const ctts_waveglow_config* cfg) { return packed_bf16_bytes_impl(cfg, 3); }

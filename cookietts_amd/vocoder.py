@@ -34,10 +34,11 @@ class WaveGlowVocoder(torch.nn.Module):
         return audio.unsqueeze(1)
 
     def half(self):
-        """``load_hifigan`` calls ``vocoder.half()`` (text2speech.py:261): fp16 is not built; the reduced
-        precision mode of this path is bf16-MFMA with fp32 master weights, so parameters (and hence the dtype
-        the server casts mels to) stay fp32."""
-        self.waveglow.set_compute_dtype(torch.bfloat16)
+        """``load_hifigan`` calls ``vocoder.half()`` (text2speech.py:261): the WN stacks then run on IEEE-half storage and
+        fp16 MFMA with fp32 accumulation (``set_compute_dtype(torch.float16)``, the reference's own half mode, inside the
+        1e-3 waveform bound) from fp32 master weights - the parameters, and hence the dtype the server casts its mels to,
+        stay fp32.  (Until round 5 this selected the bf16 path: same speed, 8x the error.)"""
+        self.waveglow.set_compute_dtype(torch.float16)
         return self
 
 

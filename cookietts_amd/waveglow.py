@@ -200,17 +200,23 @@ class WaveGlow(nn.Module):
         bf16 MFMA with fp32 accumulation, WN activations stored bf16; parameters stay fp32 masters and are
         rounded to bf16 once, after weight-norm folding; ``model.bfloat16()`` selects bf16 as well), or the string
         ``"bf16x3"``: split bf16 - weights and activations carried as hi + lo bf16 pairs (16 mantissa bits), every
-        contraction as three bf16 MFMA products with fp32 accumulation (see ``ctts_waveglow_infer_spk_bf16x3``)."""
-        if dtype not in (torch.float32, torch.bfloat16, "bf16x3"):
-            raise NotImplementedError(f"compute dtype {dtype} is not built (float32, bfloat16 or 'bf16x3')")
+        contraction as three bf16 MFMA products with fp32 accumulation (see ``ctts_waveglow_infer_spk_bf16x3``); or
+        torch.float16: the bf16 path's layouts and kernels with IEEE-half storage and ``v_mfma_f32_32x32x16_f16`` - the
+        reference's own reduced-precision mode (glow.py:343), same speed as bf16, ~8x closer to the fp32 reference
+        (inside the 1e-3 waveform bound).  Explicit only: ``model.half()`` keeps computing in fp32 MFMA on the fp16-rounded
+        weights (INTEGRATION.md)."""
+        if dtype not in (torch.float32, torch.bfloat16, torch.float16, "bf16x3"):
+            raise NotImplementedError(f"compute dtype {dtype} is not built (float32, bfloat16, float16 or 'bf16x3')")
         self._compute_dtype = dtype
         self._invalidate()
         return self
 
     def _use_bf16(self):
-        """0 = fp32 MFMA, 1 = bf16, 3 = split bf16 (the number of bf16 products per contraction)."""
+        """0 = fp32 MFMA, 1 = bf16, 3 = split bf16 (the number of bf16 products per contraction), 16 = IEEE half."""
         if self._compute_dtype == "bf16x3":
             return 3
+        if self._compute_dtype == torch.float16:
+            return 16
         return 1 if (self._compute_dtype == torch.bfloat16 or next(self.parameters()).dtype == torch.bfloat16) else 0
 
     def repack(self):
@@ -336,7 +342,8 @@ class WaveGlow(nn.Module):
                 _lib.check(lib.ctts_waveglow_pack_flow(C.byref(cfg), k, C.byref(fw), _lib.ptr(blob), stream),
                            f"ctts_waveglow_pack_flow({k})")
                 if bblob is not None:
-                    pack16 = lib.ctts_waveglow_pack_flow_bf16x3 if use_bf16 == 3 else lib.ctts_waveglow_pack_flow_bf16
+                    pack16 = {1: lib.ctts_waveglow_pack_flow_bf16, 3: lib.ctts_waveglow_pack_flow_bf16x3,
+                          16: lib.ctts_waveglow_pack_flow_f16}[use_bf16]
                     _lib.check(pack16(C.byref(cfg), k, C.byref(fw), _lib.ptr(bblob), stream),
                                f"ctts_waveglow_pack_flow_bf16({k})")
             torch.cuda.current_stream(device).synchronize()   # dense temporaries may now be freed
@@ -350,7 +357,7 @@ class WaveGlow(nn.Module):
             lib = _lib.lib()
             cfg = self.c_config()
             query = {0: lib.ctts_waveglow_workspace_bytes, 1: lib.ctts_waveglow_workspace_bf16_bytes,
-                     3: lib.ctts_waveglow_workspace_bf16x3_bytes}[int(bf16)]
+                     3: lib.ctts_waveglow_workspace_bf16x3_bytes, 16: lib.ctts_waveglow_workspace_bf16_bytes}[int(bf16)]
             nbytes = query(C.byref(cfg), B, F)
             if nbytes == 0:
                 raise _lib.HipLibraryError("workspace query failed: " + lib.ctts_last_error().decode())
@@ -400,10 +407,9 @@ class WaveGlow(nn.Module):
         with torch.cuda.device(device):
             stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
             if bblob is not None:
-                infer16 = lib.ctts_waveglow_infer_spk_bf16x3 if mode == 3 else lib.ctts_waveglow_infer_spk_bf16
-                _lib.check(infer16(C.byref(cfg), _lib.ptr(blob), _lib.ptr(bblob), _lib.ptr(mel), _lib.ptr(z), _lib.ptr(ids),
-                                   _lib.ptr(wave), B, F, _lib.ptr(ws), ws.numel() * 4, stream),
-                           "ctts_waveglow_infer_spk_bf16x3" if mode == 3 else "ctts_waveglow_infer_spk_bf16")
+                name16 = {1: "ctts_waveglow_infer_spk_bf16", 3: "ctts_waveglow_infer_spk_bf16x3", 16: "ctts_waveglow_infer_spk_f16"}[mode]
+                _lib.check(getattr(lib, name16)(C.byref(cfg), _lib.ptr(blob), _lib.ptr(bblob), _lib.ptr(mel), _lib.ptr(z),
+                                                _lib.ptr(ids), _lib.ptr(wave), B, F, _lib.ptr(ws), ws.numel() * 4, stream), name16)
             else:
                 _lib.check(lib.ctts_waveglow_infer_spk_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(mel), _lib.ptr(z),
                                                           _lib.ptr(ids), _lib.ptr(wave), B, F, _lib.ptr(ws),

@@ -50,7 +50,8 @@ extern "C" {
                               *    the split modes), profiles are caller-owned handles (ctts_profile_create / _bind /
                               *    _collect(handle, ...) / _destroy replace ctts_profile_enable / _collect(which, ...)), a
                               *    row-queue abort is a status (CTTS_E_ABORT from the next ctts_waveflow_inverse_* on that
-                              *    workspace, ctts_waveflow_abort_status) besides the NaN audio */
+                              *    workspace, ctts_waveflow_abort_status) besides the NaN audio; IEEE-half variant of the
+                              *    reduced-precision WaveGlow path (ctts_waveglow_pack_flow_f16 / ctts_waveglow_infer_spk_f16) */
 
 /* Main loop of the fp32 conv-GEMM a model's launches use (field f32_gemm_mode of the config structs). */
 #define CTTS_GEMM_DEFAULT 0  /* the library default: fp32 MFMA */
@@ -167,6 +168,20 @@ int ctts_waveglow_infer_spk_bf16(const ctts_waveglow_config* cfg, const void* pa
                                  const float* mel, const float* z_scaled, const int64_t* speaker_ids, float* wave,
                                  int32_t batch, int32_t frames, void* workspace, size_t workspace_bytes,
                                  void* stream);
+
+/* IEEE-half variant ("f16", ABI 6): the reference's own reduced-precision inference mode (glow.py:343, the notebooks' `.half()`
+ * models).  Everything as in the bf16 variant - same layouts, same kernels, same blob and workspace SIZES
+ * (ctts_waveglow_packed_bf16_bytes / ctts_waveglow_workspace_bf16_bytes) - but weights and WN activations are rounded to
+ * IEEE half (11-bit significands instead of bf16's 8) and the products run on v_mfma_f32_32x32x16_f16, fp32 accumulation.
+ * Range: a WN activation beyond 65 504 would become inf (the gated activations are in (-1, 1); the residual stream of the
+ * models of this repository stays within a few units).  Same speed as bf16; waveform error against the fp32 reference about
+ * 8x smaller (gated in tests/test_waveglow_gpu.py at the fp32 tolerance: RMS rel <= 1e-3). */
+int ctts_waveglow_pack_flow_f16(const ctts_waveglow_config* cfg, int32_t flow,
+                                const ctts_waveglow_flow_weights* w, void* packed_f16, void* stream);
+int ctts_waveglow_infer_spk_f16(const ctts_waveglow_config* cfg, const void* packed, const void* packed_f16,
+                                const float* mel, const float* z_scaled, const int64_t* speaker_ids, float* wave,
+                                int32_t batch, int32_t frames, void* workspace, size_t workspace_bytes,
+                                void* stream);
 
 /* Split-bf16 variant ("bf16x3"): the same bf16 MFMA kernels with every GEMM operand carried as a hi + lo PAIR of bf16
  * planes (hi = bf16(v), lo = bf16(v - hi): 16 mantissa bits) and every contraction computed as the three products

@@ -151,42 +151,51 @@ def bf16_round(x):
     return r.view(F32)
 
 
+def f16_round(x):
+    """Round-to-nearest-even fp32 -> IEEE half -> fp32 (the storage rounding of the f16 HIP variant; numpy's cast rounds to
+    nearest even, keeps subnormals and overflows to inf like v_cvt_f16_f32)."""
+    with np.errstate(over="ignore"):
+        return np.asarray(x, dtype=F32).astype(np.float16).astype(F32)
+
+
 BF16_SKIP_GROUP = 4     # layers per skip-sum launch of the bf16 HIP variant (BF_SKIP_GROUP in waveglow_api.hip)
 
 
-def wn_forward_bf16(sd, prefix, audio0, spect, n_layers, n_channels, speaker_ids=None):
+def wn_forward_bf16(sd, prefix, audio0, spect, n_layers, n_channels, speaker_ids=None, rnd=None):
     """bf16-rounded restatement of one WN stack, mirroring the rounding points of the bf16 HIP variant
     (BASELINE config 3): in-layer / cond-layer-2 / res-skip weights and the tensors x, h, act, skip-sum are
     rounded to bf16 where the kernels store them (incl. the squeezed spectrogram and cond layers 0-1); all sums
-    are fp32; upsampling, start and end are fp32."""
+    are fp32; upsampling, start and end are fp32.  ``rnd``: the storage rounding - ``bf16_round`` (default) or ``f16_round``
+    (the IEEE-half variant: the same rounding points, 11-bit significands)."""
+    rnd = bf16_round if rnd is None else rnd
     C = n_channels
-    x = bf16_round(_conv1x1(_conv_weight(sd, prefix + ".start"), sd[prefix + ".start.bias"], audio0))
-    h = bf16_round(_with_speaker(sd, prefix, spect, speaker_ids))
+    x = rnd(_conv1x1(_conv_weight(sd, prefix + ".start"), sd[prefix + ".start.bias"], audio0))
+    h = rnd(_with_speaker(sd, prefix, spect, speaker_ids))
     for j in range(2):
-        h = bf16_round(_conv1x1(bf16_round(_conv_weight(sd, f"{prefix}.cond_layers.{j}")),
+        h = rnd(_conv1x1(rnd(_conv_weight(sd, f"{prefix}.cond_layers.{j}")),
                                 sd[f"{prefix}.cond_layers.{j}.bias"], h))
-    wc2 = bf16_round(_conv_weight(sd, f"{prefix}.cond_layers.2")[:, :, 0])
+    wc2 = rnd(_conv_weight(sd, f"{prefix}.cond_layers.2")[:, :, 0])
     bc2 = sd[f"{prefix}.cond_layers.2.bias"]
     out = None
     skip, bias_total, pending = None, None, []   # fp32 partial skip sum of the current group of BF16_SKIP_GROUP layers
     for i in range(n_layers):
         d = 2 ** i
-        w = bf16_round(_conv_weight(sd, f"{prefix}.in_layers.{i}"))
+        w = rnd(_conv_weight(sd, f"{prefix}.in_layers.{i}"))
         bias = (sd[f"{prefix}.in_layers.{i}.bias"] + bc2[2 * C * i:2 * C * (i + 1)]).astype(F32)
         u = np.matmul(np.ascontiguousarray(wc2[2 * C * i:2 * C * (i + 1)]), h)
         ks = w.shape[2]
         for t in range(ks):
             u = u + np.matmul(np.ascontiguousarray(w[:, :, t]), _shift(x, (t - ks // 2) * d))
         u = (u + bias[None, :, None]).astype(F32)
-        act = bf16_round(np.tanh(u[:, :C]) * (F32(1.0) / (F32(1.0) + np.exp(-u[:, C:]))))
+        act = rnd(np.tanh(u[:, :C]) * (F32(1.0) / (F32(1.0) + np.exp(-u[:, C:]))))
         wrs = _conv_weight(sd, f"{prefix}.res_skip_layers.{i}")
         brs = sd[f"{prefix}.res_skip_layers.{i}.bias"]
         if f"{prefix}.alpha_i.{i}" in sd:                        # the kernels fold alpha into weight and bias at pack time
             wrs, brs = (wrs * sd[f"{prefix}.alpha_i.{i}"][0]).astype(F32), (brs * sd[f"{prefix}.alpha_i.{i}"][0]).astype(F32)
-        wq = bf16_round(wrs)
+        wq = rnd(wrs)
         zero = np.zeros(C, dtype=F32)
         if i < n_layers - 1:
-            x = bf16_round(x + _conv1x1(wq[:C], brs[:C], act).astype(F32))
+            x = rnd(x + _conv1x1(wq[:C], brs[:C], act).astype(F32))
             wsk, bsk = wq[C:], brs[C:]
         else:
             wsk, bsk = wq, brs
@@ -200,13 +209,13 @@ def wn_forward_bf16(sd, prefix, audio0, spect, n_layers, n_channels, speaker_ids
             pending.append(skip)
             skip = None
     for gi, part in enumerate(pending):
-        out = bf16_round(part + bias_total[None, :, None]) if gi == 0 else bf16_round(out + part)
+        out = rnd(part + bias_total[None, :, None]) if gi == 0 else rnd(out + part)
     e = _conv1x1(np.asarray(sd[prefix + ".end.weight"], dtype=F32), sd[prefix + ".end.bias"], out)
     hh = e.shape[1] // 2
     return e[:, :hh], e[:, hh:]
 
 
-def waveglow_infer(sd, cfg, mel, z_scaled, flow_trace=None, bf16=False, speaker_ids=None):
+def waveglow_infer(sd, cfg, mel, z_scaled, flow_trace=None, bf16=False, speaker_ids=None, f16=False):
     """mel [B, n_mel, F], z_scaled [B, n_group, L] (sigma already applied) -> wave [B, F*hop].
 
     ``z_scaled`` rows: the last ``n_remaining_channels`` are the initial latent; the
@@ -227,8 +236,11 @@ def waveglow_infer(sd, cfg, mel, z_scaled, flow_trace=None, bf16=False, speaker_
     for k in reversed(range(n_flows)):
         h = audio.shape[1] // 2
         a0, a1 = audio[:, :h], audio[:, h:]
-        fwd = wn_forward_bf16 if bf16 else wn_forward
-        b, s = fwd(sd, f"WN.{k}", a0, spect, wn["n_layers"], wn["n_channels"], speaker_ids=speaker_ids)
+        if bf16 or f16:                      # reduced-precision variants: same rounding points, bf16 or IEEE-half storage
+            b, s = wn_forward_bf16(sd, f"WN.{k}", a0, spect, wn["n_layers"], wn["n_channels"], speaker_ids=speaker_ids,
+                                   rnd=f16_round if f16 else bf16_round)
+        else:
+            b, s = wn_forward(sd, f"WN.{k}", a0, spect, wn["n_layers"], wn["n_channels"], speaker_ids=speaker_ids)
         a1 = ((a1 - b) / np.exp(s)).astype(F32)
         audio = np.concatenate([a0, a1], axis=1)
         w = sd[f"convinv.{k}.conv.weight"][:, :, 0]

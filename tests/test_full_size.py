@@ -132,6 +132,11 @@ def test_config2_waveglow_full_length_matches_reference_golden(hip_lib_path):
     err16 = rms_rel_err(m.infer_from_noise(mel, torch.from_numpy(g["z_scaled"]).cuda()).cpu().numpy(), g["wave"])
     print(f"config 3 arithmetic (bf16) at full length, 80 x 900: rms rel err vs the fp32 reference = {err16:.3e}")
     assert err16 < BF16_VS_REFERENCE_LIMIT["full_len"]
+    # the same kernels on IEEE-half storage (the reference's own half mode): INSIDE the north-star bound at full length
+    m.set_compute_dtype(torch.float16)
+    errh = rms_rel_err(m.infer_from_noise(mel, torch.from_numpy(g["z_scaled"]).cuda()).cpu().numpy(), g["wave"])
+    print(f"config 3 kernels on IEEE half at full length, 80 x 900: rms rel err vs the fp32 reference = {errh:.3e}")
+    assert errh < 1e-3
 
 
 def test_config4_waveflow_full_length_matches_reference_golden(hip_lib_path):

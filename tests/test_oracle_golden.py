@@ -109,3 +109,17 @@ def test_torch_cpu_baseline_full_length_matches_reference():
     wave = wt.waveglow_infer(wt.fold(sd), cfg, mel, g["z_scaled"])
     assert wave.shape == g["wave"].shape == (1, 230400)
     assert rms_rel_err(wave, g["wave"]) < ORACLE_TOL
+
+
+@pytest.mark.parametrize("name", ["toy_early", "small"])
+def test_f16_rounded_oracle_is_inside_the_waveform_bound_where_bf16_is_not(name):
+    """The rounding points of the reduced-precision HIP variants restated with IEEE-half storage (11-bit significands) stay
+    inside the north-star bound against the reference's own output; with bf16 storage (8 bits) they do not on `small`."""
+    g = np.load(os.path.join(GOLDEN, f"waveglow_{name}.npz"))
+    cfg = synthetic.WAVEGLOW_CONFIGS[str(g["config_key"])]
+    sd = synthetic.waveglow_state_dict(cfg, seed=int(g["seed"]))
+    e16 = rms_rel_err(wo.waveglow_infer(sd, cfg, g["mel"], g["z_scaled"], f16=True), g["wave"])
+    eb = rms_rel_err(wo.waveglow_infer(sd, cfg, g["mel"], g["z_scaled"], bf16=True), g["wave"])
+    assert e16 < 1e-3 and eb > 4 * e16, (e16, eb)
+    if name == "small":
+        assert eb > 1e-3

@@ -147,6 +147,52 @@ def test_waveglow_bf16_matches_bf16_rounded_oracle(hip_lib_path, name):
     assert rms_rel_err(w32, g["wave"]) < WAVE_TOL
 
 
+# ---- IEEE half ("f16"): the bf16 path's layouts and kernels on half storage / v_mfma_f32_32x32x16_f16 -----------------
+# The reference's own reduced-precision mode (glow.py:343).  11-bit significands: against the fp32 REFERENCE goldens this
+# path is held to the north-star bound itself (RMS rel <= 1e-3), which one bf16 product per MAC cannot meet.
+F16_VS_F16_ORACLE_TOL = 1e-3
+
+
+@pytest.mark.parametrize("name", ["toy_early", "small", "full_short"])
+def test_waveglow_f16_matches_f16_rounded_oracle_and_the_reference_golden(hip_lib_path, name):
+    from oracle import waveglow_oracle as wo
+    g = np.load(os.path.join(GOLDEN, f"waveglow_{name}.npz"))
+    m, cfg, sd = _model(str(g["config_key"]), int(g["seed"]))
+    m.set_compute_dtype(torch.float16)
+    mel, z = torch.from_numpy(g["mel"]).cuda(), torch.from_numpy(g["z_scaled"]).cuda()
+    wave = m.infer_from_noise(mel, z).cpu().numpy()
+    assert np.isfinite(wave).all()
+    ref16 = wo.waveglow_infer(sd, cfg, g["mel"], g["z_scaled"], f16=True)
+    e16, e32 = rms_rel_err(wave, ref16), rms_rel_err(wave, g["wave"])
+    print(f"f16 {name}: rms rel err vs f16-rounded oracle = {e16:.3e}; vs the fp32 reference golden = {e32:.3e}")
+    assert e16 < F16_VS_F16_ORACLE_TOL
+    assert e32 < WAVE_TOL                                     # the north-star bound, against the reference's own output
+    # not the bf16 arithmetic under another name: bf16 on the same input is several times further from the reference
+    m.set_compute_dtype(torch.bfloat16)
+    eb = rms_rel_err(m.infer_from_noise(mel, z).cpu().numpy(), g["wave"])
+    assert eb > 2.5 * e32, (eb, e32)
+    m.set_compute_dtype(torch.float32)
+    assert rms_rel_err(m.infer_from_noise(mel, z).cpu().numpy(), g["wave"]) < 1e-5
+
+
+@pytest.mark.parametrize("knob", ["CTTS_BF16_NO_WIDE", "CTTS_BF16_PS", "CTTS_BF16_NO_PS", "CTTS_GEMM_NO_XCD_PAIR"])
+def test_waveglow_f16_block_shapes_agree(hip_lib_path, tuning, knob):
+    """The f16 instantiations of the skewed / persistent / narrow kernels accumulate K in the same order: identical bits
+    (same size as the bf16 block-shape test: the wide kernels with a ragged last tile, two or three tiles per persistent
+    workgroup)."""
+    m, cfg, sd = _model("full", 5)
+    m.set_compute_dtype(torch.float16)
+    B, F = 8, 131
+    mel = torch.from_numpy(synthetic.synthetic_mel(B, F, seed=6)).cuda()
+    z = torch.from_numpy(synthetic.synthetic_noise(B, 8, F * 32, seed=6) * np.float32(0.6)).cuda()
+    default = m.infer_from_noise(mel, z)
+    assert torch.isfinite(default).all()
+    for b in (0, 5):                                          # (narrow kernels: a single utterance is below the wide threshold)
+        assert torch.equal(m.infer_from_noise(mel[b:b + 1].contiguous(), z[b:b + 1].contiguous())[0], default[b])
+    tuning.set(knob)
+    assert torch.equal(default, m.infer_from_noise(mel, z))
+
+
 # ---- split bf16 ("bf16x3"): hi + lo bf16 operands, three bf16 MFMA products per contraction ---------------------
 # Held to the fp32 bar: the reference fp32 goldens at the north-star tolerance (RMS rel <= 1e-3); the measured error is
 # printed (expected ~1e-5: operands carry 16 mantissa bits).
@@ -263,10 +309,15 @@ def test_5_infer_vocoder_slot(hip_lib_path, tmp_path):
     mel_batch = torch.from_numpy(synthetic.synthetic_mel(3, 21)).cuda()
     audio = vocoder(mel_batch.to(vocoder_dtype)).squeeze(1).cpu().split(1, dim=0)       # text2speech.py:664
     assert len(audio) == 3 and audio[0].shape == (1, 21 * 256) and torch.isfinite(audio[0]).all()
+    torch.manual_seed(3)
+    audio32 = vocoder(mel_batch).squeeze(1)
     vocoder.half()                                                                       # text2speech.py:261
     assert next(vocoder.parameters()).dtype == torch.float32
+    torch.manual_seed(3)
     audio16 = vocoder(mel_batch).squeeze(1)
     assert audio16.shape == (3, 21 * 256) and torch.isfinite(audio16).all()
+    # .half() = IEEE-half storage + fp16 MFMA from fp32 masters: the same noise gives the fp32 audio within the 1e-3 bound
+    assert rms_rel_err(audio16.cpu().numpy(), audio32.cpu().numpy()) < WAVE_TOL
 
 
 def test_packed_weights_follow_parent_load_state_dict_and_in_place_updates(hip_lib_path):
