@@ -20,6 +20,8 @@
 #include <atomic>
 #include <mutex>
 
+#include <type_traits>
+
 #include "gemm_f32.h"
 #include "tuning.h"
 #include "waveflow_tail.h"
@@ -834,8 +836,15 @@ static_assert(K_BIAS + 256 <= K_NST * K_STAGE, "the epilogue lives in the stage 
 
 // (FRESH / ARGS: as gate_rs_small_tile - the tile is an item of the row queue and reads / writes what other workgroups of the same
 // launch write / read)
-template <int SEGS, bool FRESH, class ARGS>
-__device__ __forceinline__ void gate_rs_splitk_tile(ARGS& a, const int tile, const int b) {
+// WAIT (row queue only): called by every thread once the tile's data-INDEPENDENT prologue is under way - epilogue weights
+// requested, segment and chunk tables built, the weight (A) pieces of the first two chunk pairs in flight - and returns when
+// the item's dependencies are met (false: the launch is being aborted).  Everything that reads what other workgroups wrote
+// (the read-modify-write operands, the B pieces) is requested after it.  At batch 1-2 every item of a stage is held by a
+// workgroup that waits for the previous stage: the ~4 us prologue (profiles/r5_21) now runs inside that wait.
+struct SplitkNoWait { __device__ __forceinline__ bool operator()() const { return true; } };
+template <int SEGS, bool FRESH, class ARGS, class WAIT = SplitkNoWait>
+__device__ __forceinline__ void gate_rs_splitk_tile(ARGS& a, const int tile, const int b, WAIT wait = WAIT()) {
+    constexpr bool EARLY = !std::is_same<WAIT, SplitkNoWait>::value;      // prologue before the dependency wait
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -850,24 +859,27 @@ __device__ __forceinline__ void gate_rs_splitk_tile(ARGS& a, const int tile, con
     typedef float k_f32x4 __attribute__((ext_vector_type(4)));
     float old[2][16];
     k_f32x4 rsw[8];
+    auto load_old = [&]() {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int rbase = (2 * kh + j) * 32;
-        const bool second = rbase >= a.split;
-        const r_cgptr dstc = (r_cgptr)(second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride);
-        const r_cgptr src = second ? dstc : (a.src0 ? (r_cgptr)(a.src0 + (size_t)b * a.src0_bstride) : dstc);
-        const int accum = second ? a.acc1 : a.acc0;
-        const int rdst = second ? rbase - a.split : rbase;
-        if (accum && rbase < a.rs_rows) {
-            const r_cgptr sp = src + (size_t)rdst * a.dst_ld + a.dst_pad + min(n, a.L - 1);
-            const int rlast = a.rs_rows - 1 - rbase;
+        for (int j = 0; j < 2; ++j) {
+            const int rbase = (2 * kh + j) * 32;
+            const bool second = rbase >= a.split;
+            const r_cgptr dstc = (r_cgptr)(second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride);
+            const r_cgptr src = second ? dstc : (a.src0 ? (r_cgptr)(a.src0 + (size_t)b * a.src0_bstride) : dstc);
+            const int accum = second ? a.acc1 : a.acc0;
+            const int rdst = second ? rbase - a.split : rbase;
+            if (accum && rbase < a.rs_rows) {
+                const r_cgptr sp = src + (size_t)rdst * a.dst_ld + a.dst_pad + min(n, a.L - 1);
+                const int rlast = a.rs_rows - 1 - rbase;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) old[j][r] = r_load_old(sp + (size_t)min((r & 3) + 8 * (r >> 2) + 4 * lhi, rlast) * a.dst_ld, FRESH);
-        } else {
+                for (int r = 0; r < 16; ++r) old[j][r] = r_load_old(sp + (size_t)min((r & 3) + 8 * (r >> 2) + 4 * lhi, rlast) * a.dst_ld, FRESH);
+            } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) old[j][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) old[j][r] = 0.0f;
+            }
         }
-    }
+    };
+    if constexpr (!EARLY) load_old();
 #pragma unroll
     for (int k = 0; k < 8; ++k) rsw[k] = *reinterpret_cast<const __attribute__((address_space(1))) k_f32x4*>((r_cgptr)a.rs_wT + t * 4 + k * 1024);
     const float bias_pre = t < S_BM ? ((r_cgptr)a.bias)[t] : 0.0f;
@@ -941,14 +953,40 @@ __device__ __forceinline__ void gate_rs_splitk_tile(ARGS& a, const int tile, con
     const unsigned long long* ctab = reinterpret_cast<const unsigned long long*>(lds + K_CHTAB);
     const int nch = a.nch_total;
     const int npairs = (nch + 1) / 2;
+    if constexpr (!EARLY) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {                            // pairs 0 and 1 (chunks past the end: a copy of the last one)
-        const int ce = min(2 * j, nch - 1), co = min(2 * j + 1, nch - 1);
-        K_ISSUE_A(2 * j, ce, 0); K_ISSUE_A(2 * j, ce, 1); K_ISSUE_B_AT(2 * j, ctab[ce]);
-        K_ISSUE_A(2 * j + 1, co, 0); K_ISSUE_A(2 * j + 1, co, 1); K_ISSUE_B_AT(2 * j + 1, ctab[co]);
+        for (int j = 0; j < 2; ++j) {                        // pairs 0 and 1 (chunks past the end: a copy of the last one)
+            const int ce = min(2 * j, nch - 1), co = min(2 * j + 1, nch - 1);
+            K_ISSUE_A(2 * j, ce, 0); K_ISSUE_A(2 * j, ce, 1); K_ISSUE_B_AT(2 * j, ctab[ce]);
+            K_ISSUE_A(2 * j + 1, co, 0); K_ISSUE_A(2 * j + 1, co, 1); K_ISSUE_B_AT(2 * j + 1, ctab[co]);
+        }
+        if constexpr (!FRESH) S_STAMP(1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // pair 0 landed (the newest six pieces = pair 1 in flight)
+    } else {
+        // weights first: they do not depend on the previous stage ...
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ce = min(2 * j, nch - 1), co = min(2 * j + 1, nch - 1);
+            K_ISSUE_A(2 * j, ce, 0); K_ISSUE_A(2 * j, ce, 1);
+            K_ISSUE_A(2 * j + 1, co, 0); K_ISSUE_A(2 * j + 1, co, 1);
+        }
+        // ... then the dependencies, then what reads other workgroups' results.  Order of this thread's memory operations:
+        // [8 A pieces] [read-modify-write operands] [B of pair 0: 2 pieces] [B of pair 1: 2 pieces]; "pair 0 landed" =
+        // everything but the newest two.  The main loop's own counts (six pieces per pair) hold from its first pair on: what
+        // is still in flight then is older than what it issues.
+        if (!wait()) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may land in an LDS this workgroup has left
+            return;
+        }
+        load_old();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ce = min(2 * j, nch - 1), co = min(2 * j + 1, nch - 1);
+            K_ISSUE_B_AT(2 * j, ctab[ce]);
+            K_ISSUE_B_AT(2 * j + 1, ctab[co]);
+        }
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     }
-    if constexpr (!FRESH) S_STAMP(1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!FRESH) S_STAMP(2);
@@ -1264,52 +1302,66 @@ __global__ __launch_bounds__(256, 2) void wf_row_persistent_kernel(const WfRowAr
         const int row = gs / spr, layer = gs - row * spr;                    // layer == nlayers: the row's tail stage
         const int b = rem / ntiles, tile = rem - b * ntiles;
         const int halo = layer == w.nlayers ? 0 : HALO;                      // a tail item needs its own tile only
-        if (gs > 0 && t < 2 * HALO + 1 && !(w.debug & 1)) {
-            const int tt = tile + t - HALO;
-            if (tt >= tile - halo && tt <= tile + halo && tt >= 0 && tt < ntiles) {
-                const unsigned int* f = w.flags + (size_t)(gs - 1) * per_layer + b * ntiles + tt;
-                // The bound is on time WITHOUT PROGRESS, not on wall time: s_memrealtime keeps running while the process is
-                // preempted or shares the GPU, so the first expiry only takes a snapshot of the launch's item counter and opens a
-                // second period (everybody was frozen together; the others need a moment to be seen moving again); the wait
-                // aborts when a whole further period passes in which no workgroup claimed an item.
-                unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                unsigned int seen = 0;
-                bool have_seen = false;                                    // (the counter is only looked at once a period has expired)
-                for (unsigned spins = 0; __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != w.epoch; ++spins) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if ((spins & 63u) == 63u) {
-                        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-                        if (now - t0 > w.timeout_ticks) {
-                            const unsigned int c = __hip_atomic_load(w.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (have_seen && c == seen) {                  // a whole period in which nobody claimed an item
-                                __hip_atomic_store(w.abort_word, 1u + (unsigned)gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                s_abort = 1;
-                                break;
+        // Every thread calls it once per item: the (<= 2 HALO + 1) polling threads spin on their neighbour flags of the previous
+        // stage, the barrier closes the wait.  false: the launch is being aborted.
+        auto wait_deps = [&]() -> bool {
+            if (gs > 0 && t < 2 * HALO + 1 && !(w.debug & 1)) {
+                const int tt = tile + t - HALO;
+                if (tt >= tile - halo && tt <= tile + halo && tt >= 0 && tt < ntiles) {
+                    const unsigned int* f = w.flags + (size_t)(gs - 1) * per_layer + b * ntiles + tt;
+                    // The bound is on time WITHOUT PROGRESS, not on wall time: s_memrealtime keeps running while the process is
+                    // preempted or shares the GPU, so the first expiry only takes a snapshot of the launch's item counter and opens a
+                    // second period (everybody was frozen together; the others need a moment to be seen moving again); the wait
+                    // aborts when a whole further period passes in which no workgroup claimed an item.
+                    unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    unsigned int seen = 0;
+                    bool have_seen = false;                                // (the counter is only looked at once a period has expired)
+                    for (unsigned spins = 0; __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != w.epoch; ++spins) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if ((spins & 63u) == 63u) {
+                            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                            if (now - t0 > w.timeout_ticks) {
+                                const unsigned int c = __hip_atomic_load(w.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (have_seen && c == seen) {              // a whole period in which nobody claimed an item
+                                    __hip_atomic_store(w.abort_word, 1u + (unsigned)gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    s_abort = 1;
+                                    break;
+                                }
+                                seen = c;
+                                have_seen = true;
+                                t0 = now;
                             }
-                            seen = c;
-                            have_seen = true;
-                            t0 = now;
+                            if (__hip_atomic_load(w.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { s_abort = 1; break; }
                         }
-                        if (__hip_atomic_load(w.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { s_abort = 1; break; }
                     }
                 }
             }
-        }
-        __syncthreads();                                   // dependencies met
-        if (__builtin_amdgcn_readfirstlane(s_abort)) break;
-        // Acquire.  Everything another workgroup wrote inside this launch is read with sc1 loads / sc1 DMA (GemmSeg.fresh, the
-        // tail's atomic loads), which is what makes the relaxed flag protocol correct today; the invalidate (buffer_inv sc1)
-        // makes it correct for a plain load of such data too, should one ever be added.  CTTS_WF_QUEUE_DEBUG=256
-        // leaves it out (A/B: profiles/r5_17_wf_queue_acquire_ab.txt).
-        if (!(w.debug & 256)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (layer == w.nlayers) {
-            typedef const __attribute__((address_space(4))) WfTailDesc const_tail;
-            wf_tail_start_tile<BODY == 1 ? 64 : 128, const_tail>(*((const_tail*)w.tails + row), tile, b, s_tail);
-        } else if (!(w.debug & 2)) {
-            typedef const __attribute__((address_space(4))) GemmArgs const_args;     // scalar loads of the descriptor
+            __syncthreads();                               // dependencies met
+            if (__builtin_amdgcn_readfirstlane(s_abort)) return false;
+            // Acquire.  Everything another workgroup wrote inside this launch is read with sc1 loads / sc1 DMA (GemmSeg.fresh, the
+            // tail's atomic loads), which is what makes the relaxed flag protocol correct today; the invalidate (buffer_inv sc1)
+            // makes it correct for a plain load of such data too, should one ever be added.  CTTS_WF_QUEUE_DEBUG=256
+            // leaves it out (A/B: profiles/r5_17_wf_queue_acquire_ab.txt).
+            if (!(w.debug & 256)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            return true;
+        };
+        typedef const __attribute__((address_space(4))) GemmArgs const_args;         // scalar loads of the descriptor
+        if (BODY == 1 && layer < w.nlayers && !(w.debug & (2 | 512))) {
+            // split-K item: the tile's data-independent prologue runs BEFORE the wait (CTTS_WF_QUEUE_DEBUG=512: after it, as the
+            // 128 x 128 items and the tail stage do)
             const_args& a = *((const_args*)w.layers + (size_t)row * w.nlayers + layer);
-            if constexpr (BODY == 1) gate_rs_splitk_tile<SEGS, true, const_args>(a, tile, b);
-            else gate_rs_small_tile<SEGS, true, const_args>(a, tile, b);
+            if constexpr (BODY == 1) gate_rs_splitk_tile<SEGS, true, const_args>(a, tile, b, wait_deps);
+            if (__builtin_amdgcn_readfirstlane(s_abort)) break;
+        } else {
+            if (!wait_deps()) break;
+            if (layer == w.nlayers) {
+                typedef const __attribute__((address_space(4))) WfTailDesc const_tail;
+                wf_tail_start_tile<BODY == 1 ? 64 : 128, const_tail>(*((const_tail*)w.tails + row), tile, b, s_tail);
+            } else if (!(w.debug & 2)) {
+                const_args& a = *((const_args*)w.layers + (size_t)row * w.nlayers + layer);
+                if constexpr (BODY == 1) gate_rs_splitk_tile<SEGS, true, const_args>(a, tile, b);
+                else gate_rs_small_tile<SEGS, true, const_args>(a, tile, b);
+            }
         }
         // Release.  Every result was stored at agent scope (sc1: written THROUGH this XCD's L2), so a store is visible to the
         // agent once it is acknowledged: vmcnt(0) of every thread, then the barrier, then the flag.  The formal release fence

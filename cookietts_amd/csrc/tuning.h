@@ -30,7 +30,7 @@ struct Tuning {
     bool wf_no_region_split; // CTTS_WF_NO_REGION_SPLIT: the fused WaveFlow layer as ONE launch per layer (no A | M | B regions on three streams)
     bool wf_no_row_queue;  // CTTS_WF_NO_ROW_QUEUE: never the one-launch-per-row work queue of the fused WaveFlow layers
     int wf_row_queue_min;  // CTTS_WF_ROW_QUEUE_MIN: take the row queue from this many 128-column items per layer on (A/B; default in waveflow_api.hip)
-    int wf_queue_debug;    // CTTS_WF_QUEUE_DEBUG: (diagnosis) 1 no dependency waits, 2 no tile body, 4 no fresh marks, 8 full release fence per item, 16 / 32 force the 128 x 128 / split-K body, 64 two workgroups per CU at every size, 128 one launch per ROW instead of one per flow, 256 no acquire fence per item
+    int wf_queue_debug;    // CTTS_WF_QUEUE_DEBUG: (diagnosis) 1 no dependency waits, 2 no tile body, 4 no fresh marks, 8 full release fence per item, 16 / 32 force the 128 x 128 / split-K body, 64 two workgroups per CU at every size, 128 one launch per ROW instead of one per flow, 256 no acquire fence per item, 512 split-K items run their prologue after the dependency wait
     int wf_inject_abort;   // CTTS_WF_INJECT_ABORT: (tests) start the call with the queue's abort word set
     bool wf_no_vec_interp; // CTTS_WF_NO_VEC_INTERP: the scalar form of the WaveFlow conditioning interpolation (bit-identical)
     int w4_debug;          // CTTS_BF16_W4_DEBUG (only in builds with -DCTTS_W4_TIMING_EXPERIMENTS)
