@@ -30,7 +30,7 @@ def _wn_forward_variant(round_w, round_act, round_store):
     ra = rnd if round_act else (lambda a: a)
     rs = rnd if round_store else (lambda a: a)
 
-    def fwd(sd, prefix, audio0, spect, n_layers, n_channels, speaker_ids=None):
+    def fwd(sd, prefix, audio0, spect, n_layers, n_channels, speaker_ids=None, rnd=None):   # (rnd: the oracle's storage rounding, unused here)
         C = n_channels
         x = rs(wo._conv1x1(wo._conv_weight(sd, prefix + ".start"), sd[prefix + ".start.bias"], audio0))
         h = rs(spect)
