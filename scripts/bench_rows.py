@@ -212,6 +212,14 @@ def row_tacotron(args, vocoder=None):
         wg = wg.cuda().eval()
     mel = m.inference(text, lens, spk, tm, fixed_steps=steps)["pred_mel_postnet"].clamp(-11.52, 2.0)
     dv = timed(lambda: wg.infer(mel, sigma=0.6), 1, max(1, args.steps - 1))
+    # the same vocoder in the reference's half mode (WaveGlowVocoder.half(): IEEE-half storage + fp16 MFMA from the fp32 masters,
+    # inside the 1e-3 waveform bound) - what the _5_infer slot runs after load_hifigan-style .half()
+    dv16 = None
+    try:
+        wg.set_compute_dtype(torch.float16)
+        dv16 = timed(lambda: wg.infer(mel, sigma=0.6), 1, max(1, args.steps - 1))
+    finally:
+        wg.set_compute_dtype(torch.float32)
     samples = B * steps * 256
     return {"row": "C/config5", "metric": "Tacotron2-TM decoder step time, B=4, 200 symbols, 900 forced steps",
             "value": dd / steps * 1e6, "unit": "us/step", "higher_is_better": False,
@@ -226,7 +234,9 @@ def row_tacotron(args, vocoder=None):
             "fetched_per_step_MB_pmc": 0.78 if m.decoder.persistent_state == "ok" else None,
             "fetched_per_step_source": "profiles/r4_09_pmc_config5_tacotron_resident.json (committed PMC pass, not re-measured in this run)",
             "chained_vocoder_samples_per_s": samples / dv, "chained_vocoder_ms": dv * 1e3,
-            "text_to_wave_rtf": samples / (dt + dv) / 22050.0}
+            "text_to_wave_rtf": samples / (dt + dv) / 22050.0,
+            "chained_vocoder_f16_ms": None if dv16 is None else dv16 * 1e3,
+            "text_to_wave_rtf_f16_vocoder": None if dv16 is None else samples / (dt + dv16) / 22050.0}
 
 
 def row_stft(args):
