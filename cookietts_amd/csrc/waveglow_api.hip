@@ -478,13 +478,17 @@ __global__ __launch_bounds__(256) void wn_start_bf16_kernel(const float* __restr
 }
 
 // end 1x1 conv on the bf16 skip sum + coupling inverse + inverse 1x1 (+ un-squeeze), fp32 math
-template <int H>
+// FMT: 0 = bf16, 1 = split bf16 (hi + lo planes), 2 = IEEE half - a compile-time choice: with `lo_off` tested at run time the
+// compiler put a branch and a full `vmcnt(0)` behind every 16-byte load of the skip sum (0.97 ms per launch at config 3 = 1 TB/s;
+// round 5).  Eight groups of loads are in flight before the first is used.
+template <int H, int FMT>
 __global__ __launch_bounds__(256) void flow_tail_bf16_kernel(const bf16_t* __restrict__ out, float* __restrict__ audio,
                                                              float* __restrict__ wave, const float* __restrict__ Wend,
                                                              const float* __restrict__ bend, const float* __restrict__ Winv,
                                                              int C, int G, int ch_off, int L, int ld, int pad,
-                                                             long long lo_off, int f16) {
+                                                             long long lo_off) {
     constexpr int E = 2 * H;
+    constexpr int NG = 8;                                    // groups (of 8 channels) per batch of loads
     __shared__ float sW[E * 512 + E * E + E];
     const int b = blockIdx.y;
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -497,21 +501,45 @@ __global__ __launch_bounds__(256) void flow_tail_bf16_kernel(const bf16_t* __res
 #pragma unroll
     for (int j = 0; j < E; ++j) e[j] = sW[E * C + E * E + j];
     const uint4* ob = reinterpret_cast<const uint4*>(out) + ((size_t)b * (C / 8)) * ld + pad + n;
-#pragma unroll 4
-    for (int grp = 0; grp < C / 8; ++grp) {
-        const uint4 u = ob[(size_t)grp * ld];
-        const uint4 ul = lo_off ? *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(ob + (size_t)grp * ld) + lo_off)
-                                : make_uint4(0u, 0u, 0u, 0u);
-        const unsigned int w4[4] = {u.x, u.y, u.z, u.w}, l4[4] = {ul.x, ul.y, ul.z, ul.w};
+    auto accumulate = [&](const uint4& uu, const uint4& ll, int grp) {
+        const unsigned int w4[4] = {uu.x, uu.y, uu.z, uu.w}, l4[4] = {ll.x, ll.y, ll.z, ll.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float v0 = (f16 ? f16_to_f32((bf16_t)(w4[q] & 0xffff)) : bf16_to_f32((bf16_t)(w4[q] & 0xffff))) + bf16_to_f32((bf16_t)(l4[q] & 0xffff));
-            const float v1 = (f16 ? f16_to_f32((bf16_t)(w4[q] >> 16)) : bf16_to_f32((bf16_t)(w4[q] >> 16))) + bf16_to_f32((bf16_t)(l4[q] >> 16));
+            float v0, v1;
+            if constexpr (FMT == 2) {
+                v0 = f16_to_f32((bf16_t)(w4[q] & 0xffff));
+                v1 = f16_to_f32((bf16_t)(w4[q] >> 16));
+            } else {
+                v0 = bf16_to_f32((bf16_t)(w4[q] & 0xffff));
+                v1 = bf16_to_f32((bf16_t)(w4[q] >> 16));
+                if constexpr (FMT == 1) {
+                    v0 += bf16_to_f32((bf16_t)(l4[q] & 0xffff));
+                    v1 += bf16_to_f32((bf16_t)(l4[q] >> 16));
+                }
+            }
             const int c = grp * 8 + 2 * q;
 #pragma unroll
             for (int j = 0; j < E; ++j) e[j] = fmaf(sW[j * C + c + 1], v1, fmaf(sW[j * C + c], v0, e[j]));
         }
+    };
+    auto load_lo = [&](int grp) -> uint4 {
+        if constexpr (FMT == 1)
+            return *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(ob + (size_t)grp * ld) + lo_off);
+        else
+            return make_uint4(0u, 0u, 0u, 0u);
+    };
+    int g0 = 0;
+    for (; g0 + NG <= C / 8; g0 += NG) {                     // whole batches: all NG loads issued before the first use
+        uint4 u[NG], ul[NG];
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            u[k] = ob[(size_t)(g0 + k) * ld];
+            ul[k] = load_lo(g0 + k);
+        }
+#pragma unroll
+        for (int k = 0; k < NG; ++k) accumulate(u[k], ul[k], g0 + k);
     }
+    for (; g0 < C / 8; ++g0) accumulate(ob[(size_t)g0 * ld], load_lo(g0), g0);   // narrow test widths
     float* ab = audio + ((size_t)b * G + ch_off) * L + n;
     float a[E];
 #pragma unroll
@@ -1031,16 +1059,19 @@ static int infer_bf16_impl(const ctts_waveglow_config* cfg, const void* packed, 
         const auto& d = p.fd[k];
         float* wv = k == 0 ? wave : nullptr;
         dim3 tgrid((g.L + 255) / 256, batch);
+#define CTTS_BTAIL1(HH, FF)                                                                                           \
+        hipLaunchKernelGGL((flow_tail_bf16_kernel<HH, FF>), tgrid, dim3(256), 0, s, w.out, w.audio, wv, blob + f.end_w,   \
+                           blob + f.end_b, blob + f.winv, p.C, p.c.n_group, d.ch_off, g.L, g.ld, g.pad, w.x_lo)
 #define CTTS_BTAIL(HH)                                                                                            \
     case HH:                                                                                                      \
-        hipLaunchKernelGGL(flow_tail_bf16_kernel<HH>, tgrid, dim3(256), 0, s, w.out, w.audio, wv, blob + f.end_w, \
-                           blob + f.end_b, blob + f.winv, p.C, p.c.n_group, d.ch_off, g.L, g.ld, g.pad, w.x_lo, q.f16); \
+        if (q.f16) CTTS_BTAIL1(HH, 2); else if (w.x_lo) CTTS_BTAIL1(HH, 1); else CTTS_BTAIL1(HH, 0);              \
         break;
         switch (d.n_half) {
             CTTS_BTAIL(1) CTTS_BTAIL(2) CTTS_BTAIL(3) CTTS_BTAIL(4)
             default: set_error("flow_tail_bf16: n_half=%d", d.n_half); return CTTS_E_ARG;
         }
 #undef CTTS_BTAIL
+#undef CTTS_BTAIL1
         CTTS_CHECK_LAUNCH("flow_tail_bf16");
     }
     return CTTS_OK;
