@@ -742,6 +742,7 @@ void load_tuning_locked() {
     g_tune.f32_no_small = on("CTTS_F32_NO_SMALL");
     g_tune.f32_force_small = on("CTTS_F32_FORCE_SMALL");
     g_tune.f32_no_splitk = on("CTTS_F32_NO_SPLITK");
+    g_tune.f32_splitk_w4 = on("CTTS_F32_SPLITK_W4");
     g_tune.f32_no_round_split = on("CTTS_F32_NO_ROUND_SPLIT");
     g_tune.no_xcd_pair = on("CTTS_GEMM_NO_XCD_PAIR");
     g_tune.bf16_no_glds = on("CTTS_BF16_NO_GLDS");

@@ -71,6 +71,25 @@ typedef const __attribute__((address_space(1))) char* gbyte_ptr;
         __builtin_amdgcn_global_load_lds((gfloat_ptr)((ubase) + o_), (ldsdst), 16, 0, (aux));                    \
     } while (0)
 
+// A launch of these kernels starts with a cold scalar cache and a 600-byte argument struct that the prologue reads field by
+// field: five to six DEPENDENT s_load batches, each a miss (~0.5 us), before the first operand request goes out (3.6 of a
+// 37 us batch-1 WaveFlow layer: profiles/r5_31).  Touching one dword of every 64-byte line of the kernarg segment at entry
+// turns them into one parallel miss; the later loads hit.  The value is kept alive until the caller consumes it.
+template <int BYTES>
+__device__ __forceinline__ unsigned warm_kernargs() {
+    const unsigned __attribute__((address_space(4)))* kp =
+        (const unsigned __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned x = 0;
+#pragma unroll
+    for (int o = 0; o < BYTES; o += 64) x ^= kp[o / 4];
+    return x;
+}
+#define CTTS_WARM_KERNARGS(T)                                                                                    \
+    do {                                                                                                         \
+        const unsigned w_ = warm_kernargs<(int)sizeof(T)>();                                                     \
+        asm volatile("" ::"s"(w_));                                                                              \
+    } while (0)
+
 // split-bf16 main loop (X3), exactly as in conv_gemm_f32_kernel<..., X3>: the 8 k-values a lane reads per fragment and chunk
 // become one bf16x8 operand pair hi = bf16(v), lo = bf16(v - hi); a 32x32 tile of the chunk is lo*hi + hi*lo + hi*hi on
 // v_mfma_f32_32x32x16_bf16, in that order - so this shape stays bit-identical to the large one in split mode too
@@ -1174,6 +1193,309 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_splitk_kernel(co
     gate_rs_splitk_tile<SEGS, false, const GemmArgs>(a, blockIdx.x % ntiles_s, blockIdx.x / ntiles_s);
 }
 
+// ---- the split-K tile on EIGHT waves (round 5; per-layer launches only, i.e. batch 1) ------------------------------------
+// At batch 1 the tile above runs ONE wave per SIMD on 226 CUs: nobody covers a wave's LDS reads, DMA issue and barrier waits, and
+// the main loop takes 27.5 us for 20 us of matrix work (profiles/r5_21).  Same 128 x 64 tile, same stages, same K order, but
+// waves (wn, kh, mh): wave mh of a (column tile, K half) owns the accumulator tiles mh and mh + 2 - the tanh rows and the sigmoid
+// rows of channels 32 mh .. 32 mh + 31 - so a SIMD holds two waves (s and s + 4: the same K half, the two channel halves) whose
+// stalls overlap with each other's MFMAs.  Per pair and wave: one A piece of the even chunk, one of the odd chunk, one B piece
+// (waves 0-3: the even chunk's, waves 4-7: the odd chunk's).  Epilogue: the kh = 1 partial sums meet the kh = 0 ones through LDS
+// as before, four waves gate (32 channels x 32 columns each), every wave takes ONE 32-row tile of the res/skip GEMM over all 64
+// channels.  Every output element is the same expression in the same order as in the four-wave tile: bit-identical
+// (tests/test_small_shape.py).
+// scripts/micro/wf_splitk_timeline.hip -DCTTS_PROLOGUE_STAMPS: the stamp slots 1-5 resolve the PROLOGUE instead of the later phases
+#ifdef CTTS_PROLOGUE_STAMPS
+#define K8_P_STAMP(k) S_STAMP(k)
+#define K8_L_STAMP(k)
+#else
+#define K8_P_STAMP(k)
+#define K8_L_STAMP(k) S_STAMP(k)
+#endif
+template <int SEGS>
+__device__ __forceinline__ void gate_rs_splitk8_tile(const GemmArgs& a, const int tile, const int b) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wn = wave & 1, kh = (wave >> 1) & 1, mh = wave >> 2;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int n0 = tile * K_BN;
+    const int n = n0 + wn * 32 + l31;
+    S_STAMP(0);
+    S_STAMP_WHERE();
+
+    // ---- prologue (profiles/r5_32: 4.5 us of a 37 us layer in the order of the four-wave tile - epilogue operands, segment table,
+    // barrier, chunk table, barrier, requests).  Here: (1) every thread below nch_total computes ITS chunk -> B address entry
+    // straight from the argument struct - the segment it falls in from the (uniform) chunk counts, that segment's base / batch
+    // stride / shift with one lane-indexed load from the kernarg segment - no segment table, one barrier; (2) while those loads
+    // fly the weight pieces of pairs 0 and 1 are requested (they need nothing but the struct), then the epilogue operands;
+    // (3) table entries written, barrier, the B pieces of pairs 0 and 1.
+    typedef const __attribute__((address_space(4))) char* k_kargp;
+    const k_kargp kp = (k_kargp)__builtin_amdgcn_kernarg_segment_ptr();      // the GemmArgs struct is the kernel's first parameter
+    const int nch = a.nch_total;
+    const int npairs = (nch + 1) / 2;
+    unsigned long long my_entry[(S_MAX_CHUNKS + 511) / 512];
+    {
+        int nchs[SEGS];
+#pragma unroll
+        for (int k = 0; k < SEGS; ++k) nchs[k] = k < a.nseg ? a.seg[k].nch : 0x7fffffff;
+        const int ilv0 = a.interleave > 1 ? a.interleave : 0;
+        const int n_il = ilv0 * a.seg[0].nch;
+#pragma unroll
+        for (int q = 0; q < (S_MAX_CHUNKS + 511) / 512; ++q) {
+            const int c0 = min(t + 512 * q, nch - 1);
+            int c = c0, sg, loc;
+            if (c < n_il) {
+                sg = c % ilv0;
+                loc = c / ilv0;
+            } else {
+                c -= n_il;
+                sg = ilv0;
+#pragma unroll
+                for (int k = 0; k < SEGS - 1; ++k)
+                    if (sg == k && k < a.nseg - 1 && c >= nchs[k]) { c -= nchs[k]; sg = k + 1; }
+                loc = c;
+            }
+            const k_kargp sp = kp + (offsetof(GemmArgs, seg) + (size_t)sg * sizeof(GemmSeg));
+            const unsigned long long sbase = *reinterpret_cast<const __attribute__((address_space(4))) unsigned long long*>(sp + offsetof(GemmSeg, base));
+            const long long sbstr = *reinterpret_cast<const __attribute__((address_space(4))) long long*>(sp + offsetof(GemmSeg, bstride));
+            const int sshift = *reinterpret_cast<const __attribute__((address_space(4))) int*>(sp + offsetof(GemmSeg, shift));
+            my_entry[q] = sbase + (unsigned long long)(((long long)b * sbstr + (a.pad + n0 + sshift) + (long long)loc * GEMM_KC * a.ld) * 4);
+        }
+    }
+
+    // DMA pieces: A [16][128] = 8 pieces of 1 KiB (piece = wave), B [16][64] = 4 pieces (piece bw = wave & 3: k-rows 4 bw .. + 4)
+    const int bw = wave & 3;
+    const gbyte_ptr a_base = (gbyte_ptr)(a.A + (size_t)a.a_ch_off * S_ASTAGE + wave * 256);
+    const unsigned dma_a_lane = (unsigned)(lane * 16);
+    const unsigned dma_b_lane = (unsigned)(((size_t)(4 * bw + (lane >> 4)) * a.ld + (lane & 15) * 4) * 4);
+    const unsigned lds0 = (unsigned)(size_t)(lds_fptr)lds;
+#define K8_ISSUE_A(cs, c) \
+    CTTS_GLDS_U(a_base + (size_t)(c) * (S_ASTAGE * 4), dma_a_lane, (lds_fptr)(lds + (cs) * K_CHUNK + wave * 256), 0)
+#define K8_ISSUE_B(cs, ub)                                                                                       \
+    do {                                                                                                         \
+        const unsigned long long ub_ = (ub);                                                                     \
+        const unsigned long long us_ =                                                                           \
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub_ >> 32)) << 32) |             \
+            (unsigned)__builtin_amdgcn_readfirstlane((int)ub_);                                                  \
+        CTTS_GLDS_U(reinterpret_cast<gbyte_ptr>(us_), dma_b_lane,                                                \
+                    (lds_fptr)(lds + (cs) * K_CHUNK + S_ASTAGE + bw * 256), 0);                                  \
+    } while (0)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {                            // pairs 0 and 1 (chunks past the end: a copy of the last one)
+        K8_ISSUE_A(2 * j, min(2 * j, nch - 1)); K8_ISSUE_A(2 * j + 1, min(2 * j + 1, nch - 1));
+    }
+    K8_P_STAMP(1);
+
+    // epilogue operands: this wave stores row tile jt
+    typedef float k_f32x4 __attribute__((ext_vector_type(4)));
+    const int jt = 2 * kh + mh;
+    float old[16];
+    k_f32x4 rsw[4];
+    {
+        const int rbase = jt * 32;
+        const bool second = rbase >= a.split;
+        const r_cgptr dstc = (r_cgptr)(second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride);
+        const r_cgptr src = second ? dstc : (a.src0 ? (r_cgptr)(a.src0 + (size_t)b * a.src0_bstride) : dstc);
+        const int accum = second ? a.acc1 : a.acc0;
+        const int rdst = second ? rbase - a.split : rbase;
+        if (accum && rbase < a.rs_rows) {
+            const r_cgptr sp = src + (size_t)rdst * a.dst_ld + a.dst_pad + min(n, a.L - 1);
+            const int rlast = a.rs_rows - 1 - rbase;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) old[r] = r_load_old(sp + (size_t)min((r & 3) + 8 * (r >> 2) + 4 * lhi, rlast) * a.dst_ld, false);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) old[r] = 0.0f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rsw[k] = *reinterpret_cast<const __attribute__((address_space(1))) k_f32x4*>((r_cgptr)a.rs_wT + t * 4 + k * 2048);
+    const float bias_pre = t < S_BM ? ((r_cgptr)a.bias)[t] : 0.0f;
+    const float rsb_pre = t < 128 ? ((r_cgptr)a.rs_bias)[t] : 0.0f;
+    K8_P_STAMP(2);
+
+    {
+        unsigned long long* tab = reinterpret_cast<unsigned long long*>(lds + K_CHTAB);
+#pragma unroll
+        for (int q = 0; q < (S_MAX_CHUNKS + 511) / 512; ++q)
+            if (t + 512 * q < nch) tab[t + 512 * q] = my_entry[q];
+    }
+    __syncthreads();
+    K8_P_STAMP(3);
+    const unsigned long long* ctab = reinterpret_cast<const unsigned long long*>(lds + K_CHTAB);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) K8_ISSUE_B(2 * j + mh, ctab[min(2 * j + mh, nch - 1)]);
+    K8_L_STAMP(1); K8_P_STAMP(4);
+    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");         // pair 0 landed: everything but this wave's B piece of pair 1
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    K8_L_STAMP(2); K8_P_STAMP(5);
+
+    f32x16 acc[2];                                           // accumulator tiles mh, mh + 2
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    typedef float k_f32x2 __attribute__((ext_vector_type(2)));
+    k_f32x2 a2[2];
+    float bq[2];
+    const unsigned a_lane = lds0 + (unsigned)((kh * K_CHUNK + lhi * S_BM + mh * 32 + l31) * 4);
+    const unsigned b_lane = lds0 + (unsigned)((kh * K_CHUNK + S_ASTAGE + lhi * K_BN + wn * 32 + l31) * 4);
+#define K8_READ_AT(ks, aaddr, baddr)                                                                             \
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(a2[(ks) & 1]) : "v"(aaddr), "n"(4 * (ks)), "n"(4 * (ks) + 1)); \
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bq[(ks) & 1]) : "v"(baddr), "n"(2 * (ks) * K_BN * 4));
+#define K8_WAIT(n_, ks) asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(a2[(ks) & 1]), "+v"(bq[(ks) & 1]));
+#ifdef CTTS_EXP_NO_LDSREAD    /* scripts/micro/wf_splitk_timeline.hip only (as in the four-wave tile) */
+#undef K8_READ_AT
+#undef K8_WAIT
+#define K8_READ_AT(ks, aaddr, baddr)
+#define K8_WAIT(n_, ks) asm volatile("" : "+v"(a2[(ks) & 1]), "+v"(bq[(ks) & 1]));
+#endif
+#ifdef CTTS_EXP_NO_MFMA
+#define K8_MFMA_ON false
+#else
+#define K8_MFMA_ON true
+#endif
+#define K8_MFMA(ks)                                                                                              \
+    if (K8_MFMA_ON && active) {                                                                                                \
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[(ks) & 1][0], bq[(ks) & 1], acc[0], 0, 0, 0);            \
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[(ks) & 1][1], bq[(ks) & 1], acc[1], 0, 0, 0);            \
+    }
+    K8_READ_AT(0, a_lane, b_lane)
+    int cur = 0;
+    for (int i = 0; i < npairs; ++i) {
+        const bool active = 2 * i + kh < nch;               // an odd chunk count leaves the last pair's odd half empty
+        const int nxt = cur == 2 ? 0 : cur + 1;
+        const unsigned aa = a_lane + (unsigned)(cur * K_STAGE * 4), ba = b_lane + (unsigned)(cur * K_STAGE * 4);
+        const unsigned an = a_lane + (unsigned)(nxt * K_STAGE * 4), bn = b_lane + (unsigned)(nxt * K_STAGE * 4);
+        const int nb = cur >= 1 ? cur - 1 : 2;              // (cur + 2) % 3: the stage pair i - 1 occupied
+        const int ne = min(2 * (i + 2), nch - 1), no = min(2 * (i + 2) + 1, nch - 1);
+        unsigned long long ub;
+        asm volatile("ds_read_b64 %0, %1" : "=v"(ub) : "v"((unsigned)(lds0 + K_CHTAB * 4 + (mh ? no : ne) * 8)));
+        // outstanding: k-step 0 (2 instructions) and the table entry
+#ifdef CTTS_EXP_NO_DMA
+#define K8_LOOP_ISSUE_A(cs, c)
+#define K8_LOOP_ISSUE_B(cs, ub)
+#else
+#define K8_LOOP_ISSUE_A(cs, c) K8_ISSUE_A(cs, c)
+#define K8_LOOP_ISSUE_B(cs, ub) K8_ISSUE_B(cs, ub)
+#endif
+        K8_READ_AT(1, aa, ba) K8_WAIT(3, 0) K8_MFMA(0) K8_LOOP_ISSUE_A(2 * nb, ne);
+        __builtin_amdgcn_sched_barrier(0);
+        K8_READ_AT(2, aa, ba) K8_WAIT(2, 1)                 // (covers the table entry)
+        asm volatile("" : "+v"(ub));
+        K8_MFMA(1) K8_LOOP_ISSUE_A(2 * nb + 1, no);
+        __builtin_amdgcn_sched_barrier(0);
+        K8_READ_AT(3, aa, ba) K8_WAIT(2, 2) K8_MFMA(2) K8_LOOP_ISSUE_B(2 * nb + mh, ub);
+        __builtin_amdgcn_sched_barrier(0);
+        K8_READ_AT(4, aa, ba) K8_WAIT(2, 3) K8_MFMA(3)
+        __builtin_amdgcn_sched_barrier(0);
+        K8_READ_AT(5, aa, ba) K8_WAIT(2, 4) K8_MFMA(4)
+        __builtin_amdgcn_sched_barrier(0);
+        K8_READ_AT(6, aa, ba) K8_WAIT(2, 5) K8_MFMA(5)
+        __builtin_amdgcn_sched_barrier(0);
+        K8_READ_AT(7, aa, ba) K8_WAIT(2, 6) K8_MFMA(6)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");    // pair i + 1 landed, the newest still in flight
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        K8_READ_AT(0, an, bn)
+        K8_WAIT(2, 7) K8_MFMA(7)
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a2[0]), "+v"(bq[0]));
+#undef K8_READ_AT
+#undef K8_WAIT
+#undef K8_MFMA
+#undef K8_ISSUE_A
+#undef K8_ISSUE_B
+#undef K8_LOOP_ISSUE_A
+#undef K8_LOOP_ISSUE_B
+#undef K8_MFMA_ON
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    K8_L_STAMP(3);
+
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if (kh == 1) {
+        float* red = lds + K_RED + wn * 4096 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            red[(mh * 16 + r) * 64] = acc[0][r];
+            red[((mh + 2) * 16 + r) * 64] = acc[1][r];
+        }
+    }
+    if (t < S_BM) { lds[K_BIAS + t] = bias_pre; lds[K_BIAS + 128 + t] = rsb_pre; }
+    __syncthreads();
+    if (kh == 0) {
+        const float* red = lds + K_RED + wn * 4096 + lane;
+        float* act = lds + K_ACT + wn * 2048 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const bool ok = mh * 32 + row < a.pairC;
+            float u0 = (acc[0][r] + red[(mh * 16 + r) * 64]) + lds[K_BIAS + mh * 32 + row];
+            float u1 = (acc[1][r] + red[((mh + 2) * 16 + r) * 64]) + lds[K_BIAS + 64 + mh * 32 + row];
+            if (a.addend) {                                  // uniform; columns >= L of a padded row are readable
+                const r_cgptr ad = (r_cgptr)a.addend + (size_t)b * a.addend_bstride + a.addend_pad + n;
+                const int c = min(mh * 32 + row, a.pairC - 1);
+                u0 += ad[(size_t)c * a.addend_ld];
+                u1 += ad[(size_t)(a.pairC + c) * a.addend_ld];
+            }
+            act[(mh * 16 + r) * 64] = ok ? s_fast_tanh(u0) * s_fast_sigmoid(u1) : 0.0f;
+        }
+    }
+    __syncthreads();                                         // partial accumulators consumed, gated tile published
+    K8_L_STAMP(4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<k_f32x4*>(lds + K_RED + t * 4 + k * 2048) = rsw[k];
+    float actv[2][16];
+    {
+        const float* act = lds + K_ACT + wn * 2048 + lane;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) actv[mt][r] = act[(mt * 16 + r) * 64];
+    }
+    __syncthreads();
+    // res/skip GEMM on the gated tile: this wave's row tile jt over all 64 channels
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.0f;
+#pragma unroll
+    for (int s2 = 0; s2 < 32; ++s2) {
+        const int r = s2 & 15;
+        const int ch = (s2 >> 4) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[K_RED + ch * 128 + jt * 32 + l31], actv[s2 >> 4][r], acc2, 0, 0, 0);
+    }
+    K8_L_STAMP(5);
+    const float* rbias = lds + K_BIAS + 128;
+    {
+        const int rbase = jt * 32;
+        if (rbase < a.rs_rows && n < a.L) {
+            const bool second = rbase >= a.split;
+            const r_gptr dst = (r_gptr)(second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride);
+            const int rdst = second ? rbase - a.split : rbase;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const float v = acc2[r] + rbias[rbase + row] + old[r];
+                if (rbase + row < a.rs_rows) *(dst + (size_t)(rdst + row) * a.dst_ld + a.dst_pad + n) = v;
+            }
+        }
+    }
+    S_STAMP_DRAIN(7);
+}
+
+template <int SEGS>
+__global__ __launch_bounds__(512) void conv_gemm_f32_gate_rs_splitk8_kernel(const GemmArgs a, const int ntiles_s) {
+    CTTS_WARM_KERNARGS(GemmArgs);
+    gate_rs_splitk8_tile<SEGS>(a, blockIdx.x % ntiles_s, blockIdx.x / ntiles_s);
+}
+
 // ---- WaveFlow row step as ONE launch: the fused layers of a row free-run through a work queue ---------------------------
 //   A row of the WaveFlow recurrence is n_layers dependent fused layers; launched one by one, every layer
 // waits for the slowest workgroup of the one before it, although tile t of layer i + 1 only needs tiles t - 1, t, t + 1 of
@@ -1429,20 +1751,25 @@ int launch_gemm_f32_small(int epi, const GemmArgs& a, hipStream_t stream) {
         const long long nblk = (long long)nt * a.batch;
         CTTS_CHECK_ARG(nblk > 0 && nblk < (1ll << 31), "gemm (split-K fused shape): grid %lld", nblk);
         constexpr size_t LDS = K_LDS_FLOATS * sizeof(float);         // above the 64 KiB default: opt in once per kernel
-        const int vi = a.nseg <= 4 ? 0 : 1;
+        const bool w8 = !tuning().f32_splitk_w4;                     // eight waves per tile (two per SIMD), CTTS_F32_SPLITK_W4: four
+        const int vi = (a.nseg <= 4 ? 0 : 1) + (w8 ? 2 : 0);
+        const void* fns[4] = {reinterpret_cast<const void*>(conv_gemm_f32_gate_rs_splitk_kernel<4>),
+                              reinterpret_cast<const void*>(conv_gemm_f32_gate_rs_splitk_kernel<GEMM_MAX_SEG>),
+                              reinterpret_cast<const void*>(conv_gemm_f32_gate_rs_splitk8_kernel<4>),
+                              reinterpret_cast<const void*>(conv_gemm_f32_gate_rs_splitk8_kernel<GEMM_MAX_SEG>)};
         {   // once per process and kernel (one process per GPU); a failure is reported by every call that meets it
             static std::mutex mu;
-            static bool attr_set[2] = {false, false};
+            static bool attr_set[4] = {false, false, false, false};
             std::lock_guard<std::mutex> lk(mu);
             if (!attr_set[vi]) {
-                const void* fn = vi == 0 ? reinterpret_cast<const void*>(conv_gemm_f32_gate_rs_splitk_kernel<4>)
-                                         : reinterpret_cast<const void*>(conv_gemm_f32_gate_rs_splitk_kernel<GEMM_MAX_SEG>);
-                CTTS_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+                CTTS_CHECK_HIP(hipFuncSetAttribute(fns[vi], hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
                 attr_set[vi] = true;
             }
         }
         if (vi == 0) hipLaunchKernelGGL((conv_gemm_f32_gate_rs_splitk_kernel<4>), dim3((unsigned)nblk), dim3(256), LDS, stream, a, nt);
-        else hipLaunchKernelGGL((conv_gemm_f32_gate_rs_splitk_kernel<GEMM_MAX_SEG>), dim3((unsigned)nblk), dim3(256), LDS, stream, a, nt);
+        else if (vi == 1) hipLaunchKernelGGL((conv_gemm_f32_gate_rs_splitk_kernel<GEMM_MAX_SEG>), dim3((unsigned)nblk), dim3(256), LDS, stream, a, nt);
+        else if (vi == 2) hipLaunchKernelGGL((conv_gemm_f32_gate_rs_splitk8_kernel<4>), dim3((unsigned)nblk), dim3(512), LDS, stream, a, nt);
+        else hipLaunchKernelGGL((conv_gemm_f32_gate_rs_splitk8_kernel<GEMM_MAX_SEG>), dim3((unsigned)nblk), dim3(512), LDS, stream, a, nt);
         note_gemm_loop(16 | 32);                                     // fp32 MFMA whatever the mode (see cookietts_hip.h)
         CTTS_CHECK_LAUNCH("conv_gemm_f32_gate_rs_splitk");
         return CTTS_OK;

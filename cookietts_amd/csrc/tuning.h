@@ -13,6 +13,7 @@ struct Tuning {
     bool f32_no_small;     // CTTS_F32_NO_SMALL: never the 128 x 64 small-problem shape (gemm_f32_small.hip)
     bool f32_force_small;  // CTTS_F32_FORCE_SMALL: the small shape whenever it applies, whatever the grid size (A/B, tests)
     bool f32_no_splitk;    // CTTS_F32_NO_SPLITK: never the split-K shape of the fused WaveFlow layer (batch 1-2)
+    bool f32_splitk_w4;    // CTTS_F32_SPLITK_W4: the split-K shape's per-layer launches on four waves per tile (the form before round 5), not eight
     bool f32_no_round_split;  // CTTS_F32_NO_ROUND_SPLIT: never peel the tiles beyond the last whole round of workgroups off a large-shape launch
     bool no_xcd_pair;      // CTTS_GEMM_NO_XCD_PAIR: plain block id -> tile mapping
     bool bf16_no_glds;     // CTTS_BF16_NO_GLDS

@@ -7,7 +7,9 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DCTTS_SMALL_GEMM_STAMPS -I include -I cookietts_amd/csrc \
 //       scripts/micro/wf_splitk_timeline.hip -o /tmp/wf_splitk_timeline && /tmp/wf_splitk_timeline
 // Variants of the main loop (timing only, results garbage): -DCTTS_EXP_NO_MFMA (no matrix work), -DCTTS_EXP_NO_DMA (stages
-// never re-filled), -DCTTS_EXP_NO_LDSREAD (operands stay in registers).  profiles/r4_19_wf_splitk_timeline.txt.
+// never re-filled), -DCTTS_EXP_NO_LDSREAD (operands stay in registers) - these three act on the FOUR-wave tile (run with W4=1).
+// Default: the eight-wave tile of round 5 (two waves per SIMD); W4=1 in the environment: the four-wave tile.
+// profiles/r4_19_wf_splitk_timeline.txt, r5_21, r5_31.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -21,7 +23,7 @@
 namespace ctts {
 // the symbols the kernel file takes from the rest of the library
 void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
-Tuning tuning() { return Tuning{}; }
+Tuning tuning() { Tuning t{}; t.f32_splitk_w4 = getenv("W4") != nullptr; return t; }   // W4=1: the four-wave tile (the form before round 5)
 void reload_tuning() {}
 bool gemm_mode_is_split(int) { return false; }
 int gemm_split_level(int) { return 0; }
@@ -86,7 +88,7 @@ int main() {
         CK(hipEventRecord(e1, st));
         CK(hipStreamSynchronize(st));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        printf("rep %d: %d fused layers, %.1f us per layer (%d workgroups)\n", rep, layers, ms * 1000 / layers, blocks);
+        printf("rep %d: %d fused layers, %.1f us per layer (%d workgroups of %s waves)\n", rep, layers, ms * 1000 / layers, blocks, getenv("W4") ? "four" : "eight");
     }
     std::vector<unsigned long long> h((size_t)blocks * 8);
     CK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
@@ -94,7 +96,11 @@ int main() {
     for (int i = 0; i < blocks; ++i) { t0 = std::min(t0, h[i * 8]); tend = std::max(tend, h[i * 8 + 7]); }
     printf("last launch: first entry -> last store ack %.2f us\n", (tend - t0) / 100.0);
     const int slot[7] = {0, 1, 2, 3, 4, 5, 7};
+#ifdef CTTS_PROLOGUE_STAMPS   /* eight-wave tile only: slots 1-5 inside the prologue */
+    const char* phase[7] = {"entry skew", "table entry math + A requests", "epilogue operand requests", "table written + barrier", "B requests issued", "first pair lands + barrier", "everything else"};
+#else
     const char* phase[7] = {"entry skew", "tables + requests", "first pair lands", "main loop (18 pairs)", "reduce + gate", "second GEMM", "stores + ack"};
+#endif
     for (int k = 0; k < 7; ++k) {
         std::vector<double> v;
         for (int i = 0; i < blocks; ++i) {
