@@ -1331,6 +1331,9 @@ __device__ __forceinline__ void gate_rs_splitk8_tile(const GemmArgs& a, const in
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     K8_L_STAMP(2); K8_P_STAMP(5);
+#ifdef CTTS_CLOCK_STAMPS        /* scripts/micro/wf_splitk_timeline.hip: slot 6 = shader-clock cycles of the main loop (s_memtime) */
+    const unsigned long long clk0_ = __builtin_readcyclecounter();
+#endif
 
     f32x16 acc[2];                                           // accumulator tiles mh, mh + 2
 #pragma unroll
@@ -1398,8 +1401,10 @@ __device__ __forceinline__ void gate_rs_splitk8_tile(const GemmArgs& a, const in
         __builtin_amdgcn_sched_barrier(0);
         K8_READ_AT(7, aa, ba) K8_WAIT(2, 6) K8_MFMA(6)
         __builtin_amdgcn_sched_barrier(0);
+#ifndef CTTS_EXP_NO_BARRIER   /* scripts/micro/wf_splitk_timeline.hip only: the loop without its per-pair synchronisation */
         asm volatile("s_waitcnt vmcnt(3)" ::: "memory");    // pair i + 1 landed, the newest still in flight
         __builtin_amdgcn_s_barrier();
+#endif
         __builtin_amdgcn_sched_barrier(0);
         K8_READ_AT(0, an, bn)
         K8_WAIT(2, 7) K8_MFMA(7)
@@ -1418,6 +1423,9 @@ __device__ __forceinline__ void gate_rs_splitk8_tile(const GemmArgs& a, const in
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     K8_L_STAMP(3);
+#ifdef CTTS_CLOCK_STAMPS
+    if (threadIdx.x == 0) g_small_stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_readcyclecounter() - clk0_;
+#endif
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     if (kh == 1) {

@@ -607,11 +607,12 @@ constexpr int WF_TILE = 256;          // columns per region unit: every launch s
 #define WF_NBIG 2                     // big regions per layer (2: A | M | B on three streams)
 #endif
 constexpr int WF_NREG = 2 * WF_NBIG - 1;     // regions incl. the one-tile separators: big 0, sep 0, big 1, sep 1, ...
-// The row queue is taken from this many 128-column items per layer on.  Below, a layer is one wave's serial chain however it is
-// launched (config 4, batch 1 = 113 items: 37.2 ms per call per layer, 38.3 queued); at batch 2 (226 items) the whole-flow queue
-// is 2 % ahead (56.9 against 58.3 ms).
+// The row queue is taken from this many 128-column items per layer on: where the per-layer launches stop being the eight-wave
+// split-K tile (gemm_f32_small.hip gate_rs_splitk8_tile, up to GATE_RS_SPLITK_MAX_BLOCKS = 256 items).  Config 4, round 5: batch 1
+// (113 items) 30.9 ms per layer against 40.6 queued; batch 2 (226 items) 52.0 against 55.7 (until the eight-wave tile the queue was
+// 2 % ahead there: 56.9 against 58.3 ms, and the bound was 200); batch 3 (339 items) 74.4 queued against 92.9.
 #ifndef WF_ROW_QUEUE_MIN_ITEMS
-#define WF_ROW_QUEUE_MIN_ITEMS 200
+#define WF_ROW_QUEUE_MIN_ITEMS 257
 #endif
 #ifndef WF_ROW_QUEUE_MAX_ITEMS
 #define WF_ROW_QUEUE_MAX_ITEMS 1250

@@ -113,5 +113,12 @@ int main() {
         printf("    %-22s mean %6.2f  min %6.2f  median %6.2f  p90 %6.2f  max %6.2f us\n", phase[k], sum / v.size(), v.front(),
                v[v.size() / 2], v[v.size() * 9 / 10], v.back());
     }
+#ifdef CTTS_CLOCK_STAMPS
+    {
+        double cyc = 0, us = 0;
+        for (int i = 0; i < blocks; ++i) { cyc += (double)h[i * 8 + 6]; us += (h[i * 8 + 3] - h[i * 8 + 2]) / 100.0; }
+        printf("main loop: %.0f shader-clock cycles in %.2f us = %.3f GHz (mean over workgroups)\n", cyc / blocks, us / blocks, cyc / us / 1000.0);
+    }
+#endif
     return 0;
 }

@@ -111,7 +111,8 @@ def test_waveflow_fused_layer_small_shapes(hip_lib_path, tuning, name):
     """The fused WaveFlow layer (GATE_RS: dilated 2-D conv GEMM + gate + res/skip GEMM in one launch) in its three shapes:
     the 128 x 128 shape (128 x 32 wave tiles) is BIT-IDENTICAL to the 128 x 256 one; the split-K shape (128 x 64 blocks,
     the K halves on wave pairs: the default at this size) sums (even chunks) + (odd chunks) and agrees to fp32 summation
-    noise; every shape meets the reference golden."""
+    noise - its eight-wave form (the default of the per-layer launches) and its four-wave form (the row queue's items) are
+    bit-identical; every shape meets the reference golden."""
     from cookietts_amd import WaveFlow
     g = np.load(os.path.join(GOLDEN, f"waveflow_{name}.npz"))
     cfg = synthetic.WAVEFLOW_CONFIGS[str(g["config_key"])]
@@ -120,6 +121,9 @@ def test_waveflow_fused_layer_small_shapes(hip_lib_path, tuning, name):
     m = m.cuda().eval()
     z, mel = torch.from_numpy(g["z"]).cuda(), torch.from_numpy(np.pad(g["mel"], ((0, 0), (0, 0), (0, 1)))).cuda()
     splitk, _ = m.inverse(z, mel, return_CPU=False)
+    tuning.set("CTTS_F32_SPLITK_W4")                        # four waves per split-K tile (until round 5) instead of eight: same sums
+    assert torch.equal(splitk, m.inverse(z, mel, return_CPU=False)[0])
+    tuning.clear("CTTS_F32_SPLITK_W4")
     tuning.set("CTTS_F32_NO_SPLITK")
     small, _ = m.inverse(z, mel, return_CPU=False)
     tuning.set("CTTS_F32_NO_SMALL")
