@@ -287,24 +287,16 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
         S_ISSUE_A(1, c1, 0); S_ISSUE_A(1, c1, 1); S_ISSUE_B_AT(1, reinterpret_cast<unsigned long long>(c1p));
     }
 
-    // segment table -> LDS (a dynamically indexed kernarg struct would be copied to scratch), then chunk -> B address
-#pragma unroll
-    for (int sidx = 0; sidx < GEMM_MAX_SEG; ++sidx) {
-        if (sidx < SEGS && t == sidx) {
-            const GemmSeg& g = a.seg[sidx];
-            unsigned int* e = reinterpret_cast<unsigned int*>(lds + S_SEGTAB + sidx * 4);
-            if (sidx < a.nseg) {
-                const float* base = g.base + (size_t)b * g.bstride + (size_t)(mb * g.mb_rows) * a.ld + (a.pad + n0 + g.shift);
-                const unsigned long long u = reinterpret_cast<unsigned long long>(base);
-                e[0] = (unsigned int)u; e[1] = (unsigned int)(u >> 32); e[2] = (unsigned int)g.nch;
-            } else {
-                e[0] = 0; e[1] = 0; e[2] = 0x7fffffffu;
-            }
-            e[3] = 0;
-        }
-    }
-    __syncthreads();
+    // chunk -> B address table, ONE barrier (round 5; until then: a segment table written by twelve serial branches, a barrier,
+    // the chunk table through LDS reads of it, a barrier - 2.5 us, profiles/r5_32): every thread below nch_total finds the
+    // segment of its chunk from the (uniform) chunk counts and reads that segment's base / batch stride / shift / row offset
+    // with one lane-indexed load from the kernarg segment (the GemmArgs struct is the kernel's first parameter)
     {
+        typedef const __attribute__((address_space(4))) char* s_kargp;
+        const s_kargp kp = (s_kargp)__builtin_amdgcn_kernarg_segment_ptr();
+        int nchs[SEGS];
+#pragma unroll
+        for (int k = 0; k < SEGS; ++k) nchs[k] = k < a.nseg ? a.seg[k].nch : 0x7fffffff;
         unsigned long long* tab = reinterpret_cast<unsigned long long*>(lds + S_CHTAB);
         const int ilv0 = a.interleave > 1 ? a.interleave : 0;
         const int n_il = ilv0 * a.seg[0].nch;
@@ -316,15 +308,18 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
             } else {
                 c -= n_il;
                 sg = ilv0;
-                for (int k = 0; k < SEGS - 1; ++k) {                 // sequential walk over the non-interleaved segments
-                    const int nck = (int)reinterpret_cast<const unsigned int*>(lds + S_SEGTAB + k * 4)[2];
-                    if (sg == k && k < a.nseg - 1 && c >= nck) { c -= nck; sg = k + 1; }
-                }
+#pragma unroll
+                for (int k = 0; k < SEGS - 1; ++k)                   // sequential walk over the non-interleaved segments
+                    if (sg == k && k < a.nseg - 1 && c >= nchs[k]) { c -= nchs[k]; sg = k + 1; }
                 loc = c;
             }
-            const unsigned int* e = reinterpret_cast<const unsigned int*>(lds + S_SEGTAB + sg * 4);
-            const unsigned long long base = ((unsigned long long)e[1] << 32) | e[0];
-            tab[c0] = base + (unsigned long long)loc * GEMM_KC * a.ld * sizeof(float);
+            const s_kargp sp = kp + (offsetof(GemmArgs, seg) + (size_t)sg * sizeof(GemmSeg));
+            const unsigned long long sbase = *reinterpret_cast<const __attribute__((address_space(4))) unsigned long long*>(sp + offsetof(GemmSeg, base));
+            const long long sbstr = *reinterpret_cast<const __attribute__((address_space(4))) long long*>(sp + offsetof(GemmSeg, bstride));
+            const int sshift = *reinterpret_cast<const __attribute__((address_space(4))) int*>(sp + offsetof(GemmSeg, shift));
+            const int smbr = *reinterpret_cast<const __attribute__((address_space(4))) int*>(sp + offsetof(GemmSeg, mb_rows));
+            tab[c0] = sbase + (unsigned long long)(((long long)b * sbstr + (long long)(mb * smbr) * a.ld + (a.pad + n0 + sshift) +
+                                                    (long long)loc * GEMM_KC * a.ld) * 4);
         }
     }
     __syncthreads();
