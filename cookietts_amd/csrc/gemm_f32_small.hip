@@ -74,7 +74,9 @@ typedef const __attribute__((address_space(1))) char* gbyte_ptr;
 // A launch of these kernels starts with a cold scalar cache and a 600-byte argument struct that the prologue reads field by
 // field: five to six DEPENDENT s_load batches, each a miss (~0.5 us), before the first operand request goes out (3.6 of a
 // 37 us batch-1 WaveFlow layer: profiles/r5_31).  Touching one dword of every 64-byte line of the kernarg segment at entry
-// turns them into one parallel miss; the later loads hit.  The value is kept alive until the caller consumes it.
+// turns them into one parallel miss; the later loads hit.
+// (hipcc emits them as two batches, each ahead of a first use; a hand-written block of all ten loads does not come out earlier -
+// the kernel's own argument loads are hoisted above it - so the plain form stays.)
 template <int BYTES>
 __device__ __forceinline__ unsigned warm_kernargs() {
     const unsigned __attribute__((address_space(4)))* kp =
@@ -553,6 +555,12 @@ static_assert(64 * 128 + 128 <= S_NST * R_STAGE, "the res/skip weights are stage
 // counted LDS waits of the main loop)
 typedef __attribute__((address_space(1))) float* r_gptr;
 typedef const __attribute__((address_space(1))) float* r_cgptr;
+// uniform base + 32-bit BYTE offset per lane: global_load / global_store v, v, s[a:b] (an index that is scaled by 4 after the
+// zero-extension is 64-bit math per lane again)
+typedef const __attribute__((address_space(1))) char* r_cbptr;
+typedef __attribute__((address_space(1))) char* r_bptr;
+__device__ __forceinline__ float r_load_u(r_cgptr base, unsigned byte_off) { return *(r_cgptr)((r_cbptr)base + byte_off); }
+__device__ __forceinline__ void r_store_u(r_gptr base, unsigned byte_off, float v) { *(r_gptr)((r_bptr)base + byte_off) = v; }
 __device__ __forceinline__ float r_load_old(r_cgptr p, bool fresh) {
     return fresh ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
 }
@@ -1191,8 +1199,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_gate_rs_splitk_kernel(co
 // ---- the split-K tile on EIGHT waves (round 5; per-layer launches only, i.e. batch 1) ------------------------------------
 // At batch 1 the tile above runs ONE wave per SIMD on 226 CUs: nobody covers a wave's LDS reads, DMA issue and barrier waits, and
 // the main loop takes 27.5 us for 20 us of matrix work (profiles/r5_21).  Same 128 x 64 tile, same stages, same K order, but
-// waves (wn, kh, mh): wave mh of a (column tile, K half) owns the accumulator tiles mh and mh + 2 - the tanh rows and the sigmoid
-// rows of channels 32 mh .. 32 mh + 31 - so a SIMD holds two waves (s and s + 4: the same K half, the two channel halves) whose
+// waves (wn, mh, kh): wave mh of a (column tile, K half) owns the accumulator tiles mh and mh + 2 - the tanh rows and the sigmoid
+// rows of channels 32 mh .. 32 mh + 31 - so a SIMD holds two waves (s and s + 4: the two K halves of one channel half) whose
 // stalls overlap with each other's MFMAs.  Per pair and wave: one A piece of the even chunk, one of the odd chunk, one B piece
 // (waves 0-3: the even chunk's, waves 4-7: the odd chunk's).  Epilogue: the kh = 1 partial sums meet the kh = 0 ones through LDS
 // as before, four waves gate (32 channels x 32 columns each), every wave takes ONE 32-row tile of the res/skip GEMM over all 64
@@ -1212,7 +1220,10 @@ __device__ __forceinline__ void gate_rs_splitk8_tile(const GemmArgs& a, const in
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wn = wave & 1, kh = (wave >> 1) & 1, mh = wave >> 2;
+    // waves w and w + 4 share a SIMD: they are the two K HALVES of one (column tile, channel half), so that in the epilogue the four
+    // gating waves (kh = 0) sit on four different SIMDs (with the channel halves on a SIMD instead, two SIMDs gated and two idled)
+    const int wn = wave & 1, mh = (wave >> 1) & 1, kh = wave >> 2;
+    const int bp = wave >> 2;                                // B pieces: waves 0-3 request the even chunk of a pair, 4-7 the odd one
     const int l31 = lane & 31, lhi = lane >> 5;
     const int n0 = tile * K_BN;
     const int n = n0 + wn * 32 + l31;
@@ -1295,10 +1306,13 @@ __device__ __forceinline__ void gate_rs_splitk8_tile(const GemmArgs& a, const in
         const int accum = second ? a.acc1 : a.acc0;
         const int rdst = second ? rbase - a.split : rbase;
         if (accum && rbase < a.rs_rows) {
-            const r_cgptr sp = src + (size_t)rdst * a.dst_ld + a.dst_pad + min(n, a.L - 1);
+            // a wave-uniform base + 32-bit lane offsets (global_load_dword v, v, s[a:b]): the 64-bit per-lane address math of the
+            // plain form was most of the 0.9 us this block took (profiles/r5_33)
+            const r_cgptr sp = src + (size_t)rdst * a.dst_ld + a.dst_pad;
             const int rlast = a.rs_rows - 1 - rbase;
+            const unsigned col = (unsigned)min(n, a.L - 1), dld = (unsigned)a.dst_ld;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) old[r] = r_load_old(sp + (size_t)min((r & 3) + 8 * (r >> 2) + 4 * lhi, rlast) * a.dst_ld, false);
+            for (int r = 0; r < 16; ++r) old[r] = r_load_u(sp, ((unsigned)min((r & 3) + 8 * (r >> 2) + 4 * lhi, rlast) * dld + col) * 4u);
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) old[r] = 0.0f;
@@ -1320,7 +1334,7 @@ __device__ __forceinline__ void gate_rs_splitk8_tile(const GemmArgs& a, const in
     K8_P_STAMP(3);
     const unsigned long long* ctab = reinterpret_cast<const unsigned long long*>(lds + K_CHTAB);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) K8_ISSUE_B(2 * j + mh, ctab[min(2 * j + mh, nch - 1)]);
+    for (int j = 0; j < 2; ++j) K8_ISSUE_B(2 * j + bp, ctab[min(2 * j + bp, nch - 1)]);
     K8_L_STAMP(1); K8_P_STAMP(4);
     asm volatile("s_waitcnt vmcnt(1)" ::: "memory");         // pair 0 landed: everything but this wave's B piece of pair 1
     __builtin_amdgcn_s_barrier();
@@ -1336,20 +1350,25 @@ __device__ __forceinline__ void gate_rs_splitk8_tile(const GemmArgs& a, const in
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
+    // hand-scheduled loop over PAIRS: per k-step ONE ds_read2st64_b32 for the two A fragments (tiles mh, mh + 2), per TWO k-steps
+    // one for the B values of both (rows 2 ks + lhi and 2 ks + 2 + lhi of the [16][64] stage are 128 floats apart): 12 LDS
+    // instructions per chunk and wave; counted lgkmcnt waits (LDS operations complete in order)
     typedef float k_f32x2 __attribute__((ext_vector_type(2)));
-    k_f32x2 a2[2];
-    float bq[2];
+    k_f32x2 a2[2], bq2[2];
     const unsigned a_lane = lds0 + (unsigned)((kh * K_CHUNK + lhi * S_BM + mh * 32 + l31) * 4);
     const unsigned b_lane = lds0 + (unsigned)((kh * K_CHUNK + S_ASTAGE + lhi * K_BN + wn * 32 + l31) * 4);
-#define K8_READ_AT(ks, aaddr, baddr)                                                                             \
-    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(a2[(ks) & 1]) : "v"(aaddr), "n"(4 * (ks)), "n"(4 * (ks) + 1)); \
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bq[(ks) & 1]) : "v"(baddr), "n"(2 * (ks) * K_BN * 4));
-#define K8_WAIT(n_, ks) asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(a2[(ks) & 1]), "+v"(bq[(ks) & 1]));
+#define K8_RA(ks, aaddr) \
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(a2[(ks) & 1]) : "v"(aaddr), "n"(4 * (ks)), "n"(4 * (ks) + 1));
+#define K8_RB(jj, baddr) \
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(bq2[(jj) & 1]) : "v"(baddr), "n"(4 * (jj)), "n"(4 * (jj) + 2));
+#define K8_WAIT(n_, ks) asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(a2[(ks) & 1]), "+v"(bq2[((ks) >> 1) & 1]));
 #ifdef CTTS_EXP_NO_LDSREAD    /* scripts/micro/wf_splitk_timeline.hip only (as in the four-wave tile) */
-#undef K8_READ_AT
+#undef K8_RA
+#undef K8_RB
 #undef K8_WAIT
-#define K8_READ_AT(ks, aaddr, baddr)
-#define K8_WAIT(n_, ks) asm volatile("" : "+v"(a2[(ks) & 1]), "+v"(bq[(ks) & 1]));
+#define K8_RA(ks, aaddr)
+#define K8_RB(jj, baddr)
+#define K8_WAIT(n_, ks) asm volatile("" : "+v"(a2[(ks) & 1]), "+v"(bq2[((ks) >> 1) & 1]));
 #endif
 #ifdef CTTS_EXP_NO_MFMA
 #define K8_MFMA_ON false
@@ -1357,11 +1376,11 @@ __device__ __forceinline__ void gate_rs_splitk8_tile(const GemmArgs& a, const in
 #define K8_MFMA_ON true
 #endif
 #define K8_MFMA(ks)                                                                                              \
-    if (K8_MFMA_ON && active) {                                                                                                \
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[(ks) & 1][0], bq[(ks) & 1], acc[0], 0, 0, 0);            \
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[(ks) & 1][1], bq[(ks) & 1], acc[1], 0, 0, 0);            \
+    if (K8_MFMA_ON && active) {                                                                                  \
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[(ks) & 1][0], bq2[((ks) >> 1) & 1][(ks) & 1], acc[0], 0, 0, 0); \
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[(ks) & 1][1], bq2[((ks) >> 1) & 1][(ks) & 1], acc[1], 0, 0, 0); \
     }
-    K8_READ_AT(0, a_lane, b_lane)
+    K8_RA(0, a_lane) K8_RB(0, b_lane)
     int cur = 0;
     for (int i = 0; i < npairs; ++i) {
         const bool active = 2 * i + kh < nch;               // an odd chunk count leaves the last pair's odd half empty
@@ -1371,8 +1390,7 @@ __device__ __forceinline__ void gate_rs_splitk8_tile(const GemmArgs& a, const in
         const int nb = cur >= 1 ? cur - 1 : 2;              // (cur + 2) % 3: the stage pair i - 1 occupied
         const int ne = min(2 * (i + 2), nch - 1), no = min(2 * (i + 2) + 1, nch - 1);
         unsigned long long ub;
-        asm volatile("ds_read_b64 %0, %1" : "=v"(ub) : "v"((unsigned)(lds0 + K_CHTAB * 4 + (mh ? no : ne) * 8)));
-        // outstanding: k-step 0 (2 instructions) and the table entry
+        asm volatile("ds_read_b64 %0, %1" : "=v"(ub) : "v"((unsigned)(lds0 + K_CHTAB * 4 + (bp ? no : ne) * 8)));
 #ifdef CTTS_EXP_NO_DMA
 #define K8_LOOP_ISSUE_A(cs, c)
 #define K8_LOOP_ISSUE_B(cs, ub)
@@ -1380,34 +1398,36 @@ __device__ __forceinline__ void gate_rs_splitk8_tile(const GemmArgs& a, const in
 #define K8_LOOP_ISSUE_A(cs, c) K8_ISSUE_A(cs, c)
 #define K8_LOOP_ISSUE_B(cs, ub) K8_ISSUE_B(cs, ub)
 #endif
-        K8_READ_AT(1, aa, ba) K8_WAIT(3, 0) K8_MFMA(0) K8_LOOP_ISSUE_A(2 * nb, ne);
+        // outstanding before every wait, oldest first (RAk: A of k-step k, BQj: B of k-steps 2 j, 2 j + 1, T: the table entry)
+        K8_RA(1, aa) K8_WAIT(2, 0) K8_MFMA(0) K8_LOOP_ISSUE_A(2 * nb, ne);                       // RA0 BQ0 | T RA1
         __builtin_amdgcn_sched_barrier(0);
-        K8_READ_AT(2, aa, ba) K8_WAIT(2, 1)                 // (covers the table entry)
+        K8_RA(2, aa) K8_RB(1, ba) K8_WAIT(2, 1)                                                  // T RA1 | RA2 BQ1
         asm volatile("" : "+v"(ub));
         K8_MFMA(1) K8_LOOP_ISSUE_A(2 * nb + 1, no);
         __builtin_amdgcn_sched_barrier(0);
-        K8_READ_AT(3, aa, ba) K8_WAIT(2, 2) K8_MFMA(2) K8_LOOP_ISSUE_B(2 * nb + mh, ub);
+        K8_RA(3, aa) K8_WAIT(1, 2) K8_MFMA(2) K8_LOOP_ISSUE_B(2 * nb + bp, ub);                  // RA2 BQ1 | RA3
         __builtin_amdgcn_sched_barrier(0);
-        K8_READ_AT(4, aa, ba) K8_WAIT(2, 3) K8_MFMA(3)
+        K8_RA(4, aa) K8_RB(2, ba) K8_WAIT(2, 3) K8_MFMA(3)                                       // RA3 | RA4 BQ2
         __builtin_amdgcn_sched_barrier(0);
-        K8_READ_AT(5, aa, ba) K8_WAIT(2, 4) K8_MFMA(4)
+        K8_RA(5, aa) K8_WAIT(1, 4) K8_MFMA(4)                                                    // RA4 BQ2 | RA5
         __builtin_amdgcn_sched_barrier(0);
-        K8_READ_AT(6, aa, ba) K8_WAIT(2, 5) K8_MFMA(5)
+        K8_RA(6, aa) K8_RB(3, ba) K8_WAIT(2, 5) K8_MFMA(5)                                       // RA5 | RA6 BQ3
         __builtin_amdgcn_sched_barrier(0);
-        K8_READ_AT(7, aa, ba) K8_WAIT(2, 6) K8_MFMA(6)
+        K8_RA(7, aa) K8_WAIT(1, 6) K8_MFMA(6)                                                    // RA6 BQ3 | RA7
         __builtin_amdgcn_sched_barrier(0);
 #ifndef CTTS_EXP_NO_BARRIER   /* scripts/micro/wf_splitk_timeline.hip only: the loop without its per-pair synchronisation */
         asm volatile("s_waitcnt vmcnt(3)" ::: "memory");    // pair i + 1 landed, the newest still in flight
         __builtin_amdgcn_s_barrier();
 #endif
         __builtin_amdgcn_sched_barrier(0);
-        K8_READ_AT(0, an, bn)
-        K8_WAIT(2, 7) K8_MFMA(7)
+        K8_RA(0, an) K8_RB(0, bn)
+        K8_WAIT(2, 7) K8_MFMA(7)                                                                 // RA7 | RA0' BQ0'
         __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a2[0]), "+v"(bq[0]));
-#undef K8_READ_AT
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a2[0]), "+v"(bq2[0]));
+#undef K8_RA
+#undef K8_RB
 #undef K8_WAIT
 #undef K8_MFMA
 #undef K8_ISSUE_A
@@ -1480,13 +1500,15 @@ __device__ __forceinline__ void gate_rs_splitk8_tile(const GemmArgs& a, const in
         const int rbase = jt * 32;
         if (rbase < a.rs_rows && n < a.L) {
             const bool second = rbase >= a.split;
-            const r_gptr dst = (r_gptr)(second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride);
             const int rdst = second ? rbase - a.split : rbase;
+            const r_gptr dst = (r_gptr)(second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride) +
+                               ((size_t)rdst * a.dst_ld + a.dst_pad);
+            const unsigned dld = (unsigned)a.dst_ld;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 const float v = acc2[r] + rbias[rbase + row] + old[r];
-                if (rbase + row < a.rs_rows) *(dst + (size_t)(rdst + row) * a.dst_ld + a.dst_pad + n) = v;
+                if (rbase + row < a.rs_rows) r_store_u(dst, ((unsigned)row * dld + (unsigned)n) * 4u, v);
             }
         }
     }
