@@ -42,6 +42,11 @@ constexpr int S_MAX_CHUNKS = 384;                        // chunk -> B address t
 constexpr int S_NST = 3;
 // the fused WaveFlow layer takes the small shape below this many 128 x 256 blocks (set from the B = 1 / 2 / 8 measurements)
 constexpr long long SMALL_BELOW_LARGE_BLOCKS = 2048;      // generic shape: taken below this many 256 x 128 blocks
+// the same for the 128-row packing (128 x 256 blocks; WaveFlow above 64 channels, round 5): against the 1 x 4-wave 128 x 256 kernel the
+// small shape was ahead at every size measured (profiles/r5_44): batch 1, 88 blocks (20 groups, 128 channels) 240 -> 113 ms,
+// 72 blocks (50 groups, 256 channels) 1117 -> 534, 864 blocks (8 groups, 512 channels) 979 -> 854; 1728 blocks 1688 -> 1649;
+// 2592 blocks (8 groups, 128 channels, batch 12) 779 -> 711
+constexpr long long SMALL_BELOW_LARGE_BLOCKS_BM128 = 4096;
 constexpr long long GATE_RS_SMALL_BELOW_BLOCKS = 256;
 // ... and the split-K shape (128 x 64 blocks, K halves on wave pairs) up to this many 128 x 256 blocks (batch 1-2 of config 4)
 constexpr long long GATE_RS_SPLITK_MAX_BLOCKS = 128;
@@ -161,12 +166,16 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
 
     S_STAMP(0);
     S_STAMP_WHERE();
+    // 128-row slice `mbs` of the output rows: half `half` of M-block mb in the 256-row packing, or the whole M-block mbs of the
+    // 128-row packing (WaveFlow's GEMMs above 64 channels, round 5: at batch 1 their 128 x 256 launches were 44-176 blocks)
     int id = blockIdx.x;
-    const int mbs = id % (2 * a.MB);
-    id /= 2 * a.MB;
+    const bool bm128 = a.bm == 128;
+    const int nmb = bm128 ? a.MB : 2 * a.MB;
+    const int mbs = id % nmb;
+    id /= nmb;
     const int tile = id % ntiles_s;
     const int b = id / ntiles_s;
-    const int mb = mbs >> 1, half = mbs & 1;
+    const int mb = bm128 ? mbs : mbs >> 1, half = bm128 ? 0 : mbs & 1;
     const int n0 = tile * S_BN;
 
     // SPLIT-family epilogues add the destination's previous contents (x += res, skip += ...).  Nothing in this launch
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
         const int n = n0 + wn * 32 + l31;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            const int rbase = mb * 256 + 128 * half + 32 * wm + 64 * mt;
+            const int rbase = mbs * 128 + 32 * wm + 64 * mt;
             const bool second = rbase >= a.split;
             const float* dstc = second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride;
             const float* src = second ? dstc : (a.src0 ? a.src0 + (size_t)b * a.src0_bstride : dstc);
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
 #define S_LOAD_ADDEND()                                                                                          \
     do {                                                                                                         \
         const int n_ = n0 + wn * 32 + l31;                                                                       \
-        const int cb_ = (mb * 2 + half) * 64 + 32 * wm;                                                          \
+        const int cb_ = mbs * 64 + 32 * wm;                                                                      \
         if (a.addend && cb_ < a.pairC) {                                                                         \
             const int nc_ = min(n_, a.L - 1);               /* lanes past the last column re-read it (never stored) */ \
             int i0_ = nc_, i1_ = nc_;                                                                            \
@@ -240,8 +249,11 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
     // [wave * 256 + p * 1024, +256) of the [16][128] stage: k-row 2 wave + 8 p + (lane >> 5), columns 4 (lane & 31).
     // Every DMA address below is a wave-uniform 64-bit base + a 32-bit lane byte offset (CTTS_GLDS_U): the form
     // global_load_lds_dwordx4 v, s[a:b], which does not block the matrix pipe the way the 64-bit VGPR address form does.
-    const gbyte_ptr a_base = (gbyte_ptr)(a.A + ((size_t)mb * nalloc + a.a_ch_off) * (GEMM_KC * 256) + 128 * half + 2 * wave * 256);
-    const unsigned dma_a_lane = (unsigned)(((lane >> 5) * 256 + (lane & 31) * 4) * 4), dma_a_lane1 = dma_a_lane + 8 * 256 * 4;   // piece 0 / 1
+    // (128-row packing: the [16][128] chunk is contiguous - k-row stride 128 floats - and copied linearly)
+    const int a_ld = bm128 ? 128 : 256;                    // floats between the k-rows of a packed chunk
+    const unsigned a_cstride = (unsigned)(GEMM_KC * a_ld * 4);
+    const gbyte_ptr a_base = (gbyte_ptr)(a.A + ((size_t)mb * nalloc + a.a_ch_off) * (GEMM_KC * a_ld) + 128 * half + 2 * wave * a_ld);
+    const unsigned dma_a_lane = (unsigned)(((lane >> 5) * a_ld + (lane & 31) * 4) * 4), dma_a_lane1 = dma_a_lane + 8 * a_ld * 4;   // piece 0 / 1
     // B: [16][64] stage, this wave's piece = k-rows 4 wave .. +4: k-row 4 wave + (lane >> 4), columns 4 (lane & 15)
     const unsigned dma_b_lane = (unsigned)(((size_t)(4 * wave + (lane >> 4)) * a.ld + (lane & 15) * 4) * 4);
     const unsigned long long* ctab = reinterpret_cast<const unsigned long long*>(lds + S_CHTAB);
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
 #define S_ISSUE_A(buf, c, p)                                                                                     \
-    CTTS_GLDS_U(a_base + (size_t)(c) * (GEMM_KC * 256 * 4), (p) ? dma_a_lane1 : dma_a_lane,                       \
+    CTTS_GLDS_U(a_base + (size_t)(c) * a_cstride, (p) ? dma_a_lane1 : dma_a_lane,                                 \
                 (lds_fptr)(lds + (buf) * S_STAGE + wave * 256 + (p) * 1024), 0)
 #define S_ISSUE_B(buf, c)                                                                                        \
     do {                                                                                                         \
@@ -449,12 +461,12 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
     S_STAMP(3);
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    if (t < S_BM) lds[t] = a.bias[mb * 256 + 128 * half + t];
+    if (t < S_BM) lds[t] = a.bias[mbs * 128 + t];
     __syncthreads();
     const int n = n0 + wn * 32 + l31;
     if constexpr (PAIR) {
         float* dst = a.dst0 + (size_t)b * a.dst0_bstride;
-        const int cbase = (mb * 2 + half) * 64 + 32 * wm;
+        const int cbase = mbs * 64 + 32 * wm;
         if (cbase < a.pairC && n < a.L) {
             float add0[16], add1[16];
             if constexpr (HAS_ADDEND && !HOIST_ADDEND) S_LOAD_ADDEND();
@@ -504,7 +516,7 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_f32_small_kernel(const GemmA
         // rows < split -> dst0 (= src0 + v when acc0), rows >= split -> dst1[row - split] (+= when acc1)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            const int rbase = mb * 256 + 128 * half + 32 * wm + 64 * mt;     // uniform per tile
+            const int rbase = mbs * 128 + 32 * wm + 64 * mt;                 // uniform per tile
             if (rbase >= a.M) continue;
             const bool second = rbase >= a.split;
             float* dst = second ? a.dst1 + (size_t)b * a.dst1_bstride : a.dst0 + (size_t)b * a.dst0_bstride;
@@ -1759,7 +1771,7 @@ bool gemm_f32_small_applies(int epi, const GemmArgs& a) {
             return !tune.f32_no_splitk && gate_rs_blocks(a) <= GATE_RS_SPLITK_MAX_BLOCKS;
         return gate_rs_blocks(a) < GATE_RS_SMALL_BELOW_BLOCKS || tune.f32_force_small;
     }
-    if (a.bm != 256) return false;
+    if (a.bm != 256 && a.bm != 128) return false;
     if (!(epi == GEMM_EPI_SPLIT || epi == GEMM_EPI_GATE || epi == GEMM_EPI_GATEX || epi == GEMM_EPI_MAG || epi == GEMM_EPI_LOG ||
           epi == GEMM_EPI_LRELU || epi == GEMM_EPI_TANH))
         return false;
@@ -1767,7 +1779,9 @@ bool gemm_f32_small_applies(int epi, const GemmArgs& a) {
     // measured on the final tree (profiles/r3_30_shape_crossover.txt) - ax notebook B=8 (1472 large blocks) 332.9 -> 317.9 ms,
     // untts B=4 (1104) 254.8 -> 239.9, WaveGlow 12 x 512 at B=2 (1800) 219.7 -> 209.3 and B=1 113.2 -> 109.9; from B=3 (2700
     // blocks) on the large shape is ahead (303.5 vs 308.4 ms; headline B=8: 0.857 vs 0.783 of the MFMA peak)
-    return (long long)a.MB * a.ntiles * a.batch < SMALL_BELOW_LARGE_BLOCKS || tune.f32_force_small;
+    // (the 128-row packing - WaveFlow above 64 channels: bound measured in round 5, see the constant)
+    const long long below = a.bm == 128 ? SMALL_BELOW_LARGE_BLOCKS_BM128 : SMALL_BELOW_LARGE_BLOCKS;
+    return (long long)a.MB * a.ntiles * a.batch < below || tune.f32_force_small;
 }
 
 int launch_gemm_f32_small(int epi, const GemmArgs& a, hipStream_t stream) {
@@ -1810,7 +1824,7 @@ int launch_gemm_f32_small(int epi, const GemmArgs& a, hipStream_t stream) {
         return CTTS_OK;
     }
     const int ntiles_s = (a.L + S_BN - 1) / S_BN;
-    const long long blocks = 2ll * a.MB * ntiles_s * a.batch;
+    const long long blocks = (a.bm == 128 ? 1ll : 2ll) * a.MB * ntiles_s * a.batch;
     CTTS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "gemm (small shape): grid %lld", blocks);
     const dim3 grid((unsigned)blocks);
     switch (epi) {

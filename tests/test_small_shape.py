@@ -136,6 +136,29 @@ def test_waveflow_fused_layer_small_shapes(hip_lib_path, tuning, name):
     assert err < 1e-3 and err_sk < 1e-3 and d < 5e-6
 
 
+@pytest.mark.parametrize("name", ["table_g50_c128", "table_g20_c512", "table_g12_c256_sep"])
+def test_small_shape_on_the_128_row_packing_is_bit_identical(hip_lib_path, tuning, name):
+    """WaveFlow above 64 channels (the reference's published sweep: 128-512 channels at batch 1) runs its in-layer and res/skip
+    GEMMs unfused on the 128-row packing.  Since round 5 they take the 128 x 64 small shape too (their 128 x 256 launches were
+    44-176 blocks on 256 CUs): same chunk order, same MFMAs - bit-identical to the large shape, and inside the golden's bound."""
+    from cookietts_amd import WaveFlow, _lib
+    g = np.load(os.path.join(GOLDEN, f"waveflow_{name}.npz"))
+    cfg = synthetic.WAVEFLOW_CONFIGS[str(g["config_key"])]
+    m = WaveFlow(**cfg)
+    m.load_state_dict(synthetic.to_torch(synthetic.waveflow_state_dict(cfg, seed=int(g["seed"]))))
+    m = m.cuda().eval()
+    z, mel = torch.from_numpy(g["z"]).cuda(), torch.from_numpy(np.pad(g["mel"], ((0, 0), (0, 0), (0, 1)))).cuda()
+    small, _ = m.inverse(z, mel, return_CPU=False)
+    assert _lib.lib().ctts_last_gemm_loop() & 16, "the small shape did not run"
+    tuning.set("CTTS_F32_NO_SMALL")
+    big, _ = m.inverse(z, mel, return_CPU=False)
+    assert not (_lib.lib().ctts_last_gemm_loop() & 16)
+    assert torch.equal(small, big)
+    err = rms_rel_err(small.cpu().numpy(), g["inverse_full"])
+    print(f"waveflow {name}: small shape on the 128-row packing, rms rel err vs reference = {err:.3e}")
+    assert err < 1e-3
+
+
 def test_small_shape_in_split_bf16_mode_is_bit_identical(hip_lib_path, tuning):
     """The split-bf16 main loop (model.set_f32_gemm_mode('bf16x3')) in the small shape: same three products in the same
     order per chunk as the large shape, so bit-identical there too; and inside 1e-4 of the reference golden."""
