@@ -883,6 +883,7 @@ __device__ __forceinline__ void lstm_wave(const PdArgs& a, float* L, LstmLds& S,
         pd_segment<SIG, CELL_ATT, 0, 4>(w, lt, xP, lane, sl);
         pd_cells<SIG, CELL_ATT>(sl, (a.xb + a.g_atth) + (size_t)par * PD_NB * PD_RA, epoch, PD_RA, FA, lane);
         PD_STAMP(1);
+        PD_STAMP_LANE0(20 + wave);                                               // (debug build: when did EACH wave publish its att_h units)
         PD_GATHER(20, PD_RA, (a.xb + a.g_atth), X + XATT, 1u);
         PD_STAMP(2);
         if (fail) break;

@@ -54,3 +54,17 @@ print("compute between a gather and the next publish (mean over workgroups and s
       f"A {np.nanmean(col(L, 1) - col(L, 0)):.2f} | q {np.nanmean(col(slice(0, 192), 17) - col(slice(0, 192), 2)):.2f} | "
       f"attention post {np.nanmean(col(Aw, 5) - col(Aw, 2)):.2f} | C {np.nanmean(col(L, 13) - col(L, 4)):.2f} | "
       f"D {np.nanmean(col(L, 14) - col(L, 6)):.2f} | h1 {np.nanmean(col(L, 15) - col(L, 8)):.2f} | p {np.nanmean(col(L, 16) - col(L, 10)):.2f}")
+
+# per-wave att_h publish times relative to wave 0's (slots 20 + wave), and the latest wave of the whole chip relative to the last wave-0 publish
+pw = np.stack([col(L, 20 + w) for w in range(4)])                      # [wave][wg][step]
+print("att_h publish of wave w minus wave 0 of the same workgroup (mean / max over workgroups and steps): " +
+      " | ".join(f"w{w} {np.nanmean(pw[w] - pw[0]):.2f} / {np.nanmax(pw[w] - pw[0]):.2f}" for w in range(1, 4)))
+last_any = np.nanmax(pw, axis=(0, 1))
+print(f"last att_h publish of ANY wave after the last wave-0 publish: {np.nanmean(last_any - np.nanmax(col(L, 1), axis=0)):.2f} us; "
+      f"first consumer done after the last publish of any wave: {np.nanmean(np.nanmin(col(L, 2), axis=0) - last_any):.2f} us")
+for name, sl_ in (("class 0 (wg 0-19)", slice(0, 20)), ("class 1 (20-51)", slice(20, 52)), ("class 2 (52-95)", slice(52, 96)), ("class 3 (96-251)", slice(96, 252))):
+    print(f"  {name}: " + " | ".join(f"w{w} mean {np.nanmean((pw[w] - pw[0])[sl_]):.2f} max {np.nanmax((pw[w] - pw[0])[sl_]):.2f}" for w in range(1, 4)))
+late = pw[3] - pw[0]
+print("  wave 3 lateness by step (mean over workgroups), steps 8..23: " + " ".join(f"{v:.2f}" for v in np.nanmean(late, axis=0)[:16]))
+worst = np.unravel_index(np.nanargmax(late), late.shape)
+print(f"  worst: wg {worst[0]}, steady-state step index {worst[1]}; workgroups with wave-3 lateness > 1 us anywhere: {np.where(np.nanmax(late, axis=1) > 1.0)[0].tolist()[:40]}")
