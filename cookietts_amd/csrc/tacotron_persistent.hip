@@ -209,11 +209,12 @@ __device__ __forceinline__ void row_dots(const float* wrow, const float* xs, int
 
 struct AttnLds {
     __attribute__((aligned(16))) float pmw[PD_W * PD_AMAX];
-    float memw[PD_W * PD_DM];                     // the memory window (context operand), staged before the query arrives
+    __attribute__((aligned(16))) float memw[PD_W * PD_DM];   // the memory window (context operand), staged before the query arrives
     float loc[PD_W][PD_FMAX + 4];                 // rows 16-byte aligned: read as float4 broadcasts
     float wcat[2][PD_W + PD_KMAX - 1 + 1];
     float q[PD_AMAX];
-    float en[64], wts[64];
+    float en[64];
+    __attribute__((aligned(16))) float wts[64];   // read as float4 by the context pass
     float w[PD_TMAX], cum[PD_TMAX];
     float ctx[PD_DM];
     float pos;
@@ -405,22 +406,31 @@ __device__ __forceinline__ void pd_attention_post(const PdArgs& a, AttnLds& s, c
     }
     __syncthreads();
     PD_STAMP(4);
-    {   // context = sum_t w[t] * memory[t] out of the staged window: dimensions t and t + 256 per thread, two chains each
-        // (the same two-chain order per dimension as the one-dimension-per-thread form)
+    {   // context = sum_t w[t] * memory[t] out of the staged window: dimensions 2 t and 2 t + 1 per thread, two chains each (the
+        // same two-chain order per dimension as the one-dimension-per-thread form).  Round 5: adjacent dimensions (one 8-byte
+        // LDS read per window row instead of two 4-byte ones) and the 33 weights as nine 16-byte reads instead of 33 broadcasts:
+        // 42 LDS instructions per thread instead of 99 on the critical path between q and ctx.
+        float wreg[36];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const float4 w4 = *reinterpret_cast<const float4*>(&s.wts[4 * i]);
+            wreg[4 * i] = w4.x; wreg[4 * i + 1] = w4.y; wreg[4 * i + 2] = w4.z; wreg[4 * i + 3] = w4.w;
+        }
         float c0[2] = {0.f, 0.f}, c1[2] = {0.f, 0.f};
+        const float* mw = s.memw + 2 * t;
 #pragma unroll
         for (int tt = 0; tt + 1 < PD_W; tt += 2) {
-            const float w0 = tt < W ? s.wts[tt] : 0.f, w1 = tt + 1 < W ? s.wts[tt + 1] : 0.f;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                c0[k] = fmaf(w0, s.memw[tt * PD_DM + t + PD_T * k], c0[k]);
-                c1[k] = fmaf(w1, s.memw[(tt + 1) * PD_DM + t + PD_T * k], c1[k]);
-            }
+            const float w0 = tt < W ? wreg[tt] : 0.f, w1 = tt + 1 < W ? wreg[tt + 1] : 0.f;
+            const float2 m0 = *reinterpret_cast<const float2*>(mw + tt * PD_DM), m1 = *reinterpret_cast<const float2*>(mw + (tt + 1) * PD_DM);
+            c0[0] = fmaf(w0, m0.x, c0[0]); c0[1] = fmaf(w0, m0.y, c0[1]);
+            c1[0] = fmaf(w1, m1.x, c1[0]); c1[1] = fmaf(w1, m1.y, c1[1]);
         }
+        const float wl = PD_W - 1 < W ? wreg[PD_W - 1] : 0.f;
+        const float2 ml = *reinterpret_cast<const float2*>(mw + (PD_W - 1) * PD_DM);
+        c0[0] = fmaf(wl, ml.x, c0[0]); c0[1] = fmaf(wl, ml.y, c0[1]);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int d = t + PD_T * k;
-            c0[k] = fmaf(PD_W - 1 < W ? s.wts[PD_W - 1] : 0.f, s.memw[(PD_W - 1) * PD_DM + d], c0[k]);
+            const int d = 2 * t + k;
             const float c = c0[k] + c1[k];
             s.ctx[d] = c;
             publish(g_ctx, b * PD_DM + d, epoch, c);
@@ -642,13 +652,17 @@ __device__ __forceinline__ bool gather_x(const u64* g, float* dst, unsigned epoc
 }
 
 // sum of the 16 blocks: every lane ends with the total of its item (lane & 3).  Within a row of 16 lanes on the DPP
-// network (row_ror:4, row_ror:8), across the four rows through the LDS crossbar (xor 16, xor 32).
+// network (row_ror:4, row_ror:8); across the four rows with gfx950's v_permlane16_swap / v_permlane32_swap (round 5): with both
+// operands = v the swap leaves {even row, even row} in one and {odd row, odd row} in the other, so their sum is v + v[lane ^ 16]
+// (resp. ^ 32) in every lane - the same two additions as the ds_bpermute form it replaces (__shfl_xor: two LDS-crossbar round
+// trips per sum, in the tail of every phase), bit for bit (scripts/micro/permlane_swap_sum.hip).
 __device__ __forceinline__ float pd_block_sum(float v) {
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));     // row_ror:4
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));     // row_ror:8
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+    const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
 }
 
 #define PD_MFMA(acc, wv, xv) (acc) = __builtin_amdgcn_mfma_f32_4x4x1f32((wv), (xv), (acc), 0, 0, 0)
