@@ -29,6 +29,7 @@
 // timeout the workgroup records (code, workgroup, phase, step) in the control words and the whole grid drains.
 // Granule tags are zeroed by the host wrapper before EVERY launch; the control words are sticky.
 #include "tacotron_plan.h"
+#include "tuning.h"
 
 namespace ctts {
 namespace {
@@ -86,6 +87,7 @@ struct PdArgs {
     unsigned g_p, g_atth, g_q, g_ctx, g_dech, g_d2h, g_h1, ctl;                           // xb offsets (u64 words)
     u64* dbg;                   // optional [PD_WG][64 steps][PD_DBG_SLOTS] stamps of s_memrealtime (100 MHz), NULL = off
     int A, F, K, R, n_mel, T, batch, nbc, step0, n_steps, max_steps, pd_rows;   // nbc: batch rows the workspace holds
+    int dly[6];                 // s_sleep(1) units (64 cycles) before the FIRST poll of att_h, ctx, dec_h, d2_h, h1, p (see gather_x)
 };
 
 __device__ __forceinline__ float pd_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -582,7 +584,7 @@ struct PdSlotRt {          // runtime side of a slot
 typedef unsigned pd_u4 __attribute__((ext_vector_type(4)));
 constexpr int PD_AUX_SC1 = 16;
 template <int N>
-__device__ __forceinline__ bool gather_x(const u64* g, float* dst, unsigned epoch, unsigned* ctl, int t, unsigned phase, unsigned step) {
+__device__ __forceinline__ bool gather_x(const u64* g, float* dst, unsigned epoch, unsigned* ctl, int t, unsigned phase, unsigned step, int dly) {
     constexpr int PAIRS = 2 * N, PPT = (PAIRS + PD_T - 1) / PD_T;
     // pairs of a thread in flight during a full sweep: everything at once up to 6 (24 data registers), else rounds of 5
     // (att_h: 10 pairs per thread; all 10 at once spilt 70 weight registers)
@@ -603,6 +605,11 @@ __device__ __forceinline__ bool gather_x(const u64* g, float* dst, unsigned epoc
         // other three wait at the barrier: a quarter of the polling traffic of a 256-thread watch, and none of the
         // full-sweep traffic before the vector is (nearly) complete
         if (t < 64) {
+            // The first poll goes out `dly` x 64 cycles after this workgroup's own publish (round 5).  A vector cannot be complete
+            // before its slowest publisher is done - for att_h 1.6-2.0 us after the first ones (profiles/r5_53) - and every poll
+            // before that is traffic the publishers' write-through stores queue behind: with the first polls of att_h held back
+            // ~1.1 us and those of the prenet vector ~0.7 us the STEP went from 28.5 to 24.0 us (profiles/r5_59).
+            for (int i = 0; i < dly; ++i) __builtin_amdgcn_s_sleep(1);
             constexpr int NS = PPT > 6 ? PD_LIGHT_SAMPLES_BIG : 1;      // samples per lane
             for (unsigned spins = 0;; ++spins) {
                 bool ok = true;
@@ -872,7 +879,7 @@ __device__ __forceinline__ void lstm_wave(const PdArgs& a, float* L, LstmLds& S,
     bool fail = false;
 #define PD_GATHER(NPT, N, buf, dst, phase)                                                                          \
     do {                                                                                                               \
-        const bool ok_ = gather_x<N>((buf) + (size_t)par * (PD_NB * (N)), (dst), epoch, ctl, t, (phase), (unsigned)step); \
+        const bool ok_ = gather_x<N>((buf) + (size_t)par * (PD_NB * (N)), (dst), epoch, ctl, t, (phase), (unsigned)step, a.dly[(phase) == 1u ? 0 : (phase) - 2u]); \
         if (__syncthreads_or(ok_ ? 0 : 1)) { fail = true; }                                                            \
     } while (0)
 
@@ -1159,6 +1166,10 @@ int ctts_taco_decoder_steps_persistent_f32(const ctts_taco_decoder_config* cfg, 
     a.A = c.attention_dim; a.F = c.location_n_filters; a.K = c.location_kernel_size; a.R = c.window_range;
     a.n_mel = c.n_mel_channels; a.T = text_len; a.batch = batch; a.nbc = pad_batch(batch); a.step0 = step0; a.n_steps = n_steps;
     a.max_steps = max_steps; a.pd_rows = p.pd_rows;
+    {
+        const Tuning tune = tuning();
+        for (int i = 0; i < 6; ++i) a.dly[i] = tune.taco_poll_delay[i];
+    }
     a.dbg = reinterpret_cast<u64*>(g_pd_debug);
     if (a.dbg) hipLaunchKernelGGL(taco_persistent_kernel<true>, dim3(PD_WG), dim3(PD_T), 0, s, a);
     else hipLaunchKernelGGL(taco_persistent_kernel<false>, dim3(PD_WG), dim3(PD_T), 0, s, a);

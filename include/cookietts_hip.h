@@ -702,7 +702,7 @@ int ctts_set_f32_gemm_mode(int32_t mode);
 int ctts_get_f32_gemm_mode(void);
 
 /* Launch-shape overrides for A/B measurements (CTTS_F32_NO_GLDS, CTTS_F32_NO_SMALL, CTTS_F32_FORCE_SMALL, CTTS_GEMM_NO_XCD_PAIR, CTTS_BF16_NO_GLDS / _NO_WIDE /
- * _NO_PP / _W4 / _PP_STAGES / _PS / _NO_PS / _PS_STAGES / _MAP, CTTS_WF_NO_FUSE, CTTS_WF_NO_VEC_INTERP, CTTS_WF_NO_REGION_SPLIT, CTTS_WF_NO_ROW_QUEUE, CTTS_F32_NO_ROUND_SPLIT, CTTS_F32_SPLITK_W4, CTTS_TACO_NO_FUSE) never change results beyond the parity
+ * _NO_PP / _W4 / _PP_STAGES / _PS / _NO_PS / _PS_STAGES / _MAP, CTTS_WF_NO_FUSE, CTTS_WF_NO_VEC_INTERP, CTTS_WF_NO_REGION_SPLIT, CTTS_WF_NO_ROW_QUEUE, CTTS_F32_NO_ROUND_SPLIT, CTTS_F32_SPLITK_W4, CTTS_TACO_POLL_DELAY, CTTS_TACO_NO_FUSE) never change results beyond the parity
  * tolerance (CTTS_F32_NO_SPLITK changes the summation order of the fused WaveFlow layer at batch <= 2, see above).  The environment is read once,
  * at the first launch; this re-reads it (tests and profiling scripts that flip a knob in-process). */
 int ctts_tuning_reload(void);
@@ -711,7 +711,8 @@ int ctts_tuning_reload(void);
  * 9 CTTS_F32_NO_SMALL, 10 CTTS_F32_FORCE_SMALL, 11 CTTS_F32_NO_SPLITK, 12 CTTS_WF_NO_VEC_INTERP, 13 CTTS_F32_NO_DEFER_SKIP, 14 CTTS_WF_NO_REGION_SPLIT,
  * 15 CTTS_WF_NO_ROW_QUEUE, 16 CTTS_WF_ROW_QUEUE_MIN set, 17 CTTS_WF_INJECT_ABORT, 18 CTTS_WF_QUEUE_DEBUG != 0, 19 CTTS_F32_NO_ROUND_SPLIT,
  * 20 CTTS_BF16_PS (persistent form of the skewed bf16 kernel on every wide launch), 21 CTTS_BF16_NO_PS, 22 CTTS_F32_SPLITK_W4 (per-layer
- * launches of the split-K shape on four waves per tile instead of eight: bit-identical) (tests assert that a knob they set is the one in
+ * launches of the split-K shape on four waves per tile instead of eight: bit-identical), 23 CTTS_TACO_POLL_DELAY set ("a,c,d,e,h,p": 64-cycle units
+ * before the first poll of the persistent decoder's six vector exchanges; timing only) (tests assert that a knob they set is the one in
  * effect). */
 int ctts_tuning_flags(void);
 
