@@ -54,10 +54,10 @@ int launch_gemm_bf16(int epi, const BGemmArgs& a, hipStream_t stream) {
     // are held by the clock the chip sustains under bf16 MFMA + LDS traffic) and slower on the short-K
     // res GEMM, where its one-wave-per-SIMD epilogue is exposed.
     const bool w4 = tune.bf16_w4;
-    // wide (256 x 256, 512 threads) tiles when the problem has enough of them to fill the chip
+    // wide (256 x 256, 512 threads) tiles when the problem has enough of them (tune.bf16_wide_min: most of one round of the chip)
     const int ntiles_w = (a.L + 255) / 256;
     const bool pp = !no_pp && a.nch_total + 3 <= BGEMM_PP_MAX_CHUNKS;
-    const bool wide = use_glds && !no_wide && (long long)a.MB * ntiles_w * a.batch >= 512 && ntiles_w * 256 + 2 * a.pad <= a.ld;
+    const bool wide = use_glds && !no_wide && (long long)a.MB * ntiles_w * a.batch >= tune.bf16_wide_min && ntiles_w * 256 + 2 * a.pad <= a.ld;
     BGemmArgs b = a;
     if (wide) b.ntiles = ntiles_w;
     const int bn = wide ? 256 : BGEMM_BN;

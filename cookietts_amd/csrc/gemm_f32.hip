@@ -748,6 +748,9 @@ void load_tuning_locked() {
     g_tune.bf16_no_glds = on("CTTS_BF16_NO_GLDS");
     g_tune.bf16_no_wide = on("CTTS_BF16_NO_WIDE");
     g_tune.bf16_no_pp = on("CTTS_BF16_NO_PP");
+    // (512 until round 5.  One utterance of config 2 is 452 wide tiles: 17.7 -> 15.7 ms per call in the half mode with the wide block;
+    //  450 frames = 228 tiles 11.0 -> 10.4; at 225 frames = 116 tiles the narrow block is ahead, 8.8 vs 9.2: profiles/r5_61)
+    g_tune.bf16_wide_min = num("CTTS_BF16_WIDE_MIN", 192);
     g_tune.bf16_w4 = on("CTTS_BF16_W4");
     g_tune.bf16_pp_stages = num("CTTS_BF16_PP_STAGES", 3);
     g_tune.bf16_map = num("CTTS_BF16_MAP", 0);

@@ -18,6 +18,7 @@ struct Tuning {
     bool no_xcd_pair;      // CTTS_GEMM_NO_XCD_PAIR: plain block id -> tile mapping
     bool bf16_no_glds;     // CTTS_BF16_NO_GLDS
     bool bf16_no_wide;     // CTTS_BF16_NO_WIDE: never the 256 x 256 block
+    int bf16_wide_min;     // CTTS_BF16_WIDE_MIN: 256 x 256 tiles (m-blocks x column tiles x batch) from which the wide block is taken (default in gemm_f32.hip load_tuning)
     bool bf16_no_pp;       // CTTS_BF16_NO_PP: never the ping-pong kernel
     bool bf16_w4;          // CTTS_BF16_W4: four-wave 128 x 128 wave tiles (opt-in)
     int bf16_pp_stages;    // CTTS_BF16_PP_STAGES: 3 (default) or 4

@@ -702,7 +702,7 @@ int ctts_set_f32_gemm_mode(int32_t mode);
 int ctts_get_f32_gemm_mode(void);
 
 /* Launch-shape overrides for A/B measurements (CTTS_F32_NO_GLDS, CTTS_F32_NO_SMALL, CTTS_F32_FORCE_SMALL, CTTS_GEMM_NO_XCD_PAIR, CTTS_BF16_NO_GLDS / _NO_WIDE /
- * _NO_PP / _W4 / _PP_STAGES / _PS / _NO_PS / _PS_STAGES / _MAP, CTTS_WF_NO_FUSE, CTTS_WF_NO_VEC_INTERP, CTTS_WF_NO_REGION_SPLIT, CTTS_WF_NO_ROW_QUEUE, CTTS_F32_NO_ROUND_SPLIT, CTTS_F32_SPLITK_W4, CTTS_TACO_POLL_DELAY, CTTS_TACO_NO_FUSE) never change results beyond the parity
+ * _NO_PP / _W4 / _PP_STAGES / _PS / _NO_PS / _PS_STAGES / _MAP / _WIDE_MIN, CTTS_WF_NO_FUSE, CTTS_WF_NO_VEC_INTERP, CTTS_WF_NO_REGION_SPLIT, CTTS_WF_NO_ROW_QUEUE, CTTS_F32_NO_ROUND_SPLIT, CTTS_F32_SPLITK_W4, CTTS_TACO_POLL_DELAY, CTTS_TACO_NO_FUSE) never change results beyond the parity
  * tolerance (CTTS_F32_NO_SPLITK changes the summation order of the fused WaveFlow layer at batch <= 2, see above).  The environment is read once,
  * at the first launch; this re-reads it (tests and profiling scripts that flip a knob in-process). */
 int ctts_tuning_reload(void);
