@@ -19,9 +19,9 @@ def main():
     m = Tacotron2(hp)
     m.load_state_dict(synthetic.to_torch(synthetic.tacotron_state_dict(hp, seed=1234)))
     m = m.cuda().eval()
-    B, T, steps = 4, 200, 900
+    B, T, steps = int(os.environ.get("TACO_B", "4")), int(os.environ.get("TACO_T", "200")), 900      # (TACO_B / TACO_T: other batch sizes / text lengths)
     rng = np.random.default_rng(1234)
-    lens = torch.tensor([200, 195, 150, 100]).cuda()
+    lens = torch.tensor([T, max(T - 5, 1), max(3 * T // 4, 1), max(T // 2, 1)][:B]).cuda()
     mem = torch.from_numpy((rng.standard_normal((B, T, 1313)) * 0.5).astype(np.float32)).cuda()
     for v in values:
         if v == "unset":
