@@ -760,13 +760,15 @@ void load_tuning_locked() {
     g_tune.wf_no_fuse = on("CTTS_WF_NO_FUSE");
     g_tune.taco_no_fuse = on("CTTS_TACO_NO_FUSE");
     {
-        static const int dflt[6] = {36, 0, 8, 8, 16, 24};                // measured: profiles/r5_59_taco_poll_delay.txt
+        // measured: profiles/r5_59_taco_poll_delay.txt, r5_62 (0x10000 = straight to the full sweep; ctx: 128 is 0.3 us faster still but
+        // 144 is already behind - the attention workgroups' answer must not beat the delay - so it stays a quarter below that edge)
+        static const int dflt[6] = {0x10000 | 36, 0x10000 | 96, 0x10000 | 12, 0x10000 | 12, 0x10000 | 24, 0x10000 | 28};
         int v[6];
         for (int i = 0; i < 6; ++i) v[i] = dflt[i];
         const char* e = getenv("CTTS_TACO_POLL_DELAY");
         if (e && sscanf(e, "%d,%d,%d,%d,%d,%d", v, v + 1, v + 2, v + 3, v + 4, v + 5) != 6)
             for (int i = 0; i < 6; ++i) v[i] = dflt[i];
-        for (int i = 0; i < 6; ++i) g_tune.taco_poll_delay[i] = v[i] < 0 ? 0 : v[i] > 1024 ? 1024 : v[i];
+        for (int i = 0; i < 6; ++i) g_tune.taco_poll_delay[i] = v[i] < 0 ? 0 : v[i];
         g_tune.taco_poll_delay_set = e != nullptr;
     }
     g_tune.wf_no_vec_interp = on("CTTS_WF_NO_VEC_INTERP");

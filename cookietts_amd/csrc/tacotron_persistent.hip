@@ -87,7 +87,7 @@ struct PdArgs {
     unsigned g_p, g_atth, g_q, g_ctx, g_dech, g_d2h, g_h1, ctl;                           // xb offsets (u64 words)
     u64* dbg;                   // optional [PD_WG][64 steps][PD_DBG_SLOTS] stamps of s_memrealtime (100 MHz), NULL = off
     int A, F, K, R, n_mel, T, batch, nbc, step0, n_steps, max_steps, pd_rows;   // nbc: batch rows the workspace holds
-    int dly[6];                 // s_sleep(1) units (64 cycles) before the FIRST poll of att_h, ctx, dec_h, d2_h, h1, p (see gather_x)
+    int dly[6];                 // low 16 bits: s_sleep(1) units (64 cycles) before the FIRST poll of att_h, ctx, dec_h, d2_h, h1, p; + 0x10000: no light phase (see gather_x)
 };
 
 __device__ __forceinline__ float pd_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -609,7 +609,10 @@ __device__ __forceinline__ bool gather_x(const u64* g, float* dst, unsigned epoc
             // before its slowest publisher is done - for att_h 1.6-2.0 us after the first ones (profiles/r5_53) - and every poll
             // before that is traffic the publishers' write-through stores queue behind: with the first polls of att_h held back
             // ~1.1 us and those of the prenet vector ~0.7 us the STEP went from 28.5 to 24.0 us (profiles/r5_59).
-            for (int i = 0; i < dly; ++i) __builtin_amdgcn_s_sleep(1);
+            for (int i = 0; i < (dly & 0xffff); ++i) __builtin_amdgcn_s_sleep(1);
+            // + 0x10000 (the default for every vector since the delays exist): no light phase at all - once the first poll is timed to
+            // the arrival of the vector the watch only adds a round trip in front of the sweep (23.95 -> 22.4 us/step, profiles/r5_62)
+            if (!(dly & 0x10000)) {
             constexpr int NS = PPT > 6 ? PD_LIGHT_SAMPLES_BIG : 1;      // samples per lane
             for (unsigned spins = 0;; ++spins) {
                 bool ok = true;
@@ -622,6 +625,7 @@ __device__ __forceinline__ bool gather_x(const u64* g, float* dst, unsigned epoc
                 if (__all(ok)) break;
                 if (timed_out(spins)) break;          // recorded in the control words: the sweep below gives up on them
                 __builtin_amdgcn_s_sleep(1);
+            }
             }
         }
         __syncthreads();
