@@ -22,12 +22,13 @@
 // product's input vector has arrived ("early" products of the next cell evaluation run right after a publish, inside
 // the next exchange's latency) and reduced over the wave (DPP) only in the fresh phase.
 // Exchanges: a vector produced by many workgroups and needed by all (att_h, q, ctx, dec_h, d2_h, h1, prenet) is
-// all-gathered through 8-byte {tag = step + 1, value} granules written with ONE agent-scope (write-through) store each
+// all-gathered through granules written with ONE agent-scope (write-through) store each - q: 8 bytes {tag = step + 1, value};
+// the X vectors since round 5: self-flagging 4-byte values (publish_x below) -
 // and polled with agent-scope loads: the data is the flag, no fences, no grid barrier (MI355X_MICROARCH.md
 // "handoff" / "allgather" rows; cdna_hip_programming.md Guideline 16 R2).  With no weight stream in the CU's memory
 // pipeline the polls are the only traffic ("parked" column of the price list).  Every poll loop is bounded; on a
 // timeout the workgroup records (code, workgroup, phase, step) in the control words and the whole grid drains.
-// Granule tags are zeroed by the host wrapper before EVERY launch; the control words are sticky.
+// The granule area is filled with 0xFF by the host wrapper before EVERY launch; the control words are sticky.
 #include "tacotron_plan.h"
 #include "tuning.h"
 
@@ -125,6 +126,23 @@ __device__ __forceinline__ void publish(u64* g, int idx, unsigned epoch, float v
     __hip_atomic_store((gu64*)g + idx, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// X vectors (att_h, ctx, dec_h, d2_h, h1, prenet: produced by many workgroups, needed by all 252) travel as SELF-FLAGGING 4-byte
+// values (round 5): a float IS the granule, PD_SENT (a NaN pattern no arithmetic here produces) means "not yet".  Two buffers per
+// vector by step parity; whoever publishes slot i of step s also puts PD_SENT back into slot i of the OTHER buffer, which holds
+// step s - 1: every consumer has finished with it (each publish follows a gather that needed a later publish of every consumer),
+// and it is polled again in step s + 1 - after the publisher's own later gathers, whose vmcnt waits cover the reset store, and at
+// least one more exchange between the two workgroups.  Half the bytes of the {tag, value} form (which q keeps), and att_h is ONE
+// round of five 16-byte loads per thread instead of two.  (Built once before the polls were timed: no gain then - r5_53 - because the
+// early polls were the bound.)  The host fills the buffers with 0xFF before every launch.
+constexpr unsigned PD_SENT = 0xFFFFFFFFu;
+typedef __attribute__((address_space(1))) unsigned gu32w;
+__device__ __forceinline__ void publish_x(float* cur, float* oth, int idx, float v) {
+    __hip_atomic_store((gu32w*)cur + idx, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((gu32w*)oth + idx, PD_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the two parity buffers of an X vector of N values per item inside its exchange region (offset in u64 words)
+__device__ __forceinline__ float* pd_xbuf(u64* xb, unsigned off, int par, int N) { return reinterpret_cast<float*>(xb + off) + (size_t)par * PD_NB * N; }
 
 // All-gather receive: thread t owns granules t, t + 256, ...; a granule is accepted when its tag equals `epoch`.
 // Returns false on timeout / abort (after recording it).  The caller follows with a workgroup barrier.
@@ -346,7 +364,7 @@ __device__ __forceinline__ int pd_attention_pre(const PdArgs& a, AttnLds& s, con
 // softmax, context, publish.
 template <bool DBG>
 __device__ __forceinline__ void pd_attention_post(const PdArgs& a, AttnLds& s, const AttnRegs& r, int b, int s0, unsigned epoch,
-                                                  int step, u64* g_ctx) {
+                                                  int step, float* g_ctx) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int wg = blockIdx.x;
     const int W = 2 * a.R + 1;
@@ -435,7 +453,7 @@ __device__ __forceinline__ void pd_attention_post(const PdArgs& a, AttnLds& s, c
             const int d = 2 * t + k;
             const float c = c0[k] + c1[k];
             s.ctx[d] = c;
-            publish(g_ctx, b * PD_DM + d, epoch, c);
+            __hip_atomic_store((gu32w*)g_ctx + (b * PD_DM + d), __float_as_uint(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     PD_STAMP(5);
@@ -489,10 +507,16 @@ __device__ __forceinline__ void attention_workgroup(const PdArgs& a, AttnLds& at
                                    (unsigned)step);
         if (__syncthreads_or(ok_ ? 0 : 1)) return;
         PD_STAMP(2);
+        // ctx of step - 1 (other parity) back to "not yet": q(step) has arrived, so every LSTM workgroup is past its step - 1.  This
+        // workgroup publishes nothing but ctx, so the reset goes out HERE, a whole attention evaluation ahead of the data stores
+        // of this step that a consumer waits for before it can come back to this buffer.
+        for (int d = t; d < PD_DM; d += PD_T)
+            __hip_atomic_store((gu32w*)pd_xbuf(a.xb, a.g_ctx, par ^ 1, PD_DM) + (b * PD_DM + d), PD_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (real) {
-            pd_attention_post<DBG>(a, att, r, b, s0, epoch, step, (a.xb + a.g_ctx) + (size_t)par * PD_NB * PD_DM);
+            pd_attention_post<DBG>(a, att, r, b, s0, epoch, step, pd_xbuf(a.xb, a.g_ctx, par, PD_DM));
         } else {
-            for (int d = t; d < PD_DM; d += PD_T) publish((a.xb + a.g_ctx) + (size_t)par * PD_NB * PD_DM, b * PD_DM + d, epoch, 0.f);
+            for (int d = t; d < PD_DM; d += PD_T)
+                __hip_atomic_store((gu32w*)pd_xbuf(a.xb, a.g_ctx, par, PD_DM) + (b * PD_DM + d), __float_as_uint(0.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         PD_STAMP(6);
     }
@@ -573,24 +597,24 @@ struct PdSlotRt {          // runtime side of a slot
     float c, h;            // cell state / hidden value of item (lane & 3)
 };
 
-// all-gather receive into a padded X vector (item stride n + 16).  Two granules per 16-byte agent-scope load (each half is
-// written by ONE 8-byte store and carries its own tag; 8-byte loads swept the same vector 1.8x slower).  Every sweep of a
-// vector by all 256 CUs is 256 x 8 N bytes of fabric traffic (10 MB for att_h) that the publishers' stores and every
-// other CU's sweep queue behind, so the wait is split: a LIGHT phase polls one pair per thread (512 of the 4 N granules)
-// until those are there - the publishers of a vector finish within ~0.8 us of each other - and only then the FULL sweep
-// reads everything, PB pairs of a thread in flight at a time, and re-reads what was still missing.
+// all-gather receive into a padded X vector (item stride n + 16): four values per 16-byte agent-scope load, each its own flag
+// (see publish_x).  Every sweep of a vector by all 256 CUs is 256 x 4 N x 4 bytes of fabric traffic that the publishers' stores and
+// every other CU's sweep queue behind, so NOTHING is polled before the vector can be complete: the first poll goes out `dly` x 64
+// cycles after wave 0's own publish (round 5).  A vector cannot be complete before its slowest publisher is done - for att_h
+// 1.6-2.0 us after the first ones with early polls on the fabric, 0.5 us without (profiles/r5_53, r5_59) - and a poll that cannot
+// succeed yet is traffic that publisher's write-through stores queue behind: holding the first polls back took the STEP from 28.4
+// to 24.0 us (r5_59); then straight to the FULL sweep (dly + 0x10000, the default) instead of a light phase first, 22.4 (r5_62);
+// this 4-byte format - att_h in ONE round of five loads per thread instead of two - 21.2 (r5_64).  The sweep re-reads what was
+// still missing.
 // The loads are raw buffer loads with the sc1 bit (what an agent-scope atomic load lowers to), so that the compiler
 // tracks them itself (inline-asm loads cost ~125 spilled weight registers around every gather).
 typedef unsigned pd_u4 __attribute__((ext_vector_type(4)));
 constexpr int PD_AUX_SC1 = 16;
 template <int N>
-__device__ __forceinline__ bool gather_x(const u64* g, float* dst, unsigned epoch, unsigned* ctl, int t, unsigned phase, unsigned step, int dly) {
-    constexpr int PAIRS = 2 * N, PPT = (PAIRS + PD_T - 1) / PD_T;
-    // pairs of a thread in flight during a full sweep: everything at once up to 6 (24 data registers), else rounds of 5
-    // (att_h: 10 pairs per thread; all 10 at once spilt 70 weight registers)
-    constexpr int PB = PPT <= PD_PB_MAX ? PPT : 5;
-    static_assert(PAIRS >= PD_T && N % 2 == 0, "every thread owns at least one pair");
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64*>(g), 0, PD_NB * N * 8, 0x00020000);
+__device__ __forceinline__ bool gather_x(const float* g, float* dst, unsigned* ctl, int t, unsigned phase, unsigned step, int dly) {
+    constexpr int QUADS = PD_NB * N / 4, PPT = (QUADS + PD_T - 1) / PD_T;
+    static_assert(QUADS >= PD_T && N % 4 == 0 && PPT <= 5, "every thread owns one to five quads, a quad lies inside one item");
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g), 0, PD_NB * N * 4, 0x00020000);
     auto timed_out = [&](unsigned spins) -> bool {
         if ((spins & 255u) != 255u) return false;
         if (__hip_atomic_load((gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
@@ -600,64 +624,49 @@ __device__ __forceinline__ bool gather_x(const u64* g, float* dst, unsigned epoc
         }
         return false;
     };
+    auto landed = [](const pd_u4& v) { return v[0] != PD_SENT && v[1] != PD_SENT && v[2] != PD_SENT && v[3] != PD_SENT; };
     {
-        // light phase: ONE wave watches 64 pairs spread over all units of item 0 (= over all publishing workgroups) while the
-        // other three wait at the barrier: a quarter of the polling traffic of a 256-thread watch, and none of the
-        // full-sweep traffic before the vector is (nearly) complete
+        // ONE wave holds the first poll back (and, without the 0x10000 flag, then watches 64 quads spread over item 0 - the light
+        // phase of round 4, kept for A/B) while the other three wait at the barrier: the sweep of ALL waves starts `dly` after wave
+        // 0's publish, which absorbs the lateness of a wave with two cells (every wave waiting for itself: 22.4 -> 25.7 us/step)
         if (t < 64) {
-            // The first poll goes out `dly` x 64 cycles after this workgroup's own publish (round 5).  A vector cannot be complete
-            // before its slowest publisher is done - for att_h 1.6-2.0 us after the first ones (profiles/r5_53) - and every poll
-            // before that is traffic the publishers' write-through stores queue behind: with the first polls of att_h held back
-            // ~1.1 us and those of the prenet vector ~0.7 us the STEP went from 28.5 to 24.0 us (profiles/r5_59).
             for (int i = 0; i < (dly & 0xffff); ++i) __builtin_amdgcn_s_sleep(1);
-            // + 0x10000 (the default for every vector since the delays exist): no light phase at all - once the first poll is timed to
-            // the arrival of the vector the watch only adds a round trip in front of the sweep (23.95 -> 22.4 us/step, profiles/r5_62)
             if (!(dly & 0x10000)) {
-            constexpr int NS = PPT > 6 ? PD_LIGHT_SAMPLES_BIG : 1;      // samples per lane
-            for (unsigned spins = 0;; ++spins) {
-                bool ok = true;
-#pragma unroll
-                for (int q = 0; q < NS; ++q) {
-                    const int pl = (t * NS + q) * (N / 2 / (64 * NS));
-                    const pd_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * pl, 0, PD_AUX_SC1);
-                    ok = ok && v[1] == epoch && v[3] == epoch;
+                const int ql = t * (N / 4 / 64);                            // quads of item 0, spread over its units
+                for (unsigned spins = 0;; ++spins) {
+                    const pd_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * ql, 0, PD_AUX_SC1);
+                    if (__all(landed(v))) break;
+                    if (timed_out(spins)) break;          // recorded in the control words: the sweep below gives up on them
+                    __builtin_amdgcn_s_sleep(1);
                 }
-                if (__all(ok)) break;
-                if (timed_out(spins)) break;          // recorded in the control words: the sweep below gives up on them
-                __builtin_amdgcn_s_sleep(1);
-            }
             }
         }
         __syncthreads();
     }
-#pragma unroll 1
-    for (int k0 = 0; k0 < PPT; k0 += PB) {          // full sweep
-        unsigned done = 0;
-        for (unsigned spins = 0;; ++spins) {
-            pd_u4 v[PB];
+    unsigned done = 0;
+    for (unsigned spins = 0;; ++spins) {            // full sweep
+        pd_u4 v[PPT];
 #pragma unroll
-            for (int k = 0; k < PB; ++k)
-                if (k0 + k < PPT && t + PD_T * (k0 + k) < PAIRS && !((done >> k) & 1u))
-                    v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * (t + PD_T * (k0 + k)), 0, PD_AUX_SC1);
-                else v[k] = pd_u4{0u, 0u, 0u, 0u};
-            bool ok = true;
+        for (int k = 0; k < PPT; ++k)
+            if (t + PD_T * k < QUADS && !((done >> k) & 1u))
+                v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * (t + PD_T * k), 0, PD_AUX_SC1);
+            else v[k] = pd_u4{0u, 0u, 0u, 0u};
+        bool ok = true;
 #pragma unroll
-            for (int k = 0; k < PB; ++k) {
-                const int i = 2 * (t + PD_T * (k0 + k));
-                if (k0 + k < PPT && t + PD_T * (k0 + k) < PAIRS && !((done >> k) & 1u)) {
-                    if (v[k][1] == epoch && v[k][3] == epoch) {
-                        float* d = dst + i + 16 * (i / N);
-                        d[0] = __uint_as_float(v[k][0]); d[1] = __uint_as_float(v[k][2]);
-                        done |= 1u << k;
-                    } else {
-                        ok = false;
-                    }
+        for (int k = 0; k < PPT; ++k) {
+            const int i = 4 * (t + PD_T * k);
+            if (t + PD_T * k < QUADS && !((done >> k) & 1u)) {
+                if (landed(v[k])) {
+                    *reinterpret_cast<pd_u4*>(dst + i + 16 * (i / N)) = v[k];
+                    done |= 1u << k;
+                } else {
+                    ok = false;
                 }
             }
-            if (__all(ok)) break;
-            if (timed_out(spins)) return false;
-            __builtin_amdgcn_s_sleep(1);
         }
+        if (__all(ok)) break;
+        if (timed_out(spins)) return false;
+        __builtin_amdgcn_s_sleep(1);
     }
     return true;
 }
@@ -717,7 +726,7 @@ __device__ __forceinline__ void pd_segment(const PdWaveW<SIG>& w, const float* l
 // LSTM cell update of every slot of cell CELL (layers.py:308-372, gate order i, f, g, o): block sums, activations,
 // publish h' of item (lane & 3) at [item][first + unit] from the lanes of block 0.
 template <class SIG, int CELL>
-__device__ __forceinline__ void pd_cells(PdSlotRt (&sl)[3], u64* g, unsigned epoch, int H, int first, int lane) {
+__device__ __forceinline__ void pd_cells(PdSlotRt (&sl)[3], float* g, float* goth, int H, int first, int lane) {
     static_for<0, 3>([&](auto ss) {
         constexpr int s = decltype(ss)::value;
         if constexpr (SIG::cell[s] == CELL) {
@@ -730,7 +739,7 @@ __device__ __forceinline__ void pd_cells(PdSlotRt (&sl)[3], u64* g, unsigned epo
             const float gg = acc_tanh(pre[2]), go = acc_sigmoid(pre[3]);
             sl[s].c = gf * sl[s].c + gi * gg;
             sl[s].h = go * acc_tanh(sl[s].c);
-            if (lane < PD_NB) publish(g, lane * H + first + sl[s].unit, epoch, sl[s].h);
+            if (lane < PD_NB) publish_x(g, goth, lane * H + first + sl[s].unit, sl[s].h);
             sl[s].acc = pd_f4{0.f, 0.f, 0.f, 0.f};
         }
     });
@@ -883,7 +892,7 @@ __device__ __forceinline__ void lstm_wave(const PdArgs& a, float* L, LstmLds& S,
     bool fail = false;
 #define PD_GATHER(NPT, N, buf, dst, phase)                                                                          \
     do {                                                                                                               \
-        const bool ok_ = gather_x<N>((buf) + (size_t)par * (PD_NB * (N)), (dst), epoch, ctl, t, (phase), (unsigned)step, a.dly[(phase) == 1u ? 0 : (phase) - 2u]); \
+        const bool ok_ = gather_x<N>(pd_xbuf(a.xb, (buf), par, (N)), (dst), ctl, t, (phase), (unsigned)step, a.dly[(phase) == 1u ? 0 : (phase) - 2u]); \
         if (__syncthreads_or(ok_ ? 0 : 1)) { fail = true; }                                                            \
     } while (0)
 
@@ -906,10 +915,10 @@ __device__ __forceinline__ void lstm_wave(const PdArgs& a, float* L, LstmLds& S,
         }
         // ---- A: attention RNN on the fresh prenet columns (model.py:707-717)
         pd_segment<SIG, CELL_ATT, 0, 4>(w, lt, xP, lane, sl);
-        pd_cells<SIG, CELL_ATT>(sl, (a.xb + a.g_atth) + (size_t)par * PD_NB * PD_RA, epoch, PD_RA, FA, lane);
+        pd_cells<SIG, CELL_ATT>(sl, pd_xbuf(a.xb, a.g_atth, par, PD_RA), pd_xbuf(a.xb, a.g_atth, par ^ 1, PD_RA), PD_RA, FA, lane);
         PD_STAMP(1);
         PD_STAMP_LANE0(20 + wave);                                               // (debug build: when did EACH wave publish its att_h units)
-        PD_GATHER(20, PD_RA, (a.xb + a.g_atth), X + XATT, 1u);
+        PD_GATHER(20, PD_RA, a.g_atth, X + XATT, 1u);
         PD_STAMP(2);
         if (fail) break;
         // ---- B: query row (model.py:126 query_layer); then, while the attention workgroups work, the products on
@@ -924,21 +933,21 @@ __device__ __forceinline__ void lstm_wave(const PdArgs& a, float* L, LstmLds& S,
         pd_segment<SIG, CELL_DEC, 8, 20>(w, lt, xA, lane, sl);
         pd_segment<SIG, CELL_ATT, 24, 20>(w, lt, xA, lane, sl);
         PD_STAMP(3);
-        PD_GATHER(8, PD_DM, (a.xb + a.g_ctx), X + XCTX, 3u);
+        PD_GATHER(8, PD_DM, a.g_ctx, X + XCTX, 3u);
         PD_STAMP(4);
         if (fail) break;
         // ---- C: decoder RNN on the fresh context columns (model.py:741-747)
         pd_segment<SIG, CELL_DEC, 0, 8>(w, lt, xC, lane, sl);
-        pd_cells<SIG, CELL_DEC>(sl, (a.xb + a.g_dech) + (size_t)par * PD_NB * PD_RD, epoch, PD_RD, FD, lane);
+        pd_cells<SIG, CELL_DEC>(sl, pd_xbuf(a.xb, a.g_dech, par, PD_RD), pd_xbuf(a.xb, a.g_dech, par ^ 1, PD_RD), PD_RD, FD, lane);
         PD_STAMP(13);
         pd_segment<SIG, CELL_ATT, 4, 8>(w, lt, xC, lane, sl);                   // attention RNN of step + 1 on ctx(step)
         PD_STAMP(5);
-        PD_GATHER(12, PD_RD, (a.xb + a.g_dech), X + XDEC, 4u);
+        PD_GATHER(12, PD_RD, a.g_dech, X + XDEC, 4u);
         PD_STAMP(6);
         if (fail) break;
         // ---- D: second decoder RNN on the fresh decoder-hidden columns (model.py:749-755)
         pd_segment<SIG, CELL_D2, 0, 12>(w, lt, xD, lane, sl);
-        pd_cells<SIG, CELL_D2>(sl, (a.xb + a.g_d2h) + (size_t)par * PD_NB * PD_RD, epoch, PD_RD, F2, lane);
+        pd_cells<SIG, CELL_D2>(sl, pd_xbuf(a.xb, a.g_d2h, par, PD_RD), pd_xbuf(a.xb, a.g_d2h, par ^ 1, PD_RD), PD_RD, F2, lane);
         PD_STAMP(14);
         // products of step + 1 on dec_h(step): the attention RNN's decoder-hidden columns, the decoder RNN's recurrent
         // ones; and the part of the projection rows that does not need d2_h
@@ -950,7 +959,7 @@ __device__ __forceinline__ void lstm_wave(const PdArgs& a, float* L, LstmLds& S,
             pd_row<8>(wrow + PD_RD, xC, lane, accP);                             // W[:, 768:] . ctx
         }
         PD_STAMP(7);
-        PD_GATHER(12, PD_RD, (a.xb + a.g_d2h), X + XD2, 5u);
+        PD_GATHER(12, PD_RD, a.g_d2h, X + XD2, 5u);
         PD_STAMP(8);
         if (fail) break;
         // ---- E: projection row set on [dec_h + d2_h | ctx] (model.py:757-765; rows: mel, gate, folded prenet layer 1)
@@ -969,7 +978,7 @@ __device__ __forceinline__ void lstm_wave(const PdArgs& a, float* L, LstmLds& S,
                 } else if (have_next) {     // first prenet layer of step + 1: relu, always-on dropout (model.py:187-190)
                     const int j = row - a.n_mel - 1;
                     const bool kp = keep_next != 0;        // (lanes >= batch loaded nothing: 0)
-                    publish((a.xb + a.g_h1) + (size_t)par * PD_NB * PD_P, b * PD_P + j, epoch, kp ? fmaxf(val, 0.f) * 2.0f : 0.0f);
+                    publish_x(pd_xbuf(a.xb, a.g_h1, par, PD_P), pd_xbuf(a.xb, a.g_h1, par ^ 1, PD_P), b * PD_P + j, kp ? fmaxf(val, 0.f) * 2.0f : 0.0f);
                 }
             }
             if (wave == 1) PD_STAMP_LANE0(15);
@@ -977,7 +986,7 @@ __device__ __forceinline__ void lstm_wave(const PdArgs& a, float* L, LstmLds& S,
         pd_segment<SIG, CELL_D2, 12, 12>(w, lt, x2, lane, sl);                  // second decoder RNN of step + 1 on d2_h(step)
         if (have_next) {
             PD_STAMP(9);
-            PD_GATHER(4, PD_P, (a.xb + a.g_h1), X + XH1, 6u);
+            PD_GATHER(4, PD_P, a.g_h1, X + XH1, 6u);
             PD_STAMP(10);
             if (fail) break;
             // ---- F: second prenet layer rows
@@ -992,12 +1001,12 @@ __device__ __forceinline__ void lstm_wave(const PdArgs& a, float* L, LstmLds& S,
                     const bool kp = keep_next != 0;
                     const float pv = kp ? fmaxf(val, 0.f) * 2.0f : 0.0f;
                     S.pown[k][b] = pv;
-                    publish((a.xb + a.g_p) + (size_t)par * PD_NB * PD_P, b * PD_P + row, epoch, pv);
+                    publish_x(pd_xbuf(a.xb, a.g_p, par, PD_P), pd_xbuf(a.xb, a.g_p, par ^ 1, PD_P), b * PD_P + row, pv);
                 }
                 if (wave == 3) PD_STAMP_LANE0(16);
             }
             PD_STAMP(11);
-            PD_GATHER(4, PD_P, (a.xb + a.g_p), X + XP, 7u);
+            PD_GATHER(4, PD_P, a.g_p, X + XP, 7u);
             PD_STAMP(12);
             if (fail) break;
         }
@@ -1147,7 +1156,7 @@ int ctts_taco_decoder_steps_persistent_f32(const ctts_taco_decoder_config* cfg, 
     hipStream_t s = as_stream(stream);
     const float* blob = static_cast<const float*>(packed);
     u64* xb = static_cast<u64*>(exchange);
-    CTTS_CHECK_HIP(hipMemsetAsync(exchange, 0, x.ctl * sizeof(u64), s));        // every tag, before every launch
+    CTTS_CHECK_HIP(hipMemsetAsync(exchange, 0xFF, x.ctl * sizeof(u64), s));     // every granule "not yet" (X vectors: PD_SENT; q: a tag no step has), before every launch
     const auto& c = p.c;
     PdArgs a{};
     a.blob = blob; a.ws = static_cast<float*>(workspace); a.xb = xb;
