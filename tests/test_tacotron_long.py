@@ -181,6 +181,34 @@ def test_hip_tacotron_matches_long_goldens(hip_lib_path, name, form):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(4, 120), (1, 40)])
+def test_persistent_decoder_is_bit_identical_run_to_run(hip_lib_path, B, T):
+    """The persistent decoder's vectors travel as self-flagging values in two parity buffers that their publishers reset a step ahead
+    (tacotron_persistent.hip, publish_x): a stale read - a value of step s - 2 taken for step s - would be a silent error.  Same
+    memory, same dropout keep-masks, several runs: every output must be bit-identical (scripts/debug/taco_determinism_soak.py runs
+    the same check over millions of steps: profiles/r5_65)."""
+    from cookietts_amd.tacotron2 import Tacotron2
+    hp = synthetic.tacotron_hparams()
+    m = Tacotron2(hp)
+    m.load_state_dict(synthetic.to_torch(synthetic.tacotron_state_dict(hp, seed=1234)))
+    m = m.cuda().eval()
+    steps = 300
+    rng = np.random.default_rng(B * 1000 + T)
+    lens = torch.tensor([T, max(T - 5, 1), max(3 * T // 4, 1), max(T // 2, 1)][:B]).cuda()
+    mem = torch.from_numpy((rng.standard_normal((B, T, 1313)) * 0.5).astype(np.float32)).cuda()
+    keep = torch.from_numpy((rng.random((steps, 2, B, m.decoder.prenet_dim)) < 0.5).astype(np.uint8)).cuda()
+    ref = None
+    for _ in range(6):
+        out = [o.clone() for o in m.decoder.inference(mem, lens, keep_masks=keep, fixed_steps=steps)[:3]]
+        assert m.decoder.persistent_state == "ok"
+        assert all(bool(torch.isfinite(o).all()) for o in out)
+        if ref is None:
+            ref = out
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(ref, out))
+
+
+@pytest.mark.gpu
 def test_postnet_at_900_frames_matches_oracle(hip_lib_path):
     """Postnet.forward (model.py:218-228) at the metric's 900 frames, B=4, against the fp64 restatement."""
     g, hp, sd, masks, n = _load("long")
