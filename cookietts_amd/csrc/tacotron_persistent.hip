@@ -369,35 +369,39 @@ __device__ __forceinline__ void pd_attention_post(const PdArgs& a, AttnLds& s, c
     const int wg = blockIdx.x;
     const int W = 2 * a.R + 1;
     const int len = reinterpret_cast<const int*>(a.ws + a.lengths)[b];
-    {   // energies (model.py:107-112): wave wv takes window positions wv, wv + 4, ...; a lane sums its three attention
-        // dims (lane, lane + 64, lane + 128) first, so a position costs ONE 64-lane reduction, not three
+    // energies (model.py:107-112): wave wv takes window positions wv, wv + 4, ...; a lane sums its attention dims (lane, lane + 64,
+    // lane + 128) first, so a position costs ONE 64-lane reduction, not three.  NJ = 2 when attention_dim <= 128 (the repo default:
+    // the third dim of every lane is masked, and its nine exp2 / rcp chains per lane were a third of this phase - round 5); the masked
+    // terms were exact zeros, so the sums are bit-identical.
+    auto energies = [&](auto njc) {
+        constexpr int NJ = decltype(njc)::value;
         constexpr int NE = (PD_W + PD_NW - 1) / PD_NW;
-        float qv[3], ev[NE];
+        float qv[NJ], ev[NE];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) qv[j] = lane + 64 * j < a.A ? s.q[lane + 64 * j] : 0.f;
-        // staged by hand: all 27 loads, then all exp2, then all rcp, then the sums.  Written as one loop per position the
+        for (int j = 0; j < NJ; ++j) qv[j] = lane + 64 * j < a.A ? s.q[lane + 64 * j] : 0.f;
+        // staged by hand: all loads, then all exp2, then all rcp, then the sums.  Written as one loop per position the
         // wave executed 27 dependent exp2 -> add -> rcp -> fma chains back to back (2.1 us: a wave issues in order and the
         // transcendental pipe has ~40 cycles of latency); the order of every sum is unchanged
         // (tanhf here: arbiter distance of band 1 1.6e-4 -> 1.1e-4, step 32 -> 36 us with libm in the cells as well: not taken)
-        float x[NE][3];
+        float x[NE][NJ];
 #pragma unroll
         for (int i = 0; i < NE; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j)     // pmw = processed memory + location term (pd_attention_pre)
+            for (int j = 0; j < NJ; ++j)     // pmw = processed memory + location term (pd_attention_pre)
                 x[i][j] = lane + 64 * j < a.A ? s.pmw[min(wv + PD_NW * i, W - 1) * a.A + lane + 64 * j] + qv[j] : 0.f;
 #pragma unroll
         for (int i = 0; i < NE; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) x[i][j] = __builtin_amdgcn_exp2f(x[i][j] * 2.8853900817779268f);
+            for (int j = 0; j < NJ; ++j) x[i][j] = __builtin_amdgcn_exp2f(x[i][j] * 2.8853900817779268f);
 #pragma unroll
         for (int i = 0; i < NE; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) x[i][j] = __builtin_amdgcn_rcpf(1.0f + x[i][j]);
+            for (int j = 0; j < NJ; ++j) x[i][j] = __builtin_amdgcn_rcpf(1.0f + x[i][j]);
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
             float e = 0.f;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) e += lane + 64 * j < a.A ? r.va3[j] * (1.0f - 2.0f * x[i][j]) : 0.f;
+            for (int j = 0; j < NJ; ++j) e += lane + 64 * j < a.A ? r.va3[j] * (1.0f - 2.0f * x[i][j]) : 0.f;
             ev[i] = e;
         }
         PD_STAMP(18);
@@ -406,7 +410,9 @@ __device__ __forceinline__ void pd_attention_post(const PdArgs& a, AttnLds& s, c
 #pragma unroll
         for (int i = 0; i < NE; ++i)
             if (lane == 0 && wv + PD_NW * i < W) s.en[wv + PD_NW * i] = ev[i];
-    }
+    };
+    if (a.A > 128) energies(std::integral_constant<int, 3>{});
+    else energies(std::integral_constant<int, 2>{});
     __syncthreads();
     PD_STAMP(3);
     if (wv == 0) {
