@@ -762,7 +762,7 @@ void load_tuning_locked() {
     {
         // measured: profiles/r5_59_taco_poll_delay.txt, r5_62 (0x10000 = straight to the full sweep; ctx: 128 is 0.3 us faster still but
         // 144 is already behind - the attention workgroups' answer must not beat the delay - so it stays a quarter below that edge)
-        static const int dflt[6] = {0x10000 | 36, 0x10000 | 96, 0x10000 | 12, 0x10000 | 12, 0x10000 | 24, 0x10000 | 28};
+        static const int dflt[6] = {0x10000 | 36, 0x10000 | 96, 0x10000 | 12, 0x10000 | 20, 0x10000 | 8, 0x10000 | 8};   // (h1 / prenet: 24 / 28 until the early products of phase D moved in front of their gathers, r5_68)
         int v[6];
         for (int i = 0; i < 6; ++i) v[i] = dflt[i];
         const char* e = getenv("CTTS_TACO_POLL_DELAY");

@@ -955,10 +955,10 @@ __device__ __forceinline__ void lstm_wave(const PdArgs& a, float* L, LstmLds& S,
         pd_segment<SIG, CELL_D2, 0, 12>(w, lt, xD, lane, sl);
         pd_cells<SIG, CELL_D2>(sl, pd_xbuf(a.xb, a.g_d2h, par, PD_RD), pd_xbuf(a.xb, a.g_d2h, par ^ 1, PD_RD), PD_RD, F2, lane);
         PD_STAMP(14);
-        // products of step + 1 on dec_h(step): the attention RNN's decoder-hidden columns, the decoder RNN's recurrent
-        // ones; and the part of the projection rows that does not need d2_h
-        pd_segment<SIG, CELL_ATT, 12, 12>(w, lt, xD, lane, sl);
-        pd_segment<SIG, CELL_DEC, 28, 12>(w, lt, xD, lane, sl);
+        // the part of the projection rows that does not need d2_h.  (The products of step + 1 on dec_h(step) - the attention RNN's
+        // decoder-hidden columns, the decoder RNN's recurrent ones - ran HERE until round 5: 1.2 us between this workgroup's d2_h
+        // publish and its d2_h gather, more than the exchange needs.  They now hide in the h1 / prenet exchanges below, which had
+        // nothing to cover; every slot still accumulates its segments in the same order: bit-identical.)
         if (wave == 1 || (wave == 2 && pr_row1 >= 0)) {
             const float* wrow = L + WPR + (wave == 1 ? 0 : Dp);
             pd_row<12>(wrow, xD, lane, accP);                                    // W[:, :768] . dec_h
@@ -990,6 +990,7 @@ __device__ __forceinline__ void lstm_wave(const PdArgs& a, float* L, LstmLds& S,
             if (wave == 1) PD_STAMP_LANE0(15);
         }
         pd_segment<SIG, CELL_D2, 12, 12>(w, lt, x2, lane, sl);                  // second decoder RNN of step + 1 on d2_h(step)
+        pd_segment<SIG, CELL_ATT, 12, 12>(w, lt, xD, lane, sl);                 // attention RNN of step + 1 on dec_h(step) (see D)
         if (have_next) {
             PD_STAMP(9);
             PD_GATHER(4, PD_P, a.g_h1, X + XH1, 6u);
@@ -1011,6 +1012,7 @@ __device__ __forceinline__ void lstm_wave(const PdArgs& a, float* L, LstmLds& S,
                 }
                 if (wave == 3) PD_STAMP_LANE0(16);
             }
+            pd_segment<SIG, CELL_DEC, 28, 12>(w, lt, xD, lane, sl);             // decoder RNN of step + 1: recurrent columns on dec_h(step) (see D)
             PD_STAMP(11);
             PD_GATHER(4, PD_P, a.g_p, X + XP, 7u);
             PD_STAMP(12);

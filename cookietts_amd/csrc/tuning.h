@@ -28,7 +28,7 @@ struct Tuning {
     int bf16_map;          // CTTS_BF16_MAP: (A/B) 1 = MB == 2 launches keep the plain id -> tile map, 2 = MB == 4 launches put all four m-blocks of a tile on one XCD
     bool wf_no_fuse;       // CTTS_WF_NO_FUSE: WaveFlow layer as separate GATE + res/skip launches
     bool taco_poll_delay_set;
-    int taco_poll_delay[6];  // CTTS_TACO_POLL_DELAY="a,c,d,e,h,p": persistent decoder, s_sleep(1) units before the first poll of the att_h, ctx, dec_h, d2_h, h1, prenet exchanges (+ 65536: no light phase, straight to the full sweep; default 65572,65632,65548,65548,65560,65564; all 0: the form before round 5)
+    int taco_poll_delay[6];  // CTTS_TACO_POLL_DELAY="a,c,d,e,h,p": persistent decoder, s_sleep(1) units before the first poll of the att_h, ctx, dec_h, d2_h, h1, prenet exchanges (+ 65536: no light phase, straight to the full sweep; default 65572,65632,65548,65556,65544,65544; all 0: the form before round 5)
     bool taco_no_fuse;     // CTTS_TACO_NO_FUSE: per-launch decoder without the fused projection kernel
     bool f32_no_defer_skip;  // CTTS_F32_NO_DEFER_SKIP: WaveGlow fp32 WN stack with one res/skip GEMM per layer (the form before round 4)
     bool wf_no_region_split; // CTTS_WF_NO_REGION_SPLIT: the fused WaveFlow layer as ONE launch per layer (no A | M | B regions on three streams)
