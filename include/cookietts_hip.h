@@ -500,13 +500,13 @@ int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void*
 /* Persistent form of ctts_taco_decoder_steps_f32: ONE launch of 256 resident workgroups (256 threads each, one wave per
  * SIMD) runs all n_steps steps with EVERY LSTM weight resident on the compute units for the whole launch (registers + LDS;
  * the 108 MB of weights are read once, at entry: ask for blocks of >= 32 steps), products on v_mfma_f32_4x4x1, and vectors
- * move between workgroups as 8-byte {tag, value} granules (no grid barrier, no per-step launches).  Same state (workspace), same outputs, same keep_masks contract as ctts_taco_decoder_steps_f32, so the
+ * move between workgroups as granules that carry their own flag (4-byte self-flagging values, 8-byte {tag, value} for the query; no grid barrier, no per-step launches).  Same state (workspace), same outputs, same keep_masks contract as ctts_taco_decoder_steps_f32, so the
  * two can be mixed call by call.  Built for the repo-default decoder shape (attention RNN 1280, decoder RNNs 768,
  * prenet 256, memory 512, window 16), batch <= 4, text_len <= 1024 on a device with >= 256 CUs:
  * ctts_taco_decoder_persistent_bytes returns 0 otherwise, also when the CURRENT device has fewer CUs (use the per-launch
  * form); with no device at all it answers for the shape alone.
- *   exchange: ctts_taco_decoder_persistent_bytes(...) device bytes, zero-filled ONCE by the caller; the call clears the
- *   granule tags itself before every launch.  The LAST 64 bytes (bytes - 64 .. bytes) are control words (uint32): word 0 stays 0 on success;
+ *   exchange: ctts_taco_decoder_persistent_bytes(...) device bytes, zero-filled ONCE by the caller; the call re-initialises the
+ *   granule area (everything but the control words) itself before every launch.  The LAST 64 bytes (bytes - 64 .. bytes) are control words (uint32): word 0 stays 0 on success;
  *   non-zero = a bounded wait gave up (words 1..3: workgroup, phase, step), the outputs of that call are invalid and
  *   every later launch on the same buffer returns immediately (sticky) until the caller zeroes the words. */
 size_t ctts_taco_decoder_persistent_bytes(const ctts_taco_decoder_config* cfg, int32_t batch, int32_t text_len);
