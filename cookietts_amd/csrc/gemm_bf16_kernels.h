@@ -575,8 +575,11 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_bf16_pp_kernel(const BGemmAr
 //     belongs to, so the next tile's first chunks land while this tile's epilogue runs;
 //   * a half runs its epilogue inside the interval that follows its last COMPUTE of the tile, after issuing that
 //     interval's DMA: the two halves' epilogues overlap each other and the lagging half's last COMPUTE;
-//   * bias staged once per workgroup (the m-block is fixed), chunk -> address tables double-buffered by tile parity and
-//     built one tile ahead (when the DMA cursor enters tile k, the table of tile k + 1 is written over that of k - 1).
+//   * bias staged once per workgroup (the m-block is fixed), chunk -> address tables in THREE slots (tile % 3), built one
+//     tile ahead: when the leading half's DMA cursor enters tile k + 1 it writes the table of tile k + 2 over that of
+//     k - 1.  Three, not two: in that same interval the lagging half still reads tile k's last entry (its cursor follows
+//     one interval behind, no barrier in between), so the slot being written must be neither k's nor k + 1's; slot k - 1
+//     was last read nch > NS intervals (and as many barriers) earlier, and the new table is first read nch intervals later.
 // Arithmetic and summation order are those of the per-tile kernel: bit-identical results.
 // (An earlier form with every wave a self-contained software-pipelined stream - fragments double-buffered per k-step, DMA
 // issued between MFMAs - measured 39-41 cycles per MFMA and SIMD against this structure's 36.5: a DMA issued inside an
@@ -591,10 +594,11 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16_ps_kernel(const BGemmArgs 
     constexpr int B_UNITS = 4 * BN;
     constexpr int SU = A_UNITS + B_UNITS;
     typedef unsigned long long u64;
-    // stages | tabs[2][MAXC] (absolute chunk addresses of the DMA cursor's tile, by tile parity) | rel[MAXC] | bsb[MAXC] | bias[256]
-    __shared__ __attribute__((aligned(16))) u32x4 lds[NS * SU + MAXC + MAXC + BGEMM_BM / 4];
+    // stages | tabs[3][MAXC] (absolute chunk addresses of the DMA cursor's tile, slot = tile % 3) | rel[MAXC] | bsb[MAXC] | bias[256]
+    static_assert(MAXC % 2 == 0, "table slots are whole 16-byte units");
+    __shared__ __attribute__((aligned(16))) u32x4 lds[NS * SU + 3 * MAXC / 2 + MAXC + BGEMM_BM / 4];
     u64* tabs = reinterpret_cast<u64*>(lds + NS * SU);
-    u64* rel = tabs + 2 * MAXC;
+    u64* rel = tabs + 3 * MAXC;
     u64* bsb = rel + MAXC;
     u32x4* bias_lds = reinterpret_cast<u32x4*>(bsb + MAXC);
 
@@ -685,7 +689,7 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16_ps_kernel(const BGemmArgs 
         const u64 ub0 = CTTS_UNIFORM64(tabs[c]);
         CTTS_PS_DMA(c, c, ub0);
     }
-    int dk = 0, dch = NS - 1;                               // DMA cursor: next chunk to issue = chunk dch of tile dk ...
+    int dk = 0, dch = NS - 1, dslot = 0;                    // DMA cursor: next chunk to issue = chunk dch of tile dk (table slot dslot = dk % 3) ...
     u64 ub = CTTS_UNIFORM64(tabs[NS - 1]);                  // ... whose B rows start at ub
     CTTS_WAIT_VM(4 * (NS - 2));
     __builtin_amdgcn_s_barrier();                           // chunk 0 is in LDS
@@ -715,7 +719,7 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16_ps_kernel(const BGemmArgs 
                     acc[mt][nt] = mfma_k16<F16>(av[ks][mt], bv[ks][nt], acc[mt][nt]);              \
                     if (FETCH && ks * 8 + mt * 2 + nt == 1) {                                       \
                         __builtin_amdgcn_sched_barrier(0);                                          \
-                        tnext_ = tabs[(dk & 1) * MAXC + dch];                                       \
+                        tnext_ = tabs[dslot * MAXC + dch];                                          \
                         __builtin_amdgcn_sched_barrier(0);                                          \
                     }                                                                               \
                     if (FETCH && ks * 8 + mt * 2 + nt == 11) {                                      \
@@ -734,9 +738,11 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16_ps_kernel(const BGemmArgs 
         if (++dch == nch) {                                                                         \
             dch = 0;                                                                                \
             ++dk;                                                                                   \
+            dslot = dslot == 2 ? 0 : dslot + 1;                                                     \
             if (dk + 1 < my_tiles && t < nch) {                                                     \
                 const int g2 = first + (dk + 1) * step;                                             \
-                tabs[((dk + 1) & 1) * MAXC + t] = rel[t] + (u64)(g2 / a.ntiles) * bsb[t] + 16ull * (u64)((g2 % a.ntiles) * BN); \
+                const int wslot = dslot == 2 ? 0 : dslot + 1;   /* (dk + 1) % 3: neither the slot entered nor the one left */ \
+                tabs[wslot * MAXC + t] = rel[t] + (u64)(g2 / a.ntiles) * bsb[t] + 16ull * (u64)((g2 % a.ntiles) * BN); \
             }                                                                                       \
         }                                                                                           \
     } while (0)

@@ -1,4 +1,4 @@
-"""``_5_infer`` vocoder slot for the MI355X WaveGlow path.
+"""``_5_infer`` vocoder slot for the MI355X WaveGlow / WaveFlow paths.
 
 The reference server wires Tacotron2 -> a vocoder object through two call sites only
 (``/root/reference/CookieTTS/_5_infer/t2s_server/text2speech.py``):
@@ -7,44 +7,101 @@ The reference server wires Tacotron2 -> a vocoder object through two call sites 
   * ``dtype = next(self.vocoder.parameters()).dtype``;
     ``self.vocoder(mel[b<=16, n_mel, T].to(dtype)).squeeze(1).cpu().split(1, 0)``   (:658-665)
 
-``WaveGlowVocoder`` satisfies that contract on top of ``cookietts_amd.WaveGlow`` (``forward(mel) -> [b, 1, T*hop]``,
-``parameters()`` report the compute dtype's natural input dtype), and ``load_waveglow`` mirrors ``load_hifigan``:
-it reads a reference-format WaveGlow checkpoint (``{'model', 'waveglow_config', 'speaker_lookup', ...}``,
-``_4_mtw/waveglow/train.py:128-145``, including the legacy key renames of :121) and returns ``(vocoder, config)``.
+``WaveGlowVocoder`` satisfies that contract (``forward(mel) -> [b, 1, samples]``, ``parameters()`` report the dtype the
+server casts its mels to) and ``load_waveglow`` mirrors ``load_hifigan``: it reads a reference-format checkpoint
+(``{'model', 'waveglow_config', 'speaker_lookup', ...}``, ``_4_mtw/waveglow/train.py:128-145``, including the legacy key
+renames of :121) and returns ``(vocoder, config)``.
+
+Which class a checkpoint builds follows its ``waveglow_config``, as the reference's own trainer does
+(``train.py:385-394``): that file hard-codes ``ax = True``, so every checkpoint cookietts trains carries the option set
+of ``efficient_model_ax.WaveGlow`` (``upsample_first``, ``speaker_embed``, ``cond_layers``, ``waveflow`` ...:
+efficient_model_ax.py:18-19) and builds ``cookietts_amd.waveglow_ax.WaveGlow`` (WaveFlow or the 1-D ax WaveGlow);
+a config with only ``glow.py``'s thirteen keys (glow.py:225-226) builds ``cookietts_amd.WaveGlow``.
 """
 from __future__ import annotations
 
 import torch
 
 from .waveglow import WaveGlow
+from .waveglow_ax import WaveGlow as WaveGlowAx
 
-__all__ = ["WaveGlowVocoder", "load_waveglow", "waveglow_from_checkpoint"]
+__all__ = ["WaveGlowVocoder", "load_waveglow", "waveglow_from_checkpoint", "is_ax_config"]
+
+# keyword arguments only efficient_model_ax.WaveGlow.__init__ has (efficient_model_ax.py:18-19): the first five are
+# REQUIRED there, so every config written for the ax core names them; the rest are its optional extras
+_AX_ONLY_KEYS = ("upsample_first", "speaker_embed", "cond_layers", "cond_hidden_channels", "cond_output_channels",
+                 "cond_kernel_size", "cond_residual", "cond_padding_mode", "waveflow", "channel_mixing", "mix_first",
+                 "preceived_vol_scaling", "shift_spect", "scale_spect", "preempthasis", "use_logvar_channels",
+                 "transposed_conv_scales", "group_conv_output_dim", "iso226_empthasis", "sampling_rate")
+
+
+def is_ax_config(cfg: dict) -> bool:
+    """True when ``waveglow_config`` is written for efficient_model_ax.WaveGlow (what train.py:385-388 builds)."""
+    return any(k in cfg for k in _AX_ONLY_KEYS)
 
 
 class WaveGlowVocoder(torch.nn.Module):
-    def __init__(self, waveglow: WaveGlow, sigma: float = 0.8):
+    """``vocoder(mel)`` as text2speech.py:661-665 calls it, over either model family.
+
+    * glow.py model: ``WaveGlow.infer(mel, sigma)`` -> ``[b, 1, T*hop]`` (glow.py:314-350).
+    * ax model: ``WaveGlow.infer(mel, speaker_ids, sigma=sigma, return_CPU=False)`` -> ``[b, 1, (T-1)*hop]``: the ax
+      ``infer`` pads one frame and trims ``artifact_trimming * hop`` samples from what the padded mel produces
+      (efficient_model_ax.py:359-388); the audio stays on the device (the server's ``.cpu()`` at :665 moves it).
+
+    ``speaker_ids`` (internal ids, as the model's embedding tables index them) is needed by checkpoints trained with a
+    speaker embedding; ``speaker_lookup`` is the checkpoint's external-id -> internal-id table (train.py:140, used as
+    train.py:248 does) and ``speaker_ids_for`` applies it.  ``noise`` replaces the internally drawn latent (already
+    multiplied by sigma; the tests' deterministic entry) - shape ``[b, samples + hop]`` for an ax model,
+    ``[b, n_group, T*hop/n_group]`` for a glow.py model.
+    """
+
+    def __init__(self, waveglow, sigma: float = 0.8, speaker_lookup=None):
         super().__init__()
         self.waveglow = waveglow
         self.sigma = sigma
+        self.is_ax = isinstance(waveglow, WaveGlowAx)
+        self.speaker_lookup = dict(speaker_lookup or {})
+
+    def speaker_ids_for(self, external_ids):
+        """External speaker ids (dataset ids, train.py:248) -> a LongTensor of the model's internal ids."""
+        try:
+            return torch.tensor([self.speaker_lookup[int(i)] for i in external_ids], dtype=torch.int64)
+        except KeyError as e:
+            raise KeyError(f"speaker id {e.args[0]} is not in the checkpoint's speaker_lookup") from None
 
     @torch.no_grad()
-    def forward(self, mel):
-        """mel [b, n_mel, T] -> audio [b, 1, T*hop] on the model's device, in mel's dtype."""
-        audio = self.waveglow.infer(mel.to(next(self.waveglow.parameters()).device), sigma=self.sigma)
+    def forward(self, mel, speaker_ids=None, noise=None):
+        """mel [b, n_mel, T] -> audio [b, 1, samples] on the model's device, in mel's dtype."""
+        device = next(self.waveglow.parameters()).device
+        mel = mel.to(device)
+        if speaker_ids is not None:
+            speaker_ids = torch.as_tensor(speaker_ids).to(device)
+        if self.is_ax:
+            if noise is None:
+                audio = self.waveglow.infer(mel, speaker_ids=speaker_ids, sigma=self.sigma, return_CPU=False)
+            else:
+                audio = self.waveglow.infer_from_noise(mel, noise, speaker_ids=speaker_ids, return_CPU=False)
+        elif noise is None:
+            audio = self.waveglow.infer(mel, speaker_id=speaker_ids, sigma=self.sigma)
+        else:
+            audio = self.waveglow.infer_from_noise(mel, noise, speaker_id=speaker_ids).to(mel.dtype)
         return audio.unsqueeze(1)
 
     def half(self):
         """``load_hifigan`` calls ``vocoder.half()`` (text2speech.py:261): the WN stacks then run on IEEE-half storage and
         fp16 MFMA with fp32 accumulation (``set_compute_dtype(torch.float16)``, the reference's own half mode, inside the
         1e-3 waveform bound) from fp32 master weights - the parameters, and hence the dtype the server casts its mels to,
-        stay fp32.  (Until round 5 this selected the bf16 path: same speed, 8x the error.)"""
-        self.waveglow.set_compute_dtype(torch.float16)
+        stay fp32.  Models without a reduced-precision path (WaveFlow: 64-channel, latency-bound layers that gain nothing
+        from half storage) keep computing in fp32."""
+        if hasattr(self.waveglow, "set_compute_dtype"):
+            self.waveglow.set_compute_dtype(torch.float16)
         return self
 
 
-def waveglow_from_checkpoint(checkpoint: dict) -> WaveGlow:
+def waveglow_from_checkpoint(checkpoint: dict):
+    """Build the class the checkpoint's ``waveglow_config`` was written for and load its ``model`` state dict."""
     cfg = checkpoint['waveglow_config']
-    model = WaveGlow(**cfg)
+    model = WaveGlowAx(**cfg) if is_ax_config(cfg) else WaveGlow(**cfg)
     sd = checkpoint['model']
     sd = {k.replace("invconv1x1", "convinv").replace(".F.", ".WN.").replace("WNs.", "WN."): v for k, v in sd.items()}
     model.load_state_dict(sd)
@@ -64,4 +121,5 @@ def load_waveglow(vocoder_path, device='cuda', sigma=0.8, trust_checkpoint=False
             raise
         checkpoint = torch.load(vocoder_path, map_location='cpu', weights_only=False)
     model = waveglow_from_checkpoint(checkpoint).to(device).eval()
-    return WaveGlowVocoder(model, sigma=sigma), checkpoint['waveglow_config']
+    vocoder = WaveGlowVocoder(model, sigma=sigma, speaker_lookup=checkpoint.get('speaker_lookup'))
+    return vocoder, checkpoint['waveglow_config']

@@ -867,16 +867,20 @@ class WaveGlow(nn.Module):
             audio = audio.cpu()
         return audio, None
 
-    @torch.no_grad()
-    def infer(self, spect, speaker_ids=None, artifact_trimming=1, sigma=1., t_scaler=1.0, return_CPU=True):
-        """efficient_model_ax.py:359-388."""
-        input_dtype = spect.dtype
+    def _prep_spect(self, spect, artifact_trimming):
         p = next(self.parameters())
         spect = spect.to(p.device, p.dtype)
         if spect.dim() == 2:
             spect = spect[None, ...]
         if artifact_trimming > 0:
             spect = F.pad(spect, (0, artifact_trimming), value=0.0)
+        return spect
+
+    @torch.no_grad()
+    def infer(self, spect, speaker_ids=None, artifact_trimming=1, sigma=1., t_scaler=1.0, return_CPU=True):
+        """efficient_model_ax.py:359-388."""
+        input_dtype = spect.dtype
+        spect = self._prep_spect(spect, artifact_trimming)
         batch_dim, _, steps = spect.shape
         samples = (steps - 1) * self.hop_length * t_scaler
         samples = int(samples - (samples % self.n_group))
@@ -886,6 +890,21 @@ class WaveGlow(nn.Module):
         else:
             z.zero_()
         audio, _ = self.inverse(z, spect, speaker_ids, return_CPU=return_CPU)
+        if artifact_trimming > 0:
+            audio = audio[:, :-artifact_trimming * self.hop_length]
+        return audio.to(input_dtype)
+
+    @torch.no_grad()
+    def infer_from_noise(self, spect, z_scaled, speaker_ids=None, artifact_trimming=1, return_CPU=True):
+        """Deterministic entry: ``infer`` (efficient_model_ax.py:359-388) with the latent it would draw at :376-378 given
+        by the caller - ``z_scaled`` [B, (F + artifact_trimming - 1) * hop - remainder], sigma already applied."""
+        input_dtype = spect.dtype
+        spect = self._prep_spect(spect, artifact_trimming)
+        samples = (spect.shape[2] - 1) * self.hop_length
+        samples -= samples % self.n_group
+        if tuple(z_scaled.shape) != (spect.shape[0], samples):
+            raise ValueError(f"z_scaled is {tuple(z_scaled.shape)}, this mel needs {(spect.shape[0], samples)}")
+        audio, _ = self.inverse(z_scaled, spect, speaker_ids, return_CPU=return_CPU)
         if artifact_trimming > 0:
             audio = audio[:, :-artifact_trimming * self.hop_length]
         return audio.to(input_dtype)

@@ -189,3 +189,25 @@ def test_gemm_mode_names_and_tuning_bits(hip_lib_path):
     for name, bit in _lib.TUNING_BITS.items():
         assert f"{bit} {name}" in hdr or name in hdr, name
     assert _lib.TUNING_BITS["CTTS_F32_NO_SPLITK"] == 11
+
+
+def test_checkpoint_config_selects_the_model_class():
+    """_4_mtw/waveglow/train.py:385-394: the trainer builds efficient_model_ax.WaveGlow (``ax = True``), so the checkpoints it
+    writes (train.py:128-145) carry that class's kwargs; a glow.py config has only glow.py:225-226's thirteen keys."""
+    from cookietts_amd.vocoder import is_ax_config, waveglow_from_checkpoint, WaveGlowVocoder
+    from cookietts_amd.waveglow_ax import WaveGlow as WaveGlowAx
+    for table, make, keys in ((synthetic.WAVEFLOW_CONFIGS, synthetic.waveflow_state_dict, ("toy", "author_toy")),
+                              (synthetic.WAVEGLOW_AX_CONFIGS, synthetic.waveglow_ax_state_dict, ("notebook_toy",))):
+        for key in keys:
+            cfg = table[key]
+            assert is_ax_config(cfg)
+            # legacy key spellings are renamed on load like train.py:121 does
+            sd = {k.replace("convinv", "invconv1x1", 1): v for k, v in synthetic.to_torch(make(cfg, seed=1)).items()}
+            m = waveglow_from_checkpoint({"model": sd, "waveglow_config": cfg})
+            assert isinstance(m, WaveGlowAx) and m.waveflow == bool(cfg.get("waveflow", True))
+            v = WaveGlowVocoder(m, speaker_lookup={11: 0, 12: 3})
+            assert v.is_ax and v.speaker_ids_for([12, 11]).tolist() == [3, 0]
+    cfg = synthetic.WAVEGLOW_CONFIGS["toy"]
+    assert not is_ax_config(cfg)
+    m = waveglow_from_checkpoint({"model": synthetic.to_torch(synthetic.waveglow_state_dict(cfg, seed=1)), "waveglow_config": cfg})
+    assert isinstance(m, WaveGlow) and not WaveGlowVocoder(m).is_ax

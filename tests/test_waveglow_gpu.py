@@ -320,6 +320,50 @@ def test_5_infer_vocoder_slot(hip_lib_path, tmp_path):
     assert rms_rel_err(audio16.cpu().numpy(), audio32.cpu().numpy()) < WAVE_TOL
 
 
+def _reference_format_checkpoint(path, cfg, sd, lookup):
+    """What _4_mtw/waveglow/train.py:128-145 writes (optimizer / scheduler states left out: the loader never reads them)."""
+    torch.save({"model": synthetic.to_torch(sd), "waveglow_config": cfg, "iteration": 7, "learning_rate": 1e-4,
+                "speaker_lookup": lookup}, path)
+
+
+@pytest.mark.parametrize("golden,table", [("waveflow_author_toy", "WAVEFLOW_CONFIGS"), ("waveflow_author_short", "WAVEFLOW_CONFIGS"),
+                                          ("waveglow_ax_notebook_toy", "WAVEGLOW_AX_CONFIGS"), ("waveglow_ax_notebook", "WAVEGLOW_AX_CONFIGS")])
+def test_5_infer_vocoder_slot_loads_the_checkpoints_cookietts_trains(hip_lib_path, tmp_path, golden, table):
+    """train.py:385-388 hard-codes the ax core, so a cookietts-trained vocoder checkpoint carries efficient_model_ax kwargs.
+    ``load_waveglow`` must build the ax class from it, and ``vocoder(mel)`` must be the reference's own ``infer`` of that
+    checkpoint: the author's WaveFlow option set and the inference notebook's 1-D ax WaveGlow against their reference goldens
+    (``audio`` = efficient_model_ax.WaveGlow.infer with artifact_trimming=1, [b, (F-1)*hop])."""
+    from cookietts_amd import load_waveglow
+    from cookietts_amd.waveglow_ax import WaveGlow as WaveGlowAx
+    g = np.load(os.path.join(GOLDEN, f"{golden}.npz"))
+    cfg = getattr(synthetic, table)[str(g["config_key"])]
+    make_sd = synthetic.waveflow_state_dict if table == "WAVEFLOW_CONFIGS" else synthetic.waveglow_ax_state_dict
+    sd = make_sd(cfg, seed=int(g["seed"]))
+    ext = [1000 + 7 * int(i) for i in g["speaker_ids"]]                       # dataset ids -> the model's internal ids
+    path = str(tmp_path / "ax_ckpt.pt")
+    _reference_format_checkpoint(path, cfg, sd, {e: int(i) for e, i in zip(ext, g["speaker_ids"])})
+    vocoder, vcfg = load_waveglow(path)
+    assert isinstance(vocoder.waveglow, WaveGlowAx) and vcfg["hop_length"] == cfg["hop_length"]
+    ids = vocoder.speaker_ids_for(ext)
+    assert ids.tolist() == [int(i) for i in g["speaker_ids"]]
+    mel = torch.from_numpy(g["mel"]).cuda()
+    vocoder_dtype = next(vocoder.parameters()).dtype                          # text2speech.py:661
+    audio = vocoder(mel.to(vocoder_dtype), speaker_ids=ids, noise=torch.from_numpy(g["z"]).cuda())
+    assert audio.is_cuda and tuple(audio.shape) == (mel.shape[0], 1, (mel.shape[2] - 1) * cfg["hop_length"])
+    err = rms_rel_err(audio.squeeze(1).cpu().numpy(), g["audio"])
+    print(f"{golden} through load_waveglow + vocoder(mel): rms rel err vs reference infer = {err:.3e}")
+    assert err < WAVE_TOL
+    # the server's call (no noise argument: the latent is drawn inside, efficient_model_ax.py:376-378) and its .half()
+    out = vocoder(mel, speaker_ids=ids).squeeze(1).cpu().split(1, dim=0)      # text2speech.py:664-665
+    assert len(out) == mel.shape[0] and torch.isfinite(out[0]).all() and out[0].shape == (1, g["audio"].shape[1])
+    vocoder.half()
+    assert next(vocoder.parameters()).dtype == torch.float32
+    audio_h = vocoder(mel, speaker_ids=ids, noise=torch.from_numpy(g["z"]).cuda())
+    assert rms_rel_err(audio_h.squeeze(1).cpu().numpy(), g["audio"]) < WAVE_TOL
+    with pytest.raises(KeyError):
+        vocoder.speaker_ids_for([5])
+
+
 def test_packed_weights_follow_parent_load_state_dict_and_in_place_updates(hip_lib_path):
     """A parent's load_state_dict never calls the child's override (it recurses through _load_from_state_dict):
     the packed blob must still be rebuilt, or the second checkpoint would silently play the first one's weights."""
