@@ -759,6 +759,9 @@ void load_tuning_locked() {
     g_tune.bf16_ps_stages = num("CTTS_BF16_PS_STAGES", 4) == 3 ? 3 : 4;
     g_tune.wf_no_fuse = on("CTTS_WF_NO_FUSE");
     g_tune.taco_no_fuse = on("CTTS_TACO_NO_FUSE");
+    g_tune.taco_valu = on("CTTS_TACO_VALU");
+    { const char* e = getenv("CTTS_TACO_BG_SHAPE"); g_tune.taco_bg_shape = e ? atoi(e) : 0; }
+    { const char* e = getenv("CTTS_TACO_BG_DEBUG"); g_tune.taco_bg_debug = e ? atoi(e) : 0; }
     {
         // measured: profiles/r5_59_taco_poll_delay.txt, r5_62 (0x10000 = straight to the full sweep; ctx: 128 is 0.3 us faster still but
         // 144 is already behind - the attention workgroups' answer must not beat the delay - so it stays a quarter below that edge)

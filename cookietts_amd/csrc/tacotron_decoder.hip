@@ -13,6 +13,7 @@
 //   energies are finite, so location conv, energies, softmax (wave-level reductions), context and the
 //   expected position are computed for the window only; weights outside it are exact zeros.
 #include "tacotron_plan.h"
+#include "taco_math.h"
 #include "tuning.h"
 
 namespace ctts {
@@ -779,6 +780,92 @@ LstmCall make_call(const float* blob, const size_t* off, const float* in0, int n
                     nullptr, none, pt, I, H, NB};
 }
 
+#include "tacotron_batched.h"
+
+// One decoder step of the batched form (4 < batch <= MAX_BATCH): seven dependent launches
+//   attention RNN (bg CELL) with the attention's part 1 as extra workgroups -> query rows (bg LINEAR) -> attention part 2 (one
+//   workgroup per item) -> decoder RNN -> second decoder RNN -> projection row set [mel | gate | first prenet layer] (bg PROJ)
+//   -> second prenet layer (bg PRENET2)
+int batched_steps(const DecPlan& p, const DecWs& w, const float* blob, const uint8_t* keep_masks, float* mel_out, float* gate_out,
+                  float* align_out, int batch, int text_len, int step0, int n_steps, int max_steps, hipStream_t s) {
+    const auto& c = p.c;
+    const int NB = ws_rows(p, batch);
+    const int Pn = c.prenet_dim, Ra = c.attention_rnn_dim, Rd = c.decoder_rnn_dim, Rd2 = c.second_decoder_rnn_dim, Dm = c.memory_dim;
+    const int shape = tuning().taco_bg_shape;
+    int rc;
+    for (int step = step0; step < step0 + n_steps; ++step) {
+        const int cur = step & 1, nxt = cur ^ 1;
+        AttnArgs at{};
+        at.Wq = blob + p.query_w; at.v = blob + p.v_w; at.Wloc = blob + p.loc_conv_w; at.Wd = blob + p.loc_dense_w;
+        at.scalars = blob + p.scalars;
+        at.att_h = w.att_h[nxt]; at.memory = w.memory; at.pm = w.pm;
+        at.w = w.w; at.cum = w.cum; at.ctx = w.ctx; at.pos = w.pos; at.align_out = align_out; at.lengths = w.lengths;
+        at.T = text_len; at.A = c.attention_dim; at.Ra = Ra; at.Dm = Dm;
+        at.F = c.location_n_filters; at.K = c.location_kernel_size; at.R = c.window_range;
+        at.step = step; at.max_steps = max_steps;
+        {   // attention RNN on [prenet | context | decoder hidden], recurrent on its own hidden state (model.py:707-717)
+            BgArgs a{};
+            a.W = blob + p.bg_att.off; a.rows = p.bg_att.rows; a.batch = batch;
+            bg_set_x(a, p.bg_att, w.prenet, Pn, w.ctx, Dm, w.dec_h[cur], Rd, w.att_h[cur], Ra);
+            a.bih = blob + p.att[2]; a.bhh = blob + p.att[3]; a.c = w.att_c; a.h_new = w.att_h[nxt]; a.H = Ra;
+            if ((rc = bg_launch_cell(a, NB, &at, w.apre, w.astart, batch, shape, s))) return rc;
+        }
+        {   // query rows (model.py:126)
+            BgArgs a{};
+            a.W = blob + p.bg_q.off; a.rows = p.bg_q.rows; a.batch = batch;
+            bg_set_x(a, p.bg_q, w.att_h[nxt], Ra, nullptr, 0, nullptr, 0, nullptr, 0);
+            a.y = w.qbuf; a.ldy = c.attention_dim;
+            if ((rc = bg_launch_small<BG_EPI_LINEAR>(a, NB, s))) return rc;
+        }
+        hipLaunchKernelGGL(attn_post_kernel, dim3(batch), dim3(256), 0, s, at, w.qbuf, w.apre, w.astart, tuning().taco_bg_debug);
+        CTTS_CHECK_LAUNCH("attn_post");
+        {   // decoder RNN on [attention hidden | context] (model.py:741-747)
+            BgArgs a{};
+            a.W = blob + p.bg_dec.off; a.rows = p.bg_dec.rows; a.batch = batch;
+            bg_set_x(a, p.bg_dec, w.att_h[nxt], Ra, w.ctx, Dm, w.dec_h[cur], Rd, nullptr, 0);
+            a.bih = blob + p.dec[2]; a.bhh = blob + p.dec[3]; a.c = w.dec_c; a.h_new = w.dec_h[nxt]; a.H = Rd;
+            if ((rc = bg_launch_cell(a, NB, nullptr, nullptr, nullptr, batch, shape, s))) return rc;
+        }
+        {   // second decoder RNN on the first one's output (model.py:749-755)
+            BgArgs a{};
+            a.W = blob + p.bg_d2.off; a.rows = p.bg_d2.rows; a.batch = batch;
+            bg_set_x(a, p.bg_d2, w.dec_h[nxt], Rd, w.d2_h[cur], Rd2, nullptr, 0, nullptr, 0);
+            a.bih = blob + p.d2[2]; a.bhh = blob + p.d2[3]; a.c = w.d2_c; a.h_new = w.d2_h[nxt]; a.H = Rd2;
+            if ((rc = bg_launch_cell(a, NB, nullptr, nullptr, nullptr, batch, shape, s))) return rc;
+        }
+        const unsigned char* keep = step + 1 < max_steps ? keep_masks + (size_t)(step + 1) * 2 * batch * Pn : nullptr;
+        {   // projection row set on [dec_h + d2_h | ctx] (model.py:755-765) + first prenet layer of the next step (:187-190)
+            BgArgs a{};
+            a.W = blob + p.bg_proj.off; a.rows = p.bg_proj.rows; a.batch = batch;
+            bg_set_x(a, p.bg_proj, w.dec_h[nxt], Rd, w.d2_h[nxt], Rd2, w.ctx, Dm, nullptr, 0);
+            a.bias = blob + p.pd_proj_b; a.keep = keep; a.mel_out = mel_out; a.gate_out = gate_out; a.act_out = w.h1;
+            a.n_mel = c.n_mel_channels; a.P = Pn; a.step = step; a.max_steps = max_steps;
+            if ((rc = bg_launch_small<BG_EPI_PROJ>(a, NB, s))) return rc;
+        }
+        if (keep) {   // second prenet layer
+            BgArgs a{};
+            a.W = blob + p.bg_w2.off; a.rows = p.bg_w2.rows; a.batch = batch;
+            bg_set_x(a, p.bg_w2, w.h1, Pn, nullptr, 0, nullptr, 0, nullptr, 0);
+            a.keep = keep; a.act_out = w.prenet; a.P = Pn;
+            if ((rc = bg_launch_small<BG_EPI_PRENET2>(a, NB, s))) return rc;
+        }
+    }
+    return CTTS_OK;
+}
+
+int bg_pack(float* dst, const BgMat& m, const BgSeg* segs, int nseg, int interleave_H, hipStream_t s) {
+    BgPackArgs a{};
+    for (int i = 0; i < nseg; ++i) a.seg[i] = segs[i];
+    a.nseg = nseg; a.rows = m.rows; a.tiles = m.tiles; a.nchunks = m.nchunks; a.interleave_H = interleave_H; a.dst = dst + m.off;
+    const size_t total = (size_t)m.tiles * m.nchunks * 256;
+    hipLaunchKernelGGL(bg_pack_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, s, a);
+    CTTS_CHECK_LAUNCH("bg_pack");
+    return CTTS_OK;
+}
+
+static_assert(AW == 33 && ADM == 512 && AAD == 256 && AF == 32 && AK == 31, "make_dec_plan's bg_ok restates these limits");
+bool bg_supported(const DecPlan& p) { return p.bg_ok; }
+
 }  // namespace
 }  // namespace ctts
 
@@ -844,15 +931,37 @@ int ctts_taco_decoder_pack(const ctts_taco_decoder_config* cfg, const ctts_taco_
                        c.prenet_dim, c.n_mel_channels, p.Dproj);
     CTTS_CHECK_LAUNCH("fold_prenet_proj");
     if ((rc = copy(p.pd_w2, w->prenet_w2, (size_t)c.prenet_dim * c.prenet_dim))) return rc;
+    if (p.bg_ok) {   // batched form: MFMA tiles (sources: the copies above, already in the blob)
+        const int Ra = c.attention_rnn_dim, Rd = c.decoder_rnn_dim, Rd2 = c.second_decoder_rnn_dim;
+        const BgSeg att[2] = {{blob + p.att[0], p.I_att, 0, p.I_att}, {blob + p.att[1], Ra, 0, Ra}};
+        const BgSeg dec[2] = {{blob + p.dec[0], p.I_dec, 0, p.I_dec}, {blob + p.dec[1], Rd, 0, Rd}};
+        const BgSeg d2[2] = {{blob + p.d2[0], p.I_d2, 0, p.I_d2}, {blob + p.d2[1], Rd2, 0, Rd2}};
+        const BgSeg q[1] = {{blob + p.query_w, Ra, 0, Ra}};
+        const BgSeg pr[3] = {{blob + p.pd_proj_w, p.Dproj, 0, Rd2}, {blob + p.pd_proj_w, p.Dproj, 0, Rd2},
+                             {blob + p.pd_proj_w, p.Dproj, Rd2, c.memory_dim}};
+        const BgSeg w2[1] = {{blob + p.pd_w2, c.prenet_dim, 0, c.prenet_dim}};
+        if ((rc = bg_pack(blob, p.bg_att, att, 2, Ra, s))) return rc;
+        if ((rc = bg_pack(blob, p.bg_dec, dec, 2, Rd, s))) return rc;
+        if ((rc = bg_pack(blob, p.bg_d2, d2, 2, Rd2, s))) return rc;
+        if ((rc = bg_pack(blob, p.bg_q, q, 1, 0, s))) return rc;
+        if ((rc = bg_pack(blob, p.bg_proj, pr, 3, 0, s))) return rc;
+        if ((rc = bg_pack(blob, p.bg_w2, w2, 1, 0, s))) return rc;
+    }
     const float sc[4] = {w->windowed_att_pos_offset, w->exp_smoothing_factor, 0.f, 0.f};
     CTTS_CHECK_HIP(hipMemcpyAsync(blob + p.scalars, sc, sizeof(sc), hipMemcpyHostToDevice, s));
     CTTS_CHECK_HIP(hipStreamSynchronize(s));     // `sc` is a stack temporary
     return CTTS_OK;
 }
 
+int32_t ctts_taco_decoder_max_batch(const ctts_taco_decoder_config* cfg) {
+    DecPlan p;
+    if (make_dec_plan(cfg, p)) return 0;
+    return bg_supported(p) ? MAX_BATCH : MAX_NB;
+}
+
 size_t ctts_taco_decoder_workspace_bytes(const ctts_taco_decoder_config* cfg, int32_t batch, int32_t text_len) {
     DecPlan p; DecWs w;
-    if (make_dec_plan(cfg, p) || batch < 1 || batch > MAX_NB || text_len < 1) return 0;
+    if (make_dec_plan(cfg, p) || batch < 1 || batch > (bg_supported(p) ? MAX_BATCH : MAX_NB) || text_len < 1) return 0;
     dec_carve(p, batch, text_len, nullptr, w);
     return w.total * sizeof(float);
 }
@@ -863,7 +972,8 @@ int ctts_taco_decoder_init_f32(const ctts_taco_decoder_config* cfg, const void* 
     DecPlan p; DecWs w;
     int rc = make_dec_plan(cfg, p); if (rc) return rc;
     CTTS_CHECK_ARG(packed && memory_in && lengths && workspace, "decoder init: NULL pointer");
-    CTTS_CHECK_ARG(batch >= 1 && batch <= MAX_NB, "decoder init: batch=%d (1..%d built)", batch, MAX_NB);
+    const int max_batch = bg_supported(p) ? MAX_BATCH : MAX_NB;
+    CTTS_CHECK_ARG(batch >= 1 && batch <= max_batch, "decoder init: batch=%d (1..%d built for this shape)", batch, max_batch);
     CTTS_CHECK_ARG(text_len >= 1, "decoder init: text_len=%d", text_len);
     dec_carve(p, batch, text_len, static_cast<float*>(workspace), w);
     if (w.total * sizeof(float) > workspace_bytes) {
@@ -892,9 +1002,16 @@ int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void*
     DecPlan p; DecWs w;
     int rc = make_dec_plan(cfg, p); if (rc) return rc;
     CTTS_CHECK_ARG(packed && keep_masks && mel_out && gate_out && align_out && workspace, "decoder steps: NULL pointer");
-    CTTS_CHECK_ARG(batch >= 1 && batch <= MAX_NB && step0 >= 0 && n_steps >= 0 && step0 + n_steps <= max_steps,
-                   "decoder steps: batch=%d step0=%d n_steps=%d max_steps=%d", batch, step0, n_steps, max_steps);
+    const int max_batch = bg_supported(p) ? MAX_BATCH : MAX_NB;
+    CTTS_CHECK_ARG(batch >= 1 && batch <= max_batch && step0 >= 0 && n_steps >= 0 && step0 + n_steps <= max_steps,
+                   "decoder steps: batch=%d (1..%d) step0=%d n_steps=%d max_steps=%d", batch, max_batch, step0, n_steps, max_steps);
     dec_carve(p, batch, text_len, static_cast<float*>(workspace), w);
+    // the batched MFMA form serves every batch it is built for: at batch <= 4 it is also ahead of the VALU kernels below (default
+    // widths 64 against 88 us/step, the non-default golden shape 43 against 63: profiles/r6_05), which stay as the form for shapes
+    // it does not take and, through CTTS_TACO_VALU, as an independent cross-check of both other forms
+    if (batch > MAX_NB || (bg_supported(p) && !tuning().taco_valu))
+        return batched_steps(p, w, static_cast<const float*>(packed), keep_masks, mel_out, gate_out, align_out, batch, text_len,
+                             step0, n_steps, max_steps, as_stream(stream));
     const auto& c = p.c;
     const int NB = pad_batch(batch);
     hipStream_t s = as_stream(stream);

@@ -30,6 +30,9 @@ struct Tuning {
     bool taco_poll_delay_set;
     int taco_poll_delay[6];  // CTTS_TACO_POLL_DELAY="a,c,d,e,h,p": persistent decoder, s_sleep(1) units before the first poll of the att_h, ctx, dec_h, d2_h, h1, prenet exchanges (+ 65536: no light phase, straight to the full sweep; default 65572,65632,65548,65556,65544,65544; all 0: the form before round 5)
     bool taco_no_fuse;     // CTTS_TACO_NO_FUSE: per-launch decoder without the fused projection kernel
+    int taco_bg_debug;     // CTTS_TACO_BG_DEBUG: timing experiments of attn_post_kernel (wrong results): 1 no tanh, 2 no context, 4 no alignment row, 8 no memory DMA, 16 empty
+    int taco_bg_shape;     // CTTS_TACO_BG_SHAPE=100 MTW + S: launch shape of the batched decoder's cell GEMMs (A/B; 0 = by batch)
+    bool taco_valu;        // CTTS_TACO_VALU: ctts_taco_decoder_steps_f32 at batch <= 4 on the VALU kernels of rounds 1-3 (six launches per step) instead of the batched MFMA form
     bool f32_no_defer_skip;  // CTTS_F32_NO_DEFER_SKIP: WaveGlow fp32 WN stack with one res/skip GEMM per layer (the form before round 4)
     bool wf_no_region_split; // CTTS_WF_NO_REGION_SPLIT: the fused WaveFlow layer as ONE launch per layer (no A | M | B regions on three streams)
     bool wf_no_row_queue;  // CTTS_WF_NO_ROW_QUEUE: never the one-launch-per-row work queue of the fused WaveFlow layers

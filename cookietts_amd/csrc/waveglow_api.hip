@@ -881,7 +881,8 @@ int ctts_tuning_flags(void) {
            (t.wf_no_vec_interp ? 4096 : 0) | (t.f32_no_defer_skip ? 8192 : 0) | (t.wf_no_region_split ? 16384 : 0) |
            (t.wf_no_row_queue ? 32768 : 0) | (t.wf_row_queue_min >= 0 ? 65536 : 0) | (t.wf_inject_abort ? 131072 : 0) |
            (t.wf_queue_debug ? 262144 : 0) | (t.f32_no_round_split ? 524288 : 0) | (t.bf16_ps ? (1 << 20) : 0) |
-           (t.bf16_no_ps ? (1 << 21) : 0) | (t.f32_splitk_w4 ? (1 << 22) : 0) | (t.taco_poll_delay_set ? (1 << 23) : 0);
+           (t.bf16_no_ps ? (1 << 21) : 0) | (t.f32_splitk_w4 ? (1 << 22) : 0) | (t.taco_poll_delay_set ? (1 << 23) : 0) |
+           (t.taco_valu ? (1 << 24) : 0);
 }
 
 int ctts_profile_create(void** handle) {

@@ -287,9 +287,14 @@ class Decoder(nn.Module):
             keep_masks = torch.as_tensor(keep_masks).to(device=device, dtype=torch.uint8).contiguous()
             assert keep_masks.shape[0] >= max_steps and tuple(keep_masks.shape[1:]) == (2, B, self.prenet_dim)
             keep_masks = keep_masks[:max_steps].contiguous()
-        # the device loop holds <= MAX_GROUP utterances per workspace: larger batches run as groups in lockstep (same
-        # chunk of steps for every group, then ONE stop-rule evaluation over the whole batch, like model.py:898-904)
-        groups = [(g0, min(g0 + MAX_GROUP, B)) for g0 in range(0, B, MAX_GROUP)]
+        # One workspace holds the whole batch where the library builds the batched MFMA form for this shape (up to 256 rows:
+        # what the server's simultaneous_texts x batch_size_per_text asks for, text2speech.py:418-424, 537, 554); batches of
+        # <= MAX_GROUP take the weight-resident persistent kernel.  Anything larger than the library's limit runs as groups in
+        # lockstep (same chunk of steps for every group, then ONE stop-rule evaluation over the whole batch, model.py:898-904)
+        per_ws = MAX_GROUP
+        if B >= BATCHED_FROM:
+            per_ws = max(MAX_GROUP, int(lib.ctts_taco_decoder_max_batch(C.byref(cfg))))
+        groups = [(g0, min(g0 + per_ws, B)) for g0 in range(0, B, per_ws)]
         key = (device, B, T)
         wss = self._ws.get(key)
         if wss is None:
@@ -418,7 +423,11 @@ class Decoder(nn.Module):
         return (mel[:, :, :n_total].contiguous(), torch.sigmoid(gate[:, :n_total]), align[:, :n_total].contiguous(), None)
 
 
-MAX_GROUP = 4      # utterances per decoder / packed-LSTM workspace (ctts_taco_decoder_*, ctts_lstm_seq_*: batch <= 4)
+MAX_GROUP = 4      # utterances per persistent-decoder / packed-LSTM workspace (ctts_taco_decoder_steps_persistent_f32, ctts_lstm_seq_*: batch <= 4)
+# batches from this size on decode in ONE workspace on the batched MFMA form (ctts_taco_decoder_max_batch rows at most); below it,
+# groups of MAX_GROUP on the persistent kernel.  Measured (profiles/r6_05): the batched step costs 63-64 us from 5 to 16 rows, a
+# persistent group of <= 4 rows 22 us - two groups (<= 8 rows) are ahead of one batched call, three are not
+BATCHED_FROM = int(os.environ.get("CTTS_TACO_BATCHED_FROM", "9"))
 PAD = 8            # halo of the padded [B][C][ld] layout used by the conv primitives (>= kernel_size // 2)
 
 

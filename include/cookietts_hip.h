@@ -480,6 +480,12 @@ typedef struct ctts_taco_decoder_weights {
 size_t ctts_taco_decoder_packed_bytes(const ctts_taco_decoder_config* cfg);
 int ctts_taco_decoder_pack(const ctts_taco_decoder_config* cfg, const ctts_taco_decoder_weights* w,
                            void* packed, void* stream);
+/* Largest batch one workspace / one ctts_taco_decoder_steps_f32 call takes for this shape: 256 where the batched MFMA form is
+ * built (every cell's K = I + H a multiple of 64, every state width a multiple of 16, the windowed attention's limits: window
+ * <= +-16, memory <= 512, attention dim <= 256, <= 32 location filters of <= 31 taps - the repo defaults and every checkpoint
+ * shape under tests/golden), else 4; 0 for an invalid config.  The reference's server decodes up to
+ * simultaneous_texts x batch_size_per_text = 256 rows per call (_5_infer/t2s_server/text2speech.py:418-424, 537, 554). */
+int32_t ctts_taco_decoder_max_batch(const ctts_taco_decoder_config* cfg);
 size_t ctts_taco_decoder_workspace_bytes(const ctts_taco_decoder_config* cfg, int32_t batch,
                                          int32_t text_len);
 /* Decoder.inference prologue (model.py:866-877): memory bottleneck, processed_memory, zero states.
@@ -491,7 +497,11 @@ int ctts_taco_decoder_init_f32(const ctts_taco_decoder_config* cfg, const void* 
 /* Run decoder steps [step0, step0 + n_steps) (model.py:879-883 body = prenet + decode()).
  *   keep_masks [max_steps][2][B][P] uint8: the prenet's always-on dropout keep-masks (model.py:189-190)
  *   mel_out [B][n_mel][max_steps], gate_out [B][max_steps] (logits), align_out [B][max_steps][text_len]
- * The stop rule (model.py:898-904) is evaluated by the caller on gate_out between calls. */
+ * The stop rule (model.py:898-904) is evaluated by the caller on gate_out between calls.
+ * Where ctts_taco_decoder_max_batch(cfg) is 256 every batch takes the batched form: seven launches per step with the cells /
+ * query / projection / prenet as MFMA GEMMs over the whole batch (v_mfma_f32_16x16x4_f32, weights streamed once per step
+ * whatever the batch: csrc/tacotron_batched.h).  Other shapes (batch <= 4 only), or CTTS_TACO_VALU: six launches per step on
+ * the VALU.  Same state layout in the workspace: the forms (and the persistent one below) can be mixed call by call. */
 int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void* packed,
                                 const uint8_t* keep_masks, float* mel_out, float* gate_out,
                                 float* align_out, int32_t batch, int32_t text_len, int32_t step0,
@@ -712,7 +722,8 @@ int ctts_tuning_reload(void);
  * 15 CTTS_WF_NO_ROW_QUEUE, 16 CTTS_WF_ROW_QUEUE_MIN set, 17 CTTS_WF_INJECT_ABORT, 18 CTTS_WF_QUEUE_DEBUG != 0, 19 CTTS_F32_NO_ROUND_SPLIT,
  * 20 CTTS_BF16_PS (persistent form of the skewed bf16 kernel on every wide launch), 21 CTTS_BF16_NO_PS, 22 CTTS_F32_SPLITK_W4 (per-layer
  * launches of the split-K shape on four waves per tile instead of eight: bit-identical), 23 CTTS_TACO_POLL_DELAY set ("a,c,d,e,h,p": 64-cycle units
- * before the first poll of the persistent decoder's six vector exchanges; timing only) (tests assert that a knob they set is the one in
+ * before the first poll of the persistent decoder's six vector exchanges; timing only), 24 CTTS_TACO_VALU
+ * (ctts_taco_decoder_steps_f32 at batch <= 4 on the VALU kernels instead of the batched MFMA form) (tests assert that a knob they set is the one in
  * effect). */
 int ctts_tuning_flags(void);
 

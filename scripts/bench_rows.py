@@ -221,8 +221,27 @@ def row_tacotron(args, vocoder=None):
     finally:
         wg.set_compute_dtype(torch.float32)
     samples = B * steps * 256
+    # the batch sizes the reference's server decodes per call (text2speech.py:418-424, 537, 554): one batched-form workspace
+    server = []
+    for Bs in (16, 64, 256):
+        mem_s = torch.from_numpy((rng.standard_normal((Bs, T, 1313)) * 0.5).astype(np.float32)).cuda()
+        lens_s = torch.full((Bs,), T, dtype=torch.int64).cuda()
+        ds = timed(lambda: m.decoder.inference(mem_s, lens_s, fixed_steps=256), 1, max(1, args.steps))
+        us = ds / 256 * 1e6
+        server.append({"batch": Bs, "us_per_step": us, "mel_frames_per_s": Bs * 256 / ds, "workspaces": len(next(iter(m.decoder._ws.values()))),
+                       # a step = one pass over the decoder's weights, whatever the batch; the batched form streams them
+                       "roofline": {"kernel": "bg_kernel<CELL> x 3 + query / projection / prenet GEMMs + attention (7 launches per step)",
+                                    "bound": "hbm", "achieved": weights_mb / 1e3 / (us * 1e-6), "peak": 8000.0, "unit": "GB/s",
+                                    "frac": weights_mb / 1e3 / (us * 1e-6) / 8000.0, "traffic": None}})
+        del mem_s
+    m.decoder._ws, m.decoder._xchg = {}, {}
     return {"row": "C/config5", "metric": "Tacotron2-TM decoder step time, B=4, 200 symbols, 900 forced steps",
             "value": dd / steps * 1e6, "unit": "us/step", "higher_is_better": False,
+            "server_batches": server,
+            # common schema (the headline's): SURVEY 8d's algorithmic bytes per step = one pass over the weights.  The persistent
+            # form keeps them on the CUs (0.78 MB fetched per step), so `achieved` is the rate a streaming step of this length would need
+            "roofline": {"kernel": "taco_persistent_kernel", "bound": "hbm", "achieved": weights_mb / 1e3 / (dd / steps), "peak": 8000.0,
+                         "unit": "GB/s", "frac": weights_mb / 1e3 / (dd / steps) / 8000.0, "traffic": 0.78e6},
             "mel_frames_per_s_batch": B * steps / dd, "end_to_end_ms_incl_encoder_postnet": dt * 1e3,
             "dtype": "f32", "decoder_form": m.decoder.persistent_state,
             # SURVEY 8d prices a step as one pass over the decoder's weights.  Since round 4 the persistent decoder keeps them in

@@ -551,6 +551,51 @@ def make_tacotron_long():
               f"max weight {align.max(-1).mean():.3f} -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def make_tacotron_batch8():
+    """Tacotron2.inference on EIGHT ragged utterances (more than the four one persistent-decoder workspace holds: the HIP side
+    decodes them as one batched MFMA call, csrc/tacotron_batched.h), 48 forced steps, the peaked attention recipe so that the
+    windows advance; texts of 12 and 20 symbols are shorter than the 33-token window (model.py:131-146 clamps)."""
+    torch.set_num_threads(8)
+    hp = synthetic.tacotron_hparams()
+    seed, n_steps, B, T_txt = 1234, 48, 8, 64
+    drive = TACOTRON_LONG["long_peaked"]
+    model, ref_model, sd = _ref_tacotron(hp, seed, attention_drive=drive)
+    lengths = np.array([64, 61, 50, 47, 33, 20, 12, 40], dtype=np.int64)
+    order = np.argsort(-lengths, kind="stable")                          # pack_padded_sequence wants them sorted (model.py:299)
+    lengths = lengths[order]
+    rng = np.random.default_rng(808)
+    text = rng.integers(1, hp.n_symbols, size=(B, T_txt)).astype(np.int64)
+    for b in range(B):
+        text[b, lengths[b]:] = 0
+    speakers = np.array([3, 1, 4, 1, 5, 9, 2, 6], dtype=np.int64)
+    tm = rng.standard_normal((B, hp.torchMoji_attDim)).astype(np.float32)
+    mask_seed = seed + 8
+    masks = synthetic.prenet_dropout_masks(n_steps, B, hp.prenet_dim, seed=mask_seed)
+    dec_mel = []
+    h2 = model.postnet.register_forward_pre_hook(lambda m, a: dec_mel.append(a[0].detach().clone()))
+    saved = ref_model.F.dropout
+    ref_model.F.dropout = _MaskedDropout(masks)
+    try:
+        model.decoder.max_decoder_steps = n_steps
+        model.decoder.gate_threshold = 2.0
+        with torch.no_grad():
+            out = model.inference(torch.from_numpy(text), torch.from_numpy(lengths), torch.from_numpy(speakers),
+                                  torch.from_numpy(tm))
+    finally:
+        ref_model.F.dropout = saved
+        h2.remove()
+    align = out["alignments"].numpy().astype(np.float32)
+    path = os.path.join(HERE, "tacotron_batch8.npz")
+    np.savez_compressed(path, seed=seed, mask_seed=mask_seed, n_steps=n_steps, attention_drive=np.array(drive, dtype=np.float32),
+                        text=text, lengths=lengths, speakers=speakers, torchmoji=tm,
+                        decoder_mel=dec_mel[0].numpy().astype(np.float32),
+                        pred_mel_postnet=out["pred_mel_postnet"].numpy().astype(np.float32),
+                        pred_gate=out["pred_gate"].numpy().astype(np.float32), alignments=align)
+    print(f"[golden] tacotron_batch8: postnet mel {tuple(out['pred_mel_postnet'].shape)}, mean max weight "
+          f"{align.max(-1).mean():.3f}, last-step arg-max per item {align[:, -1].argmax(-1).tolist()} -> "
+          f"{os.path.getsize(path) / 1024:.0f} KiB")
+
+
 # name -> (gate_threshold, gate_delay, max_decoder_steps) set on the decoder the way the server does (text2speech.py:410-412,457)
 TACOTRON_STOP_CASES = {
     "delay0": (0.5, 0, 200), "delay2": (0.5, 2, 200), "delay3": (0.5, 3, 200), "delay4": (0.5, 4, 200),
@@ -729,6 +774,8 @@ if __name__ == "__main__":
         make_tacotron_long()
     if "tacotron_stop" in which:
         make_tacotron_stop()
+    if "tacotron_batch8" in which:
+        make_tacotron_batch8()
     if "waveflow" in which:
         make_waveflow()
     if "waveglow" in which:

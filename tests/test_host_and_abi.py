@@ -145,12 +145,22 @@ def test_host_side_queries_of_the_other_families(hip_lib_path):
     assert lib.ctts_alignment_workspace_bytes(4, 900, 200) == (4 * 900 * 2 + 4 * 29 * 200) * 4
     assert lib.ctts_alignment_workspace_bytes(0, 900, 200) == 0
     assert lib.ctts_lstm_seq_workspace_bytes(512, 4, 256) > 0 and lib.ctts_lstm_seq_workspace_bytes(512, 5, 256) == 0
-    # Tacotron decoder: batch 1..4 per workspace
+    # Tacotron decoder: up to ctts_taco_decoder_max_batch rows per workspace - 256 where the batched MFMA form is built
+    # (every K a multiple of 64, every width of 16, the window kernel's limits), 4 otherwise; persistent form: <= 4 rows
     from cookietts_amd.tacotron2 import Tacotron2
     dc = Tacotron2(synthetic.tacotron_hparams()).decoder.c_config()
     assert lib.ctts_taco_decoder_packed_bytes(ctypes.byref(dc)) > 0
+    assert lib.ctts_taco_decoder_max_batch(ctypes.byref(dc)) == 256
     assert lib.ctts_taco_decoder_workspace_bytes(ctypes.byref(dc), 4, 200) > 0
-    assert lib.ctts_taco_decoder_workspace_bytes(ctypes.byref(dc), 5, 200) == 0
+    assert lib.ctts_taco_decoder_workspace_bytes(ctypes.byref(dc), 256, 200) > lib.ctts_taco_decoder_workspace_bytes(ctypes.byref(dc), 5, 200) > 0
+    assert lib.ctts_taco_decoder_workspace_bytes(ctypes.byref(dc), 257, 200) == 0
+    assert lib.ctts_taco_decoder_persistent_bytes(ctypes.byref(dc), 5, 200) == 0
+    small = Tacotron2(synthetic.tacotron_hparams(**synthetic.TACOTRON_SMALL_OVERRIDES)).decoder.c_config()
+    assert lib.ctts_taco_decoder_max_batch(ctypes.byref(small)) == 256      # the non-default golden checkpoint shape too
+    odd = Tacotron2(synthetic.tacotron_hparams()).decoder.c_config()
+    odd.prenet_dim = 200                                                    # K of the second prenet layer not a multiple of 64
+    assert lib.ctts_taco_decoder_max_batch(ctypes.byref(odd)) == 4
+    assert lib.ctts_taco_decoder_workspace_bytes(ctypes.byref(odd), 5, 200) == 0
 
 
 def test_gemm_mode_names_and_tuning_bits(hip_lib_path):

@@ -213,9 +213,12 @@ def test_oracle_full_model_matches_reference_golden():
 
 
 @pytest.mark.gpu
-def test_batches_larger_than_a_device_group_run_in_lockstep(hip_lib_path):
-    """The device loop holds 4 utterances per workspace; the host runs larger batches as groups that advance together
-    (one stop-rule evaluation over the whole batch, model.py:898-904).  7 utterances = groups of 4 + 3."""
+def test_batches_larger_than_a_device_group_run_in_lockstep(hip_lib_path, monkeypatch):
+    """A workspace of the persistent / VALU forms holds 4 utterances; batches beyond what one workspace takes run as groups
+    that advance together (one stop-rule evaluation over the whole batch, model.py:898-904).  7 utterances = groups of 4 + 3
+    here because the batched form (one workspace up to 256 rows: tests/test_tacotron_batched.py) is switched off."""
+    from cookietts_amd import tacotron2
+    monkeypatch.setattr(tacotron2, "BATCHED_FROM", 1 << 30)
     m, g, hp, sd = _model()
     B, T, n = 7, 37, 14
     rng = np.random.default_rng(77)
@@ -279,10 +282,14 @@ def test_persistent_decoder_size_query(hip_lib_path):
 
 
 @pytest.mark.gpu
-def test_persistent_decoder_equals_per_launch_decoder(hip_lib_path, monkeypatch):
-    """The persistent kernel (one launch per block of steps) and the six-launches-per-step form implement the same
-    arithmetic in different summation orders: same outputs to fp32 rounding, over a free-running decode that crosses
+@pytest.mark.parametrize("other", ["batched", "valu"])
+def test_persistent_decoder_equals_per_launch_decoder(hip_lib_path, tuning, other):
+    """The persistent kernel (one launch per block of steps) and the per-launch forms - the batched MFMA form (seven launches per
+    step: what ctts_taco_decoder_steps_f32 runs by default) and the VALU kernels (six launches, CTTS_TACO_VALU) - implement the
+    same arithmetic in different summation orders: same outputs to fp32 rounding, over a free-running decode that crosses
     several launch blocks, with ragged lengths, and for a batch of 1 (padded rows of the exchange stay zero)."""
+    if other == "valu":
+        tuning.set("CTTS_TACO_VALU")
     m, g, hp, sd = _model()
     rng = np.random.default_rng(11)
     for B, T, n in ((4, 200, 150), (1, 33, 40), (3, 64, 70)):
@@ -440,18 +447,22 @@ def test_non_default_hparams_build_the_reference_module_tree_and_match_the_oracl
 
 
 @pytest.mark.gpu
-def test_hip_non_default_hparams_match_reference_golden(hip_lib_path):
+@pytest.mark.parametrize("form", ["batched", "valu"])
+def test_hip_non_default_hparams_match_reference_golden(hip_lib_path, tuning, form):
     """Loads from a reference-format state dict and runs on the per-launch decoder (the persistent form is built for the
     default widths only and reports 0 bytes for this shape)."""
     from cookietts_amd import _lib
     from cookietts_amd.tacotron2 import Tacotron2
     import ctypes as C
+    if form == "valu":
+        tuning.set("CTTS_TACO_VALU")
     g, hp, sd, _ = _small()
     m = Tacotron2(hp)
     m.load_state_dict(synthetic.to_torch(sd))
     m = m.cuda().eval()
     cfg = m.decoder.c_config()
-    assert _lib.lib().ctts_taco_decoder_persistent_bytes(C.byref(cfg), 3, 40) == 0
+    assert _lib.lib().ctts_taco_decoder_persistent_bytes(C.byref(cfg), 3, 40) == 0      # persistent kernel: default widths only
+    assert _lib.lib().ctts_taco_decoder_max_batch(C.byref(cfg)) == 256                  # ... the batched form takes this shape
     n = g["masks"].shape[0]
     out = m.inference(torch.from_numpy(g["text"]).cuda(), torch.from_numpy(g["lengths"]).cuda(),
                       torch.from_numpy(g["speakers"]).cuda(), torch.from_numpy(g["torchmoji"]).cuda(),

@@ -140,14 +140,17 @@ def _model(sd, hp):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["persistent", "per_launch"])
+@pytest.mark.parametrize("form", ["persistent", "per_launch", "batched"])
 @pytest.mark.parametrize("name", ["long", "long_peaked", "long_sharp"])
-def test_hip_tacotron_matches_long_goldens(hip_lib_path, name, form):
-    """Both forms of the decoder, the encoder at 200 ragged tokens, the memory assembly and the postnet against the
-    reference over 256 steps; the measured L_inf per 64-step band is printed and gated."""
+def test_hip_tacotron_matches_long_goldens(hip_lib_path, tuning, name, form):
+    """All three forms of the decoder (batched: the MFMA form of batch > 4, here on one 16-item column tile with 12 padding
+    columns), the encoder at 200 ragged tokens, the memory assembly and the postnet against the reference over 256 steps; the
+    measured L_inf per 64-step band is printed and gated."""
     g, hp, sd, masks, n = _load(name)
     m = _model(sd, hp)
     m.decoder.use_persistent = form == "persistent"
+    if form == "per_launch":
+        tuning.set("CTTS_TACO_VALU")
     out = m.inference(torch.from_numpy(g["text"]).cuda(), torch.from_numpy(g["lengths"]).cuda(),
                       torch.from_numpy(g["speakers"]).cuda(), torch.from_numpy(g["torchmoji"]).cuda(),
                       keep_masks=masks, fixed_steps=n)

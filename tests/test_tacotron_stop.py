@@ -74,13 +74,15 @@ def _model(sd, hp):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["persistent", "per_launch"])
-def test_hip_stop_rule_ends_the_loop_where_the_reference_does(hip_lib_path, form):
+@pytest.mark.parametrize("form", ["persistent", "per_launch", "batched"])
+def test_hip_stop_rule_ends_the_loop_where_the_reference_does(hip_lib_path, tuning, form):
     """Tacotron2.inference with the stop rule live (no ``fixed_steps``): T_mel bit-exact in all nine cases, outputs within
-    1e-4 of the reference's, both forms of the decoder."""
+    1e-4 of the reference's, all three forms of the decoder (batched = the MFMA form of batch > 4, forced here at B = 4)."""
     g, hp, sd, masks, cases = _load()
     m = _model(sd, hp)
     m.decoder.use_persistent = form == "persistent"
+    if form == "per_launch":
+        tuning.set("CTTS_TACO_VALU")
     args = [torch.from_numpy(g[k]).cuda() for k in ("text", "lengths", "speakers", "torchmoji")]
     for name, (thr, delay, cap, T) in cases.items():
         m.decoder.gate_delay = int(delay)                   # text2speech.py:410
