@@ -35,7 +35,7 @@ typedef unsigned bg_u4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) bg_u4* bg_gptr;
 typedef __attribute__((address_space(3))) bg_u4* bg_lptr;
 
-enum { BG_EPI_CELL = 0, BG_EPI_LINEAR = 1, BG_EPI_PROJ = 2, BG_EPI_PRENET2 = 3 };
+enum { BG_EPI_CELL = 0, BG_EPI_LINEAR = 1, BG_EPI_PROJ = 2, BG_EPI_PRENET2 = 3, BG_EPI_SEQ = 4 };
 
 struct BgSeg { const float* ptr; int ld, col0, width; };   // pack time: `width` columns of a row-major matrix from column col0
 struct BgPiece { const float* ptr; int width; };            // run time: X piece, dense item-major [item][width]
@@ -48,6 +48,9 @@ struct BgArgs {
     int rows, batch;            // valid rows (the last tile may be padded), real items (columns beyond are padding)
     // BG_EPI_CELL: LSTMCell, gate order i, f, g, o; bias and state in the checkpoint / workspace layouts
     const float *bih, *bhh; float *c, *h_new; int H;
+    // BG_EPI_SEQ: one time step of a packed-sequence LSTM direction (the encoder's BiLSTM): the input projection of every
+    // step is precomputed (sq.gadd, biases included), item b is active while sq.step < lengths[b] (see LstmSeq)
+    LstmSeq sq; const float* h_old;
     // BG_EPI_LINEAR: y[item * ldy + row] = sum
     float* y; int ldy;
     // BG_EPI_PROJ: rows [0, n_mel) mel, n_mel gate, then the first prenet layer folded through the mel projection;
@@ -245,6 +248,27 @@ __device__ __forceinline__ void bg_body(const BgArgs& a, bg_u4* lds, int blk, in
             const float cy = fg * (first ? e_c : a.c[ix]) + ig * gg;
             a.c[ix] = cy;
             a.h_new[ix] = og * tanhf(cy);
+        } else if constexpr (EPI == BG_EPI_SEQ) {
+            const int unit = 4 * tile + j, H = a.H;
+            const LstmSeq& sq = a.sq;
+            const size_t ix = (size_t)it * H + unit;
+            const int len = sq.lengths[it];
+            if (sq.step < len) {
+                const int tb = sq.reverse ? len - 1 - sq.step : sq.step;
+                float pre[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    pre[g] = sum[g] + sq.gadd[(size_t)it * sq.ga_bstride + (size_t)(g * H + unit) * sq.ga_ld + sq.ga_pad + tb];
+                const float ig = bg_sigmoid(pre[0]), fg = bg_sigmoid(pre[1]), gg = tanhf(pre[2]), og = bg_sigmoid(pre[3]);
+                const float cy = fg * a.c[ix] + ig * gg;
+                const float hy = og * tanhf(cy);
+                a.c[ix] = cy;
+                a.h_new[ix] = hy;
+                sq.out[(size_t)it * sq.out_bstride + (size_t)tb * sq.out_tstride + sq.out_col + unit] = hy;
+                if (sq.step == len - 1) sq.hn[(size_t)it * sq.hn_stride + sq.hn_col + unit] = hy;
+            } else {
+                a.h_new[ix] = a.h_old[ix];
+            }
         } else {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
@@ -486,6 +510,14 @@ __global__ __launch_bounds__(WAVES * 64) void bg_cell_attn_kernel(const BgArgs a
 }
 
 // more than 64 KiB of dynamic LDS has to be allowed per kernel, once (per instantiation: the flag is a template static)
+// both directions of a bidirectional layer advance in ONE launch per time step (blockIdx.z = direction)
+template <int MTW, int NT, int S>
+__global__ __launch_bounds__(256) void bg_seq2_kernel(const BgArgs a0, const BgArgs a1) {
+    extern __shared__ __attribute__((aligned(16))) bg_u4 bg_lds[];
+    if (blockIdx.z == 0) bg_body<MTW, NT, S, 4, BG_EPI_SEQ>(a0, bg_lds, blockIdx.x, blockIdx.y);
+    else bg_body<MTW, NT, S, 4, BG_EPI_SEQ>(a1, bg_lds, blockIdx.x, blockIdx.y);
+}
+
 template <class K, K kernel>
 int bg_allow_lds(int bytes) {
     static bool done = false;
@@ -532,6 +564,24 @@ inline int bg_launch_cell(const BgArgs& a, int nb_pad, const AttnArgs* attn, flo
 #undef BG_TRY
     CTTS_CHECK_ARG(found, "batched decoder: cell shape MTW=%d NT=%d S=%d waves=%d is not instantiated", mtw, nt, st, wvs);
     CTTS_CHECK_LAUNCH("bg_cell");
+    return CTTS_OK;
+}
+
+// one time step of one (ndir = 1) or both directions of a packed-sequence LSTM over nb_pad items
+inline int bg_launch_seq(const BgArgs& a0, const BgArgs& a1, int ndir, int nb_pad, hipStream_t s) {
+    int rc;
+#define BG_SEQ(M, N, SS)                                                                                              \
+    {                                                                                                                 \
+        constexpr int LDS = bg_lds_bytes<M, N, SS, 4>();                                                              \
+        if ((rc = BG_ALLOW_LDS((bg_seq2_kernel<M, N, SS>), LDS))) return rc;                                          \
+        hipLaunchKernelGGL((bg_seq2_kernel<M, N, SS>), dim3((a0.tiles + M - 1) / M, nb_pad <= 32 ? 1 : nb_pad / 64, ndir), \
+                           dim3(256), LDS, s, a0, a1);                                                                \
+    }
+    if (nb_pad <= 16) BG_SEQ(1, 1, 8)
+    else if (nb_pad <= 32) BG_SEQ(2, 2, 5)
+    else BG_SEQ(2, 4, 4)
+#undef BG_SEQ
+    CTTS_CHECK_LAUNCH("bg_seq");
     return CTTS_OK;
 }
 

@@ -1110,7 +1110,7 @@ int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void*
 
 // ---- packed-sequence LSTM (encoder BiLSTM, model.py:299-309) ---------------------------------------
 namespace {
-struct SeqPlan { int I, H, mb, nch; size_t A, bias, whh, total; };
+struct SeqPlan { int I, H, mb, nch; size_t A, bias, whh, total; BgMat bg; bool bg_ok; };   // bg: W_hh as MFMA tiles, gate-interleaved (batch > 4)
 int make_seq_plan(int I, int H, SeqPlan& p) {
     CTTS_CHECK_ARG(I >= 16 && I % 16 == 0 && H >= 4 && H % 4 == 0, "lstm_seq: input_size=%d hidden_size=%d", I, H);
     p.I = I; p.H = H;
@@ -1120,6 +1120,12 @@ int make_seq_plan(int I, int H, SeqPlan& p) {
     p.A = take((size_t)p.mb * p.nch * 16 * 256);
     p.bias = take((size_t)p.mb * 256);
     p.whh = take((size_t)4 * H * H);
+    p.bg_ok = H % 64 == 0;
+    p.bg = BgMat{0, 0, 0, 0};
+    if (p.bg_ok) {
+        p.bg.rows = 4 * H; p.bg.tiles = 4 * H / BG_MT; p.bg.nchunks = H / BG_KC;
+        p.bg.off = take((size_t)p.bg.tiles * p.bg.nchunks * 256);
+    }
     p.total = o;
     return CTTS_OK;
 }
@@ -1142,11 +1148,16 @@ int ctts_lstm_seq_pack_f32(const ctts_lstm_weights* w, int32_t input_size, int32
     rc = launch_pack_bias(blob + p.bias, 256, p.mb, w->b_ih, 0, w->b_hh, 0, GEMM_EPI_SPLIT, 0, 4 * p.H, s);
     if (rc) return rc;
     CTTS_CHECK_HIP(hipMemcpyAsync(blob + p.whh, w->w_hh, (size_t)4 * p.H * p.H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (p.bg_ok) {
+        const BgSeg seg[1] = {{blob + p.whh, p.H, 0, p.H}};
+        if ((rc = bg_pack(blob, p.bg, seg, 1, p.H, s))) return rc;
+    }
     return CTTS_OK;
 }
 
 size_t ctts_lstm_seq_workspace_bytes(int32_t hidden_size, int32_t batch, int32_t ld) {
-    if (hidden_size < 4 || batch < 1 || batch > MAX_NB || ld < 4) return 0;
+    // batch <= 4: the VALU step kernels; up to MAX_BATCH where the recurrent GEMM runs on the batched MFMA form (H % 64 == 0)
+    if (hidden_size < 4 || batch < 1 || batch > (hidden_size % 64 == 0 ? MAX_BATCH : MAX_NB) || ld < 4) return 0;
     const size_t NB = pad_batch(batch);
     return (align_up((size_t)batch * 4 * hidden_size * ld) + 3 * align_up(NB * hidden_size)) * sizeof(float);
 }
@@ -1155,7 +1166,16 @@ namespace {
 // One direction of a packed-sequence LSTM, ready to step: workspace carved and zeroed, input projection launched.
 struct SeqDir {
     const float* whh; float *h0, *h1, *c; LstmSeq sq; int H, NB;
+    const float* bg_w; BgMat bg;       // batched form (batch > 4)
 };
+
+BgArgs seq_bg_args(const SeqDir& d, const float* hold, float* hnew, int batch) {
+    BgArgs a{};
+    a.W = d.bg_w; a.rows = d.bg.rows; a.batch = batch;
+    bg_set_x(a, d.bg, hold, d.H, nullptr, 0, nullptr, 0, nullptr, 0);
+    a.c = d.c; a.h_new = hnew; a.h_old = hold; a.H = d.H; a.sq = d.sq;
+    return a;
+}
 
 int seq_prepare(const void* packed, const float* x, const int32_t* lengths, int32_t reverse, float* out, int64_t out_bstride,
                 int32_t out_tstride, int32_t out_col, float* hn, int32_t hn_stride, int32_t hn_col, int32_t batch, int32_t T,
@@ -1164,7 +1184,8 @@ int seq_prepare(const void* packed, const float* x, const int32_t* lengths, int3
     SeqPlan p;
     int rc = make_seq_plan(input_size, hidden_size, p); if (rc) return rc;
     CTTS_CHECK_ARG(packed && x && lengths && out && hn && workspace, "lstm_seq: NULL pointer");
-    CTTS_CHECK_ARG(batch >= 1 && batch <= MAX_NB && T >= 1, "lstm_seq: batch=%d (1..%d) T=%d", batch, MAX_NB, T);
+    const int max_batch = p.bg_ok ? MAX_BATCH : MAX_NB;
+    CTTS_CHECK_ARG(batch >= 1 && batch <= max_batch && T >= 1, "lstm_seq: batch=%d (1..%d) T=%d", batch, max_batch, T);
     const int ntiles = (T + 127) / 128;
     CTTS_CHECK_ARG(ld % 4 == 0 && ntiles * 128 + 2 * pad <= ld, "lstm_seq: geometry T=%d ld=%d pad=%d", T, ld, pad);
     const size_t need = ctts_lstm_seq_workspace_bytes(hidden_size, batch, ld);
@@ -1176,6 +1197,7 @@ int seq_prepare(const void* packed, const float* x, const int32_t* lengths, int3
     d.h1 = d.h0 + align_up((size_t)NB * H);
     d.c = d.h1 + align_up((size_t)NB * H);
     d.whh = blob + p.whh; d.H = H; d.NB = NB;
+    d.bg_w = blob + p.bg.off; d.bg = p.bg;
     CTTS_CHECK_HIP(hipMemsetAsync(d.h0, 0, 3 * align_up((size_t)NB * H) * sizeof(float), s));
     // input projection for every time step: Xp[b][4H][t] = W_ih x_t + b_ih + b_hh
     GemmArgs a{};
@@ -1209,6 +1231,11 @@ int ctts_lstm_seq_f32(const void* packed, const float* x, const int32_t* lengths
         d.sq.step = step;
         float* hold = (step & 1) ? d.h1 : d.h0;
         float* hnew = (step & 1) ? d.h0 : d.h1;
+        if (batch > MAX_NB) {
+            const BgArgs a = seq_bg_args(d, hold, hnew, batch);
+            if ((rc = bg_launch_seq(a, a, 1, d.NB, s))) return rc;
+            continue;
+        }
         rc = launch_lstm_raw(d.NB, nullptr, d.whh, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, hold, hnew, d.c,
                              0, d.H, batch, d.sq, s);
         if (rc) return rc;
@@ -1231,7 +1258,15 @@ int ctts_lstm_biseq_f32(const void* packed_fwd, const void* packed_bwd, const fl
                      input_size, hidden_size, ld, pad, workspace_bwd, workspace_bytes, s, d[1]);
     if (rc) return rc;
     const LstmPart whole{nullptr, nullptr, 0, 0, 1};
-    for (int step = 0; step < T; ++step) {
+    for (int step = 0; step < T && batch > MAX_NB; ++step) {      // batched form: the recurrent product as an MFMA GEMM over the batch
+        BgArgs a[2];
+        for (int k = 0; k < 2; ++k) {
+            d[k].sq.step = step;
+            a[k] = seq_bg_args(d[k], (step & 1) ? d[k].h1 : d[k].h0, (step & 1) ? d[k].h0 : d[k].h1, batch);
+        }
+        if ((rc = bg_launch_seq(a[0], a[1], 2, d[0].NB, s))) return rc;
+    }
+    for (int step = 0; step < T && batch <= MAX_NB; ++step) {
         LstmCall q[2];
         for (int k = 0; k < 2; ++k) {
             d[k].sq.step = step;

@@ -619,8 +619,13 @@ class Encoder(nn.Module):
                 x = y
             lens = text_lengths.to(device=device, dtype=torch.int32).contiguous()
             row = memory_in.shape[2]
-            for g0 in range(0, B, MAX_GROUP):                  # the packed-sequence LSTM runs <= MAX_GROUP utterances per call
-                g1 = min(g0 + MAX_GROUP, B)
+            # the packed-sequence LSTM takes <= MAX_GROUP utterances per call on its VALU step kernels, up to 256 where the
+            # library runs the recurrent product as an MFMA GEMM over the batch (hidden size a multiple of 64)
+            per = MAX_GROUP
+            if B > MAX_GROUP and lib.ctts_lstm_seq_workspace_bytes(H, min(B, 256), ld) > 0:
+                per = 256
+            for g0 in range(0, B, per):
+                g1 = min(g0 + per, B)
                 nbytes = lib.ctts_lstm_seq_workspace_bytes(H, g1 - g0, ld)
                 if nbytes == 0:
                     raise _lib.HipLibraryError("lstm_seq workspace query failed: " + lib.ctts_last_error().decode())

@@ -562,7 +562,9 @@ int ctts_lstm_seq_pack_f32(const ctts_lstm_weights* w, int32_t input_size, int32
                            void* stream);
 size_t ctts_lstm_seq_workspace_bytes(int32_t hidden_size, int32_t batch, int32_t ld);
 /*   x [B][I][ld] padded; out[b][t][out_col + u] (row stride out_tstride, batch stride out_bstride) = h_t;
- *   hn[b][hn_col + u] (row stride hn_stride) = final hidden state; lengths int32 device; batch <= 4. */
+ *   hn[b][hn_col + u] (row stride hn_stride) = final hidden state; lengths int32 device.
+ *   batch <= 4: one VALU launch per time step; hidden_size % 64 == 0: batch <= 256, the recurrent product of a time step is an
+ *   MFMA GEMM over the batch (csrc/tacotron_batched.h, BG_EPI_SEQ) - ctts_lstm_seq_workspace_bytes answers 0 beyond that. */
 int ctts_lstm_seq_f32(const void* packed, const float* x, const int32_t* lengths, int32_t reverse, float* out,
                       int64_t out_bstride, int32_t out_tstride, int32_t out_col, float* hn, int32_t hn_stride,
                       int32_t hn_col, int32_t batch, int32_t T, int32_t input_size, int32_t hidden_size, int32_t ld,

@@ -144,7 +144,8 @@ def test_host_side_queries_of_the_other_families(hip_lib_path):
     # alignment scoring and packed-sequence LSTM workspaces
     assert lib.ctts_alignment_workspace_bytes(4, 900, 200) == (4 * 900 * 2 + 4 * 29 * 200) * 4
     assert lib.ctts_alignment_workspace_bytes(0, 900, 200) == 0
-    assert lib.ctts_lstm_seq_workspace_bytes(512, 4, 256) > 0 and lib.ctts_lstm_seq_workspace_bytes(512, 5, 256) == 0
+    assert lib.ctts_lstm_seq_workspace_bytes(512, 4, 256) > 0 and lib.ctts_lstm_seq_workspace_bytes(512, 256, 256) > 0      # batched MFMA steps: H % 64 == 0
+    assert lib.ctts_lstm_seq_workspace_bytes(512, 257, 256) == 0 and lib.ctts_lstm_seq_workspace_bytes(100, 5, 256) == 0 and lib.ctts_lstm_seq_workspace_bytes(100, 4, 256) > 0
     # Tacotron decoder: up to ctts_taco_decoder_max_batch rows per workspace - 256 where the batched MFMA form is built
     # (every K a multiple of 64, every width of 16, the window kernel's limits), 4 otherwise; persistent form: <= 4 rows
     from cookietts_amd.tacotron2 import Tacotron2
