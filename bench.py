@@ -57,7 +57,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
 # HBM bytes per in-layer launch from committed PMC passes (2 x FETCH_SIZE (gfx950 half-count correction,
 # calibrated on flow_tail) + WRITE_SIZE) of the exact launch shapes named in the file; not re-measured inside a bench run
 # (PMC collection needs its own rocprofv3 passes: scripts/pmc3.sh).
-TRAFFIC_FILES = ["r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r1_17_pmc_traffic.json"]
+TRAFFIC_FILES = ["r6_pmc_traffic.json", "r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r1_17_pmc_traffic.json"]
 
 
 def load_traffic():
@@ -85,7 +85,7 @@ def parse_args(argv=None):
                     help="mel frames per utterance of the concurrent-instances leg of the CPU baseline (the single-instance leg "
                          "runs --cpu-frames; the shorter utterance keeps the whole CPU part near 90 s; samples/s is what is "
                          "compared, and the WN convolutions are linear in the utterance length)")
-    ap.add_argument("--rows", default="config3,config3f16,bf16x6,config4,config5",
+    ap.add_argument("--rows", default="config3,config3f16,f16server,bf16x6,config4,config5",
                     help="N = 1 only: short secondary rows run AFTER the headline's timed region and attached to the JSON "
                          "line as \"rows\" (config3 = bf16 B=32, bf16x6 = six-product loop at the headline batch, config4 = "
                          "WaveFlow B=8 and B=1, config5 = Tacotron2 900 forced steps B=4 + chained vocoder); empty = none")
@@ -274,7 +274,8 @@ def wn_roofline(prof, cfg, dtype, gemm_mode, B, F, steps, elapsed, config_key="f
     kname = "conv_gemm_f32_kernel<GATE>" if dtype == "f32" else ("conv_gemm_bf16_pp_kernel<GATE, F16>" if dtype == "f16" else "conv_gemm_bf16_pp_kernel<GATE>")
     if dtype == "f32" and gemm_mode != "f32":
         kname, peak = f"conv_gemm_f32_kernel<GATE, X{products}>", BF16_MFMA_PEAK_TFLOPS
-    key = ("f32_" + gemm_mode) if (dtype == "f32" and gemm_mode != "f32") else ("bf16" if half else dtype)
+    # (the IEEE-half kernels have their own PMC entries: their traffic is not the bf16 instantiation's)
+    key = ("f32_" + gemm_mode) if (dtype == "f32" and gemm_mode != "f32") else dtype
     e = traffic.get(key)
     tbytes = e.get("hbm_bytes_per_launch") if (e and config_key == "full" and F == 900 and B == e.get("batch", 8)) else None
     roofline = {"kernel": kname + " (WN in-layer: dilated conv + cond + tanh*sigmoid)",
@@ -304,17 +305,29 @@ def wn_roofline(prof, cfg, dtype, gemm_mode, B, F, steps, elapsed, config_key="f
         # In bf16 the in-layer GEMM stays MFMA-bound (1430 FLOP/B vs a ridge of ~312); the memory-bound WN kernels are the
         # res GEMM (per layer: act read + x read-modify-write = 3*C*2 B per time step) and the deferred skip GEMM (4 act
         # reads + the skip sum written, and re-read by the second launch = 5.5*C*2 B per time step on average).
-        for key2, which, kname2, bpt in (
-                ("res_hbm", _lib.PROF_WN_RS, "conv_gemm_bf16_ps_kernel<SPLIT> (WN res 1x1: x += W_res act; persistent form)", 3.0),
-                ("skip_hbm", _lib.PROF_WN_SKIP, "conv_gemm_bf16_pp_kernel<SPLIT> (WN skip sum over 4 layers' act)", 5.5)):
-            if which in slots:
-                n2, mean2 = slots[which]
-                bytes2 = float(bpt * C * 2) * B * L
-                e2 = traffic.get("bf16_res" if key2 == "res_hbm" else "bf16_skip")
-                t2 = e2.get("hbm_bytes_per_launch") if (e2 and config_key == "full" and F == 900 and B == e2.get("batch")) else None
-                roofline[key2] = {"kernel": kname2, "bound": "hbm", "achieved": round(bytes2 / mean2 / 1e9, 1), "peak": 8000.0,
-                                  "unit": "GB/s", "frac": round(bytes2 / mean2 / 8e12, 4), "launches": n2,
-                                  "mean_launch_ms": round(mean2 * 1e3, 4), "bytes_per_launch": bytes2, "traffic": t2}
+        kt = "<SPLIT, F16>" if dtype == "f16" else "<SPLIT>"
+        if _lib.PROF_WN_RS in slots:
+            n2, mean2 = slots[_lib.PROF_WN_RS]
+            bytes2 = float(3.0 * C * 2) * B * L
+            e2 = traffic.get(dtype + "_res")
+            t2 = e2.get("hbm_bytes_per_launch") if (e2 and config_key == "full" and F == 900 and B == e2.get("batch")) else None
+            roofline["res_hbm"] = {"kernel": f"conv_gemm_bf16_ps_kernel{kt} (WN res 1x1: x += W_res act; persistent form)", "bound": "hbm",
+                                   "achieved": round(bytes2 / mean2 / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                   "frac": round(bytes2 / mean2 / 8e12, 4), "launches": n2, "mean_launch_ms": round(mean2 * 1e3, 4),
+                                   "bytes_per_launch": bytes2, "traffic": t2}
+        if _lib.PROF_WN_SKIP in slots:
+            # the deferred skip GEMM (K = 4 C over four layers' gated activations): 2 * C * 4C flop against 5.5 * C * 2 B per time
+            # step = 372 FLOP/B at C = 512, above the ~312 ridge: an MFMA-bound launch (it was priced against HBM until round 5)
+            n2, mean2 = slots[_lib.PROF_WN_SKIP]
+            flop2 = 2.0 * C * 4 * C * B * L
+            bytes2 = float(5.5 * C * 2) * B * L
+            e2 = traffic.get(dtype + "_skip")
+            t2 = e2.get("hbm_bytes_per_launch") if (e2 and config_key == "full" and F == 900 and B == e2.get("batch")) else None
+            roofline["skip_mfma"] = {"kernel": f"conv_gemm_bf16_pp_kernel{kt} (WN skip sum over 4 layers' act, K = 4 C)", "bound": "mfma",
+                                     "achieved": round(flop2 / mean2 / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
+                                     "frac": round(flop2 / mean2 / 1e12 / peak, 4), "launches": n2, "mean_launch_ms": round(mean2 * 1e3, 4),
+                                     "flop_per_launch_mean": flop2, "bytes_per_launch": bytes2,
+                                     "hbm_GBps_algorithmic": round(bytes2 / mean2 / 1e9, 1), "traffic": t2}
     else:
         deferred = _lib.PROF_WN_SKIP in slots
         if _lib.PROF_WN_RS in slots:
@@ -407,6 +420,24 @@ def run_rows(which, model, cfg, lib, args, device):
                          "config 3's shard on the same kernels with IEEE-half storage and v_mfma_f32_32x32x16_f16 (the reference's own "
                          "reduced-precision mode, glow.py:343): 8x closer to the fp32 reference than bf16, inside the 1e-3 bound")}
 
+    def f16_server():
+        """The shapes the _5_infer slot sees (text2speech.py:658-665: <= 16 mels per vocoder call, .half()): 80 x 900 at 1 / 4 / 16."""
+        out_rows = []
+        model.set_compute_dtype(torch.float16)
+        try:
+            for Bs in (1, 4, 16):
+                mel = torch.from_numpy(synthetic.synthetic_mel(Bs, F, seed=4400 + Bs)).to(device)
+                dt, out = timed_infer(mel, 5, 2)
+                roof = wn_roofline(prof, cfg, "f16", "f32", Bs, F, 5, dt, args.config)
+                out_rows.append({"batch": Bs, "ms_per_step": dt / 5 * 1e3, "samples_per_s": Bs * T * 5 / dt, "rtf": Bs * T * 5 / dt / 22050.0,
+                                 "roofline": roof})
+        finally:
+            model.set_compute_dtype(torch.float32)
+        return {"row": "A/f16 at the server's batch sizes", "metric": METRIC, "value": out_rows[0]["samples_per_s"], "unit": "samples/s (batch 1)",
+                "dtype": "f16", "frames": F, "steps": 5, "warmup": 2, "batches": out_rows,
+                "note": "WaveGlowVocoder.half() mode (IEEE-half storage + fp16 MFMA from fp32 masters, inside the 1e-3 waveform bound); one 80 x 900 "
+                        "utterance = 452 tiles of the 256 x 256 in-layer block on 256 CUs = 1.77 rounds: the launch runs two"}
+
     def bf16x6():
         mel = torch.from_numpy(synthetic.synthetic_mel(args.batch, F, seed=4322)).to(device)
         model.set_f32_gemm_mode("bf16x6")
@@ -425,6 +456,8 @@ def run_rows(which, model, cfg, lib, args, device):
             guard("A/config3", config3)
         elif name == "config3f16" and args.dtype == "f32":
             guard("A/config3f16", lambda: config3("f16"))
+        elif name == "f16server" and args.dtype == "f32":
+            guard("A/f16server", f16_server)
         elif name == "bf16x6" and args.dtype == "f32" and args.gemm_mode == "f32":
             guard("A/bf16x6", bf16x6)
         elif name == "config4":

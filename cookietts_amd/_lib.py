@@ -233,8 +233,6 @@ SIGNATURES = {
     "ctts_vol_unscale_f32": (C.c_int, [_FP, C.c_int64, _FP]),
     "ctts_resample_rows_f32": (C.c_int, [_FP, _FP] + [C.c_int32] * 9 + [C.c_float, _FP]),
     "ctts_interleave_phases_f32": (C.c_int, [_FP, _FP] + [C.c_int32] * 10 + [_FP]),
-    "ctts_set_f32_gemm_mode": (C.c_int, [C.c_int32]),
-    "ctts_get_f32_gemm_mode": (C.c_int, []),
     "ctts_last_gemm_loop": (C.c_int, []),
     "ctts_tuning_reload": (C.c_int, []),
     "ctts_tuning_flags": (C.c_int, []),
@@ -360,7 +358,7 @@ def lib():
                 raise HipLibraryError(f"{path} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
-        if handle.ctts_abi_version() != 6:
+        if handle.ctts_abi_version() != 7:
             raise HipLibraryError(f"ABI version mismatch: library reports {handle.ctts_abi_version()}")
         _LIB = handle
     return _LIB

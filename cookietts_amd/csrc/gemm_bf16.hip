@@ -97,6 +97,9 @@ int launch_gemm_bf16(int epi, const BGemmArgs& a, hipStream_t stream) {
     if (b.f16) {
         // IEEE-half operands: the default shapes only (the A/B knobs of the bf16 kernels other than PS / NO_PS / NO_WIDE do not apply)
         CTTS_CHECK_ARG(b.lo_off == 0, "gemm_bf16: the split (hi + lo) form exists for bf16 only");
+        // ... and a knob without an IEEE-half instantiation is refused, not ignored: an A/B run would compare two identical kernels
+        CTTS_CHECK_ARG(use_glds && !w4 && pp_stages != 4 && ps_stages != 3,
+                       "gemm_bf16: CTTS_BF16_NO_GLDS / _W4 / _PP_STAGES=4 / _PS_STAGES=3 select bf16-only kernels; unset them for the f16 path");
         const dim3 pg((unsigned)(ps_grid > 0 ? ps_grid : 1));
         if (epi == BGEMM_EPI_GATE) {
             if (ps && ps_grid >= 16 && b.nch_total > 4) hipLaunchKernelGGL((conv_gemm_bf16_ps_kernel<BGEMM_EPI_GATE, 4, 0, true>), pg, dim3(512), 0, stream, b);

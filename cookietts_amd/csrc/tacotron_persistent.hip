@@ -117,8 +117,17 @@ __device__ __forceinline__ void publish(u64* g, int idx, unsigned epoch, float v
 // early polls were the bound.)  The host fills the buffers with 0xFF before every launch.
 constexpr unsigned PD_SENT = 0xFFFFFFFFu;
 typedef __attribute__((address_space(1))) unsigned gu32w;
+// A value can never BE the sentinel: PD_SENT is a valid quiet NaN (sign set, full payload), and AMD's NaN propagation keeps an
+// input NaN's sign and payload - a 0xFF-filled or uninitialised weight / state buffer would publish exactly PD_SENT, every
+// consumer would spin to its timeout and the launch would abort instead of producing NaN frames like the other forms.
+__device__ __forceinline__ unsigned pd_bits(float v) {
+    const unsigned b = __float_as_uint(v);
+    return b == PD_SENT ? 0x7FC00000u : b;
+}
+// (The reset store of the other parity relies on a workgroup's stores to one address retiring in order - vmcnt, in-order
+// return of same-type memory operations - and on the exchanges in between: see the paragraph above.)
 __device__ __forceinline__ void publish_x(float* cur, float* oth, int idx, float v) {
-    __hip_atomic_store((gu32w*)cur + idx, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((gu32w*)cur + idx, pd_bits(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store((gu32w*)oth + idx, PD_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // the two parity buffers of an X vector of N values per item inside its exchange region (offset in u64 words)
@@ -399,7 +408,7 @@ __device__ __forceinline__ void pd_attention_post(const PdArgs& a, AttnLds& s, c
             const int d = 2 * t + k;
             const float c = c0[k] + c1[k];
             s.ctx[d] = c;
-            __hip_atomic_store((gu32w*)g_ctx + (b * PD_DM + d), __float_as_uint(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((gu32w*)g_ctx + (b * PD_DM + d), pd_bits(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     PD_STAMP(5);

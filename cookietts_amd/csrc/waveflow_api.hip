@@ -735,12 +735,31 @@ struct WfRegionSplit {
 };
 
 
-thread_local const void* t_wf_queued_ws = nullptr;          // workspace of this thread's last row-queue call, not yet checked
+// Row-queue calls of this thread whose status word has not been looked at yet: (workspace, event recorded behind the call's
+// last kernel).  A SET, not the last one: a thread that alternates two workspaces (two batch sizes, two models) must find
+// the first one's abort at its next call on THAT workspace; and the event, not the new call's stream, is what is waited for -
+// the earlier call may have run on another stream.
+struct WfPending {
+    static constexpr int N = 16;
+    const void* ws[N] = {};
+    unsigned int* st[N] = {};                               // the workspace's status word
+    hipEvent_t ev[N] = {};
+    unsigned long long age[N] = {};
+    unsigned long long clock = 0;
+    int find(const void* w) const {
+        for (int i = 0; i < N; ++i)
+            if (ws[i] == w) return i;
+        return -1;
+    }
+};
+thread_local WfPending t_wf_pending;
 
-// Synchronises `s`, reads the workspace's sticky status word and clears it: CTTS_E_ABORT (+ ctts_last_error) if a row-queue
-// call on this workspace gave up its bounded wait since the last report.
-int wf_report_abort(unsigned int* status, hipStream_t s) {
+// Reads the workspace's sticky status word and clears it: CTTS_E_ABORT (+ ctts_last_error) if a row-queue call on this
+// workspace gave up its bounded wait since the last report.  `done`: the event behind that call (waited for), or NULL (then
+// stream `s` is synchronised: the caller says the call ran there).
+int wf_report_abort(unsigned int* status, hipEvent_t done, hipStream_t s) {
     unsigned int host = 0;
+    if (done) CTTS_CHECK_HIP(hipEventSynchronize(done));
     CTTS_CHECK_HIP(hipMemcpyAsync(&host, status, sizeof host, hipMemcpyDeviceToHost, s));
     CTTS_CHECK_HIP(hipStreamSynchronize(s));
     if (host != WF_ABORT_MAGIC) return CTTS_OK;
@@ -749,6 +768,37 @@ int wf_report_abort(unsigned int* status, hipStream_t s) {
               "expired); that call's audio is NaN.  Repeat it - with CTTS_WF_NO_ROW_QUEUE=1 (one launch per layer) if it "
               "happens again");
     return CTTS_E_ABORT;
+}
+
+// the pending entry of `workspace`, if any, is checked and removed
+int wf_check_pending(const void* workspace, unsigned int* status, hipStream_t s) {
+    auto& pd = t_wf_pending;
+    const int i = pd.find(workspace);
+    if (i < 0) return CTTS_OK;
+    pd.ws[i] = nullptr;
+    return wf_report_abort(status, pd.ev[i], s);
+}
+
+// remember that `workspace` ran the row queue on `s`.  A full table gives up its oldest entry: that workspace's status is read
+// now (its call is long done) and an abort found there is reported by THIS call - late and against the wrong call, but not lost.
+int wf_note_pending(const void* workspace, unsigned int* status, hipStream_t s) {
+    auto& pd = t_wf_pending;
+    int i = pd.find(workspace);
+    int rc = CTTS_OK;
+    if (i < 0) i = pd.find(nullptr);
+    if (i < 0) {
+        i = 0;
+        for (int k = 1; k < WfPending::N; ++k)
+            if (pd.age[k] < pd.age[i]) i = k;
+        pd.ws[i] = nullptr;
+        rc = wf_report_abort(pd.st[i], pd.ev[i], s);
+    }
+    if (!pd.ev[i]) CTTS_CHECK_HIP(hipEventCreateWithFlags(&pd.ev[i], hipEventDisableTiming));
+    CTTS_CHECK_HIP(hipEventRecord(pd.ev[i], s));
+    pd.ws[i] = workspace;
+    pd.st[i] = status;
+    pd.age[i] = ++pd.clock;
+    return rc;
 }
 
 int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float* z, const float* cond, int cond_ld,
@@ -766,10 +816,7 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
     hipStream_t s = as_stream(stream);
     // the previous call of this thread on this workspace used the row queue: if it aborted, say so now instead of computing
     // on top of it (one stream synchronisation + 4 bytes; the caller sees CTTS_E_ABORT once, the call after that runs)
-    if (t_wf_queued_ws == workspace) {
-        t_wf_queued_ws = nullptr;
-        if ((rc = wf_report_abort(w.q.status, s))) return rc;
-    }
+    if ((rc = wf_check_pending(workspace, w.q.status, s))) return rc;
     const float* blob = static_cast<const float*>(packed);
     const int G = p.c.n_group, C = p.C, L = g.L, kh = p.c.kernel_size_h, kw = p.c.kernel_size_w;
     const int gkh = p.sep ? 1 : kh, gkw = p.sep ? 1 : kw;
@@ -1095,7 +1142,7 @@ int wf_inverse(const ctts_waveflow_config* cfg, const void* packed, const float*
         hipLaunchKernelGGL(wf_abort_poison_kernel, dim3(batch), dim3(256), 0, s, w.q.abort_word, audio, (long long)G * L,
                            w.q.status);
         CTTS_CHECK_LAUNCH("wf_abort_poison");
-        t_wf_queued_ws = workspace;                        // the thread's next call on this workspace looks at the status first
+        if ((rc = wf_note_pending(workspace, w.q.status, s))) return rc;   // this thread's next call on this workspace looks at the status first
     }
     return CTTS_OK;
 }
@@ -1196,8 +1243,14 @@ int ctts_waveflow_abort_status(const ctts_waveflow_config* cfg, int32_t batch, i
         set_error("waveflow abort_status: workspace %zu bytes < required %zu", workspace_bytes, w.total * sizeof(float));
         return CTTS_E_WORKSPACE;
     }
-    if (t_wf_queued_ws == workspace) t_wf_queued_ws = nullptr;
-    return wf_report_abort(w.q.status, as_stream(stream));
+    {   // the pending entry (if this thread has one) carries the event of the call in question; without one the caller's
+        // stream is what the call ran on
+        auto& pd = t_wf_pending;
+        const int i = pd.find(workspace);
+        hipEvent_t done = nullptr;
+        if (i >= 0) { pd.ws[i] = nullptr; done = pd.ev[i]; }
+        return wf_report_abort(w.q.status, done, as_stream(stream));
+    }
 }
 
 int ctts_waveflow_inverse_cond_f32(const ctts_waveflow_config* cfg, const void* packed, const float* z,

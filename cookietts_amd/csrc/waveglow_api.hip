@@ -60,7 +60,7 @@ int make_plan(const ctts_waveglow_config* cfg, Plan& p) {
     const auto& c = p.c;
     CTTS_CHECK_ARG(c.n_flows >= 1 && c.n_layers >= 1 && c.n_layers <= 12, "n_flows=%d n_layers=%d", c.n_flows, c.n_layers);
     CTTS_CHECK_ARG(gemm_mode_valid(c.f32_gemm_mode), "f32_gemm_mode=%d (CTTS_GEMM_DEFAULT / _F32 / _BF16X3 / _BF16X6)", c.f32_gemm_mode);
-    CTTS_CHECK_ARG(c.n_group >= 2 && c.n_group % 2 == 0 && c.n_group <= 8, "n_group=%d (even, <= 8)", c.n_group);
+    CTTS_CHECK_ARG(c.n_group >= 4 && c.n_group % 4 == 0 && c.n_group <= 16, "n_group=%d (4, 8, 12 or 16)", c.n_group);
     CTTS_CHECK_ARG(c.kernel_size == 3, "kernel_size=%d (only 3 built)", c.kernel_size);
     CTTS_CHECK_ARG(c.n_channels >= 128 && c.n_channels % 128 == 0, "n_channels=%d (multiple of 128)", c.n_channels);
     CTTS_CHECK_ARG(c.cond_hidden == GEMM_BM, "cond_hidden=%d (reference hard-codes 256)", c.cond_hidden);
@@ -860,17 +860,6 @@ int ctts_waveglow_infer_spk_f32(const ctts_waveglow_config* cfg, const void* pac
     return CTTS_OK;
 }
 
-int ctts_set_f32_gemm_mode(int32_t mode) {
-    // ABI 6: there is no process-wide default any more (hidden state shared by every model and thread of the process)
-    if (mode == CTTS_GEMM_DEFAULT || mode == CTTS_GEMM_F32) return CTTS_OK;
-    if (mode == CTTS_GEMM_BF16X3 || mode == CTTS_GEMM_BF16X6)
-        set_error("set_f32_gemm_mode: the process-wide default was removed in ABI 6; put CTTS_GEMM_* %d into the f32_gemm_mode "
-                  "field of the model's config struct", mode);
-    else
-        set_error("set_f32_gemm_mode: unknown mode %d (CTTS_GEMM_F32 = 1, CTTS_GEMM_BF16X3 = 2, CTTS_GEMM_BF16X6 = 3)", mode);
-    return CTTS_E_ARG;
-}
-int ctts_get_f32_gemm_mode(void) { return get_gemm_f32_mode(); }
 int ctts_last_gemm_loop(void) { return last_gemm_loop(); }
 int ctts_tuning_reload(void) { reload_tuning(); return CTTS_OK; }
 int ctts_tuning_flags(void) {
@@ -1008,6 +997,7 @@ static int infer_bf16_impl(const ctts_waveglow_config* cfg, const void* packed, 
     rc = make_geom(p, frames, g); if (rc) return rc;
     CTTS_CHECK_ARG(packed && packed_bf16 && mel && z_scaled && wave && workspace && batch >= 1, "infer_bf16: bad argument");
     CTTS_CHECK_ARG(p.C % BGEMM_KC == 0 && p.C <= 512, "infer_bf16: n_channels=%d (multiple of 32, <= 512)", p.C);
+    CTTS_CHECK_ARG(p.c.n_group <= 8, "infer_bf16: n_group=%d (the reduced-precision flow boundaries hold <= 8 channels; fp32 takes 16)", p.c.n_group);
     make_bf_plan(p, q, P, f16);
     carve_bf(p, g, batch, static_cast<char*>(workspace), w, P);
     if (w.total_bytes > workspace_bytes) {

@@ -69,13 +69,26 @@ class WaveGlowVocoder(torch.nn.Module):
         except KeyError as e:
             raise KeyError(f"speaker id {e.args[0]} is not in the checkpoint's speaker_lookup") from None
 
+    # lengths=: utterances whose length is within this factor of a bucket's longest share its call
+    RAGGED_BUCKET_RATIO = 0.85
+    RAGGED_MAX_BUCKETS = 4
+
     @torch.no_grad()
-    def forward(self, mel, speaker_ids=None, noise=None):
-        """mel [b, n_mel, T] -> audio [b, 1, samples] on the model's device, in mel's dtype."""
+    def forward(self, mel, speaker_ids=None, noise=None, lengths=None):
+        """mel [b, n_mel, T] -> audio [b, 1, samples] on the model's device, in mel's dtype.
+
+        ``lengths`` [b] (frames; the server has them: ``output_lengths``, text2speech.py:646, 677) makes the call ragged-aware: the
+        server pads every mel of a vocoder call to the longest with -11.52 (:651) and trims the audio afterwards (:677), so the
+        padding frames are computed and thrown away.  With lengths the batch is cut into <= 4 buckets of similar length, each
+        run at its own longest; every utterance's audio equals the reference's ``infer`` of a batch trimmed to that bucket
+        length (the receptive field sees zeros past the end instead of padding frames), the tail beyond
+        ``lengths[i] * hop`` is zero.  Without lengths: the reference's call, padding included."""
         device = next(self.waveglow.parameters()).device
         mel = mel.to(device)
         if speaker_ids is not None:
             speaker_ids = torch.as_tensor(speaker_ids).to(device)
+        if lengths is not None and noise is None and mel.dim() == 3 and mel.shape[0] > 1:
+            return self._forward_ragged(mel, speaker_ids, [int(x) for x in torch.as_tensor(lengths).reshape(-1).tolist()])
         if self.is_ax:
             if noise is None:
                 audio = self.waveglow.infer(mel, speaker_ids=speaker_ids, sigma=self.sigma, return_CPU=False)
@@ -86,6 +99,32 @@ class WaveGlowVocoder(torch.nn.Module):
         else:
             audio = self.waveglow.infer_from_noise(mel, noise, speaker_id=speaker_ids).to(mel.dtype)
         return audio.unsqueeze(1)
+
+    def _forward_ragged(self, mel, speaker_ids, lengths):
+        b, _, T = mel.shape
+        if len(lengths) != b or min(lengths) < 1 or max(lengths) > T:
+            raise ValueError(f"lengths {lengths} do not describe a [{b}, n_mel, {T}] batch")
+        order = sorted(range(b), key=lambda i: -lengths[i])
+        buckets = [[order[0]]]
+        for i in order[1:]:
+            head = lengths[buckets[-1][0]]
+            if lengths[i] >= self.RAGGED_BUCKET_RATIO * head or len(buckets) == self.RAGGED_MAX_BUCKETS:
+                buckets[-1].append(i)
+            else:
+                buckets.append([i])
+        out = None
+        for idx in buckets:
+            Tb = lengths[idx[0]]
+            sel = torch.tensor(idx, device=mel.device)
+            part = self.forward(mel.index_select(0, sel)[:, :, :Tb].contiguous(),
+                                None if speaker_ids is None else speaker_ids.index_select(0, sel))
+            if out is None:       # the longest bucket comes first: its sample count (glow.py: T hop; ax: (T - 1) hop) is the batch's
+                out = torch.zeros(b, 1, part.shape[2] + (T - Tb) * self.waveglow.hop_length, dtype=part.dtype, device=part.device)
+            out[sel, :, :part.shape[2]] = part
+        hop = self.waveglow.hop_length
+        for i in range(b):        # beyond an utterance's own frames: silence (the server trims there anyway)
+            out[i, :, lengths[i] * hop:] = 0
+        return out
 
     def half(self):
         """``load_hifigan`` calls ``vocoder.half()`` (text2speech.py:261): the WN stacks then run on IEEE-half storage and

@@ -117,6 +117,22 @@ class WaveGlow(nn.Module):
         if memory_efficient:
             raise NotImplementedError("memory_efficient builds no layers in the reference (glow.py:263)")
         assert n_group % 2 == 0
+        assert hop_length % n_group == 0 and win_length % hop_length == 0
+
+        # What glow.py:226-265 accepts and the HIP path does not build is refused HERE, where the user can see it (the
+        # library's own plan check, waveglow_api.hip make_plan, restates these and would otherwise speak at the first infer)
+        def need(cond, what):
+            if not cond:
+                raise NotImplementedError(f"cookietts_amd.WaveGlow (glow.py topology): {what} is not built on the HIP path")
+        wn = WN_config
+        need(n_group in (4, 8, 12, 16), f"n_group={n_group} (4, 8, 12 or 16: the un-squeeze writes whole float4s, the flow-boundary "
+             "kernels hold <= 8 half-channels)")
+        need(wn['kernel_size'] == 3, f"WN kernel_size={wn['kernel_size']} (3: the dilated in-layers are three K segments of one GEMM)")
+        need(wn['n_channels'] >= 128 and wn['n_channels'] % 128 == 0, f"WN n_channels={wn['n_channels']} (a multiple of 128: the GEMM's m-block)")
+        need(1 <= wn['n_layers'] <= 12, f"WN n_layers={wn['n_layers']} (1..12: dilation 2^11 is the largest halo)")
+        need((n_mel_channels * n_group) % 16 == 0, f"n_mel_channels * n_group = {n_mel_channels * n_group} (a multiple of 16: one K chunk)")
+        need(not wn['speaker_embed_dim'] or (n_mel_channels * n_group) % 32 == 0,
+             "a speaker embedding with n_mel_channels * n_group not a multiple of 32")
         self.spect_scaling = spect_scaling
         self.multispeaker = WN_config['speaker_embed_dim'] > 0
         self.n_mel_channels = n_mel_channels
@@ -207,6 +223,9 @@ class WaveGlow(nn.Module):
         weights (INTEGRATION.md)."""
         if dtype not in (torch.float32, torch.bfloat16, torch.float16, "bf16x3"):
             raise NotImplementedError(f"compute dtype {dtype} is not built (float32, bfloat16, float16 or 'bf16x3')")
+        if dtype != torch.float32 and self.n_group > 8:
+            raise NotImplementedError(f"reduced-precision compute with n_group={self.n_group}: the bf16 / f16 flow-boundary kernels hold "
+                                      "<= 8 channels (fp32 takes 16)")
         self._compute_dtype = dtype
         self._invalidate()
         return self

@@ -804,7 +804,7 @@ class WaveGlow(nn.Module):
             nbytes = lib.ctts_waveflow_workspace_bytes(C.byref(cfg), B, T)
             if nbytes == 0:
                 raise _lib.HipLibraryError("WaveFlow workspace query failed: " + lib.ctts_last_error().decode())
-            self._ws = {}
+            self._drop_workspaces()
             ws = self._ws.setdefault(key, torch.zeros(nbytes // 4, dtype=torch.float32, device=device))
         audio = torch.empty(B, T, dtype=torch.float32, device=device)
         with torch.cuda.device(device):
@@ -831,6 +831,21 @@ class WaveGlow(nn.Module):
                 _lib.check(lib.ctts_waveflow_abort_status(C.byref(cfg), B, T, _lib.ptr(ws), ws.numel() * 4, stream),
                            "WaveFlow.inverse")
         return audio, None
+
+    def _drop_workspaces(self):
+        """Forget the cached WaveFlow workspaces (another shape is coming) - but not an abort one of them still holds: a
+        row-queue call that stayed on the device (``return_CPU=False``) reports a given-up wait through the workspace's status
+        word, and dropping the workspace would drop the report.  Raises HipLibraryError (CTTS_E_ABORT) then."""
+        old, self._ws = self._ws, {}
+        if not self.waveflow:
+            return
+        lib = _lib.lib()
+        cfg = self.c_config()
+        for (device, B, T), ws in old.items():
+            with torch.cuda.device(device):
+                stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+                _lib.check(lib.ctts_waveflow_abort_status(C.byref(cfg), B, T, _lib.ptr(ws), ws.numel() * 4, stream),
+                           "WaveFlow.inverse (an earlier call on a workspace that is being replaced)")
 
     def _inverse_1d(self, z, cond, speaker_ids, return_CPU):
         """waveflow=False: efficient_model_ax.py:279-357 with AffineCouplingBlock + 1-D WN (ctts_wgax_inverse_f32)."""

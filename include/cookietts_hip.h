@@ -15,8 +15,13 @@
  *     enqueued asynchronously on it; no entry point synchronises.
  *   - Return value: 0 = ok, negative = error (CTTS_E_*); ctts_last_error() returns a
  *     thread-local human-readable message for the last failure on this thread.
- *   - No hidden global state: the immutable pair (config, packed weight blob) is the
- *     "plan"; calls are thread-safe per (workspace, stream).
+ *   - No hidden MODEL state: the immutable pair (config, packed weight blob) is the
+ *     "plan" - arithmetic mode, shapes and weights travel in it - and calls are thread-safe
+ *     per (workspace, stream).  Process-wide are only the A/B and timing knobs latched from
+ *     the environment at the first launch (ctts_tuning_reload / ctts_tuning_flags below:
+ *     launch shapes, the persistent decoder's poll delays - never arithmetic except where a
+ *     knob's line says "summation order"), and the profiling stamp buffer of
+ *     ctts_taco_decoder_persistent_debug.
  *
  * "Padded activation layout": internal activation tensors are [B][rows][ld] fp32 with
  * the L valid time steps of a row at columns [pad, pad+L) and zeros in the halo, so
@@ -39,7 +44,7 @@ extern "C" {
 #define CTTS_E_WORKSPACE (-3) /* workspace too small */
 #define CTTS_E_ABORT (-4)     /* an earlier call on this workspace gave up a bounded device-side wait (ABI 6; ctts_waveflow_abort_status) */
 
-#define CTTS_ABI_VERSION 6   /* 2: ctts_waveglow_config.speaker_embed_dim, ctts_waveglow_flow_weights.speaker_embed
+#define CTTS_ABI_VERSION 7   /* 2: ctts_waveglow_config.speaker_embed_dim, ctts_waveglow_flow_weights.speaker_embed
                               * 3: gated_unit / merge_res_skip in ctts_waveflow_config and ctts_wgax_config
                               * 4: f32_gemm_mode in ctts_waveglow_config, ctts_waveflow_config, ctts_wgax_config and
                               *    ctts_conv1d_desc (the arithmetic mode belongs to the model, not to the process);
@@ -51,7 +56,11 @@ extern "C" {
                               *    _collect(handle, ...) / _destroy replace ctts_profile_enable / _collect(which, ...)), a
                               *    row-queue abort is a status (CTTS_E_ABORT from the next ctts_waveflow_inverse_* on that
                               *    workspace, ctts_waveflow_abort_status) besides the NaN audio; IEEE-half variant of the
-                              *    reduced-precision WaveGlow path (ctts_waveglow_pack_flow_f16 / ctts_waveglow_infer_spk_f16) */
+                              *    reduced-precision WaveGlow path (ctts_waveglow_pack_flow_f16 / ctts_waveglow_infer_spk_f16)
+                              * 7: ctts_set_f32_gemm_mode / ctts_get_f32_gemm_mode are gone (dead since 6); the Tacotron decoder and
+                              *    the packed-sequence LSTM take batches up to 256 (ctts_taco_decoder_max_batch, the batched MFMA
+                              *    form: larger packed blobs and workspaces - re-query the *_bytes functions); glow.py-class
+                              *    WaveGlow: any hop_length, n_group 4 / 8 / 12 / 16 */
 
 /* Main loop of the fp32 conv-GEMM a model's launches use (field f32_gemm_mode of the config structs). */
 #define CTTS_GEMM_DEFAULT 0  /* the library default: fp32 MFMA */
@@ -311,8 +320,10 @@ size_t ctts_waveflow_workspace_bytes(const ctts_waveflow_config* cfg, int32_t ba
  * row during which no workgroup of the launch claimed an item - time without progress, not wall time); if it ever expires
  * every workgroup leaves, the call fills `audio` with NaN instead of returning plausible noise (stream-ordered, so THIS
  * call's status code cannot report it) and a sticky status word in the workspace is set: the calling thread's NEXT
- * ctts_waveflow_inverse_* on that workspace synchronises the stream first, returns CTTS_E_ABORT with ctts_last_error() text
- * and clears the word (the call after that runs normally); ctts_waveflow_abort_status asks at once.  NaN is also a legal
+ * ctts_waveflow_inverse_* on that workspace - whichever workspaces and streams it used in between: the thread keeps an
+ * event per not-yet-checked workspace (16 of them; beyond that the oldest is checked early and reported by the call that
+ * displaced it) - waits for that event first, returns CTTS_E_ABORT with ctts_last_error() text and clears the word (the call
+ * after that runs normally); ctts_waveflow_abort_status asks at once (a workspace about to be freed: ask before).  NaN is also a legal
  * output of this path (ignore_nan, ax:333-334) - the status, not the NaN, is what says "aborted".
  * CTTS_WF_NO_ROW_QUEUE = always one launch per layer.  The queue's control words and layer
  * descriptors live in the caller's workspace (included in ctts_waveflow_workspace_bytes); the descriptors reach it through a
@@ -704,14 +715,11 @@ int ctts_taco_stop_rule_f32(const float* gate_logits, int32_t batch, int32_t gat
  * thread ran, so that a benchmark row can label itself: bits 0-3 = split level (0 fp32 MFMA, 3, 6), bit 4 = small shape,
  * bit 5 = split-K shape, bit 6 = the WaveFlow row queue, bit 7 = its whole-flow form (one launch per flow, see ctts_waveflow_inverse_f32).
  *
- * REMOVED in ABI 6 - the process-wide default of ABI <= 5 (ctts_set_f32_gemm_mode): hidden state shared by every model and
- * thread of a process.  CTTS_GEMM_DEFAULT (0) in a config struct now always means fp32 MFMA, and so do the two entry points
- * without a config struct (ctts_lstm_seq_f32's input projection, ctts_taco_decoder_init_f32's processed memory).  The symbols
- * stay for old callers: set accepts CTTS_GEMM_DEFAULT / CTTS_GEMM_F32 (no-op) and fails with CTTS_E_ARG for the split modes,
- * get returns CTTS_GEMM_F32. */
+ * REMOVED: the process-wide default of ABI <= 5 (ctts_set_f32_gemm_mode / ctts_get_f32_gemm_mode; no-ops in ABI 6, gone in 7):
+ * hidden state shared by every model and thread of a process.  CTTS_GEMM_DEFAULT (0) in a config struct always means fp32
+ * MFMA, and so do the two entry points without a config struct (ctts_lstm_seq_f32's input projection,
+ * ctts_taco_decoder_init_f32's processed memory). */
 int ctts_last_gemm_loop(void);
-int ctts_set_f32_gemm_mode(int32_t mode);
-int ctts_get_f32_gemm_mode(void);
 
 /* Launch-shape overrides for A/B measurements (CTTS_F32_NO_GLDS, CTTS_F32_NO_SMALL, CTTS_F32_FORCE_SMALL, CTTS_GEMM_NO_XCD_PAIR, CTTS_BF16_NO_GLDS / _NO_WIDE /
  * _NO_PP / _W4 / _PP_STAGES / _PS / _NO_PS / _PS_STAGES / _MAP / _WIDE_MIN, CTTS_WF_NO_FUSE, CTTS_WF_NO_VEC_INTERP, CTTS_WF_NO_REGION_SPLIT, CTTS_WF_NO_ROW_QUEUE, CTTS_F32_NO_ROUND_SPLIT, CTTS_F32_SPLITK_W4, CTTS_TACO_POLL_DELAY, CTTS_TACO_NO_FUSE) never change results beyond the parity

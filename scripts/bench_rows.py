@@ -79,8 +79,11 @@ def row_waveflow(args):
                      # per row of the recurrence: start + tail + (row queue: ONE launch for the n_layers fused layers | one per layer)
                      "kernel_launches_per_utterance_batch": (2 * cfg["n_flows"] if "per flow" in loop else
                                                              ((1 if "row queue" in loop else wn["n_layers"]) + 2) * cfg["n_flows"] * (G - 1)),
-                     "achieved_tflops_algorithmic": 2 * mac * samples / dt / 1e12,
-                     "mfma_frac_algorithmic": 2 * mac * samples / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                     # common schema (the headline's): the fused WaveFlow layer kernels against the fp32 MFMA peak on SURVEY 8d's
+                     # algorithmic MACs per output sample; the survey's 138 KB-per-sample HBM denominator stays below as extra keys
+                     "roofline": {"kernel": "fused WaveFlow layer (" + loop + ")", "bound": "mfma",
+                                  "achieved": 2 * mac * samples / dt / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": 2 * mac * samples / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": None},
                      "last_gemm_loop": loop,
                      # 138 KB of per-layer-kernel traffic per output sample (2304 B per row, step, layer)
                      "achieved_GBps_vs_138KB_per_sample": 138e3 * samples / dt / 1e9,
@@ -180,7 +183,9 @@ def row_waveglow_ax_notebook(args):
                      "reference_published": {"eager_fp16_rtf_48k": 4.5977, "jit_fp16_rtf_48k": 5.1905, "batch": 1,
                                              "hardware": "not stated", "source": "BASELINE.md section 1"},
                      "vs_reference_eager": (samples / dt / 48000.0) / 4.5977 if B == 1 else None,
-                     "achieved_tflops_wn_gemms": flop / dt / 1e12})
+                     "roofline": {"kernel": "ax 1-D WN in-layer + res/skip conv-GEMMs", "bound": "mfma", "achieved": flop / dt / 1e12,
+                                  "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                  "traffic": None}})
     return rows
 
 
@@ -249,7 +254,6 @@ def row_tacotron(args, vocoder=None):
             # a STREAMING step would cost, not what this kernel moves - the step is bound by its seven all-gathers
             "decoder_weights_MB": weights_mb,
             "streaming_floor_us_per_step_at_8TBps": weights_mb / 1e3 / 8000.0 * 1e6,
-            "step_time_over_streaming_floor": (dd / steps * 1e6) / (weights_mb / 1e3 / 8000.0 * 1e6),
             "fetched_per_step_MB_pmc": 0.78 if m.decoder.persistent_state == "ok" else None,
             "fetched_per_step_source": "profiles/r4_09_pmc_config5_tacotron_resident.json (committed PMC pass, not re-measured in this run)",
             "chained_vocoder_samples_per_s": samples / dv, "chained_vocoder_ms": dv * 1e3,

@@ -112,7 +112,7 @@ def test_bench_defaults_and_profiler_guard(monkeypatch):
     sys.path.insert(0, REPO)
     import bench
     a = bench.parse_args([])
-    assert a.gpus == 1 and a.rows == "config3,config3f16,bf16x6,config4,config5" and not a.no_rows
+    assert a.gpus == 1 and a.rows == "config3,config3f16,f16server,bf16x6,config4,config5" and not a.no_rows
     assert a.cpu_frames == 900 and a.cpu_aggregate_frames == 300 and a.cpu_budget <= 30
     for k in list(os.environ):
         if k.startswith(("ROCPROF", "ROCP_")):

@@ -12,15 +12,12 @@ pytestmark = pytest.mark.gpu
 
 
 def test_there_is_no_process_wide_mode(hip_lib_path):
-    """ABI 6: the mode travels in each model's config struct only.  The old process-wide switch is
-    read-only: the C symbol refuses the split modes with an error text, the Python function raises."""
+    """The mode travels in each model's config struct only (ABI 6); the old process-wide switch is gone from the C ABI (ABI 7) and
+    the Python function of the same name raises for the split modes."""
     import cookietts_amd
     from cookietts_amd import _lib
     lib = _lib.lib()
-    assert lib.ctts_get_f32_gemm_mode() == 1 == _lib.MODEL_GEMM_MODES["f32"]
-    assert lib.ctts_set_f32_gemm_mode(2) != 0 and b"removed in ABI 6" in lib.ctts_last_error()
-    assert lib.ctts_set_f32_gemm_mode(7) != 0 and b"unknown mode" in lib.ctts_last_error()
-    assert lib.ctts_set_f32_gemm_mode(0) == 0 and lib.ctts_set_f32_gemm_mode(1) == 0 and lib.ctts_get_f32_gemm_mode() == 1
+    assert not hasattr(lib, "ctts_set_f32_gemm_mode") and _lib.MODEL_GEMM_MODES["f32"] == 1
     assert cookietts_amd.set_f32_gemm_mode("f32") == "f32"
     with pytest.raises(RuntimeError, match="model.set_f32_gemm_mode"):
         cookietts_amd.set_f32_gemm_mode("bf16x3")
@@ -102,7 +99,6 @@ def test_two_models_two_modes_interleaved_on_two_streams(hip_lib_path):
         err = rms_rel_err(alone[k].cpu().numpy(), g["wave"])
         print(f"{k}: rms rel err vs reference = {err:.3e}")
         assert err < (1e-5 if k == "f32" else 1e-4)
-    assert _lib.lib().ctts_get_f32_gemm_mode() == 1                              # CTTS_GEMM_F32: the process default untouched
     with pytest.raises(ValueError):
         models["f32"].set_f32_gemm_mode("tf32")
 

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(hip_lib_path):
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in include/cookietts_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == declared, "ctypes signature table out of sync with the header"
-    assert handle.ctts_abi_version() == 6
+    assert handle.ctts_abi_version() == 7
 
 
 def test_host_side_queries_run_without_gpu(hip_lib_path):
@@ -80,6 +80,18 @@ def test_unsupported_options_fail_loudly():
     m = WaveGlow(**dict(cfg, spect_scaling=True))
     with pytest.raises(NotImplementedError):
         m.infer_from_noise(torch.zeros(1, 80, 4), torch.zeros(1, 8, 128))  # parameters never created (glow.py:233-235)
+    # shapes glow.py:226-265 accepts and the HIP path does not build are refused at CONSTRUCTION, naming the option
+    wn = cfg["WN_config"]
+    for bad, word in ((dict(n_group=6, hop_length=300, win_length=1200), "n_group=6"), (dict(n_group=32), "n_group=32"),
+                      (dict(WN_config=dict(wn, kernel_size=5)), "kernel_size=5"), (dict(WN_config=dict(wn, n_channels=192)), "n_channels=192"),
+                      (dict(WN_config=dict(wn, n_layers=13)), "n_layers=13"), (dict(n_mel_channels=81), "n_mel_channels * n_group")):
+        with pytest.raises(NotImplementedError, match=re.escape(word)):
+            WaveGlow(**dict(cfg, **bad))
+    for ok in (dict(n_group=16, hop_length=512), dict(n_group=12, hop_length=300, win_length=1200), dict(n_group=4)):
+        WaveGlow(**dict(cfg, **ok))                                        # other hop / n_group combinations build
+    half = WaveGlow(**dict(cfg, n_group=16, hop_length=512))
+    with pytest.raises(NotImplementedError, match="n_group"):
+        half.set_compute_dtype(torch.float16)                             # reduced precision: flow boundaries of <= 8 channels
 
 
 def test_unknown_constructor_options_raise_type_error():
@@ -181,12 +193,10 @@ def test_gemm_mode_names_and_tuning_bits(hip_lib_path):
     assert _lib.GEMM_MODES == {"f32": 1, "bf16x3": 2, "bf16x6": 3}
     assert all(_lib.MODEL_GEMM_MODES[k] == v for k, v in _lib.GEMM_MODES.items())
     lib = _lib.lib()
-    assert lib.ctts_abi_version() == 6
-    assert lib.ctts_get_f32_gemm_mode() == 1                                             # CTTS_GEMM_F32, always
-    assert lib.ctts_set_f32_gemm_mode(4) != 0 and lib.ctts_set_f32_gemm_mode(-1) != 0 and lib.ctts_get_f32_gemm_mode() == 1
-    assert lib.ctts_set_f32_gemm_mode(3) != 0 and b"removed in ABI 6" in lib.ctts_last_error() and lib.ctts_get_f32_gemm_mode() == 1
-    assert lib.ctts_set_f32_gemm_mode(0) == 0 and lib.ctts_set_f32_gemm_mode(1) == 0
-    assert "REMOVED in ABI 6" in hdr and lib.ctts_last_gemm_loop() == 0
+    assert lib.ctts_abi_version() == 7
+    # the process-wide switch of ABI <= 5 is not even a symbol any more (ABI 7)
+    assert not hasattr(lib, "ctts_set_f32_gemm_mode") and not hasattr(lib, "ctts_get_f32_gemm_mode")
+    assert "ctts_set_f32_gemm_mode(" not in hdr and lib.ctts_last_gemm_loop() == 0
     # profiles are caller-owned handles (no GPU needed to create, bind, collect an empty slot and destroy one)
     import ctypes as C
     h = C.c_void_p()

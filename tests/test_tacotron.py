@@ -472,3 +472,24 @@ def test_hip_non_default_hparams_match_reference_golden(hip_lib_path, tuning, fo
     print("non-default hparams: encoder Linf", np.abs(enc - g["encoder_outputs"]).max(), errs)
     assert np.abs(enc - g["encoder_outputs"]).max() < MEL_TOL
     assert all(e < MEL_TOL for e in errs.values()), errs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["persistent", "batched"])
+def test_a_nan_with_the_sentinels_bit_pattern_flows_through_as_nan(hip_lib_path, form):
+    """The persistent decoder's vectors travel as self-flagging 4-byte values whose "not yet" pattern, 0xFFFFFFFF, is itself a
+    quiet NaN.  AMD NaN propagation keeps sign and payload of an input NaN, so a weight with exactly that pattern (a 0xFF-filled
+    buffer) would publish the sentinel: every consumer would spin into its timeout and the launch would abort.  The publishers
+    canonicalise (pd_bits): the run completes and the frames are NaN, as on the per-launch form."""
+    m, g, hp, sd = _model()
+    with torch.no_grad():
+        m.decoder.attention_rnn.bias_ih[5] = torch.tensor([0xFFFFFFFF - (1 << 32)], dtype=torch.int32).view(torch.float32)[0]
+    m.decoder._invalidate()
+    m.decoder.use_persistent = form == "persistent"
+    n = 40
+    mem = torch.from_numpy(g["memory_in"]).cuda()
+    lens = torch.from_numpy(g["lengths"]).cuda()
+    mel, gate, align, _ = m.decoder.inference(mem, lens, keep_masks=synthetic.prenet_dropout_masks(n, 2, seed=5), fixed_steps=n)
+    assert mel.shape == (2, 80, n) and torch.isnan(mel[:, :, -1]).all()      # it ran all steps; the NaN reached every frame
+    if form == "persistent":
+        assert m.decoder.persistent_state == "ok" and m.decoder._xchg      # ... on the persistent kernel, without an abort

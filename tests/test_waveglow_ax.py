@@ -115,8 +115,6 @@ def test_c_abi_size_queries_and_argument_validation(hip_lib_path):
     assert lib.ctts_resample_rows_f32(None, None, 1, 16, 8, 64, 8, 40, 128, 8, 0, 0.0, None) != 0
     assert lib.ctts_interleave_phases_f32(None, None, 1, 16, 2, 1, 8, 64, 8, 16, 64, 8, None) != 0
     assert b"interleave_phases" in lib.ctts_last_error()
-    assert lib.ctts_set_f32_gemm_mode(4) != 0 and b"unknown mode" in lib.ctts_last_error()
-    assert lib.ctts_get_f32_gemm_mode() == 1                              # CTTS_GEMM_F32 (fp32 MFMA products), read-only since ABI 6
 
 
 def _model(key, seed):

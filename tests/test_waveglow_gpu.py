@@ -391,9 +391,10 @@ def test_packed_weights_follow_parent_load_state_dict_and_in_place_updates(hip_l
     assert rms_rel_err(out_c, ref_b) > 1e-2                                   # and it really changed the output
 
 
-@pytest.mark.parametrize("name", ["toy_spk_rezero", "toy_simple"])
+@pytest.mark.parametrize("name", ["toy_spk_rezero", "toy_simple", "toy_hop512_g16", "toy_hop300_g12"])
 def test_waveglow_options_match_reference_golden(hip_lib_path, name):
-    """Multispeaker + ReZero WaveGlow and grouped ('simple') upsampling against the reference's own outputs."""
+    """Multispeaker + ReZero WaveGlow, grouped ('simple') upsampling, and hop_length / n_group other than the benchmark's
+    256 / 8 (512 / 16: flows of 16 and 12 channels; 300 / 12) against the reference's own outputs."""
     g = np.load(os.path.join(GOLDEN, f"waveglow_{name}.npz"))
     m, cfg, sd = _model(str(g["config_key"]), int(g["seed"]))
     ids = torch.from_numpy(g["speaker_ids"]).cuda() if "speaker_ids" in g.files else None
@@ -436,3 +437,48 @@ def test_waveglow_simple_half_upsampling_matches_oracle(hip_lib_path):
     z = synthetic.synthetic_noise(2, 8, 9 * 32, seed=5) * np.float32(0.9)
     wave = m.infer_from_noise(torch.from_numpy(mel).cuda(), torch.from_numpy(z).cuda()).cpu().numpy()
     assert rms_rel_err(wave, wo.waveglow_infer(sd, cfg, mel, z)) < WAVE_TOL
+
+
+def test_round_aligned_launch_is_bit_identical_to_the_single_launch(hip_lib_path, tuning):
+    """The fp32 conv-GEMM peels the column tiles beyond the last whole round of 2 x CUs workgroups into a small-shape launch
+    (gemm_f32.hip launch_gemm_f32; default on the headline path): same packed operands, same K order - the audio must be bit for
+    bit that of the single launch (CTTS_F32_NO_ROUND_SPLIT).  512 channels (4 m-blocks) x 270 column tiles = 2.1 rounds."""
+    cfg = synthetic.waveglow_config(n_flows=2, n_channels=512, n_layers=2, n_early_every=4)
+    m = WaveGlow(**cfg)
+    m.load_state_dict(synthetic.to_torch(synthetic.waveglow_state_dict(cfg, seed=77)))
+    m = m.cuda().eval()
+    F = 1080                                                    # 34560 columns = 270 tiles of 128
+    mel = torch.from_numpy(synthetic.synthetic_mel(1, F, seed=7)).cuda()
+    z = torch.from_numpy(synthetic.synthetic_noise(1, 8, F * 32, seed=7)).cuda() * 0.6
+    split = m.infer_from_noise(mel, z)
+    tuning.set("CTTS_F32_NO_ROUND_SPLIT")
+    one = m.infer_from_noise(mel, z)
+    assert torch.isfinite(split).all() and torch.equal(split, one)
+
+
+def test_vocoder_slot_with_lengths_runs_buckets_of_similar_length(hip_lib_path):
+    """``vocoder(mel, lengths=output_lengths)``: the server pads the mels of a vocoder call to the longest with -11.52 and trims
+    the audio afterwards (text2speech.py:651, 677).  With lengths the padding frames are not computed: buckets of similar
+    length, each at its own longest; an utterance's audio is the reference's infer of its bucket-trimmed mel (checked against
+    the single-utterance call, sigma = 0 so that no noise is drawn), silence beyond its own frames."""
+    from cookietts_amd import WaveGlowVocoder
+    m, cfg, sd = _model("toy", 8)
+    voc = WaveGlowVocoder(m, sigma=0.0)
+    lengths = [40, 37, 21, 20, 9]
+    T = max(lengths)
+    mel = torch.full((5, 80, T), -11.52)
+    raw = synthetic.synthetic_mel(5, T, seed=3)
+    for i, n in enumerate(lengths):
+        mel[i, :, :n] = torch.from_numpy(raw[i, :, :n])
+    mel = mel.cuda()
+    out = voc(mel, lengths=torch.tensor(lengths))
+    assert out.shape == (5, 1, T * 256) and torch.isfinite(out).all()
+    buckets = {0: 40, 1: 40, 2: 21, 3: 21, 4: 9}                            # 37 >= 0.85 * 40, 20 >= 0.85 * 21
+    for i, n in enumerate(lengths):
+        alone = voc(mel[i:i + 1, :, :buckets[i]].contiguous())
+        assert float((out[i, :, :n * 256] - alone[0, :, :n * 256]).abs().max()) < 1e-5, i
+        assert (out[i, :, n * 256:] == 0).all()
+    padded = voc(mel)                                                        # the reference's call: padding frames computed
+    assert float((padded[2, :, :21 * 256] - out[2, :, :21 * 256]).abs().max()) > 1e-4     # ... and felt near the end of item 2
+    with pytest.raises(ValueError):
+        voc(mel, lengths=[41, 1, 1, 1, 1])
