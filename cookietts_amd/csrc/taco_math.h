@@ -13,7 +13,9 @@ namespace tmath {
 // rounding-amplifying trajectory (tests/test_tacotron_long.py): distance to the exact run in band 1 1.6e-4 with the
 // fast forms, 1.1e-4 with libm or these; step time 32.2 / 34.1 (libm) us.
 __device__ __forceinline__ float acc_exp(float y) {
-    y = fminf(y, 88.0f);                                  // e^88 is finite: inf * (correction) would be NaN, and 1 / (1 + e^88) is 0 anyway
+    y = y > 88.0f ? 88.0f : y;                            // e^88 is finite: inf * (correction) would be NaN, and 1 / (1 + e^88) is 0 anyway
+                                                          // (a select, not fminf: v_min_f32 returns the OTHER operand for a NaN - a NaN
+                                                          // pre-activation would come out as a finite gate where the reference's is NaN)
     const float p = y * 1.4426950408889634f;
     const float r = fmaf(y, 1.4426950408889634f, -p) + y * 1.925963033500011e-08f;     // log2(e) = hi + lo
     const float e = __builtin_amdgcn_exp2f(p);

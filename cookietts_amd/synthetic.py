@@ -65,11 +65,12 @@ WAVEGLOW_CONFIGS = {
     "toy_simple_half": waveglow_config(n_flows=2, n_channels=128, n_layers=2, n_early_every=4,
                                        upsample_mode='simple_half'),
     # glow.py:226-265 takes any hop_length / n_group: the widest latent the HIP path builds (16 rows, early outputs of 4
-    # rows -> flows of 16 and 12 channels) at hop 512 with two upsampling taps, and n_group 12 at the 48 kHz hop of 300
+    # rows -> flows of 16 and 12 channels) at hop 512 with two upsampling taps, and n_group 12 at hop 384 (hop / n_group must
+    # be a multiple of 4 on the HIP path: latent rows of whole float4s)
     "toy_hop512_g16": waveglow_config(n_flows=4, n_channels=128, n_layers=2, n_group=16, n_early_every=2, n_early_size=4,
                                       win_length=1024, hop_length=512),
-    "toy_hop300_g12": waveglow_config(n_flows=3, n_channels=128, n_layers=2, n_group=12, n_early_every=2, n_early_size=4,
-                                      win_length=1200, hop_length=300),
+    "toy_hop384_g12": waveglow_config(n_flows=3, n_channels=128, n_layers=2, n_group=12, n_early_every=2, n_early_size=4,
+                                      win_length=1152, hop_length=384),
 }
 
 

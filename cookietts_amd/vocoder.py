@@ -127,12 +127,21 @@ class WaveGlowVocoder(torch.nn.Module):
         return out
 
     def half(self):
-        """``load_hifigan`` calls ``vocoder.half()`` (text2speech.py:261): the WN stacks then run on IEEE-half storage and
-        fp16 MFMA with fp32 accumulation (``set_compute_dtype(torch.float16)``, the reference's own half mode, inside the
-        1e-3 waveform bound) from fp32 master weights - the parameters, and hence the dtype the server casts its mels to,
-        stay fp32.  Models without a reduced-precision path (WaveFlow: 64-channel, latency-bound layers that gain nothing
-        from half storage) keep computing in fp32."""
-        if hasattr(self.waveglow, "set_compute_dtype"):
+        """``load_hifigan`` calls ``vocoder.half()`` (text2speech.py:261): the reference's request for its reduced-precision mode.
+        The parameters - and hence the dtype the server casts its mels to - stay fp32 masters in every case.
+
+        * glow.py model: the WN stacks run on IEEE-half storage and fp16 MFMA with fp32 accumulation
+          (``set_compute_dtype(torch.float16)``, the reference's own half mode: inside the 1e-3 waveform bound).
+        * ax model (what cookietts' own trainer writes: WaveFlow, 1-D ax WaveGlow): every conv-GEMM takes its products on the
+          bf16 matrix pipe as hi + lo splits with fp32 accumulation (``set_f32_gemm_mode("bf16x3")``: three bf16 products per
+          MAC, tensors stay fp32) - 1.3-2x the fp32 MFMA rate where a launch is arithmetic-bound (the notebook's 1-D WaveGlow:
+          124 -> 186x real time at batch 1, 146 -> 291x at 8; WaveFlow config 4 at batch 8: 163 -> 110 ms), <= 7e-6 RMS
+          from the fp32 reference.  Half STORAGE is not built for the ax core: its batch-1 launches are latency-bound
+          (64-256 channels), where narrower tensors buy nothing.
+        """
+        if self.is_ax:
+            self.waveglow.set_f32_gemm_mode("bf16x3")
+        else:
             self.waveglow.set_compute_dtype(torch.float16)
         return self
 

@@ -127,6 +127,8 @@ class WaveGlow(nn.Module):
         wn = WN_config
         need(n_group in (4, 8, 12, 16), f"n_group={n_group} (4, 8, 12 or 16: the un-squeeze writes whole float4s, the flow-boundary "
              "kernels hold <= 8 half-channels)")
+        need((hop_length // n_group) % 4 == 0, f"hop_length / n_group = {hop_length // n_group} (a multiple of 4: latent rows of any "
+             "number of frames are then whole float4s)")
         need(wn['kernel_size'] == 3, f"WN kernel_size={wn['kernel_size']} (3: the dilated in-layers are three K segments of one GEMM)")
         need(wn['n_channels'] >= 128 and wn['n_channels'] % 128 == 0, f"WN n_channels={wn['n_channels']} (a multiple of 128: the GEMM's m-block)")
         need(1 <= wn['n_layers'] <= 12, f"WN n_layers={wn['n_layers']} (1..12: dilation 2^11 is the largest halo)")

@@ -85,7 +85,7 @@ def make_waveglow(full_length=False, options=False):
         # glow.py options: WN speaker embeddings + ReZero (glow.py:127-133, 193-196, 211-212), grouped upsampling (:241)
         cases = [("toy_spk_rezero", "toy_spk_rezero", 3, 10, 0.8, 31), ("toy_simple", "toy_simple", 2, 7, 1.0, 32),
                  # hop_length / n_group away from the benchmark's 256 / 8
-                 ("toy_hop512_g16", "toy_hop512_g16", 2, 7, 0.8, 33), ("toy_hop300_g12", "toy_hop300_g12", 2, 9, 0.9, 34)]
+                 ("toy_hop512_g16", "toy_hop512_g16", 2, 7, 0.8, 33), ("toy_hop384_g12", "toy_hop384_g12", 2, 9, 0.9, 34)]
         only = sys.argv[2:]
         if only:
             cases = [c for c in cases if c[0] in only]

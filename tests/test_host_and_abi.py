@@ -83,11 +83,12 @@ def test_unsupported_options_fail_loudly():
     # shapes glow.py:226-265 accepts and the HIP path does not build are refused at CONSTRUCTION, naming the option
     wn = cfg["WN_config"]
     for bad, word in ((dict(n_group=6, hop_length=300, win_length=1200), "n_group=6"), (dict(n_group=32), "n_group=32"),
+                      (dict(n_group=12, hop_length=300, win_length=1200), "hop_length / n_group = 25"),
                       (dict(WN_config=dict(wn, kernel_size=5)), "kernel_size=5"), (dict(WN_config=dict(wn, n_channels=192)), "n_channels=192"),
                       (dict(WN_config=dict(wn, n_layers=13)), "n_layers=13"), (dict(n_mel_channels=81), "n_mel_channels * n_group")):
         with pytest.raises(NotImplementedError, match=re.escape(word)):
             WaveGlow(**dict(cfg, **bad))
-    for ok in (dict(n_group=16, hop_length=512), dict(n_group=12, hop_length=300, win_length=1200), dict(n_group=4)):
+    for ok in (dict(n_group=16, hop_length=512), dict(n_group=12, hop_length=384, win_length=1152), dict(n_group=4)):
         WaveGlow(**dict(cfg, **ok))                                        # other hop / n_group combinations build
     half = WaveGlow(**dict(cfg, n_group=16, hop_length=512))
     with pytest.raises(NotImplementedError, match="n_group"):

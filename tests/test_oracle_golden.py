@@ -27,10 +27,10 @@ def test_waveglow_oracle_matches_reference(name):
     assert rms_rel_err(wave, g["wave"]) < ORACLE_TOL
 
 
-@pytest.mark.parametrize("name", ["toy_spk_rezero", "toy_simple", "toy_hop512_g16", "toy_hop300_g12"])
+@pytest.mark.parametrize("name", ["toy_spk_rezero", "toy_simple", "toy_hop512_g16", "toy_hop384_g12"])
 def test_waveglow_oracle_options_match_reference(name):
     """glow.py options: WN speaker embeddings + ReZero (glow.py:127-133, 193-196, 211-212); upsample_mode='simple'; hop_length /
-    n_group away from 256 / 8 (glow.py:226-265, 318-324: 512 / 16 with two upsampling taps, 300 / 12)."""
+    n_group away from 256 / 8 (glow.py:226-265, 318-324: 512 / 16 with two upsampling taps, 384 / 12)."""
     g, cfg, sd = _load(name)
     ids = g["speaker_ids"] if "speaker_ids" in g.files else None
     wave = wo.waveglow_infer(sd, cfg, g["mel"], g["z_scaled"], speaker_ids=ids)
