@@ -169,6 +169,8 @@ SIGNATURES = {
                                              C.c_size_t, _FP]),
     "ctts_taco_decoder_steps_f32": (C.c_int, [C.POINTER(TacoDecoderConfig), _FP, _FP, _FP, _FP, _FP, C.c_int32,
                                               C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP, _FP]),
+    "ctts_taco_decoder_steps_hidden_f32": (C.c_int, [C.POINTER(TacoDecoderConfig), _FP, _FP, _FP, _FP, _FP, _FP, C.c_int32,
+                                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP, _FP]),
     "ctts_taco_decoder_persistent_bytes": (C.c_size_t, [C.POINTER(TacoDecoderConfig), C.c_int32, C.c_int32]),
     "ctts_taco_decoder_steps_persistent_f32": (C.c_int, [C.POINTER(TacoDecoderConfig), _FP, _FP, _FP, _FP, _FP, C.c_int32,
                                                          C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP, _FP, C.c_size_t,
@@ -191,6 +193,8 @@ SIGNATURES = {
                                       C.c_int32, _FP]),
     "ctts_taco_memory_f32": (C.c_int, [C.POINTER(TacoMemoryWeights), _FP, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP]),
+    "ctts_taco_memory_sylps_f32": (C.c_int, [C.POINTER(TacoMemoryWeights), _FP, _FP, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32,
+                                             C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP]),
     "ctts_pad_rows_f32": (C.c_int, [_FP, C.c_int64, C.c_int32, _FP, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, _FP]),
     "ctts_unpad_rows_f32": (C.c_int, [_FP, _FP, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

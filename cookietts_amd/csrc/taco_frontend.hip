@@ -81,6 +81,7 @@ struct MemArgs {
     ctts_taco_memory_weights w;
     const float* hn; const long long* speakers; const float* tm;
     float *memory_in, *pred_sylps;
+    const float* gt_sylps;      // model.py:1058 "gt_sylps or pred_sylps": what the SylpsNet reads when the caller gives one, else NULL
     int T, enc_dim, spk_dim, syl_hidden, tm_dim, tm_crushed;
 };
 
@@ -103,8 +104,9 @@ __global__ __launch_bounds__(256) void memory_kernel(const MemArgs a) {
     // pred_sylps = sylps_layer(hidden_state)
     float acc = 0.f;
     for (int k = t; k < a.enc_dim; k += 256) acc = fmaf(a.w.sylps_w[k], a.hn[(size_t)b * a.enc_dim + k], acc);
-    const float sylps = block_sum(acc, red) + a.w.sylps_b[0];
-    if (t == 0) a.pred_sylps[b] = sylps;
+    const float pred = block_sum(acc, red) + a.w.sylps_b[0];
+    if (t == 0) a.pred_sylps[b] = pred;
+    const float sylps = a.gt_sylps ? a.gt_sylps[b] : pred;
     // SylpsNet.infer_auto: cat(sylps, ln sylps) -> Linear -> LeakyReLU(0.05) -> Linear; zu = (cat + res_w * res)[0]
     const float ln = logf(sylps);
     if (t < a.syl_hidden) {
@@ -215,11 +217,19 @@ int ctts_taco_memory_f32(const ctts_taco_memory_weights* w, const float* hn, con
                          const float* torchmoji, float* memory_in, float* pred_sylps, int32_t batch, int32_t T,
                          int32_t enc_dim, int32_t spk_dim, int32_t syl_hidden, int32_t tm_dim, int32_t tm_crushed,
                          void* stream) {
+    return ctts_taco_memory_sylps_f32(w, hn, speakers, torchmoji, nullptr, memory_in, pred_sylps, batch, T, enc_dim, spk_dim,
+                                      syl_hidden, tm_dim, tm_crushed, stream);
+}
+
+int ctts_taco_memory_sylps_f32(const ctts_taco_memory_weights* w, const float* hn, const int64_t* speakers,
+                               const float* torchmoji, const float* gt_sylps, float* memory_in, float* pred_sylps, int32_t batch,
+                               int32_t T, int32_t enc_dim, int32_t spk_dim, int32_t syl_hidden, int32_t tm_dim,
+                               int32_t tm_crushed, void* stream) {
     CTTS_CHECK_ARG(w && hn && speakers && torchmoji && memory_in && pred_sylps && batch >= 1 && T >= 1, "memory: bad argument");
     CTTS_CHECK_ARG(spk_dim + 1 + tm_crushed <= 1024 && syl_hidden <= 64, "memory: dims too large");
     MemArgs a{};
     a.w = *w; a.hn = hn; a.speakers = reinterpret_cast<const long long*>(speakers); a.tm = torchmoji;
-    a.memory_in = memory_in; a.pred_sylps = pred_sylps;
+    a.memory_in = memory_in; a.pred_sylps = pred_sylps; a.gt_sylps = gt_sylps;
     a.T = T; a.enc_dim = enc_dim; a.spk_dim = spk_dim; a.syl_hidden = syl_hidden; a.tm_dim = tm_dim; a.tm_crushed = tm_crushed;
     hipLaunchKernelGGL(memory_kernel, dim3(batch), dim3(256), 0, as_stream(stream), a);
     CTTS_CHECK_LAUNCH("memory");

@@ -780,6 +780,16 @@ LstmCall make_call(const float* blob, const size_t* off, const float* in0, int n
                     nullptr, none, pt, I, H, NB};
 }
 
+// Decoder.inference(return_hidden_state=True) (model.py:762, 888-889): the vector the gate and the mel projection read,
+// hidden[b][k][step] = k < Rd ? dec_h + d2_h (the residual sum, model.py:755-759) : attention context
+__global__ __launch_bounds__(256) void hidden_state_kernel(const float* __restrict__ dec_h, const float* __restrict__ d2_h,
+                                                           const float* __restrict__ ctx, float* __restrict__ hidden, int Rd, int Dm,
+                                                           int step, int max_steps) {
+    const int b = blockIdx.x, D = Rd + Dm;
+    for (int k = threadIdx.x; k < D; k += 256)
+        hidden[((size_t)b * D + k) * max_steps + step] = k < Rd ? dec_h[(size_t)b * Rd + k] + d2_h[(size_t)b * Rd + k] : ctx[(size_t)b * Dm + k - Rd];
+}
+
 #include "tacotron_batched.h"
 
 // One decoder step of the batched form (4 < batch <= MAX_BATCH): seven dependent launches
@@ -787,7 +797,7 @@ LstmCall make_call(const float* blob, const size_t* off, const float* in0, int n
 //   workgroup per item) -> decoder RNN -> second decoder RNN -> projection row set [mel | gate | first prenet layer] (bg PROJ)
 //   -> second prenet layer (bg PRENET2)
 int batched_steps(const DecPlan& p, const DecWs& w, const float* blob, const uint8_t* keep_masks, float* mel_out, float* gate_out,
-                  float* align_out, int batch, int text_len, int step0, int n_steps, int max_steps, hipStream_t s) {
+                  float* align_out, float* hidden_out, int batch, int text_len, int step0, int n_steps, int max_steps, hipStream_t s) {
     const auto& c = p.c;
     const int NB = ws_rows(p, batch);
     const int Pn = c.prenet_dim, Ra = c.attention_rnn_dim, Rd = c.decoder_rnn_dim, Rd2 = c.second_decoder_rnn_dim, Dm = c.memory_dim;
@@ -848,6 +858,10 @@ int batched_steps(const DecPlan& p, const DecWs& w, const float* blob, const uin
             bg_set_x(a, p.bg_w2, w.h1, Pn, nullptr, 0, nullptr, 0, nullptr, 0);
             a.keep = keep; a.act_out = w.prenet; a.P = Pn;
             if ((rc = bg_launch_small<BG_EPI_PRENET2>(a, NB, s))) return rc;
+        }
+        if (hidden_out) {
+            hipLaunchKernelGGL(hidden_state_kernel, dim3(batch), dim3(256), 0, s, w.dec_h[nxt], w.d2_h[nxt], w.ctx, hidden_out, Rd, Dm, step, max_steps);
+            CTTS_CHECK_LAUNCH("hidden_state");
         }
     }
     return CTTS_OK;
@@ -999,6 +1013,14 @@ int ctts_taco_decoder_init_f32(const ctts_taco_decoder_config* cfg, const void* 
 int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void* packed, const uint8_t* keep_masks,
                                 float* mel_out, float* gate_out, float* align_out, int32_t batch, int32_t text_len,
                                 int32_t step0, int32_t n_steps, int32_t max_steps, void* workspace, void* stream) {
+    return ctts_taco_decoder_steps_hidden_f32(cfg, packed, keep_masks, mel_out, gate_out, align_out, nullptr, batch, text_len, step0,
+                                              n_steps, max_steps, workspace, stream);
+}
+
+int ctts_taco_decoder_steps_hidden_f32(const ctts_taco_decoder_config* cfg, const void* packed, const uint8_t* keep_masks,
+                                       float* mel_out, float* gate_out, float* align_out, float* hidden_out, int32_t batch,
+                                       int32_t text_len, int32_t step0, int32_t n_steps, int32_t max_steps, void* workspace,
+                                       void* stream) {
     DecPlan p; DecWs w;
     int rc = make_dec_plan(cfg, p); if (rc) return rc;
     CTTS_CHECK_ARG(packed && keep_masks && mel_out && gate_out && align_out && workspace, "decoder steps: NULL pointer");
@@ -1010,8 +1032,8 @@ int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void*
     // widths 64 against 88 us/step, the non-default golden shape 43 against 63: profiles/r6_05), which stay as the form for shapes
     // it does not take and, through CTTS_TACO_VALU, as an independent cross-check of both other forms
     if (batch > MAX_NB || (bg_supported(p) && !tuning().taco_valu))
-        return batched_steps(p, w, static_cast<const float*>(packed), keep_masks, mel_out, gate_out, align_out, batch, text_len,
-                             step0, n_steps, max_steps, as_stream(stream));
+        return batched_steps(p, w, static_cast<const float*>(packed), keep_masks, mel_out, gate_out, align_out, hidden_out, batch,
+                             text_len, step0, n_steps, max_steps, as_stream(stream));
     const auto& c = p.c;
     const int NB = pad_batch(batch);
     hipStream_t s = as_stream(stream);
@@ -1104,6 +1126,11 @@ int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void*
             hipLaunchKernelGGL(project_prenet_kernel, dim3(batch), dim3(256), 0, s, q);
         }
         CTTS_CHECK_LAUNCH("project_prenet");
+        if (hidden_out) {
+            hipLaunchKernelGGL(hidden_state_kernel, dim3(batch), dim3(256), 0, s, w.dec_h[nxt], w.d2_h[nxt], w.ctx, hidden_out, Rd2,
+                               c.memory_dim, step, max_steps);
+            CTTS_CHECK_LAUNCH("hidden_state");
+        }
     }
     return CTTS_OK;
 }

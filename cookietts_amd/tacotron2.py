@@ -270,8 +270,6 @@ class Decoder(nn.Module):
         Returns (mel [B, n_mel, T], gate (sigmoid) [B, T], alignments [B, T, txt_T], None).
         ``keep_masks`` [>=T, 2, B, prenet_dim] uint8 overrides the random prenet dropout;
         ``fixed_steps`` runs exactly that many steps with the stop rule disabled (benchmarks)."""
-        if return_hidden_state:
-            raise NotImplementedError("return_hidden_state is not built")
         device = memory.device
         blob = self._ensure_packed(device)
         lib = _lib.lib()
@@ -313,7 +311,9 @@ class Decoder(nn.Module):
             self._persist_fallback_calls += 1
             if self._persist_fallback_calls > PERSIST_REPROBE_AFTER:
                 self.reprobe_persistent()
-        persist = bool(self.use_persistent) and self._persist != "disabled"
+        # (return_hidden_state: the per-launch forms record [dec_h + d2_h | context] per step, model.py:762, 888-889; the persistent
+        #  kernel has no such output)
+        persist = bool(self.use_persistent) and self._persist != "disabled" and not return_hidden_state
         xchg = self._xchg.get(key) if persist else [None] * len(groups)
         if xchg is None:
             xchg = []
@@ -339,6 +339,8 @@ class Decoder(nn.Module):
         mel = torch.zeros(B, self.n_mel_channels, max_steps, dtype=torch.float32, device=device)
         gate = torch.zeros(B, max_steps, dtype=torch.float32, device=device)
         align = torch.zeros(B, max_steps, T, dtype=torch.float32, device=device)
+        hidden = torch.zeros(B, self.second_decoder_rnn_dim + self.memory_dim, max_steps, dtype=torch.float32, device=device) \
+            if return_hidden_state else None
         with torch.cuda.device(device):
             stream_obj = torch.cuda.current_stream(device)
             stream = C.c_void_p(stream_obj.cuda_stream)
@@ -388,9 +390,10 @@ class Decoder(nn.Module):
                                 self._xchg = {}
                                 xb = None
                     if xb is None:
-                        _lib.check(lib.ctts_taco_decoder_steps_f32(C.byref(cfg), _lib.ptr(blob), _lib.ptr(km), _lib.ptr(mel[g0:g1]),
-                                                                  _lib.ptr(gate[g0:g1]), _lib.ptr(align[g0:g1]), g1 - g0, T, done,
-                                                                  n, max_steps, _lib.ptr(ws), stream), "ctts_taco_decoder_steps_f32")
+                        _lib.check(lib.ctts_taco_decoder_steps_hidden_f32(
+                            C.byref(cfg), _lib.ptr(blob), _lib.ptr(km), _lib.ptr(mel[g0:g1]), _lib.ptr(gate[g0:g1]),
+                            _lib.ptr(align[g0:g1]), None if hidden is None else _lib.ptr(hidden[g0:g1]), g1 - g0, T, done, n,
+                            max_steps, _lib.ptr(ws), stream), "ctts_taco_decoder_steps_hidden_f32")
                 done += n
                 if fixed_steps is None:
                     _lib.check(lib.ctts_taco_stop_rule_f32(_lib.ptr(gate), B, max_steps, done - n, n,
@@ -420,7 +423,8 @@ class Decoder(nn.Module):
                 n_total = max_steps
                 if fixed_steps is None:
                     print("Warning! Reached max decoder steps")
-        return (mel[:, :, :n_total].contiguous(), torch.sigmoid(gate[:, :n_total]), align[:, :n_total].contiguous(), None)
+        return (mel[:, :, :n_total].contiguous(), torch.sigmoid(gate[:, :n_total]), align[:, :n_total].contiguous(),
+                None if hidden is None else hidden[:, :, :n_total].contiguous())
 
 
 MAX_GROUP = 4      # utterances per persistent-decoder / packed-LSTM workspace (ctts_taco_decoder_steps_persistent_f32, ctts_lstm_seq_*: batch <= 4)
@@ -687,8 +691,6 @@ class Tacotron2(nn.Module):
         """model.py:1044-1080.  Returns the reference's dict (pred_mel_postnet, pred_gate, alignments, pred_sylps)."""
         if self.training:
             raise RuntimeError("call .eval() first: inference uses eval-mode batch norm / no dropout but the prenet's")
-        if gt_sylps is not None:
-            raise NotImplementedError("gt_sylps override is not built on the HIP path")
         device = text_seq.device
         if device.type != 'cuda':
             raise _lib.HipLibraryError("Tacotron2 HIP path needs GPU tensors (no CPU fallback)")
@@ -721,16 +723,24 @@ class Tacotron2(nn.Module):
             mw.tm_mean, mw.tm_var = dev(self.tm_bn.running_mean), dev(self.tm_bn.running_var)
         tmh = torchmoji_hdn.detach().to(device=device, dtype=torch.float32).contiguous()
         spk64 = speaker_id.to(torch.int64).contiguous()
+        # model.py:1058 ``gt_sylps or pred_sylps``: a given syllables-per-second value [B] or [B, 1] feeds the SylpsNet instead of the
+        # predicted one (the reference's ``or`` only works for one utterance; "use gt_sylps if given" is what it stands for)
+        gts = None if gt_sylps is None else torch.as_tensor(gt_sylps).detach().to(device=device, dtype=torch.float32).reshape(-1).contiguous()
+        if gts is not None and gts.numel() != B:
+            raise ValueError(f"gt_sylps has {gts.numel()} values for a batch of {B}")
         with torch.cuda.device(device):
-            _lib.check(lib.ctts_taco_memory_f32(C.byref(mw), _lib.ptr(hn), _lib.ptr(spk64), _lib.ptr(tmh), _lib.ptr(memory),
-                                               _lib.ptr(pred_sylps), B, txt_T, enc_dim, self.speaker_embedding_dim,
-                                               sn[0].linear_layer.out_features, tmh.shape[1], self.tm_linear.out_features,
-                                               _stream(device)), "ctts_taco_memory_f32")
-        pred_mel, pred_gate, alignments, _ = self.decoder.inference(memory, memory_lengths=text_lengths,
-                                                                    keep_masks=keep_masks, fixed_steps=fixed_steps)
+            _lib.check(lib.ctts_taco_memory_sylps_f32(C.byref(mw), _lib.ptr(hn), _lib.ptr(spk64), _lib.ptr(tmh), _lib.ptr(gts),
+                                                     _lib.ptr(memory), _lib.ptr(pred_sylps), B, txt_T, enc_dim,
+                                                     self.speaker_embedding_dim, sn[0].linear_layer.out_features, tmh.shape[1],
+                                                     self.tm_linear.out_features, _stream(device)), "ctts_taco_memory_sylps_f32")
+        pred_mel, pred_gate, alignments, hidden = self.decoder.inference(memory, memory_lengths=text_lengths, keep_masks=keep_masks,
+                                                                         fixed_steps=fixed_steps, return_hidden_state=return_hidden_state)
         pred_mel_postnet = self.postnet(pred_mel) if hasattr(self, 'postnet') else pred_mel
-        return {"pred_mel_postnet": pred_mel_postnet, "pred_gate": pred_gate, "alignments": alignments,
-                "pred_sylps": pred_sylps, "pred_mel": pred_mel, "encoder_outputs": memory[:, :, :enc_dim]}
+        out = {"pred_mel_postnet": pred_mel_postnet, "pred_gate": pred_gate, "alignments": alignments,
+               "pred_sylps": pred_sylps, "pred_mel": pred_mel, "encoder_outputs": memory[:, :, :enc_dim]}
+        if return_hidden_state:      # (the reference computes them and drops them from its dict, model.py:1069-1079; kept here)
+            out["hidden_att_contexts"] = hidden
+        return out
 
 
 def load_model(hparams):
@@ -738,6 +748,7 @@ def load_model(hparams):
     model = Tacotron2(hparams)
     if torch.cuda.is_available():
         model = model.cuda()
-    if hparams.fp16_run:
-        raise NotImplementedError("fp16_run is not built on the HIP path (fp32 only)")
+    # fp16_run (model.py:25-31) only swaps the attention's score_mask_value for finfo(float16).min: masked energies then give
+    # exp(-65504 - max) = 0 exactly in fp32, as -inf does - the window kernels' weights past a text's length are exact zeros
+    # either way.  (Half precision itself is apex's business in the reference's trainer; inference here computes in fp32.)
     return model

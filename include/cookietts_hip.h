@@ -517,6 +517,14 @@ int ctts_taco_decoder_steps_f32(const ctts_taco_decoder_config* cfg, const void*
                                 const uint8_t* keep_masks, float* mel_out, float* gate_out,
                                 float* align_out, int32_t batch, int32_t text_len, int32_t step0,
                                 int32_t n_steps, int32_t max_steps, void* workspace, void* stream);
+/* The same, also recording what Decoder.inference(return_hidden_state=True) returns (model.py:762, 888-889):
+ *   hidden_out [B][second_decoder_rnn_dim + memory_dim][max_steps] = [dec_h + d2_h | attention context] per step (NULL = off).
+ * (The persistent form has no such output: a caller that wants the hidden states uses this entry point.) */
+int ctts_taco_decoder_steps_hidden_f32(const ctts_taco_decoder_config* cfg, const void* packed,
+                                       const uint8_t* keep_masks, float* mel_out, float* gate_out,
+                                       float* align_out, float* hidden_out, int32_t batch, int32_t text_len,
+                                       int32_t step0, int32_t n_steps, int32_t max_steps, void* workspace,
+                                       void* stream);
 
 /* Persistent form of ctts_taco_decoder_steps_f32: ONE launch of 256 resident workgroups (256 threads each, one wave per
  * SIMD) runs all n_steps steps with EVERY LSTM weight resident on the compute units for the whole launch (registers + LDS;
@@ -609,6 +617,12 @@ int ctts_taco_memory_f32(const ctts_taco_memory_weights* w, const float* hn, con
                          const float* torchmoji, float* memory_in, float* pred_sylps, int32_t batch, int32_t T,
                          int32_t enc_dim, int32_t spk_dim, int32_t syl_hidden, int32_t tm_dim, int32_t tm_crushed,
                          void* stream);
+/* The same with the reference's ``gt_sylps`` override (model.py:1044, 1058 "gt_sylps or pred_sylps"): gt_sylps [B] device floats
+ * are what SylpsNet.infer_auto reads (NULL = the predicted value, i.e. ctts_taco_memory_f32); pred_sylps is written either way. */
+int ctts_taco_memory_sylps_f32(const ctts_taco_memory_weights* w, const float* hn, const int64_t* speakers,
+                               const float* torchmoji, const float* gt_sylps, float* memory_in, float* pred_sylps,
+                               int32_t batch, int32_t T, int32_t enc_dim, int32_t spk_dim, int32_t syl_hidden,
+                               int32_t tm_dim, int32_t tm_crushed, void* stream);
 /* dense [B][C][src_ld] (first T columns) <-> padded [B][C][ld] copies */
 int ctts_pad_rows_f32(const float* src, int64_t src_bstride, int32_t src_ld, float* dst, int32_t batch,
                       int32_t C, int32_t T, int32_t ld, int32_t pad, void* stream);

@@ -240,11 +240,13 @@ def postnet(sd, hp, mel):
     return x_orig
 
 
-def tacotron_inference_steps(sd, hp, text, lengths, speaker_ids, torchmoji_hdn, keep_masks, n_steps):
-    """Tacotron2.inference (model.py:1044-1080) for a fixed number of decoder steps."""
+def tacotron_inference_steps(sd, hp, text, lengths, speaker_ids, torchmoji_hdn, keep_masks, n_steps, gt_sylps=None):
+    """Tacotron2.inference (model.py:1044-1080) for a fixed number of decoder steps.  ``gt_sylps`` [B]: model.py:1058
+    ``gt_sylps or pred_sylps`` - the given value feeds the SylpsNet, pred_sylps is returned either way."""
     sd = {k: np.asarray(v) for k, v in sd.items()}
     enc_out, sylps = encoder(sd, hp, np.asarray(text), lengths, np.asarray(speaker_ids))
-    memory_in = memory_assemble(sd, hp, enc_out, sylps, np.asarray(speaker_ids), torchmoji_hdn)
+    syl_in = sylps if gt_sylps is None else np.asarray(gt_sylps, dtype=np.float32).reshape(sylps.shape)
+    memory_in = memory_assemble(sd, hp, enc_out, syl_in, np.asarray(speaker_ids), torchmoji_hdn)
     mel, gate, align = decoder_inference_steps(sd, hp, memory_in, lengths, keep_masks, n_steps)
     return dict(encoder_outputs=enc_out, pred_sylps=sylps, memory_in=memory_in, pred_mel=mel,
                 pred_mel_postnet=postnet(sd, hp, mel), gate_logits=gate, alignments=align)

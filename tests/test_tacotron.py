@@ -493,3 +493,35 @@ def test_a_nan_with_the_sentinels_bit_pattern_flows_through_as_nan(hip_lib_path,
     assert mel.shape == (2, 80, n) and torch.isnan(mel[:, :, -1]).all()      # it ran all steps; the NaN reached every frame
     if form == "persistent":
         assert m.decoder.persistent_state == "ok" and m.decoder._xchg      # ... on the persistent kernel, without an abort
+
+
+@pytest.mark.gpu
+def test_gt_sylps_and_hidden_states_follow_the_reference_semantics(hip_lib_path):
+    """model.py:1044, 1058: a given ``gt_sylps`` feeds the SylpsNet instead of the predicted value (pred_sylps is returned either
+    way); model.py:762, 888-889: ``return_hidden_state`` records [dec_h + d2_h | attention context] per step - the vector the
+    gate layer and the mel projection read, so the recorded states reproduce the call's own gate logits and mel frames."""
+    m, g, hp, sd = _model()
+    f = np.load(os.path.join(GOLDEN, "tacotron_full.npz"))
+    args = [torch.from_numpy(f[k]).cuda() for k in ("text", "lengths", "speakers", "torchmoji")]
+    n = f["masks"].shape[0]
+    base = m.inference(*args, keep_masks=f["masks"], fixed_steps=n)
+    same = m.inference(*args, gt_sylps=base["pred_sylps"], keep_masks=f["masks"], fixed_steps=n)
+    assert torch.equal(same["pred_mel_postnet"], base["pred_mel_postnet"])                # the predicted value given back: no change
+    other = m.inference(*args, gt_sylps=base["pred_sylps"][:, 0] * 1.5, keep_masks=f["masks"], fixed_steps=n, return_hidden_state=True)
+    assert torch.equal(other["pred_sylps"], base["pred_sylps"])
+    assert float((other["pred_mel_postnet"] - base["pred_mel_postnet"]).abs().max()) > 1e-4
+    # oracle with the same override
+    o = to.tacotron_inference_steps(sd, hp, f["text"], f["lengths"], f["speakers"], f["torchmoji"], f["masks"], n,
+                                    gt_sylps=(base["pred_sylps"][:, 0] * 1.5).cpu().numpy())
+    assert np.abs(other["pred_mel_postnet"].cpu().numpy() - o["pred_mel_postnet"]).max() < MEL_TOL
+    h = other["hidden_att_contexts"]
+    dec = m.decoder
+    assert h.shape == (3, dec.second_decoder_rnn_dim + dec.memory_dim, n)
+    gate_w, gate_b = dec.gate_layer.linear_layer.weight.detach(), dec.gate_layer.linear_layer.bias.detach()
+    logits = torch.einsum("bdt,od->bt", h, gate_w) + gate_b
+    assert float((torch.sigmoid(logits) - other["pred_gate"]).abs().max()) < 1e-5
+    pw, pb = dec.linear_projection.linear_layer.weight.detach(), dec.linear_projection.linear_layer.bias.detach()
+    mel = torch.einsum("bdt,od->bot", h, pw) + pb[None, :, None]
+    assert float((mel - other["pred_mel"]).abs().max()) < 1e-4
+    with pytest.raises(ValueError):
+        m.inference(*args, gt_sylps=torch.ones(2), keep_masks=f["masks"], fixed_steps=n)
