@@ -46,8 +46,9 @@ struct BgArgs {
     BgPiece x[4];
     int cend[4];                // chunk index at which piece i ends (cend[3] = nchunks)
     int rows, batch;            // valid rows (the last tile may be padded), real items (columns beyond are padding)
-    // BG_EPI_CELL: LSTMCell, gate order i, f, g, o; bias and state in the checkpoint / workspace layouts
-    const float *bih, *bhh; float *c, *h_new; int H;
+    // BG_EPI_CELL: LSTMCell, gate order i, f, g, o; bias and state in the checkpoint / workspace layouts.  hsum (second decoder RNN):
+    // also hsum[ix] = h' + hres[ix], the residual sum dec_h + d2_h that the gate / mel projection reads (model.py:755-759)
+    const float *bih, *bhh; float *c, *h_new; int H; float* hsum; const float* hres;
     // BG_EPI_SEQ: one time step of a packed-sequence LSTM direction (the encoder's BiLSTM): the input projection of every
     // step is precomputed (sq.gadd, biases included), item b is active while sq.step < lengths[b] (see LstmSeq)
     LstmSeq sq; const float* h_old;
@@ -87,6 +88,9 @@ template <int MTW, int NT, int S, int WAVES>
 constexpr int bg_lds_bytes() { return WAVES * S * (MTW + NT) * 1024; }
 
 // blk = which group of MTW m-tiles, ngrp = which group of 16 NT items
+// (Fusing dependent stages into one launch through arrival counters - query rows + attention part 2, second decoder RNN +
+//  projection + prenet layer, projection + prenet layer alone; fences or fence-free sc1 hand-off - was built and measured: equal
+//  at best, up to 1.4x slower where a streaming stage shares the launch: profiles/r6_06.  Seven launches per step it is.)
 template <int MTW, int NT, int S, int WAVES, int EPI>
 __device__ __forceinline__ void bg_body(const BgArgs& a, bg_u4* lds, int blk, int ngrp) {
     constexpr int UNITS = MTW + NT;                       // 1 KiB units per stage: MTW weight tiles + NT item tiles of one chunk
@@ -246,8 +250,10 @@ __device__ __forceinline__ void bg_body(const BgArgs& a, bg_u4* lds, int blk, in
             const size_t ix = (size_t)it * H + unit;
             const float ig = bg_sigmoid(pre[0]), fg = bg_sigmoid(pre[1]), gg = tanhf(pre[2]), og = bg_sigmoid(pre[3]);
             const float cy = fg * (first ? e_c : a.c[ix]) + ig * gg;
+            const float hy = og * tanhf(cy);
             a.c[ix] = cy;
-            a.h_new[ix] = og * tanhf(cy);
+            a.h_new[ix] = hy;
+            if (a.hsum) a.hsum[ix] = hy + a.hres[ix];
         } else if constexpr (EPI == BG_EPI_SEQ) {
             const int unit = 4 * tile + j, H = a.H;
             const LstmSeq& sq = a.sq;

@@ -836,29 +836,27 @@ int batched_steps(const DecPlan& p, const DecWs& w, const float* blob, const uin
             a.bih = blob + p.dec[2]; a.bhh = blob + p.dec[3]; a.c = w.dec_c; a.h_new = w.dec_h[nxt]; a.H = Rd;
             if ((rc = bg_launch_cell(a, NB, nullptr, nullptr, nullptr, batch, shape, s))) return rc;
         }
-        {   // second decoder RNN on the first one's output (model.py:749-755)
+        {   // second decoder RNN on the first one's output (model.py:749-755); its epilogue also leaves the residual sum dec_h + d2_h
             BgArgs a{};
             a.W = blob + p.bg_d2.off; a.rows = p.bg_d2.rows; a.batch = batch;
             bg_set_x(a, p.bg_d2, w.dec_h[nxt], Rd, w.d2_h[cur], Rd2, nullptr, 0, nullptr, 0);
             a.bih = blob + p.d2[2]; a.bhh = blob + p.d2[3]; a.c = w.d2_c; a.h_new = w.d2_h[nxt]; a.H = Rd2;
+            a.hsum = w.hsum; a.hres = w.dec_h[nxt];
             if ((rc = bg_launch_cell(a, NB, nullptr, nullptr, nullptr, batch, shape, s))) return rc;
         }
         const unsigned char* keep = step + 1 < max_steps ? keep_masks + (size_t)(step + 1) * 2 * batch * Pn : nullptr;
-        {   // projection row set on [dec_h + d2_h | ctx] (model.py:755-765) + first prenet layer of the next step (:187-190)
-            BgArgs a{};
-            a.W = blob + p.bg_proj.off; a.rows = p.bg_proj.rows; a.batch = batch;
-            bg_set_x(a, p.bg_proj, w.dec_h[nxt], Rd, w.d2_h[nxt], Rd2, w.ctx, Dm, nullptr, 0);
-            a.bias = blob + p.pd_proj_b; a.keep = keep; a.mel_out = mel_out; a.gate_out = gate_out; a.act_out = w.h1;
-            a.n_mel = c.n_mel_channels; a.P = Pn; a.step = step; a.max_steps = max_steps;
-            if ((rc = bg_launch_small<BG_EPI_PROJ>(a, NB, s))) return rc;
-        }
-        if (keep) {   // second prenet layer
-            BgArgs a{};
-            a.W = blob + p.bg_w2.off; a.rows = p.bg_w2.rows; a.batch = batch;
-            bg_set_x(a, p.bg_w2, w.h1, Pn, nullptr, 0, nullptr, 0, nullptr, 0);
-            a.keep = keep; a.act_out = w.prenet; a.P = Pn;
-            if ((rc = bg_launch_small<BG_EPI_PRENET2>(a, NB, s))) return rc;
-        }
+        BgArgs pr{}, w2{};
+        // projection row set on [dec_h + d2_h | ctx] (model.py:755-765) + first prenet layer of the next step (:187-190)
+        pr.W = blob + p.bg_proj.off; pr.rows = p.bg_proj.rows; pr.batch = batch;
+        bg_set_x(pr, p.bg_proj, w.hsum, Rd2, w.ctx, Dm, nullptr, 0, nullptr, 0);
+        pr.bias = blob + p.pd_proj_b; pr.keep = keep; pr.mel_out = mel_out; pr.gate_out = gate_out; pr.act_out = w.h1;
+        pr.n_mel = c.n_mel_channels; pr.P = Pn; pr.step = step; pr.max_steps = max_steps;
+        // second prenet layer
+        w2.W = blob + p.bg_w2.off; w2.rows = p.bg_w2.rows; w2.batch = batch;
+        bg_set_x(w2, p.bg_w2, w.h1, Pn, nullptr, 0, nullptr, 0, nullptr, 0);
+        w2.keep = keep; w2.act_out = w.prenet; w2.P = Pn;
+        if ((rc = bg_launch_small<BG_EPI_PROJ>(pr, NB, s))) return rc;
+        if (keep && (rc = bg_launch_small<BG_EPI_PRENET2>(w2, NB, s))) return rc;
         if (hidden_out) {
             hipLaunchKernelGGL(hidden_state_kernel, dim3(batch), dim3(256), 0, s, w.dec_h[nxt], w.d2_h[nxt], w.ctx, hidden_out, Rd, Dm, step, max_steps);
             CTTS_CHECK_LAUNCH("hidden_state");
@@ -951,14 +949,13 @@ int ctts_taco_decoder_pack(const ctts_taco_decoder_config* cfg, const ctts_taco_
         const BgSeg dec[2] = {{blob + p.dec[0], p.I_dec, 0, p.I_dec}, {blob + p.dec[1], Rd, 0, Rd}};
         const BgSeg d2[2] = {{blob + p.d2[0], p.I_d2, 0, p.I_d2}, {blob + p.d2[1], Rd2, 0, Rd2}};
         const BgSeg q[1] = {{blob + p.query_w, Ra, 0, Ra}};
-        const BgSeg pr[3] = {{blob + p.pd_proj_w, p.Dproj, 0, Rd2}, {blob + p.pd_proj_w, p.Dproj, 0, Rd2},
-                             {blob + p.pd_proj_w, p.Dproj, Rd2, c.memory_dim}};
+        const BgSeg pr[1] = {{blob + p.pd_proj_w, p.Dproj, 0, p.Dproj}};
         const BgSeg w2[1] = {{blob + p.pd_w2, c.prenet_dim, 0, c.prenet_dim}};
         if ((rc = bg_pack(blob, p.bg_att, att, 2, Ra, s))) return rc;
         if ((rc = bg_pack(blob, p.bg_dec, dec, 2, Rd, s))) return rc;
         if ((rc = bg_pack(blob, p.bg_d2, d2, 2, Rd2, s))) return rc;
         if ((rc = bg_pack(blob, p.bg_q, q, 1, 0, s))) return rc;
-        if ((rc = bg_pack(blob, p.bg_proj, pr, 3, 0, s))) return rc;
+        if ((rc = bg_pack(blob, p.bg_proj, pr, 1, 0, s))) return rc;
         if ((rc = bg_pack(blob, p.bg_w2, w2, 1, 0, s))) return rc;
     }
     const float sc[4] = {w->windowed_att_pos_offset, w->exp_smoothing_factor, 0.f, 0.f};

@@ -28,7 +28,7 @@ struct DecPlan {
     size_t pd_proj_w, pd_proj_b, pd_w2;
     int pd_rows;
     // batched form (batch > 4): the three cells (rows gate-interleaved: tile row 4 j + g = gate g of unit 4 tile + j), the
-    // query rows, the folded projection row set with the decoder-hidden columns twice (dec_h and d2_h are separate X pieces),
+    // query rows, the folded projection row set,
     // the second prenet layer.  bg_ok = every K a multiple of 64 and every X piece a multiple of 16 wide.
     BgMat bg_att, bg_dec, bg_d2, bg_q, bg_proj, bg_w2;
     bool bg_ok;
@@ -83,7 +83,7 @@ inline int make_dec_plan(const ctts_taco_decoder_config* cfg, DecPlan& p) {
     };
     const int w16 = c.prenet_dim % 16 | c.memory_dim % 16 | c.decoder_rnn_dim % 16 | c.attention_rnn_dim % 16;
     const int Ks[6] = {p.I_att + c.attention_rnn_dim, p.I_dec + c.decoder_rnn_dim, p.I_d2 + c.second_decoder_rnn_dim,
-                       c.attention_rnn_dim, 2 * c.second_decoder_rnn_dim + c.memory_dim, c.prenet_dim};
+                       c.attention_rnn_dim, c.second_decoder_rnn_dim + c.memory_dim, c.prenet_dim};
     // ... and the windowed-attention kernel's own limits (attention_window_kernel: AW / ADM / AAD / AF / AK in tacotron_decoder.hip)
     p.bg_ok = w16 == 0 && c.window_range <= 16 && c.memory_dim <= 512 && c.attention_dim <= 256 && c.attention_dim % 4 == 0 &&
               c.location_n_filters <= 32 && c.location_kernel_size <= 31;
@@ -103,7 +103,7 @@ inline int make_dec_plan(const ctts_taco_decoder_config* cfg, DecPlan& p) {
 }
 
 struct DecWs {
-    float *memory, *pm, *att_h[2], *att_c, *dec_h[2], *dec_c, *d2_h[2], *d2_c, *w, *cum, *ctx, *pos, *prenet, *qbuf, *gp_att, *gp_dec, *gp_d2, *h1, *apre;
+    float *memory, *pm, *att_h[2], *att_c, *dec_h[2], *dec_c, *d2_h[2], *d2_c, *w, *cum, *ctx, *pos, *prenet, *qbuf, *gp_att, *gp_dec, *gp_d2, *h1, *apre, *hsum;
     int *lengths, *astart;
     size_t total;
 };
@@ -140,6 +140,7 @@ inline void dec_carve(const DecPlan& p, int batch, int T, float* base, DecWs& w)
     w.h1 = take(NB * c.prenet_dim);                          // batched form: first prenet layer of the next step
     w.apre = take(p.bg_ok ? NB * 33 * c.attention_dim : 0);  // batched form: processed-memory window + location term (attn_pre_body)
     w.astart = reinterpret_cast<int*>(take(NB));             // ... and the window start
+    w.hsum = take(p.bg_ok ? NB * c.second_decoder_rnn_dim : 0);   // batched form: dec_h + d2_h (the projection's input)
     w.lengths = reinterpret_cast<int*>(take(NB));
     w.total = o;
 }
