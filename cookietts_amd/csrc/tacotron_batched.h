@@ -46,6 +46,11 @@ struct BgArgs {
     BgPiece x[4];
     int cend[4];                // chunk index at which piece i ends (cend[3] = nchunks)
     int rows, batch;            // valid rows (the last tile may be padded), real items (columns beyond are padding)
+    // K split over ks = 2 or 4 workgroups (cells at >= 64 items: the m-tile count that keeps the X re-reads low leaves too few
+    // workgroups to fill the matrix pipes): each part leaves its partial sums in `part` (write-through), the LAST arriver of a
+    // group (*pair_cnt only ever grows by ks per launch: old % ks == ks - 1) adds them up in part order and runs the epilogue.
+    // part == NULL (ks = 1): one workgroup sums the whole K.
+    float* part; unsigned* pair_cnt; int nt_total, ks;
     // BG_EPI_CELL: LSTMCell, gate order i, f, g, o; bias and state in the checkpoint / workspace layouts.  hsum (second decoder RNN):
     // also hsum[ix] = h' + hres[ix], the residual sum dec_h + d2_h that the gate / mel projection reads (model.py:755-759)
     const float *bih, *bhh; float *c, *h_new; int H; float* hsum; const float* hres;
@@ -91,16 +96,18 @@ constexpr int bg_lds_bytes() { return WAVES * S * (MTW + NT) * 1024; }
 // (Fusing dependent stages into one launch through arrival counters - query rows + attention part 2, second decoder RNN +
 //  projection + prenet layer, projection + prenet layer alone; fences or fence-free sc1 hand-off - was built and measured: equal
 //  at best, up to 1.4x slower where a streaming stage shares the launch: profiles/r6_06.  Seven launches per step it is.)
+typedef __attribute__((address_space(1))) unsigned long long bg_gu64;
 template <int MTW, int NT, int S, int WAVES, int EPI>
-__device__ __forceinline__ void bg_body(const BgArgs& a, bg_u4* lds, int blk, int ngrp) {
+__device__ __forceinline__ void bg_body(const BgArgs& a, bg_u4* lds, int blk, int ngrp, int khalf = 0) {
     constexpr int UNITS = MTW + NT;                       // 1 KiB units per stage: MTW weight tiles + NT item tiles of one chunk
     static_assert((S - 1) * UNITS <= 60, "vmcnt is a 6-bit counter");
     static_assert(S * UNITS >= MTW * NT, "the ring also holds the waves' partial sums");
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int tile0 = blk * MTW, n0 = ngrp * (16 * NT);
-    const int per = (a.nchunks + WAVES - 1) / WAVES;
-    const int c0 = min(wave * per, a.nchunks), cpw = min(per, a.nchunks - c0);      // this wave's chunks [c0, c0 + cpw)
+    const int nch_wg = a.part ? a.nchunks / a.ks : a.nchunks, cbase = khalf * nch_wg;     // this workgroup's chunks [cbase, cbase + nch_wg)
+    const int per = (nch_wg + WAVES - 1) / WAVES;
+    const int c0 = cbase + min(wave * per, nch_wg), cpw = min(per, cbase + nch_wg - c0);  // this wave's chunks [c0, c0 + cpw)
     bg_u4* ring = lds + wave * (S * UNITS * 64);
 
     const float* wl[MTW];                                  // weight cursor of the issue side: tile, chunk c0, this lane
@@ -226,17 +233,66 @@ __device__ __forceinline__ void bg_body(const BgArgs& a, bg_u4* lds, int blk, in
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) red[((wave * MTW + m) * NT + nt) * 64 + lane] = acc[0][m][nt] + acc[1][m][nt];
     __syncthreads();
-    for (int idx = wave; idx < MTW * NT; idx += WAVES) {
+    constexpr int NK = (MTW * NT + WAVES - 1) / WAVES;     // (m-tile, item tile) pairs per wave
+    bg_f4 sums[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int idx = wave + k * WAVES;
+        const int m = min(idx, MTW * NT - 1) / NT, nt = min(idx, MTW * NT - 1) % NT;
+        bg_f4 pw[WAVES];
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) pw[w] = red[((w * MTW + m) * NT + nt) * 64 + lane];
+#pragma unroll
+        for (int w = 0; w < WAVES; w += 2) pw[w] += pw[w + 1];
+#pragma unroll
+        for (int w = 0; w < WAVES; w += 4) pw[w] += pw[w + 2];
+        sums[k] = pw[0];
+        if constexpr (WAVES == 8) sums[k] += pw[4];
+    }
+    if (a.part) {
+        // K split over ks workgroups: partial sums out (write-through, 8-byte agent-scope stores), one arrival per workgroup; all
+        // but the last arriver are done, the last reads every part back (agent-scope loads: past its own XCD's L2 - its own
+        // part too, so that the sum's order does not depend on who arrives last) and runs the epilogue
+        __shared__ unsigned s_old;
+        auto paddr = [&](int h, int idx) -> bg_gu64* {
+            const int m = idx / NT, nt = idx % NT;
+            return (bg_gu64*)(a.part + ((((size_t)h * (a.tiles + MTW) + tile0 + m) * a.nt_total + ngrp * NT + nt) * 64 + lane) * 4);
+        };
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int idx = wave + k * WAVES;
+            if (idx < MTW * NT) {
+                bg_gu64* d = paddr(khalf, idx);
+                const bg_u4 bits = __builtin_bit_cast(bg_u4, sums[k]);
+                __hip_atomic_store(d, (unsigned long long)bits[0] | ((unsigned long long)bits[1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(d + 1, (unsigned long long)bits[2] | ((unsigned long long)bits[3] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) s_old = __hip_atomic_fetch_add(a.pair_cnt + (blk * gridDim.y + ngrp), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if ((int)(__builtin_amdgcn_readfirstlane(s_old) % (unsigned)a.ks) != a.ks - 1) return;
+        for (int h = 0; h < a.ks; ++h) {                   // fixed order p0 + p1 (+ p2 + p3) whoever arrives last
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int idx = wave + k * WAVES;
+                if (idx < MTW * NT) {
+                    const bg_gu64* o = paddr(h, idx);
+                    const unsigned long long lo = __hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long hi = __hip_atomic_load(o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bg_u4 bits = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+                    sums[k] = h == 0 ? __builtin_bit_cast(bg_f4, bits) : sums[k] + __builtin_bit_cast(bg_f4, bits);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int idx = wave + k * WAVES;
+        if (idx >= MTW * NT) continue;
         const int m = idx / NT, nt = idx % NT;
-        bg_f4 part[WAVES];
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) part[w] = red[((w * MTW + m) * NT + nt) * 64 + lane];
-#pragma unroll
-        for (int w = 0; w < WAVES; w += 2) part[w] += part[w + 1];
-#pragma unroll
-        for (int w = 0; w < WAVES; w += 4) part[w] += part[w + 2];
-        bg_f4 sum = part[0];
-        if constexpr (WAVES == 8) sum += part[4];
+        const bg_f4 sum = sums[k];
         const int tile = tile0 + m;
         const int it = n0 + 16 * nt + (lane & 15);
         const int j = lane >> 4;                           // rows 16 tile + 4 j + v, v = 0..3
@@ -503,7 +559,8 @@ __global__ __launch_bounds__(256) void attn_post_kernel(const AttnArgs a, const 
 template <int MTW, int NT, int S, int WAVES, int EPI>
 __global__ __launch_bounds__(WAVES * 64) void bg_kernel(const BgArgs a) {
     extern __shared__ __attribute__((aligned(16))) bg_u4 bg_lds[];
-    bg_body<MTW, NT, S, WAVES, EPI>(a, bg_lds, blockIdx.x, blockIdx.y);
+    if (a.part) bg_body<MTW, NT, S, WAVES, EPI>(a, bg_lds, blockIdx.x / a.ks, blockIdx.y, blockIdx.x % a.ks);     // K parts: neighbouring blocks
+    else bg_body<MTW, NT, S, WAVES, EPI>(a, bg_lds, blockIdx.x, blockIdx.y);
 }
 
 // the attention RNN's launch: workgroups [0, nblk) are the cell's, [nblk, nblk + batch) (of grid row 0) the attention's part 1
@@ -511,7 +568,10 @@ template <int MTW, int NT, int S, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void bg_cell_attn_kernel(const BgArgs a, int nblk, const AttnArgs at, float* apre, int* astart, int dbg) {
     extern __shared__ __attribute__((aligned(16))) bg_u4 bg_lds[];
     static_assert(sizeof(BgAttnLds) <= bg_lds_bytes<MTW, NT, S, WAVES>(), "the attention scratch shares the ring");
-    if ((int)blockIdx.x < nblk) bg_body<MTW, NT, S, WAVES, BG_EPI_CELL>(a, bg_lds, blockIdx.x, blockIdx.y);
+    if ((int)blockIdx.x < nblk) {
+        if (a.part) bg_body<MTW, NT, S, WAVES, BG_EPI_CELL>(a, bg_lds, blockIdx.x / a.ks, blockIdx.y, blockIdx.x % a.ks);
+        else bg_body<MTW, NT, S, WAVES, BG_EPI_CELL>(a, bg_lds, blockIdx.x, blockIdx.y);
+    }
     else if (blockIdx.y == 0 && !(dbg & 32)) attn_pre_body(at, apre, astart, *reinterpret_cast<BgAttnLds*>(bg_lds), blockIdx.x - nblk);
 }
 
@@ -540,15 +600,25 @@ int bg_allow_lds(int bytes) {
 // a CU sustains ~45 GB/s with 100 KiB in flight: 16 items 75 us/step at MTW 1, 78 at 2, 88 at 4; 64 items 120 at MTW 2, 172 at 4)
 // attn != NULL: the attention's part 1 rides along (the attention RNN's launch).
 #define BG_CELL_SHAPES(X) X(4, 1, 6, 4) X(2, 1, 8, 4) X(1, 1, 8, 4) X(2, 1, 6, 8) X(4, 1, 3, 8) X(1, 1, 8, 8) \
-    X(4, 2, 4, 4) X(2, 2, 5, 4) X(1, 2, 8, 4) X(2, 2, 4, 8) X(4, 2, 3, 8) X(4, 4, 3, 4) X(2, 4, 4, 4) X(1, 4, 3, 4) X(2, 4, 3, 8) X(4, 4, 2, 8)
-inline int bg_launch_cell(const BgArgs& a, int nb_pad, const AttnArgs* attn, float* apre, int* astart, int batch, int shape, hipStream_t s) {
-    int mtw = nb_pad <= 16 ? 1 : 2, nt = nb_pad <= 16 ? 1 : nb_pad <= 32 ? 2 : 4, st = nb_pad <= 16 ? 8 : nb_pad <= 32 ? 5 : 4;
-    int wvs = 4;
-    // the attention RNN at 16 items: 320 m-tiles x 2 (W + X) is the chip's whole DMA rate (115 MB in 16.9 us); two m-tiles
-    // per workgroup leave 160 workgroups, enough to pull 1.5 W at the same rate.  The decoder RNNs' 192 tiles as 96
-    // workgroups would be bound by what ONE CU sustains (~45 GB/s): they keep one tile per workgroup (profiles/r6_04)
+    X(4, 2, 4, 4) X(2, 2, 5, 4) X(1, 2, 8, 4) X(2, 2, 4, 8) X(4, 2, 3, 8) X(4, 4, 3, 4) X(2, 4, 4, 4) X(2, 4, 3, 4) X(4, 4, 2, 4) X(1, 4, 3, 4) X(2, 4, 3, 8) X(4, 4, 2, 8)
+inline int bg_launch_cell(const BgArgs& a_in, int nb_pad, const AttnArgs* attn, float* apre, int* astart, int batch, int shape,
+                          float* part, unsigned* pair_cnt, hipStream_t s) {
+    // Shapes (measured, profiles/r6_03 ... r6_07).  DMA traffic of a cell launch = W x (B / 16) x (1 / NT + 1 / MTW): every workgroup
+    // re-reads the X columns of its items, so more m-tiles per workgroup cut it - but a CU sustains only ~45 GB/s with 100 KiB in
+    // flight, so a launch needs >= ~150 workgroups to pull at the fabric's 6.3-6.8 TB/s.
+    //   16 items: attention RNN MTW 2 (160 workgroups, 1.5 W), decoder RNNs MTW 1 (192, 2 W: as 96 they are per-CU bound)
+    //   32 items: MTW 2, NT 2 (2 W)
+    //   64 items: MTW 2, NT 4 (3 W), K split over TWO workgroups, a 3-deep ring (72 KiB: two workgroups per CU): 109 us/step against
+    //             116 as one workgroup per tile pair; 128 + items: MTW 2, NT 4, 4-deep ring, no K split, grid.y = items / 64
+    //   (MTW 4 / NT 4 - 2 W - with K over 2 or 4 workgroups, 96 KiB = one workgroup per CU: 123-139 us at 64 items, r6_07)
+    int mtw = nb_pad <= 16 ? 1 : 2, nt = nb_pad <= 16 ? 1 : nb_pad <= 32 ? 2 : 4, st = nb_pad <= 16 ? 8 : nb_pad <= 32 ? 5 : nb_pad == 64 ? 3 : 4;
+    int wvs = 4, ks = nb_pad == 64 ? 2 : 1;
     if (attn && nb_pad <= 16) mtw = 2;
-    if (shape > 0) { wvs = shape >= 1000 ? 8 : 4; mtw = shape % 1000 / 100; st = shape % 100; }   // A/B knob: CTTS_TACO_BG_SHAPE = (1000 for eight waves) + 100 MTW + S
+    if (shape > 0) { ks = shape >= 10000 ? shape / 10000 : 1; wvs = shape % 10000 >= 1000 ? 8 : 4; mtw = shape % 1000 / 100; st = shape % 100; }   // A/B knob: CTTS_TACO_BG_SHAPE = 10000 ks (K over 2 / 4 workgroups) + (1000: eight waves) + 100 MTW + S
+    BgArgs a = a_in;
+    a.part = ks > 1 ? part : nullptr; a.pair_cnt = pair_cnt; a.nt_total = nb_pad / 16; a.ks = ks;
+    CTTS_CHECK_ARG(ks == 1 || ((ks == 2 || ks == 4) && nb_pad >= 32 && part && pair_cnt && a.nchunks % (4 * ks) == 0),
+                   "batched decoder: K split %d needs >= 32 items, its partial-sum buffers and K %% %d == 0", ks, 64 * ks);
     const int ny = nb_pad <= 32 ? 1 : nb_pad / 64;
     int rc = CTTS_E_ARG;
     bool found = false;
@@ -557,7 +627,7 @@ inline int bg_launch_cell(const BgArgs& a, int nb_pad, const AttnArgs* attn, flo
         found = true;                                                                                                             \
         constexpr int LDS = bg_lds_bytes<M, N, SS, WV>();                                                                         \
         static_assert(LDS <= 160 * 1024, "LDS of a CU");                                                                          \
-        const int nblk = (a.tiles + M - 1) / M;                                                                                   \
+        const int nblk = (a.tiles + M - 1) / M * ks;                                                                              \
         if (attn) {                                                                                                               \
             if ((rc = BG_ALLOW_LDS((bg_cell_attn_kernel<M, N, SS, WV>), LDS))) return rc;                                         \
             hipLaunchKernelGGL((bg_cell_attn_kernel<M, N, SS, WV>), dim3(nblk + batch, ny), dim3(64 * WV), LDS, s, a, nblk, *attn, apre, astart, tuning().taco_bg_debug); \

@@ -818,7 +818,7 @@ int batched_steps(const DecPlan& p, const DecWs& w, const float* blob, const uin
             a.W = blob + p.bg_att.off; a.rows = p.bg_att.rows; a.batch = batch;
             bg_set_x(a, p.bg_att, w.prenet, Pn, w.ctx, Dm, w.dec_h[cur], Rd, w.att_h[cur], Ra);
             a.bih = blob + p.att[2]; a.bhh = blob + p.att[3]; a.c = w.att_c; a.h_new = w.att_h[nxt]; a.H = Ra;
-            if ((rc = bg_launch_cell(a, NB, &at, w.apre, w.astart, batch, shape, s))) return rc;
+            if ((rc = bg_launch_cell(a, NB, &at, w.apre, w.astart, batch, shape, w.bgpart, w.bgcnt, s))) return rc;
         }
         {   // query rows (model.py:126)
             BgArgs a{};
@@ -834,7 +834,7 @@ int batched_steps(const DecPlan& p, const DecWs& w, const float* blob, const uin
             a.W = blob + p.bg_dec.off; a.rows = p.bg_dec.rows; a.batch = batch;
             bg_set_x(a, p.bg_dec, w.att_h[nxt], Ra, w.ctx, Dm, w.dec_h[cur], Rd, nullptr, 0);
             a.bih = blob + p.dec[2]; a.bhh = blob + p.dec[3]; a.c = w.dec_c; a.h_new = w.dec_h[nxt]; a.H = Rd;
-            if ((rc = bg_launch_cell(a, NB, nullptr, nullptr, nullptr, batch, shape, s))) return rc;
+            if ((rc = bg_launch_cell(a, NB, nullptr, nullptr, nullptr, batch, shape, w.bgpart, w.bgcnt, s))) return rc;
         }
         {   // second decoder RNN on the first one's output (model.py:749-755); its epilogue also leaves the residual sum dec_h + d2_h
             BgArgs a{};
@@ -842,7 +842,7 @@ int batched_steps(const DecPlan& p, const DecWs& w, const float* blob, const uin
             bg_set_x(a, p.bg_d2, w.dec_h[nxt], Rd, w.d2_h[cur], Rd2, nullptr, 0, nullptr, 0);
             a.bih = blob + p.d2[2]; a.bhh = blob + p.d2[3]; a.c = w.d2_c; a.h_new = w.d2_h[nxt]; a.H = Rd2;
             a.hsum = w.hsum; a.hres = w.dec_h[nxt];
-            if ((rc = bg_launch_cell(a, NB, nullptr, nullptr, nullptr, batch, shape, s))) return rc;
+            if ((rc = bg_launch_cell(a, NB, nullptr, nullptr, nullptr, batch, shape, w.bgpart, w.bgcnt, s))) return rc;
         }
         const unsigned char* keep = step + 1 < max_steps ? keep_masks + (size_t)(step + 1) * 2 * batch * Pn : nullptr;
         BgArgs pr{}, w2{};

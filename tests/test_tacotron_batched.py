@@ -35,9 +35,10 @@ def _inputs(hp, B, T, lens, n, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,T,n", [(5, 37, 9), (16, 60, 9), (33, 45, 7), (70, 40, 5)])
+@pytest.mark.parametrize("B,T,n", [(5, 37, 9), (16, 60, 9), (33, 45, 7), (64, 40, 5), (70, 40, 5)])
 def test_batched_decoder_matches_oracle(hip_lib_path, monkeypatch, B, T, n):
-    """Column-tile shapes 16 / 32 / 64 / 128 items (NT = 1, 2, 4, 4 x 2), ragged lengths incl. texts shorter than the window.
+    """Column-tile shapes 16 / 32 / 64 / 128 items (NT = 1, 2, 4 with K split over two workgroups, 4 x 2), ragged lengths incl. texts
+    shorter than the window.
     (B = 5 is below the size from which the host picks this form by itself: the line is moved for the test.)"""
     import cookietts_amd.tacotron2 as t2
     monkeypatch.setattr(t2, "BATCHED_FROM", 5)
