@@ -46,11 +46,11 @@ struct BgArgs {
     BgPiece x[4];
     int cend[4];                // chunk index at which piece i ends (cend[3] = nchunks)
     int rows, batch;            // valid rows (the last tile may be padded), real items (columns beyond are padding)
-    // K split over ks = 2 or 4 workgroups (cells at >= 64 items: the m-tile count that keeps the X re-reads low leaves too few
-    // workgroups to fill the matrix pipes): each part leaves its partial sums in `part` (write-through), the LAST arriver of a
-    // group (*pair_cnt only ever grows by ks per launch: old % ks == ks - 1) adds them up in part order and runs the epilogue.
-    // part == NULL (ks = 1): one workgroup sums the whole K.
-    float* part; unsigned* pair_cnt; int nt_total, ks;
+    // A GEMM may be spread over several LAUNCHES (pipelined step, batched_steps): this role covers chunks [c_begin, c_end) of K;
+    // pmode 1 (EARLY): its sums go to slot `pslot` of `part` and nothing else happens; pmode 2 (FINAL): the sums of slots
+    // [0, npart) are added (slot order, then its own) before the epilogue.  pmode 0, c_end = 0: the whole K in one launch.
+    // part: [slot][m-tile][item tile][lane][4].
+    int c_begin, c_end, pmode, pslot, npart, nt_total; float* part;
     // BG_EPI_CELL: LSTMCell, gate order i, f, g, o; bias and state in the checkpoint / workspace layouts.  hsum (second decoder RNN):
     // also hsum[ix] = h' + hres[ix], the residual sum dec_h + d2_h that the gate / mel projection reads (model.py:755-759)
     const float *bih, *bhh; float *c, *h_new; int H; float* hsum; const float* hres;
@@ -96,16 +96,15 @@ constexpr int bg_lds_bytes() { return WAVES * S * (MTW + NT) * 1024; }
 // (Fusing dependent stages into one launch through arrival counters - query rows + attention part 2, second decoder RNN +
 //  projection + prenet layer, projection + prenet layer alone; fences or fence-free sc1 hand-off - was built and measured: equal
 //  at best, up to 1.4x slower where a streaming stage shares the launch: profiles/r6_06.  Seven launches per step it is.)
-typedef __attribute__((address_space(1))) unsigned long long bg_gu64;
 template <int MTW, int NT, int S, int WAVES, int EPI>
-__device__ __forceinline__ void bg_body(const BgArgs& a, bg_u4* lds, int blk, int ngrp, int khalf = 0) {
+__device__ __forceinline__ void bg_body(const BgArgs& a, bg_u4* lds, int blk, int ngrp) {
     constexpr int UNITS = MTW + NT;                       // 1 KiB units per stage: MTW weight tiles + NT item tiles of one chunk
     static_assert((S - 1) * UNITS <= 60, "vmcnt is a 6-bit counter");
     static_assert(S * UNITS >= MTW * NT, "the ring also holds the waves' partial sums");
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int tile0 = blk * MTW, n0 = ngrp * (16 * NT);
-    const int nch_wg = a.part ? a.nchunks / a.ks : a.nchunks, cbase = khalf * nch_wg;     // this workgroup's chunks [cbase, cbase + nch_wg)
+    const int cbase = a.c_end ? a.c_begin : 0, nch_wg = (a.c_end ? a.c_end : a.nchunks) - cbase;   // this role's chunks [cbase, cbase + nch_wg)
     const int per = (nch_wg + WAVES - 1) / WAVES;
     const int c0 = cbase + min(wave * per, nch_wg), cpw = min(per, cbase + nch_wg - c0);  // this wave's chunks [c0, c0 + cpw)
     bg_u4* ring = lds + wave * (S * UNITS * 64);
@@ -163,7 +162,7 @@ __device__ __forceinline__ void bg_body(const BgArgs& a, bg_u4* lds, int blk, in
     {
         const int idx = wave;
         const int tile = tile0 + idx / NT, it = n0 + 16 * (idx % NT) + (lane & 15), j = lane >> 4;
-        if (idx < MTW * NT && it < a.batch && tile < a.tiles) {
+        if (idx < MTW * NT && it < a.batch && tile < a.tiles && a.pmode != 1) {
             if constexpr (EPI == BG_EPI_CELL) {
                 const int unit = 4 * tile + j;
 #pragma unroll
@@ -249,42 +248,21 @@ __device__ __forceinline__ void bg_body(const BgArgs& a, bg_u4* lds, int blk, in
         sums[k] = pw[0];
         if constexpr (WAVES == 8) sums[k] += pw[4];
     }
-    if (a.part) {
-        // K split over ks workgroups: partial sums out (write-through, 8-byte agent-scope stores), one arrival per workgroup; all
-        // but the last arriver are done, the last reads every part back (agent-scope loads: past its own XCD's L2 - its own
-        // part too, so that the sum's order does not depend on who arrives last) and runs the epilogue
-        __shared__ unsigned s_old;
-        auto paddr = [&](int h, int idx) -> bg_gu64* {
+    if (a.pmode) {
+        auto paddr = [&](int slot, int idx) -> bg_f4* {
             const int m = idx / NT, nt = idx % NT;
-            return (bg_gu64*)(a.part + ((((size_t)h * (a.tiles + MTW) + tile0 + m) * a.nt_total + ngrp * NT + nt) * 64 + lane) * 4);
+            return reinterpret_cast<bg_f4*>(a.part) + (((size_t)slot * (a.tiles + 4) + tile0 + m) * a.nt_total + ngrp * NT + nt) * 64 + lane;
         };
+        if (a.pmode == 1) {                                // EARLY: this launch's share of the sums, for the FINAL launch
 #pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const int idx = wave + k * WAVES;
-            if (idx < MTW * NT) {
-                bg_gu64* d = paddr(khalf, idx);
-                const bg_u4 bits = __builtin_bit_cast(bg_u4, sums[k]);
-                __hip_atomic_store(d, (unsigned long long)bits[0] | ((unsigned long long)bits[1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(d + 1, (unsigned long long)bits[2] | ((unsigned long long)bits[3] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            for (int k = 0; k < NK; ++k)
+                if (wave + k * WAVES < MTW * NT) *paddr(a.pslot, wave + k * WAVES) = sums[k];
+            return;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t == 0) s_old = __hip_atomic_fetch_add(a.pair_cnt + (blk * gridDim.y + ngrp), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if ((int)(__builtin_amdgcn_readfirstlane(s_old) % (unsigned)a.ks) != a.ks - 1) return;
-        for (int h = 0; h < a.ks; ++h) {                   // fixed order p0 + p1 (+ p2 + p3) whoever arrives last
+        for (int sl = 0; sl < a.npart; ++sl) {             // FINAL: slot order, fixed
 #pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                const int idx = wave + k * WAVES;
-                if (idx < MTW * NT) {
-                    const bg_gu64* o = paddr(h, idx);
-                    const unsigned long long lo = __hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned long long hi = __hip_atomic_load(o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bg_u4 bits = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
-                    sums[k] = h == 0 ? __builtin_bit_cast(bg_f4, bits) : sums[k] + __builtin_bit_cast(bg_f4, bits);
-                }
-            }
+            for (int k = 0; k < NK; ++k)
+                if (wave + k * WAVES < MTW * NT) sums[k] += *paddr(sl, wave + k * WAVES);
         }
     }
 #pragma unroll
@@ -449,18 +427,18 @@ __device__ __forceinline__ void attn_pre_body(const AttnArgs& a, float* apre, in
 // softmax over the window (:141-146), expected position, context, the step's alignment row.  The memory window goes
 // straight into LDS by DMA while the energies are computed.
 constexpr int BGA_DM = 512, BGA_A = 256;
-__global__ __launch_bounds__(256) void attn_post_kernel(const AttnArgs a, const float* __restrict__ qbuf, const float* __restrict__ apre,
-                                                        const int* __restrict__ astart, int dbg) {
-    __shared__ __attribute__((aligned(16))) float memw[BGA_W * BGA_DM];
-    __shared__ float en[64];
-    __shared__ __attribute__((aligned(16))) float wts[64];
-    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63;
+constexpr int BGA_POST_LDS_BYTES = ((BGA_W * BGA_DM + 128) * 4 + 1023) / 1024 * 1024;
+__device__ __forceinline__ void attn_post_body(const AttnArgs& a, const float* __restrict__ qbuf, const float* __restrict__ apre,
+                                               const int* __restrict__ astart, int dbg, float* lds, int b) {
+    float* memw = lds;                                     // [BGA_W][Dm] (16-byte aligned)
+    float* en = memw + BGA_W * BGA_DM;                     // [64]
+    float* wts = en + 64;                                  // [64] (16-byte aligned)
+    const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int W = 2 * a.R + 1;
     const int s = astart[b];
     const int len = a.lengths[b];
     const float pos_old = a.pos[b], sf_raw = a.scalars[1];     // (used by one lane after the softmax: requested here)
-    if (dbg & 16) return;
     if (!(dbg & 8))
     {   // memory window -> LDS: row tt = 16-byte units [tt * Dm / 4, ...), one wave-instruction = 64 units = 256 floats
         const int upr = a.Dm / 4;                          // units per row (Dm % 256 == 0 is not required: units beyond are masked)
@@ -555,12 +533,17 @@ __global__ __launch_bounds__(256) void attn_post_kernel(const AttnArgs a, const 
     }
 }
 
+__global__ __launch_bounds__(256) void attn_post_kernel(const AttnArgs a, const float* __restrict__ qbuf, const float* __restrict__ apre,
+                                                        const int* __restrict__ astart, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) bg_u4 bg_lds[];
+    attn_post_body(a, qbuf, apre, astart, dbg, reinterpret_cast<float*>(bg_lds), blockIdx.x);
+}
+
 // ---- kernels and launch shapes ---------------------------------------------------------------------------------------------
 template <int MTW, int NT, int S, int WAVES, int EPI>
 __global__ __launch_bounds__(WAVES * 64) void bg_kernel(const BgArgs a) {
     extern __shared__ __attribute__((aligned(16))) bg_u4 bg_lds[];
-    if (a.part) bg_body<MTW, NT, S, WAVES, EPI>(a, bg_lds, blockIdx.x / a.ks, blockIdx.y, blockIdx.x % a.ks);     // K parts: neighbouring blocks
-    else bg_body<MTW, NT, S, WAVES, EPI>(a, bg_lds, blockIdx.x, blockIdx.y);
+    bg_body<MTW, NT, S, WAVES, EPI>(a, bg_lds, blockIdx.x, blockIdx.y);
 }
 
 // the attention RNN's launch: workgroups [0, nblk) are the cell's, [nblk, nblk + batch) (of grid row 0) the attention's part 1
@@ -568,10 +551,7 @@ template <int MTW, int NT, int S, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void bg_cell_attn_kernel(const BgArgs a, int nblk, const AttnArgs at, float* apre, int* astart, int dbg) {
     extern __shared__ __attribute__((aligned(16))) bg_u4 bg_lds[];
     static_assert(sizeof(BgAttnLds) <= bg_lds_bytes<MTW, NT, S, WAVES>(), "the attention scratch shares the ring");
-    if ((int)blockIdx.x < nblk) {
-        if (a.part) bg_body<MTW, NT, S, WAVES, BG_EPI_CELL>(a, bg_lds, blockIdx.x / a.ks, blockIdx.y, blockIdx.x % a.ks);
-        else bg_body<MTW, NT, S, WAVES, BG_EPI_CELL>(a, bg_lds, blockIdx.x, blockIdx.y);
-    }
+    if ((int)blockIdx.x < nblk) bg_body<MTW, NT, S, WAVES, BG_EPI_CELL>(a, bg_lds, blockIdx.x, blockIdx.y);
     else if (blockIdx.y == 0 && !(dbg & 32)) attn_pre_body(at, apre, astart, *reinterpret_cast<BgAttnLds*>(bg_lds), blockIdx.x - nblk);
 }
 
@@ -594,31 +574,22 @@ int bg_allow_lds(int bytes) {
 }
 #define BG_ALLOW_LDS(kernel, bytes) bg_allow_lds<decltype(&kernel), &kernel>(bytes)
 
-// Cells.  Shape by padded batch (X bytes per weight byte = NT / MTW; ring depth S fills 96-120 KiB of LDS):
-//   16 items: MTW 1, NT 1, S 8 (64 KiB)      32: MTW 2, NT 2, S 5 (80 KiB)      64 k: MTW 2, NT 4, S 4 (96 KiB), grid.y = k
-// (measured, profiles/r6_03: more m-tiles per workgroup cut the X re-reads but leave too few workgroups to pull the weights -
-// a CU sustains ~45 GB/s with 100 KiB in flight: 16 items 75 us/step at MTW 1, 78 at 2, 88 at 4; 64 items 120 at MTW 2, 172 at 4)
+// Cells.  Shapes (measured, profiles/r6_03 ... r6_07).  DMA traffic of a cell GEMM = W x (B / 16) x (1 / NT + 1 / MTW): every
+// workgroup re-reads the X columns of its items, so more m-tiles per workgroup cut it - but a CU sustains only ~45 GB/s with
+// 100 KiB in flight, so a launch needs >= ~150 workgroups to pull at the fabric's 6.3-6.8 TB/s.
+//   16 items: attention RNN MTW 2 (160 workgroups, 1.5 W), decoder RNNs MTW 1 (192, 2 W: as 96 they are per-CU bound)
+//   32 items: MTW 2, NT 2 (2 W);  64 k items: MTW 2, NT 4 (3 W), grid.y = k
 // attn != NULL: the attention's part 1 rides along (the attention RNN's launch).
-#define BG_CELL_SHAPES(X) X(4, 1, 6, 4) X(2, 1, 8, 4) X(1, 1, 8, 4) X(2, 1, 6, 8) X(4, 1, 3, 8) X(1, 1, 8, 8) \
-    X(4, 2, 4, 4) X(2, 2, 5, 4) X(1, 2, 8, 4) X(2, 2, 4, 8) X(4, 2, 3, 8) X(4, 4, 3, 4) X(2, 4, 4, 4) X(2, 4, 3, 4) X(4, 4, 2, 4) X(1, 4, 3, 4) X(2, 4, 3, 8) X(4, 4, 2, 8)
-inline int bg_launch_cell(const BgArgs& a_in, int nb_pad, const AttnArgs* attn, float* apre, int* astart, int batch, int shape,
-                          float* part, unsigned* pair_cnt, hipStream_t s) {
-    // Shapes (measured, profiles/r6_03 ... r6_07).  DMA traffic of a cell launch = W x (B / 16) x (1 / NT + 1 / MTW): every workgroup
-    // re-reads the X columns of its items, so more m-tiles per workgroup cut it - but a CU sustains only ~45 GB/s with 100 KiB in
-    // flight, so a launch needs >= ~150 workgroups to pull at the fabric's 6.3-6.8 TB/s.
-    //   16 items: attention RNN MTW 2 (160 workgroups, 1.5 W), decoder RNNs MTW 1 (192, 2 W: as 96 they are per-CU bound)
-    //   32 items: MTW 2, NT 2 (2 W)
-    //   64 items: MTW 2, NT 4 (3 W), K split over TWO workgroups, a 3-deep ring (72 KiB: two workgroups per CU): 109 us/step against
-    //             116 as one workgroup per tile pair; 128 + items: MTW 2, NT 4, 4-deep ring, no K split, grid.y = items / 64
-    //   (MTW 4 / NT 4 - 2 W - with K over 2 or 4 workgroups, 96 KiB = one workgroup per CU: 123-139 us at 64 items, r6_07)
-    int mtw = nb_pad <= 16 ? 1 : 2, nt = nb_pad <= 16 ? 1 : nb_pad <= 32 ? 2 : 4, st = nb_pad <= 16 ? 8 : nb_pad <= 32 ? 5 : nb_pad == 64 ? 3 : 4;
-    int wvs = 4, ks = nb_pad == 64 ? 2 : 1;
-    if (attn && nb_pad <= 16) mtw = 2;
-    if (shape > 0) { ks = shape >= 10000 ? shape / 10000 : 1; wvs = shape % 10000 >= 1000 ? 8 : 4; mtw = shape % 1000 / 100; st = shape % 100; }   // A/B knob: CTTS_TACO_BG_SHAPE = 10000 ks (K over 2 / 4 workgroups) + (1000: eight waves) + 100 MTW + S
-    BgArgs a = a_in;
-    a.part = ks > 1 ? part : nullptr; a.pair_cnt = pair_cnt; a.nt_total = nb_pad / 16; a.ks = ks;
-    CTTS_CHECK_ARG(ks == 1 || ((ks == 2 || ks == 4) && nb_pad >= 32 && part && pair_cnt && a.nchunks % (4 * ks) == 0),
-                   "batched decoder: K split %d needs >= 32 items, its partial-sum buffers and K %% %d == 0", ks, 64 * ks);
+#define BG_CELL_SHAPES(X) X(4, 1, 6, 4) X(2, 1, 8, 4) X(1, 1, 8, 4) X(2, 1, 6, 8) X(1, 1, 8, 8) \
+    X(4, 2, 4, 4) X(2, 2, 5, 4) X(1, 2, 8, 4) X(2, 2, 4, 8) X(2, 4, 4, 4) X(2, 4, 3, 4) X(1, 4, 3, 4) X(2, 4, 3, 8)
+inline void bg_cell_shape(int nb_pad, bool att, int shape, int& mtw, int& nt, int& st, int& wvs) {
+    mtw = nb_pad <= 16 ? 1 : 2; nt = nb_pad <= 16 ? 1 : nb_pad <= 32 ? 2 : 4; st = nb_pad <= 16 ? 8 : nb_pad <= 32 ? 5 : 4; wvs = 4;
+    if (att && nb_pad <= 16) mtw = 2;
+    if (shape > 0) { wvs = shape >= 1000 ? 8 : 4; mtw = shape % 1000 / 100; st = shape % 100; }   // A/B knob: CTTS_TACO_BG_SHAPE = (1000: eight waves) + 100 MTW + S
+}
+inline int bg_launch_cell(const BgArgs& a, int nb_pad, const AttnArgs* attn, float* apre, int* astart, int batch, int shape, hipStream_t s) {
+    int mtw, nt, st, wvs;
+    bg_cell_shape(nb_pad, attn != nullptr, shape, mtw, nt, st, wvs);
     const int ny = nb_pad <= 32 ? 1 : nb_pad / 64;
     int rc = CTTS_E_ARG;
     bool found = false;
@@ -627,7 +598,7 @@ inline int bg_launch_cell(const BgArgs& a_in, int nb_pad, const AttnArgs* attn, 
         found = true;                                                                                                             \
         constexpr int LDS = bg_lds_bytes<M, N, SS, WV>();                                                                         \
         static_assert(LDS <= 160 * 1024, "LDS of a CU");                                                                          \
-        const int nblk = (a.tiles + M - 1) / M * ks;                                                                              \
+        const int nblk = (a.tiles + M - 1) / M;                                                                                   \
         if (attn) {                                                                                                               \
             if ((rc = BG_ALLOW_LDS((bg_cell_attn_kernel<M, N, SS, WV>), LDS))) return rc;                                         \
             hipLaunchKernelGGL((bg_cell_attn_kernel<M, N, SS, WV>), dim3(nblk + batch, ny), dim3(64 * WV), LDS, s, a, nblk, *attn, apre, astart, tuning().taco_bg_debug); \
@@ -640,6 +611,100 @@ inline int bg_launch_cell(const BgArgs& a_in, int nb_pad, const AttnArgs* attn, 
 #undef BG_TRY
     CTTS_CHECK_ARG(found, "batched decoder: cell shape MTW=%d NT=%d S=%d waves=%d is not instantiated", mtw, nt, st, wvs);
     CTTS_CHECK_LAUNCH("bg_cell");
+    return CTTS_OK;
+}
+
+// ---- heterogeneous launches of the pipelined step ---------------------------------------------------------------------------
+// A latency-bound stage (a small GEMM of 8-22 m-tiles; the attention's part 2) and the EARLY parts of the next cell GEMMs - the
+// K columns whose inputs exist already - share one launch: independent roles by block range, no synchronisation between them
+// (the cells' FINAL launches add the early sums from their `part` slots).  The streaming work of the step is spread over all
+// seven launches instead of three.  What it buys (profiles/r6_08): 81 -> 76 us/step at 32 items, 114 -> 109 at 64, 65 -> 64 at
+// 16 - the step is a chain of seven DEPENDENT launches (attention RNN -> query -> attention -> decoder RNN -> second decoder RNN
+// -> projection -> prenet -> next step) and a launch of this design costs 5-6 us however little it does (a FINAL cell launch with
+// 12 chunks per wave: 6.1 us), so re-distributing the streaming work cannot go below ~45 us; only fewer dependent launches could.
+struct BgRoles {
+    BgArgs small; int n_small, small_epi;             // blocks [0, n_small): tile = r % tiles, item tile = r / tiles
+    BgArgs cell[2]; int n_cell[2], nblk_cell[2];      // then the cell roles: blk = r % nblk, item group = r / nblk
+    const AttnArgs* pre; float* apre; int* astart; int n_pre;   // then the NEXT step's attention part 1, one block per item (pre != NULL)
+};
+// 512 threads: small GEMM (eight waves) + up to two EARLY cell roles of shape <M, N, SS, 8>
+// (separate kernel parameters, not one struct holding an array of roles: the kernel reads X pieces by a run-time index, and a
+//  dynamically indexed member of an array inside a by-value struct is copied to scratch - 1 KB per lane, 34 us per launch)
+template <int M, int N, int SS>
+__global__ __launch_bounds__(512) void bg_multi8_kernel(const BgArgs small, int n_small, int small_epi, const BgArgs c0, int n0, int nblk0,
+                                                        const BgArgs c1, int n1, int nblk1, const AttnArgs pre, float* apre, int* astart) {
+    extern __shared__ __attribute__((aligned(16))) bg_u4 bg_lds[];
+    int r = blockIdx.x;
+    if (r < n_small) {
+        const int tile = r % small.tiles, ng = r / small.tiles;
+        if (small_epi == BG_EPI_LINEAR) bg_body<1, 1, 8, 8, BG_EPI_LINEAR>(small, bg_lds, tile, ng);
+        else if (small_epi == BG_EPI_PROJ) bg_body<1, 1, 8, 8, BG_EPI_PROJ>(small, bg_lds, tile, ng);
+        else bg_body<1, 1, 8, 8, BG_EPI_PRENET2>(small, bg_lds, tile, ng);
+        return;
+    }
+    r -= n_small;
+    if (r < n0) { bg_body<M, N, SS, 8, BG_EPI_CELL>(c0, bg_lds, r % nblk0, r / nblk0); return; }
+    r -= n0;
+    if (r < n1) { bg_body<M, N, SS, 8, BG_EPI_CELL>(c1, bg_lds, r % nblk1, r / nblk1); return; }
+    attn_pre_body(pre, apre, astart, *reinterpret_cast<BgAttnLds*>(bg_lds), r - n1);       // (the first 256 threads work)
+}
+// 256 threads: attention part 2 (one block per item) + up to two EARLY cell roles of shape <M, N, SS, 4>
+template <int M, int N, int SS>
+__global__ __launch_bounds__(256) void bg_post_multi4_kernel(const AttnArgs at, const float* qbuf, const float* apre, const int* astart, int dbg,
+                                                             int n_post, const BgArgs c0, int n0, int nblk0, const BgArgs c1, int n1, int nblk1) {
+    extern __shared__ __attribute__((aligned(16))) bg_u4 bg_lds[];
+    int r = blockIdx.x;
+    if (r < n_post) { attn_post_body(at, qbuf, apre, astart, dbg, reinterpret_cast<float*>(bg_lds), r); return; }
+    r -= n_post;
+    if (r < n0) { bg_body<M, N, SS, 4, BG_EPI_CELL>(c0, bg_lds, r % nblk0, r / nblk0); return; }
+    r -= n0;
+    if (r < n1) bg_body<M, N, SS, 4, BG_EPI_CELL>(c1, bg_lds, r % nblk1, r / nblk1);
+}
+
+// role shapes by padded batch: eight-wave EARLY roles (M, N, S) = 16: (2, 1, 6), 32: (2, 2, 4), 64: (2, 4, 3); four-wave: 16: (1, 1, 8),
+// 32: (2, 2, 5), 64: (2, 4, 3)
+inline int bg_launch_multi8(BgRoles& m, int nb_pad, hipStream_t s) {
+    const int ny = nb_pad <= 32 ? 1 : nb_pad / 64;
+    const int M = 2;
+    for (int i = 0; i < 2; ++i) {
+        m.nblk_cell[i] = m.n_cell[i] ? (m.cell[i].tiles + M - 1) / M : 1;
+        m.n_cell[i] = m.n_cell[i] ? m.nblk_cell[i] * ny : 0;
+    }
+    const int blocks = m.n_small + m.n_cell[0] + m.n_cell[1] + (m.pre ? m.n_pre : 0);
+    if (blocks == 0) return CTTS_OK;
+    const AttnArgs none{};
+    int rc;
+#define BG_M8(MM, N, SS)                                                                                          \
+    {                                                                                                             \
+        constexpr int LDS = bg_lds_bytes<MM, N, SS, 8>() > bg_lds_bytes<1, 1, 8, 8>() ? bg_lds_bytes<MM, N, SS, 8>() : bg_lds_bytes<1, 1, 8, 8>(); \
+        if ((rc = BG_ALLOW_LDS((bg_multi8_kernel<MM, N, SS>), LDS))) return rc;                                   \
+        hipLaunchKernelGGL((bg_multi8_kernel<MM, N, SS>), dim3(blocks), dim3(512), LDS, s, m.small, m.n_small, m.small_epi, m.cell[0], \
+                           m.n_cell[0], m.nblk_cell[0], m.cell[1], m.n_cell[1], m.nblk_cell[1], m.pre ? *m.pre : none, m.apre, m.astart); \
+    }
+    if (nb_pad <= 16) BG_M8(2, 1, 6)
+    else if (nb_pad <= 32) BG_M8(2, 2, 4)
+    else BG_M8(2, 4, 3)
+#undef BG_M8
+    CTTS_CHECK_LAUNCH("bg_multi8");
+    return CTTS_OK;
+}
+inline int bg_launch_post_multi4(const AttnArgs& at, const float* qbuf, const float* apre, const int* astart, int batch, const BgArgs& c0,
+                                 const BgArgs& c1, int nb_pad, hipStream_t s) {
+    const int ny = nb_pad <= 32 ? 1 : nb_pad / 64;
+    int rc;
+#define BG_P4(MM, N, SS)                                                                                          \
+    {                                                                                                             \
+        constexpr int LDS = bg_lds_bytes<MM, N, SS, 4>() > BGA_POST_LDS_BYTES ? bg_lds_bytes<MM, N, SS, 4>() : BGA_POST_LDS_BYTES; \
+        const int nb0 = (c0.tiles + MM - 1) / MM, nb1 = (c1.tiles + MM - 1) / MM;                                 \
+        if ((rc = BG_ALLOW_LDS((bg_post_multi4_kernel<MM, N, SS>), LDS))) return rc;                              \
+        hipLaunchKernelGGL((bg_post_multi4_kernel<MM, N, SS>), dim3(batch + (nb0 + nb1) * ny), dim3(256), LDS, s, at, qbuf, apre, astart, \
+                           tuning().taco_bg_debug, batch, c0, nb0 * ny, nb0, c1, nb1 * ny, nb1);                  \
+    }
+    if (nb_pad <= 16) BG_P4(1, 1, 8)
+    else if (nb_pad <= 32) BG_P4(2, 2, 5)
+    else BG_P4(2, 4, 3)
+#undef BG_P4
+    CTTS_CHECK_LAUNCH("bg_post_multi4");
     return CTTS_OK;
 }
 

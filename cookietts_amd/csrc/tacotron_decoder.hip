@@ -792,71 +792,137 @@ __global__ __launch_bounds__(256) void hidden_state_kernel(const float* __restri
 
 #include "tacotron_batched.h"
 
-// One decoder step of the batched form (4 < batch <= MAX_BATCH): seven dependent launches
-//   attention RNN (bg CELL) with the attention's part 1 as extra workgroups -> query rows (bg LINEAR) -> attention part 2 (one
+// One decoder step of the batched form (4 < batch <= MAX_BATCH, and batch <= 4 where the persistent kernel is not used): seven
+// dependent launches.  Plain schedule (more than 64 items, or CTTS_TACO_BG_NO_PIPE):
+//   attention RNN (bg CELL) + the attention's part 1 as extra workgroups -> query rows (bg LINEAR) -> attention part 2 (one
 //   workgroup per item) -> decoder RNN -> second decoder RNN -> projection row set [mel | gate | first prenet layer] (bg PROJ)
 //   -> second prenet layer (bg PRENET2)
+// Pipelined schedule (<= 64 items): the same seven launches, but the K columns of a cell whose inputs exist EARLY are summed in
+// the launches of the latency-bound stages (independent roles of one launch, tacotron_batched.h "heterogeneous launches"), and the
+// cell's own launch only adds the columns that arrive last:
+//   1  attention RNN FINAL: prenet columns + [ctx | dec_h] and [att_h] sums of the previous step's launches 6 / 7; attention part 1
+//   2  query rows                 + decoder RNN EARLY on att_h(step)
+//   3  attention part 2           + decoder RNN EARLY on dec_h(step - 1) + second decoder RNN EARLY on d2_h(step - 1)
+//   4  decoder RNN FINAL: context columns + both sums          5  second decoder RNN FINAL: dec_h(step) columns + its sum
+//   6  projection row set         + next step's attention RNN EARLY on [ctx(step) | dec_h(step)]
+//   7  second prenet layer        + next step's attention RNN EARLY on att_h(step)
 int batched_steps(const DecPlan& p, const DecWs& w, const float* blob, const uint8_t* keep_masks, float* mel_out, float* gate_out,
                   float* align_out, float* hidden_out, int batch, int text_len, int step0, int n_steps, int max_steps, hipStream_t s) {
     const auto& c = p.c;
     const int NB = ws_rows(p, batch);
     const int Pn = c.prenet_dim, Ra = c.attention_rnn_dim, Rd = c.decoder_rnn_dim, Rd2 = c.second_decoder_rnn_dim, Dm = c.memory_dim;
     const int shape = tuning().taco_bg_shape;
+    const bool pipe = NB <= 64 && shape == 0 && !tuning().taco_bg_no_pipe;
+    const int nyb = NB / 16;
     int rc;
-    for (int step = step0; step < step0 + n_steps; ++step) {
-        const int cur = step & 1, nxt = cur ^ 1;
+    // the three cells' GEMMs for a given step parity (cur = step & 1): X pieces and state, K range / partial mode set by the caller
+    auto att_args = [&](int cur) {
+        BgArgs a{};
+        a.W = blob + p.bg_att.off; a.rows = p.bg_att.rows; a.batch = batch;
+        bg_set_x(a, p.bg_att, w.prenet, Pn, w.ctx, Dm, w.dec_h[cur], Rd, w.att_h[cur], Ra);
+        a.bih = blob + p.att[2]; a.bhh = blob + p.att[3]; a.c = w.att_c; a.h_new = w.att_h[cur ^ 1]; a.H = Ra;
+        a.part = w.part_att; a.nt_total = nyb;
+        return a;
+    };
+    auto dec_args = [&](int cur) {
+        BgArgs a{};
+        a.W = blob + p.bg_dec.off; a.rows = p.bg_dec.rows; a.batch = batch;
+        bg_set_x(a, p.bg_dec, w.att_h[cur ^ 1], Ra, w.ctx, Dm, w.dec_h[cur], Rd, nullptr, 0);
+        a.bih = blob + p.dec[2]; a.bhh = blob + p.dec[3]; a.c = w.dec_c; a.h_new = w.dec_h[cur ^ 1]; a.H = Rd;
+        a.part = w.part_dec; a.nt_total = nyb;
+        return a;
+    };
+    auto d2_args = [&](int cur) {
+        BgArgs a{};
+        a.W = blob + p.bg_d2.off; a.rows = p.bg_d2.rows; a.batch = batch;
+        bg_set_x(a, p.bg_d2, w.dec_h[cur ^ 1], Rd, w.d2_h[cur], Rd2, nullptr, 0, nullptr, 0);
+        a.bih = blob + p.d2[2]; a.bhh = blob + p.d2[3]; a.c = w.d2_c; a.h_new = w.d2_h[cur ^ 1]; a.H = Rd2;
+        a.hsum = w.hsum; a.hres = w.dec_h[cur ^ 1];
+        a.part = w.part_d2; a.nt_total = nyb;
+        return a;
+    };
+    auto early = [](BgArgs a, int c0, int c1, int slot) { a.c_begin = c0; a.c_end = c1; a.pmode = 1; a.pslot = slot; return a; };
+    auto final_ = [](BgArgs a, int c0, int c1, int nslots) { a.c_begin = c0; a.c_end = c1; a.pmode = 2; a.npart = nslots; return a; };
+    // K chunk boundaries of the pieces (bg_set_x order): att [prenet | ctx | dec_h | att_h], dec [att_h | ctx | dec_h], d2 [dec_h | d2_h]
+    const int aP = Pn / BG_KC, aD = (Pn + Dm + Rd) / BG_KC, aK = p.bg_att.nchunks;
+    const int dA = Ra / BG_KC, dC = (Ra + Dm) / BG_KC, dK = p.bg_dec.nchunks;
+    const int sD = Rd / BG_KC, sK = p.bg_d2.nchunks;
+    auto attn_args = [&](int step) {
         AttnArgs at{};
         at.Wq = blob + p.query_w; at.v = blob + p.v_w; at.Wloc = blob + p.loc_conv_w; at.Wd = blob + p.loc_dense_w;
         at.scalars = blob + p.scalars;
-        at.att_h = w.att_h[nxt]; at.memory = w.memory; at.pm = w.pm;
+        at.att_h = w.att_h[(step & 1) ^ 1]; at.memory = w.memory; at.pm = w.pm;
         at.w = w.w; at.cum = w.cum; at.ctx = w.ctx; at.pos = w.pos; at.align_out = align_out; at.lengths = w.lengths;
         at.T = text_len; at.A = c.attention_dim; at.Ra = Ra; at.Dm = Dm;
         at.F = c.location_n_filters; at.K = c.location_kernel_size; at.R = c.window_range;
         at.step = step; at.max_steps = max_steps;
-        {   // attention RNN on [prenet | context | decoder hidden], recurrent on its own hidden state (model.py:707-717)
-            BgArgs a{};
-            a.W = blob + p.bg_att.off; a.rows = p.bg_att.rows; a.batch = batch;
-            bg_set_x(a, p.bg_att, w.prenet, Pn, w.ctx, Dm, w.dec_h[cur], Rd, w.att_h[cur], Ra);
-            a.bih = blob + p.att[2]; a.bhh = blob + p.att[3]; a.c = w.att_c; a.h_new = w.att_h[nxt]; a.H = Ra;
-            if ((rc = bg_launch_cell(a, NB, &at, w.apre, w.astart, batch, shape, w.bgpart, w.bgcnt, s))) return rc;
-        }
-        {   // query rows (model.py:126)
-            BgArgs a{};
-            a.W = blob + p.bg_q.off; a.rows = p.bg_q.rows; a.batch = batch;
-            bg_set_x(a, p.bg_q, w.att_h[nxt], Ra, nullptr, 0, nullptr, 0, nullptr, 0);
-            a.y = w.qbuf; a.ldy = c.attention_dim;
-            if ((rc = bg_launch_small<BG_EPI_LINEAR>(a, NB, s))) return rc;
-        }
-        hipLaunchKernelGGL(attn_post_kernel, dim3(batch), dim3(256), 0, s, at, w.qbuf, w.apre, w.astart, tuning().taco_bg_debug);
-        CTTS_CHECK_LAUNCH("attn_post");
-        {   // decoder RNN on [attention hidden | context] (model.py:741-747)
-            BgArgs a{};
-            a.W = blob + p.bg_dec.off; a.rows = p.bg_dec.rows; a.batch = batch;
-            bg_set_x(a, p.bg_dec, w.att_h[nxt], Ra, w.ctx, Dm, w.dec_h[cur], Rd, nullptr, 0);
-            a.bih = blob + p.dec[2]; a.bhh = blob + p.dec[3]; a.c = w.dec_c; a.h_new = w.dec_h[nxt]; a.H = Rd;
-            if ((rc = bg_launch_cell(a, NB, nullptr, nullptr, nullptr, batch, shape, w.bgpart, w.bgcnt, s))) return rc;
-        }
-        {   // second decoder RNN on the first one's output (model.py:749-755); its epilogue also leaves the residual sum dec_h + d2_h
-            BgArgs a{};
-            a.W = blob + p.bg_d2.off; a.rows = p.bg_d2.rows; a.batch = batch;
-            bg_set_x(a, p.bg_d2, w.dec_h[nxt], Rd, w.d2_h[cur], Rd2, nullptr, 0, nullptr, 0);
-            a.bih = blob + p.d2[2]; a.bhh = blob + p.d2[3]; a.c = w.d2_c; a.h_new = w.d2_h[nxt]; a.H = Rd2;
-            a.hsum = w.hsum; a.hres = w.dec_h[nxt];
-            if ((rc = bg_launch_cell(a, NB, nullptr, nullptr, nullptr, batch, shape, w.bgpart, w.bgcnt, s))) return rc;
+        return at;
+    };
+    if (pipe && n_steps > 0) {      // what the previous call's last step did not leave: the EARLY sums of step0's attention RNN and
+        const AttnArgs at0 = attn_args(step0);                  // its attention part 1
+        BgRoles m{};
+        m.cell[0] = early(att_args(step0 & 1), aP, aD, 0); m.n_cell[0] = 1;
+        m.cell[1] = early(att_args(step0 & 1), aD, aK, 1); m.n_cell[1] = 1;
+        m.pre = &at0; m.apre = w.apre; m.astart = w.astart; m.n_pre = batch;
+        if ((rc = bg_launch_multi8(m, NB, s))) return rc;
+    }
+    for (int step = step0; step < step0 + n_steps; ++step) {
+        const int cur = step & 1, nxt = cur ^ 1;
+        const bool more = step + 1 < step0 + n_steps;          // the next step belongs to this call: leave its EARLY sums
+        const AttnArgs at = attn_args(step), at_next = attn_args(step + 1);
+        // 1: attention RNN on [prenet | context | decoder hidden], recurrent on its own hidden state (model.py:707-717); in the plain
+        // schedule the attention's part 1 rides along, in the pipelined one it ran in the previous step's launch 7
+        if ((rc = bg_launch_cell(pipe ? final_(att_args(cur), 0, aP, 2) : att_args(cur), NB, pipe ? nullptr : &at, w.apre, w.astart, batch, shape, s))) return rc;
+        BgArgs q{};     // 2: query rows (model.py:126)
+        q.W = blob + p.bg_q.off; q.rows = p.bg_q.rows; q.batch = batch;
+        bg_set_x(q, p.bg_q, w.att_h[nxt], Ra, nullptr, 0, nullptr, 0, nullptr, 0);
+        q.y = w.qbuf; q.ldy = c.attention_dim;
+        if (pipe) {
+            BgRoles m{};
+            m.small = q; m.n_small = p.bg_q.tiles * nyb; m.small_epi = BG_EPI_LINEAR;
+            m.cell[0] = early(dec_args(cur), 0, dA, 0); m.n_cell[0] = 1;
+            if ((rc = bg_launch_multi8(m, NB, s))) return rc;
+            // 3: attention part 2 + the EARLY sums on last step's dec_h / d2_h
+            if ((rc = bg_launch_post_multi4(at, w.qbuf, w.apre, w.astart, batch, early(dec_args(cur), dC, dK, 1),
+                                            early(d2_args(cur), sD, sK, 0), NB, s))) return rc;
+            // 4, 5: decoder RNN on [attention hidden | context] (model.py:741-747), second decoder RNN on its output (:749-755)
+            if ((rc = bg_launch_cell(final_(dec_args(cur), dA, dC, 2), NB, nullptr, nullptr, nullptr, batch, shape, s))) return rc;
+            if ((rc = bg_launch_cell(final_(d2_args(cur), 0, sD, 1), NB, nullptr, nullptr, nullptr, batch, shape, s))) return rc;
+        } else {
+            if ((rc = bg_launch_small<BG_EPI_LINEAR>(q, NB, s))) return rc;
+            if ((rc = BG_ALLOW_LDS(attn_post_kernel, BGA_POST_LDS_BYTES))) return rc;
+            hipLaunchKernelGGL(attn_post_kernel, dim3(batch), dim3(256), BGA_POST_LDS_BYTES, s, at, w.qbuf, w.apre, w.astart, tuning().taco_bg_debug);
+            CTTS_CHECK_LAUNCH("attn_post");
+            if ((rc = bg_launch_cell(dec_args(cur), NB, nullptr, nullptr, nullptr, batch, shape, s))) return rc;
+            if ((rc = bg_launch_cell(d2_args(cur), NB, nullptr, nullptr, nullptr, batch, shape, s))) return rc;
         }
         const unsigned char* keep = step + 1 < max_steps ? keep_masks + (size_t)(step + 1) * 2 * batch * Pn : nullptr;
         BgArgs pr{}, w2{};
-        // projection row set on [dec_h + d2_h | ctx] (model.py:755-765) + first prenet layer of the next step (:187-190)
+        // 6: projection row set on [dec_h + d2_h | ctx] (model.py:755-765) + first prenet layer of the next step (:187-190)
         pr.W = blob + p.bg_proj.off; pr.rows = p.bg_proj.rows; pr.batch = batch;
         bg_set_x(pr, p.bg_proj, w.hsum, Rd2, w.ctx, Dm, nullptr, 0, nullptr, 0);
         pr.bias = blob + p.pd_proj_b; pr.keep = keep; pr.mel_out = mel_out; pr.gate_out = gate_out; pr.act_out = w.h1;
         pr.n_mel = c.n_mel_channels; pr.P = Pn; pr.step = step; pr.max_steps = max_steps;
-        // second prenet layer
+        // 7: second prenet layer
         w2.W = blob + p.bg_w2.off; w2.rows = p.bg_w2.rows; w2.batch = batch;
         bg_set_x(w2, p.bg_w2, w.h1, Pn, nullptr, 0, nullptr, 0, nullptr, 0);
         w2.keep = keep; w2.act_out = w.prenet; w2.P = Pn;
-        if ((rc = bg_launch_small<BG_EPI_PROJ>(pr, NB, s))) return rc;
-        if (keep && (rc = bg_launch_small<BG_EPI_PRENET2>(w2, NB, s))) return rc;
+        if (pipe) {
+            BgRoles m{};
+            m.small = pr; m.n_small = p.bg_proj.tiles * nyb; m.small_epi = BG_EPI_PROJ;
+            if (more) { m.cell[0] = early(att_args(nxt), aP, aD, 0); m.n_cell[0] = 1; }
+            if ((rc = bg_launch_multi8(m, NB, s))) return rc;
+            BgRoles m2{};
+            if (keep) { m2.small = w2; m2.n_small = p.bg_w2.tiles * nyb; m2.small_epi = BG_EPI_PRENET2; }
+            if (more) {
+                m2.cell[0] = early(att_args(nxt), aD, aK, 1); m2.n_cell[0] = 1;
+                m2.pre = &at_next; m2.apre = w.apre; m2.astart = w.astart; m2.n_pre = batch;     // (reads what launch 3 left: weights, position)
+            }
+            if ((rc = bg_launch_multi8(m2, NB, s))) return rc;
+        } else {
+            if ((rc = bg_launch_small<BG_EPI_PROJ>(pr, NB, s))) return rc;
+            if (keep && (rc = bg_launch_small<BG_EPI_PRENET2>(w2, NB, s))) return rc;
+        }
         if (hidden_out) {
             hipLaunchKernelGGL(hidden_state_kernel, dim3(batch), dim3(256), 0, s, w.dec_h[nxt], w.d2_h[nxt], w.ctx, hidden_out, Rd, Dm, step, max_steps);
             CTTS_CHECK_LAUNCH("hidden_state");

@@ -105,8 +105,7 @@ inline int make_dec_plan(const ctts_taco_decoder_config* cfg, DecPlan& p) {
 struct DecWs {
     float *memory, *pm, *att_h[2], *att_c, *dec_h[2], *dec_c, *d2_h[2], *d2_c, *w, *cum, *ctx, *pos, *prenet, *qbuf, *gp_att, *gp_dec, *gp_d2, *h1, *apre, *hsum;
     int *lengths, *astart;
-    float* bgpart;       // batched form, K split over 2 / 4 workgroups: partial pre-activations [4][m-tiles + 4][NB / 16][64][4]
-    unsigned* bgcnt;     // ... and the group counters [2048] (zeroed with the workspace at init; they only ever grow by ks per launch)
+    float *part_att, *part_dec, *part_d2;   // batched form, pipelined step: EARLY sums of the cells [slot][m-tiles + 4][NB / 16][64][4] (2, 2, 1 slots)
     size_t total;
 };
 
@@ -144,9 +143,11 @@ inline void dec_carve(const DecPlan& p, int batch, int T, float* base, DecWs& w)
     w.astart = reinterpret_cast<int*>(take(NB));             // ... and the window start
     w.hsum = take(p.bg_ok ? NB * c.second_decoder_rnn_dim : 0);   // batched form: dec_h + d2_h (the projection's input)
     {
-        const size_t tmax = (size_t)(c.attention_rnn_dim > c.decoder_rnn_dim ? c.attention_rnn_dim : c.decoder_rnn_dim) / 4 + 4;
-        w.bgpart = take(p.bg_ok && NB >= 32 ? 4 * tmax * (NB / 16) * 256 : 0);
-        w.bgcnt = reinterpret_cast<unsigned*>(take(2048));
+        const size_t nt = NB / 16;
+        const bool pipe = p.bg_ok && NB >= 16 && NB <= 64;
+        w.part_att = take(pipe ? 2 * (size_t)(c.attention_rnn_dim / 4 + 4) * nt * 256 : 0);
+        w.part_dec = take(pipe ? 2 * (size_t)(c.decoder_rnn_dim / 4 + 4) * nt * 256 : 0);
+        w.part_d2 = take(pipe ? (size_t)(c.second_decoder_rnn_dim / 4 + 4) * nt * 256 : 0);
     }
     w.lengths = reinterpret_cast<int*>(take(NB));
     w.total = o;

@@ -31,6 +31,7 @@ struct Tuning {
     int taco_poll_delay[6];  // CTTS_TACO_POLL_DELAY="a,c,d,e,h,p": persistent decoder, s_sleep(1) units before the first poll of the att_h, ctx, dec_h, d2_h, h1, prenet exchanges (+ 65536: no light phase, straight to the full sweep; default 65572,65632,65548,65556,65544,65544; all 0: the form before round 5)
     bool taco_no_fuse;     // CTTS_TACO_NO_FUSE: per-launch decoder without the fused projection kernel
     int taco_bg_debug;     // CTTS_TACO_BG_DEBUG: timing experiments of attn_post_kernel (wrong results): 1 no tanh, 2 no context, 4 no alignment row, 8 no memory DMA, 16 empty
+    bool taco_bg_no_pipe;  // CTTS_TACO_BG_NO_PIPE: batched decoder without the pipelined step (no EARLY cell sums in the small stages' launches)
     int taco_bg_shape;     // CTTS_TACO_BG_SHAPE=100 MTW + S: launch shape of the batched decoder's cell GEMMs (A/B; 0 = by batch)
     bool taco_valu;        // CTTS_TACO_VALU: ctts_taco_decoder_steps_f32 at batch <= 4 on the VALU kernels of rounds 1-3 (six launches per step) instead of the batched MFMA form
     bool f32_no_defer_skip;  // CTTS_F32_NO_DEFER_SKIP: WaveGlow fp32 WN stack with one res/skip GEMM per layer (the form before round 4)
