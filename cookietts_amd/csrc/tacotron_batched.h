@@ -185,6 +185,19 @@ __device__ __forceinline__ void bg_body(const BgArgs& a, bg_u4* lds, int blk, in
         }
     }
 
+    // ... and a FINAL role's EARLY sums (<= 2 slots), which are just as old
+    constexpr int NKP = (MTW * NT + WAVES - 1) / WAVES;
+    bg_f4 ppre[NKP][2];
+    if (a.pmode == 2) {
+#pragma unroll
+        for (int k = 0; k < NKP; ++k)
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                const int idx = min(wave + k * WAVES, MTW * NT - 1);
+                ppre[k][sl] = sl < a.npart ? reinterpret_cast<const bg_f4*>(a.part)[(((size_t)sl * (a.tiles + 4) + tile0 + idx / NT) * a.nt_total + ngrp * NT + idx % NT) * 64 + lane]
+                                           : bg_f4{0.f, 0.f, 0.f, 0.f};
+            }
+    }
     // Software pipeline per wave: DMA S - 1 chunks ahead; the operands of chunk i + 1 are read from LDS into the other
     // register set while the MFMAs of chunk i run.
     bg_u4 opA[UNITS], opB[UNITS];
@@ -259,11 +272,8 @@ __device__ __forceinline__ void bg_body(const BgArgs& a, bg_u4* lds, int blk, in
                 if (wave + k * WAVES < MTW * NT) *paddr(a.pslot, wave + k * WAVES) = sums[k];
             return;
         }
-        for (int sl = 0; sl < a.npart; ++sl) {             // FINAL: slot order, fixed
 #pragma unroll
-            for (int k = 0; k < NK; ++k)
-                if (wave + k * WAVES < MTW * NT) sums[k] += *paddr(sl, wave + k * WAVES);
-        }
+        for (int k = 0; k < NK; ++k) sums[k] = (sums[k] + ppre[k][0]) + ppre[k][1];      // FINAL: own + slot 0 + slot 1 (requested before the K loop)
     }
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
