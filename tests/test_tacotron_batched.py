@@ -122,3 +122,44 @@ def test_hip_matches_the_eight_utterance_reference_golden(hip_lib_path, monkeypa
     assert max(e) < MEL_TOL
     for b, L in enumerate(g["lengths"]):
         assert (o["alignments"][b, :, L:] == 0).all()
+
+
+@pytest.mark.gpu
+def test_batched_form_is_bit_identical_run_to_run(hip_lib_path):
+    """Sixteen rows, 120 steps, same memory and dropout masks, three runs: every output bit for bit (fixed summation orders: the
+    K slices of a workgroup, the EARLY sums of the pipelined step's launches in slot order)."""
+    m, hp, sd = _model()
+    B, T, n = 16, 90, 120
+    rng = np.random.default_rng(16)
+    memory_in, lengths, masks = _inputs(hp, B, T, [T] + [int(x) for x in rng.integers(40, T + 1, size=B - 1)], n, seed=160)
+    mem, lens = torch.from_numpy(memory_in).cuda(), torch.from_numpy(lengths).cuda()
+    ref = m.decoder.inference(mem, lens, keep_masks=masks, fixed_steps=n)
+    assert len(next(iter(m.decoder._ws.values()))) == 1 and torch.isfinite(ref[0]).all()
+    for _ in range(2):
+        out = m.decoder.inference(mem, lens, keep_masks=masks, fixed_steps=n)
+        assert all(torch.equal(a, b) for a, b in zip(ref[:3], out[:3]))
+
+
+@pytest.mark.gpu
+def test_sixteen_rows_stop_together_where_the_reference_stops_its_four(hip_lib_path):
+    """The stop-rule golden's four utterances four times over = 16 rows in one batched-form call: the rule waits for the LAST row
+    (model.py:898-904: ``sig_max_gates.min() > gate_threshold``), rows are independent, so T_mel is the golden's in every case and
+    every copy of an utterance gets the golden's frames."""
+    from test_tacotron_stop import _load, _model as _stop_model
+    g, hp, sd, masks, cases = _load()
+    m = _stop_model(sd, hp)
+    rep = lambda a: np.concatenate([a] * 4, axis=0)                        # noqa: E731
+    order = np.argsort(-rep(g["lengths"]), kind="stable")                  # pack_padded_sequence wants the lengths sorted
+    args = [torch.from_numpy(rep(g[k])[order]).cuda() for k in ("text", "lengths", "speakers", "torchmoji")]
+    masks16 = np.ascontiguousarray(np.concatenate([masks] * 4, axis=2)[:, :, order])
+    src = (order % 4)
+    for name in ("delay0", "delay3", "thr_hi", "cap_in_delay", "never"):
+        thr, delay, cap, T = cases[name]
+        m.decoder.gate_delay, m.decoder.max_decoder_steps, m.decoder.gate_threshold = int(delay), int(cap), float(thr)
+        out = m.inference(*args, keep_masks=masks16)
+        assert len(next(iter(m.decoder._ws.values()))) == 1
+        o = out["pred_mel_postnet"].cpu().numpy()
+        assert o.shape == (16, 80, T), (name, o.shape, T)
+        e = np.abs(o - g[f"{name}_pred_mel_postnet"][src]).max()
+        print(f"16 rows / {name}: T_mel {T}, postnet mel L_inf vs the reference's four {e:.2e}")
+        assert e < MEL_TOL
