@@ -163,3 +163,20 @@ def test_sixteen_rows_stop_together_where_the_reference_stops_its_four(hip_lib_p
         e = np.abs(o - g[f"{name}_pred_mel_postnet"][src]).max()
         print(f"16 rows / {name}: T_mel {T}, postnet mel L_inf vs the reference's four {e:.2e}")
         assert e < MEL_TOL
+
+
+@pytest.mark.gpu
+def test_more_rows_than_one_workspace_takes_run_as_lockstep_groups_of_256(hip_lib_path):
+    """260 rows = a group of 256 and one of 4 (one workspace each, the same block of steps for both, one stop-rule evaluation):
+    every row equals the same row decoded in a batch of its own kind."""
+    m, hp, sd = _model()
+    B, T, n = 260, 24, 4
+    rng = np.random.default_rng(260)
+    memory_in, lengths, masks = _inputs(hp, B, T, [T] + [int(x) for x in rng.integers(18, T + 1, size=B - 1)], n, seed=2600)
+    mem, lens = torch.from_numpy(memory_in).cuda(), torch.from_numpy(lengths).cuda()
+    full = m.decoder.inference(mem, lens, keep_masks=masks, fixed_steps=n)
+    assert len(next(iter(m.decoder._ws.values()))) == 2 and torch.isfinite(full[0]).all()
+    head = m.decoder.inference(mem[:256].contiguous(), lens[:256], keep_masks=np.ascontiguousarray(masks[:, :, :256]), fixed_steps=n)
+    assert torch.equal(head[0], full[0][:256]) and torch.equal(head[2], full[2][:256])
+    ref_mel, _, ref_align = to.decoder_inference_steps(sd, hp, memory_in[256:], lengths[256:], np.ascontiguousarray(masks[:, :, 256:]), n)
+    assert np.abs(full[0][256:].cpu().numpy() - ref_mel).max() < MEL_TOL and np.abs(full[2][256:].cpu().numpy() - ref_align).max() < MEL_TOL
