@@ -312,7 +312,7 @@ class Profile:
 TUNING_BITS = {"CTTS_F32_NO_GLDS": 0, "CTTS_GEMM_NO_XCD_PAIR": 1, "CTTS_BF16_NO_GLDS": 2, "CTTS_BF16_NO_WIDE": 3,
                "CTTS_BF16_NO_PP": 4, "CTTS_BF16_W4": 5, "CTTS_BF16_PP_STAGES": 6, "CTTS_WF_NO_FUSE": 7, "CTTS_TACO_NO_FUSE": 8,
                "CTTS_F32_NO_SMALL": 9, "CTTS_F32_FORCE_SMALL": 10, "CTTS_F32_NO_SPLITK": 11, "CTTS_WF_NO_VEC_INTERP": 12, "CTTS_F32_NO_DEFER_SKIP": 13, "CTTS_WF_NO_REGION_SPLIT": 14,
-               "CTTS_WF_NO_ROW_QUEUE": 15, "CTTS_WF_ROW_QUEUE_MIN": 16, "CTTS_WF_INJECT_ABORT": 17, "CTTS_WF_QUEUE_DEBUG": 18, "CTTS_F32_NO_ROUND_SPLIT": 19, "CTTS_BF16_PS": 20, "CTTS_BF16_NO_PS": 21, "CTTS_F32_SPLITK_W4": 22, "CTTS_TACO_POLL_DELAY": 23, "CTTS_TACO_VALU": 24}
+               "CTTS_WF_NO_ROW_QUEUE": 15, "CTTS_WF_ROW_QUEUE_MIN": 16, "CTTS_WF_INJECT_ABORT": 17, "CTTS_WF_QUEUE_DEBUG": 18, "CTTS_F32_NO_ROUND_SPLIT": 19, "CTTS_BF16_PS": 20, "CTTS_BF16_NO_PS": 21, "CTTS_F32_SPLITK_W4": 22, "CTTS_TACO_POLL_DELAY": 23, "CTTS_TACO_VALU": 24, "CTTS_UP_NO_MFMA": 25}
 
 
 def tuning_reload():

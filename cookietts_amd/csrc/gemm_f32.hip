@@ -760,6 +760,7 @@ void load_tuning_locked() {
     g_tune.wf_no_fuse = on("CTTS_WF_NO_FUSE");
     g_tune.taco_no_fuse = on("CTTS_TACO_NO_FUSE");
     g_tune.taco_valu = on("CTTS_TACO_VALU");
+    g_tune.up_no_mfma = on("CTTS_UP_NO_MFMA");
     g_tune.taco_bg_no_pipe = on("CTTS_TACO_BG_NO_PIPE");
     { const char* e = getenv("CTTS_TACO_BG_SHAPE"); g_tune.taco_bg_shape = e ? atoi(e) : 0; }
     { const char* e = getenv("CTTS_TACO_BG_DEBUG"); g_tune.taco_bg_debug = e ? atoi(e) : 0; }

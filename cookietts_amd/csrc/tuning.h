@@ -33,6 +33,7 @@ struct Tuning {
     int taco_bg_debug;     // CTTS_TACO_BG_DEBUG: timing experiments of attn_post_kernel (wrong results): 1 no tanh, 2 no context, 4 no alignment row, 8 no memory DMA, 16 empty
     bool taco_bg_no_pipe;  // CTTS_TACO_BG_NO_PIPE: batched decoder without the pipelined step (no EARLY cell sums in the small stages' launches)
     int taco_bg_shape;     // CTTS_TACO_BG_SHAPE=100 MTW + S: launch shape of the batched decoder's cell GEMMs (A/B; 0 = by batch)
+    bool up_no_mfma;       // CTTS_UP_NO_MFMA: the VALU upsampling kernel also for the shape the MFMA one is built for (A/B)
     bool taco_valu;        // CTTS_TACO_VALU: ctts_taco_decoder_steps_f32 at batch <= 4 on the VALU kernels of rounds 1-3 (six launches per step) instead of the batched MFMA form
     bool f32_no_defer_skip;  // CTTS_F32_NO_DEFER_SKIP: WaveGlow fp32 WN stack with one res/skip GEMM per layer (the form before round 4)
     bool wf_no_region_split; // CTTS_WF_NO_REGION_SPLIT: the fused WaveFlow layer as ONE launch per layer (no A | M | B regions on three streams)

@@ -35,7 +35,8 @@ struct Plan {
     int mb_in;                          // M-blocks of the in-layer GEMM
     std::vector<FlowDims> fd;
     // packed blob offsets (floats)
-    size_t up_w, up_b, cond0_A, cond0_b, cond1_A, cond1_b;
+    size_t up_w, up_wp, up_b, cond0_A, cond0_b, cond1_A, cond1_b;
+    bool up_mfma;
     struct Flow {
         size_t start_w, start_b, end_w, end_b, winv, spk_tab;
         std::vector<size_t> in_A, in_b, rs_A, rs_b;
@@ -91,6 +92,9 @@ int make_plan(const ctts_waveglow_config* cfg, Plan& p) {
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o = align_up(o + n); return r; };
     p.up_w = take((size_t)c.n_mel_channels * c.n_mel_channels * c.win_length);
+    // the same weights in MFMA fragment order, for the shape the MFMA upsampling kernel is built for (waveglow_kernels.hip)
+    p.up_mfma = upsample_mfma_shape(c.n_mel_channels, c.win_length, c.hop_length, c.n_group);
+    p.up_wp = p.up_mfma ? take((size_t)c.n_mel_channels * c.n_mel_channels * c.win_length) : 0;
     p.up_b = take(c.n_mel_channels);
     p.cond0_A = take((size_t)c.n_flows * p.nch0 * A_TILE);
     p.cond0_b = take((size_t)c.n_flows * GEMM_BM);
@@ -694,6 +698,7 @@ int ctts_waveglow_pack_upsample(const ctts_waveglow_config* cfg, const float* up
     CTTS_CHECK_HIP(hipMemcpyAsync(blob + p.up_w, up_w, nw * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)));
     CTTS_CHECK_HIP(hipMemcpyAsync(blob + p.up_b, up_b, p.c.n_mel_channels * sizeof(float), hipMemcpyDeviceToDevice,
                                   as_stream(stream)));
+    if (p.up_mfma) return launch_upsample_pack_mfma(up_w, blob + p.up_wp, as_stream(stream));
     return CTTS_OK;
 }
 
@@ -786,7 +791,7 @@ int ctts_upsample_squeeze_f32(const ctts_waveglow_config* cfg, const void* packe
     rc = make_geom(p, frames, g); if (rc) return rc;
     CTTS_CHECK_ARG(packed && mel && spect && batch >= 1, "upsample_squeeze: bad argument");
     const float* blob = static_cast<const float*>(packed);
-    return launch_upsample_squeeze(mel, blob + p.up_w, blob + p.up_b, spect, batch, p.c.n_mel_channels, frames,
+    return launch_upsample_squeeze(mel, blob + p.up_w, p.up_mfma ? blob + p.up_wp : nullptr, blob + p.up_b, spect, batch, p.c.n_mel_channels, frames,
                                    p.c.win_length, p.c.hop_length, p.c.n_group, g.ld, g.pad, as_stream(stream));
 }
 
@@ -844,7 +849,7 @@ int ctts_waveglow_infer_spk_f32(const ctts_waveglow_config* cfg, const void* pac
     const float* blob = static_cast<const float*>(packed);
     CTTS_CHECK_HIP(hipMemcpyAsync(w.audio, z_scaled, (size_t)batch * p.c.n_group * g.L * sizeof(float),
                                   hipMemcpyDeviceToDevice, s));
-    rc = launch_upsample_squeeze(mel, blob + p.up_w, blob + p.up_b, w.spect, batch, p.c.n_mel_channels, frames,
+    rc = launch_upsample_squeeze(mel, blob + p.up_w, p.up_mfma ? blob + p.up_wp : nullptr, blob + p.up_b, w.spect, batch, p.c.n_mel_channels, frames,
                                  p.c.win_length, p.c.hop_length, p.c.n_group, g.ld, g.pad, s);
     if (rc) return rc;
     rc = fill_speaker_rows(p, g, blob, speaker_ids, w.spk, batch, s);
@@ -871,7 +876,7 @@ int ctts_tuning_flags(void) {
            (t.wf_no_row_queue ? 32768 : 0) | (t.wf_row_queue_min >= 0 ? 65536 : 0) | (t.wf_inject_abort ? 131072 : 0) |
            (t.wf_queue_debug ? 262144 : 0) | (t.f32_no_round_split ? 524288 : 0) | (t.bf16_ps ? (1 << 20) : 0) |
            (t.bf16_no_ps ? (1 << 21) : 0) | (t.f32_splitk_w4 ? (1 << 22) : 0) | (t.taco_poll_delay_set ? (1 << 23) : 0) |
-           (t.taco_valu ? (1 << 24) : 0);
+           (t.taco_valu ? (1 << 24) : 0) | (t.up_no_mfma ? (1 << 25) : 0);
 }
 
 int ctts_profile_create(void** handle) {
@@ -1009,7 +1014,7 @@ static int infer_bf16_impl(const ctts_waveglow_config* cfg, const void* packed, 
     const bf16_t* bblob = static_cast<const bf16_t*>(packed_bf16);
     CTTS_CHECK_HIP(hipMemcpyAsync(w.audio, z_scaled, (size_t)batch * p.c.n_group * g.L * sizeof(float),
                                   hipMemcpyDeviceToDevice, s));
-    rc = launch_upsample_squeeze(mel, blob + p.up_w, blob + p.up_b, w.spect, batch, p.c.n_mel_channels, frames,
+    rc = launch_upsample_squeeze(mel, blob + p.up_w, p.up_mfma ? blob + p.up_wp : nullptr, blob + p.up_b, w.spect, batch, p.c.n_mel_channels, frames,
                                  p.c.win_length, p.c.hop_length, p.c.n_group, g.ld, g.pad, s);
     if (rc) return rc;
     // cond layers 0 / 1 for all flows on bf16 MFMA: spect -> bf16 K8, then two flow-batched GEMMs whose

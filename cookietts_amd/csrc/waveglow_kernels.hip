@@ -1,6 +1,7 @@
 // Non-GEMM kernels of the WaveGlow path (all HBM-bound byte/float shuffles around the
 // MFMA conv-GEMM) and the weight-ingest kernels.  gfx950 only.
 #include "waveglow_kernels.h"
+#include "tuning.h"
 
 namespace ctts {
 
@@ -162,6 +163,95 @@ __global__ __launch_bounds__(256) void upsample_squeeze_generic_kernel(const flo
     spect[((size_t)b * n_mel * G + (size_t)o * G + (int)(t % G)) * ld + pad + t / G] = acc;
 }
 
+// MFMA form of the benchmark's shape (n_mel 80, hop 256, win 4 hop, n_group 8).  The transposed conv is the GEMM
+//   out[(o, p)][(b, q)] = sum_{(i, j)} W[i][o][p + hop j] * mel[b][i][q - j],      M = n_mel hop = 20 480, K = 4 n_mel = 320,
+// 11.8 GFLOP per 900-frame utterance - the VALU kernel above runs it at 29 TFLOP/s.  Here W is the STATIONARY operand: a workgroup
+// owns one output channel o (256 phases = 16 m-tiles of 16 rows, two per wave) and keeps its 256 x 320 slab in registers as
+// `v_mfma_f32_16x16x4_f32` A fragments (160 VGPRs per lane), the mel frames of its chunk sit in LDS ([i][frame], read as B
+// fragments: lane (n, j) = frame n - j of channel i, k = 4 i + j), and the chunk's frames stream past 32 at a time.
+// Row order of the m-tiles is chosen for the SQUEEZED output: wave g holds the phases p = 8 r + g (r = 0..31), which are the 32
+// consecutive time steps of frame q in spect row o G + g - a lane's four accumulators are one aligned float4 of that row and a
+// store instruction writes 64-byte runs.  W comes pre-packed in fragment order (upsample_pack_mfma_kernel, at pack time).
+constexpr int UM_NMEL = 80, UM_HOP = 256, UM_G = 8, UM_TAPS = 4;
+constexpr int UM_KCH = UM_NMEL * UM_TAPS / 4;       // k-chunks of 4 = input channels
+constexpr int UM_CHUNK_MAX = 320;                   // frames per workgroup (LDS: n_mel x (320 + 4) floats = 101 KiB)
+
+__global__ __launch_bounds__(256) void upsample_pack_mfma_kernel(const float* __restrict__ W, float* __restrict__ Wp) {
+    // Wp[((o G + g) 2 + mt)][q = i / 4][lane][e = i % 4] = W[i][o][hop j + 8 (16 mt + lane % 16) + g],  j = lane / 16
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)UM_NMEL * UM_NMEL * UM_HOP * UM_TAPS) return;
+    const int e = idx % 4, lane = (idx / 4) % 64, q = (idx / 256) % (UM_KCH / 4);
+    const int mt = (idx / (256 * (UM_KCH / 4))) % 2, g = (idx / (512 * (UM_KCH / 4))) % UM_G;
+    const int o = (int)(idx / ((size_t)512 * (UM_KCH / 4) * UM_G));
+    const int i = 4 * q + e, j = lane / 16, ph = 8 * (16 * mt + lane % 16) + g;
+    Wp[idx] = W[((size_t)i * UM_NMEL + o) * (UM_HOP * UM_TAPS) + UM_HOP * j + ph];
+}
+
+__global__ __launch_bounds__(512) void upsample_squeeze_mfma_kernel(const float* __restrict__ mel, const float* __restrict__ Wp,
+                                                                    const float* __restrict__ bias, float* __restrict__ spect,
+                                                                    int F, int chunk, int nchunks, int srow, int ld, int pad) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float smel[];       // [n_mel][srow]: frame (f0 - 3 + x) at x, zeros outside [0, F)
+    const int o = blockIdx.x, b = blockIdx.y / nchunks, f0 = (blockIdx.y % nchunks) * chunk;
+    const int fend = min(F, f0 + chunk);
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    // A fragments first: their latency hides behind the staging of the mel chunk
+    f32x4 a[2][UM_KCH / 4];
+    const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + ((size_t)(o * UM_G + g) * 2) * (UM_KCH / 4) * 64 + lane;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int q = 0; q < UM_KCH / 4; ++q) a[mt][q] = __builtin_nontemporal_load(wp + (mt * (UM_KCH / 4) + q) * 64);
+    const float* melb = mel + (size_t)b * UM_NMEL * F;
+    // wave g stages channels g, g + 8, ...: <= 6 independent loads per channel in flight (srow <= 324)
+    for (int i = g; i < UM_NMEL; i += 8) {
+        float v[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int f = f0 - (UM_TAPS - 1) + lane + 64 * u;
+            v[u] = (lane + 64 * u < srow && f >= 0 && f < F) ? melb[(size_t)i * F + f] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+            if (lane + 64 * u < srow) smel[i * srow + lane + 64 * u] = v[u];
+    }
+    __syncthreads();
+    const float bo = bias[o];
+    const int n = lane & 15, jq = lane >> 4;
+    const float* sb = smel + (UM_TAPS - 1) + n - jq;                   // B fragment of k-chunk i, frame tile t: sb[i srow + 16 t]
+    float* row = spect + ((size_t)b * UM_NMEL * UM_G + (size_t)o * UM_G + g) * ld + pad + 4 * jq;
+    for (int t0 = 0; f0 + 16 * t0 < fend; t0 += 2) {
+        f32x4 acc[2][2] = {};
+        float b0 = sb[16 * t0], b1 = sb[16 * t0 + 16];
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+        for (int i = 0; i < UM_KCH; ++i) {
+            const float c0 = b0, c1 = b1;
+            if (i + 1 < UM_KCH) { b0 = sb[(i + 1) * srow + 16 * t0]; b1 = sb[(i + 1) * srow + 16 * t0 + 16]; }   // one k-chunk ahead of its use
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][i / 4][i % 4], c0, acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][i / 4][i % 4], c1, acc[mt][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // the next chunk's fragment read (one ds_read2) ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      // ... ahead of this chunk's four MFMAs
+        }
+        // D: lane (n, jq) holds rows 4 jq + v of m-tile mt = time steps 32 f + 16 mt + 4 jq + v of frame f = f0 + 16 t + n
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int f = f0 + 16 * (t0 + tt) + n;
+            if (f < fend) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    f32x4 v = acc[mt][tt];
+                    v.x += bo; v.y += bo; v.z += bo; v.w += bo;
+                    *reinterpret_cast<f32x4*>(row + (size_t)f * (UM_HOP / UM_G) + 16 * mt) = v;
+                }
+            }
+        }
+    }
+}
+
 // --------------------------------------------------------------------- WN start ----
 // x[b][c][pad + n] = bs[c] + sum_{j<h} Ws[c][j] * audio[b][ch_off + j][n]     (glow.py:189)
 template <int H>
@@ -311,9 +401,37 @@ int launch_pack_bias(float* dst, int bm, int MB, const float* src0, long long of
     return CTTS_OK;
 }
 
-int launch_upsample_squeeze(const float* mel, const float* W, const float* bias, float* spect, int batch,
+bool upsample_mfma_shape(int n_mel, int win, int hop, int G) {
+    return n_mel == UM_NMEL && hop == UM_HOP && win == UM_HOP * UM_TAPS && G == UM_G;
+}
+
+int launch_upsample_pack_mfma(const float* W, float* Wp, hipStream_t s) {
+    const size_t n = (size_t)UM_NMEL * UM_NMEL * UM_HOP * UM_TAPS;
+    hipLaunchKernelGGL(upsample_pack_mfma_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, Wp);
+    CTTS_CHECK_LAUNCH("upsample_pack_mfma");
+    return CTTS_OK;
+}
+
+int launch_upsample_squeeze(const float* mel, const float* W, const float* Wp, const float* bias, float* spect, int batch,
                             int n_mel, int F, int win, int hop, int G, int ld, int pad, hipStream_t s) {
     CTTS_CHECK_ARG(win % hop == 0 && hop % G == 0, "upsample_squeeze: win %d hop %d n_group %d", win, hop, G);
+    if (Wp && upsample_mfma_shape(n_mel, win, hop, G) && ld % 4 == 0 && pad % 4 == 0 && !tuning().up_no_mfma) {
+        // chunks of <= 320 frames, equal up to a 16-frame tile (900 frames: 304 + 304 + 292): 80 x 3 workgroups per utterance
+        const int nchunks = (F + UM_CHUNK_MAX - 1) / UM_CHUNK_MAX;
+        const int chunk = ((F + nchunks - 1) / nchunks + 15) / 16 * 16;
+        const int srow = (chunk + 31) / 32 * 32 + 4;           // frames f0 - 3 ... f0 + (chunk rounded to a pair of tiles)
+        const int lds = UM_NMEL * srow * (int)sizeof(float);
+        static bool allowed = false;
+        if (!allowed) {
+            CTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(upsample_squeeze_mfma_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, UM_NMEL * (UM_CHUNK_MAX + 4) * (int)sizeof(float)));
+            allowed = true;
+        }
+        hipLaunchKernelGGL(upsample_squeeze_mfma_kernel, dim3(UM_NMEL, (unsigned)(batch * nchunks)), dim3(512), lds, s, mel, Wp, bias,
+                           spect, F, chunk, nchunks, srow, ld, pad);
+        CTTS_CHECK_LAUNCH("upsample_squeeze_mfma");
+        return CTTS_OK;
+    }
     if (hop != 256 || G != 8) {
         dim3 ggrid((unsigned)(((long long)F * hop + 255) / 256), n_mel, batch);
         hipLaunchKernelGGL(upsample_squeeze_generic_kernel, ggrid, dim3(256), 0, s, mel, W, bias, spect, n_mel, F, win, hop, G, ld, pad);

@@ -212,7 +212,8 @@ int ctts_waveglow_infer_spk_bf16x3(const ctts_waveglow_config* cfg, const void* 
 /* Stage entry points (same kernels, exposed for parity tests and profiling). */
 
 /* upsample (ConvTranspose1d) + trim + squeeze: glow.py:318-324.  spect is padded layout
- * [B][n_mel*G][ld]. */
+ * [B][n_mel*G][ld].  n_mel 80 / hop 256 / win 1024 / n_group 8 (the benchmark's): a W-stationary fp32 MFMA GEMM over the
+ * fragment-ordered copy of the weights that ctts_waveglow_pack_upsample writes beside the plain one; other shapes: VALU kernels. */
 int ctts_upsample_squeeze_f32(const ctts_waveglow_config* cfg, const void* packed,
                               const float* mel, float* spect, int32_t batch, int32_t frames,
                               void* stream);
@@ -736,7 +737,7 @@ int ctts_taco_stop_rule_f32(const float* gate_logits, int32_t batch, int32_t gat
 int ctts_last_gemm_loop(void);
 
 /* Launch-shape overrides for A/B measurements (CTTS_F32_NO_GLDS, CTTS_F32_NO_SMALL, CTTS_F32_FORCE_SMALL, CTTS_GEMM_NO_XCD_PAIR, CTTS_BF16_NO_GLDS / _NO_WIDE /
- * _NO_PP / _W4 / _PP_STAGES / _PS / _NO_PS / _PS_STAGES / _MAP / _WIDE_MIN, CTTS_WF_NO_FUSE, CTTS_WF_NO_VEC_INTERP, CTTS_WF_NO_REGION_SPLIT, CTTS_WF_NO_ROW_QUEUE, CTTS_F32_NO_ROUND_SPLIT, CTTS_F32_SPLITK_W4, CTTS_TACO_POLL_DELAY, CTTS_TACO_NO_FUSE) never change results beyond the parity
+ * _NO_PP / _W4 / _PP_STAGES / _PS / _NO_PS / _PS_STAGES / _MAP / _WIDE_MIN, CTTS_WF_NO_FUSE, CTTS_WF_NO_VEC_INTERP, CTTS_WF_NO_REGION_SPLIT, CTTS_WF_NO_ROW_QUEUE, CTTS_F32_NO_ROUND_SPLIT, CTTS_F32_SPLITK_W4, CTTS_TACO_POLL_DELAY, CTTS_TACO_NO_FUSE, CTTS_UP_NO_MFMA) never change results beyond the parity
  * tolerance (CTTS_F32_NO_SPLITK changes the summation order of the fused WaveFlow layer at batch <= 2, see above).  The environment is read once,
  * at the first launch; this re-reads it (tests and profiling scripts that flip a knob in-process). */
 int ctts_tuning_reload(void);
@@ -747,8 +748,8 @@ int ctts_tuning_reload(void);
  * 20 CTTS_BF16_PS (persistent form of the skewed bf16 kernel on every wide launch), 21 CTTS_BF16_NO_PS, 22 CTTS_F32_SPLITK_W4 (per-layer
  * launches of the split-K shape on four waves per tile instead of eight: bit-identical), 23 CTTS_TACO_POLL_DELAY set ("a,c,d,e,h,p": 64-cycle units
  * before the first poll of the persistent decoder's six vector exchanges; timing only), 24 CTTS_TACO_VALU
- * (ctts_taco_decoder_steps_f32 at batch <= 4 on the VALU kernels instead of the batched MFMA form) (tests assert that a knob they set is the one in
- * effect). */
+ * (ctts_taco_decoder_steps_f32 at batch <= 4 on the VALU kernels instead of the batched MFMA form), 25 CTTS_UP_NO_MFMA (the VALU upsampling kernel
+ * also for the shape the MFMA one is built for: bit-identical) (tests assert that a knob they set is the one in effect). */
 int ctts_tuning_flags(void);
 
 /* ---- in-library kernel timing (bench.py roofline leg) ---------------------------------

@@ -107,6 +107,39 @@ def test_stage_upsample_squeeze_against_oracle(hip_lib_path):
     assert float(halo.abs().max()) == 0.0                     # halo columns stay zero
 
 
+@pytest.mark.parametrize("B,F", [(1, 19), (3, 333), (2, 900)])
+def test_mfma_upsampling_is_bit_identical_to_the_valu_kernel(hip_lib_path, tuning, B, F):
+    """The benchmark's upsampling shape (n_mel 80, hop 256, win 1024, n_group 8) runs as a W-stationary fp32 MFMA GEMM
+    (waveglow_kernels.hip upsample_squeeze_mfma_kernel); ``v_mfma_f32_16x16x4_f32`` adds its four k in order, and the kernel walks
+    k = (input channel, tap) in the VALU kernel's order - so the two agree bit for bit, on whole and ragged chunks (333 frames =
+    2 chunks of 176 / 157; 900 = 304 / 304 / 292), and neither touches the halo columns."""
+    import ctypes as C
+    from cookietts_amd import _lib
+    from oracle import waveglow_oracle as wo
+    m, cfg, sd = _model("toy", 5)
+    mel = synthetic.synthetic_mel(B, F, seed=11)
+    blob, _ = m._ensure_packed(torch.device("cuda", 0))
+    lib = _lib.lib()
+    c = m.c_config()
+    geo = _lib.WaveGlowGeometry()
+    _lib.check(lib.ctts_waveglow_geometry_for(C.byref(c), F, C.byref(geo)), "geometry")
+    melt = torch.from_numpy(mel).cuda()
+
+    def run():
+        spect = torch.zeros(B, 640, geo.ld, device="cuda")
+        _lib.check(lib.ctts_upsample_squeeze_f32(C.byref(c), _lib.ptr(blob), _lib.ptr(melt), _lib.ptr(spect), B, F, None), "upsample_squeeze")
+        torch.cuda.synchronize()
+        return spect
+    mfma = run()
+    tuning.set("CTTS_UP_NO_MFMA")
+    valu = run()
+    assert torch.equal(mfma, valu)
+    assert float(mfma[:, :, :geo.pad].abs().max()) == 0.0 and float(mfma[:, :, geo.pad + geo.steps:].abs().max()) == 0.0
+    if F <= 333:
+        ref = wo.upsample_squeeze(mel, sd["upsample.weight"], sd["upsample.bias"], 256, 8)
+        assert np.abs(mfma[:, :, geo.pad:geo.pad + geo.steps].cpu().numpy() - ref).max() < 1e-4
+
+
 def test_no_cpu_fallback(hip_lib_path):
     from cookietts_amd import _lib
     cfg = synthetic.WAVEGLOW_CONFIGS["toy"]
