@@ -415,18 +415,17 @@ int launch_upsample_pack_mfma(const float* W, float* Wp, hipStream_t s) {
 int launch_upsample_squeeze(const float* mel, const float* W, const float* Wp, const float* bias, float* spect, int batch,
                             int n_mel, int F, int win, int hop, int G, int ld, int pad, hipStream_t s) {
     CTTS_CHECK_ARG(win % hop == 0 && hop % G == 0, "upsample_squeeze: win %d hop %d n_group %d", win, hop, G);
-    if (Wp && upsample_mfma_shape(n_mel, win, hop, G) && ld % 4 == 0 && pad % 4 == 0 && !tuning().up_no_mfma) {
+    if (Wp && upsample_mfma_shape(n_mel, win, hop, G) && ld % 4 == 0 && pad % 4 == 0 && (reinterpret_cast<uintptr_t>(spect) & 15) == 0 &&
+        !tuning().up_no_mfma) {
         // chunks of <= 320 frames, equal up to a 16-frame tile (900 frames: 304 + 304 + 292): 80 x 3 workgroups per utterance
         const int nchunks = (F + UM_CHUNK_MAX - 1) / UM_CHUNK_MAX;
         const int chunk = ((F + nchunks - 1) / nchunks + 15) / 16 * 16;
         const int srow = (chunk + 31) / 32 * 32 + 4;           // frames f0 - 3 ... f0 + (chunk rounded to a pair of tiles)
         const int lds = UM_NMEL * srow * (int)sizeof(float);
-        static bool allowed = false;
-        if (!allowed) {
+        // once per inference, so set on every call: the attribute belongs to the current device's copy of the kernel
+        if (lds > 64 * 1024)
             CTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(upsample_squeeze_mfma_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, UM_NMEL * (UM_CHUNK_MAX + 4) * (int)sizeof(float)));
-            allowed = true;
-        }
         hipLaunchKernelGGL(upsample_squeeze_mfma_kernel, dim3(UM_NMEL, (unsigned)(batch * nchunks)), dim3(512), lds, s, mel, Wp, bias,
                            spect, F, chunk, nchunks, srow, ld, pad);
         CTTS_CHECK_LAUNCH("upsample_squeeze_mfma");
