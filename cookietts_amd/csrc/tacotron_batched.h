@@ -676,6 +676,12 @@ __global__ __launch_bounds__(256) void bg_post_multi4_kernel(const AttnArgs at, 
 inline int bg_launch_multi8(BgRoles& m, int nb_pad, hipStream_t s) {
     const int ny = nb_pad <= 32 ? 1 : nb_pad / 64;
     const int M = 2;
+    {   // timing experiments (CTTS_TACO_BG_DEBUG; wrong results): 64 = without the EARLY roles, 128 = without the small stage, 256 = without attention part 1
+        const int dbg = tuning().taco_bg_debug;
+        if (dbg & 64) m.n_cell[0] = m.n_cell[1] = 0;
+        if (dbg & 128) m.n_small = 0;
+        if (dbg & 256) m.pre = nullptr;
+    }
     for (int i = 0; i < 2; ++i) {
         m.nblk_cell[i] = m.n_cell[i] ? (m.cell[i].tiles + M - 1) / M : 1;
         m.n_cell[i] = m.n_cell[i] ? m.nblk_cell[i] * ny : 0;
