@@ -345,91 +345,67 @@ __device__ __forceinline__ void bg_body(const BgArgs& a, bg_u4* lds, int blk, in
 }
 
 // ---- windowed location-sensitive attention, split at the query ----------------------------------------------------------
-// Part 1 (attn_pre_body, 256 threads, item b): everything that depends only on the previous step's weights and position -
-// window start (model.py:131-140), location conv (:56-60), location-dense term (:61-62) added to the processed-memory window:
-//   apre[b][tt][a] = processed_memory[b][s + tt][a] + sum_f Wd[f][a] * loc[tt][f],  astart[b] = s
-constexpr int BGA_W = 33, BGA_F = 32, BGA_K = 31;
+// Part 1 (attn_pre_body, item b): everything that depends only on the previous step's weights and position - window start
+// (model.py:131-140), location conv (:56-60) and location-dense term (:61-62), added to the processed-memory window:
+//   apre[b][tt][a] = processed_memory[b][s + tt][a] + sum_(c, j) G[c][j][a] * wcat[c][s + tt - pad + j],  astart[b] = s
+// with the two linear maps FOLDED at pack time, G[c][j][a] = sum_f Wd[f][a] * Wloc[f][c][j] (location_fold_kernel): one 62-tap
+// filter per attention dim instead of 32 filters, an LDS round trip and a 32-term dense sum.  As conv + dense the stage was ~10 us
+// of single-wave LDS latency per workgroup - two thirds of the pipelined step's launch 7 (profiles/r6_10).  Thread = (attention
+// dim, run of NPOS consecutive window positions): its filter in 62 registers, the NPOS + 30 weights under the run read once per
+// channel (a wave-wide broadcast), NPOS independent accumulators.
+constexpr int BGA_W = 33, BGA_F = 32, BGA_K = 31, BGA_RUN = 9;
 struct BgAttnLds {
     float wcat[2][BGA_W + BGA_K - 1 + 1];
-    float wloc[BGA_F * 2 * BGA_K];
-    __attribute__((aligned(16))) float loc[BGA_W][BGA_F];
 };
+template <int NPOS>
+__device__ __forceinline__ void attn_pre_run(const AttnArgs& a, float* apre, const BgAttnLds& L, int b, int s, int W, int ad, int tt0,
+                                             const float (&g)[2][BGA_K]) {
+    float pmv[NPOS], acc[NPOS];
+#pragma unroll
+    for (int u = 0; u < NPOS; ++u) {
+        const int pos = min(s + min(tt0 + u, W - 1), a.T - 1);
+        pmv[u] = a.pm[((size_t)b * a.T + pos) * a.A + ad];
+        acc[u] = 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < NPOS + BGA_K - 1; ++q) {           // weight tt0 + q of each channel feeds position u through tap q - u
+        const int qi = min(tt0 + q, W + BGA_K - 2);
+        const float w0 = L.wcat[0][qi], w1 = L.wcat[1][qi];
+#pragma unroll
+        for (int u = 0; u < NPOS; ++u)
+            if (q - u >= 0 && q - u < BGA_K) acc[u] = fmaf(g[1][q - u], w1, fmaf(g[0][q - u], w0, acc[u]));
+    }
+#pragma unroll
+    for (int u = 0; u < NPOS; ++u)
+        if (tt0 + u < W) apre[((size_t)b * BGA_W + tt0 + u) * a.A + ad] = pmv[u] + acc[u];
+}
 __device__ __forceinline__ void attn_pre_body(const AttnArgs& a, float* apre, int* astart, BgAttnLds& L, int b) {
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, nthr = blockDim.x;
     const int W = 2 * a.R + 1, padk = (a.K - 1) / 2;
     const int len = a.lengths[b];
     float cur = a.pos[b];
     const float off = a.scalars[0];
+    // this thread's folded filter [2][K] of attention dim ad: does not depend on the window, requested first
+    const int per = a.A <= 64 ? 64 : a.A <= 128 ? 128 : 256, ad = t % per, part = t / per, nparts = nthr / per;
+    const bool live = ad < a.A;
+    float g[2][BGA_K];
+#pragma unroll
+    for (int j = 0; j < BGA_K; ++j) {
+        g[0][j] = (live && j < a.K) ? a.G[(size_t)j * a.A + ad] : 0.f;
+        g[1][j] = (live && j < a.K) ? a.G[((size_t)a.K + j) * a.A + ad] : 0.f;
+    }
     if (off != 0.f) cur += off;
     cur = fminf(fmaxf(cur, (float)a.R), (float)(len - 1 - a.R));
     const int s = (int)rintf(fmaxf(cur - (float)a.R, 0.f));
-    // this thread's column of the location-dense weight [F][A] and its processed-memory values: issued before the conv
-    const bool act = t < 256;                              // (a 512-thread launch: the upper half only keeps the barriers)
-    const int per = a.A <= 128 ? 128 : 256, ad = t % per, part = (t & 255) / per, nparts = 256 / per;
-    const bool live = act && ad < a.A;
-    float wd[BGA_F];
-#pragma unroll
-    for (int f = 0; f < BGA_F; ++f) wd[f] = (live && f < a.F) ? a.Wd[(size_t)f * a.A + ad] : 0.f;
-    constexpr int NP = (BGA_W + 1) / 2;                    // positions per thread when two threads share an attention dim
-    float pmv[BGA_W];
-#pragma unroll
-    for (int i = 0; i < BGA_W; ++i) {
-        const int tt = part + nparts * i;
-        const int pos = min(s + min(tt, W - 1), a.T - 1);
-        pmv[i] = (live && (nparts == 1 || i < NP)) ? a.pm[((size_t)b * a.T + pos) * a.A + ad] : 0.f;
-    }
-    for (int i = act ? t : 1 << 30; i < 2 * (BGA_W + BGA_K - 1); i += 256) {
+    for (int i = t; i < 2 * (BGA_W + BGA_K - 1); i += nthr) {
         const int c = i / (BGA_W + BGA_K - 1), j = i % (BGA_W + BGA_K - 1);
         const int pos = s - padk + j;
         const float* src = c == 0 ? a.w : a.cum;
         L.wcat[c][j] = (j < W + a.K - 1 && pos >= 0 && pos < a.T) ? src[(size_t)b * a.T + pos] : 0.f;
     }
-    for (int i = act ? t : 1 << 30; i < a.F * 2 * a.K; i += 256) L.wloc[i] = a.Wloc[i];
     __syncthreads();
-    {   // location conv (model.py:56-60): thread = (filter f, run of five consecutive window positions): the 62 taps of the
-        // filter in registers, the 35 weights under the run read once each per channel (a broadcast: the 32 lanes of a run
-        // share them) - 132 LDS reads per thread where one output per thread and iteration took 620
-        const int f = t & 31, tt0 = 5 * (t >> 5);
-        if (act && tt0 < W) {
-            float tap[2][BGA_K];
-#pragma unroll
-            for (int j = 0; j < BGA_K; ++j) {
-                tap[0][j] = (f < a.F && j < a.K) ? L.wloc[(f * 2 + 0) * a.K + j] : 0.f;
-                tap[1][j] = (f < a.F && j < a.K) ? L.wloc[(f * 2 + 1) * a.K + j] : 0.f;
-            }
-            float o[5][2];
-#pragma unroll
-            for (int u = 0; u < 5; ++u) o[u][0] = o[u][1] = 0.f;
-#pragma unroll
-            for (int q = 0; q < BGA_K + 4; ++q) {            // weight tt0 + q of each channel feeds output u through tap q - u
-                const int qi = min(tt0 + q, W + BGA_K - 2);
-                const float w0 = L.wcat[0][qi], w1 = L.wcat[1][qi];
-#pragma unroll
-                for (int u = 0; u < 5; ++u)
-                    if (q - u >= 0 && q - u < BGA_K) { o[u][0] = fmaf(tap[0][q - u], w0, o[u][0]); o[u][1] = fmaf(tap[1][q - u], w1, o[u][1]); }
-            }
-#pragma unroll
-            for (int u = 0; u < 5; ++u)
-                if (tt0 + u < W) L.loc[tt0 + u][f] = o[u][0] + o[u][1];
-        }
-    }
-    __syncthreads();
-    if (live) {
-#pragma unroll
-        for (int i = 0; i < BGA_W; ++i) {
-            const int tt = part + nparts * i;
-            if ((nparts == 1 || i < NP) && tt < W) {
-                float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-#pragma unroll
-                for (int f4 = 0; f4 < BGA_F / 4; ++f4) {
-                    const float4 l = *reinterpret_cast<const float4*>(&L.loc[tt][4 * f4]);
-                    c0 = fmaf(wd[4 * f4 + 0], l.x, c0); c1 = fmaf(wd[4 * f4 + 1], l.y, c1);
-                    c2 = fmaf(wd[4 * f4 + 2], l.z, c2); c3 = fmaf(wd[4 * f4 + 3], l.w, c3);
-                }
-                apre[((size_t)b * BGA_W + tt) * a.A + ad] = pmv[i] + ((c0 + c2) + (c1 + c3));
-            }
-        }
-    }
+    if (live)                                              // runs of nine positions: 512 threads x 128 dims -> one run per thread, 256 x 128 -> two
+        for (int r = part; BGA_RUN * r < W; r += nparts) attn_pre_run<BGA_RUN>(a, apre, L, b, s, W, ad, BGA_RUN * r, g);
     if (t == 0) astart[b] = s;
 }
 
@@ -656,7 +632,7 @@ __global__ __launch_bounds__(512) void bg_multi8_kernel(const BgArgs small, int 
     if (r < n0) { bg_body<M, N, SS, 8, BG_EPI_CELL>(c0, bg_lds, r % nblk0, r / nblk0); return; }
     r -= n0;
     if (r < n1) { bg_body<M, N, SS, 8, BG_EPI_CELL>(c1, bg_lds, r % nblk1, r / nblk1); return; }
-    attn_pre_body(pre, apre, astart, *reinterpret_cast<BgAttnLds*>(bg_lds), r - n1);       // (the first 256 threads work)
+    attn_pre_body(pre, apre, astart, *reinterpret_cast<BgAttnLds*>(bg_lds), r - n1);
 }
 // 256 threads: attention part 2 (one block per item) + up to two EARLY cell roles of shape <M, N, SS, 4>
 template <int M, int N, int SS>

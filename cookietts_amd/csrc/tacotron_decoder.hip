@@ -338,6 +338,7 @@ __global__ __launch_bounds__(256) void lstm_step2_kernel(const LstmCall q0, cons
 // ---- attention step --------------------------------------------------------------------
 struct AttnArgs {
     const float *Wq, *v, *Wloc, *Wd, *scalars;
+    const float* G;                        // batched form: the location conv folded into the location-dense layer, [2][K][A]
     const float *att_h, *memory, *pm;
     float *w, *cum, *ctx, *pos, *align_out;
     const int* lengths;
@@ -850,6 +851,7 @@ int batched_steps(const DecPlan& p, const DecWs& w, const float* blob, const uin
     auto attn_args = [&](int step) {
         AttnArgs at{};
         at.Wq = blob + p.query_w; at.v = blob + p.v_w; at.Wloc = blob + p.loc_conv_w; at.Wd = blob + p.loc_dense_w;
+        at.G = blob + p.loc_fold;
         at.scalars = blob + p.scalars;
         at.att_h = w.att_h[(step & 1) ^ 1]; at.memory = w.memory; at.pm = w.pm;
         at.w = w.w; at.cum = w.cum; at.ctx = w.ctx; at.pos = w.pos; at.align_out = align_out; at.lengths = w.lengths;
@@ -929,6 +931,17 @@ int batched_steps(const DecPlan& p, const DecWs& w, const float* blob, const uin
         }
     }
     return CTTS_OK;
+}
+
+// G[c][j][a] = sum_f Wd[f][a] * Wloc[f][c][j]: the location conv (model.py:56-60) folded into the location-dense layer (:61-62)
+__global__ __launch_bounds__(256) void location_fold_kernel(const float* __restrict__ Wloc, const float* __restrict__ Wd, float* __restrict__ G,
+                                                            int F, int K, int A) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * K * A) return;
+    const int ad = i % A, j = (i / A) % K, c = i / (A * K);
+    float acc = 0.f;
+    for (int f = 0; f < F; ++f) acc = fmaf(Wd[(size_t)f * A + ad], Wloc[(f * 2 + c) * K + j], acc);
+    G[i] = acc;
 }
 
 int bg_pack(float* dst, const BgMat& m, const BgSeg* segs, int nseg, int interleave_H, hipStream_t s) {
@@ -1023,6 +1036,10 @@ int ctts_taco_decoder_pack(const ctts_taco_decoder_config* cfg, const ctts_taco_
         if ((rc = bg_pack(blob, p.bg_q, q, 1, 0, s))) return rc;
         if ((rc = bg_pack(blob, p.bg_proj, pr, 1, 0, s))) return rc;
         if ((rc = bg_pack(blob, p.bg_w2, w2, 1, 0, s))) return rc;
+        const int n = 2 * c.location_kernel_size * c.attention_dim;
+        hipLaunchKernelGGL(location_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, s, blob + p.loc_conv_w, blob + p.loc_dense_w,
+                           blob + p.loc_fold, c.location_n_filters, c.location_kernel_size, c.attention_dim);
+        CTTS_CHECK_LAUNCH("location_fold");
     }
     const float sc[4] = {w->windowed_att_pos_offset, w->exp_smoothing_factor, 0.f, 0.f};
     CTTS_CHECK_HIP(hipMemcpyAsync(blob + p.scalars, sc, sizeof(sc), hipMemcpyHostToDevice, s));

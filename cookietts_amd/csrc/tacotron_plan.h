@@ -20,7 +20,7 @@ struct BgMat { size_t off; int rows, tiles, nchunks; };
 struct DecPlan {
     ctts_taco_decoder_config c;
     int I_att, I_dec, I_d2, Dproj;
-    size_t bottleneck_wT, memory_wT, query_w, v_w, loc_conv_w, loc_dense_w, prenet_w1, prenet_w2;
+    size_t bottleneck_wT, memory_wT, query_w, v_w, loc_conv_w, loc_dense_w, loc_fold, prenet_w1, prenet_w2;
     size_t att[4], dec[4], d2[4];
     size_t proj_w, proj_b, scalars;   // proj rows: n_mel mel rows then the gate row; scalars: offset, smoothing
     // persistent decoder (tacotron_persistent.hip): rows [0, n_mel) mel, row n_mel gate, rows [n_mel+1, n_mel+1+P) the
@@ -95,7 +95,9 @@ inline int make_dec_plan(const ctts_taco_decoder_config* cfg, DecPlan& p) {
         mat(p.bg_q, c.attention_dim, Ks[3]);
         mat(p.bg_proj, p.pd_rows, Ks[4]);
         mat(p.bg_w2, c.prenet_dim, Ks[5]);
+        p.loc_fold = take((size_t)2 * c.location_kernel_size * c.attention_dim);    // location conv folded into the dense layer [2][K][A]
     } else {
+        p.loc_fold = 0;
         p.bg_att = p.bg_dec = p.bg_d2 = p.bg_q = p.bg_proj = p.bg_w2 = BgMat{0, 0, 0, 0};
     }
     p.total = o;
